@@ -1,0 +1,112 @@
+"""numpy Philox4x32-10 and the bits->float maps used by the HIP kernels (dposer_amd/csrc/rng.h).
+
+TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  This is *our* counter-based RNG contract
+(the reference draws from torch's CPU generator, which a GPU kernel cannot reproduce; SURVEY.md
+§7 "RNG"), restated on the CPU so tests can feed the oracle the very numbers the kernels draw.
+
+Counter / key contract (all uint32):
+    counter = (index_lo, index_hi, stream, offset)      key = (seed_lo, seed_hi)
+    index  : which group of random numbers inside one draw (see each kernel)
+    stream : what the numbers are for (STREAM_* below)
+    offset : optimisation / sampler step number
+"""
+from __future__ import annotations
+
+import numpy as np
+
+M0 = np.uint64(0xD2511F53)
+M1 = np.uint64(0xCD9E8D57)
+W0 = np.uint32(0x9E3779B9)
+W1 = np.uint32(0xBB67AE85)
+
+STREAM_TRAIN_T = 1          # t ~ U(eps, T): one u32 per sample          (index = sample)
+STREAM_TRAIN_Z = 2          # z ~ N(0, I): 4 normals per call            (index = flat_elem // 4)
+STREAM_EM_NOISE = 3         # predictor noise                             (index = flat_elem // 4)
+STREAM_IMPUTE_A = 4         # imputation noise after the corrector
+STREAM_IMPUTE_B = 5         # imputation noise after the predictor
+STREAM_LANGEVIN = 6         # corrector noise
+STREAM_PRIOR = 7            # x_T ~ N(0, I) prior draw / prior-loss z
+STREAM_DROPOUT0 = 16        # + dropout-site id (0..4): 8 x 16-bit lanes per call
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10.  All inputs broadcastable uint32 arrays; returns 4 uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(a, dtype=np.uint32) for a in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    for _ in range(10):
+        p0 = M0 * c0.astype(np.uint64)
+        p1 = M1 * c2.astype(np.uint64)
+        hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
+        lo0 = p0.astype(np.uint32)
+        hi1 = (p1 >> np.uint64(32)).astype(np.uint32)
+        lo1 = p1.astype(np.uint32)
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = np.uint32((int(k0) + int(W0)) & 0xFFFFFFFF)
+        k1 = np.uint32((int(k1) + int(W1)) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def u01_open_low(bits):
+    """(0, 1]: ((bits >> 8) + 1) * 2^-24 -- safe argument for log()."""
+    return ((bits >> np.uint32(8)).astype(np.float32) + np.float32(1.0)) * np.float32(2.0 ** -24)
+
+
+def u01(bits):
+    """[0, 1): (bits >> 8) * 2^-24 -- same support as torch.rand for fp32."""
+    return (bits >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+
+
+def normals4(index, stream, offset, seed):
+    """Four N(0,1) numbers per counter (Box-Muller on (r0,r1) and (r2,r3)); fp32.
+    Returns array [..., 4]."""
+    index = np.asarray(index, dtype=np.uint64)
+    lo = (index & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (index >> np.uint64(32)).astype(np.uint32)
+    r = philox4x32_10(lo, hi, np.uint32(stream), np.uint32(offset),
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    out = []
+    for a, b in ((r[0], r[1]), (r[2], r[3])):
+        rad = np.sqrt(np.float32(-2.0) * np.log(u01_open_low(a)))
+        ang = np.float32(2.0 * np.pi) * u01(b)
+        out += [rad * np.cos(ang), rad * np.sin(ang)]
+    return np.stack(out, axis=-1).astype(np.float32)
+
+
+def normal_matrix(rows, cols, stream, offset, seed):
+    """[rows, cols] N(0,1) matrix as the kernels draw it: flat element e = r*cols + c uses
+    counter index e // 4, lane e % 4."""
+    n = rows * cols
+    groups = (n + 3) // 4
+    z = normals4(np.arange(groups, dtype=np.uint64), stream, offset, seed).reshape(-1)[:n]
+    return z.reshape(rows, cols)
+
+
+def uniform_t(rows, offset, seed, eps=1e-5, T=1.0):
+    """t = u*(T-eps)+eps with u in [0,1) -- one counter per sample, lane 0."""
+    idx = np.arange(rows, dtype=np.uint64)
+    r = philox4x32_10((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+                      (idx >> np.uint64(32)).astype(np.uint32),
+                      np.uint32(STREAM_TRAIN_T), np.uint32(offset),
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return u01(r[0]) * np.float32(T - eps) + np.float32(eps)
+
+
+def dropout_keep_mask(rows, channels, site, offset, seed, p):
+    """{0,1} keep mask [rows, channels] for dropout site ``site`` (0 = after pre_gnorm,
+    1..4 = block layers in order).  One Philox call covers 8 consecutive channels of one sample:
+    index = sample * (channels // 8) + channel // 8; the 8 lanes are the low/high 16 bits of
+    r0..r3 (lane 2j = low half of r_j, lane 2j+1 = high half).  keep <=> lane16 < floor((1-p)*65536)."""
+    thr = np.uint32(int((1.0 - p) * 65536.0))
+    groups = channels // 8
+    idx = np.arange(rows * groups, dtype=np.uint64)
+    r = philox4x32_10((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+                      (idx >> np.uint64(32)).astype(np.uint32),
+                      np.uint32(STREAM_DROPOUT0 + site), np.uint32(offset),
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    lanes = []
+    for w in r:
+        lanes += [w & np.uint32(0xFFFF), w >> np.uint32(16)]
+    keep = (np.stack(lanes, axis=-1) < thr).astype(np.float32)
+    return keep.reshape(rows, channels)

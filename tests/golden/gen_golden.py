@@ -1,0 +1,434 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by IMPORTING the reference (read-only, /root/reference).
+
+Run in the build container only:   python tests/golden/gen_golden.py
+Writes small ``.npz`` fixtures next to this file.  Nothing of the reference's source travels:
+only inputs, outputs and seeds (weights are regenerated from ``weights.make_weights(seed)``).
+
+Absent third-party modules the reference imports at module scope are stubbed (MagicMock) --
+none of them is exercised by the captured paths except where noted:
+  torchgeometry (transforms.py tgm-backed conversions: NOT captured), ml_collections (attr-dict),
+  smplx / cv2 / pyrender / ... (import-only).
+Randomness inside the reference (torch.rand / torch.randn_like / F.dropout) is replaced by a
+recorded numpy RandomState stream so every draw is part of the fixture.
+"""
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+for _name in ["torchgeometry", "cv2", "smplx", "smplx.utils", "smplx.body_models", "tensorboardX",
+              "absl", "absl.flags", "absl.app", "absl.flags.argparse_flags",
+              "ml_collections.config_flags", "pyrender", "trimesh", "pytorch3d", "plyfile",
+              "pymeshlab", "chumpy", "yacs"]:
+    sys.modules[_name] = mock.MagicMock()
+
+
+class _ConfigDict(dict):
+    __getattr__ = dict.__getitem__
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+_mlc = types.ModuleType("ml_collections")
+_mlc.ConfigDict = _ConfigDict
+sys.modules["ml_collections"] = _mlc
+
+from weights import make_weights, probe_indices  # noqa: E402
+
+import lib.algorithms.advanced.losses as ref_losses  # noqa: E402
+import lib.algorithms.advanced.sampling as ref_sampling  # noqa: E402
+import lib.algorithms.advanced.sde_lib as ref_sde  # noqa: E402
+import lib.algorithms.advanced.utils as ref_mutils  # noqa: E402
+from lib.algorithms.advanced.model import ScoreModelFC  # noqa: E402
+from lib.algorithms.ema import ExponentialMovingAverage  # noqa: E402
+import lib.utils.misc as ref_misc  # noqa: E402
+import lib.utils.transforms as ref_tf  # noqa: E402
+import lib.dataset.AMASS as ref_amass  # noqa: E402
+import lib.body_model.constants as ref_const  # noqa: E402
+import lib.body_model.utils as ref_bmu  # noqa: E402
+import lib.dataset.EvaSampler as ref_eva  # noqa: E402
+import run.completion as ref_completion  # noqa: E402
+from configs.subvp.amass_scorefc_continuous import get_config  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+class Recorder:
+    """Replaces torch.rand / torch.randn_like / F.dropout with a recorded numpy stream."""
+
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+        self.draws = []
+
+    def rand(self, *shape, **kw):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else shape
+        a = self.rs.random_sample(size=tuple(shape)).astype(np.float32)
+        self.draws.append(("rand", a))
+        return torch.tensor(a)
+
+    def randn_like(self, x, **kw):
+        a = self.rs.standard_normal(size=tuple(x.shape)).astype(np.float32)
+        self.draws.append(("randn", a))
+        return torch.tensor(a).to(x.dtype)
+
+    def dropout(self, x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        keep = (self.rs.random_sample(size=tuple(x.shape)) >= p).astype(np.float32)
+        self.draws.append(("keep", keep))
+        return x * torch.tensor(keep) / (1.0 - p)
+
+    def __enter__(self):
+        self._p = [mock.patch.object(torch, "rand", self.rand),
+                   mock.patch.object(torch, "randn_like", self.randn_like),
+                   mock.patch.object(torch.nn.functional, "dropout", self.dropout)]
+        for p in self._p:
+            p.start()
+        return self
+
+    def __exit__(self, *a):
+        for p in self._p:
+            p.stop()
+
+    def by_kind(self, kind):
+        return [a for k, a in self.draws if k == kind]
+
+
+def build_model(seed, D, embedding="positional", dropout=0.1):
+    cfg = get_config()
+    cfg.model.embedding_type = embedding
+    cfg.model.dropout = dropout
+    pose_dim = D // 21
+    m = ScoreModelFC(cfg, n_poses=21, pose_dim=pose_dim, hidden_dim=cfg.model.HIDDEN_DIM,
+                     embed_dim=cfg.model.EMBED_DIM, n_blocks=cfg.model.N_BLOCKS)
+    w = make_weights(seed, D=D, fourier=(embedding == "fourier"),
+                     fourier_scale=cfg.model.fourier_scale)
+    sd = m.state_dict()
+    for k, v in w.items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = v
+    m.load_state_dict(sd)
+    return cfg, m
+
+
+def toy_batch(n, rot="axis", seed=42):
+    poses = np.load(os.path.join(REF, "examples/toy_data.npz"))["pose_samples"]
+    idx = np.random.RandomState(seed).randint(0, poses.shape[0], size=n)
+    x = torch.tensor(poses[idx])
+    stats = torch.load(os.path.join(REF, "data/AMASS/amass_processed/version1/train/axis_normalize2.pt"))
+    return (x - stats["mean_poses"]) / stats["std_poses"], x
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def sample_tensor(name, t):
+    idx = probe_indices(name, t.numel())
+    flat = t.detach().reshape(-1).double().numpy()
+    return np.concatenate([[np.sqrt((flat ** 2).sum())], flat[idx]])
+
+
+# ---------------------------------------------------------------------------------------------
+def g1_forward():
+    """G1/G2: ScoreModelFC eval forward + get_score_fn (subVP continuous, VP continuous, VE)."""
+    out = {}
+    for tag, D, emb, seed in (("axis_pos", 63, "positional", 1), ("rot6d_pos", 126, "positional", 2),
+                              ("axis_fourier", 63, "fourier", 3)):
+        cfg, m = build_model(seed, D, emb)
+        m.eval()
+        rs = np.random.RandomState(100 + seed)
+        x = torch.tensor(rs.standard_normal((64, D)).astype(np.float32))
+        t = np.concatenate([[1e-5, 1e-3, 0.25, 0.5, 1.0], rs.uniform(1e-5, 1, 59)]).astype(np.float32)
+        t = torch.tensor(t)
+        with torch.no_grad():
+            if emb == "positional":
+                out[f"{tag}_model"] = m(x, t * 999).numpy()
+                for sname, sde in (("subvp", ref_sde.subVPSDE(0.1, 20.0, 1000)),
+                                   ("vp", ref_sde.VPSDE(0.1, 20.0, 1000))):
+                    fn = ref_mutils.get_score_fn(sde, m, train=False, continuous=True)
+                    out[f"{tag}_score_{sname}"] = fn(x, t, None, None).numpy()
+            else:
+                ve = ref_sde.VESDE(0.01, 50.0, 1000)
+                fn = ref_mutils.get_score_fn(ve, m, train=False, continuous=True)
+                out[f"{tag}_score_ve"] = fn(x, t, None, None).numpy()
+        out[f"{tag}_x"] = x.numpy()
+        out[f"{tag}_t"] = t.numpy()
+        out[f"{tag}_seed"] = np.int64(seed)
+    save("g1_forward", **out)
+
+
+def g3_loss_grads():
+    """G3: DSM loss + all parameter grads, injected (t, z); dropout off and on (injected masks)."""
+    out = {}
+    for tag, drop in (("nodrop", 0.0), ("drop", 0.1)):
+        cfg, m = build_model(5, 63, dropout=drop)
+        sde = ref_sde.subVPSDE(0.1, 20.0, 1000)
+        batch, _ = toy_batch(32)
+        loss_fn = ref_losses.get_sde_loss_fn(sde, train=True, reduce_mean=True, continuous=True)
+        with Recorder(7) as rec:
+            loss = loss_fn(m, batch, None, None)
+        loss.backward()
+        out[f"{tag}_loss"] = np.float64(loss.item())
+        out[f"{tag}_u"] = rec.by_kind("rand")[0]
+        out[f"{tag}_z"] = rec.by_kind("randn")[0]
+        if drop > 0:
+            out[f"{tag}_keep"] = np.stack(rec.by_kind("keep")).astype(np.uint8)
+        for n, p in m.named_parameters():
+            out[f"{tag}_grad/{n}"] = (np.zeros(1) if p.grad is None else sample_tensor(n, p.grad))
+        out[f"{tag}_batch"] = batch.numpy()
+    # likelihood-weighted / sum-reduced variant (losses.py:127-129), loss only
+    cfg, m = build_model(5, 63, dropout=0.0)
+    sde = ref_sde.subVPSDE(0.1, 20.0, 1000)
+    batch, _ = toy_batch(32)
+    loss_fn = ref_losses.get_sde_loss_fn(sde, train=True, reduce_mean=False, continuous=True,
+                                         likelihood_weighting=True)
+    with Recorder(7):
+        out["lw_loss"] = np.float64(loss_fn(m, batch, None, None).item())
+    out["seed"] = np.int64(5)
+    save("g3_loss_grads", **out)
+
+
+def g4_train_steps():
+    """G4: step_fn updates (Adam + warm-up + clip + EMA); steps 0,1,2 then 4999,5000; dropout 0.1
+    with injected masks.  Stores loss, lr, and probes of params / Adam state / EMA shadows."""
+    cfg, m = build_model(6, 63, dropout=0.1)
+    sde = ref_sde.subVPSDE(0.1, 20.0, 1000)
+    opt = ref_losses.get_optimizer(cfg, m.parameters())
+    ema = ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate)
+    state = dict(optimizer=opt, model=m, ema=ema, step=0)
+    optimize_fn = ref_losses.optimization_manager(cfg)
+    step_fn = ref_losses.get_step_fn(sde, train=True, optimize_fn=optimize_fn, reduce_mean=True,
+                                     continuous=True, likelihood_weighting=False)
+    batch, _ = toy_batch(32, seed=43)
+    out = {"batch": batch.numpy(), "seed": np.int64(6)}
+    names = [n for n, _ in m.named_parameters()]
+    schedule = [0, 1, 2, 4999, 5000]
+    for i, s in enumerate(schedule):
+        state["step"] = s
+        with Recorder(1000 + i) as rec:
+            ld = step_fn(state, batch)
+        out[f"s{i}_step"] = np.int64(s)
+        out[f"s{i}_loss"] = np.float64(ld["step_loss"].item())
+        out[f"s{i}_lr"] = np.float64(opt.param_groups[0]["lr"])
+        out[f"s{i}_u"] = rec.by_kind("rand")[0]
+        out[f"s{i}_z"] = rec.by_kind("randn")[0]
+        out[f"s{i}_keep"] = np.stack(rec.by_kind("keep")).astype(np.uint8)
+        for j, (n, p) in enumerate(m.named_parameters()):
+            out[f"s{i}_param/{n}"] = sample_tensor(n, p)
+            out[f"s{i}_ema/{n}"] = sample_tensor(n, ema.shadow_params[j])
+            st = opt.state.get(p, {})
+            if "exp_avg" in st:
+                out[f"s{i}_m/{n}"] = sample_tensor(n, st["exp_avg"])
+                out[f"s{i}_v/{n}"] = sample_tensor(n, st["exp_avg_sq"])
+    out["ema_num_updates"] = np.int64(ema.num_updates)
+    save("g4_train_steps", **out)
+
+
+def g5_sampler():
+    """G5/G6: pc_sampler trajectories with injected noise: EM only (N=8), EM + completion
+    imputation (legs, N=8), EM + Langevin corrector (N=4), and the full N=1000 run (B=8)."""
+    cfg, m = build_model(8, 63)
+    m.eval()
+    out = {"seed": np.int64(8)}
+
+    class Args:
+        task = None
+
+    def run(tag, N, B, corrector, task, start_step=0):
+        sde = ref_sde.subVPSDE(0.1, 20.0, N)
+        cfg.sampling.corrector = corrector
+        fn = ref_sampling.get_sampling_fn(cfg, sde, (B, 63), lambda x: x, 1e-3, device="cpu")
+        rs = np.random.RandomState(900 + N + B)
+        scale = 0.05 if start_step > 900 else 1.0
+        z0 = torch.tensor((scale * rs.standard_normal((B, 63))).astype(np.float32))
+        obs = mask = None
+        args = None
+        if task is not None:
+            args = Args()
+            args.task = task
+        if task == "completion":
+            poses, _ = toy_batch(B, seed=44)
+            with Recorder(55) as r0:
+                mask, obs = ref_misc.create_mask(poses, part="legs")
+            out[f"{tag}_mask"] = mask.numpy()
+            out[f"{tag}_obs"] = obs.numpy()
+        with Recorder(77) as rec:
+            trajs, x = fn(m, observation=obs, mask=mask, z=z0, start_step=start_step, args=args)
+        out[f"{tag}_z0"] = z0.numpy()
+        noise = np.stack(rec.by_kind("randn"))
+        if noise.shape[0] <= 64:
+            out[f"{tag}_noise"] = noise
+        else:   # regenerate in the test: RandomState(77).standard_normal((B,63)) per draw, in order
+            out[f"{tag}_noise_seed"] = np.int64(77)
+            out[f"{tag}_noise_count"] = np.int64(noise.shape[0])
+        out[f"{tag}_final"] = x.numpy()
+        tr = trajs.numpy()
+        out[f"{tag}_trajs"] = tr if tr.shape[0] <= 16 else tr[99::100]
+        return tr
+
+    run("em8", 8, 16, "none", None)
+    run("comp8", 8, 16, "none", "completion")
+    run("lang4", 1000, 16, "langevin", "denoise", start_step=996)
+    run("den8", 8, 16, "none", "denoise", start_step=3)
+    run("em1000", 1000, 8, "none", None)
+    save("g5_sampler", **out)
+
+
+def g7_prior_loss():
+    """G7: DPoserComp.loss (run/completion.py:131-149) value + autograd grad wrt x_0 at the
+    quan_t schedule of completion.py:189-190 for steps {0,99,100,199}; injected z."""
+    cfg, m = build_model(9, 63)
+    m.eval()
+    sde = ref_sde.subVPSDE(0.1, 20.0, 1000)
+    B = 16
+    comp = ref_completion.DPoserComp(m, sde, continuous=True, batch_size=B)
+    x0, _ = toy_batch(B, seed=45)
+    timesteps = torch.linspace(sde.T, 1e-3, sde.N)
+    out = {"x0": x0.numpy(), "seed": np.int64(9)}
+    import math
+    total = 200
+    for step in (0, 99, 100, 199):
+        quan_t = sde.N - math.floor(torch.tensor(total - step - 1) * (sde.N / (5.0 * total))) - 2
+        t = timesteps[quan_t]
+        vec_t = torch.ones(B) * t
+        xv = x0.clone().requires_grad_(True)
+        with Recorder(300 + step) as rec:
+            loss = comp.loss(xv, vec_t, quan_t)          # quan_t lands in `weighted` (quirk)
+        loss.backward()
+        out[f"s{step}_quan_t"] = np.int64(quan_t)
+        out[f"s{step}_t"] = np.float32(t.item())
+        out[f"s{step}_z"] = rec.by_kind("randn")[0]
+        out[f"s{step}_loss"] = np.float64(loss.item())
+        out[f"s{step}_grad"] = xv.grad.numpy()
+        with torch.no_grad(), Recorder(300 + step):
+            out[f"s{step}_loss_unweighted"] = np.float64(comp.loss(x0, vec_t, False).item())
+    save("g7_prior_loss", **out)
+
+
+def g8_scalars():
+    """G8: marginal_prob / sde / return_alpha_sigma / discretize tables on linspace(1,1e-3,1000)."""
+    t = torch.linspace(1.0, 1e-3, 1000)
+    x = torch.ones(1000, 1)
+    out = {"t": t.numpy()}
+    for name, sde in (("subvp", ref_sde.subVPSDE(0.1, 20.0, 1000)), ("vp", ref_sde.VPSDE(0.1, 20.0, 1000)),
+                      ("ve", ref_sde.VESDE(0.01, 50.0, 1000))):
+        mean, std = sde.marginal_prob(x, t)
+        drift, diff = sde.sde(x, t)
+        a, s = sde.return_alpha_sigma(t)
+        f, G = sde.discretize(x, t)
+        out[f"{name}_mean"] = mean.numpy()
+        out[f"{name}_std"] = std.numpy()
+        out[f"{name}_drift"] = drift.numpy()
+        out[f"{name}_diffusion"] = diff.numpy()
+        out[f"{name}_alpha"] = a.numpy()
+        out[f"{name}_sigma"] = s.numpy()
+        out[f"{name}_disc_f"] = f.numpy()
+        out[f"{name}_disc_G"] = G.numpy()
+        out[f"{name}_prior_logp"] = sde.prior_logp(torch.linspace(-2, 2, 63 * 4).reshape(4, 63)).numpy()
+    cfg, m = build_model(1, 63)
+    out["sigmas_buffer"] = m.sigmas.numpy()
+    out["temb_labels"] = (t * 999).numpy()
+    from lib.algorithms.advanced.model import get_timestep_embedding
+    out["temb"] = get_timestep_embedding(t[::50] * 999, 512).numpy()
+    save("g8_scalars", **out)
+
+
+def g9_tables():
+    """G9: integer index tables (bit-exact): create_mask, BodyPartIndices, BodySegIndices lengths
+    + checksums, JOINT_NAMES/JOINT_MAP, smpl.py joint_map, smpl_to_openpose, 22-joint parents,
+    DistributedEvalSampler shard indices."""
+    out = {}
+    parts = ["left_leg", "right_leg", "left_arm", "right_arm", "trunk", "hands", "legs", "arms"]
+    for part in parts:
+        out[f"part/{part}"] = np.array(getattr(ref_bmu.BodyPartIndices, part), dtype=np.int64)
+        seg = np.array(getattr(ref_bmu.BodySegIndices, part), dtype=np.int64)
+        out[f"seg/{part}"] = seg
+        for rot_n in (3, 6):
+            poses = torch.zeros(4, 21 * rot_n)
+            mask, _ = ref_misc.create_mask(poses, part=part)
+            out[f"mask/{part}/{rot_n}"] = mask[0].numpy().astype(np.uint8)
+    out["joint_names"] = np.array(ref_const.JOINT_NAMES)
+    out["joint_map"] = np.array([ref_const.JOINT_MAP[n] for n in ref_const.JOINT_NAMES], dtype=np.int64)
+    jm = [ref_const.JOINT_MAP[i] for i in ref_const.JOINT_NAMES]
+    jm[:25] = [55, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65]
+    # ^ the literal list of lib/body_model/smpl.py:55-57 (smpl.py imports smplx at module scope;
+    #   it is imported above with smplx stubbed, the list itself is data)
+    out["smplx_joint_map"] = np.array(jm, dtype=np.int64)
+    for mt in ("smpl", "smplh", "smplx"):
+        out[f"openpose/{mt}"] = ref_bmu.smpl_to_openpose(mt).astype(np.int64)
+    skel = ref_bmu.get_smpl_skeleton()
+    parents = -np.ones(22, dtype=np.int64)
+    for a, b in skel:
+        parents[b] = a
+    out["parents22"] = parents
+    out["skeleton"] = np.asarray(skel, dtype=np.int64)
+    for perm in ("SMPL_JOINTS_FLIP_PERM", "SMPL_POSE_FLIP_PERM", "J24_FLIP_PERM", "J49_FLIP_PERM",
+                 "H36M_TO_J17", "H36M_TO_J14", "J24_TO_J17", "J24_TO_J14"):
+        out[f"const/{perm}"] = np.array(getattr(ref_const, perm), dtype=np.int64)
+
+    class DS:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    for total, world in ((103, 4), (16, 8), (7, 2), (100, 1)):
+        for rank in range(world):
+            s = ref_eva.DistributedEvalSampler(DS(total), num_replicas=world, rank=rank, shuffle=False)
+            out[f"eva/{total}/{world}/{rank}"] = np.array(list(iter(s)), dtype=np.int64)
+    save("g9_tables", **out)
+
+
+def g10_normalizer():
+    """G10: Posenormalizer z-score and min-max round trips on toy_data (axis)."""
+    out = {}
+    path = os.path.join(REF, "data/AMASS/amass_processed/version1/train")
+    _, raw = toy_batch(64, seed=46)
+    out["raw"] = raw.numpy()
+    for mm in (False, True):
+        nz = ref_amass.Posenormalizer(path, device="cpu", normalize=True, min_max=mm, rot_rep="axis")
+        n = nz.offline_normalize(raw)
+        out[f"norm_minmax{int(mm)}"] = n.numpy()
+        out[f"denorm_minmax{int(mm)}"] = nz.offline_denormalize(n).numpy()
+        out[f"norm3d_minmax{int(mm)}"] = nz.offline_normalize(raw.reshape(4, 16, 63)).numpy()
+    for f in ("axis_normalize1", "axis_normalize2", "rot6d_normalize1", "rot6d_normalize2"):
+        d = torch.load(os.path.join(path, f + ".pt"))
+        for k, v in d.items():
+            if v is not None:
+                out[f"stats/{f}/{k}"] = v.numpy()
+    out["toy_pose_samples"] = np.load(os.path.join(REF, "examples/toy_data.npz"))["pose_samples"]
+    save("g10_normalizer", **out)
+
+
+def g11_rot6d():
+    rs = np.random.RandomState(11)
+    x = torch.tensor(rs.standard_normal((257, 6)).astype(np.float32))
+    out = {"rot6d": x.numpy(), "rotmat": ref_tf.rot6d_to_mat3x3(x).numpy()}
+    ts = torch.linspace(0.1, 0.9, 7)
+    out["lin_interp"] = ref_misc.linear_interpolation(ts, ts / 10, 6).numpy()
+    data = torch.tensor(rs.standard_normal((60, 63)).astype(np.float32))
+    out["smooth_in"] = data.numpy()
+    out["smooth_out"] = ref_misc.gaussian_smoothing(data, 5, 2.0).numpy()
+    save("g11_rot6d", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11"]
+    fns = dict(g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
+               g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d)
+    for w in which:
+        fns[w]()

@@ -1,0 +1,189 @@
+"""Pins the CPU oracle (oracle/score_ref.py, oracle/fk_ref.py) to golden vectors captured from
+the imported reference (tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, rel_err, probe, masks_from_keep
+from weights import make_weights
+from oracle import score_ref as R
+from oracle import fk_ref
+
+torch.set_num_threads(8)
+TOL = 2e-5          # fp32 restatement vs fp32 reference: summation-order noise only
+
+
+@pytest.mark.parametrize("tag,D", [("axis_pos", 63), ("rot6d_pos", 126)])
+def test_forward_positional(tag, D):
+    g = load("g1_forward")
+    p = make_weights(int(g[f"{tag}_seed"]), D=D)
+    p["sigmas"] = R.sigma_table()
+    x, t = torch.tensor(g[f"{tag}_x"]), torch.tensor(g[f"{tag}_t"])
+    out = R.scorefc_forward(p, x, t * 999)
+    assert rel_err(out, g[f"{tag}_model"]) < TOL
+    assert rel_err(R.score_fn(p, R.SubVP(), x, t), g[f"{tag}_score_subvp"]) < TOL
+    assert rel_err(R.score_fn(p, R.VP(), x, t), g[f"{tag}_score_vp"]) < TOL
+
+
+def test_forward_fourier_ve():
+    g = load("g1_forward")
+    p = make_weights(int(g["axis_fourier_seed"]), D=63, fourier=True)
+    p["sigmas"] = R.sigma_table()
+    x, t = torch.tensor(g["axis_fourier_x"]), torch.tensor(g["axis_fourier_t"])
+    out = R.score_fn(p, R.VE(), x, t, embedding_type="fourier")
+    assert rel_err(out, g["axis_fourier_score_ve"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["nodrop", "drop"])
+def test_dsm_loss_and_grads(tag):
+    g = load("g3_loss_grads")
+    p = make_weights(int(g["seed"]))
+    p["sigmas"] = R.sigma_table()
+    names = [n for n in R.param_names()]
+    leaves = {n: p[n].clone().requires_grad_(True) for n in names}
+    full = dict(p)
+    full.update(leaves)
+    batch = torch.tensor(g[f"{tag}_batch"])
+    t = torch.tensor(g[f"{tag}_u"]) * (1.0 - 1e-5) + 1e-5
+    z = torch.tensor(g[f"{tag}_z"])
+    fw = {}
+    if tag == "drop":
+        fw = dict(drop_masks=masks_from_keep(g["drop_keep"]), drop_p=0.1)
+    loss = R.dsm_loss(full, R.SubVP(), batch, t, z, **fw)
+    assert abs(loss.item() - float(g[f"{tag}_loss"])) / float(g[f"{tag}_loss"]) < 1e-5
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    for n, gr in zip(names, grads):
+        ref = g[f"{tag}_grad/{n}"]
+        if gr is None:
+            assert n.startswith("pre_dense_cond") and ref.shape == (1,)
+            continue
+        assert rel_err(probe(n, gr), ref) < 1e-4, n
+    if tag == "nodrop":
+        lw = R.dsm_loss(p, R.SubVP(), batch, t, z, reduce_mean=False, likelihood_weighting=True)
+        assert abs(lw.item() - float(g["lw_loss"])) / float(g["lw_loss"]) < 1e-5
+
+
+def test_train_steps():
+    g = load("g4_train_steps")
+    p = make_weights(int(g["seed"]))
+    p["sigmas"] = R.sigma_table()
+    names = R.param_names()
+    st = R.TrainState(p, names)
+    batch = torch.tensor(g["batch"])
+    for i in range(5):
+        st.step = int(g[f"s{i}_step"])
+        t = torch.tensor(g[f"s{i}_u"]) * (1.0 - 1e-5) + 1e-5
+        z = torch.tensor(g[f"s{i}_z"])
+        loss, _, _ = R.train_step(st, R.SubVP(), batch, t, z,
+                                  drop_masks=masks_from_keep(g[f"s{i}_keep"]), drop_p=0.1)
+        assert abs(loss.item() - float(g[f"s{i}_loss"])) / float(g[f"s{i}_loss"]) < 2e-4, i
+        for n in names:
+            assert rel_err(probe(n, st.p[n]), g[f"s{i}_param/{n}"]) < 1e-5, (i, n)
+            assert rel_err(probe(n, st.ema[n]), g[f"s{i}_ema/{n}"]) < 1e-5, (i, n)
+            if f"s{i}_m/{n}" in g.files:
+                assert rel_err(probe(n, st.m[n]), g[f"s{i}_m/{n}"]) < 2e-3, (i, n)
+                assert rel_err(probe(n, st.v[n]), g[f"s{i}_v/{n}"]) < 2e-3, (i, n)
+    assert st.ema_updates == int(g["ema_num_updates"])
+
+
+def _sampler_case(g, tag, N, **kw):
+    p = make_weights(int(g["seed"]))
+    p["sigmas"] = R.sigma_table()
+    z0 = torch.tensor(g[f"{tag}_z0"])
+    if f"{tag}_noise" in g.files:
+        noise = torch.tensor(g[f"{tag}_noise"])
+    else:
+        rs = np.random.RandomState(int(g[f"{tag}_noise_seed"]))
+        noise = torch.tensor(np.stack([rs.standard_normal(z0.shape).astype(np.float32)
+                                       for _ in range(int(g[f"{tag}_noise_count"]))]))
+    return p, z0, noise
+
+
+def test_sampler_em8():
+    g = load("g5_sampler")
+    p, z0, noise = _sampler_case(g, "em8", 8)
+    trajs, x = R.pc_sampler(p, R.SubVP(N=8), z0, noise)
+    assert rel_err(trajs, g["em8_trajs"]) < 1e-4
+    assert rel_err(x, g["em8_final"]) < 1e-4
+
+
+def test_sampler_denoise_start_step():
+    g = load("g5_sampler")
+    p, z0, noise = _sampler_case(g, "den8", 8)
+    noises = [None] * 3 + list(noise)
+    trajs, x = R.pc_sampler(p, R.SubVP(N=8), z0, noises, start_step=3)
+    assert rel_err(trajs, g["den8_trajs"]) < 1e-4
+    assert rel_err(x, g["den8_final"]) < 1e-4
+
+
+def test_sampler_completion():
+    g = load("g5_sampler")
+    p, z0, noise = _sampler_case(g, "comp8", 8)
+    # draw order per step: impute-after-corrector, EM z, impute-after-predictor
+    imp = [(noise[3 * i], noise[3 * i + 2]) for i in range(8)]
+    em = [noise[3 * i + 1] for i in range(8)]
+    trajs, x = R.pc_sampler(p, R.SubVP(N=8), z0, em, observation=torch.tensor(g["comp8_obs"]),
+                            mask=torch.tensor(g["comp8_mask"]), impute_noises=imp)
+    assert rel_err(trajs, g["comp8_trajs"]) < 1e-4
+    assert rel_err(x, g["comp8_final"]) < 1e-4
+
+
+def test_sampler_langevin():
+    g = load("g5_sampler")
+    p, z0, noise = _sampler_case(g, "lang4", 4)
+    cor = [None] * 996 + [noise[2 * i] for i in range(4)]
+    em = [None] * 996 + [noise[2 * i + 1] for i in range(4)]
+    trajs, x = R.pc_sampler(p, R.SubVP(N=1000), z0, em, corrector_noises=cor, start_step=996)
+    assert np.isfinite(g["lang4_trajs"]).all()
+    assert rel_err(trajs, g["lang4_trajs"]) < 1e-4
+    assert rel_err(x, g["lang4_final"]) < 1e-4
+
+
+def test_sampler_em1000():
+    g = load("g5_sampler")
+    p, z0, noise = _sampler_case(g, "em1000", 1000)
+    trajs, x = R.pc_sampler(p, R.SubVP(N=1000), z0, noise)
+    assert rel_err(trajs[99::100], g["em1000_trajs"]) < 2e-3
+    assert rel_err(x, g["em1000_final"]) < 2e-3
+
+
+def test_prior_loss():
+    g = load("g7_prior_loss")
+    p = make_weights(int(g["seed"]))
+    p["sigmas"] = R.sigma_table()
+    x0 = torch.tensor(g["x0"])
+    sde = R.SubVP()
+    ts = torch.linspace(1.0, 1e-3, 1000)
+    for step in (0, 99, 100, 199):
+        q = R.completion_quan_t(step, 200, 1000)
+        assert q == int(g[f"s{step}_quan_t"])
+        t = torch.ones(16) * ts[q]
+        z = torch.tensor(g[f"s{step}_z"])
+        loss, grad = R.dposer_prior_loss(p, sde, x0, t, z, weighted=bool(q))
+        assert abs(loss.item() - float(g[f"s{step}_loss"])) / abs(float(g[f"s{step}_loss"])) < 1e-4
+        assert rel_err(grad, g[f"s{step}_grad"]) < 1e-4
+        lu, _ = R.dposer_prior_loss(p, sde, x0, t, z, weighted=False)
+        assert abs(lu.item() - float(g[f"s{step}_loss_unweighted"])) / abs(float(g[f"s{step}_loss_unweighted"])) < 1e-4
+
+
+def test_scalar_tables():
+    g = load("g8_scalars")
+    t = torch.tensor(g["t"])
+    x = torch.ones(1000, 1)
+    for name, sde in (("subvp", R.SubVP()), ("vp", R.VP()), ("ve", R.VE())):
+        mean, std = sde.marginal_prob(x, t)
+        drift, diff = sde.sde(x, t)
+        a, s = sde.alpha_sigma(t)
+        for got, key in ((mean, "mean"), (std, "std"), (drift, "drift"), (diff, "diffusion"),
+                         (a, "alpha"), (s, "sigma")):
+            ref = g[f"{name}_{key}"]
+            assert np.allclose(np.broadcast_to(got.numpy(), ref.shape), ref, rtol=2e-6, atol=1e-7), (name, key)
+    assert np.array_equal(R.sigma_table().numpy(), g["sigmas_buffer"])
+    emb = R.timestep_embedding(t[::50] * 999, 512)
+    assert np.allclose(emb.numpy(), g["temb"], atol=2e-6)
+
+
+def test_rot6d():
+    g = load("g11_rot6d")
+    out = fk_ref.rot6d_to_mat3x3(g["rot6d"].astype(np.float32))
+    assert np.allclose(out, g["rotmat"], atol=2e-6)
