@@ -1,0 +1,118 @@
+// Shared device/host helpers for the DPoser MI355X (gfx950) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// ----------------------------------------------------------------------------------------------
+// error plumbing for the C ABI (thread-local last error string)
+// ----------------------------------------------------------------------------------------------
+#include "../../include/dposer_hip.h"   // DPOSER_OK / DPOSER_ERR_* status codes
+
+int dposer_set_error(int code, const std::string& msg);
+
+#define DP_CHECK_ARG(cond, msg)                                                \
+    do {                                                                       \
+        if (!(cond)) return dposer_set_error(DPOSER_ERR_BAD_ARG, std::string(__func__) + ": " + (msg)); \
+    } while (0)
+
+#define DP_CHECK_HIP(expr)                                                     \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess)                                                  \
+            return dposer_set_error(DPOSER_ERR_HIP, std::string(__func__) + ": " + #expr + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define DP_CHECK_LAUNCH() DP_CHECK_HIP(hipGetLastError())
+
+#define DP_TRY(expr)                   \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != DPOSER_OK) return _rc; \
+    } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
+
+// ----------------------------------------------------------------------------------------------
+// Fragment-tiled ("FT") matrix layout -- the HBM layout of every intermediate of the score net.
+//
+// A logical matrix T[R][K] (R = samples or output channels, K = the reduction dimension of the
+// GEMM that CONSUMES it) is stored as 1-KiB blocks, block (rb, kb) at ((rb * K/KBS) + kb) KiB:
+//     block = 64 lanes x 16 B, lane l = (kh = l >> 5, r = l & 31)
+//     bf16: KBS = 16, lane holds T[32 rb + r][16 kb + 8 kh + 0..7]   (= one v_mfma_f32_32x32x16_bf16 operand)
+//     fp32: KBS = 8,  lane holds T[32 rb + r][ 8 kb + 4 kh + 0..3]   (= four v_mfma_f32_32x32x2_f32 operands)
+// so a wave fetches an MFMA operand with ONE perfectly coalesced 1-KiB load, the LDS image of a
+// tile is the HBM image (global_load_lds friendly, ds_read_b128 conflict-free without swizzle),
+// and the epilogue of the producing GEMM (lane = sample, registers = channels in quads of 4)
+// stores straight into it.
+// ----------------------------------------------------------------------------------------------
+template <typename T> struct FT {
+    static constexpr int EPL = 16 / sizeof(T);   // elements per lane chunk (8 bf16 / 4 fp32)
+    static constexpr int KBS = 2 * EPL;          // reduction elements per block (16 / 8)
+    static constexpr int BLOCK_ELEMS = 64 * EPL;
+    // element index of T[r][k] for a matrix with K (multiple of KBS) columns
+    __host__ __device__ static inline int64_t index(int64_t r, int k, int K) {
+        return ((r >> 5) * (int64_t)(K / KBS) + (k / KBS)) * BLOCK_ELEMS + ((((k % KBS) / EPL) << 5) + (r & 31)) * EPL + (k % EPL);
+    }
+};
+
+__device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
+
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    // round-to-nearest-even, NaN preserved
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// 4 consecutive elements (a "quad") load/store in the storage type
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+    __device__ static inline f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    __device__ static inline void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Quad<__bf16> {
+    __device__ static inline f32x4 load(const __bf16* p) {
+        uint2 u = *reinterpret_cast<const uint2*>(p);
+        f32x4 v;
+        v[0] = __uint_as_float(u.x << 16);
+        v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[2] = __uint_as_float(u.y << 16);
+        v[3] = __uint_as_float(u.y & 0xffff0000u);
+        return v;
+    }
+    __device__ static inline void store(__bf16* p, f32x4 v) {
+        uint2 u;
+        u.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+        u.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+};
+
+template <typename T> __device__ __forceinline__ T from_f32(float f);
+template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float f) {
+    unsigned short b = f32_to_bf16_bits(f);
+    return *reinterpret_cast<__bf16*>(&b);
+}
+
+// precise / fast scalar math selected by the storage type (fp32 mode = parity mode)
+template <bool PRECISE> __device__ __forceinline__ float silu_f(float a) {
+    if (PRECISE) return a / (1.0f + expf(-a));
+    return a * __frcp_rn(1.0f + __expf(-a));
+}
+// d silu / da
+template <bool PRECISE> __device__ __forceinline__ float dsilu_f(float a) {
+    float s = PRECISE ? 1.0f / (1.0f + expf(-a)) : __frcp_rn(1.0f + __expf(-a));
+    return s * (1.0f + a * (1.0f - s));
+}

@@ -1,0 +1,621 @@
+// Elementwise, layout and optimizer kernels of the DPoser score path (gfx950).
+// These are HBM-bound: one thread handles a "quad" (4 consecutive channels = 8 or 16 contiguous
+// bytes of the fragment-tiled layout), grids are sized to the data, no LDS unless transposing.
+//
+// Scalar SDE arithmetic mirrors the op order of the reference's fp32 torch expressions
+// (lib/algorithms/advanced/sde_lib.py) and is compiled with FMA contraction off so that integer
+// indices derived from floats (sigmas[(t*999).long()], model.py:159) agree bit-for-bit.
+#include "kernels_api.h"
+#include "rng.h"
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------------
+// SDE scalars (sde_lib.py:122-231)
+// ------------------------------------------------------------------------------------------------
+struct SdeDev {
+    int kind;
+    float b0, db, m2b0;   // beta_0, (beta_1 - beta_0), -2*beta_0  (python doubles rounded to fp32)
+    float dt, sqrt_mdt;   // -1/N, sqrt(1/N)
+};
+static SdeDev make_sde_dev(const SdeCfg& s) {
+    SdeDev d;
+    d.kind = s.kind;
+    d.b0 = (float)(double)s.beta_0;
+    d.db = (float)((double)s.beta_1 - (double)s.beta_0);
+    d.m2b0 = (float)(-2.0 * (double)s.beta_0);
+    d.dt = (float)(-1.0 / (double)s.N);
+    d.sqrt_mdt = (float)sqrt(1.0 / (double)s.N);
+    return d;
+}
+__device__ __forceinline__ float sde_lmc(const SdeDev& s, float t) {          // sde_lib.py:214
+    return (-0.25f * (t * t)) * s.db - (0.5f * t) * s.b0;
+}
+__device__ __forceinline__ float sde_std(const SdeDev& s, float lmc) {         // :216 (subVP) / :155 (VP)
+    const float v = 1.0f - expf(2.0f * lmc);
+    return s.kind == SDE_SUBVP ? v : sqrtf(v);
+}
+__device__ __forceinline__ float sde_beta(const SdeDev& s, float t) { return s.b0 + t * s.db; }   // :207
+__device__ __forceinline__ float sde_diffusion(const SdeDev& s, float t) {     // :209-210 / :149
+    const float beta = sde_beta(s, t);
+    if (s.kind == SDE_VP) return sqrtf(beta);
+    const float discount = 1.0f - expf(s.m2b0 * t - s.db * (t * t));
+    return sqrtf(beta * discount);
+}
+
+template <typename T> __device__ __forceinline__ void store_quad_ft(void* base, int64_t s, int c, int K, f32x4 v) {
+    Quad<T>::store(reinterpret_cast<T*>(base) + FT<T>::index(s, c, K), v);
+}
+
+// time embedding value for channel e of E (model.py:37-51 positional / :19-21 fourier)
+__device__ __forceinline__ float temb_value(float label, int e, int E, const float* freq, int fourier) {
+    const int half = E >> 1;
+    const int k = e < half ? e : e - half;
+    float arg;
+    if (fourier) arg = ((logf(label) * freq[k]) * 2.0f) * 3.14159274101257324f;
+    else arg = label * freq[k];
+    return e < half ? sinf(arg) : cosf(arg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void pack_chunk(const PackJob& j, const float* flat, unsigned char* packed, int64_t chunk) {
+    constexpr int EPL = FT<T>::EPL, KBS = FT<T>::KBS;
+    const int kblocks = j.kpad / KBS;
+    const int lane = (int)(chunk & 63);
+    const int64_t blk = chunk >> 6;
+    const int kb = (int)(blk % kblocks);
+    const int64_t rb = blk / kblocks;
+    const int r = (int)(rb * 32 + (lane & 31));
+    const int k0 = kb * KBS + (lane >> 5) * EPL;
+    const float* src = flat + j.src_off;
+    T vals[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        const int k = k0 + e;
+        float v = 0.f;
+        if (r < j.rows_valid && k < j.cols_valid) v = j.trans ? src[(int64_t)k * j.ld + r] : src[(int64_t)r * j.ld + k];
+        vals[e] = from_f32<T>(v);
+    }
+    T* dst = reinterpret_cast<T*>(packed + j.dst_off) + FT<T>::index(r, j.koff + k0, j.ktot);
+    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<u32x4*>(vals);
+}
+__global__ void __launch_bounds__(256) k_pack(PackJobs jobs, const float* flat, unsigned char* packed) {
+    // select the job without dynamically indexing the kernel-argument array
+    PackJob j = jobs.job[0];
+    for (int i = 1; i < MAX_PACK_JOBS; ++i)
+        if (i == (int)blockIdx.y) j = jobs.job[i];
+    const int epl = j.f32 ? 4 : 8;
+    const int64_t nchunks = (int64_t)j.rows_pad * j.kpad / epl;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * blockDim.x) {
+        if (j.f32) pack_chunk<float>(j, flat, packed, c);
+        else pack_chunk<__bf16>(j, flat, packed, c);
+    }
+}
+hipError_t launch_pack(const PackJobs& jobs, const float* flat, void* packed, hipStream_t st) {
+    if (jobs.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack, dim3(256, jobs.n), dim3(256), 0, st, jobs, flat, reinterpret_cast<unsigned char*>(packed));
+    return hipGetLastError();
+}
+
+__global__ void k_bias_cat(BiasCatJobs j, const float* flat, float* dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= j.n * j.H) return;
+    const int l = i / j.H, c = i % j.H;
+    int64_t a = j.a_off[0], b = j.b_off[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { a = (l == k) ? j.a_off[k] : a; b = (l == k) ? j.b_off[k] : b; }
+    dst[i] = flat[a + c] + flat[b + c];
+}
+hipError_t launch_bias_cat(const BiasCatJobs& j, const float* flat, float* dst, hipStream_t st) {
+    const int n = j.n * j.H;
+    hipLaunchKernelGGL(k_bias_cat, dim3((n + 255) / 256), dim3(256), 0, st, j, flat, dst);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// input preparation
+// ------------------------------------------------------------------------------------------------
+template <typename T> __global__ void __launch_bounds__(256) k_prep_infer(PrepArgs a) {
+    const int qx = a.Dpad >> 2, qe = a.emb ? (a.E >> 2) : 0;
+    const int64_t total = a.Bpad * (qx + qe);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // sample index fastest so that consecutive lanes hit consecutive 16-B chunks of an FT block
+        const int64_t s = i % a.Bpad;
+        const int q = (int)(i / a.Bpad);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q < qx) {
+            const int c = q * 4;
+            if (s < a.B) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c + r < a.D) v[r] = a.x[s * a.D + c + r];
+            }
+            store_quad_ft<T>(a.xin, s, c, a.Dpad, v);
+        } else {
+            const int e = (q - qx) * 4;
+            const float label = s < a.B ? a.labels[s] : (a.fourier ? 1.0f : 0.0f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = temb_value(label, e + r, a.E, a.freq, a.fourier);
+            store_quad_ft<T>(a.emb, s, e, a.E, v);
+        }
+    }
+}
+static inline int grid_for(int64_t n, int per_block = 256, int cap = 8192) {
+    int64_t g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+hipError_t launch_prep_infer(const PrepArgs& a, hipStream_t st) {
+    const int64_t total = a.Bpad * ((a.Dpad >> 2) + (a.emb ? (a.E >> 2) : 0));
+    if (a.f32) hipLaunchKernelGGL(k_prep_infer<float>, dim3(grid_for(total)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_prep_infer<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+struct PrepTrainDev {
+    PrepTrainArgs a;
+    SdeDev sde;
+    float t_scale;   // (T - eps) as fp32
+};
+template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTrainDev d) {
+    const PrepTrainArgs& a = d.a;
+    const int qx = a.Dpad >> 2, qe = a.E >> 2;
+    const int QD = (a.D + 3) >> 2;
+    const int64_t total = a.Bpad * (qx + qe);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % a.Bpad;
+        const int q = (int)(i / a.Bpad);
+        float t = a.eps;
+        if (s < a.B) {
+            if (a.t_in) t = a.t_in[s];
+            else {                                          // losses.py:110  t = rand(B)*(T-eps)+eps
+                Philox4 r = philox_at((uint64_t)s, STREAM_TRAIN_T, a.step, a.seed);
+                t = u01(r.v[0]) * d.t_scale + a.eps;
+            }
+        }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q < qx) {
+            const int c = q * 4;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (s < a.B && c < a.D) {
+                if (a.z_in) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c + r < a.D) z[r] = a.z_in[s * a.D + c + r];
+                } else {                                    // losses.py:111  z = randn_like(batch)
+                    float n4[4];
+                    normals4((uint64_t)s * QD + q, STREAM_TRAIN_Z, a.step, a.seed, n4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c + r < a.D) z[r] = n4[r];
+                }
+                const float lmc = sde_lmc(d.sde, t);
+                const float mc = expf(lmc), sd = sde_std(d.sde, lmc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)                 // losses.py:112-113  x_t = mean + std*z
+                    if (c + r < a.D) v[r] = mc * a.x0[s * a.D + c + r] + sd * z[r];
+            }
+            store_quad_ft<T>(a.xin, s, c, a.Dpad, v);
+            *reinterpret_cast<f32x4*>(a.z_out + s * a.Dpad + c) = z;
+            if (q == 0) a.t_out[s] = t;
+        } else {
+            const int e = (q - qx) * 4;
+            const float label = t * 999.0f;                 // utils.py:152
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = temb_value(label, e + r, a.E, a.freq, a.fourier);
+            store_quad_ft<T>(a.emb, s, e, a.E, v);
+        }
+    }
+}
+hipError_t launch_prep_train(const PrepTrainArgs& a, hipStream_t st) {
+    PrepTrainDev d;
+    d.a = a;
+    d.sde = make_sde_dev(a.sde);
+    d.t_scale = (float)((double)a.sde.T - (double)a.eps);
+    const int64_t total = a.Bpad * ((a.Dpad >> 2) + (a.E >> 2));
+    if (a.f32) hipLaunchKernelGGL(k_prep_train<float>, dim3(grid_for(total)), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(k_prep_train<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_time_embed(const float* labels, float label0, int64_t n, int64_t npad, const float* freq, int E, int fourier, float* emb) {
+    const int qe = E >> 2;
+    const int64_t total = npad * qe;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % npad;
+        const int e = (int)(i / npad) * 4;
+        const float label = s < n ? (labels ? labels[s] : label0) : (fourier ? 1.0f : 0.0f);
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = temb_value(label, e + r, E, freq, fourier);
+        store_quad_ft<float>(emb, s, e, E, v);
+    }
+}
+hipError_t launch_time_embed(const float* labels, float label0, int64_t n, int64_t npad, const float* freq, int E, int fourier, float* emb, hipStream_t st) {
+    hipLaunchKernelGGL(k_time_embed, dim3(grid_for(npad * (E >> 2))), dim3(256), 0, st, labels, label0, n, npad, freq, E, fourier, emb);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// output stages
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float used_sigma(const float* sigmas, int num_scales, float label, int fourier) {
+    if (fourier) return label;                                  // model.py:152
+    int idx = (int)label;                                       // model.py:159  t.long() truncates
+    idx = idx < 0 ? 0 : (idx >= num_scales ? num_scales - 1 : idx);
+    return sigmas[idx];
+}
+
+__global__ void __launch_bounds__(256) k_out_model(OutModelArgs a) {
+    const int64_t total = a.B * a.D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / a.D;
+        const int c = (int)(i % a.D);
+        float v = a.res[s * a.Cp + c];
+        if (a.scale_by_sigma) v = v / used_sigma(a.sigmas, a.num_scales, a.labels[s], a.fourier);   // model.py:192-194
+        a.out[i] = v;
+    }
+}
+hipError_t launch_out_model(const OutModelArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_out_model, dim3(grid_for(a.B * a.D)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+struct EmDev {
+    EmUpdateArgs a;
+    SdeDev sde;
+};
+template <typename T> __global__ void __launch_bounds__(256) k_em_update(EmDev d) {
+    const EmUpdateArgs& a = d.a;
+    const int qx = a.Dpad >> 2;
+    const int QD = (a.D + 3) >> 2;
+    const int64_t total = a.Bpad * qx;
+    // per-step scalars (identical for every sample: vec_t = ones(B)*t, sampling.py:458)
+    const float t = a.t;
+    const float lmc = sde_lmc(d.sde, t);
+    const float mc = expf(lmc), sd = sde_std(d.sde, lmc);
+    const float beta = sde_beta(d.sde, t);
+    const float g = sde_diffusion(d.sde, t);
+    const float label = t * 999.0f;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, label, 0) : 1.0f;
+    float mcn = 0.f, sdn = 0.f;
+    if (a.t_next >= 0.f) { const float l2 = sde_lmc(d.sde, a.t_next); mcn = expf(l2); sdn = sde_std(d.sde, l2); }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % a.Bpad;
+        const int q = (int)(i / a.Bpad);
+        const int c = q * 4;
+        f32x4 xn = {0.f, 0.f, 0.f, 0.f};
+        if (s < a.B && c < a.D) {
+            float zp[4], zb[4], za[4];
+            if (a.res && !a.z_pred) normals4((uint64_t)s * QD + q, STREAM_EM_NOISE, a.step, a.seed, zp);
+            if (a.obs && a.res && !a.z_impB) normals4((uint64_t)s * QD + q, STREAM_IMPUTE_B, a.step, a.seed, zb);
+            if (a.obs && a.t_next >= 0.f && !a.z_impA) normals4((uint64_t)s * QD + q, STREAM_IMPUTE_A, a.step + 1, a.seed, za);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (c + r >= a.D) continue;
+                const int64_t o = s * a.D + c + r;
+                float x = a.x[o];
+                if (a.res) {
+                    // score = -(res / used_sigmas) / std                         model.py:194, utils.py:162
+                    const float model = a.res[s * a.Cp + c + r] / usig;
+                    const float score = -model / sd;
+                    // rsde.sde: drift = -0.5 beta x - g^2 score                  sde_lib.py:98-104
+                    float drift = (-0.5f * beta) * x;
+                    drift = drift - ((g * g) * score) * 1.0f;
+                    const float x_mean = x + drift * d.sde.dt;                    // sampling.py:186
+                    const float z = a.z_pred ? a.z_pred[o] : zp[r];
+                    x = x_mean + (g * d.sde.sqrt_mdt) * z;                         // sampling.py:187
+                    a.x_mean[o] = x_mean;
+                    if (a.obs) {                                                   // sampling.py:416-420 (after predictor)
+                        const float m = a.mask[o];
+                        const float nz = a.z_impB ? a.z_impB[o] : zb[r];
+                        x = x * (1.0f - m) + (mc * a.obs[o] + nz * sd) * m;
+                    }
+                    if (a.traj) a.traj[o] = x;                                     // sampling.py:461
+                }
+                if (a.obs && a.t_next >= 0.f) {                                    // imputation ahead of the next predictor call
+                    const float m = a.mask[o];
+                    const float nz = a.z_impA ? a.z_impA[o] : za[r];
+                    x = x * (1.0f - m) + (mcn * a.obs[o] + nz * sdn) * m;
+                }
+                a.x[o] = x;
+                xn[r] = x;
+            }
+        }
+        store_quad_ft<T>(a.xin, s, c, a.Dpad, xn);
+    }
+}
+hipError_t launch_em_update(const EmUpdateArgs& a, hipStream_t st) {
+    EmDev d;
+    d.a = a;
+    d.sde = make_sde_dev(a.sde);
+    const int64_t total = a.Bpad * (a.Dpad >> 2);
+    if (a.f32) hipLaunchKernelGGL(k_em_update<float>, dim3(grid_for(total)), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(k_em_update<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+
+// block-wide sum -> one partial per block (deterministic)
+__device__ __forceinline__ float block_sum_256(float v) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+struct PerturbDev {
+    PerturbSharedArgs a;
+    SdeDev sde;
+};
+template <typename T> __global__ void __launch_bounds__(256) k_perturb_shared(PerturbDev d) {
+    const PerturbSharedArgs& a = d.a;
+    const int qx = a.Dpad >> 2;
+    const int QD = (a.D + 3) >> 2;
+    const float lmc = sde_lmc(d.sde, a.t);
+    const float mc = expf(lmc), sd = sde_std(d.sde, lmc);
+    const int64_t total = a.Bpad * qx;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % a.Bpad;
+        const int q = (int)(i / a.Bpad);
+        const int c = q * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (s < a.B && c < a.D) {
+            float n4[4];
+            if (!a.z_in) normals4((uint64_t)s * QD + q, STREAM_PRIOR, a.step, a.seed, n4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c + r < a.D) {
+                    const float z = a.z_in ? a.z_in[s * a.D + c + r] : n4[r];
+                    v[r] = mc * a.x0[s * a.D + c + r] + sd * z;          // completion.py:134-135
+                }
+        }
+        store_quad_ft<T>(a.xin, s, c, a.Dpad, v);
+        *reinterpret_cast<f32x4*>(a.xt + s * a.Dpad + c) = v;
+    }
+}
+hipError_t launch_perturb_shared(const PerturbSharedArgs& a, hipStream_t st) {
+    PerturbDev d;
+    d.a = a;
+    d.sde = make_sde_dev(a.sde);
+    const int64_t total = a.Bpad * (a.Dpad >> 2);
+    if (a.f32) hipLaunchKernelGGL(k_perturb_shared<float>, dim3(grid_for(total)), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(k_perturb_shared<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+
+struct DenoiseDev {
+    DenoiseArgs a;
+    SdeDev sde;
+};
+__global__ void __launch_bounds__(256) k_denoise(DenoiseDev d) {
+    const DenoiseArgs& a = d.a;
+    const float t = a.t;
+    const float lmc = sde_lmc(d.sde, t);
+    const float alpha = expf(lmc), sigma = sde_std(d.sde, lmc);      // return_alpha_sigma, sde_lib.py:227-231
+    const float sigma2 = sigma * sigma;
+    const float label = t * 999.0f;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, label, 0) : 1.0f;
+    const float snr = alpha / sqrtf(sigma2);                          // completion.py:108
+    const float w = a.weighted ? 0.5f * sqrtf(1.0f + snr) : 0.5f;     // completion.py:143-146
+    float acc = 0.f;
+    const int64_t total = a.B * a.D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / a.D;
+        const int c = (int)(i % a.D);
+        const float model = a.res[s * a.Cp + c] / usig;
+        const float score = -model / sigma;                           // utils.py:155,162 (std == sigma)
+        const float x0h = (a.xt[s * a.Dpad + c] + sigma2 * score) / alpha;   // completion.py:107
+        const float diff = a.x0[i] - x0h;
+        acc += w * (diff * diff);
+        if (a.x0_hat) a.x0_hat[i] = x0h;
+        if (a.grad) a.grad[i] = (2.0f * w) * diff * a.inv_n;
+    }
+    const float tot = block_sum_256(acc);
+    if (threadIdx.x == 0) a.loss_part[blockIdx.x] = tot * a.inv_n;
+}
+hipError_t launch_denoise(const DenoiseArgs& a, int* nblocks, hipStream_t st) {
+    DenoiseDev d;
+    d.a = a;
+    d.sde = make_sde_dev(a.sde);
+    const int g = grid_for(a.B * a.D, 256, 1024);
+    *nblocks = g;
+    hipLaunchKernelGGL(k_denoise, dim3(g), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+
+struct DsmDev {
+    DsmArgs a;
+    SdeDev sde;
+};
+template <typename T> __global__ void __launch_bounds__(256) k_dsm(DsmDev d) {
+    const DsmArgs& a = d.a;
+    const int qc = a.Cp >> 2;
+    const int64_t total = a.Bpad * qc;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % a.Bpad;
+        const int c = (int)(i / a.Bpad) * 4;
+        f32x4 dr = {0.f, 0.f, 0.f, 0.f};
+        if (s < a.B && c < a.D) {
+            const float t = a.t[s];
+            const float lmc = sde_lmc(d.sde, t);
+            const float sd = sde_std(d.sde, lmc);
+            const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, t * 999.0f, a.fourier) : 1.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c + r < a.D) {
+                    const float model = a.res[s * a.Cp + c + r] / usig;
+                    const float score = -model / sd;                               // utils.py:162
+                    const float e = score * sd + a.z[s * a.Dpad + c + r];          // losses.py:124
+                    acc += e * e;
+                    dr[r] = (-2.0f * e) * a.grad_scale / usig;
+                }
+        }
+        store_quad_ft<T>(a.dres, s, c, a.Cp, dr);
+    }
+    const float tot = block_sum_256(acc);
+    if (threadIdx.x == 0) a.loss_part[blockIdx.x] = tot * a.grad_scale;
+}
+hipError_t launch_dsm(const DsmArgs& a, int* nblocks, hipStream_t st) {
+    DsmDev d;
+    d.a = a;
+    d.sde = make_sde_dev(a.sde);
+    const int g = grid_for(a.Bpad * (a.Cp >> 2), 256, 1024);
+    *nblocks = g;
+    if (a.f32) hipLaunchKernelGGL(k_dsm<float>, dim3(g), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(k_dsm<__bf16>, dim3(g), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout helpers
+// ------------------------------------------------------------------------------------------------
+// One block transposes a 32-sample x 32-channel tile through LDS.
+template <typename T> __global__ void __launch_bounds__(256) k_ft_transpose(const T* in, T* out, int64_t Spad, int C, int Cpad) {
+    __shared__ float tile[32][33];
+    const int64_t s0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    {
+        const int sl = threadIdx.x & 31, cq = threadIdx.x >> 5;          // 8 channel quads
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c0 + cq * 4 < C) v = Quad<T>::load(in + FT<T>::index(s0 + sl, c0 + cq * 4, C));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[cq * 4 + r][sl] = v[r];
+    }
+    __syncthreads();
+    {
+        const int cl = threadIdx.x & 31, sq = threadIdx.x >> 5;          // 8 sample quads
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = tile[cl][sq * 4 + r];
+        Quad<T>::store(out + FT<T>::index(c0 + cl, (int)(s0 + sq * 4), (int)Spad), v);
+    }
+}
+hipError_t launch_ft_transpose(int f32, const void* in, void* out, int64_t Spad, int C, hipStream_t st) {
+    const int Cpad = (int)round_up(C, 32);
+    dim3 grid((unsigned)(Spad / 32), (unsigned)(Cpad / 32));
+    if (f32) hipLaunchKernelGGL(k_ft_transpose<float>, grid, dim3(256), 0, st, (const float*)in, (float*)out, Spad, C, Cpad);
+    else hipLaunchKernelGGL(k_ft_transpose<__bf16>, grid, dim3(256), 0, st, (const __bf16*)in, (__bf16*)out, Spad, C, Cpad);
+    return hipGetLastError();
+}
+
+constexpr int COLSUM_CHUNK = 2048;   // samples per partial row
+template <typename T> __global__ void __launch_bounds__(256) k_colsum(const T* in, float* part, int64_t Spad, int C) {
+    // block = (channel quad group of 8 quads, sample chunk): thread (sl = tid&31, cq = tid>>5)
+    const int c = (blockIdx.x * 8 + (threadIdx.x >> 5)) * 4;
+    const int64_t s_begin = (int64_t)blockIdx.y * COLSUM_CHUNK;
+    const int64_t s_end = s_begin + COLSUM_CHUNK < Spad ? s_begin + COLSUM_CHUNK : Spad;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < C)
+        for (int64_t s = s_begin + (threadIdx.x & 31); s < s_end; s += 32) {
+            f32x4 v = Quad<T>::load(in + FT<T>::index(s, c, C));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += v[r];
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) acc[r] += __shfl_xor(acc[r], d);
+    if ((threadIdx.x & 31) == 0 && c < C) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(int64_t)blockIdx.y * C + c + r] = acc[r];
+    }
+}
+hipError_t launch_colsum(int f32, const void* in, float* part, int64_t Spad, int C, int* nchunks, hipStream_t st) {
+    const int nc = (int)ceil_div(Spad, COLSUM_CHUNK);
+    *nchunks = nc;
+    dim3 grid((unsigned)ceil_div(C / 4, 8), (unsigned)nc);
+    if (f32) hipLaunchKernelGGL(k_colsum<float>, grid, dim3(256), 0, st, (const float*)in, part, Spad, C);
+    else hipLaunchKernelGGL(k_colsum<__bf16>, grid, dim3(256), 0, st, (const __bf16*)in, part, Spad, C);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient finalisation and optimizer
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const float* scratch, float* grad) {
+    ReduceJob j = jobs.job[0];
+    for (int i = 1; i < MAX_REDUCE_JOBS; ++i)
+        if (i == (int)blockIdx.y) j = jobs.job[i];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < j.count; e += (int64_t)gridDim.x * blockDim.x) {
+        const float* p = scratch + j.src_off + e;
+        float acc = 0.f;
+        for (int k = 0; k < j.nsrc; ++k) acc += p[(int64_t)k * j.src_stride];
+        grad[j.dst_off + e] = acc;
+    }
+}
+hipError_t launch_reduce_grads(const ReduceJobs& jobs, const float* scratch, float* flat_grad, hipStream_t st) {
+    if (jobs.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_reduce_grads, dim3(512, jobs.n), dim3(256), 0, st, jobs, scratch, flat_grad);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_sum_partials(const float* part, int n, float* out) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+    const float tot = block_sum_256(acc);
+    if (threadIdx.x == 0) out[0] = tot;
+}
+hipError_t launch_sum_partials(const float* part, int n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, part, n, out);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_sqnorm(const float* g, int64_t n, float* part) {
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = g4[i];
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; acc += v * v; }
+    const float tot = block_sum_256(acc);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+hipError_t launch_sqnorm(const float* g, int64_t n, float* part, int* nblocks, hipStream_t st) {
+    const int nb = grid_for(n / 4, 256, 1024);
+    *nblocks = nb;
+    hipLaunchKernelGGL(k_sqnorm, dim3(nb), dim3(256), 0, st, g, n, part);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) k_adam_ema(AdamArgs a) {
+    // clip_grad_norm_ (losses.py:54-55): coef = max_norm / (total_norm + 1e-6), clamped to 1
+    float coef = a.grad_scale;
+    if (a.grad_clip >= 0.f) {
+        const float total_norm = sqrtf(a.sqnorm[0]) * a.grad_scale;
+        float cc = a.grad_clip / (total_norm + 1e-6f);
+        cc = cc > 1.0f ? 1.0f : cc;
+        coef = a.grad_scale * cc;
+    }
+    const float step_size = a.lr / a.bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        float p = a.p[i];
+        const bool skip = (i >= a.skip_lo[0] && i < a.skip_hi[0]) || (i >= a.skip_lo[1] && i < a.skip_hi[1]);
+        if (!skip) {
+            const float g = a.g[i] * coef;
+            float m = a.m[i], v = a.v[i];
+            m = m + (g - m) * (1.0f - a.beta1);                   // exp_avg.lerp_(grad, 1 - beta1)
+            v = v * a.beta2 + (1.0f - a.beta2) * (g * g);         // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+            const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+            p = p - step_size * (m / denom);                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+            a.m[i] = m;
+            a.v[i] = v;
+            a.p[i] = p;
+        }
+        if (a.ema) {                                              // ema.py:51  s -= (1 - decay) * (s - p)
+            const float s = a.ema[i];
+            a.ema[i] = s - a.ema_one_minus_decay * (s - p);
+        }
+    }
+}
+hipError_t launch_adam_ema(const AdamArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_adam_ema, dim3(grid_for(a.n, 256, 4096)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}

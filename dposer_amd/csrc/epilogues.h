@@ -1,0 +1,400 @@
+// Fused GEMM epilogues for the score network (forward and backward).
+// Register layout on entry (see gemm.h): acc[tc][ts][4q + r] = D[channel = cbase + 32 tc + 8 q + 4 hi + r]
+//                                                             [sample  = sbase + 32 ts + (lane & 31)],  hi = lane >> 5.
+#pragma once
+#include "common.h"
+#include "rng.h"
+
+// dropout keep-mask for one lane's 16 channels of GroupNorm group g (contract: oracle/philox.py
+// dropout_keep_mask).  Two Philox calls; call m covers quads q = 2m, 2m+1; 16-bit lanes.
+struct DropoutCfg {
+    float p;           // drop probability; 0 => disabled
+    float scale;       // 1/(1-p)
+    uint32_t thr;      // keep <=> lane16 < thr, thr = floor((1-p) * 65536)
+    uint32_t site;     // dropout site id 0..4
+    uint32_t offset;   // optimisation step
+    uint64_t seed;
+    int groups_x4;     // H/8 = number of counters per sample
+};
+
+__device__ __forceinline__ void dropout_mask16(const DropoutCfg& d, int64_t s, int g, int hi, float keep[16]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        Philox4 r = philox_at((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            // lanes 2w (low half) and 2w+1 (high half); lane_in_call = (q%2)*4 + r
+            const int q = 2 * m + (w >> 1), r0 = (w & 1) * 2;
+            keep[4 * q + r0] = ((r.v[w] & 0xffffu) < d.thr) ? d.scale : 0.f;
+            keep[4 * q + r0 + 1] = ((r.v[w] >> 16) < d.thr) ? d.scale : 0.f;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// forward:  out = [resid +] Drop(SiLU(GroupNorm32(acc + bias)))         model.py:166-187
+// ----------------------------------------------------------------------------------------------
+struct GNParams {
+    const float* bias;     // [H] dense bias (+ time bias row in shared-t mode)
+    const float* gamma;    // [H]
+    const float* beta;     // [H]
+    void* out;             // FT [Spad][H]
+    const void* resid;     // FT [Spad][H] or null
+    void* xhat;            // TRAIN: FT [Spad][H]
+    float* rstd;           // TRAIN: [Spad][H/32]
+    int H;
+    DropoutCfg drop;
+};
+template <typename T, bool TRAIN> struct EpiGN {
+    typedef GNParams Params;
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int) {
+        struct { const float *bias, *gamma, *beta; T* out; const T* resid; T* xhat; float* rstd; int H; DropoutCfg drop; } p =
+            {pp.bias, pp.gamma, pp.beta, (T*)pp.out, (const T*)pp.resid, (T*)pp.xhat, pp.rstd, pp.H, pp.drop};
+        constexpr bool PRECISE = sizeof(T) == 4;
+        const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) {
+            const int c0 = cbase + tc * 32;
+            float bia[16], gam[16], bet[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + 8 * q + 4 * hi;
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + c);
+                f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c);
+                f32x4 e4 = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { bia[4 * q + r] = b4[r]; gam[4 * q + r] = g4[r]; bet[4 * q + r] = e4[r]; }
+            }
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                const int64_t s = sbase + ts * 32 + j;
+                float v[16];
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { v[r] = acc[tc][ts][r] + bia[r]; sum += v[r]; }
+                sum += __shfl_xor(sum, 32);
+                const float mean = sum * (1.0f / 32.0f);
+                float ss = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { v[r] -= mean; ss += v[r] * v[r]; }
+                ss += __shfl_xor(ss, 32);
+                const float var = ss * (1.0f / 32.0f);
+                const float rstd = PRECISE ? 1.0f / sqrtf(var + 1e-5f) : rsqrtf(var + 1e-5f);
+                float keep[16];
+                if (TRAIN && p.drop.p > 0.f) dropout_mask16(p.drop, s, c0 >> 5, hi, keep);
+                if (TRAIN && hi == 0) p.rstd[s * (p.H >> 5) + (c0 >> 5)] = rstd;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + 8 * q + 4 * hi;
+                    const int64_t off = FT<T>::index(s, c, p.H);
+                    f32x4 xh, o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        xh[r] = v[4 * q + r] * rstd;
+                        float a = gam[4 * q + r] * xh[r] + bet[4 * q + r];
+                        float y = silu_f<PRECISE>(a);
+                        if (TRAIN && p.drop.p > 0.f) y *= keep[4 * q + r];
+                        o[r] = y;
+                    }
+                    if (TRAIN) Quad<T>::store(p.xhat + off, xh);
+                    if (p.resid) {
+                        f32x4 rr = Quad<T>::load(p.resid + off);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] += rr[r];
+                    }
+                    Quad<T>::store(p.out + off, o);
+                }
+            }
+        }
+    }
+};
+
+// forward: temb = SiLU(acc + bias)  (shared_time_embed, model.py:124-127,164); TRAIN keeps u.
+struct BiasSiLUParams {
+    const float* bias;
+    void* out;     // FT [Spad][N]
+    void* pre;     // TRAIN: u = acc + bias, FT [Spad][N]
+    int N;
+};
+template <typename T, bool TRAIN> struct EpiBiasSiLU {
+    typedef BiasSiLUParams Params;
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int) {
+        struct { const float* bias; T* out; T* pre; int N; } p = {pp.bias, (T*)pp.out, (T*)pp.pre, pp.N};
+        constexpr bool PRECISE = sizeof(T) == 4;
+        const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cbase + tc * 32 + 8 * q + 4 * hi;
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + c);
+#pragma unroll
+                for (int ts = 0; ts < TS; ++ts) {
+                    const int64_t s = sbase + ts * 32 + j;
+                    const int64_t off = FT<T>::index(s, c, p.N);
+                    f32x4 u, o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { u[r] = acc[tc][ts][4 * q + r] + b4[r]; o[r] = silu_f<PRECISE>(u[r]); }
+                    if (TRAIN) Quad<T>::store(p.pre + off, u);
+                    Quad<T>::store(p.out + off, o);
+                }
+            }
+    }
+};
+
+// out[s][c] = acc + bias[c] (fp32, row-major, leading dimension ldc) for c < C_valid, s < S_valid.
+// Used by post_dense (model.py:189), the shared-t time-bias table and plain input-gradients.
+struct RowMajorParams {
+    const float* bias;   // may be null
+    float* out;
+    int64_t ldc;
+    int C_valid;
+    int64_t S_valid;
+};
+template <typename T> struct EpiRowMajor {
+    typedef RowMajorParams Params;
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int) {
+        const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cbase + tc * 32 + 8 * q + 4 * hi;
+                float b[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b[r] = (p.bias && c + r < p.C_valid) ? p.bias[c + r] : 0.f;
+#pragma unroll
+                for (int ts = 0; ts < TS; ++ts) {
+                    const int64_t s = sbase + ts * 32 + j;
+                    if (s < p.S_valid) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (c + r < p.C_valid) p.out[s * p.ldc + c + r] = acc[tc][ts][4 * q + r] + b[r];
+                    }
+                }
+            }
+    }
+};
+
+// out FT = acc  (+ optional FT addend): plain fragment-tiled store (dgrad into the time branch).
+struct PlainFTParams {
+    void* out;
+    int N;
+};
+template <typename T> struct EpiPlainFT {
+    typedef PlainFTParams Params;
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int) {
+        struct { T* out; int N; } p = {(T*)pp.out, pp.N};
+        const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ts = 0; ts < TS; ++ts) {
+                    const int c = cbase + tc * 32 + 8 * q + 4 * hi;
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = acc[tc][ts][4 * q + r];
+                    Quad<T>::store(p.out + FT<T>::index(sbase + ts * 32 + j, c, p.N), o);
+                }
+    }
+};
+
+// ----------------------------------------------------------------------------------------------
+// backward helpers
+// ----------------------------------------------------------------------------------------------
+// All-to-all butterfly: on entry every lane holds N partial values; on exit lane (l & 31) == i
+// holds the sum over the 32 lanes (same l >> 5) of value i.  31 shuffles for N = 32.
+template <int N> __device__ __forceinline__ void butterfly_reduce32(float (&v)[N], int lane) {
+    static_assert(N == 32, "N must be 32");
+#pragma unroll
+    for (int d = 16, n = 16; d >= 1; d >>= 1, n >>= 1) {
+        const bool up = (lane & d) != 0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            const float send = up ? v[i] : v[i + n];
+            const float keep = up ? v[i + n] : v[i];
+            v[i] = keep + __shfl_xor(send, d);
+        }
+    }
+}
+
+// dgrad epilogue: acc = dL/d(out_l) contribution through the NEXT layer's weights.
+//   g   = acc [+ carry_in]          (carry = gradient arriving over the residual connection)
+//   da  = g * keep/(1-p) * silu'(a),   a = gamma*xhat + beta
+//   dy  = rstd * (dx - mean_g(dx) - xhat * mean_g(dx * xhat)),   dx = da * gamma
+// writes dy (FT), optional carry_out = g, and per-wave partial sums of dgamma, dbeta, dbias.
+struct GNBwdParams {
+    const void* carry_in;  // FT [Spad][H] or null
+    void* carry_out;       // FT [Spad][H] or null
+    const void* xhat;      // FT [Spad][H]
+    const float* rstd;     // [Spad][H/32]
+    const float* gamma;
+    const float* beta;
+    void* dy;              // FT [Spad][H]
+    float* part;           // [n_rows][3][H] partial sums (row = wave row id), deterministic
+    int H;
+    int64_t S_valid;
+    DropoutCfg drop;
+};
+template <typename T> struct EpiGNBwd {
+    typedef GNBwdParams Params;
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int) {
+        struct { const T* carry_in; T* carry_out; const T* xhat; const float *rstd, *gamma, *beta; T* dy; float* part; int H; int64_t S_valid; DropoutCfg drop; } p =
+            {(const T*)pp.carry_in, (T*)pp.carry_out, (const T*)pp.xhat, pp.rstd, pp.gamma, pp.beta, (T*)pp.dy, pp.part, pp.H, pp.S_valid, pp.drop};
+        constexpr bool PRECISE = sizeof(T) == 4;
+        const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) {
+            const int c0 = cbase + tc * 32;
+            float gam[16], bet[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + 8 * q + 4 * hi;
+                f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c);
+                f32x4 e4 = *reinterpret_cast<const f32x4*>(p.beta + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { gam[4 * q + r] = g4[r]; bet[4 * q + r] = e4[r]; }
+            }
+            float stat[32];   // [0..15] dgamma, [16..31] dbeta (this lane's 16 channels)
+            float dbias[16];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) stat[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dbias[r] = 0.f;
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                const int64_t s = sbase + ts * 32 + j;
+                const bool valid = s < p.S_valid;
+                float keep[16];
+                if (p.drop.p > 0.f) dropout_mask16(p.drop, s, c0 >> 5, hi, keep);
+                const float rstd = p.rstd[s * (p.H >> 5) + (c0 >> 5)];
+                float dx[16], xh[16];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + 8 * q + 4 * hi;
+                    const int64_t off = FT<T>::index(s, c, p.H);
+                    f32x4 x4 = Quad<T>::load(p.xhat + off);
+                    f32x4 g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g[r] = acc[tc][ts][4 * q + r];
+                    if (p.carry_in) {
+                        f32x4 ci = Quad<T>::load(p.carry_in + off);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g[r] += ci[r];
+                    }
+                    if (p.carry_out) Quad<T>::store(p.carry_out + off, g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * q + r;
+                        float gg = valid ? g[r] : 0.f;
+                        if (p.drop.p > 0.f) gg *= keep[i];
+                        const float a = gam[i] * x4[r] + bet[i];
+                        const float da = gg * dsilu_f<PRECISE>(a);
+                        stat[i] += da * x4[r];
+                        stat[16 + i] += da;
+                        xh[i] = x4[r];
+                        dx[i] = da * gam[i];
+                        s1 += dx[i];
+                        s2 += dx[i] * x4[r];
+                    }
+                }
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                const float m1 = s1 * (1.0f / 32.0f), m2 = s2 * (1.0f / 32.0f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + 8 * q + 4 * hi;
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * q + r;
+                        o[r] = rstd * (dx[i] - m1 - xh[i] * m2);
+                        dbias[i] += o[r];
+                    }
+                    Quad<T>::store(p.dy + FT<T>::index(s, c, p.H), o);
+                }
+            }
+            // reduce over the 32 samples of the lane group; lane i ends with value i.
+            butterfly_reduce32(stat, lane);
+            float db2[32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { db2[r] = dbias[r]; db2[16 + r] = 0.f; }
+            butterfly_reduce32(db2, lane);
+            float* row = p.part + (int64_t)wrow * 3 * p.H;
+            {
+                const int i = j & 15;                              // register index this lane ended up with
+                const int c = c0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                row[(j >> 4) * p.H + c] = stat[0];                 // j<16: dgamma, j>=16: dbeta
+                if (j < 16) row[2 * p.H + c] = db2[0];
+            }
+        }
+    }
+};
+
+// dU = acc * silu'(u)  (backward of shared_time_embed's SiLU), FT store.
+struct SiLUBwdParams {
+    const void* pre;   // u, FT [Spad][N]
+    void* out;         // dU, FT [Spad][N]
+    int N;
+    int64_t S_valid;
+};
+template <typename T> struct EpiSiLUBwd {
+    typedef SiLUBwdParams Params;
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int) {
+        struct { const T* pre; T* out; int N; int64_t S_valid; } p = {(const T*)pp.pre, (T*)pp.out, pp.N, pp.S_valid};
+        constexpr bool PRECISE = sizeof(T) == 4;
+        const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ts = 0; ts < TS; ++ts) {
+                    const int c = cbase + tc * 32 + 8 * q + 4 * hi;
+                    const int64_t s = sbase + ts * 32 + j;
+                    const int64_t off = FT<T>::index(s, c, p.N);
+                    f32x4 u = Quad<T>::load(p.pre + off), o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (s < p.S_valid) ? acc[tc][ts][4 * q + r] * dsilu_f<PRECISE>(u[r]) : 0.f;
+                    Quad<T>::store(p.out + off, o);
+                }
+    }
+};
+
+// wgrad: slab[split][n][k] = acc   (fp32 row-major, lane = k column => 128-B coalesced rows)
+struct WgradParams {
+    float* slab;            // base of this parameter inside slab 0
+    int64_t slab_stride;    // elements between consecutive split slabs
+    int ld;                 // = K_valid (row length of the parameter)
+    int N_valid, K_valid;
+};
+template <typename T> struct EpiWgrad {
+    typedef WgradParams Params;
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int split) {
+        const int j = lane & 31, hi = lane >> 5;
+        float* base = p.slab + (int64_t)split * p.slab_stride;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                const int k = (int)sbase + ts * 32 + j;
+                if (k < p.K_valid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = cbase + tc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (n < p.N_valid) base[(int64_t)n * p.ld + k] = acc[tc][ts][r];
+                    }
+                }
+            }
+    }
+};

@@ -1,0 +1,516 @@
+// Body-model kernels: rotation conversions and forward kinematics (gfx950).
+//
+//   rot6d_to_rotmat  -- reference lib/utils/transforms.py:227-235
+//   rodrigues        -- smplx==0.1.28 lbs.py batch_rodrigues            (un-vendored dependency)
+//   fk_joints        -- smplx lbs.py batch_rigid_transform + the pose assembly of
+//                       SMPLX.forward (reference call site lib/body_model/body_model.py:68-88)
+//
+// These are HBM-bound (FK joints-only: 252 B in + 264 B out and ~3 kFLOP per pose), so the design
+// is: one lane = one pose (the whole kinematic chain runs in that lane's registers, the parents
+// table is a compile-time constant, no cross-lane traffic at all), and every global access goes
+// through an LDS transpose so that HBM only ever sees fully coalesced 16-byte-per-lane streams.
+// A lane-per-joint + wave-shuffle chain was rejected: it needs ~12 shuffles per tree level per
+// pose and is instruction-bound far below the HBM roofline.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <utility>
+
+#include "../../include/dposer_hip.h"
+#include "common.h"
+#include "gemm_api.h"
+#include "kernels_api.h"
+
+#pragma clang fp contract(off)
+
+#define FK_HIP_LAUNCH(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return dposer_set_error(DPOSER_ERR_HIP, std::string(__func__) + ": " + #expr + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// LDS-transposed streaming: a block of NT lanes owns NT consecutive items of IN / OUT floats.
+// ------------------------------------------------------------------------------------------------
+template <int NT> __device__ __forceinline__ void stream_in(const float* __restrict__ g, float* lds, int64_t item0, int64_t n_items, int width) {
+    // copy items [item0, item0+NT) x width floats; global side contiguous, LDS row stride = width (+1 if even)
+    const int64_t base = item0 * width;
+    const int64_t limit = n_items * (int64_t)width;
+    const int total = NT * width;
+    const int stride = width | 1;
+    for (int i = threadIdx.x; i < total; i += NT) {
+        const int64_t gi = base + i;
+        const float v = gi < limit ? g[gi] : 0.f;
+        lds[(i / width) * stride + (i % width)] = v;
+    }
+}
+template <int NT> __device__ __forceinline__ void stream_out(float* __restrict__ g, const float* lds, int64_t item0, int64_t n_items, int width) {
+    const int64_t base = item0 * width;
+    const int64_t limit = n_items * (int64_t)width;
+    const int total = NT * width;
+    const int stride = width | 1;
+    for (int i = threadIdx.x; i < total; i += NT) {
+        const int64_t gi = base + i;
+        if (gi < limit) g[gi] = lds[(i / width) * stride + (i % width)];
+    }
+}
+
+struct Mat3 {
+    float m[9];
+};
+
+// smplx lbs.py batch_rodrigues: angle = ||r + 1e-8||, k = r / angle, R = I + sin K + (1 - cos) K K
+__device__ __forceinline__ Mat3 rodrigues(float rx, float ry, float rz) {
+    const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
+    const float angle = sqrtf(ax * ax + ay * ay + az * az);
+    const float kx = rx / angle, ky = ry / angle, kz = rz / angle;
+    const float s = sinf(angle), c1 = 1.0f - cosf(angle);
+    Mat3 R;
+    R.m[0] = 1.0f + c1 * (-(kz * kz) - ky * ky);
+    R.m[1] = s * (-kz) + c1 * (kx * ky);
+    R.m[2] = s * ky + c1 * (kx * kz);
+    R.m[3] = s * kz + c1 * (kx * ky);
+    R.m[4] = 1.0f + c1 * (-(kz * kz) - kx * kx);
+    R.m[5] = s * (-kx) + c1 * (ky * kz);
+    R.m[6] = s * (-ky) + c1 * (kx * kz);
+    R.m[7] = s * kx + c1 * (ky * kz);
+    R.m[8] = 1.0f + c1 * (-(ky * ky) - kx * kx);
+    return R;
+}
+
+__global__ void __launch_bounds__(256) k_rodrigues(const float* __restrict__ aa, float* __restrict__ out, int64_t n) {
+    __shared__ float lds[256 * 9];
+    const int64_t item0 = (int64_t)blockIdx.x * 256;
+    stream_in<256>(aa, lds, item0, n, 3);
+    __syncthreads();
+    const float* r = lds + threadIdx.x * 3;
+    const Mat3 R = rodrigues(r[0], r[1], r[2]);
+    __syncthreads();
+    float* o = lds + threadIdx.x * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = R.m[i];
+    __syncthreads();
+    stream_out<256>(out, lds, item0, n, 9);
+}
+
+// lib/utils/transforms.py:227-235 (F.normalize eps = 1e-12; R = stack(b1, b2, b3, dim=-1))
+__global__ void __launch_bounds__(256) k_rot6d(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+    __shared__ float lds[256 * 9];
+    const int64_t item0 = (int64_t)blockIdx.x * 256;
+    stream_in<256>(in, lds, item0, n, 6);
+    __syncthreads();
+    const float* r = lds + threadIdx.x * 7;   // row stride 6|1 = 7
+    const float a1x = r[0], a2x = r[1], a1y = r[2], a2y = r[3], a1z = r[4], a2z = r[5];   // view(-1,3,2)
+    __syncthreads();
+    const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float d = b1x * a2x + b1y * a2y + b1z * a2z;
+    const float ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
+    const float n2 = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
+    const float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
+    const float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
+    float* o = lds + threadIdx.x * 9;
+    o[0] = b1x; o[1] = b2x; o[2] = b3x;
+    o[3] = b1y; o[4] = b2y; o[5] = b3y;
+    o[6] = b1z; o[7] = b2z; o[8] = b3z;
+    __syncthreads();
+    stream_out<256>(out, lds, item0, n, 9);
+}
+
+extern "C" int dposer_rodrigues(const float* aa, float* rotmat, int64_t n, void* stream) {
+    DP_CHECK_ARG(aa && rotmat && n >= 0, "bad argument");
+    if (n == 0) return DPOSER_OK;
+    hipLaunchKernelGGL(k_rodrigues, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, aa, rotmat, n);
+    FK_HIP_LAUNCH(hipGetLastError());
+    return DPOSER_OK;
+}
+extern "C" int dposer_rot6d_to_rotmat(const float* rot6d, float* rotmat, int64_t n, void* stream) {
+    DP_CHECK_ARG(rot6d && rotmat && n >= 0, "bad argument");
+    if (n == 0) return DPOSER_OK;
+    hipLaunchKernelGGL(k_rot6d, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, rot6d, rotmat, n);
+    FK_HIP_LAUNCH(hipGetLastError());
+    return DPOSER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward kinematics
+// ------------------------------------------------------------------------------------------------
+struct KinSMPL {
+    static constexpr int J = 24;
+    static constexpr int P[24] = {-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21};
+};
+struct KinSMPLH {
+    static constexpr int J = 52;
+    static constexpr int P[52] = {-1, 0,  0,  0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  9,  9,  12, 13, 14, 16, 17, 18, 19, 20, 22, 23, 20,
+                                  25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35, 21, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50};
+};
+struct KinSMPLX {
+    static constexpr int J = 55;
+    static constexpr int P[55] = {-1, 0,  0,  0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  9,  9,  12, 13, 14, 16, 17, 18, 19, 15, 15, 15, 20, 25, 26,
+                                  20, 28, 29, 20, 31, 32, 20, 34, 35, 20, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53};
+};
+
+struct Xf {        // 3x4 rigid transform
+    float r[9];
+    float t[3];
+};
+
+constexpr int FK_MAX_SEG = 8;
+struct FkArgs {
+    const float* seg[FK_MAX_SEG];   // pose segments [B][seg_joints*3]; null => zeros (identity rotations)
+    int seg_first[FK_MAX_SEG];      // first joint of each segment
+    int seg_joints[FK_MAX_SEG];
+    int nseg;
+    const float* j_rest;            // [J][3] or [B][J][3]
+    int j_rest_batched;
+    const float* transl;            // [B][3] or null
+    float* joints;                  // [B][joints_ld] rows, first n_out*3 floats written
+    int64_t joints_ld;              // floats per pose row in `joints` (>= n_out*3)
+    float* rel;                     // [B][n_out][12] or null
+    float* pf;                      // pose feature (R_i - I, i >= 1) as FT32 [Bpad][pf_K] or null   (smplx lbs.py: pose_feature)
+    int pf_K;
+    int n_out;                      // joints [0, n_out) are computed and written
+    int64_t B;
+};
+
+// One joint of the chain, with the joint index (and therefore its parent) a compile-time constant
+// so that the per-lane transforms G[] stay in registers.
+template <typename Kin, int I>
+__device__ __forceinline__ void fk_step(Xf (&G)[Kin::J], const float* pose, const float* jr, float* row, const float (&tr)[3],
+                                        const FkArgs& a, int64_t b, int n_out) {
+    if (I >= n_out) return;
+    constexpr int PI = Kin::P[I] < 0 ? 0 : Kin::P[I];
+    const Mat3 R = rodrigues(pose[3 * I], pose[3 * I + 1], pose[3 * I + 2]);
+    float rel[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rel[k] = jr[3 * I + k] - (I > 0 ? jr[3 * PI + k] : 0.f);
+    if (I == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) G[0].r[k] = R.m[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) G[0].t[k] = rel[k];
+    } else {
+        const Xf Pm = G[PI];
+        // G_i = G_parent @ [R rel; 0 1]
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                G[I].r[3 * r + c] = Pm.r[3 * r] * R.m[c] + Pm.r[3 * r + 1] * R.m[3 + c] + Pm.r[3 * r + 2] * R.m[6 + c];
+            G[I].t[r] = Pm.r[3 * r] * rel[0] + Pm.r[3 * r + 1] * rel[1] + Pm.r[3 * r + 2] * rel[2] + Pm.t[r];
+        }
+    }
+    // posed joint (+ transl) overwrites the (already consumed) axis-angle of joint I in the lane's LDS row
+#pragma unroll
+    for (int k = 0; k < 3; ++k) row[3 * I + k] = G[I].t[k] + tr[k];
+    if (a.pf && I > 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            a.pf[FT<float>::index(b, (I - 1) * 9 + k, a.pf_K)] = (b < a.B) ? R.m[k] - ((k % 4 == 0) ? 1.0f : 0.0f) : 0.f;
+    }
+    // skinning transform A_I = [R_I | t_I - R_I J_I] (rest pose removed), 3 x float4 per joint
+    if (a.rel && b < a.B) {
+        const float jx = jr[3 * I], jy = jr[3 * I + 1], jz = jr[3 * I + 2];
+        f32x4* q = reinterpret_cast<f32x4*>(a.rel + (b * n_out + I) * 12);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            f32x4 v;
+            v[0] = G[I].r[3 * r]; v[1] = G[I].r[3 * r + 1]; v[2] = G[I].r[3 * r + 2];
+            v[3] = G[I].t[r] - (G[I].r[3 * r] * jx + G[I].r[3 * r + 1] * jy + G[I].r[3 * r + 2] * jz);
+            q[r] = v;
+        }
+    }
+}
+template <typename Kin, int... Is>
+__device__ __forceinline__ void fk_chain(std::integer_sequence<int, Is...>, Xf (&G)[Kin::J], const float* pose, const float* jr, float* row,
+                                         const float (&tr)[3], const FkArgs& a, int64_t b, int n_out) {
+    (fk_step<Kin, Is>(G, pose, jr, row, tr, a, b, n_out), ...);
+}
+
+// One lane = one pose.  NT lanes per block; pose rows and outputs are staged through LDS.
+template <typename Kin, int NT> __global__ void __launch_bounds__(NT) k_fk_joints(FkArgs a) {
+    constexpr int J = Kin::J;
+    extern __shared__ float lds[];
+    const int64_t item0 = (int64_t)blockIdx.x * NT;
+    const int n_out = a.n_out;
+    // ---- stage the pose segments: LDS row = [J*3] axis-angle floats of one pose (stride odd) ----
+    constexpr int ROW = (J * 3) | 1;
+    for (int sg = 0; sg < FK_MAX_SEG; ++sg) {
+        if (sg >= a.nseg) break;
+        const int width = a.seg_joints[sg] * 3;
+        const int col0 = a.seg_first[sg] * 3;
+        const float* g = a.seg[sg];
+        const int total = NT * width;
+        const int64_t base = item0 * width, limit = a.B * (int64_t)width;
+        for (int i = threadIdx.x; i < total; i += NT) {
+            const int64_t gi = base + i;
+            lds[(i / width) * ROW + col0 + (i % width)] = (g && gi < limit) ? g[gi] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int64_t b = item0 + threadIdx.x;
+    float* row = lds + threadIdx.x * ROW;   // this lane's private LDS row: pose in, posed joints out (in place)
+    const float* jr = a.j_rest_batched ? a.j_rest + (b < a.B ? b : 0) * (int64_t)J * 3 : a.j_rest;
+    float tr[3] = {0.f, 0.f, 0.f};
+    if (a.transl && b < a.B) { tr[0] = a.transl[b * 3]; tr[1] = a.transl[b * 3 + 1]; tr[2] = a.transl[b * 3 + 2]; }
+    Xf G[J];
+    fk_chain<Kin>(std::make_integer_sequence<int, J>{}, G, row, jr, row, tr, a, b, n_out);
+    __syncthreads();
+    // ---- posed joints: LDS rows (stride ROW) -> coalesced global stream ----
+    {
+        const int width = n_out * 3;
+        for (int i = threadIdx.x; i < NT * width; i += NT) {
+            const int64_t bb = item0 + i / width;
+            if (bb < a.B) a.joints[bb * a.joints_ld + (i % width)] = lds[(i / width) * ROW + (i % width)];
+        }
+    }
+}
+
+struct dposer_body_s {
+    dposer_body_desc d;
+    int kind;   // 0 SMPL, 1 SMPL-H, 2 SMPL-X
+};
+
+template <typename Kin> static bool same_tree(const int32_t* p, int n) {
+    if (n != Kin::J) return false;
+    for (int i = 0; i < n; ++i)
+        if (p[i] != Kin::P[i] && !(i == 0 && p[i] < 0)) return false;
+    return true;
+}
+
+extern "C" int dposer_body_create(const dposer_body_desc* desc, const int32_t* parents_host, dposer_body_t* out) {
+    DP_CHECK_ARG(desc && parents_host && out, "null argument");
+    int kind = -1;
+    if (same_tree<KinSMPL>(parents_host, desc->num_joints)) kind = 0;
+    else if (same_tree<KinSMPLH>(parents_host, desc->num_joints)) kind = 1;
+    else if (same_tree<KinSMPLX>(parents_host, desc->num_joints)) kind = 2;
+    if (kind < 0)
+        return dposer_set_error(DPOSER_ERR_UNSUPPORTED,
+                                "dposer_body_create: kinematic tree is not SMPL (24), SMPL-H (52) or SMPL-X (55); "
+                                "the FK kernel unrolls the chain over a compile-time parents table");
+    auto* h = new dposer_body_s();
+    h->d = *desc;
+    h->kind = kind;
+    *out = h;
+    return DPOSER_OK;
+}
+extern "C" void dposer_body_destroy(dposer_body_t h) { delete h; }
+
+template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t st) {
+    constexpr int NT = 64;
+    const int lds_floats = NT * ((Kin::J * 3) | 1);
+    hipLaunchKernelGGL((k_fk_joints<Kin, NT>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
+    return hipGetLastError();
+}
+
+extern "C" int dposer_fk_joints(dposer_body_t h, const float* const* pose_segments_host, const int32_t* segment_joints_host,
+                                int32_t num_segments, const float* j_rest, int32_t j_rest_batched, const float* transl, float* joints,
+                                float* rel_transforms, int32_t n_out, int64_t batch, void* stream) {
+    DP_CHECK_ARG(h && pose_segments_host && segment_joints_host && j_rest && joints, "null argument");
+    DP_CHECK_ARG(num_segments >= 1 && num_segments <= FK_MAX_SEG, "1..8 pose segments");
+    DP_CHECK_ARG(batch > 0, "batch must be positive");
+    FkArgs a;
+    std::memset(&a, 0, sizeof(a));
+    int first = 0;
+    for (int i = 0; i < num_segments; ++i) {
+        a.seg[i] = pose_segments_host[i];
+        a.seg_first[i] = first;
+        a.seg_joints[i] = segment_joints_host[i];
+        first += segment_joints_host[i];
+    }
+    DP_CHECK_ARG(first == h->d.num_joints, "pose segments must cover all joints of the kinematic tree");
+    DP_CHECK_ARG(n_out >= 1 && n_out <= h->d.num_joints, "n_out must be in 1..num_joints");
+    a.nseg = num_segments; a.j_rest = j_rest; a.j_rest_batched = j_rest_batched; a.transl = transl; a.joints = joints;
+    a.rel = rel_transforms; a.n_out = n_out; a.B = batch; a.joints_ld = (int64_t)n_out * 3;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->kind == 0) FK_HIP_LAUNCH(launch_fk<KinSMPL>(a, st));
+    else if (h->kind == 1) FK_HIP_LAUNCH(launch_fk<KinSMPLH>(a, st));
+    else FK_HIP_LAUNCH(launch_fk<KinSMPLX>(a, st));
+    return DPOSER_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Linear blend skinning  (smplx lbs.py lbs(); reference call site lib/body_model/body_model.py:75-103)
+//   v_posed = v_shaped + pose_feature @ posedirs            -> fp32 MFMA GEMM (exact fp32 fma chain)
+//   T_v     = sum_j W[v][j] A_j ;  v = T_v [v_posed ; 1]     -> ELL-sparse skinning, A staged in LDS
+//   joints  = [J posed joints | vertex-selected extras | barycentric landmarks] (+ transl)
+// ------------------------------------------------------------------------------------------------
+struct SkinArgs {
+    const float* offsets;      // [B][ld_off] pose-blend offsets (3V valid)
+    int64_t ld_off;
+    const float* v_shaped;     // [V][3] or [B][V][3]
+    int v_shaped_batched;
+    const float* A;            // [B][J][12]
+    const int32_t* skin_idx;   // [V][K]
+    const float* skin_w;       // [V][K]
+    int K, J, V;
+    const float* transl;       // [B][3] or null
+    float* verts;              // [B][V][3]
+};
+__global__ void __launch_bounds__(256) k_skin(SkinArgs a) {
+    extern __shared__ float sA[];   // [J][12]
+    const int64_t b = blockIdx.y;
+    for (int i = threadIdx.x; i < a.J * 12; i += 256) sA[i] = a.A[b * a.J * 12 + i];
+    __syncthreads();
+    float tr[3] = {0.f, 0.f, 0.f};
+    if (a.transl) { tr[0] = a.transl[b * 3]; tr[1] = a.transl[b * 3 + 1]; tr[2] = a.transl[b * 3 + 2]; }
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < a.V; v += gridDim.x * 256) {
+        const float* vs = a.v_shaped + (a.v_shaped_batched ? b * a.V * 3 : 0) + (int64_t)v * 3;
+        const float* off = a.offsets + b * a.ld_off + (int64_t)v * 3;
+        const float px = vs[0] + off[0], py = vs[1] + off[1], pz = vs[2] + off[2];
+        float T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = 0.f;
+        for (int k = 0; k < a.K; ++k) {
+            const float w = a.skin_w[(int64_t)v * a.K + k];
+            const float* Aj = sA + a.skin_idx[(int64_t)v * a.K + k] * 12;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] += w * Aj[i];
+        }
+        float* o = a.verts + (b * a.V + v) * 3;
+        o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3] + tr[0];
+        o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7] + tr[1];
+        o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11] + tr[2];
+    }
+}
+
+struct ExtraArgs {
+    const float* verts;          // [B][V][3] (transl already applied)
+    const int32_t* extra_ids;    // [n_extra] vertex ids   (smplx VertexJointSelector)
+    const int32_t* lmk_tri;      // [n_lmk][3] vertex ids of the landmark faces (faces[lmk_faces_idx])
+    const float* lmk_bary;       // [n_lmk][3]
+    float* joints;               // [B][ld] rows; entries [J, J + n_extra + n_lmk) written here
+    int64_t ld;
+    int J, n_extra, n_lmk, V;
+    int64_t B;
+};
+__global__ void __launch_bounds__(256) k_extra_joints(ExtraArgs a) {
+    const int per = a.n_extra + a.n_lmk;
+    const int64_t total = a.B * per;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / per;
+        const int e = (int)(i % per);
+        const float* vb = a.verts + b * a.V * 3;
+        float x, y, z;
+        if (e < a.n_extra) {
+            const float* p = vb + (int64_t)a.extra_ids[e] * 3;
+            x = p[0]; y = p[1]; z = p[2];
+        } else {
+            const int l = e - a.n_extra;
+            x = y = z = 0.f;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {      // einsum('blfi,blf->bli') in smplx vertices2landmarks
+                const float* p = vb + (int64_t)a.lmk_tri[l * 3 + f] * 3;
+                const float w = a.lmk_bary[l * 3 + f];
+                x += p[0] * w; y += p[1] * w; z += p[2] * w;
+            }
+        }
+        float* o = a.joints + b * a.ld + (int64_t)(a.J + e) * 3;
+        o[0] = x; o[1] = y; o[2] = z;
+    }
+}
+
+static int64_t lbs_pad_batch(int64_t B) { return round_up(B, 128); }
+static int lbs_ppad(int J) { return (int)round_up((J - 1) * 9, 32); }
+static int64_t lbs_cpad(int V) { return round_up((int64_t)V * 3, 128); }
+
+extern "C" int64_t dposer_lbs_posedirs_packed_bytes(dposer_body_t h) {
+    if (!h) return -1;
+    return lbs_cpad(h->d.num_vertices) * lbs_ppad(h->d.num_joints) * 4;
+}
+// posedirs [(J-1)*9][V*3] fp32 row-major (the layout smplx keeps after its reshape/transposition)
+extern "C" int dposer_lbs_pack_posedirs(dposer_body_t h, const float* posedirs, void* packed, void* stream) {
+    DP_CHECK_ARG(h && posedirs && packed, "null argument");
+    PackJobs js;
+    js.n = 1;
+    PackJob& j = js.job[0];
+    const int P = (h->d.num_joints - 1) * 9;
+    j.dst_off = 0; j.src_off = 0; j.ktot = lbs_ppad(h->d.num_joints); j.koff = 0;
+    j.rows_pad = (int)lbs_cpad(h->d.num_vertices); j.kpad = j.ktot; j.rows_valid = h->d.num_vertices * 3; j.cols_valid = P;
+    j.ld = h->d.num_vertices * 3; j.trans = 1; j.f32 = 1;
+    FK_HIP_LAUNCH(launch_pack(js, posedirs, packed, (hipStream_t)stream));
+    return DPOSER_OK;
+}
+extern "C" int64_t dposer_lbs_workspace_bytes(dposer_body_t h, int64_t batch) {
+    if (!h || batch <= 0) return -1;
+    const int64_t Bpad = lbs_pad_batch(batch);
+    int64_t p = 0;
+    p += round_up(Bpad * lbs_ppad(h->d.num_joints) * 4, 256);          // pose feature FT32
+    p += round_up(batch * h->d.num_joints * 12 * 4, 256);              // A
+    p += round_up(batch * lbs_cpad(h->d.num_vertices) * 4, 256);       // offsets
+    return p;
+}
+
+extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedirs_packed, const float* const* pose_segments_host,
+                                  const int32_t* segment_joints_host, int32_t num_segments, const float* j_rest, int32_t j_rest_batched,
+                                  const float* v_shaped, int32_t v_shaped_batched, const int32_t* skin_idx, const float* skin_w,
+                                  int32_t skin_k, const float* transl, const int32_t* extra_vertex_ids, const int32_t* lmk_tri,
+                                  const float* lmk_bary, float* verts, float* joints, int64_t batch, void* stream) {
+    DP_CHECK_ARG(h && ws && posedirs_packed && pose_segments_host && segment_joints_host && j_rest && v_shaped && skin_idx && skin_w && verts && joints,
+                 "null argument");
+    DP_CHECK_ARG(batch > 0 && skin_k >= 1, "bad size");
+    DP_CHECK_ARG(((uintptr_t)ws & 255) == 0 && ((uintptr_t)posedirs_packed & 255) == 0, "workspace / packed posedirs must be 256-byte aligned");
+    DP_CHECK_ARG(num_segments >= 1 && num_segments <= FK_MAX_SEG, "1..8 pose segments");
+    hipStream_t st = (hipStream_t)stream;
+    const int J = h->d.num_joints, V = h->d.num_vertices;
+    const int64_t Bpad = lbs_pad_batch(batch);
+    const int Ppad = lbs_ppad(J);
+    const int64_t Cpad = lbs_cpad(V);
+    char* p = (char*)ws;
+    float* pf = (float*)p; p += round_up(Bpad * Ppad * 4, 256);
+    float* A = (float*)p; p += round_up(batch * J * 12 * 4, 256);
+    float* offsets = (float*)p;
+    const int n_total = J + h->d.num_extra + h->d.num_landmarks;
+
+    // 1. FK: posed joints -> joints[:, :J], skinning transforms A, pose feature (FT32 operand of the blend GEMM)
+    DP_CHECK_HIP(hipMemsetAsync(pf, 0, Bpad * Ppad * 4, st));
+    FkArgs a;
+    std::memset(&a, 0, sizeof(a));
+    int first = 0;
+    for (int i = 0; i < num_segments; ++i) {
+        a.seg[i] = pose_segments_host[i];
+        a.seg_first[i] = first;
+        a.seg_joints[i] = segment_joints_host[i];
+        first += segment_joints_host[i];
+    }
+    DP_CHECK_ARG(first == J, "pose segments must cover all joints of the kinematic tree");
+    a.nseg = num_segments; a.j_rest = j_rest; a.j_rest_batched = j_rest_batched; a.transl = transl; a.joints = joints;
+    a.joints_ld = (int64_t)n_total * 3; a.rel = A; a.pf = pf; a.pf_K = Ppad; a.n_out = J; a.B = batch;
+    if (h->kind == 0) FK_HIP_LAUNCH(launch_fk<KinSMPL>(a, st));
+    else if (h->kind == 1) FK_HIP_LAUNCH(launch_fk<KinSMPLH>(a, st));
+    else FK_HIP_LAUNCH(launch_fk<KinSMPLX>(a, st));
+
+    // 2. pose-blend offsets[b][3V] = pose_feature @ posedirs: fp32 MFMA, rows = poses, lanes = vertex coords
+    {
+        GemmArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.W = pf; g.w_stride_blocks = Ppad / 8; g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(Cpad / 128); g.ksplit = 1;
+        g.src[0] = posedirs_packed; g.seg_kblocks[0] = Ppad / 8; g.nseg = 1; g.ktot_blocks = Ppad / 8;
+        WgradParams wp;
+        wp.slab = offsets; wp.slab_stride = 0; wp.ld = (int)Cpad; wp.N_valid = (int)batch; wp.K_valid = V * 3;
+        FK_HIP_LAUNCH(gemm_wgrad(PREC_FP32, SHAPE_MID, g, wp, st));
+    }
+    // 3. skinning
+    {
+        SkinArgs s;
+        s.offsets = offsets; s.ld_off = Cpad; s.v_shaped = v_shaped; s.v_shaped_batched = v_shaped_batched; s.A = A;
+        s.skin_idx = skin_idx; s.skin_w = skin_w; s.K = skin_k; s.J = J; s.V = V; s.transl = transl; s.verts = verts;
+        dim3 grid((unsigned)ceil_div(V, 256 * 4), (unsigned)batch);
+        hipLaunchKernelGGL(k_skin, grid, dim3(256), J * 12 * sizeof(float), st, s);
+        FK_HIP_LAUNCH(hipGetLastError());
+    }
+    // 4. extra joints + landmarks
+    if (h->d.num_extra + h->d.num_landmarks > 0) {
+        DP_CHECK_ARG((h->d.num_extra == 0 || extra_vertex_ids) && (h->d.num_landmarks == 0 || (lmk_tri && lmk_bary)), "missing landmark tables");
+        ExtraArgs e;
+        e.verts = verts; e.extra_ids = extra_vertex_ids; e.lmk_tri = lmk_tri; e.lmk_bary = lmk_bary; e.joints = joints;
+        e.ld = (int64_t)n_total * 3; e.J = J; e.n_extra = h->d.num_extra; e.n_lmk = h->d.num_landmarks; e.V = V; e.B = batch;
+        const int64_t total = batch * (e.n_extra + e.n_lmk);
+        hipLaunchKernelGGL(k_extra_joints, dim3((unsigned)(ceil_div(total, 256) > 4096 ? 4096 : ceil_div(total, 256))), dim3(256), 0, st, e);
+        FK_HIP_LAUNCH(hipGetLastError());
+    }
+    return DPOSER_OK;
+}

@@ -1,0 +1,213 @@
+// MFMA GEMM core for the score network on gfx950 (CDNA4).
+//
+// Every layer of ScoreModelFC (reference lib/algorithms/advanced/model.py:141-196) and every
+// backward GEMM of its training step is one instance of
+//
+//        D[c][s] = sum_k  Wp[c][k] * X[s][k]          c = output channel, s = sample
+//
+// computed in the "swapped" orientation: the MFMA A operand is the (packed) weight matrix, the
+// B operand is the activation matrix, so that in the 32x32 accumulator tile
+//        lane  = sample (l & 31),   registers = 16 of the 32 channels of ONE GroupNorm group
+//        channel(reg, lane) = 32*tile + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+// GroupNorm statistics (32 contiguous channels per group, model.py:112) therefore reduce over a
+// lane's own registers plus ONE cross-lane exchange with lane^32 -- no LDS, no 32-lane shuffles.
+// Both operands live in HBM in the fragment-tiled layout of common.h, so staging a tile is a
+// stream of coalesced 1-KiB copies and LDS reads are conflict-free ds_read_b128.
+//
+// T = __bf16 : v_mfma_f32_32x32x16_bf16 (fp32 accumulate)       -- throughput mode
+// T = float  : v_mfma_f32_32x32x2_f32   (exact fp32 fma chain)  -- parity mode
+#pragma once
+#include "common.h"
+
+constexpr int GEMM_MAX_SEG = 8;
+
+struct GemmArgs {
+    const void* W;                  // packed weights, FT [Cpad][Ktot]
+    const void* src[GEMM_MAX_SEG];  // activation segments, FT [Spad][Kseg]; concatenated along k
+    int seg_kblocks[GEMM_MAX_SEG];  // k-blocks (of FT<T>::KBS) per segment, multiples of KB
+    int nseg;
+    int ktot_blocks;                // sum of seg_kblocks = k-blocks reduced over
+    int w_stride_blocks;            // k-blocks per packed weight row-block (>= ktot_blocks: a K-prefix may be used)
+    int n_cblk;                     // channel block tiles in the grid
+    int n_sblk;                     // sample block tiles in the grid
+    int ksplit;                     // >1: reduction split over blockIdx.y (wgrad); each split gets
+                                    //     seg_kblocks[0]/ksplit k-blocks of the (single) segment
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+    typedef bf16x8 Frag;
+    __device__ static inline void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x4 Frag;
+    __device__ static inline void run(const Frag& a, const Frag& b, f32x16& c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[i], c, 0, 0, 0);
+    }
+};
+
+// XCD-aware, bijective block remap (guide T1): hardware places block b on XCD b % 8; give each
+// XCD a contiguous run of logical tiles so that tiles sharing a sample panel share an L2.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+template <typename T, int WC, int WS, int TC, int TS, int KB>
+struct GemmCfg {
+    static constexpr int NW = WC * WS;
+    static constexpr int THREADS = NW * 64;
+    static constexpr int CT = WC * TC;   // 32-channel tiles per block
+    static constexpr int ST = WS * TS;   // 32-sample tiles per block
+    static constexpr int BLOCKS_PER_STAGE = (CT + ST) * KB;
+    static constexpr int STAGE_BYTES = BLOCKS_PER_STAGE * 1024;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int LPW_A = CT * KB / NW;   // 1-KiB weight blocks copied per wave per stage
+    static constexpr int LPW_B = ST * KB / NW;   // 1-KiB activation blocks copied per wave per stage
+    static constexpr int LPW = LPW_A + LPW_B;
+    static_assert((CT * KB) % NW == 0 && (ST * KB) % NW == 0, "stage must split evenly over the waves");
+};
+
+// The kernel.  Epi::apply(params, acc, channel_base, sample_base, lane, wave-in-sample-dim ids)
+template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi>
+__global__ void __launch_bounds__(WC* WS * 64) gemm_ft_kernel(GemmArgs g, typename Epi::Params ep) {
+    typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
+    typedef typename Mma<T>::Frag Frag;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wc = wave / WS, ws = wave % WS;
+
+    const int ntiles = g.n_cblk * g.n_sblk;
+    const int L = xcd_remap(blockIdx.x, ntiles);
+    const int cblk = L % g.n_cblk;
+    const int sblk = L / g.n_cblk;
+    const int split = blockIdx.y;
+
+    f32x16 acc[TC][TS];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TS; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- stage bookkeeping -------------------------------------------------------------------
+    // (segment table is only ever indexed through unrolled selects: dynamic indexing of a
+    //  kernel-argument array would push the whole struct to scratch)
+    auto seg_ptr = [&](int i) __attribute__((always_inline)) {
+        const void* p = g.src[0];
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_SEG; ++k) p = (i == k) ? g.src[k] : p;
+        return reinterpret_cast<const unsigned char*>(p);
+    };
+    auto seg_blocks = [&](int i) __attribute__((always_inline)) {
+        int n = g.seg_kblocks[0];
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_SEG; ++k) n = (i == k) ? g.seg_kblocks[k] : n;
+        return n;
+    };
+    int seg = 0, seg_kb = 0;   // position of the NEXT stage to fetch
+    int w_kb = 0;              // weight k-block of the next stage
+    int seg_total = g.seg_kblocks[0];          // k-blocks per row-block of the current segment
+    int seg_end = seg_total;                   // first k-block NOT to fetch from this segment
+    int nstages = g.ktot_blocks / KB;
+    if (g.ksplit > 1) {
+        const int per = seg_total / g.ksplit;
+        nstages = per / KB;
+        seg_kb = split * per;
+        w_kb = seg_kb;
+        seg_end = seg_kb + per;
+    }
+    const unsigned char* sbase = seg_ptr(0);
+
+    u32x4 stg[C::LPW];
+    auto fetch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < C::LPW_A; ++i) {
+            const int blk = wave + i * C::NW;
+            const int rb = blk / KB, kb = blk % KB;
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(g.W) +
+                                     (((int64_t)(cblk * C::CT + rb) * g.w_stride_blocks + w_kb + kb) << 10);
+            stg[i] = *reinterpret_cast<const u32x4*>(p + lane * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < C::LPW_B; ++i) {
+            const int blk = wave + i * C::NW;
+            const int rb = blk / KB, kb = blk % KB;
+            const unsigned char* p = sbase + (((int64_t)(sblk * C::ST + rb) * seg_total + seg_kb + kb) << 10);
+            stg[C::LPW_A + i] = *reinterpret_cast<const u32x4*>(p + lane * 16);
+        }
+        seg_kb += KB;
+        w_kb += KB;
+        if (seg_kb >= seg_end && seg + 1 < g.nseg) {
+            ++seg;
+            seg_kb = 0;
+            seg_total = seg_blocks(seg);
+            seg_end = seg_total;
+            sbase = seg_ptr(seg);
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < C::LPW_A; ++i) {
+            const int blk = wave + i * C::NW;
+            *reinterpret_cast<u32x4*>(smem + buf * C::STAGE_BYTES + (blk << 10) + lane * 16) = stg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < C::LPW_B; ++i) {
+            const int blk = C::CT * KB + wave + i * C::NW;
+            *reinterpret_cast<u32x4*>(smem + buf * C::STAGE_BYTES + (blk << 10) + lane * 16) = stg[C::LPW_A + i];
+        }
+    };
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* a_base = smem + buf * C::STAGE_BYTES + ((wc * TC * KB) << 10) + lane * 16;
+        const unsigned char* b_base = smem + buf * C::STAGE_BYTES + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            Frag a[TC], b[TS];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const Frag*>(a_base + ((i * KB + kb) << 10));
+#pragma unroll
+            for (int j = 0; j < TS; ++j) b[j] = *reinterpret_cast<const Frag*>(b_base + ((j * KB + kb) << 10));
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TS; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+        }
+    };
+
+    // ---- software pipeline: global -> regs (next stage) overlaps MFMA on the current stage -----
+    fetch();
+    commit(0);
+    __syncthreads();
+    for (int t = 0; t < nstages; ++t) {
+        const bool more = (t + 1 < nstages);
+        if (more) fetch();
+        compute(t & 1);
+        if (more) commit((t + 1) & 1);
+        __syncthreads();
+    }
+
+    Epi::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
+                                sblk * WS + ws, split);
+}
+
+template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi>
+static inline hipError_t launch_gemm(const GemmArgs& g, const typename Epi::Params& ep, hipStream_t stream) {
+    typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
+    auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi>;
+    static bool attr_set = false;
+    if (!attr_set && C::LDS_BYTES > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    dim3 grid(g.n_cblk * g.n_sblk, g.ksplit > 1 ? g.ksplit : 1, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), C::LDS_BYTES, stream, g, ep);
+    return hipGetLastError();
+}

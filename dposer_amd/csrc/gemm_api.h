@@ -1,0 +1,27 @@
+// Non-template entry points of the MFMA GEMM family (instantiated in gemm_launch.hip).
+#pragma once
+#include "epilogues.h"
+#include "gemm.h"
+
+// Workgroup tilings (channels x samples), all with K-stage depth KB = 4 FT blocks:
+enum GemmShape : int {
+    SHAPE_BIG = 0,      // 256 x 256, 8 waves (2x4), wave tile 128 x 64    -- large batches
+    SHAPE_MID = 1,      // 128 x 128, 4 waves (2x2), wave tile  64 x 64
+    SHAPE_SMALL = 2,    // 128 x  32, 4 waves (4x1), wave tile  32 x 32    -- small batches
+    SHAPE_FINAL = 3,    //  64 x 128, 4 waves (1x4), wave tile  64 x 32    -- post_dense (N = 63 -> 64)
+    SHAPE_FINAL_S = 4,  //  64 x  32, 2 waves (2x1), wave tile  32 x 32
+    SHAPE_WIDE64 = 5,   // 128 x  64, 4 waves (2x2), wave tile  64 x 32    -- wgrad of pre_dense (K = 63 -> 64)
+};
+static inline int shape_ct(int s) { static const int v[] = {8, 4, 4, 2, 2, 4}; return v[s]; }   // 32-channel tiles / block
+static inline int shape_st(int s) { static const int v[] = {8, 4, 1, 4, 1, 2}; return v[s]; }   // 32-sample tiles / block
+static inline int shape_ws(int s) { static const int v[] = {4, 2, 1, 4, 1, 2}; return v[s]; }   // waves along samples
+
+enum : int { PREC_BF16 = 0, PREC_FP32 = 1 };
+
+hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st);
+hipError_t gemm_bias_silu(int prec, bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st);
+hipError_t gemm_rowmajor(int prec, int shape, const GemmArgs& g, const RowMajorParams& p, hipStream_t st);
+hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTParams& p, hipStream_t st);
+hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st);
+hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st);
+hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st);

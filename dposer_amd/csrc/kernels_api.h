@@ -1,0 +1,193 @@
+// Elementwise / layout / optimizer kernels of the score path (implemented in elementwise.hip).
+#pragma once
+#include "common.h"
+#include "gemm_api.h"
+
+// ---- weight packing -----------------------------------------------------------------------------
+struct PackJob {
+    int64_t dst_off;      // byte offset inside the packed workspace
+    int64_t src_off;      // element offset inside the flat fp32 parameter buffer
+    int ktot;             // columns of the destination FT matrix
+    int koff;             // first destination column written by this job
+    int rows_pad, kpad;   // extent written (multiples of 32 / KBS), zero-filled outside the source
+    int rows_valid, cols_valid, ld;
+    int trans;            // 0: dst[r][koff+k] = src[r*ld + k]     1: dst[r][koff+k] = src[k*ld + r]
+    int f32;              // destination element type: 1 fp32, 0 bf16
+};
+constexpr int MAX_PACK_JOBS = 40;
+struct PackJobs {
+    PackJob job[MAX_PACK_JOBS];
+    int n;
+};
+hipError_t launch_pack(const PackJobs& jobs, const float* flat, void* packed, hipStream_t st);
+// dst[i] = flat[a_off[i/H] + i%H] + flat[b_off[..]]
+struct BiasCatJobs {
+    int64_t a_off[8], b_off[8];
+    int n, H;
+};
+hipError_t launch_bias_cat(const BiasCatJobs& j, const float* flat, float* dst, hipStream_t st);
+
+// ---- SDE description (reference lib/algorithms/advanced/sde_lib.py) --------------------------------
+enum : int { SDE_SUBVP = 0, SDE_VP = 1 };
+struct SdeCfg {
+    int kind;
+    float beta_0, beta_1;
+    int N;
+    float T;
+};
+
+// ---- input preparation ---------------------------------------------------------------------------
+struct PrepArgs {
+    const float* x;        // [B][D] fp32 row-major
+    const float* labels;   // [B] (per-sample t path) or null
+    const float* freq;     // [E/2] positional frequencies, or fourier W
+    void* xin;             // FT [Bpad][Dpad]
+    void* emb;             // FT [Bpad][E] or null
+    int64_t B, Bpad;
+    int D, Dpad, E;
+    int fourier;
+    int f32;
+};
+hipError_t launch_prep_infer(const PrepArgs& a, hipStream_t st);
+
+struct PrepTrainArgs {
+    const float* x0;       // [B][D] clean (normalised) poses
+    const float* t_in;     // [B] injected t or null (-> Philox STREAM_TRAIN_T)
+    const float* z_in;     // [B][D] injected z or null (-> Philox STREAM_TRAIN_Z)
+    const float* freq;
+    void* xin;             // FT [Bpad][Dpad]  perturbed data
+    void* emb;             // FT [Bpad][E]
+    float* t_out;          // [Bpad]
+    float* z_out;          // [Bpad][Dpad] fp32 row-major
+    int64_t B, Bpad;
+    int D, Dpad, E;
+    int fourier, f32;
+    SdeCfg sde;
+    float eps;             // smallest t (1e-5)
+    uint64_t seed;
+    uint32_t step;
+};
+hipError_t launch_prep_train(const PrepTrainArgs& a, hipStream_t st);
+
+// time embedding rows for a list of labels (labels == null: every row uses label0): emb FT32 [Npad][E]
+hipError_t launch_time_embed(const float* labels, float label0, int64_t n, int64_t npad, const float* freq, int E, int fourier, float* emb_ft32, hipStream_t st);
+
+// ---- output stages ---------------------------------------------------------------------------------
+struct OutModelArgs {      // ScoreModelFC.forward tail: res / used_sigmas   (model.py:189-196)
+    const float* res;      // [Bpad][Cp]
+    const float* labels;   // [B]
+    const float* sigmas;   // [num_scales]
+    float* out;            // [B][D]
+    int64_t B;
+    int D, Cp, num_scales;
+    int scale_by_sigma, fourier;
+};
+hipError_t launch_out_model(const OutModelArgs& a, hipStream_t st);
+
+struct EmUpdateArgs {      // EulerMaruyamaPredictor.update_fn + imputation (sampling.py:182-188, 416-420)
+    const float* res;      // [Bpad][Cp] post_dense output of this step (null: no predictor step, only impute A + pack)
+    float* x;              // [B][D] state, updated in place
+    float* x_mean;         // [B][D]
+    void* xin;             // FT [Bpad][Dpad]: next step's network input
+    float* traj;           // [B][D] slot for this step or null
+    const float* sigmas;
+    const float* obs;      // completion: observation [B][D] or null
+    const float* mask;     // completion: mask [B][D]
+    const float* z_pred;   // injected predictor noise [B][D] or null (-> Philox)
+    const float* z_impB;   // injected imputation noise after the predictor, or null
+    const float* z_impA;   // injected imputation noise before the NEXT predictor step, or null
+    float t, t_next;       // current / next timestep (t_next < 0: last step, no look-ahead imputation)
+    int64_t B, Bpad;
+    int D, Dpad, Cp, num_scales;
+    int f32;
+    int scale_by_sigma;
+    SdeCfg sde;
+    uint64_t seed;
+    uint32_t step;
+};
+hipError_t launch_em_update(const EmUpdateArgs& a, hipStream_t st);
+
+struct DenoiseArgs {       // one_step_denoise + prior loss (run/completion.py:105-149, run/smplify.py:69-107)
+    const float* res;      // [Bpad][Cp]
+    const float* x0;       // [B][D]
+    const float* xt;       // [B][Dpad] perturbed data (fp32 row-major)
+    const float* sigmas;
+    float* x0_hat;         // [B][D] or null
+    float* grad;           // [B][D] d loss / d x0 (analytic, x0_hat detached) or null
+    float* loss_part;      // per-block partial sums
+    float t;
+    float inv_n;           // 1/n of the reduction (mean: 1/(B*D), sum/batch: 1/B)
+    int weighted;
+    int64_t B;
+    int D, Dpad, Cp, num_scales, scale_by_sigma;
+    SdeCfg sde;
+};
+hipError_t launch_denoise(const DenoiseArgs& a, int* nblocks, hipStream_t st);
+
+struct PerturbSharedArgs { // x_t = mean + std*z at one shared t; writes xin (FT) and xt (fp32)
+    const float* x0;
+    const float* z_in;     // injected or null (-> Philox STREAM_PRIOR)
+    void* xin;
+    float* xt;             // [Bpad][Dpad]
+    float t;
+    int64_t B, Bpad;
+    int D, Dpad, f32;
+    SdeCfg sde;
+    uint64_t seed;
+    uint32_t step;
+};
+hipError_t launch_perturb_shared(const PerturbSharedArgs& a, hipStream_t st);
+
+struct DsmArgs {           // get_sde_loss_fn tail (losses.py:121-131) + d loss / d res
+    const float* res;      // [Bpad][Cp]
+    const float* t;        // [Bpad]
+    const float* z;        // [Bpad][Dpad]
+    const float* sigmas;
+    void* dres;            // FT [Bpad][Cp]
+    float* loss_part;      // per-block partial sums of the (already normalised) loss
+    int64_t B, Bpad;
+    int D, Dpad, Cp, num_scales, scale_by_sigma, f32, fourier;
+    float grad_scale;      // 1/(B*D) for reduce_mean
+    SdeCfg sde;
+};
+hipError_t launch_dsm(const DsmArgs& a, int* nblocks, hipStream_t st);
+
+// ---- layout helpers ---------------------------------------------------------------------------------
+// out FT [Cpad][Spad] = transpose of in FT [Spad][C]
+hipError_t launch_ft_transpose(int f32, const void* in, void* out, int64_t Spad, int C, hipStream_t st);
+// part[chunk][c] = sum over the chunk's samples of in[s][c];  returns number of chunks
+hipError_t launch_colsum(int f32, const void* in, float* part, int64_t Spad, int C, int* nchunks, hipStream_t st);
+
+// ---- gradient finalisation and optimizer --------------------------------------------------------------
+struct ReduceJob {
+    int64_t dst_off;       // element offset in the flat gradient
+    int64_t count;
+    int64_t src_off;       // element offset in the scratch buffer
+    int64_t src_stride;
+    int nsrc;
+};
+constexpr int MAX_REDUCE_JOBS = 48;
+struct ReduceJobs {
+    ReduceJob job[MAX_REDUCE_JOBS];
+    int n;
+};
+hipError_t launch_reduce_grads(const ReduceJobs& jobs, const float* scratch, float* flat_grad, hipStream_t st);
+hipError_t launch_sum_partials(const float* part, int n, float* out, hipStream_t st);             // out[0] = sum(part[0..n))
+hipError_t launch_sqnorm(const float* g, int64_t n, float* part, int* nblocks, hipStream_t st);   // partial sums of g^2
+
+struct AdamArgs {          // losses.py:44-58 optimize_fn + torch.optim.Adam + ema.py:32-51, one pass
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    float* ema;            // may be null
+    int64_t n;
+    int64_t skip_lo[2], skip_hi[2];   // parameter ranges without gradient (Adam skipped, EMA still applied)
+    const float* sqnorm;   // device scalar: sum of g^2 over the whole flat gradient (before grad_scale)
+    float grad_scale;      // applied to g before anything else (1/world_size)
+    float grad_clip;       // < 0: disabled
+    float lr, beta1, beta2, eps;
+    float bc1, bc2_sqrt;   // 1 - beta1^t, sqrt(1 - beta2^t)
+    float ema_one_minus_decay;
+};
+hipError_t launch_adam_ema(const AdamArgs& a, hipStream_t st);

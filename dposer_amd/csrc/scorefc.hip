@@ -1,0 +1,726 @@
+// Host orchestration of the score network on MI355X + the C ABI of include/dposer_hip.h.
+//
+// A ScoreModelFC evaluation (reference lib/algorithms/advanced/model.py:141-196) is 2 + L GEMM
+// launches with fused epilogues (L = 1 + 2*n_blocks GroupNorm layers):
+//   per-sample t : emb -> [GEMM bias+SiLU] temb -> L x [GEMM K-concat(h, temb) + GN + SiLU (+residual)]
+//                  -> [GEMM post_dense] -> elementwise tail
+//   shared t     : the whole time branch collapses into a per-step bias row (table built once
+//                  for all N steps with two fp32 GEMMs), the L layer GEMMs run on the x-path only.
+// Training adds the mirrored dgrad chain (GroupNorm/SiLU/dropout backward fused into the dgrad
+// epilogue), split-K wgrad GEMMs over transposed fragment-tiled copies, and a deterministic
+// slab reduction into the flat gradient.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dposer_hip.h"
+#include "gemm_api.h"
+#include "kernels_api.h"
+
+static thread_local std::string g_last_error;
+int dposer_set_error(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+extern "C" const char* dposer_last_error(void) { return g_last_error.c_str(); }
+extern "C" int dposer_abi_version(void) { return DPOSER_ABI_VERSION; }
+
+#define DP_HIP_LAUNCH(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return dposer_set_error(DPOSER_ERR_HIP, std::string(__func__) + ": " + #expr + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+constexpr int MAX_L = 7;
+
+struct LayerOff {
+    int64_t w, b, wt, bt, gamma, beta;   // flat offsets (elements)
+    int kin, kin_pad;
+};
+
+struct dposer_scorefc_s {
+    dposer_scorefc_desc d;
+    int D, Dpad, H, E, L, Cp;
+    bool f32;
+    int esz, KBS;
+    std::vector<int64_t> toff, tnum;
+    LayerOff layer[MAX_L];
+    int64_t off_cond_w, off_cond_b, off_gauss, off_se_w, off_se_b, off_post_w, off_post_b;
+    int64_t nparams;
+    int64_t nograd_lo[2], nograd_hi[2];
+    int n_nograd;
+    // packed workspace (byte offsets)
+    int64_t pk_wse, pk_wl[MAX_L], pk_wpost, pk_bias_cat, pk_wt_all32, pk_wse32, pk_fwd_end;
+    int64_t pk_wpostT, pk_wlT[MAX_L], pk_wtT_all, pk_bwd_end;
+    PackJobs fwd_jobs, bwd_jobs;
+    BiasCatJobs bias_jobs;
+    std::vector<float> host_stage;   // staging for small H2D copies (labels)
+};
+
+static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+static PackJob mk_job(int64_t dst_off, int64_t src_off, int ktot, int koff, int rows_pad, int kpad, int rows_valid, int cols_valid,
+                      int ld, int trans, int f32) {
+    PackJob j;
+    j.dst_off = dst_off; j.src_off = src_off; j.ktot = ktot; j.koff = koff; j.rows_pad = rows_pad; j.kpad = kpad;
+    j.rows_valid = rows_valid; j.cols_valid = cols_valid; j.ld = ld; j.trans = trans; j.f32 = f32;
+    return j;
+}
+
+extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_scorefc_t* out) {
+    DP_CHECK_ARG(desc && out, "null argument");
+    DP_CHECK_ARG(desc->hidden_dim > 0 && desc->hidden_dim % 1024 == 0,
+                 "hidden_dim must be a multiple of 1024 (GroupNorm(32, H) with 32-channel groups is what the MFMA epilogue fuses)");
+    DP_CHECK_ARG(desc->embed_dim > 0 && desc->embed_dim % 128 == 0, "embed_dim must be a multiple of 128");
+    DP_CHECK_ARG(desc->n_blocks >= 1 && desc->n_blocks <= 3, "n_blocks must be 1..3");
+    DP_CHECK_ARG(desc->data_dim > 0 && desc->data_dim <= 256, "data_dim must be in 1..256");
+    DP_CHECK_ARG(desc->precision == DPOSER_PREC_BF16 || desc->precision == DPOSER_PREC_FP32, "bad precision");
+    DP_CHECK_ARG(desc->dropout_p >= 0.f && desc->dropout_p < 1.f, "dropout_p must be in [0,1)");
+    auto* h = new dposer_scorefc_s();
+    h->d = *desc;
+    h->D = desc->data_dim;
+    h->Dpad = (int)round_up(h->D, 64);
+    h->Cp = h->Dpad;
+    h->H = desc->hidden_dim;
+    h->E = desc->embed_dim;
+    h->L = 1 + 2 * desc->n_blocks;
+    h->f32 = desc->precision == DPOSER_PREC_FP32;
+    h->esz = h->f32 ? 4 : 2;
+    h->KBS = h->f32 ? 8 : 16;
+    const int D = h->D, H = h->H, E = h->E, L = h->L;
+
+    // ---- flat parameter layout = ScoreModelFC.parameters() order (model.py:98-139) ----------------
+    int64_t off = 0;
+    auto add = [&](int64_t n) { int64_t o = off; h->toff.push_back(o); h->tnum.push_back(n); off += n; return o; };
+    h->layer[0].w = add((int64_t)H * D); h->layer[0].b = add(H);
+    h->layer[0].wt = add((int64_t)H * E); h->layer[0].bt = add(H);
+    h->off_cond_w = add((int64_t)H * H); h->off_cond_b = add(H);
+    h->layer[0].gamma = add(H); h->layer[0].beta = add(H);
+    h->layer[0].kin = D; h->layer[0].kin_pad = h->Dpad;
+    h->off_gauss = -1;
+    if (desc->embedding == DPOSER_EMB_FOURIER) h->off_gauss = add(E / 2);
+    h->off_se_w = add((int64_t)E * E); h->off_se_b = add(E);
+    for (int l = 1; l < L; ++l) {
+        h->layer[l].w = add((int64_t)H * H); h->layer[l].b = add(H);
+        h->layer[l].wt = add((int64_t)H * E); h->layer[l].bt = add(H);
+        h->layer[l].gamma = add(H); h->layer[l].beta = add(H);
+        h->layer[l].kin = H; h->layer[l].kin_pad = H;
+    }
+    h->off_post_w = add((int64_t)D * H); h->off_post_b = add(D);
+    h->nparams = off;
+    h->n_nograd = 1;
+    h->nograd_lo[0] = h->off_cond_w; h->nograd_hi[0] = h->off_cond_b + H;       // pre_dense_cond: unused in forward (model.py:111)
+    h->nograd_lo[1] = h->nograd_hi[1] = 0;
+    if (h->off_gauss >= 0) { h->nograd_lo[1] = h->off_gauss; h->nograd_hi[1] = h->off_gauss + E / 2; h->n_nograd = 2; }
+
+    // ---- packed workspace ----------------------------------------------------------------------------
+    const int esz = h->esz, f = h->f32 ? 1 : 0;
+    int64_t p = 0;
+    h->fwd_jobs.n = 0;
+    auto push = [&](PackJobs& js, const PackJob& j) { js.job[js.n++] = j; };
+    h->pk_wse = p; p = align256(p + (int64_t)E * E * esz);
+    push(h->fwd_jobs, mk_job(h->pk_wse, h->off_se_w, E, 0, E, E, E, E, E, 0, f));
+    for (int l = 0; l < L; ++l) {
+        const LayerOff& lo = h->layer[l];
+        const int ktot = lo.kin_pad + E;
+        h->pk_wl[l] = p; p = align256(p + (int64_t)H * ktot * esz);
+        push(h->fwd_jobs, mk_job(h->pk_wl[l], lo.w, ktot, 0, H, lo.kin_pad, H, lo.kin, lo.kin, 0, f));
+        push(h->fwd_jobs, mk_job(h->pk_wl[l], lo.wt, ktot, lo.kin_pad, H, E, H, E, E, 0, f));
+    }
+    h->pk_wpost = p; p = align256(p + (int64_t)h->Cp * H * esz);
+    push(h->fwd_jobs, mk_job(h->pk_wpost, h->off_post_w, H, 0, h->Cp, H, D, H, H, 0, f));
+    h->pk_bias_cat = p; p = align256(p + (int64_t)L * H * 4);
+    h->bias_jobs.n = L; h->bias_jobs.H = H;
+    for (int l = 0; l < L; ++l) { h->bias_jobs.a_off[l] = h->layer[l].b; h->bias_jobs.b_off[l] = h->layer[l].bt; }
+    h->pk_wt_all32 = p; p = align256(p + (int64_t)L * H * E * 4);
+    for (int l = 0; l < L; ++l)
+        push(h->fwd_jobs, mk_job(h->pk_wt_all32 + (int64_t)l * H * E * 4, h->layer[l].wt, E, 0, H, E, H, E, E, 0, 1));
+    if (h->f32) h->pk_wse32 = h->pk_wse;
+    else {
+        h->pk_wse32 = p; p = align256(p + (int64_t)E * E * 4);
+        push(h->fwd_jobs, mk_job(h->pk_wse32, h->off_se_w, E, 0, E, E, E, E, E, 0, 1));
+    }
+    h->pk_fwd_end = p;
+    // backward: transposed copies (dgrad computes dX = dY @ W, i.e. "weights" = W^T)
+    h->bwd_jobs.n = 0;
+    h->pk_wpostT = p; p = align256(p + (int64_t)H * h->Cp * esz);
+    push(h->bwd_jobs, mk_job(h->pk_wpostT, h->off_post_w, h->Cp, 0, H, h->Cp, H, D, H, 1, f));
+    for (int l = 0; l < L; ++l) {
+        const LayerOff& lo = h->layer[l];
+        h->pk_wlT[l] = p; p = align256(p + (int64_t)lo.kin_pad * H * esz);
+        push(h->bwd_jobs, mk_job(h->pk_wlT[l], lo.w, H, 0, lo.kin_pad, H, lo.kin, H, lo.kin, 1, f));
+    }
+    h->pk_wtT_all = p; p = align256(p + (int64_t)E * L * H * esz);
+    for (int l = 0; l < L; ++l)
+        push(h->bwd_jobs, mk_job(h->pk_wtT_all, h->layer[l].wt, L * H, l * H, E, H, E, H, E, 1, f));
+    h->pk_bwd_end = p;
+    *out = h;
+    return DPOSER_OK;
+}
+
+extern "C" void dposer_scorefc_destroy(dposer_scorefc_t h) { delete h; }
+extern "C" int64_t dposer_scorefc_num_params(dposer_scorefc_t h) { return h ? h->nparams : -1; }
+extern "C" int32_t dposer_scorefc_num_tensors(dposer_scorefc_t h) { return h ? (int32_t)h->toff.size() : -1; }
+extern "C" int64_t dposer_scorefc_tensor_offset(dposer_scorefc_t h, int32_t i) { return (h && i >= 0 && i < (int)h->toff.size()) ? h->toff[i] : -1; }
+extern "C" int64_t dposer_scorefc_tensor_numel(dposer_scorefc_t h, int32_t i) { return (h && i >= 0 && i < (int)h->tnum.size()) ? h->tnum[i] : -1; }
+extern "C" int32_t dposer_scorefc_nograd_ranges(dposer_scorefc_t h, int64_t lo[2], int64_t hi[2]) {
+    if (!h) return -1;
+    for (int i = 0; i < 2; ++i) { lo[i] = h->nograd_lo[i]; hi[i] = h->nograd_hi[i]; }
+    return h->n_nograd;
+}
+extern "C" int64_t dposer_scorefc_packed_bytes(dposer_scorefc_t h, int32_t with_backward) {
+    if (!h) return -1;
+    return with_backward ? h->pk_bwd_end : h->pk_fwd_end;
+}
+
+extern "C" int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat, void* packed, int32_t with_backward, void* stream) {
+    DP_CHECK_ARG(h && flat && packed, "null argument");
+    DP_CHECK_ARG(((uintptr_t)flat & 15) == 0 && ((uintptr_t)packed & 255) == 0, "flat_params must be 16-B aligned, packed 256-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    DP_HIP_LAUNCH(launch_pack(h->fwd_jobs, flat, packed, st));
+    DP_HIP_LAUNCH(launch_bias_cat(h->bias_jobs, flat, reinterpret_cast<float*>((char*)packed + h->pk_bias_cat), st));
+    if (with_backward) DP_HIP_LAUNCH(launch_pack(h->bwd_jobs, flat, packed, st));
+    return DPOSER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout
+// ------------------------------------------------------------------------------------------------
+static int64_t pad_batch(int64_t B) { return B <= 512 ? round_up(B, 64) : round_up(B, 256); }
+static int main_shape(int64_t Spad) {
+    if (Spad % 256 == 0 && Spad >= 4096) return SHAPE_BIG;
+    if (Spad % 128 == 0) return SHAPE_MID;
+    return SHAPE_SMALL;
+}
+static int gnbwd_shape(int64_t Spad) { return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL; }
+static int final_shape(int64_t Spad) { return Spad % 128 == 0 ? SHAPE_FINAL : SHAPE_FINAL_S; }
+
+struct Ws {
+    int64_t Bpad;
+    char *xin, *emb, *temb, *upre, *hbuf[MAX_L], *xhat[MAX_L], *dy[MAX_L], *carry[2], *dU, *dres;
+    float *rstd[MAX_L], *res, *xt, *tbuf, *zbuf, *loss_part, *scalar;
+    // shared-t time table
+    int64_t npad;
+    float *tt_labels, *tt_emb, *tt_temb, *table;
+    // transposed copies / partials / slabs (training)
+    char *dyT, *inT, *tembT, *embT, *xinT, *dresT, *dUT;
+    float *gn_part[MAX_L], *cs_part_post, *cs_part_se, *slabs;
+    int64_t total;
+};
+
+struct WgradPlan {
+    int shape, ksplit;
+    int64_t slab_off;   // element offset inside Ws::slabs
+};
+static int pick_ksplit(int64_t tiles, int64_t stages) {
+    int ks = 1;
+    while (ks < 32 && tiles * ks < 512 && stages % (ks * 2) == 0 && stages / (ks * 2) >= 4) ks *= 2;
+    return ks;
+}
+
+static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_steps, char* base, Ws& w) {
+    std::memset(&w, 0, sizeof(w));
+    const int64_t Bpad = pad_batch(B);
+    w.Bpad = Bpad;
+    const int esz = h->esz, H = h->H, E = h->E, L = h->L;
+    int64_t p = 0;
+    auto take = [&](int64_t bytes) { char* r = base + p; p = align256(p + bytes); return r; };
+    w.xin = take(Bpad * h->Dpad * esz);
+    w.res = (float*)take(Bpad * h->Cp * 4);
+    w.loss_part = (float*)take(8192 * 4);
+    w.scalar = (float*)take(256);
+    if (mode == DPOSER_WS_INFER) {
+        w.emb = take(Bpad * E * esz);
+        w.temb = take(Bpad * E * esz);
+        for (int i = 0; i < 3; ++i) w.hbuf[i] = take(Bpad * H * esz);
+    } else if (mode == DPOSER_WS_SHARED_T) {
+        for (int i = 0; i < 3; ++i) w.hbuf[i] = take(Bpad * H * esz);
+        w.xt = (float*)take(Bpad * h->Dpad * 4);
+        w.npad = round_up(n_steps < 1 ? 1 : n_steps, 32);
+        w.tt_labels = (float*)take(w.npad * 4);
+        w.tt_emb = (float*)take(w.npad * E * 4);
+        w.tt_temb = (float*)take(w.npad * E * 4);
+        w.table = (float*)take(w.npad * (int64_t)L * H * 4);
+    } else {
+        w.emb = take(Bpad * E * esz);
+        w.temb = take(Bpad * E * esz);
+        w.upre = take(Bpad * E * esz);
+        for (int l = 0; l < L; ++l) {
+            w.hbuf[l] = take(Bpad * H * esz);
+            w.xhat[l] = take(Bpad * H * esz);
+            w.dy[l] = take(Bpad * H * esz);
+            w.rstd[l] = (float*)take(Bpad * (H / 32) * 4);
+            w.gn_part[l] = (float*)take((Bpad / 32) * 3 * (int64_t)H * 4);
+        }
+        w.carry[0] = take(Bpad * H * esz);
+        w.carry[1] = take(Bpad * H * esz);
+        w.dU = take(Bpad * E * esz);
+        w.dres = take(Bpad * h->Cp * esz);
+        w.tbuf = (float*)take(Bpad * 4);
+        w.zbuf = (float*)take(Bpad * h->Dpad * 4);
+        w.dyT = take(Bpad * H * esz);
+        w.inT = take(Bpad * H * esz);
+        w.tembT = take(Bpad * E * esz);
+        w.embT = take(Bpad * E * esz);
+        w.xinT = take(Bpad * h->Dpad * esz);
+        w.dresT = take(Bpad * h->Cp * esz);
+        w.dUT = take(Bpad * E * esz);
+        const int64_t nchunks = ceil_div(Bpad, 2048);
+        w.cs_part_post = (float*)take(nchunks * h->Cp * 4);
+        w.cs_part_se = (float*)take(nchunks * E * 4);
+        // slabs: worst case ksplit 32 is never reached for the big tensors; size exactly below
+        const int64_t stages = Bpad / (h->KBS * 4);
+        int64_t slab_elems = 0;
+        auto acc = [&](int64_t n_rows_pad, int64_t k_cols_pad, int ct, int st, int64_t numel) {
+            const int64_t tiles = (n_rows_pad / (ct * 32)) * (k_cols_pad / (st * 32));
+            slab_elems += (int64_t)pick_ksplit(tiles, stages) * numel;
+        };
+        for (int l = 0; l < L; ++l) {
+            const bool wide = h->layer[l].kin_pad == 64;
+            acc(H, h->layer[l].kin_pad, 4, wide ? 2 : 4, (int64_t)H * h->layer[l].kin);
+            acc(H, E, 4, 4, (int64_t)H * E);
+        }
+        acc(h->Cp, H, 2, 4, (int64_t)h->D * H);
+        acc(E, E, 4, 4, (int64_t)E * E);
+        w.slabs = (float*)take(slab_elems * 4);
+    }
+    w.total = p;
+}
+
+extern "C" int64_t dposer_scorefc_workspace_bytes(dposer_scorefc_t h, int64_t batch, int32_t mode, int32_t n_steps) {
+    if (!h || batch <= 0) return -1;
+    Ws w;
+    layout_ws(h, batch, mode, n_steps, nullptr, w);
+    return w.total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM launch helpers
+// ------------------------------------------------------------------------------------------------
+static GemmArgs gemm_args(const void* W, int w_stride_blocks, int n_cblk, int n_sblk) {
+    GemmArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.W = W;
+    g.w_stride_blocks = w_stride_blocks;
+    g.n_cblk = n_cblk;
+    g.n_sblk = n_sblk;
+    g.ksplit = 1;
+    return g;
+}
+static void add_seg(GemmArgs& g, const void* src, int kblocks) {
+    g.src[g.nseg] = src;
+    g.seg_kblocks[g.nseg] = kblocks;
+    g.nseg++;
+    g.ktot_blocks += kblocks;
+}
+
+static DropoutCfg drop_cfg(const dposer_scorefc_s* h, bool train, int site, uint64_t seed, uint32_t step) {
+    DropoutCfg d;
+    std::memset(&d, 0, sizeof(d));
+    if (train && h->d.dropout_p > 0.f) {
+        d.p = h->d.dropout_p;
+        d.scale = 1.0f / (1.0f - d.p);
+        d.thr = (uint32_t)((1.0 - (double)d.p) * 65536.0);
+        d.site = site;
+        d.offset = step;
+        d.seed = seed;
+        d.groups_x4 = h->H / 8;
+    }
+    return d;
+}
+
+// One GroupNorm layer.  per_sample_t: K-concat(h, temb) with packed bias_cat; else x-path only with
+// `bias_row` (time-table row of this step and layer).
+static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* packed, int l, const void* in, const void* temb,
+                        const float* bias_row, void* out, const void* resid, void* xhat, float* rstd, bool train,
+                        int64_t Bpad, uint64_t seed, uint32_t step, hipStream_t st) {
+    const int shape = main_shape(Bpad);
+    const LayerOff& lo = h->layer[l];
+    const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
+    GemmArgs g = gemm_args(packed + h->pk_wl[l], kx + ke, h->H / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
+    add_seg(g, in, kx);
+    if (temb) add_seg(g, temb, ke);
+    GNParams p;
+    p.bias = temb ? reinterpret_cast<const float*>(packed + h->pk_bias_cat) + (int64_t)l * h->H : bias_row;
+    p.gamma = flat + lo.gamma;
+    p.beta = flat + lo.beta;
+    p.out = out;
+    p.resid = resid;
+    p.xhat = xhat;
+    p.rstd = rstd;
+    p.H = h->H;
+    p.drop = drop_cfg(h, train, l, seed, step);
+    DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, train, shape, g, p, st));
+    return DPOSER_OK;
+}
+
+static int run_post(dposer_scorefc_s* h, const float* flat, const char* packed, const void* in, float* res, int64_t B, int64_t Bpad, hipStream_t st) {
+    const int shape = final_shape(Bpad);
+    GemmArgs g = gemm_args(packed + h->pk_wpost, h->H / h->KBS, h->Cp / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
+    add_seg(g, in, h->H / h->KBS);
+    RowMajorParams p;
+    p.bias = flat + h->off_post_b;
+    p.out = res;
+    p.ldc = h->Cp;
+    p.C_valid = h->D;
+    p.S_valid = Bpad;     // padded rows are written too (finite, never read back as samples)
+    (void)B;
+    DP_HIP_LAUNCH(gemm_rowmajor(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
+    return DPOSER_OK;
+}
+
+static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, const void* emb, void* temb, void* upre, bool train,
+                    int64_t Bpad, hipStream_t st) {
+    const int shape = main_shape(Bpad);
+    GemmArgs g = gemm_args(packed + h->pk_wse, h->E / h->KBS, h->E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
+    add_seg(g, emb, h->E / h->KBS);
+    BiasSiLUParams p;
+    p.bias = flat + h->off_se_b;
+    p.out = temb;
+    p.pre = upre;
+    p.N = h->E;
+    DP_HIP_LAUNCH(gemm_bias_silu(h->f32 ? PREC_FP32 : PREC_BF16, train, shape, g, p, st));
+    return DPOSER_OK;
+}
+
+static int check_common(dposer_scorefc_t h, const float* flat, const void* packed, void* ws, int64_t batch) {
+    DP_CHECK_ARG(h && flat && packed && ws, "null argument");
+    DP_CHECK_ARG(batch > 0, "batch must be positive");
+    DP_CHECK_ARG(((uintptr_t)flat & 15) == 0, "flat_params must be 16-byte aligned");
+    DP_CHECK_ARG(((uintptr_t)packed & 255) == 0 && ((uintptr_t)ws & 255) == 0, "packed / workspace must be 256-byte aligned");
+    return DPOSER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ScoreModelFC.forward
+// ------------------------------------------------------------------------------------------------
+extern "C" int dposer_scorefc_forward(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const float* x,
+                                      const float* labels, const float* freq, const float* sigmas, float* out, int64_t B,
+                                      void* stream) {
+    DP_TRY(check_common(h, flat, packed_, ws_, B));
+    DP_CHECK_ARG(x && labels && freq && sigmas && out, "null tensor argument");
+    hipStream_t st = (hipStream_t)stream;
+    const char* packed = (const char*)packed_;
+    Ws w;
+    layout_ws(h, B, DPOSER_WS_INFER, 0, (char*)ws_, w);
+    PrepArgs pa;
+    pa.x = x; pa.labels = labels; pa.freq = freq; pa.xin = w.xin; pa.emb = w.emb;
+    pa.B = B; pa.Bpad = w.Bpad; pa.D = h->D; pa.Dpad = h->Dpad; pa.E = h->E;
+    pa.fourier = h->d.embedding == DPOSER_EMB_FOURIER; pa.f32 = h->f32;
+    DP_HIP_LAUNCH(launch_prep_infer(pa, st));
+    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, nullptr, false, w.Bpad, st));
+    const void* in = w.xin;
+    for (int l = 0; l < h->L; ++l) {
+        void* o = w.hbuf[l % 3];
+        const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[(l - 2) % 3] : nullptr;
+        DP_TRY(run_gn_layer(h, flat, packed, l, in, w.temb, nullptr, o, resid, nullptr, nullptr, false, w.Bpad, 0, 0, st));
+        in = o;
+    }
+    DP_TRY(run_post(h, flat, packed, in, w.res, B, w.Bpad, st));
+    OutModelArgs oa;
+    oa.res = w.res; oa.labels = labels; oa.sigmas = sigmas; oa.out = out; oa.B = B; oa.D = h->D; oa.Cp = h->Cp;
+    oa.num_scales = h->d.num_scales; oa.scale_by_sigma = h->d.scale_by_sigma; oa.fourier = pa.fourier;
+    DP_HIP_LAUNCH(launch_out_model(oa, st));
+    return DPOSER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared-t machinery: time-bias table for a list of labels
+// ------------------------------------------------------------------------------------------------
+static int build_time_table(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, const float* labels_dev, float label0,
+                            int64_t n, const float* freq, hipStream_t st) {
+    const int E = h->E, H = h->H, L = h->L;
+    const int64_t npad = round_up(n, 32);
+    DP_HIP_LAUNCH(launch_time_embed(labels_dev, label0, n, npad, freq, E, h->d.embedding == DPOSER_EMB_FOURIER, w.tt_emb, st));
+    const int shape = npad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL;
+    {
+        GemmArgs g = gemm_args(packed + h->pk_wse32, E / 8, E / (shape_ct(shape) * 32), (int)(npad / (shape_st(shape) * 32)));
+        add_seg(g, w.tt_emb, E / 8);
+        BiasSiLUParams p;
+        p.bias = flat + h->off_se_b; p.out = w.tt_temb; p.pre = nullptr; p.N = E;
+        DP_HIP_LAUNCH(gemm_bias_silu(PREC_FP32, false, shape, g, p, st));
+    }
+    {
+        GemmArgs g = gemm_args(packed + h->pk_wt_all32, E / 8, L * H / (shape_ct(shape) * 32), (int)(npad / (shape_st(shape) * 32)));
+        add_seg(g, w.tt_temb, E / 8);
+        RowMajorParams p;
+        p.bias = reinterpret_cast<const float*>(packed + h->pk_bias_cat);
+        p.out = w.table; p.ldc = (int64_t)L * H; p.C_valid = L * H; p.S_valid = npad;
+        DP_HIP_LAUNCH(gemm_rowmajor(PREC_FP32, shape, g, p, st));
+    }
+    return DPOSER_OK;
+}
+
+// one shared-t network evaluation: xin -> res, bias rows from table row `row`
+static int run_shared_t(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t row, int64_t B, hipStream_t st) {
+    const void* in = w.xin;
+    const float* trow = w.table + row * (int64_t)h->L * h->H;
+    for (int l = 0; l < h->L; ++l) {
+        void* o = w.hbuf[l % 3];
+        const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[(l - 2) % 3] : nullptr;
+        DP_TRY(run_gn_layer(h, flat, packed, l, in, nullptr, trow + (int64_t)l * h->H, o, resid, nullptr, nullptr, false, w.Bpad, 0, 0, st));
+        in = o;
+    }
+    return run_post(h, flat, packed, in, w.res, B, w.Bpad, st);
+}
+
+static SdeCfg to_sde(const dposer_sde_desc* s) {
+    SdeCfg c;
+    c.kind = s->kind == DPOSER_SDE_VP ? SDE_VP : SDE_SUBVP;
+    c.beta_0 = (float)s->beta_min;
+    c.beta_1 = (float)s->beta_max;
+    c.N = s->N;
+    c.T = (float)s->T;
+    return c;
+}
+
+extern "C" int dposer_em_sampler(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                 float* x, float* x_mean, const float* timesteps_host, int32_t start_step, const float* observation,
+                                 const float* mask, const float* noise, uint64_t seed, float* traj, int32_t traj_stride,
+                                 const float* freq, const float* sigmas, int64_t B, void* stream) {
+    DP_TRY(check_common(h, flat, packed_, ws_, B));
+    DP_CHECK_ARG(sde && x && x_mean && timesteps_host && freq && sigmas, "null argument");
+    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused sampler supports subVP / VP SDEs");
+    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused sampler supports the positional embedding");
+    DP_CHECK_ARG(sde->N >= 1 && start_step >= 0 && start_step <= sde->N, "bad step range");
+    DP_CHECK_ARG((observation == nullptr) == (mask == nullptr), "observation and mask go together");
+    DP_CHECK_ARG(traj_stride >= 1, "traj_stride must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    const char* packed = (const char*)packed_;
+    const int N = sde->N;
+    const int n_run = N - start_step;
+    if (n_run == 0) return DPOSER_OK;
+    Ws w;
+    layout_ws(h, B, DPOSER_WS_SHARED_T, n_run, (char*)ws_, w);
+    // labels = t * 999 (utils.py:152), fp32 product on the host, one H2D copy
+    h->host_stage.resize(n_run);
+    for (int i = 0; i < n_run; ++i) h->host_stage[i] = timesteps_host[start_step + i] * 999.0f;
+    DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n_run * sizeof(float), hipMemcpyHostToDevice, st));
+    DP_TRY(build_time_table(h, flat, packed, w, w.tt_labels, 0.f, n_run, freq, st));
+
+    const SdeCfg sc = to_sde(sde);
+    const int k_noise = observation ? 3 : 1;
+    const int64_t BD = B * h->D;
+    EmUpdateArgs ea;
+    std::memset(&ea, 0, sizeof(ea));
+    ea.x = x; ea.x_mean = x_mean; ea.xin = w.xin; ea.sigmas = sigmas; ea.obs = observation; ea.mask = mask;
+    ea.B = B; ea.Bpad = w.Bpad; ea.D = h->D; ea.Dpad = h->Dpad; ea.Cp = h->Cp; ea.num_scales = h->d.num_scales;
+    ea.f32 = h->f32; ea.scale_by_sigma = h->d.scale_by_sigma; ea.sde = sc; ea.seed = seed;
+    // step "-1": imputation ahead of the first predictor call (sampling.py:459) + pack x
+    ea.res = nullptr; ea.t = timesteps_host[start_step]; ea.t_next = timesteps_host[start_step];
+    ea.step = (uint32_t)(start_step - 1);
+    ea.z_impA = (noise && observation) ? noise : nullptr;
+    DP_HIP_LAUNCH(launch_em_update(ea, st));
+    for (int i = 0; i < n_run; ++i) {
+        const int gi = start_step + i;
+        DP_TRY(run_shared_t(h, flat, packed, w, i, B, st));
+        ea.res = w.res;
+        ea.t = timesteps_host[gi];
+        ea.t_next = (i + 1 < n_run) ? timesteps_host[gi + 1] : -1.0f;
+        ea.step = (uint32_t)gi;
+        const float* nz = noise ? noise + (int64_t)i * k_noise * BD : nullptr;
+        ea.z_pred = nz ? nz + (observation ? BD : 0) : nullptr;
+        ea.z_impB = (nz && observation) ? nz + 2 * BD : nullptr;
+        ea.z_impA = (nz && observation && i + 1 < n_run) ? nz + (int64_t)k_noise * BD : nullptr;
+        ea.traj = (traj && ((i + 1) % traj_stride == 0)) ? traj + (int64_t)((i + 1) / traj_stride - 1) * BD : nullptr;
+        DP_HIP_LAUNCH(launch_em_update(ea, st));
+    }
+    return DPOSER_OK;
+}
+
+extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                 const float* x0, const float* z, float t, int32_t weighted, float inv_n, float* x0_hat, float* grad,
+                                 float* loss, uint64_t seed, uint32_t step, const float* freq, const float* sigmas, int64_t B,
+                                 void* stream) {
+    DP_TRY(check_common(h, flat, packed_, ws_, B));
+    DP_CHECK_ARG(sde && x0 && loss && freq && sigmas, "null argument");
+    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "prior loss supports subVP / VP SDEs");
+    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "prior loss supports the positional embedding");
+    hipStream_t st = (hipStream_t)stream;
+    const char* packed = (const char*)packed_;
+    Ws w;
+    layout_ws(h, B, DPOSER_WS_SHARED_T, 1, (char*)ws_, w);
+    DP_TRY(build_time_table(h, flat, packed, w, nullptr, t * 999.0f, 1, freq, st));
+    const SdeCfg sc = to_sde(sde);
+    PerturbSharedArgs pa;
+    pa.x0 = x0; pa.z_in = z; pa.xin = w.xin; pa.xt = w.xt; pa.t = t; pa.B = B; pa.Bpad = w.Bpad; pa.D = h->D; pa.Dpad = h->Dpad;
+    pa.f32 = h->f32; pa.sde = sc; pa.seed = seed; pa.step = step;
+    DP_HIP_LAUNCH(launch_perturb_shared(pa, st));
+    DP_TRY(run_shared_t(h, flat, packed, w, 0, B, st));
+    DenoiseArgs da;
+    da.res = w.res; da.x0 = x0; da.xt = w.xt; da.sigmas = sigmas; da.x0_hat = x0_hat; da.grad = grad; da.loss_part = w.loss_part;
+    da.t = t; da.inv_n = inv_n; da.weighted = weighted; da.B = B; da.D = h->D; da.Dpad = h->Dpad; da.Cp = h->Cp;
+    da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma; da.sde = sc;
+    int nb = 0;
+    DP_HIP_LAUNCH(launch_denoise(da, &nb, st));
+    DP_HIP_LAUNCH(launch_sum_partials(w.loss_part, nb, loss, st));
+    return DPOSER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// training: DSM loss forward + backward
+// ------------------------------------------------------------------------------------------------
+static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n_valid, const void* inT, int k_rows_pad, int k_valid,
+                     int64_t Bpad, float* slabs, int64_t& slab_cursor, int64_t numel, int64_t flat_off, ReduceJobs& rj, hipStream_t st) {
+    int shape = SHAPE_MID;
+    if (n_rows_pad < 128) shape = SHAPE_FINAL;
+    else if (k_rows_pad < 128) shape = SHAPE_WIDE64;
+    const int ct = shape_ct(shape), stt = shape_st(shape);
+    const int kb_total = (int)(Bpad / h->KBS);
+    const int64_t stages = kb_total / 4;
+    const int n_cblk = n_rows_pad / (ct * 32), n_sblk = k_rows_pad / (stt * 32);
+    const int ks = pick_ksplit((int64_t)n_cblk * n_sblk, stages);
+    GemmArgs g = gemm_args(dyT, kb_total, n_cblk, n_sblk);
+    add_seg(g, inT, kb_total);
+    g.ksplit = ks;
+    WgradParams p;
+    p.slab = slabs + slab_cursor;
+    p.slab_stride = numel;
+    p.ld = k_valid;
+    p.N_valid = n_valid;
+    p.K_valid = k_valid;
+    DP_HIP_LAUNCH(gemm_wgrad(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
+    ReduceJob& j = rj.job[rj.n++];
+    j.dst_off = flat_off; j.count = numel; j.src_off = slab_cursor; j.src_stride = numel; j.nsrc = ks;
+    slab_cursor += (int64_t)ks * numel;
+    return DPOSER_OK;
+}
+
+extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                       const float* batch_x, const float* t_in, const float* z_in, float eps, uint64_t seed,
+                                       uint32_t step, const float* freq, const float* sigmas, float* flat_grad, float* loss, int64_t B,
+                                       void* stream) {
+    DP_TRY(check_common(h, flat, packed_, ws_, B));
+    DP_CHECK_ARG(sde && batch_x && freq && sigmas && flat_grad && loss, "null argument");
+    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused DSM step supports subVP / VP SDEs");
+    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused DSM step supports the positional embedding");
+    hipStream_t st = (hipStream_t)stream;
+    const char* packed = (const char*)packed_;
+    const int prec = h->f32 ? PREC_FP32 : PREC_BF16;
+    const int H = h->H, E = h->E, L = h->L, KBS = h->KBS;
+    Ws w;
+    layout_ws(h, B, DPOSER_WS_TRAIN, 0, (char*)ws_, w);
+    const int64_t Bpad = w.Bpad;
+    const SdeCfg sc = to_sde(sde);
+
+    // ---------------- forward (model.train(): dropout active) ----------------
+    PrepTrainArgs pa;
+    pa.x0 = batch_x; pa.t_in = t_in; pa.z_in = z_in; pa.freq = freq; pa.xin = w.xin; pa.emb = w.emb; pa.t_out = w.tbuf; pa.z_out = w.zbuf;
+    pa.B = B; pa.Bpad = Bpad; pa.D = h->D; pa.Dpad = h->Dpad; pa.E = E; pa.fourier = 0; pa.f32 = h->f32; pa.sde = sc; pa.eps = eps;
+    pa.seed = seed; pa.step = step;
+    DP_HIP_LAUNCH(launch_prep_train(pa, st));
+    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, w.upre, true, Bpad, st));
+    for (int l = 0; l < L; ++l) {
+        const void* in = l == 0 ? (const void*)w.xin : (const void*)w.hbuf[l - 1];
+        const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[l - 2] : nullptr;
+        DP_TRY(run_gn_layer(h, flat, packed, l, in, w.temb, nullptr, w.hbuf[l], resid, w.xhat[l], w.rstd[l], true, Bpad, seed, step, st));
+    }
+    DP_TRY(run_post(h, flat, packed, w.hbuf[L - 1], w.res, B, Bpad, st));
+    DsmArgs da;
+    da.res = w.res; da.t = w.tbuf; da.z = w.zbuf; da.sigmas = sigmas; da.dres = w.dres; da.loss_part = w.loss_part; da.B = B; da.Bpad = Bpad;
+    da.D = h->D; da.Dpad = h->Dpad; da.Cp = h->Cp; da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma;
+    da.f32 = h->f32; da.fourier = 0; da.grad_scale = (float)(1.0 / ((double)B * (double)h->D)); da.sde = sc;
+    int nb = 0;
+    DP_HIP_LAUNCH(launch_dsm(da, &nb, st));
+    DP_HIP_LAUNCH(launch_sum_partials(w.loss_part, nb, loss, st));
+
+    // ---------------- backward ----------------
+    ReduceJobs rj;
+    rj.n = 0;
+    int64_t slab_cursor = 0;
+    const int64_t part_rows_base = 0;
+    (void)part_rows_base;
+    // transposed copies shared by several wgrads
+    DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.temb, w.tembT, Bpad, E, st));
+    // post_dense: bias (column sums of dres), weight, dgrad
+    int n_chunks_post = 0;
+    DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, st));
+    DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, st));
+    DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.hbuf[L - 1], w.inT, Bpad, H, st));
+    DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.inT, H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, st));
+
+    const int gshape = gnbwd_shape(Bpad);
+    const int ws_rows = (int)(Bpad / (shape_st(gshape) * 32)) * shape_ws(gshape);   // partial rows written by the dgrad epilogue
+    for (int j = L - 1; j >= 0; --j) {
+        // gradient w.r.t. the output of GN layer j, through the layer that consumes it
+        const bool from_post = (j == L - 1);
+        const void* Wt = packed + (from_post ? h->pk_wpostT : h->pk_wlT[j + 1]);
+        const int kblocks = (from_post ? h->Cp : H) / KBS;
+        GemmArgs g = gemm_args(Wt, kblocks, H / (shape_ct(gshape) * 32), (int)(Bpad / (shape_st(gshape) * 32)));
+        add_seg(g, from_post ? (const void*)w.dres : (const void*)w.dy[j + 1], kblocks);
+        GNBwdParams p;
+        const bool even = (j % 2) == 0;
+        p.carry_in = (even && j < L - 1) ? w.carry[(j / 2 + 1) & 1] : nullptr;
+        p.carry_out = (even && j >= 2) ? w.carry[(j / 2) & 1] : nullptr;
+        p.xhat = w.xhat[j]; p.rstd = w.rstd[j]; p.gamma = flat + h->layer[j].gamma; p.beta = flat + h->layer[j].beta;
+        p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B; p.drop = drop_cfg(h, true, j, seed, step);
+        DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st));
+        // parameter gradients of layer j
+        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dy[j], w.dyT, Bpad, H, st));
+        const void* inT;
+        if (j == 0) { DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.xin, w.xinT, Bpad, h->Dpad, st)); inT = w.xinT; }
+        else { DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.hbuf[j - 1], w.inT, Bpad, H, st)); inT = w.inT; }
+        const LayerOff& lo = h->layer[j];
+        DP_TRY(run_wgrad(h, w.dyT, H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, st));
+        DP_TRY(run_wgrad(h, w.dyT, H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, st));
+    }
+    // time branch: dtemb = sum_l dy_l @ Wt_l ; dU = dtemb * silu'(u)
+    {
+        const int shape = main_shape(Bpad);
+        GemmArgs g = gemm_args(packed + h->pk_wtT_all, L * H / KBS, E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
+        for (int l = 0; l < L; ++l) add_seg(g, w.dy[l], H / KBS);
+        SiLUBwdParams p;
+        p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B;
+        DP_HIP_LAUNCH(gemm_silu_bwd(prec, shape, g, p, st));
+    }
+    int n_chunks_se = 0;
+    DP_HIP_LAUNCH(launch_colsum(h->f32, w.dU, w.cs_part_se, Bpad, E, &n_chunks_se, st));
+    DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dU, w.dUT, Bpad, E, st));
+    DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, st));
+    DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, st));
+
+    // ---------------- deterministic reduction into the flat gradient ----------------
+    // All partial buffers live in the workspace; offsets are taken relative to w.slabs.
+    auto rel = [&](const float* p) { return (int64_t)(p - w.slabs); };
+    auto add_job = [&](int64_t dst, int64_t count, const float* src, int64_t stride, int nsrc) {
+        ReduceJob& j = rj.job[rj.n++];
+        j.dst_off = dst; j.count = count; j.src_off = rel(src); j.src_stride = stride; j.nsrc = nsrc;
+    };
+    for (int l = 0; l < L; ++l) {
+        add_job(h->layer[l].gamma, H, w.gn_part[l] + 0 * H, 3 * (int64_t)H, ws_rows);
+        add_job(h->layer[l].beta, H, w.gn_part[l] + 1 * H, 3 * (int64_t)H, ws_rows);
+        add_job(h->layer[l].b, H, w.gn_part[l] + 2 * H, 3 * (int64_t)H, ws_rows);
+        add_job(h->layer[l].bt, H, w.gn_part[l] + 2 * H, 3 * (int64_t)H, ws_rows);
+    }
+    add_job(h->off_post_b, h->D, w.cs_part_post, h->Cp, n_chunks_post);
+    add_job(h->off_se_b, E, w.cs_part_se, E, n_chunks_se);
+    if (rj.n > MAX_REDUCE_JOBS) return dposer_set_error(DPOSER_ERR_UNSUPPORTED, "too many reduce jobs");
+    for (int i = 0; i < h->n_nograd; ++i)
+        DP_CHECK_HIP(hipMemsetAsync(flat_grad + h->nograd_lo[i], 0, (h->nograd_hi[i] - h->nograd_lo[i]) * sizeof(float), st));
+    DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, st));
+    return DPOSER_OK;
+}
+
+extern "C" int dposer_adam_ema_clip_step(dposer_scorefc_t h, float* flat, const float* grad, float* m, float* v, float* ema, float lr,
+                                         float beta1, float beta2, float eps, float grad_clip, float grad_scale, int64_t adam_step,
+                                         float ema_decay, float* scratch, void* stream) {
+    DP_CHECK_ARG(h && flat && grad && m && v && scratch, "null argument");
+    DP_CHECK_ARG(adam_step >= 1, "adam_step counts from 1");
+    hipStream_t st = (hipStream_t)stream;
+    int nb = 0;
+    DP_HIP_LAUNCH(launch_sqnorm(grad, h->nparams, scratch + 16, &nb, st));
+    DP_HIP_LAUNCH(launch_sum_partials(scratch + 16, nb, scratch, st));
+    AdamArgs a;
+    a.p = flat; a.g = grad; a.m = m; a.v = v; a.ema = ema; a.n = h->nparams;
+    for (int i = 0; i < 2; ++i) { a.skip_lo[i] = h->nograd_lo[i]; a.skip_hi[i] = h->nograd_hi[i]; }
+    a.sqnorm = scratch; a.grad_scale = grad_scale; a.grad_clip = grad_clip; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.bc1 = (float)(1.0 - std::pow((double)beta1, (double)adam_step));
+    a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)adam_step));
+    a.ema_one_minus_decay = (float)(1.0 - (double)ema_decay);
+    DP_HIP_LAUNCH(launch_adam_ema(a, st));
+    return DPOSER_OK;
+}

@@ -1,0 +1,192 @@
+/*
+ * dposer_hip.h -- C ABI of libdposer_hip.so: the MI355X (gfx950) implementation of DPoser's
+ * diffusion hot path.
+ *
+ * The reference (moonbow721/DPoser) has NO native boundary: the path sits behind Python call
+ * sites.  Each entry point below therefore names the reference *Python*
+ * function it replaces (paths relative to the reference root); dposer_amd/ binds them with
+ * ctypes (dposer_amd/_C.py) and INTEGRATION.md shows the binding a reference maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - matrices are fp32 row-major exactly as the reference's torch tensors ([B, D] poses, ...);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     kernels are only enqueued, never synchronised, no allocation happens inside a call;
+ *   - scratch memory is caller-owned: query *_bytes(), allocate once (e.g. a torch uint8
+ *     tensor), pass the pointer;
+ *   - return value: 0 = ok, <0 = error (DPOSER_ERR_*), message via dposer_last_error().
+ */
+#ifndef DPOSER_HIP_H
+#define DPOSER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPOSER_ABI_VERSION 1
+
+enum {
+    DPOSER_OK = 0,
+    DPOSER_ERR_BAD_ARG = -1,
+    DPOSER_ERR_UNSUPPORTED = -2,
+    DPOSER_ERR_HIP = -3,
+    DPOSER_ERR_WORKSPACE = -4
+};
+
+int dposer_abi_version(void);
+const char* dposer_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Score network  (lib/algorithms/advanced/model.py:93-196  class ScoreModelFC)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dposer_scorefc_s* dposer_scorefc_t;
+
+enum { DPOSER_PREC_BF16 = 0, DPOSER_PREC_FP32 = 1 };
+enum { DPOSER_EMB_POSITIONAL = 0, DPOSER_EMB_FOURIER = 1 };
+enum { DPOSER_SDE_SUBVP = 0, DPOSER_SDE_VP = 1 };
+
+typedef struct {
+    int32_t data_dim;        /* n_poses * pose_dim: 63 (axis-angle) or 126 (rot6d)  model.py:109 */
+    int32_t hidden_dim;      /* must be a multiple of 1024 (GroupNorm(32, H) groups of 32 channels) */
+    int32_t embed_dim;       /* multiple of 128 */
+    int32_t n_blocks;        /* 1..3 */
+    int32_t embedding;       /* DPOSER_EMB_*      config.model.embedding_type  model.py:116-122 */
+    int32_t scale_by_sigma;  /* config.model.scale_by_sigma  model.py:192 */
+    int32_t num_scales;      /* length of the `sigmas` buffer  model.py:128 */
+    int32_t precision;       /* DPOSER_PREC_*: bf16 MFMA (throughput) or fp32 MFMA (parity) */
+    float dropout_p;         /* config.model.dropout  model.py:113 */
+} dposer_scorefc_desc;
+
+typedef struct {             /* lib/algorithms/advanced/sde_lib.py:122-231 */
+    int32_t kind;            /* DPOSER_SDE_* */
+    int32_t N;               /* sde.N (mutable after construction in the reference) */
+    double beta_min, beta_max, T;
+} dposer_sde_desc;
+
+int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_scorefc_t* out);
+void dposer_scorefc_destroy(dposer_scorefc_t h);
+
+/* Flat parameter buffer: all tensors of ScoreModelFC.parameters() (model.py:98-139), in that
+ * order, contiguous fp32.  The Python module keeps its nn.Parameters as views into it. */
+int64_t dposer_scorefc_num_params(dposer_scorefc_t h);
+int32_t dposer_scorefc_num_tensors(dposer_scorefc_t h);
+int64_t dposer_scorefc_tensor_offset(dposer_scorefc_t h, int32_t idx);
+int64_t dposer_scorefc_tensor_numel(dposer_scorefc_t h, int32_t idx);
+/* ranges of the flat buffer that never receive a gradient (pre_dense_cond, gauss_proj.W) */
+int32_t dposer_scorefc_nograd_ranges(dposer_scorefc_t h, int64_t lo[2], int64_t hi[2]);
+
+/* Re-tile the fp32 master weights into MFMA-fragment order (bf16 or fp32) for the forward
+ * GEMMs and, when with_backward != 0, transposed copies for dgrad. */
+int64_t dposer_scorefc_packed_bytes(dposer_scorefc_t h, int32_t with_backward);
+int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat_params, void* packed, int32_t with_backward, void* stream);
+
+enum { DPOSER_WS_INFER = 0, DPOSER_WS_SHARED_T = 1, DPOSER_WS_TRAIN = 2 };
+int64_t dposer_scorefc_workspace_bytes(dposer_scorefc_t h, int64_t batch, int32_t mode, int32_t n_steps);
+
+/* ScoreModelFC.forward(batch, t) in eval mode -- model.py:141-196.
+ *   x [B, D], labels [B] (what the reference calls `t` inside the model, i.e. t*999 from
+ *   get_score_fn utils.py:152), freq [E/2] = exp(arange(E/2) * -ln(1e4)/(E/2-1)) (model.py:39-46)
+ *   or gauss_proj.W for the fourier embedding, sigmas [num_scales] (model.py:128), out [B, D]. */
+int dposer_scorefc_forward(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws,
+                           const float* x, const float* labels, const float* freq, const float* sigmas,
+                           float* out, int64_t batch, void* stream);
+
+/* pc_sampler with the EulerMaruyama predictor, corrector 'none', optional completion imputation
+ * -- lib/algorithms/advanced/sampling.py:177-188, 375-468 (score via utils.py:141-163, reverse
+ * SDE sde_lib.py:75-109).  Runs loop indices [start_step, sde.N) on-device:
+ *   x [B, D] in: initial state (prior sample or z), out: final x;  x_mean [B, D] out;
+ *   timesteps_host [sde.N] = torch.linspace(sde.T, eps, sde.N) (sampling.py:449), HOST pointer;
+ *   observation/mask [B, D] or NULL (args.task == 'completion', sampling.py:416-420);
+ *   noise [n_steps][k][B][D] injected draws in the reference's draw order per step
+ *     (k = 1: predictor z;  k = 3 with completion: impute-after-corrector, z, impute-after-predictor)
+ *     or NULL -> in-kernel Philox4x32-10 keyed by `seed`;
+ *   traj [ceil(n_steps/traj_stride)][B][D] or NULL: state after steps start+traj_stride-1, ... */
+int dposer_em_sampler(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws,
+                      const dposer_sde_desc* sde, float* x, float* x_mean, const float* timesteps_host,
+                      int32_t start_step, const float* observation, const float* mask, const float* noise,
+                      uint64_t seed, float* traj, int32_t traj_stride, const float* freq, const float* sigmas,
+                      int64_t batch, void* stream);
+
+/* DPoser prior: perturb -> one_step_denoise -> weighted L2 -- run/completion.py:105-149,
+ * run/smplify.py:69-107, run/motion_denoising.py:99-143.  All samples share time t.
+ *   x0 [B, D]; z [B, D] injected noise or NULL; x0_hat [B, D] or NULL; grad [B, D] = d loss/d x0
+ *   (x0_hat is detached in the reference) or NULL; loss [1];
+ *   inv_n = 1/(B*D) for torch.mean (completion.py:147), 1/batch_size for smplify.py:105. */
+int dposer_prior_loss(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws,
+                      const dposer_sde_desc* sde, const float* x0, const float* z, float t, int32_t weighted,
+                      float inv_n, float* x0_hat, float* grad, float* loss, uint64_t seed, uint32_t step,
+                      const float* freq, const float* sigmas, int64_t batch, void* stream);
+
+/* get_sde_loss_fn.loss_fn + loss.backward() -- lib/algorithms/advanced/losses.py:80-137, 260
+ * (continuous=True, reduce_mean=True, likelihood_weighting=False, model.train()).
+ *   batch [B, D]; t [B] / z [B, D] injected draws or NULL (Philox: t = u*(T-eps)+eps, z ~ N(0,I));
+ *   flat_grad [num_params] out: d loss / d params (no-grad ranges zeroed); loss [1] out. */
+int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws,
+                            const dposer_sde_desc* sde, const float* batch_x, const float* t, const float* z,
+                            float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
+                            float* flat_grad, float* loss, int64_t batch, void* stream);
+
+/* optimize_fn + ema.update -- losses.py:44-58 (lr warm-up is computed by the caller), torch.optim.Adam
+ * (losses.py:31-41), lib/algorithms/ema.py:32-51 -- one pass over flat fp32 buffers.
+ *   grad_scale: multiplied into the gradient first (1/world_size after an all-reduce SUM);
+ *   grad_clip < 0 disables clipping; adam_step = optimizer step count AFTER this update (>= 1);
+ *   ema may be NULL; scratch >= 8 KiB floats for the norm partials. */
+int dposer_adam_ema_clip_step(dposer_scorefc_t h, float* flat_params, const float* flat_grad, float* exp_avg,
+                              float* exp_avg_sq, float* ema, float lr, float beta1, float beta2, float eps,
+                              float grad_clip, float grad_scale, int64_t adam_step, float ema_decay,
+                              float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Body model  (lib/body_model/body_model.py:68-112 -> smplx.lbs, lib/utils/transforms.py:227-235)
+ * ---------------------------------------------------------------------------------------- */
+/* rot6d_to_mat3x3 -- lib/utils/transforms.py:227-235: rot6d [n, 6] -> rotmat [n, 3, 3] */
+int dposer_rot6d_to_rotmat(const float* rot6d, float* rotmat, int64_t n, void* stream);
+/* batch_rodrigues -- smplx/lbs.py: axis-angle [n, 3] -> rotmat [n, 3, 3] */
+int dposer_rodrigues(const float* axis_angle, float* rotmat, int64_t n, void* stream);
+
+typedef struct dposer_body_s* dposer_body_t;
+typedef struct {
+    int32_t num_joints;      /* 24 SMPL / 52 SMPL-H / 55 SMPL-X */
+    int32_t num_vertices;
+    int32_t num_shape;       /* betas + expression coefficients */
+    int32_t num_extra;       /* vertex-selected extra joints */
+    int32_t num_landmarks;   /* barycentric landmarks */
+} dposer_body_desc;
+int dposer_body_create(const dposer_body_desc* desc, const int32_t* parents_host, dposer_body_t* out);
+void dposer_body_destroy(dposer_body_t h);
+
+/* Forward kinematics: Rodrigues + kinematic chain (smplx/lbs.py batch_rodrigues, batch_rigid_transform)
+ * with the pose assembled as SMPLX.forward does (reference call site lib/body_model/body_model.py:75-88):
+ *   pose_segments_host[i]: DEVICE pointer to segment i, [B, segment_joints[i]*3] axis-angle, or NULL
+ *     (= zeros, what the reference gets from the module's default parameters); the host arrays
+ *     themselves are HOST memory.  SMPL-X order: global(1) body(21) jaw(1) leye(1) reye(1) lhand(15) rhand(15).
+ *   j_rest [J,3] (shared) or [B,J,3]: rest-pose joints (J_regressor @ v_shaped);
+ *   joints [B, n_out, 3] out: posed joints [0, n_out) (+ transl [B,3] if not NULL);
+ *   rel_transforms [B, n_out, 12] out or NULL: rows of the 3x4 skinning transforms A_i. */
+int dposer_fk_joints(dposer_body_t h, const float* const* pose_segments_host, const int32_t* segment_joints_host,
+                     int32_t num_segments, const float* j_rest, int32_t j_rest_batched, const float* transl,
+                     float* joints, float* rel_transforms, int32_t n_out, int64_t batch, void* stream);
+
+/* Linear blend skinning -- smplx/lbs.py lbs() + SMPLX.forward joint assembly, as called from
+ * lib/body_model/body_model.py:75-103 (BodyModel.forward) and lib/body_model/smpl.py:67-77.
+ *   posedirs_packed: dposer_lbs_pack_posedirs(posedirs [(J-1)*9, V*3]) (MFMA fragment order, fp32);
+ *   v_shaped [V,3] (betas folded in, shared) or [B,V,3]; j_rest as in dposer_fk_joints;
+ *   skin_idx / skin_w [V, skin_k]: ELL form of lbs_weights [V,J] (zero weights dropped or padded);
+ *   extra_vertex_ids [num_extra], lmk_tri [num_landmarks,3] (= faces[lmk_faces_idx]), lmk_bary [num_landmarks,3];
+ *   verts [B,V,3] out; joints [B, J+num_extra+num_landmarks, 3] out (SMPL-X: 55+21+51 = 127). */
+int64_t dposer_lbs_posedirs_packed_bytes(dposer_body_t h);
+int dposer_lbs_pack_posedirs(dposer_body_t h, const float* posedirs, void* packed, void* stream);
+int64_t dposer_lbs_workspace_bytes(dposer_body_t h, int64_t batch);
+int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedirs_packed, const float* const* pose_segments_host,
+                       const int32_t* segment_joints_host, int32_t num_segments, const float* j_rest, int32_t j_rest_batched,
+                       const float* v_shaped, int32_t v_shaped_batched, const int32_t* skin_idx, const float* skin_w,
+                       int32_t skin_k, const float* transl, const int32_t* extra_vertex_ids, const int32_t* lmk_tri,
+                       const float* lmk_bary, float* verts, float* joints, int64_t batch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPOSER_HIP_H */
