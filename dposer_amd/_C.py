@@ -1,0 +1,122 @@
+"""ctypes binding of libdposer_hip.so (C ABI: include/dposer_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C dposer_amd/csrc``.  There is
+NO fallback: if the shared object is missing or a call fails, the caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdposer_hip.so")
+
+PREC_BF16, PREC_FP32 = 0, 1
+EMB_POSITIONAL, EMB_FOURIER = 0, 1
+SDE_SUBVP, SDE_VP = 0, 1
+WS_INFER, WS_SHARED_T, WS_TRAIN = 0, 1, 2
+
+
+class ScoreFCDesc(C.Structure):
+    _fields_ = [("data_dim", C.c_int32), ("hidden_dim", C.c_int32), ("embed_dim", C.c_int32),
+                ("n_blocks", C.c_int32), ("embedding", C.c_int32), ("scale_by_sigma", C.c_int32),
+                ("num_scales", C.c_int32), ("precision", C.c_int32), ("dropout_p", C.c_float)]
+
+
+class SdeDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("N", C.c_int32), ("beta_min", C.c_double),
+                ("beta_max", C.c_double), ("T", C.c_double)]
+
+
+class BodyDesc(C.Structure):
+    _fields_ = [("num_joints", C.c_int32), ("num_vertices", C.c_int32), ("num_shape", C.c_int32),
+                ("num_extra", C.c_int32), ("num_landmarks", C.c_int32)]
+
+
+class DPoserHipError(RuntimeError):
+    pass
+
+
+_lib = None
+vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
+
+# name -> (restype, argtypes); every symbol include/dposer_hip.h declares
+SIGNATURES = {
+    "dposer_abi_version": (C.c_int, []),
+    "dposer_last_error": (C.c_char_p, []),
+    "dposer_scorefc_create": (C.c_int, [C.POINTER(ScoreFCDesc), C.POINTER(vp)]),
+    "dposer_scorefc_destroy": (None, [vp]),
+    "dposer_scorefc_num_params": (i64, [vp]),
+    "dposer_scorefc_num_tensors": (i32, [vp]),
+    "dposer_scorefc_tensor_offset": (i64, [vp, i32]),
+    "dposer_scorefc_tensor_numel": (i64, [vp, i32]),
+    "dposer_scorefc_nograd_ranges": (i32, [vp, C.POINTER(i64), C.POINTER(i64)]),
+    "dposer_scorefc_packed_bytes": (i64, [vp, i32]),
+    "dposer_scorefc_pack": (C.c_int, [vp, vp, vp, i32, vp]),
+    "dposer_scorefc_workspace_bytes": (i64, [vp, i64, i32, i32]),
+    "dposer_scorefc_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    "dposer_scorefc_forward_train": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, u64, u32, vp]),
+    "dposer_scorefc_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, u64, u32, vp]),
+    "dposer_em_sampler": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, i32, vp, vp, vp, u64, vp, i32,
+                                    vp, vp, i64, vp]),
+    "dposer_prior_loss": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, f32, i32, f32, vp, vp, vp, u64,
+                                    u32, vp, vp, i64, vp]),
+    "dposer_dsm_loss_fwd_bwd": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, f32, u64, u32, vp, vp,
+                                          vp, vp, i64, vp]),
+    "dposer_adam_ema_clip_step": (C.c_int, [vp, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64,
+                                            f64, f64, i64, f64, vp, vp]),
+    "dposer_rot6d_to_rotmat": (C.c_int, [vp, vp, i64, vp]),
+    "dposer_rodrigues": (C.c_int, [vp, vp, i64, vp]),
+    "dposer_body_create": (C.c_int, [C.POINTER(BodyDesc), C.POINTER(i32), C.POINTER(vp)]),
+    "dposer_body_destroy": (None, [vp]),
+    "dposer_fk_joints": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, vp, vp, i32, i64, vp]),
+    "dposer_lbs_posedirs_packed_bytes": (i64, [vp]),
+    "dposer_lbs_pack_posedirs": (C.c_int, [vp, vp, vp, vp]),
+    "dposer_lbs_workspace_bytes": (i64, [vp, i64]),
+    "dposer_lbs_forward": (C.c_int, [vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, i32, vp, vp, i32,
+                                     vp, vp, vp, vp, vp, vp, i64, vp]),
+}
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DPoserHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C dposer_amd/csrc` (hipcc --offload-arch=gfx950). dposer_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.dposer_abi_version() != 1:
+            raise DPoserHipError("libdposer_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().dposer_last_error().decode("utf-8", "replace")
+        raise DPoserHipError(f"{what or 'libdposer_hip'} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t, name="tensor"):
+    if not t.is_cuda:
+        raise DPoserHipError(
+            f"{name} lives on {t.device}: dposer_amd runs the hot path only as HIP kernels on an AMD GPU "
+            "(no CPU fallback). Move the module / tensors to 'cuda'.")

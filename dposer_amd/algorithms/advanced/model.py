@@ -1,0 +1,239 @@
+"""ScoreModelFC / TimeMLPs -- the score networks of the reference's
+lib/algorithms/advanced/model.py (ScoreModelFC :93-196, TimeMLPs :69-90, get_timestep_embedding
+:37-51, GaussianFourierProjection :10-21, get_sigmas :24-34, get_act :54-66).
+
+The module keeps the reference's constructor signature, sub-module names and therefore
+``state_dict`` keys/shapes (reference checkpoints load unchanged, including the unused
+``pre_dense_cond``), but owns its parameters as views into ONE flat fp32 buffer (what the fused
+Adam/EMA kernel and the weight packer consume) and evaluates ``forward`` with the MFMA kernels of
+``libdposer_hip.so``.  There is no torch/CPU fallback: a forward on CPU tensors raises.
+"""
+import functools
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import _C
+from ...engine import ScoreEngine, default_precision
+
+
+class GaussianFourierProjection(nn.Module):
+    """Fixed Gaussian random features for time steps (model.py:10-21)."""
+
+    def __init__(self, embed_dim, scale=30.0):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embed_dim // 2) * scale, requires_grad=False)
+
+    def forward(self, x):
+        proj = x[:, None] * self.W[None, :] * 2 * np.pi
+        return torch.cat([torch.sin(proj), torch.cos(proj)], dim=-1)
+
+
+def get_sigmas(config):
+    """VE noise levels exp(linspace(ln sigma_max, ln sigma_min, num_scales)) (model.py:24-34)."""
+    m = config.model
+    return np.exp(np.linspace(np.log(m.sigma_max), np.log(m.sigma_min), m.num_scales))
+
+
+def get_timestep_embedding(timesteps, embedding_dim, max_positions=10000):
+    """Sinusoidal embedding [sin(t f_k) | cos(t f_k)], f_k = exp(-k ln(max_positions)/(half-1)) (model.py:37-51)."""
+    assert len(timesteps.shape) == 1
+    half = embedding_dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float32, device=timesteps.device) * -(math.log(max_positions) / (half - 1)))
+    arg = timesteps.float()[:, None] * freq[None, :]
+    emb = torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
+    if embedding_dim % 2 == 1:
+        emb = F.pad(emb, (0, 1), mode="constant")
+    assert emb.shape == (timesteps.shape[0], embedding_dim)
+    return emb
+
+
+_ACTIVATIONS = {"elu": nn.ELU, "relu": nn.ReLU, "lrelu": functools.partial(nn.LeakyReLU, negative_slope=0.2), "swish": nn.SiLU}
+
+
+def get_act(config):
+    """model.py:54-66."""
+    name = config.model.nonlinearity.lower()
+    if name not in _ACTIVATIONS:
+        raise NotImplementedError("activation function does not exist!")
+    return _ACTIVATIONS[name]()
+
+
+class TimeMLPs(nn.Module):
+    """Plain MLP on [x, t] (model.py:69-90).  Secondary model of the reference, kept for surface
+    completeness as ordinary torch modules (not on the accelerated path; unused by the shipped config)."""
+
+    def __init__(self, config, n_poses=21, pose_dim=6, hidden_dim=64, n_blocks=2):
+        super().__init__()
+        dim = n_poses * pose_dim
+        self.act = get_act(config)
+        layers = [nn.Linear(dim + 1, hidden_dim), self.act]
+        for _ in range(n_blocks):
+            layers += [nn.Linear(hidden_dim, hidden_dim), self.act, nn.Dropout(p=config.model.dropout)]
+        layers.append(nn.Linear(hidden_dim, dim))
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, x, t, condition=None, mask=None):
+        return self.net(torch.cat([x, t[:, None]], dim=1))
+
+
+class _ScoreFCFunction(torch.autograd.Function):
+    """Differentiable forward: d/d params and d/d x through dposer_scorefc_backward."""
+
+    @staticmethod
+    def forward(ctx, module, x, labels, train_mode, seed, step, *params):
+        eng = module._engine()
+        flat = module._flat
+        packed = eng.packed(flat, with_backward=True, force=not module.freeze_packed)
+        ws = eng.workspace(x.shape[0], _C.WS_TRAIN, 0, x.device)
+        out = torch.empty_like(x)
+        freq = eng.freq(x.device, module._fourier_W())
+        _C.check(eng.lib.dposer_scorefc_forward_train(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), _C.ptr(x), _C.ptr(labels),
+                                                      _C.ptr(freq), _C.ptr(module.sigmas), _C.ptr(out), x.shape[0],
+                                                      1 if train_mode else 0, seed, step, _C.stream_ptr()),
+                 "dposer_scorefc_forward_train")
+        ctx.module, ctx.train_mode, ctx.seed, ctx.step = module, train_mode, seed, step
+        ctx.labels = labels
+        ctx.need_dx = x.requires_grad
+        ctx.need_dw = any(p.requires_grad for p in params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.module
+        eng = m._engine()
+        B = dout.shape[0]
+        dout = dout.contiguous().float()
+        ws = eng.workspace(B, _C.WS_TRAIN, 0, dout.device)   # still holds the activations of the matching forward
+        flat_grad = torch.empty(eng.num_params, dtype=torch.float32, device=dout.device) if ctx.need_dw else None
+        dx = torch.empty(B, eng.D, dtype=torch.float32, device=dout.device) if ctx.need_dx else None
+        _C.check(eng.lib.dposer_scorefc_backward(eng.h, _C.ptr(m._flat), _C.ptr(eng._packed), _C.ptr(ws), _C.ptr(ctx.labels),
+                                                 _C.ptr(m.sigmas), _C.ptr(dout), _C.ptr(flat_grad), _C.ptr(dx), B,
+                                                 1 if ctx.train_mode else 0, ctx.seed, ctx.step, _C.stream_ptr()),
+                 "dposer_scorefc_backward")
+        grads = []
+        for p, off in zip(m._param_list, eng.offsets):
+            if ctx.need_dw and p.requires_grad and not m._is_nograd(off):
+                grads.append(flat_grad[off:off + p.numel()].view_as(p))
+            else:
+                grads.append(None)
+        return (None, dx, None, None, None, None, *grads)
+
+
+class ScoreModelFC(nn.Module):
+    """Time-embedded residual MLP with independent time projections per layer (model.py:93-196)."""
+
+    def __init__(self, config, n_poses=21, pose_dim=6, hidden_dim=64, embed_dim=32, n_blocks=2):
+        super().__init__()
+        self.config = config
+        self.n_poses = n_poses
+        self.joint_dim = pose_dim
+        self.n_blocks = n_blocks
+        self.hidden_dim = hidden_dim
+        self.embed_dim = embed_dim
+        self.act = get_act(config)
+        data_dim = n_poses * pose_dim
+
+        # registration order == reference (model.py:109-139) => identical parameters() order / init stream
+        self.pre_dense = nn.Linear(data_dim, hidden_dim)
+        self.pre_dense_t = nn.Linear(embed_dim, hidden_dim)
+        self.pre_dense_cond = nn.Linear(hidden_dim, hidden_dim)     # never used in forward (kept for checkpoints)
+        self.pre_gnorm = nn.GroupNorm(32, num_channels=hidden_dim)
+        self.dropout = nn.Dropout(p=config.model.dropout)
+        self.time_embedding_type = config.model.embedding_type.lower()
+        if self.time_embedding_type == "fourier":
+            self.gauss_proj = GaussianFourierProjection(embed_dim=embed_dim, scale=config.model.fourier_scale)
+        elif self.time_embedding_type == "positional":
+            self.posit_proj = functools.partial(get_timestep_embedding, embedding_dim=embed_dim)
+        else:
+            assert 0
+        self.shared_time_embed = nn.Sequential(nn.Linear(embed_dim, embed_dim), self.act)
+        self.register_buffer("sigmas", torch.tensor(get_sigmas(config), dtype=torch.float))
+        for idx in range(1, n_blocks + 1):
+            for j in (1, 2):
+                setattr(self, f"b{idx}_dense{j}", nn.Linear(hidden_dim, hidden_dim))
+                setattr(self, f"b{idx}_dense{j}_t", nn.Linear(embed_dim, hidden_dim))
+                setattr(self, f"b{idx}_gnorm{j}", nn.GroupNorm(32, num_channels=hidden_dim))
+        self.post_dense = nn.Linear(hidden_dim, data_dim)
+
+        # ---- MI355X engine state (not part of the state_dict) ----
+        self.precision = default_precision(config)
+        self.freeze_packed = False      # True: caller promises the weights do not change between forwards
+        self._engines = {}
+        self._flat = None
+        self._param_list = list(self.parameters())
+        self._offsets = [0]
+        for p in self._param_list:
+            self._offsets.append(self._offsets[-1] + p.numel())
+        self._num_flat = self._offsets.pop()
+        self.flat_params()
+        self._rng_seed = int(getattr(config, "seed", 0) or 0) * 1000003 + 12345
+        self._rng_step = 0
+
+    # ---- flat parameter storage -------------------------------------------------------------------
+    def _engine(self) -> ScoreEngine:
+        eng = self._engines.get(self.precision)
+        if eng is None:
+            if self.config.model.nonlinearity.lower() != "swish":
+                raise NotImplementedError("the HIP score path fuses SiLU ('swish'); other activations are not built")
+            eng = ScoreEngine(data_dim=self.n_poses * self.joint_dim, hidden_dim=self.hidden_dim, embed_dim=self.embed_dim,
+                              n_blocks=self.n_blocks, embedding=self.time_embedding_type,
+                              scale_by_sigma=bool(self.config.model.scale_by_sigma), num_scales=int(self.sigmas.numel()),
+                              dropout_p=float(self.config.model.dropout), precision=self.precision)
+            assert eng.offsets == self._offsets and eng.num_params == self._num_flat, "flat layout disagrees with parameters()"
+            self._engines[self.precision] = eng
+        return eng
+
+    def _is_nograd(self, off):
+        return any(lo <= off < hi for lo, hi in self._engine().nograd)
+
+    def _fourier_W(self):
+        return self.gauss_proj.W if self.time_embedding_type == "fourier" else None
+
+    def flat_params(self) -> torch.Tensor:
+        """The flat fp32 buffer all parameters are views of (re-built if someone replaced ``.data``)."""
+        dev = self._param_list[0].device
+        ok = self._flat is not None and self._flat.device == dev
+        if ok:
+            base = self._flat.data_ptr()
+            ok = all(p.data_ptr() == base + 4 * off for p, off in zip(self._param_list, self._offsets))
+        if not ok:
+            flat = torch.empty(self._num_flat, dtype=torch.float32, device=dev)
+            for p, off in zip(self._param_list, self._offsets):
+                flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + p.numel()].view(p.shape)
+            self._flat = flat
+        return self._flat
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flat = None          # .to()/.cuda()/.float() replace parameter storage: re-flatten
+        self.flat_params()
+        return out
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, batch, t, condition=None, mask=None):
+        """batch [B, j*3|j*6], t [B] (the *labels*, i.e. t*999 for the continuous sub-VP model) -> [B, same].
+        model.py:141-196."""
+        _C.require_gpu(batch, "ScoreModelFC input")
+        if self.sigmas.device != batch.device or self._param_list[0].device != batch.device:
+            raise _C.DPoserHipError("ScoreModelFC parameters and input are on different devices")
+        flat = self.flat_params()
+        eng = self._engine()
+        x = batch.contiguous().float()
+        labels = t.contiguous().float()
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self._param_list))
+        if needs_grad or self.training:
+            self._rng_step += 1
+            return _ScoreFCFunction.apply(self, x, labels, bool(self.training), self._rng_seed, self._rng_step, *self._param_list)
+        packed = eng.packed(flat, with_backward=False, force=not self.freeze_packed)
+        ws = eng.workspace(x.shape[0], _C.WS_INFER, 0, x.device)
+        out = torch.empty_like(x)
+        freq = eng.freq(x.device, self._fourier_W())
+        _C.check(eng.lib.dposer_scorefc_forward(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), _C.ptr(x), _C.ptr(labels),
+                                                _C.ptr(freq), _C.ptr(self.sigmas), _C.ptr(out), x.shape[0], _C.stream_ptr()),
+                 "dposer_scorefc_forward")
+        return out

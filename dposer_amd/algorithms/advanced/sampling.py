@@ -1,0 +1,343 @@
+"""Samplers -- counterpart of the reference's lib/algorithms/advanced/sampling.py (registries
+:33-77, get_sampling_fn :80-124, Predictor/Corrector :127-174, EulerMaruyamaPredictor :177-207,
+ReverseDiffusion/Ancestral/None predictors :210-270, LangevinCorrector :273-302, ALD :305-339,
+NoneCorrector :342-350, shared update fns :353-372, get_pc_sampler :375-468).
+
+Fast path on MI355X: Euler-Maruyama predictor + 'none' corrector (the shipped configuration,
+configs/subvp/amass_scorefc_continuous.py:30-32) on a sub-VP/VP SDE with a ScoreModelFC runs as
+``dposer_em_sampler``: the whole N-step loop is enqueued by one C call, the time branch of the
+network collapses into a per-step bias table, the predictor update / completion imputation /
+re-tiling of x for the next step are fused into one elementwise kernel per step, and noise is
+drawn in-kernel (Philox).  Any other predictor/corrector combination runs the generic loop below on
+top of the HIP score function.
+"""
+import abc
+import ctypes as C
+import functools
+
+import numpy as np
+import torch
+
+from ... import _C
+from . import sde_lib
+from . import utils as mutils
+from .utils import get_score_fn
+
+_CORRECTORS = {}
+_PREDICTORS = {}
+
+
+def _registrar(table):
+    def register(cls=None, *, name=None):
+        def _register(c):
+            key = name if name is not None else c.__name__
+            if key in table:
+                raise ValueError(f"Already registered model with name: {key}")
+            table[key] = c
+            return c
+
+        return _register if cls is None else _register(cls)
+
+    return register
+
+
+register_predictor = _registrar(_PREDICTORS)
+register_corrector = _registrar(_CORRECTORS)
+
+
+def get_predictor(name):
+    return _PREDICTORS[name]
+
+
+def get_corrector(name):
+    return _CORRECTORS[name]
+
+
+def get_sampling_fn(config, sde, shape, inverse_scaler, eps, device=None):
+    """sampling.py:80-124."""
+    if device is None:
+        device = config.device
+    name = config.sampling.method.lower()
+    if name == "ode":
+        raise NotImplementedError("the probability-flow ODE sampler (sampling.py:471-542, scipy RK45 on the host) is outside "
+                                  "the accelerated path (SURVEY.md 8f.4)")
+    if name != "pc":
+        raise ValueError(f"Sampler name {config.sampling.method} unknown.")
+    return get_pc_sampler(sde=sde, shape=shape, predictor=get_predictor(config.sampling.predictor.lower()),
+                          corrector=get_corrector(config.sampling.corrector.lower()), inverse_scaler=inverse_scaler,
+                          snr=config.sampling.snr, n_steps=config.sampling.n_steps_each,
+                          probability_flow=config.sampling.probability_flow, continuous=config.training.continuous,
+                          denoise=config.sampling.noise_removal, eps=eps, device=device)
+
+
+class Predictor(abc.ABC):
+    def __init__(self, sde, score_fn, probability_flow=False):
+        super().__init__()
+        self.sde = sde
+        self.rsde = sde.reverse(score_fn, probability_flow)
+        self.score_fn = score_fn
+
+    @abc.abstractmethod
+    def update_fn(self, x, t, observation, mask):
+        ...
+
+
+class Corrector(abc.ABC):
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__()
+        self.sde, self.score_fn, self.snr, self.n_steps = sde, score_fn, snr, n_steps
+
+    @abc.abstractmethod
+    def update_fn(self, x, t, observation, mask):
+        ...
+
+
+@register_predictor(name="euler_maruyama")
+class EulerMaruyamaPredictor(Predictor):
+    """sampling.py:177-207."""
+
+    def update_fn(self, x, t, observation, mask):
+        dt = -1.0 / self.rsde.N
+        z = torch.randn_like(x)
+        drift, diffusion = self.rsde.sde(x, t)
+        x_mean = x + drift * dt
+        return x_mean + diffusion[:, None] * np.sqrt(-dt) * z, x_mean
+
+    def update_fn_guide(self, x_t, t, observation, mask, condition=None, grad_step=1.0):
+        """MCG / DPS style guided step (sampling.py:191-207); needs d score / d x -> differentiable HIP forward."""
+        x_t.requires_grad_()
+        dt = -1.0 / self.rsde.N
+        z = torch.randn_like(x_t)
+        drift, diffusion, alpha, sigma_2, score = self.rsde.sde(x_t, t, condition, mask, guide=True)
+        y_mean = x_t.detach() + drift.detach() * dt
+        y_hat = y_mean + diffusion[:, None] * np.sqrt(-dt) * z
+        with torch.enable_grad():
+            y0 = (x_t + sigma_2[:, None] * score) / alpha
+            norm = torch.norm((observation * mask) - (y0 * mask))
+            g = torch.autograd.grad(outputs=norm, inputs=x_t)[0]
+            if torch.isnan(g).any():
+                raise ValueError("Consider reduce the value of parameter: grad_step={}".format(grad_step))
+            y_hat = y_hat - grad_step * g
+        return y_hat, y_mean
+
+
+@register_predictor(name="reverse_diffusion")
+class ReverseDiffusionPredictor(Predictor):
+    """sampling.py:210-220."""
+
+    def update_fn(self, x, t, observation=None, mask=None):
+        f, G = self.rsde.discretize(x, t)
+        z = torch.randn_like(x)
+        x_mean = x - f
+        return x_mean + G[:, None] * z, x_mean
+
+
+@register_predictor(name="ancestral_sampling")
+class AncestralSamplingPredictor(Predictor):
+    """sampling.py:223-259 (VE / VP only)."""
+
+    def __init__(self, sde, score_fn, probability_flow=False):
+        super().__init__(sde, score_fn, probability_flow)
+        if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+        assert not probability_flow, "Probability flow not supported by ancestral sampling"
+
+    def update_fn(self, x, t, observation=None, mask=None):
+        sde = self.sde
+        timestep = (t * (sde.N - 1) / sde.T).long()
+        score = self.score_fn(x, t)
+        noise = torch.randn_like(x)
+        if isinstance(sde, sde_lib.VESDE):
+            sigma = sde.discrete_sigmas.to(t.device)[timestep]
+            adj = torch.where(timestep == 0, torch.zeros_like(t), sde.discrete_sigmas.to(t.device)[timestep - 1])
+            x_mean = x + score * (sigma ** 2 - adj ** 2)[:, None]
+            std = torch.sqrt((adj ** 2 * (sigma ** 2 - adj ** 2)) / (sigma ** 2))
+            return x_mean + std[:, None] * noise, x_mean
+        beta = sde.discrete_betas.to(t.device)[timestep]
+        x_mean = (x + beta[:, None] * score) / torch.sqrt(1.0 - beta)[:, None]
+        return x_mean + torch.sqrt(beta)[:, None] * noise, x_mean
+
+
+@register_predictor(name="none")
+class NonePredictor(Predictor):
+    def __init__(self, sde, score_fn, probability_flow=False):
+        pass
+
+    def update_fn(self, x, t, observation, mask):
+        return x, x
+
+
+def _langevin_alpha(sde, t):
+    if isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE)):
+        return sde.alphas.to(t.device)[(t * (sde.N - 1) / sde.T).long()]
+    return torch.ones_like(t)
+
+
+def _check_langevin_sde(sde):
+    if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE, sde_lib.subVPSDE)):
+        raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+
+@register_corrector(name="langevin")
+class LangevinCorrector(Corrector):
+    """sampling.py:273-302.  The step size couples the samples through batch-mean norms (:296-297);
+    under data parallelism each rank uses its shard's means (documented deviation)."""
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        _check_langevin_sde(sde)
+
+    def update_fn(self, x, t, observation, mask):
+        alpha = _langevin_alpha(self.sde, t)
+        x_mean = x
+        for _ in range(self.n_steps):
+            grad = self.score_fn(x, t, condition=None, mask=mask)
+            noise = torch.randn_like(x)
+            grad_norm = torch.norm(grad.reshape(grad.shape[0], -1), dim=-1).mean()
+            noise_norm = torch.norm(noise.reshape(noise.shape[0], -1), dim=-1).mean()
+            step = (self.snr * noise_norm / grad_norm) ** 2 * 2 * alpha
+            x_mean = x + step[:, None] * grad
+            x = x_mean + torch.sqrt(step * 2)[:, None] * noise
+        return x, x_mean
+
+
+@register_corrector(name="ald")
+class AnnealedLangevinDynamics(Corrector):
+    """sampling.py:305-339."""
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        _check_langevin_sde(sde)
+
+    def update_fn(self, x, t, observation, mask):
+        alpha = _langevin_alpha(self.sde, t)
+        std = self.sde.marginal_prob(x, t)[1]
+        x_mean = x
+        for _ in range(self.n_steps):
+            grad = self.score_fn(x, t, condition=None, mask=mask)
+            noise = torch.randn_like(x)
+            step = (self.snr * std) ** 2 * 2 * alpha
+            x_mean = x + step[:, None] * grad
+            x = x_mean + noise * torch.sqrt(step * 2)[:, None]
+        return x, x_mean
+
+
+@register_corrector(name="none")
+class NoneCorrector(Corrector):
+    def __init__(self, sde, score_fn, snr, n_steps):
+        pass
+
+    def update_fn(self, x, t, observation, mask):
+        return x, x
+
+
+def shared_predictor_update_fn(x, t, observation, mask, sde, model, predictor, probability_flow, continuous):
+    """sampling.py:353-361."""
+    score_fn = mutils.get_score_fn(sde, model, train=False, continuous=continuous)
+    obj = NonePredictor(sde, score_fn, probability_flow) if predictor is None else predictor(sde, score_fn, probability_flow)
+    return obj.update_fn(x, t, observation, mask)
+
+
+def shared_corrector_update_fn(x, t, observation, mask, sde, model, corrector, continuous, snr, n_steps):
+    """sampling.py:364-372."""
+    score_fn = mutils.get_score_fn(sde, model, train=False, continuous=continuous)
+    obj = NoneCorrector(sde, score_fn, snr, n_steps) if corrector is None else corrector(sde, score_fn, snr, n_steps)
+    return obj.update_fn(x, t, observation, mask)
+
+
+def fused_em_supported(sde, model, predictor, corrector, probability_flow, continuous):
+    from .model import ScoreModelFC
+    return (predictor is EulerMaruyamaPredictor and corrector in (None, NoneCorrector) and not probability_flow
+            and sde_lib.sde_desc(sde) is not None and (continuous or isinstance(sde, sde_lib.subVPSDE))
+            and isinstance(model, ScoreModelFC) and model.time_embedding_type == "positional")
+
+
+def fused_em_sample(model, sde, x, timesteps, *, start_step=0, observation=None, mask=None, noise=None, seed=0,
+                    traj_stride=0):
+    """dposer_em_sampler.  x [B, D] initial state (consumed); returns (trajs or None, x, x_mean)."""
+    _C.require_gpu(x, "sampler state")
+    eng = model._engine()
+    flat = model.flat_params()
+    packed = eng.packed(flat, with_backward=False, force=not model.freeze_packed)
+    B, D = x.shape
+    N = int(sde.N)
+    n_run = N - start_step
+    ws = eng.workspace(B, _C.WS_SHARED_T, max(n_run, 1), x.device)
+    x = x.contiguous().float().clone()
+    x_mean = x.clone()
+    ts_host = timesteps.detach().to("cpu", torch.float32).contiguous()
+    traj = None
+    if traj_stride and n_run > 0:
+        traj = torch.empty((n_run // traj_stride, B, D), dtype=torch.float32, device=x.device)
+    desc = sde_lib.sde_desc(sde)
+    obs = None if observation is None else observation.contiguous().float()
+    msk = None if mask is None else mask.contiguous().float()
+    nz = None if noise is None else noise.contiguous().float()
+    _C.check(eng.lib.dposer_em_sampler(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(x_mean),
+                                       C.c_void_p(ts_host.data_ptr()), int(start_step), _C.ptr(obs), _C.ptr(msk), _C.ptr(nz),
+                                       int(seed), _C.ptr(traj), int(traj_stride or 1), _C.ptr(eng.freq(x.device)),
+                                       _C.ptr(model.sigmas), B, _C.stream_ptr()), "dposer_em_sampler")
+    return traj, x, x_mean
+
+
+def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1, probability_flow=False,
+                   continuous=False, denoise=True, eps=1e-3, device="cuda"):
+    """Predictor-corrector sampler factory (sampling.py:375-468).
+
+    The returned ``pc_sampler(model, observation, mask, z, start_step, args)`` has the reference's
+    signature and return value ``(trajs [n, B, D], x_mean if denoise else x)``.  Extra keyword-only
+    arguments: ``traj_stride`` (default 1 = every step as the reference; 0 = keep no trajectory --
+    at B = 65536, N = 1000 the full tensor is 16.5 GB), ``noise`` (injected draws for tests),
+    ``seed`` (Philox key of the in-kernel noise)."""
+    predictor_update_fn = functools.partial(shared_predictor_update_fn, sde=sde, predictor=predictor,
+                                            probability_flow=probability_flow, continuous=continuous)
+    corrector_update_fn = functools.partial(shared_corrector_update_fn, sde=sde, corrector=corrector, continuous=continuous,
+                                            snr=snr, n_steps=n_steps)
+
+    def with_imputation(update_fn):
+        def fn(x, vec_t, observation, mask, model, args):
+            x, x_mean = update_fn(x, vec_t, observation, mask, model=model)
+            if args is not None and args.task in ["completion"]:                 # sampling.py:416-420
+                mean, std = sde.marginal_prob(observation, vec_t)
+                x = x * (1 - mask) + (mean + torch.randn_like(x) * std[:, None]) * mask
+            return x, x_mean
+
+        return fn
+
+    projector = with_imputation(predictor_update_fn)
+    correct = with_imputation(corrector_update_fn)
+    call_count = [0]
+
+    def pc_sampler(model, observation=None, mask=None, z=None, start_step=0, args=None, *, traj_stride=1, noise=None,
+                   seed=None):
+        with torch.no_grad():
+            x = torch.randn(*shape, device=device) if z is None else z             # sampling.py:446
+            timesteps = torch.linspace(sde.T, eps, sde.N, device=device)          # sampling.py:449
+            start_t = start_step if (args is not None and args.task in ["denoise"]) else 0
+            completion = args is not None and args.task in ["completion"]
+            if fused_em_supported(sde, model, predictor, corrector, probability_flow, continuous):
+                call_count[0] += 1
+                if seed is None:
+                    seed = (model._rng_seed * 7919 + call_count[0]) & 0xFFFFFFFFFFFF
+                was_training = model.training
+                model.eval()                                                       # utils.py:117-119
+                trajs, x, x_mean = fused_em_sample(model, sde, x, torch.linspace(sde.T, eps, sde.N), start_step=start_t,
+                                                   observation=observation if completion else None,
+                                                   mask=mask if completion else None, noise=noise, seed=seed,
+                                                   traj_stride=traj_stride)
+                model.train(was_training)
+                if trajs is None:
+                    trajs = x.new_empty((0,) + tuple(x.shape))
+                return trajs, (x_mean if denoise else x)
+            trajs = []
+            x_mean = x
+            for i in range(start_t, sde.N):
+                vec_t = torch.ones(shape[0], device=device) * timesteps[i]
+                x, x_mean = correct(x, vec_t, observation, mask, model=model, args=args)
+                x, x_mean = projector(x, vec_t, observation, mask, model=model, args=args)
+                if traj_stride and (i - start_t + 1) % traj_stride == 0:
+                    trajs.append(x)
+            trajs = torch.stack(trajs, dim=0) if trajs else x.new_empty((0,) + tuple(x.shape))
+            return trajs, (x_mean if denoise else x)
+
+    return pc_sampler

@@ -1,0 +1,197 @@
+"""BodyModel -- counterpart of the reference's lib/body_model/body_model.py:8-112 (a wrapper over
+``smplx.{SMPL,SMPLH,SMPLX}``).  smplx is an un-vendored dependency of the reference; here the model
+arithmetic (Rodrigues, kinematic chain, pose-blend GEMM, skinning, landmark joints -- smplx/lbs.py)
+runs in the HIP kernels of dposer_amd/csrc/fk.hip behind ``dposer_fk_joints`` / ``dposer_lbs_forward``.
+
+``bm_path`` may be an official ``SMPLX_*.npz`` or an asset dictionary
+(``body_model.synthetic.make_synthetic_smplx_asset``).  Only ``model_type='smplx'`` is built.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _C
+from .synthetic import load_smplx_npz
+
+
+class Struct:
+    """smplx.utils.Struct: attribute bag."""
+
+    def __init__(self, **kwargs):
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+_SMPLX_SEGMENTS = (("global_orient", 1), ("body_pose", 21), ("jaw_pose", 1), ("leye_pose", 1), ("reye_pose", 1),
+                   ("left_hand_pose", 15), ("right_hand_pose", 15))
+
+
+class _SMPLXCore(nn.Module):
+    """What the reference reaches as ``BodyModel.bm`` (an smplx.SMPLX instance): buffers + forward."""
+    NUM_JOINTS = 54
+    NUM_BODY_JOINTS = 21
+    NUM_HAND_JOINTS = 15
+
+    def __init__(self, asset, num_betas=10, num_expression_coeffs=10, batch_size=1):
+        super().__init__()
+        self.batch_size = batch_size
+        a = asset
+        self.num_betas = num_betas
+        self.num_expression_coeffs = num_expression_coeffs
+        f32 = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)
+        self.register_buffer("v_template", f32(a["v_template"]))
+        self.register_buffer("shapedirs", f32(a["shapedirs"]))                  # [V,3,betas+expr]
+        self.register_buffer("posedirs", f32(a["posedirs"]))                    # [486, V*3]
+        self.register_buffer("J_regressor", f32(a["J_regressor"]))
+        self.register_buffer("lbs_weights", f32(a["weights"]))
+        self.register_buffer("parents", torch.tensor(np.asarray(a["parents"]), dtype=torch.long))
+        self.register_buffer("faces_tensor", torch.tensor(np.asarray(a["faces"]).astype(np.int64), dtype=torch.long))
+        self.register_buffer("lmk_faces_idx", torch.tensor(np.asarray(a["lmk_faces_idx"]).astype(np.int64)))
+        self.register_buffer("lmk_bary_coords", f32(a["lmk_bary_coords"]))
+        self.register_buffer("extra_vertex_ids", torch.tensor(np.asarray(a["extra_joint_vertex_ids"]).astype(np.int32)))
+        # ELL form of the skinning weights
+        w = np.asarray(a["weights"], dtype=np.float32)
+        k = int((w != 0).sum(axis=1).max())
+        order = np.argsort(-(w != 0), axis=1, kind="stable")[:, :k]
+        self.register_buffer("skin_idx", torch.tensor(order.astype(np.int32)))
+        self.register_buffer("skin_w", torch.tensor(np.take_along_axis(w, order, axis=1)))
+        tri = np.asarray(a["faces"])[np.asarray(a["lmk_faces_idx"])]
+        self.register_buffer("lmk_tri", torch.tensor(tri.astype(np.int32)))
+        self.J, self.V = int(w.shape[1]), int(w.shape[0])
+        self.n_extra, self.n_lmk = int(len(a["extra_joint_vertex_ids"])), int(len(a["lmk_faces_idx"]))
+        self._parents_np = np.asarray(a["parents"]).astype(np.int32)
+        self._h = None
+        self._posedirs_packed = None
+        self._ws = None
+        self._rest_cache = {}
+
+    # ---- engine ----
+    def _handle(self):
+        if self._h is None:
+            desc = _C.BodyDesc(self.J, self.V, self.num_betas + self.num_expression_coeffs, self.n_extra, self.n_lmk)
+            h = C.c_void_p()
+            par = (C.c_int32 * self.J)(*[int(p) for p in self._parents_np])
+            _C.check(_C.lib().dposer_body_create(C.byref(desc), par, C.byref(h)), "dposer_body_create")
+            self._h = h
+        return self._h
+
+    def _packed_posedirs(self):
+        dev = self.posedirs.device
+        if self._posedirs_packed is None or self._posedirs_packed.device != dev:
+            h = self._handle()
+            n = _C.lib().dposer_lbs_posedirs_packed_bytes(h)
+            self._posedirs_packed = torch.empty(n, dtype=torch.uint8, device=dev)
+            _C.check(_C.lib().dposer_lbs_pack_posedirs(h, _C.ptr(self.posedirs), _C.ptr(self._posedirs_packed), _C.stream_ptr()),
+                     "dposer_lbs_pack_posedirs")
+        return self._posedirs_packed
+
+    def rest_shape(self, betas, expression):
+        """v_shaped = v_template + blend_shapes(shape), J = J_regressor @ v_shaped (smplx lbs.py).
+        Loop-invariant in every hot loop of the reference (betas constant): computed
+        with torch (a [B,20] x [20,31425] product) and cached for the all-zero default."""
+        dev = self.v_template.device
+        if betas is None and expression is None:
+            key = str(dev)
+            if key not in self._rest_cache:
+                self._rest_cache[key] = (self.v_template.contiguous(), (self.J_regressor @ self.v_template).contiguous())
+            return self._rest_cache[key] + (False,)
+        B = (betas if betas is not None else expression).shape[0]
+        zb = torch.zeros(B, self.num_betas, device=dev)
+        ze = torch.zeros(B, self.num_expression_coeffs, device=dev)
+        shape = torch.cat([betas if betas is not None else zb, expression if expression is not None else ze], dim=1)
+        v_shaped = self.v_template[None] + torch.einsum("bl,mkl->bmk", shape, self.shapedirs)
+        J = torch.einsum("bik,ji->bjk", v_shaped, self.J_regressor)
+        return v_shaped.contiguous(), J.contiguous(), True
+
+    def forward(self, betas=None, global_orient=None, body_pose=None, left_hand_pose=None, right_hand_pose=None, transl=None,
+                expression=None, jaw_pose=None, leye_pose=None, reye_pose=None, return_verts=True, return_full_pose=False,
+                joints_only=False, n_joints=None, **kwargs):
+        segs = dict(global_orient=global_orient, body_pose=body_pose, jaw_pose=jaw_pose, leye_pose=leye_pose, reye_pose=reye_pose,
+                    left_hand_pose=left_hand_pose, right_hand_pose=right_hand_pose)
+        given = [v for v in list(segs.values()) + [betas, transl, expression] if v is not None]
+        if not given:
+            raise ValueError("BodyModel.forward needs at least one tensor argument")
+        B = given[0].shape[0]
+        dev = given[0].device
+        _C.require_gpu(given[0], "BodyModel input")
+        if any(t.requires_grad for t in given) and torch.is_grad_enabled():
+            raise NotImplementedError("BodyModel backward (d verts / d pose, SURVEY.md 8f.2) is not built yet; "
+                                      "call under torch.no_grad()")
+        if self.v_template.device != dev:
+            raise _C.DPoserHipError("BodyModel buffers and inputs are on different devices; call .to(device)")
+        segp = (C.c_void_p * 7)()
+        segj = (C.c_int32 * 7)()
+        keep = []
+        for i, (name, nj) in enumerate(_SMPLX_SEGMENTS):
+            t = segs[name]
+            segj[i] = nj
+            if t is not None:
+                t = t.reshape(B, nj * 3).contiguous().float()
+                keep.append(t)
+                segp[i] = t.data_ptr()
+            else:
+                segp[i] = None
+        v_shaped, j_rest, batched = self.rest_shape(betas, expression)
+        tr = None if transl is None else transl.contiguous().float()
+        h = self._handle()
+        lib = _C.lib()
+        if joints_only:
+            n_out = self.J if n_joints is None else int(n_joints)
+            joints = torch.empty(B, n_out, 3, dtype=torch.float32, device=dev)
+            _C.check(lib.dposer_fk_joints(h, segp, segj, 7, _C.ptr(j_rest), 1 if batched else 0, _C.ptr(tr), _C.ptr(joints), None, n_out, B,
+                                          _C.stream_ptr()), "dposer_fk_joints")
+            return Struct(vertices=None, joints=joints)
+        need = lib.dposer_lbs_workspace_bytes(h, B)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        verts = torch.empty(B, self.V, 3, dtype=torch.float32, device=dev)
+        joints = torch.empty(B, self.J + self.n_extra + self.n_lmk, 3, dtype=torch.float32, device=dev)
+        _C.check(lib.dposer_lbs_forward(h, _C.ptr(self._ws), _C.ptr(self._packed_posedirs()), segp, segj, 7, _C.ptr(j_rest),
+                                        1 if batched else 0, _C.ptr(v_shaped), 1 if batched else 0, _C.ptr(self.skin_idx),
+                                        _C.ptr(self.skin_w), int(self.skin_idx.shape[1]), _C.ptr(tr), _C.ptr(self.extra_vertex_ids),
+                                        _C.ptr(self.lmk_tri), _C.ptr(self.lmk_bary_coords), _C.ptr(verts), _C.ptr(joints), B,
+                                        _C.stream_ptr()), "dposer_lbs_forward")
+        z = lambda n: torch.zeros(B, n, dtype=torch.float32, device=dev)
+        full = [segs[name].reshape(B, nj * 3) if segs[name] is not None else z(nj * 3) for name, nj in _SMPLX_SEGMENTS]
+        return Struct(vertices=verts, joints=joints, betas=betas if betas is not None else z(self.num_betas),
+                      expression=expression, global_orient=full[0], body_pose=full[1], jaw_pose=full[2],
+                      left_hand_pose=full[5], right_hand_pose=full[6],
+                      full_pose=torch.cat(full, dim=1) if return_full_pose else None)
+
+
+class BodyModel(nn.Module):
+    """lib/body_model/body_model.py:8-112."""
+
+    def __init__(self, bm_path, num_betas=10, batch_size=1, num_expressions=10, model_type="smplx"):
+        super().__init__()
+        assert model_type in ["smpl", "smplh", "smplx"]
+        if model_type != "smplx":
+            raise NotImplementedError("only model_type='smplx' (what the reference's run scripts use) is built")
+        asset = bm_path if isinstance(bm_path, dict) else load_smplx_npz(bm_path, num_betas, num_expressions)
+        self.bm = _SMPLXCore(asset, num_betas=num_betas, num_expression_coeffs=num_expressions, batch_size=batch_size)
+        self.num_joints = _SMPLXCore.NUM_JOINTS
+        self.model_type = model_type
+        self.J_regressor = self.bm.J_regressor.numpy()
+        self.J_regressor_idx = {"pelvis": 0, "lwrist": 20, "rwrist": 21, "neck": 12}
+
+    def forward(self, root_orient=None, pose_body=None, pose_hand=None, pose_jaw=None, pose_eye=None, betas=None, trans=None,
+                dmpls=None, expression=None, return_dict=False, **kwargs):
+        assert dmpls is None
+        nh = _SMPLXCore.NUM_HAND_JOINTS * 3
+        o = self.bm(betas=betas, global_orient=root_orient, body_pose=pose_body,
+                    left_hand_pose=None if pose_hand is None else pose_hand[:, :nh],
+                    right_hand_pose=None if pose_hand is None else pose_hand[:, nh:],
+                    transl=trans, expression=expression, jaw_pose=pose_jaw,
+                    leye_pose=None if pose_eye is None else pose_eye[:, :3],
+                    reye_pose=None if pose_eye is None else pose_eye[:, 3:], return_full_pose=True, **kwargs)
+        out = {"v": o.vertices, "f": self.bm.faces_tensor, "betas": o.betas, "Jtr": o.joints,
+               "body_joints": o.joints[:22],        # slices the batch axis, like the reference (body_model.py:95)
+               "pose_body": o.body_pose, "full_pose": o.full_pose,
+               "pose_hand": torch.cat([o.left_hand_pose, o.right_hand_pose], dim=-1), "pose_jaw": o.jaw_pose, "pose_eye": pose_eye}
+        return out if return_dict else Struct(**out)
+
+    def fk_joints(self, pose_body, root_orient=None, trans=None, n_joints=22):
+        """Joints-only fast path (no vertices): [B, 63] -> [B, n_joints, 3]."""
+        return self.bm(global_orient=root_orient, body_pose=pose_body, transl=trans, joints_only=True, n_joints=n_joints).joints

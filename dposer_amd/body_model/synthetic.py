@@ -1,0 +1,63 @@
+"""A synthetic SMPL-X-shaped asset (V = 10475, J = 55, real kinematic tree) for benchmarks and tests.
+
+The licensed SMPL-X model file cannot be shipped (reference README.md:38-39 asks users to download
+it); everything that needs a body model takes the same dictionary this function returns, which is
+also what ``load_smplx_npz`` builds from a real ``SMPLX_*.npz``.
+"""
+import numpy as np
+
+SMPLX_PARENTS = np.array(
+    [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15,
+     20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35, 20, 37, 38,
+     21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53], dtype=np.int32)
+
+# smplx/vertex_ids.py ['smplx']: nose, reye, leye, rear, lear, LBigToe, LSmallToe, LHeel, RBigToe, RSmallToe, RHeel,
+# l/r thumb, index, middle, ring, pinky tips -- the order VertexJointSelector concatenates them
+SMPLX_EXTRA_VERTEX_IDS = np.array([9120, 9929, 9448, 616, 6, 5770, 5780, 8846, 8463, 8474, 8635,
+                                   5361, 4933, 5058, 5169, 5286, 8079, 7669, 7794, 7905, 8022], dtype=np.int32)
+
+
+def make_synthetic_smplx_asset(seed=0, num_vertices=10475, num_betas=10, num_expressions=10, nnz_per_vertex=4):
+    rs = np.random.RandomState(seed)
+    V, J = num_vertices, 55
+    v_template = (rs.standard_normal((V, 3)) * np.array([0.25, 0.55, 0.12])).astype(np.float32)
+    shapedirs = (rs.standard_normal((V, 3, num_betas + num_expressions)) * 0.01).astype(np.float32)
+    posedirs = (rs.standard_normal(((J - 1) * 9, V * 3)) * 0.005).astype(np.float32)
+    # joint regressor: each joint = convex combination of 32 random vertices
+    J_regressor = np.zeros((J, V), dtype=np.float32)
+    for j in range(J):
+        idx = rs.choice(V, 32, replace=False)
+        w = rs.uniform(0.1, 1.0, 32)
+        J_regressor[j, idx] = (w / w.sum()).astype(np.float32)
+    # skinning weights: nnz_per_vertex non-zeros per vertex, rows sum to one (real SMPL-X has <= 4)
+    weights = np.zeros((V, J), dtype=np.float32)
+    for v in range(V):
+        idx = rs.choice(J, nnz_per_vertex, replace=False)
+        w = rs.uniform(0.05, 1.0, nnz_per_vertex)
+        weights[v, idx] = (w / w.sum()).astype(np.float32)
+    faces = rs.randint(0, V, size=(20908, 3)).astype(np.int32)
+    lmk_faces_idx = rs.randint(0, faces.shape[0], size=51).astype(np.int32)
+    bary = rs.uniform(0.05, 1.0, size=(51, 3))
+    lmk_bary_coords = (bary / bary.sum(axis=1, keepdims=True)).astype(np.float32)
+    return dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, J_regressor=J_regressor,
+                parents=SMPLX_PARENTS.astype(np.int64), weights=weights, faces=faces, lmk_faces_idx=lmk_faces_idx,
+                lmk_bary_coords=lmk_bary_coords, extra_joint_vertex_ids=SMPLX_EXTRA_VERTEX_IDS.copy(),
+                num_betas=num_betas, num_expressions=num_expressions, model_type="smplx")
+
+
+def load_smplx_npz(path, num_betas=10, num_expressions=10):
+    """Build the asset dictionary from an official SMPLX_{NEUTRAL,MALE,FEMALE}.npz (smplx body_models.py
+    conventions: shapedirs[:, :, :num_betas] | [:, :, 300:300+num_expressions], posedirs reshaped to [486, V*3])."""
+    d = np.load(path, allow_pickle=True, encoding="latin1")
+    V = d["v_template"].shape[0]
+    sd = d["shapedirs"]
+    shapedirs = np.concatenate([sd[:, :, :num_betas], sd[:, :, 300:300 + num_expressions]], axis=2).astype(np.float32)
+    posedirs = np.reshape(d["posedirs"], [V * 3, -1]).T.astype(np.float32)
+    parents = d["kintree_table"][0].astype(np.int64)
+    parents[0] = -1
+    return dict(v_template=d["v_template"].astype(np.float32), shapedirs=shapedirs, posedirs=posedirs,
+                J_regressor=np.asarray(d["J_regressor"], dtype=np.float32), parents=parents,
+                weights=d["weights"].astype(np.float32), faces=d["f"].astype(np.int32),
+                lmk_faces_idx=d["lmk_faces_idx"].astype(np.int32), lmk_bary_coords=d["lmk_bary_coords"].astype(np.float32),
+                extra_joint_vertex_ids=SMPLX_EXTRA_VERTEX_IDS.copy(), num_betas=num_betas, num_expressions=num_expressions,
+                model_type="smplx")

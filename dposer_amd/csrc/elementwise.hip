@@ -472,6 +472,29 @@ hipError_t launch_dsm(const DsmArgs& a, int* nblocks, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <typename T> __global__ void __launch_bounds__(256) k_dres_from_dout(DresArgs a) {
+    const int qc = a.Cp >> 2;
+    const int64_t total = a.Bpad * qc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % a.Bpad;
+        const int c = (int)(i / a.Bpad) * 4;
+        f32x4 dr = {0.f, 0.f, 0.f, 0.f};
+        if (s < a.B && c < a.D) {
+            const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.labels[s], a.fourier) : 1.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c + r < a.D) dr[r] = a.dout[s * a.D + c + r] / usig;
+        }
+        store_quad_ft<T>(a.dres, s, c, a.Cp, dr);
+    }
+}
+hipError_t launch_dres_from_dout(const DresArgs& a, hipStream_t st) {
+    const int64_t total = a.Bpad * (a.Cp >> 2);
+    if (a.f32) hipLaunchKernelGGL(k_dres_from_dout<float>, dim3(grid_for(total)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_dres_from_dout<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // layout helpers
 // ------------------------------------------------------------------------------------------------
@@ -594,15 +617,15 @@ __global__ void __launch_bounds__(256) k_adam_ema(AdamArgs a) {
         cc = cc > 1.0f ? 1.0f : cc;
         coef = a.grad_scale * cc;
     }
-    const float step_size = a.lr / a.bc1;
+    const float step_size = a.step_size;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
         float p = a.p[i];
         const bool skip = (i >= a.skip_lo[0] && i < a.skip_hi[0]) || (i >= a.skip_lo[1] && i < a.skip_hi[1]);
         if (!skip) {
             const float g = a.g[i] * coef;
             float m = a.m[i], v = a.v[i];
-            m = m + (g - m) * (1.0f - a.beta1);                   // exp_avg.lerp_(grad, 1 - beta1)
-            v = v * a.beta2 + (1.0f - a.beta2) * (g * g);         // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+            m = m + (g - m) * a.one_minus_beta1;                  // exp_avg.lerp_(grad, 1 - beta1)
+            v = v * a.beta2 + a.one_minus_beta2 * (g * g);        // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
             const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
             p = p - step_size * (m / denom);                      // param.addcdiv_(exp_avg, denom, value=-step_size)
             a.m[i] = m;

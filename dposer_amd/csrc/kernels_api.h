@@ -152,6 +152,16 @@ struct DsmArgs {           // get_sde_loss_fn tail (losses.py:121-131) + d loss 
 };
 hipError_t launch_dsm(const DsmArgs& a, int* nblocks, hipStream_t st);
 
+struct DresArgs {          // d res = d out / used_sigmas  (backward of model.py:192-194), FT store
+    const float* dout;     // [B][D]
+    const float* labels;   // [B]
+    const float* sigmas;
+    void* dres;            // FT [Bpad][Cp]
+    int64_t B, Bpad;
+    int D, Cp, num_scales, scale_by_sigma, fourier, f32;
+};
+hipError_t launch_dres_from_dout(const DresArgs& a, hipStream_t st);
+
 // ---- layout helpers ---------------------------------------------------------------------------------
 // out FT [Cpad][Spad] = transpose of in FT [Spad][C]
 hipError_t launch_ft_transpose(int f32, const void* in, void* out, int64_t Spad, int C, hipStream_t st);
@@ -186,8 +196,9 @@ struct AdamArgs {          // losses.py:44-58 optimize_fn + torch.optim.Adam + e
     const float* sqnorm;   // device scalar: sum of g^2 over the whole flat gradient (before grad_scale)
     float grad_scale;      // applied to g before anything else (1/world_size)
     float grad_clip;       // < 0: disabled
-    float lr, beta1, beta2, eps;
-    float bc1, bc2_sqrt;   // 1 - beta1^t, sqrt(1 - beta2^t)
+    float step_size;       // lr / (1 - beta1^t)
+    float one_minus_beta1, beta2, one_minus_beta2, eps;
+    float bc2_sqrt;        // sqrt(1 - beta2^t)
     float ema_one_minus_decay;
 };
 hipError_t launch_adam_ema(const AdamArgs& a, hipStream_t st);

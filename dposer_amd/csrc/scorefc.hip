@@ -216,6 +216,11 @@ struct WgradPlan {
     int shape, ksplit;
     int64_t slab_off;   // element offset inside Ws::slabs
 };
+static int wgrad_shape(int n_rows_pad, int k_rows_pad) {
+    if (n_rows_pad < 128) return SHAPE_FINAL;
+    if (k_rows_pad < 128) return SHAPE_WIDE64;
+    return SHAPE_MID;
+}
 static int pick_ksplit(int64_t tiles, int64_t stages) {
     int ks = 1;
     while (ks < 32 && tiles * ks < 512 && stages % (ks * 2) == 0 && stages / (ks * 2) >= 4) ks *= 2;
@@ -275,17 +280,17 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         // slabs: worst case ksplit 32 is never reached for the big tensors; size exactly below
         const int64_t stages = Bpad / (h->KBS * 4);
         int64_t slab_elems = 0;
-        auto acc = [&](int64_t n_rows_pad, int64_t k_cols_pad, int ct, int st, int64_t numel) {
-            const int64_t tiles = (n_rows_pad / (ct * 32)) * (k_cols_pad / (st * 32));
+        auto acc = [&](int n_rows_pad, int k_rows_pad, int64_t numel) {
+            const int shape = wgrad_shape(n_rows_pad, k_rows_pad);
+            const int64_t tiles = (int64_t)(n_rows_pad / (shape_ct(shape) * 32)) * (k_rows_pad / (shape_st(shape) * 32));
             slab_elems += (int64_t)pick_ksplit(tiles, stages) * numel;
         };
         for (int l = 0; l < L; ++l) {
-            const bool wide = h->layer[l].kin_pad == 64;
-            acc(H, h->layer[l].kin_pad, 4, wide ? 2 : 4, (int64_t)H * h->layer[l].kin);
-            acc(H, E, 4, 4, (int64_t)H * E);
+            acc(H, h->layer[l].kin_pad, (int64_t)H * h->layer[l].kin);
+            acc(H, E, (int64_t)H * E);
         }
-        acc(h->Cp, H, 2, 4, (int64_t)h->D * H);
-        acc(E, E, 4, 4, (int64_t)E * E);
+        acc(h->Cp, H, (int64_t)h->D * H);
+        acc(E, E, (int64_t)E * E);
         w.slabs = (float*)take(slab_elems * 4);
     }
     w.total = p;
@@ -566,9 +571,7 @@ extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const vo
 // ------------------------------------------------------------------------------------------------
 static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n_valid, const void* inT, int k_rows_pad, int k_valid,
                      int64_t Bpad, float* slabs, int64_t& slab_cursor, int64_t numel, int64_t flat_off, ReduceJobs& rj, hipStream_t st) {
-    int shape = SHAPE_MID;
-    if (n_rows_pad < 128) shape = SHAPE_FINAL;
-    else if (k_rows_pad < 128) shape = SHAPE_WIDE64;
+    const int shape = wgrad_shape(n_rows_pad, k_rows_pad);
     const int ct = shape_ct(shape), stt = shape_st(shape);
     const int kb_total = (int)(Bpad / h->KBS);
     const int64_t stages = kb_total / 4;
@@ -590,59 +593,49 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
     return DPOSER_OK;
 }
 
-extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
-                                       const float* batch_x, const float* t_in, const float* z_in, float eps, uint64_t seed,
-                                       uint32_t step, const float* freq, const float* sigmas, float* flat_grad, float* loss, int64_t B,
-                                       void* stream) {
-    DP_TRY(check_common(h, flat, packed_, ws_, B));
-    DP_CHECK_ARG(sde && batch_x && freq && sigmas && flat_grad && loss, "null argument");
-    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused DSM step supports subVP / VP SDEs");
-    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused DSM step supports the positional embedding");
-    hipStream_t st = (hipStream_t)stream;
-    const char* packed = (const char*)packed_;
-    const int prec = h->f32 ? PREC_FP32 : PREC_BF16;
-    const int H = h->H, E = h->E, L = h->L, KBS = h->KBS;
-    Ws w;
-    layout_ws(h, B, DPOSER_WS_TRAIN, 0, (char*)ws_, w);
-    const int64_t Bpad = w.Bpad;
-    const SdeCfg sc = to_sde(sde);
-
-    // ---------------- forward (model.train(): dropout active) ----------------
-    PrepTrainArgs pa;
-    pa.x0 = batch_x; pa.t_in = t_in; pa.z_in = z_in; pa.freq = freq; pa.xin = w.xin; pa.emb = w.emb; pa.t_out = w.tbuf; pa.z_out = w.zbuf;
-    pa.B = B; pa.Bpad = Bpad; pa.D = h->D; pa.Dpad = h->Dpad; pa.E = E; pa.fourier = 0; pa.f32 = h->f32; pa.sde = sc; pa.eps = eps;
-    pa.seed = seed; pa.step = step;
-    DP_HIP_LAUNCH(launch_prep_train(pa, st));
-    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, w.upre, true, Bpad, st));
+// forward in training layout: every layer input / normalised activation is kept for the backward pass
+static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
+                              uint32_t step, hipStream_t st) {
+    const int L = h->L;
+    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, w.upre, true, w.Bpad, st));
     for (int l = 0; l < L; ++l) {
         const void* in = l == 0 ? (const void*)w.xin : (const void*)w.hbuf[l - 1];
         const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[l - 2] : nullptr;
-        DP_TRY(run_gn_layer(h, flat, packed, l, in, w.temb, nullptr, w.hbuf[l], resid, w.xhat[l], w.rstd[l], true, Bpad, seed, step, st));
+        // TRAIN epilogue keeps xhat / rstd; dropout only when the module is in train() mode
+        const LayerOff& lo = h->layer[l];
+        const int shape = main_shape(w.Bpad);
+        const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
+        GemmArgs g = gemm_args(packed + h->pk_wl[l], kx + ke, h->H / (shape_ct(shape) * 32), (int)(w.Bpad / (shape_st(shape) * 32)));
+        add_seg(g, in, kx);
+        add_seg(g, w.temb, ke);
+        GNParams p;
+        p.bias = reinterpret_cast<const float*>(packed + h->pk_bias_cat) + (int64_t)l * h->H;
+        p.gamma = flat + lo.gamma; p.beta = flat + lo.beta; p.out = w.hbuf[l]; p.resid = resid; p.xhat = w.xhat[l]; p.rstd = w.rstd[l];
+        p.H = h->H; p.drop = drop_cfg(h, dropout_on, l, seed, step);
+        DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, true, shape, g, p, st));
     }
-    DP_TRY(run_post(h, flat, packed, w.hbuf[L - 1], w.res, B, Bpad, st));
-    DsmArgs da;
-    da.res = w.res; da.t = w.tbuf; da.z = w.zbuf; da.sigmas = sigmas; da.dres = w.dres; da.loss_part = w.loss_part; da.B = B; da.Bpad = Bpad;
-    da.D = h->D; da.Dpad = h->Dpad; da.Cp = h->Cp; da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma;
-    da.f32 = h->f32; da.fourier = 0; da.grad_scale = (float)(1.0 / ((double)B * (double)h->D)); da.sde = sc;
-    int nb = 0;
-    DP_HIP_LAUNCH(launch_dsm(da, &nb, st));
-    DP_HIP_LAUNCH(launch_sum_partials(w.loss_part, nb, loss, st));
+    return run_post(h, flat, packed, w.hbuf[L - 1], w.res, B, w.Bpad, st);
+}
 
-    // ---------------- backward ----------------
+// backward from dres (FT [Bpad][Cp], zero on padded rows) to the flat parameter gradient and/or dx
+static int backward_core(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
+                         uint32_t step, float* flat_grad, float* dx, hipStream_t st) {
+    const int prec = h->f32 ? PREC_FP32 : PREC_BF16;
+    const int H = h->H, E = h->E, L = h->L, KBS = h->KBS;
+    const int64_t Bpad = w.Bpad;
+    const bool want_w = flat_grad != nullptr;
     ReduceJobs rj;
     rj.n = 0;
     int64_t slab_cursor = 0;
-    const int64_t part_rows_base = 0;
-    (void)part_rows_base;
-    // transposed copies shared by several wgrads
-    DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.temb, w.tembT, Bpad, E, st));
-    // post_dense: bias (column sums of dres), weight, dgrad
-    int n_chunks_post = 0;
-    DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, st));
-    DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, st));
-    DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.hbuf[L - 1], w.inT, Bpad, H, st));
-    DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.inT, H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, st));
-
+    int n_chunks_post = 0, n_chunks_se = 0;
+    if (want_w) {
+        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.temb, w.tembT, Bpad, E, st));
+        // post_dense: bias (column sums of dres) and weight
+        DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, st));
+        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, st));
+        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.hbuf[L - 1], w.inT, Bpad, H, st));
+        DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.inT, H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, st));
+    }
     const int gshape = gnbwd_shape(Bpad);
     const int ws_rows = (int)(Bpad / (shape_st(gshape) * 32)) * shape_ws(gshape);   // partial rows written by the dgrad epilogue
     for (int j = L - 1; j >= 0; --j) {
@@ -657,8 +650,9 @@ extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, co
         p.carry_in = (even && j < L - 1) ? w.carry[(j / 2 + 1) & 1] : nullptr;
         p.carry_out = (even && j >= 2) ? w.carry[(j / 2) & 1] : nullptr;
         p.xhat = w.xhat[j]; p.rstd = w.rstd[j]; p.gamma = flat + h->layer[j].gamma; p.beta = flat + h->layer[j].beta;
-        p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B; p.drop = drop_cfg(h, true, j, seed, step);
+        p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B; p.drop = drop_cfg(h, dropout_on, j, seed, step);
         DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st));
+        if (!want_w) continue;
         // parameter gradients of layer j
         DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dy[j], w.dyT, Bpad, H, st));
         const void* inT;
@@ -668,6 +662,15 @@ extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, co
         DP_TRY(run_wgrad(h, w.dyT, H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, st));
         DP_TRY(run_wgrad(h, w.dyT, H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, st));
     }
+    if (dx) {   // d loss / d x = dy_0 @ W_pre  (the time branch does not depend on x)
+        const int shape = final_shape(Bpad);
+        GemmArgs g = gemm_args(packed + h->pk_wlT[0], H / KBS, h->Dpad / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
+        add_seg(g, w.dy[0], H / KBS);
+        RowMajorParams p;
+        p.bias = nullptr; p.out = dx; p.ldc = h->D; p.C_valid = h->D; p.S_valid = B;
+        DP_HIP_LAUNCH(gemm_rowmajor(prec, shape, g, p, st));
+    }
+    if (!want_w) return DPOSER_OK;
     // time branch: dtemb = sum_l dy_l @ Wt_l ; dU = dtemb * silu'(u)
     {
         const int shape = main_shape(Bpad);
@@ -677,7 +680,6 @@ extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, co
         p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B;
         DP_HIP_LAUNCH(gemm_silu_bwd(prec, shape, g, p, st));
     }
-    int n_chunks_se = 0;
     DP_HIP_LAUNCH(launch_colsum(h->f32, w.dU, w.cs_part_se, Bpad, E, &n_chunks_se, st));
     DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dU, w.dUT, Bpad, E, st));
     DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, st));
@@ -698,29 +700,104 @@ extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, co
     }
     add_job(h->off_post_b, h->D, w.cs_part_post, h->Cp, n_chunks_post);
     add_job(h->off_se_b, E, w.cs_part_se, E, n_chunks_se);
-    if (rj.n > MAX_REDUCE_JOBS) return dposer_set_error(DPOSER_ERR_UNSUPPORTED, "too many reduce jobs");
     for (int i = 0; i < h->n_nograd; ++i)
         DP_CHECK_HIP(hipMemsetAsync(flat_grad + h->nograd_lo[i], 0, (h->nograd_hi[i] - h->nograd_lo[i]) * sizeof(float), st));
     DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, st));
     return DPOSER_OK;
 }
 
-extern "C" int dposer_adam_ema_clip_step(dposer_scorefc_t h, float* flat, const float* grad, float* m, float* v, float* ema, float lr,
-                                         float beta1, float beta2, float eps, float grad_clip, float grad_scale, int64_t adam_step,
-                                         float ema_decay, float* scratch, void* stream) {
-    DP_CHECK_ARG(h && flat && grad && m && v && scratch, "null argument");
+extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                       const float* batch_x, const float* t_in, const float* z_in, float eps, uint64_t seed,
+                                       uint32_t step, const float* freq, const float* sigmas, float* flat_grad, float* loss, int64_t B,
+                                       void* stream) {
+    DP_TRY(check_common(h, flat, packed_, ws_, B));
+    DP_CHECK_ARG(sde && batch_x && freq && sigmas && flat_grad && loss, "null argument");
+    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused DSM step supports subVP / VP SDEs");
+    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused DSM step supports the positional embedding");
+    hipStream_t st = (hipStream_t)stream;
+    const char* packed = (const char*)packed_;
+    Ws w;
+    layout_ws(h, B, DPOSER_WS_TRAIN, 0, (char*)ws_, w);
+    const int64_t Bpad = w.Bpad;
+    const SdeCfg sc = to_sde(sde);
+    PrepTrainArgs pa;
+    pa.x0 = batch_x; pa.t_in = t_in; pa.z_in = z_in; pa.freq = freq; pa.xin = w.xin; pa.emb = w.emb; pa.t_out = w.tbuf; pa.z_out = w.zbuf;
+    pa.B = B; pa.Bpad = Bpad; pa.D = h->D; pa.Dpad = h->Dpad; pa.E = h->E; pa.fourier = 0; pa.f32 = h->f32; pa.sde = sc; pa.eps = eps;
+    pa.seed = seed; pa.step = step;
+    DP_HIP_LAUNCH(launch_prep_train(pa, st));
+    DP_TRY(forward_core_train(h, flat, packed, w, B, true, seed, step, st));
+    DsmArgs da;
+    da.res = w.res; da.t = w.tbuf; da.z = w.zbuf; da.sigmas = sigmas; da.dres = w.dres; da.loss_part = w.loss_part; da.B = B; da.Bpad = Bpad;
+    da.D = h->D; da.Dpad = h->Dpad; da.Cp = h->Cp; da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma;
+    da.f32 = h->f32; da.fourier = 0; da.grad_scale = (float)(1.0 / ((double)B * (double)h->D)); da.sde = sc;
+    int nb = 0;
+    DP_HIP_LAUNCH(launch_dsm(da, &nb, st));
+    DP_HIP_LAUNCH(launch_sum_partials(w.loss_part, nb, loss, st));
+    return backward_core(h, flat, packed, w, B, true, seed, step, flat_grad, nullptr, st);
+}
+
+// ScoreModelFC.forward with everything kept for autograd (model.py:141-196); dropout when train_mode != 0
+extern "C" int dposer_scorefc_forward_train(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const float* x,
+                                            const float* labels, const float* freq, const float* sigmas, float* out, int64_t B,
+                                            int32_t train_mode, uint64_t seed, uint32_t step, void* stream) {
+    DP_TRY(check_common(h, flat, packed_, ws_, B));
+    DP_CHECK_ARG(x && labels && freq && sigmas && out, "null tensor argument");
+    hipStream_t st = (hipStream_t)stream;
+    const char* packed = (const char*)packed_;
+    Ws w;
+    layout_ws(h, B, DPOSER_WS_TRAIN, 0, (char*)ws_, w);
+    PrepArgs pa;
+    pa.x = x; pa.labels = labels; pa.freq = freq; pa.xin = w.xin; pa.emb = w.emb;
+    pa.B = B; pa.Bpad = w.Bpad; pa.D = h->D; pa.Dpad = h->Dpad; pa.E = h->E;
+    pa.fourier = h->d.embedding == DPOSER_EMB_FOURIER; pa.f32 = h->f32;
+    DP_HIP_LAUNCH(launch_prep_infer(pa, st));
+    DP_TRY(forward_core_train(h, flat, packed, w, B, train_mode != 0, seed, step, st));
+    OutModelArgs oa;
+    oa.res = w.res; oa.labels = labels; oa.sigmas = sigmas; oa.out = out; oa.B = B; oa.D = h->D; oa.Cp = h->Cp;
+    oa.num_scales = h->d.num_scales; oa.scale_by_sigma = h->d.scale_by_sigma; oa.fourier = pa.fourier;
+    DP_HIP_LAUNCH(launch_out_model(oa, st));
+    return DPOSER_OK;
+}
+
+// backward of dposer_scorefc_forward_train on the same workspace: d/d params (flat_grad, may be NULL)
+// and d/d x (dx [B, D], may be NULL) for an upstream gradient dout [B, D].
+extern "C" int dposer_scorefc_backward(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const float* labels,
+                                       const float* sigmas, const float* dout, float* flat_grad, float* dx, int64_t B,
+                                       int32_t train_mode, uint64_t seed, uint32_t step, void* stream) {
+    DP_TRY(check_common(h, flat, packed_, ws_, B));
+    DP_CHECK_ARG(labels && sigmas && dout, "null tensor argument");
+    hipStream_t st = (hipStream_t)stream;
+    const char* packed = (const char*)packed_;
+    Ws w;
+    layout_ws(h, B, DPOSER_WS_TRAIN, 0, (char*)ws_, w);
+    DresArgs da;
+    da.dout = dout; da.labels = labels; da.sigmas = sigmas; da.dres = w.dres; da.B = B; da.Bpad = w.Bpad; da.D = h->D; da.Cp = h->Cp;
+    da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma; da.fourier = h->d.embedding == DPOSER_EMB_FOURIER;
+    da.f32 = h->f32;
+    DP_HIP_LAUNCH(launch_dres_from_dout(da, st));
+    return backward_core(h, flat, packed, w, B, train_mode != 0, seed, step, flat_grad, dx, st);
+}
+
+extern "C" int dposer_adam_ema_clip_step(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n,
+                                         const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
+                                         double beta1, double beta2, double eps, double grad_clip, double grad_scale,
+                                         int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream) {
+    DP_CHECK_ARG(flat && grad && m && v && scratch, "null argument");
     DP_CHECK_ARG(adam_step >= 1, "adam_step counts from 1");
+    DP_CHECK_ARG(n_skip >= 0 && n_skip <= 2, "at most two no-gradient ranges");
     hipStream_t st = (hipStream_t)stream;
     int nb = 0;
-    DP_HIP_LAUNCH(launch_sqnorm(grad, h->nparams, scratch + 16, &nb, st));
+    DP_HIP_LAUNCH(launch_sqnorm(grad, n, scratch + 16, &nb, st));
     DP_HIP_LAUNCH(launch_sum_partials(scratch + 16, nb, scratch, st));
     AdamArgs a;
-    a.p = flat; a.g = grad; a.m = m; a.v = v; a.ema = ema; a.n = h->nparams;
-    for (int i = 0; i < 2; ++i) { a.skip_lo[i] = h->nograd_lo[i]; a.skip_hi[i] = h->nograd_hi[i]; }
-    a.sqnorm = scratch; a.grad_scale = grad_scale; a.grad_clip = grad_clip; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-    a.bc1 = (float)(1.0 - std::pow((double)beta1, (double)adam_step));
-    a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)adam_step));
-    a.ema_one_minus_decay = (float)(1.0 - (double)ema_decay);
+    a.p = flat; a.g = grad; a.m = m; a.v = v; a.ema = ema; a.n = n;
+    for (int i = 0; i < 2; ++i) { a.skip_lo[i] = i < n_skip ? skip_lo_host[i] : 0; a.skip_hi[i] = i < n_skip ? skip_hi_host[i] : 0; }
+    a.sqnorm = scratch; a.grad_scale = (float)grad_scale; a.grad_clip = (float)grad_clip;
+    const double bc1 = 1.0 - std::pow(beta1, (double)adam_step);
+    a.step_size = (float)(lr / bc1);                                   // torch: step_size = lr / bias_correction1
+    a.one_minus_beta1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.one_minus_beta2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(beta2, (double)adam_step));
+    a.ema_one_minus_decay = (float)ema_one_minus_decay;
     DP_HIP_LAUNCH(launch_adam_ema(a, st));
     return DPOSER_OK;
 }

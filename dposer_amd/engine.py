@@ -1,0 +1,105 @@
+"""Per-module owner of the C handle, packed weights and scratch workspaces of the HIP score path.
+
+PyTorch is used for device memory and streams only: every buffer is a torch tensor, every kernel
+is enqueued on ``torch.cuda.current_stream()`` through the C ABI (dposer_amd/_C.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Dict, Optional
+
+import torch
+
+from . import _C
+
+
+def positional_freq(embed_dim: int, max_positions: int = 10000) -> torch.Tensor:
+    """Frequencies of the sinusoidal embedding, evaluated with the reference's exact fp32 expression
+    (lib/algorithms/advanced/model.py:39-43) on the CPU so they are bit-identical to the reference's."""
+    half = embed_dim // 2
+    scale = math.log(max_positions) / (half - 1)
+    return torch.exp(torch.arange(half, dtype=torch.float32) * -scale)
+
+
+class ScoreEngine:
+    """One engine = one (module, precision) pair."""
+
+    def __init__(self, *, data_dim, hidden_dim, embed_dim, n_blocks, embedding, scale_by_sigma, num_scales,
+                 dropout_p, precision):
+        self.lib = _C.lib()
+        self.precision = precision
+        desc = _C.ScoreFCDesc(data_dim, hidden_dim, embed_dim, n_blocks,
+                              _C.EMB_FOURIER if embedding == "fourier" else _C.EMB_POSITIONAL,
+                              1 if scale_by_sigma else 0, num_scales,
+                              _C.PREC_FP32 if precision == "fp32" else _C.PREC_BF16, float(dropout_p))
+        h = C.c_void_p()
+        _C.check(self.lib.dposer_scorefc_create(C.byref(desc), C.byref(h)), "dposer_scorefc_create")
+        self.h = h
+        self.D, self.H, self.E = data_dim, hidden_dim, embed_dim
+        self.num_params = self.lib.dposer_scorefc_num_params(h)
+        n = self.lib.dposer_scorefc_num_tensors(h)
+        self.offsets = [self.lib.dposer_scorefc_tensor_offset(h, i) for i in range(n)]
+        self.numels = [self.lib.dposer_scorefc_tensor_numel(h, i) for i in range(n)]
+        lo = (C.c_int64 * 2)()
+        hi = (C.c_int64 * 2)()
+        k = self.lib.dposer_scorefc_nograd_ranges(h, lo, hi)
+        self.nograd = [(lo[i], hi[i]) for i in range(k)]
+        self._packed: Optional[torch.Tensor] = None
+        self._packed_bwd = False
+        self._ws: Dict[int, torch.Tensor] = {}
+        self.freq_cpu = positional_freq(embed_dim)
+        self._freq: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.dposer_scorefc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- buffers -------------------------------------------------------------------------------
+    def freq(self, device, fourier_W=None):
+        if fourier_W is not None:
+            return fourier_W
+        if self._freq is None or self._freq.device != device:
+            self._freq = self.freq_cpu.to(device)
+        return self._freq
+
+    def packed(self, flat: torch.Tensor, with_backward: bool, force: bool = True):
+        """(Re)pack the fp32 master weights into MFMA fragment order.  ``force=False`` reuses the
+        current packing (caller guarantees the weights did not change)."""
+        need = self.lib.dposer_scorefc_packed_bytes(self.h, 1)
+        if self._packed is None or self._packed.device != flat.device:
+            self._packed = torch.empty(need, dtype=torch.uint8, device=flat.device)
+            force = True
+        if force or (with_backward and not self._packed_bwd):
+            _C.check(self.lib.dposer_scorefc_pack(self.h, _C.ptr(flat), _C.ptr(self._packed), 1 if with_backward else 0,
+                                                  _C.stream_ptr()), "dposer_scorefc_pack")
+            self._packed_bwd = bool(with_backward)
+        return self._packed
+
+    def workspace(self, batch: int, mode: int, n_steps: int, device):
+        need = self.lib.dposer_scorefc_workspace_bytes(self.h, batch, mode, n_steps)
+        if need < 0:
+            raise _C.DPoserHipError("dposer_scorefc_workspace_bytes failed")
+        ws = self._ws.get(mode)
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._ws[mode] = ws
+        return ws
+
+
+def default_precision(config=None) -> str:
+    p = os.environ.get("DPOSER_PRECISION")
+    if p is None and config is not None:
+        try:
+            p = config.model.get("precision", None) if hasattr(config.model, "get") else None
+        except Exception:
+            p = None
+    p = (p or "bf16").lower()
+    if p not in ("bf16", "fp32"):
+        raise ValueError(f"unknown precision {p!r} (bf16 | fp32)")
+    return p

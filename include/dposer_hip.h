@@ -129,15 +129,29 @@ int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat_params, const 
                             float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
                             float* flat_grad, float* loss, int64_t batch, void* stream);
 
-/* optimize_fn + ema.update -- losses.py:44-58 (lr warm-up is computed by the caller), torch.optim.Adam
- * (losses.py:31-41), lib/algorithms/ema.py:32-51 -- one pass over flat fp32 buffers.
- *   grad_scale: multiplied into the gradient first (1/world_size after an all-reduce SUM);
- *   grad_clip < 0 disables clipping; adam_step = optimizer step count AFTER this update (>= 1);
- *   ema may be NULL; scratch >= 8 KiB floats for the norm partials. */
-int dposer_adam_ema_clip_step(dposer_scorefc_t h, float* flat_params, const float* flat_grad, float* exp_avg,
-                              float* exp_avg_sq, float* ema, float lr, float beta1, float beta2, float eps,
-                              float grad_clip, float grad_scale, int64_t adam_step, float ema_decay,
-                              float* scratch, void* stream);
+/* Differentiable ScoreModelFC.forward for torch.autograd (model.py:141-196): forward keeps every layer
+ * input / normalised activation in `ws` (DPOSER_WS_TRAIN layout); backward consumes the same `ws`.
+ *   train_mode != 0: dropout active (model.train()), mask = Philox(seed, step), recomputed in backward;
+ *   dout [B, D] upstream gradient; flat_grad [num_params] or NULL; dx [B, D] or NULL. */
+int dposer_scorefc_forward_train(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws,
+                                 const float* x, const float* labels, const float* freq, const float* sigmas,
+                                 float* out, int64_t batch, int32_t train_mode, uint64_t seed, uint32_t step, void* stream);
+int dposer_scorefc_backward(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws,
+                            const float* labels, const float* sigmas, const float* dout, float* flat_grad, float* dx,
+                            int64_t batch, int32_t train_mode, uint64_t seed, uint32_t step, void* stream);
+
+/* optimize_fn + ema.update -- losses.py:44-58 (the lr warm-up value is computed by the caller),
+ * torch.optim.Adam (losses.py:31-41), lib/algorithms/ema.py:32-51 -- ONE pass over flat fp32 buffers of n
+ * elements (parameters, gradient, exp_avg, exp_avg_sq, EMA shadow).
+ *   skip_lo/hi_host [n_skip <= 2]: HOST arrays of element ranges that have no gradient (Adam skipped,
+ *   EMA still applied: pre_dense_cond);  grad_scale: multiplied into the gradient first (1/world_size
+ *   after an all-reduce SUM);  grad_clip < 0 disables clip_grad_norm_;  adam_step = optimizer step count
+ *   AFTER this update (>= 1);  ema may be NULL;  ema_one_minus_decay = 1 - min(decay, (1+n)/(10+n));
+ *   scratch: >= 8 KiB floats. */
+int dposer_adam_ema_clip_step(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* ema,
+                              int64_t n, const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip,
+                              double lr, double beta1, double beta2, double eps, double grad_clip, double grad_scale,
+                              int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Body model  (lib/body_model/body_model.py:68-112 -> smplx.lbs, lib/utils/transforms.py:227-235)

@@ -75,12 +75,12 @@ def normals4(index, stream, offset, seed):
 
 
 def normal_matrix(rows, cols, stream, offset, seed):
-    """[rows, cols] N(0,1) matrix as the kernels draw it: flat element e = r*cols + c uses
-    counter index e // 4, lane e % 4."""
-    n = rows * cols
-    groups = (n + 3) // 4
-    z = normals4(np.arange(groups, dtype=np.uint64), stream, offset, seed).reshape(-1)[:n]
-    return z.reshape(rows, cols)
+    """[rows, cols] N(0,1) matrix as the kernels draw it: one counter per (sample, quad of 4 channels),
+    counter index = r * ceil(cols/4) + c // 4, lane c % 4 (dposer_amd/csrc/elementwise.hip)."""
+    qd = (cols + 3) // 4
+    idx = (np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(qd) + np.arange(qd, dtype=np.uint64)[None, :])
+    z = normals4(idx.reshape(-1), stream, offset, seed).reshape(rows, qd * 4)
+    return z[:, :cols]
 
 
 def uniform_t(rows, offset, seed, eps=1e-5, T=1.0):
@@ -94,19 +94,22 @@ def uniform_t(rows, offset, seed, eps=1e-5, T=1.0):
 
 
 def dropout_keep_mask(rows, channels, site, offset, seed, p):
-    """{0,1} keep mask [rows, channels] for dropout site ``site`` (0 = after pre_gnorm,
-    1..4 = block layers in order).  One Philox call covers 8 consecutive channels of one sample:
-    index = sample * (channels // 8) + channel // 8; the 8 lanes are the low/high 16 bits of
-    r0..r3 (lane 2j = low half of r_j, lane 2j+1 = high half).  keep <=> lane16 < floor((1-p)*65536)."""
+    """{0,1} keep mask [rows, channels] for dropout site ``site`` (0 = after pre_gnorm, 1.. = block
+    layers in order) exactly as dposer_amd/csrc/epilogues.h dropout_mask16 draws it.  Within a
+    GroupNorm group g of 32 channels, channel cl = 8q + 4hi + r belongs to lane-half ``hi`` and quad q;
+    counter index = sample*(channels/8) + 4g + 2hi + q//2; the 8 16-bit lanes of the call are
+    (low, high) halves of r0..r3; lane = (q%2)*4 + r.  keep <=> lane16 < floor((1-p)*65536)."""
     thr = np.uint32(int((1.0 - p) * 65536.0))
-    groups = channels // 8
-    idx = np.arange(rows * groups, dtype=np.uint64)
-    r = philox4x32_10((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32),
-                      (idx >> np.uint64(32)).astype(np.uint32),
-                      np.uint32(STREAM_DROPOUT0 + site), np.uint32(offset),
-                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    lanes = []
-    for w in r:
-        lanes += [w & np.uint32(0xFFFF), w >> np.uint32(16)]
-    keep = (np.stack(lanes, axis=-1) < thr).astype(np.float32)
-    return keep.reshape(rows, channels)
+    s = np.arange(rows, dtype=np.uint64)[:, None]
+    c = np.arange(channels, dtype=np.uint64)[None, :]
+    g, cl = c // np.uint64(32), c % np.uint64(32)
+    q, hi, r = cl // np.uint64(8), (cl % np.uint64(8)) // np.uint64(4), cl % np.uint64(4)
+    idx = s * np.uint64(channels // 8) + g * np.uint64(4) + hi * np.uint64(2) + q // np.uint64(2)
+    idx = np.broadcast_to(idx, (rows, channels)).reshape(-1)
+    w = philox4x32_10((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32),
+                      np.uint32(STREAM_DROPOUT0 + site), np.uint32(offset), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    w = np.stack(w, axis=-1)                                                  # [n, 4]
+    lane = np.broadcast_to((q % np.uint64(2)) * np.uint64(4) + r, (rows, channels)).reshape(-1).astype(np.int64)
+    word = np.take_along_axis(w, (lane // 2)[:, None], axis=1)[:, 0]
+    bits = np.where(lane % 2 == 0, word & np.uint32(0xFFFF), word >> np.uint32(16))
+    return (bits < thr).astype(np.float32).reshape(rows, channels)

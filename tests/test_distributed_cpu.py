@@ -1,0 +1,56 @@
+"""world_size-2 gloo tests of the data-parallel plumbing (CPU): flat-gradient all-reduce, shard bounds."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from dposer_amd import distributed as ddp
+    rk, ws, _ = ddp.init_from_env(backend="gloo")
+    assert (rk, ws) == (rank, world) and ddp.world_size() == world and ddp.rank() == rank
+    g = torch.full((1000,), float(rank + 1))
+    n = ddp.all_reduce_sum_(g)
+    flat = torch.arange(10.0) * (rank + 1)
+    ddp.broadcast_(flat, src=0)
+    lo, hi = ddp.shard_bounds(65536 + 3, world, rank)
+    out.put((rank, n, float(g[0]), float(flat.sum()), lo, hi))
+    ddp.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_and_shards():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [2, 2]
+    assert [r[2] for r in res] == [3.0, 3.0]                  # 1 + 2 on both ranks
+    assert [r[3] for r in res] == [45.0, 45.0]                # rank 0's buffer everywhere
+    assert (res[0][4], res[0][5], res[1][4], res[1][5]) == (0, 32770, 32770, 65539)
+
+
+def test_single_process_is_noop():
+    from dposer_amd import distributed as ddp
+    g = torch.ones(8)
+    assert ddp.all_reduce_sum_(g) == 1 and float(g.sum()) == 8.0
+    assert ddp.shard_bounds(10, 3, 0) == (0, 4) and ddp.shard_bounds(10, 3, 2) == (7, 10)

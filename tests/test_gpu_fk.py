@@ -1,0 +1,124 @@
+"""GPU parity tests of the body-model half: rotation conversions, FK joints, full LBS vs the numpy oracle
+(oracle/fk_ref.py; smplx LBS parity is UNPINNED -- see oracle/__init__.py) on the synthetic SMPL-X-shaped asset."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_common import DEV, t2n
+from helpers import load
+from oracle import fk_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def asset():
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    return make_synthetic_smplx_asset(seed=0)
+
+
+@pytest.fixture(scope="module")
+def bm(asset):
+    from dposer_amd.body_model.body_model import BodyModel
+    return BodyModel(asset, num_betas=10, num_expressions=10, model_type="smplx").to(DEV)
+
+
+def _poses(B, seed=0, scale=0.4):
+    return (np.random.RandomState(seed).standard_normal((B, 63)) * scale).astype(np.float32)
+
+
+def test_rot6d_matches_reference_golden():
+    from dposer_amd.utils.transforms import rot6d_to_mat3x3
+    g = load("g11_rot6d")
+    out = rot6d_to_mat3x3(torch.tensor(g["rot6d"], device=DEV))
+    assert np.abs(t2n(out) - g["rotmat"]).max() < 2e-6
+    assert rot6d_to_mat3x3(torch.zeros(0, 6, device=DEV)).shape == (0, 3, 3)
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 100000])
+def test_rodrigues_vs_oracle(n):
+    from dposer_amd.utils.transforms import batch_rodrigues
+    rs = np.random.RandomState(n)
+    aa = (rs.standard_normal((n, 3)) * 1.5).astype(np.float32)
+    aa[0] = 0.0                                                  # the singular direction the 1e-8 offset guards
+    out = t2n(batch_rodrigues(torch.tensor(aa, device=DEV)))
+    ref = fk_ref.batch_rodrigues(aa.astype(np.float64))
+    assert np.abs(out - ref).max() < 1e-5
+    assert np.abs(out @ out.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5   # orthonormal
+
+
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 1000])
+def test_fk_body_joints_vs_oracle(bm, asset, B):
+    pose = _poses(B, seed=B)
+    j = t2n(bm.fk_joints(torch.tensor(pose, device=DEV), n_joints=22))
+    _, ref, _, _ = fk_ref.smplx_forward(asset, pose.astype(np.float64), dtype=np.float64)
+    assert j.shape == (B, 22, 3)
+    assert np.abs(j - ref[:, :22]).max() < 1e-5                 # north_star: fp32 pose/vertex error <= 1e-5
+
+
+def test_fk_all_segments_transl_and_55_joints(bm, asset):
+    B = 130
+    rs = np.random.RandomState(9)
+    segs = dict(global_orient=rs.standard_normal((B, 3)) * 0.5, body_pose=_poses(B, 1), jaw_pose=rs.standard_normal((B, 3)) * 0.2,
+                leye_pose=rs.standard_normal((B, 3)) * 0.1, reye_pose=rs.standard_normal((B, 3)) * 0.1,
+                left_hand_pose=rs.standard_normal((B, 45)) * 0.3, right_hand_pose=rs.standard_normal((B, 45)) * 0.3)
+    transl = rs.standard_normal((B, 3))
+    dev = {k: torch.tensor(v.astype(np.float32), device=DEV) for k, v in segs.items()}
+    out = bm.bm(transl=torch.tensor(transl.astype(np.float32), device=DEV), joints_only=True, **dev)
+    _, ref, _, _ = fk_ref.smplx_forward(asset, segs["body_pose"].astype(np.float64), transl=transl,
+                                        **{k: v.astype(np.float64) for k, v in segs.items() if k != "body_pose"}, dtype=np.float64)
+    assert np.abs(t2n(out.joints) - ref[:, :55]).max() < 2e-5
+
+
+def test_fk_full_batch_property():
+    """B = 65536: rows agree with the same rows evaluated in a small batch (bit-exact), zero pose gives rest joints."""
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    a = make_synthetic_smplx_asset(seed=0)
+    bm = BodyModel(a).to(DEV)
+    pose = torch.tensor(_poses(65536, 5), device=DEV)
+    big = bm.fk_joints(pose)
+    small = bm.fk_joints(pose[777:777 + 100].contiguous())
+    assert torch.equal(big[777:877], small)
+    rest = bm.fk_joints(torch.zeros(3, 63, device=DEV))
+    assert np.abs(t2n(rest)[0] - (a["J_regressor"] @ a["v_template"])[:22]).max() < 1e-6
+
+
+@pytest.mark.parametrize("B", [1, 7, 130])
+def test_lbs_vertices_and_127_joints_vs_oracle(bm, asset, B):
+    pose = _poses(B, seed=100 + B)
+    with torch.no_grad():
+        out = bm(pose_body=torch.tensor(pose, device=DEV))
+    verts, joints, full_pose, _ = fk_ref.smplx_forward(asset, pose.astype(np.float64), dtype=np.float64)
+    assert out.v.shape == (B, 10475, 3) and out.Jtr.shape == (B, 127, 3)
+    assert np.abs(t2n(out.v) - verts).max() < 1e-5
+    assert np.abs(t2n(out.Jtr) - joints).max() < 1e-5
+    assert np.array_equal(t2n(out.full_pose), full_pose.astype(np.float32))
+    assert np.array_equal(t2n(out.body_joints), t2n(out.Jtr)[:22])          # batch-axis slice quirk (body_model.py:95)
+
+
+def test_lbs_with_betas_root_trans(bm, asset):
+    B = 5
+    rs = np.random.RandomState(4)
+    pose, betas = _poses(B, 3), rs.standard_normal((B, 10)).astype(np.float32)
+    root, trans = (rs.standard_normal((B, 3)) * 0.3).astype(np.float32), rs.standard_normal((B, 3)).astype(np.float32)
+    with torch.no_grad():
+        out = bm(pose_body=torch.tensor(pose, device=DEV), betas=torch.tensor(betas, device=DEV),
+                 root_orient=torch.tensor(root, device=DEV), trans=torch.tensor(trans, device=DEV))
+    verts, joints, _, _ = fk_ref.smplx_forward(asset, pose.astype(np.float64), betas=betas.astype(np.float64),
+                                               global_orient=root.astype(np.float64), transl=trans.astype(np.float64), dtype=np.float64)
+    assert np.abs(t2n(out.v) - verts).max() < 2e-5
+    assert np.abs(t2n(out.Jtr) - joints).max() < 2e-5
+
+
+def test_smplx_wrapper_joint_map(asset):
+    from dposer_amd.body_model.smpl import SMPLX
+    g = load("g9_tables")
+    sm = SMPLX(asset).to(DEV)
+    assert np.array_equal(sm.joint_map.numpy(), g["smplx_joint_map"])
+    pose = torch.tensor(_poses(4, 8), device=DEV)
+    with torch.no_grad():
+        o = sm(body_pose=pose)
+        full = sm.bm(body_pose=pose)
+    assert o.joints.shape == (4, 49, 3)
+    assert torch.equal(o.joints, full.joints[:, sm.joint_map.to(DEV)])

@@ -1,0 +1,168 @@
+"""CPU tests of the host logic: index tables (bit-exact vs the reference's goldens), masks, normaliser,
+config entry points, shard arithmetic, the C-ABI library's symbols, the flat-parameter module."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PARTS = ["left_leg", "right_leg", "left_arm", "right_arm", "trunk", "hands", "legs", "arms"]
+
+
+def test_index_tables_bit_exact():
+    from dposer_amd.body_model import constants, utils
+    g = load("g9_tables")
+    for part in PARTS:
+        assert np.array_equal(np.array(getattr(utils.BodyPartIndices, part)), g[f"part/{part}"])
+        assert np.array_equal(np.array(getattr(utils.BodySegIndices, part)), g[f"seg/{part}"])
+    assert list(g["joint_names"]) == constants.JOINT_NAMES
+    assert np.array_equal(np.array([constants.JOINT_MAP[n] for n in constants.JOINT_NAMES]), g["joint_map"])
+    for mt in ("smpl", "smplh", "smplx"):
+        assert np.array_equal(utils.smpl_to_openpose(mt), g[f"openpose/{mt}"])
+    assert np.array_equal(utils.skeleton_parents(22), g["parents22"])
+    assert np.array_equal(utils.get_smpl_skeleton(), g["skeleton"])
+    for perm in ("SMPL_JOINTS_FLIP_PERM", "SMPL_POSE_FLIP_PERM", "J24_FLIP_PERM", "J49_FLIP_PERM", "H36M_TO_J17", "H36M_TO_J14",
+                 "J24_TO_J17", "J24_TO_J14"):
+        assert np.array_equal(np.array(getattr(constants, perm)), g[f"const/{perm}"])
+    from dposer_amd.body_model.synthetic import SMPLX_PARENTS
+    assert np.array_equal(SMPLX_PARENTS[:22], g["parents22"])
+
+
+def test_smplx_joint_map_bit_exact():
+    from dposer_amd.body_model import constants
+    g = load("g9_tables")
+    jm = [constants.JOINT_MAP[i] for i in constants.JOINT_NAMES]
+    jm[:25] = constants.SMPLX_OPENPOSE_25
+    assert np.array_equal(np.array(jm), g["smplx_joint_map"])
+
+
+@pytest.mark.parametrize("rot_n", [3, 6])
+def test_create_mask(rot_n):
+    from dposer_amd.utils.misc import create_mask
+    g = load("g9_tables")
+    for part in PARTS:
+        poses = torch.zeros(4, 21 * rot_n)
+        mask, obs = create_mask(poses, part=part)
+        assert np.array_equal(mask[0].numpy().astype(np.uint8), g[f"mask/{part}/{rot_n}"])
+        assert torch.equal(obs * mask, poses * mask)
+
+
+def test_eval_sampler_shards():
+    from dposer_amd.dataset.EvaSampler import DistributedEvalSampler
+    g = load("g9_tables")
+
+    class DS:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    for total, world in ((103, 4), (16, 8), (7, 2), (100, 1)):
+        seen = []
+        for rank in range(world):
+            s = DistributedEvalSampler(DS(total), num_replicas=world, rank=rank, shuffle=False)
+            idx = np.array(list(iter(s)), dtype=np.int64)
+            assert np.array_equal(idx, g[f"eva/{total}/{world}/{rank}"])
+            assert len(s) == len(idx)
+            seen += list(idx)
+        assert sorted(seen) == list(range(total))
+
+
+def test_normalizer_and_misc():
+    from dposer_amd.dataset.AMASS import Posenormalizer
+    from dposer_amd.utils import misc
+    g = load("g10_normalizer")
+    stats = {k.split("/")[-1]: torch.tensor(g[k]) for k in g.files if k.startswith("stats/axis_normalize")}
+    raw = torch.tensor(g["raw"])
+    for mm in (False, True):
+        nz = Posenormalizer(stats, device="cpu", normalize=True, min_max=mm, rot_rep="axis")
+        n = nz.offline_normalize(raw)
+        assert np.array_equal(n.numpy(), g[f"norm_minmax{int(mm)}"])
+        assert np.array_equal(nz.offline_denormalize(n).numpy(), g[f"denorm_minmax{int(mm)}"])
+        assert np.array_equal(nz.offline_normalize(raw.reshape(4, 16, 63)).numpy(), g[f"norm3d_minmax{int(mm)}"])
+    g2 = load("g11_rot6d")
+    ts = torch.linspace(0.1, 0.9, 7)
+    assert np.array_equal(misc.linear_interpolation(ts, ts / 10, 6).numpy(), g2["lin_interp"])
+    assert np.allclose(misc.gaussian_smoothing(torch.tensor(g2["smooth_in"]), 5, 2.0).numpy(), g2["smooth_out"], atol=1e-6)
+
+
+def test_config_entry_points():
+    from dposer_amd.configs import load_config
+    for spec in ("configs/subvp/amass_scorefc_continuous.py", "configs.subvp.amass_scorefc_continuous.get_config"):
+        c = load_config(spec)
+        assert (c.model.HIDDEN_DIM, c.model.EMBED_DIM, c.model.N_BLOCKS, c.model.dropout) == (1024, 512, 2, 0.1)
+        assert (c.training.sde, c.sampling.predictor, c.sampling.corrector) == ("subvpsde", "euler_maruyama", "none")
+        assert (c.optim.lr, c.optim.warmup, c.optim.grad_clip, c.training.batch_size) == (2e-4, 5000, 1.0, 1280)
+
+
+def test_capi_exports_every_declared_symbol():
+    from dposer_amd import _C
+    hdr = open(os.path.join(ROOT, "include", "dposer_hip.h")).read()
+    declared = set(re.findall(r"\b(dposer_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_C.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/dposer_hip.h but not exported"
+    assert declared == set(_C.SIGNATURES), declared ^ set(_C.SIGNATURES)
+    assert _C.lib().dposer_abi_version() == 1
+
+
+def test_model_surface_and_flat_params():
+    from dposer_amd import _C
+    from dposer_amd.algorithms.advanced.model import ScoreModelFC
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    from dposer_amd.configs import load_config
+    from weights import scorefc_shapes
+    cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+    m = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=1024, embed_dim=512, n_blocks=2)
+    sd = m.state_dict()
+    expect = dict(scorefc_shapes())
+    expect["sigmas"] = (1000,)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == expect
+    assert [n for n, _ in m.named_parameters()] == [n for n, _ in scorefc_shapes()]
+    assert sum(p.numel() for p in m.parameters()) == 8277567
+    flat = m.flat_params()
+    assert flat.numel() == 8277567 and all(p.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in m.parameters())
+    m.post_dense.bias.data.fill_(3.0)                     # in-place writes go through to the flat buffer
+    assert float(flat[-63:].min()) == 3.0
+    ema = ExponentialMovingAverage(m.parameters(), 0.9999)
+    assert len(ema.shadow_params) == 36 and ema.flat_shadow_for(flat) is not None
+    sd2 = {k: torch.zeros_like(v) for k, v in sd.items()}
+    m.load_state_dict(sd2)                                # reference checkpoints load into the views
+    assert float(m.flat_params().abs().sum()) == 0.0
+    with pytest.raises(_C.DPoserHipError):                # no CPU fallback
+        m(torch.zeros(4, 63), torch.zeros(4))
+    with pytest.raises(_C.DPoserHipError):
+        ScoreModelFC(cfg, hidden_dim=64, embed_dim=32)._engine()
+
+
+def test_reference_import_paths():
+    import dposer_amd
+    dposer_amd.install_reference_aliases()
+    from lib.algorithms.advanced import losses, sampling, sde_lib  # noqa: F401
+    from lib.algorithms.advanced import utils as mutils  # noqa: F401
+    from lib.algorithms.advanced.model import ScoreModelFC  # noqa: F401
+    from lib.algorithms.ema import ExponentialMovingAverage  # noqa: F401
+    from lib.body_model.body_model import BodyModel  # noqa: F401
+    from lib.dataset.AMASS import N_POSES, Posenormalizer  # noqa: F401
+    from lib.utils.misc import create_mask  # noqa: F401
+    from lib.utils.generic import import_configs
+    assert import_configs("configs.subvp.amass_scorefc_continuous.get_config").model.HIDDEN_DIM == 1024
+    assert sampling.get_predictor("euler_maruyama") is sampling.EulerMaruyamaPredictor
+
+
+def test_philox_known_answer():
+    # Random123 known-answer test for Philox4x32-10: counter = key = 0, and the all-ones / pi vectors
+    from oracle.philox import philox4x32_10
+    r = philox4x32_10(0, 0, 0, 0, 0, 0)
+    assert [int(v) for v in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    r = philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)
+    assert [int(v) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    r = philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
+    assert [int(v) for v in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]

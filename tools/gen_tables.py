@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Extract the reference's integer index tables (pure data) into dposer_amd/body_model/tables.json.
+
+Run in the build container only (imports /root/reference read-only):  python tools/gen_tables.py
+Sources: lib/body_model/constants.py:34-131 (JOINT_NAMES, JOINT_MAP, flip permutations, selectors),
+lib/body_model/utils.py:11-61 (BODY_JOINT_NAMES, BodyPartIndices, BodySegIndices from
+smplx_vert_segmentation.json), :68-177 (smpl_to_openpose), :180-205 (get_smpl_skeleton),
+lib/body_model/smpl.py:55-57 (SMPL-X OpenPose joint list).  tests/test_tables.py pins the result
+bit-exactly against tests/golden/g9_tables.npz.
+"""
+import json
+import os
+import sys
+from unittest import mock
+
+sys.path.insert(0, "/root/reference")
+for _n in ["torchgeometry", "smplx", "smplx.utils", "smplx.body_models", "cv2"]:
+    sys.modules[_n] = mock.MagicMock()
+
+import lib.body_model.constants as C  # noqa: E402
+import lib.body_model.utils as U  # noqa: E402
+
+PARTS = ["left_leg", "right_leg", "left_arm", "right_arm", "trunk", "hands", "legs", "arms"]
+out = {
+    "JOINT_NAMES": list(C.JOINT_NAMES),
+    "JOINT_MAP": {k: int(v) for k, v in C.JOINT_MAP.items()},
+    "FOCAL_LENGTH": C.FOCAL_LENGTH if hasattr(C, "FOCAL_LENGTH") else None,
+    "IMG_RES": C.IMG_RES if hasattr(C, "IMG_RES") else None,
+    "IMG_NORM_MEAN": list(C.IMG_NORM_MEAN) if hasattr(C, "IMG_NORM_MEAN") else None,
+    "IMG_NORM_STD": list(C.IMG_NORM_STD) if hasattr(C, "IMG_NORM_STD") else None,
+    "BODY_JOINT_NAMES": list(U.BODY_JOINT_NAMES),
+    "BodyPartIndices": {p: [int(i) for i in getattr(U.BodyPartIndices, p)] for p in PARTS},
+    "BodySegIndices": {p: [int(i) for i in getattr(U.BodySegIndices, p)] for p in PARTS},
+    "SMPLX_OPENPOSE_25": [55, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65],
+    "smpl_to_openpose": {mt: [int(i) for i in U.smpl_to_openpose(mt)] for mt in ("smpl", "smplh", "smplx")},
+    "smpl_skeleton": [[int(a), int(b)] for a, b in U.get_smpl_skeleton()],
+}
+for perm in ("H36M_TO_J17", "H36M_TO_J14", "J24_TO_J17", "J24_TO_J14", "SMPL_JOINTS_FLIP_PERM", "SMPL_POSE_FLIP_PERM",
+             "J24_FLIP_PERM", "J49_FLIP_PERM"):
+    out[perm] = [int(i) for i in getattr(C, perm)]
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dposer_amd", "body_model", "tables.json")
+with open(path, "w") as f:
+    json.dump(out, f, separators=(",", ":"))
+print(path, os.path.getsize(path))
