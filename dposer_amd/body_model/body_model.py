@@ -54,7 +54,7 @@ class _SMPLXCore(nn.Module):
         # ELL form of the skinning weights
         w = np.asarray(a["weights"], dtype=np.float32)
         k = int((w != 0).sum(axis=1).max())
-        order = np.argsort(-(w != 0), axis=1, kind="stable")[:, :k]
+        order = np.argsort(-(w != 0).astype(np.int8), axis=1, kind="stable")[:, :k]
         self.register_buffer("skin_idx", torch.tensor(order.astype(np.int32)))
         self.register_buffer("skin_w", torch.tensor(np.take_along_axis(w, order, axis=1)))
         tri = np.asarray(a["faces"])[np.asarray(a["lmk_faces_idx"])]

@@ -18,6 +18,8 @@ def _launch_rot(fn_name, x, in_w):
     _C.require_gpu(x, fn_name + " input")
     x = x.reshape(-1, in_w).contiguous().float()
     out = torch.empty(x.shape[0], 3, 3, dtype=torch.float32, device=x.device)
+    if x.shape[0] == 0:
+        return out
     _C.check(getattr(_C.lib(), fn_name)(_C.ptr(x), _C.ptr(out), x.shape[0], _C.stream_ptr()), fn_name)
     return out
 
