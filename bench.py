@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the DPoser hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE score-network training step (BASELINE.json metric M1) on a global batch of 65536
+synthetic z-scored [B, 63] pose vectors: in-kernel perturbation (t ~ U, z ~ N), forward with dropout,
+DSM loss, full backward into the flat fp32 gradient, RCCL all-reduce (N > 1), global-norm clip +
+Adam + EMA.  The global batch is fixed as N grows ("B = 65536 @ 1/2/4/8 GPU") => strong scaling.
+Rank 0 prints ONE JSON line; besides the contract's keys it carries
+  roofline      -- live HIP-event timing of the dominant MFMA GEMM kernel over the timed region
+  cpu_baseline  -- the CPU oracle (oracle/score_ref.py, torch-CPU port of the reference path) on the host cores
+  extra         -- M2 (1000-step sub-VP sampling, samples/s) and M3 (SMPL-X FK joints, poses/s) of this run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GLOBAL_BATCH = 65536
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_poses(n, device, seed=42):
+    """rows of the reference's examples/toy_data.npz (shipped as a fixture) sampled with replacement,
+    z-scored with axis_normalize2."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g10_normalizer.npz"))
+    poses = torch.tensor(g["toy_pose_samples"])
+    mean, std = torch.tensor(g["stats/axis_normalize2/mean_poses"]), torch.tensor(g["stats/axis_normalize2/std_poses"])
+    idx = torch.randint(0, poses.shape[0], (n,), generator=torch.Generator().manual_seed(seed))
+    return ((poses[idx] - mean) / std).to(device), poses[idx].to(device)
+
+
+def cpu_baseline(budget_s=12.0):
+    """Reference-path CPU port (oracle) timed on the host cores: train step at the reference's default batch 1280."""
+    from oracle import score_ref as R
+    from dposer_amd.algorithms.advanced.model import ScoreModelFC
+    from dposer_amd.configs import load_config
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, 32)          # torch-CPU GEMMs at B=1280 thrash on a 256-thread host (measured: 81 s/step at 256 threads)
+    torch.set_num_threads(cores)
+    cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+    torch.manual_seed(42)
+    m = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=1024, embed_dim=512, n_blocks=2)
+    p = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    st = R.TrainState(p, R.param_names())
+    B = 1280
+    batch, _ = synthetic_poses(B, "cpu")
+    gen = torch.Generator().manual_seed(0)
+
+    def one():
+        t = torch.rand(B, generator=gen) * (1 - 1e-5) + 1e-5
+        z = torch.randn(B, 63, generator=gen)
+        masks = [(torch.rand(B, 1024, generator=gen) >= 0.1).float() for _ in range(5)]
+        R.train_step(st, R.SubVP(), batch, t, z, drop_masks=masks, drop_p=0.1)
+
+    t0 = time.perf_counter()
+    one()                                                   # warm-up (also sizes the sample)
+    warm = time.perf_counter() - t0
+    n_target = max(1, min(30, int(budget_s / max(warm, 1e-3))))
+    n, t0 = 0, time.perf_counter()
+    for _ in range(n_target):
+        one()
+        n += 1
+    el = time.perf_counter() - t0
+    return {"value": B * n / el, "unit": "poses/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps at B={B} (reference default batch), torch-CPU oracle, {torch.get_num_threads()} threads "
+                      f"(host reports {os.cpu_count()} CPUs)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH)
+    ap.add_argument("--sampler-steps", type=int, default=1000)
+    ap.add_argument("--no-extra", action="store_true", help="skip the sampler / FK measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16")
+    args = ap.parse_args()
+
+    from dposer_amd import _C
+    from dposer_amd import distributed as ddp
+    from dposer_amd.algorithms.advanced import losses, sampling, sde_lib
+    from dposer_amd.algorithms.advanced.model import ScoreModelFC
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    from dposer_amd.configs import load_config
+
+    rank, world, local_rank = ddp.init_from_env()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    B_local = args.global_batch // world
+
+    cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+    cfg.seed = 42
+    torch.manual_seed(42)                                   # run/train.py:414
+    model = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=cfg.model.HIDDEN_DIM, embed_dim=cfg.model.EMBED_DIM,
+                         n_blocks=cfg.model.N_BLOCKS)
+    model.precision = args.precision
+    model.to(dev)
+    model._rng_seed = 42 + rank                             # per-rank Philox streams
+    ddp.broadcast_(model.flat_params())
+    sde = sde_lib.subVPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
+    state = dict(optimizer=losses.get_optimizer(cfg, model.parameters()), model=model,
+                 ema=ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate), step=0)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+    lo, hi = ddp.shard_bounds(args.global_batch, world, rank)
+    batch_all, raw_all = synthetic_poses(args.global_batch, "cpu")
+    batch = batch_all[lo:hi].to(dev).contiguous()
+
+    for _ in range(args.warmup):
+        step_fn(state, batch)
+    ddp.barrier()
+    torch.cuda.synchronize()
+    _C.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step_fn(state, batch)
+    torch.cuda.synchronize()
+    ddp.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = _C.profile_collect()
+    _C.profile_enable(False)
+    loss = float(out["step_loss"])
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.global_batch * args.steps / elapsed
+
+    # ---- live roofline of the dominant GEMM kernel (HIP events on the launch stream, timed region only) ----
+    roofline = None
+    kernels = {}
+    if prof:
+        tot_ms = sum(v[0] for v in prof.values())
+        for name, (ms, cnt, fl) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+            kernels[name] = {"launches": int(cnt), "avg_us": ms / cnt * 1e3, "share_of_gemm_time": ms / tot_ms,
+                             "tflops": (fl / (ms * 1e-3)) / 1e12 if ms > 0 else None}
+        name, (ms, cnt, fl) = max(prof.items(), key=lambda kv: kv[1][0])
+        ach = (fl / (ms * 1e-3)) / 1e12
+        roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3,
+                    "flops_per_launch": fl / cnt, "gemm_time_share_of_step": tot_ms / (elapsed * 1e3)}
+
+    extra = {"train_loss_last_step": loss, "train_tflops_algorithmic": 42.59e6 * value / 1e12, "gemm_kernels": kernels}
+    if not args.no_extra:
+        # ---- M2: 1000-step Euler-Maruyama sampling of the local shard, no trajectory kept ----
+        model.eval()
+        sde_s = sde_lib.subVPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=args.sampler_steps)
+        fn = sampling.get_sampling_fn(cfg, sde_s, (B_local, 63), lambda v: v, 1e-3, device=dev)
+        ddp.barrier()
+        torch.cuda.synchronize()
+        _C.profile_enable(True)
+        t1 = time.perf_counter()
+        _, xs = fn(model, traj_stride=0)
+        torch.cuda.synchronize()
+        ddp.barrier()
+        t_s = time.perf_counter() - t1
+        sprof = _C.profile_collect()
+        _C.profile_enable(False)
+        if world > 1:
+            tt = torch.tensor([t_s], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            t_s = float(tt[0])
+        sps = args.global_batch / t_s
+        extra["sampler"] = {"samples_per_s": sps, "seconds": t_s, "steps": args.sampler_steps, "finite": bool(torch.isfinite(xs).all()),
+                            "tflops_algorithmic": 8.647e6 * args.sampler_steps * sps / 1e12}
+        if sprof:
+            name, (ms, cnt, fl) = max(sprof.items(), key=lambda kv: kv[1][0])
+            extra["sampler"]["dominant_kernel"] = {"kernel": name, "tflops": (fl / (ms * 1e-3)) / 1e12, "avg_us": ms / cnt * 1e3,
+                                                   "frac_of_mfma_peak": (fl / (ms * 1e-3)) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+        # ---- M3: SMPL-X forward kinematics, joints only ([B,63] -> [B,22,3]), HBM-bound: 516 B / pose ----
+        from dposer_amd.body_model.body_model import BodyModel
+        from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+        bm = BodyModel(make_synthetic_smplx_asset(seed=0)).to(dev)
+        nfk = 1 << 20
+        pose = raw_all[torch.randint(0, raw_all.shape[0], (nfk,), generator=torch.Generator().manual_seed(1))].to(dev).contiguous()
+        for _ in range(3):
+            bm.fk_joints(pose)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            bm.fk_joints(pose)
+        e1.record()
+        torch.cuda.synchronize()
+        fk_s = e0.elapsed_time(e1) * 1e-3 / 20
+        extra["fk_joints"] = {"poses_per_s_per_gpu": nfk / fk_s, "batch": nfk, "algorithmic_GBps": 516.0 * nfk / fk_s / 1e9,
+                              "frac_of_hbm_peak": 516.0 * nfk / fk_s / 1e9 / HBM_PEAK_GBS}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "poses/sec score-net train step (subVP DSM, ScoreModelFC) at global B=65536",
+            "value": value, "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "subVP denoising-score-matching train step (fwd+bwd+clip+Adam+EMA), ScoreModelFC H=1024 E=512 2 blocks, "
+                                   "z-scored toy-pose rows [B,63]", "global_batch": args.global_batch, "per_gpu_batch": B_local,
+                       "parallelism": f"dp{world}"},
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra}))
+    if ddp.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

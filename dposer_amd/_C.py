@@ -65,6 +65,10 @@ SIGNATURES = {
                                           vp, vp, i64, vp]),
     "dposer_adam_ema_clip_step": (C.c_int, [vp, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64,
                                             f64, f64, i64, f64, vp, vp]),
+    "dposer_profile_enable": (None, [i32]),
+    "dposer_profile_num_kinds": (i32, []),
+    "dposer_profile_collect": (C.c_int, [C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
+    "dposer_profile_kind_name": (None, [i32, C.c_char_p, i32]),
     "dposer_rot6d_to_rotmat": (C.c_int, [vp, vp, i64, vp]),
     "dposer_rodrigues": (C.c_int, [vp, vp, i64, vp]),
     "dposer_body_create": (C.c_int, [C.POINTER(BodyDesc), C.POINTER(i32), C.POINTER(vp)]),
@@ -120,3 +124,22 @@ def require_gpu(t, name="tensor"):
         raise DPoserHipError(
             f"{name} lives on {t.device}: dposer_amd runs the hot path only as HIP kernels on an AMD GPU "
             "(no CPU fallback). Move the module / tensors to 'cuda'.")
+
+
+def profile_enable(on: bool):
+    lib().dposer_profile_enable(1 if on else 0)
+
+
+def profile_collect():
+    """{kernel kind name: (total_ms, launches, algorithmic_flops)} of the GEMM launches since the last collect."""
+    l = lib()
+    n = l.dposer_profile_num_kinds()
+    ms, cnt, fl = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)()
+    check(l.dposer_profile_collect(ms, cnt, fl), "dposer_profile_collect")
+    out = {}
+    buf = C.create_string_buffer(128)
+    for k in range(n):
+        if cnt[k]:
+            l.dposer_profile_kind_name(k, buf, 128)
+            out[buf.value.decode()] = (ms[k], cnt[k], fl[k])
+    return out

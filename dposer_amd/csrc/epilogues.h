@@ -210,18 +210,23 @@ template <typename T> struct EpiPlainFT {
 // ----------------------------------------------------------------------------------------------
 // All-to-all butterfly: on entry every lane holds N partial values; on exit lane (l & 31) == i
 // holds the sum over the 32 lanes (same l >> 5) of value i.  31 shuffles for N = 32.
+template <int D> __device__ __forceinline__ void butterfly_step(float (&v)[32], int lane) {
+    // lanes with bit D set keep the upper half of the D*2 live values, the others the lower half
+    const bool up = (lane & D) != 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const float send = up ? v[i] : v[i + D];
+        const float keep = up ? v[i + D] : v[i];
+        v[i] = keep + __shfl_xor(send, D);
+    }
+}
 template <int N> __device__ __forceinline__ void butterfly_reduce32(float (&v)[N], int lane) {
     static_assert(N == 32, "N must be 32");
-#pragma unroll
-    for (int d = 16, n = 16; d >= 1; d >>= 1, n >>= 1) {
-        const bool up = (lane & d) != 0;
-#pragma unroll
-        for (int i = 0; i < n; ++i) {
-            const float send = up ? v[i] : v[i + n];
-            const float keep = up ? v[i + n] : v[i];
-            v[i] = keep + __shfl_xor(send, d);
-        }
-    }
+    butterfly_step<16>(v, lane);
+    butterfly_step<8>(v, lane);
+    butterfly_step<4>(v, lane);
+    butterfly_step<2>(v, lane);
+    butterfly_step<1>(v, lane);
 }
 
 // dgrad epilogue: acc = dL/d(out_l) contribution through the NEXT layer's weights.
@@ -244,6 +249,7 @@ struct GNBwdParams {
 };
 template <typename T> struct EpiGNBwd {
     typedef GNBwdParams Params;
+    static constexpr int kMinWaves = 2;   // keep two 256-thread workgroups per CU (register-heavy epilogue)
     template <int TC, int TS>
     __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int) {
         struct { const T* carry_in; T* carry_out; const T* xhat; const float *rstd, *gamma, *beta; T* dy; float* part; int H; int64_t S_valid; DropoutCfg drop; } p =

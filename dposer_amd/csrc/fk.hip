@@ -230,23 +230,29 @@ __device__ __forceinline__ void fk_chain(std::integer_sequence<int, Is...>, Xf (
 }
 
 // One lane = one pose.  NT lanes per block; pose rows and outputs are staged through LDS.
+// LDS row of a pose = 3*n_out floats (+1 pad to make the stride odd => conflict-free per-lane rows): only the
+// joints that are actually evaluated are staged, so a 22-joint body query needs 17 KiB per 64 poses, not 42.
 template <typename Kin, int NT> __global__ void __launch_bounds__(NT) k_fk_joints(FkArgs a) {
     constexpr int J = Kin::J;
     extern __shared__ float lds[];
     const int64_t item0 = (int64_t)blockIdx.x * NT;
     const int n_out = a.n_out;
-    // ---- stage the pose segments: LDS row = [J*3] axis-angle floats of one pose (stride odd) ----
-    constexpr int ROW = (J * 3) | 1;
+    const int ROW = (n_out * 3) | 1;
     for (int sg = 0; sg < FK_MAX_SEG; ++sg) {
         if (sg >= a.nseg) break;
-        const int width = a.seg_joints[sg] * 3;
-        const int col0 = a.seg_first[sg] * 3;
+        const int first = a.seg_first[sg];
+        if (first >= n_out) break;
+        const int gw = a.seg_joints[sg] * 3;                                    // floats per pose in global memory
+        const int width = (first + a.seg_joints[sg] <= n_out ? a.seg_joints[sg] : n_out - first) * 3;   // floats staged
+        const int col0 = first * 3;
         const float* g = a.seg[sg];
-        const int total = NT * width;
-        const int64_t base = item0 * width, limit = a.B * (int64_t)width;
-        for (int i = threadIdx.x; i < total; i += NT) {
-            const int64_t gi = base + i;
-            lds[(i / width) * ROW + col0 + (i % width)] = (g && gi < limit) ? g[gi] : 0.f;
+        // walk (row, col) incrementally: no integer division in the copy loop
+        int row = threadIdx.x / width, col = threadIdx.x % width;
+        while (row < NT) {
+            const int64_t b = item0 + row;
+            lds[row * ROW + col0 + col] = (g && b < a.B) ? g[b * gw + col] : 0.f;
+            col += NT;
+            while (col >= width) { col -= width; ++row; }
         }
     }
     __syncthreads();
@@ -261,9 +267,12 @@ template <typename Kin, int NT> __global__ void __launch_bounds__(NT) k_fk_joint
     // ---- posed joints: LDS rows (stride ROW) -> coalesced global stream ----
     {
         const int width = n_out * 3;
-        for (int i = threadIdx.x; i < NT * width; i += NT) {
-            const int64_t bb = item0 + i / width;
-            if (bb < a.B) a.joints[bb * a.joints_ld + (i % width)] = lds[(i / width) * ROW + (i % width)];
+        int r = threadIdx.x / width, col = threadIdx.x % width;
+        while (r < NT) {
+            const int64_t bb = item0 + r;
+            if (bb < a.B) a.joints[bb * a.joints_ld + col] = lds[r * ROW + col];
+            col += NT;
+            while (col >= width) { col -= width; ++r; }
         }
     }
 }
@@ -300,7 +309,7 @@ extern "C" void dposer_body_destroy(dposer_body_t h) { delete h; }
 
 template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t st) {
     constexpr int NT = 64;
-    const int lds_floats = NT * ((Kin::J * 3) | 1);
+    const int lds_floats = NT * ((a.n_out * 3) | 1);
     hipLaunchKernelGGL((k_fk_joints<Kin, NT>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
     return hipGetLastError();
 }

@@ -32,6 +32,7 @@ struct GemmArgs {
     int n_sblk;                     // sample block tiles in the grid
     int ksplit;                     // >1: reduction split over blockIdx.y (wgrad); each split gets
                                     //     seg_kblocks[0]/ksplit k-blocks of the (single) segment
+    double alg_flops;               // algorithmic FLOPs of this launch (2*M*N*K on the un-padded problem); profiling only
 };
 
 template <typename T> struct Mma;
@@ -71,9 +72,13 @@ struct GemmCfg {
     static_assert((CT * KB) % NW == 0 && (ST * KB) % NW == 0, "stage must split evenly over the waves");
 };
 
+// Register budget hint: epilogues may ask for >= kMinWaves waves per SIMD (caps the allocator at 512 / kMinWaves).
+template <typename Epi, typename = void> struct EpiMinWaves { static constexpr int value = 1; };
+template <typename Epi> struct EpiMinWaves<Epi, decltype((void)Epi::kMinWaves)> { static constexpr int value = Epi::kMinWaves; };
+
 // The kernel.  Epi::apply(params, acc, channel_base, sample_base, lane, wave-in-sample-dim ids)
 template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi>
-__global__ void __launch_bounds__(WC* WS * 64) gemm_ft_kernel(GemmArgs g, typename Epi::Params ep) {
+__global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_ft_kernel(GemmArgs g, typename Epi::Params ep) {
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
     typedef typename Mma<T>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

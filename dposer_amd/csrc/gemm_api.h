@@ -25,3 +25,11 @@ hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTPa
 hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st);
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st);
 hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st);
+
+// ---- optional per-launch profiling (HIP events on the launch stream; off by default) ------------------
+enum GemmEpiKind : int { EPI_GN = 0, EPI_GN_TRAIN, EPI_BIAS_SILU, EPI_ROWMAJOR, EPI_PLAIN_FT, EPI_GN_BWD, EPI_SILU_BWD, EPI_WGRAD, EPI_KINDS };
+constexpr int GEMM_PROF_KINDS = EPI_KINDS * 2 * 6;
+void gemm_prof_enable(int on);
+// synchronises the recorded events, accumulates them per kind and clears the record list
+int gemm_prof_collect(double* ms, long long* launches, double* flops);   // arrays of GEMM_PROF_KINDS
+void gemm_prof_kind_name(int kind, char* out, int n);

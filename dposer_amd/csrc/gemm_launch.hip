@@ -2,6 +2,58 @@
 // network uses.  Kept in its own translation unit: it dominates compile time.
 #include "gemm_api.h"
 
+#include <cstdio>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// launch profiler: one hipEvent pair per GEMM launch, recorded on the launch stream
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+struct Prof {
+    int enabled = 0;
+    std::vector<ProfRec> pool;
+    size_t used = 0;
+} g_prof;
+struct ProfScope {
+    ProfRec* r = nullptr;
+    hipStream_t st;
+    ProfScope(int kind, const GemmArgs& g, hipStream_t s) : st(s) {
+        if (!g_prof.enabled) return;
+        if (g_prof.used == g_prof.pool.size()) {
+            ProfRec n;
+            if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+            g_prof.pool.push_back(n);
+        }
+        r = &g_prof.pool[g_prof.used++];
+        r->kind = kind;
+        r->flops = g.alg_flops;
+        hipEventRecord(r->a, st);
+    }
+    ~ProfScope() { if (r) hipEventRecord(r->b, st); }
+};
+const char* kEpiNames[EPI_KINDS] = {"gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad"};
+const char* kShapeNames[6] = {"256x256", "128x128", "128x32", "64x128", "64x32", "128x64"};
+}   // namespace
+void gemm_prof_enable(int on) { g_prof.enabled = on; if (!on) g_prof.used = 0; }
+int gemm_prof_collect(double* ms, long long* launches, double* flops) {
+    for (int i = 0; i < GEMM_PROF_KINDS; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = 0; }
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        ProfRec& r = g_prof.pool[i];
+        if (hipEventSynchronize(r.b) != hipSuccess) return -1;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return -1;
+        ms[r.kind] += t; launches[r.kind] += 1; flops[r.kind] += r.flops;
+    }
+    g_prof.used = 0;
+    return 0;
+}
+void gemm_prof_kind_name(int kind, char* out, int n) {
+    const int epi = kind / 12, prec = (kind / 6) % 2, shape = kind % 6;
+    snprintf(out, n, "gemm_ft_kernel<%s,%s,%s>", prec ? "fp32" : "bf16", kShapeNames[shape], kEpiNames[epi]);
+}
+#define PROF(EPI) ProfScope _ps((EPI) * 12 + (prec == PREC_FP32 ? 6 : 0) + shape, g, st)
+
 
 // Each epilogue only instantiates the tilings it is used with (bit i = GemmShape i).
 constexpr unsigned M_BIG = 1u << SHAPE_BIG, M_MID = 1u << SHAPE_MID, M_SMALL = 1u << SHAPE_SMALL, M_FINAL = 1u << SHAPE_FINAL,
@@ -27,25 +79,32 @@ static hipError_t by_shape_masked(int shape, const GemmArgs& g, const typename E
 constexpr unsigned M_MAIN = M_BIG | M_MID | M_SMALL;
 
 hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st) {
+    PROF(train ? EPI_GN_TRAIN : EPI_GN);
     if (train) { typedef EpiGN<__bf16, true> A; typedef EpiGN<float, true> B; DISPATCH(A, B, M_MAIN); }
     typedef EpiGN<__bf16, false> A; typedef EpiGN<float, false> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_bias_silu(int prec, bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st) {
+    PROF(EPI_BIAS_SILU);
     if (train) { typedef EpiBiasSiLU<__bf16, true> A; typedef EpiBiasSiLU<float, true> B; DISPATCH(A, B, M_MAIN); }
     typedef EpiBiasSiLU<__bf16, false> A; typedef EpiBiasSiLU<float, false> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_rowmajor(int prec, int shape, const GemmArgs& g, const RowMajorParams& p, hipStream_t st) {
+    PROF(EPI_ROWMAJOR);
     typedef EpiRowMajor<__bf16> A; typedef EpiRowMajor<float> B; DISPATCH(A, B, M_MID | M_SMALL | M_FINAL | M_FINAL_S);
 }
 hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTParams& p, hipStream_t st) {
+    PROF(EPI_PLAIN_FT);
     typedef EpiPlainFT<__bf16> A; typedef EpiPlainFT<float> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st) {
+    PROF(EPI_GN_BWD);
     typedef EpiGNBwd<__bf16> A; typedef EpiGNBwd<float> B; DISPATCH(A, B, M_MID | M_SMALL);   // BIG spills: register-heavy epilogue
 }
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st) {
+    PROF(EPI_SILU_BWD);
     typedef EpiSiLUBwd<__bf16> A; typedef EpiSiLUBwd<float> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st) {
+    PROF(EPI_WGRAD);
     typedef EpiWgrad<__bf16> A; typedef EpiWgrad<float> B; DISPATCH(A, B, M_MID | M_FINAL | M_WIDE);
 }

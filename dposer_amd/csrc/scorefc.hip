@@ -306,9 +306,12 @@ extern "C" int64_t dposer_scorefc_workspace_bytes(dposer_scorefc_t h, int64_t ba
 // ------------------------------------------------------------------------------------------------
 // GEMM launch helpers
 // ------------------------------------------------------------------------------------------------
+static thread_local double g_next_flops = 0.0;   // algorithmic FLOPs of the next GEMM launch (profiling only)
 static GemmArgs gemm_args(const void* W, int w_stride_blocks, int n_cblk, int n_sblk) {
     GemmArgs g;
     std::memset(&g, 0, sizeof(g));
+    g.alg_flops = g_next_flops;
+    g_next_flops = 0.0;
     g.W = W;
     g.w_stride_blocks = w_stride_blocks;
     g.n_cblk = n_cblk;
@@ -323,6 +326,7 @@ static void add_seg(GemmArgs& g, const void* src, int kblocks) {
     g.ktot_blocks += kblocks;
 }
 
+static thread_local int64_t g_alg_batch = 0;   // un-padded batch of the running call (profiling only)
 static DropoutCfg drop_cfg(const dposer_scorefc_s* h, bool train, int site, uint64_t seed, uint32_t step) {
     DropoutCfg d;
     std::memset(&d, 0, sizeof(d));
@@ -346,6 +350,7 @@ static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* pack
     const int shape = main_shape(Bpad);
     const LayerOff& lo = h->layer[l];
     const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
+    g_next_flops = 2.0 * (double)g_alg_batch * h->H * (lo.kin + (temb ? h->E : 0));
     GemmArgs g = gemm_args(packed + h->pk_wl[l], kx + ke, h->H / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
     add_seg(g, in, kx);
     if (temb) add_seg(g, temb, ke);
@@ -365,6 +370,7 @@ static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* pack
 
 static int run_post(dposer_scorefc_s* h, const float* flat, const char* packed, const void* in, float* res, int64_t B, int64_t Bpad, hipStream_t st) {
     const int shape = final_shape(Bpad);
+    g_next_flops = 2.0 * (double)B * h->D * h->H;
     GemmArgs g = gemm_args(packed + h->pk_wpost, h->H / h->KBS, h->Cp / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
     add_seg(g, in, h->H / h->KBS);
     RowMajorParams p;
@@ -381,6 +387,7 @@ static int run_post(dposer_scorefc_s* h, const float* flat, const char* packed, 
 static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, const void* emb, void* temb, void* upre, bool train,
                     int64_t Bpad, hipStream_t st) {
     const int shape = main_shape(Bpad);
+    g_next_flops = 2.0 * (double)g_alg_batch * h->E * h->E;
     GemmArgs g = gemm_args(packed + h->pk_wse, h->E / h->KBS, h->E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
     add_seg(g, emb, h->E / h->KBS);
     BiasSiLUParams p;
@@ -407,6 +414,7 @@ extern "C" int dposer_scorefc_forward(dposer_scorefc_t h, const float* flat, con
                                       const float* labels, const float* freq, const float* sigmas, float* out, int64_t B,
                                       void* stream) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
+    g_alg_batch = B;
     DP_CHECK_ARG(x && labels && freq && sigmas && out, "null tensor argument");
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
@@ -488,6 +496,7 @@ extern "C" int dposer_em_sampler(dposer_scorefc_t h, const float* flat, const vo
                                  const float* mask, const float* noise, uint64_t seed, float* traj, int32_t traj_stride,
                                  const float* freq, const float* sigmas, int64_t B, void* stream) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
+    g_alg_batch = B;
     DP_CHECK_ARG(sde && x && x_mean && timesteps_host && freq && sigmas, "null argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused sampler supports subVP / VP SDEs");
     DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused sampler supports the positional embedding");
@@ -542,6 +551,7 @@ extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const vo
                                  float* loss, uint64_t seed, uint32_t step, const float* freq, const float* sigmas, int64_t B,
                                  void* stream) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
+    g_alg_batch = B;
     DP_CHECK_ARG(sde && x0 && loss && freq && sigmas, "null argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "prior loss supports subVP / VP SDEs");
     DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "prior loss supports the positional embedding");
@@ -577,6 +587,7 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
     const int64_t stages = kb_total / 4;
     const int n_cblk = n_rows_pad / (ct * 32), n_sblk = k_rows_pad / (stt * 32);
     const int ks = pick_ksplit((int64_t)n_cblk * n_sblk, stages);
+    g_next_flops = 2.0 * (double)g_alg_batch * n_valid * k_valid;
     GemmArgs g = gemm_args(dyT, kb_total, n_cblk, n_sblk);
     add_seg(g, inT, kb_total);
     g.ksplit = ks;
@@ -605,6 +616,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         const LayerOff& lo = h->layer[l];
         const int shape = main_shape(w.Bpad);
         const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
+        g_next_flops = 2.0 * (double)B * h->H * (lo.kin + h->E);
         GemmArgs g = gemm_args(packed + h->pk_wl[l], kx + ke, h->H / (shape_ct(shape) * 32), (int)(w.Bpad / (shape_st(shape) * 32)));
         add_seg(g, in, kx);
         add_seg(g, w.temb, ke);
@@ -643,6 +655,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         const bool from_post = (j == L - 1);
         const void* Wt = packed + (from_post ? h->pk_wpostT : h->pk_wlT[j + 1]);
         const int kblocks = (from_post ? h->Cp : H) / KBS;
+        g_next_flops = 2.0 * (double)B * H * (from_post ? h->D : H);
         GemmArgs g = gemm_args(Wt, kblocks, H / (shape_ct(gshape) * 32), (int)(Bpad / (shape_st(gshape) * 32)));
         add_seg(g, from_post ? (const void*)w.dres : (const void*)w.dy[j + 1], kblocks);
         GNBwdParams p;
@@ -664,6 +677,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     }
     if (dx) {   // d loss / d x = dy_0 @ W_pre  (the time branch does not depend on x)
         const int shape = final_shape(Bpad);
+        g_next_flops = 2.0 * (double)B * H * h->D;
         GemmArgs g = gemm_args(packed + h->pk_wlT[0], H / KBS, h->Dpad / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
         add_seg(g, w.dy[0], H / KBS);
         RowMajorParams p;
@@ -674,6 +688,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     // time branch: dtemb = sum_l dy_l @ Wt_l ; dU = dtemb * silu'(u)
     {
         const int shape = main_shape(Bpad);
+        g_next_flops = 2.0 * (double)B * E * L * H;
         GemmArgs g = gemm_args(packed + h->pk_wtT_all, L * H / KBS, E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
         for (int l = 0; l < L; ++l) add_seg(g, w.dy[l], H / KBS);
         SiLUBwdParams p;
@@ -711,6 +726,7 @@ extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, co
                                        uint32_t step, const float* freq, const float* sigmas, float* flat_grad, float* loss, int64_t B,
                                        void* stream) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
+    g_alg_batch = B;
     DP_CHECK_ARG(sde && batch_x && freq && sigmas && flat_grad && loss, "null argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused DSM step supports subVP / VP SDEs");
     DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused DSM step supports the positional embedding");
@@ -741,6 +757,7 @@ extern "C" int dposer_scorefc_forward_train(dposer_scorefc_t h, const float* fla
                                             const float* labels, const float* freq, const float* sigmas, float* out, int64_t B,
                                             int32_t train_mode, uint64_t seed, uint32_t step, void* stream) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
+    g_alg_batch = B;
     DP_CHECK_ARG(x && labels && freq && sigmas && out, "null tensor argument");
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
@@ -765,6 +782,7 @@ extern "C" int dposer_scorefc_backward(dposer_scorefc_t h, const float* flat, co
                                        const float* sigmas, const float* dout, float* flat_grad, float* dx, int64_t B,
                                        int32_t train_mode, uint64_t seed, uint32_t step, void* stream) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
+    g_alg_batch = B;
     DP_CHECK_ARG(labels && sigmas && dout, "null tensor argument");
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
@@ -801,3 +819,14 @@ extern "C" int dposer_adam_ema_clip_step(float* flat, const float* grad, float* 
     DP_HIP_LAUNCH(launch_adam_ema(a, st));
     return DPOSER_OK;
 }
+
+// ---- profiling hooks ------------------------------------------------------------------------------------
+extern "C" void dposer_profile_enable(int32_t on) { gemm_prof_enable(on); }
+extern "C" int32_t dposer_profile_num_kinds(void) { return GEMM_PROF_KINDS; }
+extern "C" int dposer_profile_collect(double* ms_host, int64_t* launches_host, double* flops_host) {
+    DP_CHECK_ARG(ms_host && launches_host && flops_host, "null argument");
+    if (gemm_prof_collect(ms_host, reinterpret_cast<long long*>(launches_host), flops_host) != 0)
+        return dposer_set_error(DPOSER_ERR_HIP, "dposer_profile_collect: event query failed");
+    return DPOSER_OK;
+}
+extern "C" void dposer_profile_kind_name(int32_t kind, char* out, int32_t n) { gemm_prof_kind_name(kind, out, n); }

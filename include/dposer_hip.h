@@ -153,6 +153,15 @@ int dposer_adam_ema_clip_step(float* flat_params, const float* flat_grad, float*
                               double lr, double beta1, double beta2, double eps, double grad_clip, double grad_scale,
                               int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream);
 
+/* Per-launch GEMM timing (HIP events recorded on the launch stream around every MFMA GEMM launch; off by
+ * default).  collect() synchronises the recorded events and returns, per kernel kind, the summed
+ * duration [ms], launch count and algorithmic FLOPs (2*M*N*K of the un-padded problem); arrays of
+ * dposer_profile_num_kinds() entries in HOST memory.  Used by bench.py for the live roofline. */
+void dposer_profile_enable(int32_t on);
+int32_t dposer_profile_num_kinds(void);
+int dposer_profile_collect(double* ms_host, int64_t* launches_host, double* flops_host);
+void dposer_profile_kind_name(int32_t kind, char* out, int32_t n);
+
 /* ------------------------------------------------------------------------------------------
  * Body model  (lib/body_model/body_model.py:68-112 -> smplx.lbs, lib/utils/transforms.py:227-235)
  * ---------------------------------------------------------------------------------------- */
