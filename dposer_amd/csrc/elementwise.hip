@@ -119,11 +119,13 @@ hipError_t launch_bias_cat(const BiasCatJobs& j, const float* flat, float* dst, 
 // ------------------------------------------------------------------------------------------------
 template <typename T> __global__ void __launch_bounds__(256) k_prep_infer(PrepArgs a) {
     const int qx = a.Dpad >> 2, qe = a.emb ? (a.E >> 2) : 0;
-    const int64_t total = a.Bpad * (qx + qe);
+    const int64_t nx = a.Bpad * qx;
+    const int64_t total = nx + a.Bpad * qe;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        // sample index fastest so that consecutive lanes hit consecutive 16-B chunks of an FT block
-        const int64_t s = i % a.Bpad;
-        const int q = (int)(i / a.Bpad);
+        // x part: quad index fastest (consecutive lanes read consecutive floats of one row-major pose);
+        // embedding part: sample index fastest (consecutive lanes write consecutive 16-B chunks of an FT block)
+        const int64_t s = i < nx ? i / qx : (i - nx) % a.Bpad;
+        const int q = i < nx ? (int)(i % qx) : qx + (int)((i - nx) / a.Bpad);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (q < qx) {
             const int c = q * 4;
@@ -162,10 +164,11 @@ template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTr
     const PrepTrainArgs& a = d.a;
     const int qx = a.Dpad >> 2, qe = a.E >> 2;
     const int QD = (a.D + 3) >> 2;
-    const int64_t total = a.Bpad * (qx + qe);
+    const int64_t nx = a.Bpad * qx;
+    const int64_t total = nx + a.Bpad * qe;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = i % a.Bpad;
-        const int q = (int)(i / a.Bpad);
+        const int64_t s = i < nx ? i / qx : (i - nx) % a.Bpad;
+        const int q = i < nx ? (int)(i % qx) : qx + (int)((i - nx) / a.Bpad);
         float t = a.eps;
         if (s < a.B) {
             if (a.t_in) t = a.t_in[s];
@@ -282,8 +285,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_em_update(EmDev d
     float mcn = 0.f, sdn = 0.f;
     if (a.t_next >= 0.f) { const float l2 = sde_lmc(d.sde, a.t_next); mcn = expf(l2); sdn = sde_std(d.sde, l2); }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = i % a.Bpad;
-        const int q = (int)(i / a.Bpad);
+        const int64_t s = i / qx;              // quad index fastest: row-major [B][D] streams are read/written contiguously
+        const int q = (int)(i % qx);
         const int c = q * 4;
         f32x4 xn = {0.f, 0.f, 0.f, 0.f};
         if (s < a.B && c < a.D) {
@@ -360,8 +363,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_perturb_shared(Pe
     const float mc = expf(lmc), sd = sde_std(d.sde, lmc);
     const int64_t total = a.Bpad * qx;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = i % a.Bpad;
-        const int q = (int)(i / a.Bpad);
+        const int64_t s = i / qx;
+        const int q = (int)(i % qx);
         const int c = q * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (s < a.B && c < a.D) {
@@ -438,8 +441,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_dsm(DsmDev d) {
     const int64_t total = a.Bpad * qc;
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = i % a.Bpad;
-        const int c = (int)(i / a.Bpad) * 4;
+        const int64_t s = i / qc;
+        const int c = (int)(i % qc) * 4;
         f32x4 dr = {0.f, 0.f, 0.f, 0.f};
         if (s < a.B && c < a.D) {
             const float t = a.t[s];
@@ -476,8 +479,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_dres_from_dout(Dr
     const int qc = a.Cp >> 2;
     const int64_t total = a.Bpad * qc;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = i % a.Bpad;
-        const int c = (int)(i / a.Bpad) * 4;
+        const int64_t s = i / qc;
+        const int c = (int)(i % qc) * 4;
         f32x4 dr = {0.f, 0.f, 0.f, 0.f};
         if (s < a.B && c < a.D) {
             const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.labels[s], a.fourier) : 1.0f;
@@ -562,9 +565,33 @@ hipError_t launch_colsum(int f32, const void* in, float* part, int64_t Spad, int
 // gradient finalisation and optimizer
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const float* scratch, float* grad) {
+    __shared__ float red[8][32];
     ReduceJob j = jobs.job[0];
     for (int i = 1; i < MAX_REDUCE_JOBS; ++i)
         if (i == (int)blockIdx.y) j = jobs.job[i];
+    if (j.nsrc > 64) {
+        // many partial rows, few elements (GroupNorm / bias partials): 32 elements x 8 source slices per block,
+        // fixed summation order => deterministic
+        const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        for (int64_t e0 = (int64_t)blockIdx.x * 32; e0 < j.count; e0 += (int64_t)gridDim.x * 32) {
+            const int64_t e = e0 + el;
+            float acc = 0.f;
+            if (e < j.count) {
+                const float* p = scratch + j.src_off + e;
+                for (int k = sl; k < j.nsrc; k += 8) acc += p[(int64_t)k * j.src_stride];
+            }
+            __syncthreads();
+            red[sl][el] = acc;
+            __syncthreads();
+            if (sl == 0 && e < j.count) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t += red[k][el];
+                grad[j.dst_off + e] = t;
+            }
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < j.count; e += (int64_t)gridDim.x * blockDim.x) {
         const float* p = scratch + j.src_off + e;
         float acc = 0.f;

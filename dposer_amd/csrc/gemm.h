@@ -57,6 +57,10 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// s_waitcnt immediate for "vmcnt(N) only" on gfx9-family encodings: vmcnt = [15:14|3:0], expcnt [6:4], lgkmcnt [11:8]
+constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+constexpr int waitcnt_vm_lgkm0(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0x0 << 8); }
+
 template <typename T, int WC, int WS, int TC, int TS, int KB>
 struct GemmCfg {
     static constexpr int NW = WC * WS;
@@ -65,7 +69,7 @@ struct GemmCfg {
     static constexpr int ST = WS * TS;   // 32-sample tiles per block
     static constexpr int BLOCKS_PER_STAGE = (CT + ST) * KB;
     static constexpr int STAGE_BYTES = BLOCKS_PER_STAGE * 1024;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // GLDS == 3 uses 3 * STAGE_BYTES (see launch_gemm)
     static constexpr int LPW_A = CT * KB / NW;   // 1-KiB weight blocks copied per wave per stage
     static constexpr int LPW_B = ST * KB / NW;   // 1-KiB activation blocks copied per wave per stage
     static constexpr int LPW = LPW_A + LPW_B;
@@ -77,7 +81,8 @@ template <typename Epi, typename = void> struct EpiMinWaves { static constexpr i
 template <typename Epi> struct EpiMinWaves<Epi, decltype((void)Epi::kMinWaves)> { static constexpr int value = Epi::kMinWaves; };
 
 // The kernel.  Epi::apply(params, acc, channel_base, sample_base, lane, wave-in-sample-dim ids)
-template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi>
+// GLDS: 0 = register staging, 1 = global_load_lds double buffer, 3 = global_load_lds 3-deep ring with counted vmcnt
+template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int GLDS = 0>
 __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_ft_kernel(GemmArgs g, typename Epi::Params ep) {
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
     typedef typename Mma<T>::Frag Frag;
@@ -169,6 +174,36 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
             *reinterpret_cast<u32x4*>(smem + buf * C::STAGE_BYTES + (blk << 10) + lane * 16) = stg[C::LPW_A + i];
         }
     };
+    // direct-to-LDS staging (global_load_lds_dwordx4): the fragment-tiled HBM image IS the LDS image, so a wave
+    // copies a 1-KiB block with one instruction (LDS address = wave-uniform base + lane*16), no VGPR round trip.
+    auto fetch_glds = [&](int buf) __attribute__((always_inline)) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+        for (int i = 0; i < C::LPW_A; ++i) {
+            const int blk = wave + i * C::NW;
+            const int rb = blk / KB, kb = blk % KB;
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(g.W) +
+                                     (((int64_t)(cblk * C::CT + rb) * g.w_stride_blocks + w_kb + kb) << 10);
+            __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + (blk << 10)), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < C::LPW_B; ++i) {
+            const int blk = wave + i * C::NW;
+            const int rb = blk / KB, kb = blk % KB;
+            const unsigned char* p = sbase + (((int64_t)(sblk * C::ST + rb) * seg_total + seg_kb + kb) << 10);
+            __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + ((C::CT * KB + blk) << 10)), 16, 0, 0);
+        }
+        seg_kb += KB;
+        w_kb += KB;
+        if (seg_kb >= seg_end && seg + 1 < g.nseg) {
+            ++seg;
+            seg_kb = 0;
+            seg_total = seg_blocks(seg);
+            seg_end = seg_total;
+            sbase = seg_ptr(seg);
+        }
+    };
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const unsigned char* a_base = smem + buf * C::STAGE_BYTES + ((wc * TC * KB) << 10) + lane * 16;
         const unsigned char* b_base = smem + buf * C::STAGE_BYTES + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
@@ -187,32 +222,62 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     };
 
     // ---- software pipeline: global -> regs (next stage) overlaps MFMA on the current stage -----
-    fetch();
-    commit(0);
-    __syncthreads();
-    for (int t = 0; t < nstages; ++t) {
-        const bool more = (t + 1 < nstages);
-        if (more) fetch();
-        compute(t & 1);
-        if (more) commit((t + 1) & 1);
+    if constexpr (GLDS == 3) {
+        // 3-deep LDS ring, prefetch distance 2: the DMA of stage t+1 stays in flight across the barrier of stage t
+        // (raw s_barrier + counted vmcnt; __syncthreads() would drain it).
+        fetch_glds(0);
+        if (nstages > 1) fetch_glds(1);
+        int buf = 0;
+        for (int t = 0; t < nstages; ++t) {
+            if (t + 1 < nstages) __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(C::LPW));   // stage t landed, t+1 may fly
+            else __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 2 < nstages) fetch_glds(buf >= 1 ? buf - 1 : 2);                       // (t + 2) % 3
+            compute(buf);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    } else if constexpr (GLDS == 1) {
+        fetch_glds(0);
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): stage 0 landed in LDS
         __syncthreads();
+        for (int t = 0; t < nstages; ++t) {
+            if (t + 1 < nstages) fetch_glds((t + 1) & 1);
+            compute(t & 1);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+        }
+    } else {
+        fetch();
+        commit(0);
+        __syncthreads();
+        for (int t = 0; t < nstages; ++t) {
+            const bool more = (t + 1 < nstages);
+            if (more) fetch();
+            compute(t & 1);
+            if (more) commit((t + 1) & 1);
+            __syncthreads();
+        }
     }
 
     Epi::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
                                 sblk * WS + ws, split);
 }
 
-template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi>
+template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int GLDS = 0>
 static inline hipError_t launch_gemm(const GemmArgs& g, const typename Epi::Params& ep, hipStream_t stream) {
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
-    auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi>;
+    auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi, GLDS>;
+    constexpr int lds_bytes = (GLDS == 3 ? 3 : 2) * C::STAGE_BYTES;
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
-    if (!attr_set && C::LDS_BYTES > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (!attr_set && lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     dim3 grid(g.n_cblk * g.n_sblk, g.ksplit > 1 ? g.ksplit : 1, 1);
-    hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), C::LDS_BYTES, stream, g, ep);
+    hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), lds_bytes, stream, g, ep);
     return hipGetLastError();
 }
