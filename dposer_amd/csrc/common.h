@@ -98,6 +98,74 @@ template <> struct Quad<__bf16> {
     }
 };
 
+// ----------------------------------------------------------------------------------------------
+// Whole-tile I/O between a 32x32 accumulator tile (lane = sample, v[4q + r] = channel 8q + 4hi + r of a
+// 32-channel group) and the FT layout.  `tile` points at element 0 of FT block (sample block, k-block of
+// the group's first channel).  Every access is 16 bytes per lane, lane-linear (1 KiB per instruction):
+//   fp32: quad q of lane (j, hi) IS the lane's chunk of k-block q                       -> 4 x b128
+//   bf16: a lane owns 8 bytes of each chunk; one v_permlane32_swap per dword regroups the two half-waves so
+//         that lane (j, hi) holds the full 16-byte chunk (kh = hi) of k-blocks 0 and 1    -> 2 x b128
+// ----------------------------------------------------------------------------------------------
+template <typename T> struct TileIO;
+template <> struct TileIO<float> {
+    __device__ static inline void store(float* tile, int lane, const float (&v)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(tile + q * 256 + lane * 4) = o;
+        }
+    }
+    __device__ static inline void load(const float* tile, int lane, float (&v)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o = *reinterpret_cast<const f32x4*>(tile + q * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * q + r] = o[r];
+        }
+    }
+};
+template <> struct TileIO<__bf16> {
+    __device__ static inline unsigned pack2(float a, float b) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        bf16x2 t = {(__bf16)a, (__bf16)b};
+        return *reinterpret_cast<unsigned*>(&t);
+    }
+    __device__ static inline void swap_halves(unsigned& a, unsigned& b) {
+        // lanes 32-63 of a <-> lanes 0-31 of b   (v_permlane32_swap_b32)
+        auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        a = r[0];
+        b = r[1];
+    }
+    __device__ static inline void store(__bf16* tile, int lane, const float (&v)[16]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {               // k-block h of the group: quads 2h, 2h+1
+            unsigned a0 = pack2(v[8 * h + 0], v[8 * h + 1]), a1 = pack2(v[8 * h + 2], v[8 * h + 3]);
+            unsigned b0 = pack2(v[8 * h + 4], v[8 * h + 5]), b1 = pack2(v[8 * h + 6], v[8 * h + 7]);
+            swap_halves(a0, b0);
+            swap_halves(a1, b1);
+            u32x4 o = {a0, a1, b0, b1};
+            *reinterpret_cast<u32x4*>(tile + h * 512 + lane * 8) = o;
+        }
+    }
+    __device__ static inline void load(const __bf16* tile, int lane, float (&v)[16]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 o = *reinterpret_cast<const u32x4*>(tile + h * 512 + lane * 8);
+            unsigned a0 = o[0], a1 = o[1], b0 = o[2], b1 = o[3];
+            swap_halves(a0, b0);                    // the regrouping is an involution
+            swap_halves(a1, b1);
+            v[8 * h + 0] = __uint_as_float(a0 << 16); v[8 * h + 1] = __uint_as_float(a0 & 0xffff0000u);
+            v[8 * h + 2] = __uint_as_float(a1 << 16); v[8 * h + 3] = __uint_as_float(a1 & 0xffff0000u);
+            v[8 * h + 4] = __uint_as_float(b0 << 16); v[8 * h + 5] = __uint_as_float(b0 & 0xffff0000u);
+            v[8 * h + 6] = __uint_as_float(b1 << 16); v[8 * h + 7] = __uint_as_float(b1 & 0xffff0000u);
+        }
+    }
+};
+// element offset of the FT block holding (sample block of s0, k-block of channel c0); s0 % 32 == 0, c0 % 32 == 0
+template <typename T> __device__ __forceinline__ int64_t ft_tile_base(int64_t s0, int c0, int K) {
+    return ((s0 >> 5) * (int64_t)(K / FT<T>::KBS) + c0 / FT<T>::KBS) * FT<T>::BLOCK_ELEMS;
+}
+
 template <typename T> __device__ __forceinline__ T from_f32(float f);
 template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float f) { return (__bf16)f; }

@@ -47,8 +47,10 @@ struct GNParams {
 };
 template <typename T, bool TRAIN> struct EpiGN {
     typedef GNParams Params;
+    static constexpr int kParamArrays = 3;
+    __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.bias : (a == 1 ? p.gamma : p.beta); }
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride) {
         struct { const float *bias, *gamma, *beta; T* out; const T* resid; T* xhat; float* rstd; int H; DropoutCfg drop; } p =
             {pp.bias, pp.gamma, pp.beta, (T*)pp.out, (const T*)pp.resid, (T*)pp.xhat, pp.rstd, pp.H, pp.drop};
         constexpr bool PRECISE = sizeof(T) == 4;
@@ -59,16 +61,17 @@ template <typename T, bool TRAIN> struct EpiGN {
             float bia[16], gam[16], bet[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c = c0 + 8 * q + 4 * hi;
-                f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + c);
-                f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c);
-                f32x4 e4 = *reinterpret_cast<const f32x4*>(p.beta + c);
+                const int cl = tc * 32 + 8 * q + 4 * hi;              // channel inside the wave's LDS-staged slice
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(lpar + cl);
+                f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
+                f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + 2 * lstride + cl);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { bia[4 * q + r] = b4[r]; gam[4 * q + r] = g4[r]; bet[4 * q + r] = e4[r]; }
             }
 #pragma unroll
             for (int ts = 0; ts < TS; ++ts) {
                 const int64_t s = sbase + ts * 32 + j;
+                const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.H);
                 float v[16];
                 float sum = 0.f;
 #pragma unroll
@@ -84,27 +87,22 @@ template <typename T, bool TRAIN> struct EpiGN {
                 float keep[16];
                 if (TRAIN && p.drop.p > 0.f) dropout_mask16(p.drop, s, c0 >> 5, hi, keep);
                 if (TRAIN && hi == 0) p.rstd[s * (p.H >> 5) + (c0 >> 5)] = rstd;
+                float o[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = c0 + 8 * q + 4 * hi;
-                    const int64_t off = FT<T>::index(s, c, p.H);
-                    f32x4 xh, o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        xh[r] = v[4 * q + r] * rstd;
-                        float a = gam[4 * q + r] * xh[r] + bet[4 * q + r];
-                        float y = silu_f<PRECISE>(a);
-                        if (TRAIN && p.drop.p > 0.f) y *= keep[4 * q + r];
-                        o[r] = y;
-                    }
-                    if (TRAIN) Quad<T>::store(p.xhat + off, xh);
-                    if (p.resid) {
-                        f32x4 rr = Quad<T>::load(p.resid + off);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] += rr[r];
-                    }
-                    Quad<T>::store(p.out + off, o);
+                for (int r = 0; r < 16; ++r) {
+                    v[r] *= rstd;                                   // x_hat
+                    float y = silu_f<PRECISE>(gam[r] * v[r] + bet[r]);
+                    if (TRAIN && p.drop.p > 0.f) y *= keep[r];
+                    o[r] = y;
                 }
+                if (TRAIN) TileIO<T>::store(p.xhat + tb, lane, v);
+                if (p.resid) {
+                    float rr[16];
+                    TileIO<T>::load(p.resid + tb, lane, rr);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] += rr[r];
+                }
+                TileIO<T>::store(p.out + tb, lane, o);
             }
         }
     }
@@ -119,28 +117,33 @@ struct BiasSiLUParams {
 };
 template <typename T, bool TRAIN> struct EpiBiasSiLU {
     typedef BiasSiLUParams Params;
+    static constexpr int kParamArrays = 1;
+    __device__ static inline const float* param_array(const Params& p, int) { return p.bias; }
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride) {
         struct { const float* bias; T* out; T* pre; int N; } p = {pp.bias, (T*)pp.out, (T*)pp.pre, pp.N};
         constexpr bool PRECISE = sizeof(T) == 4;
-        const int j = lane & 31, hi = lane >> 5;
+        const int hi = lane >> 5;
 #pragma unroll
-        for (int tc = 0; tc < TC; ++tc)
+        for (int tc = 0; tc < TC; ++tc) {
+            const int c0 = cbase + tc * 32;
+            float bia[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c = cbase + tc * 32 + 8 * q + 4 * hi;
-                f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + c);
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(lpar + tc * 32 + 8 * q + 4 * hi);
 #pragma unroll
-                for (int ts = 0; ts < TS; ++ts) {
-                    const int64_t s = sbase + ts * 32 + j;
-                    const int64_t off = FT<T>::index(s, c, p.N);
-                    f32x4 u, o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { u[r] = acc[tc][ts][4 * q + r] + b4[r]; o[r] = silu_f<PRECISE>(u[r]); }
-                    if (TRAIN) Quad<T>::store(p.pre + off, u);
-                    Quad<T>::store(p.out + off, o);
-                }
+                for (int r = 0; r < 4; ++r) bia[4 * q + r] = b4[r];
             }
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.N);
+                float u[16], o[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { u[r] = acc[tc][ts][r] + bia[r]; o[r] = silu_f<PRECISE>(u[r]); }
+                if (TRAIN) TileIO<T>::store(p.pre + tb, lane, u);
+                TileIO<T>::store(p.out + tb, lane, o);
+            }
+        }
     }
 };
 
@@ -156,7 +159,7 @@ struct RowMajorParams {
 template <typename T> struct EpiRowMajor {
     typedef RowMajorParams Params;
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int) {
+    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride) {
         const int j = lane & 31, hi = lane >> 5;
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc)
@@ -187,21 +190,17 @@ struct PlainFTParams {
 template <typename T> struct EpiPlainFT {
     typedef PlainFTParams Params;
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride) {
         struct { T* out; int N; } p = {(T*)pp.out, pp.N};
-        const int j = lane & 31, hi = lane >> 5;
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int ts = 0; ts < TS; ++ts) {
+                float o[16];
 #pragma unroll
-                for (int ts = 0; ts < TS; ++ts) {
-                    const int c = cbase + tc * 32 + 8 * q + 4 * hi;
-                    f32x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = acc[tc][ts][4 * q + r];
-                    Quad<T>::store(p.out + FT<T>::index(sbase + ts * 32 + j, c, p.N), o);
-                }
+                for (int r = 0; r < 16; ++r) o[r] = acc[tc][ts][r];
+                TileIO<T>::store(p.out + ft_tile_base<T>(sbase + ts * 32, cbase + tc * 32, p.N), lane, o);
+            }
     }
 };
 
@@ -250,8 +249,10 @@ struct GNBwdParams {
 template <typename T> struct EpiGNBwd {
     typedef GNBwdParams Params;
     static constexpr int kMinWaves = 2;   // keep two 256-thread workgroups per CU (register-heavy epilogue)
+    static constexpr int kParamArrays = 2;
+    __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.gamma : p.beta; }
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int, const float* lpar, int lstride) {
         struct { const T* carry_in; T* carry_out; const T* xhat; const float *rstd, *gamma, *beta; T* dy; float* part; int H; int64_t S_valid; DropoutCfg drop; } p =
             {(const T*)pp.carry_in, (T*)pp.carry_out, (const T*)pp.xhat, pp.rstd, pp.gamma, pp.beta, (T*)pp.dy, pp.part, pp.H, pp.S_valid, pp.drop};
         constexpr bool PRECISE = sizeof(T) == 4;
@@ -262,9 +263,9 @@ template <typename T> struct EpiGNBwd {
             float gam[16], bet[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c = c0 + 8 * q + 4 * hi;
-                f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + c);
-                f32x4 e4 = *reinterpret_cast<const f32x4*>(p.beta + c);
+                const int cl = tc * 32 + 8 * q + 4 * hi;
+                f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + cl);
+                f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { gam[4 * q + r] = g4[r]; bet[4 * q + r] = e4[r]; }
             }
@@ -278,55 +279,42 @@ template <typename T> struct EpiGNBwd {
             for (int ts = 0; ts < TS; ++ts) {
                 const int64_t s = sbase + ts * 32 + j;
                 const bool valid = s < p.S_valid;
+                const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.H);
                 float keep[16];
                 if (p.drop.p > 0.f) dropout_mask16(p.drop, s, c0 >> 5, hi, keep);
                 const float rstd = p.rstd[s * (p.H >> 5) + (c0 >> 5)];
-                float dx[16], xh[16];
+                float xh[16], g[16];
+                TileIO<T>::load(p.xhat + tb, lane, xh);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[r] = acc[tc][ts][r];
+                if (p.carry_in) {
+                    float ci[16];
+                    TileIO<T>::load(p.carry_in + tb, lane, ci);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) g[r] += ci[r];
+                }
+                if (p.carry_out) TileIO<T>::store(p.carry_out + tb, lane, g);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = c0 + 8 * q + 4 * hi;
-                    const int64_t off = FT<T>::index(s, c, p.H);
-                    f32x4 x4 = Quad<T>::load(p.xhat + off);
-                    f32x4 g;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) g[r] = acc[tc][ts][4 * q + r];
-                    if (p.carry_in) {
-                        f32x4 ci = Quad<T>::load(p.carry_in + off);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) g[r] += ci[r];
-                    }
-                    if (p.carry_out) Quad<T>::store(p.carry_out + off, g);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 4 * q + r;
-                        float gg = valid ? g[r] : 0.f;
-                        if (p.drop.p > 0.f) gg *= keep[i];
-                        const float a = gam[i] * x4[r] + bet[i];
-                        const float da = gg * dsilu_f<PRECISE>(a);
-                        stat[i] += da * x4[r];
-                        stat[16 + i] += da;
-                        xh[i] = x4[r];
-                        dx[i] = da * gam[i];
-                        s1 += dx[i];
-                        s2 += dx[i] * x4[r];
-                    }
+                for (int i = 0; i < 16; ++i) {
+                    float gg = valid ? g[i] : 0.f;
+                    if (p.drop.p > 0.f) gg *= keep[i];
+                    const float da = gg * dsilu_f<PRECISE>(gam[i] * xh[i] + bet[i]);
+                    stat[i] += da * xh[i];
+                    stat[16 + i] += da;
+                    g[i] = da * gam[i];                 // dx
+                    s1 += g[i];
+                    s2 += g[i] * xh[i];
                 }
                 s1 += __shfl_xor(s1, 32);
                 s2 += __shfl_xor(s2, 32);
                 const float m1 = s1 * (1.0f / 32.0f), m2 = s2 * (1.0f / 32.0f);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c = c0 + 8 * q + 4 * hi;
-                    f32x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 4 * q + r;
-                        o[r] = rstd * (dx[i] - m1 - xh[i] * m2);
-                        dbias[i] += o[r];
-                    }
-                    Quad<T>::store(p.dy + FT<T>::index(s, c, p.H), o);
+                for (int i = 0; i < 16; ++i) {
+                    g[i] = rstd * (g[i] - m1 - xh[i] * m2);   // dy
+                    dbias[i] += g[i];
                 }
+                TileIO<T>::store(p.dy + tb, lane, g);
             }
             // reduce over the 32 samples of the lane group; lane i ends with value i.
             butterfly_reduce32(stat, lane);
@@ -355,24 +343,22 @@ struct SiLUBwdParams {
 template <typename T> struct EpiSiLUBwd {
     typedef SiLUBwdParams Params;
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride) {
         struct { const T* pre; T* out; int N; int64_t S_valid; } p = {(const T*)pp.pre, (T*)pp.out, pp.N, pp.S_valid};
         constexpr bool PRECISE = sizeof(T) == 4;
-        const int j = lane & 31, hi = lane >> 5;
+        const int j = lane & 31;
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int ts = 0; ts < TS; ++ts) {
+                const int64_t s = sbase + ts * 32 + j;
+                const int64_t tb = ft_tile_base<T>(sbase + ts * 32, cbase + tc * 32, p.N);
+                float u[16], o[16];
+                TileIO<T>::load(p.pre + tb, lane, u);
 #pragma unroll
-                for (int ts = 0; ts < TS; ++ts) {
-                    const int c = cbase + tc * 32 + 8 * q + 4 * hi;
-                    const int64_t s = sbase + ts * 32 + j;
-                    const int64_t off = FT<T>::index(s, c, p.N);
-                    f32x4 u = Quad<T>::load(p.pre + off), o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (s < p.S_valid) ? acc[tc][ts][4 * q + r] * dsilu_f<PRECISE>(u[r]) : 0.f;
-                    Quad<T>::store(p.out + off, o);
-                }
+                for (int r = 0; r < 16; ++r) o[r] = (s < p.S_valid) ? acc[tc][ts][r] * dsilu_f<PRECISE>(u[r]) : 0.f;
+                TileIO<T>::store(p.out + tb, lane, o);
+            }
     }
 };
 
@@ -386,7 +372,7 @@ struct WgradParams {
 template <typename T> struct EpiWgrad {
     typedef WgradParams Params;
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int split) {
+    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int split, const float*, int) {
         const int j = lane & 31, hi = lane >> 5;
         float* base = p.slab + (int64_t)split * p.slab_stride;
 #pragma unroll

@@ -80,6 +80,12 @@ struct GemmCfg {
 template <typename Epi, typename = void> struct EpiMinWaves { static constexpr int value = 1; };
 template <typename Epi> struct EpiMinWaves<Epi, decltype((void)Epi::kMinWaves)> { static constexpr int value = Epi::kMinWaves; };
 
+// Epilogues may ask for up to 3 per-channel fp32 arrays (bias / gamma / beta) to be staged into LDS at kernel
+// start: global-load latency of those small vectors is then hidden under the whole K loop instead of being paid
+// once per channel tile in the epilogue.
+template <typename Epi, typename = void> struct EpiParamArrays { static constexpr int value = 0; };
+template <typename Epi> struct EpiParamArrays<Epi, decltype((void)Epi::kParamArrays)> { static constexpr int value = Epi::kParamArrays; };
+
 // The kernel.  Epi::apply(params, acc, channel_base, sample_base, lane, wave-in-sample-dim ids)
 // GLDS: 0 = register staging, 1 = global_load_lds double buffer, 3 = global_load_lds 3-deep ring with counted vmcnt
 template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int GLDS = 0>
@@ -97,6 +103,15 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     const int cblk = L % g.n_cblk;
     const int sblk = L / g.n_cblk;
     const int split = blockIdx.y;
+
+    constexpr int NPAR = EpiParamArrays<Epi>::value;
+    float* lds_par = reinterpret_cast<float*>(smem + (GLDS == 3 ? 3 : 2) * C::STAGE_BYTES);   // [NPAR][CT*32]
+    if constexpr (NPAR > 0) {
+        for (int i = threadIdx.x; i < NPAR * C::CT * 32; i += C::THREADS) {
+            const int a = i / (C::CT * 32), c = i % (C::CT * 32);
+            lds_par[i] = Epi::param_array(ep, a)[cblk * C::CT * 32 + c];
+        }
+    }
 
     f32x16 acc[TC][TS];
 #pragma unroll
@@ -262,14 +277,14 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     }
 
     Epi::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
-                                sblk * WS + ws, split);
+                                sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32);
 }
 
 template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int GLDS = 0>
 static inline hipError_t launch_gemm(const GemmArgs& g, const typename Epi::Params& ep, hipStream_t stream) {
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
     auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi, GLDS>;
-    constexpr int lds_bytes = (GLDS == 3 ? 3 : 2) * C::STAGE_BYTES;
+    constexpr int lds_bytes = (GLDS == 3 ? 3 : 2) * C::STAGE_BYTES + EpiParamArrays<Epi>::value * C::CT * 32 * 4;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && lds_bytes > 64 * 1024) {

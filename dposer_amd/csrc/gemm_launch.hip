@@ -98,7 +98,7 @@ hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTPa
 }
 hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st) {
     PROF(EPI_GN_BWD);
-    typedef EpiGNBwd<__bf16> A; typedef EpiGNBwd<float> B; DISPATCH(A, B, M_MID | M_SMALL);   // BIG spills: register-heavy epilogue
+    typedef EpiGNBwd<__bf16> A; typedef EpiGNBwd<float> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st) {
     PROF(EPI_SILU_BWD);
@@ -106,5 +106,5 @@ hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdPa
 }
 hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st) {
     PROF(EPI_WGRAD);
-    typedef EpiWgrad<__bf16> A; typedef EpiWgrad<float> B; DISPATCH(A, B, M_MID | M_FINAL | M_WIDE);
+    typedef EpiWgrad<__bf16> A; typedef EpiWgrad<float> B; DISPATCH(A, B, M_BIG | M_MID | M_FINAL | M_WIDE);
 }

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -196,7 +197,11 @@ static int main_shape(int64_t Spad) {
     if (Spad % 128 == 0) return SHAPE_MID;
     return SHAPE_SMALL;
 }
-static int gnbwd_shape(int64_t Spad) { return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL; }
+static int gnbwd_shape(int64_t Spad) {
+    const char* e = getenv("DPOSER_GNBWD_BIG");
+    if (e && e[0] == '1' && Spad % 256 == 0 && Spad >= 4096) return SHAPE_BIG;
+    return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL;
+}
 static int final_shape(int64_t Spad) { return Spad % 128 == 0 ? SHAPE_FINAL : SHAPE_FINAL_S; }
 
 struct Ws {
@@ -219,6 +224,8 @@ struct WgradPlan {
 static int wgrad_shape(int n_rows_pad, int k_rows_pad) {
     if (n_rows_pad < 128) return SHAPE_FINAL;
     if (k_rows_pad < 128) return SHAPE_WIDE64;
+    const char* e = getenv("DPOSER_WGRAD_BIG");
+    if (e && e[0] == '1' && n_rows_pad % 256 == 0 && k_rows_pad % 256 == 0) return SHAPE_BIG;
     return SHAPE_MID;
 }
 static int pick_ksplit(int64_t tiles, int64_t stages) {
