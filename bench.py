@@ -101,6 +101,7 @@ def main():
 
     rank, world, local_rank = ddp.init_from_env()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)     # (test rigs may run several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B_local = args.global_batch // world

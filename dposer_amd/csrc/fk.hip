@@ -61,12 +61,37 @@ struct Mat3 {
     float m[9];
 };
 
+// sin and cos with a 3-term Cody-Waite reduction by pi/2 and the cephes minimax polynomials on [-pi/4, pi/4]
+// (~1 ulp for |x| < 1e4, no slow path): libm's sincosf carries a Payne-Hanek large-argument branch that costs
+// ~150 instructions per call, 3x the rest of a joint.
+__device__ __forceinline__ void sincos_small(float x, float& s, float& c) {
+    const float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(k, -1.57079625129699707031f, x);
+    r = fmaf(k, -7.54978941586159635335e-08f, r);
+    r = fmaf(k, -5.39030285815811905290e-15f, r);
+    const float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    sp = fmaf(sp * r2, r, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    cp = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)k;
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // smplx lbs.py batch_rodrigues: angle = ||r + 1e-8||, k = r / angle, R = I + sin K + (1 - cos) K K
 __device__ __forceinline__ Mat3 rodrigues(float rx, float ry, float rz) {
     const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
-    const float angle = sqrtf(ax * ax + ay * ay + az * az);
-    const float kx = rx / angle, ky = ry / angle, kz = rz / angle;
-    const float s = sinf(angle), c1 = 1.0f - cosf(angle);
+    const float d2 = fmaf(ax, ax, fmaf(ay, ay, az * az));
+    const float inv = rsqrtf(d2);                        // v_rsq_f32 (1 ulp); d2 >= 3e-16 thanks to the 1e-8 offset
+    const float angle = d2 * inv;
+    const float kx = rx * inv, ky = ry * inv, kz = rz * inv;
+    float s, c;
+    sincos_small(angle, s, c);
+    const float c1 = 1.0f - c;
     Mat3 R;
     R.m[0] = 1.0f + c1 * (-(kz * kz) - ky * ky);
     R.m[1] = s * (-kz) + c1 * (kx * ky);
@@ -198,8 +223,8 @@ __device__ __forceinline__ void fk_step(Xf (&G)[Kin::J], const float* pose, cons
         for (int r = 0; r < 3; ++r) {
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                G[I].r[3 * r + c] = Pm.r[3 * r] * R.m[c] + Pm.r[3 * r + 1] * R.m[3 + c] + Pm.r[3 * r + 2] * R.m[6 + c];
-            G[I].t[r] = Pm.r[3 * r] * rel[0] + Pm.r[3 * r + 1] * rel[1] + Pm.r[3 * r + 2] * rel[2] + Pm.t[r];
+                G[I].r[3 * r + c] = fmaf(Pm.r[3 * r], R.m[c], fmaf(Pm.r[3 * r + 1], R.m[3 + c], Pm.r[3 * r + 2] * R.m[6 + c]));
+            G[I].t[r] = fmaf(Pm.r[3 * r], rel[0], fmaf(Pm.r[3 * r + 1], rel[1], fmaf(Pm.r[3 * r + 2], rel[2], Pm.t[r])));
         }
     }
     // posed joint (+ transl) overwrites the (already consumed) axis-angle of joint I in the lane's LDS row
@@ -246,13 +271,49 @@ template <typename Kin, int NT> __global__ void __launch_bounds__(NT) k_fk_joint
         const int width = (first + a.seg_joints[sg] <= n_out ? a.seg_joints[sg] : n_out - first) * 3;   // floats staged
         const int col0 = first * 3;
         const float* g = a.seg[sg];
-        // walk (row, col) incrementally: no integer division in the copy loop
-        int row = threadIdx.x / width, col = threadIdx.x % width;
-        while (row < NT) {
-            const int64_t b = item0 + row;
-            lds[row * ROW + col0 + col] = (g && b < a.B) ? g[b * gw + col] : 0.f;
-            col += NT;
-            while (col >= width) { col -= width; ++row; }
+        if (!g) {                                                               // absent segment = zeros (identity rotations)
+            for (int e = threadIdx.x; e < NT * width; e += NT) lds[(e / width) * ROW + col0 + (e % width)] = 0.f;
+            continue;
+        }
+        const bool full = (item0 + NT <= a.B) && (width == gw);
+        if (full) {
+            // the block's NT poses are one contiguous, 16-byte aligned span of NT*gw floats: batches of 8 float4 loads
+            // in flight per lane, then scattered into the per-pose LDS rows
+            const f32x4* g4 = reinterpret_cast<const f32x4*>(g + item0 * gw);
+            const int n4 = NT * gw / 4;
+            // element e = 4*i4 lives at (row, col) = (e / gw, e % gw); consecutive batches advance e by 4*NT:
+            // (row, col) += ((4*NT) / gw, (4*NT) % gw) with one carry -- no division inside the loop
+            const int drow = (4 * NT) / gw, dcol = (4 * NT) % gw;
+            int rw = (4 * threadIdx.x) / gw, col = (4 * threadIdx.x) % gw;
+            for (int base = 0; base < n4; base += NT * 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i4 = base + k * NT + threadIdx.x;
+                    if (i4 < n4) v[k] = g4[i4];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i4 = base + k * NT + threadIdx.x;
+                    if (i4 < n4) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool wrap = col + r >= gw;
+                            lds[(rw + (wrap ? 1 : 0)) * ROW + col0 + col + r - (wrap ? gw : 0)] = v[k][r];
+                        }
+                    }
+                    rw += drow; col += dcol;
+                    if (col >= gw) { col -= gw; ++rw; }
+                }
+            }
+        } else {
+            int rw = threadIdx.x / width, col = threadIdx.x % width;
+            while (rw < NT) {
+                const int64_t bb = item0 + rw;
+                lds[rw * ROW + col0 + col] = (bb < a.B) ? g[bb * gw + col] : 0.f;
+                col += NT;
+                while (col >= width) { col -= width; ++rw; }
+            }
         }
     }
     __syncthreads();
@@ -267,12 +328,30 @@ template <typename Kin, int NT> __global__ void __launch_bounds__(NT) k_fk_joint
     // ---- posed joints: LDS rows (stride ROW) -> coalesced global stream ----
     {
         const int width = n_out * 3;
-        int r = threadIdx.x / width, col = threadIdx.x % width;
-        while (r < NT) {
-            const int64_t bb = item0 + r;
-            if (bb < a.B) a.joints[bb * a.joints_ld + col] = lds[r * ROW + col];
-            col += NT;
-            while (col >= width) { col -= width; ++r; }
+        if (item0 + NT <= a.B && a.joints_ld == width) {
+            f32x4* o4 = reinterpret_cast<f32x4*>(a.joints + item0 * width);
+            const int n4 = NT * width / 4;
+            const int drow = (4 * NT) / width, dcol = (4 * NT) % width;
+            int rw = (4 * threadIdx.x) / width, col = (4 * threadIdx.x) % width;
+            for (int i4 = threadIdx.x; i4 < n4; i4 += NT) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool wrap = col + r >= width;
+                    v[r] = lds[(rw + (wrap ? 1 : 0)) * ROW + col + r - (wrap ? width : 0)];
+                }
+                o4[i4] = v;
+                rw += drow; col += dcol;
+                if (col >= width) { col -= width; ++rw; }
+            }
+        } else {
+            int r = threadIdx.x / width, col = threadIdx.x % width;
+            while (r < NT) {
+                const int64_t bb = item0 + r;
+                if (bb < a.B) a.joints[bb * a.joints_ld + col] = lds[r * ROW + col];
+                col += NT;
+                while (col >= width) { col -= width; ++r; }
+            }
         }
     }
 }
@@ -308,7 +387,11 @@ extern "C" int dposer_body_create(const dposer_body_desc* desc, const int32_t* p
 extern "C" void dposer_body_destroy(dposer_body_t h) { delete h; }
 
 template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t st) {
+#ifdef FK_NT
+    constexpr int NT = FK_NT;
+#else
     constexpr int NT = 64;
+#endif
     const int lds_floats = NT * ((a.n_out * 3) | 1);
     hipLaunchKernelGGL((k_fk_joints<Kin, NT>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
     return hipGetLastError();

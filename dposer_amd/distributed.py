@@ -36,11 +36,11 @@ def init_from_env(backend=None):
     lr = int(os.environ.get("LOCAL_RANK", "0"))
     if ws > 1 and not is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("DPOSER_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(lr)
+            torch.cuda.set_device(lr % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rk, world_size=ws)
     return rk, ws, lr
 
