@@ -28,6 +28,88 @@ _SMPLX_SEGMENTS = (("global_orient", 1), ("body_pose", 21), ("jaw_pose", 1), ("l
                    ("left_hand_pose", 15), ("right_hand_pose", 15))
 
 
+class _LBSFunction(torch.autograd.Function):
+    """dposer_lbs_forward / dposer_lbs_backward as one differentiable op.
+    inputs: core, n_seg_tensors..., v_shaped, j_rest, transl (any may be None)."""
+
+    @staticmethod
+    def forward(ctx, core, batched, v_shaped, j_rest, transl, *segs):
+        B = next(t for t in segs if t is not None).shape[0] if any(t is not None for t in segs) else (transl.shape[0] if transl is not None else v_shaped.shape[0])
+        dev = core.v_template.device
+        h, lib = core._handle(), _C.lib()
+        ws = torch.empty(lib.dposer_lbs_workspace_bytes(h, B), dtype=torch.uint8, device=dev)     # private: read back in backward
+        segp = (C.c_void_p * 7)()
+        segj = (C.c_int32 * 7)()
+        keep = []
+        for i, ((_, nj), t) in enumerate(zip(_SMPLX_SEGMENTS, segs)):
+            segj[i] = nj
+            if t is not None:
+                t = t.detach().reshape(B, nj * 3).contiguous().float()
+                keep.append(t)
+                segp[i] = t.data_ptr()
+            else:
+                keep.append(None)
+                segp[i] = None
+        vs, jr = v_shaped.detach().contiguous(), j_rest.detach().contiguous()
+        tr = None if transl is None else transl.detach().contiguous().float()
+        verts = torch.empty(B, core.V, 3, dtype=torch.float32, device=dev)
+        joints = torch.empty(B, core.J + core.n_extra + core.n_lmk, 3, dtype=torch.float32, device=dev)
+        _C.check(lib.dposer_lbs_forward(h, _C.ptr(ws), _C.ptr(core._packed_posedirs()), segp, segj, 7, _C.ptr(jr), 1 if batched else 0,
+                                        _C.ptr(vs), 1 if batched else 0, _C.ptr(core.skin_idx), _C.ptr(core.skin_w),
+                                        int(core.skin_idx.shape[1]), _C.ptr(tr), _C.ptr(core.extra_vertex_ids), _C.ptr(core.lmk_tri),
+                                        _C.ptr(core.lmk_bary_coords), _C.ptr(verts), _C.ptr(joints), B, _C.stream_ptr()),
+                 "dposer_lbs_forward")
+        ctx.core, ctx.batched, ctx.ws, ctx.keep, ctx.vs, ctx.jr, ctx.B = core, batched, ws, keep, vs, jr, B
+        ctx.has_transl = transl is not None
+        ctx.seg_given = [t is not None for t in segs]
+        return verts, joints
+
+    @staticmethod
+    def backward(ctx, d_verts, d_joints):
+        core, B = ctx.core, ctx.B
+        dev = d_verts.device
+        h, lib = core._handle(), _C.lib()
+        J = core.J
+        dv = d_verts.contiguous().float().clone()
+        dj = d_joints.contiguous().float()
+        # extras / landmarks are gathers of vertices: fold their gradients into d verts
+        if core.n_extra:
+            dv.index_add_(1, core.extra_vertex_ids.long(), dj[:, J:J + core.n_extra])
+        if core.n_lmk:
+            dl = dj[:, J + core.n_extra:]
+            for f in range(3):
+                dv.index_add_(1, core.lmk_tri[:, f].long(), dl * core.lmk_bary_coords[:, f].view(1, -1, 1))
+        # transl shifts every vertex and the J LBS joints (extras / landmarks move with their vertices: already in dv)
+        d_transl = (dv.sum(dim=1) + dj[:, :J].sum(dim=1)) if ctx.has_transl else None
+        ws_b = torch.empty(lib.dposer_lbs_backward_workspace_bytes(h, B), dtype=torch.uint8, device=dev)
+        segp, dsegp = (C.c_void_p * 7)(), (C.c_void_p * 7)()
+        segj = (C.c_int32 * 7)()
+        dsegs = []
+        for i, ((_, nj), t) in enumerate(zip(_SMPLX_SEGMENTS, ctx.keep)):
+            segj[i] = nj
+            segp[i] = None if t is None else t.data_ptr()
+            if t is not None:
+                g = torch.empty_like(t)
+                dsegs.append(g)
+                dsegp[i] = g.data_ptr()
+            else:
+                dsegs.append(None)
+                dsegp[i] = None
+        d_jrest = torch.empty(B, J, 3, dtype=torch.float32, device=dev)
+        d_vposed = torch.empty(B, core.V, 3, dtype=torch.float32, device=dev)
+        jptr, jvidx, jw = core.joint_csr()
+        _C.check(lib.dposer_lbs_backward(h, _C.ptr(ctx.ws), _C.ptr(ws_b), _C.ptr(core._packed_posedirs_bwd()), segp, segj, 7, _C.ptr(ctx.jr),
+                                         1 if ctx.batched else 0, _C.ptr(ctx.vs), 1 if ctx.batched else 0, _C.ptr(core.skin_idx),
+                                         _C.ptr(core.skin_w), int(core.skin_idx.shape[1]), _C.ptr(jptr), _C.ptr(jvidx), _C.ptr(jw), _C.ptr(dv),
+                                         _C.ptr(dj), dj.shape[1] * 3, dsegp, _C.ptr(d_jrest), _C.ptr(d_vposed), B, _C.stream_ptr()),
+                 "dposer_lbs_backward")
+        if ctx.batched:
+            g_vs, g_jr = d_vposed, d_jrest
+        else:
+            g_vs, g_jr = d_vposed.sum(dim=0), d_jrest.sum(dim=0)
+        return (None, None, g_vs, g_jr, d_transl, *dsegs)
+
+
 class _SMPLXCore(nn.Module):
     """What the reference reaches as ``BodyModel.bm`` (an smplx.SMPLX instance): buffers + forward."""
     NUM_JOINTS = 54
@@ -77,6 +159,32 @@ class _SMPLXCore(nn.Module):
             self._h = h
         return self._h
 
+    def joint_csr(self):
+        """CSR-by-joint form of the skinning weights (which vertices does joint j move) for the backward kernel."""
+        if getattr(self, "_jcsr", None) is None or self._jcsr[0].device != self.skin_idx.device:
+            idx, w = self.skin_idx.cpu().numpy(), self.skin_w.cpu().numpy()
+            v = np.repeat(np.arange(idx.shape[0], dtype=np.int32), idx.shape[1])
+            j, ww = idx.reshape(-1), w.reshape(-1)
+            nz = ww != 0
+            v, j, ww = v[nz], j[nz], ww[nz]
+            order = np.argsort(j, kind="stable")
+            ptr = np.zeros(self.J + 1, dtype=np.int32)
+            np.add.at(ptr, j + 1, 1)
+            ptr = np.cumsum(ptr).astype(np.int32)
+            dev = self.skin_idx.device
+            self._jcsr = (torch.tensor(ptr, device=dev), torch.tensor(v[order].astype(np.int32), device=dev),
+                          torch.tensor(ww[order].astype(np.float32), device=dev))
+        return self._jcsr
+
+    def _packed_posedirs_bwd(self):
+        dev = self.posedirs.device
+        if getattr(self, "_posedirs_bwd", None) is None or self._posedirs_bwd.device != dev:
+            h = self._handle()
+            self._posedirs_bwd = torch.empty(_C.lib().dposer_lbs_posedirs_bwd_packed_bytes(h), dtype=torch.uint8, device=dev)
+            _C.check(_C.lib().dposer_lbs_pack_posedirs_bwd(h, _C.ptr(self.posedirs), _C.ptr(self._posedirs_bwd), _C.stream_ptr()),
+                     "dposer_lbs_pack_posedirs_bwd")
+        return self._posedirs_bwd
+
     def _packed_posedirs(self):
         dev = self.posedirs.device
         if self._posedirs_packed is None or self._posedirs_packed.device != dev:
@@ -116,9 +224,7 @@ class _SMPLXCore(nn.Module):
         B = given[0].shape[0]
         dev = given[0].device
         _C.require_gpu(given[0], "BodyModel input")
-        if any(t.requires_grad for t in given) and torch.is_grad_enabled():
-            raise NotImplementedError("BodyModel backward (d verts / d pose, SURVEY.md 8f.2) is not built yet; "
-                                      "call under torch.no_grad()")
+        needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in given)
         if self.v_template.device != dev:
             raise _C.DPoserHipError("BodyModel buffers and inputs are on different devices; call .to(device)")
         segp = (C.c_void_p * 7)()
@@ -137,6 +243,16 @@ class _SMPLXCore(nn.Module):
         tr = None if transl is None else transl.contiguous().float()
         h = self._handle()
         lib = _C.lib()
+        if needs_grad:
+            verts, joints = _LBSFunction.apply(self, batched, v_shaped, j_rest, transl, *[segs[name] for name, _ in _SMPLX_SEGMENTS])
+            if joints_only:
+                return Struct(vertices=None, joints=joints[:, :(self.J if n_joints is None else int(n_joints))])
+            z = lambda n: torch.zeros(B, n, dtype=torch.float32, device=dev)
+            full = [segs[name].reshape(B, nj * 3) if segs[name] is not None else z(nj * 3) for name, nj in _SMPLX_SEGMENTS]
+            return Struct(vertices=verts, joints=joints, betas=betas if betas is not None else z(self.num_betas),
+                          expression=expression, global_orient=full[0], body_pose=full[1], jaw_pose=full[2],
+                          left_hand_pose=full[5], right_hand_pose=full[6],
+                          full_pose=torch.cat(full, dim=1) if return_full_pose else None)
         if joints_only:
             n_out = self.J if n_joints is None else int(n_joints)
             joints = torch.empty(B, n_out, 3, dtype=torch.float32, device=dev)

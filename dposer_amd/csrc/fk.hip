@@ -359,6 +359,7 @@ template <typename Kin, int NT> __global__ void __launch_bounds__(NT) k_fk_joint
 struct dposer_body_s {
     dposer_body_desc d;
     int kind;   // 0 SMPL, 1 SMPL-H, 2 SMPL-X
+    int parents[64];
 };
 
 template <typename Kin> static bool same_tree(const int32_t* p, int n) {
@@ -381,6 +382,7 @@ extern "C" int dposer_body_create(const dposer_body_desc* desc, const int32_t* p
     auto* h = new dposer_body_s();
     h->d = *desc;
     h->kind = kind;
+    for (int i = 0; i < desc->num_joints && i < 64; ++i) h->parents[i] = parents_host[i] < 0 ? 0 : parents_host[i];
     *out = h;
     return DPOSER_OK;
 }
@@ -602,6 +604,333 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
         e.ld = (int64_t)n_total * 3; e.J = J; e.n_extra = h->d.num_extra; e.n_lmk = h->d.num_landmarks; e.V = V; e.B = batch;
         const int64_t total = batch * (e.n_extra + e.n_lmk);
         hipLaunchKernelGGL(k_extra_joints, dim3((unsigned)(ceil_div(total, 256) > 4096 ? 4096 : ceil_div(total, 256))), dim3(256), 0, st, e);
+        FK_HIP_LAUNCH(hipGetLastError());
+    }
+    return DPOSER_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Backward of linear blend skinning + forward kinematics (d verts, d joints -> d pose, d rest joints, d v_shaped)
+// needed by the fitting loops that differentiate through the body model (run/motion_denoising.py:217-218,255-267).
+// ------------------------------------------------------------------------------------------------
+struct SkinBwdArgs {
+    const float* dverts;       // [B][V][3]
+    const float* offsets;      // [B][ld_off] (forward workspace)
+    int64_t ld_off;
+    const float* v_shaped;
+    int v_shaped_batched;
+    const float* A;            // [B][J][12]
+    const int32_t* skin_idx;
+    const float* skin_w;
+    int K, J, V;
+    float* vp;                 // [B][V][3] out: posed-blend vertices (v_shaped + offsets)
+    float* dvp;                // [B][V][3] out: d loss / d v_posed
+    float* doff_ft;            // FT32 [Bpad][Cpad] out (same values, GEMM operand layout)
+    int Cpad;
+};
+__global__ void __launch_bounds__(256) k_skin_bwd(SkinBwdArgs a) {
+    extern __shared__ float sA[];
+    const int64_t b = blockIdx.y;
+    for (int i = threadIdx.x; i < a.J * 12; i += 256) sA[i] = a.A[b * a.J * 12 + i];
+    __syncthreads();
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < a.V; v += gridDim.x * 256) {
+        const float* vs = a.v_shaped + (a.v_shaped_batched ? b * a.V * 3 : 0) + (int64_t)v * 3;
+        const float* off = a.offsets + b * a.ld_off + (int64_t)v * 3;
+        const float* dv = a.dverts + (b * a.V + v) * 3;
+        float T[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) T[i] = 0.f;
+        for (int k = 0; k < a.K; ++k) {
+            const float w = a.skin_w[(int64_t)v * a.K + k];
+            const float* Aj = sA + a.skin_idx[(int64_t)v * a.K + k] * 12;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) T[3 * r + c] += w * Aj[4 * r + c];
+        }
+        const float dx = dv[0], dy = dv[1], dz = dv[2];
+        float g[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] = T[c] * dx + T[3 + c] * dy + T[6 + c] * dz;     // T_R^T dv
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.vp[(b * a.V + v) * 3 + c] = vs[c] + off[c];
+            a.dvp[(b * a.V + v) * 3 + c] = g[c];
+            a.doff_ft[FT<float>::index(b, v * 3 + c, a.Cpad)] = g[c];
+        }
+    }
+}
+
+// dA[b][j] = sum over the vertices skinned to joint j of w_vj * (dv_v (x) [vp_v ; 1]); one block per (pose, joint),
+// fixed-order tree reduction => deterministic.
+struct JointBwdArgs {
+    const float* dverts;
+    const float* vp;
+    const int32_t* jptr;       // [J+1] CSR by joint
+    const int32_t* jvidx;      // [nnz]
+    const float* jw;           // [nnz]
+    float* dA;                 // [B][J][12]
+    int J, V;
+};
+__global__ void __launch_bounds__(128) k_skin_bwd_joints(JointBwdArgs a) {
+    __shared__ float red[128][13];
+    const int j = blockIdx.x;
+    const int64_t b = blockIdx.y;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int e = a.jptr[j] + threadIdx.x; e < a.jptr[j + 1]; e += 128) {
+        const int v = a.jvidx[e];
+        const float w = a.jw[e];
+        const float* dv = a.dverts + (b * a.V + v) * 3;
+        const float* p = a.vp + (b * a.V + v) * 3;
+        const float h[4] = {p[0], p[1], p[2], 1.0f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[4 * r + c] += w * dv[r] * h[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) red[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    for (int s = 64; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) red[threadIdx.x][i] += red[threadIdx.x + s][i];
+        __syncthreads();
+    }
+    if (threadIdx.x < 12) a.dA[(b * a.J + j) * 12 + threadIdx.x] = red[0][threadIdx.x];
+}
+
+struct FkBwdArgs {
+    const float* seg[FK_MAX_SEG];
+    float* dseg[FK_MAX_SEG];       // gradient w.r.t. each pose segment (null: not needed)
+    int seg_first[FK_MAX_SEG], seg_joints[FK_MAX_SEG], nseg;
+    const float* j_rest;
+    int j_rest_batched;
+    const float* A;                // [B][J][12] forward skinning transforms
+    const float* dA;               // [B][J][12]
+    const float* djoints;          // [B][ld_dj] gradient w.r.t. posed joints (first J*3 of each row)
+    int64_t ld_dj;
+    const float* dpf;              // [nsplit][Bpad_pf][ldpf] slabs of d loss / d pose_feature, or null
+    int64_t dpf_slab, ldpf;
+    int nsplit;
+    float* djrest;                 // [B][J][3] out or null
+    float* dG;                     // scratch [B][J][12]
+    const int* parents;            // device [J]
+    int J;
+    int64_t B;
+};
+__device__ __forceinline__ int fk_seg_of(const FkBwdArgs& a, int joint, int& local) {
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < FK_MAX_SEG; ++k)
+        if (k < a.nseg && joint >= a.seg_first[k]) s = k;
+    local = joint - a.seg_first[s];
+    return s;
+}
+__global__ void __launch_bounds__(64) k_fk_bwd(FkBwdArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    const int J = a.J;
+    const float* jr = a.j_rest_batched ? a.j_rest + b * J * 3 : a.j_rest;
+    float* dG = a.dG + b * J * 12;
+    const float* A = a.A + b * J * 12;
+    // initialise dG_i from dA_i and d joints:  A_i = [R | t - R J_i],  joints_i = t
+    for (int i = 0; i < J; ++i) {
+        const float* dAi = a.dA + (b * J + i) * 12;
+        const float J3[3] = {jr[3 * i], jr[3 * i + 1], jr[3 * i + 2]};
+        float djr[3] = {0.f, 0.f, 0.f};
+        for (int r = 0; r < 3; ++r) {
+            const float dat = dAi[4 * r + 3];
+            for (int c = 0; c < 3; ++c) {
+                dG[i * 12 + 4 * r + c] = dAi[4 * r + c] - dat * J3[c];            // d R^G
+                djr[c] -= A[i * 12 + 4 * r + c] * dat;                               // d J_i += -R^T dA_t
+            }
+            dG[i * 12 + 4 * r + 3] = dat + a.djoints[b * a.ld_dj + 3 * i + r];      // d t
+        }
+        if (a.djrest) for (int c = 0; c < 3; ++c) a.djrest[(b * J + i) * 3 + c] = djr[c];
+    }
+    // reverse chain
+    for (int i = J - 1; i >= 0; --i) {
+        const int p = a.parents[i];
+        int li;
+        const int sg = fk_seg_of(a, i, li);
+        const float* pose = a.seg[sg];
+        float rx = 0.f, ry = 0.f, rz = 0.f;
+        if (pose) { const float* q = pose + (b * a.seg_joints[sg] + li) * 3; rx = q[0]; ry = q[1]; rz = q[2]; }
+        const Mat3 R = rodrigues(rx, ry, rz);
+        float dRG[9], dt[3];
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) dRG[3 * r + c] = dG[i * 12 + 4 * r + c]; dt[r] = dG[i * 12 + 4 * r + 3]; }
+        float dR[9];                                   // gradient w.r.t. the LOCAL rotation R_i
+        if (i == 0) {
+            for (int k = 0; k < 9; ++k) dR[k] = dRG[k];
+            if (a.djrest) for (int c = 0; c < 3; ++c) a.djrest[(b * J) * 3 + c] += dt[c];      // t_0 = J_0
+        } else {
+            // parent's global transform from the forward pass: R^G_p = A_p[:, :3],  rel_i = J_i - J_p
+            float RP[9];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) RP[3 * r + c] = A[p * 12 + 4 * r + c];
+            const float rel[3] = {jr[3 * i] - jr[3 * p], jr[3 * i + 1] - jr[3 * p + 1], jr[3 * i + 2] - jr[3 * p + 2]};
+            // dR_i = RP^T dRG ;  d rel = RP^T dt ;  dRG_p += dRG R_i^T + dt (x) rel ;  dt_p += dt
+            float drel[3];
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) dR[3 * r + c] = RP[r] * dRG[c] + RP[3 + r] * dRG[3 + c] + RP[6 + r] * dRG[6 + c];
+                drel[r] = RP[r] * dt[0] + RP[3 + r] * dt[1] + RP[6 + r] * dt[2];
+            }
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c)
+                    dG[p * 12 + 4 * r + c] += dRG[3 * r] * R.m[3 * c] + dRG[3 * r + 1] * R.m[3 * c + 1] + dRG[3 * r + 2] * R.m[3 * c + 2] + dt[r] * rel[c];
+                dG[p * 12 + 4 * r + 3] += dt[r];
+            }
+            if (a.djrest) for (int c = 0; c < 3; ++c) { a.djrest[(b * J + i) * 3 + c] += drel[c]; a.djrest[(b * J + p) * 3 + c] -= drel[c]; }
+            if (a.dpf)                                 // pose feature = R_i - I for i >= 1
+                for (int k = 0; k < 9; ++k) {
+                    float acc = 0.f;
+                    for (int sidx = 0; sidx < a.nsplit; ++sidx) acc += a.dpf[sidx * a.dpf_slab + b * a.ldpf + (i - 1) * 9 + k];
+                    dR[k] += acc;
+                }
+        }
+        float* dq = a.dseg[sg];
+        if (!dq) continue;
+        // Rodrigues backward: R = I + s K + c1 K^2, K = skew(k), k = r / angle
+        const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
+        const float angle = sqrtf(ax * ax + ay * ay + az * az);
+        const float inv = 1.0f / angle;
+        const float kx = rx * inv, ky = ry * inv, kz = rz * inv;
+        float sn, cs;
+        sincos_small(angle, sn, cs);
+        const float c1 = 1.0f - cs;
+        const float K[9] = {0.f, -kz, ky, kz, 0.f, -kx, -ky, kx, 0.f};
+        float KK[9];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) KK[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+        float ds = 0.f, dc1 = 0.f;
+        for (int k = 0; k < 9; ++k) { ds += dR[k] * K[k]; dc1 += dR[k] * KK[k]; }
+        float dK[9];                                   // s dR + c1 (dR K^T + K^T dR)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                float t1 = 0.f, t2 = 0.f;
+                for (int m = 0; m < 3; ++m) { t1 += dR[3 * r + m] * K[3 * c + m]; t2 += K[3 * m + r] * dR[3 * m + c]; }
+                dK[3 * r + c] = sn * dR[3 * r + c] + c1 * (t1 + t2);
+            }
+        const float dk[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+        const float dtheta = ds * cs + dc1 * sn;
+        const float kdk = kx * dk[0] + ky * dk[1] + kz * dk[2];
+        const float kv[3] = {kx, ky, kz};
+        float* o = dq + (b * a.seg_joints[sg] + li) * 3;
+        for (int c = 0; c < 3; ++c) o[c] = (dk[c] - kdk * kv[c]) * inv + dtheta * kv[c];
+    }
+}
+
+extern "C" int64_t dposer_lbs_posedirs_bwd_packed_bytes(dposer_body_t h) {
+    if (!h) return -1;
+    return round_up((h->d.num_joints - 1) * 9, 128) * lbs_cpad(h->d.num_vertices) * 4;        // FT32 [rows = pose feature][k = vertex coord]
+}
+extern "C" int dposer_lbs_pack_posedirs_bwd(dposer_body_t h, const float* posedirs, void* packed, void* stream) {
+    DP_CHECK_ARG(h && posedirs && packed, "null argument");
+    PackJobs js;
+    js.n = 1;
+    PackJob& j = js.job[0];
+    const int P = (h->d.num_joints - 1) * 9;
+    j.dst_off = 0; j.src_off = 0; j.ktot = (int)lbs_cpad(h->d.num_vertices); j.koff = 0;
+    j.rows_pad = (int)round_up(P, 128); j.kpad = j.ktot; j.rows_valid = P; j.cols_valid = h->d.num_vertices * 3;
+    j.ld = h->d.num_vertices * 3; j.trans = 0; j.f32 = 1;
+    FK_HIP_LAUNCH(launch_pack(js, posedirs, packed, (hipStream_t)stream));
+    return DPOSER_OK;
+}
+static int lbs_bwd_ksplit(int64_t stages) {
+    int ks = 1;
+    for (int c = 2; c <= 24; ++c)
+        if (stages % c == 0 && stages / c >= 8) ks = c;
+    return ks;
+}
+extern "C" int64_t dposer_lbs_backward_workspace_bytes(dposer_body_t h, int64_t batch) {
+    if (!h || batch <= 0) return -1;
+    const int64_t Bpad = lbs_pad_batch(batch), Cpad = lbs_cpad(h->d.num_vertices);
+    const int J = h->d.num_joints, V = h->d.num_vertices;
+    const int64_t prow = round_up((J - 1) * 9, 128);
+    int64_t p = 0;
+    p += round_up(batch * V * 3 * 4, 256) * 2;         // vp, dvp
+    p += round_up(Bpad * Cpad * 4, 256);               // doff FT32
+    p += round_up(batch * J * 12 * 4, 256) * 2;        // dA, dG
+    p += round_up(24 * Bpad * prow * 4, 256);          // dpf slabs
+    p += 256;                                          // parents
+    return p;
+}
+
+// ws_fwd: the workspace the matching dposer_lbs_forward call used (pose feature, A, offsets are read back).
+extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
+                                   const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,
+                                   const float* j_rest, int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched,
+                                   const int32_t* skin_idx, const float* skin_w, int32_t skin_k, const int32_t* joint_ptr,
+                                   const int32_t* joint_vidx, const float* joint_w, const float* d_verts, const float* d_joints,
+                                   int64_t d_joints_ld, float* const* d_pose_segments_host, float* d_jrest, float* d_vposed,
+                                   int64_t batch, void* stream) {
+    DP_CHECK_ARG(h && ws_fwd && ws_bwd && posedirs_bwd_packed && pose_segments_host && segment_joints_host && j_rest && v_shaped && skin_idx &&
+                     skin_w && joint_ptr && joint_vidx && joint_w && d_verts && d_joints && d_pose_segments_host,
+                 "null argument");
+    DP_CHECK_ARG(batch > 0 && num_segments >= 1 && num_segments <= FK_MAX_SEG, "bad size");
+    hipStream_t st = (hipStream_t)stream;
+    const int J = h->d.num_joints, V = h->d.num_vertices;
+    const int64_t Bpad = lbs_pad_batch(batch), Cpad = lbs_cpad(V);
+    const int Ppad = lbs_ppad(J);
+    const int64_t prow = round_up((J - 1) * 9, 128);
+    // forward workspace layout (dposer_lbs_forward)
+    const char* pf_ = (const char*)ws_fwd;
+    const float* A = (const float*)(pf_ + round_up(Bpad * Ppad * 4, 256));
+    const float* offsets = (const float*)((const char*)A + round_up(batch * J * 12 * 4, 256));
+    char* p = (char*)ws_bwd;
+    float* vp = (float*)p; p += round_up(batch * V * 3 * 4, 256);
+    float* dvp = (float*)p; p += round_up(batch * V * 3 * 4, 256);
+    float* doff = (float*)p; p += round_up(Bpad * Cpad * 4, 256);
+    float* dA = (float*)p; p += round_up(batch * J * 12 * 4, 256);
+    float* dG = (float*)p; p += round_up(batch * J * 12 * 4, 256);
+    float* dpf = (float*)p; p += round_up(24 * Bpad * prow * 4, 256);
+    int* parents_dev = (int*)p;
+    DP_CHECK_HIP(hipMemcpyAsync(parents_dev, h->parents, J * sizeof(int), hipMemcpyHostToDevice, st));
+    DP_CHECK_HIP(hipMemsetAsync(doff, 0, Bpad * Cpad * 4, st));
+    {
+        SkinBwdArgs a;
+        a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
+        a.skin_idx = skin_idx; a.skin_w = skin_w; a.K = skin_k; a.J = J; a.V = V; a.vp = vp; a.dvp = d_vposed ? d_vposed : dvp; a.doff_ft = doff;
+        a.Cpad = (int)Cpad;
+        hipLaunchKernelGGL(k_skin_bwd, dim3((unsigned)ceil_div(V, 256 * 4), (unsigned)batch), dim3(256), J * 12 * sizeof(float), st, a);
+        FK_HIP_LAUNCH(hipGetLastError());
+    }
+    {
+        JointBwdArgs a;
+        a.dverts = d_verts; a.vp = vp; a.jptr = joint_ptr; a.jvidx = joint_vidx; a.jw = joint_w; a.dA = dA; a.J = J; a.V = V;
+        hipLaunchKernelGGL(k_skin_bwd_joints, dim3((unsigned)J, (unsigned)batch), dim3(128), 0, st, a);
+        FK_HIP_LAUNCH(hipGetLastError());
+    }
+    // d pose_feature [B][486] = d_off [B][3V] @ posedirs^T : fp32 MFMA, split over the vertex dimension
+    const int64_t stages = Cpad / 32;
+    const int ks = lbs_bwd_ksplit(stages);
+    {
+        GemmArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.W = doff; g.w_stride_blocks = (int)(Cpad / 8); g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(prow / 128); g.ksplit = ks;
+        g.src[0] = posedirs_bwd_packed; g.seg_kblocks[0] = (int)(Cpad / 8); g.nseg = 1; g.ktot_blocks = (int)(Cpad / 8);
+        WgradParams wp;
+        wp.slab = dpf; wp.slab_stride = Bpad * prow; wp.ld = (int)prow; wp.N_valid = (int)batch; wp.K_valid = (J - 1) * 9;
+        FK_HIP_LAUNCH(gemm_wgrad(PREC_FP32, SHAPE_MID, g, wp, st));
+    }
+    {
+        FkBwdArgs a;
+        std::memset(&a, 0, sizeof(a));
+        int first = 0;
+        for (int i = 0; i < num_segments; ++i) {
+            a.seg[i] = pose_segments_host[i];
+            a.dseg[i] = d_pose_segments_host[i];
+            a.seg_first[i] = first;
+            a.seg_joints[i] = segment_joints_host[i];
+            first += segment_joints_host[i];
+        }
+        DP_CHECK_ARG(first == J, "pose segments must cover all joints of the kinematic tree");
+        a.nseg = num_segments; a.j_rest = j_rest; a.j_rest_batched = j_rest_batched; a.A = A; a.dA = dA; a.djoints = d_joints; a.ld_dj = d_joints_ld;
+        a.dpf = dpf; a.dpf_slab = Bpad * prow; a.ldpf = prow; a.nsplit = ks; a.djrest = d_jrest; a.dG = dG; a.parents = parents_dev; a.J = J;
+        a.B = batch;
+        hipLaunchKernelGGL(k_fk_bwd, dim3((unsigned)ceil_div(batch, 64)), dim3(64), 0, st, a);
         FK_HIP_LAUNCH(hipGetLastError());
     }
     return DPOSER_OK;

@@ -193,7 +193,8 @@ extern "C" int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat, void* 
 // ------------------------------------------------------------------------------------------------
 static int64_t pad_batch(int64_t B) { return B <= 512 ? round_up(B, 64) : round_up(B, 256); }
 static int main_shape(int64_t Spad) {
-    if (Spad % 256 == 0 && Spad >= 4096) return SHAPE_BIG;
+    static const int64_t big_min = [] { const char* e = getenv("DPOSER_BIG_MIN_BATCH"); return e ? atoll(e) : (int64_t)16384; }();
+    if (Spad % 256 == 0 && Spad >= big_min) return SHAPE_BIG;
     if (Spad % 128 == 0) return SHAPE_MID;
     return SHAPE_SMALL;
 }

@@ -209,6 +209,25 @@ int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedirs_packed, c
                        int32_t skin_k, const float* transl, const int32_t* extra_vertex_ids, const int32_t* lmk_tri,
                        const float* lmk_bary, float* verts, float* joints, int64_t batch, void* stream);
 
+/* Backward of dposer_lbs_forward (autograd of BodyModel.forward w.r.t. pose / rest joints / v_posed; the reference
+ * differentiates through smplx in run/motion_denoising.py:217-218,255-267 and run/smplify.py:200-260).
+ *   ws_fwd: the workspace of the matching forward call (unmodified since);  posedirs_bwd_packed:
+ *   dposer_lbs_pack_posedirs_bwd(posedirs);  joint_ptr [J+1] / joint_vidx / joint_w: CSR-by-joint form of lbs_weights;
+ *   d_verts [B,V,3]; d_joints [B, d_joints_ld] (first J*3 entries of a row = gradient of the posed LBS joints; extras and
+ *   landmarks are vertex gathers and must be folded into d_verts by the caller);
+ *   d_pose_segments_host[i]: DEVICE pointer [B, seg_joints*3] out or NULL;  d_jrest [B,J,3] out or NULL;
+ *   d_vposed [B,V,3] out or NULL (= gradient w.r.t. v_shaped). */
+int64_t dposer_lbs_posedirs_bwd_packed_bytes(dposer_body_t h);
+int dposer_lbs_pack_posedirs_bwd(dposer_body_t h, const float* posedirs, void* packed, void* stream);
+int64_t dposer_lbs_backward_workspace_bytes(dposer_body_t h, int64_t batch);
+int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
+                        const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,
+                        const float* j_rest, int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched,
+                        const int32_t* skin_idx, const float* skin_w, int32_t skin_k, const int32_t* joint_ptr,
+                        const int32_t* joint_vidx, const float* joint_w, const float* d_verts, const float* d_joints,
+                        int64_t d_joints_ld, float* const* d_pose_segments_host, float* d_jrest, float* d_vposed,
+                        int64_t batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

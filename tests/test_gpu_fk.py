@@ -122,3 +122,48 @@ def test_smplx_wrapper_joint_map(asset):
         full = sm.bm(body_pose=pose)
     assert o.joints.shape == (4, 49, 3)
     assert torch.equal(o.joints, full.joints[:, sm.joint_map.to(DEV)])
+
+
+def test_body_model_backward_vs_torch_autograd(bm, asset):
+    """d(loss)/d(pose_body, root_orient, betas, trans) of a random linear functional of vertices and the 127 joints:
+    HIP LBS backward vs torch fp64 autograd on the restated algorithm (oracle/fk_torch.py)."""
+    from oracle import fk_torch
+    B = 6
+    rs = np.random.RandomState(12)
+    pose, root = _poses(B, 21), (rs.standard_normal((B, 3)) * 0.4).astype(np.float32)
+    betas, trans = (rs.standard_normal((B, 10)) * 0.5).astype(np.float32), rs.standard_normal((B, 3)).astype(np.float32)
+    wv = rs.standard_normal((B, 10475, 3)).astype(np.float32) / 100.0
+    wj = rs.standard_normal((B, 127, 3)).astype(np.float32)
+    dev = lambda a: torch.tensor(a, device=DEV, requires_grad=True)
+    p_d, r_d, b_d, t_d = dev(pose), dev(root), dev(betas), dev(trans)
+    out = bm(pose_body=p_d, root_orient=r_d, betas=b_d, trans=t_d)
+    loss = (out.v * torch.tensor(wv, device=DEV)).sum() + (out.Jtr * torch.tensor(wj, device=DEV)).sum()
+    loss.backward()
+    ref = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    p_r, r_r, b_r, t_r = ref(pose), ref(root), ref(betas), ref(trans)
+    v, j = fk_torch.smplx_forward(asset, p_r, betas=b_r, global_orient=r_r, transl=t_r)
+    lref = (v * torch.tensor(wv, dtype=torch.float64)).sum() + (j * torch.tensor(wj, dtype=torch.float64)).sum()
+    lref.backward()
+    assert abs(float(loss) - float(lref)) / abs(float(lref)) < 1e-5
+    for name, got, want in (("pose", p_d.grad, p_r.grad), ("root", r_d.grad, r_r.grad), ("betas", b_d.grad, b_r.grad), ("trans", t_d.grad, t_r.grad)):
+        err = float(np.linalg.norm(t2n(got) - want.numpy()) / np.linalg.norm(want.numpy()))
+        assert err < 2e-4, (name, err)
+
+
+def test_body_model_backward_pose_only_shared_shape(bm, asset):
+    """The motion-denoising configuration: betas constant (shared v_shaped), gradient w.r.t. pose_body only, data term on
+    Jtr[:, :22] and a temporal term on vertices (run/motion_denoising.py:255-261)."""
+    from oracle import fk_torch
+    B = 12
+    pose = _poses(B, 33, scale=0.3)
+    p_d = torch.tensor(pose, device=DEV, requires_grad=True)
+    out = bm(pose_body=p_d)
+    tgt = torch.tensor(np.random.RandomState(5).standard_normal((B, 22, 3)).astype(np.float32), device=DEV)
+    loss = ((out.v[:-1] - out.v[1:]) ** 2).mean() + ((out.Jtr[:, :22] - tgt) ** 2).mean()
+    loss.backward()
+    p_r = torch.tensor(pose, dtype=torch.float64, requires_grad=True)
+    v, j = fk_torch.smplx_forward(asset, p_r)
+    lref = ((v[:-1] - v[1:]) ** 2).mean() + ((j[:, :22] - tgt.cpu().double()) ** 2).mean()
+    lref.backward()
+    err = float(np.linalg.norm(t2n(p_d.grad) - p_r.grad.numpy()) / np.linalg.norm(p_r.grad.numpy()))
+    assert err < 2e-4, err
