@@ -55,3 +55,46 @@ class Posenormalizer:
             from ..utils.transforms import rot6d_to_axis_angle
             out = rot6d_to_axis_angle(out.reshape(-1, 6)).reshape(*out.shape[:-1], -1)
         return out
+
+
+class Evaler:
+    """Completion evaluator -- counterpart of lib/dataset/AMASS.py:263-324.  The reference copies the whole
+    [B, 10475, 3] vertex tensor to the host inside a per-sample python loop; here the part-vertex / part-joint errors
+    are reduced on the device and only the [B] metric vectors travel."""
+
+    def __init__(self, body_model, part=None):
+        import numpy as np
+        from ..body_model.utils import BodyPartIndices, BodySegIndices
+        self.body_model = body_model
+        self.part = part
+        if part is not None:
+            self.joint_idx = torch.tensor(np.array(getattr(BodyPartIndices, part)) + 1)      # skip pelvis
+            self.vert_idx = torch.tensor(np.array(getattr(BodySegIndices, part)))
+        else:
+            self.joint_idx = self.vert_idx = None
+
+    def eval_bodys(self, outs, gts):
+        """outs, gts [b, 63] axis-angle body poses -> {'mpvpe_all': [b], 'mpjpe_body': [b]} in mm (device tensors)."""
+        with torch.no_grad():
+            body_gt = self.body_model(pose_body=gts)
+            body_out = self.body_model(pose_body=outs)
+            dv, dj = body_out.v - body_gt.v, body_out.Jtr - body_gt.Jtr
+            if self.vert_idx is not None:
+                dv = dv[:, self.vert_idx.to(dv.device)]
+                dj = dj[:, self.joint_idx.to(dj.device)]
+            return {"mpvpe_all": torch.sqrt((dv ** 2).sum(-1)).mean(-1) * 1000, "mpjpe_body": torch.sqrt((dj ** 2).sum(-1)).mean(-1) * 1000}
+
+    def multi_eval_bodys(self, outs, gts):
+        """outs [b, hypo, 63]: minimum over hypotheses (AMASS.py:300-316); returns numpy vectors like the reference."""
+        res = [self.eval_bodys(outs[:, h].contiguous(), gts) for h in range(outs.shape[1])]
+        return {k: torch.stack([r[k] for r in res], 0).min(0).values.cpu().numpy() for k in ("mpvpe_all", "mpjpe_body")}
+
+    def print_eval_result(self, eval_result):
+        import numpy as np
+        print("MPVPE (All): %.2f mm" % np.mean(eval_result["mpvpe_all"]))
+        print("MPJPE (Body): %.2f mm" % np.mean(eval_result["mpjpe_body"]))
+
+    def print_multi_eval_result(self, eval_result, hypo_num):
+        import numpy as np
+        print(f"multihypo {hypo_num} MPVPE (All): %.2f mm" % np.mean(eval_result["mpvpe_all"]))
+        print(f"multihypo {hypo_num} MPJPE (Body): %.2f mm" % np.mean(eval_result["mpjpe_body"]))

@@ -1,0 +1,153 @@
+"""GPU tests of the task-loop counterparts and the DPoser prior module: a few optimisation
+steps with injected noise against the same loop restated with the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_common import DEV, make_model, t2n
+from helpers import load, rel_err
+from oracle import fk_ref, fk_torch
+from oracle import score_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_completion(p, sde, obs, mask, noise, iterations, steps_per_iter, lr=0.1):
+    x = torch.tensor(obs, dtype=torch.float32, requires_grad=True)
+    opt = torch.optim.Adam([x], lr, betas=(0.9, 0.999))
+    obs_t, mask_t = torch.tensor(obs), torch.tensor(mask)
+    ts = torch.linspace(1.0, 1e-3, sde.N)
+    total = iterations * steps_per_iter
+    for it in range(iterations):
+        for i in range(steps_per_iter):
+            step = it * steps_per_iter + i
+            opt.zero_grad()
+            q = R.completion_quan_t(step, total, sde.N)
+            t = torch.ones(x.shape[0]) * ts[q]
+            lp, g = R.dposer_prior_loss(p, sde, x.detach(), t, torch.tensor(noise[step]), weighted=bool(q), reduction="mean")
+            ld = torch.nn.functional.mse_loss(x * mask_t, obs_t * mask_t)
+            (100 * ld / (1 + it)).backward()
+            x.grad += 0.1 * (it + 1) * g
+            opt.step()
+    return (obs_t * mask_t + x.detach() * (1 - mask_t)).numpy()
+
+
+def test_completion_loop_matches_oracle():
+    from dposer_amd.algorithms.advanced import sde_lib
+    from dposer_amd.tasks.completion import DPoserComp
+    from dposer_amd.utils.misc import create_mask
+    cfg, m, p = make_model(61, precision="fp32")
+    B, iters, spi = 24, 2, 4
+    g = load("g10_normalizer")
+    poses = torch.tensor(g["norm_minmax0"][:B])
+    torch.manual_seed(0)
+    mask, obs = create_mask(poses, part="legs")
+    noise = np.random.RandomState(1).standard_normal((iters * spi, B, 63)).astype(np.float32)
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    comp = DPoserComp(m, sde, continuous=True, batch_size=B)
+    for step in (0, 3, 7):
+        assert comp.quan_t(step, iters * spi, 1000) == R.completion_quan_t(step, iters * spi, 1000)
+    out = comp.optimize(obs.to(DEV), mask.to(DEV), iterations=iters, steps_per_iter=spi, noise=torch.tensor(noise, device=DEV))
+    ref = _oracle_completion(p, R.SubVP(), obs.numpy(), mask.numpy(), noise, iters, spi)
+    assert rel_err(t2n(out), ref) < 2e-4
+    assert np.array_equal(t2n(out) * mask.numpy(), obs.numpy() * mask.numpy())      # observed entries untouched
+
+
+def test_dposer_module_forward():
+    """DPoser(batch_size, config_path, args).forward(poses, betas, quan_t) (run/smplify.py:109-115) vs the oracle."""
+    from dposer_amd.dataset.AMASS import Posenormalizer
+    from dposer_amd.prior import DPoser
+    cfg, m, p = make_model(62, precision="fp32")
+    g = load("g10_normalizer")
+    stats = {k.split("/")[-1]: torch.tensor(g[k]) for k in g.files if k.startswith("stats/axis_normalize")}
+    B = 16
+
+    class Args:
+        device = DEV
+        sde_N = 500
+
+    nz = Posenormalizer(stats, device=DEV, normalize=True, min_max=False, rot_rep="axis")
+    prior = DPoser(batch_size=B, config_path="configs.subvp.amass_scorefc_continuous.get_config", args=Args(), model=m, normalizer=nz)
+    raw = torch.tensor(g["raw"][:B])
+    full = torch.cat([raw, torch.zeros(B, 6)], dim=1).to(DEV).requires_grad_(True)      # [B, 69] like SMPL body pose
+    z = np.random.RandomState(3).standard_normal((B, 63)).astype(np.float32)
+    loss = prior(full, None, 250, z=torch.tensor(z, device=DEV))
+    loss.backward()
+    x0 = (raw - stats["mean_poses"]) / stats["std_poses"]
+    t = torch.ones(B) * torch.linspace(1.0, 1e-3, 500)[250]
+    ref, gref = R.dposer_prior_loss(p, R.SubVP(N=500), x0, t, torch.tensor(z), weighted=True, reduction="sum_over_batch", batch_size=B)
+    assert abs(float(loss) - ref.item()) / abs(ref.item()) < 2e-4
+    assert rel_err(t2n(full.grad)[:, :63], (gref / stats["std_poses"]).numpy()) < 2e-4
+    assert float(full.grad[:, 63:].abs().max()) == 0.0
+
+
+def test_motion_denoise_steps_match_oracle():
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    from dposer_amd.dataset.AMASS import Posenormalizer
+    from dposer_amd.tasks.motion_denoising import MotionDenoise
+    cfg, m, p = make_model(63, precision="fp32")
+    asset = make_synthetic_smplx_asset(seed=0)
+    bm = BodyModel(asset).to(DEV)
+    g = load("g10_normalizer")
+    stats = {k.split("/")[-1]: torch.tensor(g[k]) for k in g.files if k.startswith("stats/axis_normalize")}
+    T, iters, spi = 12, 1, 3
+    gt = g["raw"][:T].astype(np.float32)
+    rs = np.random.RandomState(7)
+    init = (gt + rs.standard_normal(gt.shape) * 0.05).astype(np.float32)
+    _, jgt, _, _ = fk_ref.smplx_forward(asset, gt.astype(np.float64), dtype=np.float64)
+    joints3d = (jgt[:, :22] + rs.standard_normal((T, 22, 3)) * 0.04).astype(np.float32)
+    noise = rs.standard_normal((iters * spi, T, 63)).astype(np.float32)
+
+    class Args:
+        device = DEV
+
+    nz = Posenormalizer(stats, device=DEV, normalize=True, min_max=False, rot_rep="axis")
+    md = MotionDenoise(cfg, Args(), m, bm, sde_N=500, batch_size=T, normalizer=nz)
+    res = md.optimize(torch.tensor(joints3d, device=DEV), gt_poses=torch.tensor(gt, device=DEV), time_strategy="3", iterations=iters,
+                      steps_per_iter=spi, noise=torch.tensor(noise, device=DEV), init_poses=torch.tensor(init, device=DEV))
+    # oracle loop (float64 body model via torch autograd, fp32 score oracle)
+    pose = torch.tensor(init, dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam([pose], 0.03, betas=(0.9, 0.999))
+    ts = torch.linspace(1.0, 1e-3, 500)
+    mean, std = stats["mean_poses"].double(), stats["std_poses"].double()
+    for step in range(iters * spi):
+        opt.zero_grad()
+        q = int(500 - np.floor(float(np.float32(iters * spi - step - 1) * np.float32(500 / (2.0 * iters * spi)))) - 2)
+        x0 = ((pose - mean) / std).float().detach()
+        _, gprior = R.dposer_prior_loss(p, R.SubVP(N=500), x0, torch.ones(T) * ts[q], torch.tensor(noise[step]), weighted=False,
+                                        reduction="sum_over_batch", batch_size=T)
+        v, j = fk_torch.smplx_forward(asset, pose)
+        temp = v[:-1] - v[1:]
+        l_temp = torch.mean(torch.sqrt(torch.sum(temp * temp, dim=2)))
+        data = j[:, :22] - torch.tensor(joints3d, dtype=torch.float64)
+        l_data = torch.mean(torch.sqrt(torch.sum(data * data, dim=2)))
+        (10.0 * l_temp * 1 + 100.0 * l_data / 1).backward()
+        pose.grad += 0.1 * (gprior.double() / std)
+        opt.step()
+    assert rel_err(t2n(res["pose_body"]), pose.detach().numpy()) < 5e-4
+    assert res["MPJPE"].shape == (T,) and np.isfinite(res["MPVPE"]).all()
+
+
+def test_evaler_min_over_hypotheses():
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    from dposer_amd.dataset.AMASS import Evaler
+    asset = make_synthetic_smplx_asset(seed=0)
+    bm = BodyModel(asset).to(DEV)
+    g = load("g10_normalizer")
+    gts = g["raw"][:5].astype(np.float32)
+    rs = np.random.RandomState(2)
+    outs = np.stack([gts + rs.standard_normal(gts.shape).astype(np.float32) * s for s in (0.2, 0.05, 0.1)], axis=1)
+    ev = Evaler(bm, part="legs")
+    res = ev.multi_eval_bodys(torch.tensor(outs, device=DEV), torch.tensor(gts, device=DEV))
+    from dposer_amd.body_model.utils import BodyPartIndices, BodySegIndices
+    ji, vi = np.array(BodyPartIndices.legs) + 1, np.array(BodySegIndices.legs)
+    vg, jg, _, _ = fk_ref.smplx_forward(asset, gts.astype(np.float64), dtype=np.float64)
+    mv, mj = [], []
+    for h in range(3):
+        vo, jo, _, _ = fk_ref.smplx_forward(asset, outs[:, h].astype(np.float64), dtype=np.float64)
+        mv.append(np.sqrt(((vo - vg)[:, vi] ** 2).sum(-1)).mean(-1) * 1000)
+        mj.append(np.sqrt(((jo - jg)[:, ji] ** 2).sum(-1)).mean(-1) * 1000)
+    assert np.allclose(res["mpvpe_all"], np.min(mv, 0), rtol=1e-4, atol=1e-3)
+    assert np.allclose(res["mpjpe_body"], np.min(mj, 0), rtol=1e-4, atol=1e-3)
