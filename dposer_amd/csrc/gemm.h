@@ -59,6 +59,11 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 
 // s_waitcnt immediate for "vmcnt(N) only" on gfx9-family encodings: vmcnt = [15:14|3:0], expcnt [6:4], lgkmcnt [11:8]
 constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+__device__ __forceinline__ void __syncthreads_lds_only() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 constexpr int waitcnt_vm_lgkm0(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0x0 << 8); }
 
 template <typename T, int WC, int WS, int TC, int TS, int KB>
@@ -105,7 +110,7 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     const int split = blockIdx.y;
 
     constexpr int NPAR = EpiParamArrays<Epi>::value;
-    float* lds_par = reinterpret_cast<float*>(smem + (GLDS == 3 ? 3 : 2) * C::STAGE_BYTES);   // [NPAR][CT*32]
+    float* lds_par = reinterpret_cast<float*>(smem + (GLDS >= 3 ? GLDS : 2) * C::STAGE_BYTES);   // [NPAR][CT*32]
     if constexpr (NPAR > 0) {
         for (int i = threadIdx.x; i < NPAR * C::CT * 32; i += C::THREADS) {
             const int a = i / (C::CT * 32), c = i % (C::CT * 32);
@@ -194,6 +199,7 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     auto fetch_glds = [&](int buf) __attribute__((always_inline)) {
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
+#ifndef GEMM_EXPERIMENT_SKIP_A
 #pragma unroll
         for (int i = 0; i < C::LPW_A; ++i) {
             const int blk = wave + i * C::NW;
@@ -202,6 +208,8 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
                                      (((int64_t)(cblk * C::CT + rb) * g.w_stride_blocks + w_kb + kb) << 10);
             __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + (blk << 10)), 16, 0, 0);
         }
+#endif
+#ifndef GEMM_EXPERIMENT_SKIP_B
 #pragma unroll
         for (int i = 0; i < C::LPW_B; ++i) {
             const int blk = wave + i * C::NW;
@@ -209,6 +217,7 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
             const unsigned char* p = sbase + (((int64_t)(sblk * C::ST + rb) * seg_total + seg_kb + kb) << 10);
             __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + ((C::CT * KB + blk) << 10)), 16, 0, 0);
         }
+#endif
         seg_kb += KB;
         w_kb += KB;
         if (seg_kb >= seg_end && seg + 1 < g.nseg) {
@@ -227,8 +236,13 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
             Frag a[TC], b[TS];
 #pragma unroll
             for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const Frag*>(a_base + ((i * KB + kb) << 10));
+#ifdef GEMM_EXPERIMENT_NO_B_READ
+#pragma unroll
+            for (int j = 0; j < TS; ++j) b[j] = a[j];
+#else
 #pragma unroll
             for (int j = 0; j < TS; ++j) b[j] = *reinterpret_cast<const Frag*>(b_base + ((j * KB + kb) << 10));
+#endif
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -237,31 +251,142 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     };
 
     // ---- software pipeline: global -> regs (next stage) overlaps MFMA on the current stage -----
-    if constexpr (GLDS == 3) {
-        // 3-deep LDS ring, prefetch distance 2: the DMA of stage t+1 stays in flight across the barrier of stage t
-        // (raw s_barrier + counted vmcnt; __syncthreads() would drain it).
-        fetch_glds(0);
-        if (nstages > 1) fetch_glds(1);
-        int buf = 0;
+    if constexpr (GLDS >= 3) {
+        // GLDS-deep LDS ring, prefetch distance GLDS-1: the DMAs of up to GLDS-2 later stages stay in flight across the
+        // barrier of stage t (raw s_barrier + counted vmcnt; __syncthreads() would drain them).  More bytes in flight
+        // per CU is what hides the ~2 us L2/HBM -> LDS latency (Little's law: 64 KiB in flight = 32 GB/s per CU).
+        constexpr int NB = GLDS, D = GLDS - 1;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+            if (i < nstages) fetch_glds(i);
+        int buf = 0, fbuf = D % NB;
         for (int t = 0; t < nstages; ++t) {
-            if (t + 1 < nstages) __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(C::LPW));   // stage t landed, t+1 may fly
+            const int ahead = nstages - 1 - t;       // stages issued after t that may still be in flight
+            if (ahead >= D - 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0((D - 1) * C::LPW));
+            else if (D >= 3 && ahead == 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(1 * C::LPW));
+            else if (D >= 4 && ahead == 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(2 * C::LPW));
             else __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (t + 2 < nstages) fetch_glds(buf >= 1 ? buf - 1 : 2);                       // (t + 2) % 3
+            if (t + D < nstages) fetch_glds(fbuf);                 // refills the buffer stage t-1 just released
             compute(buf);
-            buf = buf == 2 ? 0 : buf + 1;
+            buf = buf + 1 == NB ? 0 : buf + 1;
+            fbuf = fbuf + 1 == NB ? 0 : fbuf + 1;
         }
-    } else if constexpr (GLDS == 1) {
+    } else if constexpr (GLDS == 2) {
+        // double buffer, but the DMA of stage t+1 is issued in KB slices between the MFMA groups of stage t and the
+        // MFMA clusters run at raised priority
+        auto fetch_part = [&](int buf, int part) __attribute__((always_inline)) {
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+            for (int i = 0; i < C::LPW_A; ++i) {
+                if (i % KB != part) continue;
+                const int blk = wave + i * C::NW;
+                const int rb = blk / KB, kb = blk % KB;
+                const unsigned char* p = reinterpret_cast<const unsigned char*>(g.W) +
+                                         (((int64_t)(cblk * C::CT + rb) * g.w_stride_blocks + w_kb + kb) << 10);
+                __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + (blk << 10)), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < C::LPW_B; ++i) {
+                if (i % KB != part) continue;
+                const int blk = wave + i * C::NW;
+                const int rb = blk / KB, kb = blk % KB;
+                const unsigned char* p = sbase + (((int64_t)(sblk * C::ST + rb) * seg_total + seg_kb + kb) << 10);
+                __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + ((C::CT * KB + blk) << 10)), 16, 0, 0);
+            }
+        };
+        auto advance = [&]() __attribute__((always_inline)) {
+            seg_kb += KB;
+            w_kb += KB;
+            if (seg_kb >= seg_end && seg + 1 < g.nseg) {
+                ++seg;
+                seg_kb = 0;
+                seg_total = seg_blocks(seg);
+                seg_end = seg_total;
+                sbase = seg_ptr(seg);
+            }
+        };
         fetch_glds(0);
-        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): stage 0 landed in LDS
+        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         for (int t = 0; t < nstages; ++t) {
-            if (t + 1 < nstages) fetch_glds((t + 1) & 1);
-            compute(t & 1);
+            const bool more = t + 1 < nstages;
+            const int buf = t & 1;
+            const unsigned char* a_base = smem + buf * C::STAGE_BYTES + ((wc * TC * KB) << 10) + lane * 16;
+            const unsigned char* b_base = smem + buf * C::STAGE_BYTES + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                Frag a[TC], b[TS];
+#pragma unroll
+                for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const Frag*>(a_base + ((i * KB + kb) << 10));
+#pragma unroll
+                for (int j = 0; j < TS; ++j) b[j] = *reinterpret_cast<const Frag*>(b_base + ((j * KB + kb) << 10));
+                if (more) fetch_part(buf ^ 1, kb);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TS; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (more) advance();
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
+        }
+    } else if constexpr (GLDS == 1) {
+        // Double-buffered LDS ring + double-buffered operand fragments: the ds_reads of k-block kb+1 are issued BEFORE the
+        // MFMAs of k-block kb, so LDS latency hides under the matrix pipe (left to itself hipcc reuses one fragment register
+        // set and serialises read -> wait -> MFMA per k-block: 44 % MFMA utilisation).  The stage barrier sits in front of
+        // the LAST MFMA group of a stage, followed by the DMA issue of stage t+2 and the first fragment reads of stage t+1.
+        Frag fa[2][TC], fb[2][TS];
+        auto load_frags = [&](int buf, int kb, int set) __attribute__((always_inline)) {
+            const unsigned char* a_base = smem + buf * C::STAGE_BYTES + ((wc * TC * KB) << 10) + lane * 16;
+            const unsigned char* b_base = smem + buf * C::STAGE_BYTES + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
+#ifdef GEMM_EXPERIMENT_NO_A_READ
+            if (kb == 0 && buf == 0)
+#endif
+#pragma unroll
+            for (int i = 0; i < TC; ++i) fa[set][i] = *reinterpret_cast<const Frag*>(a_base + ((i * KB + kb) << 10));
+#ifdef GEMM_EXPERIMENT_NO_B_READ
+            if (kb == 0 && buf == 0)
+#endif
+#pragma unroll
+            for (int j = 0; j < TS; ++j) fb[set][j] = *reinterpret_cast<const Frag*>(b_base + ((j * KB + kb) << 10));
+        };
+        auto mma = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TS; ++j) Mma<T>::run(fa[set][i], fb[set][j], acc[i][j]);
+        };
+        static_assert(KB % 2 == 0, "fragment double buffering assumes an even number of k-blocks per stage");
+        fetch_glds(0);
+        if (nstages > 1) fetch_glds(1);
+        if (nstages > 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(C::LPW)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+        __syncthreads_lds_only();
+        load_frags(0, 0, 0);
+        for (int t = 0; t < nstages; ++t) {
+            const int buf = t & 1;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                if (kb + 1 < KB) {
+                    load_frags(buf, kb + 1, (kb + 1) & 1);
+                } else if (t + 1 < nstages) {
+                    // stage t+1 must have landed (its DMA was issued one full stage ago); every wave is done reading buf
+                    __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (t + 2 < nstages) fetch_glds(buf);            // refill the buffer we just finished reading
+                    load_frags(buf ^ 1, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma(kb & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     } else {
         fetch();
@@ -284,7 +409,7 @@ template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int 
 static inline hipError_t launch_gemm(const GemmArgs& g, const typename Epi::Params& ep, hipStream_t stream) {
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
     auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi, GLDS>;
-    constexpr int lds_bytes = (GLDS == 3 ? 3 : 2) * C::STAGE_BYTES + EpiParamArrays<Epi>::value * C::CT * 32 * 4;
+    constexpr int lds_bytes = (GLDS >= 3 ? GLDS : 2) * C::STAGE_BYTES + EpiParamArrays<Epi>::value * C::CT * 32 * 4;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && lds_bytes > 64 * 1024) {
