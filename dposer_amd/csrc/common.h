@@ -161,6 +161,60 @@ template <> struct TileIO<__bf16> {
         }
     }
 };
+// Transposed store of a 32x32 tile: the same values written as FT[channel rows][sample k] (the operand layout of the
+// wgrad GEMMs, which reduce over samples).  The tile is transposed through a per-wave LDS scratch (row = channel, row
+// stride 80 B / 144 B => conflict-free b128 reads) and leaves as lane-linear 16-byte chunks, 1 KiB per instruction.
+//   tileT points at element 0 of FT block (row block c0/32, k-block of sample s0) of the [C][Spad] matrix.
+template <typename T> struct TileT;
+template <> struct TileT<__bf16> {
+    static constexpr int SCRATCH_BYTES = 32 * 80;
+    __device__ static inline void store(__bf16* tileT, unsigned char* scratch, int lane, const float (&v)[16]) {
+        const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<__bf16*>(scratch + (8 * q + 4 * hi + r) * 80 + j * 2) = (__bf16)v[4 * q + r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): this wave's LDS writes are done (wave-private scratch)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                             // k-block h = samples 16h .. 16h+15
+            u32x4 o = *reinterpret_cast<const u32x4*>(scratch + j * 80 + (16 * h + 8 * hi) * 2);
+            *reinterpret_cast<u32x4*>(tileT + h * 512 + lane * 8) = o;
+        }
+        asm volatile("" ::: "memory");
+    }
+};
+template <> struct TileT<float> {
+    static constexpr int SCRATCH_BYTES = 16 * 144;                // two passes of 16 channels keep the BIG fp32 tile inside 160 KB
+    __device__ static inline void store(float* tileT, unsigned char* scratch, int lane, const float (&v)[16]) {
+        const int j = lane & 31, hi = lane >> 5;
+        const int r16 = lane & 15, c4 = lane >> 4;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {                    // channels 16*pass .. 16*pass+15
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<float*>(scratch + (8 * q2 + 4 * hi + r) * 144 + j * 4) = v[4 * (2 * pass + q2) + r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {                // sample chunk sc = 4 samples; k-block = sc>>1, kh = sc&1
+                const int sc = 4 * half + c4;
+                f32x4 o = *reinterpret_cast<const f32x4*>(scratch + r16 * 144 + sc * 16);
+                *reinterpret_cast<f32x4*>(tileT + (sc >> 1) * 256 + ((sc & 1) * 32 + 16 * pass + r16) * 4) = o;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                   // reads done before the next pass overwrites the scratch
+            asm volatile("" ::: "memory");
+        }
+    }
+};
+// element offset of FT block (row block of channel c0, k-block of sample s0) in the transposed [C][Spad] matrix
+template <typename T> __device__ __forceinline__ int64_t ft_tileT_base(int64_t s0, int c0, int64_t Spad) {
+    return ((int64_t)(c0 >> 5) * (Spad / FT<T>::KBS) + s0 / FT<T>::KBS) * FT<T>::BLOCK_ELEMS;
+}
+
 // element offset of the FT block holding (sample block of s0, k-block of channel c0); s0 % 32 == 0, c0 % 32 == 0
 template <typename T> __device__ __forceinline__ int64_t ft_tile_base(int64_t s0, int c0, int K) {
     return ((s0 >> 5) * (int64_t)(K / FT<T>::KBS) + c0 / FT<T>::KBS) * FT<T>::BLOCK_ELEMS;

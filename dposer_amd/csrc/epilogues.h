@@ -44,13 +44,16 @@ struct GNParams {
     float* rstd;           // TRAIN: [Spad][H/32]
     int H;
     DropoutCfg drop;
+    void* outT;            // TRAIN, optional: the output again as FT [H][Spad] (operand of the wgrad GEMMs)
+    int64_t Spad;
 };
 template <typename T, bool TRAIN> struct EpiGN {
     typedef GNParams Params;
+    static constexpr int kScratchPerWave = TRAIN ? TileT<T>::SCRATCH_BYTES : 0;
     static constexpr int kParamArrays = 3;
     __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.bias : (a == 1 ? p.gamma : p.beta); }
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
         struct { const float *bias, *gamma, *beta; T* out; const T* resid; T* xhat; float* rstd; int H; DropoutCfg drop; } p =
             {pp.bias, pp.gamma, pp.beta, (T*)pp.out, (const T*)pp.resid, (T*)pp.xhat, pp.rstd, pp.H, pp.drop};
         constexpr bool PRECISE = sizeof(T) == 4;
@@ -103,6 +106,7 @@ template <typename T, bool TRAIN> struct EpiGN {
                     for (int r = 0; r < 16; ++r) o[r] += rr[r];
                 }
                 TileIO<T>::store(p.out + tb, lane, o);
+                if (TRAIN && pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, o);
             }
         }
     }
@@ -114,13 +118,16 @@ struct BiasSiLUParams {
     void* out;     // FT [Spad][N]
     void* pre;     // TRAIN: u = acc + bias, FT [Spad][N]
     int N;
+    void* outT;    // TRAIN, optional: FT [N][Spad]
+    int64_t Spad;
 };
 template <typename T, bool TRAIN> struct EpiBiasSiLU {
     typedef BiasSiLUParams Params;
+    static constexpr int kScratchPerWave = TRAIN ? TileT<T>::SCRATCH_BYTES : 0;
     static constexpr int kParamArrays = 1;
     __device__ static inline const float* param_array(const Params& p, int) { return p.bias; }
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
         struct { const float* bias; T* out; T* pre; int N; } p = {pp.bias, (T*)pp.out, (T*)pp.pre, pp.N};
         constexpr bool PRECISE = sizeof(T) == 4;
         const int hi = lane >> 5;
@@ -142,6 +149,7 @@ template <typename T, bool TRAIN> struct EpiBiasSiLU {
                 for (int r = 0; r < 16; ++r) { u[r] = acc[tc][ts][r] + bia[r]; o[r] = silu_f<PRECISE>(u[r]); }
                 if (TRAIN) TileIO<T>::store(p.pre + tb, lane, u);
                 TileIO<T>::store(p.out + tb, lane, o);
+                if (TRAIN && pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, o);
             }
         }
     }
@@ -159,7 +167,7 @@ struct RowMajorParams {
 template <typename T> struct EpiRowMajor {
     typedef RowMajorParams Params;
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride) {
+    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
         const int j = lane & 31, hi = lane >> 5;
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc)
@@ -190,7 +198,7 @@ struct PlainFTParams {
 template <typename T> struct EpiPlainFT {
     typedef PlainFTParams Params;
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
         struct { T* out; int N; } p = {(T*)pp.out, pp.N};
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc)
@@ -245,14 +253,17 @@ struct GNBwdParams {
     int H;
     int64_t S_valid;
     DropoutCfg drop;
+    void* dyT;             // optional: dy again as FT [H][Spad]
+    int64_t Spad;
 };
 template <typename T> struct EpiGNBwd {
     typedef GNBwdParams Params;
+    static constexpr int kScratchPerWave = TileT<T>::SCRATCH_BYTES;
     static constexpr int kMinWaves = 2;   // keep two 256-thread workgroups per CU (register-heavy epilogue)
     static constexpr int kParamArrays = 2;
     __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.gamma : p.beta; }
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int, const float* lpar, int lstride) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int, const float* lpar, int lstride, unsigned char* scr) {
         struct { const T* carry_in; T* carry_out; const T* xhat; const float *rstd, *gamma, *beta; T* dy; float* part; int H; int64_t S_valid; DropoutCfg drop; } p =
             {(const T*)pp.carry_in, (T*)pp.carry_out, (const T*)pp.xhat, pp.rstd, pp.gamma, pp.beta, (T*)pp.dy, pp.part, pp.H, pp.S_valid, pp.drop};
         constexpr bool PRECISE = sizeof(T) == 4;
@@ -315,6 +326,7 @@ template <typename T> struct EpiGNBwd {
                     dbias[i] += g[i];
                 }
                 TileIO<T>::store(p.dy + tb, lane, g);
+                if (pp.dyT) TileT<T>::store((T*)pp.dyT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, g);
             }
             // reduce over the 32 samples of the lane group; lane i ends with value i.
             butterfly_reduce32(stat, lane);
@@ -339,11 +351,14 @@ struct SiLUBwdParams {
     void* out;         // dU, FT [Spad][N]
     int N;
     int64_t S_valid;
+    void* outT;        // optional: FT [N][Spad]
+    int64_t Spad;
 };
 template <typename T> struct EpiSiLUBwd {
     typedef SiLUBwdParams Params;
+    static constexpr int kScratchPerWave = TileT<T>::SCRATCH_BYTES;
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
         struct { const T* pre; T* out; int N; int64_t S_valid; } p = {(const T*)pp.pre, (T*)pp.out, pp.N, pp.S_valid};
         constexpr bool PRECISE = sizeof(T) == 4;
         const int j = lane & 31;
@@ -358,6 +373,7 @@ template <typename T> struct EpiSiLUBwd {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] = (s < p.S_valid) ? acc[tc][ts][r] * dsilu_f<PRECISE>(u[r]) : 0.f;
                 TileIO<T>::store(p.out + tb, lane, o);
+                if (pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, cbase + tc * 32, pp.Spad), scr, lane, o);
             }
     }
 };
@@ -372,7 +388,7 @@ struct WgradParams {
 template <typename T> struct EpiWgrad {
     typedef WgradParams Params;
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int split, const float*, int) {
+    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int split, const float*, int, unsigned char*) {
         const int j = lane & 31, hi = lane >> 5;
         float* base = p.slab + (int64_t)split * p.slab_stride;
 #pragma unroll

@@ -91,6 +91,10 @@ template <typename Epi> struct EpiMinWaves<Epi, decltype((void)Epi::kMinWaves)> 
 template <typename Epi, typename = void> struct EpiParamArrays { static constexpr int value = 0; };
 template <typename Epi> struct EpiParamArrays<Epi, decltype((void)Epi::kParamArrays)> { static constexpr int value = Epi::kParamArrays; };
 
+// Per-wave LDS scratch (bytes) an epilogue may ask for (transposed tile stores).
+template <typename Epi, typename = void> struct EpiScratch { static constexpr int value = 0; };
+template <typename Epi> struct EpiScratch<Epi, decltype((void)Epi::kScratchPerWave)> { static constexpr int value = Epi::kScratchPerWave; };
+
 // The kernel.  Epi::apply(params, acc, channel_base, sample_base, lane, wave-in-sample-dim ids)
 // GLDS: 0 = register staging, 1 = global_load_lds double buffer, 3 = global_load_lds 3-deep ring with counted vmcnt
 template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int GLDS = 0>
@@ -104,10 +108,19 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     const int wc = wave / WS, ws = wave % WS;
 
     const int ntiles = g.n_cblk * g.n_sblk;
-    const int L = xcd_remap(blockIdx.x, ntiles);
+    int L, split;
+    if (g.ksplit >= 8 && (g.ksplit & 7) == 0) {
+        // split-K (wgrad): hardware XCD = linear block id % 8.  Put a k-range on ONE XCD with all output tiles, so each
+        // slice of the two operands is fetched from HBM once and shared through that XCD's L2 by every tile.
+        const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+        split = lin % g.ksplit;
+        L = lin / g.ksplit;
+    } else {
+        L = xcd_remap(blockIdx.x, ntiles);
+        split = blockIdx.y;
+    }
     const int cblk = L % g.n_cblk;
     const int sblk = L / g.n_cblk;
-    const int split = blockIdx.y;
 
     constexpr int NPAR = EpiParamArrays<Epi>::value;
     float* lds_par = reinterpret_cast<float*>(smem + (GLDS >= 3 ? GLDS : 2) * C::STAGE_BYTES);   // [NPAR][CT*32]
@@ -401,15 +414,17 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
         }
     }
 
+    unsigned char* wave_scratch = reinterpret_cast<unsigned char*>(lds_par + NPAR * C::CT * 32) + wave * EpiScratch<Epi>::value;
     Epi::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
-                                sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32);
+                                sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32, wave_scratch);
 }
 
 template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int GLDS = 0>
 static inline hipError_t launch_gemm(const GemmArgs& g, const typename Epi::Params& ep, hipStream_t stream) {
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
     auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi, GLDS>;
-    constexpr int lds_bytes = (GLDS >= 3 ? GLDS : 2) * C::STAGE_BYTES + EpiParamArrays<Epi>::value * C::CT * 32 * 4;
+    constexpr int lds_bytes = (GLDS >= 3 ? GLDS : 2) * C::STAGE_BYTES + EpiParamArrays<Epi>::value * C::CT * 32 * 4 +
+                              EpiScratch<Epi>::value * C::NW;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && lds_bytes > 64 * 1024) {

@@ -213,7 +213,7 @@ struct Ws {
     int64_t npad;
     float *tt_labels, *tt_emb, *tt_temb, *table;
     // transposed copies / partials / slabs (training)
-    char *dyT, *inT, *tembT, *embT, *xinT, *dresT, *dUT;
+    char *dyT, *hT[MAX_L], *tembT, *embT, *xinT, *dresT, *dUT;
     float *gn_part[MAX_L], *cs_part_post, *cs_part_se, *slabs;
     int64_t total;
 };
@@ -276,7 +276,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         w.tbuf = (float*)take(Bpad * 4);
         w.zbuf = (float*)take(Bpad * h->Dpad * 4);
         w.dyT = take(Bpad * H * esz);
-        w.inT = take(Bpad * H * esz);
+        for (int l = 0; l < L; ++l) w.hT[l] = take(Bpad * H * esz);
         w.tembT = take(Bpad * E * esz);
         w.embT = take(Bpad * E * esz);
         w.xinT = take(Bpad * h->Dpad * esz);
@@ -371,6 +371,8 @@ static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* pack
     p.xhat = xhat;
     p.rstd = rstd;
     p.H = h->H;
+    p.outT = nullptr;
+    p.Spad = Bpad;
     p.drop = drop_cfg(h, train, l, seed, step);
     DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, train, shape, g, p, st));
     return DPOSER_OK;
@@ -392,8 +394,8 @@ static int run_post(dposer_scorefc_s* h, const float* flat, const char* packed, 
     return DPOSER_OK;
 }
 
-static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, const void* emb, void* temb, void* upre, bool train,
-                    int64_t Bpad, hipStream_t st) {
+static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, const void* emb, void* temb, void* upre, void* tembT,
+                    bool train, int64_t Bpad, hipStream_t st) {
     const int shape = main_shape(Bpad);
     g_next_flops = 2.0 * (double)g_alg_batch * h->E * h->E;
     GemmArgs g = gemm_args(packed + h->pk_wse, h->E / h->KBS, h->E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
@@ -403,6 +405,8 @@ static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, 
     p.out = temb;
     p.pre = upre;
     p.N = h->E;
+    p.outT = tembT;
+    p.Spad = Bpad;
     DP_HIP_LAUNCH(gemm_bias_silu(h->f32 ? PREC_FP32 : PREC_BF16, train, shape, g, p, st));
     return DPOSER_OK;
 }
@@ -433,7 +437,7 @@ extern "C" int dposer_scorefc_forward(dposer_scorefc_t h, const float* flat, con
     pa.B = B; pa.Bpad = w.Bpad; pa.D = h->D; pa.Dpad = h->Dpad; pa.E = h->E;
     pa.fourier = h->d.embedding == DPOSER_EMB_FOURIER; pa.f32 = h->f32;
     DP_HIP_LAUNCH(launch_prep_infer(pa, st));
-    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, nullptr, false, w.Bpad, st));
+    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, nullptr, nullptr, false, w.Bpad, st));
     const void* in = w.xin;
     for (int l = 0; l < h->L; ++l) {
         void* o = w.hbuf[l % 3];
@@ -462,7 +466,7 @@ static int build_time_table(dposer_scorefc_s* h, const float* flat, const char* 
         GemmArgs g = gemm_args(packed + h->pk_wse32, E / 8, E / (shape_ct(shape) * 32), (int)(npad / (shape_st(shape) * 32)));
         add_seg(g, w.tt_emb, E / 8);
         BiasSiLUParams p;
-        p.bias = flat + h->off_se_b; p.out = w.tt_temb; p.pre = nullptr; p.N = E;
+        p.bias = flat + h->off_se_b; p.out = w.tt_temb; p.pre = nullptr; p.N = E; p.outT = nullptr; p.Spad = npad;
         DP_HIP_LAUNCH(gemm_bias_silu(PREC_FP32, false, shape, g, p, st));
     }
     {
@@ -616,7 +620,7 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
 static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
                               uint32_t step, hipStream_t st) {
     const int L = h->L;
-    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, w.upre, true, w.Bpad, st));
+    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, w.upre, w.tembT, true, w.Bpad, st));
     for (int l = 0; l < L; ++l) {
         const void* in = l == 0 ? (const void*)w.xin : (const void*)w.hbuf[l - 1];
         const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[l - 2] : nullptr;
@@ -632,6 +636,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         p.bias = reinterpret_cast<const float*>(packed + h->pk_bias_cat) + (int64_t)l * h->H;
         p.gamma = flat + lo.gamma; p.beta = flat + lo.beta; p.out = w.hbuf[l]; p.resid = resid; p.xhat = w.xhat[l]; p.rstd = w.rstd[l];
         p.H = h->H; p.drop = drop_cfg(h, dropout_on, l, seed, step);
+        p.outT = w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
         DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, true, shape, g, p, st));
     }
     return run_post(h, flat, packed, w.hbuf[L - 1], w.res, B, w.Bpad, st);
@@ -649,12 +654,10 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     int64_t slab_cursor = 0;
     int n_chunks_post = 0, n_chunks_se = 0;
     if (want_w) {
-        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.temb, w.tembT, Bpad, E, st));
         // post_dense: bias (column sums of dres) and weight
         DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, st));
         DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, st));
-        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.hbuf[L - 1], w.inT, Bpad, H, st));
-        DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.inT, H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, st));
+        DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.hT[L - 1], H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, st));
     }
     const int gshape = gnbwd_shape(Bpad);
     const int ws_rows = (int)(Bpad / (shape_st(gshape) * 32)) * shape_ws(gshape);   // partial rows written by the dgrad epilogue
@@ -672,13 +675,13 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         p.carry_out = (even && j >= 2) ? w.carry[(j / 2) & 1] : nullptr;
         p.xhat = w.xhat[j]; p.rstd = w.rstd[j]; p.gamma = flat + h->layer[j].gamma; p.beta = flat + h->layer[j].beta;
         p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B; p.drop = drop_cfg(h, dropout_on, j, seed, step);
+        p.dyT = want_w ? w.dyT : nullptr; p.Spad = Bpad;
         DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st));
         if (!want_w) continue;
         // parameter gradients of layer j
-        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dy[j], w.dyT, Bpad, H, st));
         const void* inT;
         if (j == 0) { DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.xin, w.xinT, Bpad, h->Dpad, st)); inT = w.xinT; }
-        else { DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.hbuf[j - 1], w.inT, Bpad, H, st)); inT = w.inT; }
+        else inT = w.hT[j - 1];
         const LayerOff& lo = h->layer[j];
         DP_TRY(run_wgrad(h, w.dyT, H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, st));
         DP_TRY(run_wgrad(h, w.dyT, H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, st));
@@ -700,11 +703,10 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         GemmArgs g = gemm_args(packed + h->pk_wtT_all, L * H / KBS, E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
         for (int l = 0; l < L; ++l) add_seg(g, w.dy[l], H / KBS);
         SiLUBwdParams p;
-        p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B;
+        p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B; p.outT = w.dUT; p.Spad = Bpad;
         DP_HIP_LAUNCH(gemm_silu_bwd(prec, shape, g, p, st));
     }
     DP_HIP_LAUNCH(launch_colsum(h->f32, w.dU, w.cs_part_se, Bpad, E, &n_chunks_se, st));
-    DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dU, w.dUT, Bpad, E, st));
     DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, st));
     DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, st));
 
