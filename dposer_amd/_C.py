@@ -63,6 +63,12 @@ SIGNATURES = {
                                     u32, vp, vp, i64, vp]),
     "dposer_dsm_loss_fwd_bwd": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, f32, u64, u32, vp, vp,
                                           vp, vp, i64, vp]),
+    "dposer_dsm_loss_fwd_bwd_bucketed": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, f32, u64, u32, vp, vp,
+                                                   vp, vp, i64, C.POINTER(vp), i32, vp]),
+    "dposer_scorefc_grad_buckets": (i32, [vp, C.POINTER(i64), C.POINTER(i64), i32]),
+    "dposer_event_create": (C.c_int, [C.POINTER(vp)]),
+    "dposer_event_destroy": (None, [vp]),
+    "dposer_stream_wait_event": (C.c_int, [vp, vp]),
     "dposer_adam_ema_clip_step": (C.c_int, [vp, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64,
                                             f64, f64, i64, f64, vp, vp]),
     "dposer_profile_enable": (None, [i32]),

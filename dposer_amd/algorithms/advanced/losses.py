@@ -216,8 +216,9 @@ def fused_dsm_supported(sde, model, continuous, reduce_mean, likelihood_weightin
             and isinstance(model, ScoreModelFC) and model.time_embedding_type == "positional")
 
 
-def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, seed=0, step=0):
-    """dposer_dsm_loss_fwd_bwd: loss (device scalar) and d loss/d params into ``flat_grad``."""
+def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, seed=0, step=0, bucket_events=None):
+    """dposer_dsm_loss_fwd_bwd[_bucketed]: loss (device scalar) and d loss/d params into ``flat_grad``.
+    ``bucket_events`` (ScoreEngine.bucket_events()) are recorded as each gradient bucket becomes final."""
     _C.require_gpu(batch, "training batch")
     eng = model._engine()
     flat = model.flat_params()
@@ -227,10 +228,10 @@ def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, se
     loss = torch.empty(1, dtype=torch.float32, device=batch.device)
     desc = sde_desc(sde)
     x = batch.contiguous().float()
-    _C.check(eng.lib.dposer_dsm_loss_fwd_bwd(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(t), _C.ptr(z),
-                                             float(eps), int(seed), int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(batch.device)),
-                                             _C.ptr(model.sigmas), _C.ptr(flat_grad), _C.ptr(loss), B, _C.stream_ptr()),
-             "dposer_dsm_loss_fwd_bwd")
+    _C.check(eng.lib.dposer_dsm_loss_fwd_bwd_bucketed(
+        eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(t), _C.ptr(z), float(eps), int(seed),
+        int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(batch.device)), _C.ptr(model.sigmas), _C.ptr(flat_grad), _C.ptr(loss), B,
+        bucket_events, 0 if bucket_events is None else len(bucket_events), _C.stream_ptr()), "dposer_dsm_loss_fwd_bwd_bucketed")
     return loss[0]
 
 
@@ -272,8 +273,19 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
             model.train()
             params = list(model.parameters())
             flat_grad = optimizer.flat_grad()
-            loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=model._rng_seed, step=state["step"])
-            world = ddp.all_reduce_sum_(flat_grad)                                  # RCCL over xGMI (no-op for 1 process)
+            if ddp.world_size() > 1:
+                # bucketed: each GN layer's gradient is all-reduced (RCCL over xGMI) on a side stream while the layers in
+                # front of it are still being differentiated
+                eng = model._engine()
+                events = eng.bucket_events()
+                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=model._rng_seed, step=state["step"],
+                                      bucket_events=events)
+                world = ddp.all_reduce_buckets_(flat_grad, eng.grad_buckets,
+                                                lambda i, stream: _C.check(eng.lib.dposer_stream_wait_event(stream, events[i]),
+                                                                           "dposer_stream_wait_event"))
+            else:
+                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=model._rng_seed, step=state["step"])
+                world = 1
             optimize_fn.warm_lr(optimizer, state["step"])                           # losses.py:51-53
             live = [not model._is_nograd(o) and p.requires_grad for p, o in zip(params, model._offsets)]
             optimizer.fused_step(live=live, grad_clip=optimize_fn.grad_clip, grad_scale=1.0 / world, ema=state["ema"])

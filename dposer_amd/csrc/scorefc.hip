@@ -643,8 +643,55 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
 }
 
 // backward from dres (FT [Bpad][Cp], zero on padded rows) to the flat parameter gradient and/or dx
+// Launch the pending reduction jobs of one gradient bucket and mark the bucket final on the stream.
+static int flush_bucket(ReduceJobs& rj, const Ws& w, float* flat_grad, void* const* events, int n_events, int bucket, hipStream_t st) {
+    if (rj.n > 0) DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, st));
+    rj.n = 0;
+    if (events && bucket < n_events && events[bucket]) DP_CHECK_HIP(hipEventRecord((hipEvent_t)events[bucket], st));
+    return DPOSER_OK;
+}
+
+// Gradient buckets in the order the backward pass finishes them (dposer_scorefc_grad_buckets): bucket b < L-1 is GN layer
+// L-1-b (bucket 0 also holds post_dense, which follows the last layer in parameters() order); the last bucket is everything
+// in front of layer 1: layer 0, the dead pre_dense_cond, gauss_proj.W and the shared time embedding.
+static void bucket_range(const dposer_scorefc_s* h, int b, int64_t& lo, int64_t& hi) {
+    const int L = h->L;
+    if (b < L - 1) {
+        const int j = L - 1 - b;
+        lo = h->layer[j].w;
+        hi = (b == 0) ? h->nparams : h->layer[j + 1].w;
+    } else {
+        lo = 0;
+        hi = L > 1 ? h->layer[1].w : h->nparams;
+    }
+}
+
+extern "C" int32_t dposer_scorefc_grad_buckets(dposer_scorefc_t h, int64_t* lo, int64_t* hi, int32_t max_buckets) {
+    if (!h) return -1;
+    const int n = h->L;
+    for (int b = 0; b < n && b < max_buckets; ++b)
+        if (lo && hi) bucket_range(h, b, lo[b], hi[b]);
+    return n;
+}
+
+extern "C" int dposer_event_create(void** event) {
+    DP_CHECK_ARG(event, "null argument");
+    hipEvent_t e;
+    DP_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = e;
+    return DPOSER_OK;
+}
+extern "C" void dposer_event_destroy(void* event) {
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+extern "C" int dposer_stream_wait_event(void* stream, void* event) {
+    DP_CHECK_ARG(event, "null event");
+    DP_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return DPOSER_OK;
+}
+
 static int backward_core(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
-                         uint32_t step, float* flat_grad, float* dx, hipStream_t st) {
+                         uint32_t step, float* flat_grad, float* dx, void* const* events, int n_events, hipStream_t st) {
     const int prec = h->f32 ? PREC_FP32 : PREC_BF16;
     const int H = h->H, E = h->E, L = h->L, KBS = h->KBS;
     const int64_t Bpad = w.Bpad;
@@ -661,6 +708,13 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     }
     const int gshape = gnbwd_shape(Bpad);
     const int ws_rows = (int)(Bpad / (shape_st(gshape) * 32)) * shape_ws(gshape);   // partial rows written by the dgrad epilogue
+    // Deterministic reduction into the flat gradient: every partial buffer lives in the workspace (offsets relative to
+    // w.slabs); the jobs of one bucket are launched together as soon as its last wgrad has been queued.
+    auto rel = [&](const float* p) { return (int64_t)(p - w.slabs); };
+    auto add_job = [&](int64_t dst, int64_t count, const float* src, int64_t stride, int nsrc) {
+        ReduceJob& jb = rj.job[rj.n++];
+        jb.dst_off = dst; jb.count = count; jb.src_off = rel(src); jb.src_stride = stride; jb.nsrc = nsrc;
+    };
     for (int j = L - 1; j >= 0; --j) {
         // gradient w.r.t. the output of GN layer j, through the layer that consumes it
         const bool from_post = (j == L - 1);
@@ -685,6 +739,14 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         const LayerOff& lo = h->layer[j];
         DP_TRY(run_wgrad(h, w.dyT, H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, st));
         DP_TRY(run_wgrad(h, w.dyT, H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, st));
+        add_job(lo.gamma, H, w.gn_part[j] + 0 * H, 3 * (int64_t)H, ws_rows);
+        add_job(lo.beta, H, w.gn_part[j] + 1 * H, 3 * (int64_t)H, ws_rows);
+        add_job(lo.b, H, w.gn_part[j] + 2 * H, 3 * (int64_t)H, ws_rows);
+        add_job(lo.bt, H, w.gn_part[j] + 2 * H, 3 * (int64_t)H, ws_rows);
+        if (from_post) add_job(h->off_post_b, h->D, w.cs_part_post, h->Cp, n_chunks_post);
+        // layer j's gradient (and everything behind it in the flat buffer) is final: the data-parallel all-reduce of this
+        // bucket can start while the remaining layers are still being differentiated
+        if (j >= 1) DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1 - j, st));
     }
     if (dx) {   // d loss / d x = dy_0 @ W_pre  (the time branch does not depend on x)
         const int shape = final_shape(Bpad);
@@ -710,31 +772,19 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, st));
     DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, st));
 
-    // ---------------- deterministic reduction into the flat gradient ----------------
-    // All partial buffers live in the workspace; offsets are taken relative to w.slabs.
-    auto rel = [&](const float* p) { return (int64_t)(p - w.slabs); };
-    auto add_job = [&](int64_t dst, int64_t count, const float* src, int64_t stride, int nsrc) {
-        ReduceJob& j = rj.job[rj.n++];
-        j.dst_off = dst; j.count = count; j.src_off = rel(src); j.src_stride = stride; j.nsrc = nsrc;
-    };
-    for (int l = 0; l < L; ++l) {
-        add_job(h->layer[l].gamma, H, w.gn_part[l] + 0 * H, 3 * (int64_t)H, ws_rows);
-        add_job(h->layer[l].beta, H, w.gn_part[l] + 1 * H, 3 * (int64_t)H, ws_rows);
-        add_job(h->layer[l].b, H, w.gn_part[l] + 2 * H, 3 * (int64_t)H, ws_rows);
-        add_job(h->layer[l].bt, H, w.gn_part[l] + 2 * H, 3 * (int64_t)H, ws_rows);
-    }
-    add_job(h->off_post_b, h->D, w.cs_part_post, h->Cp, n_chunks_post);
+    // last bucket: layer 0 (jobs queued above), the shared time embedding and the parameters that never get a gradient
     add_job(h->off_se_b, E, w.cs_part_se, E, n_chunks_se);
     for (int i = 0; i < h->n_nograd; ++i)
         DP_CHECK_HIP(hipMemsetAsync(flat_grad + h->nograd_lo[i], 0, (h->nograd_hi[i] - h->nograd_lo[i]) * sizeof(float), st));
-    DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, st));
+    DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1, st));
     return DPOSER_OK;
 }
 
-extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
-                                       const float* batch_x, const float* t_in, const float* z_in, float eps, uint64_t seed,
-                                       uint32_t step, const float* freq, const float* sigmas, float* flat_grad, float* loss, int64_t B,
-                                       void* stream) {
+extern "C" int dposer_dsm_loss_fwd_bwd_bucketed(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_,
+                                                const dposer_sde_desc* sde, const float* batch_x, const float* t_in, const float* z_in,
+                                                float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
+                                                float* flat_grad, float* loss, int64_t B, void* const* bucket_events, int32_t n_events,
+                                                void* stream) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(sde && batch_x && freq && sigmas && flat_grad && loss, "null argument");
@@ -759,7 +809,15 @@ extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, co
     int nb = 0;
     DP_HIP_LAUNCH(launch_dsm(da, &nb, st));
     DP_HIP_LAUNCH(launch_sum_partials(w.loss_part, nb, loss, st));
-    return backward_core(h, flat, packed, w, B, true, seed, step, flat_grad, nullptr, st);
+    return backward_core(h, flat, packed, w, B, true, seed, step, flat_grad, nullptr, bucket_events, n_events, st);
+}
+
+extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, const void* packed, void* ws, const dposer_sde_desc* sde,
+                                       const float* batch_x, const float* t_in, const float* z_in, float eps, uint64_t seed,
+                                       uint32_t step, const float* freq, const float* sigmas, float* flat_grad, float* loss, int64_t B,
+                                       void* stream) {
+    return dposer_dsm_loss_fwd_bwd_bucketed(h, flat, packed, ws, sde, batch_x, t_in, z_in, eps, seed, step, freq, sigmas, flat_grad, loss, B,
+                                            nullptr, 0, stream);
 }
 
 // ScoreModelFC.forward with everything kept for autograd (model.py:141-196); dropout when train_mode != 0
@@ -803,7 +861,7 @@ extern "C" int dposer_scorefc_backward(dposer_scorefc_t h, const float* flat, co
     da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma; da.fourier = h->d.embedding == DPOSER_EMB_FOURIER;
     da.f32 = h->f32;
     DP_HIP_LAUNCH(launch_dres_from_dout(da, st));
-    return backward_core(h, flat, packed, w, B, train_mode != 0, seed, step, flat_grad, dx, st);
+    return backward_core(h, flat, packed, w, B, train_mode != 0, seed, step, flat_grad, dx, nullptr, 0, st);
 }
 
 extern "C" int dposer_adam_ema_clip_step(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n,

@@ -46,14 +46,34 @@ class ScoreEngine:
         hi = (C.c_int64 * 2)()
         k = self.lib.dposer_scorefc_nograd_ranges(h, lo, hi)
         self.nograd = [(lo[i], hi[i]) for i in range(k)]
+        nb = self.lib.dposer_scorefc_grad_buckets(h, None, None, 0)
+        blo, bhi = (C.c_int64 * nb)(), (C.c_int64 * nb)()
+        self.lib.dposer_scorefc_grad_buckets(h, blo, bhi, nb)
+        self.grad_buckets = [(blo[i], bhi[i]) for i in range(nb)]        # flat ranges in backward completion order
+        self._bucket_events = None
         self._packed: Optional[torch.Tensor] = None
         self._packed_bwd = False
         self._ws: Dict[int, torch.Tensor] = {}
         self.freq_cpu = positional_freq(embed_dim)
         self._freq: Optional[torch.Tensor] = None
 
+    def bucket_events(self):
+        """One HIP event per gradient bucket (created once), as a ctypes array for dposer_dsm_loss_fwd_bwd_bucketed."""
+        if self._bucket_events is None:
+            arr = (C.c_void_p * len(self.grad_buckets))()
+            for i in range(len(self.grad_buckets)):
+                ev = C.c_void_p()
+                _C.check(self.lib.dposer_event_create(C.byref(ev)), "dposer_event_create")
+                arr[i] = ev.value
+            self._bucket_events = arr
+        return self._bucket_events
+
     def __del__(self):
         try:
+            if getattr(self, "_bucket_events", None) is not None:
+                for ev in self._bucket_events:
+                    self.lib.dposer_event_destroy(ev)
+                self._bucket_events = None
             if getattr(self, "h", None):
                 self.lib.dposer_scorefc_destroy(self.h)
                 self.h = None

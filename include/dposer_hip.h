@@ -129,6 +129,23 @@ int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat_params, const 
                             float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
                             float* flat_grad, float* loss, int64_t batch, void* stream);
 
+/* Same step with the flat gradient delivered in BUCKETS so that the data-parallel all-reduce (RCCL, issued by the host
+ * through torch.distributed) overlaps the rest of the backward pass -- the reference trains on one device
+ * (run/train.py:150-170); this is the MI355X data-parallel extension BASELINE.json's north star asks for.
+ *   dposer_scorefc_grad_buckets: number of buckets; [lo[b], hi[b]) are disjoint ranges of the flat buffer that cover it,
+ *     listed in the order the backward pass completes them (last GN layer + post_dense first).
+ *   bucket_events[b] (from dposer_event_create) is recorded on `stream` once bucket b of flat_grad is final; a
+ *     communication stream waits on it with dposer_stream_wait_event before reducing that range. */
+int32_t dposer_scorefc_grad_buckets(dposer_scorefc_t h, int64_t* lo, int64_t* hi, int32_t max_buckets);
+int dposer_event_create(void** event);
+void dposer_event_destroy(void* event);
+int dposer_stream_wait_event(void* stream, void* event);
+int dposer_dsm_loss_fwd_bwd_bucketed(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws,
+                                     const dposer_sde_desc* sde, const float* batch, const float* t, const float* z,
+                                     float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
+                                     float* flat_grad, float* loss, int64_t batch_size, void* const* bucket_events,
+                                     int32_t n_events, void* stream);
+
 /* Differentiable ScoreModelFC.forward for torch.autograd (model.py:141-196): forward keeps every layer
  * input / normalised activation in `ws` (DPOSER_WS_TRAIN layout); backward consumes the same `ws`.
  *   train_mode != 0: dropout active (model.train()), mask = Philox(seed, step), recomputed in backward;

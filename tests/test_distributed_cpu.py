@@ -23,6 +23,10 @@ def _worker(rank, world, port, out):
     assert (rk, ws) == (rank, world) and ddp.world_size() == world and ddp.rank() == rank
     g = torch.full((1000,), float(rank + 1))
     n = ddp.all_reduce_sum_(g)
+    gb = torch.arange(100.0) * (rank + 1)
+    seen = []
+    nb = ddp.all_reduce_buckets_(gb, [(60, 100), (30, 60), (0, 30)], None)
+    assert nb == world and torch.equal(gb, torch.arange(100.0) * 3)
     flat = torch.arange(10.0) * (rank + 1)
     ddp.broadcast_(flat, src=0)
     lo, hi = ddp.shard_bounds(65536 + 3, world, rank)
@@ -53,4 +57,5 @@ def test_single_process_is_noop():
     from dposer_amd import distributed as ddp
     g = torch.ones(8)
     assert ddp.all_reduce_sum_(g) == 1 and float(g.sum()) == 8.0
+    assert ddp.all_reduce_buckets_(g, [(0, 4), (4, 8)]) == 1 and float(g.sum()) == 8.0
     assert ddp.shard_bounds(10, 3, 0) == (0, 4) and ddp.shard_bounds(10, 3, 2) == (7, 10)

@@ -73,8 +73,27 @@ def pmc(paths):
         print(f"| `{k}` | {n} | {fr:.0f} | {rd:.1f} | {wrk:.0f} | {wr:.1f} | {tot:.1f} |")
 
 
+def counters(paths):
+    """Per-kernel average of every counter found in the given PMC-pass databases."""
+    agg, names = {}, []
+    for path in paths:
+        cur = sqlite3.connect(path).cursor()
+        for name, counter, n, avg in cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                                 "group by kernel_name, counter_name"):
+            agg.setdefault(short(name), {})[counter] = (n, avg)
+            if counter not in names:
+                names.append(counter)
+    print("| kernel | launches | " + " | ".join(names) + " |")
+    print("|---|---:|" + "---:|" * len(names))
+    for k, v in agg.items():
+        n = max(x[0] for x in v.values())
+        print(f"| `{k}` | {n} | " + " | ".join(f"{v[c][1]:.4g}" if c in v else "" for c in names) + " |")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "--pmc":
         pmc(sys.argv[2:])
+    elif sys.argv[1] == "--counters":
+        counters(sys.argv[2:])
     else:
         main(sys.argv[1])

@@ -16,70 +16,88 @@ int dposer_set_error(int code, const std::string&) { return code; }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
+#include <algorithm>
+#include <functional>
+struct Case { std::string name; std::function<void()> launch; double flops; std::vector<double> us; };
+static std::vector<Case> g_cases;
+static int g_stagger = 0;
+
 template <int WC, int WS, int TC, int TS, int KB, int GLDS>
-void run_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void* out) {
+void add_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void* out) {
     typedef GemmCfg<__bf16, WC, WS, TC, TS, KB> Cfg;
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.W = W; g.w_stride_blocks = K / 16; g.src[0] = X; g.seg_kblocks[0] = K / 16; g.nseg = 1; g.ktot_blocks = K / 16;
     g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1;
+    g.max_blocks = g_stagger;
     PlainFTParams p;
     p.out = out; p.N = C;
-    hipEvent_t a, b;
-    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiPlainFT<__bf16>, GLDS>(g, p, 0)));
-    CK(hipDeviceSynchronize());
-    const int reps = 20;
-    CK(hipEventRecord(a, 0));
-    for (int i = 0; i < reps; ++i) CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiPlainFT<__bf16>, GLDS>(g, p, 0)));
-    CK(hipEventRecord(b, 0));
-    CK(hipEventSynchronize(b));
-    float ms = 0;
-    CK(hipEventElapsedTime(&ms, a, b));
-    const double us = ms * 1e3 / reps;
-    printf("%-34s tile %3dx%-3d waves %d KB %d glds %d PLAIN-STORE epilogue : %8.1f us  %7.1f TF\n", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB,
-           (int)GLDS, us, 2.0 * S * C * K / (us * 1e-6) / 1e12);
+    char buf[160];
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d plain stg%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, g_stagger);
+    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiPlainFT<__bf16>, GLDS>(g, p, 0))); }, 2.0 * S * C * K, {}});
+}
+
+template <int WC, int WS, int TC, int TS, int KB, int GLDS, bool TRAIN = false>
+void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* out, float* bias, float* gamma, float* beta, void* xhat, float* rstd, void* outT) {
+    typedef GemmCfg<__bf16, WC, WS, TC, TS, KB> Cfg;
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.W = W; g.w_stride_blocks = K / 16; g.src[0] = X; g.seg_kblocks[0] = K / 16; g.nseg = 1; g.ktot_blocks = K / 16;
+    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1; g.max_blocks = g_stagger;
+    GNParams p;
+    memset(&p, 0, sizeof(p));
+    p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C; p.Spad = S;
+    if (TRAIN) { p.xhat = xhat; p.rstd = rstd; p.outT = outT; }
+    char buf[160];
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d %s stg%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, TRAIN ? "gn-train" : "gn", g_stagger);
+    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, TRAIN>, GLDS>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
 template <int WC, int WS, int TC, int TS, int KB, int GLDS>
-void run(const char* name, int64_t S, int C, int K, void* W, void* X, void* out, float* bias, float* gamma, float* beta, void* ref_out) {
+void add_gnbwd(const char* name, int64_t S, int C, int K, void* Wt, void* dyn, void* dy, void* xhat, float* rstd, float* gamma, float* beta,
+               float* part, void* dyT, void* carry_in, void* carry_out, float drop_p) {
     typedef GemmCfg<__bf16, WC, WS, TC, TS, KB> Cfg;
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.W = W; g.w_stride_blocks = K / 16; g.src[0] = X; g.seg_kblocks[0] = K / 16; g.nseg = 1; g.ktot_blocks = K / 16;
-    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1;
-    GNParams p;
+    g.W = Wt; g.w_stride_blocks = K / 16; g.src[0] = dyn; g.seg_kblocks[0] = K / 16; g.nseg = 1; g.ktot_blocks = K / 16;
+    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1; g.max_blocks = g_stagger;
+    GNBwdParams p;
     memset(&p, 0, sizeof(p));
-    p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C;
+    p.carry_in = carry_in; p.carry_out = carry_out; p.xhat = xhat; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.dy = dy; p.part = part;
+    p.H = C; p.S_valid = S; p.dyT = dyT; p.Spad = S;
+    if (drop_p > 0.f) { p.drop.p = drop_p; p.drop.scale = 1.f / (1.f - drop_p); p.drop.thr = (uint32_t)((1.0 - drop_p) * 65536.0); p.drop.groups_x4 = C / 8; p.drop.seed = 7; }
+    char buf[160];
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d gnbwd drop%d T%d carry%d%d stg%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, drop_p > 0.f,
+             dyT != nullptr, carry_in != nullptr, carry_out != nullptr, g_stagger);
+    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGNBwd<__bf16>, GLDS>(g, p, 0))); }, 2.0 * S * C * K, {}});
+}
+
+static void run_all(int rounds, int reps) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, false>, GLDS>(g, p, 0)));
+    for (auto& c : g_cases) { c.launch(); }
     CK(hipDeviceSynchronize());
-    const int reps = 20;
-    CK(hipEventRecord(a, 0));
-    for (int i = 0; i < reps; ++i) CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, false>, GLDS>(g, p, 0)));
-    CK(hipEventRecord(b, 0));
-    CK(hipEventSynchronize(b));
-    float ms = 0;
-    CK(hipEventElapsedTime(&ms, a, b));
-    const double us = ms * 1e3 / reps;
-    const double tf = 2.0 * S * C * K / (us * 1e-6) / 1e12;
-    // correctness vs the first configuration's output
-    std::vector<unsigned short> h0(1 << 16), h1(1 << 16);
-    int bad = -1;
-    if (ref_out != out) {
-        CK(hipMemcpy(h0.data(), ref_out, h0.size() * 2, hipMemcpyDeviceToHost));
-        CK(hipMemcpy(h1.data(), out, h1.size() * 2, hipMemcpyDeviceToHost));
-        bad = 0;
-        for (size_t i = 0; i < h0.size(); ++i) bad += (h0[i] != h1[i]);
+    for (int r = 0; r < rounds; ++r)
+        for (auto& c : g_cases) {
+            c.launch();
+            CK(hipEventRecord(a, 0));
+            for (int i = 0; i < reps; ++i) c.launch();
+            CK(hipEventRecord(b, 0));
+            CK(hipEventSynchronize(b));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, a, b));
+            c.us.push_back(ms * 1e3 / reps);
+        }
+    for (auto& c : g_cases) {
+        std::sort(c.us.begin(), c.us.end());
+        const double mn = c.us.front(), md = c.us[c.us.size() / 2];
+        printf("%-44s min %7.1f us (%6.0f TF)  median %7.1f us (%6.0f TF)\n", c.name.c_str(), mn, c.flops / mn * 1e-6, md, c.flops / md * 1e-6);
     }
-    printf("%-34s tile %3dx%-3d waves %d KB %d lds %3d KiB glds %d : %8.1f us  %7.1f TF  mismatches %d\n", name, Cfg::CT * 32, Cfg::ST * 32,
-           Cfg::NW, KB, Cfg::LDS_BYTES / 1024, (int)GLDS, us, tf, bad);
 }
 
 int main(int argc, char** argv) {
     const int64_t S = argc > 1 ? atoll(argv[1]) : 65536;
-    const int C = 1024, K = 1024;
+    const int C = 1024, K = getenv("TUNE_K") ? atoi(getenv("TUNE_K")) : 1024;
     void *W, *X, *o0, *o1;
     float *bias, *gamma, *beta;
     CK(hipMalloc(&W, (size_t)C * K * 2)); CK(hipMalloc(&X, (size_t)S * K * 2)); CK(hipMalloc(&o0, (size_t)S * C * 2)); CK(hipMalloc(&o1, (size_t)S * C * 2));
@@ -94,15 +112,38 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(bias, hb.data(), C * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(gamma, hg.data(), C * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(beta, hb.data(), C * 4, hipMemcpyHostToDevice));
     printf("forward GN layer GEMM: S=%lld C=%d K=%d bf16\n", (long long)S, C, K);
-#define RUN(WC, WS, TC, TS, KB, G, OUT) run<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, OUT, bias, gamma, beta, o0)
-#define RUNP(WC, WS, TC, TS, KB, G) run_plain<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1)
-    if (argc > 2) {   // profiling mode: only the two kernels of interest
-        RUN(2, 4, 4, 2, 4, 1, o0);
-        RUNP(2, 4, 4, 2, 4, 1);
+    void *xhat; float* rstd; void* outT;
+    CK(hipMalloc(&xhat, (size_t)S * C * 2)); CK(hipMalloc(&rstd, (size_t)S * (C / 32) * 4)); CK(hipMalloc(&outT, (size_t)S * C * 2));
+#define GN(WC, WS, TC, TS, KB, G) add_gn<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, bias, gamma, beta, xhat, rstd, outT)
+#define GNT(WC, WS, TC, TS, KB, G) add_gn<WC, WS, TC, TS, KB, G, true>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, bias, gamma, beta, xhat, rstd, outT)
+#define PL(WC, WS, TC, TS, KB, G) add_plain<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1)
+    float* part; void *cin, *cout;
+    CK(hipMalloc(&part, (size_t)(S / 32) * 3 * C * 4)); CK(hipMalloc(&cin, (size_t)S * C * 2)); CK(hipMalloc(&cout, (size_t)S * C * 2));
+    CK(hipMemset(rstd, 0, (size_t)S * (C / 32) * 4)); CK(hipMemset(xhat, 0, (size_t)S * C * 2)); CK(hipMemset(cin, 0, (size_t)S * C * 2));
+#define GB(WC, WS, TC, TS, KB, G, DROP, DYT, CI, CO) add_gnbwd<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, xhat, rstd, gamma, beta, part, DYT ? outT : nullptr, CI ? cin : nullptr, CO ? cout : nullptr, DROP ? 0.1f : 0.f)
+    if (getenv("TUNE_PROFILE")) {
+        GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0);
+        GB(2, 2, 2, 2, 4, 1, 0, 0, 0, 0);
+        PL(2, 2, 2, 2, 4, 1);
+        GNT(2, 4, 4, 2, 4, 1);
+        GN(2, 4, 4, 2, 4, 1);
+        PL(2, 4, 4, 2, 4, 1);
+        run_all(1, 2);
         return 0;
     }
-    RUNP(2, 4, 4, 2, 4, 1);
-    RUNP(2, 4, 4, 2, 4, 1);
-    RUNP(2, 2, 2, 2, 4, 1);
+    for (int stg : {-1, 0}) {
+        g_stagger = stg;
+        GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0);
+        GN(2, 2, 2, 4, 2, 1);
+        GNT(2, 2, 2, 4, 2, 1);
+        GNT(4, 1, 2, 4, 2, 1);
+        GN(2, 4, 4, 2, 4, 1);
+        GNT(2, 4, 4, 2, 4, 1);
+        GN(2, 2, 2, 2, 4, 1);
+        PL(2, 4, 4, 2, 4, 1);
+        PL(2, 2, 2, 2, 4, 1);
+    }
+    g_stagger = 0;
+    run_all(7, 10);
     return 0;
 }
