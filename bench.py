@@ -30,6 +30,23 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
+_EPI_CLASS = {"gn_fwd": "EpiGN", "gn_fwd_train": "EpiGN<train>", "bias_silu": "EpiBiasSiLU<train>", "rowmajor": "EpiRowMajor",
+              "plain": "EpiPlainFT", "gn_bwd_dgrad": "EpiGNBwd", "silu_bwd_dgrad": "EpiSiLUBwd", "wgrad": "EpiWgrad"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes of this same command
+    (profiles/pmc_hbm_traffic.json, written by tools/profile_bench.sh: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2
+    read correction).  PMC counters cannot be collected from inside the process, so this is a lookup; None if absent."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+        head, epi = kernel.rstrip(">").rsplit(",", 1)
+        row = table.get(f"{head},{_EPI_CLASS[epi]}>")
+        return None if row is None else (row["read_MB"] + row["write_MB"]) * 1e6
+    except Exception:
+        return None
+
+
 def synthetic_poses(n, device, seed=42):
     """rows of the reference's examples/toy_data.npz (shipped as a fixture) sampled with replacement,
     z-scored with axis_normalize2."""
@@ -155,7 +172,7 @@ def main():
         name, (ms, cnt, fl) = max(prof.items(), key=lambda kv: kv[1][0])
         ach = (fl / (ms * 1e-3)) / 1e12
         roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3,
+                    "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(name), "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3,
                     "flops_per_launch": fl / cnt, "gemm_time_share_of_step": tot_ms / (elapsed * 1e3)}
 
     extra = {"train_loss_last_step": loss, "train_tflops_algorithmic": 42.59e6 * value / 1e12, "gemm_kernels": kernels}

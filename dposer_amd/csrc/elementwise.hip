@@ -577,8 +577,19 @@ __global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const flo
             const int64_t e = e0 + el;
             float acc = 0.f;
             if (e < j.count) {
+                // 8 independent partial sums keep 8 strided loads in flight per thread (a single chain is latency bound:
+                // nsrc/8 dependent L2 round trips); the combination order is fixed, so the result stays deterministic
                 const float* p = scratch + j.src_off + e;
-                for (int k = sl; k < j.nsrc; k += 8) acc += p[(int64_t)k * j.src_stride];
+                float a8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a8[u] = 0.f;
+                int k = sl;
+                for (; k + 56 < j.nsrc; k += 64) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a8[u] += p[(int64_t)(k + 8 * u) * j.src_stride];
+                }
+                for (int u = 0; k < j.nsrc; k += 8, ++u) a8[u] += p[(int64_t)k * j.src_stride];
+                acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
             }
             __syncthreads();
             red[sl][el] = acc;

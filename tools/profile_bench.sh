@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the GPU box:  bash tools/profile_bench.sh <tag>     (e.g. r01)
+# 1. rocprofv3 kernel trace of the default bench.py command            -> gpurun_out/prof_<tag>/
+# 2. separate PMC passes (FETCH_SIZE, WRITE_SIZE) of a short bench run  -> gpurun_out/pmc_<tag>_{rd,wr}/
+# 3. markdown / json summaries                                          -> gpurun_out/<tag>_*.md|json  (copy into profiles/)
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/prof_$TAG $R/gpurun_out/pmc_${TAG}_rd $R/gpurun_out/pmc_${TAG}_wr
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o bench -- python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_default.log 2>&1
+grep '^{' $R/gpurun_out/${TAG}_bench_default.log | tail -1 > $R/gpurun_out/${TAG}_bench_default.json
+SHORT="--steps 3 --warmup 1 --no-cpu-baseline --sampler-steps 20"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${TAG}_rd -o rd -- python3 $R/bench.py $SHORT > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${TAG}_wr -o wr -- python3 $R/bench.py $SHORT > /dev/null 2>&1
+cd $R
+python3 tools/rocpd_summary.py $(find gpurun_out/prof_$TAG -name "*.db" | head -1) > gpurun_out/${TAG}_bench_kernel_stats.md
+python3 tools/rocpd_summary.py --pmc $(find gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr -name "*.db") > gpurun_out/${TAG}_pmc_hbm_traffic.md
+python3 tools/rocpd_summary.py --pmc-json $(find gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr -name "*.db") > gpurun_out/${TAG}_pmc_hbm_traffic.json
+head -30 gpurun_out/${TAG}_bench_kernel_stats.md; head -24 gpurun_out/${TAG}_pmc_hbm_traffic.md; cat gpurun_out/${TAG}_bench_default.json
