@@ -24,6 +24,7 @@ _ALIASES = {
     "lib.algorithms.advanced.utils": "dposer_amd.algorithms.advanced.utils",
     "lib.algorithms.advanced.sampling": "dposer_amd.algorithms.advanced.sampling",
     "lib.algorithms.advanced.losses": "dposer_amd.algorithms.advanced.losses",
+    "lib.algorithms.advanced.likelihood": "dposer_amd.algorithms.advanced.likelihood",
     "lib.body_model": "dposer_amd.body_model",
     "lib.body_model.body_model": "dposer_amd.body_model.body_model",
     "lib.body_model.smpl": "dposer_amd.body_model.smpl",
@@ -33,6 +34,7 @@ _ALIASES = {
     "lib.utils.transforms": "dposer_amd.utils.transforms",
     "lib.utils.misc": "dposer_amd.utils.misc",
     "lib.utils.generic": "dposer_amd.utils.generic",
+    "lib.utils.metric": "dposer_amd.utils.metric",
     "lib.dataset": "dposer_amd.dataset",
     "lib.dataset.AMASS": "dposer_amd.dataset.AMASS",
     "lib.dataset.EvaSampler": "dposer_amd.dataset.EvaSampler",

@@ -59,8 +59,8 @@ def get_sampling_fn(config, sde, shape, inverse_scaler, eps, device=None):
         device = config.device
     name = config.sampling.method.lower()
     if name == "ode":
-        raise NotImplementedError("the probability-flow ODE sampler (sampling.py:471-542, scipy RK45 on the host) is outside "
-                                  "the accelerated path (SURVEY.md 8f.4)")
+        return get_ode_sampler(sde=sde, shape=shape, inverse_scaler=inverse_scaler, denoise=config.sampling.noise_removal, eps=eps,
+                               device=device)
     if name != "pc":
         raise ValueError(f"Sampler name {config.sampling.method} unknown.")
     return get_pc_sampler(sde=sde, shape=shape, predictor=get_predictor(config.sampling.predictor.lower()),
@@ -341,3 +341,32 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
             return trajs, (x_mean if denoise else x)
 
     return pc_sampler
+
+
+def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1e-5, method="RK45", eps=1e-3, device="cuda"):
+    """Probability-flow ODE sampler (sampling.py:471-542): ``ode_sampler(model, z=None) -> (nfe, samples)``.
+
+    ``scipy.integrate.solve_ivp`` drives the adaptive steps on the host exactly like the reference (tolerances and
+    ``nfe`` are part of the result); each drift evaluation is one HIP forward of the score network.  ``denoise`` adds one
+    noise-free reverse-diffusion predictor step at ``eps`` (sampling.py:492-499)."""
+    from .likelihood import probability_flow_drift
+    from scipy import integrate
+
+    def ode_sampler(model, z=None):
+        with torch.no_grad():
+            x = sde.prior_sampling(shape).to(device) if z is None else z
+
+            def rhs(t, state):
+                xt = torch.from_numpy(state.reshape(shape)).to(device, torch.float32)
+                vec_t = torch.full((shape[0],), float(t), device=device, dtype=torch.float32)
+                return mutils.to_flattened_numpy(probability_flow_drift(sde, model, xt, vec_t))
+
+            sol = integrate.solve_ivp(rhs, (sde.T, eps), mutils.to_flattened_numpy(x), rtol=rtol, atol=atol, method=method)
+            x = torch.from_numpy(sol.y[:, -1].reshape(shape)).to(device, torch.float32)
+            if denoise:
+                score_fn = get_score_fn(sde, model, train=False, continuous=True)
+                vec_eps = torch.full((shape[0],), float(eps), device=device, dtype=torch.float32)
+                x = ReverseDiffusionPredictor(sde, score_fn, probability_flow=False).update_fn(x, vec_eps)[1]
+            return sol.nfev, inverse_scaler(x)
+
+    return ode_sampler

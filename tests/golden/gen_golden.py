@@ -426,9 +426,48 @@ def g11_rot6d():
     save("g11_rot6d", **out)
 
 
+def g12_likelihood_ode():
+    """Probability-flow ODE: likelihood (likelihood.py:40-113, called as in run/train.py:235) and the black-box ODE
+    sampler (sampling.py:471-542), plus the APD metric (lib/utils/metric.py:8-37)."""
+    import lib.algorithms.advanced.likelihood as ref_lik
+    import lib.utils.metric as ref_metric
+    out = {"seed": np.int64(21)}
+    cfg, m = build_model(21, 63)
+    m.eval()
+    sde = ref_sde.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000)
+    data, _ = toy_batch(6, seed=3)
+    out["data"] = data.numpy()
+    rs = np.random.RandomState(77)
+    for kind in ("Rademacher", "Gaussian"):
+        eps_np = (rs.randint(0, 2, size=data.shape).astype(np.float32) * 2 - 1) if kind == "Rademacher" \
+            else rs.standard_normal(size=data.shape).astype(np.float32)
+        with mock.patch.object(torch, "randint_like", lambda x, low=0, high=2: torch.tensor((eps_np + 1) / 2)), \
+                mock.patch.object(torch, "randn_like", lambda x: torch.tensor(eps_np)):
+            fn = ref_lik.get_likelihood_fn(sde, lambda v: v, hutchinson_type=kind, rtol=1e-4, atol=1e-4, eps=1e-4)
+            bpd, z, nfe = fn(m, data.clone())
+        out[f"lik_{kind}/eps"] = eps_np
+        out[f"lik_{kind}/bpd"] = bpd.numpy()
+        out[f"lik_{kind}/z"] = z.numpy()
+        out[f"lik_{kind}/nfe"] = np.int64(nfe)
+        print(kind, "bpd", bpd.numpy(), "nfe", nfe)
+    z0 = rs.standard_normal(size=(6, 63)).astype(np.float32)
+    out["ode/z"] = z0
+    for denoise in (False, True):
+        sampler = ref_sampling.get_ode_sampler(sde, (6, 63), lambda v: v, denoise=denoise, rtol=1e-4, atol=1e-4, eps=1e-3, device="cpu")
+        with Recorder(5):
+            nfe, x = sampler(m, z=torch.tensor(z0))
+        out[f"ode/x_denoise{int(denoise)}"] = x.numpy()
+        out[f"ode/nfe_denoise{int(denoise)}"] = np.int64(nfe)
+        print("ode denoise", denoise, "nfe", nfe, float(x.abs().max()))
+    joints = rs.standard_normal(size=(7, 22, 3)).astype(np.float32)
+    out["apd/joints"] = joints
+    out["apd/value"] = ref_metric.average_pairwise_distance(torch.tensor(joints)).numpy()
+    save("g12_likelihood_ode", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12"]
     fns = dict(g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
-               g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d)
+               g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode)
     for w in which:
         fns[w]()

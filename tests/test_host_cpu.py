@@ -145,8 +145,10 @@ def test_model_surface_and_flat_params():
 def test_reference_import_paths():
     import dposer_amd
     dposer_amd.install_reference_aliases()
-    from lib.algorithms.advanced import losses, sampling, sde_lib  # noqa: F401
+    from lib.algorithms.advanced import likelihood, losses, sampling, sde_lib  # noqa: F401
     from lib.algorithms.advanced import utils as mutils  # noqa: F401
+    from lib.utils import metric  # noqa: F401
+    assert callable(likelihood.get_likelihood_fn) and callable(sampling.get_ode_sampler)
     from lib.algorithms.advanced.model import ScoreModelFC  # noqa: F401
     from lib.algorithms.ema import ExponentialMovingAverage  # noqa: F401
     from lib.body_model.body_model import BodyModel  # noqa: F401
@@ -155,6 +157,15 @@ def test_reference_import_paths():
     from lib.utils.generic import import_configs
     assert import_configs("configs.subvp.amass_scorefc_continuous.get_config").model.HIDDEN_DIM == 1024
     assert sampling.get_predictor("euler_maruyama") is sampling.EulerMaruyamaPredictor
+
+
+def test_average_pairwise_distance_matches_reference_golden():
+    from dposer_amd.utils.metric import average_pairwise_distance, self_intersections_percentage
+    g = load("g12_likelihood_ode")
+    j = torch.tensor(g["apd/joints"])
+    assert abs(float(average_pairwise_distance(j)) - float(g["apd/value"])) < 1e-6
+    assert abs(float(average_pairwise_distance(j, chunk=3)) - float(g["apd/value"])) < 1e-6     # chunking is invisible
+    assert np.isnan(self_intersections_percentage(np.zeros((2, 4, 3)), np.zeros((2, 3), dtype=np.int64))).all()
 
 
 def test_philox_known_answer():
