@@ -5,8 +5,8 @@
 #include "common.h"
 #include "rng.h"
 
-// dropout keep-mask for one lane's 16 channels of GroupNorm group g (contract: oracle/philox.py
-// dropout_keep_mask).  Two Philox calls; call m covers quads q = 2m, 2m+1; 16-bit lanes.
+// dropout keep decisions for one lane's 16 channels of GroupNorm group g (contract: oracle/philox.py
+// dropout_keep_mask).  Two Philox calls; call m covers quads q = 2m, 2m+1; 16-bit lanes; lane_in_call = (q%2)*4 + r.
 struct DropoutCfg {
     float p;           // drop probability; 0 => disabled
     float scale;       // 1/(1-p)
@@ -17,13 +17,15 @@ struct DropoutCfg {
     int groups_x4;     // H/8 = number of counters per sample
 };
 
+// keep[4q + r] = 1/(1-p) or 0 for channel 8q + 4hi + r.  Storing the decisions (one bit each) in the forward pass for the
+// backward pass was measured (tools/tune_gemm.hip, TUNE_GNBWD): -3 % on the GN-backward GEMM, +3 % on the forward one -- the
+// masks are therefore regenerated from Philox(seed, step, site) on both sides and never stored.
 __device__ __forceinline__ void dropout_mask16(const DropoutCfg& d, int64_t s, int g, int hi, float keep[16]) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         Philox4 r = philox_at((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            // lanes 2w (low half) and 2w+1 (high half); lane_in_call = (q%2)*4 + r
             const int q = 2 * m + (w >> 1), r0 = (w & 1) * 2;
             keep[4 * q + r0] = ((r.v[w] & 0xffffu) < d.thr) ? d.scale : 0.f;
             keep[4 * q + r0 + 1] = ((r.v[w] >> 16) < d.thr) ? d.scale : 0.f;
@@ -227,6 +229,17 @@ template <int D> __device__ __forceinline__ void butterfly_step(float (&v)[32], 
         v[i] = keep + __shfl_xor(send, D);
     }
 }
+// 16 values per lane: lane (l & 15) == i ends with the sum over the 32 lanes (same l >> 5) of value i -- 16 shuffles.
+__device__ __forceinline__ float butterfly_reduce16(const float (&in)[16], int lane) {
+    float v[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = in[r];
+    butterfly_step<8>(v, lane);
+    butterfly_step<4>(v, lane);
+    butterfly_step<2>(v, lane);
+    butterfly_step<1>(v, lane);
+    return v[0] + __shfl_xor(v[0], 16);
+}
 template <int N> __device__ __forceinline__ void butterfly_reduce32(float (&v)[N], int lane) {
     static_assert(N == 32, "N must be 32");
     butterfly_step<16>(v, lane);
@@ -330,16 +343,13 @@ template <typename T> struct EpiGNBwd {
             }
             // reduce over the 32 samples of the lane group; lane i ends with value i.
             butterfly_reduce32(stat, lane);
-            float db2[32];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { db2[r] = dbias[r]; db2[16 + r] = 0.f; }
-            butterfly_reduce32(db2, lane);
+            const float db = butterfly_reduce16(dbias, lane);
             float* row = p.part + (int64_t)wrow * 3 * p.H;
             {
                 const int i = j & 15;                              // register index this lane ended up with
                 const int c = c0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
                 row[(j >> 4) * p.H + c] = stat[0];                 // j<16: dgamma, j>=16: dbeta
-                if (j < 16) row[2 * p.H + c] = db2[0];
+                if (j < 16) row[2 * p.H + c] = db;
             }
         }
     }

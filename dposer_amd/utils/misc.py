@@ -26,7 +26,7 @@ def mask_indices(part, rot_N):
 
 def create_mask(body_poses, part="legs", observation_type="noise"):
     """mask [B, D] (0 on the masked part) and the observation with the masked entries replaced by
-    N(0, 1) noise (misc.py:27-55)."""
+    N(0, 1) noise, or by the SMPL mean pose for any other ``observation_type`` (misc.py:27-55)."""
     assert len(body_poses.shape) == 2 and body_poses.shape[1] % N_POSES == 0
     rot_N = body_poses.shape[1] // N_POSES
     assert rot_N in [3, 6]
@@ -37,8 +37,17 @@ def create_mask(body_poses, part="legs", observation_type="noise"):
     if observation_type == "noise":
         observation[:, idx] = torch.randn_like(observation[:, idx])
     else:
-        raise NotImplementedError("mean-pose observations need the SMPL mean-params asset and torchgeometry-free "
-                                  "conversions (SURVEY.md 8f.3)")
+        # the mean pose as observation (misc.py:44-53): 'pose' of the SMPL mean-params file is [144] rot6d, body joints from 6 on
+        import numpy as np
+        from ..body_model import constants
+        from .transforms import rot6d_to_axis_angle
+        mean = np.load(constants.SMPL_MEAN_PATH)
+        rot6d_body = torch.tensor(mean["pose"][6:], dtype=torch.float32, device=body_poses.device)       # [138]
+        if rot_N == 3:
+            fill = rot6d_to_axis_angle(rot6d_body.reshape(-1, 6)).reshape(-1)                          # [69]
+        else:
+            fill = rot6d_body
+        observation[:, idx] = fill[idx][None].repeat(body_poses.shape[0], 1)
     return mask, observation
 
 

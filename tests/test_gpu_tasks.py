@@ -151,3 +151,29 @@ def test_evaler_min_over_hypotheses():
         mj.append(np.sqrt(((jo - jg)[:, ji] ** 2).sum(-1)).mean(-1) * 1000)
     assert np.allclose(res["mpvpe_all"], np.min(mv, 0), rtol=1e-4, atol=1e-3)
     assert np.allclose(res["mpjpe_body"], np.min(mj, 0), rtol=1e-4, atol=1e-3)
+
+
+def test_create_mask_mean_pose_observation(tmp_path, monkeypatch):
+    """observation_type != 'noise' (misc.py:44-53): masked entries come from the SMPL mean-params file (rot6d), converted to
+    axis-angle for rot_N = 3.  The asset is user supplied; a synthetic file with the same layout stands in."""
+    from dposer_amd.body_model import constants
+    from dposer_amd.utils.misc import create_mask, mask_indices
+    from oracle import fk_ref
+    rs = np.random.RandomState(4)
+    aa = (rs.standard_normal((24, 3)) * 0.5)
+    R = fk_ref.batch_rodrigues(aa)                                            # [24, 3, 3]
+    pose6d = R[:, :, :2].reshape(24, 6).astype(np.float32).reshape(-1)        # row-major 3x2 = first two columns (transforms.py:227-235)
+    f = tmp_path / "smpl_mean_params.npz"
+    np.savez(f, pose=pose6d, shape=np.zeros(10, np.float32), cam=np.zeros(3, np.float32))
+    monkeypatch.setattr(constants, "SMPL_MEAN_PATH", str(f))
+    x = torch.tensor(rs.standard_normal((5, 63)).astype(np.float32), device=DEV)
+    mask, obs = create_mask(x, part="legs", observation_type="mean")
+    idx = mask_indices("legs", 3).numpy()
+    keep = np.setdiff1d(np.arange(63), idx)
+    assert np.array_equal(t2n(obs)[:, keep], t2n(x)[:, keep]) and float(mask[:, idx].abs().sum()) == 0.0
+    want = aa[1:22].reshape(-1)[idx]                                          # body joints 1..21 of the mean pose, as axis-angle
+    assert np.abs(t2n(obs)[:, idx] - want[None]).max() < 1e-5
+    x6 = torch.tensor(rs.standard_normal((3, 126)).astype(np.float32), device=DEV)
+    mask6, obs6 = create_mask(x6, part="left_arm", observation_type="mean")
+    idx6 = mask_indices("left_arm", 6).numpy()
+    assert np.abs(t2n(obs6)[:, idx6] - pose6d[6:][idx6][None]).max() == 0.0

@@ -29,7 +29,7 @@ void add_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void
     memset(&g, 0, sizeof(g));
     g.W = W; g.w_stride_blocks = K / 16; g.src[0] = X; g.seg_kblocks[0] = K / 16; g.nseg = 1; g.ktot_blocks = K / 16;
     g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1;
-    g.max_blocks = g_stagger;
+   
     PlainFTParams p;
     p.out = out; p.N = C;
     char buf[160];
@@ -43,7 +43,7 @@ void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* o
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.W = W; g.w_stride_blocks = K / 16; g.src[0] = X; g.seg_kblocks[0] = K / 16; g.nseg = 1; g.ktot_blocks = K / 16;
-    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1; g.max_blocks = g_stagger;
+    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1;
     GNParams p;
     memset(&p, 0, sizeof(p));
     p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C; p.Spad = S;
@@ -60,15 +60,15 @@ void add_gnbwd(const char* name, int64_t S, int C, int K, void* Wt, void* dyn, v
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.W = Wt; g.w_stride_blocks = K / 16; g.src[0] = dyn; g.seg_kblocks[0] = K / 16; g.nseg = 1; g.ktot_blocks = K / 16;
-    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1; g.max_blocks = g_stagger;
+    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1;
     GNBwdParams p;
     memset(&p, 0, sizeof(p));
     p.carry_in = carry_in; p.carry_out = carry_out; p.xhat = xhat; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.dy = dy; p.part = part;
     p.H = C; p.S_valid = S; p.dyT = dyT; p.Spad = S;
     if (drop_p > 0.f) { p.drop.p = drop_p; p.drop.scale = 1.f / (1.f - drop_p); p.drop.thr = (uint32_t)((1.0 - drop_p) * 65536.0); p.drop.groups_x4 = C / 8; p.drop.seed = 7; }
     char buf[160];
-    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d gnbwd drop%d T%d carry%d%d stg%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, drop_p > 0.f,
-             dyT != nullptr, carry_in != nullptr, carry_out != nullptr, g_stagger);
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d gnbwd drop%d T%d carry%d%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, drop_p > 0.f,
+             dyT != nullptr, carry_in != nullptr, carry_out != nullptr);
     g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGNBwd<__bf16>, GLDS>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
@@ -121,6 +121,26 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&part, (size_t)(S / 32) * 3 * C * 4)); CK(hipMalloc(&cin, (size_t)S * C * 2)); CK(hipMalloc(&cout, (size_t)S * C * 2));
     CK(hipMemset(rstd, 0, (size_t)S * (C / 32) * 4)); CK(hipMemset(xhat, 0, (size_t)S * C * 2)); CK(hipMemset(cin, 0, (size_t)S * C * 2));
 #define GB(WC, WS, TC, TS, KB, G, DROP, DYT, CI, CO) add_gnbwd<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, xhat, rstd, gamma, beta, part, DYT ? outT : nullptr, CI ? cin : nullptr, CO ? cout : nullptr, DROP ? 0.1f : 0.f)
+    if (getenv("TUNE_GNBWD")) {
+        for (int rep = 0; rep < 2; ++rep) {
+            GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0);
+            GB(2, 2, 2, 2, 4, 1, 0, 1, 0, 0);
+            GB(2, 2, 2, 2, 4, 1, 1, 0, 0, 0);
+        }
+        PL(2, 2, 2, 2, 4, 1);
+        run_all(7, 10);
+        return 0;
+    }
+    if (getenv("TUNE_PLAIN")) {
+        g_stagger = 0;
+        PL(2, 2, 2, 2, 4, 1);
+        PL(2, 4, 4, 2, 4, 1);
+        PL(2, 2, 2, 2, 2, 1);
+        GN(2, 2, 2, 2, 4, 1);
+        GN(2, 4, 4, 2, 4, 1);
+        run_all(7, 20);
+        return 0;
+    }
     if (getenv("TUNE_PROFILE")) {
         GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0);
         GB(2, 2, 2, 2, 4, 1, 0, 0, 0, 0);
