@@ -603,6 +603,20 @@ __global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const flo
         }
         return;
     }
+    // few partial rows, many elements (split-K weight slabs): 16-byte accesses when every address is 16-byte aligned
+    if (((j.src_off | j.src_stride | j.dst_off | j.count) & 3) == 0) {
+        const int64_t n4 = j.count >> 2;
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(scratch + j.src_off) + e;
+            f32x4 acc = p[0];
+            for (int k = 1; k < j.nsrc; ++k) {
+                const f32x4 v = p[(int64_t)k * (j.src_stride >> 2)];
+                acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+            }
+            reinterpret_cast<f32x4*>(grad + j.dst_off)[e] = acc;
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < j.count; e += (int64_t)gridDim.x * blockDim.x) {
         const float* p = scratch + j.src_off + e;
         float acc = 0.f;

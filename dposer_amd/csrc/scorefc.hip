@@ -60,6 +60,9 @@ struct dposer_scorefc_s {
     PackJobs fwd_jobs, bwd_jobs;
     BiasCatJobs bias_jobs;
     std::vector<float> host_stage;   // staging for small H2D copies (labels)
+    // second stream for the parameter-gradient side of the backward pass (small batches), see backward_core
+    hipStream_t side = nullptr;
+    hipEvent_t ev_start = nullptr, ev_layer[MAX_L] = {}, ev_time = nullptr, ev_join = nullptr;
 };
 
 static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -163,7 +166,18 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
     return DPOSER_OK;
 }
 
-extern "C" void dposer_scorefc_destroy(dposer_scorefc_t h) { delete h; }
+extern "C" void dposer_scorefc_destroy(dposer_scorefc_t h) {
+    if (!h) return;
+    if (h->side) {
+        (void)hipStreamSynchronize(h->side);
+        (void)hipEventDestroy(h->ev_start);
+        (void)hipEventDestroy(h->ev_time);
+        (void)hipEventDestroy(h->ev_join);
+        for (int l = 0; l < MAX_L; ++l) (void)hipEventDestroy(h->ev_layer[l]);
+        (void)hipStreamDestroy(h->side);
+    }
+    delete h;
+}
 extern "C" int64_t dposer_scorefc_num_params(dposer_scorefc_t h) { return h ? h->nparams : -1; }
 extern "C" int32_t dposer_scorefc_num_tensors(dposer_scorefc_t h) { return h ? (int32_t)h->toff.size() : -1; }
 extern "C" int64_t dposer_scorefc_tensor_offset(dposer_scorefc_t h, int32_t i) { return (h && i >= 0 && i < (int)h->toff.size()) ? h->toff[i] : -1; }
@@ -213,7 +227,7 @@ struct Ws {
     int64_t npad;
     float *tt_labels, *tt_emb, *tt_temb, *table;
     // transposed copies / partials / slabs (training)
-    char *dyT, *hT[MAX_L], *tembT, *embT, *xinT, *dresT, *dUT;
+    char *dyT[MAX_L], *hT[MAX_L], *tembT, *embT, *xinT, *dresT, *dUT;
     float *gn_part[MAX_L], *cs_part_post, *cs_part_se, *slabs;
     int64_t total;
 };
@@ -275,7 +289,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         w.dres = take(Bpad * h->Cp * esz);
         w.tbuf = (float*)take(Bpad * 4);
         w.zbuf = (float*)take(Bpad * h->Dpad * 4);
-        w.dyT = take(Bpad * H * esz);
+        for (int l = 0; l < L; ++l) w.dyT[l] = take(Bpad * H * esz);
         for (int l = 0; l < L; ++l) w.hT[l] = take(Bpad * H * esz);
         w.tembT = take(Bpad * E * esz);
         w.embT = take(Bpad * E * esz);
@@ -690,24 +704,43 @@ extern "C" int dposer_stream_wait_event(void* stream, void* event) {
     return DPOSER_OK;
 }
 
+// Should the parameter-gradient half of the backward pass run on the handle's second stream?
+// Below ~2 tile rounds per launch (Bpad <= 16384: the per-GPU shard of B = 65536 at 4 and 8 GPUs) single kernels leave CUs idle
+// and launch gaps show, so the two wgrad GEMMs + bucket reduction of layer j run concurrently with the dgrad GEMM of layer j-1.
+// DPOSER_WGRAD_STREAM = 0 / 1 forces it off / on.
+static bool use_side_stream(int64_t Bpad) {
+    const char* e = getenv("DPOSER_WGRAD_STREAM");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    return Bpad <= 16384;
+}
+static int ensure_side_stream(dposer_scorefc_s* h) {
+    if (h->side) return DPOSER_OK;
+    DP_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    DP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+    DP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_time, hipEventDisableTiming));
+    DP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    for (int l = 0; l < MAX_L; ++l) DP_CHECK_HIP(hipEventCreateWithFlags(&h->ev_layer[l], hipEventDisableTiming));
+    return DPOSER_OK;
+}
+
+// backward from dres (FT [Bpad][Cp], zero on padded rows) to the flat parameter gradient and/or dx.
+//   critical path (stream st): dgrad GEMM of layer L-1 ... 0 (each writes dy_j, dy_j^T and the GroupNorm partial sums),
+//                              dx GEMM, dgrad into the time branch;
+//   gradient side (stream sw = st, or the handle's second stream): per layer the two split-K wgrad GEMMs and the
+//                              deterministic reduction of that layer's bucket (+ bucket event), in the same layer order.
 static int backward_core(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
                          uint32_t step, float* flat_grad, float* dx, void* const* events, int n_events, hipStream_t st) {
     const int prec = h->f32 ? PREC_FP32 : PREC_BF16;
     const int H = h->H, E = h->E, L = h->L, KBS = h->KBS;
     const int64_t Bpad = w.Bpad;
     const bool want_w = flat_grad != nullptr;
+    const bool two = want_w && use_side_stream(Bpad);
+    if (two) DP_TRY(ensure_side_stream(h));
+    hipStream_t sw = two ? h->side : st;
     ReduceJobs rj;
     rj.n = 0;
     int64_t slab_cursor = 0;
     int n_chunks_post = 0, n_chunks_se = 0;
-    if (want_w) {
-        // post_dense: bias (column sums of dres) and weight
-        DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, st));
-        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, st));
-        DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.hT[L - 1], H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, st));
-    }
-    const int gshape = gnbwd_shape(Bpad);
-    const int ws_rows = (int)(Bpad / (shape_st(gshape) * 32)) * shape_ws(gshape);   // partial rows written by the dgrad epilogue
     // Deterministic reduction into the flat gradient: every partial buffer lives in the workspace (offsets relative to
     // w.slabs); the jobs of one bucket are launched together as soon as its last wgrad has been queued.
     auto rel = [&](const float* p) { return (int64_t)(p - w.slabs); };
@@ -715,6 +748,23 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         ReduceJob& jb = rj.job[rj.n++];
         jb.dst_off = dst; jb.count = count; jb.src_off = rel(src); jb.src_stride = stride; jb.nsrc = nsrc;
     };
+    if (want_w) {
+        if (two) {   // everything the gradient side reads at this point (dres, forward activations) is complete on st
+            DP_CHECK_HIP(hipEventRecord(h->ev_start, st));
+            DP_CHECK_HIP(hipStreamWaitEvent(sw, h->ev_start, 0));
+        }
+        for (int i = 0; i < h->n_nograd; ++i)
+            DP_CHECK_HIP(hipMemsetAsync(flat_grad + h->nograd_lo[i], 0, (h->nograd_hi[i] - h->nograd_lo[i]) * sizeof(float), sw));
+        // operands that only depend on the forward pass
+        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.xin, w.xinT, Bpad, h->Dpad, sw));
+        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, sw));
+        // post_dense: bias (column sums of dres) and weight
+        DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, sw));
+        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, sw));
+        DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.hT[L - 1], H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, sw));
+    }
+    const int gshape = gnbwd_shape(Bpad);
+    const int ws_rows = (int)(Bpad / (shape_st(gshape) * 32)) * shape_ws(gshape);   // partial rows written by the dgrad epilogue
     for (int j = L - 1; j >= 0; --j) {
         // gradient w.r.t. the output of GN layer j, through the layer that consumes it
         const bool from_post = (j == L - 1);
@@ -729,16 +779,18 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         p.carry_out = (even && j >= 2) ? w.carry[(j / 2) & 1] : nullptr;
         p.xhat = w.xhat[j]; p.rstd = w.rstd[j]; p.gamma = flat + h->layer[j].gamma; p.beta = flat + h->layer[j].beta;
         p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B; p.drop = drop_cfg(h, dropout_on, j, seed, step);
-        p.dyT = want_w ? w.dyT : nullptr; p.Spad = Bpad;
+        p.dyT = want_w ? w.dyT[j] : nullptr; p.Spad = Bpad;
         DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st));
         if (!want_w) continue;
+        if (two) {
+            DP_CHECK_HIP(hipEventRecord(h->ev_layer[j], st));
+            DP_CHECK_HIP(hipStreamWaitEvent(sw, h->ev_layer[j], 0));
+        }
         // parameter gradients of layer j
-        const void* inT;
-        if (j == 0) { DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.xin, w.xinT, Bpad, h->Dpad, st)); inT = w.xinT; }
-        else inT = w.hT[j - 1];
+        const void* inT = (j == 0) ? (const void*)w.xinT : (const void*)w.hT[j - 1];
         const LayerOff& lo = h->layer[j];
-        DP_TRY(run_wgrad(h, w.dyT, H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, st));
-        DP_TRY(run_wgrad(h, w.dyT, H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, st));
+        DP_TRY(run_wgrad(h, w.dyT[j], H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw));
+        DP_TRY(run_wgrad(h, w.dyT[j], H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw));
         add_job(lo.gamma, H, w.gn_part[j] + 0 * H, 3 * (int64_t)H, ws_rows);
         add_job(lo.beta, H, w.gn_part[j] + 1 * H, 3 * (int64_t)H, ws_rows);
         add_job(lo.b, H, w.gn_part[j] + 2 * H, 3 * (int64_t)H, ws_rows);
@@ -746,7 +798,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         if (from_post) add_job(h->off_post_b, h->D, w.cs_part_post, h->Cp, n_chunks_post);
         // layer j's gradient (and everything behind it in the flat buffer) is final: the data-parallel all-reduce of this
         // bucket can start while the remaining layers are still being differentiated
-        if (j >= 1) DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1 - j, st));
+        if (j >= 1) DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1 - j, sw));
     }
     if (dx) {   // d loss / d x = dy_0 @ W_pre  (the time branch does not depend on x)
         const int shape = final_shape(Bpad);
@@ -768,15 +820,19 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B; p.outT = w.dUT; p.Spad = Bpad;
         DP_HIP_LAUNCH(gemm_silu_bwd(prec, shape, g, p, st));
     }
-    DP_HIP_LAUNCH(launch_colsum(h->f32, w.dU, w.cs_part_se, Bpad, E, &n_chunks_se, st));
-    DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, st));
-    DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, st));
-
+    if (two) {
+        DP_CHECK_HIP(hipEventRecord(h->ev_time, st));
+        DP_CHECK_HIP(hipStreamWaitEvent(sw, h->ev_time, 0));
+    }
+    DP_HIP_LAUNCH(launch_colsum(h->f32, w.dU, w.cs_part_se, Bpad, E, &n_chunks_se, sw));
+    DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw));
     // last bucket: layer 0 (jobs queued above), the shared time embedding and the parameters that never get a gradient
     add_job(h->off_se_b, E, w.cs_part_se, E, n_chunks_se);
-    for (int i = 0; i < h->n_nograd; ++i)
-        DP_CHECK_HIP(hipMemsetAsync(flat_grad + h->nograd_lo[i], 0, (h->nograd_hi[i] - h->nograd_lo[i]) * sizeof(float), st));
-    DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1, st));
+    DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1, sw));
+    if (two) {   // the caller's stream owns the complete gradient (and may reuse the workspace) from here on
+        DP_CHECK_HIP(hipEventRecord(h->ev_join, sw));
+        DP_CHECK_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+    }
     return DPOSER_OK;
 }
 
