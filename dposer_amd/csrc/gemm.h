@@ -74,7 +74,7 @@ struct GemmCfg {
     static constexpr int ST = WS * TS;   // 32-sample tiles per block
     static constexpr int BLOCKS_PER_STAGE = (CT + ST) * KB;
     static constexpr int STAGE_BYTES = BLOCKS_PER_STAGE * 1024;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // GLDS == 3 uses 3 * STAGE_BYTES (see launch_gemm)
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
     static constexpr int LPW_A = CT * KB / NW;   // 1-KiB weight blocks copied per wave per stage
     static constexpr int LPW_B = ST * KB / NW;   // 1-KiB activation blocks copied per wave per stage
     static constexpr int LPW = LPW_A + LPW_B;
@@ -95,12 +95,23 @@ template <typename Epi> struct EpiParamArrays<Epi, decltype((void)Epi::kParamArr
 template <typename Epi, typename = void> struct EpiScratch { static constexpr int value = 0; };
 template <typename Epi> struct EpiScratch<Epi, decltype((void)Epi::kScratchPerWave)> { static constexpr int value = Epi::kScratchPerWave; };
 
-// The kernel.  Epi::apply(params, acc, channel_base, sample_base, lane, wave-in-sample-dim ids)
-// GLDS: 0 = register staging, 1 = global_load_lds double buffer, 3 = global_load_lds 3-deep ring with counted vmcnt
-template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int GLDS = 0>
+// The kernel.  One workgroup = one output tile (x one k-split).
+// Main loop: double-buffered LDS ring filled with global_load_lds_dwordx4 (the fragment-tiled HBM image IS the LDS
+// image: one 1-KiB block per wave instruction, LDS address = wave-uniform base + lane*16, no VGPR round trip) and
+// double-buffered operand fragments: the ds_reads of k-block kb+1 are issued BEFORE the MFMAs of k-block kb, so LDS
+// latency hides under the matrix pipe (left to itself hipcc reuses one fragment register set and serialises
+// read -> wait -> MFMA per k-block).  The stage barrier sits in front of the LAST MFMA group of a stage, followed by
+// the DMA issue of stage t+2 and the first fragment reads of stage t+1.
+// Variants that were built and measured without gain (3/4/8-deep rings with counted vmcnt, DMA issue interleaved
+// between MFMA groups under s_setprio, register staging, persistent workgroups) are described in DESIGN.md 4.1.
+// Epi::apply(params, acc, channel_base, sample_base, lane, wave row id, split, staged params, stride, scratch).
+template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi>
 __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_ft_kernel(GemmArgs g, typename Epi::Params ep) {
+    static_assert(KB % 2 == 0, "fragment double buffering assumes an even number of k-blocks per stage");
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
     typedef typename Mma<T>::Frag Frag;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -123,7 +134,7 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     const int sblk = L / g.n_cblk;
 
     constexpr int NPAR = EpiParamArrays<Epi>::value;
-    float* lds_par = reinterpret_cast<float*>(smem + (GLDS >= 3 ? GLDS : 2) * C::STAGE_BYTES);   // [NPAR][CT*32]
+    float* lds_par = reinterpret_cast<float*>(smem + 2 * C::STAGE_BYTES);   // [NPAR][CT*32]
     if constexpr (NPAR > 0) {
         for (int i = threadIdx.x; i < NPAR * C::CT * 32; i += C::THREADS) {
             const int a = i / (C::CT * 32), c = i % (C::CT * 32);
@@ -168,51 +179,7 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     }
     const unsigned char* sbase = seg_ptr(0);
 
-    u32x4 stg[C::LPW];
-    auto fetch = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < C::LPW_A; ++i) {
-            const int blk = wave + i * C::NW;
-            const int rb = blk / KB, kb = blk % KB;
-            const unsigned char* p = reinterpret_cast<const unsigned char*>(g.W) +
-                                     (((int64_t)(cblk * C::CT + rb) * g.w_stride_blocks + w_kb + kb) << 10);
-            stg[i] = *reinterpret_cast<const u32x4*>(p + lane * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < C::LPW_B; ++i) {
-            const int blk = wave + i * C::NW;
-            const int rb = blk / KB, kb = blk % KB;
-            const unsigned char* p = sbase + (((int64_t)(sblk * C::ST + rb) * seg_total + seg_kb + kb) << 10);
-            stg[C::LPW_A + i] = *reinterpret_cast<const u32x4*>(p + lane * 16);
-        }
-        seg_kb += KB;
-        w_kb += KB;
-        if (seg_kb >= seg_end && seg + 1 < g.nseg) {
-            ++seg;
-            seg_kb = 0;
-            seg_total = seg_blocks(seg);
-            seg_end = seg_total;
-            sbase = seg_ptr(seg);
-        }
-    };
-    auto commit = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < C::LPW_A; ++i) {
-            const int blk = wave + i * C::NW;
-            *reinterpret_cast<u32x4*>(smem + buf * C::STAGE_BYTES + (blk << 10) + lane * 16) = stg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < C::LPW_B; ++i) {
-            const int blk = C::CT * KB + wave + i * C::NW;
-            *reinterpret_cast<u32x4*>(smem + buf * C::STAGE_BYTES + (blk << 10) + lane * 16) = stg[C::LPW_A + i];
-        }
-    };
-    // direct-to-LDS staging (global_load_lds_dwordx4): the fragment-tiled HBM image IS the LDS image, so a wave
-    // copies a 1-KiB block with one instruction (LDS address = wave-uniform base + lane*16), no VGPR round trip.
     auto fetch_glds = [&](int buf) __attribute__((always_inline)) {
-        typedef const __attribute__((address_space(1))) void* gptr_t;
-        typedef __attribute__((address_space(3))) void* lptr_t;
-#ifndef GEMM_EXPERIMENT_SKIP_A
 #pragma unroll
         for (int i = 0; i < C::LPW_A; ++i) {
             const int blk = wave + i * C::NW;
@@ -221,8 +188,6 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
                                      (((int64_t)(cblk * C::CT + rb) * g.w_stride_blocks + w_kb + kb) << 10);
             __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + (blk << 10)), 16, 0, 0);
         }
-#endif
-#ifndef GEMM_EXPERIMENT_SKIP_B
 #pragma unroll
         for (int i = 0; i < C::LPW_B; ++i) {
             const int blk = wave + i * C::NW;
@@ -230,7 +195,6 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
             const unsigned char* p = sbase + (((int64_t)(sblk * C::ST + rb) * seg_total + seg_kb + kb) << 10);
             __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + ((C::CT * KB + blk) << 10)), 16, 0, 0);
         }
-#endif
         seg_kb += KB;
         w_kb += KB;
         if (seg_kb >= seg_end && seg + 1 < g.nseg) {
@@ -241,176 +205,46 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
             sbase = seg_ptr(seg);
         }
     };
-    auto compute = [&](int buf) __attribute__((always_inline)) {
+
+    Frag fa[2][TC], fb[2][TS];
+    auto load_frags = [&](int buf, int kb, int set) __attribute__((always_inline)) {
         const unsigned char* a_base = smem + buf * C::STAGE_BYTES + ((wc * TC * KB) << 10) + lane * 16;
         const unsigned char* b_base = smem + buf * C::STAGE_BYTES + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            Frag a[TC], b[TS];
+        for (int i = 0; i < TC; ++i) fa[set][i] = *reinterpret_cast<const Frag*>(a_base + ((i * KB + kb) << 10));
 #pragma unroll
-            for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const Frag*>(a_base + ((i * KB + kb) << 10));
-#ifdef GEMM_EXPERIMENT_NO_B_READ
+        for (int j = 0; j < TS; ++j) fb[set][j] = *reinterpret_cast<const Frag*>(b_base + ((j * KB + kb) << 10));
+    };
+    auto mma = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < TS; ++j) b[j] = a[j];
-#else
+        for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int j = 0; j < TS; ++j) b[j] = *reinterpret_cast<const Frag*>(b_base + ((j * KB + kb) << 10));
-#endif
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TS; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
-        }
+            for (int j = 0; j < TS; ++j) Mma<T>::run(fa[set][i], fb[set][j], acc[i][j]);
     };
 
-    // ---- software pipeline: global -> regs (next stage) overlaps MFMA on the current stage -----
-    if constexpr (GLDS >= 3) {
-        // GLDS-deep LDS ring, prefetch distance GLDS-1: the DMAs of up to GLDS-2 later stages stay in flight across the
-        // barrier of stage t (raw s_barrier + counted vmcnt; __syncthreads() would drain them).  More bytes in flight
-        // per CU is what hides the ~2 us L2/HBM -> LDS latency (Little's law: 64 KiB in flight = 32 GB/s per CU).
-        constexpr int NB = GLDS, D = GLDS - 1;
+    fetch_glds(0);
+    if (nstages > 1) fetch_glds(1);
+    if (nstages > 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(C::LPW)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    __syncthreads_lds_only();
+    load_frags(0, 0, 0);
+    for (int t = 0; t < nstages; ++t) {
+        const int buf = t & 1;
 #pragma unroll
-        for (int i = 0; i < D; ++i)
-            if (i < nstages) fetch_glds(i);
-        int buf = 0, fbuf = D % NB;
-        for (int t = 0; t < nstages; ++t) {
-            const int ahead = nstages - 1 - t;       // stages issued after t that may still be in flight
-            if (ahead >= D - 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0((D - 1) * C::LPW));
-            else if (D >= 3 && ahead == 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(1 * C::LPW));
-            else if (D >= 4 && ahead == 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(2 * C::LPW));
-            else __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (t + D < nstages) fetch_glds(fbuf);                 // refills the buffer stage t-1 just released
-            compute(buf);
-            buf = buf + 1 == NB ? 0 : buf + 1;
-            fbuf = fbuf + 1 == NB ? 0 : fbuf + 1;
-        }
-    } else if constexpr (GLDS == 2) {
-        // double buffer, but the DMA of stage t+1 is issued in KB slices between the MFMA groups of stage t and the
-        // MFMA clusters run at raised priority
-        auto fetch_part = [&](int buf, int part) __attribute__((always_inline)) {
-            typedef const __attribute__((address_space(1))) void* gptr_t;
-            typedef __attribute__((address_space(3))) void* lptr_t;
-#pragma unroll
-            for (int i = 0; i < C::LPW_A; ++i) {
-                if (i % KB != part) continue;
-                const int blk = wave + i * C::NW;
-                const int rb = blk / KB, kb = blk % KB;
-                const unsigned char* p = reinterpret_cast<const unsigned char*>(g.W) +
-                                         (((int64_t)(cblk * C::CT + rb) * g.w_stride_blocks + w_kb + kb) << 10);
-                __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + (blk << 10)), 16, 0, 0);
+        for (int kb = 0; kb < KB; ++kb) {
+            if (kb + 1 < KB) {
+                load_frags(buf, kb + 1, (kb + 1) & 1);
+            } else if (t + 1 < nstages) {
+                // stage t+1 must have landed (its DMA was issued one full stage ago); every wave is done reading buf
+                __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (t + 2 < nstages) fetch_glds(buf);            // refill the buffer we just finished reading
+                load_frags(buf ^ 1, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < C::LPW_B; ++i) {
-                if (i % KB != part) continue;
-                const int blk = wave + i * C::NW;
-                const int rb = blk / KB, kb = blk % KB;
-                const unsigned char* p = sbase + (((int64_t)(sblk * C::ST + rb) * seg_total + seg_kb + kb) << 10);
-                __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + ((C::CT * KB + blk) << 10)), 16, 0, 0);
-            }
-        };
-        auto advance = [&]() __attribute__((always_inline)) {
-            seg_kb += KB;
-            w_kb += KB;
-            if (seg_kb >= seg_end && seg + 1 < g.nseg) {
-                ++seg;
-                seg_kb = 0;
-                seg_total = seg_blocks(seg);
-                seg_end = seg_total;
-                sbase = seg_ptr(seg);
-            }
-        };
-        fetch_glds(0);
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        for (int t = 0; t < nstages; ++t) {
-            const bool more = t + 1 < nstages;
-            const int buf = t & 1;
-            const unsigned char* a_base = smem + buf * C::STAGE_BYTES + ((wc * TC * KB) << 10) + lane * 16;
-            const unsigned char* b_base = smem + buf * C::STAGE_BYTES + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                Frag a[TC], b[TS];
-#pragma unroll
-                for (int i = 0; i < TC; ++i) a[i] = *reinterpret_cast<const Frag*>(a_base + ((i * KB + kb) << 10));
-#pragma unroll
-                for (int j = 0; j < TS; ++j) b[j] = *reinterpret_cast<const Frag*>(b_base + ((j * KB + kb) << 10));
-                if (more) fetch_part(buf ^ 1, kb);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < TC; ++i)
-#pragma unroll
-                    for (int j = 0; j < TS; ++j) Mma<T>::run(a[i], b[j], acc[i][j]);
-                __builtin_amdgcn_s_setprio(0);
-            }
-            if (more) advance();
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-        }
-    } else if constexpr (GLDS == 1) {
-        // Double-buffered LDS ring + double-buffered operand fragments: the ds_reads of k-block kb+1 are issued BEFORE the
-        // MFMAs of k-block kb, so LDS latency hides under the matrix pipe (left to itself hipcc reuses one fragment register
-        // set and serialises read -> wait -> MFMA per k-block: 44 % MFMA utilisation).  The stage barrier sits in front of
-        // the LAST MFMA group of a stage, followed by the DMA issue of stage t+2 and the first fragment reads of stage t+1.
-        Frag fa[2][TC], fb[2][TS];
-        auto load_frags = [&](int buf, int kb, int set) __attribute__((always_inline)) {
-            const unsigned char* a_base = smem + buf * C::STAGE_BYTES + ((wc * TC * KB) << 10) + lane * 16;
-            const unsigned char* b_base = smem + buf * C::STAGE_BYTES + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
-#ifdef GEMM_EXPERIMENT_NO_A_READ
-            if (kb == 0 && buf == 0)
-#endif
-#pragma unroll
-            for (int i = 0; i < TC; ++i) fa[set][i] = *reinterpret_cast<const Frag*>(a_base + ((i * KB + kb) << 10));
-#ifdef GEMM_EXPERIMENT_NO_B_READ
-            if (kb == 0 && buf == 0)
-#endif
-#pragma unroll
-            for (int j = 0; j < TS; ++j) fb[set][j] = *reinterpret_cast<const Frag*>(b_base + ((j * KB + kb) << 10));
-        };
-        auto mma = [&](int set) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TS; ++j) Mma<T>::run(fa[set][i], fb[set][j], acc[i][j]);
-        };
-        static_assert(KB % 2 == 0, "fragment double buffering assumes an even number of k-blocks per stage");
-        fetch_glds(0);
-        if (nstages > 1) fetch_glds(1);
-        if (nstages > 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(C::LPW)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
-        __syncthreads_lds_only();
-        load_frags(0, 0, 0);
-        for (int t = 0; t < nstages; ++t) {
-            const int buf = t & 1;
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) {
-                if (kb + 1 < KB) {
-                    load_frags(buf, kb + 1, (kb + 1) & 1);
-                } else if (t + 1 < nstages) {
-                    // stage t+1 must have landed (its DMA was issued one full stage ago); every wave is done reading buf
-                    __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (t + 2 < nstages) fetch_glds(buf);            // refill the buffer we just finished reading
-                    load_frags(buf ^ 1, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                mma(kb & 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    } else {
-        fetch();
-        commit(0);
-        __syncthreads();
-        for (int t = 0; t < nstages; ++t) {
-            const bool more = (t + 1 < nstages);
-            if (more) fetch();
-            compute(t & 1);
-            if (more) commit((t + 1) & 1);
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            mma(kb & 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -419,12 +253,11 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
                                 sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32, wave_scratch);
 }
 
-template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int GLDS = 0>
+template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi>
 static inline hipError_t launch_gemm(const GemmArgs& g, const typename Epi::Params& ep, hipStream_t stream) {
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
-    auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi, GLDS>;
-    constexpr int lds_bytes = (GLDS >= 3 ? GLDS : 2) * C::STAGE_BYTES + EpiParamArrays<Epi>::value * C::CT * 32 * 4 +
-                              EpiScratch<Epi>::value * C::NW;
+    auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi>;
+    constexpr int lds_bytes = 2 * C::STAGE_BYTES + EpiParamArrays<Epi>::value * C::CT * 32 * 4 + EpiScratch<Epi>::value * C::NW;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && lds_bytes > 64 * 1024) {

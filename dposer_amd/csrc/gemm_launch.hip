@@ -62,12 +62,12 @@ constexpr unsigned M_BIG = 1u << SHAPE_BIG, M_MID = 1u << SHAPE_MID, M_SMALL = 1
 template <typename T, typename Epi, unsigned ALLOWED>
 static hipError_t by_shape_masked(int shape, const GemmArgs& g, const typename Epi::Params& p, hipStream_t st) {
     switch (shape) {
-        case SHAPE_BIG: if constexpr (ALLOWED & M_BIG) return launch_gemm<T, 2, 4, 4, 2, 4, Epi, 1>(g, p, st); break;
-        case SHAPE_MID: if constexpr (ALLOWED & M_MID) return launch_gemm<T, 2, 2, 2, 2, 4, Epi, 1>(g, p, st); break;
-        case SHAPE_SMALL: if constexpr (ALLOWED & M_SMALL) return launch_gemm<T, 4, 1, 1, 1, 4, Epi, 1>(g, p, st); break;
-        case SHAPE_FINAL: if constexpr (ALLOWED & M_FINAL) return launch_gemm<T, 1, 4, 2, 1, 4, Epi, 1>(g, p, st); break;
-        case SHAPE_FINAL_S: if constexpr (ALLOWED & M_FINAL_S) return launch_gemm<T, 2, 1, 1, 1, 4, Epi, 1>(g, p, st); break;
-        case SHAPE_WIDE64: if constexpr (ALLOWED & M_WIDE) return launch_gemm<T, 2, 2, 2, 1, 4, Epi, 1>(g, p, st); break;
+        case SHAPE_BIG: if constexpr (ALLOWED & M_BIG) return launch_gemm<T, 2, 4, 4, 2, 4, Epi>(g, p, st); break;
+        case SHAPE_MID: if constexpr (ALLOWED & M_MID) return launch_gemm<T, 2, 2, 2, 2, 4, Epi>(g, p, st); break;
+        case SHAPE_SMALL: if constexpr (ALLOWED & M_SMALL) return launch_gemm<T, 4, 1, 1, 1, 4, Epi>(g, p, st); break;
+        case SHAPE_FINAL: if constexpr (ALLOWED & M_FINAL) return launch_gemm<T, 1, 4, 2, 1, 4, Epi>(g, p, st); break;
+        case SHAPE_FINAL_S: if constexpr (ALLOWED & M_FINAL_S) return launch_gemm<T, 2, 1, 1, 1, 4, Epi>(g, p, st); break;
+        case SHAPE_WIDE64: if constexpr (ALLOWED & M_WIDE) return launch_gemm<T, 2, 2, 2, 1, 4, Epi>(g, p, st); break;
     }
     return hipErrorInvalidConfiguration;
 }

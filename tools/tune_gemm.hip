@@ -34,7 +34,7 @@ void add_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void
     p.out = out; p.N = C;
     char buf[160];
     snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d plain stg%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, g_stagger);
-    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiPlainFT<__bf16>, GLDS>(g, p, 0))); }, 2.0 * S * C * K, {}});
+    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiPlainFT<__bf16>>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
 template <int WC, int WS, int TC, int TS, int KB, int GLDS, bool TRAIN = false>
@@ -50,7 +50,7 @@ void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* o
     if (TRAIN) { p.xhat = xhat; p.rstd = rstd; p.outT = outT; }
     char buf[160];
     snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d %s stg%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, TRAIN ? "gn-train" : "gn", g_stagger);
-    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, TRAIN>, GLDS>(g, p, 0))); }, 2.0 * S * C * K, {}});
+    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, TRAIN>>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
 template <int WC, int WS, int TC, int TS, int KB, int GLDS>
@@ -69,7 +69,7 @@ void add_gnbwd(const char* name, int64_t S, int C, int K, void* Wt, void* dyn, v
     char buf[160];
     snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d gnbwd drop%d T%d carry%d%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, drop_p > 0.f,
              dyT != nullptr, carry_in != nullptr, carry_out != nullptr);
-    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGNBwd<__bf16>, GLDS>(g, p, 0))); }, 2.0 * S * C * K, {}});
+    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGNBwd<__bf16>>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
 static void run_all(int rounds, int reps) {
