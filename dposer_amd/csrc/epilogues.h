@@ -33,6 +33,16 @@ __device__ __forceinline__ void dropout_mask16(const DropoutCfg& d, int64_t s, i
     }
 }
 
+// Run Epi::sub<TC, TS, tc, ts> over every sub-tile of a wave tile in (tc, ts) order (compile-time indices).
+template <typename Epi, int TC, int TS, int I = 0, typename P, typename C>
+__device__ __forceinline__ void epi_for_each_sub(const P& pp, C& carry, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow,
+                                                 int split, const float* lpar, int lstride, unsigned char* scr) {
+    if constexpr (I < TC * TS) {
+        Epi::template sub<TC, TS, I / TS, I % TS>(pp, carry, acc[I / TS][I % TS], cbase, sbase, lane, wrow, split, lpar, lstride, scr);
+        epi_for_each_sub<Epi, TC, TS, I + 1>(pp, carry, acc, cbase, sbase, lane, wrow, split, lpar, lstride, scr);
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // forward:  out = [resid +] Drop(SiLU(GroupNorm32(acc + bias)))         model.py:166-187
 // ----------------------------------------------------------------------------------------------
@@ -49,68 +59,85 @@ struct GNParams {
     void* outT;            // TRAIN, optional: the output again as FT [H][Spad] (operand of the wgrad GEMMs)
     int64_t Spad;
 };
-template <typename T, bool TRAIN> struct EpiGN {
+// RESID: -1 = decide at run time from Params::resid (and null-check the optional outputs); 0 / 1 = residual input absent /
+// present at compile time AND no other branch in the code: rstd is stored by both lane halves, dropout is always drawn
+// (DropoutCfg must then be valid: thr = 65536, scale = 1 when disabled), outT must be non-null.  The branch-free form is what
+// the pipelined kernel (gemm_pipe.h) needs: a branch would split the basic block its MFMA / VALU interleave is scheduled in.
+template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
     typedef GNParams Params;
+    static constexpr bool FLAT = RESID >= 0;
     static constexpr int kScratchPerWave = TRAIN ? TileT<T>::SCRATCH_BYTES : 0;
     static constexpr int kParamArrays = 3;
     __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.bias : (a == 1 ? p.gamma : p.beta); }
-    template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
+    // One 32x32 sub-tile (tc, ts) of the wave tile; `a` = its accumulator.  Sub-tiles are independent of each other, which is
+    // what lets the pipelined kernel (gemm_pipe.h) run them inside the k-loop of the NEXT tile.  The work is split in kPhases = 2
+    // halves of similar VALU weight (PH = 0: statistics + dropout draw, PH = 1: normalise / SiLU / stores; PH = -1: both), the
+    // state between them lives in Carry.
+    static constexpr int kPhases = 2;
+    struct Carry {
+        float v[16];       // centred values (phase 0) -> x_hat
+        float keep[16];
+        float rstd;
+    };
+    template <int TC, int TS, int tc, int ts, int PH = -1>
+    __device__ static inline void sub(const Params& pp, Carry& cy, const f32x16& a, int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
         struct { const float *bias, *gamma, *beta; T* out; const T* resid; T* xhat; float* rstd; int H; DropoutCfg drop; } p =
             {pp.bias, pp.gamma, pp.beta, (T*)pp.out, (const T*)pp.resid, (T*)pp.xhat, pp.rstd, pp.H, pp.drop};
         constexpr bool PRECISE = sizeof(T) == 4;
         const int j = lane & 31, hi = lane >> 5;
-#pragma unroll
-        for (int tc = 0; tc < TC; ++tc) {
-            const int c0 = cbase + tc * 32;
-            float bia[16], gam[16], bet[16];
+        const int c0 = cbase + tc * 32;
+        const int64_t s = sbase + ts * 32 + j;
+        const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.H);
+        const bool drop = TRAIN && (FLAT || p.drop.p > 0.f);
+        if constexpr (PH != 1) {
+            float sum = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cl = tc * 32 + 8 * q + 4 * hi;              // channel inside the wave's LDS-staged slice
-                f32x4 b4 = *reinterpret_cast<const f32x4*>(lpar + cl);
-                f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
-                f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + 2 * lstride + cl);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(lpar + tc * 32 + 8 * q + 4 * hi);   // channel inside the wave's LDS-staged slice
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { bia[4 * q + r] = b4[r]; gam[4 * q + r] = g4[r]; bet[4 * q + r] = e4[r]; }
+                for (int r = 0; r < 4; ++r) { cy.v[4 * q + r] = a[4 * q + r] + b4[r]; sum += cy.v[4 * q + r]; }
             }
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / 32.0f);
+            float ss = 0.f;
 #pragma unroll
-            for (int ts = 0; ts < TS; ++ts) {
-                const int64_t s = sbase + ts * 32 + j;
-                const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.H);
-                float v[16];
-                float sum = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { v[r] = acc[tc][ts][r] + bia[r]; sum += v[r]; }
-                sum += __shfl_xor(sum, 32);
-                const float mean = sum * (1.0f / 32.0f);
-                float ss = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { v[r] -= mean; ss += v[r] * v[r]; }
-                ss += __shfl_xor(ss, 32);
-                const float var = ss * (1.0f / 32.0f);
-                const float rstd = PRECISE ? 1.0f / sqrtf(var + 1e-5f) : rsqrtf(var + 1e-5f);
-                float keep[16];
-                if (TRAIN && p.drop.p > 0.f) dropout_mask16(p.drop, s, c0 >> 5, hi, keep);
-                if (TRAIN && hi == 0) p.rstd[s * (p.H >> 5) + (c0 >> 5)] = rstd;
-                float o[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    v[r] *= rstd;                                   // x_hat
-                    float y = silu_f<PRECISE>(gam[r] * v[r] + bet[r]);
-                    if (TRAIN && p.drop.p > 0.f) y *= keep[r];
-                    o[r] = y;
-                }
-                if (TRAIN) TileIO<T>::store(p.xhat + tb, lane, v);
-                if (p.resid) {
-                    float rr[16];
-                    TileIO<T>::load(p.resid + tb, lane, rr);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[r] += rr[r];
-                }
-                TileIO<T>::store(p.out + tb, lane, o);
-                if (TRAIN && pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, o);
-            }
+            for (int r = 0; r < 16; ++r) { cy.v[r] -= mean; ss += cy.v[r] * cy.v[r]; }
+            ss += __shfl_xor(ss, 32);
+            const float var = ss * (1.0f / 32.0f);
+            cy.rstd = PRECISE ? 1.0f / sqrtf(var + 1e-5f) : rsqrtf(var + 1e-5f);
+            if (drop) dropout_mask16(p.drop, s, c0 >> 5, hi, cy.keep);
+            if (TRAIN && (FLAT || hi == 0)) p.rstd[s * (p.H >> 5) + (c0 >> 5)] = cy.rstd;
         }
+        if constexpr (PH != 0) {
+            float o[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = tc * 32 + 8 * q + 4 * hi;
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
+                const f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + 2 * lstride + cl);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cy.v[4 * q + r] *= cy.rstd;                                   // x_hat
+                    float y = silu_f<PRECISE>(g4[r] * cy.v[4 * q + r] + e4[r]);
+                    if (drop) y *= cy.keep[4 * q + r];
+                    o[4 * q + r] = y;
+                }
+            }
+            if (TRAIN) TileIO<T>::store(p.xhat + tb, lane, cy.v);
+            if (RESID == 1 || (RESID < 0 && p.resid)) {
+                float rr[16];
+                TileIO<T>::load(p.resid + tb, lane, rr);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] += rr[r];
+            }
+            TileIO<T>::store(p.out + tb, lane, o);
+            if (TRAIN && (FLAT || pp.outT)) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, o);
+        }
+    }
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int split, const float* lpar, int lstride, unsigned char* scr) {
+        Carry c;
+        epi_for_each_sub<EpiGN, TC, TS>(pp, c, acc, cbase, sbase, lane, wrow, split, lpar, lstride, scr);
     }
 };
 
@@ -199,18 +226,19 @@ struct PlainFTParams {
 };
 template <typename T> struct EpiPlainFT {
     typedef PlainFTParams Params;
+    static constexpr int kPhases = 1;
+    struct Carry {};
+    template <int TC, int TS, int tc, int ts, int PH = -1>
+    __device__ static inline void sub(const Params& pp, Carry&, const f32x16& a, int cbase, int64_t sbase, int lane, int, int, const float*, int, unsigned char*) {
+        float o[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = a[r];
+        TileIO<T>::store((T*)pp.out + ft_tile_base<T>(sbase + ts * 32, cbase + tc * 32, pp.N), lane, o);
+    }
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
-        struct { T* out; int N; } p = {(T*)pp.out, pp.N};
-#pragma unroll
-        for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-            for (int ts = 0; ts < TS; ++ts) {
-                float o[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = acc[tc][ts][r];
-                TileIO<T>::store(p.out + ft_tile_base<T>(sbase + ts * 32, cbase + tc * 32, p.N), lane, o);
-            }
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int split, const float* lpar, int lstride, unsigned char* scr) {
+        Carry c;
+        epi_for_each_sub<EpiPlainFT, TC, TS>(pp, c, acc, cbase, sbase, lane, wrow, split, lpar, lstride, scr);
     }
 };
 

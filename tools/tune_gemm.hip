@@ -11,6 +11,7 @@
 
 #include "epilogues.h"
 #include "gemm.h"
+#include "experimental/gemm_pipe.h"
 
 int dposer_set_error(int code, const std::string&) { return code; }
 
@@ -51,6 +52,36 @@ void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* o
     char buf[160];
     snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d %s stg%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, TRAIN ? "gn-train" : "gn", g_stagger);
     g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, TRAIN>>(g, p, 0))); }, 2.0 * S * C * K, {}});
+}
+
+template <int WC, int WS, int TC, int TS, int KB, bool TRAIN = false>
+void add_gn_pipe(const char* name, int64_t S, int C, int K, void* W, void* X, void* out, float* bias, float* gamma, float* beta, void* xhat, float* rstd, void* outT) {
+    typedef GemmCfg<__bf16, WC, WS, TC, TS, KB> Cfg;
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.W = W; g.w_stride_blocks = K / 16; g.src[0] = X; g.seg_kblocks[0] = K / 16; g.nseg = 1; g.ktot_blocks = K / 16;
+    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1;
+    GNParams p;
+    memset(&p, 0, sizeof(p));
+    p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C; p.Spad = S;
+    if (TRAIN) { p.xhat = xhat; p.rstd = rstd; p.outT = outT; }
+    char buf[160];
+    p.drop.thr = 65536; p.drop.scale = 1.f; p.drop.groups_x4 = C / 8;
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d PIPE %s", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, TRAIN ? "gn-train" : "gn");
+    g_cases.push_back({buf, [=] { CK((launch_gemm_pipe<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, TRAIN, 0>>(g, p, 0))); }, 2.0 * S * C * K, {}});
+}
+template <int WC, int WS, int TC, int TS, int KB>
+void add_plain_pipe(const char* name, int64_t S, int C, int K, void* W, void* X, void* out) {
+    typedef GemmCfg<__bf16, WC, WS, TC, TS, KB> Cfg;
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.W = W; g.w_stride_blocks = K / 16; g.src[0] = X; g.seg_kblocks[0] = K / 16; g.nseg = 1; g.ktot_blocks = K / 16;
+    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1;
+    PlainFTParams p;
+    p.out = out; p.N = C;
+    char buf[160];
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d PIPE plain", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB);
+    g_cases.push_back({buf, [=] { CK((launch_gemm_pipe<__bf16, WC, WS, TC, TS, KB, EpiPlainFT<__bf16>>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
 template <int WC, int WS, int TC, int TS, int KB, int GLDS>
@@ -121,6 +152,35 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&part, (size_t)(S / 32) * 3 * C * 4)); CK(hipMalloc(&cin, (size_t)S * C * 2)); CK(hipMalloc(&cout, (size_t)S * C * 2));
     CK(hipMemset(rstd, 0, (size_t)S * (C / 32) * 4)); CK(hipMemset(xhat, 0, (size_t)S * C * 2)); CK(hipMemset(cin, 0, (size_t)S * C * 2));
 #define GB(WC, WS, TC, TS, KB, G, DROP, DYT, CI, CO) add_gnbwd<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, xhat, rstd, gamma, beta, part, DYT ? outT : nullptr, CI ? cin : nullptr, CO ? cout : nullptr, DROP ? 0.1f : 0.f)
+    if (getenv("TUNE_PIPE")) {
+        // correctness: pipelined vs reference kernel, bit for bit
+        {
+            add_gn<2, 4, 4, 2, 4, 1>("ref", S, C, K, W, X, o0, bias, gamma, beta, xhat, rstd, outT);
+            add_gn_pipe<2, 2, 4, 2, 4>("pipe", S, C, K, W, X, o1, bias, gamma, beta, xhat, rstd, outT);
+            CK(hipMemset(o0, 0, (size_t)S * C * 2)); CK(hipMemset(o1, 0xff, (size_t)S * C * 2));
+            g_cases[0].launch(); g_cases[1].launch();
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned short> h0((size_t)S * C), h1((size_t)S * C);
+            CK(hipMemcpy(h0.data(), o0, h0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i < h0.size(); ++i) if (h0[i] != h1[i]) { if (!bad) first = i; ++bad; }
+            printf("pipelined vs reference GN output: %zu mismatches of %zu (first at %zu)\n", bad, h0.size(), first);
+            g_cases.clear();
+        }
+#define GNP(WC, WS, TC, TS, KB) add_gn_pipe<WC, WS, TC, TS, KB>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, bias, gamma, beta, xhat, rstd, outT)
+#define GNPT(WC, WS, TC, TS, KB) add_gn_pipe<WC, WS, TC, TS, KB, true>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, bias, gamma, beta, xhat, rstd, outT)
+#define PLP(WC, WS, TC, TS, KB) add_plain_pipe<WC, WS, TC, TS, KB>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1)
+        g_stagger = 0;
+        GN(2, 4, 4, 2, 4, 1);
+        GNP(2, 2, 4, 2, 4);
+        GNP(1, 4, 4, 2, 4);
+        GNT(2, 4, 4, 2, 4, 1);
+        GNPT(2, 2, 4, 2, 4);
+        PL(2, 4, 4, 2, 4, 1);
+        PLP(2, 2, 4, 2, 4);
+        run_all(7, 10);
+        return 0;
+    }
     if (getenv("TUNE_GNBWD")) {
         for (int rep = 0; rep < 2; ++rep) {
             GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0);
