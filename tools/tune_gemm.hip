@@ -1,6 +1,9 @@
-// Tile-shape / staging tuner for the score-network GEMM (run on the GPU box):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Idposer_amd/csrc tools/tune_gemm.hip -o gpurun_out/tune_gemm && gpurun_out/tune_gemm
-// Times the forward GroupNorm layer GEMM (C = 1024 channels, K = 1024, S samples) for several workgroup tilings.
+// Tile-shape / epilogue-cost tuner for the score-network GEMM (run on the GPU box):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Idposer_amd/csrc -Iinclude -Itools tools/tune_gemm.hip -o tools/bin/tune_gemm
+//   tools/bin/tune_gemm [S]            default table        TUNE_K=1536 ...    reduction length of the layer GEMM
+//   TUNE_GNBWD=1 / TUNE_PLAIN=1 / TUNE_PIPE=1 / TUNE_PROFILE=1   focused case lists (see main)
+// Times one layer GEMM (C = 1024 channels, K = 1024, S = 65536 samples) per (tiling, epilogue); the cases of a run are
+// interleaved over 7 rounds and min / median are reported, because clocks drift by several percent within a process.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -21,7 +24,6 @@ int dposer_set_error(int code, const std::string&) { return code; }
 #include <functional>
 struct Case { std::string name; std::function<void()> launch; double flops; std::vector<double> us; };
 static std::vector<Case> g_cases;
-static int g_stagger = 0;
 
 template <int WC, int WS, int TC, int TS, int KB, int GLDS>
 void add_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void* out) {
@@ -34,7 +36,7 @@ void add_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void
     PlainFTParams p;
     p.out = out; p.N = C;
     char buf[160];
-    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d plain stg%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, g_stagger);
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d  plain", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB);
     g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiPlainFT<__bf16>>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
@@ -50,7 +52,7 @@ void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* o
     p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C; p.Spad = S;
     if (TRAIN) { p.xhat = xhat; p.rstd = rstd; p.outT = outT; }
     char buf[160];
-    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d %s stg%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, TRAIN ? "gn-train" : "gn", g_stagger);
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d  %s", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, TRAIN ? "gn-train" : "gn");
     g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, TRAIN>>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
@@ -98,7 +100,7 @@ void add_gnbwd(const char* name, int64_t S, int C, int K, void* Wt, void* dyn, v
     p.H = C; p.S_valid = S; p.dyT = dyT; p.Spad = S;
     if (drop_p > 0.f) { p.drop.p = drop_p; p.drop.scale = 1.f / (1.f - drop_p); p.drop.thr = (uint32_t)((1.0 - drop_p) * 65536.0); p.drop.groups_x4 = C / 8; p.drop.seed = 7; }
     char buf[160];
-    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d glds%d gnbwd drop%d T%d carry%d%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS, drop_p > 0.f,
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d  gnbwd drop%d T%d carry%d%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, drop_p > 0.f,
              dyT != nullptr, carry_in != nullptr, carry_out != nullptr);
     g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGNBwd<__bf16>>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
@@ -170,7 +172,6 @@ int main(int argc, char** argv) {
 #define GNP(WC, WS, TC, TS, KB) add_gn_pipe<WC, WS, TC, TS, KB>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, bias, gamma, beta, xhat, rstd, outT)
 #define GNPT(WC, WS, TC, TS, KB) add_gn_pipe<WC, WS, TC, TS, KB, true>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, bias, gamma, beta, xhat, rstd, outT)
 #define PLP(WC, WS, TC, TS, KB) add_plain_pipe<WC, WS, TC, TS, KB>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1)
-        g_stagger = 0;
         GN(2, 4, 4, 2, 4, 1);
         GNP(2, 2, 4, 2, 4);
         GNP(1, 4, 4, 2, 4);
@@ -184,15 +185,17 @@ int main(int argc, char** argv) {
     if (getenv("TUNE_GNBWD")) {
         for (int rep = 0; rep < 2; ++rep) {
             GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0);
-            GB(2, 2, 2, 2, 4, 1, 0, 1, 0, 0);
-            GB(2, 2, 2, 2, 4, 1, 1, 0, 0, 0);
+            GB(4, 2, 2, 2, 4, 1, 1, 1, 0, 0);
+            GB(2, 4, 2, 2, 4, 1, 1, 1, 0, 0);
+            GB(4, 2, 2, 2, 2, 1, 1, 1, 0, 0);
+            GB(2, 2, 2, 2, 2, 1, 1, 1, 0, 0);
         }
         PL(2, 2, 2, 2, 4, 1);
+        PL(4, 2, 2, 2, 4, 1);
         run_all(7, 10);
         return 0;
     }
     if (getenv("TUNE_PLAIN")) {
-        g_stagger = 0;
         PL(2, 2, 2, 2, 4, 1);
         PL(2, 4, 4, 2, 4, 1);
         PL(2, 2, 2, 2, 2, 1);
@@ -211,19 +214,22 @@ int main(int argc, char** argv) {
         run_all(1, 2);
         return 0;
     }
-    for (int stg : {-1, 0}) {
-        g_stagger = stg;
-        GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0);
-        GN(2, 2, 2, 4, 2, 1);
-        GNT(2, 2, 2, 4, 2, 1);
-        GNT(4, 1, 2, 4, 2, 1);
-        GN(2, 4, 4, 2, 4, 1);
-        GNT(2, 4, 4, 2, 4, 1);
-        GN(2, 2, 2, 2, 4, 1);
-        PL(2, 4, 4, 2, 4, 1);
-        PL(2, 2, 2, 2, 4, 1);
-    }
-    g_stagger = 0;
+    // default table: the shipped tilings (256x256 / 8 waves, 128x128 / 4 waves) and the 4-wave two-workgroups-per-CU alternatives
+    PL(2, 4, 4, 2, 4, 1);
+    PL(2, 2, 2, 2, 4, 1);
+    GN(2, 4, 4, 2, 4, 1);
+    GN(2, 2, 2, 2, 4, 1);
+    GN(2, 2, 2, 4, 2, 1);
+    GN(4, 1, 2, 4, 2, 1);
+    GNT(2, 4, 4, 2, 4, 1);
+    GNT(2, 2, 2, 4, 2, 1);
+    GNT(4, 1, 2, 4, 2, 1);
+    GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0);
+    GB(2, 2, 2, 2, 4, 1, 0, 1, 0, 0);
+    GB(2, 2, 2, 2, 4, 1, 1, 0, 0, 0);
+    GB(2, 2, 2, 2, 4, 1, 0, 0, 0, 0);
+    GB(2, 2, 2, 2, 4, 1, 1, 1, 1, 1);
+    GB(4, 2, 2, 2, 4, 1, 1, 1, 0, 0);
     run_all(7, 10);
     return 0;
 }
