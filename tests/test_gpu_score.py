@@ -397,3 +397,59 @@ def test_dsm_grads_ragged_batches_and_rot6d_vs_oracle(B, D):
             assert float(got.abs().max()) == 0.0, n
             continue
         assert rel_err(t2n(got), gr.reshape(-1).numpy()) < 3e-4, (n, B)
+
+
+def test_checkpoint_round_trip_in_reference_format(tmp_path):
+    """run/train.py:395-403 saves {'model_state_dict', 'optimizer_state_dict', 'ema', 'step'}; run/train.py:186-190 restores
+    them.  A run resumed from such a file must continue bit-identically, and a state dict produced by torch.optim.Adam itself
+    (what a reference checkpoint holds) must load into the fused optimizer."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+
+    def build():
+        cfg, m, p = make_model(23, precision="fp32", dropout=0.0)
+        cfg.optim.warmup = 2
+        opt = losses.get_optimizer(cfg, m.parameters())
+        ema = ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate)
+        fn = losses.get_step_fn(sde_lib.subVPSDE(0.1, 20.0, 1000), True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True,
+                                continuous=True)
+        return cfg, m, dict(model=m, optimizer=opt, ema=ema, step=0), fn
+
+    rs = np.random.RandomState(8)
+    data = [(_dev(rs.standard_normal((64, 63)).astype(np.float32)), _dev(rs.uniform(1e-3, 1, 64).astype(np.float32)),
+             _dev(rs.standard_normal((64, 63)).astype(np.float32))) for _ in range(4)]
+    cfg, m, state, fn = build()
+    for b, t, z in data[:2]:
+        fn(state, b, t=t, z=z)
+    path = tmp_path / "checkpoint-step2.pth"
+    torch.save({"epoch": 1, "model_state_dict": m.state_dict(), "optimizer_state_dict": state["optimizer"].state_dict(),
+                "ema": state["ema"].state_dict(), "step": state["step"]}, path)
+    for b, t, z in data[2:]:
+        fn(state, b, t=t, z=z)
+
+    cfg2, m2, state2, fn2 = build()
+    ck = torch.load(path, map_location=DEV, weights_only=False)
+    m2.load_state_dict(ck["model_state_dict"])
+    state2["optimizer"].load_state_dict(ck["optimizer_state_dict"])
+    state2["ema"].load_state_dict(ck["ema"])
+    state2["step"] = ck["step"]
+    for b, t, z in data[2:]:
+        fn2(state2, b, t=t, z=z)
+    assert torch.equal(m.flat_params(), m2.flat_params())
+    assert all(torch.equal(a, b) for a, b in zip(state["ema"].shadow_params, state2["ema"].shadow_params))
+    assert state2["step"] == 4 and state2["ema"].num_updates == state["ema"].num_updates
+
+    # a plain torch.optim.Adam state dict (reference checkpoints) -> FusedAdam
+    ref_params = [torch.nn.Parameter(q.detach().clone()) for q in m.parameters()]
+    ref_opt = torch.optim.Adam(ref_params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    for q in ref_params:
+        q.grad = torch.full_like(q, 1e-3)
+    ref_opt.step()
+    cfg3, m3, state3, fn3 = build()
+    state3["optimizer"].load_state_dict(ref_opt.state_dict())
+    flat, offs, params = state3["optimizer"]._ensure_flat()
+    for q, o in zip(ref_params, offs):
+        st = ref_opt.state[q]
+        assert torch.equal(state3["optimizer"]._flat_m[o:o + q.numel()], st["exp_avg"].reshape(-1))
+        assert torch.equal(state3["optimizer"]._flat_v[o:o + q.numel()], st["exp_avg_sq"].reshape(-1))
+    assert state3["optimizer"]._step_count == 1
