@@ -1,10 +1,105 @@
-"""Pose normaliser -- counterpart of the hot-path surface of the reference's lib/dataset/AMASS.py
-(N_POSES :9, Posenormalizer :187-259).  Dataset IO (AMASSDataset) is host-side and out of scope."""
+"""Counterpart of the reference's lib/dataset/AMASS.py: the AMASS ``.pt`` data format (AMASSDataset :12-182), the pose
+normaliser (Posenormalizer :187-259) and the evaluation metrics (Evaler :262-330)."""
 import os
 
 import torch
 
 N_POSES = 21
+
+
+class AMASSDataset(torch.utils.data.Dataset):
+    """``{root}/{version}/{subset}/pose_body.pt`` ([N, 63] axis-angle) and optionally ``betas.pt`` ([N, 10]) -- AMASS.py:12-182.
+
+    Host-side data format: tensors stay where ``torch.load`` puts them (CPU); items are ``{'poses': [D] (, 'shapes': [10])}``.
+    Normalisation statistics come from ``{root}/{version}/train/{rot_rep}_normalize{1: min-max, 2: z-score}.pt`` and are
+    computed from this subset and written there when the file does not exist, exactly like the reference.  ``rot_rep='rot6d'``
+    converts with the HIP rotation kernels (needs a GPU; the result is moved back to the poses' device)."""
+
+    def __init__(self, root_path, version="version0", subset="train", sample_interval=None, rot_rep="rot6d", return_shape=False,
+                 normalize=True, min_max=True):
+        assert subset in ["train", "valid", "test"]
+        assert rot_rep in ["axis", "rot6d"]
+        self.root_path, self.version, self.subset = root_path, version, subset
+        self.sample_interval, self.rot_rep, self.return_shape = sample_interval, rot_rep, return_shape
+        self.normalize, self.min_max = normalize, min_max
+        self.poses, self.shapes = self.read_data()
+        if self.sample_interval:
+            self._sample(sample_interval)
+        if self.normalize:
+            if self.min_max:
+                self.min_poses, self.max_poses, self.min_shapes, self.max_shapes = self.Normalize()
+            else:
+                self.mean_poses, self.std_poses, self.mean_shapes, self.std_shapes = self.Normalize()
+        self.real_data_len = len(self.poses)
+
+    def __getitem__(self, idx):
+        item = {"poses": self.poses[idx % self.real_data_len]}
+        if self.return_shape:
+            item["shapes"] = self.shapes[idx % self.real_data_len]
+        return item
+
+    def __len__(self):
+        return len(self.poses)
+
+    def _sample(self, sample_interval):
+        print(f"Class AMASSDataset({self.subset}): sample dataset every {sample_interval} frame")
+        self.poses = self.poses[::sample_interval]                 # (the reference leaves `shapes` un-sampled, AMASS.py:56-58)
+
+    def read_data(self):
+        data_path = os.path.join(self.root_path, self.version, self.subset)
+        poses = torch.load(os.path.join(data_path, "pose_body.pt"))
+        shapes = torch.load(os.path.join(data_path, "betas.pt")) if self.return_shape else None
+        if self.rot_rep == "rot6d":
+            from ..utils.transforms import axis_angle_to_rot6d
+            n, home = len(poses), poses.device
+            dev = home if poses.is_cuda else torch.device("cuda")
+            poses = axis_angle_to_rot6d(poses.reshape(-1, 3).to(dev)).reshape(n, -1).to(home)
+        return poses, shapes
+
+    def _stat_path(self):
+        return os.path.join(self.root_path, self.version, "train", self.rot_rep + ("_normalize1.pt" if self.min_max else "_normalize2.pt"))
+
+    def Normalize(self):
+        path = self._stat_path()
+        keys = ("min_poses", "max_poses", "min_shapes", "max_shapes") if self.min_max else ("mean_poses", "std_poses", "mean_shapes", "std_shapes")
+        if os.path.exists(path):
+            saved = torch.load(path)
+            a, b, sa, sb = (saved[k] for k in keys)
+        else:
+            lo_fn = (lambda x: torch.min(x, dim=0)[0]) if self.min_max else (lambda x: torch.mean(x, dim=0))
+            hi_fn = (lambda x: torch.max(x, dim=0)[0]) if self.min_max else (lambda x: torch.std(x, dim=0))
+            a, b = lo_fn(self.poses), hi_fn(self.poses)
+            sa = lo_fn(self.shapes) if self.return_shape else None
+            sb = hi_fn(self.shapes) if self.return_shape else None
+            torch.save(dict(zip(keys, (a, b, sa, sb))), path)
+        if self.min_max:
+            self.poses = 2 * (self.poses - a) / (b - a) - 1
+            if self.return_shape:
+                self.shapes = 2 * (self.shapes - sa) / (sb - sa) - 1
+        else:
+            self.poses = (self.poses - a) / b
+            if self.return_shape:
+                self.shapes = (self.shapes - sa) / sb
+        return a, b, sa, sb
+
+    def Denormalize(self, poses, shapes=None):
+        assert len(poses.shape) == 2 or len(poses.shape) == 3      # [b, data_dim] or [t, b, data_dim]
+
+        def undo(x, a, b):
+            a, b = a.view(1, -1).to(x.device), b.view(1, -1).to(x.device)
+            if len(x.shape) == 3:
+                a, b = a.unsqueeze(0), b.unsqueeze(0)
+            return 0.5 * ((x + 1) * (b - a) + 2 * a) if self.min_max else x * b + a
+
+        a, b, sa = (self.min_poses, self.max_poses, self.min_shapes) if self.min_max else (self.mean_poses, self.std_poses, self.mean_shapes)
+        sb = self.max_shapes if self.min_max else self.std_shapes
+        out = undo(poses, a, b)
+        if shapes is not None and sa is not None:
+            return out, undo(shapes, sa, sb)
+        return out
+
+    def eval(self, preds):
+        pass
 
 
 class Posenormalizer:

@@ -465,9 +465,38 @@ def g12_likelihood_ode():
     save("g12_likelihood_ode", **out)
 
 
+def g13_dataset():
+    """AMASSDataset (lib/dataset/AMASS.py:12-182) on a temporary root holding the toy poses: sampling, both normalisations
+    (statistics computed and written, then re-read), Denormalize."""
+    import tempfile
+    poses = torch.tensor(np.load(os.path.join(REF, "examples/toy_data.npz"))["pose_samples"])          # [500, 63]
+    betas = torch.tensor(np.random.RandomState(3).standard_normal((500, 10)).astype(np.float32))
+    out = {"betas": betas.numpy()}
+    with tempfile.TemporaryDirectory() as root:
+        for sub in ("train", "valid"):
+            os.makedirs(os.path.join(root, "v", sub))
+            torch.save(poses if sub == "train" else poses[:100] * 0.5, os.path.join(root, "v", sub, "pose_body.pt"))
+            torch.save(betas if sub == "train" else betas[:100], os.path.join(root, "v", sub, "betas.pt"))
+        for tag, mm in (("minmax", True), ("zscore", False)):
+            ds = ref_amass.AMASSDataset(root, version="v", subset="train", sample_interval=3, rot_rep="axis", return_shape=True,
+                                        normalize=True, min_max=mm)
+            out[f"{tag}/len"] = np.int64(len(ds))
+            out[f"{tag}/poses"] = ds.poses.numpy()
+            out[f"{tag}/shapes"] = ds.shapes.numpy()
+            out[f"{tag}/item7_poses"] = ds[7]["poses"].numpy()
+            out[f"{tag}/denorm"] = ds.Denormalize(ds.poses[:5]).numpy()
+            dp, dsh = ds.Denormalize(ds.poses[None, :5], ds.shapes[None, :5])
+            out[f"{tag}/denorm3_poses"], out[f"{tag}/denorm3_shapes"] = dp.numpy(), dsh.numpy()
+            # the valid subset re-reads the statistics the train subset just wrote
+            dv = ref_amass.AMASSDataset(root, version="v", subset="valid", sample_interval=None, rot_rep="axis", return_shape=False,
+                                        normalize=True, min_max=mm)
+            out[f"{tag}/valid_poses"] = dv.poses.numpy()
+    save("g13_dataset", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     fns = dict(g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
-               g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode)
+               g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
     for w in which:
         fns[w]()

@@ -177,3 +177,19 @@ def test_create_mask_mean_pose_observation(tmp_path, monkeypatch):
     mask6, obs6 = create_mask(x6, part="left_arm", observation_type="mean")
     idx6 = mask_indices("left_arm", 6).numpy()
     assert np.abs(t2n(obs6)[:, idx6] - pose6d[6:][idx6][None]).max() == 0.0
+
+
+def test_amass_dataset_rot6d_uses_gpu_conversion(tmp_path):
+    import os
+    from dposer_amd.dataset.AMASS import AMASSDataset
+    from dposer_amd.utils.transforms import axis_angle_to_rot6d
+    toy = torch.tensor(load("g10_normalizer")["toy_pose_samples"])
+    os.makedirs(tmp_path / "v" / "train")
+    torch.save(toy, tmp_path / "v" / "train" / "pose_body.pt")
+    ds = AMASSDataset(str(tmp_path), version="v", subset="train", rot_rep="rot6d", normalize=False)
+    assert ds.poses.shape == (toy.shape[0], 126) and not ds.poses.is_cuda
+    want = axis_angle_to_rot6d(toy.reshape(-1, 3).to(DEV)).reshape(toy.shape[0], -1).cpu()
+    assert torch.equal(ds.poses, want)
+    # the 6 numbers are the first two columns of the rotation matrix, row-major 3x2 (transforms.py:227-235)
+    R = fk_ref.batch_rodrigues(toy[:4].reshape(-1, 3).double().numpy())
+    assert np.abs(ds.poses[:4].reshape(-1, 3, 2).numpy() - R[:, :, :2]).max() < 1e-5

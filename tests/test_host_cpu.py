@@ -177,3 +177,28 @@ def test_philox_known_answer():
     assert [int(v) for v in r] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     r = philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
     assert [int(v) for v in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_amass_dataset_matches_reference_golden(tmp_path):
+    """The AMASS .pt data format: sampling, statistics written / re-read, both normalisations, Denormalize (axis-angle; the
+    rot6d variant needs the GPU rotation kernels)."""
+    from dposer_amd.dataset.AMASS import AMASSDataset
+    g = load("g13_dataset")
+    toy = torch.tensor(load("g10_normalizer")["toy_pose_samples"])
+    betas = torch.tensor(g["betas"])
+    for sub in ("train", "valid"):
+        os.makedirs(tmp_path / "v" / sub)
+        torch.save(toy if sub == "train" else toy[:100] * 0.5, tmp_path / "v" / sub / "pose_body.pt")
+        torch.save(betas if sub == "train" else betas[:100], tmp_path / "v" / sub / "betas.pt")
+    for tag, mm in (("minmax", True), ("zscore", False)):
+        ds = AMASSDataset(str(tmp_path), version="v", subset="train", sample_interval=3, rot_rep="axis", return_shape=True, normalize=True,
+                          min_max=mm)
+        assert len(ds) == int(g[f"{tag}/len"])
+        assert np.array_equal(ds.poses.numpy(), g[f"{tag}/poses"]) and np.array_equal(ds.shapes.numpy(), g[f"{tag}/shapes"])
+        assert np.array_equal(ds[7]["poses"].numpy(), g[f"{tag}/item7_poses"])
+        assert np.array_equal(ds.Denormalize(ds.poses[:5]).numpy(), g[f"{tag}/denorm"])
+        dp, dsh = ds.Denormalize(ds.poses[None, :5], ds.shapes[None, :5])
+        assert np.array_equal(dp.numpy(), g[f"{tag}/denorm3_poses"]) and np.array_equal(dsh.numpy(), g[f"{tag}/denorm3_shapes"])
+        dv = AMASSDataset(str(tmp_path), version="v", subset="valid", rot_rep="axis", normalize=True, min_max=mm)
+        assert np.array_equal(dv.poses.numpy(), g[f"{tag}/valid_poses"])
+        assert os.path.exists(tmp_path / "v" / "train" / ("axis_normalize1.pt" if mm else "axis_normalize2.pt"))
