@@ -202,3 +202,51 @@ def test_amass_dataset_matches_reference_golden(tmp_path):
         dv = AMASSDataset(str(tmp_path), version="v", subset="valid", rot_rep="axis", normalize=True, min_max=mm)
         assert np.array_equal(dv.poses.numpy(), g[f"{tag}/valid_poses"])
         assert os.path.exists(tmp_path / "v" / "train" / ("axis_normalize1.pt" if mm else "axis_normalize2.pt"))
+
+
+def test_capi_handle_layout_and_error_codes():
+    """Host-only entry points (no GPU): parameter layout = ScoreModelFC.parameters() order, gradient buckets partition the flat
+    buffer, argument errors come back as negative codes with a message in dposer_last_error()."""
+    import ctypes as C
+    from dposer_amd import _C
+    from oracle import score_ref as R
+    lib = _C.lib()
+    h = C.c_void_p()
+    bad = _C.ScoreFCDesc(63, 1000, 512, 2, _C.EMB_POSITIONAL, 1, 1000, _C.PREC_BF16, 0.1)
+    rc = lib.dposer_scorefc_create(C.byref(bad), C.byref(h))
+    assert rc < 0 and b"hidden_dim" in lib.dposer_last_error()
+    with pytest.raises(_C.DPoserHipError, match="hidden_dim"):
+        _C.check(rc, "dposer_scorefc_create")
+    assert lib.dposer_scorefc_create(None, C.byref(h)) < 0
+
+    good = _C.ScoreFCDesc(63, 1024, 512, 2, _C.EMB_POSITIONAL, 1, 1000, _C.PREC_BF16, 0.1)
+    assert lib.dposer_scorefc_create(C.byref(good), C.byref(h)) == 0
+    try:
+        assert lib.dposer_scorefc_num_params(h) == 8277567                      # SURVEY 8(a2)
+        shapes = {"pre_dense.weight": 1024 * 63, "pre_dense_cond.weight": 1024 * 1024, "shared_time_embed.0.weight": 512 * 512,
+                  "b1_dense1_t.weight": 1024 * 512, "b2_gnorm2.bias": 1024, "post_dense.weight": 63 * 1024, "post_dense.bias": 63}
+        names = R.param_names()
+        assert lib.dposer_scorefc_num_tensors(h) == len(names) == 36
+        off = 0
+        for i, n in enumerate(names):
+            assert lib.dposer_scorefc_tensor_offset(h, i) == off
+            if n in shapes:
+                assert lib.dposer_scorefc_tensor_numel(h, i) == shapes[n], n
+            off += lib.dposer_scorefc_tensor_numel(h, i)
+        assert off == 8277567
+        lo, hi = (C.c_int64 * 2)(), (C.c_int64 * 2)()
+        assert lib.dposer_scorefc_nograd_ranges(h, lo, hi) == 1                  # the dead pre_dense_cond
+        i_cond = names.index("pre_dense_cond.weight")
+        assert lo[0] == lib.dposer_scorefc_tensor_offset(h, i_cond) and hi[0] - lo[0] == 1024 * 1024 + 1024
+        nb = lib.dposer_scorefc_grad_buckets(h, None, None, 0)
+        blo, bhi = (C.c_int64 * nb)(), (C.c_int64 * nb)()
+        assert lib.dposer_scorefc_grad_buckets(h, blo, bhi, nb) == nb == 5
+        assert bhi[0] == 8277567 and blo[nb - 1] == 0 and all(bhi[b + 1] == blo[b] for b in range(nb - 1))
+        assert blo[0] == lib.dposer_scorefc_tensor_offset(h, names.index("b2_dense2.weight"))
+        assert lib.dposer_scorefc_workspace_bytes(h, 0, _C.WS_TRAIN, 0) < 0       # batch must be positive
+        assert lib.dposer_scorefc_workspace_bytes(h, 65536, _C.WS_TRAIN, 0) > lib.dposer_scorefc_workspace_bytes(h, 65536, _C.WS_INFER, 0) > 0
+        # NULL tensors are rejected before anything is launched
+        assert lib.dposer_scorefc_forward(h, None, None, None, None, None, None, None, None, 8, None) < 0
+        assert b"null" in lib.dposer_last_error()
+    finally:
+        lib.dposer_scorefc_destroy(h)
