@@ -102,6 +102,27 @@ def shard_bounds(total: int, num_replicas: int, rank_: int):
     return start, start + base + (1 if rank_ < extra else 0)
 
 
+def gather_metrics(all_results, dst=0):
+    """End-of-evaluation reduction of run/completion.py:300-323: every rank holds ``all_results`` = a list (one entry per batch)
+    of ``{metric name: per-sample values}``; rank ``dst`` receives them all, concatenates per metric and returns
+    ``({name: mean over every sample of every rank}, {name: all values})``; other ranks get ``(None, None)``.
+    Single process: the same arithmetic without a collective."""
+    import numpy as np
+    if is_initialized() and dist.get_world_size() > 1:
+        collection = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+        dist.gather_object(all_results, collection, dst=dst)
+        if dist.get_rank() != dst:
+            return None, None
+        batches = [b for rank_results in collection for b in rank_results]
+    else:
+        batches = list(all_results)
+    merged = {}
+    for batch in batches:
+        for key, value in batch.items():
+            merged.setdefault(key, []).extend(np.asarray(value.detach().cpu() if torch.is_tensor(value) else value).reshape(-1).tolist())
+    return {k: float(np.mean(np.array(v))) for k, v in merged.items()}, merged
+
+
 def barrier():
     if is_initialized():
         dist.barrier()

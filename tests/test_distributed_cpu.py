@@ -27,6 +27,13 @@ def _worker(rank, world, port, out):
     seen = []
     nb = ddp.all_reduce_buckets_(gb, [(60, 100), (30, 60), (0, 30)], None)
     assert nb == world and torch.equal(gb, torch.arange(100.0) * 3)
+    # per-batch metric dicts, unequal number of batches per rank (drop_last=False shards)
+    mine = [{"mpjpe": torch.full((4,), float(rank)), "mpvpe": np.full(4, 10.0 * rank)} for _ in range(1 + rank)]
+    means, allv = ddp.gather_metrics(mine)
+    if rank == 0:
+        assert len(allv["mpjpe"]) == 4 * 3 and abs(means["mpjpe"] - (0 * 4 + 1 * 8) / 12) < 1e-12 and abs(means["mpvpe"] - 80 / 12) < 1e-12
+    else:
+        assert means is None and allv is None
     flat = torch.arange(10.0) * (rank + 1)
     ddp.broadcast_(flat, src=0)
     lo, hi = ddp.shard_bounds(65536 + 3, world, rank)
@@ -58,4 +65,6 @@ def test_single_process_is_noop():
     g = torch.ones(8)
     assert ddp.all_reduce_sum_(g) == 1 and float(g.sum()) == 8.0
     assert ddp.all_reduce_buckets_(g, [(0, 4), (4, 8)]) == 1 and float(g.sum()) == 8.0
+    means, allv = ddp.gather_metrics([{"e": [1.0, 3.0]}, {"e": torch.tensor([5.0])}])
+    assert means == {"e": 3.0} and allv["e"] == [1.0, 3.0, 5.0]
     assert ddp.shard_bounds(10, 3, 0) == (0, 4) and ddp.shard_bounds(10, 3, 2) == (7, 10)
