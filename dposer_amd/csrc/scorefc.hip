@@ -215,7 +215,12 @@ static int main_shape(int64_t Spad) {
 // The GroupNorm-backward epilogue needs ~210 VGPRs next to a 128x128 tile's accumulators; on the 256x256 tile it spills
 // (measured slower), so that tiling is not instantiated for it.
 static int gnbwd_shape(int64_t Spad) { return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL; }
-static int final_shape(int64_t Spad) { return Spad % 128 == 0 ? SHAPE_FINAL : SHAPE_FINAL_S; }
+// post_dense / dx: one 64-channel block tile, so the grid is Spad/128 (or Spad/32) workgroups: below 32768 samples the
+// 64x128 tiling leaves most CUs idle and the 64x32 one is used.
+static int final_shape(int64_t Spad) {
+    static const int64_t small_max = [] { const char* e = getenv("DPOSER_FINAL_SMALL_MAX"); return e ? atoll(e) : (int64_t)16384; }();
+    return (Spad % 128 == 0 && Spad > small_max) ? SHAPE_FINAL : SHAPE_FINAL_S;
+}
 
 struct Ws {
     int64_t Bpad;
