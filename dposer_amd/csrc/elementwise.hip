@@ -48,12 +48,20 @@ template <typename T> __device__ __forceinline__ void store_quad_ft(void* base, 
 }
 
 // time embedding value for channel e of E (model.py:37-51 positional / :19-21 fourier)
+// FAST (bf16 storage): hardware v_sin_f32 / v_cos_f32 on the argument in revolutions.  |arg| <= 999 rad = 159 revolutions,
+// inside the instruction's +-256 domain; the fp32 product arg * (1/2pi) is off by <= 1e-5 revolutions (6e-5 rad), two orders
+// below the bf16 rounding of the stored embedding.  The fp32 parity mode keeps libm sinf / cosf.
+template <bool FAST = false>
 __device__ __forceinline__ float temb_value(float label, int e, int E, const float* freq, int fourier) {
     const int half = E >> 1;
     const int k = e < half ? e : e - half;
     float arg;
     if (fourier) arg = ((logf(label) * freq[k]) * 2.0f) * 3.14159274101257324f;
     else arg = label * freq[k];
+    if (FAST && !fourier) {
+        const float rev = arg * 0.15915494309189535f;
+        return e < half ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
+    }
     return e < half ? sinf(arg) : cosf(arg);
 }
 
@@ -139,7 +147,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_prep_infer(PrepAr
             const int e = (q - qx) * 4;
             const float label = s < a.B ? a.labels[s] : (a.fourier ? 1.0f : 0.0f);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = temb_value(label, e + r, a.E, a.freq, a.fourier);
+            for (int r = 0; r < 4; ++r) v[r] = temb_value<sizeof(T) == 2>(label, e + r, a.E, a.freq, a.fourier);
             store_quad_ft<T>(a.emb, s, e, a.E, v);
         }
     }
@@ -206,7 +214,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTr
             const int e = (q - qx) * 4;
             const float label = t * 999.0f;                 // utils.py:152
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = temb_value(label, e + r, a.E, a.freq, a.fourier);
+            for (int r = 0; r < 4; ++r) v[r] = temb_value<sizeof(T) == 2>(label, e + r, a.E, a.freq, a.fourier);
             store_quad_ft<T>(a.emb, s, e, a.E, v);
         }
     }
