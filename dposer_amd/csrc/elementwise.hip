@@ -6,6 +6,7 @@
 // (lib/algorithms/advanced/sde_lib.py) and is compiled with FMA contraction off so that integer
 // indices derived from floats (sigmas[(t*999).long()], model.py:159) agree bit-for-bit.
 #include "kernels_api.h"
+#include "sde_dev.h"
 #include "rng.h"
 
 #pragma clang fp contract(off)
@@ -13,35 +14,6 @@
 // ------------------------------------------------------------------------------------------------
 // SDE scalars (sde_lib.py:122-231)
 // ------------------------------------------------------------------------------------------------
-struct SdeDev {
-    int kind;
-    float b0, db, m2b0;   // beta_0, (beta_1 - beta_0), -2*beta_0  (python doubles rounded to fp32)
-    float dt, sqrt_mdt;   // -1/N, sqrt(1/N)
-};
-static SdeDev make_sde_dev(const SdeCfg& s) {
-    SdeDev d;
-    d.kind = s.kind;
-    d.b0 = (float)(double)s.beta_0;
-    d.db = (float)((double)s.beta_1 - (double)s.beta_0);
-    d.m2b0 = (float)(-2.0 * (double)s.beta_0);
-    d.dt = (float)(-1.0 / (double)s.N);
-    d.sqrt_mdt = (float)sqrt(1.0 / (double)s.N);
-    return d;
-}
-__device__ __forceinline__ float sde_lmc(const SdeDev& s, float t) {          // sde_lib.py:214
-    return (-0.25f * (t * t)) * s.db - (0.5f * t) * s.b0;
-}
-__device__ __forceinline__ float sde_std(const SdeDev& s, float lmc) {         // :216 (subVP) / :155 (VP)
-    const float v = 1.0f - expf(2.0f * lmc);
-    return s.kind == SDE_SUBVP ? v : sqrtf(v);
-}
-__device__ __forceinline__ float sde_beta(const SdeDev& s, float t) { return s.b0 + t * s.db; }   // :207
-__device__ __forceinline__ float sde_diffusion(const SdeDev& s, float t) {     // :209-210 / :149
-    const float beta = sde_beta(s, t);
-    if (s.kind == SDE_VP) return sqrtf(beta);
-    const float discount = 1.0f - expf(s.m2b0 * t - s.db * (t * t));
-    return sqrtf(beta * discount);
-}
 
 template <typename T> __device__ __forceinline__ void store_quad_ft(void* base, int64_t s, int c, int K, f32x4 v) {
     Quad<T>::store(reinterpret_cast<T*>(base) + FT<T>::index(s, c, K), v);
@@ -248,15 +220,6 @@ hipError_t launch_time_embed(const float* labels, float label0, int64_t n, int64
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// output stages
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float used_sigma(const float* sigmas, int num_scales, float label, int fourier) {
-    if (fourier) return label;                                  // model.py:152
-    int idx = (int)label;                                       // model.py:159  t.long() truncates
-    idx = idx < 0 ? 0 : (idx >= num_scales ? num_scales - 1 : idx);
-    return sigmas[idx];
-}
 
 __global__ void __launch_bounds__(256) k_out_model(OutModelArgs a) {
     const int64_t total = a.B * a.D;
@@ -335,7 +298,32 @@ template <typename T> __global__ void __launch_bounds__(256) k_em_update(EmDev d
             }
         }
         store_quad_ft<T>(a.xin, s, c, a.Dpad, xn);
+        if (a.x_ft) store_quad_ft<float>(a.x_ft, s, c, a.Dpad, xn);
     }
+}
+__global__ void __launch_bounds__(256) k_ft_to_rows(const float* a_ft, float* a, const float* b_ft, float* b, int64_t B, int D, int Dpad) {
+    const int qx = Dpad >> 2;
+    const int64_t total = B * qx;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / qx;
+        const int c = (int)(i % qx) * 4;
+        const int64_t off = FT<float>::index(s, c, Dpad);
+        if (a_ft) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a_ft + off);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (c + r < D) a[s * D + c + r] = v[r];
+        }
+        if (b_ft) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(b_ft + off);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (c + r < D) b[s * D + c + r] = v[r];
+        }
+    }
+}
+hipError_t launch_ft_to_rows(const float* a_ft, float* a, const float* b_ft, float* b, int64_t B, int64_t Bpad, int D, int Dpad, hipStream_t st) {
+    (void)Bpad;
+    hipLaunchKernelGGL(k_ft_to_rows, dim3(grid_for(B * (Dpad >> 2))), dim3(256), 0, st, a_ft, a, b_ft, b, B, D, Dpad);
+    return hipGetLastError();
 }
 hipError_t launch_em_update(const EmUpdateArgs& a, hipStream_t st) {
     EmDev d;

@@ -4,6 +4,7 @@
 #pragma once
 #include "common.h"
 #include "rng.h"
+#include "sde_dev.h"
 
 // dropout keep decisions for one lane's 16 channels of GroupNorm group g (contract: oracle/philox.py
 // dropout_keep_mask).  Two Philox calls; call m covers quads q = 2m, 2m+1; 16-bit lanes; lane_in_call = (q%2)*4 + r.
@@ -215,6 +216,75 @@ template <typename T> struct EpiRowMajor {
                             if (c + r < p.C_valid) p.out[s * p.ldc + c + r] = acc[tc][ts][4 * q + r] + b[r];
                     }
                 }
+            }
+    }
+};
+
+// post_dense fused with one Euler-Maruyama predictor step (sampler fast path: no observation, in-kernel noise, no trajectory).
+//   res    = acc + bias                                   model.py:189
+//   score  = -(res / used_sigma) / std(t)                 model.py:194, utils.py:162
+//   x_mean = x + (-1/2 beta x - g^2 score) * dt           sde_lib.py:98-104, sampling.py:186
+//   x      = x_mean + g sqrt(-dt) z,  z ~ Philox          sampling.py:187
+// The state x lives in HBM as fp32 FT [Spad][64] between steps (coalesced tile I/O; row-major only at the two ends of the
+// sampler), and the next step's network input (FT of T) is written from the same registers.  Same fp32 operation order as
+// k_em_update; the Philox counter (sample * QD + channel / 4, STREAM_EM_NOISE, step) is the one oracle/philox.py restates.
+struct EmStepParams {
+    const float* bias;     // [Cp] post_dense bias
+    float* x_ft;           // FT fp32 [Spad][Cp], in/out
+    float* x_mean_ft;      // FT fp32 [Spad][Cp] or null (only the last step's is needed)
+    void* xin;             // FT [Spad][Dpad] next network input
+    const float* sigmas;
+    SdeDev sde;
+    float t;
+    int num_scales, scale_by_sigma;
+    int D, Cp, QD;
+    int64_t S_valid;
+    uint64_t seed;
+    uint32_t step;
+};
+template <typename T> struct EpiEmStep {
+    typedef EmStepParams Params;
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float*, int, unsigned char*) {
+#pragma clang fp contract(off)
+        const int j = lane & 31, hi = lane >> 5;
+        // per-step scalars (identical for every sample: vec_t = ones(B) * t, sampling.py:458)
+        const float t = p.t;
+        const float lmc = sde_lmc(p.sde, t);
+        const float sd = sde_std(p.sde, lmc);
+        const float beta = sde_beta(p.sde, t);
+        const float g = sde_diffusion(p.sde, t);
+        const float usig = p.scale_by_sigma ? used_sigma(p.sigmas, p.num_scales, t * 999.0f, 0) : 1.0f;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                const int c0 = cbase + tc * 32;
+                const int64_t s = sbase + ts * 32 + j;
+                const int64_t tb = ft_tile_base<float>(sbase + ts * 32, c0, p.Cp);
+                float x[16], xm[16];
+                TileIO<float>::load(p.x_ft + tb, lane, x);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + 8 * q + 4 * hi;
+                    float z[4];
+                    normals4((uint64_t)s * p.QD + (c >> 2), STREAM_EM_NOISE, p.step, p.seed, z);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * q + r;
+                        const bool valid = s < p.S_valid && c + r < p.D;
+                        const float model = (acc[tc][ts][i] + (c + r < p.D ? p.bias[c + r] : 0.f)) / usig;
+                        const float score = -model / sd;
+                        float drift = (-0.5f * beta) * x[i];
+                        drift = drift - ((g * g) * score) * 1.0f;
+                        const float mean = x[i] + drift * p.sde.dt;
+                        xm[i] = valid ? mean : 0.f;
+                        x[i] = valid ? mean + (g * p.sde.sqrt_mdt) * z[r] : 0.f;
+                    }
+                }
+                TileIO<float>::store(p.x_ft + tb, lane, x);
+                if (p.x_mean_ft) TileIO<float>::store(p.x_mean_ft + tb, lane, xm);
+                TileIO<T>::store((T*)p.xin + ft_tile_base<T>(sbase + ts * 32, c0, p.Cp), lane, x);
             }
     }
 };

@@ -27,14 +27,7 @@ struct BiasCatJobs {
 };
 hipError_t launch_bias_cat(const BiasCatJobs& j, const float* flat, float* dst, hipStream_t st);
 
-// ---- SDE description (reference lib/algorithms/advanced/sde_lib.py) --------------------------------
-enum : int { SDE_SUBVP = 0, SDE_VP = 1 };
-struct SdeCfg {
-    int kind;
-    float beta_0, beta_1;
-    int N;
-    float T;
-};
+#include "sde_dev.h"   // SdeCfg, SdeDev
 
 // ---- input preparation ---------------------------------------------------------------------------
 struct PrepArgs {
@@ -90,6 +83,7 @@ struct EmUpdateArgs {      // EulerMaruyamaPredictor.update_fn + imputation (sam
     float* x_mean;         // [B][D]
     void* xin;             // FT [Bpad][Dpad]: next step's network input
     float* traj;           // [B][D] slot for this step or null
+    float* x_ft;           // optional: the new state again as fp32 FT [Bpad][Dpad] (start of the fused sampler fast path)
     const float* sigmas;
     const float* obs;      // completion: observation [B][D] or null
     const float* mask;     // completion: mask [B][D]
@@ -106,6 +100,8 @@ struct EmUpdateArgs {      // EulerMaruyamaPredictor.update_fn + imputation (sam
     uint32_t step;
 };
 hipError_t launch_em_update(const EmUpdateArgs& a, hipStream_t st);
+// fp32 FT [Bpad][Dpad] -> row-major [B][D] (end of the fused sampler fast path); any of the two pairs may be null
+hipError_t launch_ft_to_rows(const float* a_ft, float* a, const float* b_ft, float* b, int64_t B, int64_t Bpad, int D, int Dpad, hipStream_t st);
 
 struct DenoiseArgs {       // one_step_denoise + prior loss (run/completion.py:105-149, run/smplify.py:69-107)
     const float* res;      // [Bpad][Cp]

@@ -226,6 +226,7 @@ struct Ws {
     int64_t Bpad;
     char *xin, *emb, *temb, *upre, *hbuf[MAX_L], *xhat[MAX_L], *dy[MAX_L], *carry[2], *dU, *dres;
     float *rstd[MAX_L], *res, *xt, *tbuf, *zbuf, *loss_part, *scalar;
+    float *xft, *xmft;        // sampler fast path: state and last x_mean as fp32 FT [Bpad][Dpad]
     // shared-t time table
     int64_t npad;
     float *tt_labels, *tt_emb, *tt_temb, *table;
@@ -270,6 +271,8 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
     } else if (mode == DPOSER_WS_SHARED_T) {
         for (int i = 0; i < 3; ++i) w.hbuf[i] = take(Bpad * H * esz);
         w.xt = (float*)take(Bpad * h->Dpad * 4);
+        w.xft = (float*)take(Bpad * h->Dpad * 4);
+        w.xmft = (float*)take(Bpad * h->Dpad * 4);
         w.npad = round_up(n_steps < 1 ? 1 : n_steps, 32);
         w.tt_labels = (float*)take(w.npad * 4);
         w.tt_emb = (float*)take(w.npad * E * 4);
@@ -497,6 +500,20 @@ static int build_time_table(dposer_scorefc_s* h, const float* flat, const char* 
     return DPOSER_OK;
 }
 
+// the GroupNorm layers of one shared-t network evaluation (bias rows from table row `row`); returns the last activation
+static int run_shared_t_layers(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t row, hipStream_t st, const void** last) {
+    const void* in = w.xin;
+    const float* trow = w.table + row * (int64_t)h->L * h->H;
+    for (int l = 0; l < h->L; ++l) {
+        void* o = w.hbuf[l % 3];
+        const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[(l - 2) % 3] : nullptr;
+        DP_TRY(run_gn_layer(h, flat, packed, l, in, nullptr, trow + (int64_t)l * h->H, o, resid, nullptr, nullptr, false, w.Bpad, 0, 0, st));
+        in = o;
+    }
+    *last = in;
+    return DPOSER_OK;
+}
+
 // one shared-t network evaluation: xin -> res, bias rows from table row `row`
 static int run_shared_t(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t row, int64_t B, hipStream_t st) {
     const void* in = w.xin;
@@ -557,7 +574,31 @@ extern "C" int dposer_em_sampler(dposer_scorefc_t h, const float* flat, const vo
     ea.res = nullptr; ea.t = timesteps_host[start_step]; ea.t_next = timesteps_host[start_step];
     ea.step = (uint32_t)(start_step - 1);
     ea.z_impA = (noise && observation) ? noise : nullptr;
+    // Fast path (plain generation: no observation, in-kernel noise, no trajectory): the state stays in HBM as fp32 FT and
+    // post_dense + the Euler-Maruyama update are ONE GEMM launch per step (EpiEmStep) -- no `res` round trip, no update kernel.
+    const bool fused = !observation && !noise && !traj && h->Cp == h->Dpad;
+    if (fused) ea.x_ft = w.xft;
     DP_HIP_LAUNCH(launch_em_update(ea, st));
+    if (fused) {
+        const int shape = final_shape(w.Bpad);
+        for (int i = 0; i < n_run; ++i) {
+            const int gi = start_step + i;
+            const void* last = nullptr;
+            DP_TRY(run_shared_t_layers(h, flat, packed, w, i, st, &last));
+            g_next_flops = 2.0 * (double)B * h->D * h->H;
+            GemmArgs g = gemm_args(packed + h->pk_wpost, h->H / h->KBS, h->Cp / (shape_ct(shape) * 32), (int)(w.Bpad / (shape_st(shape) * 32)));
+            add_seg(g, last, h->H / h->KBS);
+            EmStepParams p;
+            std::memset(&p, 0, sizeof(p));
+            p.bias = flat + h->off_post_b; p.x_ft = w.xft; p.x_mean_ft = (i + 1 == n_run) ? w.xmft : nullptr; p.xin = w.xin;
+            p.sigmas = sigmas; p.sde = make_sde_dev(sc); p.t = timesteps_host[gi]; p.num_scales = h->d.num_scales;
+            p.scale_by_sigma = h->d.scale_by_sigma; p.D = h->D; p.Cp = h->Cp; p.QD = (h->D + 3) >> 2; p.S_valid = B;
+            p.seed = seed; p.step = (uint32_t)gi;
+            DP_HIP_LAUNCH(gemm_em_step(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
+        }
+        DP_HIP_LAUNCH(launch_ft_to_rows(w.xft, x, w.xmft, x_mean, B, w.Bpad, h->D, h->Dpad, st));
+        return DPOSER_OK;
+    }
     for (int i = 0; i < n_run; ++i) {
         const int gi = start_step + i;
         DP_TRY(run_shared_t(h, flat, packed, w, i, B, st));

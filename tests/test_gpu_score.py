@@ -172,6 +172,26 @@ def test_em_sampler_inkernel_philox_matches_oracle():
     assert not torch.equal(trajs, trajs3)
 
 
+@pytest.mark.parametrize("B,prec,tol", [(40, "fp32", 1e-4), (300, "fp32", 1e-4), (1000, "bf16", 6e-2)])
+def test_em_sampler_fused_step_path_matches_oracle(B, prec, tol):
+    """traj_stride = 0 (no trajectory), no observation, in-kernel noise: post_dense and the Euler-Maruyama update run as one
+    GEMM launch per step on an FT-resident state.  Must agree with the oracle fed the same Philox draws, return x_mean of the
+    last step (noise_removal), and be bit-identical to the unfused path (same arithmetic, same counters) in fp32."""
+    cfg, m, p = make_model(21, precision=prec)
+    N, seed = 6, 4242
+    sde, fn = _sampler(m, cfg, N, B)
+    z0 = np.random.RandomState(B).standard_normal((B, 63)).astype(np.float32)
+    trajs, x = fn(m, z=_dev(z0), seed=seed, traj_stride=0)
+    assert trajs.shape[0] == 0 and x.shape == (B, 63)
+    noises = [torch.tensor(PH.normal_matrix(B, 63, PH.STREAM_EM_NOISE, i, seed)) for i in range(N)]
+    ref_trajs, ref_x = R.pc_sampler(p, R.SubVP(N=N), torch.tensor(z0), noises)
+    assert rel_err(t2n(x), ref_x.numpy()) < tol
+    trajs_u, x_u = fn(m, z=_dev(z0), seed=seed, traj_stride=1)                # unfused path keeps the trajectory
+    if prec == "fp32":
+        assert rel_err(t2n(x), t2n(x_u)) < 2e-6
+    assert rel_err(t2n(trajs_u[-1]), ref_trajs[-1].numpy()) < tol
+
+
 def test_inkernel_noise_statistics():
     cfg, m, p = make_model(22, precision="bf16")
     sde, fn = _sampler(m, cfg, 2, 8192)
