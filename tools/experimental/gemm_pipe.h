@@ -5,7 +5,8 @@
 // Status (round 1, B = 65536, K = 1024, one MI355X): results agree with the shipped kernel (3 of 6.7e7 outputs differ by one
 // bf16 ulp), hipcc does emit the requested "1 MFMA : N VALU" interleave once the epilogue is branch-free, but it is SLOWER
 // than the shipped kernels: plain 141 us (shipped 256x256 / 8 waves: 121), GroupNorm forward 168 us (145), GroupNorm forward
-// training 256 us (183).  With one wave per SIMD every s_waitcnt of the interleaved epilogue (LDS parameter reads, the
+// training 256 us (183) with 4-wave workgroups; with 8-wave workgroups of 2x2 wave tiles (two waves per SIMD, 256 registers each)
+// plain 136 us, GroupNorm forward 152 us, training 229 us.  With one wave per SIMD every s_waitcnt of the interleaved epilogue (LDS parameter reads, the
 // lane^32 exchange, global loads) also stalls that wave's MFMA issue, and the 1-wave main loop is 17 % slower to begin with.
 // Kept as the starting point for a hand-scheduled version (explicit prefetch of epilogue operands one stage ahead,
 // v_permlane32_swap instead of LDS shuffles).

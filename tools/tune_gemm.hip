@@ -175,10 +175,14 @@ int main(int argc, char** argv) {
         GN(2, 4, 4, 2, 4, 1);
         GNP(2, 2, 4, 2, 4);
         GNP(1, 4, 4, 2, 4);
+        GNP(4, 2, 2, 2, 4);
+        GNP(2, 4, 2, 2, 4);
         GNT(2, 4, 4, 2, 4, 1);
         GNPT(2, 2, 4, 2, 4);
+        GNPT(4, 2, 2, 2, 4);
         PL(2, 4, 4, 2, 4, 1);
         PLP(2, 2, 4, 2, 4);
+        PLP(4, 2, 2, 2, 4);
         run_all(7, 10);
         return 0;
     }
