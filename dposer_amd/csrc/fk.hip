@@ -200,14 +200,27 @@ struct FkArgs {
     int64_t B;
 };
 
+// does joint I have a child among the joints [0, NOUT)?  (compile-time walk of the parents table)
+template <typename Kin> constexpr bool fk_has_child_below(int I, int NOUT) {
+    for (int c = I + 1; c < NOUT && c < Kin::J; ++c)
+        if (Kin::P[c] == I) return true;
+    return false;
+}
+
 // One joint of the chain, with the joint index (and therefore its parent) a compile-time constant
 // so that the per-lane transforms G[] stay in registers.
-template <typename Kin, int I>
+// NOUT > 0: "joints only" specialisation (n_out == NOUT, no pose feature, no skinning transforms): everything optional is
+// compiled out and a joint without a child below NOUT needs no rotation at all -- its position is parent * rest offset
+// (5 of the 22 body joints of SMPL-X: feet, head, wrists).
+template <typename Kin, int I, int NOUT>
 __device__ __forceinline__ void fk_step(Xf (&G)[Kin::J], const float* pose, const float* jr, float* row, const float (&tr)[3],
                                         const FkArgs& a, int64_t b, int n_out) {
-    if (I >= n_out) return;
+    constexpr bool LEAN = NOUT > 0;
+    if (LEAN ? I >= NOUT : I >= n_out) return;
     constexpr int PI = Kin::P[I] < 0 ? 0 : Kin::P[I];
-    const Mat3 R = rodrigues(pose[3 * I], pose[3 * I + 1], pose[3 * I + 2]);
+    constexpr bool NEED_R = !LEAN || fk_has_child_below<Kin>(I, NOUT);
+    Mat3 R;
+    if constexpr (NEED_R) R = rodrigues(pose[3 * I], pose[3 * I + 1], pose[3 * I + 2]);
     float rel[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) rel[k] = jr[3 * I + k] - (I > 0 ? jr[3 * PI + k] : 0.f);
@@ -221,15 +234,18 @@ __device__ __forceinline__ void fk_step(Xf (&G)[Kin::J], const float* pose, cons
         // G_i = G_parent @ [R rel; 0 1]
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
+            if constexpr (NEED_R) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                G[I].r[3 * r + c] = fmaf(Pm.r[3 * r], R.m[c], fmaf(Pm.r[3 * r + 1], R.m[3 + c], Pm.r[3 * r + 2] * R.m[6 + c]));
+                for (int c = 0; c < 3; ++c)
+                    G[I].r[3 * r + c] = fmaf(Pm.r[3 * r], R.m[c], fmaf(Pm.r[3 * r + 1], R.m[3 + c], Pm.r[3 * r + 2] * R.m[6 + c]));
+            }
             G[I].t[r] = fmaf(Pm.r[3 * r], rel[0], fmaf(Pm.r[3 * r + 1], rel[1], fmaf(Pm.r[3 * r + 2], rel[2], Pm.t[r])));
         }
     }
     // posed joint (+ transl) overwrites the (already consumed) axis-angle of joint I in the lane's LDS row
 #pragma unroll
     for (int k = 0; k < 3; ++k) row[3 * I + k] = G[I].t[k] + tr[k];
+    if constexpr (LEAN) return;
     if (a.pf && I > 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k)
@@ -248,16 +264,16 @@ __device__ __forceinline__ void fk_step(Xf (&G)[Kin::J], const float* pose, cons
         }
     }
 }
-template <typename Kin, int... Is>
+template <typename Kin, int NOUT, int... Is>
 __device__ __forceinline__ void fk_chain(std::integer_sequence<int, Is...>, Xf (&G)[Kin::J], const float* pose, const float* jr, float* row,
                                          const float (&tr)[3], const FkArgs& a, int64_t b, int n_out) {
-    (fk_step<Kin, Is>(G, pose, jr, row, tr, a, b, n_out), ...);
+    (fk_step<Kin, Is, NOUT>(G, pose, jr, row, tr, a, b, n_out), ...);
 }
 
 // One lane = one pose.  NT lanes per block; pose rows and outputs are staged through LDS.
 // LDS row of a pose = 3*n_out floats (+1 pad to make the stride odd => conflict-free per-lane rows): only the
 // joints that are actually evaluated are staged, so a 22-joint body query needs 17 KiB per 64 poses, not 42.
-template <typename Kin, int NT> __global__ void __launch_bounds__(NT) k_fk_joints(FkArgs a) {
+template <typename Kin, int NT, int NOUT = 0> __global__ void __launch_bounds__(NT) k_fk_joints(FkArgs a) {
     constexpr int J = Kin::J;
     extern __shared__ float lds[];
     const int64_t item0 = (int64_t)blockIdx.x * NT;
@@ -323,7 +339,7 @@ template <typename Kin, int NT> __global__ void __launch_bounds__(NT) k_fk_joint
     float tr[3] = {0.f, 0.f, 0.f};
     if (a.transl && b < a.B) { tr[0] = a.transl[b * 3]; tr[1] = a.transl[b * 3 + 1]; tr[2] = a.transl[b * 3 + 2]; }
     Xf G[J];
-    fk_chain<Kin>(std::make_integer_sequence<int, J>{}, G, row, jr, row, tr, a, b, n_out);
+    fk_chain<Kin, NOUT>(std::make_integer_sequence<int, J>{}, G, row, jr, row, tr, a, b, n_out);
     __syncthreads();
     // ---- posed joints: LDS rows (stride ROW) -> coalesced global stream ----
     {
@@ -395,7 +411,10 @@ template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t
     constexpr int NT = 64;
 #endif
     const int lds_floats = NT * ((a.n_out * 3) | 1);
-    hipLaunchKernelGGL((k_fk_joints<Kin, NT>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
+    if (a.n_out == 22 && Kin::J >= 22 && !a.pf && !a.rel)       // joints-only body query (the hot case): lean specialisation
+        hipLaunchKernelGGL((k_fk_joints<Kin, NT, 22>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
+    else
+        hipLaunchKernelGGL((k_fk_joints<Kin, NT>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
     return hipGetLastError();
 }
 
