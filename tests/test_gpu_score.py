@@ -473,3 +473,26 @@ def test_checkpoint_round_trip_in_reference_format(tmp_path):
         assert torch.equal(state3["optimizer"]._flat_m[o:o + q.numel()], st["exp_avg"].reshape(-1))
         assert torch.equal(state3["optimizer"]._flat_v[o:o + q.numel()], st["exp_avg_sq"].reshape(-1))
     assert state3["optimizer"]._step_count == 1
+
+
+def test_integration_md_ctypes_stub_runs():
+    """INTEGRATION.md section 3 shows the ctypes stub a reference maintainer would write against include/dposer_hip.h; the
+    snippet is executed as written and must reproduce the module's forward."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes as C, math, torch\n.*?)```", src, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                      # the snippet loads "dposer_amd/libdposer_hip.so" relative to the checkout
+    try:
+        exec(code, ns)
+        cfg, m, p = make_model(5, precision="bf16")
+        x = torch.randn(100, 63, device=DEV)
+        labels = torch.rand(100, device=DEV) * 999
+        out = ns["scorefc_forward"](m, x, labels)
+    finally:
+        os.chdir(cwd)
+    with torch.no_grad():
+        assert torch.equal(out, m(x, labels))
