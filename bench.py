@@ -11,7 +11,7 @@ Adam + EMA.  The global batch is fixed as N grows ("B = 65536 @ 1/2/4/8 GPU") =>
 Rank 0 prints ONE JSON line; besides the contract's keys it carries
   roofline      -- live HIP-event timing of the dominant MFMA GEMM kernel over the timed region
   cpu_baseline  -- the CPU oracle (oracle/score_ref.py, torch-CPU port of the reference path) on the host cores
-  extra         -- M2 (1000-step sub-VP sampling, samples/s) and M3 (SMPL-X FK joints, poses/s) of this run.
+  extra         -- M2 (1000-step sub-VP sampling, samples/s), M3 (SMPL-X FK joints, poses/s) and full LBS (vertices) of this run.
 """
 import argparse
 import json
@@ -220,6 +220,30 @@ def main():
         fk_s = e0.elapsed_time(e1) * 1e-3 / 20
         extra["fk_joints"] = {"poses_per_s_per_gpu": nfk / fk_s, "batch": nfk, "algorithmic_GBps": 516.0 * nfk / fk_s / 1e9,
                               "frac_of_hbm_peak": 516.0 * nfk / fk_s / 1e9 / HBM_PEAK_GBS}
+        # ---- M3b: full linear blend skinning ([B,63] -> 10475 vertices + 127 joints), forward and forward+backward ----
+        nl = 4096
+        pb = pose[:nl].clone().requires_grad_(True)
+
+        def lbs_fwd_bwd(grad):
+            if grad:
+                out = bm(pose_body=pb)
+                (out.v.sum() + out.Jtr.sum()).backward()
+                pb.grad = None
+            else:
+                with torch.no_grad():
+                    bm(pose_body=pb)
+
+        for grad in (False, True):
+            for _ in range(2):
+                lbs_fwd_bwd(grad)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                lbs_fwd_bwd(grad)
+            e1.record()
+            torch.cuda.synchronize()
+            sec = e0.elapsed_time(e1) * 1e-3 / 5
+            extra["lbs_full_fwd_bwd" if grad else "lbs_full_fwd"] = {"poses_per_s_per_gpu": nl / sec, "batch": nl, "ms": sec * 1e3}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -12,3 +12,6 @@ for f in sys.argv[1:]:
         print("   sampler", ex["sampler"]["seconds"], "s", ex["sampler"]["dominant_kernel"])
     if "fk_joints" in ex:
         print("   fk", ex["fk_joints"])
+    for k in ("lbs_full_fwd", "lbs_full_fwd_bwd"):
+        if k in ex:
+            print("   " + k, ex[k])
