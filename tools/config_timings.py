@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Wall-clock of BASELINE.json's non-headline configurations on ONE MI355X (synthetic data, random-init weights):
+  cfg2  train step at batch 8192                      cfg3  1000-step EM sampling of 500 poses
+  cfg4  pose completion, one rank's share: batch 16384, `--part legs`, 2 x 100 optimisation steps per hypothesis
+  cfg5  motion denoising of one 60-frame sequence: 5 x 50 optimisation steps (SMPL-X LBS forward + backward + prior)
+Prints a markdown table (committed as profiles/rNN_configs.md).  Parity of each loop is covered by tests/test_gpu_tasks.py."""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(fn, warm=1, reps=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    from dposer_amd.algorithms.advanced import losses, sampling, sde_lib
+    from dposer_amd.algorithms.advanced.model import ScoreModelFC
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    from dposer_amd.configs import load_config
+    from dposer_amd.dataset.AMASS import Posenormalizer
+    from dposer_amd.tasks.completion import DPoserComp
+    from dposer_amd.tasks.motion_denoising import MotionDenoise
+    from dposer_amd.utils.misc import create_mask
+    dev = "cuda:0"
+    cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+    torch.manual_seed(42)
+    model = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=1024, embed_dim=512, n_blocks=2).to(dev)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g10_normalizer.npz"))
+    toy = torch.tensor(g["toy_pose_samples"])
+    stats = {k: torch.tensor(g[f"stats/axis_normalize{n}/{k}"]) for n, ks in ((1, ("min_poses", "max_poses")), (2, ("mean_poses", "std_poses")))
+             for k in ks}
+    norm = Posenormalizer(stats, device=dev, normalize=True, min_max=False, rot_rep="axis")
+    rows = []
+
+    # cfg2: training step, batch 8192
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    state = dict(model=model, optimizer=losses.get_optimizer(cfg, model.parameters()),
+                 ema=ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate), step=0)
+    step_fn = losses.get_step_fn(sde, True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+    batch = norm.offline_normalize(toy[torch.randint(0, 500, (8192,))].to(dev))
+    s = timed(lambda: [step_fn(state, batch) for _ in range(20)], warm=1) / 20
+    rows.append(("cfg2", "train step, batch 8192 (axis-angle)", f"{s * 1e3:.3f} ms / step", f"{8192 / s:,.0f} poses/s"))
+
+    # cfg3: 500 samples, 1000-step EM sampler
+    model.eval()
+    fn = sampling.get_sampling_fn(cfg, sde, (500, 63), lambda v: v, 1e-3, device=dev)
+    s = timed(lambda: fn(model, traj_stride=0), warm=1)
+    rows.append(("cfg3", "1000-step EM sampling, 500 poses", f"{s:.3f} s", f"{500 / s:,.0f} samples/s"))
+
+    # cfg4: completion, batch 16384, legs masked, 2 x 100 steps (one hypothesis)
+    poses = norm.offline_normalize(toy[torch.randint(0, 500, (16384,))].to(dev))
+    mask, obs = create_mask(poses, part="legs")
+    comp = DPoserComp(model, sde, continuous=True, batch_size=16384)
+    s = timed(lambda: comp.optimize(obs, mask, iterations=2, steps_per_iter=100), warm=1)
+    rows.append(("cfg4", "completion (legs), batch 16384, 200 optimisation steps", f"{s:.3f} s / hypothesis", f"{16384 / s:,.0f} poses/s/hypothesis"))
+
+    # cfg5: motion denoising, one 60-frame sequence, 5 x 50 steps
+    bm = BodyModel(make_synthetic_smplx_asset(seed=0), batch_size=60).to(dev)
+    args = types.SimpleNamespace(device=dev, dataset_folder="", version="", task="denoise")
+    md = MotionDenoise(cfg, args, model, bm, sde_N=1000, batch_size=60, normalizer=norm)
+    gt = toy[:60].to(dev)
+    with torch.no_grad():
+        joints = bm(pose_body=gt, betas=md.betas).Jtr[:, :22] + 0.04 * torch.randn(60, 22, 3, device=dev)
+    s = timed(lambda: md.optimize(joints, gt_poses=gt, iterations=5, steps_per_iter=50), warm=1)
+    rows.append(("cfg5", "motion denoising, 60 frames, 250 optimisation steps (LBS fwd+bwd + prior)", f"{s:.3f} s / sequence", f"{s / 250 * 1e3:.2f} ms / step"))
+
+    print("| config | workload | time | rate |")
+    print("|---|---|---:|---:|")
+    for r in rows:
+        print("| " + " | ".join(r) + " |")
+
+
+if __name__ == "__main__":
+    main()
