@@ -240,16 +240,20 @@ struct WgradPlan {
     int shape, ksplit;
     int64_t slab_off;   // element offset inside Ws::slabs
 };
-static int wgrad_shape(int n_rows_pad, int k_rows_pad) {
+// Tiling of a split-K wgrad GEMM over Spad samples.  256x256 tiles (one workgroup per CU, k-split sized for 256 resident
+// workgroups) win from 32768 samples up (93 vs 109 us per 1024x1024 wgrad at 65536; measured slower at 16384 and below, where
+// the per-split k-range gets too short).  DPOSER_WGRAD_BIG = 0 / 1 forces the choice.
+static int wgrad_shape(int n_rows_pad, int k_rows_pad, int64_t Spad) {
     if (n_rows_pad < 128) return SHAPE_FINAL;
     if (k_rows_pad < 128) return SHAPE_WIDE64;
-    const char* e = getenv("DPOSER_WGRAD_BIG");
-    if (e && e[0] == '1' && n_rows_pad % 256 == 0 && k_rows_pad % 256 == 0) return SHAPE_BIG;
+    static const int forced = [] { const char* e = getenv("DPOSER_WGRAD_BIG"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
+    const bool big = forced >= 0 ? forced == 1 : Spad >= 32768;
+    if (big && n_rows_pad % 256 == 0 && k_rows_pad % 256 == 0) return SHAPE_BIG;
     return SHAPE_MID;
 }
-static int pick_ksplit(int64_t tiles, int64_t stages) {
+static int pick_ksplit(int64_t tiles, int64_t stages, int slots = 512) {
     int ks = 1;
-    while (ks < 32 && tiles * ks < 512 && stages % (ks * 2) == 0 && stages / (ks * 2) >= 4) ks *= 2;
+    while (ks < 32 && tiles * ks < slots && stages % (ks * 2) == 0 && stages / (ks * 2) >= 4) ks *= 2;
     return ks;
 }
 
@@ -309,9 +313,9 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         const int64_t stages = Bpad / (h->KBS * 4);
         int64_t slab_elems = 0;
         auto acc = [&](int n_rows_pad, int k_rows_pad, int64_t numel) {
-            const int shape = wgrad_shape(n_rows_pad, k_rows_pad);
+            const int shape = wgrad_shape(n_rows_pad, k_rows_pad, Bpad);
             const int64_t tiles = (int64_t)(n_rows_pad / (shape_ct(shape) * 32)) * (k_rows_pad / (shape_st(shape) * 32));
-            slab_elems += (int64_t)pick_ksplit(tiles, stages) * numel;
+            slab_elems += (int64_t)pick_ksplit(tiles, stages, shape == SHAPE_BIG ? 256 : 512) * numel;
         };
         for (int l = 0; l < L; ++l) {
             acc(H, h->layer[l].kin_pad, (int64_t)H * h->layer[l].kin);
@@ -651,12 +655,12 @@ extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const vo
 // ------------------------------------------------------------------------------------------------
 static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n_valid, const void* inT, int k_rows_pad, int k_valid,
                      int64_t Bpad, float* slabs, int64_t& slab_cursor, int64_t numel, int64_t flat_off, ReduceJobs& rj, hipStream_t st) {
-    const int shape = wgrad_shape(n_rows_pad, k_rows_pad);
+    const int shape = wgrad_shape(n_rows_pad, k_rows_pad, Bpad);
     const int ct = shape_ct(shape), stt = shape_st(shape);
     const int kb_total = (int)(Bpad / h->KBS);
     const int64_t stages = kb_total / 4;
     const int n_cblk = n_rows_pad / (ct * 32), n_sblk = k_rows_pad / (stt * 32);
-    const int ks = pick_ksplit((int64_t)n_cblk * n_sblk, stages);
+    const int ks = pick_ksplit((int64_t)n_cblk * n_sblk, stages, shape == SHAPE_BIG ? 256 : 512);   // resident workgroups of the tiling
     g_next_flops = 2.0 * (double)g_alg_batch * n_valid * k_valid;
     GemmArgs g = gemm_args(dyT, kb_total, n_cblk, n_sblk);
     add_seg(g, inT, kb_total);
