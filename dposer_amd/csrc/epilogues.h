@@ -44,6 +44,16 @@ __device__ __forceinline__ void epi_for_each_sub(const P& pp, C& carry, f32x16 (
     }
 }
 
+// One Philox call = the 8 decisions of quads 2m and 2m+1 (same numbers as dropout_mask16, for register-lean callers).
+__device__ __forceinline__ void dropout_mask8(const DropoutCfg& d, int64_t s, int g, int hi, int m, float keep[8]) {
+    Philox4 r = philox_at((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        keep[2 * w] = ((r.v[w] & 0xffffu) < d.thr) ? d.scale : 0.f;
+        keep[2 * w + 1] = ((r.v[w] >> 16) < d.thr) ? d.scale : 0.f;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // forward:  out = [resid +] Drop(SiLU(GroupNorm32(acc + bias)))         model.py:166-187
 // ----------------------------------------------------------------------------------------------
@@ -382,15 +392,8 @@ template <typename T> struct EpiGNBwd {
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc) {
             const int c0 = cbase + tc * 32;
-            float gam[16], bet[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cl = tc * 32 + 8 * q + 4 * hi;
-                f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + cl);
-                f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { gam[4 * q + r] = g4[r]; bet[4 * q + r] = e4[r]; }
-            }
+            // (gamma / beta are re-read from their LDS copy quad by quad and the dropout decisions are drawn per 8 channels:
+            //  holding 16 + 16 + 16 of them would push the 256x256 tile past 256 VGPRs)
             float stat[32];   // [0..15] dgamma, [16..31] dbeta (this lane's 16 channels)
             float dbias[16];
 #pragma unroll
@@ -402,8 +405,6 @@ template <typename T> struct EpiGNBwd {
                 const int64_t s = sbase + ts * 32 + j;
                 const bool valid = s < p.S_valid;
                 const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.H);
-                float keep[16];
-                if (p.drop.p > 0.f) dropout_mask16(p.drop, s, c0 >> 5, hi, keep);
                 const float rstd = p.rstd[s * (p.H >> 5) + (c0 >> 5)];
                 float xh[16], g[16];
                 TileIO<T>::load(p.xhat + tb, lane, xh);
@@ -417,16 +418,25 @@ template <typename T> struct EpiGNBwd {
                 }
                 if (p.carry_out) TileIO<T>::store(p.carry_out + tb, lane, g);
                 float s1 = 0.f, s2 = 0.f;
+                float keep[8];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float gg = valid ? g[i] : 0.f;
-                    if (p.drop.p > 0.f) gg *= keep[i];
-                    const float da = gg * dsilu_f<PRECISE>(gam[i] * xh[i] + bet[i]);
-                    stat[i] += da * xh[i];
-                    stat[16 + i] += da;
-                    g[i] = da * gam[i];                 // dx
-                    s1 += g[i];
-                    s2 += g[i] * xh[i];
+                for (int q = 0; q < 4; ++q) {
+                    if ((q & 1) == 0 && p.drop.p > 0.f) dropout_mask8(p.drop, s, c0 >> 5, hi, q >> 1, keep);
+                    const int cl = tc * 32 + 8 * q + 4 * hi;
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + cl);
+                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * q + r;
+                        float gg = valid ? g[i] : 0.f;
+                        if (p.drop.p > 0.f) gg *= keep[4 * (q & 1) + r];
+                        const float da = gg * dsilu_f<PRECISE>(g4[r] * xh[i] + e4[r]);
+                        stat[i] += da * xh[i];
+                        stat[16 + i] += da;
+                        g[i] = da * g4[r];                 // dx
+                        s1 += g[i];
+                        s2 += g[i] * xh[i];
+                    }
                 }
                 s1 += __shfl_xor(s1, 32);
                 s2 += __shfl_xor(s2, 32);

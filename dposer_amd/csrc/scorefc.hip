@@ -212,9 +212,14 @@ static int main_shape(int64_t Spad) {
     if (Spad % 128 == 0) return SHAPE_MID;
     return SHAPE_SMALL;
 }
-// The GroupNorm-backward epilogue needs ~210 VGPRs next to a 128x128 tile's accumulators; on the 256x256 tile it spills
-// (measured slower), so that tiling is not instantiated for it.
-static int gnbwd_shape(int64_t Spad) { return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL; }
+// GroupNorm-backward dgrad: the register-lean epilogue fits the 256x256 tile in 248 VGPRs without spilling; it wins from
+// 32768 samples up (227 vs 257 us at 65536, 2.52 vs 2.59 ms per step at 32768, a tie at 16384).  DPOSER_GNBWD_BIG = 0 / 1 forces it.
+static int gnbwd_shape(int64_t Spad) {
+    static const int forced = [] { const char* e = getenv("DPOSER_GNBWD_BIG"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
+    const bool big = forced >= 0 ? forced == 1 : Spad >= 32768;
+    if (big && Spad % 256 == 0) return SHAPE_BIG;
+    return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL;
+}
 // post_dense / dx: one 64-channel block tile, so the grid is Spad/128 (or Spad/32) workgroups: below 32768 samples the
 // 64x128 tiling leaves most CUs idle and the 64x32 one is used.
 static int final_shape(int64_t Spad) {
