@@ -16,4 +16,6 @@ cd $R
 python3 tools/rocpd_summary.py $(find gpurun_out/prof_$TAG -name "*.db" | head -1) > gpurun_out/${TAG}_bench_kernel_stats.md
 python3 tools/rocpd_summary.py --pmc $(find gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr -name "*.db") > gpurun_out/${TAG}_pmc_hbm_traffic.md
 python3 tools/rocpd_summary.py --pmc-json $(find gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr -name "*.db") > gpurun_out/${TAG}_pmc_hbm_traffic.json
+# the raw rocpd databases can exceed what gpurun copies back (64 MiB): keep the summaries only
+rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr
 head -30 gpurun_out/${TAG}_bench_kernel_stats.md; head -24 gpurun_out/${TAG}_pmc_hbm_traffic.md; cat gpurun_out/${TAG}_bench_default.json
