@@ -649,34 +649,50 @@ struct SkinBwdArgs {
     int Cpad;
 };
 __global__ void __launch_bounds__(256) k_skin_bwd(SkinBwdArgs a) {
-    extern __shared__ float sA[];
+    extern __shared__ float sA[];       // [J][12] transforms of this pose, then [768] staging of the block's d_off values
+    float* stage = sA + a.J * 12;
     const int64_t b = blockIdx.y;
     for (int i = threadIdx.x; i < a.J * 12; i += 256) sA[i] = a.A[b * a.J * 12 + i];
     __syncthreads();
-    for (int v = blockIdx.x * 256 + threadIdx.x; v < a.V; v += gridDim.x * 256) {
-        const float* vs = a.v_shaped + (a.v_shaped_batched ? b * a.V * 3 : 0) + (int64_t)v * 3;
-        const float* off = a.offsets + b * a.ld_off + (int64_t)v * 3;
-        const float* dv = a.dverts + (b * a.V + v) * 3;
-        float T[9];
+    for (int v0 = blockIdx.x * 256; v0 < a.V; v0 += gridDim.x * 256) {
+        const int v = v0 + threadIdx.x;
+        float g[3] = {0.f, 0.f, 0.f};
+        if (v < a.V) {
+            const float* vs = a.v_shaped + (a.v_shaped_batched ? b * a.V * 3 : 0) + (int64_t)v * 3;
+            const float* off = a.offsets + b * a.ld_off + (int64_t)v * 3;
+            const float* dv = a.dverts + (b * a.V + v) * 3;
+            float T[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) T[i] = 0.f;
-        for (int k = 0; k < a.K; ++k) {
-            const float w = a.skin_w[(int64_t)v * a.K + k];
-            const float* Aj = sA + a.skin_idx[(int64_t)v * a.K + k] * 12;
+            for (int i = 0; i < 9; ++i) T[i] = 0.f;
+            for (int k = 0; k < a.K; ++k) {
+                const float w = a.skin_w[(int64_t)v * a.K + k];
+                const float* Aj = sA + a.skin_idx[(int64_t)v * a.K + k] * 12;
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+                for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) T[3 * r + c] += w * Aj[4 * r + c];
+                    for (int c = 0; c < 3; ++c) T[3 * r + c] += w * Aj[4 * r + c];
+            }
+            const float dx = dv[0], dy = dv[1], dz = dv[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] = T[c] * dx + T[3 + c] * dy + T[6 + c] * dz;     // T_R^T dv
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a.vp[(b * a.V + v) * 3 + c] = vs[c] + off[c];
+                a.dvp[(b * a.V + v) * 3 + c] = g[c];
+            }
         }
-        const float dx = dv[0], dy = dv[1], dz = dv[2];
-        float g[3];
+        // the GEMM operand copy (FT32 [Bpad][Cpad]) is written as whole 16-byte quads: stage the block's 768 consecutive
+        // coordinates in LDS, then one thread per quad (4-byte stores into that layout cost 3x the HBM write traffic)
+        __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 3; ++c) g[c] = T[c] * dx + T[3 + c] * dy + T[6 + c] * dz;     // T_R^T dv
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            a.vp[(b * a.V + v) * 3 + c] = vs[c] + off[c];
-            a.dvp[(b * a.V + v) * 3 + c] = g[c];
-            a.doff_ft[FT<float>::index(b, v * 3 + c, a.Cpad)] = g[c];
+        for (int c = 0; c < 3; ++c) stage[threadIdx.x * 3 + c] = g[c];
+        __syncthreads();
+        if (threadIdx.x < 192) {
+            const int kq = v0 * 3 + threadIdx.x * 4;                                         // first coordinate of this quad
+            if (kq < a.Cpad) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(stage + threadIdx.x * 4);
+                *reinterpret_cast<f32x4*>(a.doff_ft + FT<float>::index(b, kq, a.Cpad)) = q;
+            }
         }
     }
 }
@@ -741,103 +757,153 @@ struct FkBwdArgs {
     int J;
     int64_t B;
 };
-__device__ __forceinline__ int fk_seg_of(const FkBwdArgs& a, int joint, int& local) {
-    int s = 0;
+// Reverse walk of the kinematic chain, one lane per pose, joint index (and parent) compile-time constants so that the
+// running gradients acc[joint][12] (d loss / d global transform, accumulated from the children) and the rest-joint
+// gradients stay in REGISTERS: only the few joints between a leaf and its first processed ancestor are live at any time.
+// (A first version kept them in a global scratch and paid a store -> load round trip per joint: 2 ms per call at any batch.)
+template <typename Kin, int I>
+__device__ __forceinline__ void fk_bwd_step(const FkBwdArgs& a, int64_t b, const float* jr, const float* A, float (&acc)[Kin::J][12],
+                                            float (&djr)[Kin::J][3]) {
+    constexpr int J = Kin::J;
+    constexpr int P = Kin::P[I] < 0 ? 0 : Kin::P[I];
+    // segment of joint I and its pointers through unrolled selects (indexing the kernel-argument arrays with a runtime value
+    // would spill the whole argument struct to scratch)
+    int li = I;
+    const float* pose = a.seg[0];
+    float* dq = a.dseg[0];
+    int seg_nj = a.seg_joints[0];
 #pragma unroll
     for (int k = 1; k < FK_MAX_SEG; ++k)
-        if (k < a.nseg && joint >= a.seg_first[k]) s = k;
-    local = joint - a.seg_first[s];
-    return s;
+        if (k < a.nseg && I >= a.seg_first[k]) { li = I - a.seg_first[k]; pose = a.seg[k]; dq = a.dseg[k]; seg_nj = a.seg_joints[k]; }
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (pose) { const float* q = pose + (b * seg_nj + li) * 3; rx = q[0]; ry = q[1]; rz = q[2]; }
+    // dG_I = (children's contributions) + (own terms):  A_I = [R | t - R J_I],  joints_I = t
+    const float* dAi = a.dA + (b * J + I) * 12;
+    const float J3[3] = {jr[3 * I], jr[3 * I + 1], jr[3 * I + 2]};
+    float dRG[9], dt[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const float dat = dAi[4 * r + 3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dRG[3 * r + c] = acc[I][4 * r + c] + (dAi[4 * r + c] - dat * J3[c]);
+            djr[I][c] -= A[I * 12 + 4 * r + c] * dat;                                   // d J_I += -R^T dA_t
+        }
+        dt[r] = acc[I][4 * r + 3] + (dat + a.djoints[b * a.ld_dj + 3 * I + r]);
+    }
+    float dR[9];                                   // gradient w.r.t. the LOCAL rotation R_I
+    if constexpr (I == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dR[k] = dRG[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) djr[0][c] += dt[c];                                 // t_0 = J_0
+    } else {
+        const Mat3 R = rodrigues(rx, ry, rz);
+        // parent's global transform from the forward pass: R^G_p = A_p[:, :3],  rel_I = J_I - J_p
+        float RP[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) RP[3 * r + c] = A[P * 12 + 4 * r + c];
+        const float rel[3] = {jr[3 * I] - jr[3 * P], jr[3 * I + 1] - jr[3 * P + 1], jr[3 * I + 2] - jr[3 * P + 2]};
+        // dR_I = RP^T dRG ;  d rel = RP^T dt ;  dRG_p += dRG R_I^T + dt (x) rel ;  dt_p += dt
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dR[3 * r + c] = RP[r] * dRG[c] + RP[3 + r] * dRG[3 + c] + RP[6 + r] * dRG[6 + c];
+            const float drel = RP[r] * dt[0] + RP[3 + r] * dt[1] + RP[6 + r] * dt[2];
+            djr[I][r] += drel;
+            djr[P][r] -= drel;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                acc[P][4 * r + c] += dRG[3 * r] * R.m[3 * c] + dRG[3 * r + 1] * R.m[3 * c + 1] + dRG[3 * r + 2] * R.m[3 * c + 2] + dt[r] * rel[c];
+            acc[P][4 * r + 3] += dt[r];
+        }
+        if (a.dpf) {                               // pose feature = R_I - I for I >= 1 (slabs already summed: nsplit == 1)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dR[k] += a.dpf[b * a.ldpf + (I - 1) * 9 + k];
+        }
+    }
+    if (a.djrest) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.djrest[(b * J + I) * 3 + c] = djr[I][c];        // every child (index > I) has been processed
+    }
+    if (!dq) return;
+    // Rodrigues backward: R = I + s K + c1 K^2, K = skew(k), k = r / angle
+    const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
+    const float angle = sqrtf(ax * ax + ay * ay + az * az);
+    const float inv = 1.0f / angle;
+    const float kx = rx * inv, ky = ry * inv, kz = rz * inv;
+    float sn, cs;
+    sincos_small(angle, sn, cs);
+    const float c1 = 1.0f - cs;
+    const float K[9] = {0.f, -kz, ky, kz, 0.f, -kx, -ky, kx, 0.f};
+    float KK[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) KK[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+    float ds = 0.f, dc1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { ds += dR[k] * K[k]; dc1 += dR[k] * KK[k]; }
+    float dK[9];                                   // s dR + c1 (dR K^T + K^T dR)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { t1 += dR[3 * r + m] * K[3 * c + m]; t2 += K[3 * m + r] * dR[3 * m + c]; }
+            dK[3 * r + c] = sn * dR[3 * r + c] + c1 * (t1 + t2);
+        }
+    const float dk[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+    const float dtheta = ds * cs + dc1 * sn;
+    const float kdk = kx * dk[0] + ky * dk[1] + kz * dk[2];
+    const float kv[3] = {kx, ky, kz};
+    float* o = dq + (b * seg_nj + li) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (dk[c] - kdk * kv[c]) * inv + dtheta * kv[c];
 }
-__global__ void __launch_bounds__(64) k_fk_bwd(FkBwdArgs a) {
+template <typename Kin, int I>
+__device__ __forceinline__ void fk_bwd_chain(const FkBwdArgs& a, int64_t b, const float* jr, const float* A, float (&acc)[Kin::J][12],
+                                             float (&djr)[Kin::J][3]) {
+    fk_bwd_step<Kin, I>(a, b, jr, A, acc, djr);
+    // keep the next joint's global loads from being hoisted above this joint's arithmetic (that would make every joint's
+    // inputs live at once and spill the accumulators)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    if constexpr (I > 0) fk_bwd_chain<Kin, I - 1>(a, b, jr, A, acc, djr);
+}
+template <typename Kin> __global__ void __launch_bounds__(64, 1) k_fk_bwd(FkBwdArgs a) {
     const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= a.B) return;
-    const int J = a.J;
+    constexpr int J = Kin::J;
     const float* jr = a.j_rest_batched ? a.j_rest + b * J * 3 : a.j_rest;
-    float* dG = a.dG + b * J * 12;
     const float* A = a.A + b * J * 12;
-    // initialise dG_i from dA_i and d joints:  A_i = [R | t - R J_i],  joints_i = t
+    float acc[J][12], djr[J][3];
+#pragma unroll
     for (int i = 0; i < J; ++i) {
-        const float* dAi = a.dA + (b * J + i) * 12;
-        const float J3[3] = {jr[3 * i], jr[3 * i + 1], jr[3 * i + 2]};
-        float djr[3] = {0.f, 0.f, 0.f};
-        for (int r = 0; r < 3; ++r) {
-            const float dat = dAi[4 * r + 3];
-            for (int c = 0; c < 3; ++c) {
-                dG[i * 12 + 4 * r + c] = dAi[4 * r + c] - dat * J3[c];            // d R^G
-                djr[c] -= A[i * 12 + 4 * r + c] * dat;                               // d J_i += -R^T dA_t
-            }
-            dG[i * 12 + 4 * r + 3] = dat + a.djoints[b * a.ld_dj + 3 * i + r];      // d t
-        }
-        if (a.djrest) for (int c = 0; c < 3; ++c) a.djrest[(b * J + i) * 3 + c] = djr[c];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[i][k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) djr[i][k] = 0.f;
     }
-    // reverse chain
-    for (int i = J - 1; i >= 0; --i) {
-        const int p = a.parents[i];
-        int li;
-        const int sg = fk_seg_of(a, i, li);
-        const float* pose = a.seg[sg];
-        float rx = 0.f, ry = 0.f, rz = 0.f;
-        if (pose) { const float* q = pose + (b * a.seg_joints[sg] + li) * 3; rx = q[0]; ry = q[1]; rz = q[2]; }
-        const Mat3 R = rodrigues(rx, ry, rz);
-        float dRG[9], dt[3];
-        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) dRG[3 * r + c] = dG[i * 12 + 4 * r + c]; dt[r] = dG[i * 12 + 4 * r + 3]; }
-        float dR[9];                                   // gradient w.r.t. the LOCAL rotation R_i
-        if (i == 0) {
-            for (int k = 0; k < 9; ++k) dR[k] = dRG[k];
-            if (a.djrest) for (int c = 0; c < 3; ++c) a.djrest[(b * J) * 3 + c] += dt[c];      // t_0 = J_0
-        } else {
-            // parent's global transform from the forward pass: R^G_p = A_p[:, :3],  rel_i = J_i - J_p
-            float RP[9];
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) RP[3 * r + c] = A[p * 12 + 4 * r + c];
-            const float rel[3] = {jr[3 * i] - jr[3 * p], jr[3 * i + 1] - jr[3 * p + 1], jr[3 * i + 2] - jr[3 * p + 2]};
-            // dR_i = RP^T dRG ;  d rel = RP^T dt ;  dRG_p += dRG R_i^T + dt (x) rel ;  dt_p += dt
-            float drel[3];
-            for (int r = 0; r < 3; ++r) {
-                for (int c = 0; c < 3; ++c) dR[3 * r + c] = RP[r] * dRG[c] + RP[3 + r] * dRG[3 + c] + RP[6 + r] * dRG[6 + c];
-                drel[r] = RP[r] * dt[0] + RP[3 + r] * dt[1] + RP[6 + r] * dt[2];
-            }
-            for (int r = 0; r < 3; ++r) {
-                for (int c = 0; c < 3; ++c)
-                    dG[p * 12 + 4 * r + c] += dRG[3 * r] * R.m[3 * c] + dRG[3 * r + 1] * R.m[3 * c + 1] + dRG[3 * r + 2] * R.m[3 * c + 2] + dt[r] * rel[c];
-                dG[p * 12 + 4 * r + 3] += dt[r];
-            }
-            if (a.djrest) for (int c = 0; c < 3; ++c) { a.djrest[(b * J + i) * 3 + c] += drel[c]; a.djrest[(b * J + p) * 3 + c] -= drel[c]; }
-            if (a.dpf)                                 // pose feature = R_i - I for i >= 1
-                for (int k = 0; k < 9; ++k) {
-                    float acc = 0.f;
-                    for (int sidx = 0; sidx < a.nsplit; ++sidx) acc += a.dpf[sidx * a.dpf_slab + b * a.ldpf + (i - 1) * 9 + k];
-                    dR[k] += acc;
-                }
+    fk_bwd_chain<Kin, J - 1>(a, b, jr, A, acc, djr);
+}
+
+// d pose_feature: sum of the split-K slabs of the d_off @ posedirs^T GEMM, [nsplit][Bpad][ld] -> slab 0 (fixed order)
+__global__ void __launch_bounds__(256) k_sum_slabs(float* slabs, int64_t slab_elems, int nsplit) {
+    const int64_t n4 = slab_elems >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = reinterpret_cast<const f32x4*>(slabs)[i];
+        for (int k = 1; k < nsplit; ++k) {
+            const f32x4 w = reinterpret_cast<const f32x4*>(slabs + k * slab_elems)[i];
+            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
         }
-        float* dq = a.dseg[sg];
-        if (!dq) continue;
-        // Rodrigues backward: R = I + s K + c1 K^2, K = skew(k), k = r / angle
-        const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
-        const float angle = sqrtf(ax * ax + ay * ay + az * az);
-        const float inv = 1.0f / angle;
-        const float kx = rx * inv, ky = ry * inv, kz = rz * inv;
-        float sn, cs;
-        sincos_small(angle, sn, cs);
-        const float c1 = 1.0f - cs;
-        const float K[9] = {0.f, -kz, ky, kz, 0.f, -kx, -ky, kx, 0.f};
-        float KK[9];
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) KK[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
-        float ds = 0.f, dc1 = 0.f;
-        for (int k = 0; k < 9; ++k) { ds += dR[k] * K[k]; dc1 += dR[k] * KK[k]; }
-        float dK[9];                                   // s dR + c1 (dR K^T + K^T dR)
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) {
-                float t1 = 0.f, t2 = 0.f;
-                for (int m = 0; m < 3; ++m) { t1 += dR[3 * r + m] * K[3 * c + m]; t2 += K[3 * m + r] * dR[3 * m + c]; }
-                dK[3 * r + c] = sn * dR[3 * r + c] + c1 * (t1 + t2);
-            }
-        const float dk[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
-        const float dtheta = ds * cs + dc1 * sn;
-        const float kdk = kx * dk[0] + ky * dk[1] + kz * dk[2];
-        const float kv[3] = {kx, ky, kz};
-        float* o = dq + (b * a.seg_joints[sg] + li) * 3;
-        for (int c = 0; c < 3; ++c) o[c] = (dk[c] - kdk * kv[c]) * inv + dtheta * kv[c];
+        reinterpret_cast<f32x4*>(slabs)[i] = v;
     }
 }
 
@@ -913,7 +979,7 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
         a.skin_idx = skin_idx; a.skin_w = skin_w; a.K = skin_k; a.J = J; a.V = V; a.vp = vp; a.dvp = d_vposed ? d_vposed : dvp; a.doff_ft = doff;
         a.Cpad = (int)Cpad;
-        hipLaunchKernelGGL(k_skin_bwd, dim3((unsigned)ceil_div(V, 256 * 4), (unsigned)batch), dim3(256), J * 12 * sizeof(float), st, a);
+        hipLaunchKernelGGL(k_skin_bwd, dim3((unsigned)ceil_div(V, 256 * 4), (unsigned)batch), dim3(256), (J * 12 + 768) * sizeof(float), st, a);
         FK_HIP_LAUNCH(hipGetLastError());
     }
     {
@@ -947,9 +1013,17 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         }
         DP_CHECK_ARG(first == J, "pose segments must cover all joints of the kinematic tree");
         a.nseg = num_segments; a.j_rest = j_rest; a.j_rest_batched = j_rest_batched; a.A = A; a.dA = dA; a.djoints = d_joints; a.ld_dj = d_joints_ld;
-        a.dpf = dpf; a.dpf_slab = Bpad * prow; a.ldpf = prow; a.nsplit = ks; a.djrest = d_jrest; a.dG = dG; a.parents = parents_dev; a.J = J;
+        if (ks > 1) {
+            const int64_t n4 = Bpad * prow / 4;
+            hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)(n4 < 256 * 2048 ? ceil_div(n4, 256) : 2048)), dim3(256), 0, st, dpf, Bpad * prow, ks);
+            FK_HIP_LAUNCH(hipGetLastError());
+        }
+        a.dpf = dpf; a.dpf_slab = Bpad * prow; a.ldpf = prow; a.nsplit = 1; a.djrest = d_jrest; a.dG = dG; a.parents = parents_dev; a.J = J;
         a.B = batch;
-        hipLaunchKernelGGL(k_fk_bwd, dim3((unsigned)ceil_div(batch, 64)), dim3(64), 0, st, a);
+        const dim3 grid((unsigned)ceil_div(batch, 64));
+        if (h->kind == 0) hipLaunchKernelGGL(k_fk_bwd<KinSMPL>, grid, dim3(64), 0, st, a);
+        else if (h->kind == 1) hipLaunchKernelGGL(k_fk_bwd<KinSMPLH>, grid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL(k_fk_bwd<KinSMPLX>, grid, dim3(64), 0, st, a);
         FK_HIP_LAUNCH(hipGetLastError());
     }
     return DPOSER_OK;
