@@ -161,6 +161,14 @@ template <> struct TileIO<__bf16> {
         }
     }
 };
+// x + (x of lane ^ 32) with one v_permlane32_swap: the two accumulator halves of a GroupNorm group live in lanes l and l ^ 32.
+// (__shfl_xor(x, 32) is a ds_bpermute: an LDS round trip plus an s_waitcnt that stalls the wave -- and its MFMAs -- in an epilogue.)
+__device__ __forceinline__ float sum_xor32(float x) {
+    const unsigned u = __float_as_uint(x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0]: upper half <- lower half of u; r[1]: lower half <- upper half
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);               // = x + partner in both halves (addition commutes: same bits)
+}
+
 // Transposed store of a 32x32 tile: the same values written as FT[channel rows][sample k] (the operand layout of the
 // wgrad GEMMs, which reduce over samples).  The tile is transposed through a per-wave LDS scratch (row = channel, row
 // stride 80 B / 144 B => conflict-free b128 reads) and leaves as lane-linear 16-byte chunks, 1 KiB per instruction.

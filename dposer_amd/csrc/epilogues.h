@@ -108,12 +108,12 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { cy.v[4 * q + r] = a[4 * q + r] + b4[r]; sum += cy.v[4 * q + r]; }
             }
-            sum += __shfl_xor(sum, 32);
+            sum = sum_xor32(sum);
             const float mean = sum * (1.0f / 32.0f);
             float ss = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { cy.v[r] -= mean; ss += cy.v[r] * cy.v[r]; }
-            ss += __shfl_xor(ss, 32);
+            ss = sum_xor32(ss);
             const float var = ss * (1.0f / 32.0f);
             cy.rstd = PRECISE ? 1.0f / sqrtf(var + 1e-5f) : rsqrtf(var + 1e-5f);
             if (drop) dropout_mask16(p.drop, s, c0 >> 5, hi, cy.keep);
@@ -438,8 +438,8 @@ template <typename T> struct EpiGNBwd {
                         s2 += g[i] * xh[i];
                     }
                 }
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
+                s1 = sum_xor32(s1);
+                s2 = sum_xor32(s2);
                 const float m1 = s1 * (1.0f / 32.0f), m2 = s2 * (1.0f / 32.0f);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
