@@ -183,7 +183,8 @@ template <> struct TileT<__bf16> {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 *reinterpret_cast<__bf16*>(scratch + (8 * q + 4 * hi + r) * 80 + j * 2) = (__bf16)v[4 * q + r];
-        __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): this wave's LDS writes are done (wave-private scratch)
+        // no s_waitcnt: the scratch is wave-private and a wave's LDS instructions execute in issue order, so the reads below see
+        // the writes above; the compiler barrier only pins that order
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                             // k-block h = samples 16h .. 16h+15
@@ -205,16 +206,14 @@ template <> struct TileT<float> {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     *reinterpret_cast<float*>(scratch + (8 * q2 + 4 * hi + r) * 144 + j * 4) = v[4 * (2 * pass + q2) + r];
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            asm volatile("" ::: "memory");
+            asm volatile("" ::: "memory");                        // (in-order LDS per wave, see the bf16 variant)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {                // sample chunk sc = 4 samples; k-block = sc>>1, kh = sc&1
                 const int sc = 4 * half + c4;
                 f32x4 o = *reinterpret_cast<const f32x4*>(scratch + r16 * 144 + sc * 16);
                 *reinterpret_cast<f32x4*>(tileT + (sc >> 1) * 256 + ((sc & 1) * 32 + 16 * pass + r16) * 4) = o;
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                   // reads done before the next pass overwrites the scratch
-            asm volatile("" ::: "memory");
+            asm volatile("" ::: "memory");                        // next pass's writes are issued after these reads: in order
         }
     }
 };
