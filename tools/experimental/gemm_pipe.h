@@ -8,6 +8,9 @@
 // training 256 us (183) with 4-wave workgroups; with 8-wave workgroups of 2x2 wave tiles (two waves per SIMD, 256 registers each)
 // plain 136 us, GroupNorm forward 152 us, training 229 us.  With one wave per SIMD every s_waitcnt of the interleaved epilogue (LDS parameter reads, the
 // lane^32 exchange, global loads) also stalls that wave's MFMA issue, and the 1-wave main loop is 17 % slower to begin with.
+// With two waves per SIMD the other wave's MFMAs queue at the shared issue port and block this wave's interleaved VALU again
+// (the cross-wave exclusion of overlap_probe.hip), so the interleave only pays at one wave per SIMD -- where nothing hides the
+// remaining waits.  The training epilogue (~7 VALU per MFMA averaged over a tile) is also simply too heavy to hide completely.
 // Kept as the starting point for a hand-scheduled version (explicit prefetch of epilogue operands one stage ahead,
 // v_permlane32_swap instead of LDS shuffles).
 //
