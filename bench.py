@@ -7,7 +7,8 @@
 A "step" is ONE score-network training step (BASELINE.json metric M1) on a global batch of 65536
 synthetic z-scored [B, 63] pose vectors: in-kernel perturbation (t ~ U, z ~ N), forward with dropout,
 DSM loss, full backward into the flat fp32 gradient, RCCL all-reduce (N > 1), global-norm clip +
-Adam + EMA.  The global batch is fixed as N grows ("B = 65536 @ 1/2/4/8 GPU") => strong scaling.
+Adam + EMA.  The global batch is fixed as N grows ("B = 65536 @ 1/2/4/8 GPU") => strong scaling
+(`--per-gpu-batch 65536` keeps the per-GPU batch instead and reports "scaling": "weak").
 Rank 0 prints ONE JSON line; besides the contract's keys it carries
   roofline      -- live HIP-event timing of the dominant MFMA GEMM kernel over the timed region
   cpu_baseline  -- the CPU oracle (oracle/score_ref.py, torch-CPU port of the reference path) on the host cores
@@ -103,6 +104,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH)
+    ap.add_argument("--per-gpu-batch", type=int, default=0,
+                    help="weak scaling: fix the batch per GPU (global batch = this x world size) instead of the global batch")
     ap.add_argument("--sampler-steps", type=int, default=1000)
     ap.add_argument("--no-extra", action="store_true", help="skip the sampler / FK measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,6 +124,8 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1)     # (test rigs may run several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.per_gpu_batch > 0:
+        args.global_batch = args.per_gpu_batch * world
     B_local = args.global_batch // world
 
     cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
@@ -253,7 +258,7 @@ def main():
         print(json.dumps({
             "metric": "poses/sec score-net train step (subVP DSM, ScoreModelFC) at global B=65536",
             "value": value, "unit": "poses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if args.per_gpu_batch > 0 else "strong", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "subVP denoising-score-matching train step (fwd+bwd+clip+Adam+EMA), ScoreModelFC H=1024 E=512 2 blocks, "
                                    "z-scored toy-pose rows [B,63]", "global_batch": args.global_batch, "per_gpu_batch": B_local,
