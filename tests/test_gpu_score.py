@@ -496,3 +496,25 @@ def test_integration_md_ctypes_stub_runs():
         os.chdir(cwd)
     with torch.no_grad():
         assert torch.equal(out, m(x, labels))
+
+
+@pytest.mark.parametrize("env", [
+    {"DPOSER_GNBWD_BIG": "1", "DPOSER_WGRAD_BIG": "1", "DPOSER_BIG_MIN_BATCH": "256"},      # 256x256 tilings from 256 samples up
+    {"DPOSER_GNBWD_BIG": "0", "DPOSER_WGRAD_BIG": "0", "DPOSER_WGRAD_STREAM": "0"},          # 128x128 everywhere, single stream
+])
+def test_alternative_tilings_and_streams_keep_parity(env):
+    """The tiling / stream policy depends on the batch size (256x256 GroupNorm-backward and wgrad tiles from 32768 samples,
+    second stream up to 16384).  The policies are read once per process, so the gradient-parity tests are re-run in a child
+    process with each policy forced onto the small batches the oracle can check."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("DPOSER_TILING_CHILD"):
+        pytest.skip("child process")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child_env = dict(os.environ, DPOSER_TILING_CHILD="1", **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_score.py"), "-m", "gpu", "-q", "-x", "-k",
+                        "ragged_batches_and_rot6d or dsm_loss_and_grads or train_steps_match or autograd_forward_backward"],
+                       cwd=root, env=child_env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
