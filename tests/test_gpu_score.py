@@ -518,3 +518,47 @@ def test_alternative_tilings_and_streams_keep_parity(env):
                        cwd=root, env=child_env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_vp_sde_fused_paths_vs_oracle():
+    """The fused sampler (both step paths), the prior loss and the DSM gradient under the VP SDE (std = sqrt(1 - e^{2 lmc}),
+    g = sqrt(beta): the other branch of the SDE scalars inside the kernels) against the oracle's VP class."""
+    from dposer_amd.algorithms.advanced import losses, sampling, sde_lib
+    from dposer_amd.prior import prior_loss
+    cfg, m, p = make_model(33, precision="fp32", dropout=0.0)
+    rs = np.random.RandomState(12)
+    B, N, seed = 72, 5, 99
+    # sampler
+    sde = sde_lib.VPSDE(0.1, 20.0, N)
+    cfg.sampling.corrector = "none"
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 63), lambda v: v, 1e-3, device=DEV)
+    z0 = rs.standard_normal((B, 63)).astype(np.float32)
+    noises = [torch.tensor(PH.normal_matrix(B, 63, PH.STREAM_EM_NOISE, i, seed)) for i in range(N)]
+    ref_trajs, ref_x = R.pc_sampler(p, R.VP(N=N), torch.tensor(z0), noises)
+    for stride in (0, 1):
+        _, x = fn(m, z=_dev(z0), seed=seed, traj_stride=stride)
+        assert rel_err(t2n(x), ref_x.numpy()) < 1e-4, stride
+    # prior loss + analytic gradient
+    sde1000 = sde_lib.VPSDE(0.1, 20.0, 1000)
+    x0 = rs.standard_normal((B, 63)).astype(np.float32)
+    z = rs.standard_normal((B, 63)).astype(np.float32)
+    xg = _dev(x0).requires_grad_(True)
+    loss = prior_loss(m, sde1000, xg, 0.37, weighted=True, z=_dev(z))
+    loss.backward()
+    lref, gref = R.dposer_prior_loss(p, R.VP(), torch.tensor(x0), torch.full((B,), 0.37), torch.tensor(z), weighted=True, reduction="mean")
+    assert abs(float(loss.detach()) - float(lref)) / abs(float(lref)) < 2e-4
+    assert rel_err(t2n(xg.grad), gref.numpy()) < 2e-4
+    # DSM loss and gradients
+    t = rs.uniform(1e-3, 1.0, B).astype(np.float32)
+    fg = torch.zeros(m._num_flat, device=DEV)
+    l = losses.fused_dsm_grad(m, sde1000, _dev(x0), flat_grad=fg, t=_dev(t), z=_dev(z), seed=1, step=0)
+    names = R.param_names()
+    leaves = {n: p[n].clone().requires_grad_(True) for n in names}
+    full = dict(p)
+    full.update(leaves)
+    ref = R.dsm_loss(full, R.VP(), torch.tensor(x0), torch.tensor(t), torch.tensor(z))
+    grads = torch.autograd.grad(ref, [leaves[n] for n in names], allow_unused=True)
+    assert abs(float(l) - ref.item()) / ref.item() < 5e-5
+    for n, gr, off in zip(names, grads, m._offsets):
+        if gr is not None:
+            assert rel_err(t2n(fg[off:off + gr.numel()]), gr.reshape(-1).numpy()) < 3e-4, n

@@ -186,6 +186,17 @@ int main(int argc, char** argv) {
         run_all(7, 10);
         return 0;
     }
+    if (getenv("TUNE_SMALLB")) {     // which tiling for one-round problem sizes (run with S = 8192 / 16384)?
+        GNT(2, 2, 2, 2, 4, 1);
+        GNT(2, 2, 2, 1, 4, 1);
+        GNT(4, 1, 1, 2, 4, 1);
+        GNT(2, 4, 4, 2, 4, 1);
+        GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0);
+        GB(2, 2, 2, 1, 4, 1, 1, 1, 0, 0);
+        GB(4, 1, 1, 2, 4, 1, 1, 1, 0, 0);
+        run_all(9, 20);
+        return 0;
+    }
     if (getenv("TUNE_GNBWD")) {
         for (int rep = 0; rep < 2; ++rep) {
             GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0);
