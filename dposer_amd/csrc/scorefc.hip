@@ -77,8 +77,9 @@ static PackJob mk_job(int64_t dst_off, int64_t src_off, int ktot, int koff, int 
 
 extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_scorefc_t* out) {
     DP_CHECK_ARG(desc && out, "null argument");
-    DP_CHECK_ARG(desc->hidden_dim > 0 && desc->hidden_dim % 1024 == 0,
-                 "hidden_dim must be a multiple of 1024 (GroupNorm(32, H) with 32-channel groups is what the MFMA epilogue fuses)");
+    DP_CHECK_ARG(desc->hidden_dim == 1024,
+                 "hidden_dim must be 1024: nn.GroupNorm(32, H) has H/32 channels per group and the MFMA epilogue fuses exactly one "
+                 "32-channel accumulator tile per group");
     DP_CHECK_ARG(desc->embed_dim > 0 && desc->embed_dim % 128 == 0, "embed_dim must be a multiple of 128");
     DP_CHECK_ARG(desc->n_blocks >= 1 && desc->n_blocks <= 3, "n_blocks must be 1..3");
     DP_CHECK_ARG(desc->data_dim > 0 && desc->data_dim <= 256, "data_dim must be in 1..256");

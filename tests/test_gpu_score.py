@@ -562,3 +562,49 @@ def test_vp_sde_fused_paths_vs_oracle():
     for n, gr, off in zip(names, grads, m._offsets):
         if gr is not None:
             assert rel_err(t2n(fg[off:off + gr.numel()]), gr.reshape(-1).numpy()) < 3e-4, n
+
+
+@pytest.mark.parametrize("n_blocks,E,H", [(1, 512, 1024), (3, 256, 1024), (1, 128, 1024)])
+def test_other_depths_and_embed_dims_vs_oracle(n_blocks, E, H):
+    """ScoreModelFC(n_blocks, embed_dim, hidden_dim) other than the shipped 2 / 512 / 1024: the residual-carry logic of the backward pass and the
+    bucket layout depend on the depth (L = 1 + 2 n_blocks GroupNorm layers).  Forward, score and all gradients vs the oracle."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.advanced.model import ScoreModelFC
+    from dposer_amd.configs import load_config
+    cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+    cfg.model.dropout = 0.0
+    torch.manual_seed(n_blocks)
+    m = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=H, embed_dim=E, n_blocks=n_blocks)
+    with torch.no_grad():
+        for q in m.parameters():                     # default init has zero biases / unit gains in places: make every tensor matter
+            q.add_(0.05 * torch.randn_like(q))
+    m.precision = "fp32"
+    m.to(DEV).eval()
+    p = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    p["sigmas"] = R.sigma_table()
+    assert len(m._engine().grad_buckets) == 1 + 2 * n_blocks
+    rs = np.random.RandomState(n_blocks)
+    B = 200
+    x = rs.standard_normal((B, 63)).astype(np.float32)
+    t = rs.uniform(1e-3, 1.0, B).astype(np.float32)
+    z = rs.standard_normal((B, 63)).astype(np.float32)
+    with torch.no_grad():
+        out = m(_dev(x), _dev(t) * 999)
+    ref_out = R.scorefc_forward(p, torch.tensor(x), torch.tensor(t) * 999, n_blocks=n_blocks)
+    assert rel_err(t2n(out), ref_out.numpy()) < TOL_FP32
+    fg = torch.zeros(m._num_flat, device=DEV)
+    l = losses.fused_dsm_grad(m, sde_lib.subVPSDE(0.1, 20.0, 1000), _dev(x), flat_grad=fg, t=_dev(t), z=_dev(z), seed=1, step=0)
+    names = R.param_names(n_blocks=n_blocks)
+    assert names == [k for k, _ in m.named_parameters()]
+    leaves = {n: p[n].clone().requires_grad_(True) for n in names}
+    full = dict(p)
+    full.update(leaves)
+    ref = R.dsm_loss(full, R.SubVP(), torch.tensor(x), torch.tensor(t), torch.tensor(z), n_blocks=n_blocks)
+    grads = torch.autograd.grad(ref, [leaves[n] for n in names], allow_unused=True)
+    assert abs(float(l) - ref.item()) / ref.item() < 5e-5
+    for n, gr, off in zip(names, grads, m._offsets):
+        got = fg[off:off + p[n].numel()]
+        if gr is None:
+            assert float(got.abs().max()) == 0.0, n
+        else:
+            assert rel_err(t2n(got), gr.reshape(-1).numpy()) < 3e-4, n
