@@ -564,17 +564,22 @@ def test_vp_sde_fused_paths_vs_oracle():
             assert rel_err(t2n(fg[off:off + gr.numel()]), gr.reshape(-1).numpy()) < 3e-4, n
 
 
-@pytest.mark.parametrize("n_blocks,E,H", [(1, 512, 1024), (3, 256, 1024), (1, 128, 1024)])
-def test_other_depths_and_embed_dims_vs_oracle(n_blocks, E, H):
-    """ScoreModelFC(n_blocks, embed_dim, hidden_dim) other than the shipped 2 / 512 / 1024: the residual-carry logic of the backward pass and the
-    bucket layout depend on the depth (L = 1 + 2 n_blocks GroupNorm layers).  Forward, score and all gradients vs the oracle."""
-    from dposer_amd.algorithms.advanced import losses, sde_lib
+@pytest.mark.parametrize("n_blocks,E,n_poses,pose_dim,sbs", [(1, 512, 21, 3, True), (3, 256, 21, 3, True), (1, 128, 21, 3, True),
+                                                            (2, 512, 16, 4, True), (2, 512, 32, 4, False), (2, 384, 40, 5, True),
+                                                            (2, 512, 1, 3, True)])
+def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sbs):
+    """ScoreModelFC configurations other than the shipped one (2 blocks, embed 512, D = 63, scale_by_sigma): depth (residual-carry
+    logic, bucket layout), embedding width, data dimensions that are / are not multiples of the 64-column padding (64, 128, 200, 3)
+    and scale_by_sigma off.  Forward, sampler step and all gradients vs the oracle (general, pinned at the shipped shape)."""
+    from dposer_amd.algorithms.advanced import losses, sampling, sde_lib
     from dposer_amd.algorithms.advanced.model import ScoreModelFC
     from dposer_amd.configs import load_config
     cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
     cfg.model.dropout = 0.0
-    torch.manual_seed(n_blocks)
-    m = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=H, embed_dim=E, n_blocks=n_blocks)
+    cfg.model.scale_by_sigma = sbs
+    D = n_poses * pose_dim
+    torch.manual_seed(n_blocks + D)
+    m = ScoreModelFC(cfg, n_poses=n_poses, pose_dim=pose_dim, hidden_dim=1024, embed_dim=E, n_blocks=n_blocks)
     with torch.no_grad():
         for q in m.parameters():                     # default init has zero biases / unit gains in places: make every tensor matter
             q.add_(0.05 * torch.randn_like(q))
@@ -585,12 +590,13 @@ def test_other_depths_and_embed_dims_vs_oracle(n_blocks, E, H):
     assert len(m._engine().grad_buckets) == 1 + 2 * n_blocks
     rs = np.random.RandomState(n_blocks)
     B = 200
-    x = rs.standard_normal((B, 63)).astype(np.float32)
+    x = rs.standard_normal((B, D)).astype(np.float32)
     t = rs.uniform(1e-3, 1.0, B).astype(np.float32)
-    z = rs.standard_normal((B, 63)).astype(np.float32)
+    z = rs.standard_normal((B, D)).astype(np.float32)
+    fw = dict(n_blocks=n_blocks, scale_by_sigma=sbs)
     with torch.no_grad():
         out = m(_dev(x), _dev(t) * 999)
-    ref_out = R.scorefc_forward(p, torch.tensor(x), torch.tensor(t) * 999, n_blocks=n_blocks)
+    ref_out = R.scorefc_forward(p, torch.tensor(x), torch.tensor(t) * 999, **fw)
     assert rel_err(t2n(out), ref_out.numpy()) < TOL_FP32
     fg = torch.zeros(m._num_flat, device=DEV)
     l = losses.fused_dsm_grad(m, sde_lib.subVPSDE(0.1, 20.0, 1000), _dev(x), flat_grad=fg, t=_dev(t), z=_dev(z), seed=1, step=0)
@@ -599,7 +605,7 @@ def test_other_depths_and_embed_dims_vs_oracle(n_blocks, E, H):
     leaves = {n: p[n].clone().requires_grad_(True) for n in names}
     full = dict(p)
     full.update(leaves)
-    ref = R.dsm_loss(full, R.SubVP(), torch.tensor(x), torch.tensor(t), torch.tensor(z), n_blocks=n_blocks)
+    ref = R.dsm_loss(full, R.SubVP(), torch.tensor(x), torch.tensor(t), torch.tensor(z), **fw)
     grads = torch.autograd.grad(ref, [leaves[n] for n in names], allow_unused=True)
     assert abs(float(l) - ref.item()) / ref.item() < 5e-5
     for n, gr, off in zip(names, grads, m._offsets):
@@ -608,3 +614,13 @@ def test_other_depths_and_embed_dims_vs_oracle(n_blocks, E, H):
             assert float(got.abs().max()) == 0.0, n
         else:
             assert rel_err(t2n(got), gr.reshape(-1).numpy()) < 3e-4, n
+    # three sampler steps through both step paths
+    N, seed = 3, 17
+    sde = sde_lib.subVPSDE(0.1, 20.0, N)
+    cfg.sampling.corrector = "none"
+    fn = sampling.get_sampling_fn(cfg, sde, (B, D), lambda v: v, 1e-3, device=DEV)
+    noises = [torch.tensor(PH.normal_matrix(B, D, PH.STREAM_EM_NOISE, i, seed)) for i in range(N)]
+    _, ref_x = R.pc_sampler(p, R.SubVP(N=N), torch.tensor(z), noises, **fw)
+    for stride in (0, 1):
+        _, xs = fn(m, z=_dev(z), seed=seed, traj_stride=stride)
+        assert rel_err(t2n(xs), ref_x.numpy()) < 1e-4, stride
