@@ -167,3 +167,54 @@ def test_body_model_backward_pose_only_shared_shape(bm, asset):
     lref.backward()
     err = float(np.linalg.norm(t2n(p_d.grad) - p_r.grad.numpy()) / np.linalg.norm(p_r.grad.numpy()))
     assert err < 2e-4, err
+
+
+_SMPL_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]
+_SMPLH_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 22, 23, 20, 25, 26, 20, 28, 29, 20, 31, 32,
+                  20, 34, 35, 21, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50]
+
+
+@pytest.mark.parametrize("parents,segs", [(_SMPL_PARENTS, (1, 23)), (_SMPLH_PARENTS, (1, 21, 15, 15))])
+def test_fk_smpl_and_smplh_trees_through_the_c_abi(parents, segs):
+    """The Python wrapper only builds SMPL-X (what the reference's scripts use); the library also unrolls the SMPL (24 joints)
+    and SMPL-H (52) chains.  Posed joints and skinning transforms straight through dposer_fk_joints vs the chain oracle."""
+    import ctypes as C
+    from dposer_amd import _C
+    lib = _C.lib()
+    J, B = len(parents), 130
+    desc = _C.BodyDesc(J, 100, 10, 0, 0)
+    h = C.c_void_p()
+    par = (C.c_int32 * J)(*parents)
+    _C.check(lib.dposer_body_create(C.byref(desc), par, C.byref(h)), "dposer_body_create")
+    try:
+        rs = np.random.RandomState(J)
+        full = (rs.standard_normal((B, J, 3)) * 0.5).astype(np.float32)
+        jrest = rs.standard_normal((J, 3)).astype(np.float32)
+        transl = rs.standard_normal((B, 3)).astype(np.float32)
+        parts, first = [], 0
+        for n in segs:
+            parts.append(torch.tensor(full[:, first:first + n].reshape(B, n * 3).copy(), device=DEV))
+            first += n
+        segp = (C.c_void_p * len(segs))(*[t.data_ptr() for t in parts])
+        segj = (C.c_int32 * len(segs))(*segs)
+        jr, tr = torch.tensor(jrest, device=DEV), torch.tensor(transl, device=DEV)
+        joints = torch.empty(B, J, 3, device=DEV)
+        rel = torch.empty(B, J, 12, device=DEV)
+        _C.check(lib.dposer_fk_joints(h, segp, segj, len(segs), _C.ptr(jr), 0, _C.ptr(tr), _C.ptr(joints), _C.ptr(rel), J, B, _C.stream_ptr()),
+                 "dposer_fk_joints")
+        R = fk_ref.batch_rodrigues(full.reshape(-1, 3).astype(np.float64)).reshape(B, J, 3, 3)
+        posed, A = fk_ref.batch_rigid_transform(R, np.broadcast_to(jrest.astype(np.float64), (B, J, 3)).copy(), np.array(parents))
+        assert np.abs(t2n(joints) - (posed + transl[:, None].astype(np.float64))).max() < 1e-5
+        assert np.abs(t2n(rel).reshape(B, J, 3, 4) - A[:, :, :3, :]).max() < 1e-5
+        # body-only query (22 joints; the lean specialisation) on the same trees
+        j22 = torch.empty(B, 22, 3, device=DEV)
+        _C.check(lib.dposer_fk_joints(h, segp, segj, len(segs), _C.ptr(jr), 0, None, _C.ptr(j22), None, 22, B, _C.stream_ptr()), "dposer_fk_joints")
+        assert np.abs(t2n(j22) - posed[:, :22]).max() < 1e-5
+    finally:
+        lib.dposer_body_destroy(h)
+    # an unknown kinematic tree is refused, not mis-evaluated
+    bad = list(parents)
+    bad[5] = 1
+    h2 = C.c_void_p()
+    assert lib.dposer_body_create(C.byref(desc), (C.c_int32 * J)(*bad), C.byref(h2)) < 0
+    assert b"kinematic tree" in lib.dposer_last_error()
