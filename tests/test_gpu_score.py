@@ -624,3 +624,25 @@ def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sb
     for stride in (0, 1):
         _, xs = fn(m, z=_dev(z), seed=seed, traj_stride=stride)
         assert rel_err(t2n(xs), ref_x.numpy()) < 1e-4, stride
+
+
+def test_completion_sampler_inkernel_imputation_noise_matches_oracle():
+    """Completion sampling with every draw made in-kernel: predictor noise (STREAM_EM_NOISE, offset = loop index) and the two
+    imputation draws of sampling.py:416-420 (STREAM_IMPUTE_A before / STREAM_IMPUTE_B after the predictor, same offsets),
+    against the oracle fed the numpy restatement of those Philox streams."""
+    from dposer_amd.utils.misc import create_mask
+    cfg, m, p = make_model(41, precision="fp32")
+    N, B, seed = 6, 48, 2024
+    sde, fn = _sampler(m, cfg, N, B)
+    rs = np.random.RandomState(6)
+    poses = torch.tensor(rs.standard_normal((B, 63)).astype(np.float32))
+    torch.manual_seed(1)
+    mask, obs = create_mask(poses, part="left_arm")
+    z0 = rs.standard_normal((B, 63)).astype(np.float32)
+    trajs, x = fn(m, observation=obs.to(DEV), mask=mask.to(DEV), z=_dev(z0), args=_Args("completion"), seed=seed)
+    nz = lambda stream, i: torch.tensor(PH.normal_matrix(B, 63, stream, i, seed))
+    noises = [nz(PH.STREAM_EM_NOISE, i) for i in range(N)]
+    impute = [(nz(PH.STREAM_IMPUTE_A, i), nz(PH.STREAM_IMPUTE_B, i)) for i in range(N)]
+    ref_trajs, ref_x = R.pc_sampler(p, R.SubVP(N=N), torch.tensor(z0), noises, observation=obs, mask=mask, impute_noises=impute)
+    assert rel_err(t2n(trajs), ref_trajs.numpy()) < 1e-4
+    assert rel_err(t2n(x), ref_x.numpy()) < 1e-4
