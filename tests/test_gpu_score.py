@@ -250,9 +250,10 @@ def test_dsm_loss_and_grads_match_reference_golden(prec, tol_loss, tol_grad):
         assert rel_err(probe(name, got), ref) < tol_grad, name
 
 
-def test_dsm_with_inkernel_dropout_and_rng_matches_oracle():
+@pytest.mark.parametrize("drop_p", [0.1, 0.5])
+def test_dsm_with_inkernel_dropout_and_rng_matches_oracle(drop_p):
     """Dropout masks, t and z all drawn in-kernel (Philox); the oracle gets the same draws from oracle/philox.py."""
-    cfg, m, p = make_model(31, precision="fp32", dropout=0.1)
+    cfg, m, p = make_model(31, precision="fp32", dropout=drop_p)
     B, step = 96, 7
     rs = np.random.RandomState(1)
     batch = rs.standard_normal((B, 63)).astype(np.float32)
@@ -260,12 +261,12 @@ def test_dsm_with_inkernel_dropout_and_rng_matches_oracle():
     seed = m._rng_seed
     t = torch.tensor(PH.uniform_t(B, step, seed))
     z = torch.tensor(PH.normal_matrix(B, 63, PH.STREAM_TRAIN_Z, step, seed))
-    masks = [torch.tensor(PH.dropout_keep_mask(B, 1024, site, step, seed, 0.1)) for site in range(5)]
+    masks = [torch.tensor(PH.dropout_keep_mask(B, 1024, site, step, seed, drop_p)) for site in range(5)]
     names = R.param_names()
     leaves = {n: p[n].clone().requires_grad_(True) for n in names}
     full = dict(p)
     full.update(leaves)
-    ref = R.dsm_loss(full, R.SubVP(), torch.tensor(batch), t, z, drop_masks=masks, drop_p=0.1)
+    ref = R.dsm_loss(full, R.SubVP(), torch.tensor(batch), t, z, drop_masks=masks, drop_p=drop_p)
     grads = torch.autograd.grad(ref, [leaves[n] for n in names], allow_unused=True)
     assert abs(loss - ref.item()) / ref.item() < 5e-5
     for n, gr, off in zip(names, grads, m._offsets):
