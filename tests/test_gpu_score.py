@@ -647,3 +647,37 @@ def test_completion_sampler_inkernel_imputation_noise_matches_oracle():
     ref_trajs, ref_x = R.pc_sampler(p, R.SubVP(N=N), torch.tensor(z0), noises, observation=obs, mask=mask, impute_noises=impute)
     assert rel_err(t2n(trajs), ref_trajs.numpy()) < 1e-4
     assert rel_err(t2n(x), ref_x.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("reduce_mean,lw", [(False, False), (True, True)])
+def test_generic_step_path_matches_oracle(reduce_mean, lw):
+    """Loss variants the fused step does not cover (sum reduction, likelihood weighting: losses.py:124-129) go through the
+    generic route -- torch autograd over the HIP forward / backward, clip_grad_norm_, FusedAdam.step(), ema.update() -- and must
+    follow the oracle's step just the same.  torch.rand / randn_like are pinned by a seed and re-drawn for the oracle."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    cfg, m, p = make_model(51, precision="fp32", dropout=0.0)
+    cfg.optim.warmup = 0
+    names = R.param_names()
+    st = R.TrainState({k: v.clone() for k, v in p.items()}, names, ema_rate=cfg.model.ema_rate)
+    opt = losses.get_optimizer(cfg, m.parameters())
+    ema = ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate)
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    step_fn = losses.get_step_fn(sde, True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=reduce_mean, continuous=True,
+                                 likelihood_weighting=lw)
+    state = dict(model=m, optimizer=opt, ema=ema, step=0)
+    rs = np.random.RandomState(3)
+    B = 64
+    for i in range(2):
+        batch = rs.standard_normal((B, 63)).astype(np.float32)
+        torch.manual_seed(100 + i)
+        out = step_fn(state, _dev(batch))
+        torch.manual_seed(100 + i)                                            # the same draws, in the reference's order (:110-111)
+        t = torch.rand(B, device=DEV) * (sde.T - 1e-5) + 1e-5
+        z = torch.randn_like(_dev(batch))
+        ref_loss, _, _ = R.train_step(st, R.SubVP(), torch.tensor(batch), t.cpu(), z.cpu(), warmup=0, reduce_mean=reduce_mean,
+                                      likelihood_weighting=lw)
+        assert abs(float(out["step_loss"].detach()) - ref_loss.item()) / abs(ref_loss.item()) < 5e-5
+        for (n, prm), off in zip(m.named_parameters(), m._offsets):
+            assert rel_err(t2n(prm), st.p[n].numpy()) < 2e-5, (i, n)
+            assert rel_err(t2n(ema.shadow_params[names.index(n)]), st.ema[n].numpy()) < 2e-5, (i, n)
