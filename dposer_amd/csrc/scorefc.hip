@@ -207,9 +207,11 @@ extern "C" int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat, void* 
 // workspace layout
 // ------------------------------------------------------------------------------------------------
 static int64_t pad_batch(int64_t B) { return B <= 512 ? round_up(B, 64) : round_up(B, 256); }
-static int main_shape(int64_t Spad) {
+// `channels` = output channels of the GEMM (H = 1024 for the GroupNorm layers, E for the time branch): the 256x256 tiling
+// needs them to be a multiple of 256 (embed_dim may be any multiple of 128).
+static int main_shape(int64_t Spad, int channels = 1024) {
     static const int64_t big_min = [] { const char* e = getenv("DPOSER_BIG_MIN_BATCH"); return e ? atoll(e) : (int64_t)16384; }();
-    if (Spad % 256 == 0 && Spad >= big_min) return SHAPE_BIG;
+    if (Spad % 256 == 0 && Spad >= big_min && channels % 256 == 0) return SHAPE_BIG;
     if (Spad % 128 == 0) return SHAPE_MID;
     return SHAPE_SMALL;
 }
@@ -426,7 +428,7 @@ static int run_post(dposer_scorefc_s* h, const float* flat, const char* packed, 
 
 static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, const void* emb, void* temb, void* upre, void* tembT,
                     bool train, int64_t Bpad, hipStream_t st) {
-    const int shape = main_shape(Bpad);
+    const int shape = main_shape(Bpad, h->E);
     g_next_flops = 2.0 * (double)g_alg_batch * h->E * h->E;
     GemmArgs g = gemm_args(packed + h->pk_wse, h->E / h->KBS, h->E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
     add_seg(g, emb, h->E / h->KBS);
@@ -866,7 +868,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     if (!want_w) return DPOSER_OK;
     // time branch: dtemb = sum_l dy_l @ Wt_l ; dU = dtemb * silu'(u)
     {
-        const int shape = main_shape(Bpad);
+        const int shape = main_shape(Bpad, E);
         g_next_flops = 2.0 * (double)B * E * L * H;
         GemmArgs g = gemm_args(packed + h->pk_wtT_all, L * H / KBS, E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
         for (int l = 0; l < L; ++l) add_seg(g, w.dy[l], H / KBS);

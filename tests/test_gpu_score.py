@@ -681,3 +681,38 @@ def test_generic_step_path_matches_oracle(reduce_mean, lw):
         for (n, prm), off in zip(m.named_parameters(), m._offsets):
             assert rel_err(t2n(prm), st.p[n].numpy()) < 2e-5, (i, n)
             assert rel_err(t2n(ema.shadow_params[names.index(n)]), st.ema[n].numpy()) < 2e-5, (i, n)
+
+
+def test_embed_dim_not_multiple_of_256_at_large_batch():
+    """embed_dim = 384: the time-branch GEMMs must not take the 256-channel tiling at batch sizes where the GroupNorm layers do.
+    Forward and gradients at 16384 samples must agree with the same model evaluated in small chunks (which the oracle checks)."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.advanced.model import ScoreModelFC
+    from dposer_amd.configs import load_config
+    cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+    cfg.model.dropout = 0.0
+    torch.manual_seed(7)
+    m = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=1024, embed_dim=384, n_blocks=2)
+    m.precision = "fp32"
+    m.to(DEV).eval()
+    B = 16384
+    x = torch.randn(B, 63, device=DEV)
+    t = torch.rand(B, device=DEV) * 0.999 + 1e-3
+    z = torch.randn(B, 63, device=DEV)
+    with torch.no_grad():
+        full = m(x, t * 999)
+        parts = torch.cat([m(x[i:i + 200], t[i:i + 200] * 999) for i in range(0, B, 200)])
+    assert rel_err(t2n(full), t2n(parts)) < 2e-6
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    g_full = torch.zeros(m._num_flat, device=DEV)
+    l_full = losses.fused_dsm_grad(m, sde, x, flat_grad=g_full, t=t, z=z, seed=1, step=0)
+    g_sum = torch.zeros_like(g_full)
+    l_sum = 0.0
+    n_chunk = 0
+    for i in range(0, B, 1024):                       # mean over equal chunks of a mean-reduced loss
+        gi = torch.zeros_like(g_full)
+        l_sum += float(losses.fused_dsm_grad(m, sde, x[i:i + 1024], flat_grad=gi, t=t[i:i + 1024], z=z[i:i + 1024], seed=1, step=0))
+        g_sum += gi
+        n_chunk += 1
+    assert abs(float(l_full) - l_sum / n_chunk) / abs(l_sum / n_chunk) < 1e-5
+    assert rel_err(t2n(g_full), t2n(g_sum / n_chunk)) < 1e-4
