@@ -143,6 +143,12 @@ class _SMPLXCore(nn.Module):
         self.register_buffer("lmk_tri", torch.tensor(tri.astype(np.int32)))
         self.J, self.V = int(w.shape[1]), int(w.shape[0])
         self.n_extra, self.n_lmk = int(len(a["extra_joint_vertex_ids"])), int(len(a["lmk_faces_idx"]))
+        # the kernels gather vertices through these index tables without bounds checks
+        ids = np.asarray(a["extra_joint_vertex_ids"])
+        if ids.size and (ids.min() < 0 or ids.max() >= self.V):
+            raise ValueError(f"extra_joint_vertex_ids must lie in [0, {self.V}): got [{ids.min()}, {ids.max()}]")
+        if tri.size and (tri.min() < 0 or tri.max() >= self.V):
+            raise ValueError(f"landmark faces reference vertices outside [0, {self.V})")
         self._parents_np = np.asarray(a["parents"]).astype(np.int32)
         self._h = None
         self._posedirs_packed = None

@@ -41,7 +41,7 @@ def make_synthetic_smplx_asset(seed=0, num_vertices=10475, num_betas=10, num_exp
     lmk_bary_coords = (bary / bary.sum(axis=1, keepdims=True)).astype(np.float32)
     return dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, J_regressor=J_regressor,
                 parents=SMPLX_PARENTS.astype(np.int64), weights=weights, faces=faces, lmk_faces_idx=lmk_faces_idx,
-                lmk_bary_coords=lmk_bary_coords, extra_joint_vertex_ids=SMPLX_EXTRA_VERTEX_IDS.copy(),
+                lmk_bary_coords=lmk_bary_coords, extra_joint_vertex_ids=SMPLX_EXTRA_VERTEX_IDS.copy() % V,
                 num_betas=num_betas, num_expressions=num_expressions, model_type="smplx")
 
 
