@@ -15,14 +15,18 @@ def batch_rodrigues(rv):
     return I + s * K + (1 - c) * torch.bmm(K, K)
 
 
-def smplx_forward(asset, body_pose, betas=None, global_orient=None, transl=None):
+def smplx_forward(asset, body_pose, betas=None, global_orient=None, transl=None, expression=None, jaw_pose=None, leye_pose=None,
+                  reye_pose=None, left_hand_pose=None, right_hand_pose=None):
     dt = torch.float64
     t = lambda a: torch.as_tensor(a, dtype=dt)
     B = body_pose.shape[0]
     z = lambda n: torch.zeros(B, n, dtype=dt)
-    full = torch.cat([global_orient if global_orient is not None else z(3), body_pose, z(9), z(45), z(45)], dim=1)
+    opt = lambda a, n: a if a is not None else z(n)
+    # full_pose order of SMPLX.forward: global(1) body(21) jaw(1) leye(1) reye(1) lhand(15) rhand(15)
+    full = torch.cat([opt(global_orient, 3), body_pose, opt(jaw_pose, 3), opt(leye_pose, 3), opt(reye_pose, 3),
+                      opt(left_hand_pose, 45), opt(right_hand_pose, 45)], dim=1)
     nb, ne = asset["num_betas"], asset["num_expressions"]
-    shape = torch.cat([betas if betas is not None else z(nb), z(ne)], dim=1)
+    shape = torch.cat([opt(betas, nb), opt(expression, ne)], dim=1)
     v_shaped = t(asset["v_template"])[None] + torch.einsum("bl,mkl->bmk", shape, t(asset["shapedirs"]))
     J = torch.einsum("bik,ji->bjk", v_shaped, t(asset["J_regressor"]))
     nj = J.shape[1]

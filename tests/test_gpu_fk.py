@@ -260,3 +260,27 @@ def test_body_model_rejects_out_of_range_vertex_tables():
     bad["extra_joint_vertex_ids"][3] = 500
     with pytest.raises(ValueError, match="extra_joint_vertex_ids"):
         BodyModel(bad, model_type="smplx")
+
+
+def test_body_model_backward_all_pose_segments(bm, asset):
+    """Gradients w.r.t. every pose segment BodyModel.forward accepts (hands, jaw, eyes besides body / root) and the expression
+    coefficients -- the smplify-style fitting configuration."""
+    from oracle import fk_torch
+    B = 4
+    rs = np.random.RandomState(77)
+    mk = lambda n, s=0.3: (rs.standard_normal((B, n)) * s).astype(np.float32)
+    pose, root, hand, jaw, eye, expr = mk(63), mk(3), mk(90, 0.2), mk(3, 0.2), mk(6, 0.1), mk(10, 0.5)
+    dev = lambda a: torch.tensor(a, device=DEV, requires_grad=True)
+    d = [dev(a) for a in (pose, root, hand, jaw, eye, expr)]
+    out = bm(pose_body=d[0], root_orient=d[1], pose_hand=d[2], pose_jaw=d[3], pose_eye=d[4], expression=d[5])
+    wv = rs.standard_normal((B, 10475, 3)).astype(np.float32) / 100.0
+    wj = rs.standard_normal((B, 127, 3)).astype(np.float32)
+    ((out.v * torch.tensor(wv, device=DEV)).sum() + (out.Jtr * torch.tensor(wj, device=DEV)).sum()).backward()
+    ref = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    r = [ref(a) for a in (pose, root, hand, jaw, eye, expr)]
+    v, j = fk_torch.smplx_forward(asset, r[0], global_orient=r[1], left_hand_pose=r[2][:, :45], right_hand_pose=r[2][:, 45:], jaw_pose=r[3],
+                                  leye_pose=r[4][:, :3], reye_pose=r[4][:, 3:], expression=r[5])
+    ((v * torch.tensor(wv, dtype=torch.float64)).sum() + (j * torch.tensor(wj, dtype=torch.float64)).sum()).backward()
+    for name, got, want in zip(("pose", "root", "hand", "jaw", "eye", "expression"), d, r):
+        err = float(np.linalg.norm(t2n(got.grad) - want.grad.numpy()) / np.linalg.norm(want.grad.numpy()))
+        assert err < 2e-4, (name, err)
