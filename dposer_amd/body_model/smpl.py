@@ -32,7 +32,9 @@ class SMPLX(torch.nn.Module):
 
     def forward(self, *args, **kwargs):
         kwargs.pop("get_skin", None)
-        kwargs.pop("pose2rot", None)
+        if not kwargs.pop("pose2rot", True):
+            raise NotImplementedError("pose2rot=False (rotation-matrix inputs) is not built: pass axis-angle poses "
+                                      "(utils.transforms.rotmat_to_axis_angle converts)")
         o = self.bm(*args, **kwargs)
         joints = o.joints[:, self.joint_map.to(o.joints.device), :]    # bit-exact gather (smpl.py:70)
         return SMPLOutput(vertices=o.vertices, global_orient=o.global_orient, body_pose=o.body_pose, joints=joints,
