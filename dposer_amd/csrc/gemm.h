@@ -17,6 +17,8 @@
 // T = __bf16 : v_mfma_f32_32x32x16_bf16 (fp32 accumulate)       -- throughput mode
 // T = float  : v_mfma_f32_32x32x2_f32   (exact fp32 fma chain)  -- parity mode
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 constexpr int GEMM_MAX_SEG = 8;
@@ -102,12 +104,20 @@ template <typename Epi> struct EpiScratch<Epi, decltype((void)Epi::kScratchPerWa
 // latency hides under the matrix pipe (left to itself hipcc reuses one fragment register set and serialises
 // read -> wait -> MFMA per k-block).  The stage barrier sits in front of the LAST MFMA group of a stage, followed by
 // the DMA issue of stage t+2 and the first fragment reads of stage t+1.
-// Variants that were built and measured without gain (3/4/8-deep rings with counted vmcnt, DMA issue interleaved
-// between MFMA groups under s_setprio, register staging, persistent workgroups) are described in DESIGN.md 4.1.
+// NB = 2 is that loop.  NB > 2 selects the RING pipeline the large tilings use: NB slots of KB k-blocks; the DMA of
+// stage t+NB-1 goes to the slot stage t-1 used (freed by the barrier that ended it) and is issued in single pieces
+// BETWEEN the MFMAs of stage t (weights in the groups before the barrier, activations after it), together with the
+// ds_reads of the next k-block, under an explicit sched_group_barrier pattern.  Why: `tools/gemm_ablate.hip` shows the
+// 2-slot loop loses ~25 % to the DMA issue burst -- after each barrier every wave sits ~450-970 cycles in VMEM issue
+// (64 KiB per CU through the 64 B/clk vector-memory path) with no MFMA behind it, while DMA latency itself costs
+// ~50 cycles per stage; spreading the pieces removes the burst (+9-11 % on the 256x256 loop, bit-identical results).
+// Variants that were built and measured without gain (DMA issue interleaved between MFMA GROUPS under s_setprio,
+// delayed DMA issue for the second wave of each SIMD, register staging, persistent workgroups) are in DESIGN.md 4.1.
 // Epi::apply(params, acc, channel_base, sample_base, lane, wave row id, split, staged params, stride, scratch).
-template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi>
+template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int NB = 2>
 __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_ft_kernel(GemmArgs g, typename Epi::Params ep) {
     static_assert(KB % 2 == 0, "fragment double buffering assumes an even number of k-blocks per stage");
+    static_assert(NB >= 2 && NB <= 4, "ring depth");
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
     typedef typename Mma<T>::Frag Frag;
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -134,7 +144,7 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     const int sblk = L / g.n_cblk;
 
     constexpr int NPAR = EpiParamArrays<Epi>::value;
-    float* lds_par = reinterpret_cast<float*>(smem + 2 * C::STAGE_BYTES);   // [NPAR][CT*32]
+    float* lds_par = reinterpret_cast<float*>(smem + NB * C::STAGE_BYTES);   // [NPAR][CT*32]
     if constexpr (NPAR > 0) {
         for (int i = threadIdx.x; i < NPAR * C::CT * 32; i += C::THREADS) {
             const int a = i / (C::CT * 32), c = i % (C::CT * 32);
@@ -179,7 +189,7 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     }
     const unsigned char* sbase = seg_ptr(0);
 
-    auto fetch_glds = [&](int buf) __attribute__((always_inline)) {
+    auto fetch_w = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::LPW_A; ++i) {
             const int blk = wave + i * C::NW;
@@ -188,6 +198,8 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
                                      (((int64_t)(cblk * C::CT + rb) * g.w_stride_blocks + w_kb + kb) << 10);
             __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + (blk << 10)), 16, 0, 0);
         }
+    };
+    auto fetch_x = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::LPW_B; ++i) {
             const int blk = wave + i * C::NW;
@@ -195,6 +207,8 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
             const unsigned char* p = sbase + (((int64_t)(sblk * C::ST + rb) * seg_total + seg_kb + kb) << 10);
             __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + ((C::CT * KB + blk) << 10)), 16, 0, 0);
         }
+    };
+    auto fetch_advance = [&]() __attribute__((always_inline)) {
         seg_kb += KB;
         w_kb += KB;
         if (seg_kb >= seg_end && seg + 1 < g.nseg) {
@@ -204,6 +218,11 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
             seg_end = seg_total;
             sbase = seg_ptr(seg);
         }
+    };
+    auto fetch_glds = [&](int buf) __attribute__((always_inline)) {
+        fetch_w(buf);
+        fetch_x(buf);
+        fetch_advance();
     };
 
     Frag fa[2][TC], fb[2][TS];
@@ -222,30 +241,96 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
             for (int j = 0; j < TS; ++j) Mma<T>::run(fa[set][i], fb[set][j], acc[i][j]);
     };
 
-    fetch_glds(0);
-    if (nstages > 1) fetch_glds(1);
-    if (nstages > 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(C::LPW)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
-    __syncthreads_lds_only();
-    load_frags(0, 0, 0);
-    for (int t = 0; t < nstages; ++t) {
-        const int buf = t & 1;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            if (kb + 1 < KB) {
-                load_frags(buf, kb + 1, (kb + 1) & 1);
-            } else if (t + 1 < nstages) {
-                // stage t+1 must have landed (its DMA was issued one full stage ago); every wave is done reading buf
-                __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (t + 2 < nstages) fetch_glds(buf);            // refill the buffer we just finished reading
-                load_frags(buf ^ 1, 0, 0);
+    if constexpr (NB == 2) {
+        fetch_glds(0);
+        if (nstages > 1) fetch_glds(1);
+        if (nstages > 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(C::LPW)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+        __syncthreads_lds_only();
+        load_frags(0, 0, 0);
+        for (int t = 0; t < nstages; ++t) {
+            const int buf = t & 1;
+    #pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                if (kb + 1 < KB) {
+                    load_frags(buf, kb + 1, (kb + 1) & 1);
+                } else if (t + 1 < nstages) {
+                    // stage t+1 must have landed (its DMA was issued one full stage ago); every wave is done reading buf
+                    __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (t + 2 < nstages) fetch_glds(buf);            // refill the buffer we just finished reading
+                    load_frags(buf ^ 1, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma(kb & 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            mma(kb & 1);
-            __builtin_amdgcn_sched_barrier(0);
         }
+    } else {
+        constexpr int PRE = NB - 1;                             // stages in flight ahead of the one being computed
+        constexpr int NM = TC * TS * (sizeof(T) == 4 ? 4 : 1);  // MFMA instructions per k-block
+        // one MFMA group's issue order: MFMA, ds_read (while they last), and NV DMA pieces spread evenly
+        auto pattern = [&](auto nv) __attribute__((always_inline)) {
+            constexpr int NV = decltype(nv)::value;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < TC + TS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (NV > 0 && (i * NV) / NM != ((i + 1) * NV) / NM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+        };
+        const int npre = nstages < PRE ? nstages : PRE;
+        for (int s0 = 0; s0 < npre; ++s0) fetch_glds(s0);
+        // stage 0 landed?  VMEM returns in order: all but the last npre-1 stages
+        if (npre >= 3) __builtin_amdgcn_s_waitcnt(waitcnt_vm(2 * C::LPW));
+        else if (npre == 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(C::LPW));
+        else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+        __syncthreads_lds_only();
+        load_frags(0, 0, 0);
+        int slot = 0;          // slot of the stage being computed
+        int fill = PRE;        // slot the stage fetched now goes to (= the slot of stage t-1)
+        // DMA: fetch stage t+PRE while computing; ALLOW: DMA pieces that may still be in flight at the barrier
+        // (everything issued after stage t+1); LAST: no following stage
+        auto stage = [&](auto dma, auto allow, auto last) __attribute__((always_inline)) {
+            constexpr bool DMA = decltype(dma)::value, LAST = decltype(last)::value;
+            constexpr int ALLOW = decltype(allow)::value;
+            const int nslot = (slot + 1 == NB) ? 0 : slot + 1;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                if (kb + 1 < KB) {
+                    load_frags(slot, kb + 1, (kb + 1) & 1);
+                    if (DMA && kb == 0) fetch_w(fill);
+                    mma(kb & 1);
+                    if (kb == 0) pattern(std::integral_constant<int, DMA ? C::LPW_A : 0>{});
+                    else pattern(std::integral_constant<int, 0>{});
+                } else if constexpr (!LAST) {
+                    // stage t+1 has landed for this wave, and this wave is done reading `slot`
+                    __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(ALLOW));
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    load_frags(nslot, 0, 0);
+                    if constexpr (DMA) { fetch_x(fill); fetch_advance(); }
+                    mma(kb & 1);
+                    pattern(std::integral_constant<int, DMA ? C::LPW_B : 0>{});
+                } else {
+                    mma(kb & 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slot = nslot;
+            fill = (fill + 1 == NB) ? 0 : fill + 1;
+        };
+        typedef std::true_type Y;
+        typedef std::false_type N;
+        int t = 0;
+        for (; t + PRE < nstages; ++t) stage(Y{}, std::integral_constant<int, (PRE - 2) * C::LPW + C::LPW_A>{}, N{});
+        if constexpr (PRE >= 3) {
+            if (nstages - t >= 3) { stage(N{}, std::integral_constant<int, C::LPW>{}, N{}); ++t; }
+        }
+        if (nstages - t >= 2) { stage(N{}, std::integral_constant<int, 0>{}, N{}); ++t; }
+        stage(N{}, std::integral_constant<int, 0>{}, Y{});
     }
 
     unsigned char* wave_scratch = reinterpret_cast<unsigned char*>(lds_par + NPAR * C::CT * 32) + wave * EpiScratch<Epi>::value;
@@ -253,11 +338,11 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
                                 sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32, wave_scratch);
 }
 
-template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi>
+template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int NB = 2>
 static inline hipError_t launch_gemm(const GemmArgs& g, const typename Epi::Params& ep, hipStream_t stream) {
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
-    auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi>;
-    constexpr int lds_bytes = 2 * C::STAGE_BYTES + EpiParamArrays<Epi>::value * C::CT * 32 * 4 + EpiScratch<Epi>::value * C::NW;
+    auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi, NB>;
+    constexpr int lds_bytes = NB * C::STAGE_BYTES + EpiParamArrays<Epi>::value * C::CT * 32 * 4 + EpiScratch<Epi>::value * C::NW;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && lds_bytes > 64 * 1024) {

@@ -3,7 +3,7 @@
 #include "epilogues.h"
 #include "gemm.h"
 
-// Workgroup tilings (channels x samples), all with K-stage depth KB = 4 FT blocks:
+// Workgroup tilings (channels x samples); K pipeline = ring of 4 slots x 2 FT k-blocks (128 x 32: 2 slots x 4):
 enum GemmShape : int {
     SHAPE_BIG = 0,      // 256 x 256, 8 waves (2x4), wave tile 128 x 64    -- large batches
     SHAPE_MID = 1,      // 128 x 128, 4 waves (2x2), wave tile  64 x 64

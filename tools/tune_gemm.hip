@@ -36,8 +36,8 @@ void add_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void
     PlainFTParams p;
     p.out = out; p.N = C;
     char buf[160];
-    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d  plain", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB);
-    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiPlainFT<__bf16>>(g, p, 0))); }, 2.0 * S * C * K, {}});
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d NB%d plain", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS < 2 ? 2 : GLDS);
+    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiPlainFT<__bf16>, (GLDS < 2 ? 2 : GLDS)>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
 template <int WC, int WS, int TC, int TS, int KB, int GLDS, bool TRAIN = false>
@@ -52,8 +52,8 @@ void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* o
     p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C; p.Spad = S;
     if (TRAIN) { p.xhat = xhat; p.rstd = rstd; p.outT = outT; }
     char buf[160];
-    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d  %s", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, TRAIN ? "gn-train" : "gn");
-    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, TRAIN>>(g, p, 0))); }, 2.0 * S * C * K, {}});
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d NB%d %s", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS < 2 ? 2 : GLDS, TRAIN ? "gn-train" : "gn");
+    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, TRAIN>, (GLDS < 2 ? 2 : GLDS)>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
 template <int WC, int WS, int TC, int TS, int KB, bool TRAIN = false>
@@ -100,9 +100,9 @@ void add_gnbwd(const char* name, int64_t S, int C, int K, void* Wt, void* dyn, v
     p.H = C; p.S_valid = S; p.dyT = dyT; p.Spad = S;
     if (drop_p > 0.f) { p.drop.p = drop_p; p.drop.scale = 1.f / (1.f - drop_p); p.drop.thr = (uint32_t)((1.0 - drop_p) * 65536.0); p.drop.groups_x4 = C / 8; p.drop.seed = 7; }
     char buf[160];
-    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d  gnbwd drop%d T%d carry%d%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, drop_p > 0.f,
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d NB%d gnbwd drop%d T%d carry%d%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS < 2 ? 2 : GLDS, drop_p > 0.f,
              dyT != nullptr, carry_in != nullptr, carry_out != nullptr);
-    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGNBwd<__bf16>>(g, p, 0))); }, 2.0 * S * C * K, {}});
+    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGNBwd<__bf16>, (GLDS < 2 ? 2 : GLDS)>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
 static void run_all(int rounds, int reps) {
@@ -207,6 +207,18 @@ int main(int argc, char** argv) {
         }
         PL(2, 2, 2, 2, 4, 1);
         PL(4, 2, 2, 2, 4, 1);
+        run_all(7, 10);
+        return 0;
+    }
+    if (getenv("TUNE_RING")) {       // 2-slot loop vs ring pipeline, per epilogue and tiling
+        PL(2, 4, 4, 2, 4, 1);  PL(2, 4, 4, 2, 2, 4);  PL(2, 4, 4, 2, 2, 3);
+        PL(2, 2, 2, 2, 4, 1);  PL(2, 2, 2, 2, 2, 4);
+        GN(2, 4, 4, 2, 4, 1);  GN(2, 4, 4, 2, 2, 4);
+        GN(2, 2, 2, 2, 4, 1);  GN(2, 2, 2, 2, 2, 4);
+        GNT(2, 4, 4, 2, 4, 1); GNT(2, 4, 4, 2, 2, 4);
+        GNT(2, 2, 2, 2, 4, 1); GNT(2, 2, 2, 2, 2, 4);
+        GB(2, 4, 4, 2, 4, 1, 1, 1, 0, 0); GB(2, 4, 4, 2, 2, 4, 1, 1, 0, 0);
+        GB(2, 2, 2, 2, 4, 1, 1, 1, 0, 0); GB(2, 2, 2, 2, 2, 4, 1, 1, 0, 0);
         run_all(7, 10);
         return 0;
     }
