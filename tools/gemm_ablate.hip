@@ -29,6 +29,8 @@ enum : int {
     W_ONLY = 32,     // DMA fetches only the weight half of a stage
     X_ONLY = 64,     // DMA fetches only the activation half of a stage
     TIMING = 256,    // s_memtime stamps around the vmcnt wait, the barrier and the DMA issue (written to a debug buffer)
+    CLK = 1024,      // ring: s_memtime around the whole K loop (mean cycles per tile printed) -- separates stall cycles from clock drops
+    HALF_LOAD = 512, // ring: waves 0..NW/2-1 (one per SIMD) issue all DMA pieces, their SIMD partners only compute
     FINE = 128,      // DMA / ds_read instructions interleaved one-by-one with the MFMAs of the group they precede
 };
 
@@ -238,29 +240,31 @@ __global__ void __launch_bounds__(WC* WS * 64, 1) ring_kernel(GemmArgs g, PlainF
     const int nstages = g.ktot_blocks / KB;
     // per-wave DMA source pointers (advance by one stage = KB KiB per call)
     const unsigned voff = lane * 16;
-    const unsigned char* wsrc[C::LPW_A];
-    const unsigned char* xsrc[C::LPW_B];
+    constexpr int NL = (ABL & HALF_LOAD) ? C::NW / 2 : C::NW;   // loader waves (HALF_LOAD: one per SIMD; its partner only computes)
+    constexpr int LA = C::CT * KB / NL, LB = C::ST * KB / NL, LP = LA + LB;
+    const unsigned char* wsrc[LA];
+    const unsigned char* xsrc[LB];
 #pragma unroll
-    for (int i = 0; i < C::LPW_A; ++i) {
-        const int blk = wave + i * C::NW, rb = blk / KB, kb = blk % KB;
+    for (int i = 0; i < LA; ++i) {
+        const int blk = wave + i * NL, rb = blk / KB, kb = blk % KB;
         wsrc[i] = reinterpret_cast<const unsigned char*>(g.W) + (((int64_t)(cblk * C::CT + rb) * g.w_stride_blocks + kb) << 10);
     }
 #pragma unroll
-    for (int i = 0; i < C::LPW_B; ++i) {
-        const int blk = wave + i * C::NW, rb = blk / KB, kb = blk % KB;
+    for (int i = 0; i < LB; ++i) {
+        const int blk = wave + i * NL, rb = blk / KB, kb = blk % KB;
         xsrc[i] = reinterpret_cast<const unsigned char*>(g.src[0]) + (((int64_t)(sblk * C::ST + rb) * seg_total + kb) << 10);
     }
     auto dma_w = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < C::LPW_A; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + voff), (lptr_t)(smem + slot * C::STAGE_BYTES + ((wave + i * C::NW) << 10)), 16, 0, 0);
+        for (int i = 0; i < LA; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + voff), (lptr_t)(smem + slot * C::STAGE_BYTES + ((wave + i * NL) << 10)), 16, 0, 0);
             if constexpr (!(ABL & SAME_ADDR)) wsrc[i] += KB << 10;
         }
     };
     auto dma_x = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < C::LPW_B; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + voff), (lptr_t)(smem + slot * C::STAGE_BYTES + ((C::CT * KB + wave + i * C::NW) << 10)), 16, 0, 0);
+        for (int i = 0; i < LB; ++i) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + voff), (lptr_t)(smem + slot * C::STAGE_BYTES + ((C::CT * KB + wave + i * NL) << 10)), 16, 0, 0);
             if constexpr (!(ABL & SAME_ADDR)) xsrc[i] += KB << 10;
         }
     };
@@ -291,11 +295,13 @@ __global__ void __launch_bounds__(WC* WS * 64, 1) ring_kernel(GemmArgs g, PlainF
     };
 
     constexpr int PRE = NB - 1;   // stages in flight ahead of the one being computed
+    auto run = [&](auto is_loader) __attribute__((always_inline)) {
+    constexpr bool LOADER = decltype(is_loader)::value;
 #pragma unroll
     for (int s0 = 0; s0 < PRE; ++s0)
-        if (s0 < nstages) { dma_w(s0); dma_x(s0); }
+        if (s0 < nstages && LOADER) { dma_w(s0); dma_x(s0); }
     // stage 0 landed?  (in-order VMEM return: everything but the last PRE-1 stages)
-    if (nstages >= PRE) __builtin_amdgcn_s_waitcnt(waitcnt_vm((PRE - 1) * C::LPW)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    if (nstages >= PRE) __builtin_amdgcn_s_waitcnt(waitcnt_vm((PRE - 1) * LP)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
     __syncthreads_lds_only();
     load_frags(0, 0, 0);
 
@@ -303,18 +309,18 @@ __global__ void __launch_bounds__(WC* WS * 64, 1) ring_kernel(GemmArgs g, PlainF
     int fill = PRE % NB;       // slot the DMA of this stage goes to (the one stage t-1 used)
     // steady state: stage t computes, stage t+PRE is fetched
     auto stage = [&](auto dma, auto last) __attribute__((always_inline)) {
-        constexpr bool DMA = decltype(dma)::value && !(ABL & NO_GLDS), LAST = decltype(last)::value;
+        constexpr bool DMA = decltype(dma)::value && !(ABL & NO_GLDS) && LOADER, LAST = decltype(last)::value;
         constexpr bool DMAW = DMA && !(ABL & X_ONLY), DMAX = DMA && !(ABL & W_ONLY);
         const int nslot = (slot + 1 == NB) ? 0 : slot + 1;
         // group A: fragments of k-block 1, W pieces of the new stage
         load_frags(slot, 1, 1);
         if constexpr (DMAW) dma_w(fill);
         mma(0);
-        pattern(std::integral_constant<int, DMAW ? C::LPW_A : 0>{});
+        pattern(std::integral_constant<int, DMAW ? LA : 0>{});
         __builtin_amdgcn_sched_barrier(0);
         // group B: next stage must have landed for every wave, and every wave is done reading this slot
         if constexpr (!LAST) {
-            if constexpr (DMAW && DMAX) __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0((PRE - 2) * C::LPW + C::LPW_A));
+            if constexpr (DMAW && DMAX) __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0((PRE - 2) * LP + LA));
             else __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(0));
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -322,7 +328,7 @@ __global__ void __launch_bounds__(WC* WS * 64, 1) ring_kernel(GemmArgs g, PlainF
             load_frags(nslot, 0, 0);
             if constexpr (DMAX) dma_x(fill);
             mma(1);
-            pattern(std::integral_constant<int, DMAX ? C::LPW_B : 0>{});
+            pattern(std::integral_constant<int, DMAX ? LB : 0>{});
         } else {
             mma(1);
         }
@@ -336,6 +342,10 @@ __global__ void __launch_bounds__(WC* WS * 64, 1) ring_kernel(GemmArgs g, PlainF
         for (; t + 1 < nstages; ++t) stage(std::false_type{}, std::false_type{});
         stage(std::false_type{}, std::true_type{});
     }
+    };
+    const uint64_t clk0 = (ABL & CLK) ? __builtin_amdgcn_s_memtime() : 0;
+    if ((ABL & HALF_LOAD) && wave >= NL) run(std::false_type{}); else run(std::true_type{});
+    if constexpr (ABL & CLK) { const uint64_t d = __builtin_amdgcn_s_memtime() - clk0; if (lane == 0) g_timing[(size_t)blockIdx.x * C::NW + wave] = d; }
     if constexpr (ABL & NO_EPI) {
         float s = 0.f;
 #pragma unroll
@@ -415,6 +425,11 @@ int main(int argc, char** argv) {
     add<NO_EPI | TIMING>("no epi, timing stamps", S, Cc, K, W, X, o);
     add_ring<2, 4, 4, 2, 4, 0>("ring 4x32K, plain FT store", S, Cc, K, W, X, o2);
     add_ring<2, 4, 4, 2, 4, NO_EPI>("ring 4x32K, no epi", S, Cc, K, W, X, o2);
+    add_ring<2, 4, 4, 2, 4, NO_EPI | CLK>("clk ring", S, Cc, K, W, X, o2);
+    add_ring<2, 4, 4, 2, 4, NO_EPI | CLK | NO_GLDS>("clk ring no DMA", S, Cc, K, W, X, o2);
+    add_ring<2, 4, 4, 2, 4, NO_EPI | CLK | SAME_ADDR>("clk ring same addr", S, Cc, K, W, X, o2);
+    add_ring<2, 4, 4, 2, 4, HALF_LOAD>("ring 4x32K, half loaders, plain FT store", S, Cc, K, W, X, o2);
+    add_ring<2, 4, 4, 2, 4, NO_EPI | HALF_LOAD>("ring 4x32K, half loaders, no epi", S, Cc, K, W, X, o2);
     add_ring<2, 4, 4, 2, 4, NO_EPI | NO_GLDS>("ring 4x32K, no epi, no DMA", S, Cc, K, W, X, o2);
     add_ring<2, 4, 4, 2, 4, NO_EPI | SAME_ADDR>("ring 4x32K, no epi, same addr", S, Cc, K, W, X, o2);
     add_ring<2, 4, 4, 2, 4, NO_EPI | W_ONLY>("ring 4x32K, no epi, W only", S, Cc, K, W, X, o2);
@@ -452,6 +467,17 @@ int main(int argc, char** argv) {
         std::sort(c.us.begin(), c.us.end());
         const double mn = c.us.front(), md = c.us[c.us.size() / 2];
         printf("%-48s min %7.1f us (%6.0f TF)  median %7.1f us (%6.0f TF)\n", c.name.c_str(), mn, c.flops / mn * 1e-6, md, c.flops / md * 1e-6);
+    }
+    for (auto& c : g_cases) if (c.name.find("clk ") == 0) {
+        c.launch();
+        CK(hipDeviceSynchronize());
+        const int nblk = (int)(S / 256) * (Cc / 256);
+        std::vector<unsigned long long> h((size_t)nblk * 8);
+        CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_timing), h.size() * 8));
+        double tot = 0;
+        for (auto v : h) tot += v;
+        const double cyc = tot / h.size(), us = c.us[c.us.size() / 2];
+        printf("%-24s K loop %9.0f s_memtime ticks per tile; kernel %7.1f us for %d tiles per CU -> >= %.2f ticks/ns\n", c.name.c_str(), cyc, us, nblk / 256, cyc * (nblk / 256) / (us * 1e3));
     }
     {   // per-wave stall breakdown of the TIMING variant (s_memtime ticks = 100 MHz constant clock)
         for (auto& c : g_cases) if (c.name.find("timing") != std::string::npos) { c.launch(); break; }
