@@ -649,14 +649,15 @@ struct SkinBwdArgs {
     int Cpad;
 };
 __global__ void __launch_bounds__(256) k_skin_bwd(SkinBwdArgs a) {
-    extern __shared__ float sA[];       // [J][12] transforms of this pose, then [768] staging of the block's d_off values
+    extern __shared__ float sA[];       // [J][12] transforms of this pose, then 2 x [768] staging of the block's d_off / vp values
     float* stage = sA + a.J * 12;
+    float* stage_vp = stage + 768;
     const int64_t b = blockIdx.y;
     for (int i = threadIdx.x; i < a.J * 12; i += 256) sA[i] = a.A[b * a.J * 12 + i];
     __syncthreads();
     for (int v0 = blockIdx.x * 256; v0 < a.V; v0 += gridDim.x * 256) {
         const int v = v0 + threadIdx.x;
-        float g[3] = {0.f, 0.f, 0.f};
+        float g[3] = {0.f, 0.f, 0.f}, p[3] = {0.f, 0.f, 0.f};
         if (v < a.V) {
             const float* vs = a.v_shaped + (a.v_shaped_batched ? b * a.V * 3 : 0) + (int64_t)v * 3;
             const float* off = a.offsets + b * a.ld_off + (int64_t)v * 3;
@@ -676,17 +677,22 @@ __global__ void __launch_bounds__(256) k_skin_bwd(SkinBwdArgs a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) g[c] = T[c] * dx + T[3 + c] * dy + T[6 + c] * dz;     // T_R^T dv
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                a.vp[(b * a.V + v) * 3 + c] = vs[c] + off[c];
-                a.dvp[(b * a.V + v) * 3 + c] = g[c];
-            }
+            for (int c = 0; c < 3; ++c) p[c] = vs[c] + off[c];
         }
-        // the GEMM operand copy (FT32 [Bpad][Cpad]) is written as whole 16-byte quads: stage the block's 768 consecutive
-        // coordinates in LDS, then one thread per quad (4-byte stores into that layout cost 3x the HBM write traffic)
+        // All three outputs leave through LDS: the block's 768 consecutive coordinates are staged, then stored as
+        // consecutive dwords (vp, dvp: [B][V][3], rows not 16-byte aligned) and as whole 16-byte quads (the FT32 GEMM
+        // operand).  Per-thread 3 x 4-byte stores at a 12-byte stride cost 1.8x the HBM write traffic (PMC WRITE_SIZE).
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 3; ++c) stage[threadIdx.x * 3 + c] = g[c];
+        for (int c = 0; c < 3; ++c) { stage[threadIdx.x * 3 + c] = g[c]; stage_vp[threadIdx.x * 3 + c] = p[c]; }
         __syncthreads();
+        const int64_t row = (b * a.V + v0) * 3;
+        const int nval = (a.V - v0 < 256 ? a.V - v0 : 256) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = i * 256 + threadIdx.x;
+            if (k < nval) { a.vp[row + k] = stage_vp[k]; a.dvp[row + k] = stage[k]; }
+        }
         if (threadIdx.x < 192) {
             const int kq = v0 * 3 + threadIdx.x * 4;                                         // first coordinate of this quad
             if (kq < a.Cpad) {
@@ -707,11 +713,17 @@ struct JointBwdArgs {
     const float* jw;           // [nnz]
     float* dA;                 // [B][J][12]
     int J, V;
+    int64_t B;
 };
 __global__ void __launch_bounds__(128) k_skin_bwd_joints(JointBwdArgs a) {
     __shared__ float red[128][13];
-    const int j = blockIdx.x;
-    const int64_t b = blockIdx.y;
+    // XCD-aware order (hardware XCD = linear block id % 8): all J joints of one pose run back to back on ONE XCD, so the
+    // pose's dverts / vp rows (2 x 12 B x V, gathered joint by joint) come from HBM once and from that XCD's L2 afterwards.
+    // With the plain (joint, pose) grid every XCD touched every pose: 14.4 GB of HBM reads per launch at B = 4096.
+    const int64_t q = blockIdx.x >> 3;
+    const int j = (int)(q % a.J);
+    const int64_t b = (q / a.J) * 8 + (blockIdx.x & 7);
+    if (b >= a.B) return;
     float acc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.f;
@@ -979,13 +991,13 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
         a.skin_idx = skin_idx; a.skin_w = skin_w; a.K = skin_k; a.J = J; a.V = V; a.vp = vp; a.dvp = d_vposed ? d_vposed : dvp; a.doff_ft = doff;
         a.Cpad = (int)Cpad;
-        hipLaunchKernelGGL(k_skin_bwd, dim3((unsigned)ceil_div(V, 256 * 4), (unsigned)batch), dim3(256), (J * 12 + 768) * sizeof(float), st, a);
+        hipLaunchKernelGGL(k_skin_bwd, dim3((unsigned)ceil_div(V, 256 * 4), (unsigned)batch), dim3(256), (J * 12 + 1536) * sizeof(float), st, a);
         FK_HIP_LAUNCH(hipGetLastError());
     }
     {
         JointBwdArgs a;
-        a.dverts = d_verts; a.vp = vp; a.jptr = joint_ptr; a.jvidx = joint_vidx; a.jw = joint_w; a.dA = dA; a.J = J; a.V = V;
-        hipLaunchKernelGGL(k_skin_bwd_joints, dim3((unsigned)J, (unsigned)batch), dim3(128), 0, st, a);
+        a.dverts = d_verts; a.vp = vp; a.jptr = joint_ptr; a.jvidx = joint_vidx; a.jw = joint_w; a.dA = dA; a.J = J; a.V = V; a.B = batch;
+        hipLaunchKernelGGL(k_skin_bwd_joints, dim3((unsigned)(ceil_div(batch, 8) * 8 * J)), dim3(128), 0, st, a);
         FK_HIP_LAUNCH(hipGetLastError());
     }
     // d pose_feature [B][486] = d_off [B][3V] @ posedirs^T : fp32 MFMA, split over the vertex dimension

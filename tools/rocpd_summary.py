@@ -53,6 +53,28 @@ def main(path):
         print(f"| `{short(n)}` | {c} | {s / 1e6:.3f} | {s / c / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | {100.0 * s / tot:.2f} |")
 
 
+def gaps(path):
+    """Idle time between consecutive kernels (start[i+1] - end[i]) grouped by the kernel that follows the gap."""
+    cur = sqlite3.connect(path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = list(cur.execute(f"select {name_col}, start, end from kernels order by start"))
+    agg = {}
+    for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
+        g = s1 - e0
+        if g > 200000:      # host-side pauses (phase changes, synchronisations) are not launch gaps
+            continue
+        a = agg.setdefault(short(n1), [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += g
+        a[2] += e1 - s1
+    print(f"# gaps between consecutive kernels ({path}); gaps > 200 us (host pauses) skipped\n")
+    print("| kernel (the one AFTER the gap) | n | mean gap before it us | mean duration us | gap / duration |")
+    print("|---|---:|---:|---:|---:|")
+    for k, (n, g, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+        print(f"| `{k}` | {n} | {g / n / 1e3:.2f} | {d / n / 1e3:.1f} | {g / max(d, 1):.3f} |")
+
+
 def _pmc_agg(paths):
     agg = {}
     for path in paths:
@@ -109,6 +131,9 @@ def counters(paths):
         print(f"| `{k}` | {n} | " + " | ".join(f"{v[c][1]:.4g}" if c in v else "" for c in names) + " |")
 
 
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--gaps":
+    gaps(sys.argv[2])
+    sys.exit(0)
 if __name__ == "__main__":
     if sys.argv[1] == "--pmc":
         pmc(sys.argv[2:])
