@@ -24,6 +24,7 @@ int dposer_set_error(int code, const std::string&) { return code; }
 #include <functional>
 struct Case { std::string name; std::function<void()> launch; double flops; std::vector<double> us; };
 static std::vector<Case> g_cases;
+static float g_drop_p = 0.f;   // TUNE_DROP=0.1: the gn-train cases draw dropout masks
 
 template <int WC, int WS, int TC, int TS, int KB, int GLDS>
 void add_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void* out) {
@@ -51,6 +52,7 @@ void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* o
     memset(&p, 0, sizeof(p));
     p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C; p.Spad = S;
     if (TRAIN) { p.xhat = xhat; p.rstd = rstd; p.outT = outT; }
+    if (TRAIN && g_drop_p > 0.f) { p.drop.p = g_drop_p; p.drop.scale = 1.f / (1.f - g_drop_p); p.drop.thr = (uint32_t)((1.0 - g_drop_p) * 65536.0); p.drop.groups_x4 = C / 8; p.drop.seed = 7; }
     char buf[160];
     snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d NB%d %s", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS < 2 ? 2 : GLDS, TRAIN ? "gn-train" : "gn");
     g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGN<__bf16, TRAIN>, (GLDS < 2 ? 2 : GLDS)>(g, p, 0))); }, 2.0 * S * C * K, {}});
@@ -207,6 +209,35 @@ int main(int argc, char** argv) {
         }
         PL(2, 2, 2, 2, 4, 1);
         PL(4, 2, 2, 2, 4, 1);
+        run_all(7, 10);
+        return 0;
+    }
+    if (getenv("TUNE_TAILS")) {      // ring prologue / tail paths: 1..6 stages, ring (NB 4 and 3) against the 2-slot loop, bit for bit
+        size_t total_bad = 0;
+        for (int Kt = 32; Kt <= 192 && Kt <= K; Kt += 32) {
+            g_cases.clear();
+            add_plain<2, 2, 2, 2, 2, 2>("ref", S, C, Kt, W, X, o0);
+            add_plain<2, 2, 2, 2, 2, 4>("ring4", S, C, Kt, W, X, o1);
+            add_plain<2, 4, 4, 2, 2, 3>("ring3", S, C, Kt, W, X, xhat);
+            CK(hipMemset(o0, 0, (size_t)S * C * 2)); CK(hipMemset(o1, 0xff, (size_t)S * C * 2)); CK(hipMemset(xhat, 0xee, (size_t)S * C * 2));
+            for (auto& c : g_cases) c.launch();
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned short> h0((size_t)S * C), h1((size_t)S * C), h2((size_t)S * C);
+            CK(hipMemcpy(h0.data(), o0, h0.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h2.data(), xhat, h2.size() * 2, hipMemcpyDeviceToHost));
+            size_t bad1 = 0, bad2 = 0, nz = 0;
+            for (size_t i = 0; i < h0.size(); ++i) { bad1 += h0[i] != h1[i]; bad2 += h0[i] != h2[i]; nz += h0[i] != 0; }
+            printf("K = %3d (%d stages): ring NB4 128x128 %zu mismatches, ring NB3 256x256 %zu mismatches of %zu (%zu non-zero)\n", Kt, Kt / 32, bad1, bad2, h0.size(), nz);
+            total_bad += bad1 + bad2;
+        }
+        printf(total_bad ? "TAILS FAILED\n" : "TAILS OK\n");
+        return total_bad != 0;
+    }
+    if (getenv("TUNE_DROPCOST")) {   // what do the Philox dropout draws cost in the training-forward epilogue?
+        GNT(2, 4, 4, 2, 2, 4);
+        g_drop_p = 0.1f;
+        GNT(2, 4, 4, 2, 2, 4);
+        g_cases.back().name += " +dropout";
         run_all(7, 10);
         return 0;
     }
