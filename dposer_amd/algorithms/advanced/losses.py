@@ -35,6 +35,7 @@ class FusedAdam(optim.Adam):
             raise NotImplementedError("FusedAdam: weight_decay != 0 is not built (reference default is 0)")
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._flat_m = self._flat_v = self._flat_g = self._scratch = None
+        self._flat_cache = self._state_views = None
         self._step_count = 0
         self.world_size = 1
 
@@ -43,6 +44,11 @@ class FusedAdam(optim.Adam):
 
     def _ensure_flat(self):
         params = self._params()
+        # the layout check walks every parameter: cache it while the parameter views have not moved
+        key = (len(params), params[0].data_ptr(), params[-1].data_ptr(), params[0].device) if params else None
+        cached = getattr(self, "_flat_cache", None)
+        if cached is not None and cached[0] == key and self._flat_m is not None:
+            return cached[1], cached[2], params
         flat, offs = flat_base(params)
         if flat is None:
             raise _C.DPoserHipError("FusedAdam needs parameters that are views of one flat buffer (ScoreModelFC.flat_params())")
@@ -53,12 +59,14 @@ class FusedAdam(optim.Adam):
             self._flat_v = torch.zeros_like(flat)
             self._flat_g = torch.zeros_like(flat)
             self._scratch = torch.zeros(16384, dtype=torch.float32, device=flat.device)
+            self._state_views = None
             for p, o in zip(params, offs):
                 st = old.get(p)
                 if st and "exp_avg" in st:          # state restored by load_state_dict: keep its values
                     self._flat_m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
                     self._flat_v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
                     self._step_count = max(self._step_count, int(st["step"]))
+        self._flat_cache = (key, flat, offs)
         return flat, offs, params
 
     def flat_grad(self):
@@ -94,12 +102,19 @@ class FusedAdam(optim.Adam):
                                                     float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(grad_clip),
                                                     float(grad_scale), self._step_count, float(omd), _C.ptr(self._scratch),
                                                     _C.stream_ptr()), "dposer_adam_ema_clip_step")
-        for p, o, ok in zip(params, offs, live):     # torch-compatible per-parameter state (views)
-            if ok:
-                st = self.state[p]
-                st["step"] = torch.tensor(float(self._step_count))
-                st["exp_avg"] = self._flat_m[o:o + p.numel()].view(p.shape)
-                st["exp_avg_sq"] = self._flat_v[o:o + p.numel()].view(p.shape)
+        # torch-compatible per-parameter state: {'step', 'exp_avg', 'exp_avg_sq'} are views of the flat buffers and ONE shared
+        # step tensor, rebuilt only when the set of live parameters (or the buffers) changes -- not 3 tensors per parameter per step
+        live_key = (tuple(bool(ok) for ok in live), self._flat_m.data_ptr())
+        if getattr(self, "_state_views", None) != live_key:
+            self._step_t = torch.tensor(float(self._step_count))
+            for p, o, ok in zip(params, offs, live):
+                if ok:
+                    st = self.state[p]
+                    st["step"] = self._step_t
+                    st["exp_avg"] = self._flat_m[o:o + p.numel()].view(p.shape)
+                    st["exp_avg_sq"] = self._flat_v[o:o + p.numel()].view(p.shape)
+            self._state_views = live_key
+        self._step_t.fill_(float(self._step_count))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -270,8 +285,8 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
                  and fused_dsm_supported(sde, model, continuous, reduce_mean, likelihood_weighting, auxiliary_loss))
         if fused:
             from ... import distributed as ddp
-            model.train()
-            params = list(model.parameters())
+            if not model.training:
+                model.train()
             flat_grad = optimizer.flat_grad()
             if ddp.world_size() > 1:
                 # bucketed: each GN layer's gradient is all-reduced (RCCL over xGMI) on a side stream while the layers in
@@ -287,7 +302,14 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
                 loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=model._rng_seed, step=state["step"])
                 world = 1
             optimize_fn.warm_lr(optimizer, state["step"])                           # losses.py:51-53
-            live = [not model._is_nograd(o) and p.requires_grad for p, o in zip(params, model._offsets)]
+            # parameters with a gradient (fixed per model unless requires_grad flags are flipped): cached on the model
+            params = model._param_list
+            rg = tuple(p.requires_grad for p in params)
+            cache = getattr(model, "_live_cache", None)
+            if cache is None or cache[0] != rg:
+                cache = (rg, [not model._is_nograd(o) and r for r, o in zip(rg, model._offsets)])
+                model._live_cache = cache
+            live = cache[1]
             optimizer.fused_step(live=live, grad_clip=optimize_fn.grad_clip, grad_scale=1.0 / world, ema=state["ema"])
             state["step"] += 1
             return {"step_loss": loss, "score_loss": loss}
