@@ -75,6 +75,25 @@ def gaps(path):
         print(f"| `{k}` | {n} | {g / n / 1e3:.2f} | {d / n / 1e3:.1f} | {g / max(d, 1):.3f} |")
 
 
+def sequence(path, anchor="k_prep_train", which=3):
+    """The kernels of ONE training step in launch order (from the `which`-th occurrence of `anchor` to the next one)."""
+    cur = sqlite3.connect(path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = list(cur.execute(f"select {name_col}, start, end from kernels order by start"))
+    idx = [i for i, r in enumerate(rows) if anchor in short(r[0])]
+    lo, hi = idx[which], idx[which + 1]
+    t0 = rows[lo][1]
+    print(f"# one training step, kernels in start order ({path}); step = {(rows[hi][1] - t0) / 1e3:.1f} us\n")
+    print("| # | kernel | start us | duration us | gap to previous end us |")
+    print("|---:|---|---:|---:|---:|")
+    prev_end = None
+    for k, (n, s0, e0) in enumerate(rows[lo:hi]):
+        gap = "" if prev_end is None else f"{(s0 - prev_end) / 1e3:.1f}"
+        print(f"| {k} | `{short(n)[:70]}` | {(s0 - t0) / 1e3:.1f} | {(e0 - s0) / 1e3:.1f} | {gap} |")
+        prev_end = e0 if prev_end is None else max(prev_end, e0)
+
+
 def _pmc_agg(paths):
     agg = {}
     for path in paths:
@@ -131,6 +150,9 @@ def counters(paths):
         print(f"| `{k}` | {n} | " + " | ".join(f"{v[c][1]:.4g}" if c in v else "" for c in names) + " |")
 
 
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--sequence":
+    sequence(sys.argv[2])
+    sys.exit(0)
 if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--gaps":
     gaps(sys.argv[2])
     sys.exit(0)
