@@ -106,6 +106,10 @@ template <> struct Quad<__bf16> {
 //   bf16: a lane owns 8 bytes of each chunk; one v_permlane32_swap per dword regroups the two half-waves so
 //         that lane (j, hi) holds the full 16-byte chunk (kh = hi) of k-blocks 0 and 1    -> 2 x b128
 // ----------------------------------------------------------------------------------------------
+// s_waitcnt immediate for "vmcnt(N) only" on gfx9-family encodings: vmcnt = [15:14|3:0], expcnt [6:4], lgkmcnt [11:8]
+constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+constexpr int waitcnt_vm_lgkm0(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0x0 << 8); }
+
 template <typename T> struct TileIO;
 template <> struct TileIO<float> {
     __device__ static inline void store(float* tile, int lane, const float (&v)[16]) {

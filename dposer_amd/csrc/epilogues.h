@@ -382,13 +382,45 @@ template <typename T> struct EpiGNBwd {
     static constexpr int kScratchPerWave = TileT<T>::SCRATCH_BYTES;
     static constexpr int kMinWaves = 2;   // keep two 256-thread workgroups per CU (register-heavy epilogue)
     static constexpr int kParamArrays = 2;
+    // Operand prefetch through the (then idle) K-loop ring: x_hat and the residual carry of sub-tile i+1 are DMA'd
+    // (global_load_lds, 1 KiB pieces) into a per-wave double buffer while sub-tile i is being processed.  Loaded straight
+    // into registers, each sub-tile paid a full HBM round trip behind an s_waitcnt (8 per wave tile, and both waves of a
+    // SIMD are in the same place at the same time); the register budget (248 of 256) leaves no room to prefetch there.
+    static constexpr int kTileBytes = 1024 * (int)sizeof(T);
+    static constexpr int kRingPerWave = 2 * 2 * kTileBytes;   // [2 buffers][x_hat, carry]
     __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.gamma : p.beta; }
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int, const float* lpar, int lstride, unsigned char* scr) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int split, const float* lpar, int lstride, unsigned char* scr) {
+        run<TC, TS, false>(pp, acc, cbase, sbase, lane, wrow, lpar, lstride, scr, nullptr);
+    }
+    template <int TC, int TS>
+    __device__ static inline void apply_ring(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int split, const float* lpar, int lstride, unsigned char* scr, unsigned char* ring) {
+        run<TC, TS, true>(pp, acc, cbase, sbase, lane, wrow, lpar, lstride, scr, ring);
+    }
+    template <int TC, int TS, bool RING>
+    __device__ static inline void run(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, const float* lpar, int lstride, unsigned char* scr, unsigned char* ring) {
         struct { const T* carry_in; T* carry_out; const T* xhat; const float *rstd, *gamma, *beta; T* dy; float* part; int H; int64_t S_valid; DropoutCfg drop; } p =
             {(const T*)pp.carry_in, (T*)pp.carry_out, (const T*)pp.xhat, pp.rstd, pp.gamma, pp.beta, (T*)pp.dy, pp.part, pp.H, pp.S_valid, pp.drop};
         constexpr bool PRECISE = sizeof(T) == 4;
+        constexpr int NBLK = kTileBytes / 1024;
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
         const int j = lane & 31, hi = lane >> 5;
+        const bool has_carry = p.carry_in != nullptr;
+        // DMA of sub-tile i = (tc, ts) into ring buffer i & 1
+        auto prefetch = [&](int tc, int ts) __attribute__((always_inline)) {
+            const int64_t tb = ft_tile_base<T>(sbase + ts * 32, cbase + tc * 32, p.H);
+            unsigned char* dst = ring + ((tc * TS + ts) & 1) * 2 * kTileBytes;
+#pragma unroll
+            for (int h = 0; h < NBLK; ++h)
+                __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned char*>(p.xhat + tb) + h * 1024 + lane * 16), (lptr_t)(dst + h * 1024), 16, 0, 0);
+            if (has_carry) {
+#pragma unroll
+                for (int h = 0; h < NBLK; ++h)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned char*>(p.carry_in + tb) + h * 1024 + lane * 16), (lptr_t)(dst + kTileBytes + h * 1024), 16, 0, 0);
+            }
+        };
+        if constexpr (RING) prefetch(0, 0);
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc) {
             const int c0 = cbase + tc * 32;
@@ -407,14 +439,36 @@ template <typename T> struct EpiGNBwd {
                 const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.H);
                 const float rstd = p.rstd[s * (p.H >> 5) + (c0 >> 5)];
                 float xh[16], g[16];
-                TileIO<T>::load(p.xhat + tb, lane, xh);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g[r] = acc[tc][ts][r];
-                if (p.carry_in) {
-                    float ci[16];
-                    TileIO<T>::load(p.carry_in + tb, lane, ci);
+                if constexpr (RING) {
+                    const int it = tc * TS + ts;                 // (compile-time after unrolling)
+                    // sub-tile `it` has landed once everything but the pieces just issued for `it + 1` has returned (loads
+                    // return in order; stores share the counter, so this also waits for the previous sub-tile's stores)
+                    if (it + 1 < TC * TS) {
+                        prefetch((it + 1) / TS, (it + 1) % TS);
+                        if (has_carry) __builtin_amdgcn_s_waitcnt(waitcnt_vm(2 * NBLK));
+                        else __builtin_amdgcn_s_waitcnt(waitcnt_vm(NBLK));
+                    } else {
+                        __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+                    }
+                    asm volatile("" ::: "memory");
+                    const T* src = reinterpret_cast<const T*>(ring + (it & 1) * 2 * kTileBytes);
+                    TileIO<T>::load(src, lane, xh);
+                    if (has_carry) {
+                        float ci[16];
+                        TileIO<T>::load(src + 1024, lane, ci);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) g[r] += ci[r];
+                        for (int r = 0; r < 16; ++r) g[r] += ci[r];
+                    }
+                } else {
+                    TileIO<T>::load(p.xhat + tb, lane, xh);
+                    if (has_carry) {
+                        float ci[16];
+                        TileIO<T>::load(p.carry_in + tb, lane, ci);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) g[r] += ci[r];
+                    }
                 }
                 if (p.carry_out) TileIO<T>::store(p.carry_out + tb, lane, g);
                 float s1 = 0.f, s2 = 0.f;

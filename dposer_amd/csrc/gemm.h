@@ -59,14 +59,11 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-// s_waitcnt immediate for "vmcnt(N) only" on gfx9-family encodings: vmcnt = [15:14|3:0], expcnt [6:4], lgkmcnt [11:8]
-constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
 __device__ __forceinline__ void __syncthreads_lds_only() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-constexpr int waitcnt_vm_lgkm0(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0x0 << 8); }
 
 template <typename T, int WC, int WS, int TC, int TS, int KB>
 struct GemmCfg {
@@ -96,6 +93,12 @@ template <typename Epi> struct EpiParamArrays<Epi, decltype((void)Epi::kParamArr
 // Per-wave LDS scratch (bytes) an epilogue may ask for (transposed tile stores).
 template <typename Epi, typename = void> struct EpiScratch { static constexpr int value = 0; };
 template <typename Epi> struct EpiScratch<Epi, decltype((void)Epi::kScratchPerWave)> { static constexpr int value = Epi::kScratchPerWave; };
+
+// Epilogues that prefetch their own operands through the (idle) K-loop ring declare kRingPerWave bytes and apply_ring(...).
+template <typename Epi, typename = void> struct EpiRing { static constexpr int value = 0; };
+#ifndef DPOSER_NO_EPI_RING   // (A/B switch for the tuner)
+template <typename Epi> struct EpiRing<Epi, decltype((void)Epi::kRingPerWave)> { static constexpr int value = Epi::kRingPerWave; };
+#endif
 
 // The kernel.  One workgroup = one output tile (x one k-split).
 // Main loop: double-buffered LDS ring filled with global_load_lds_dwordx4 (the fragment-tiled HBM image IS the LDS
@@ -334,8 +337,14 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     }
 
     unsigned char* wave_scratch = reinterpret_cast<unsigned char*>(lds_par + NPAR * C::CT * 32) + wave * EpiScratch<Epi>::value;
-    Epi::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
-                                sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32, wave_scratch);
+    if constexpr (EpiRing<Epi>::value > 0 && NB * C::STAGE_BYTES >= C::NW * EpiRing<Epi>::value) {
+        __syncthreads_lds_only();      // every wave is done with the ring (no DMA is in flight after the last stage)
+        Epi::template apply_ring<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
+                                         sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32, wave_scratch, smem + wave * EpiRing<Epi>::value);
+    } else {
+        Epi::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
+                                    sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32, wave_scratch);
+    }
 }
 
 template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int NB = 2>
