@@ -233,6 +233,19 @@ int main(int argc, char** argv) {
         printf(total_bad ? "TAILS FAILED\n" : "TAILS OK\n");
         return total_bad != 0;
     }
+    if (getenv("TUNE_2WG")) {        // 4-wave tiles with 128-register accumulators, two workgroups per CU (ring NB = 3), vs 256x256
+        GN(2, 4, 4, 2, 2, 4);  PL(2, 4, 4, 2, 2, 4);
+        GN(1, 4, 4, 2, 2, 3);  PL(1, 4, 4, 2, 2, 3);
+        GN(2, 2, 2, 4, 2, 3);  PL(2, 2, 2, 4, 2, 3);
+        GN(2, 2, 4, 2, 2, 3);  PL(2, 2, 4, 2, 2, 3);
+        GN(4, 1, 2, 4, 2, 3);  PL(4, 1, 2, 4, 2, 3);
+        GB(2, 4, 4, 2, 2, 4, 1, 1, 0, 0);
+        GB(4, 1, 2, 4, 2, 3, 1, 1, 0, 0);
+        GB(2, 2, 4, 2, 2, 3, 1, 1, 0, 0);
+        GB(1, 4, 4, 2, 2, 3, 1, 1, 0, 0);
+        run_all(7, 10);
+        return 0;
+    }
     if (getenv("TUNE_DROPCOST")) {   // what do the Philox dropout draws cost in the training-forward epilogue?
         GNT(2, 4, 4, 2, 2, 4);
         g_drop_p = 0.1f;
