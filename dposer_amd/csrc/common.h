@@ -127,6 +127,18 @@ template <> struct TileIO<float> {
             for (int r = 0; r < 4; ++r) v[4 * q + r] = o[r];
         }
     }
+    // split form: issue the loads early (Raw stays in registers), unpack where the values are needed
+    struct Raw { f32x4 q[4]; };
+    __device__ static inline void load_raw(const float* tile, int lane, Raw& w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w.q[q] = *reinterpret_cast<const f32x4*>(tile + q * 256 + lane * 4);
+    }
+    __device__ static inline void unpack(const Raw& w, float (&v)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * q + r] = w.q[q][r];
+    }
 };
 template <> struct TileIO<__bf16> {
     __device__ static inline unsigned pack2(float a, float b) {
@@ -149,6 +161,23 @@ template <> struct TileIO<__bf16> {
             swap_halves(a1, b1);
             u32x4 o = {a0, a1, b0, b1};
             *reinterpret_cast<u32x4*>(tile + h * 512 + lane * 8) = o;
+        }
+    }
+    struct Raw { u32x4 h[2]; };
+    __device__ static inline void load_raw(const __bf16* tile, int lane, Raw& w) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) w.h[h] = *reinterpret_cast<const u32x4*>(tile + h * 512 + lane * 8);
+    }
+    __device__ static inline void unpack(const Raw& w, float (&v)[16]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned a0 = w.h[h][0], a1 = w.h[h][1], b0 = w.h[h][2], b1 = w.h[h][3];
+            swap_halves(a0, b0);
+            swap_halves(a1, b1);
+            v[8 * h + 0] = __uint_as_float(a0 << 16); v[8 * h + 1] = __uint_as_float(a0 & 0xffff0000u);
+            v[8 * h + 2] = __uint_as_float(a1 << 16); v[8 * h + 3] = __uint_as_float(a1 & 0xffff0000u);
+            v[8 * h + 4] = __uint_as_float(b0 << 16); v[8 * h + 5] = __uint_as_float(b0 & 0xffff0000u);
+            v[8 * h + 6] = __uint_as_float(b1 << 16); v[8 * h + 7] = __uint_as_float(b1 & 0xffff0000u);
         }
     }
     __device__ static inline void load(const __bf16* tile, int lane, float (&v)[16]) {

@@ -89,6 +89,10 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
         float v[16];       // centred values (phase 0) -> x_hat
         float keep[16];
         float rstd;
+        // residual input: the tile of THIS sub-tile (rc) and the one prefetched for the NEXT sub-tile (rn).  Loaded where it
+        // is added, each sub-tile paid an exposed HBM round trip (a layer with a residual input took 25-35 us longer than
+        // one without); issued one sub-tile ahead the latency hides under ~500 VALU instructions.
+        typename TileIO<T>::Raw rc, rn;
     };
     template <int TC, int TS, int tc, int ts, int PH = -1>
     __device__ static inline void sub(const Params& pp, Carry& cy, const f32x16& a, int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
@@ -100,6 +104,20 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
         const int64_t s = sbase + ts * 32 + j;
         const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.H);
         const bool drop = TRAIN && (FLAT || p.drop.p > 0.f);
+        const bool has_res = RESID == 1 || (RESID < 0 && p.resid);
+        // (inference only: 168 -> 152 us per 256x256 layer with a residual input.  In the training epilogue neither this
+        //  (216 -> 222 us: 16 more live registers) nor a DMA prefetch through the K-loop ring (-> 224 us) helps: with three
+        //  output streams per tile that epilogue is HBM-bound, the residual read costs its bytes)
+        constexpr bool PREFETCH = !TRAIN;
+        if constexpr (PH != 1 && PREFETCH) {
+            if (has_res) {
+                constexpr int I = tc * TS + ts;
+                if constexpr (I == 0) TileIO<T>::load_raw(p.resid + tb, lane, cy.rn);
+                cy.rc = cy.rn;
+                if constexpr (I + 1 < TC * TS)
+                    TileIO<T>::load_raw(p.resid + ft_tile_base<T>(sbase + ((I + 1) % TS) * 32, cbase + ((I + 1) / TS) * 32, p.H), lane, cy.rn);
+            }
+        }
         if constexpr (PH != 1) {
             float sum = 0.f;
 #pragma unroll
@@ -135,9 +153,10 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
                 }
             }
             if (TRAIN) TileIO<T>::store(p.xhat + tb, lane, cy.v);
-            if (RESID == 1 || (RESID < 0 && p.resid)) {
+            if (has_res) {
                 float rr[16];
-                TileIO<T>::load(p.resid + tb, lane, rr);
+                if constexpr (PREFETCH) TileIO<T>::unpack(cy.rc, rr);
+                else TileIO<T>::load(p.resid + tb, lane, rr);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] += rr[r];
             }

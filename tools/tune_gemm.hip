@@ -24,7 +24,8 @@ int dposer_set_error(int code, const std::string&) { return code; }
 #include <functional>
 struct Case { std::string name; std::function<void()> launch; double flops; std::vector<double> us; };
 static std::vector<Case> g_cases;
-static float g_drop_p = 0.f;   // TUNE_DROP=0.1: the gn-train cases draw dropout masks
+static float g_drop_p = 0.f;
+static const void* g_resid = nullptr;   // TUNE_RESID cases: residual input of the GroupNorm forward epilogue   // TUNE_DROP=0.1: the gn-train cases draw dropout masks
 
 template <int WC, int WS, int TC, int TS, int KB, int GLDS>
 void add_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void* out) {
@@ -50,7 +51,7 @@ void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* o
     g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1;
     GNParams p;
     memset(&p, 0, sizeof(p));
-    p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C; p.Spad = S;
+    p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C; p.Spad = S; p.resid = g_resid;
     if (TRAIN) { p.xhat = xhat; p.rstd = rstd; p.outT = outT; }
     if (TRAIN && g_drop_p > 0.f) { p.drop.p = g_drop_p; p.drop.scale = 1.f / (1.f - g_drop_p); p.drop.thr = (uint32_t)((1.0 - g_drop_p) * 65536.0); p.drop.groups_x4 = C / 8; p.drop.seed = 7; }
     char buf[160];
@@ -232,6 +233,15 @@ int main(int argc, char** argv) {
         }
         printf(total_bad ? "TAILS FAILED\n" : "TAILS OK\n");
         return total_bad != 0;
+    }
+    if (getenv("TUNE_RESID")) {      // cost of the residual input in the GroupNorm forward epilogues
+        GN(2, 4, 4, 2, 2, 4); GNT(2, 4, 4, 2, 2, 4); GN(2, 2, 2, 2, 2, 4);
+        g_resid = cin;
+        GN(2, 4, 4, 2, 2, 4); g_cases.back().name += " +resid";
+        GNT(2, 4, 4, 2, 2, 4); g_cases.back().name += " +resid";
+        GN(2, 2, 2, 2, 2, 4); g_cases.back().name += " +resid";
+        run_all(7, 10);
+        return 0;
     }
     if (getenv("TUNE_2WG")) {        // 4-wave tiles with 128-register accumulators, two workgroups per CU (ring NB = 3), vs 256x256
         GN(2, 4, 4, 2, 2, 4);  PL(2, 4, 4, 2, 2, 4);
