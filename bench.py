@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 GLOBAL_BATCH = 65536
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
+DOMINANT_KIND = "gn_fwd_train"      # the GEMM kind with the largest share of the training step (profiles/r01_bench_kernel_stats.md)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -149,7 +150,9 @@ def main():
         step_fn(state, batch)
     ddp.barrier()
     torch.cuda.synchronize()
-    _C.profile_enable(True)
+    # live roofline: HIP events around the launches of the dominant GEMM kind only (bracketing all ~30 GEMM launches of a
+    # step costs ~3 % of it; the full per-kind table comes from three extra, untimed steps below)
+    _C.profile_enable(True, only=DOMINANT_KIND)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step_fn(state, batch)
@@ -157,6 +160,12 @@ def main():
     ddp.barrier()
     elapsed = time.perf_counter() - t0
     prof = _C.profile_collect()
+    _C.profile_enable(False)
+    _C.profile_enable(True)
+    for _ in range(3):
+        step_fn(state, batch)
+    torch.cuda.synchronize()
+    prof_all = _C.profile_collect()
     _C.profile_enable(False)
     loss = float(out["step_loss"])
     if world > 1:
@@ -170,15 +179,15 @@ def main():
     roofline = None
     kernels = {}
     if prof:
-        tot_ms = sum(v[0] for v in prof.values())
-        for name, (ms, cnt, fl) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+        tot_ms = sum(v[0] for v in prof_all.values())
+        for name, (ms, cnt, fl) in sorted(prof_all.items(), key=lambda kv: -kv[1][0]):      # untimed pass, all kinds
             kernels[name] = {"launches": int(cnt), "avg_us": ms / cnt * 1e3, "share_of_gemm_time": ms / tot_ms,
                              "tflops": (fl / (ms * 1e-3)) / 1e12 if ms > 0 else None}
-        name, (ms, cnt, fl) = max(prof.items(), key=lambda kv: kv[1][0])
+        name, (ms, cnt, fl) = max(prof.items(), key=lambda kv: kv[1][0])                     # timed region, dominant kind
         ach = (fl / (ms * 1e-3)) / 1e12
         roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(name), "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3,
-                    "flops_per_launch": fl / cnt, "gemm_time_share_of_step": tot_ms / (elapsed * 1e3)}
+                    "flops_per_launch": fl / cnt, "gemm_time_share_of_step": tot_ms / 3 / ms_per_step}
 
     extra = {"train_loss_last_step": loss, "train_tflops_algorithmic": 42.59e6 * value / 1e12, "gemm_kernels": kernels}
     if not args.no_extra:
@@ -188,12 +197,17 @@ def main():
         fn = sampling.get_sampling_fn(cfg, sde_s, (B_local, 63), lambda v: v, 1e-3, device=dev)
         ddp.barrier()
         torch.cuda.synchronize()
-        _C.profile_enable(True)
         t1 = time.perf_counter()
         _, xs = fn(model, traj_stride=0)
         torch.cuda.synchronize()
         ddp.barrier()
         t_s = time.perf_counter() - t1
+        # per-kernel rate of the sampler from a short separate run with events (not inside the timed one)
+        sde_p = sde_lib.subVPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=min(50, args.sampler_steps))
+        fn_p = sampling.get_sampling_fn(cfg, sde_p, (B_local, 63), lambda v: v, 1e-3, device=dev)
+        _C.profile_enable(True)
+        fn_p(model, traj_stride=0)
+        torch.cuda.synchronize()
         sprof = _C.profile_collect()
         _C.profile_enable(False)
         if world > 1:

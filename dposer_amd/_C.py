@@ -137,8 +137,14 @@ def require_gpu(t, name="tensor"):
             "(no CPU fallback). Move the module / tensors to 'cuda'.")
 
 
-def profile_enable(on: bool):
-    lib().dposer_profile_enable(1 if on else 0)
+PROFILE_EPI_KINDS = ("gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad",
+                     "post_em_step")
+
+
+def profile_enable(on: bool, only: str = None):
+    """HIP events around the GEMM launches; ``only`` = one of PROFILE_EPI_KINDS brackets that kind alone (cheap enough
+    for a timed region: bracketing every launch costs about 3 % of a training step)."""
+    lib().dposer_profile_enable((2 + PROFILE_EPI_KINDS.index(only) if only else 1) if on else 0)
 
 
 def profile_collect():

@@ -12,6 +12,7 @@ namespace {
 struct ProfRec { hipEvent_t a, b; int kind; double flops; };
 struct Prof {
     int enabled = 0;
+    int only = -1;      // >= 0: record launches of this epilogue kind only
     std::vector<ProfRec> pool;
     size_t used = 0;
 } g_prof;
@@ -19,7 +20,7 @@ struct ProfScope {
     ProfRec* r = nullptr;
     hipStream_t st;
     ProfScope(int kind, const GemmArgs& g, hipStream_t s) : st(s) {
-        if (!g_prof.enabled) return;
+        if (!g_prof.enabled || (g_prof.only >= 0 && kind / 12 != g_prof.only)) return;
         if (g_prof.used == g_prof.pool.size()) {
             ProfRec n;
             if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
@@ -35,7 +36,7 @@ struct ProfScope {
 const char* kEpiNames[EPI_KINDS] = {"gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad", "post_em_step"};
 const char* kShapeNames[6] = {"256x256", "128x128", "128x32", "64x128", "64x32", "128x64"};
 }   // namespace
-void gemm_prof_enable(int on) { g_prof.enabled = on; if (!on) g_prof.used = 0; }
+void gemm_prof_enable(int on) { g_prof.enabled = on != 0; g_prof.only = on >= 2 ? on - 2 : -1; if (!on) g_prof.used = 0; }
 int gemm_prof_collect(double* ms, long long* launches, double* flops) {
     for (int i = 0; i < GEMM_PROF_KINDS; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = 0; }
     for (size_t i = 0; i < g_prof.used; ++i) {

@@ -75,7 +75,7 @@ def gaps(path):
         print(f"| `{k}` | {n} | {g / n / 1e3:.2f} | {d / n / 1e3:.1f} | {g / max(d, 1):.3f} |")
 
 
-def sequence(path, anchor="k_prep_train", which=3):
+def sequence(path, anchor="k_prep_train", which=3, title="one training step"):
     """The kernels of ONE training step in launch order (from the `which`-th occurrence of `anchor` to the next one)."""
     cur = sqlite3.connect(path).cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -84,7 +84,7 @@ def sequence(path, anchor="k_prep_train", which=3):
     idx = [i for i, r in enumerate(rows) if anchor in short(r[0])]
     lo, hi = idx[which], idx[which + 1]
     t0 = rows[lo][1]
-    print(f"# one training step, kernels in start order ({path}); step = {(rows[hi][1] - t0) / 1e3:.1f} us\n")
+    print(f"# {title}, kernels in start order ({path}); span = {(rows[hi][1] - t0) / 1e3:.1f} us\n")
     print("| # | kernel | start us | duration us | gap to previous end us |")
     print("|---:|---|---:|---:|---:|")
     prev_end = None
@@ -151,7 +151,10 @@ def counters(paths):
 
 
 if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--sequence":
-    sequence(sys.argv[2])
+    if len(sys.argv) > 3:      # --sequence db anchor [which]: e.g. EpiEmStep 500 -> one sampler step
+        sequence(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 3, f"from one `{sys.argv[3]}` to the next")
+    else:
+        sequence(sys.argv[2])
     sys.exit(0)
 if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--gaps":
     gaps(sys.argv[2])
