@@ -140,15 +140,18 @@ struct PrepTrainDev {
     SdeDev sde;
     float t_scale;   // (T - eps) as fp32
 };
+constexpr int PREP_EQ = 8;   // embedding quads per thread: the Philox draw of t is shared by 32 embedding values
 template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTrainDev d) {
     const PrepTrainArgs& a = d.a;
     const int qx = a.Dpad >> 2, qe = a.E >> 2;
+    const int ge = (qe + PREP_EQ - 1) / PREP_EQ;      // embedding work items per sample
     const int QD = (a.D + 3) >> 2;
     const int64_t nx = a.Bpad * qx;
-    const int64_t total = nx + a.Bpad * qe;
+    const int64_t total = nx + a.Bpad * ge;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // x part: quad index fastest (consecutive lanes read consecutive floats of one row-major pose);
+        // embedding part: sample index fastest (consecutive lanes write consecutive 16-B chunks of an FT block)
         const int64_t s = i < nx ? i / qx : (i - nx) % a.Bpad;
-        const int q = i < nx ? (int)(i % qx) : qx + (int)((i - nx) / a.Bpad);
         float t = a.eps;
         if (s < a.B) {
             if (a.t_in) t = a.t_in[s];
@@ -157,8 +160,9 @@ template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTr
                 t = u01(r.v[0]) * d.t_scale + a.eps;
             }
         }
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (q < qx) {
+        if (i < nx) {
+            const int q = (int)(i % qx);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int c = q * 4;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             if (s < a.B && c < a.D) {
@@ -183,11 +187,18 @@ template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTr
             *reinterpret_cast<f32x4*>(a.z_out + s * a.Dpad + c) = z;
             if (q == 0) a.t_out[s] = t;
         } else {
-            const int e = (q - qx) * 4;
+            const int g0 = (int)((i - nx) / a.Bpad) * PREP_EQ;
             const float label = t * 999.0f;                 // utils.py:152
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = temb_value<sizeof(T) == 2>(label, e + r, a.E, a.freq, a.fourier);
-            store_quad_ft<T>(a.emb, s, e, a.E, v);
+            for (int k = 0; k < PREP_EQ; ++k) {
+                const int e = (g0 + k) * 4;
+                if (e < a.E) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = temb_value<sizeof(T) == 2>(label, e + r, a.E, a.freq, a.fourier);
+                    store_quad_ft<T>(a.emb, s, e, a.E, v);
+                }
+            }
         }
     }
 }
@@ -196,7 +207,7 @@ hipError_t launch_prep_train(const PrepTrainArgs& a, hipStream_t st) {
     d.a = a;
     d.sde = make_sde_dev(a.sde);
     d.t_scale = (float)((double)a.sde.T - (double)a.eps);
-    const int64_t total = a.Bpad * ((a.Dpad >> 2) + (a.E >> 2));
+    const int64_t total = a.Bpad * ((a.Dpad >> 2) + ((a.E >> 2) + PREP_EQ - 1) / PREP_EQ);
     if (a.f32) hipLaunchKernelGGL(k_prep_train<float>, dim3(grid_for(total)), dim3(256), 0, st, d);
     else hipLaunchKernelGGL(k_prep_train<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, d);
     return hipGetLastError();
