@@ -133,7 +133,7 @@ static void run_all(int rounds, int reps) {
 
 int main(int argc, char** argv) {
     const int64_t S = argc > 1 ? atoll(argv[1]) : 65536;
-    const int C = 1024, K = getenv("TUNE_K") ? atoi(getenv("TUNE_K")) : 1024;
+    const int C = getenv("TUNE_C") ? atoi(getenv("TUNE_C")) : 1024, K = getenv("TUNE_K") ? atoi(getenv("TUNE_K")) : 1024;
     void *W, *X, *o0, *o1;
     float *bias, *gamma, *beta;
     CK(hipMalloc(&W, (size_t)C * K * 2)); CK(hipMalloc(&X, (size_t)S * K * 2)); CK(hipMalloc(&o0, (size_t)S * C * 2)); CK(hipMalloc(&o1, (size_t)S * C * 2));
@@ -233,6 +233,22 @@ int main(int argc, char** argv) {
         }
         printf(total_bad ? "TAILS FAILED\n" : "TAILS OK\n");
         return total_bad != 0;
+    }
+    if (getenv("TUNE_FINAL")) {      // 64-channel outputs (post_dense, dx; run with TUNE_C=64): K pipeline of the 64x128 / 64x32 tilings
+        PL(1, 4, 2, 1, 2, 4);
+        PL(1, 4, 2, 1, 4, 2);
+        PL(1, 4, 2, 1, 4, 3);
+        PL(1, 4, 2, 1, 4, 4);
+        PL(1, 4, 2, 1, 8, 2);
+        PL(1, 4, 2, 1, 8, 3);
+        PL(2, 1, 1, 1, 2, 4);
+        PL(2, 1, 1, 1, 4, 4);
+        PL(2, 2, 1, 1, 2, 4);
+        PL(2, 2, 1, 1, 4, 4);
+        PL(2, 2, 1, 2, 2, 4);
+        PL(2, 2, 1, 2, 4, 4);
+        run_all(7, 20);
+        return 0;
     }
     if (getenv("TUNE_RESID")) {      // cost of the residual input in the GroupNorm forward epilogues
         GN(2, 4, 4, 2, 2, 4); GNT(2, 4, 4, 2, 2, 4); GN(2, 2, 2, 2, 2, 4);
