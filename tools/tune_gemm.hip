@@ -15,6 +15,7 @@
 #include "epilogues.h"
 #include "gemm.h"
 #include "experimental/gemm_pipe.h"
+#include "gemm_wgrad_tr.h"
 
 int dposer_set_error(int code, const std::string&) { return code; }
 
@@ -233,6 +234,48 @@ int main(int argc, char** argv) {
         }
         printf(total_bad ? "TAILS FAILED\n" : "TAILS OK\n");
         return total_bad != 0;
+    }
+    if (getenv("TUNE_WTR")) {        // wgrad from un-transposed operands (ds_read_b64_tr_b16) vs the plain kernel on transposed copies
+        const int N = 1024, Kc = C;                    // dW [N][Kc], contraction over S samples
+        std::vector<unsigned short> hy((size_t)S * N), hyT((size_t)S * N), hh((size_t)S * Kc), hhT((size_t)S * Kc);
+        for (auto& v : hy) v = rnd();
+        for (auto& v : hh) v = rnd();
+        for (int64_t s_ = 0; s_ < S; ++s_) {
+            for (int n = 0; n < N; ++n) hyT[FT<__bf16>::index(n, (int)s_, (int)S)] = hy[FT<__bf16>::index(s_, n, N)];
+            for (int k = 0; k < Kc; ++k) hhT[FT<__bf16>::index(k, (int)s_, (int)S)] = hh[FT<__bf16>::index(s_, k, Kc)];
+        }
+        void *dy, *dyT_, *hb, *hbT;
+        CK(hipMalloc(&dy, hy.size() * 2)); CK(hipMalloc(&dyT_, hy.size() * 2)); CK(hipMalloc(&hb, hh.size() * 2)); CK(hipMalloc(&hbT, hh.size() * 2));
+        CK(hipMemcpy(dy, hy.data(), hy.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dyT_, hyT.data(), hy.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(hb, hh.data(), hh.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(hbT, hhT.data(), hh.size() * 2, hipMemcpyHostToDevice));
+        const int ks = 16;
+        float *slab0, *slab1;
+        CK(hipMalloc(&slab0, (size_t)ks * N * Kc * 4)); CK(hipMalloc(&slab1, (size_t)ks * N * Kc * 4));
+        CK(hipMemset(slab0, 0, (size_t)ks * N * Kc * 4)); CK(hipMemset(slab1, 0xff, (size_t)ks * N * Kc * 4));
+        WgradParams wp0, wp1;
+        wp0.slab = slab0; wp0.slab_stride = (int64_t)N * Kc; wp0.ld = Kc; wp0.N_valid = N; wp0.K_valid = Kc;
+        wp1 = wp0; wp1.slab = slab1;
+        GemmArgs g0;
+        memset(&g0, 0, sizeof(g0));
+        g0.W = dyT_; g0.w_stride_blocks = (int)(S / 16); g0.src[0] = hbT; g0.seg_kblocks[0] = (int)(S / 16); g0.nseg = 1; g0.ktot_blocks = (int)(S / 16);
+        g0.n_cblk = N / 256; g0.n_sblk = Kc / 256; g0.ksplit = ks;
+        WgradTrArgs g1;
+        memset(&g1, 0, sizeof(g1));
+        g1.dY = dy; g1.H = hb; g1.N = N; g1.Kc = Kc; g1.n_cblk = N / 256; g1.n_sblk = Kc / 256; g1.sblocks = (int)(S / 32); g1.ksplit = ks;
+        const double fl = 2.0 * S * N * Kc;
+        g_cases.push_back({"wgrad 256x256, transposed copies (plain kernel)", [=] { CK((launch_gemm<__bf16, 2, 4, 4, 2, 2, EpiWgrad<__bf16>, 4>(g0, wp0, 0))); }, fl, {}});
+        g_cases.push_back({"wgrad 256x256, sample-major operands (tr reads)", [=] { CK((launch_wgrad_tr<2, 4, 4, 2, 4>(g1, wp1, 0))); }, fl, {}});
+        for (auto& c : g_cases) c.launch();
+        CK(hipDeviceSynchronize());
+        {
+            std::vector<float> a((size_t)ks * N * Kc), b((size_t)ks * N * Kc);
+            CK(hipMemcpy(a.data(), slab0, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), slab1, b.size() * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0, nz = 0;
+            for (size_t i = 0; i < a.size(); ++i) { bad += memcmp(&a[i], &b[i], 4) != 0; nz += a[i] != 0.f; }
+            printf("tr-read wgrad vs plain wgrad slabs: %zu mismatches of %zu (%zu non-zero), e.g. %g vs %g\n", bad, a.size(), nz, a[12345], b[12345]);
+        }
+        run_all(7, 10);
+        return 0;
     }
     if (getenv("TUNE_FINAL")) {      // 64-channel outputs (post_dense, dx; run with TUNE_C=64): K pipeline of the 64x128 / 64x32 tilings
         PL(1, 4, 2, 1, 2, 4);
