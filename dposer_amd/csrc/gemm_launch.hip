@@ -19,7 +19,7 @@ struct Prof {
 struct ProfScope {
     ProfRec* r = nullptr;
     hipStream_t st;
-    ProfScope(int kind, const GemmArgs& g, hipStream_t s) : st(s) {
+    ProfScope(int kind, double alg_flops, hipStream_t s) : st(s) {
         if (!g_prof.enabled || (g_prof.only >= 0 && kind / 12 != g_prof.only)) return;
         if (g_prof.used == g_prof.pool.size()) {
             ProfRec n;
@@ -28,7 +28,7 @@ struct ProfScope {
         }
         r = &g_prof.pool[g_prof.used++];
         r->kind = kind;
-        r->flops = g.alg_flops;
+        r->flops = alg_flops;
         hipEventRecord(r->a, st);
     }
     ~ProfScope() { if (r) hipEventRecord(r->b, st); }
@@ -53,7 +53,7 @@ void gemm_prof_kind_name(int kind, char* out, int n) {
     const int epi = kind / 12, prec = (kind / 6) % 2, shape = kind % 6;
     snprintf(out, n, "gemm_ft_kernel<%s,%s,%s>", prec ? "fp32" : "bf16", kShapeNames[shape], kEpiNames[epi]);
 }
-#define PROF(EPI) ProfScope _ps((EPI) * 12 + (prec == PREC_FP32 ? 6 : 0) + shape, g, st)
+#define PROF(EPI) ProfScope _ps((EPI) * 12 + (prec == PREC_FP32 ? 6 : 0) + shape, g.alg_flops, st)
 
 
 // Each epilogue only instantiates the tilings it is used with (bit i = GemmShape i).
@@ -115,6 +115,10 @@ hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st) {
     PROF(EPI_SILU_BWD);
     typedef EpiSiLUBwd<__bf16> A; typedef EpiSiLUBwd<float> B; DISPATCH(A, B, M_MAIN);
+}
+hipError_t gemm_wgrad_tr(const WgradTrArgs& g, const WgradParams& p, hipStream_t st) {
+    ProfScope _ps(EPI_WGRAD * 12 + SHAPE_BIG, g.alg_flops, st);
+    return launch_wgrad_tr<2, 4, 4, 2, 4>(g, p, st);
 }
 hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st) {
     PROF(EPI_WGRAD);

@@ -259,6 +259,14 @@ static int wgrad_shape(int n_rows_pad, int k_rows_pad, int64_t Spad) {
     if (big && n_rows_pad % 256 == 0 && k_rows_pad % 256 == 0) return SHAPE_BIG;
     return SHAPE_MID;
 }
+// bf16 wgrads on 256x256 tiles read their operands sample-major (gemm_wgrad_tr.h): when every H x H, H x E and E x E wgrad of
+// the model takes that path, the training epilogues skip the transposed activation copies those GEMMs used to need.
+// DPOSER_WGRAD_TR = 0 forces the transposed-copy path.
+static bool wgrad_tr_mode(const dposer_scorefc_s* h, int64_t Bpad) {
+    static const int forced = [] { const char* e = getenv("DPOSER_WGRAD_TR"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
+    if (forced == 0 || h->f32) return false;
+    return wgrad_shape(h->H, h->H, Bpad) == SHAPE_BIG && wgrad_shape(h->H, h->E, Bpad) == SHAPE_BIG && wgrad_shape(h->E, h->E, Bpad) == SHAPE_BIG;
+}
 static int pick_ksplit(int64_t tiles, int64_t stages, int slots = 512) {
     int ks = 1;
     while (ks < 32 && tiles * ks < slots && stages % (ks * 2) == 0 && stages / (ks * 2) >= 4) ks *= 2;
@@ -661,8 +669,11 @@ extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const vo
 // ------------------------------------------------------------------------------------------------
 // training: DSM loss forward + backward
 // ------------------------------------------------------------------------------------------------
+// dW = dy^T @ in over the batch.  dyT / inT: the operands transposed (FT [rows][Bpad]); dy / in: the same matrices sample-major
+// (FT [Bpad][rows]) -- given (non-null) when the sample-major kernel is to be used, in which case dyT / inT may be null.
 static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n_valid, const void* inT, int k_rows_pad, int k_valid,
-                     int64_t Bpad, float* slabs, int64_t& slab_cursor, int64_t numel, int64_t flat_off, ReduceJobs& rj, hipStream_t st) {
+                     int64_t Bpad, float* slabs, int64_t& slab_cursor, int64_t numel, int64_t flat_off, ReduceJobs& rj, hipStream_t st,
+                     const void* dy = nullptr, const void* in = nullptr) {
     const int shape = wgrad_shape(n_rows_pad, k_rows_pad, Bpad);
     const int ct = shape_ct(shape), stt = shape_st(shape);
     const int kb_total = (int)(Bpad / h->KBS);
@@ -679,7 +690,16 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
     p.ld = k_valid;
     p.N_valid = n_valid;
     p.K_valid = k_valid;
-    DP_HIP_LAUNCH(gemm_wgrad(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
+    if (dy && in) {
+        if (shape != SHAPE_BIG || h->f32) return dposer_set_error(DPOSER_ERR_BAD_ARG, "run_wgrad: sample-major operands need the bf16 256x256 tiling");
+        WgradTrArgs t;
+        std::memset(&t, 0, sizeof(t));
+        t.dY = dy; t.H = in; t.N = n_rows_pad; t.Kc = k_rows_pad; t.n_cblk = n_cblk; t.n_sblk = n_sblk; t.sblocks = (int)(Bpad / 32); t.ksplit = ks;
+        t.alg_flops = g.alg_flops;
+        DP_HIP_LAUNCH(gemm_wgrad_tr(t, p, st));
+    } else {
+        DP_HIP_LAUNCH(gemm_wgrad(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
+    }
     ReduceJob& j = rj.job[rj.n++];
     j.dst_off = flat_off; j.count = numel; j.src_off = slab_cursor; j.src_stride = numel; j.nsrc = ks;
     slab_cursor += (int64_t)ks * numel;
@@ -690,7 +710,8 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
 static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
                               uint32_t step, hipStream_t st) {
     const int L = h->L;
-    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, w.upre, w.tembT, true, w.Bpad, st));
+    const bool tr = wgrad_tr_mode(h, w.Bpad);   // then only post_dense's wgrad still reads a transposed activation (h_{L-1}^T)
+    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, w.upre, tr ? nullptr : w.tembT, true, w.Bpad, st));
     for (int l = 0; l < L; ++l) {
         const void* in = l == 0 ? (const void*)w.xin : (const void*)w.hbuf[l - 1];
         const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[l - 2] : nullptr;
@@ -706,7 +727,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         p.bias = reinterpret_cast<const float*>(packed + h->pk_bias_cat) + (int64_t)l * h->H;
         p.gamma = flat + lo.gamma; p.beta = flat + lo.beta; p.out = w.hbuf[l]; p.resid = resid; p.xhat = w.xhat[l]; p.rstd = w.rstd[l];
         p.H = h->H; p.drop = drop_cfg(h, dropout_on, l, seed, step);
-        p.outT = w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
+        p.outT = (tr && l < L - 1) ? nullptr : w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
         DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, true, shape, g, p, st));
     }
     return run_post(h, flat, packed, w.hbuf[L - 1], w.res, B, w.Bpad, st);
@@ -791,6 +812,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     const int64_t Bpad = w.Bpad;
     const bool want_w = flat_grad != nullptr;
     const bool two = want_w && use_side_stream(Bpad);
+    const bool tr = wgrad_tr_mode(h, Bpad);
     if (two) DP_TRY(ensure_side_stream(h));
     hipStream_t sw = two ? h->side : st;
     ReduceJobs rj;
@@ -813,7 +835,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
             DP_CHECK_HIP(hipMemsetAsync(flat_grad + h->nograd_lo[i], 0, (h->nograd_hi[i] - h->nograd_lo[i]) * sizeof(float), sw));
         // operands that only depend on the forward pass
         DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.xin, w.xinT, Bpad, h->Dpad, sw));
-        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, sw));
+        if (!tr) DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, sw));
         // post_dense: bias (column sums of dres) and weight
         DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, sw));
         DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, sw));
@@ -835,7 +857,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         p.carry_out = (even && j >= 2) ? w.carry[(j / 2) & 1] : nullptr;
         p.xhat = w.xhat[j]; p.rstd = w.rstd[j]; p.gamma = flat + h->layer[j].gamma; p.beta = flat + h->layer[j].beta;
         p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B; p.drop = drop_cfg(h, dropout_on, j, seed, step);
-        p.dyT = want_w ? w.dyT[j] : nullptr; p.Spad = Bpad;
+        p.dyT = (want_w && !(tr && j >= 1)) ? w.dyT[j] : nullptr; p.Spad = Bpad;   // (layer 0's feeds the 1024 x 64 pre_dense wgrad)
         DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st));
         if (!want_w) continue;
         if (two) {
@@ -845,8 +867,10 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         // parameter gradients of layer j
         const void* inT = (j == 0) ? (const void*)w.xinT : (const void*)w.hT[j - 1];
         const LayerOff& lo = h->layer[j];
-        DP_TRY(run_wgrad(h, w.dyT[j], H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw));
-        DP_TRY(run_wgrad(h, w.dyT[j], H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw));
+        if (tr && j >= 1) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], w.hbuf[j - 1]));
+        else DP_TRY(run_wgrad(h, w.dyT[j], H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw));
+        if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw, w.dy[j], w.temb));
+        else DP_TRY(run_wgrad(h, w.dyT[j], H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw));
         add_job(lo.gamma, H, w.gn_part[j] + 0 * H, 3 * (int64_t)H, ws_rows);
         add_job(lo.beta, H, w.gn_part[j] + 1 * H, 3 * (int64_t)H, ws_rows);
         add_job(lo.b, H, w.gn_part[j] + 2 * H, 3 * (int64_t)H, ws_rows);
@@ -875,7 +899,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         GemmArgs g = gemm_args(packed + h->pk_wtT_all, L * H / KBS, E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
         for (int l = 0; l < L; ++l) add_seg(g, w.dy[l], H / KBS);
         SiLUBwdParams p;
-        p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B; p.outT = w.dUT; p.Spad = Bpad;
+        p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B; p.outT = tr ? nullptr : w.dUT; p.Spad = Bpad;
         DP_HIP_LAUNCH(gemm_silu_bwd(prec, shape, g, p, st));
     }
     if (two) {
@@ -883,7 +907,8 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         DP_CHECK_HIP(hipStreamWaitEvent(sw, h->ev_time, 0));
     }
     DP_HIP_LAUNCH(launch_colsum(h->f32, w.dU, w.cs_part_se, Bpad, E, &n_chunks_se, sw));
-    DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw));
+    if (tr) DP_TRY(run_wgrad(h, nullptr, E, E, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw, w.dU, w.emb));
+    else DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw));
     // last bucket: layer 0 (jobs queued above), the shared time embedding and the parameters that never get a gradient
     add_job(h->off_se_b, E, w.cs_part_se, E, n_chunks_se);
     DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1, sw));
