@@ -27,8 +27,8 @@ hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTPa
 hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st);
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st);
 hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st);
-// bf16, 256x256 tiles, operands sample-major (gemm_wgrad_tr.h): no transposed activation copies needed
-hipError_t gemm_wgrad_tr(const WgradTrArgs& g, const WgradParams& p, hipStream_t st);
+// bf16, 256x256 or 128x128 tiles, operands sample-major (gemm_wgrad_tr.h): no transposed activation copies needed
+hipError_t gemm_wgrad_tr(int shape, const WgradTrArgs& g, const WgradParams& p, hipStream_t st);
 
 // ---- optional per-launch profiling (HIP events on the launch stream; off by default) ------------------
 enum GemmEpiKind : int { EPI_GN = 0, EPI_GN_TRAIN, EPI_BIAS_SILU, EPI_ROWMAJOR, EPI_PLAIN_FT, EPI_GN_BWD, EPI_SILU_BWD, EPI_WGRAD, EPI_EM_STEP, EPI_KINDS };

@@ -116,9 +116,11 @@ hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdPa
     PROF(EPI_SILU_BWD);
     typedef EpiSiLUBwd<__bf16> A; typedef EpiSiLUBwd<float> B; DISPATCH(A, B, M_MAIN);
 }
-hipError_t gemm_wgrad_tr(const WgradTrArgs& g, const WgradParams& p, hipStream_t st) {
-    ProfScope _ps(EPI_WGRAD * 12 + SHAPE_BIG, g.alg_flops, st);
-    return launch_wgrad_tr<2, 4, 4, 2, 4>(g, p, st);
+hipError_t gemm_wgrad_tr(int shape, const WgradTrArgs& g, const WgradParams& p, hipStream_t st) {
+    ProfScope _ps(EPI_WGRAD * 12 + shape, g.alg_flops, st);
+    if (shape == SHAPE_BIG) return launch_wgrad_tr<2, 4, 4, 2, 4>(g, p, st);
+    if (shape == SHAPE_MID) return launch_wgrad_tr<2, 2, 2, 2, 4>(g, p, st);
+    return hipErrorInvalidValue;
 }
 hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st) {
     PROF(EPI_WGRAD);

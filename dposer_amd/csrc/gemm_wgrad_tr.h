@@ -31,7 +31,7 @@ struct WgradTrArgs {
 };
 
 template <int WC, int WS, int TC, int TS, int NB>
-__global__ void __launch_bounds__(WC* WS * 64, 1) gemm_wgrad_tr_kernel(WgradTrArgs g, WgradParams ep) {
+__global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_wgrad_tr_kernel(WgradTrArgs g, WgradParams ep) {
     typedef __bf16 T;
     constexpr int KB = 2;
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;

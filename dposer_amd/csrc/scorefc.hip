@@ -259,13 +259,14 @@ static int wgrad_shape(int n_rows_pad, int k_rows_pad, int64_t Spad) {
     if (big && n_rows_pad % 256 == 0 && k_rows_pad % 256 == 0) return SHAPE_BIG;
     return SHAPE_MID;
 }
-// bf16 wgrads on 256x256 tiles read their operands sample-major (gemm_wgrad_tr.h): when every H x H, H x E and E x E wgrad of
+// bf16 wgrads on 256x256 / 128x128 tiles read their operands sample-major (gemm_wgrad_tr.h): when every H x H, H x E and E x E wgrad of
 // the model takes that path, the training epilogues skip the transposed activation copies those GEMMs used to need.
 // DPOSER_WGRAD_TR = 0 forces the transposed-copy path.
 static bool wgrad_tr_mode(const dposer_scorefc_s* h, int64_t Bpad) {
     static const int forced = [] { const char* e = getenv("DPOSER_WGRAD_TR"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
     if (forced == 0 || h->f32) return false;
-    return wgrad_shape(h->H, h->H, Bpad) == SHAPE_BIG && wgrad_shape(h->H, h->E, Bpad) == SHAPE_BIG && wgrad_shape(h->E, h->E, Bpad) == SHAPE_BIG;
+    auto ok = [&](int n, int k) { const int s = wgrad_shape(n, k, Bpad); return s == SHAPE_BIG || s == SHAPE_MID; };
+    return ok(h->H, h->H) && ok(h->H, h->E) && ok(h->E, h->E);
 }
 static int pick_ksplit(int64_t tiles, int64_t stages, int slots = 512) {
     int ks = 1;
@@ -691,12 +692,12 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
     p.N_valid = n_valid;
     p.K_valid = k_valid;
     if (dy && in) {
-        if (shape != SHAPE_BIG || h->f32) return dposer_set_error(DPOSER_ERR_BAD_ARG, "run_wgrad: sample-major operands need the bf16 256x256 tiling");
+        if ((shape != SHAPE_BIG && shape != SHAPE_MID) || h->f32) return dposer_set_error(DPOSER_ERR_BAD_ARG, "run_wgrad: sample-major operands need a bf16 256x256 / 128x128 tiling");
         WgradTrArgs t;
         std::memset(&t, 0, sizeof(t));
         t.dY = dy; t.H = in; t.N = n_rows_pad; t.Kc = k_rows_pad; t.n_cblk = n_cblk; t.n_sblk = n_sblk; t.sblocks = (int)(Bpad / 32); t.ksplit = ks;
         t.alg_flops = g.alg_flops;
-        DP_HIP_LAUNCH(gemm_wgrad_tr(t, p, st));
+        DP_HIP_LAUNCH(gemm_wgrad_tr(shape, t, p, st));
     } else {
         DP_HIP_LAUNCH(gemm_wgrad(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
     }
