@@ -27,7 +27,7 @@ hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTPa
 hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st);
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st);
 hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st);
-// bf16, 256x256 or 128x128 tiles, operands sample-major (gemm_wgrad_tr.h): no transposed activation copies needed
+// bf16, any wgrad tiling (256x256, 128x128, 64x128, 128x64), operands sample-major (gemm_wgrad_tr.h): no transposed activation copies needed
 hipError_t gemm_wgrad_tr(int shape, const WgradTrArgs& g, const WgradParams& p, hipStream_t st);
 
 // ---- optional per-launch profiling (HIP events on the launch stream; off by default) ------------------

@@ -120,6 +120,8 @@ hipError_t gemm_wgrad_tr(int shape, const WgradTrArgs& g, const WgradParams& p, 
     ProfScope _ps(EPI_WGRAD * 12 + shape, g.alg_flops, st);
     if (shape == SHAPE_BIG) return launch_wgrad_tr<2, 4, 4, 2, 4>(g, p, st);
     if (shape == SHAPE_MID) return launch_wgrad_tr<2, 2, 2, 2, 4>(g, p, st);
+    if (shape == SHAPE_FINAL) return launch_wgrad_tr<1, 4, 2, 1, 4>(g, p, st);
+    if (shape == SHAPE_WIDE64) return launch_wgrad_tr<2, 2, 2, 1, 4>(g, p, st);
     return hipErrorInvalidValue;
 }
 hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st) {

@@ -259,14 +259,13 @@ static int wgrad_shape(int n_rows_pad, int k_rows_pad, int64_t Spad) {
     if (big && n_rows_pad % 256 == 0 && k_rows_pad % 256 == 0) return SHAPE_BIG;
     return SHAPE_MID;
 }
-// bf16 wgrads on 256x256 / 128x128 tiles read their operands sample-major (gemm_wgrad_tr.h): when every H x H, H x E and E x E wgrad of
-// the model takes that path, the training epilogues skip the transposed activation copies those GEMMs used to need.
+// bf16 wgrads read their operands sample-major (gemm_wgrad_tr.h): the training epilogues then skip the transposed activation
+// copies those GEMMs used to need (fp32 = parity mode keeps them: there is no 32-bit transposing LDS read).
 // DPOSER_WGRAD_TR = 0 forces the transposed-copy path.
 static bool wgrad_tr_mode(const dposer_scorefc_s* h, int64_t Bpad) {
     static const int forced = [] { const char* e = getenv("DPOSER_WGRAD_TR"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
-    if (forced == 0 || h->f32) return false;
-    auto ok = [&](int n, int k) { const int s = wgrad_shape(n, k, Bpad); return s == SHAPE_BIG || s == SHAPE_MID; };
-    return ok(h->H, h->H) && ok(h->H, h->E) && ok(h->E, h->E);
+    (void)Bpad;
+    return forced != 0 && !h->f32;      // every wgrad tiling has a sample-major instantiation
 }
 static int pick_ksplit(int64_t tiles, int64_t stages, int slots = 512) {
     int ks = 1;
@@ -692,7 +691,7 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
     p.N_valid = n_valid;
     p.K_valid = k_valid;
     if (dy && in) {
-        if ((shape != SHAPE_BIG && shape != SHAPE_MID) || h->f32) return dposer_set_error(DPOSER_ERR_BAD_ARG, "run_wgrad: sample-major operands need a bf16 256x256 / 128x128 tiling");
+        if (h->f32) return dposer_set_error(DPOSER_ERR_BAD_ARG, "run_wgrad: sample-major operands are bf16 only");
         WgradTrArgs t;
         std::memset(&t, 0, sizeof(t));
         t.dY = dy; t.H = in; t.N = n_rows_pad; t.Kc = k_rows_pad; t.n_cblk = n_cblk; t.n_sblk = n_sblk; t.sblocks = (int)(Bpad / 32); t.ksplit = ks;
@@ -711,7 +710,7 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
 static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
                               uint32_t step, hipStream_t st) {
     const int L = h->L;
-    const bool tr = wgrad_tr_mode(h, w.Bpad);   // then only post_dense's wgrad still reads a transposed activation (h_{L-1}^T)
+    const bool tr = wgrad_tr_mode(h, w.Bpad);   // then no wgrad reads a transposed activation
     DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, w.upre, tr ? nullptr : w.tembT, true, w.Bpad, st));
     for (int l = 0; l < L; ++l) {
         const void* in = l == 0 ? (const void*)w.xin : (const void*)w.hbuf[l - 1];
@@ -728,7 +727,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         p.bias = reinterpret_cast<const float*>(packed + h->pk_bias_cat) + (int64_t)l * h->H;
         p.gamma = flat + lo.gamma; p.beta = flat + lo.beta; p.out = w.hbuf[l]; p.resid = resid; p.xhat = w.xhat[l]; p.rstd = w.rstd[l];
         p.H = h->H; p.drop = drop_cfg(h, dropout_on, l, seed, step);
-        p.outT = (tr && l < L - 1) ? nullptr : w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
+        p.outT = tr ? nullptr : w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
         DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, true, shape, g, p, st));
     }
     return run_post(h, flat, packed, w.hbuf[L - 1], w.res, B, w.Bpad, st);
@@ -835,12 +834,18 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         for (int i = 0; i < h->n_nograd; ++i)
             DP_CHECK_HIP(hipMemsetAsync(flat_grad + h->nograd_lo[i], 0, (h->nograd_hi[i] - h->nograd_lo[i]) * sizeof(float), sw));
         // operands that only depend on the forward pass
-        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.xin, w.xinT, Bpad, h->Dpad, sw));
-        if (!tr) DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, sw));
+        if (!tr) {
+            DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.xin, w.xinT, Bpad, h->Dpad, sw));
+            DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, sw));
+        }
         // post_dense: bias (column sums of dres) and weight
         DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, sw));
-        DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, sw));
-        DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.hT[L - 1], H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, sw));
+        if (tr) {
+            DP_TRY(run_wgrad(h, nullptr, h->Cp, h->D, nullptr, H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, sw, w.dres, w.hbuf[L - 1]));
+        } else {
+            DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, sw));
+            DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.hT[L - 1], H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, sw));
+        }
     }
     const int gshape = gnbwd_shape(Bpad);
     const int ws_rows = (int)(Bpad / (shape_st(gshape) * 32)) * shape_ws(gshape);   // partial rows written by the dgrad epilogue
@@ -858,7 +863,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         p.carry_out = (even && j >= 2) ? w.carry[(j / 2) & 1] : nullptr;
         p.xhat = w.xhat[j]; p.rstd = w.rstd[j]; p.gamma = flat + h->layer[j].gamma; p.beta = flat + h->layer[j].beta;
         p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B; p.drop = drop_cfg(h, dropout_on, j, seed, step);
-        p.dyT = (want_w && !(tr && j >= 1)) ? w.dyT[j] : nullptr; p.Spad = Bpad;   // (layer 0's feeds the 1024 x 64 pre_dense wgrad)
+        p.dyT = (want_w && !tr) ? w.dyT[j] : nullptr; p.Spad = Bpad;
         DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st));
         if (!want_w) continue;
         if (two) {
@@ -868,7 +873,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         // parameter gradients of layer j
         const void* inT = (j == 0) ? (const void*)w.xinT : (const void*)w.hT[j - 1];
         const LayerOff& lo = h->layer[j];
-        if (tr && j >= 1) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], w.hbuf[j - 1]));
+        if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], j == 0 ? (const void*)w.xin : (const void*)w.hbuf[j - 1]));
         else DP_TRY(run_wgrad(h, w.dyT[j], H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw));
         if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw, w.dy[j], w.temb));
         else DP_TRY(run_wgrad(h, w.dyT[j], H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw));
