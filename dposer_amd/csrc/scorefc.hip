@@ -315,13 +315,15 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         w.dres = take(Bpad * h->Cp * esz);
         w.tbuf = (float*)take(Bpad * 4);
         w.zbuf = (float*)take(Bpad * h->Dpad * 4);
-        for (int l = 0; l < L; ++l) w.dyT[l] = take(Bpad * H * esz);
-        for (int l = 0; l < L; ++l) w.hT[l] = take(Bpad * H * esz);
-        w.tembT = take(Bpad * E * esz);
-        w.embT = take(Bpad * E * esz);
-        w.xinT = take(Bpad * h->Dpad * esz);
-        w.dresT = take(Bpad * h->Cp * esz);
-        w.dUT = take(Bpad * E * esz);
+        if (!wgrad_tr_mode(h, Bpad)) {   // transposed operand copies of the wgrad GEMMs (fp32 mode only: bf16 reads sample-major)
+            for (int l = 0; l < L; ++l) w.dyT[l] = take(Bpad * H * esz);
+            for (int l = 0; l < L; ++l) w.hT[l] = take(Bpad * H * esz);
+            w.tembT = take(Bpad * E * esz);
+            w.embT = take(Bpad * E * esz);
+            w.xinT = take(Bpad * h->Dpad * esz);
+            w.dresT = take(Bpad * h->Cp * esz);
+            w.dUT = take(Bpad * E * esz);
+        }
         const int64_t nchunks = ceil_div(Bpad, 2048);
         w.cs_part_post = (float*)take(nchunks * h->Cp * 4);
         w.cs_part_se = (float*)take(nchunks * E * 4);
