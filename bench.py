@@ -152,9 +152,13 @@ def main():
     torch.cuda.synchronize()
     # live roofline: HIP events around the launches of the dominant GEMM kind only (bracketing all ~30 GEMM launches of a
     # step costs ~3 % of it; the full per-kind table comes from three extra, untimed steps below)
-    _C.profile_enable(True, only=DOMINANT_KIND)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        # ... and only in every 4th step: the two event records per launch keep dependent kernels ~10 us apart
+        if i % 4 == 0:
+            _C.profile_enable(True, only=DOMINANT_KIND)
+        elif i % 4 == 1:
+            _C.profile_pause()
         out = step_fn(state, batch)
     torch.cuda.synchronize()
     ddp.barrier()

@@ -147,6 +147,11 @@ def profile_enable(on: bool, only: str = None):
     lib().dposer_profile_enable((2 + PROFILE_EPI_KINDS.index(only) if only else 1) if on else 0)
 
 
+def profile_pause():
+    """Stop recording without discarding what has been recorded (profile_enable(True, ...) resumes)."""
+    lib().dposer_profile_enable(-1)
+
+
 def profile_collect():
     """{kernel kind name: (total_ms, launches, algorithmic_flops)} of the GEMM launches since the last collect."""
     l = lib()

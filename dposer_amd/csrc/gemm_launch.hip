@@ -36,7 +36,12 @@ struct ProfScope {
 const char* kEpiNames[EPI_KINDS] = {"gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad", "post_em_step"};
 const char* kShapeNames[6] = {"256x256", "128x128", "128x32", "64x128", "64x32", "128x64"};
 }   // namespace
-void gemm_prof_enable(int on) { g_prof.enabled = on != 0; g_prof.only = on >= 2 ? on - 2 : -1; if (!on) g_prof.used = 0; }
+void gemm_prof_enable(int on) {
+    if (on < 0) { g_prof.enabled = 0; return; }      // pause: keep what was recorded so far
+    g_prof.enabled = on != 0;
+    g_prof.only = on >= 2 ? on - 2 : -1;
+    if (!on) g_prof.used = 0;
+}
 int gemm_prof_collect(double* ms, long long* launches, double* flops) {
     for (int i = 0; i < GEMM_PROF_KINDS; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = 0; }
     for (size_t i = 0; i < g_prof.used; ++i) {

@@ -174,7 +174,7 @@ int dposer_adam_ema_clip_step(float* flat_params, const float* flat_grad, float*
  * default).  collect() synchronises the recorded events and returns, per kernel kind, the summed
  * duration [ms], launch count and algorithmic FLOPs (2*M*N*K of the un-padded problem); arrays of
  * dposer_profile_num_kinds() entries in HOST memory.  Used by bench.py for the live roofline.
- * enable(on): 0 = off, 1 = every GEMM launch, 2 + k = launches of epilogue kind k only (k: 0 gn_fwd, 1 gn_fwd_train,
+ * enable(on): 0 = off (and forget the records), -1 = pause (keep them), 1 = every GEMM launch, 2 + k = launches of epilogue kind k only (k: 0 gn_fwd, 1 gn_fwd_train,
  * 2 bias_silu, 3 rowmajor, 4 plain_ft, 5 gn_bwd_dgrad, 6 silu_bwd_dgrad, 7 wgrad, 8 post_em_step) -- two event records per
  * launch cost about 3 % of a training step when every launch is bracketed, so a timed region brackets one kind. */
 void dposer_profile_enable(int32_t on);
