@@ -502,6 +502,7 @@ def test_integration_md_ctypes_stub_runs():
 @pytest.mark.parametrize("env", [
     {"DPOSER_GNBWD_BIG": "1", "DPOSER_WGRAD_BIG": "1", "DPOSER_BIG_MIN_BATCH": "256"},      # 256x256 tilings from 256 samples up
     {"DPOSER_GNBWD_BIG": "0", "DPOSER_WGRAD_BIG": "0", "DPOSER_WGRAD_STREAM": "0"},          # 128x128 everywhere, single stream
+    {"DPOSER_WGRAD_TR": "0"},                                                                # bf16 wgrads on transposed copies
 ])
 def test_alternative_tilings_and_streams_keep_parity(env):
     """The tiling / stream policy depends on the batch size (256x256 GroupNorm-backward and wgrad tiles from 32768 samples,
@@ -519,6 +520,35 @@ def test_alternative_tilings_and_streams_keep_parity(env):
                        cwd=root, env=child_env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("B,extra", [(640, {}), (1024, {"DPOSER_WGRAD_BIG": "1"})])
+def test_sample_major_wgrad_is_bit_identical_to_transposed_copy_path(B, extra, tmp_path):
+    """bf16 weight gradients: the kernel that reads sample-major operands through transposing LDS reads (gemm_wgrad_tr.h,
+    default) and the plain kernel on transposed activation copies (DPOSER_WGRAD_TR=0, child process) accumulate in the same
+    order -- the flat gradient must agree bit for bit, for the 128x128 / 64x128 / 128x64 tilings and (forced) 256x256."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, os, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests')); sys.path.insert(0, os.path.join({root!r}, 'tests', 'golden'))\n"
+        "from gpu_common import make_model\n"
+        "from test_gpu_score import _fused_grad, _dev\n"
+        f"cfg, m, p = make_model(5, precision='bf16', dropout=0.1)\n"
+        f"rs = np.random.RandomState(3); batch = rs.standard_normal(({B}, 63)).astype(np.float32)\n"
+        "loss, fg = _fused_grad(m, _dev(batch), None, None, step=11)\n"
+        "np.save(sys.argv[1], fg.detach().cpu().numpy())\n")
+    outs = []
+    for tr in ("1", "0"):
+        out = str(tmp_path / f"fg_tr{tr}.npy")
+        env = dict(os.environ, DPOSER_WGRAD_TR=tr, **extra)
+        r = subprocess.run([sys.executable, "-c", code, out], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all() and np.abs(outs[0]).max() > 0
+    assert np.array_equal(outs[0], outs[1])
 
 
 def test_vp_sde_fused_paths_vs_oracle():
