@@ -503,6 +503,7 @@ def test_integration_md_ctypes_stub_runs():
     {"DPOSER_GNBWD_BIG": "1", "DPOSER_WGRAD_BIG": "1", "DPOSER_BIG_MIN_BATCH": "256"},      # 256x256 tilings from 256 samples up
     {"DPOSER_GNBWD_BIG": "0", "DPOSER_WGRAD_BIG": "0", "DPOSER_WGRAD_STREAM": "0"},          # 128x128 everywhere, single stream
     {"DPOSER_WGRAD_TR": "0"},                                                                # bf16 wgrads on transposed copies
+    {"DPOSER_WGRAD_STREAM": "1"},                                                            # wgrads on the second stream (default 8192..16384)
 ])
 def test_alternative_tilings_and_streams_keep_parity(env):
     """The tiling / stream policy depends on the batch size (256x256 GroupNorm-backward and wgrad tiles from 32768 samples,
