@@ -523,7 +523,7 @@ def test_alternative_tilings_and_streams_keep_parity(env):
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-@pytest.mark.parametrize("B,extra", [(640, {}), (1024, {"DPOSER_WGRAD_BIG": "1"})])
+@pytest.mark.parametrize("B,extra", [(640, {}), (1024, {"DPOSER_WGRAD_BIG": "1"}), (96, {}), (1500, {}), (2304, {"DPOSER_WGRAD_BIG": "1"})])
 def test_sample_major_wgrad_is_bit_identical_to_transposed_copy_path(B, extra, tmp_path):
     """bf16 weight gradients: the kernel that reads sample-major operands through transposing LDS reads (gemm_wgrad_tr.h,
     default) and the plain kernel on transposed activation copies (DPOSER_WGRAD_TR=0, child process) accumulate in the same
