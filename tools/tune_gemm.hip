@@ -1,7 +1,12 @@
 // Tile-shape / epilogue-cost tuner for the score-network GEMM (run on the GPU box):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Idposer_amd/csrc -Iinclude -Itools tools/tune_gemm.hip -o tools/bin/tune_gemm
 //   tools/bin/tune_gemm [S]            default table        TUNE_K=1536 ...    reduction length of the layer GEMM
-//   TUNE_GNBWD=1 / TUNE_PLAIN=1 / TUNE_PIPE=1 / TUNE_PROFILE=1   focused case lists (see main)
+//   focused case lists (see main), one per run:
+//     TUNE_RING      2-slot K loop vs ring pipeline per epilogue        TUNE_TAILS   ring prologue / tail paths, bit for bit
+//     TUNE_WTR       wgrad from sample-major operands (tr reads) vs the plain kernel on transposed copies, bit for bit + time
+//     TUNE_RESID     residual input of the GroupNorm forward epilogues  TUNE_DROPCOST  Philox dropout draws
+//     TUNE_2WG       4-wave tiles, two workgroups per CU                TUNE_FINAL (+ TUNE_C=64)  64-channel output tilings
+//     TUNE_GNBWD / TUNE_PLAIN / TUNE_SMALLB / TUNE_PIPE / TUNE_PROFILE  earlier studies (tilings, pipelined kernel, PMC runs)
 // Times one layer GEMM (C = 1024 channels, K = 1024, S = 65536 samples) per (tiling, epilogue); the cases of a run are
 // interleaved over 7 rounds and min / median are reported, because clocks drift by several percent within a process.
 #include <hip/hip_runtime.h>
