@@ -353,11 +353,14 @@ static inline hipError_t launch_gemm(const GemmArgs& g, const typename Epi::Para
     auto kern = gemm_ft_kernel<T, WC, WS, TC, TS, KB, Epi, NB>;
     constexpr int lds_bytes = NB * C::STAGE_BYTES + EpiParamArrays<Epi>::value * C::CT * 32 * 4 + EpiScratch<Epi>::value * C::NW;
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set && lds_bytes > 64 * 1024) {
+    // (function attributes are per device: a process that drives several GPUs sets it once on each)
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (lds_bytes > 64 * 1024 && hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (lds_bytes > 64 * 1024 && !attr_set[dev & 63]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev & 63] = true;
     }
     dim3 grid(g.n_cblk * g.n_sblk, g.ksplit > 1 ? g.ksplit : 1, 1);
     hipLaunchKernelGGL(kern, grid, dim3(C::THREADS), lds_bytes, stream, g, ep);
