@@ -252,8 +252,10 @@ struct WgradPlan {
 // workgroups) win from 32768 samples up (93 vs 109 us per 1024x1024 wgrad at 65536; measured slower at 16384 and below, where
 // the per-split k-range gets too short).  DPOSER_WGRAD_BIG = 0 / 1 forces the choice.
 static int wgrad_shape(int n_rows_pad, int k_rows_pad, int64_t Spad) {
-    if (n_rows_pad < 128) return SHAPE_FINAL;
-    if (k_rows_pad < 128) return SHAPE_WIDE64;
+    // (rows / columns come in multiples of 64: data dimensions of 129..192, e.g. 52 joints x 3, pad to 192 -- only the 64-row /
+    //  64-column tilings divide that)
+    if (n_rows_pad % 128 != 0) return SHAPE_FINAL;
+    if (k_rows_pad % 128 != 0) return SHAPE_WIDE64;
     static const int forced = [] { const char* e = getenv("DPOSER_WGRAD_BIG"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
     const bool big = forced >= 0 ? forced == 1 : Spad >= 32768;
     if (big && n_rows_pad % 256 == 0 && k_rows_pad % 256 == 0) return SHAPE_BIG;

@@ -523,8 +523,9 @@ def test_alternative_tilings_and_streams_keep_parity(env):
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-@pytest.mark.parametrize("B,extra", [(640, {}), (1024, {"DPOSER_WGRAD_BIG": "1"}), (96, {}), (1500, {}), (2304, {"DPOSER_WGRAD_BIG": "1"})])
-def test_sample_major_wgrad_is_bit_identical_to_transposed_copy_path(B, extra, tmp_path):
+@pytest.mark.parametrize("B,extra,D", [(640, {}, 63), (1024, {"DPOSER_WGRAD_BIG": "1"}, 63), (96, {}, 63), (1500, {}, 63),
+                                       (2304, {"DPOSER_WGRAD_BIG": "1"}, 63), (320, {}, 147), (320, {}, 126)])
+def test_sample_major_wgrad_is_bit_identical_to_transposed_copy_path(B, extra, D, tmp_path):
     """bf16 weight gradients: the kernel that reads sample-major operands through transposing LDS reads (gemm_wgrad_tr.h,
     default) and the plain kernel on transposed activation copies (DPOSER_WGRAD_TR=0, child process) accumulate in the same
     order -- the flat gradient must agree bit for bit, for the 128x128 / 64x128 / 128x64 tilings and (forced) 256x256."""
@@ -537,8 +538,8 @@ def test_sample_major_wgrad_is_bit_identical_to_transposed_copy_path(B, extra, t
         f"sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests')); sys.path.insert(0, os.path.join({root!r}, 'tests', 'golden'))\n"
         "from gpu_common import make_model\n"
         "from test_gpu_score import _fused_grad, _dev\n"
-        f"cfg, m, p = make_model(5, precision='bf16', dropout=0.1)\n"
-        f"rs = np.random.RandomState(3); batch = rs.standard_normal(({B}, 63)).astype(np.float32)\n"
+        f"cfg, m, p = make_model(5, D={D}, precision='bf16', dropout=0.1)\n"
+        f"rs = np.random.RandomState(3); batch = rs.standard_normal(({B}, {D})).astype(np.float32)\n"
         "loss, fg = _fused_grad(m, _dev(batch), None, None, step=11)\n"
         "np.save(sys.argv[1], fg.detach().cpu().numpy())\n")
     outs = []
@@ -598,10 +599,10 @@ def test_vp_sde_fused_paths_vs_oracle():
 
 @pytest.mark.parametrize("n_blocks,E,n_poses,pose_dim,sbs", [(1, 512, 21, 3, True), (3, 256, 21, 3, True), (1, 128, 21, 3, True),
                                                             (2, 512, 16, 4, True), (2, 512, 32, 4, False), (2, 384, 40, 5, True),
-                                                            (2, 512, 1, 3, True)])
+                                                            (2, 512, 1, 3, True), (2, 512, 50, 3, True)])
 def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sbs):
     """ScoreModelFC configurations other than the shipped one (2 blocks, embed 512, D = 63, scale_by_sigma): depth (residual-carry
-    logic, bucket layout), embedding width, data dimensions that are / are not multiples of the 64-column padding (64, 128, 200, 3)
+    logic, bucket layout), embedding width, data dimensions that are / are not multiples of the 64-column padding (64, 128, 150, 200, 3)
     and scale_by_sigma off.  Forward, sampler step and all gradients vs the oracle (general, pinned at the shipped shape)."""
     from dposer_amd.algorithms.advanced import losses, sampling, sde_lib
     from dposer_amd.algorithms.advanced.model import ScoreModelFC
