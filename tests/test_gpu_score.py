@@ -553,6 +553,28 @@ def test_sample_major_wgrad_is_bit_identical_to_transposed_copy_path(B, extra, D
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("B", [8193, 16385, 32769])
+def test_gradient_is_linear_in_the_batch_across_tiling_thresholds(B):
+    """Size-independent property at the batch sizes where the tiling / stream policies switch (padded to 8448, 16640, 33024
+    samples; bf16, dropout off, injected t and z): loss and flat gradient of the whole batch equal the sample-weighted
+    combination of two uneven halves evaluated separately (which take other tilings)."""
+    cfg, m, p = make_model(5, precision="bf16", dropout=0.0)
+    rs = np.random.RandomState(B)
+    x = rs.standard_normal((B, 63)).astype(np.float32)
+    t = rs.uniform(1e-3, 1.0, B).astype(np.float32)
+    z = rs.standard_normal((B, 63)).astype(np.float32)
+    l, g = _fused_grad(m, _dev(x), _dev(t), _dev(z))
+    g = g.clone()
+    h = B // 2 + 7
+    l1, g1 = _fused_grad(m, _dev(x[:h]), _dev(t[:h]), _dev(z[:h]))
+    g1 = g1.clone()
+    l2, g2 = _fused_grad(m, _dev(x[h:]), _dev(t[h:]), _dev(z[h:]))
+    gc = (h * g1 + (B - h) * g2) / B
+    lc = (h * l1 + (B - h) * l2) / B
+    assert abs(l - lc) / lc < 1e-4
+    assert float((g - gc).norm() / gc.norm()) < 2e-3
+
+
 def test_vp_sde_fused_paths_vs_oracle():
     """The fused sampler (both step paths), the prior loss and the DSM gradient under the VP SDE (std = sqrt(1 - e^{2 lmc}),
     g = sqrt(beta): the other branch of the SDE scalars inside the kernels) against the oracle's VP class."""
