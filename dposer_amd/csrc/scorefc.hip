@@ -82,7 +82,7 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
                  "32-channel accumulator tile per group");
     DP_CHECK_ARG(desc->embed_dim > 0 && desc->embed_dim % 128 == 0, "embed_dim must be a multiple of 128");
     DP_CHECK_ARG(desc->n_blocks >= 1 && desc->n_blocks <= 3, "n_blocks must be 1..3");
-    DP_CHECK_ARG(desc->data_dim > 0 && desc->data_dim <= 256, "data_dim must be in 1..256");
+    DP_CHECK_ARG(desc->data_dim > 0 && desc->data_dim <= 512, "data_dim must be in 1..512");
     DP_CHECK_ARG(desc->precision == DPOSER_PREC_BF16 || desc->precision == DPOSER_PREC_FP32, "bad precision");
     DP_CHECK_ARG(desc->dropout_p >= 0.f && desc->dropout_p < 1.f, "dropout_p must be in [0,1)");
     auto* h = new dposer_scorefc_s();

@@ -49,7 +49,7 @@ enum { DPOSER_EMB_POSITIONAL = 0, DPOSER_EMB_FOURIER = 1 };
 enum { DPOSER_SDE_SUBVP = 0, DPOSER_SDE_VP = 1 };
 
 typedef struct {
-    int32_t data_dim;        /* n_poses * pose_dim: 63 (axis-angle) or 126 (rot6d)  model.py:109 */
+    int32_t data_dim;        /* n_poses * pose_dim: 63 (axis-angle) or 126 (rot6d), 1..512  model.py:109 */
     int32_t hidden_dim;      /* must be a multiple of 1024 (GroupNorm(32, H) groups of 32 channels) */
     int32_t embed_dim;       /* multiple of 128 */
     int32_t n_blocks;        /* 1..3 */

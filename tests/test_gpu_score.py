@@ -524,7 +524,7 @@ def test_alternative_tilings_and_streams_keep_parity(env):
 
 
 @pytest.mark.parametrize("B,extra,D", [(640, {}, 63), (1024, {"DPOSER_WGRAD_BIG": "1"}, 63), (96, {}, 63), (1500, {}, 63),
-                                       (2304, {"DPOSER_WGRAD_BIG": "1"}, 63), (320, {}, 147), (320, {}, 126)])
+                                       (2304, {"DPOSER_WGRAD_BIG": "1"}, 63), (320, {}, 147), (320, {}, 126), (320, {}, 336)])
 def test_sample_major_wgrad_is_bit_identical_to_transposed_copy_path(B, extra, D, tmp_path):
     """bf16 weight gradients: the kernel that reads sample-major operands through transposing LDS reads (gemm_wgrad_tr.h,
     default) and the plain kernel on transposed activation copies (DPOSER_WGRAD_TR=0, child process) accumulate in the same
@@ -621,10 +621,10 @@ def test_vp_sde_fused_paths_vs_oracle():
 
 @pytest.mark.parametrize("n_blocks,E,n_poses,pose_dim,sbs", [(1, 512, 21, 3, True), (3, 256, 21, 3, True), (1, 128, 21, 3, True),
                                                             (2, 512, 16, 4, True), (2, 512, 32, 4, False), (2, 384, 40, 5, True),
-                                                            (2, 512, 1, 3, True), (2, 512, 50, 3, True)])
+                                                            (2, 512, 1, 3, True), (2, 512, 50, 3, True), (2, 512, 55, 6, True)])
 def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sbs):
     """ScoreModelFC configurations other than the shipped one (2 blocks, embed 512, D = 63, scale_by_sigma): depth (residual-carry
-    logic, bucket layout), embedding width, data dimensions that are / are not multiples of the 64-column padding (64, 128, 150, 200, 3)
+    logic, bucket layout), embedding width, data dimensions that are / are not multiples of the 64-column padding (64, 128, 150, 200, 330, 3)
     and scale_by_sigma off.  Forward, sampler step and all gradients vs the oracle (general, pinned at the shipped shape)."""
     from dposer_amd.algorithms.advanced import losses, sampling, sde_lib
     from dposer_amd.algorithms.advanced.model import ScoreModelFC
