@@ -679,6 +679,16 @@ def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sb
     for stride in (0, 1):
         _, xs = fn(m, z=_dev(z), seed=seed, traj_stride=stride)
         assert rel_err(t2n(xs), ref_x.numpy()) < 1e-4, stride
+    # prior loss (shared t) and its analytic gradient, weighted and not
+    from dposer_amd.prior import prior_loss
+    sde1k = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    for tt, weighted in ((0.31, True), (0.77, False)):
+        x0 = _dev(x).requires_grad_(True)
+        lp = prior_loss(m, sde1k, x0, tt, weighted=weighted, z=_dev(z))
+        lp.backward()
+        ref_l, ref_g = R.dposer_prior_loss(p, R.SubVP(), torch.tensor(x), torch.full((B,), tt), torch.tensor(z), weighted=weighted, **fw)
+        assert abs(float(lp) - ref_l.item()) / abs(ref_l.item()) < 2e-4
+        assert rel_err(t2n(x0.grad), ref_g.numpy()) < 2e-4
 
 
 def test_completion_sampler_inkernel_imputation_noise_matches_oracle():
