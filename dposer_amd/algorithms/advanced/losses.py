@@ -69,6 +69,28 @@ class FusedAdam(optim.Adam):
         self._flat_cache = (key, flat, offs)
         return flat, offs, params
 
+    def load_state_dict(self, state_dict):
+        """torch's loader fills ``self.state[p]`` with fresh tensors; mirror them into the flat moment buffers and the step
+        counter even when this optimizer has already stepped (in-process restore / rollback), and re-point the views."""
+        super().load_state_dict(state_dict)
+        params = self._params()
+        steps = [int(self.state[p]["step"]) for p in params if p in self.state and "step" in self.state[p]]
+        self._step_count = max(steps) if steps else 0
+        if self._flat_m is not None:
+            flat, offs = flat_base(params)
+            if flat is not None and flat.numel() == self._flat_m.numel():
+                self._flat_m.zero_()
+                self._flat_v.zero_()
+                for p, o in zip(params, offs):
+                    st = self.state.get(p)
+                    if st and "exp_avg" in st:
+                        self._flat_m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+                        self._flat_v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            else:
+                self._flat_m = self._flat_v = None        # layout changed: rebuilt (from self.state) by _ensure_flat
+        self._flat_cache = None
+        self._state_views = None
+
     def flat_grad(self):
         """Flat gradient buffer the fused backward writes into (one element per flat parameter)."""
         self._ensure_flat()
@@ -102,6 +124,7 @@ class FusedAdam(optim.Adam):
                                                     float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(grad_clip),
                                                     float(grad_scale), self._step_count, float(omd), _C.ptr(self._scratch),
                                                     _C.stream_ptr()), "dposer_adam_ema_clip_step")
+        torch.autograd.graph.increment_version(params)   # the kernel wrote the parameters through raw pointers: tell autograd
         # torch-compatible per-parameter state: {'step', 'exp_avg', 'exp_avg_sq'} are views of the flat buffers and ONE shared
         # step tensor, rebuilt only when the set of live parameters (or the buffers) changes -- not 3 tensors per parameter per step
         live_key = (tuple(bool(ok) for ok in live), self._flat_m.data_ptr())
@@ -288,18 +311,20 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
             if not model.training:
                 model.train()
             flat_grad = optimizer.flat_grad()
+            # Philox key of this rank's shard: sample i of every shard must NOT draw the same t / z / dropout mask
+            seed = (model._rng_seed + 0x9E3779B1 * ddp.rank()) & 0xFFFFFFFFFFFFFFFF if ddp.world_size() > 1 else model._rng_seed
             if ddp.world_size() > 1:
                 # bucketed: each GN layer's gradient is all-reduced (RCCL over xGMI) on a side stream while the layers in
                 # front of it are still being differentiated
                 eng = model._engine()
                 events = eng.bucket_events()
-                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=model._rng_seed, step=state["step"],
+                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"],
                                       bucket_events=events)
                 world = ddp.all_reduce_buckets_(flat_grad, eng.grad_buckets,
                                                 lambda i, stream: _C.check(eng.lib.dposer_stream_wait_event(stream, events[i]),
                                                                            "dposer_stream_wait_event"))
             else:
-                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=model._rng_seed, step=state["step"])
+                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"])
                 world = 1
             optimize_fn.warm_lr(optimizer, state["step"])                           # losses.py:51-53
             # parameters with a gradient (fixed per model unless requires_grad flags are flipped): cached on the model

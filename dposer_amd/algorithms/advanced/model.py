@@ -81,42 +81,63 @@ class TimeMLPs(nn.Module):
 
 
 class _ScoreFCFunction(torch.autograd.Function):
-    """Differentiable forward: d/d params and d/d x through dposer_scorefc_backward."""
+    """Differentiable forward: d/d params and d/d x through dposer_scorefc_backward.
+
+    The activations of the forward pass stay in a WS_TRAIN workspace that this autograd node LEASES from the engine (one
+    buffer per live node, returned when the node is freed), so any number of differentiable forwards may be outstanding.
+    ``backward`` re-reads the packed (transposed) weights: if they were re-packed in between it packs them again, and if the
+    parameters themselves were modified in place it raises, like torch does for a saved tensor."""
+
+    N_FIXED = 6     # (module, x, labels, train_mode, seed, step) in front of the parameters
 
     @staticmethod
     def forward(ctx, module, x, labels, train_mode, seed, step, *params):
         eng = module._engine()
         flat = module._flat
         packed = eng.packed(flat, with_backward=True, force=not module.freeze_packed)
-        ws = eng.workspace(x.shape[0], _C.WS_TRAIN, 0, x.device)
+        lease = eng.lease_train_workspace(x.shape[0], x.device)
         out = torch.empty_like(x)
         freq = eng.freq(x.device, module._fourier_W())
-        _C.check(eng.lib.dposer_scorefc_forward_train(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), _C.ptr(x), _C.ptr(labels),
+        _C.check(eng.lib.dposer_scorefc_forward_train(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(lease.ws), _C.ptr(x), _C.ptr(labels),
                                                       _C.ptr(freq), _C.ptr(module.sigmas), _C.ptr(out), x.shape[0],
                                                       1 if train_mode else 0, seed, step, _C.stream_ptr()),
                  "dposer_scorefc_forward_train")
         ctx.module, ctx.train_mode, ctx.seed, ctx.step = module, train_mode, seed, step
         ctx.labels = labels
-        ctx.need_dx = x.requires_grad
-        ctx.need_dw = any(p.requires_grad for p in params)
+        ctx.lease = lease
+        ctx.flat, ctx.pack_gen = flat, eng._pack_gen
+        ctx.versions = tuple(p._version for p in module._param_list)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         m = ctx.module
         eng = m._engine()
+        if ctx.lease is None or ctx.lease.ws is None:
+            raise _C.DPoserHipError("ScoreModelFC backward: the activations of this forward pass have been released")
+        if m._flat is not ctx.flat or tuple(p._version for p in m._param_list) != ctx.versions:
+            raise RuntimeError("ScoreModelFC: parameters were modified in place between forward and backward "
+                               "(their packed copies no longer match the activations saved by the forward pass)")
+        if eng._pack_gen != ctx.pack_gen or not eng._packed_bwd:
+            # another forward re-packed the weights (possibly without the transposed copies): same values, pack them again
+            eng.packed(ctx.flat, with_backward=True, force=True)
+            ctx.pack_gen = eng._pack_gen
         B = dout.shape[0]
         dout = dout.contiguous().float()
-        ws = eng.workspace(B, _C.WS_TRAIN, 0, dout.device)   # still holds the activations of the matching forward
-        flat_grad = torch.empty(eng.num_params, dtype=torch.float32, device=dout.device) if ctx.need_dw else None
-        dx = torch.empty(B, eng.D, dtype=torch.float32, device=dout.device) if ctx.need_dx else None
-        _C.check(eng.lib.dposer_scorefc_backward(eng.h, _C.ptr(m._flat), _C.ptr(eng._packed), _C.ptr(ws), _C.ptr(ctx.labels),
+        need_dx = ctx.needs_input_grad[1]
+        # parameter gradients only when autograd asks for one (a Hutchinson / guidance VJP w.r.t. x alone then skips the wgrad
+        # GEMMs, the bucket reductions and the 33 MB flat gradient)
+        want = ctx.needs_input_grad[_ScoreFCFunction.N_FIXED:]
+        need_dw = any(want)
+        flat_grad = torch.empty(eng.num_params, dtype=torch.float32, device=dout.device) if need_dw else None
+        dx = torch.empty(B, eng.D, dtype=torch.float32, device=dout.device) if need_dx else None
+        _C.check(eng.lib.dposer_scorefc_backward(eng.h, _C.ptr(ctx.flat), _C.ptr(eng._packed), _C.ptr(ctx.lease.ws), _C.ptr(ctx.labels),
                                                  _C.ptr(m.sigmas), _C.ptr(dout), _C.ptr(flat_grad), _C.ptr(dx), B,
                                                  1 if ctx.train_mode else 0, ctx.seed, ctx.step, _C.stream_ptr()),
                  "dposer_scorefc_backward")
         grads = []
-        for p, off in zip(m._param_list, eng.offsets):
-            if ctx.need_dw and p.requires_grad and not m._is_nograd(off):
+        for p, off, w in zip(m._param_list, eng.offsets, want):
+            if w and not m._is_nograd(off):
                 grads.append(flat_grad[off:off + p.numel()].view_as(p))
             else:
                 grads.append(None)

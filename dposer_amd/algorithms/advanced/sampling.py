@@ -311,7 +311,9 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
     def pc_sampler(model, observation=None, mask=None, z=None, start_step=0, args=None, *, traj_stride=1, noise=None,
                    seed=None):
         with torch.no_grad():
-            x = torch.randn(*shape, device=device) if z is None else z             # sampling.py:446
+            # sampling.py:446: the prior is drawn by the SDE (VESDE scales by sigma_max) from torch's CPU generator, so a seeded
+            # run starts from the reference's own x_T; callers that keep everything on the device pass z
+            x = sde.prior_sampling(shape).to(device) if z is None else z
             timesteps = torch.linspace(sde.T, eps, sde.N, device=device)          # sampling.py:449
             start_t = start_step if (args is not None and args.task in ["denoise"]) else 0
             completion = args is not None and args.task in ["completion"]

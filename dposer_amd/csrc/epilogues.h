@@ -54,6 +54,34 @@ __device__ __forceinline__ void dropout_mask8(const DropoutCfg& d, int64_t s, in
     }
 }
 
+// What the training forward pass leaves for the GroupNorm-backward epilogue, per lane of a 32x32 sub-tile (tile-major:
+// record ((sample block * H/32 + group) * 64 + lane), so a wave reads / writes one coalesced 512-byte run per sub-tile):
+//   rstd  the sample's 1/sqrt(var + eps) of this group (both lane halves hold it)
+//   keep  bit 4q + r = dropout keep decision of channel 8q + 4hi + r (all ones when dropout is off)
+// The decisions are the Philox draws of dropout_mask16 -- drawn ONCE, in the forward epilogue; re-drawing them in the backward
+// epilogue cost ~10 VALU instructions per element there (20 integer multiplies per 8 decisions).
+struct GnAux { float rstd; uint32_t keep; };
+__device__ __forceinline__ int64_t gn_aux_index(int64_t s0, int group, int H, int lane) { return (((s0 >> 5) * (int64_t)(H >> 5) + group) << 6) + lane; }
+
+// dropout_mask16 that also returns the 16 decisions as a bit set (bit 4q + r)
+__device__ __forceinline__ uint32_t dropout_mask16_bits(const DropoutCfg& d, int64_t s, int g, int hi, float keep[16]) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        Philox4 r = philox_at((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int i0 = 4 * (2 * m + (w >> 1)) + (w & 1) * 2;
+            const bool k0 = (r.v[w] & 0xffffu) < d.thr, k1 = (r.v[w] >> 16) < d.thr;
+            keep[i0] = k0 ? d.scale : 0.f;
+            keep[i0 + 1] = k1 ? d.scale : 0.f;
+            bits |= (k0 ? 1u : 0u) << i0;
+            bits |= (k1 ? 1u : 0u) << (i0 + 1);
+        }
+    }
+    return bits;
+}
+
 // ----------------------------------------------------------------------------------------------
 // forward:  out = [resid +] Drop(SiLU(GroupNorm32(acc + bias)))         model.py:166-187
 // ----------------------------------------------------------------------------------------------
@@ -64,14 +92,14 @@ struct GNParams {
     void* out;             // FT [Spad][H]
     const void* resid;     // FT [Spad][H] or null
     void* xhat;            // TRAIN: FT [Spad][H]
-    float* rstd;           // TRAIN: [Spad][H/32]
+    GnAux* aux;            // TRAIN: [Spad/32][H/32][64] records for the backward epilogue (rstd + dropout decisions)
     int H;
     DropoutCfg drop;
     void* outT;            // TRAIN, optional: the output again as FT [H][Spad] (operand of the wgrad GEMMs)
     int64_t Spad;
 };
 // RESID: -1 = decide at run time from Params::resid (and null-check the optional outputs); 0 / 1 = residual input absent /
-// present at compile time AND no other branch in the code: rstd is stored by both lane halves, dropout is always drawn
+// present at compile time AND no other branch in the code: dropout is always drawn
 // (DropoutCfg must then be valid: thr = 65536, scale = 1 when disabled), outT must be non-null.  The branch-free form is what
 // the pipelined kernel (gemm_pipe.h) needs: a branch would split the basic block its MFMA / VALU interleave is scheduled in.
 template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
@@ -96,8 +124,8 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
     };
     template <int TC, int TS, int tc, int ts, int PH = -1>
     __device__ static inline void sub(const Params& pp, Carry& cy, const f32x16& a, int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
-        struct { const float *bias, *gamma, *beta; T* out; const T* resid; T* xhat; float* rstd; int H; DropoutCfg drop; } p =
-            {pp.bias, pp.gamma, pp.beta, (T*)pp.out, (const T*)pp.resid, (T*)pp.xhat, pp.rstd, pp.H, pp.drop};
+        struct { const float *bias, *gamma, *beta; T* out; const T* resid; T* xhat; GnAux* aux; int H; DropoutCfg drop; } p =
+            {pp.bias, pp.gamma, pp.beta, (T*)pp.out, (const T*)pp.resid, (T*)pp.xhat, pp.aux, pp.H, pp.drop};
         constexpr bool PRECISE = sizeof(T) == 4;
         const int j = lane & 31, hi = lane >> 5;
         const int c0 = cbase + tc * 32;
@@ -134,8 +162,12 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
             ss = sum_xor32(ss);
             const float var = ss * (1.0f / 32.0f);
             cy.rstd = PRECISE ? 1.0f / sqrtf(var + 1e-5f) : rsqrtf(var + 1e-5f);
-            if (drop) dropout_mask16(p.drop, s, c0 >> 5, hi, cy.keep);
-            if (TRAIN && (FLAT || hi == 0)) p.rstd[s * (p.H >> 5) + (c0 >> 5)] = cy.rstd;
+            uint32_t bits = 0xffffu;
+            if (drop) bits = dropout_mask16_bits(p.drop, s, c0 >> 5, hi, cy.keep);
+            if (TRAIN) {
+                GnAux rec = {cy.rstd, bits};
+                p.aux[gn_aux_index(sbase + ts * 32, c0 >> 5, p.H, lane)] = rec;
+            }
         }
         if constexpr (PH != 0) {
             float o[16];
@@ -384,19 +416,42 @@ template <typename T> struct EpiPlainFT {
 // ----------------------------------------------------------------------------------------------
 // backward helpers
 // ----------------------------------------------------------------------------------------------
-// All-to-all butterfly: on entry every lane holds N partial values; on exit lane (l & 31) == i
-// holds the sum over the 32 lanes (same l >> 5) of value i.  31 shuffles for N = 32.
+// All-to-all butterfly over the 32 lanes of a half-wave: on entry every lane holds N partial values; on exit lane
+// (l & 31) == i holds the sum over the 32 lanes (same l >> 5) of value i.  A step with lane bit b pairs lane l with a partner
+// that differs in bit b; lanes with the bit set keep the upper half of the live values, the others the lower half.
+// The partner exchange never touches LDS (the first version used ds_bpermute: an LDS round trip and an s_waitcnt per
+// shuffle, 47 per channel tile):
+//   bit 4      v_permlane16_swap: one swap + one add per value pair, no select
+//   bits 3, 2  DPP row_mirror (l ^ 15) / row_half_mirror (l ^ 7) folded into the adds
+//   bits 1, 0  DPP quad_perm (l ^ 2, l ^ 1)
+// (the mirror partners flip lower bits too; the lower bits are still "unreduced" at that point, so the orbit of a lane
+//  under {^16, ^15, ^7, ^2, ^1} is still the whole half-wave and the result lands where the xor butterfly put it.)
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int D> struct DppCtrl;
+template <> struct DppCtrl<8> { static constexpr int value = 0x140; };   // row_mirror
+template <> struct DppCtrl<4> { static constexpr int value = 0x141; };   // row_half_mirror
+template <> struct DppCtrl<2> { static constexpr int value = 0x4E; };    // quad_perm [2,3,0,1]
+template <> struct DppCtrl<1> { static constexpr int value = 0xB1; };    // quad_perm [1,0,3,2]
 template <int D> __device__ __forceinline__ void butterfly_step(float (&v)[32], int lane) {
-    // lanes with bit D set keep the upper half of the D*2 live values, the others the lower half
-    const bool up = (lane & D) != 0;
+    if constexpr (D == 16) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-        const float send = up ? v[i] : v[i + D];
-        const float keep = up ? v[i + D] : v[i];
-        v[i] = keep + __shfl_xor(send, D);
+        for (int i = 0; i < 16; ++i) {
+            auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+            v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+    } else {
+        const bool up = (lane & D) != 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const float lo = v[i] + dpp_f32<DppCtrl<D>::value>(v[i]);
+            const float hi = v[i + D] + dpp_f32<DppCtrl<D>::value>(v[i + D]);
+            v[i] = up ? hi : lo;
+        }
     }
 }
-// 16 values per lane: lane (l & 15) == i ends with the sum over the 32 lanes (same l >> 5) of value i -- 16 shuffles.
+// 16 values per lane: lane (l & 15) == i ends with the sum over the 32 lanes (same l >> 5) of value i.
 __device__ __forceinline__ float butterfly_reduce16(const float (&in)[16], int lane) {
     float v[32];
 #pragma unroll
@@ -405,7 +460,8 @@ __device__ __forceinline__ float butterfly_reduce16(const float (&in)[16], int l
     butterfly_step<4>(v, lane);
     butterfly_step<2>(v, lane);
     butterfly_step<1>(v, lane);
-    return v[0] + __shfl_xor(v[0], 16);
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[0]), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 template <int N> __device__ __forceinline__ void butterfly_reduce32(float (&v)[N], int lane) {
     static_assert(N == 32, "N must be 32");
@@ -415,28 +471,52 @@ template <int N> __device__ __forceinline__ void butterfly_reduce32(float (&v)[N
     butterfly_step<2>(v, lane);
     butterfly_step<1>(v, lane);
 }
+// the first version (ds_bpermute shuffles), kept for the tuner's A/B
+template <int D> __device__ __forceinline__ void butterfly_step_bperm(float (&v)[32], int lane) {
+    const bool up = (lane & D) != 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const float send = up ? v[i] : v[i + D];
+        const float keep = up ? v[i + D] : v[i];
+        v[i] = keep + __shfl_xor(send, D);
+    }
+}
+__device__ __forceinline__ float butterfly_reduce16_bperm(const float (&in)[16], int lane) {
+    float v[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = in[r];
+    butterfly_step_bperm<8>(v, lane); butterfly_step_bperm<4>(v, lane); butterfly_step_bperm<2>(v, lane); butterfly_step_bperm<1>(v, lane);
+    return v[0] + __shfl_xor(v[0], 16);
+}
+__device__ __forceinline__ void butterfly_reduce32_bperm(float (&v)[32], int lane) {
+    butterfly_step_bperm<16>(v, lane); butterfly_step_bperm<8>(v, lane); butterfly_step_bperm<4>(v, lane); butterfly_step_bperm<2>(v, lane);
+    butterfly_step_bperm<1>(v, lane);
+}
 
 // dgrad epilogue: acc = dL/d(out_l) contribution through the NEXT layer's weights.
 //   g   = acc [+ carry_in]          (carry = gradient arriving over the residual connection)
 //   da  = g * keep/(1-p) * silu'(a),   a = gamma*xhat + beta
 //   dy  = rstd * (dx - mean_g(dx) - xhat * mean_g(dx * xhat)),   dx = da * gamma
 // writes dy (FT), optional carry_out = g, and per-wave partial sums of dgamma, dbeta, dbias.
+// Padded rows: the incoming gradient is zero there (dres is written as zeros on padded rows and every dgrad keeps that), so
+// nothing has to be masked per element; the row validity is folded into the dropout decision bits once per sub-tile.
 struct GNBwdParams {
     const void* carry_in;  // FT [Spad][H] or null
     void* carry_out;       // FT [Spad][H] or null
     const void* xhat;      // FT [Spad][H]
-    const float* rstd;     // [Spad][H/32]
+    const GnAux* aux;      // records of the forward epilogue (rstd + dropout decisions), tile-major
     const float* gamma;
     const float* beta;
     void* dy;              // FT [Spad][H]
     float* part;           // [n_rows][3][H] partial sums (row = wave row id), deterministic
     int H;
     int64_t S_valid;
-    DropoutCfg drop;
+    float drop_scale;      // 1/(1-p) of the forward pass (1 when dropout was off)
     void* dyT;             // optional: dy again as FT [H][Spad]
     int64_t Spad;
 };
-template <typename T> struct EpiGNBwd {
+// ABL (tuner only): 1 = no parameter-gradient sums, 2 = no SiLU', 4 = ds_bpermute butterflies, 8 = loads / stores only
+template <typename T, int ABL = 0> struct EpiGNBwd {
     typedef GNBwdParams Params;
     static constexpr int kScratchPerWave = TileT<T>::SCRATCH_BYTES;
     static constexpr int kMinWaves = 2;   // keep two 256-thread workgroups per CU (register-heavy epilogue)
@@ -444,7 +524,7 @@ template <typename T> struct EpiGNBwd {
     // Operand prefetch through the (then idle) K-loop ring: x_hat and the residual carry of sub-tile i+1 are DMA'd
     // (global_load_lds, 1 KiB pieces) into a per-wave double buffer while sub-tile i is being processed.  Loaded straight
     // into registers, each sub-tile paid a full HBM round trip behind an s_waitcnt (8 per wave tile, and both waves of a
-    // SIMD are in the same place at the same time); the register budget (248 of 256) leaves no room to prefetch there.
+    // SIMD are in the same place at the same time); the register budget leaves no room to prefetch there.
     static constexpr int kTileBytes = 1024 * (int)sizeof(T);
     static constexpr int kRingPerWave = 2 * 2 * kTileBytes;   // [2 buffers][x_hat, carry]
     __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.gamma : p.beta; }
@@ -458,8 +538,8 @@ template <typename T> struct EpiGNBwd {
     }
     template <int TC, int TS, bool RING>
     __device__ static inline void run(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, const float* lpar, int lstride, unsigned char* scr, unsigned char* ring) {
-        struct { const T* carry_in; T* carry_out; const T* xhat; const float *rstd, *gamma, *beta; T* dy; float* part; int H; int64_t S_valid; DropoutCfg drop; } p =
-            {(const T*)pp.carry_in, (T*)pp.carry_out, (const T*)pp.xhat, pp.rstd, pp.gamma, pp.beta, (T*)pp.dy, pp.part, pp.H, pp.S_valid, pp.drop};
+        struct { const T* carry_in; T* carry_out; const T* xhat; const GnAux* aux; T* dy; float* part; int H; int64_t S_valid; float scale; } p =
+            {(const T*)pp.carry_in, (T*)pp.carry_out, (const T*)pp.xhat, pp.aux, (T*)pp.dy, pp.part, pp.H, pp.S_valid, pp.drop_scale};
         constexpr bool PRECISE = sizeof(T) == 4;
         constexpr int NBLK = kTileBytes / 1024;
         typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -483,9 +563,9 @@ template <typename T> struct EpiGNBwd {
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc) {
             const int c0 = cbase + tc * 32;
-            // (gamma / beta are re-read from their LDS copy quad by quad and the dropout decisions are drawn per 8 channels:
-            //  holding 16 + 16 + 16 of them would push the 256x256 tile past 256 VGPRs)
-            float stat[32];   // [0..15] dgamma, [16..31] dbeta (this lane's 16 channels)
+            // (gamma / beta are re-read from their LDS copy quad by quad: holding 16 + 16 of them would push the 256x256
+            //  tile past 256 VGPRs)
+            float stat[32];   // [0..15] dgamma, [16..31] dbeta (this lane's 16 channels), without the 1/(1-p) factor
             float dbias[16];
 #pragma unroll
             for (int r = 0; r < 32; ++r) stat[r] = 0.f;
@@ -494,9 +574,10 @@ template <typename T> struct EpiGNBwd {
 #pragma unroll
             for (int ts = 0; ts < TS; ++ts) {
                 const int64_t s = sbase + ts * 32 + j;
-                const bool valid = s < p.S_valid;
                 const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.H);
-                const float rstd = p.rstd[s * (p.H >> 5) + (c0 >> 5)];
+                const GnAux rec = p.aux[gn_aux_index(sbase + ts * 32, c0 >> 5, p.H, lane)];
+                const float rstd = rec.rstd;
+                const uint32_t bits = s < p.S_valid ? rec.keep : 0u;
                 float xh[16], g[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g[r] = acc[tc][ts][r];
@@ -530,46 +611,51 @@ template <typename T> struct EpiGNBwd {
                     }
                 }
                 if (p.carry_out) TileIO<T>::store(p.carry_out + tb, lane, g);
-                float s1 = 0.f, s2 = 0.f;
-                float keep[8];
+                if constexpr ((ABL & 8) == 0) {
+                    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if ((q & 1) == 0 && p.drop.p > 0.f) dropout_mask8(p.drop, s, c0 >> 5, hi, q >> 1, keep);
-                    const int cl = tc * 32 + 8 * q + 4 * hi;
-                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + cl);
-                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
+                    for (int q = 0; q < 4; ++q) {
+                        const int cl = tc * 32 + 8 * q + 4 * hi;
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + cl);
+                        const f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 4 * q + r;
-                        float gg = valid ? g[i] : 0.f;
-                        if (p.drop.p > 0.f) gg *= keep[4 * (q & 1) + r];
-                        const float da = gg * dsilu_f<PRECISE>(g4[r] * xh[i] + e4[r]);
-                        stat[i] += da * xh[i];
-                        stat[16 + i] += da;
-                        g[i] = da * g4[r];                 // dx
-                        s1 += g[i];
-                        s2 += g[i] * xh[i];
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 4 * q + r;
+                            // keep decision as an all-ones / all-zeros word: one v_bfe_i32 + one v_and per element
+                            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, i, 1);
+                            const float gg = __uint_as_float(__float_as_uint(g[i]) & m);
+                            const float ds = (ABL & 2) ? 1.0f : dsilu_f<PRECISE>(g4[r] * xh[i] + e4[r]);
+                            const float da = gg * ds;                  // (the 1/(1-p) factor is applied to gamma and to the sums)
+                            if constexpr ((ABL & 1) == 0) {
+                                stat[i] += da * xh[i];
+                                stat[16 + i] += da;
+                            }
+                            g[i] = da * (g4[r] * p.scale);             // dx
+                            s1 += g[i];
+                            s2 += g[i] * xh[i];
+                        }
                     }
-                }
-                s1 = sum_xor32(s1);
-                s2 = sum_xor32(s2);
-                const float m1 = s1 * (1.0f / 32.0f), m2 = s2 * (1.0f / 32.0f);
+                    s1 = sum_xor32(s1);
+                    s2 = sum_xor32(s2);
+                    const float m1 = s1 * (1.0f / 32.0f), m2 = s2 * (1.0f / 32.0f);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    g[i] = rstd * (g[i] - m1 - xh[i] * m2);   // dy
-                    dbias[i] += g[i];
+                    for (int i = 0; i < 16; ++i) {
+                        g[i] = rstd * (g[i] - m1 - xh[i] * m2);   // dy
+                        if constexpr ((ABL & 1) == 0) dbias[i] += g[i];
+                    }
                 }
                 TileIO<T>::store(p.dy + tb, lane, g);
                 if (pp.dyT) TileT<T>::store((T*)pp.dyT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, g);
             }
-            // reduce over the 32 samples of the lane group; lane i ends with value i.
-            butterfly_reduce32(stat, lane);
-            const float db = butterfly_reduce16(dbias, lane);
-            float* row = p.part + (int64_t)wrow * 3 * p.H;
-            {
+            if constexpr ((ABL & 9) == 0) {
+                // reduce over the 32 samples of the lane group; lane i ends with value i.
+                float db;
+                if constexpr (ABL & 4) { butterfly_reduce32_bperm(stat, lane); db = butterfly_reduce16_bperm(dbias, lane); }
+                else { butterfly_reduce32(stat, lane); db = butterfly_reduce16(dbias, lane); }
+                float* row = p.part + (int64_t)wrow * 3 * p.H;
                 const int i = j & 15;                              // register index this lane ended up with
                 const int c = c0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                row[(j >> 4) * p.H + c] = stat[0];                 // j<16: dgamma, j>=16: dbeta
+                row[(j >> 4) * p.H + c] = stat[0] * p.scale;       // j<16: dgamma, j>=16: dbeta
                 if (j < 16) row[2 * p.H + c] = db;
             }
         }

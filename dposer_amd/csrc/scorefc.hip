@@ -233,7 +233,8 @@ static int final_shape(int64_t Spad) {
 struct Ws {
     int64_t Bpad;
     char *xin, *emb, *temb, *upre, *hbuf[MAX_L], *xhat[MAX_L], *dy[MAX_L], *carry[2], *dU, *dres;
-    float *rstd[MAX_L], *res, *xt, *tbuf, *zbuf, *loss_part, *scalar;
+    GnAux* aux[MAX_L];        // per GroupNorm layer: rstd + dropout decisions for the backward epilogue (epilogues.h)
+    float *res, *xt, *tbuf, *zbuf, *loss_part, *scalar;
     float *xft, *xmft;        // sampler fast path: state and last x_mean as fp32 FT [Bpad][Dpad]
     // shared-t time table
     int64_t npad;
@@ -308,7 +309,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
             w.hbuf[l] = take(Bpad * H * esz);
             w.xhat[l] = take(Bpad * H * esz);
             w.dy[l] = take(Bpad * H * esz);
-            w.rstd[l] = (float*)take(Bpad * (H / 32) * 4);
+            w.aux[l] = (GnAux*)take((Bpad / 32) * (H / 32) * 64 * (int64_t)sizeof(GnAux));
             w.gn_part[l] = (float*)take((Bpad / 32) * 3 * (int64_t)H * 4);
         }
         w.carry[0] = take(Bpad * H * esz);
@@ -397,7 +398,7 @@ static DropoutCfg drop_cfg(const dposer_scorefc_s* h, bool train, int site, uint
 // One GroupNorm layer.  per_sample_t: K-concat(h, temb) with packed bias_cat; else x-path only with
 // `bias_row` (time-table row of this step and layer).
 static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* packed, int l, const void* in, const void* temb,
-                        const float* bias_row, void* out, const void* resid, void* xhat, float* rstd, bool train,
+                        const float* bias_row, void* out, const void* resid, void* xhat, GnAux* aux, bool train,
                         int64_t Bpad, uint64_t seed, uint32_t step, hipStream_t st) {
     const int shape = main_shape(Bpad);
     const LayerOff& lo = h->layer[l];
@@ -413,7 +414,7 @@ static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* pack
     p.out = out;
     p.resid = resid;
     p.xhat = xhat;
-    p.rstd = rstd;
+    p.aux = aux;
     p.H = h->H;
     p.outT = nullptr;
     p.Spad = Bpad;
@@ -719,7 +720,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
     for (int l = 0; l < L; ++l) {
         const void* in = l == 0 ? (const void*)w.xin : (const void*)w.hbuf[l - 1];
         const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[l - 2] : nullptr;
-        // TRAIN epilogue keeps xhat / rstd; dropout only when the module is in train() mode
+        // TRAIN epilogue keeps xhat and the GnAux records (rstd, dropout decisions); dropout only when the module is in train() mode
         const LayerOff& lo = h->layer[l];
         const int shape = main_shape(w.Bpad);
         const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
@@ -729,7 +730,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         add_seg(g, w.temb, ke);
         GNParams p;
         p.bias = reinterpret_cast<const float*>(packed + h->pk_bias_cat) + (int64_t)l * h->H;
-        p.gamma = flat + lo.gamma; p.beta = flat + lo.beta; p.out = w.hbuf[l]; p.resid = resid; p.xhat = w.xhat[l]; p.rstd = w.rstd[l];
+        p.gamma = flat + lo.gamma; p.beta = flat + lo.beta; p.out = w.hbuf[l]; p.resid = resid; p.xhat = w.xhat[l]; p.aux = w.aux[l];
         p.H = h->H; p.drop = drop_cfg(h, dropout_on, l, seed, step);
         p.outT = tr ? nullptr : w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
         DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, true, shape, g, p, st));
@@ -865,8 +866,9 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         const bool even = (j % 2) == 0;
         p.carry_in = (even && j < L - 1) ? w.carry[(j / 2 + 1) & 1] : nullptr;
         p.carry_out = (even && j >= 2) ? w.carry[(j / 2) & 1] : nullptr;
-        p.xhat = w.xhat[j]; p.rstd = w.rstd[j]; p.gamma = flat + h->layer[j].gamma; p.beta = flat + h->layer[j].beta;
-        p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B; p.drop = drop_cfg(h, dropout_on, j, seed, step);
+        p.xhat = w.xhat[j]; p.aux = w.aux[j]; p.gamma = flat + h->layer[j].gamma; p.beta = flat + h->layer[j].beta;
+        p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B;
+        p.drop_scale = (dropout_on && h->d.dropout_p > 0.f) ? 1.0f / (1.0f - h->d.dropout_p) : 1.0f;   // the decisions themselves come from the forward pass (GnAux)
         p.dyT = (want_w && !tr) ? w.dyT[j] : nullptr; p.Spad = Bpad;
         DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st));
         if (!want_w) continue;

@@ -53,7 +53,9 @@ class ScoreEngine:
         self._bucket_events = None
         self._packed: Optional[torch.Tensor] = None
         self._packed_bwd = False
+        self._pack_gen = 0                 # bumped by every (re)pack: lets a backward notice that the packed buffer was rewritten
         self._ws: Dict[int, torch.Tensor] = {}
+        self._train_pool = []              # free WS_TRAIN buffers (see lease_train_workspace)
         self.freq_cpu = positional_freq(embed_dim)
         self._freq: Optional[torch.Tensor] = None
 
@@ -99,6 +101,7 @@ class ScoreEngine:
             _C.check(self.lib.dposer_scorefc_pack(self.h, _C.ptr(flat), _C.ptr(self._packed), 1 if with_backward else 0,
                                                   _C.stream_ptr()), "dposer_scorefc_pack")
             self._packed_bwd = bool(with_backward)
+            self._pack_gen += 1
         return self._packed
 
     def workspace(self, batch: int, mode: int, n_steps: int, device):
@@ -110,6 +113,50 @@ class ScoreEngine:
             ws = torch.empty(need, dtype=torch.uint8, device=device)
             self._ws[mode] = ws
         return ws
+
+    def lease_train_workspace(self, batch: int, device) -> "TrainWorkspaceLease":
+        """A WS_TRAIN workspace that belongs to ONE forward/backward pair until the lease object dies.
+
+        The training workspace holds every activation the backward pass needs, so two differentiable forwards that are alive
+        at the same time (two score evaluations in one graph, gradient accumulation, an eval forward between loss and
+        ``.backward()``) must not share one: each autograd node keeps its lease, a node that is freed returns the buffer to
+        the pool.  With 288 GB of HBM the pool simply grows to the number of simultaneously live graphs (3.4 GB each at
+        B = 65536)."""
+        need = self.lib.dposer_scorefc_workspace_bytes(self.h, batch, _C.WS_TRAIN, 0)
+        if need < 0:
+            raise _C.DPoserHipError("dposer_scorefc_workspace_bytes failed")
+        best = None
+        for i, ws in enumerate(self._train_pool):
+            if ws.device == device and ws.numel() >= need and (best is None or ws.numel() < self._train_pool[best].numel()):
+                best = i
+        if best is not None:
+            ws = self._train_pool.pop(best)
+        else:
+            # drop free buffers that are too small instead of keeping them next to the new, larger one
+            self._train_pool[:] = [w for w in self._train_pool if w.device != device or w.numel() >= need]   # (in place: leases hold this list)
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return TrainWorkspaceLease(self._train_pool, ws)
+
+
+class TrainWorkspaceLease:
+    """Owner token of one WS_TRAIN buffer; returns it to the engine's pool when garbage-collected (kernels that still use it
+    were enqueued on the current stream before that, and any later user is enqueued behind them)."""
+
+    __slots__ = ("_pool", "ws")
+
+    def __init__(self, pool, ws):
+        self._pool, self.ws = pool, ws
+
+    def release(self):
+        if self.ws is not None:
+            self._pool.append(self.ws)
+            self.ws = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 def default_precision(config=None) -> str:

@@ -86,7 +86,13 @@ class MotionDenoise:
                 temp = body.v[:-1] - body.v[1:]
                 losses["temp"] = torch.mean(torch.sqrt(torch.sum(temp * temp, dim=2)))
                 data = body.Jtr[:, :22] - init_joints
-                losses["data"] = torch.mean(torch.sqrt(torch.sum(data * data, dim=2)))   # (the reference's `if data_term > 0` host sync is dropped)
+                # motion_denoising.py:262 keeps the data term only `if data_term > 0` ("for nans"): a host sync per step whose
+                # real job is the all-zero case (pose still equal to the observation: value 0, but sqrt'(0) = inf poisons the
+                # backward pass).  Same effect without the sync: distances are clamped away from 0 before the sqrt, so a zero
+                # residual contributes the value ~0 and a ZERO gradient, and a non-finite / non-positive term is dropped by value.
+                dist = torch.sqrt(torch.sum(data * data, dim=2).clamp_min(1e-36))
+                data_term = torch.mean(dist)
+                losses["data"] = torch.where(torch.isfinite(data_term) & (data_term > 0), data_term, torch.zeros_like(data_term))
                 tot = torch.stack([weights[k](v, it) for k, v in losses.items()]).sum()
                 tot.backward()
                 optimizer.step()

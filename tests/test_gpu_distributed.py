@@ -98,3 +98,44 @@ def test_two_rank_bucketed_step_equals_single_process_step():
     assert np.abs(f0 - ref.numpy()).max() < 2e-5
     mean_losses = [(a + b) / 2 for a, b in zip(res[0][3], res[1][3])]
     assert np.allclose(mean_losses, ref_losses, rtol=2e-5)
+
+
+def _worker_rng(rank, world, port, q, x):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      DPOSER_DIST_BACKEND="gloo")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from dposer_amd import distributed as ddp
+    import torch.distributed as dist
+    from gpu_common import make_model
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    ddp.init_from_env()
+    torch.cuda.set_device(0)
+    cfg, m, p = make_model(3, precision="fp32", dropout=0.1)
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    state = dict(model=m, optimizer=losses.get_optimizer(cfg, m.parameters()), ema=ExponentialMovingAverage(m.parameters(), 0.9999), step=0)
+    step_fn = losses.get_step_fn(sde, True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+    loss = float(step_fn(state, x.cuda())["step_loss"])          # in-kernel t, z, dropout: no injected draws
+    q.put((rank, loss))
+    ddp.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_draw_different_noise():
+    """Every rank must key its Philox streams differently (losses.py:110-111 draw fresh t, z per sample of the GLOBAL batch):
+    two ranks fed the SAME shard get different losses; with a rank-independent key they would be bit-identical."""
+    rs = np.random.RandomState(11)
+    x = torch.tensor(rs.standard_normal((128, 63)).astype(np.float32))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rng, args=(r, 2, port, q, x)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.isfinite(res[0]) and np.isfinite(res[1])
+    assert abs(res[0] - res[1]) > 1e-3 * abs(res[0])

@@ -49,7 +49,7 @@ void add_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void
 }
 
 template <int WC, int WS, int TC, int TS, int KB, int GLDS, bool TRAIN = false>
-void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* out, float* bias, float* gamma, float* beta, void* xhat, float* rstd, void* outT) {
+void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* out, float* bias, float* gamma, float* beta, void* xhat, GnAux* rstd, void* outT) {
     typedef GemmCfg<__bf16, WC, WS, TC, TS, KB> Cfg;
     GemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -58,7 +58,7 @@ void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* o
     GNParams p;
     memset(&p, 0, sizeof(p));
     p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C; p.Spad = S; p.resid = g_resid;
-    if (TRAIN) { p.xhat = xhat; p.rstd = rstd; p.outT = outT; }
+    if (TRAIN) { p.xhat = xhat; p.aux = rstd; p.outT = outT; }
     if (TRAIN && g_drop_p > 0.f) { p.drop.p = g_drop_p; p.drop.scale = 1.f / (1.f - g_drop_p); p.drop.thr = (uint32_t)((1.0 - g_drop_p) * 65536.0); p.drop.groups_x4 = C / 8; p.drop.seed = 7; }
     char buf[160];
     snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d NB%d %s", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS < 2 ? 2 : GLDS, TRAIN ? "gn-train" : "gn");
@@ -66,7 +66,7 @@ void add_gn(const char* name, int64_t S, int C, int K, void* W, void* X, void* o
 }
 
 template <int WC, int WS, int TC, int TS, int KB, bool TRAIN = false>
-void add_gn_pipe(const char* name, int64_t S, int C, int K, void* W, void* X, void* out, float* bias, float* gamma, float* beta, void* xhat, float* rstd, void* outT) {
+void add_gn_pipe(const char* name, int64_t S, int C, int K, void* W, void* X, void* out, float* bias, float* gamma, float* beta, void* xhat, GnAux* rstd, void* outT) {
     typedef GemmCfg<__bf16, WC, WS, TC, TS, KB> Cfg;
     GemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -75,7 +75,7 @@ void add_gn_pipe(const char* name, int64_t S, int C, int K, void* W, void* X, vo
     GNParams p;
     memset(&p, 0, sizeof(p));
     p.bias = bias; p.gamma = gamma; p.beta = beta; p.out = out; p.H = C; p.Spad = S;
-    if (TRAIN) { p.xhat = xhat; p.rstd = rstd; p.outT = outT; }
+    if (TRAIN) { p.xhat = xhat; p.aux = rstd; p.outT = outT; }
     char buf[160];
     p.drop.thr = 65536; p.drop.scale = 1.f; p.drop.groups_x4 = C / 8;
     snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d PIPE %s", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, TRAIN ? "gn-train" : "gn");
@@ -95,8 +95,8 @@ void add_plain_pipe(const char* name, int64_t S, int C, int K, void* W, void* X,
     g_cases.push_back({buf, [=] { CK((launch_gemm_pipe<__bf16, WC, WS, TC, TS, KB, EpiPlainFT<__bf16>>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
-template <int WC, int WS, int TC, int TS, int KB, int GLDS>
-void add_gnbwd(const char* name, int64_t S, int C, int K, void* Wt, void* dyn, void* dy, void* xhat, float* rstd, float* gamma, float* beta,
+template <int WC, int WS, int TC, int TS, int KB, int GLDS, int ABL = 0>
+void add_gnbwd(const char* name, int64_t S, int C, int K, void* Wt, void* dyn, void* dy, void* xhat, GnAux* rstd, float* gamma, float* beta,
                float* part, void* dyT, void* carry_in, void* carry_out, float drop_p) {
     typedef GemmCfg<__bf16, WC, WS, TC, TS, KB> Cfg;
     GemmArgs g;
@@ -105,13 +105,13 @@ void add_gnbwd(const char* name, int64_t S, int C, int K, void* Wt, void* dyn, v
     g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1;
     GNBwdParams p;
     memset(&p, 0, sizeof(p));
-    p.carry_in = carry_in; p.carry_out = carry_out; p.xhat = xhat; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.dy = dy; p.part = part;
+    p.carry_in = carry_in; p.carry_out = carry_out; p.xhat = xhat; p.aux = rstd; p.gamma = gamma; p.beta = beta; p.dy = dy; p.part = part;
     p.H = C; p.S_valid = S; p.dyT = dyT; p.Spad = S;
-    if (drop_p > 0.f) { p.drop.p = drop_p; p.drop.scale = 1.f / (1.f - drop_p); p.drop.thr = (uint32_t)((1.0 - drop_p) * 65536.0); p.drop.groups_x4 = C / 8; p.drop.seed = 7; }
+    p.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
     char buf[160];
-    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d NB%d gnbwd drop%d T%d carry%d%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS < 2 ? 2 : GLDS, drop_p > 0.f,
+    snprintf(buf, sizeof buf, "%-8s %3dx%-3d w%d KB%d NB%d gnbwd abl%d drop%d T%d carry%d%d", name, Cfg::CT * 32, Cfg::ST * 32, Cfg::NW, KB, GLDS < 2 ? 2 : GLDS, ABL, drop_p > 0.f,
              dyT != nullptr, carry_in != nullptr, carry_out != nullptr);
-    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGNBwd<__bf16>, (GLDS < 2 ? 2 : GLDS)>(g, p, 0))); }, 2.0 * S * C * K, {}});
+    g_cases.push_back({buf, [=] { CK((launch_gemm<__bf16, WC, WS, TC, TS, KB, EpiGNBwd<__bf16, ABL>, (GLDS < 2 ? 2 : GLDS)>(g, p, 0))); }, 2.0 * S * C * K, {}});
 }
 
 static void run_all(int rounds, int reps) {
@@ -154,14 +154,14 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(bias, hb.data(), C * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(gamma, hg.data(), C * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(beta, hb.data(), C * 4, hipMemcpyHostToDevice));
     printf("forward GN layer GEMM: S=%lld C=%d K=%d bf16\n", (long long)S, C, K);
-    void *xhat; float* rstd; void* outT;
-    CK(hipMalloc(&xhat, (size_t)S * C * 2)); CK(hipMalloc(&rstd, (size_t)S * (C / 32) * 4)); CK(hipMalloc(&outT, (size_t)S * C * 2));
+    void *xhat; GnAux* rstd; void* outT;
+    CK(hipMalloc(&xhat, (size_t)S * C * 2)); CK(hipMalloc(&rstd, (size_t)(S / 32) * (C / 32) * 64 * sizeof(GnAux))); CK(hipMalloc(&outT, (size_t)S * C * 2));
 #define GN(WC, WS, TC, TS, KB, G) add_gn<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, bias, gamma, beta, xhat, rstd, outT)
 #define GNT(WC, WS, TC, TS, KB, G) add_gn<WC, WS, TC, TS, KB, G, true>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, bias, gamma, beta, xhat, rstd, outT)
 #define PL(WC, WS, TC, TS, KB, G) add_plain<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1)
     float* part; void *cin, *cout;
     CK(hipMalloc(&part, (size_t)(S / 32) * 3 * C * 4)); CK(hipMalloc(&cin, (size_t)S * C * 2)); CK(hipMalloc(&cout, (size_t)S * C * 2));
-    CK(hipMemset(rstd, 0, (size_t)S * (C / 32) * 4)); CK(hipMemset(xhat, 0, (size_t)S * C * 2)); CK(hipMemset(cin, 0, (size_t)S * C * 2));
+    CK(hipMemset(rstd, 0x3f, (size_t)(S / 32) * (C / 32) * 64 * sizeof(GnAux))); CK(hipMemset(xhat, 0, (size_t)S * C * 2)); CK(hipMemset(cin, 0, (size_t)S * C * 2));
 #define GB(WC, WS, TC, TS, KB, G, DROP, DYT, CI, CO) add_gnbwd<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, xhat, rstd, gamma, beta, part, DYT ? outT : nullptr, CI ? cin : nullptr, CO ? cout : nullptr, DROP ? 0.1f : 0.f)
     if (getenv("TUNE_PIPE")) {
         // correctness: pipelined vs reference kernel, bit for bit
@@ -204,6 +204,24 @@ int main(int argc, char** argv) {
         GB(2, 2, 2, 1, 4, 1, 1, 1, 0, 0);
         GB(4, 1, 1, 2, 4, 1, 1, 1, 0, 0);
         run_all(9, 20);
+        return 0;
+    }
+    if (getenv("TUNE_GNBWD2")) {     // round 2: where the GroupNorm-backward epilogue spends its time (ablations) and the trimmed version
+#define GBA(WC, WS, TC, TS, ABL, DROP, CI, CO) add_gnbwd<WC, WS, TC, TS, 2, 4, ABL>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, xhat, rstd, gamma, beta, part, nullptr, CI ? cin : nullptr, CO ? cout : nullptr, DROP ? 0.1f : 0.f)
+        PL(2, 4, 4, 2, 2, 4);
+        GBA(2, 4, 4, 2, 0, 1, 0, 0);      // shipped tiling, trimmed epilogue
+        GBA(2, 4, 4, 2, 4, 1, 0, 0);      // ... with the ds_bpermute butterflies
+        GBA(2, 4, 4, 2, 1, 1, 0, 0);      // no parameter-gradient sums
+        GBA(2, 4, 4, 2, 2, 1, 0, 0);      // no SiLU'
+        GBA(2, 4, 4, 2, 3, 1, 0, 0);      // neither
+        GBA(2, 4, 4, 2, 8, 1, 0, 0);      // loads / stores only
+        GBA(4, 2, 2, 4, 0, 1, 0, 0);      // wave tile 64 channels x 128 samples: half as many butterflies
+        GBA(2, 4, 4, 2, 0, 1, 1, 1);      // with the residual carry in and out
+        GBA(4, 2, 2, 4, 0, 1, 1, 1);
+        GNT(2, 4, 4, 2, 2, 4);
+        g_drop_p = 0.1f;
+        GNT(2, 4, 4, 2, 2, 4); g_cases.back().name += " +dropout";
+        run_all(7, 10);
         return 0;
     }
     if (getenv("TUNE_GNBWD")) {
