@@ -318,6 +318,109 @@ def g7_prior_loss():
     save("g7_prior_loss", **out)
 
 
+def _stub_finder():
+    """run/motion_denoising.py imports the rendering stack at module scope (pytorch3d.renderer, ...): any module below these
+    packages resolves to a MagicMock.  None of it is called by the captured loop."""
+    import importlib.abc
+    import importlib.machinery
+
+    class StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        PREFIX = ("pytorch3d", "pyrender", "trimesh", "cv2", "smplx", "imageio", "matplotlib", "tqdm", "open3d")
+
+        def find_spec(self, name, path, target=None):
+            return importlib.machinery.ModuleSpec(name, self) if name.split(".")[0] in self.PREFIX else None
+
+        def create_module(self, spec):
+            m = mock.MagicMock()
+            m.__path__, m.__name__, m.__spec__ = [], spec.name, spec
+            return m
+
+        def exec_module(self, module):
+            pass
+
+    for k in list(sys.modules):
+        if k.split(".")[0] in StubFinder.PREFIX:
+            del sys.modules[k]
+    sys.meta_path.insert(0, StubFinder())
+
+
+def g14_completion_loop():
+    """G14: the reference's own DPoserComp.optimize (run/completion.py:167-207): B = 16, 2 x 4 steps, part = legs, time
+    strategy '3', every z of completion.py:133 recorded."""
+    cfg, m = build_model(61, 63)
+    m.eval()
+    sde = ref_sde.subVPSDE(0.1, 20.0, 1000)
+    B, iters, spi = 16, 2, 4
+    _, raw = toy_batch(B, seed=47)
+    nz = ref_amass.Posenormalizer(os.path.join(REF, "data/AMASS/amass_processed/version1/train"), device="cpu", normalize=True,
+                                  min_max=False, rot_rep="axis")
+    poses = nz.offline_normalize(raw)
+    torch.manual_seed(0)
+    mask, obs = ref_misc.create_mask(poses, part="legs")
+    comp = ref_completion.DPoserComp(m, sde, continuous=True, batch_size=B)
+    with Recorder(1400) as rec:
+        out = comp.optimize(obs, mask, iterations=iters, steps_per_iter=spi)
+    noise = np.stack(rec.by_kind("randn"))
+    assert noise.shape == (iters * spi, B, 63)
+    save("g14_completion_loop", seed=np.int64(61), poses=poses.numpy(), observation=obs.numpy(), mask=mask.numpy(), noise=noise,
+         out=out.detach().numpy(), iterations=np.int64(iters), steps_per_iter=np.int64(spi))
+
+
+def g15_motion_denoise_loop():
+    """G15: the reference's own MotionDenoise.optimize (run/motion_denoising.py:199-300) driving a torch body model that stands in
+    for smplx (oracle.fk_torch on the synthetic SMPL-X-shaped asset): pins the LOOP -- loss weights, time schedule '3', the
+    `data_term > 0` guard, Adam, Gaussian smoothing, metrics.  Case 'a': noisy joints.  Case 'b': the observed joints are exactly
+    the joints of the initial pose, so the guard drops the data term at step 0."""
+    _stub_finder()
+    import run.motion_denoising as ref_md
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import fk_torch
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    asset = make_synthetic_smplx_asset(seed=0)
+    cfg, m = build_model(63, 63)
+    m.eval()
+
+    class TorchBM:
+        def __init__(self):
+            self.calls = []
+
+        def __call__(self, betas=None, pose_body=None, **kw):
+            v, j = fk_torch.smplx_forward(asset, pose_body.double())
+            self.calls.append(pose_body.detach().clone())
+            return types.SimpleNamespace(v=v, Jtr=j, f=None, betas=betas, pose_body=pose_body)
+
+    class Args:
+        device = "cpu"
+        dataset_folder = os.path.join(REF, "data/AMASS/amass_processed")
+        version = "version1"
+
+    T, iters, spi, N = 12, 2, 3, 500
+    _, raw = toy_batch(T, seed=48)
+    gt = raw.numpy().astype(np.float32)
+    rs = np.random.RandomState(7)
+    init = (gt + rs.standard_normal(gt.shape) * 0.05).astype(np.float32)
+    with torch.no_grad():
+        _, jgt = fk_torch.smplx_forward(asset, torch.tensor(gt).double())
+        _, jinit = fk_torch.smplx_forward(asset, torch.tensor(init).double())
+    out = {"gt": gt, "init": init, "T": np.int64(T), "iterations": np.int64(iters), "steps_per_iter": np.int64(spi), "sde_N": np.int64(N),
+           "seed": np.int64(63)}
+    for tag, joints3d in (("a", jgt[:, :22] + torch.tensor(rs.standard_normal((T, 22, 3)) * 0.04)), ("b", jinit[:, :22].clone())):
+        bm = TorchBM()
+        md = ref_md.MotionDenoise(cfg, Args(), m, bm, sde_N=N, batch_size=T)
+        md.poses = torch.tensor(init)
+        with Recorder(1500 + ord(tag)) as rec:
+            res = md.optimize(joints3d, gt_poses=torch.tensor(gt), time_strategy="3", iterations=iters, steps_per_iter=spi)
+        out[f"{tag}_joints3d"] = joints3d.numpy()
+        out[f"{tag}_noise"] = np.stack(rec.by_kind("randn"))
+        out[f"{tag}_pose_final"] = md.poses.detach().numpy()      # the optimised leaf (Adam updates it in place)
+        out[f"{tag}_pose_before_last_step"] = bm.calls[-2].numpy()
+        out[f"{tag}_pose_smooth"] = bm.calls[-1].numpy()
+        for k, v in res.items():
+            out[f"{tag}_{k}"] = np.asarray(v)
+    save("g15_motion_denoise_loop", **out)
+
+
+
 def g8_scalars():
     """G8: marginal_prob / sde / return_alpha_sigma / discretize tables on linspace(1,1e-3,1000)."""
     t = torch.linspace(1.0, 1e-3, 1000)
@@ -495,8 +598,8 @@ def g13_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
-    fns = dict(g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    fns = dict(g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
                g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
     for w in which:
         fns[w]()

@@ -284,3 +284,108 @@ def test_body_model_backward_all_pose_segments(bm, asset):
     for name, got, want in zip(("pose", "root", "hand", "jaw", "eye", "expression"), d, r):
         err = float(np.linalg.norm(t2n(got.grad) - want.grad.numpy()) / np.linalg.norm(want.grad.numpy()))
         assert err < 2e-4, (name, err)
+
+
+# ------------------------------------------------------------------------------------------------
+# Pins that need neither smplx nor the restatement in oracle/fk_ref.py: closed-form consequences of the LBS definition
+# (rotations from scipy.spatial.transform, everything else from the asset arrays).
+# ------------------------------------------------------------------------------------------------
+def _rot(aa):
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_rotvec(np.asarray(aa, dtype=np.float64)).as_matrix()
+
+
+def _descendants(parents, k):
+    out = []
+    for j in range(len(parents)):
+        a = j
+        while a != -1 and a != k:
+            a = int(parents[a])
+        if a == k and j != k:
+            out.append(j)
+    return out
+
+
+def test_zero_pose_returns_the_template_and_its_regressed_joints(bm, asset):
+    """theta = 0, beta = 0: every transform is the identity, the pose feature vanishes, so v == v_template and the 55 skeleton
+    joints == J_regressor @ v_template (lbs.py definition, no arithmetic to restate)."""
+    z = torch.zeros(3, 63, device=DEV)
+    o = bm(pose_body=z)
+    vt = asset["v_template"].astype(np.float64)
+    assert np.abs(t2n(o.v) - vt[None]).max() < 2e-6
+    assert np.abs(t2n(o.Jtr)[:, :55] - (asset["J_regressor"].astype(np.float64) @ vt)[None]).max() < 2e-6
+
+
+@pytest.mark.parametrize("joint", [1, 4, 9, 16, 20])       # left hip, left knee, spine3, left shoulder, left wrist (SMPL numbering)
+def test_single_joint_rotation_closed_form(bm, asset, joint):
+    """Rotating ONE joint k by R moves its descendants rigidly about J_k and nothing else:
+    J_d' = J_k + R (J_d - J_k) for d below k, J_j' = J_j otherwise."""
+    rs = np.random.RandomState(joint)
+    aa = rs.standard_normal(3) * 0.7
+    pose = np.zeros((1, 63), np.float32)
+    pose[0, 3 * (joint - 1):3 * joint] = aa
+    j = t2n(bm.fk_joints(torch.tensor(pose, device=DEV), n_joints=55))[0].astype(np.float64)
+    J0 = asset["J_regressor"].astype(np.float64) @ asset["v_template"].astype(np.float64)
+    want = J0.copy()
+    R = _rot(pose[0, 3 * (joint - 1):3 * joint])
+    for d in _descendants(asset["parents"], joint):
+        want[d] = J0[joint] + R @ (J0[d] - J0[joint])
+    assert np.abs(j - want).max() < 2e-6
+
+
+def test_two_joint_chain_closed_form(bm, asset):
+    """Hip then knee: J_ankle' = J_hip + R1 (J_knee - J_hip) + R1 R2 (J_ankle - J_knee)."""
+    rs = np.random.RandomState(3)
+    a1, a2 = rs.standard_normal(3) * 0.6, rs.standard_normal(3) * 0.9
+    pose = np.zeros((1, 63), np.float32)
+    pose[0, 0:3], pose[0, 9:12] = a1, a2                      # joints 1 (left hip) and 4 (left knee)
+    j = t2n(bm.fk_joints(torch.tensor(pose, device=DEV), n_joints=22))[0].astype(np.float64)
+    J0 = asset["J_regressor"].astype(np.float64) @ asset["v_template"].astype(np.float64)
+    R1, R2 = _rot(pose[0, 0:3]), _rot(pose[0, 9:12])
+    knee = J0[1] + R1 @ (J0[4] - J0[1])
+    ankle = knee + R1 @ R2 @ (J0[7] - J0[4])
+    foot = ankle + R1 @ R2 @ (J0[10] - J0[7])
+    assert np.abs(j[4] - knee).max() < 2e-6 and np.abs(j[7] - ankle).max() < 2e-6 and np.abs(j[10] - foot).max() < 2e-6
+    assert np.abs(j[2] - J0[2]).max() < 2e-6                 # the other leg does not move
+
+
+def test_root_orientation_and_translation_act_rigidly(bm, asset):
+    """global_orient = R, transl = t:  x' = J_root + R (x - J_root) + t for every vertex and joint (the pose-blend feature
+    excludes the root joint, so the body does not deform)."""
+    B = 5
+    pose = _poses(B, seed=77)
+    rs = np.random.RandomState(78)
+    root = (rs.standard_normal((B, 3)) * 0.8).astype(np.float32)
+    tr = rs.standard_normal((B, 3)).astype(np.float32)
+    dev = lambda a: torch.tensor(a, device=DEV)
+    o0 = bm(pose_body=dev(pose))
+    o1 = bm(pose_body=dev(pose), root_orient=dev(root), trans=dev(tr))
+    Jr = (asset["J_regressor"].astype(np.float64) @ asset["v_template"].astype(np.float64))[0]
+    R = _rot(root)
+    for a0, a1 in ((t2n(o0.v), t2n(o1.v)), (t2n(o0.Jtr), t2n(o1.Jtr))):
+        want = np.einsum("bij,bnj->bni", R, a0.astype(np.float64) - Jr) + Jr + tr[:, None].astype(np.float64)
+        assert np.abs(a1 - want).max() < 1e-5
+
+
+def test_lbs_backward_against_finite_differences(bm):
+    """Directional derivative of a random linear functional of (vertices, joints) w.r.t. the body pose, root orientation and
+    translation: autograd through the HIP backward kernels vs central differences of the HIP forward."""
+    B = 6
+    rs = np.random.RandomState(9)
+    dev = lambda a: torch.tensor(a.astype(np.float32), device=DEV)
+    pose, root, tr = dev(rs.standard_normal((B, 63)) * 0.3), dev(rs.standard_normal((B, 3)) * 0.3), dev(rs.standard_normal((B, 3)))
+    wv, wj = dev(rs.standard_normal((B, 10475, 3)) / 100), dev(rs.standard_normal((B, 127, 3)))
+
+    def L(p, r, t):
+        o = bm(pose_body=p, root_orient=r, trans=t)
+        return ((o.v * wv).sum() + (o.Jtr * wj).sum()).double()
+
+    p, r, t = pose.clone().requires_grad_(True), root.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+    gp, gr, gt = torch.autograd.grad(L(p, r, t), [p, r, t])
+    eps = 1e-2
+    for k in range(3):
+        dp, dr, dt = dev(rs.standard_normal((B, 63))), dev(rs.standard_normal((B, 3))), dev(rs.standard_normal((B, 3)))
+        with torch.no_grad():
+            fd = float(L(pose + eps * dp, root + eps * dr, tr + eps * dt) - L(pose - eps * dp, root - eps * dr, tr - eps * dt)) / (2 * eps)
+        an = float((gp * dp).sum() + (gr * dr).sum() + (gt * dt).sum())
+        assert abs(fd - an) / max(abs(an), 1e-3) < 5e-3, (fd, an)

@@ -187,3 +187,37 @@ def test_rot6d():
     g = load("g11_rot6d")
     out = fk_ref.rot6d_to_mat3x3(g["rot6d"].astype(np.float32))
     assert np.allclose(out, g["rotmat"], atol=2e-6)
+
+
+def test_completion_loop_restatement_matches_the_reference_loop():
+    """oracle/task_loops.completion_optimize vs the reference's own DPoserComp.optimize (g14: 2 x 4 steps, legs masked)."""
+    from oracle import task_loops
+    g = load("g14_completion_loop")
+    p = make_weights(int(g["seed"]))
+    p["sigmas"] = R.sigma_table()
+    out = task_loops.completion_optimize(p, R.SubVP(), g["observation"], g["mask"], g["noise"], iterations=int(g["iterations"]),
+                                         steps_per_iter=int(g["steps_per_iter"]))
+    assert rel_err(out, g["out"]) < 1e-5
+    m = g["mask"]
+    assert np.array_equal(out * m, g["observation"] * m)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_motion_denoise_loop_restatement_matches_the_reference_loop(tag):
+    """oracle/task_loops.motion_denoise_optimize vs the reference's own MotionDenoise.optimize driving the same torch body model
+    (g15).  Case b: the observed joints equal the joints of the initial pose, so the reference's `data_term > 0` guard drops the
+    data term at step 0 (its gradient would be 0/0)."""
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    from oracle import task_loops
+    g = load("g15_motion_denoise_loop")
+    st = load("g10_normalizer")
+    p = make_weights(int(g["seed"]))
+    p["sigmas"] = R.sigma_table()
+    asset = make_synthetic_smplx_asset(seed=0)
+    final, res = task_loops.motion_denoise_optimize(p, R.SubVP(N=int(g["sde_N"])), asset, st["stats/axis_normalize2/mean_poses"],
+                                                    st["stats/axis_normalize2/std_poses"], g[f"{tag}_joints3d"], g["gt"], g["init"],
+                                                    g[f"{tag}_noise"], iterations=int(g["iterations"]), steps_per_iter=int(g["steps_per_iter"]))
+    assert np.isfinite(final).all()
+    assert rel_err(final, g[f"{tag}_pose_final"]) < 1e-5
+    for k in ("init_MPJPE", "MPJPE", "MPVPE"):
+        assert np.allclose(res[k], g[f"{tag}_{k}"], rtol=1e-4, atol=1e-5), k
