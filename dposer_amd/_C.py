@@ -79,6 +79,9 @@ SIGNATURES = {
     "dposer_rodrigues": (C.c_int, [vp, vp, i64, vp]),
     "dposer_body_create": (C.c_int, [C.POINTER(BodyDesc), C.POINTER(i32), C.POINTER(vp)]),
     "dposer_body_destroy": (None, [vp]),
+    "dposer_shape_blend_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, vp]),
+    "dposer_shape_blend_scratch_floats": (i64, [i32, i32, i64]),
+    "dposer_shape_blend_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, vp]),
     "dposer_fk_joints": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, vp, vp, i32, i64, vp]),
     "dposer_lbs_posedirs_packed_bytes": (i64, [vp]),
     "dposer_lbs_pack_posedirs": (C.c_int, [vp, vp, vp, vp]),

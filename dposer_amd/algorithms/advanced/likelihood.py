@@ -7,6 +7,8 @@ atol / nfe are part of the result); every right-hand-side evaluation -- the prob
 Hutchinson divergence estimate -- is one HIP forward plus one HIP input-gradient (vector-Jacobian product) of the
 score network through ``ScoreModelFC``'s autograd function; only the flattened state crosses PCIe per evaluation.
 """
+import contextlib
+
 import numpy as np
 import torch
 from scipy import integrate
@@ -57,7 +59,8 @@ def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e
             vec_t = torch.full((B,), float(t), device=dev, dtype=torch.float32)
             with torch.no_grad():
                 drift = probability_flow_drift(sde, model, x, vec_t)
-            dlogp = div(x, vec_t, noise)
+            with (model.input_grad_only() if hasattr(model, "input_grad_only") else contextlib.nullcontext()):
+                dlogp = div(x, vec_t, noise)
             return np.concatenate([mutils.to_flattened_numpy(drift), mutils.to_flattened_numpy(dlogp)])
 
         init = np.concatenate([mutils.to_flattened_numpy(data), np.zeros((B,))])

@@ -8,6 +8,7 @@ The module keeps the reference's constructor signature, sub-module names and the
 Adam/EMA kernel and the weight packer consume) and evaluates ``forward`` with the MFMA kernels of
 ``libdposer_hip.so``.  There is no torch/CPU fallback: a forward on CPU tensors raises.
 """
+import contextlib
 import functools
 import math
 
@@ -183,6 +184,7 @@ class ScoreModelFC(nn.Module):
         # ---- MI355X engine state (not part of the state_dict) ----
         self.precision = default_precision(config)
         self.freeze_packed = False      # True: caller promises the weights do not change between forwards
+        self._input_grad_only = False   # see input_grad_only()
         self._engines = {}
         self._flat = None
         self._param_list = list(self.parameters())
@@ -193,6 +195,17 @@ class ScoreModelFC(nn.Module):
         self.flat_params()
         self._rng_seed = int(getattr(config, "seed", 0) or 0) * 1000003 + 12345
         self._rng_step = 0
+
+    @contextlib.contextmanager
+    def input_grad_only(self):
+        """Forwards inside this context are differentiable w.r.t. the INPUT only (Hutchinson divergence of the likelihood,
+        likelihood.py:29-35; guided sampling, sampling.py:191-207): their backward skips the weight-gradient GEMMs, the bucket
+        reductions and the 33 MB flat gradient.  The reference gets the same saving for free from torch's per-edge pruning."""
+        prev, self._input_grad_only = self._input_grad_only, True
+        try:
+            yield self
+        finally:
+            self._input_grad_only = prev
 
     # ---- flat parameter storage -------------------------------------------------------------------
     def _engine(self) -> ScoreEngine:
@@ -249,7 +262,10 @@ class ScoreModelFC(nn.Module):
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self._param_list))
         if needs_grad or self.training:
             self._rng_step += 1
-            return _ScoreFCFunction.apply(self, x, labels, bool(self.training), self._rng_seed, self._rng_step, *self._param_list)
+            # inside input_grad_only() the parameters are not handed to autograd at all: the backward then has no parameter
+            # gradient to produce (ctx.needs_input_grad only reflects requires_grad flags, not what a given backward call wants)
+            params = () if self._input_grad_only else self._param_list
+            return _ScoreFCFunction.apply(self, x, labels, bool(self.training), self._rng_seed, self._rng_step, *params)
         packed = eng.packed(flat, with_backward=False, force=not self.freeze_packed)
         ws = eng.workspace(x.shape[0], _C.WS_INFER, 0, x.device)
         out = torch.empty_like(x)

@@ -3,8 +3,9 @@
 arithmetic (Rodrigues, kinematic chain, pose-blend GEMM, skinning, landmark joints -- smplx/lbs.py)
 runs in the HIP kernels of dposer_amd/csrc/fk.hip behind ``dposer_fk_joints`` / ``dposer_lbs_forward``.
 
-``bm_path`` may be an official ``SMPLX_*.npz`` or an asset dictionary
-(``body_model.synthetic.make_synthetic_smplx_asset``).  Only ``model_type='smplx'`` is built.
+``bm_path`` may be an official model ``.npz`` or an asset dictionary (``body_model.synthetic.make_synthetic_asset``).
+``model_type`` 'smpl' (24 joints), 'smplh' (52) and 'smplx' (55) share the kernels: the C library unrolls the kinematic chain
+over the matching compile-time parents table.
 """
 import ctypes as C
 
@@ -13,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .. import _C
-from .synthetic import load_smplx_npz
+from .synthetic import load_model_npz, load_smplx_npz  # noqa: F401
 
 
 class Struct:
@@ -24,8 +25,44 @@ class Struct:
             setattr(self, k, v)
 
 
-_SMPLX_SEGMENTS = (("global_orient", 1), ("body_pose", 21), ("jaw_pose", 1), ("leye_pose", 1), ("reye_pose", 1),
-                   ("left_hand_pose", 15), ("right_hand_pose", 15))
+# full_pose order of smplx.{SMPL,SMPLH,SMPLX}.forward (body_models.py): which keyword feeds which joints
+_SEGMENTS = {
+    "smpl": (("global_orient", 1), ("body_pose", 23)),
+    "smplh": (("global_orient", 1), ("body_pose", 21), ("left_hand_pose", 15), ("right_hand_pose", 15)),
+    "smplx": (("global_orient", 1), ("body_pose", 21), ("jaw_pose", 1), ("leye_pose", 1), ("reye_pose", 1),
+              ("left_hand_pose", 15), ("right_hand_pose", 15)),
+}
+_SMPLX_SEGMENTS = _SEGMENTS["smplx"]
+_MAX_SEG = 7
+
+
+class _ShapeBlendFunction(torch.autograd.Function):
+    """dposer_shape_blend_forward / _backward: (shape [B, L]) -> (v_shaped [B, V, 3], j_rest [B, J, 3])."""
+
+    @staticmethod
+    def forward(ctx, core, shape):
+        B, L = shape.shape
+        dev = shape.device
+        sh = shape.detach().contiguous().float()
+        vs = torch.empty(B, core.V, 3, dtype=torch.float32, device=dev)
+        jr = torch.empty(B, core.J, 3, dtype=torch.float32, device=dev)
+        _C.check(_C.lib().dposer_shape_blend_forward(_C.ptr(core.v_template), _C.ptr(core.shapedirs), _C.ptr(core.j_template), _C.ptr(core.jdirs),
+                                                     _C.ptr(sh), _C.ptr(vs), _C.ptr(jr), core.V, core.J, L, B, _C.stream_ptr()),
+                 "dposer_shape_blend_forward")
+        ctx.core, ctx.B, ctx.L = core, B, L
+        return vs, jr
+
+    @staticmethod
+    def backward(ctx, d_vs, d_jr):
+        core, B, L = ctx.core, ctx.B, ctx.L
+        lib = _C.lib()
+        dv = d_vs.contiguous().float()
+        dj = d_jr.contiguous().float()
+        out = torch.empty(B, L, dtype=torch.float32, device=dv.device)
+        scratch = torch.empty(lib.dposer_shape_blend_scratch_floats(core.V, L, B), dtype=torch.float32, device=dv.device)
+        _C.check(lib.dposer_shape_blend_backward(_C.ptr(core.shapedirs), _C.ptr(core.jdirs), _C.ptr(dv), _C.ptr(dj), _C.ptr(out), _C.ptr(scratch),
+                                                 core.V, core.J, L, B, _C.stream_ptr()), "dposer_shape_blend_backward")
+        return None, out
 
 
 class _LBSFunction(torch.autograd.Function):
@@ -38,10 +75,11 @@ class _LBSFunction(torch.autograd.Function):
         dev = core.v_template.device
         h, lib = core._handle(), _C.lib()
         ws = torch.empty(lib.dposer_lbs_workspace_bytes(h, B), dtype=torch.uint8, device=dev)     # private: read back in backward
-        segp = (C.c_void_p * 7)()
-        segj = (C.c_int32 * 7)()
+        segp = (C.c_void_p * _MAX_SEG)()
+        segj = (C.c_int32 * _MAX_SEG)()
+        nseg = len(core.segments)
         keep = []
-        for i, ((_, nj), t) in enumerate(zip(_SMPLX_SEGMENTS, segs)):
+        for i, ((_, nj), t) in enumerate(zip(core.segments, segs)):
             segj[i] = nj
             if t is not None:
                 t = t.detach().reshape(B, nj * 3).contiguous().float()
@@ -54,7 +92,7 @@ class _LBSFunction(torch.autograd.Function):
         tr = None if transl is None else transl.detach().contiguous().float()
         verts = torch.empty(B, core.V, 3, dtype=torch.float32, device=dev)
         joints = torch.empty(B, core.J + core.n_extra + core.n_lmk, 3, dtype=torch.float32, device=dev)
-        _C.check(lib.dposer_lbs_forward(h, _C.ptr(ws), _C.ptr(core._packed_posedirs()), segp, segj, 7, _C.ptr(jr), 1 if batched else 0,
+        _C.check(lib.dposer_lbs_forward(h, _C.ptr(ws), _C.ptr(core._packed_posedirs()), segp, segj, nseg, _C.ptr(jr), 1 if batched else 0,
                                         _C.ptr(vs), 1 if batched else 0, _C.ptr(core.skin_idx), _C.ptr(core.skin_w),
                                         int(core.skin_idx.shape[1]), _C.ptr(tr), _C.ptr(core.extra_vertex_ids), _C.ptr(core.lmk_tri),
                                         _C.ptr(core.lmk_bary_coords), _C.ptr(verts), _C.ptr(joints), B, _C.stream_ptr()),
@@ -82,10 +120,10 @@ class _LBSFunction(torch.autograd.Function):
         # transl shifts every vertex and the J LBS joints (extras / landmarks move with their vertices: already in dv)
         d_transl = (dv.sum(dim=1) + dj[:, :J].sum(dim=1)) if ctx.has_transl else None
         ws_b = torch.empty(lib.dposer_lbs_backward_workspace_bytes(h, B), dtype=torch.uint8, device=dev)
-        segp, dsegp = (C.c_void_p * 7)(), (C.c_void_p * 7)()
-        segj = (C.c_int32 * 7)()
+        segp, dsegp = (C.c_void_p * _MAX_SEG)(), (C.c_void_p * _MAX_SEG)()
+        segj = (C.c_int32 * _MAX_SEG)()
         dsegs = []
-        for i, ((_, nj), t) in enumerate(zip(_SMPLX_SEGMENTS, ctx.keep)):
+        for i, ((_, nj), t) in enumerate(zip(core.segments, ctx.keep)):
             segj[i] = nj
             segp[i] = None if t is None else t.data_ptr()
             if t is not None:
@@ -98,7 +136,7 @@ class _LBSFunction(torch.autograd.Function):
         d_jrest = torch.empty(B, J, 3, dtype=torch.float32, device=dev)
         d_vposed = torch.empty(B, core.V, 3, dtype=torch.float32, device=dev)
         jptr, jvidx, jw = core.joint_csr()
-        _C.check(lib.dposer_lbs_backward(h, _C.ptr(ctx.ws), _C.ptr(ws_b), _C.ptr(core._packed_posedirs_bwd()), segp, segj, 7, _C.ptr(ctx.jr),
+        _C.check(lib.dposer_lbs_backward(h, _C.ptr(ctx.ws), _C.ptr(ws_b), _C.ptr(core._packed_posedirs_bwd()), segp, segj, len(core.segments), _C.ptr(ctx.jr),
                                          1 if ctx.batched else 0, _C.ptr(ctx.vs), 1 if ctx.batched else 0, _C.ptr(core.skin_idx),
                                          _C.ptr(core.skin_w), int(core.skin_idx.shape[1]), _C.ptr(jptr), _C.ptr(jvidx), _C.ptr(jw), _C.ptr(dv),
                                          _C.ptr(dj), dj.shape[1] * 3, dsegp, _C.ptr(d_jrest), _C.ptr(d_vposed), B, _C.stream_ptr()),
@@ -110,18 +148,21 @@ class _LBSFunction(torch.autograd.Function):
         return (None, None, g_vs, g_jr, d_transl, *dsegs)
 
 
-class _SMPLXCore(nn.Module):
-    """What the reference reaches as ``BodyModel.bm`` (an smplx.SMPLX instance): buffers + forward."""
-    NUM_JOINTS = 54
-    NUM_BODY_JOINTS = 21
+class _SMPLCore(nn.Module):
+    """What the reference reaches as ``BodyModel.bm`` (an smplx.SMPL / SMPLH / SMPLX instance): buffers + forward.
+    ``model_type`` selects the full-pose layout (``_SEGMENTS``); expression coefficients and landmarks exist for SMPL-X only."""
     NUM_HAND_JOINTS = 15
 
-    def __init__(self, asset, num_betas=10, num_expression_coeffs=10, batch_size=1):
+    def __init__(self, asset, num_betas=10, num_expression_coeffs=10, batch_size=1, model_type="smplx"):
         super().__init__()
         self.batch_size = batch_size
+        self.model_type = model_type
+        self.segments = _SEGMENTS[model_type]
+        self.NUM_BODY_JOINTS = dict(self.segments)["body_pose"]
+        self.NUM_JOINTS = sum(n for _, n in self.segments) - 1          # smplx's class constant: joints without the root
         a = asset
         self.num_betas = num_betas
-        self.num_expression_coeffs = num_expression_coeffs
+        self.num_expression_coeffs = num_expression_coeffs if model_type == "smplx" else 0
         f32 = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)
         self.register_buffer("v_template", f32(a["v_template"]))
         self.register_buffer("shapedirs", f32(a["shapedirs"]))                  # [V,3,betas+expr]
@@ -131,7 +172,7 @@ class _SMPLXCore(nn.Module):
         self.register_buffer("parents", torch.tensor(np.asarray(a["parents"]), dtype=torch.long))
         self.register_buffer("faces_tensor", torch.tensor(np.asarray(a["faces"]).astype(np.int64), dtype=torch.long))
         self.register_buffer("lmk_faces_idx", torch.tensor(np.asarray(a["lmk_faces_idx"]).astype(np.int64)))
-        self.register_buffer("lmk_bary_coords", f32(a["lmk_bary_coords"]))
+        self.register_buffer("lmk_bary_coords", f32(np.asarray(a["lmk_bary_coords"]).reshape(-1, 3)))
         self.register_buffer("extra_vertex_ids", torch.tensor(np.asarray(a["extra_joint_vertex_ids"]).astype(np.int32)))
         # ELL form of the skinning weights
         w = np.asarray(a["weights"], dtype=np.float32)
@@ -139,10 +180,18 @@ class _SMPLXCore(nn.Module):
         order = np.argsort(-(w != 0).astype(np.int8), axis=1, kind="stable")[:, :k]
         self.register_buffer("skin_idx", torch.tensor(order.astype(np.int32)))
         self.register_buffer("skin_w", torch.tensor(np.take_along_axis(w, order, axis=1)))
-        tri = np.asarray(a["faces"])[np.asarray(a["lmk_faces_idx"])]
+        tri = np.asarray(a["faces"])[np.asarray(a["lmk_faces_idx"]).astype(np.int64)].reshape(-1, 3)
         self.register_buffer("lmk_tri", torch.tensor(tri.astype(np.int32)))
         self.J, self.V = int(w.shape[1]), int(w.shape[0])
+        if self.J != self.NUM_JOINTS + 1:
+            raise ValueError(f"model_type {model_type!r} has {self.NUM_JOINTS + 1} joints, the asset has {self.J}")
         self.n_extra, self.n_lmk = int(len(a["extra_joint_vertex_ids"])), int(len(a["lmk_faces_idx"]))
+        L = self.num_betas + self.num_expression_coeffs
+        if self.shapedirs.shape[2] != L:
+            raise ValueError(f"asset has {self.shapedirs.shape[2]} shape directions, expected num_betas + num_expression_coeffs = {L}")
+        # joint regression is linear: apply it to the template and to every blend-shape direction once (dposer_shape_blend_*)
+        self.register_buffer("j_template", (self.J_regressor @ self.v_template).contiguous())                       # [J, 3]
+        self.register_buffer("jdirs", torch.einsum("jv,vkl->jkl", self.J_regressor, self.shapedirs).contiguous())   # [J, 3, L]
         # the kernels gather vertices through these index tables without bounds checks
         ids = np.asarray(a["extra_joint_vertex_ids"])
         if ids.size and (ids.min() < 0 or ids.max() >= self.V):
@@ -202,28 +251,43 @@ class _SMPLXCore(nn.Module):
         return self._posedirs_packed
 
     def rest_shape(self, betas, expression):
-        """v_shaped = v_template + blend_shapes(shape), J = J_regressor @ v_shaped (smplx lbs.py).
-        Loop-invariant in every hot loop of the reference (betas constant): computed
-        with torch (a [B,20] x [20,31425] product) and cached for the all-zero default."""
+        """v_shaped = v_template + blend_shapes(shape), J = J_regressor @ v_shaped (smplx lbs.py) -> (v_shaped, j_rest, batched).
+
+        * no betas / expression: the template (shared by the whole batch, nothing computed);
+        * otherwise ``dposer_shape_blend_forward`` (HIP; differentiable w.r.t. betas / expression through
+          ``dposer_shape_blend_backward``).  The task loops pass the SAME constant betas tensor every step
+          (motion_denoising.py:64,217: ``self.betas``), so the result is cached on (storage, version, shape) of the inputs --
+          an unchanged tensor costs no launch and no host sync; a tensor that requires grad is never cached."""
         dev = self.v_template.device
         if betas is None and expression is None:
-            key = str(dev)
-            if key not in self._rest_cache:
-                self._rest_cache[key] = (self.v_template.contiguous(), (self.J_regressor @ self.v_template).contiguous())
-            return self._rest_cache[key] + (False,)
+            return self.v_template, self.j_template, False
         B = (betas if betas is not None else expression).shape[0]
-        zb = torch.zeros(B, self.num_betas, device=dev)
-        ze = torch.zeros(B, self.num_expression_coeffs, device=dev)
-        shape = torch.cat([betas if betas is not None else zb, expression if expression is not None else ze], dim=1)
-        v_shaped = self.v_template[None] + torch.einsum("bl,mkl->bmk", shape, self.shapedirs)
-        J = torch.einsum("bik,ji->bjk", v_shaped, self.J_regressor)
-        return v_shaped.contiguous(), J.contiguous(), True
+        differentiable = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (betas, expression))
+        key = None
+        if not differentiable:
+            key = tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) if t is not None else None for t in (betas, expression))
+            hit = self._rest_cache.get("shape")
+            if hit is not None and hit[0] == key:
+                return hit[1], hit[2], True
+        parts = [betas if betas is not None else torch.zeros(B, self.num_betas, device=dev)]
+        if self.num_expression_coeffs:
+            parts.append(expression if expression is not None else torch.zeros(B, self.num_expression_coeffs, device=dev))
+        elif expression is not None:
+            raise ValueError(f"model_type {self.model_type!r} has no expression coefficients")
+        shape = torch.cat([t.float() for t in parts], dim=1) if len(parts) > 1 else parts[0].float()
+        if shape.shape[1] != self.shapedirs.shape[2]:
+            raise ValueError(f"expected {self.shapedirs.shape[2]} shape coefficients, got {shape.shape[1]}")
+        v_shaped, j_rest = _ShapeBlendFunction.apply(self, shape)
+        if key is not None:
+            self._rest_cache["shape"] = (key, v_shaped, j_rest)
+        return v_shaped, j_rest, True
 
     def forward(self, betas=None, global_orient=None, body_pose=None, left_hand_pose=None, right_hand_pose=None, transl=None,
                 expression=None, jaw_pose=None, leye_pose=None, reye_pose=None, return_verts=True, return_full_pose=False,
                 joints_only=False, n_joints=None, **kwargs):
-        segs = dict(global_orient=global_orient, body_pose=body_pose, jaw_pose=jaw_pose, leye_pose=leye_pose, reye_pose=reye_pose,
-                    left_hand_pose=left_hand_pose, right_hand_pose=right_hand_pose)
+        allsegs = dict(global_orient=global_orient, body_pose=body_pose, jaw_pose=jaw_pose, leye_pose=leye_pose, reye_pose=reye_pose,
+                       left_hand_pose=left_hand_pose, right_hand_pose=right_hand_pose)
+        segs = {name: allsegs[name] for name, _ in self.segments}      # (smplx.SMPL ignores hand / face keywords the same way)
         given = [v for v in list(segs.values()) + [betas, transl, expression] if v is not None]
         if not given:
             raise ValueError("BodyModel.forward needs at least one tensor argument")
@@ -233,10 +297,11 @@ class _SMPLXCore(nn.Module):
         needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in given)
         if self.v_template.device != dev:
             raise _C.DPoserHipError("BodyModel buffers and inputs are on different devices; call .to(device)")
-        segp = (C.c_void_p * 7)()
-        segj = (C.c_int32 * 7)()
+        segp = (C.c_void_p * _MAX_SEG)()
+        segj = (C.c_int32 * _MAX_SEG)()
+        nseg = len(self.segments)
         keep = []
-        for i, (name, nj) in enumerate(_SMPLX_SEGMENTS):
+        for i, (name, nj) in enumerate(self.segments):
             t = segs[name]
             segj[i] = nj
             if t is not None:
@@ -250,19 +315,15 @@ class _SMPLXCore(nn.Module):
         h = self._handle()
         lib = _C.lib()
         if needs_grad:
-            verts, joints = _LBSFunction.apply(self, batched, v_shaped, j_rest, transl, *[segs[name] for name, _ in _SMPLX_SEGMENTS])
+            verts, joints = _LBSFunction.apply(self, batched, v_shaped, j_rest, transl, *[segs[name] for name, _ in self.segments])
             if joints_only:
                 return Struct(vertices=None, joints=joints[:, :(self.J if n_joints is None else int(n_joints))])
             z = lambda n: torch.zeros(B, n, dtype=torch.float32, device=dev)
-            full = [segs[name].reshape(B, nj * 3) if segs[name] is not None else z(nj * 3) for name, nj in _SMPLX_SEGMENTS]
-            return Struct(vertices=verts, joints=joints, betas=betas if betas is not None else z(self.num_betas),
-                          expression=expression, global_orient=full[0], body_pose=full[1], jaw_pose=full[2],
-                          left_hand_pose=full[5], right_hand_pose=full[6],
-                          full_pose=torch.cat(full, dim=1) if return_full_pose else None)
+            return self._output(verts, joints, segs, betas, expression, B, dev, return_full_pose)
         if joints_only:
             n_out = self.J if n_joints is None else int(n_joints)
             joints = torch.empty(B, n_out, 3, dtype=torch.float32, device=dev)
-            _C.check(lib.dposer_fk_joints(h, segp, segj, 7, _C.ptr(j_rest), 1 if batched else 0, _C.ptr(tr), _C.ptr(joints), None, n_out, B,
+            _C.check(lib.dposer_fk_joints(h, segp, segj, nseg, _C.ptr(j_rest), 1 if batched else 0, _C.ptr(tr), _C.ptr(joints), None, n_out, B,
                                           _C.stream_ptr()), "dposer_fk_joints")
             return Struct(vertices=None, joints=joints)
         need = lib.dposer_lbs_workspace_bytes(h, B)
@@ -270,17 +331,24 @@ class _SMPLXCore(nn.Module):
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
         verts = torch.empty(B, self.V, 3, dtype=torch.float32, device=dev)
         joints = torch.empty(B, self.J + self.n_extra + self.n_lmk, 3, dtype=torch.float32, device=dev)
-        _C.check(lib.dposer_lbs_forward(h, _C.ptr(self._ws), _C.ptr(self._packed_posedirs()), segp, segj, 7, _C.ptr(j_rest),
+        _C.check(lib.dposer_lbs_forward(h, _C.ptr(self._ws), _C.ptr(self._packed_posedirs()), segp, segj, nseg, _C.ptr(j_rest),
                                         1 if batched else 0, _C.ptr(v_shaped), 1 if batched else 0, _C.ptr(self.skin_idx),
                                         _C.ptr(self.skin_w), int(self.skin_idx.shape[1]), _C.ptr(tr), _C.ptr(self.extra_vertex_ids),
                                         _C.ptr(self.lmk_tri), _C.ptr(self.lmk_bary_coords), _C.ptr(verts), _C.ptr(joints), B,
                                         _C.stream_ptr()), "dposer_lbs_forward")
+        return self._output(verts, joints, segs, betas, expression, B, dev, return_full_pose)
+
+    def _output(self, verts, joints, segs, betas, expression, B, dev, return_full_pose):
+        """smplx ModelOutput fields (body_models.py): the per-segment poses as given (zeros where the module default applies)."""
         z = lambda n: torch.zeros(B, n, dtype=torch.float32, device=dev)
-        full = [segs[name].reshape(B, nj * 3) if segs[name] is not None else z(nj * 3) for name, nj in _SMPLX_SEGMENTS]
-        return Struct(vertices=verts, joints=joints, betas=betas if betas is not None else z(self.num_betas),
-                      expression=expression, global_orient=full[0], body_pose=full[1], jaw_pose=full[2],
-                      left_hand_pose=full[5], right_hand_pose=full[6],
-                      full_pose=torch.cat(full, dim=1) if return_full_pose else None)
+        full = {name: (segs[name].reshape(B, nj * 3) if segs[name] is not None else z(nj * 3)) for name, nj in self.segments}
+        return Struct(vertices=verts, joints=joints, betas=betas if betas is not None else z(self.num_betas), expression=expression,
+                      global_orient=full["global_orient"], body_pose=full["body_pose"], jaw_pose=full.get("jaw_pose"),
+                      left_hand_pose=full.get("left_hand_pose"), right_hand_pose=full.get("right_hand_pose"),
+                      full_pose=torch.cat([full[name] for name, _ in self.segments], dim=1) if return_full_pose else None)
+
+
+_SMPLXCore = _SMPLCore      # (name kept for callers that reach for the SMPL-X core directly)
 
 
 class BodyModel(nn.Module):
@@ -288,12 +356,10 @@ class BodyModel(nn.Module):
 
     def __init__(self, bm_path, num_betas=10, batch_size=1, num_expressions=10, model_type="smplx"):
         super().__init__()
-        assert model_type in ["smpl", "smplh", "smplx"]
-        if model_type != "smplx":
-            raise NotImplementedError("only model_type='smplx' (what the reference's run scripts use) is built")
-        asset = bm_path if isinstance(bm_path, dict) else load_smplx_npz(bm_path, num_betas, num_expressions)
-        self.bm = _SMPLXCore(asset, num_betas=num_betas, num_expression_coeffs=num_expressions, batch_size=batch_size)
-        self.num_joints = _SMPLXCore.NUM_JOINTS
+        assert model_type in ["smpl", "smplh", "smplx"]                    # body_model.py:39
+        asset = bm_path if isinstance(bm_path, dict) else load_model_npz(bm_path, model_type, num_betas, num_expressions)
+        self.bm = _SMPLCore(asset, num_betas=num_betas, num_expression_coeffs=num_expressions, batch_size=batch_size, model_type=model_type)
+        self.num_joints = self.bm.NUM_JOINTS                                # SMPL 23 / SMPL-H 51 / SMPL-X 54 (body_model.py:42,58,62)
         self.model_type = model_type
         self.J_regressor = self.bm.J_regressor.numpy()
         self.J_regressor_idx = {"pelvis": 0, "lwrist": 20, "rwrist": 21, "neck": 12}
@@ -301,7 +367,7 @@ class BodyModel(nn.Module):
     def forward(self, root_orient=None, pose_body=None, pose_hand=None, pose_jaw=None, pose_eye=None, betas=None, trans=None,
                 dmpls=None, expression=None, return_dict=False, **kwargs):
         assert dmpls is None
-        nh = _SMPLXCore.NUM_HAND_JOINTS * 3
+        nh = _SMPLCore.NUM_HAND_JOINTS * 3
         o = self.bm(betas=betas, global_orient=root_orient, body_pose=pose_body,
                     left_hand_pose=None if pose_hand is None else pose_hand[:, :nh],
                     right_hand_pose=None if pose_hand is None else pose_hand[:, nh:],
@@ -310,8 +376,12 @@ class BodyModel(nn.Module):
                     reye_pose=None if pose_eye is None else pose_eye[:, 3:], return_full_pose=True, **kwargs)
         out = {"v": o.vertices, "f": self.bm.faces_tensor, "betas": o.betas, "Jtr": o.joints,
                "body_joints": o.joints[:22],        # slices the batch axis, like the reference (body_model.py:95)
-               "pose_body": o.body_pose, "full_pose": o.full_pose,
-               "pose_hand": torch.cat([o.left_hand_pose, o.right_hand_pose], dim=-1), "pose_jaw": o.jaw_pose, "pose_eye": pose_eye}
+               "pose_body": o.body_pose, "full_pose": o.full_pose}
+        if self.model_type in ["smplh", "smplx"]:                                        # body_model.py:99-103
+            out["pose_hand"] = torch.cat([o.left_hand_pose, o.right_hand_pose], dim=-1)
+        if self.model_type == "smplx":
+            out["pose_jaw"] = o.jaw_pose
+            out["pose_eye"] = pose_eye
         return out if return_dict else Struct(**out)
 
     def fk_joints(self, pose_body, root_orient=None, trans=None, n_joints=22):

@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from . import constants
-from .body_model import _SMPLXCore, Struct
+from .body_model import _SMPLCore, Struct
 from .synthetic import load_smplx_npz
 
 SMPLOutput = Struct
@@ -15,8 +15,8 @@ class SMPLX(torch.nn.Module):
     def __init__(self, model_path, **kwargs):
         super().__init__()
         asset = model_path if isinstance(model_path, dict) else load_smplx_npz(model_path)
-        self.bm = _SMPLXCore(asset, num_betas=kwargs.get("num_betas", 10),
-                             num_expression_coeffs=kwargs.get("num_expression_coeffs", 10), batch_size=kwargs.get("batch_size", 1))
+        self.bm = _SMPLCore(asset, num_betas=kwargs.get("num_betas", 10), num_expression_coeffs=kwargs.get("num_expression_coeffs", 10),
+                            batch_size=kwargs.get("batch_size", 1), model_type="smplx")
         joints = [constants.JOINT_MAP[i] for i in constants.JOINT_NAMES]
         joints[:25] = constants.SMPLX_OPENPOSE_25                      # smpl.py:55-57
         self.joint_map = torch.tensor(joints, dtype=torch.long)

@@ -17,9 +17,31 @@ SMPLX_EXTRA_VERTEX_IDS = np.array([9120, 9929, 9448, 616, 6, 5770, 5780, 8846, 8
                                    5361, 4933, 5058, 5169, 5286, 8079, 7669, 7794, 7905, 8022], dtype=np.int32)
 
 
-def make_synthetic_smplx_asset(seed=0, num_vertices=10475, num_betas=10, num_expressions=10, nnz_per_vertex=4):
+SMPL_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21], dtype=np.int32)
+SMPLH_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19,
+                          20, 22, 23, 20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35,
+                          21, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50], dtype=np.int32)
+# smplx/vertex_ids.py ['smplh'] (shared by SMPL and SMPL-H, V = 6890) in VertexJointSelector order [upstream-knowledge]
+SMPLH_EXTRA_VERTEX_IDS = np.array([332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 6617, 6624, 6787,
+                                   2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905, 6016, 6133], dtype=np.int32)
+
+
+def make_synthetic_asset(model_type="smplx", seed=0, num_betas=10, num_expressions=10, nnz_per_vertex=4):
+    """SMPL (V 6890, J 24), SMPL-H (V 6890, J 52) or SMPL-X (V 10475, J 55) shaped asset with the real kinematic tree."""
+    if model_type == "smplx":
+        return make_synthetic_smplx_asset(seed=seed, num_betas=num_betas, num_expressions=num_expressions, nnz_per_vertex=nnz_per_vertex)
+    parents = {"smpl": SMPL_PARENTS, "smplh": SMPLH_PARENTS}[model_type]
+    a = make_synthetic_smplx_asset(seed=seed, num_vertices=6890, num_betas=num_betas, num_expressions=0, nnz_per_vertex=nnz_per_vertex,
+                                   parents=parents)
+    a.update(extra_joint_vertex_ids=SMPLH_EXTRA_VERTEX_IDS.copy(), lmk_faces_idx=np.zeros((0,), np.int32),
+             lmk_bary_coords=np.zeros((0, 3), np.float32), model_type=model_type)
+    return a
+
+
+def make_synthetic_smplx_asset(seed=0, num_vertices=10475, num_betas=10, num_expressions=10, nnz_per_vertex=4, parents=None):
     rs = np.random.RandomState(seed)
-    V, J = num_vertices, 55
+    parents = SMPLX_PARENTS if parents is None else parents
+    V, J = num_vertices, len(parents)
     v_template = (rs.standard_normal((V, 3)) * np.array([0.25, 0.55, 0.12])).astype(np.float32)
     shapedirs = (rs.standard_normal((V, 3, num_betas + num_expressions)) * 0.01).astype(np.float32)
     posedirs = (rs.standard_normal(((J - 1) * 9, V * 3)) * 0.005).astype(np.float32)
@@ -40,7 +62,7 @@ def make_synthetic_smplx_asset(seed=0, num_vertices=10475, num_betas=10, num_exp
     bary = rs.uniform(0.05, 1.0, size=(51, 3))
     lmk_bary_coords = (bary / bary.sum(axis=1, keepdims=True)).astype(np.float32)
     return dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, J_regressor=J_regressor,
-                parents=SMPLX_PARENTS.astype(np.int64), weights=weights, faces=faces, lmk_faces_idx=lmk_faces_idx,
+                parents=np.asarray(parents).astype(np.int64), weights=weights, faces=faces, lmk_faces_idx=lmk_faces_idx,
                 lmk_bary_coords=lmk_bary_coords, extra_joint_vertex_ids=SMPLX_EXTRA_VERTEX_IDS.copy() % V,
                 num_betas=num_betas, num_expressions=num_expressions, model_type="smplx")
 
@@ -61,3 +83,23 @@ def load_smplx_npz(path, num_betas=10, num_expressions=10):
                 lmk_faces_idx=d["lmk_faces_idx"].astype(np.int32), lmk_bary_coords=d["lmk_bary_coords"].astype(np.float32),
                 extra_joint_vertex_ids=SMPLX_EXTRA_VERTEX_IDS.copy(), num_betas=num_betas, num_expressions=num_expressions,
                 model_type="smplx")
+
+
+def load_model_npz(path, model_type="smplx", num_betas=10, num_expressions=10):
+    """Asset dictionary from an official model ``.npz``: SMPL-X via ``load_smplx_npz``; SMPL / SMPL-H the way the reference
+    loads them (lib/body_model/body_model.py:44-57: raw arrays, shape space truncated to ``num_betas``, flat hand mean)."""
+    if model_type == "smplx":
+        return load_smplx_npz(path, num_betas, num_expressions)
+    d = np.load(path, allow_pickle=True, encoding="latin1")
+    V = d["v_template"].shape[0]
+    posedirs = np.reshape(d["posedirs"], [V * 3, -1]).T.astype(np.float32)
+    parents = d["kintree_table"][0].astype(np.int64)
+    parents[0] = -1
+    sd = np.asarray(d["shapedirs"], dtype=np.float32)[:, :, :num_betas]
+    if sd.shape[2] < num_betas:                                     # body_model.py:53-56 pads the shape space with zeros
+        sd = np.concatenate([sd, np.zeros((V, 3, num_betas - sd.shape[2]), np.float32)], axis=2)
+    return dict(v_template=d["v_template"].astype(np.float32), shapedirs=sd, posedirs=posedirs,
+                J_regressor=np.asarray(d["J_regressor"].todense() if hasattr(d["J_regressor"], "todense") else d["J_regressor"], dtype=np.float32),
+                parents=parents, weights=d["weights"].astype(np.float32), faces=d["f"].astype(np.int32),
+                lmk_faces_idx=np.zeros((0,), np.int32), lmk_bary_coords=np.zeros((0, 3), np.float32),
+                extra_joint_vertex_ids=SMPLH_EXTRA_VERTEX_IDS.copy(), num_betas=num_betas, num_expressions=0, model_type=model_type)

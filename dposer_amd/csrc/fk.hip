@@ -160,6 +160,114 @@ extern "C" int dposer_rot6d_to_rotmat(const float* rot6d, float* rotmat, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// Rest shape: blend shapes + joint regression (smplx lbs.py blend_shapes / vertices2joints; include/dposer_hip.h)
+// ------------------------------------------------------------------------------------------------
+// HBM-bound on its output (B x V*3 floats): one thread owns one vertex coordinate i, keeps its L blend-shape coefficients in
+// registers (one 4*L-byte contiguous read, L2-resident across the pose chunks) and walks a chunk of poses; the shape
+// coefficients are wave-uniform, i.e. scalar loads.  The joint part (J*3 coordinates) runs as extra tiles of the same grid
+// on the pre-regressed directions.
+constexpr int SB_MAX_L = 32;     // betas + expression coefficients (smplx: 10 + 10; the reference's hack for SMPL-H: 16)
+constexpr int SB_POSES = 8;      // poses per block
+__global__ void __launch_bounds__(256) k_shape_blend(const float* __restrict__ vt, const float* __restrict__ sd, const float* __restrict__ jt,
+                                                      const float* __restrict__ jd, const float* __restrict__ shape, float* __restrict__ vs,
+                                                      float* __restrict__ jr, int V3, int J3, int L, int64_t B, int v_tiles) {
+    const bool joints = (int)blockIdx.x >= v_tiles;
+    const int n = joints ? J3 : V3;
+    const int i = (joints ? blockIdx.x - v_tiles : blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* dir = (joints ? jd : sd) + (int64_t)i * L;
+    const float base = (joints ? jt : vt)[i];
+    float* out = joints ? jr : vs;
+    float c[SB_MAX_L];
+#pragma unroll
+    for (int l = 0; l < SB_MAX_L; ++l) c[l] = l < L ? dir[l] : 0.f;
+    const int64_t b0 = (int64_t)blockIdx.y * SB_POSES;
+    for (int k = 0; k < SB_POSES && b0 + k < B; ++k) {
+        const float* sh = shape + (b0 + k) * L;
+        float acc = 0.f;                         // sum_l shape[l] * dir[l] in index order (torch.einsum's reduction order is
+#pragma unroll                                   // not part of any contract; fp32 agreement is ~1e-7)
+        for (int l = 0; l < SB_MAX_L; ++l)
+            if (l < L) acc += sh[l] * c[l];
+        out[(b0 + k) * n + i] = base + acc;
+    }
+}
+// d_shape[b][l] = sum_i dv[b][i] * sd[i][l]: stage 1 = per (pose, coordinate chunk) partial sums (fixed order => deterministic)
+constexpr int SBB_CHUNK = 4096;
+__global__ void __launch_bounds__(256) k_shape_blend_bwd_part(const float* __restrict__ sd, const float* __restrict__ dv, float* __restrict__ part,
+                                                               int V3, int L, int n_chunks) {
+    __shared__ float red[4][SB_MAX_L];
+    const int64_t b = blockIdx.y;
+    const int i0 = blockIdx.x * SBB_CHUNK;
+    float acc[SB_MAX_L];
+#pragma unroll
+    for (int l = 0; l < SB_MAX_L; ++l) acc[l] = 0.f;
+    for (int i = i0 + threadIdx.x; i < i0 + SBB_CHUNK && i < V3; i += 256) {
+        const float g = dv[b * V3 + i];
+        const float* d = sd + (int64_t)i * L;
+#pragma unroll
+        for (int l = 0; l < SB_MAX_L; ++l)
+            if (l < L) acc[l] += g * d[l];
+    }
+#pragma unroll
+    for (int l = 0; l < SB_MAX_L; ++l) {
+        float v = acc[l];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][l] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < L) part[(b * n_chunks + blockIdx.x) * L + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// stage 2: chunks in order, then the joint term
+__global__ void k_shape_blend_bwd_final(const float* __restrict__ part, const float* __restrict__ jd, const float* __restrict__ dj, float* __restrict__ d_shape,
+                                        int J3, int L, int n_chunks, int64_t B) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * L) return;
+    const int64_t b = t / L;
+    const int l = (int)(t % L);
+    float acc = 0.f;
+    for (int c = 0; c < n_chunks; ++c) acc += part[(b * n_chunks + c) * L + l];
+    if (dj)
+        for (int i = 0; i < J3; ++i) acc += dj[b * J3 + i] * jd[(int64_t)i * L + l];
+    d_shape[t] = acc;
+}
+extern "C" int dposer_shape_blend_forward(const float* v_template, const float* shapedirs, const float* j_template, const float* jdirs,
+                                          const float* shape, float* v_shaped, float* j_rest, int32_t num_vertices, int32_t num_joints,
+                                          int32_t num_shape, int64_t batch, void* stream) {
+    DP_CHECK_ARG(v_template && shapedirs && j_template && jdirs && shape && v_shaped && j_rest, "null argument");
+    DP_CHECK_ARG(num_shape >= 1 && num_shape <= SB_MAX_L, "num_shape must be in 1..32");
+    DP_CHECK_ARG(num_vertices > 0 && num_joints > 0 && batch >= 0, "bad size");
+    if (batch == 0) return DPOSER_OK;
+    const int V3 = num_vertices * 3, J3 = num_joints * 3;
+    const int v_tiles = (int)ceil_div(V3, 256), j_tiles = (int)ceil_div(J3, 256);
+    DP_CHECK_ARG(ceil_div(batch, SB_POSES) <= 65535, "batch too large for one launch");
+    hipLaunchKernelGGL(k_shape_blend, dim3(v_tiles + j_tiles, (unsigned)ceil_div(batch, SB_POSES)), dim3(256), 0, (hipStream_t)stream, v_template,
+                       shapedirs, j_template, jdirs, shape, v_shaped, j_rest, V3, J3, num_shape, batch, v_tiles);
+    FK_HIP_LAUNCH(hipGetLastError());
+    return DPOSER_OK;
+}
+extern "C" int64_t dposer_shape_blend_scratch_floats(int32_t num_vertices, int32_t num_shape, int64_t batch) {
+    return batch * ceil_div((int64_t)num_vertices * 3, SBB_CHUNK) * num_shape;
+}
+extern "C" int dposer_shape_blend_backward(const float* shapedirs, const float* jdirs, const float* d_v_shaped, const float* d_j_rest,
+                                           float* d_shape, float* scratch, int32_t num_vertices, int32_t num_joints, int32_t num_shape,
+                                           int64_t batch, void* stream) {
+    DP_CHECK_ARG(shapedirs && jdirs && d_v_shaped && d_shape && scratch, "null argument");
+    DP_CHECK_ARG(num_shape >= 1 && num_shape <= SB_MAX_L, "num_shape must be in 1..32");
+    if (batch == 0) return DPOSER_OK;
+    DP_CHECK_ARG(batch <= 65535, "batch too large for one launch");
+    const int V3 = num_vertices * 3, J3 = num_joints * 3;
+    const int n_chunks = (int)ceil_div(V3, SBB_CHUNK);
+    hipLaunchKernelGGL(k_shape_blend_bwd_part, dim3(n_chunks, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, shapedirs, d_v_shaped, scratch, V3,
+                       num_shape, n_chunks);
+    FK_HIP_LAUNCH(hipGetLastError());
+    hipLaunchKernelGGL(k_shape_blend_bwd_final, dim3((unsigned)ceil_div(batch * num_shape, 128)), dim3(128), 0, (hipStream_t)stream, scratch, jdirs,
+                       d_j_rest, d_shape, J3, num_shape, n_chunks, batch);
+    FK_HIP_LAUNCH(hipGetLastError());
+    return DPOSER_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Forward kinematics
 // ------------------------------------------------------------------------------------------------
 struct KinSMPL {

@@ -201,6 +201,23 @@ typedef struct {
 int dposer_body_create(const dposer_body_desc* desc, const int32_t* parents_host, dposer_body_t* out);
 void dposer_body_destroy(dposer_body_t h);
 
+/* Rest shape: shape blend shapes + joint regression -- smplx/lbs.py blend_shapes + vertices2joints at the head of lbs(), as
+ * reached from lib/body_model/body_model.py:75-88 with betas / expression given per pose (run/smplify.py:200-260 optimises
+ * betas; the task loops pass constant ones).
+ *   v_shaped[b] = v_template + shapedirs . shape[b]          shapedirs [V*3, L] (the asset's [V,3,L]), shape [B, L]
+ *   j_rest[b]   = J_regressor @ v_shaped[b] = j_template + jdirs . shape[b]
+ * The regressor is LINEAR, so it is applied once to the template and to every blend-shape direction on the host side
+ * (j_template [J*3] = J_regressor @ v_template, jdirs [J*3, L] = J_regressor @ shapedirs[..., l]); per pose the joints are an
+ * L-term combination instead of a [J, V] x [V, 3] product.
+ * Backward: d_shape [B, L] = d_v_shaped . shapedirs + d_j_rest . jdirs; scratch >= dposer_shape_blend_scratch_floats(...) floats. */
+int dposer_shape_blend_forward(const float* v_template, const float* shapedirs, const float* j_template, const float* jdirs,
+                               const float* shape, float* v_shaped, float* j_rest, int32_t num_vertices, int32_t num_joints,
+                               int32_t num_shape, int64_t batch, void* stream);
+int64_t dposer_shape_blend_scratch_floats(int32_t num_vertices, int32_t num_shape, int64_t batch);
+int dposer_shape_blend_backward(const float* shapedirs, const float* jdirs, const float* d_v_shaped, const float* d_j_rest,
+                                float* d_shape, float* scratch, int32_t num_vertices, int32_t num_joints, int32_t num_shape,
+                                int64_t batch, void* stream);
+
 /* Forward kinematics: Rodrigues + kinematic chain (smplx/lbs.py batch_rodrigues, batch_rigid_transform)
  * with the pose assembled as SMPLX.forward does (reference call site lib/body_model/body_model.py:75-88):
  *   pose_segments_host[i]: DEVICE pointer to segment i, [B, segment_joints[i]*3] axis-angle, or NULL

@@ -129,3 +129,22 @@ def smplx_forward(asset, body_pose, betas=None, global_orient=None, transl=None,
         joints = joints + transl[:, None].astype(dtype)
         verts = verts + transl[:, None].astype(dtype)
     return verts, joints, full_pose, aux
+
+
+def model_forward(asset, full_pose, shape=None, transl=None, dtype=np.float64):
+    """smplx.{SMPL,SMPLH,SMPLX}.forward for an already assembled ``full_pose`` [B, J*3] (global orient first, then the body /
+    hand / face segments in the order of smplx body_models.py): lbs() + vertex-selected extra joints (+ landmarks when the
+    asset has them) + transl.  ``shape`` = [betas | expression] or None (zeros)."""
+    B = full_pose.shape[0]
+    L = asset["shapedirs"].shape[2]
+    sh = np.zeros((B, L), dtype=dtype) if shape is None else shape.astype(dtype)
+    verts, joints, aux = lbs(sh, full_pose.astype(dtype), asset, dtype=dtype)
+    parts = [joints, verts[:, asset["extra_joint_vertex_ids"]]]
+    if len(asset["lmk_faces_idx"]):
+        faces = asset["faces"][asset["lmk_faces_idx"]]
+        parts.append(np.einsum("blfi,lf->bli", verts[:, faces], asset["lmk_bary_coords"].astype(dtype)))
+    joints = np.concatenate(parts, axis=1)
+    if transl is not None:
+        joints = joints + transl[:, None].astype(dtype)
+        verts = verts + transl[:, None].astype(dtype)
+    return verts, joints, aux

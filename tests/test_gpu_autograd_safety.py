@@ -86,8 +86,8 @@ def test_backward_twice_with_retain_graph():
 
 
 def test_input_gradient_only_skips_the_parameter_gradients():
-    """A VJP w.r.t. x alone (Hutchinson divergence, likelihood.py:29-35; guidance, sampling.py:191-207) must not run the
-    wgrad side: the backward call gets flat_grad = NULL."""
+    """A VJP w.r.t. x alone (Hutchinson divergence, likelihood.py:29-35; guidance, sampling.py:191-207) inside
+    ScoreModelFC.input_grad_only() must not run the wgrad side: the backward call gets flat_grad = NULL."""
     from dposer_amd import _C
     cfg, m, p = make_model(4, precision="fp32", dropout=0.0)
     x, t, w = _inputs(7)
@@ -102,7 +102,8 @@ def test_input_gradient_only_skips_the_parameter_gradients():
     m._engine().lib = type("L", (), {"__getattr__": lambda s, n: Spy() if n == "dposer_scorefc_backward" else getattr(lib, n)})()
     try:
         xx = x.clone().requires_grad_(True)
-        g, = torch.autograd.grad((m(xx, t) * w).sum(), xx)
+        with m.input_grad_only():
+            g, = torch.autograd.grad((m(xx, t) * w).sum(), xx)
         assert seen and (seen[-1] is None or getattr(seen[-1], "value", seen[-1]) in (None, 0))
     finally:
         m._engine().lib = lib

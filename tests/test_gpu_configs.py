@@ -184,7 +184,7 @@ def test_cfg5_motion_denoising_60_frames_180_steps_vs_oracle_loop():
     asset = make_synthetic_smplx_asset(seed=0)
     bm = BodyModel(asset).to(DEV)
     st = load("g10_normalizer")
-    stats = {k.split("/")[-1]: torch.tensor(st[k]) for k in st.files if k.startswith("stats/axis_normalize2")}
+    stats = {k.split("/")[-1]: torch.tensor(st[k]) for k in st.files if k.startswith("stats/axis_normalize")}
     raw, _ = _toy_rows(2, 60)
     w = np.linspace(0, 1, T, dtype=np.float32)[:, None]
     gt = ((1 - w) * raw[0] + w * raw[1]).astype(np.float32)                       # a smooth 60-frame sequence between two toy poses

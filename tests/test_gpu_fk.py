@@ -389,3 +389,94 @@ def test_lbs_backward_against_finite_differences(bm):
             fd = float(L(pose + eps * dp, root + eps * dr, tr + eps * dt) - L(pose - eps * dp, root - eps * dr, tr - eps * dt)) / (2 * eps)
         an = float((gp * dp).sum() + (gr * dr).sum() + (gt * dt).sum())
         assert abs(fd - an) / max(abs(an), 1e-3) < 5e-3, (fd, an)
+
+
+# ------------------------------------------------------------------------------------------------
+# rest shape kernel (blend shapes + joint regression) and the SMPL / SMPL-H wrappers
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B", [1, 7, 8, 9, 300])
+def test_shape_blend_and_joint_regression_vs_oracle(bm, asset, B):
+    """v_shaped = v_template + shapedirs . [betas | expression], J = J_regressor @ v_shaped (lbs.py), per pose."""
+    rs = np.random.RandomState(B)
+    betas = rs.standard_normal((B, 10)).astype(np.float32) * 2
+    expr = rs.standard_normal((B, 10)).astype(np.float32)
+    vs, jr, batched = bm.bm.rest_shape(torch.tensor(betas, device=DEV), torch.tensor(expr, device=DEV))
+    assert batched and vs.shape == (B, 10475, 3) and jr.shape == (B, 55, 3)
+    shape = np.concatenate([betas, expr], axis=1).astype(np.float64)
+    ref_v = asset["v_template"].astype(np.float64)[None] + np.einsum("bl,mkl->bmk", shape, asset["shapedirs"].astype(np.float64))
+    ref_j = np.einsum("bik,ji->bjk", ref_v, asset["J_regressor"].astype(np.float64))
+    assert np.abs(t2n(vs) - ref_v).max() < 1e-6 and np.abs(t2n(jr) - ref_j).max() < 1e-6
+    # full forward with betas: vertices / joints vs the oracle
+    pose = _poses(B, seed=B + 1)
+    o = bm(pose_body=torch.tensor(pose, device=DEV), betas=torch.tensor(betas, device=DEV), expression=torch.tensor(expr, device=DEV))
+    v_ref, j_ref, _, _ = fk_ref.smplx_forward(asset, pose.astype(np.float64), betas=betas.astype(np.float64), expression=expr.astype(np.float64),
+                                              dtype=np.float64)
+    assert np.abs(t2n(o.v) - v_ref).max() < 1e-5 and np.abs(t2n(o.Jtr) - j_ref).max() < 1e-5
+
+
+def test_constant_betas_are_blended_once(bm):
+    """The fitting loops pass the same betas tensor every step (motion_denoising.py:64,217): the rest shape is computed on the
+    first call and reused while the tensor is unchanged; an in-place change or another tensor recomputes it."""
+    betas = torch.zeros(6, 10, device=DEV)
+    a = bm.bm.rest_shape(betas, None)
+    b = bm.bm.rest_shape(betas, None)
+    assert a[0] is b[0] and a[1] is b[1]
+    betas.add_(1.0)
+    c = bm.bm.rest_shape(betas, None)
+    assert c[0] is not a[0] and float((c[0] - a[0]).abs().max()) > 0
+    d = bm.bm.rest_shape(betas.clone(), None)
+    assert d[0] is not c[0] and torch.equal(d[0], c[0])
+
+
+def test_betas_gradient_through_shape_blend_and_lbs(bm, asset):
+    """d loss / d betas, d expression (run/smplify.py:200-260 optimises betas) vs the differentiable fp64 restatement."""
+    from oracle import fk_torch
+    B = 5
+    rs = np.random.RandomState(12)
+    dev = lambda a: torch.tensor(a.astype(np.float32), device=DEV)
+    pose, betas, expr = rs.standard_normal((B, 63)) * 0.3, rs.standard_normal((B, 10)), rs.standard_normal((B, 10)) * 0.5
+    wv, wj = rs.standard_normal((B, 10475, 3)) / 100, rs.standard_normal((B, 127, 3))
+    p, b, e = dev(pose).requires_grad_(True), dev(betas).requires_grad_(True), dev(expr).requires_grad_(True)
+    o = bm(pose_body=p, betas=b, expression=e)
+    ((o.v * dev(wv)).sum() + (o.Jtr * dev(wj)).sum()).backward()
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    p2, b2, e2 = t64(pose.astype(np.float32)), t64(betas.astype(np.float32)), t64(expr.astype(np.float32))
+    v, j = fk_torch.smplx_forward(asset, p2, betas=b2, expression=e2)
+    ((v * torch.tensor(wv.astype(np.float32)).double()).sum() + (j * torch.tensor(wj.astype(np.float32)).double()).sum()).backward()
+    for got, ref in ((p.grad, p2.grad), (b.grad, b2.grad), (e.grad, e2.grad)):
+        assert np.abs(t2n(got) - ref.numpy()).max() / np.abs(ref.numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("model_type", ["smpl", "smplh"])
+def test_smpl_and_smplh_wrappers_vs_oracle(model_type):
+    """BodyModel(model_type='smpl' / 'smplh') (body_model.py:38-62): full-pose layouts global(1) body(23) and
+    global(1) body(21) lhand(15) rhand(15); joints = LBS joints + 21 vertex-selected extras (45 / 73)."""
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_asset
+    a = make_synthetic_asset(model_type, seed=3)
+    m = BodyModel(a, num_betas=10, model_type=model_type).to(DEV)
+    B = 37
+    rs = np.random.RandomState(5)
+    nb = 23 if model_type == "smpl" else 21
+    body = (rs.standard_normal((B, nb * 3)) * 0.4).astype(np.float32)
+    root = (rs.standard_normal((B, 3)) * 0.5).astype(np.float32)
+    betas = rs.standard_normal((B, 10)).astype(np.float32)
+    tr = rs.standard_normal((B, 3)).astype(np.float32)
+    hand = (rs.standard_normal((B, 90)) * 0.3).astype(np.float32)
+    dev = lambda x: torch.tensor(x, device=DEV)
+    kw = dict(root_orient=dev(root), pose_body=dev(body), betas=dev(betas), trans=dev(tr))
+    full = [root, body]
+    if model_type == "smplh":
+        kw["pose_hand"] = dev(hand)
+        full.append(hand)
+    o = m(**kw)
+    v_ref, j_ref, _ = fk_ref.model_forward(a, np.concatenate(full, axis=1), shape=betas, transl=tr)
+    assert m.num_joints == (23 if model_type == "smpl" else 51)
+    assert o.Jtr.shape == (B, (24 if model_type == "smpl" else 52) + 21, 3) and o.v.shape == (B, 6890, 3)
+    assert np.abs(t2n(o.v) - v_ref).max() < 1e-5 and np.abs(t2n(o.Jtr) - j_ref).max() < 1e-5
+    assert o.full_pose.shape == (B, (24 if model_type == "smpl" else 52) * 3)
+    assert hasattr(o, "pose_hand") == (model_type == "smplh") and not hasattr(o, "pose_jaw")
+    # gradients flow through the same kernels
+    p = dev(body).requires_grad_(True)
+    m(pose_body=p, betas=dev(betas)).Jtr.sum().backward()
+    assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0

@@ -118,7 +118,7 @@ def _motion_denoise_golden(tag):
     cfg, m, p = make_model(int(g["seed"]), precision="fp32")
     bm = BodyModel(make_synthetic_smplx_asset(seed=0)).to(DEV)
     st = load("g10_normalizer")
-    stats = {k.split("/")[-1]: torch.tensor(st[k]) for k in st.files if k.startswith("stats/axis_normalize2")}
+    stats = {k.split("/")[-1]: torch.tensor(st[k]) for k in st.files if k.startswith("stats/axis_normalize")}
 
     class Args:
         device = DEV
