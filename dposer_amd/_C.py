@@ -61,6 +61,8 @@ SIGNATURES = {
                                     vp, vp, i64, vp]),
     "dposer_prior_loss": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, f32, i32, f32, vp, vp, vp, u64,
                                     u32, vp, vp, i64, vp]),
+    "dposer_completion_optimize": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, vp, vp, C.POINTER(f32), C.POINTER(i32),
+                                             C.POINTER(f32), C.POINTER(f32), i32, f64, f64, f64, f64, vp, u64, u32, vp, vp, i64, vp]),
     "dposer_dsm_loss_fwd_bwd": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, f32, u64, u32, vp, vp,
                                           vp, vp, i64, vp]),
     "dposer_dsm_loss_fwd_bwd_bucketed": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, f32, u64, u32, vp, vp,

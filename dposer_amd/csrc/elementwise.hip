@@ -438,6 +438,52 @@ hipError_t launch_denoise(const DenoiseArgs& a, int* nblocks, hipStream_t st) {
     return hipGetLastError();
 }
 
+// One step of DPoserComp.optimize behind the network evaluation: Tweedie estimate (completion.py:105-110), gradient of
+//   w_prior * mean(w (x - x0_hat)^2) + w_data * MSE(x * mask, obs * mask)                (completion.py:131-149,195-201)
+// w.r.t. x (x0_hat is detached in the reference), and torch.optim.Adam's update of x with per-element moments -- one pass
+// over seven [B, D] streams instead of ~10 torch kernels.
+struct CompletionDev {
+    CompletionUpdateArgs a;
+    SdeDev sde;
+};
+__global__ void __launch_bounds__(256) k_completion_update(CompletionDev d) {
+    const CompletionUpdateArgs& a = d.a;
+    const float lmc = sde_lmc(d.sde, a.t);
+    const float alpha = expf(lmc), sigma = sde_std(d.sde, lmc);      // return_alpha_sigma, sde_lib.py:227-231
+    const float sigma2 = sigma * sigma;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, 0) : 1.0f;
+    const float snr = alpha / sqrtf(sigma2);                          // completion.py:108
+    const float w = a.weighted ? 0.5f * sqrtf(1.0f + snr) : 0.5f;     // completion.py:143-146
+    const int64_t total = a.B * a.D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / a.D;
+        const int c = (int)(i % a.D);
+        const float model = a.res[s * a.Cp + c] / usig;
+        const float score = -model / sigma;                           // utils.py:155,162
+        const float x0h = (a.xt[s * a.Dpad + c] + sigma2 * score) / alpha;   // completion.py:107
+        float x = a.x[i];
+        const float mk = a.mask[i];
+        const float g_prior = ((2.0f * w) * (x - x0h) * a.inv_n) * a.w_prior;
+        const float g_data = (((2.0f * (x * mk - a.obs[i] * mk)) * a.inv_n) * a.w_data) * mk;
+        const float g = g_prior + g_data;
+        float m = a.m[i], v = a.v[i];
+        m = m + (g - m) * a.one_minus_beta1;                          // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * a.beta2 + a.one_minus_beta2 * (g * g);                // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        x = x - a.step_size * (m / denom);                            // param.addcdiv_(exp_avg, denom, value=-step_size)
+        a.m[i] = m;
+        a.v[i] = v;
+        a.x[i] = x;
+    }
+}
+hipError_t launch_completion_update(const CompletionUpdateArgs& a, hipStream_t st) {
+    CompletionDev d;
+    d.a = a;
+    d.sde = make_sde_dev(a.sde);
+    hipLaunchKernelGGL(k_completion_update, dim3(grid_for(a.B * a.D, 256, 2048)), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+
 struct DsmDev {
     DsmArgs a;
     SdeDev sde;

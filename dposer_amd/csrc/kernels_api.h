@@ -134,6 +134,26 @@ struct PerturbSharedArgs { // x_t = mean + std*z at one shared t; writes xin (FT
 };
 hipError_t launch_perturb_shared(const PerturbSharedArgs& a, hipStream_t st);
 
+struct CompletionUpdateArgs {   // one optimisation step of DPoserComp.optimize (run/completion.py:167-207) after the network evaluation
+    const float* res;      // [Bpad][Cp] model output at x_t
+    const float* xt;       // [Bpad][Dpad] perturbed data
+    const float* obs;      // [B][D]
+    const float* mask;     // [B][D]
+    const float* sigmas;
+    float* x;              // [B][D] optimisation variable, updated in place
+    float* m;              // [B][D] Adam first moment
+    float* v;              // [B][D] Adam second moment
+    float t;
+    float inv_n;           // 1 / (B * D): both losses are means over the batch (completion.py:147, nn.MSELoss)
+    float w_prior, w_data; // loss weights of this step (completion.py:151-155)
+    int weighted;
+    float step_size, one_minus_beta1, beta2, one_minus_beta2, bc2_sqrt, eps;   // torch.optim.Adam scalars of this step
+    int64_t B;
+    int D, Dpad, Cp, num_scales, scale_by_sigma;
+    SdeCfg sde;
+};
+hipError_t launch_completion_update(const CompletionUpdateArgs& a, hipStream_t st);
+
 struct DsmArgs {           // get_sde_loss_fn tail (losses.py:121-131) + d loss / d res
     const float* res;      // [Bpad][Cp]
     const float* t;        // [Bpad]

@@ -671,6 +671,53 @@ extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const vo
     return DPOSER_OK;
 }
 
+// DPoserComp.optimize (run/completion.py:167-207): the whole optimisation loop in one call.  Per step: perturb x at the step's
+// shared t, one forward-only network evaluation on the time-table row of that step (the table for ALL steps is built once),
+// and one kernel for Tweedie estimate + loss gradients + per-sample Adam.  Nothing returns to the host in between.
+extern "C" int dposer_completion_optimize(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                          float* x, const float* observation, const float* mask, float* adam_m, float* adam_v,
+                                          const float* t_host, const int32_t* weighted_host, const float* w_prior_host,
+                                          const float* w_data_host, int32_t n_steps, double lr, double beta1, double beta2, double eps,
+                                          const float* noise, uint64_t seed, uint32_t step0, const float* freq, const float* sigmas,
+                                          int64_t B, void* stream) {
+    DP_TRY(check_common(h, flat, packed_, ws_, B));
+    g_alg_batch = B;
+    DP_CHECK_ARG(sde && x && observation && mask && adam_m && adam_v && t_host && weighted_host && w_prior_host && w_data_host && freq && sigmas,
+                 "null argument");
+    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused completion loop supports subVP / VP SDEs");
+    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused completion loop supports the positional embedding");
+    DP_CHECK_ARG(n_steps >= 0, "n_steps must be >= 0");
+    if (n_steps == 0) return DPOSER_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const char* packed = (const char*)packed_;
+    Ws w;
+    layout_ws(h, B, DPOSER_WS_SHARED_T, n_steps, (char*)ws_, w);
+    h->host_stage.resize(n_steps);
+    for (int i = 0; i < n_steps; ++i) h->host_stage[i] = t_host[i] * 999.0f;      // labels = t * 999 (utils.py:152)
+    DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n_steps * sizeof(float), hipMemcpyHostToDevice, st));
+    DP_TRY(build_time_table(h, flat, packed, w, w.tt_labels, 0.f, n_steps, freq, st));
+    const SdeCfg sc = to_sde(sde);
+    const int64_t BD = B * h->D;
+    for (int i = 0; i < n_steps; ++i) {
+        PerturbSharedArgs pa;
+        pa.x0 = x; pa.z_in = noise ? noise + (int64_t)i * BD : nullptr; pa.xin = w.xin; pa.xt = w.xt; pa.t = t_host[i]; pa.B = B; pa.Bpad = w.Bpad;
+        pa.D = h->D; pa.Dpad = h->Dpad; pa.f32 = h->f32; pa.sde = sc; pa.seed = seed; pa.step = step0 + (uint32_t)i;
+        DP_HIP_LAUNCH(launch_perturb_shared(pa, st));
+        DP_TRY(run_shared_t(h, flat, packed, w, i, B, st));
+        CompletionUpdateArgs ua;
+        ua.res = w.res; ua.xt = w.xt; ua.obs = observation; ua.mask = mask; ua.sigmas = sigmas; ua.x = x; ua.m = adam_m; ua.v = adam_v;
+        ua.t = t_host[i]; ua.inv_n = (float)(1.0 / ((double)B * (double)h->D)); ua.w_prior = w_prior_host[i]; ua.w_data = w_data_host[i];
+        ua.weighted = weighted_host[i];
+        const double k = (double)(i + 1);
+        ua.step_size = (float)(lr / (1.0 - std::pow(beta1, k)));                   // torch: step_size = lr / bias_correction1
+        ua.one_minus_beta1 = (float)(1.0 - beta1); ua.beta2 = (float)beta2; ua.one_minus_beta2 = (float)(1.0 - beta2);
+        ua.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(beta2, k)); ua.eps = (float)eps;
+        ua.B = B; ua.D = h->D; ua.Dpad = h->Dpad; ua.Cp = h->Cp; ua.num_scales = h->d.num_scales; ua.scale_by_sigma = h->d.scale_by_sigma; ua.sde = sc;
+        DP_HIP_LAUNCH(launch_completion_update(ua, st));
+    }
+    return DPOSER_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // training: DSM loss forward + backward
 // ------------------------------------------------------------------------------------------------

@@ -179,10 +179,13 @@ class Evaler:
                 dj = dj[:, self.joint_idx.to(dj.device)]
             return {"mpvpe_all": torch.sqrt((dv ** 2).sum(-1)).mean(-1) * 1000, "mpjpe_body": torch.sqrt((dj ** 2).sum(-1)).mean(-1) * 1000}
 
-    def multi_eval_bodys(self, outs, gts):
-        """outs [b, hypo, 63]: minimum over hypotheses (AMASS.py:300-316); returns numpy vectors like the reference."""
+    def multi_eval_bodys(self, outs, gts, as_tensors=False):
+        """outs [b, hypo, 63]: minimum over hypotheses (AMASS.py:300-316).  Returns numpy vectors like the reference, or -- with
+        ``as_tensors`` -- device tensors, so a whole evaluation run never synchronises with the host until
+        ``distributed.reduce_metric_means`` at the end."""
         res = [self.eval_bodys(outs[:, h].contiguous(), gts) for h in range(outs.shape[1])]
-        return {k: torch.stack([r[k] for r in res], 0).min(0).values.cpu().numpy() for k in ("mpvpe_all", "mpjpe_body")}
+        out = {k: torch.stack([r[k] for r in res], 0).min(0).values for k in ("mpvpe_all", "mpjpe_body")}
+        return out if as_tensors else {k: v.cpu().numpy() for k, v in out.items()}
 
     def print_eval_result(self, eval_result):
         import numpy as np

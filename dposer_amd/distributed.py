@@ -123,6 +123,32 @@ def gather_metrics(all_results, dst=0):
     return {k: float(np.mean(np.array(v))) for k, v in merged.items()}, merged
 
 
+def reduce_metric_means(all_results, device=None):
+    """The means of run/completion.py:318-321 without shipping per-sample values: every rank folds its batches into one
+    [n_metrics, 2] device tensor of (sum, count) in float64, ONE all-reduce (SUM) combines the ranks, and every rank gets
+    ``{name: mean over every sample of every rank}``.  ``all_results``: list (one entry per batch) of {name: per-sample tensor}.
+    Metric names must agree across ranks (they come from the same Evaler)."""
+    names = sorted({k for batch in all_results for k in batch})
+    if device is None:
+        device = next((v.device for batch in all_results for v in batch.values() if torch.is_tensor(v)), torch.device("cpu"))
+    acc = torch.zeros(len(names), 2, dtype=torch.float64, device=device)
+    for batch in all_results:
+        for i, k in enumerate(names):
+            if k in batch:
+                v = torch.as_tensor(batch[k], device=device).reshape(-1).double()
+                acc[i, 0] += v.sum()
+                acc[i, 1] += v.numel()
+    if is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo" and acc.is_cuda:      # (gloo test rigs reduce on the host)
+            host = acc.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            acc = host
+        else:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    acc = acc.cpu()
+    return {k: float(acc[i, 0] / acc[i, 1]) if acc[i, 1] > 0 else float("nan") for i, k in enumerate(names)}
+
+
 def barrier():
     if is_initialized():
         dist.barrier()

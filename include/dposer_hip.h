@@ -170,6 +170,20 @@ int dposer_adam_ema_clip_step(float* flat_params, const float* flat_grad, float*
                               double lr, double beta1, double beta2, double eps, double grad_clip, double grad_scale,
                               int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream);
 
+/* DPoserComp.optimize -- run/completion.py:167-207 (loss :131-149, weights :151-155): `n_steps` Adam steps on the pose batch
+ * x [B, D] (in: the initial value, i.e. the observation; out: the optimised variable -- the caller applies the final
+ * observation/mask blend of :205) under  w_prior[i] * mean(w (x - x0_hat)^2) + w_data[i] * MSE(x * mask, obs * mask).
+ *   adam_m / adam_v [B, D]: torch.optim.Adam moments, zero on entry for a fresh optimiser (per-sample state: the loop shards
+ *   over GPUs with no collective);  t_host / weighted_host / w_prior_host / w_data_host [n_steps]: HOST arrays of the
+ *   per-step time, the `weighted` flag (the reference passes quan_t there, :196) and the loss weights;
+ *   noise [n_steps, B, D] injected z of :133, or NULL -> Philox(seed, step0 + i).  Workspace: DPOSER_WS_SHARED_T with
+ *   n_steps table rows. */
+int dposer_completion_optimize(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws, const dposer_sde_desc* sde,
+                               float* x, const float* observation, const float* mask, float* adam_m, float* adam_v,
+                               const float* t_host, const int32_t* weighted_host, const float* w_prior_host, const float* w_data_host,
+                               int32_t n_steps, double lr, double beta1, double beta2, double eps, const float* noise, uint64_t seed,
+                               uint32_t step0, const float* freq, const float* sigmas, int64_t batch, void* stream);
+
 /* Per-launch GEMM timing (HIP events recorded on the launch stream around every MFMA GEMM launch; off by
  * default).  collect() synchronises the recorded events and returns, per kernel kind, the summed
  * duration [ms], launch count and algorithmic FLOPs (2*M*N*K of the un-padded problem); arrays of

@@ -11,10 +11,20 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
+def _log_measured(kind, value):
+    """DPOSER_LOG_ERR=<file>: append every measured error with the id of the running test (how the tolerances were set)."""
+    path = os.environ.get("DPOSER_LOG_ERR")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?')}\t{kind}\t{value:.3e}\n")
+
+
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    e = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    _log_measured("rel_err", e)
+    return e
 
 
 def max_rel(a, b, floor=1e-6):

@@ -34,6 +34,9 @@ def _worker(rank, world, port, out):
         assert len(allv["mpjpe"]) == 4 * 3 and abs(means["mpjpe"] - (0 * 4 + 1 * 8) / 12) < 1e-12 and abs(means["mpvpe"] - 80 / 12) < 1e-12
     else:
         assert means is None and allv is None
+    # the same means from (sum, count) pairs with ONE all-reduce: every rank gets them, no per-sample values travel
+    red = ddp.reduce_metric_means(mine)
+    assert abs(red["mpjpe"] - 8 / 12) < 1e-12 and abs(red["mpvpe"] - 80 / 12) < 1e-12
     flat = torch.arange(10.0) * (rank + 1)
     ddp.broadcast_(flat, src=0)
     lo, hi = ddp.shard_bounds(65536 + 3, world, rank)
@@ -67,4 +70,5 @@ def test_single_process_is_noop():
     assert ddp.all_reduce_buckets_(g, [(0, 4), (4, 8)]) == 1 and float(g.sum()) == 8.0
     means, allv = ddp.gather_metrics([{"e": [1.0, 3.0]}, {"e": torch.tensor([5.0])}])
     assert means == {"e": 3.0} and allv["e"] == [1.0, 3.0, 5.0]
+    assert ddp.reduce_metric_means([{"e": [1.0, 3.0]}, {"e": torch.tensor([5.0])}]) == {"e": 3.0}
     assert ddp.shard_bounds(10, 3, 0) == (0, 4) and ddp.shard_bounds(10, 3, 2) == (7, 10)

@@ -46,7 +46,8 @@ def test_two_outstanding_forwards_keep_their_own_activations(precision):
     assert torch.equal(a.grad, dxa) and torch.equal(b.grad, dxb)          # bit-identical to the runs on their own
     dw = torch.cat([q.grad.reshape(-1) if q.grad is not None else torch.zeros(q.numel(), device=DEV) for q in m.parameters()])
     assert rel_err(t2n(dw), t2n(dwa + dwb)) < 1e-6
-    assert len(m._engine()._train_pool) >= 1              # leases went back to the pool when the graph was freed
+    del oa, ob, a, b                                      # the autograd nodes die with their outputs ...
+    assert len(m._engine()._train_pool) == 2              # ... and both leases went back to the pool
 
 
 def test_gradient_accumulation_over_micro_batches_and_fused_step_in_between():
