@@ -59,6 +59,10 @@ SIGNATURES = {
     "dposer_scorefc_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, u64, u32, vp]),
     "dposer_em_sampler": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, i32, vp, vp, vp, u64, vp, i32,
                                     vp, vp, i64, vp]),
+    "dposer_em_sampler_steps": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, i32, i32, vp, vp, vp, u64, vp, i32,
+                                          vp, vp, i64, vp]),
+    "dposer_langevin_step": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, f32, f32, f32, vp, u64, u32, vp, i32, f64, vp, vp,
+                                       i64, vp]),
     "dposer_prior_loss": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, f32, i32, f32, vp, vp, vp, u64,
                                     u32, vp, vp, i64, vp]),
     "dposer_completion_optimize": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, vp, vp, C.POINTER(f32), C.POINTER(i32),

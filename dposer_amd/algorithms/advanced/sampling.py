@@ -180,8 +180,10 @@ def _check_langevin_sde(sde):
 
 @register_corrector(name="langevin")
 class LangevinCorrector(Corrector):
-    """sampling.py:273-302.  The step size couples the samples through batch-mean norms (:296-297);
-    under data parallelism each rank uses its shard's means (documented deviation)."""
+    """sampling.py:273-302.  The step size couples the samples through batch-mean norms (:296-297).  This class is the generic
+    form (any score function, means over the tensor it is given); ``pc_sampler`` runs Langevin + Euler-Maruyama on the HIP
+    path instead (``fused_pc_langevin_sample``), where the means are GLOBAL-batch means also under data parallelism: the two
+    norm sums are all-reduced between the two phases of ``dposer_langevin_step``."""
 
     def __init__(self, sde, score_fn, snr, n_steps):
         super().__init__(sde, score_fn, snr, n_steps)
@@ -280,6 +282,70 @@ def fused_em_sample(model, sde, x, timesteps, *, start_step=0, observation=None,
     return traj, x, x_mean
 
 
+def fused_langevin_supported(sde, model, predictor, corrector, probability_flow, continuous):
+    from .model import ScoreModelFC
+    return (predictor is EulerMaruyamaPredictor and corrector is LangevinCorrector and not probability_flow
+            and sde_lib.sde_desc(sde) is not None and (continuous or isinstance(sde, sde_lib.subVPSDE))
+            and isinstance(model, ScoreModelFC) and model.time_embedding_type == "positional")
+
+
+def fused_pc_langevin_sample(model, sde, x, timesteps, *, snr, n_steps=1, start_step=0, observation=None, mask=None, noise=None,
+                             seed=0, traj_stride=0):
+    """Predictor-corrector loop of sampling.py:455-461 with the Langevin corrector (:282-302) and the Euler-Maruyama predictor
+    on the HIP path.  Per outer step: ``n_steps`` x [``dposer_langevin_step`` phase 0 -> all-reduce of the two norm sums over
+    the data-parallel ranks -> phase 1], then ``dposer_em_sampler_steps`` for the (imputation,) predictor (, imputation) of that
+    step.  Nothing synchronises with the host inside the loop.
+    ``noise`` [n_run, n_steps + (3 if completion else 1), B, D]: injected draws in the reference's order (tests)."""
+    from ... import distributed as ddp
+    _C.require_gpu(x, "sampler state")
+    eng = model._engine()
+    flat = model.flat_params()
+    packed = eng.packed(flat, with_backward=False, force=not model.freeze_packed)
+    B, D = x.shape
+    N = int(sde.N)
+    n_run = N - start_step
+    ws = eng.workspace(B, _C.WS_SHARED_T, 1, x.device)
+    x = x.contiguous().float().clone()
+    x_mean = x.clone()
+    ts_host = timesteps.detach().to("cpu", torch.float32).contiguous()
+    desc = sde_lib.sde_desc(sde)
+    obs = None if observation is None else observation.contiguous().float()
+    msk = None if mask is None else mask.contiguous().float()
+    nz = None if noise is None else noise.contiguous().float()
+    k_pred = 3 if obs is not None else 1
+    world = ddp.world_size()
+    global_batch = B
+    if world > 1:                                  # ragged shards: the global batch is the sum of the local ones (once per call)
+        cnt = torch.tensor([float(B)], dtype=torch.float64)
+        ddp.all_reduce_sum_(cnt)
+        global_batch = int(cnt[0])
+    norms = torch.empty(2, dtype=torch.float32, device=x.device)
+    alphas = sde.alphas.detach().to("cpu") if hasattr(sde, "alphas") else None
+    traj = torch.empty((n_run // traj_stride, B, D), dtype=torch.float32, device=x.device) if (traj_stride and n_run > 0) else None
+    freq, lib = eng.freq(x.device), eng.lib
+    for i in range(n_run):
+        gi = start_step + i
+        t = ts_host[gi]
+        alpha = float(alphas[int((t * (sde.N - 1) / sde.T).long())]) if alphas is not None else 1.0      # sampling.py:290-294
+        for k in range(n_steps):
+            z = None if nz is None else nz[i, k]
+            args = (eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(x_mean), float(t), alpha, float(snr),
+                    _C.ptr(z), int(seed), (gi * n_steps + k) & 0xFFFFFFFF, _C.ptr(norms))
+            _C.check(lib.dposer_langevin_step(*args, 0, 1.0 / global_batch, _C.ptr(freq), _C.ptr(model.sigmas), B, _C.stream_ptr()),
+                     "dposer_langevin_step")
+            if world > 1:
+                ddp.all_reduce_sum_(norms)         # two floats: keeps the reference's global-batch means under DP
+            _C.check(lib.dposer_langevin_step(*args, 1, 1.0 / global_batch, _C.ptr(freq), _C.ptr(model.sigmas), B, _C.stream_ptr()),
+                     "dposer_langevin_step")
+        zp = None if nz is None else nz[i, n_steps:n_steps + k_pred].contiguous()
+        slot = traj[(i + 1) // traj_stride - 1] if (traj is not None and (i + 1) % traj_stride == 0) else None
+        _C.check(lib.dposer_em_sampler_steps(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(x_mean),
+                                             C.c_void_p(ts_host.data_ptr()), int(gi), 1, _C.ptr(obs), _C.ptr(msk), _C.ptr(zp), int(seed),
+                                             _C.ptr(slot), 1, _C.ptr(freq), _C.ptr(model.sigmas), B, _C.stream_ptr()),
+                 "dposer_em_sampler_steps")
+    return traj, x, x_mean
+
+
 def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1, probability_flow=False,
                    continuous=False, denoise=True, eps=1e-3, device="cuda"):
     """Predictor-corrector sampler factory (sampling.py:375-468).
@@ -327,6 +393,20 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
                                                    observation=observation if completion else None,
                                                    mask=mask if completion else None, noise=noise, seed=seed,
                                                    traj_stride=traj_stride)
+                model.train(was_training)
+                if trajs is None:
+                    trajs = x.new_empty((0,) + tuple(x.shape))
+                return trajs, (x_mean if denoise else x)
+            if fused_langevin_supported(sde, model, predictor, corrector, probability_flow, continuous):
+                call_count[0] += 1
+                if seed is None:
+                    seed = (model._rng_seed * 7919 + call_count[0]) & 0xFFFFFFFFFFFF
+                was_training = model.training
+                model.eval()
+                trajs, x, x_mean = fused_pc_langevin_sample(model, sde, x, torch.linspace(sde.T, eps, sde.N), snr=snr, n_steps=n_steps,
+                                                            start_step=start_t, observation=observation if completion else None,
+                                                            mask=mask if completion else None, noise=noise, seed=seed,
+                                                            traj_stride=traj_stride)
                 model.train(was_training)
                 if trajs is None:
                     trajs = x.new_empty((0,) + tuple(x.shape))

@@ -484,6 +484,133 @@ hipError_t launch_completion_update(const CompletionUpdateArgs& a, hipStream_t s
     return hipGetLastError();
 }
 
+// ---- Langevin corrector (sampling.py:282-302) ------------------------------------------------------------------------
+//   grad = score(x, t);  noise ~ N(0, I)
+//   step = (snr * mean_b ||noise_b|| / mean_b ||grad_b||)^2 * 2 * alpha          (the means run over the WHOLE batch, :296-298)
+//   x_mean = x + step * grad;   x = x_mean + sqrt(2 step) * noise
+// Two passes around the grid-wide (and, under data parallelism, cross-rank) mean: norms -> [all-reduce of two scalars] -> update.
+// Both recompute score and noise from the same inputs / Philox counters, so nothing but the two sums travels between them.
+struct LangevinDev {
+    LangevinArgs a;
+    SdeDev sde;
+};
+__device__ __forceinline__ float langevin_score(const LangevinDev& d, float res, float usig, float sd) {
+    return -(res / usig) / sd;                                        // model.py:194, utils.py:155,162
+}
+__global__ void __launch_bounds__(256) k_langevin_norms(LangevinDev d) {
+    const LangevinArgs& a = d.a;
+    const int QD = (a.D + 3) >> 2;
+    const float sd = sde_std(d.sde, sde_lmc(d.sde, a.t));
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, 0) : 1.0f;
+    float gsum = 0.f, nsum = 0.f;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.B; s += (int64_t)gridDim.x * blockDim.x) {
+        float g2 = 0.f, n2 = 0.f;
+        for (int q = 0; q < QD; ++q) {
+            float z[4];
+            if (!a.noise) normals4((uint64_t)s * QD + q, STREAM_LANGEVIN, a.step, a.seed, z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = q * 4 + r;
+                if (c >= a.D) continue;
+                const float g = langevin_score(d, a.res[s * a.Cp + c], usig, sd);
+                const float n = a.noise ? a.noise[s * a.D + c] : z[r];
+                g2 += g * g;
+                n2 += n * n;
+            }
+        }
+        gsum += sqrtf(g2);                                            // torch.norm(grad.reshape(B, -1), dim=-1)
+        nsum += sqrtf(n2);
+    }
+    const float gt = block_sum_256(gsum);
+    __syncthreads();
+    const float nt = block_sum_256(nsum);
+    if (threadIdx.x == 0) { a.part[blockIdx.x] = gt; a.part[gridDim.x + blockIdx.x] = nt; }
+}
+hipError_t launch_langevin_norms(const LangevinArgs& a, int* nblocks, hipStream_t st) {
+    LangevinDev d;
+    d.a = a;
+    d.sde = make_sde_dev(a.sde);
+    const int g = grid_for(a.B, 256, 1024);
+    *nblocks = g;
+    hipLaunchKernelGGL(k_langevin_norms, dim3(g), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) k_sum_partials2(const float* part, int n, float* out2) {
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += part[blockIdx.x * n + i];
+    const float tot = block_sum_256(v);
+    if (threadIdx.x == 0) out2[blockIdx.x] = tot;
+}
+hipError_t launch_sum_partials2(const float* part, int n, float* out2, hipStream_t st) {
+    hipLaunchKernelGGL(k_sum_partials2, dim3(2), dim3(256), 0, st, part, n, out2);
+    return hipGetLastError();
+}
+template <typename T> __global__ void __launch_bounds__(256) k_langevin_update(LangevinDev d) {
+    const LangevinArgs& a = d.a;
+    const int qx = a.Dpad >> 2;
+    const int QD = (a.D + 3) >> 2;
+    const float sd = sde_std(d.sde, sde_lmc(d.sde, a.t));
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, 0) : 1.0f;
+    const float grad_norm = a.norm_sums[0] * a.inv_global_batch, noise_norm = a.norm_sums[1] * a.inv_global_batch;   // .mean()
+    const float r0 = a.snr * noise_norm / grad_norm;
+    const float step = ((r0 * r0) * 2.0f) * a.alpha;                  // sampling.py:298
+    const float nscale = sqrtf(step * 2.0f);                          // :300
+    const int64_t total = a.Bpad * qx;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / qx;
+        const int q = (int)(i % qx);
+        const int c = q * 4;
+        f32x4 xn = {0.f, 0.f, 0.f, 0.f};
+        if (s < a.B && c < a.D) {
+            float z[4];
+            if (!a.noise) normals4((uint64_t)s * QD + q, STREAM_LANGEVIN, a.step, a.seed, z);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (c + r >= a.D) continue;
+                const int64_t o = s * a.D + c + r;
+                const float g = langevin_score(d, a.res[s * a.Cp + c + r], usig, sd);
+                const float n = a.noise ? a.noise[o] : z[r];
+                const float xm = a.x[o] + step * g;                   // :299
+                const float x = xm + nscale * n;                      // :300
+                a.x_mean[o] = xm;
+                a.x[o] = x;
+                xn[r] = x;
+            }
+        }
+        if (a.xin) store_quad_ft<T>(a.xin, s, c, a.Dpad, xn);
+    }
+}
+hipError_t launch_langevin_update(const LangevinArgs& a, hipStream_t st) {
+    LangevinDev d;
+    d.a = a;
+    d.sde = make_sde_dev(a.sde);
+    const int64_t total = a.Bpad * (a.Dpad >> 2);
+    if (a.f32) hipLaunchKernelGGL(k_langevin_update<float>, dim3(grid_for(total)), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(k_langevin_update<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, d);
+    return hipGetLastError();
+}
+// row-major [B][D] fp32 -> FT [Bpad][Dpad] network input (zero padded)
+template <typename T> __global__ void __launch_bounds__(256) k_pack_rows(const float* x, void* xin, int64_t B, int64_t Bpad, int D, int Dpad) {
+    const int qx = Dpad >> 2;
+    const int64_t total = Bpad * qx;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / qx;
+        const int c = (int)(i % qx) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (s < B)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c + r < D) v[r] = x[s * D + c + r];
+        store_quad_ft<T>(xin, s, c, Dpad, v);
+    }
+}
+hipError_t launch_pack_rows(const float* x, void* xin, int64_t B, int64_t Bpad, int D, int Dpad, int f32, hipStream_t st) {
+    const int64_t total = Bpad * (Dpad >> 2);
+    if (f32) hipLaunchKernelGGL(k_pack_rows<float>, dim3(grid_for(total)), dim3(256), 0, st, x, xin, B, Bpad, D, Dpad);
+    else hipLaunchKernelGGL(k_pack_rows<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, x, xin, B, Bpad, D, Dpad);
+    return hipGetLastError();
+}
+
 struct DsmDev {
     DsmArgs a;
     SdeDev sde;

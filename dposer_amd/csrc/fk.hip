@@ -166,7 +166,7 @@ extern "C" int dposer_rot6d_to_rotmat(const float* rot6d, float* rotmat, int64_t
 // registers (one 4*L-byte contiguous read, L2-resident across the pose chunks) and walks a chunk of poses; the shape
 // coefficients are wave-uniform, i.e. scalar loads.  The joint part (J*3 coordinates) runs as extra tiles of the same grid
 // on the pre-regressed directions.
-constexpr int SB_MAX_L = 32;     // betas + expression coefficients (smplx: 10 + 10; the reference's hack for SMPL-H: 16)
+constexpr int SB_L = 32;         // shape coefficients per register pass (smplx: 10 + 10 = one pass; full spaces of 300 + 100 loop)
 constexpr int SB_POSES = 8;      // poses per block
 __global__ void __launch_bounds__(256) k_shape_blend(const float* __restrict__ vt, const float* __restrict__ sd, const float* __restrict__ jt,
                                                       const float* __restrict__ jd, const float* __restrict__ shape, float* __restrict__ vs,
@@ -178,45 +178,56 @@ __global__ void __launch_bounds__(256) k_shape_blend(const float* __restrict__ v
     const float* dir = (joints ? jd : sd) + (int64_t)i * L;
     const float base = (joints ? jt : vt)[i];
     float* out = joints ? jr : vs;
-    float c[SB_MAX_L];
-#pragma unroll
-    for (int l = 0; l < SB_MAX_L; ++l) c[l] = l < L ? dir[l] : 0.f;
     const int64_t b0 = (int64_t)blockIdx.y * SB_POSES;
-    for (int k = 0; k < SB_POSES && b0 + k < B; ++k) {
-        const float* sh = shape + (b0 + k) * L;
-        float acc = 0.f;                         // sum_l shape[l] * dir[l] in index order (torch.einsum's reduction order is
-#pragma unroll                                   // not part of any contract; fp32 agreement is ~1e-7)
-        for (int l = 0; l < SB_MAX_L; ++l)
-            if (l < L) acc += sh[l] * c[l];
-        out[(b0 + k) * n + i] = base + acc;
+    float acc[SB_POSES];
+#pragma unroll
+    for (int k = 0; k < SB_POSES; ++k) acc[k] = 0.f;
+    for (int l0 = 0; l0 < L; l0 += SB_L) {
+        float c[SB_L];
+#pragma unroll
+        for (int l = 0; l < SB_L; ++l) c[l] = l0 + l < L ? dir[l0 + l] : 0.f;
+#pragma unroll
+        for (int k = 0; k < SB_POSES; ++k) {
+            if (b0 + k >= B) break;
+            const float* sh = shape + (b0 + k) * L + l0;       // sum_l shape[l] * dir[l] in index order (torch.einsum's reduction
+#pragma unroll                                                 // order is not part of any contract; fp32 agreement is ~1e-7)
+            for (int l = 0; l < SB_L; ++l)
+                if (l0 + l < L) acc[k] += sh[l] * c[l];
+        }
     }
+#pragma unroll
+    for (int k = 0; k < SB_POSES; ++k)
+        if (b0 + k < B) out[(b0 + k) * n + i] = base + acc[k];
 }
-// d_shape[b][l] = sum_i dv[b][i] * sd[i][l]: stage 1 = per (pose, coordinate chunk) partial sums (fixed order => deterministic)
+// d_shape[b][l] = sum_i dv[b][i] * sd[i][l]: stage 1 = per (pose, coordinate chunk, block of 32 coefficients) partial sums (fixed
+// order => deterministic)
 constexpr int SBB_CHUNK = 4096;
 __global__ void __launch_bounds__(256) k_shape_blend_bwd_part(const float* __restrict__ sd, const float* __restrict__ dv, float* __restrict__ part,
                                                                int V3, int L, int n_chunks) {
-    __shared__ float red[4][SB_MAX_L];
+    __shared__ float red[4][SB_L];
     const int64_t b = blockIdx.y;
     const int i0 = blockIdx.x * SBB_CHUNK;
-    float acc[SB_MAX_L];
+    const int l0 = blockIdx.z * SB_L;
+    float acc[SB_L];
 #pragma unroll
-    for (int l = 0; l < SB_MAX_L; ++l) acc[l] = 0.f;
+    for (int l = 0; l < SB_L; ++l) acc[l] = 0.f;
     for (int i = i0 + threadIdx.x; i < i0 + SBB_CHUNK && i < V3; i += 256) {
         const float g = dv[b * V3 + i];
-        const float* d = sd + (int64_t)i * L;
+        const float* d = sd + (int64_t)i * L + l0;
 #pragma unroll
-        for (int l = 0; l < SB_MAX_L; ++l)
-            if (l < L) acc[l] += g * d[l];
+        for (int l = 0; l < SB_L; ++l)
+            if (l0 + l < L) acc[l] += g * d[l];
     }
 #pragma unroll
-    for (int l = 0; l < SB_MAX_L; ++l) {
+    for (int l = 0; l < SB_L; ++l) {
         float v = acc[l];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][l] = v;
     }
     __syncthreads();
-    if (threadIdx.x < L) part[(b * n_chunks + blockIdx.x) * L + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < SB_L && l0 + threadIdx.x < L)
+        part[(b * n_chunks + blockIdx.x) * L + l0 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 // stage 2: chunks in order, then the joint term
 __global__ void k_shape_blend_bwd_final(const float* __restrict__ part, const float* __restrict__ jd, const float* __restrict__ dj, float* __restrict__ d_shape,
@@ -235,7 +246,7 @@ extern "C" int dposer_shape_blend_forward(const float* v_template, const float* 
                                           const float* shape, float* v_shaped, float* j_rest, int32_t num_vertices, int32_t num_joints,
                                           int32_t num_shape, int64_t batch, void* stream) {
     DP_CHECK_ARG(v_template && shapedirs && j_template && jdirs && shape && v_shaped && j_rest, "null argument");
-    DP_CHECK_ARG(num_shape >= 1 && num_shape <= SB_MAX_L, "num_shape must be in 1..32");
+    DP_CHECK_ARG(num_shape >= 1 && num_shape <= 1024, "num_shape must be in 1..1024");
     DP_CHECK_ARG(num_vertices > 0 && num_joints > 0 && batch >= 0, "bad size");
     if (batch == 0) return DPOSER_OK;
     const int V3 = num_vertices * 3, J3 = num_joints * 3;
@@ -253,12 +264,12 @@ extern "C" int dposer_shape_blend_backward(const float* shapedirs, const float* 
                                            float* d_shape, float* scratch, int32_t num_vertices, int32_t num_joints, int32_t num_shape,
                                            int64_t batch, void* stream) {
     DP_CHECK_ARG(shapedirs && jdirs && d_v_shaped && d_shape && scratch, "null argument");
-    DP_CHECK_ARG(num_shape >= 1 && num_shape <= SB_MAX_L, "num_shape must be in 1..32");
+    DP_CHECK_ARG(num_shape >= 1 && num_shape <= 1024, "num_shape must be in 1..1024");
     if (batch == 0) return DPOSER_OK;
     DP_CHECK_ARG(batch <= 65535, "batch too large for one launch");
     const int V3 = num_vertices * 3, J3 = num_joints * 3;
     const int n_chunks = (int)ceil_div(V3, SBB_CHUNK);
-    hipLaunchKernelGGL(k_shape_blend_bwd_part, dim3(n_chunks, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, shapedirs, d_v_shaped, scratch, V3,
+    hipLaunchKernelGGL(k_shape_blend_bwd_part, dim3(n_chunks, (unsigned)batch, (unsigned)ceil_div(num_shape, SB_L)), dim3(256), 0, (hipStream_t)stream, shapedirs, d_v_shaped, scratch, V3,
                        num_shape, n_chunks);
     FK_HIP_LAUNCH(hipGetLastError());
     hipLaunchKernelGGL(k_shape_blend_bwd_final, dim3((unsigned)ceil_div(batch * num_shape, 128)), dim3(128), 0, (hipStream_t)stream, scratch, jdirs,

@@ -154,6 +154,27 @@ struct CompletionUpdateArgs {   // one optimisation step of DPoserComp.optimize 
 };
 hipError_t launch_completion_update(const CompletionUpdateArgs& a, hipStream_t st);
 
+struct LangevinArgs {           // LangevinCorrector.update_fn (sampling.py:282-302) around one network evaluation at a shared t
+    const float* res;      // [Bpad][Cp] model output at x
+    const float* noise;    // injected noise [B][D] or null (-> Philox STREAM_LANGEVIN)
+    const float* sigmas;
+    float* x;              // [B][D] state (update phase: in/out)
+    float* x_mean;         // [B][D] out (update phase)
+    void* xin;             // FT [Bpad][Dpad]: the updated state packed as the next network input (update phase) or null
+    float* part;           // norms phase: per-block partial sums, [2][nblocks]
+    const float* norm_sums;// update phase: [2] = sum_b ||grad_b||, sum_b ||noise_b|| over the GLOBAL batch
+    float t, alpha, snr, inv_global_batch;
+    int64_t B, Bpad;
+    int D, Dpad, Cp, num_scales, scale_by_sigma, f32;
+    SdeCfg sde;
+    uint64_t seed;
+    uint32_t step;
+};
+hipError_t launch_langevin_norms(const LangevinArgs& a, int* nblocks, hipStream_t st);
+hipError_t launch_sum_partials2(const float* part, int n, float* out2, hipStream_t st);   // out2[k] = sum part[k*n .. k*n+n)
+hipError_t launch_langevin_update(const LangevinArgs& a, hipStream_t st);
+hipError_t launch_pack_rows(const float* x, void* xin, int64_t B, int64_t Bpad, int D, int Dpad, int f32, hipStream_t st);
+
 struct DsmArgs {           // get_sde_loss_fn tail (losses.py:121-131) + d loss / d res
     const float* res;      // [Bpad][Cp]
     const float* t;        // [Bpad]

@@ -562,10 +562,29 @@ static SdeCfg to_sde(const dposer_sde_desc* s) {
     return c;
 }
 
+static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde, float* x,
+                           float* x_mean, const float* timesteps_host, int32_t start_step, int32_t n_steps, const float* observation,
+                           const float* mask, const float* noise, uint64_t seed, float* traj, int32_t traj_stride, const float* freq,
+                           const float* sigmas, int64_t B, void* stream);
 extern "C" int dposer_em_sampler(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
                                  float* x, float* x_mean, const float* timesteps_host, int32_t start_step, const float* observation,
                                  const float* mask, const float* noise, uint64_t seed, float* traj, int32_t traj_stride,
                                  const float* freq, const float* sigmas, int64_t B, void* stream) {
+    return em_sampler_impl(h, flat, packed_, ws_, sde, x, x_mean, timesteps_host, start_step, -1, observation, mask, noise, seed, traj,
+                           traj_stride, freq, sigmas, B, stream);
+}
+extern "C" int dposer_em_sampler_steps(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                       float* x, float* x_mean, const float* timesteps_host, int32_t start_step, int32_t n_steps,
+                                       const float* observation, const float* mask, const float* noise, uint64_t seed, float* traj,
+                                       int32_t traj_stride, const float* freq, const float* sigmas, int64_t B, void* stream) {
+    DP_CHECK_ARG(n_steps >= 0, "n_steps must be >= 0");
+    return em_sampler_impl(h, flat, packed_, ws_, sde, x, x_mean, timesteps_host, start_step, n_steps, observation, mask, noise, seed, traj,
+                           traj_stride, freq, sigmas, B, stream);
+}
+static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde, float* x,
+                           float* x_mean, const float* timesteps_host, int32_t start_step, int32_t n_steps, const float* observation,
+                           const float* mask, const float* noise, uint64_t seed, float* traj, int32_t traj_stride, const float* freq,
+                           const float* sigmas, int64_t B, void* stream) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x && x_mean && timesteps_host && freq && sigmas, "null argument");
@@ -577,7 +596,7 @@ extern "C" int dposer_em_sampler(dposer_scorefc_t h, const float* flat, const vo
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
     const int N = sde->N;
-    const int n_run = N - start_step;
+    const int n_run = (n_steps < 0 || n_steps > N - start_step) ? N - start_step : n_steps;   // (a range ends without look-ahead imputation)
     if (n_run == 0) return DPOSER_OK;
     Ws w;
     layout_ws(h, B, DPOSER_WS_SHARED_T, n_run, (char*)ws_, w);
@@ -637,6 +656,45 @@ extern "C" int dposer_em_sampler(dposer_scorefc_t h, const float* flat, const vo
         ea.z_impA = (nz && observation && i + 1 < n_run) ? nz + (int64_t)k_noise * BD : nullptr;
         ea.traj = (traj && ((i + 1) % traj_stride == 0)) ? traj + (int64_t)((i + 1) / traj_stride - 1) * BD : nullptr;
         DP_HIP_LAUNCH(launch_em_update(ea, st));
+    }
+    return DPOSER_OK;
+}
+
+// LangevinCorrector.update_fn (sampling.py:282-302), one corrector step at a shared t, in two phases around the batch means:
+//   phase 0: pack x, evaluate the network, write sum_b ||grad_b|| and sum_b ||noise_b|| of THIS rank's samples to norm_sums[0..1]
+//   (the caller all-reduces the two floats over the data-parallel ranks -- or not, on one GPU)
+//   phase 1: x_mean = x + step * grad, x = x_mean + sqrt(2 step) * noise with step from norm_sums * inv_global_batch.
+// The workspace keeps the network output between the two phases: nothing else may run on it in between.
+extern "C" int dposer_langevin_step(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                    float* x, float* x_mean, float t, float alpha, float snr, const float* noise, uint64_t seed,
+                                    uint32_t step, float* norm_sums, int32_t phase, double inv_global_batch, const float* freq,
+                                    const float* sigmas, int64_t B, void* stream) {
+    DP_TRY(check_common(h, flat, packed_, ws_, B));
+    g_alg_batch = B;
+    DP_CHECK_ARG(sde && x && norm_sums && freq && sigmas, "null argument");
+    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused Langevin step supports subVP / VP SDEs");
+    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused Langevin step supports the positional embedding");
+    DP_CHECK_ARG(phase == 0 || phase == 1, "phase must be 0 (norms) or 1 (update)");
+    DP_CHECK_ARG(phase == 0 || x_mean, "x_mean is required in the update phase");
+    hipStream_t st = (hipStream_t)stream;
+    const char* packed = (const char*)packed_;
+    Ws w;
+    layout_ws(h, B, DPOSER_WS_SHARED_T, 1, (char*)ws_, w);
+    LangevinArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.res = w.res; a.noise = noise; a.sigmas = sigmas; a.x = x; a.x_mean = x_mean; a.part = w.loss_part; a.norm_sums = norm_sums;
+    a.t = t; a.alpha = alpha; a.snr = snr; a.inv_global_batch = (float)inv_global_batch; a.B = B; a.Bpad = w.Bpad; a.D = h->D; a.Dpad = h->Dpad;
+    a.Cp = h->Cp; a.num_scales = h->d.num_scales; a.scale_by_sigma = h->d.scale_by_sigma; a.f32 = h->f32; a.sde = to_sde(sde); a.seed = seed;
+    a.step = step;
+    if (phase == 0) {
+        DP_TRY(build_time_table(h, flat, packed, w, nullptr, t * 999.0f, 1, freq, st));
+        DP_HIP_LAUNCH(launch_pack_rows(x, w.xin, B, w.Bpad, h->D, h->Dpad, h->f32, st));
+        DP_TRY(run_shared_t(h, flat, packed, w, 0, B, st));
+        int nb = 0;
+        DP_HIP_LAUNCH(launch_langevin_norms(a, &nb, st));
+        DP_HIP_LAUNCH(launch_sum_partials2(w.loss_part, nb, norm_sums, st));
+    } else {
+        DP_HIP_LAUNCH(launch_langevin_update(a, st));
     }
     return DPOSER_OK;
 }

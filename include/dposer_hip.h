@@ -170,6 +170,25 @@ int dposer_adam_ema_clip_step(float* flat_params, const float* flat_grad, float*
                               double lr, double beta1, double beta2, double eps, double grad_clip, double grad_scale,
                               int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream);
 
+/* dposer_em_sampler restricted to the steps [start_step, start_step + n_steps) (no look-ahead imputation after the last one):
+ * what a predictor-corrector loop with a corrector between the predictor calls drives (sampling.py:455-461). */
+int dposer_em_sampler_steps(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws, const dposer_sde_desc* sde,
+                            float* x, float* x_mean, const float* timesteps_host, int32_t start_step, int32_t n_steps,
+                            const float* observation, const float* mask, const float* noise, uint64_t seed, float* traj,
+                            int32_t traj_stride, const float* freq, const float* sigmas, int64_t batch, void* stream);
+
+/* LangevinCorrector.update_fn -- sampling.py:282-302, one corrector step at a shared t (alpha = sde.alphas[timestep] for VP,
+ * 1 for sub-VP, :290-294), in two phases around the batch means of :296-297:
+ *   phase 0: evaluates the network at x and writes norm_sums[0] = sum_b ||grad_b||, norm_sums[1] = sum_b ||noise_b|| over this
+ *            call's `batch` samples (DEVICE float[2]); under data parallelism the caller all-reduces (SUM) the two floats;
+ *   phase 1: x_mean = x + step * grad, x = x_mean + sqrt(2 step) * noise, step = (snr * mean||noise|| / mean||grad||)^2 * 2 * alpha
+ *            with mean = norm_sums * inv_global_batch.  Same ws for both phases, nothing else on it in between.
+ * noise [B, D] injected or NULL -> Philox(seed, step) (the two phases regenerate the same numbers). */
+int dposer_langevin_step(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws, const dposer_sde_desc* sde,
+                         float* x, float* x_mean, float t, float alpha, float snr, const float* noise, uint64_t seed, uint32_t step,
+                         float* norm_sums, int32_t phase, double inv_global_batch, const float* freq, const float* sigmas,
+                         int64_t batch, void* stream);
+
 /* DPoserComp.optimize -- run/completion.py:167-207 (loss :131-149, weights :151-155): `n_steps` Adam steps on the pose batch
  * x [B, D] (in: the initial value, i.e. the observation; out: the optimised variable -- the caller applies the final
  * observation/mask blend of :205) under  w_prior[i] * mean(w (x - x0_hat)^2) + w_data[i] * MSE(x * mask, obs * mask).

@@ -34,4 +34,4 @@ def t2n(t):
 
 # parity tolerances (relative L2 unless noted)
 TOL_FP32 = 2e-5      # fp32 MFMA path vs fp32 CPU oracle/reference: summation order + libm ulps
-TOL_BF16 = 3e-2      # bf16 MFMA path: 8-bit mantissa on weights and on every inter-layer activation
+TOL_BF16 = 1e-2      # bf16 MFMA path: 8-bit mantissa on weights and on every inter-layer activation (measured 4.4e-3 / 5.0e-3)

@@ -139,3 +139,53 @@ def test_ranks_draw_different_noise():
         assert p.exitcode == 0
     assert np.isfinite(res[0]) and np.isfinite(res[1])
     assert abs(res[0] - res[1]) > 1e-3 * abs(res[0])
+
+
+def _langevin_run(z0, noise, world, rank):
+    from gpu_common import make_model
+    from dposer_amd.algorithms.advanced import sampling, sde_lib
+    from dposer_amd import distributed as ddp
+    cfg, m, p = make_model(7, precision="fp32")
+    cfg.sampling.corrector = "langevin"
+    lo, hi = ddp.shard_bounds(z0.shape[0], world, rank)
+    sde = sde_lib.subVPSDE(0.1, 20.0, 6)
+    fn = sampling.get_sampling_fn(cfg, sde, (hi - lo, 63), lambda v: v, 1e-3, device="cuda:0")
+    _, x = fn(m, z=z0[lo:hi].cuda(), noise=noise[:, :, lo:hi].cuda())
+    torch.cuda.synchronize()
+    return x.cpu()
+
+
+def _worker_langevin(rank, world, port, q, z0, noise):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      DPOSER_DIST_BACKEND="gloo")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from dposer_amd import distributed as ddp
+    import torch.distributed as dist
+    ddp.init_from_env()
+    torch.cuda.set_device(0)
+    q.put((rank, _langevin_run(z0, noise, world, rank).numpy()))
+    ddp.barrier()
+    dist.destroy_process_group()
+
+
+def test_langevin_step_size_uses_global_batch_means_under_data_parallelism():
+    """sampling.py:296-298 takes the norm means over the WHOLE batch: two ranks with (ragged) shards must reproduce the
+    single-process samples -- the two norm sums are all-reduced inside every corrector step."""
+    rs = np.random.RandomState(13)
+    B, N = 45, 6                                                     # 23 + 22 samples
+    z0 = torch.tensor(rs.standard_normal((B, 63)).astype(np.float32))
+    noise = torch.tensor(rs.standard_normal((N, 2, B, 63)).astype(np.float32))
+    ref = _langevin_run(z0, noise, 1, 0).numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_langevin, args=(r, 2, port, q, z0, noise)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = np.concatenate([res[0], res[1]], axis=0)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5

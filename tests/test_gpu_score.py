@@ -91,7 +91,7 @@ class _Args:
         self.task = task
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("bf16", 1e-2)])      # bf16 measured 4.0e-3
 def test_em_sampler_matches_reference_golden(prec, tol):
     g = load("g5_sampler")
     cfg, m, p = make_model(int(g["seed"]), precision=prec)
@@ -127,18 +127,60 @@ def test_em_sampler_completion_golden():
     assert np.abs(t2n(trajs)[-1] * mask - g["comp8_trajs"][-1] * mask).max() < 1e-3
 
 
-def test_langevin_generic_path_golden():
-    """Langevin corrector + EM predictor run the generic python loop on the HIP score function; the torch RNG
-    draws are replaced by the golden's recorded noise."""
-    from unittest import mock
+def test_langevin_corrector_fused_path_matches_reference_golden():
+    """Langevin corrector + EM predictor (sampling.py:282-302, 182-188) on the HIP path -- dposer_langevin_step (two phases around
+    the batch-mean norms) + dposer_em_sampler_steps -- fed the golden's recorded draws in the reference's order."""
     g = load("g5_sampler")
     cfg, m, p = make_model(int(g["seed"]), precision="fp32")
     sde, fn = _sampler(m, cfg, 1000, 16, corrector="langevin")
+    noise = _dev(g["lang4_noise"]).reshape(4, 2, 16, 63)             # per step: corrector draw, predictor draw
+    trajs, x = fn(m, z=_dev(g["lang4_z0"]), start_step=996, args=_Args("denoise"), noise=noise)
+    assert rel_err(t2n(trajs), g["lang4_trajs"]) < 2e-5              # measured ~1e-6
+    assert rel_err(t2n(x), g["lang4_final"]) < 2e-5
+
+
+def test_langevin_generic_class_matches_reference_golden():
+    """The generic LangevinCorrector / EulerMaruyamaPredictor classes (any score function) on the HIP score function; the torch
+    RNG draws are replaced by the golden's recorded noise."""
+    from unittest import mock
+    from dposer_amd.algorithms.advanced import sampling
+    g = load("g5_sampler")
+    cfg, m, p = make_model(int(g["seed"]), precision="fp32")
+    sde, _ = _sampler(m, cfg, 1000, 16, corrector="langevin")
     noise = iter(_dev(g["lang4_noise"]))
-    with mock.patch.object(torch, "randn_like", lambda x, **k: next(noise)):
-        trajs, x = fn(m, z=_dev(g["lang4_z0"]), start_step=996, args=_Args("denoise"))
-    assert rel_err(t2n(trajs), g["lang4_trajs"]) < 2e-4
-    assert rel_err(t2n(x), g["lang4_final"]) < 2e-4
+    x = _dev(g["lang4_z0"])
+    ts = torch.linspace(sde.T, 1e-3, sde.N, device=DEV)
+    trajs = []
+    with torch.no_grad(), mock.patch.object(torch, "randn_like", lambda x, **k: next(noise)):
+        for i in range(996, 1000):
+            vec_t = torch.ones(16, device=DEV) * ts[i]
+            x, _ = sampling.shared_corrector_update_fn(x, vec_t, None, None, sde, m, sampling.LangevinCorrector, True, cfg.sampling.snr, 1)
+            x, xm = sampling.shared_predictor_update_fn(x, vec_t, None, None, sde, m, sampling.EulerMaruyamaPredictor, False, True)
+            trajs.append(x)
+    assert rel_err(t2n(torch.stack(trajs)), g["lang4_trajs"]) < 2e-4
+    assert rel_err(t2n(xm), g["lang4_final"]) < 2e-4
+
+
+def test_langevin_fused_inkernel_noise_vs_oracle():
+    """No injected draws: corrector and predictor noise from Philox (two phases of a Langevin step regenerate the same numbers);
+    the oracle gets them from oracle/philox.py."""
+    cfg, m, p = make_model(23, precision="fp32")
+    N, B, seed = 5, 48, 99
+    sde, fn = _sampler(m, cfg, N, B, corrector="langevin")
+    rs = np.random.RandomState(6)
+    z0 = rs.standard_normal((B, 63)).astype(np.float32)
+    trajs, x = fn(m, z=_dev(z0), seed=seed)
+    xo = torch.tensor(z0)
+    so = R.SubVP(N=N)
+    ts = torch.linspace(1.0, 1e-3, N)
+    for i in range(N):
+        t = torch.ones(B) * ts[i]
+        zc = torch.tensor(PH.normal_matrix(B, 63, PH.STREAM_LANGEVIN, i, seed))
+        xo, _ = R.langevin_step(p, so, xo, t, zc, snr=cfg.sampling.snr)
+        zp = torch.tensor(PH.normal_matrix(B, 63, PH.STREAM_EM_NOISE, i, seed))
+        xo, xm = R.em_step(p, so, xo, t, zp)
+        assert rel_err(t2n(trajs[i]), xo.numpy()) < 1e-4, i
+    assert rel_err(t2n(x), xm.numpy()) < 1e-4
 
 
 def test_em_sampler_1000_steps_golden():
@@ -172,7 +214,7 @@ def test_em_sampler_inkernel_philox_matches_oracle():
     assert not torch.equal(trajs, trajs3)
 
 
-@pytest.mark.parametrize("B,prec,tol", [(40, "fp32", 1e-4), (300, "fp32", 1e-4), (1000, "bf16", 6e-2)])
+@pytest.mark.parametrize("B,prec,tol", [(40, "fp32", 1e-4), (300, "fp32", 1e-4), (1000, "bf16", 1e-2)])      # bf16 measured 4.4e-3
 def test_em_sampler_fused_step_path_matches_oracle(B, prec, tol):
     """traj_stride = 0 (no trajectory), no observation, in-kernel noise: post_dense and the Euler-Maruyama update run as one
     GEMM launch per step on an FT-resident state.  Must agree with the oracle fed the same Philox draws, return x_mean of the
@@ -205,7 +247,7 @@ def test_inkernel_noise_statistics():
 # ------------------------------------------------------------------------------------------------
 # DPoser prior loss
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 2e-3)])      # bf16 measured 3.4e-4 (gradient)
 def test_prior_loss_matches_reference_golden(prec, tol):
     from dposer_amd.algorithms.advanced import sde_lib
     from dposer_amd.prior import prior_loss
@@ -233,7 +275,7 @@ def _fused_grad(m, batch, t, z, step=0):
     return float(loss), fg
 
 
-@pytest.mark.parametrize("prec,tol_loss,tol_grad", [("fp32", 2e-5, 2e-4), ("bf16", 2e-2, 6e-2)])
+@pytest.mark.parametrize("prec,tol_loss,tol_grad", [("fp32", 2e-5, 2e-4), ("bf16", 5e-3, 5e-3)])      # bf16 gradients measured 1.9e-3
 def test_dsm_loss_and_grads_match_reference_golden(prec, tol_loss, tol_grad):
     g = load("g3_loss_grads")
     cfg, m, p = make_model(int(g["seed"]), precision=prec, dropout=0.0)
