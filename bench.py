@@ -59,44 +59,90 @@ def synthetic_poses(n, device, seed=42):
     return ((poses[idx] - mean) / std).to(device), poses[idx].to(device)
 
 
-def cpu_baseline(budget_s=12.0):
-    """Reference-path CPU port (oracle) timed on the host cores: train step at the reference's default batch 1280."""
-    from oracle import score_ref as R
-    from dposer_amd.algorithms.advanced.model import ScoreModelFC
-    from dposer_amd.configs import load_config
+def _host():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = min(cores, 32)          # torch-CPU GEMMs at B=1280 thrash on a 256-thread host (measured: 81 s/step at 256 threads)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return cores, model
+
+
+def cpu_baseline(budget_s=10.0):
+    """Reference-path CPU port (the oracle: torch-CPU restatement pinned to the reference's goldens) timed on this box's host cores,
+    SURVEY 8d: the train step at B = 8192 (primary object) and, as ``legs``, the train step at the reference's default batch
+    1280, the 1000-step sampler at B = 500 and SMPL-X LBS at B = 8192 -- each on a bounded sample (~10 s) of the workload."""
+    from oracle import fk_ref
+    from oracle import score_ref as R
+    from dposer_amd.algorithms.advanced.model import ScoreModelFC
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    from dposer_amd.configs import load_config
+    avail, cpu_model = _host()
+    cores = min(avail, 32)          # torch-CPU GEMMs at these sizes thrash on a 256-thread host (measured: 81 s/step at 256 threads)
     torch.set_num_threads(cores)
     cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
     torch.manual_seed(42)
     m = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=1024, embed_dim=512, n_blocks=2)
     p = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    st = R.TrainState(p, R.param_names())
-    B = 1280
-    batch, _ = synthetic_poses(B, "cpu")
+    p["sigmas"] = R.sigma_table()
     gen = torch.Generator().manual_seed(0)
 
-    def one():
-        t = torch.rand(B, generator=gen) * (1 - 1e-5) + 1e-5
-        z = torch.randn(B, 63, generator=gen)
-        masks = [(torch.rand(B, 1024, generator=gen) >= 0.1).float() for _ in range(5)]
-        R.train_step(st, R.SubVP(), batch, t, z, drop_masks=masks, drop_p=0.1)
+    def timed(fn, budget):
+        t0 = time.perf_counter()
+        fn()                                                # warm-up (also sizes the sample)
+        warm = time.perf_counter() - t0
+        n_target = max(1, min(30, int(budget / max(warm, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(n_target):
+            fn()
+        return n_target, time.perf_counter() - t0
 
-    t0 = time.perf_counter()
-    one()                                                   # warm-up (also sizes the sample)
-    warm = time.perf_counter() - t0
-    n_target = max(1, min(30, int(budget_s / max(warm, 1e-3))))
-    n, t0 = 0, time.perf_counter()
-    for _ in range(n_target):
-        one()
-        n += 1
-    el = time.perf_counter() - t0
-    return {"value": B * n / el, "unit": "poses/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps at B={B} (reference default batch), torch-CPU oracle, {torch.get_num_threads()} threads "
-                      f"(host reports {os.cpu_count()} CPUs)"}
+    def train_leg(B, budget):
+        st = R.TrainState({k: v.clone() for k, v in p.items()}, R.param_names())
+        batch, _ = synthetic_poses(B, "cpu")
+
+        def one():
+            t = torch.rand(B, generator=gen) * (1 - 1e-5) + 1e-5
+            z = torch.randn(B, 63, generator=gen)
+            masks = [(torch.rand(B, 1024, generator=gen) >= 0.1).float() for _ in range(5)]
+            R.train_step(st, R.SubVP(), batch, t, z, drop_masks=masks, drop_p=0.1)
+
+        n, el = timed(one, budget)
+        return {"value": B * n / el, "unit": "poses/s", "sample": f"{n} train steps at B={B}"}
+
+    legs = {"train_b1280": train_leg(1280, budget_s * 0.6)}
+    # sampler: B = 500, N = 1000 -- a bounded run of consecutive reverse steps, scaled to the 1000 of the metric
+    x = torch.randn(500, 63, generator=gen)
+    sde = R.SubVP(N=1000)
+    ts = torch.linspace(1.0, 1e-3, 1000)
+    state = {"x": x, "i": 0}
+
+    def em():
+        with torch.no_grad():
+            i = state["i"] % 1000
+            state["x"], _ = R.em_step(p, sde, state["x"], torch.ones(500) * ts[i], torch.randn(500, 63, generator=gen))
+            state["i"] += 1
+
+    n, el = timed(em, budget_s * 0.6)
+    legs["sampler_b500_n1000"] = {"value": 500 / (el / n * 1000), "unit": "samples/s",
+                                  "sample": f"{n} consecutive Euler-Maruyama steps at B=500, scaled to N=1000 steps per sample"}
+    # SMPL-X LBS (vertices + 127 joints), numpy fp32 restatement of smplx lbs, on a slice of the B = 8192 workload
+    asset = make_synthetic_smplx_asset(seed=0)
+    _, raw = synthetic_poses(8192, "cpu")
+    nb = 256
+    n, el = timed(lambda: fk_ref.smplx_forward(asset, raw[:nb].numpy(), dtype=np.float32), budget_s * 0.4)
+    legs["lbs_full_b8192"] = {"value": nb * n / el, "unit": "poses/s", "sample": f"{n} x {nb} poses of the B=8192 batch (numpy fp32 LBS, 10475 vertices)"}
+    main_leg = train_leg(8192, budget_s)
+    return {"value": main_leg["value"], "unit": "poses/s", "cores": cores, "kind": "port",
+            "sample": f"{main_leg['sample']} (BASELINE config 2 batch), torch-CPU oracle, {torch.get_num_threads()} threads",
+            "cpu_model": cpu_model, "host_cpus": os.cpu_count(), "legs": legs}
 
 
 def main():
@@ -190,10 +236,36 @@ def main():
         name, (ms, cnt, fl) = max(prof.items(), key=lambda kv: kv[1][0])                     # timed region, dominant kind
         ach = (fl / (ms * 1e-3)) / 1e12
         roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(name), "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3,
+                    "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(name),
+                    "traffic_source": "lookup: profiles/pmc_hbm_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "command, tools/profile_bench.sh); NOT measured in this run", "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3,
                     "flops_per_launch": fl / cnt, "gemm_time_share_of_step": tot_ms / 3 / ms_per_step}
 
     extra = {"train_loss_last_step": loss, "train_tflops_algorithmic": 42.59e6 * value / 1e12, "gemm_kernels": kernels}
+    if not args.no_extra and args.precision != "fp32":
+        # the same step in fp32 parity mode (exact-fp32 MFMA, 1/16 of the bf16 matrix rate): the mode the tight parity numbers
+        # of the test suite come from, next to the bf16 headline
+        model.precision = "fp32"
+        for _ in range(2):
+            step_fn(state, batch)
+        ddp.barrier()
+        torch.cuda.synchronize()
+        t32 = time.perf_counter()
+        n32 = 5
+        for _ in range(n32):
+            step_fn(state, batch)
+        torch.cuda.synchronize()
+        ddp.barrier()
+        e32 = time.perf_counter() - t32
+        if world > 1:
+            tt = torch.tensor([e32], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            e32 = float(tt[0])
+        extra["train_step_fp32_mode"] = {"poses_per_s": args.global_batch * n32 / e32, "ms_per_step": e32 / n32 * 1e3, "steps": n32,
+                                         "tflops_algorithmic": 42.59e6 * args.global_batch * n32 / e32 / 1e12, "fp32_mfma_peak_tflops": 157.3}
+        model.precision = args.precision
+        model._engines.pop("fp32", None)                    # release the fp32 engine's packed weights / workspaces
+        torch.cuda.empty_cache()
     if not args.no_extra:
         # ---- M2: 1000-step Euler-Maruyama sampling of the local shard, no trajectory kept ----
         model.eval()
@@ -226,8 +298,13 @@ def main():
                             "tflops_algorithmic": 8.647e6 * args.sampler_steps * sps / 1e12}
         if sprof:
             name, (ms, cnt, fl) = max(sprof.items(), key=lambda kv: kv[1][0])
-            extra["sampler"]["dominant_kernel"] = {"kernel": name, "tflops": (fl / (ms * 1e-3)) / 1e12, "avg_us": ms / cnt * 1e3,
-                                                   "frac_of_mfma_peak": (fl / (ms * 1e-3)) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+            ach_s = (fl / (ms * 1e-3)) / 1e12
+            extra["sampler"]["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach_s, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": ach_s / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(name),
+                                            "traffic_source": "lookup: profiles/pmc_hbm_traffic.json; NOT measured in this run",
+                                            "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3, "flops_per_launch": fl / cnt,
+                                            "measured": f"HIP events around every GEMM launch of a separate {min(50, args.sampler_steps)}-step run"}
+            extra["sampler"]["whole_run_frac_of_mfma_peak"] = extra["sampler"]["tflops_algorithmic"] / MFMA_BF16_PEAK_TFLOPS
         # ---- M3: SMPL-X forward kinematics, joints only ([B,63] -> [B,22,3]), HBM-bound: 516 B / pose ----
         from dposer_amd.body_model.body_model import BodyModel
         from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
@@ -244,8 +321,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         fk_s = e0.elapsed_time(e1) * 1e-3 / 20
-        extra["fk_joints"] = {"poses_per_s_per_gpu": nfk / fk_s, "batch": nfk, "algorithmic_GBps": 516.0 * nfk / fk_s / 1e9,
-                              "frac_of_hbm_peak": 516.0 * nfk / fk_s / 1e9 / HBM_PEAK_GBS}
+        fk_gbs = 516.0 * nfk / fk_s / 1e9
+        extra["fk_joints"] = {"poses_per_s_per_gpu": nfk / fk_s, "batch": nfk,
+                              "roofline": {"bound": "hbm", "kernel": "k_fk_joints<KinSMPLX, 64, 22>", "achieved": fk_gbs, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": fk_gbs / HBM_PEAK_GBS, "traffic": None,
+                                           "algorithmic_bytes_per_pose": 516, "avg_launch_us": fk_s * 1e6,
+                                           "measured": "HIP events on the launch stream around 20 launches of 2^20 poses"}}
         # ---- M3b: full linear blend skinning ([B,63] -> 10475 vertices + 127 joints), forward and forward+backward ----
         nl = 4096
         pb = pose[:nl].clone().requires_grad_(True)

@@ -8,6 +8,7 @@ Hutchinson divergence estimate -- is one HIP forward plus one HIP input-gradient
 score network through ``ScoreModelFC``'s autograd function; only the flattened state crosses PCIe per evaluation.
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -43,8 +44,16 @@ def hutchinson_noise(data, kind):
     raise NotImplementedError(f"Hutchinson type {kind} unknown.")
 
 
-def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e-5, atol=1e-5, method="RK45", eps=1e-5):
-    """Returns ``likelihood_fn(model, data) -> (bpd [B], z like data, nfe)`` (likelihood.py:40-113)."""
+def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e-5, atol=1e-5, method="RK45", eps=1e-5, driver=None):
+    """Returns ``likelihood_fn(model, data) -> (bpd [B], z like data, nfe)`` (likelihood.py:40-113).
+
+    ``driver``: 'device' (default for RK45) integrates with ``ode_device.solve_rk45`` -- scipy's RK45 controller with the state and
+    all stage arithmetic resident on the GPU in float64, one scalar to the host per attempted step; 'scipy' is the reference's
+    own driver (host float64 state, two state copies per right-hand-side evaluation; the only choice for other ``method``s).
+    ``DPOSER_ODE_DRIVER`` overrides the default."""
+    driver = driver or os.environ.get("DPOSER_ODE_DRIVER") or ("device" if method == "RK45" else "scipy")
+    if driver == "device" and method != "RK45":
+        raise NotImplementedError("the device-resident driver implements RK45 (the reference's default); use driver='scipy'")
 
     def likelihood_fn(model, data, *, epsilon=None):
         shape, B = tuple(data.shape), data.shape[0]
@@ -53,24 +62,38 @@ def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e
         with torch.no_grad():
             noise = hutchinson_noise(data, hutchinson_type) if epsilon is None else epsilon
         div = get_div_fn(lambda xx, tt: probability_flow_drift(sde, model, xx, tt))
+        only_x = model.input_grad_only() if hasattr(model, "input_grad_only") else contextlib.nullcontext()
 
-        def rhs(t, state):
-            x = torch.from_numpy(state[:n_state].reshape(shape)).to(dev, torch.float32)
+        def rhs_dev(t, state):
+            """state float64 [n_state + B] on the device -> d state / dt (likelihood.py:86-95)."""
+            x = state[:n_state].reshape(shape).float()
             vec_t = torch.full((B,), float(t), device=dev, dtype=torch.float32)
             with torch.no_grad():
                 drift = probability_flow_drift(sde, model, x, vec_t)
-            with (model.input_grad_only() if hasattr(model, "input_grad_only") else contextlib.nullcontext()):
+            with only_x:
                 dlogp = div(x, vec_t, noise)
-            return np.concatenate([mutils.to_flattened_numpy(drift), mutils.to_flattened_numpy(dlogp)])
+            return torch.cat([drift.reshape(-1).double(), dlogp.reshape(-1).double()])
 
-        init = np.concatenate([mutils.to_flattened_numpy(data), np.zeros((B,))])
-        sol = integrate.solve_ivp(rhs, (eps, sde.T), init, rtol=rtol, atol=atol, method=method)
-        end = sol.y[:, -1]
-        with torch.no_grad():
+        if driver == "device":
+            from .ode_device import solve_rk45
+            init = torch.cat([data.detach().reshape(-1).double(), torch.zeros(B, dtype=torch.float64, device=dev)])
+            end, nfev = solve_rk45(rhs_dev, eps, sde.T, init, rtol=rtol, atol=atol)
+            z = end[:n_state].reshape(shape).float()
+            delta_logp = end[n_state:].float()
+        else:
+            def rhs(t, state):
+                out = rhs_dev(t, torch.from_numpy(state).to(dev))
+                return out.cpu().numpy()
+
+            init = np.concatenate([mutils.to_flattened_numpy(data), np.zeros((B,))])
+            sol = integrate.solve_ivp(rhs, (eps, sde.T), init, rtol=rtol, atol=atol, method=method)
+            nfev = sol.nfev
+            end = sol.y[:, -1]
             z = torch.from_numpy(end[:n_state].reshape(shape)).to(dev, torch.float32)
             delta_logp = torch.from_numpy(end[n_state:]).to(dev, torch.float32)
+        with torch.no_grad():
             bpd = -(sde.prior_logp(z) + delta_logp) / np.log(2)
             bpd = bpd / np.prod(shape[1:])
-        return bpd, z, sol.nfev
+        return bpd, z, nfev
 
     return likelihood_fn

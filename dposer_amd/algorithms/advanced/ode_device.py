@@ -1,0 +1,140 @@
+"""Device-resident adaptive Runge-Kutta driver for the probability-flow ODE.
+
+The reference integrates the probability-flow ODE with ``scipy.integrate.solve_ivp(method='RK45')`` (sampling.py:530,
+likelihood.py:99): every right-hand-side evaluation moves the state host -> device -> host, and the step-size controller is
+part of the result (``nfe`` is returned to the caller).  This module keeps the state, the seven stage derivatives and every
+stage combination ON THE DEVICE (float64, like scipy's host arithmetic) and runs the SAME controller -- Dormand-Prince 5(4)
+tableau, error norm ``||err / (atol + rtol max(|y|, |y_new|))||_rms``, step factor ``0.9 err^(-1/5)`` clamped to [0.2, 10],
+Hairer's initial-step heuristic -- as published in scipy's ``integrate/_ivp/rk.py`` (``RK45``, ``rk_step``) and
+``_ivp/common.py`` (``select_initial_step``, ``norm``), scipy 1.15.  One scalar (the error norm) crosses to the host per
+attempted step -- instead of the whole state twice per right-hand-side evaluation, six times per step.
+
+``solve_rk45(fun, t0, t1, y0, rtol, atol) -> (y(t1), nfev)``;  ``fun(t: float, y: float64 tensor [n]) -> float64 tensor [n]``.
+``solve_fixed(fun, t0, t1, y0, n_steps, method='rk4')``: the fixed-step variant (no host synchronisation at all).
+"""
+import math
+
+import torch
+
+SAFETY, MIN_FACTOR, MAX_FACTOR = 0.9, 0.2, 10.0
+
+# Dormand-Prince 5(4) (Hairer, Norsett, Wanner, "Solving ODEs I", II.5; the coefficients scipy's RK45 tabulates)
+_C = (0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0)
+_A = ((),
+      (1 / 5,),
+      (3 / 40, 9 / 40),
+      (44 / 45, -56 / 15, 32 / 9),
+      (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+      (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656))
+_B = (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84)
+_E = (-71 / 57600, 0.0, 71 / 16695, -71 / 1920, 17253 / 339200, -22 / 525, 1 / 40)
+ORDER_ERR = 4
+
+
+def _rms(x):
+    return float(torch.linalg.vector_norm(x) / math.sqrt(x.numel()))          # scipy _ivp/common.py norm(); the one host sync
+
+
+def _initial_step(fun, t0, y0, t_bound, f0, direction, rtol, atol):
+    """scipy _ivp/common.py select_initial_step (Hairer II.4); one extra right-hand-side evaluation."""
+    interval = abs(t_bound - t0)
+    if y0.numel() == 0:
+        return math.inf
+    if interval == 0.0:
+        return 0.0
+    scale = atol + y0.abs() * rtol
+    d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
+    h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+    h0 = min(h0, interval)
+    f1 = fun(t0 + h0 * direction, y0 + h0 * direction * f0)
+    d2 = _rms((f1 - f0) / scale) / h0
+    h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / (ORDER_ERR + 1))
+    return min(100 * h0, h1, interval)
+
+
+def solve_rk45(fun, t0, t1, y0, rtol=1e-3, atol=1e-6, max_steps=100000):
+    """Integrate dy/dt = fun(t, y) from t0 to t1 (either direction); returns (y(t1), nfev) with scipy's evaluation count."""
+    t0, t1 = float(t0), float(t1)
+    y = y0.to(torch.float64)
+    nfev = [0]
+
+    def f(t, yy):
+        nfev[0] += 1
+        return fun(t, yy).to(torch.float64)
+
+    direction = 1.0 if t1 >= t0 else -1.0
+    fy = f(t0, y)
+    h_abs = _initial_step(f, t0, y, t1, fy, direction, rtol, atol)
+    t = t0
+    K = [None] * 7
+    exponent = -1.0 / (ORDER_ERR + 1)
+    for _ in range(max_steps):
+        if direction * (t - t1) >= 0:
+            break
+        min_step = 10 * abs(math.nextafter(t, direction * math.inf) - t)
+        h_abs = max(h_abs, min_step)
+        rejected = False
+        while True:
+            if h_abs < min_step:
+                raise RuntimeError("solve_rk45: required step size is less than spacing between numbers")
+            h = h_abs * direction
+            t_new = t + h
+            if direction * (t_new - t1) > 0:
+                t_new = t1
+            h = t_new - t
+            h_abs = abs(h)
+            # rk_step: K[s] = fun(t + c_s h, y + h sum_j a_sj K[j]);  y_new = y + h sum_j b_j K[j];  K[6] = fun(t + h, y_new)
+            K[0] = fy
+            for s in range(1, 6):
+                dy = K[0] * _A[s][0]
+                for j in range(1, s):
+                    dy = dy + K[j] * _A[s][j]
+                K[s] = f(t + _C[s] * h, y + dy * h)
+            acc = K[0] * _B[0]
+            for j in range(1, 6):
+                if _B[j] != 0.0:
+                    acc = acc + K[j] * _B[j]
+            y_new = y + acc * h
+            f_new = f(t + h, y_new)
+            K[6] = f_new
+            err = K[0] * _E[0]
+            for j in range(1, 7):
+                if _E[j] != 0.0:
+                    err = err + K[j] * _E[j]
+            scale = atol + torch.maximum(y.abs(), y_new.abs()) * rtol
+            error_norm = _rms(err * h / scale)
+            if error_norm < 1:
+                factor = MAX_FACTOR if error_norm == 0 else min(MAX_FACTOR, SAFETY * error_norm ** exponent)
+                if rejected:
+                    factor = min(1.0, factor)
+                h_abs *= factor
+                break
+            h_abs *= max(MIN_FACTOR, SAFETY * error_norm ** exponent)
+            rejected = True
+        t, y, fy = t_new, y_new, f_new
+    else:
+        raise RuntimeError("solve_rk45: step budget exhausted")
+    return y, nfev[0]
+
+
+def solve_fixed(fun, t0, t1, y0, n_steps, method="rk4"):
+    """Fixed-step explicit integration (classical RK4 or Euler) with no host synchronisation: n_steps x {4, 1} evaluations."""
+    t0, t1 = float(t0), float(t1)
+    y = y0.to(torch.float64)
+    h = (t1 - t0) / n_steps
+    nfev = 0
+    for i in range(n_steps):
+        t = t0 + i * h
+        if method == "euler":
+            y = y + h * fun(t, y).to(torch.float64)
+            nfev += 1
+        elif method == "rk4":
+            k1 = fun(t, y).to(torch.float64)
+            k2 = fun(t + h / 2, y + (h / 2) * k1).to(torch.float64)
+            k3 = fun(t + h / 2, y + (h / 2) * k2).to(torch.float64)
+            k4 = fun(t + h, y + h * k3).to(torch.float64)
+            y = y + (h / 6) * (k1 + 2 * k2 + 2 * k3 + k4)
+            nfev += 4
+        else:
+            raise ValueError(f"unknown fixed-step method {method!r}")
+    return y, nfev

@@ -425,30 +425,42 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
     return pc_sampler
 
 
-def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1e-5, method="RK45", eps=1e-3, device="cuda"):
+def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1e-5, method="RK45", eps=1e-3, device="cuda", driver=None):
     """Probability-flow ODE sampler (sampling.py:471-542): ``ode_sampler(model, z=None) -> (nfe, samples)``.
 
-    ``scipy.integrate.solve_ivp`` drives the adaptive steps on the host exactly like the reference (tolerances and
-    ``nfe`` are part of the result); each drift evaluation is one HIP forward of the score network.  ``denoise`` adds one
-    noise-free reverse-diffusion predictor step at ``eps`` (sampling.py:492-499)."""
+    The adaptive RK45 steps follow scipy's controller exactly like the reference (tolerances and ``nfe`` are part of the
+    result); with ``driver='device'`` (default for RK45, ``likelihood.get_likelihood_fn`` has the details) the state never leaves
+    the GPU, with ``driver='scipy'`` ``scipy.integrate.solve_ivp`` drives it from the host.  Each drift evaluation is one HIP
+    forward of the score network.  ``denoise`` adds one noise-free reverse-diffusion predictor step at ``eps`` (:492-499)."""
+    import os
     from .likelihood import probability_flow_drift
     from scipy import integrate
+    driver = driver or os.environ.get("DPOSER_ODE_DRIVER") or ("device" if method == "RK45" else "scipy")
+    if driver == "device" and method != "RK45":
+        raise NotImplementedError("the device-resident driver implements RK45 (the reference's default); use driver='scipy'")
 
     def ode_sampler(model, z=None):
         with torch.no_grad():
             x = sde.prior_sampling(shape).to(device) if z is None else z
 
-            def rhs(t, state):
-                xt = torch.from_numpy(state.reshape(shape)).to(device, torch.float32)
+            def rhs_dev(t, state):
+                xt = state.reshape(shape).float()
                 vec_t = torch.full((shape[0],), float(t), device=device, dtype=torch.float32)
-                return mutils.to_flattened_numpy(probability_flow_drift(sde, model, xt, vec_t))
+                return probability_flow_drift(sde, model, xt, vec_t).reshape(-1).double()
 
-            sol = integrate.solve_ivp(rhs, (sde.T, eps), mutils.to_flattened_numpy(x), rtol=rtol, atol=atol, method=method)
-            x = torch.from_numpy(sol.y[:, -1].reshape(shape)).to(device, torch.float32)
+            if driver == "device":
+                from .ode_device import solve_rk45
+                end, nfev = solve_rk45(rhs_dev, sde.T, eps, x.reshape(-1).double(), rtol=rtol, atol=atol)
+                x = end.reshape(shape).float()
+            else:
+                sol = integrate.solve_ivp(lambda t, s_: rhs_dev(t, torch.from_numpy(s_).to(device)).cpu().numpy(), (sde.T, eps),
+                                          mutils.to_flattened_numpy(x), rtol=rtol, atol=atol, method=method)
+                nfev = sol.nfev
+                x = torch.from_numpy(sol.y[:, -1].reshape(shape)).to(device, torch.float32)
             if denoise:
                 score_fn = get_score_fn(sde, model, train=False, continuous=True)
                 vec_eps = torch.full((shape[0],), float(eps), device=device, dtype=torch.float32)
                 x = ReverseDiffusionPredictor(sde, score_fn, probability_flow=False).update_fn(x, vec_eps)[1]
-            return sol.nfev, inverse_scaler(x)
+            return nfev, inverse_scaler(x)
 
     return ode_sampler

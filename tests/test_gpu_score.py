@@ -400,17 +400,19 @@ def test_full_batch_train_step_properties():
     assert float(fg[lo:hi].abs().max()) == 0.0
 
 
-def test_likelihood_matches_reference_golden():
+@pytest.mark.parametrize("driver", ["device", "scipy"])
+def test_likelihood_matches_reference_golden(driver):
     """get_likelihood_fn (probability-flow ODE + Hutchinson divergence through the HIP forward / input-gradient) against the
-    reference's CPU run with the same injected epsilon.  scipy's adaptive RK45 amplifies rounding differences through its
-    step-size decisions, hence the looser bound than a single forward."""
+    reference's CPU run with the same injected epsilon, with the device-resident RK45 driver (ode_device.py: scipy's controller,
+    state on the GPU) and with scipy itself.  The adaptive RK45 amplifies rounding differences through its step-size
+    decisions, hence the looser bound than a single forward."""
     from dposer_amd.algorithms.advanced import likelihood, sde_lib
     g = load("g12_likelihood_ode")
     cfg, m, p = make_model(int(g["seed"]), precision="fp32")
     sde = sde_lib.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000)
     data = _dev(g["data"])
     for kind in ("Rademacher", "Gaussian"):
-        fn = likelihood.get_likelihood_fn(sde, lambda v: v, hutchinson_type=kind, rtol=1e-4, atol=1e-4, eps=1e-4)
+        fn = likelihood.get_likelihood_fn(sde, lambda v: v, hutchinson_type=kind, rtol=1e-4, atol=1e-4, eps=1e-4, driver=driver)
         bpd, z, nfe = fn(m, data, epsilon=_dev(g[f"lik_{kind}/eps"]))
         assert rel_err(t2n(bpd), g[f"lik_{kind}/bpd"]) < 2e-3, kind
         assert rel_err(t2n(z), g[f"lik_{kind}/z"]) < 2e-3, kind
@@ -422,13 +424,30 @@ def test_likelihood_matches_reference_golden():
         likelihood.hutchinson_noise(data, "uniform")
 
 
-def test_ode_sampler_matches_reference_golden():
+def test_device_and_scipy_ode_drivers_agree():
+    """Same right-hand side (the HIP forward), same controller: the device-resident driver and scipy.integrate.solve_ivp make the
+    same step decisions (identical nfe) and end on the same samples."""
+    from dposer_amd.algorithms.advanced import sampling, sde_lib
+    g = load("g12_likelihood_ode")
+    cfg, m, p = make_model(int(g["seed"]), precision="fp32")
+    sde = sde_lib.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000)
+    out = {}
+    for driver in ("device", "scipy"):
+        fn = sampling.get_ode_sampler(sde, (6, 63), lambda v: v, rtol=1e-4, atol=1e-4, eps=1e-3, device=DEV, driver=driver)
+        out[driver] = fn(m, z=_dev(g["ode/z"]))
+    assert out["device"][0] == out["scipy"][0]
+    assert rel_err(t2n(out["device"][1]), t2n(out["scipy"][1])) < 1e-6
+
+
+@pytest.mark.parametrize("driver", ["device", "scipy"])
+def test_ode_sampler_matches_reference_golden(driver):
     from dposer_amd.algorithms.advanced import sampling, sde_lib
     g = load("g12_likelihood_ode")
     cfg, m, p = make_model(int(g["seed"]), precision="fp32")
     sde = sde_lib.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000)
     for denoise in (0, 1):
-        fn = sampling.get_ode_sampler(sde, (6, 63), lambda v: v, denoise=bool(denoise), rtol=1e-4, atol=1e-4, eps=1e-3, device=DEV)
+        fn = sampling.get_ode_sampler(sde, (6, 63), lambda v: v, denoise=bool(denoise), rtol=1e-4, atol=1e-4, eps=1e-3, device=DEV,
+                                      driver=driver)
         nfe, x = fn(m, z=_dev(g["ode/z"]))
         # random weights are not a trained score: the flow expands |x| by four orders of magnitude, and rounding differences with it
         assert rel_err(t2n(x), g[f"ode/x_denoise{denoise}"]) < 2e-2
