@@ -241,7 +241,11 @@ def main():
                                       "command, tools/profile_bench.sh); NOT measured in this run", "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3,
                     "flops_per_launch": fl / cnt, "gemm_time_share_of_step": tot_ms / 3 / ms_per_step}
 
-    extra = {"train_loss_last_step": loss, "train_tflops_algorithmic": 42.59e6 * value / 1e12, "gemm_kernels": kernels}
+    dropped = state["optimizer"].nonfinite_steps()
+    if not np.isfinite(loss) or dropped:
+        raise RuntimeError(f"training diverged inside the benchmark: last loss {loss}, {dropped} step(s) dropped for a non-finite gradient")
+    extra = {"train_loss_last_step": loss, "nonfinite_gradient_steps_dropped": dropped, "train_tflops_algorithmic": 42.59e6 * value / 1e12,
+             "gemm_kernels": kernels}
     if not args.no_extra and args.precision != "fp32":
         # the same step in fp32 parity mode (exact-fp32 MFMA, 1/16 of the bf16 matrix rate): the mode the tight parity numbers
         # of the test suite come from, next to the bf16 headline
@@ -371,4 +375,5 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    from dposer_amd.distributed import run_fail_fast
+    run_fail_fast(main)

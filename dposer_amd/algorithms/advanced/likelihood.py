@@ -62,7 +62,7 @@ def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e
         with torch.no_grad():
             noise = hutchinson_noise(data, hutchinson_type) if epsilon is None else epsilon
         div = get_div_fn(lambda xx, tt: probability_flow_drift(sde, model, xx, tt))
-        only_x = model.input_grad_only() if hasattr(model, "input_grad_only") else contextlib.nullcontext()
+        only_x = (lambda: model.input_grad_only()) if hasattr(model, "input_grad_only") else contextlib.nullcontext
 
         def rhs_dev(t, state):
             """state float64 [n_state + B] on the device -> d state / dt (likelihood.py:86-95)."""
@@ -70,7 +70,7 @@ def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e
             vec_t = torch.full((B,), float(t), device=dev, dtype=torch.float32)
             with torch.no_grad():
                 drift = probability_flow_drift(sde, model, x, vec_t)
-            with only_x:
+            with only_x():
                 dlogp = div(x, vec_t, noise)
             return torch.cat([drift.reshape(-1).double(), dlogp.reshape(-1).double()])
 

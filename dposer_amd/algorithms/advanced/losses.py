@@ -91,6 +91,12 @@ class FusedAdam(optim.Adam):
         self._flat_cache = None
         self._state_views = None
 
+    def nonfinite_steps(self) -> int:
+        """How many optimisation steps the device dropped because the gradient contained NaN / Inf (the fused update checks the
+        squared gradient norm and leaves parameters, moments and EMA untouched).  Reading it synchronises; call it at logging
+        / checkpoint time, not per step."""
+        return 0 if self._scratch is None else int(self._scratch[1].item())
+
     def flat_grad(self):
         """Flat gradient buffer the fused backward writes into (one element per flat parameter)."""
         self._ensure_flat()

@@ -43,8 +43,30 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(lr % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(backend=backend, rank=rk, world_size=ws)
+            # fail fast: a failed / timed-out RCCL collective aborts the process instead of hanging its peers
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        import datetime
+        timeout = datetime.timedelta(seconds=int(os.environ.get("DPOSER_DIST_TIMEOUT_S", "600")))
+        dist.init_process_group(backend=backend, rank=rk, world_size=ws, timeout=timeout)
     return rk, ws, lr
+
+
+def run_fail_fast(fn, *args, **kwargs):
+    """Entry-point wrapper for multi-process jobs: any exception on this rank (a collective error, a device fault, a failed
+    check) prints its traceback and ends the PROCESS with a non-zero code at once -- no destroy_process_group() that would
+    wait for peers stuck in a collective -- so the launcher (torchrun) tears the job down.  The reference's train loop swallows
+    exceptions (train.py:243,406-407); a data-parallel job must not."""
+    import sys
+    import traceback
+    try:
+        return fn(*args, **kwargs)
+    except SystemExit:
+        raise
+    except BaseException:
+        traceback.print_exc()
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)
 
 
 def all_reduce_sum_(flat: torch.Tensor) -> int:

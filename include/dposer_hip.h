@@ -164,7 +164,9 @@ int dposer_scorefc_backward(dposer_scorefc_t h, const float* flat_params, const 
  *   EMA still applied: pre_dense_cond);  grad_scale: multiplied into the gradient first (1/world_size
  *   after an all-reduce SUM);  grad_clip < 0 disables clip_grad_norm_;  adam_step = optimizer step count
  *   AFTER this update (>= 1);  ema may be NULL;  ema_one_minus_decay = 1 - min(decay, (1+n)/(10+n));
- *   scratch: >= 8 KiB floats. */
+ *   scratch: >= 8 KiB floats, caller-owned and persistent across steps: scratch[0] = squared gradient norm of this step,
+ *   scratch[1] = number of steps DROPPED so far because that norm was not finite (NaN / Inf gradient: parameters, moments and
+ *   EMA are left untouched on the device, no host round trip; zero scratch[1] once, before the first step). */
 int dposer_adam_ema_clip_step(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* ema,
                               int64_t n, const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip,
                               double lr, double beta1, double beta2, double eps, double grad_clip, double grad_scale,
