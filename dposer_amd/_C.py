@@ -77,6 +77,9 @@ SIGNATURES = {
     "dposer_stream_wait_event": (C.c_int, [vp, vp]),
     "dposer_adam_ema_clip_step": (C.c_int, [vp, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64,
                                             f64, f64, i64, f64, vp, vp]),
+    "dposer_grad_sqnorm": (C.c_int, [vp, i64, vp, vp]),
+    "dposer_adam_ema_clip_step_presummed": (C.c_int, [vp, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64,
+                                                      f64, f64, i64, f64, vp, vp]),
     "dposer_profile_enable": (None, [i32]),
     "dposer_profile_num_kinds": (i32, []),
     "dposer_profile_collect": (C.c_int, [C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),

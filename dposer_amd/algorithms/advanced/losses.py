@@ -11,6 +11,7 @@ gradient) -> optional RCCL all-reduce of the flat gradient (dposer_amd.distribut
 with torch autograd.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -146,6 +147,48 @@ class FusedAdam(optim.Adam):
         self._step_t.fill_(float(self._step_count))
 
     @torch.no_grad()
+    def fused_step_sharded(self, *, live, bounds, rank, grad_clip=-1.0, grad_scale=1.0, ema: ExponentialMovingAverage = None):
+        """ZeRO-1 style update (SURVEY 8e): ``self._flat_g`` holds this rank's reduce-scattered gradient range ``bounds[rank]``;
+        the global squared norm for the clip is one all-reduced float; Adam / EMA touch only the owned range (1/G of the
+        work and of the moment traffic); the caller all-gathers the parameters afterwards.  Moments outside the owned range stay
+        zero on this rank (a checkpoint of a sharded run must gather them first: ``gather_state``)."""
+        from ... import distributed as ddp
+        flat, offs, params = self._ensure_flat()
+        lo, hi = bounds[rank]
+        lib = _C.lib()
+        g = self.param_groups[0]
+        self._step_count += 1
+        ema_flat, omd = None, 0.0
+        if ema is not None:
+            ema_flat = ema.flat_shadow_for(flat)
+            if ema_flat is None:
+                raise _C.DPoserHipError("EMA shadow parameters are not flat-backed")
+            omd = ema.next_one_minus_decay()
+        # squared norm of the owned range, excluding parameters without a gradient (their range holds zeros already)
+        _C.check(lib.dposer_grad_sqnorm(_C.ptr(self._flat_g[lo:hi]), hi - lo, _C.ptr(self._scratch), _C.stream_ptr()), "dposer_grad_sqnorm")
+        ddp.all_reduce_sum_(self._scratch[0:1])
+        skip = []
+        for p, o, ok in zip(params, offs, live):
+            if not ok:
+                a, b = max(o, lo) - lo, min(o + p.numel(), hi) - lo
+                if b > a:
+                    if skip and skip[-1][1] == a:
+                        skip[-1][1] = b
+                    else:
+                        skip.append([a, b])
+        if len(skip) > 2:
+            raise _C.DPoserHipError("FusedAdam: more than two disjoint parameter ranges without gradient")
+        slo = (C.c_int64 * 2)(*([s_[0] for s_ in skip] + [0, 0])[:2])
+        shi = (C.c_int64 * 2)(*([s_[1] for s_ in skip] + [0, 0])[:2])
+        if hi > lo:
+            _C.check(lib.dposer_adam_ema_clip_step_presummed(
+                _C.ptr(flat[lo:hi]), _C.ptr(self._flat_g[lo:hi]), _C.ptr(self._flat_m[lo:hi]), _C.ptr(self._flat_v[lo:hi]),
+                _C.ptr(None if ema_flat is None else ema_flat[lo:hi]), hi - lo, slo, shi, len(skip), float(g["lr"]), float(g["betas"][0]),
+                float(g["betas"][1]), float(g["eps"]), float(grad_clip), float(grad_scale), self._step_count, float(omd),
+                _C.ptr(self._scratch), _C.stream_ptr()), "dposer_adam_ema_clip_step_presummed")
+        torch.autograd.graph.increment_version(params)
+
+    @torch.no_grad()
     def step(self, closure=None):
         """Generic entry (gradients in ``p.grad``, already clipped by the caller)."""
         loss = closure() if closure is not None else None
@@ -279,6 +322,17 @@ def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, se
     return loss[0]
 
 
+def _live_params(model):
+    """Which parameters get a gradient (fixed per model unless requires_grad flags are flipped): cached on the model."""
+    params = model._param_list
+    rg = tuple(p.requires_grad for p in params)
+    cache = getattr(model, "_live_cache", None)
+    if cache is None or cache[0] != rg:
+        cache = (rg, [not model._is_nograd(o) and r for r, o in zip(rg, model._offsets)])
+        model._live_cache = cache
+    return cache[1]
+
+
 def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True, likelihood_weighting=False,
                 auxiliary_loss=False, denormalize=None, body_model=None, rot_rep="rot6d", denoise_steps=5):
     """One-step training / evaluation function (losses.py:187-275).
@@ -319,6 +373,24 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
             flat_grad = optimizer.flat_grad()
             # Philox key of this rank's shard: sample i of every shard must NOT draw the same t / z / dropout mask
             seed = (model._rng_seed + 0x9E3779B1 * ddp.rank()) & 0xFFFFFFFFFFFFFFFF if ddp.world_size() > 1 else model._rng_seed
+            zero1 = ddp.world_size() > 1 and (os.environ.get("DPOSER_ZERO1") == "1" or bool(getattr(optimizer, "zero1", False)))
+            if zero1:
+                # ZeRO-1 style step: reduce-scatter the gradient, update only the owned 1/G range of parameters,
+                # moments and EMA, all-gather the parameters (and the EMA shadow, which every rank keeps whole for evaluation)
+                world, rk = ddp.world_size(), ddp.rank()
+                bounds = ddp.zero1_bounds(flat_grad.numel(), world)
+                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"])
+                ddp.reduce_scatter_flat_(flat_grad, bounds)
+                optimize_fn.warm_lr(optimizer, state["step"])
+                live = _live_params(model)
+                optimizer.fused_step_sharded(live=live, bounds=bounds, rank=rk, grad_clip=optimize_fn.grad_clip, grad_scale=1.0 / world,
+                                             ema=state["ema"])
+                ddp.all_gather_flat_(model.flat_params(), bounds)
+                shadow = state["ema"].flat_shadow_for(model.flat_params()) if state["ema"] is not None else None
+                if shadow is not None:
+                    ddp.all_gather_flat_(shadow, bounds)
+                state["step"] += 1
+                return {"step_loss": loss, "score_loss": loss}
             if ddp.world_size() > 1:
                 # bucketed: each GN layer's gradient is all-reduced (RCCL over xGMI) on a side stream while the layers in
                 # front of it are still being differentiated
@@ -333,14 +405,7 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
                 loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"])
                 world = 1
             optimize_fn.warm_lr(optimizer, state["step"])                           # losses.py:51-53
-            # parameters with a gradient (fixed per model unless requires_grad flags are flipped): cached on the model
-            params = model._param_list
-            rg = tuple(p.requires_grad for p in params)
-            cache = getattr(model, "_live_cache", None)
-            if cache is None or cache[0] != rg:
-                cache = (rg, [not model._is_nograd(o) and r for r, o in zip(rg, model._offsets)])
-                model._live_cache = cache
-            live = cache[1]
+            live = _live_params(model)
             optimizer.fused_step(live=live, grad_clip=optimize_fn.grad_clip, grad_scale=1.0 / world, ema=state["ema"])
             state["step"] += 1
             return {"step_loss": loss, "score_loss": loss}

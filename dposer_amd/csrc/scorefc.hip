@@ -1120,17 +1120,43 @@ extern "C" int dposer_scorefc_backward(dposer_scorefc_t h, const float* flat, co
     return backward_core(h, flat, packed, w, B, train_mode != 0, seed, step, flat_grad, dx, nullptr, 0, st);
 }
 
-extern "C" int dposer_adam_ema_clip_step(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n,
-                                         const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
-                                         double beta1, double beta2, double eps, double grad_clip, double grad_scale,
-                                         int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream) {
-    DP_CHECK_ARG(flat && grad && m && v && scratch, "null argument");
-    DP_CHECK_ARG(adam_step >= 1, "adam_step counts from 1");
-    DP_CHECK_ARG(n_skip >= 0 && n_skip <= 2, "at most two no-gradient ranges");
+extern "C" int dposer_grad_sqnorm(const float* grad, int64_t n, float* scratch, void* stream) {
+    DP_CHECK_ARG(grad && scratch && n >= 0, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     int nb = 0;
     DP_HIP_LAUNCH(launch_sqnorm(grad, n, scratch + 16, &nb, st));
     DP_HIP_LAUNCH(launch_sum_partials(scratch + 16, nb, scratch, st));
+    return DPOSER_OK;
+}
+static int adam_step_impl(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n, const int64_t* skip_lo_host,
+                          const int64_t* skip_hi_host, int32_t n_skip, double lr, double beta1, double beta2, double eps, double grad_clip,
+                          double grad_scale, int64_t adam_step, double ema_one_minus_decay, float* scratch, bool presummed, void* stream);
+extern "C" int dposer_adam_ema_clip_step(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n,
+                                         const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
+                                         double beta1, double beta2, double eps, double grad_clip, double grad_scale,
+                                         int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream) {
+    return adam_step_impl(flat, grad, m, v, ema, n, skip_lo_host, skip_hi_host, n_skip, lr, beta1, beta2, eps, grad_clip, grad_scale, adam_step,
+                          ema_one_minus_decay, scratch, false, stream);
+}
+extern "C" int dposer_adam_ema_clip_step_presummed(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n,
+                                                   const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
+                                                   double beta1, double beta2, double eps, double grad_clip, double grad_scale,
+                                                   int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream) {
+    return adam_step_impl(flat, grad, m, v, ema, n, skip_lo_host, skip_hi_host, n_skip, lr, beta1, beta2, eps, grad_clip, grad_scale, adam_step,
+                          ema_one_minus_decay, scratch, true, stream);
+}
+static int adam_step_impl(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n, const int64_t* skip_lo_host,
+                          const int64_t* skip_hi_host, int32_t n_skip, double lr, double beta1, double beta2, double eps, double grad_clip,
+                          double grad_scale, int64_t adam_step, double ema_one_minus_decay, float* scratch, bool presummed, void* stream) {
+    DP_CHECK_ARG(flat && grad && m && v && scratch, "null argument");
+    DP_CHECK_ARG(adam_step >= 1, "adam_step counts from 1");
+    DP_CHECK_ARG(n_skip >= 0 && n_skip <= 2, "at most two no-gradient ranges");
+    hipStream_t st = (hipStream_t)stream;
+    if (!presummed) {
+        int nb = 0;
+        DP_HIP_LAUNCH(launch_sqnorm(grad, n, scratch + 16, &nb, st));
+        DP_HIP_LAUNCH(launch_sum_partials(scratch + 16, nb, scratch, st));
+    }
     AdamArgs a;
     a.p = flat; a.g = grad; a.m = m; a.v = v; a.ema = ema; a.n = n;
     for (int i = 0; i < 2; ++i) { a.skip_lo[i] = i < n_skip ? skip_lo_host[i] : 0; a.skip_hi[i] = i < n_skip ? skip_hi_host[i] : 0; }

@@ -109,6 +109,49 @@ def all_reduce_buckets_(flat: torch.Tensor, buckets, wait_bucket=None) -> int:
     return dist.get_world_size()
 
 
+def zero1_bounds(n: int, num_replicas: int):
+    """Contiguous ownership ranges of a flat buffer of n elements for the sharded optimiser step: equal sizes rounded up to a
+    multiple of 4 floats (16-byte aligned shard starts), the last rank takes what is left."""
+    per = -(-n // num_replicas)
+    per = (per + 3) // 4 * 4
+    return [(min(r * per, n), min((r + 1) * per, n)) for r in range(num_replicas)]
+
+
+def reduce_scatter_flat_(flat: torch.Tensor, bounds):
+    """SUM-reduce ``flat`` so that rank r ends with the reduced values of its range ``bounds[r]`` (other ranges: unspecified).
+    RCCL: one reduce_scatter over equal chunks when the ranges are equal-sized, else one reduce per range (gloo has no
+    reduce-scatter)."""
+    if not is_initialized() or dist.get_world_size() == 1:
+        return 1
+    ws, rk = dist.get_world_size(), dist.get_rank()
+    sizes = {hi - lo for lo, hi in bounds}
+    if dist.get_backend() == "nccl" and len(sizes) == 1 and bounds[-1][1] == flat.numel():
+        lo, hi = bounds[rk]
+        out = torch.empty(hi - lo, dtype=flat.dtype, device=flat.device)
+        dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM)
+        flat[lo:hi].copy_(out)
+    else:
+        works = [dist.reduce(flat[lo:hi], dst=r, op=dist.ReduceOp.SUM, async_op=True) for r, (lo, hi) in enumerate(bounds) if hi > lo]
+        for w in works:
+            w.wait()
+    return ws
+
+
+def all_gather_flat_(flat: torch.Tensor, bounds):
+    """Every rank publishes its range ``bounds[rank]`` of ``flat``; afterwards all ranks hold all ranges."""
+    if not is_initialized() or dist.get_world_size() == 1:
+        return
+    rk = dist.get_rank()
+    sizes = {hi - lo for lo, hi in bounds}
+    if dist.get_backend() == "nccl" and len(sizes) == 1 and bounds[-1][1] == flat.numel():
+        lo, hi = bounds[rk]
+        dist.all_gather_into_tensor(flat, flat[lo:hi].clone())
+    else:
+        works = [dist.broadcast(flat[lo:hi], src=r, async_op=True) for r, (lo, hi) in enumerate(bounds) if hi > lo]
+        for w in works:
+            w.wait()
+
+
 def broadcast_(flat: torch.Tensor, src=0):
     """Make every rank start from rank ``src``'s parameters."""
     if is_initialized() and dist.get_world_size() > 1:

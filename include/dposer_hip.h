@@ -172,6 +172,17 @@ int dposer_adam_ema_clip_step(float* flat_params, const float* flat_grad, float*
                               double lr, double beta1, double beta2, double eps, double grad_clip, double grad_scale,
                               int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream);
 
+/* Sharded optimiser step (ZeRO-1 style data parallelism): every rank owns a contiguous range of the flat buffers.
+ *   dposer_grad_sqnorm: scratch[0] = sum of squares of grad[0..n) (this rank's reduce-scattered gradient range); the caller
+ *   all-reduces that one float over the ranks to get the global squared norm for clip_grad_norm_ (losses.py:54-55);
+ *   dposer_adam_ema_clip_step_presummed: dposer_adam_ema_clip_step on the range, taking the squared norm from scratch[0] instead
+ *   of recomputing it (pointers and skip ranges are relative to the range). */
+int dposer_grad_sqnorm(const float* grad, int64_t n, float* scratch, void* stream);
+int dposer_adam_ema_clip_step_presummed(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* ema,
+                                        int64_t n, const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip,
+                                        double lr, double beta1, double beta2, double eps, double grad_clip, double grad_scale,
+                                        int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream);
+
 /* dposer_em_sampler restricted to the steps [start_step, start_step + n_steps) (no look-ahead imputation after the last one):
  * what a predictor-corrector loop with a corrector between the predictor calls drives (sampling.py:455-461). */
 int dposer_em_sampler_steps(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws, const dposer_sde_desc* sde,

@@ -72,3 +72,38 @@ def test_single_process_is_noop():
     assert means == {"e": 3.0} and allv["e"] == [1.0, 3.0, 5.0]
     assert ddp.reduce_metric_means([{"e": [1.0, 3.0]}, {"e": torch.tensor([5.0])}]) == {"e": 3.0}
     assert ddp.shard_bounds(10, 3, 0) == (0, 4) and ddp.shard_bounds(10, 3, 2) == (7, 10)
+
+
+def _worker_shards(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from dposer_amd import distributed as ddp
+    ddp.init_from_env(backend="gloo")
+    n = 1003
+    bounds = ddp.zero1_bounds(n, world)
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    ddp.reduce_scatter_flat_(g, bounds)
+    lo, hi = bounds[rank]
+    ok = torch.equal(g[lo:hi], torch.arange(n, dtype=torch.float32)[lo:hi] * 3)      # 1x + 2x
+    p = torch.zeros(n)
+    p[lo:hi] = float(rank + 1)
+    ddp.all_gather_flat_(p, bounds)
+    want = torch.cat([torch.full((b - a,), float(r + 1)) for r, (a, b) in enumerate(bounds)])
+    out.put((rank, bool(ok), bool(torch.equal(p, want)), bounds))
+    ddp.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_and_all_gather_of_flat_ranges():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_shards, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] for r in res)
+    assert res[0][3] == [(0, 504), (504, 1003)]                     # 16-byte aligned shard starts, the last rank takes the rest

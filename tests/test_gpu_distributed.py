@@ -245,3 +245,40 @@ def test_nonfinite_gradient_step_is_dropped_on_the_device():
     assert all(torch.equal(a, b) for a, b in zip(before, after))
     step_fn(state, x)                                      # and training continues
     assert opt.nonfinite_steps() == 1 and not torch.equal(m.flat_params(), before[0])
+
+
+def _worker_zero1(rank, world, port, q, model_seed, batch, t, z, n_steps):
+    os.environ["DPOSER_ZERO1"] = "1"
+    _worker(rank, world, port, q, model_seed, batch, t, z, n_steps)
+
+
+def test_zero1_sharded_step_equals_replicated_step():
+    """DPOSER_ZERO1=1: reduce-scatter of the gradient, clip from one all-reduced squared norm, Adam / EMA on the owned range only,
+    all-gather of the parameters -- must track the replicated (all-reduce) step and the single-process step on the whole batch."""
+    rs = np.random.RandomState(5)
+    n_steps, B = 3, 256
+    batch = torch.tensor(rs.standard_normal((n_steps, B, 63)).astype(np.float32))
+    t = torch.tensor(rs.uniform(1e-3, 1.0, (n_steps, B)).astype(np.float32))
+    z = torch.tensor(rs.standard_normal((n_steps, B, 63)).astype(np.float32))
+    ref, ref_mom, ref_losses = _steps(9, batch, t, z, n_steps, 1, 0, "fp32")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_zero1, args=(r, 2, port, q, 9, batch, t, z, n_steps)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    f0, f1 = res[0][1], res[1][1]
+    assert np.array_equal(f0, f1)                                   # every rank holds the same gathered parameters
+    assert np.abs(f0 - ref.numpy()).max() < 2e-5
+    # moments live only on the owner of a range: the two halves together are the replicated first moment
+    n = f0.size
+    per = (-(-n // 2) + 3) // 4 * 4
+    mom = np.concatenate([res[0][2][:per], res[1][2][per:]])
+    assert np.linalg.norm(mom - ref_mom.numpy()) / np.linalg.norm(ref_mom.numpy()) < 1e-4
+    assert np.abs(res[0][2][per:]).max() == 0.0 and np.abs(res[1][2][:per]).max() == 0.0
+    mean_losses = [(a + b) / 2 for a, b in zip(res[0][3], res[1][3])]
+    assert np.allclose(mean_losses, ref_losses, rtol=2e-5)
