@@ -480,3 +480,22 @@ def test_smpl_and_smplh_wrappers_vs_oracle(model_type):
     p = dev(body).requires_grad_(True)
     m(pose_body=p, betas=dev(betas)).Jtr.sum().backward()
     assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0
+
+
+def test_streaming_fk_kernel_matches_the_one_tile_kernel(bm):
+    """From 131072 poses up the joints-only body query runs as persistent blocks that prefetch the next pose tile into registers
+    (k_fk_joints_stream): the same arithmetic in the same order, so its joints must be bit-identical to the one-tile-per-block
+    kernel (which serves the same poses when they arrive in smaller calls) -- ragged tail, translation and root orientation
+    included."""
+    n = 300_003
+    g = torch.Generator(device=DEV).manual_seed(3)
+    pose = torch.randn(n, 63, device=DEV, generator=g) * 0.4
+    tr = torch.randn(n, 3, device=DEV, generator=g)
+    root = torch.randn(n, 3, device=DEV, generator=g) * 0.5
+    for kw in (dict(), dict(trans=tr), dict(root_orient=root, trans=tr)):
+        big = bm.fk_joints(pose, **kw)
+        parts = []
+        for lo in range(0, n, 100_000):
+            sub = {k: v[lo:lo + 100_000].contiguous() for k, v in kw.items()}
+            parts.append(bm.fk_joints(pose[lo:lo + 100_000].contiguous(), **sub))
+        assert torch.equal(big, torch.cat(parts))
