@@ -491,120 +491,6 @@ template <typename Kin, int NT, int NOUT = 0> __global__ void __launch_bounds__(
     }
 }
 
-// Streaming variant of the joints-only query (the hot case): PERSISTENT single-wave blocks walk the pose tiles, and the raw
-// rows of the next tile's (largest) pose segment are fetched into registers while the kinematic chain of the current tile runs.
-// Why: with one tile per block every wave issues its whole 16 KB of loads at once and then computes without any memory traffic
-// -- 9 resident waves per CU (LDS-limited) queue 37 MB of requests chip-wide and sit ~80 % of their life waiting (3.3 TB/s,
-// VALU 43 % busy); the same kernel without the chain streams at 5 TB/s.  Prefetching one tile ahead keeps the memory system fed
-// during the arithmetic at the cost of 64-72 more live registers (2 waves per SIMD instead of 2.25: no loss).
-// `ps` = the prefetched segment (present, fully inside n_out); all other segments go through the generic staging code.
-template <typename Kin, int NT, int NOUT> __global__ void __launch_bounds__(NT, 2) k_fk_joints_stream(FkArgs a, int ps, int64_t n_tiles) {
-    constexpr int J = Kin::J;
-    constexpr int NV = 18;                      // float4 per lane of one tile of the prefetched segment: ceil(23 joints * 3 / 4)
-    extern __shared__ float lds[];
-    const int n_out = a.n_out;
-    const int ROW = (n_out * 3) | 1;
-    const int gwp = a.seg_joints[ps] * 3;
-    const int col0p = a.seg_first[ps] * 3;
-    const int n4p = NT * gwp / 4;
-    f32x4 v[NV];
-    auto prefetch = [&](int64_t tile) __attribute__((always_inline)) {
-        const f32x4* g4 = reinterpret_cast<const f32x4*>(a.seg[ps] + tile * NT * gwp);
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int i4 = k * NT + threadIdx.x;
-            if (i4 < n4p) v[k] = g4[i4];
-        }
-    };
-    int64_t tile = blockIdx.x;
-    bool have = tile < n_tiles && (tile + 1) * NT <= a.B;
-    if (have) prefetch(tile);
-    for (; tile < n_tiles; tile += gridDim.x) {
-        const int64_t item0 = tile * NT;
-        for (int sg = 0; sg < FK_MAX_SEG; ++sg) {
-            if (sg >= a.nseg) break;
-            const int first = a.seg_first[sg];
-            if (first >= n_out) break;
-            const int gw = a.seg_joints[sg] * 3;
-            const int width = (first + a.seg_joints[sg] <= n_out ? a.seg_joints[sg] : n_out - first) * 3;
-            const int col0 = first * 3;
-            const float* g = a.seg[sg];
-            if (sg == ps && have) continue;                                     // scattered from the prefetch registers below
-            if (!g) {
-                for (int e = threadIdx.x; e < NT * width; e += NT) lds[(e / width) * ROW + col0 + (e % width)] = 0.f;
-                continue;
-            }
-            int rw = threadIdx.x / width, col = threadIdx.x % width;
-            while (rw < NT) {
-                const int64_t bb = item0 + rw;
-                lds[rw * ROW + col0 + col] = (bb < a.B) ? g[bb * gw + col] : 0.f;
-                col += NT;
-                while (col >= width) { col -= width; ++rw; }
-            }
-        }
-        if (have) {
-            // element e = 4*i4 of the tile lives at (row, col) = (e / gw, e % gw); consecutive k advance e by 4*NT
-            const int drow = (4 * NT) / gwp, dcol = (4 * NT) % gwp;
-            int rw = (4 * threadIdx.x) / gwp, col = (4 * threadIdx.x) % gwp;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int i4 = k * NT + threadIdx.x;
-                if (i4 < n4p) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool wrap = col + r >= gwp;
-                        lds[(rw + (wrap ? 1 : 0)) * ROW + col0p + col + r - (wrap ? gwp : 0)] = v[k][r];
-                    }
-                }
-                rw += drow; col += dcol;
-                if (col >= gwp) { col -= gwp; ++rw; }
-            }
-        }
-        __syncthreads();
-        const int64_t next = tile + gridDim.x;
-        const bool have_next = next < n_tiles && (next + 1) * NT <= a.B;
-        if (have_next) prefetch(next);                                          // in flight while the chain below runs
-        const int64_t b = item0 + threadIdx.x;
-        float* row = lds + threadIdx.x * ROW;
-        const float* jr = a.j_rest_batched ? a.j_rest + (b < a.B ? b : 0) * (int64_t)J * 3 : a.j_rest;
-        float tr[3] = {0.f, 0.f, 0.f};
-        if (a.transl && b < a.B) { tr[0] = a.transl[b * 3]; tr[1] = a.transl[b * 3 + 1]; tr[2] = a.transl[b * 3 + 2]; }
-        {
-            Xf G[J];
-            fk_chain<Kin, NOUT>(std::make_integer_sequence<int, J>{}, G, row, jr, row, tr, a, b, n_out);
-        }
-        __syncthreads();
-        const int width = n_out * 3;
-        if (item0 + NT <= a.B && a.joints_ld == width) {
-            f32x4* o4 = reinterpret_cast<f32x4*>(a.joints + item0 * width);
-            const int n4 = NT * width / 4;
-            const int drow = (4 * NT) / width, dcol = (4 * NT) % width;
-            int rw = (4 * threadIdx.x) / width, col = (4 * threadIdx.x) % width;
-            for (int i4 = threadIdx.x; i4 < n4; i4 += NT) {
-                f32x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool wrap = col + r >= width;
-                    o[r] = lds[(rw + (wrap ? 1 : 0)) * ROW + col + r - (wrap ? width : 0)];
-                }
-                o4[i4] = o;
-                rw += drow; col += dcol;
-                if (col >= width) { col -= width; ++rw; }
-            }
-        } else {
-            int r = threadIdx.x / width, col = threadIdx.x % width;
-            while (r < NT) {
-                const int64_t bb = item0 + r;
-                if (bb < a.B) a.joints[bb * a.joints_ld + col] = lds[r * ROW + col];
-                col += NT;
-                while (col >= width) { col -= width; ++r; }
-            }
-        }
-        __syncthreads();
-        have = have_next;
-    }
-}
-
 struct dposer_body_s {
     dposer_body_desc d;
     int kind;   // 0 SMPL, 1 SMPL-H, 2 SMPL-X
@@ -644,26 +530,11 @@ template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t
     constexpr int NT = 64;
 #endif
     const int lds_floats = NT * ((a.n_out * 3) | 1);
-    if (a.n_out == 22 && Kin::J >= 22 && !a.pf && !a.rel) {     // joints-only body query (the hot case): lean specialisation
-        // streaming form when one pose segment dominates (the body pose): persistent blocks, next tile prefetched into registers
-        static const bool stream_off = [] { const char* e = getenv("DPOSER_FK_STREAM"); return e && e[0] == '0'; }();
-        int ps = -1;
-        for (int sg = 0; sg < a.nseg; ++sg)
-            if (a.seg[sg] && a.seg_first[sg] + a.seg_joints[sg] <= a.n_out && a.seg_joints[sg] * 3 <= 72 && (a.seg_joints[sg] * 3 * NT) % 4 == 0 &&
-                ((uintptr_t)a.seg[sg] & 15) == 0 && (ps < 0 || a.seg_joints[sg] > a.seg_joints[ps]))
-                ps = sg;
-        const int64_t n_tiles = ceil_div(a.B, NT);
-        static const int resident = [] {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            return cus * 8;                                     // 2 waves per SIMD (register-limited), 8 x 17 KB of LDS per CU
-        }();
-        if (ps >= 0 && !stream_off && n_tiles > resident) {
-            hipLaunchKernelGGL((k_fk_joints_stream<Kin, NT, 22>), dim3((unsigned)resident), dim3(NT), lds_floats * sizeof(float), st, a, ps, n_tiles);
-            return hipGetLastError();
-        }
+    // (a persistent variant that prefetches the next pose tile into registers while the chain runs was measured 13-20 % SLOWER --
+    //  6.1 vs 7.1 G poses/s at 2^20 poses, 6.6 vs 8.3 at 2^22: 256 VGPRs with spills; tools/experimental/fk_stream.md)
+    if (a.n_out == 22 && Kin::J >= 22 && !a.pf && !a.rel)       // joints-only body query (the hot case): lean specialisation
         hipLaunchKernelGGL((k_fk_joints<Kin, NT, 22>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
-    } else
+    else
         hipLaunchKernelGGL((k_fk_joints<Kin, NT>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
     return hipGetLastError();
 }

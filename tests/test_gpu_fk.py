@@ -482,11 +482,9 @@ def test_smpl_and_smplh_wrappers_vs_oracle(model_type):
     assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0
 
 
-def test_streaming_fk_kernel_matches_the_one_tile_kernel(bm):
-    """From 131072 poses up the joints-only body query runs as persistent blocks that prefetch the next pose tile into registers
-    (k_fk_joints_stream): the same arithmetic in the same order, so its joints must be bit-identical to the one-tile-per-block
-    kernel (which serves the same poses when they arrive in smaller calls) -- ragged tail, translation and root orientation
-    included."""
+def test_fk_large_batch_equals_the_same_poses_in_smaller_calls(bm):
+    """300003 poses in one call (4688 single-wave blocks, ragged tail) vs the same poses in three calls: bit-identical joints,
+    translation and root orientation included."""
     n = 300_003
     g = torch.Generator(device=DEV).manual_seed(3)
     pose = torch.randn(n, 63, device=DEV, generator=g) * 0.4
