@@ -723,3 +723,209 @@ template <typename T> struct EpiWgrad {
             }
     }
 };
+
+// ----------------------------------------------------------------------------------------------
+// GroupNorm with 16 or 64 channels per group (hidden_dim 512 / 2048 under nn.GroupNorm(32, H), model.py:112)
+// ----------------------------------------------------------------------------------------------
+// EpiGN / EpiGNBwd above are the shipped hidden_dim = 1024 case: one 32x32 accumulator tile IS one group.  These generic forms
+// cover the neighbouring sizes with the same register layout:
+//   GS = 16: a tile holds TWO groups -- registers 0..7 of both lane halves are channels 0..15, registers 8..15 are 16..31 -- so
+//            every statistic exists twice per tile and still needs one lane^32 exchange each;
+//   GS = 64: a group spans the two adjacent 32-channel tiles (2k, 2k+1) of a wave, whose accumulators live in the same lane:
+//            sums run over both tiles before the exchange.
+// No residual / operand prefetch here: these sizes are not the benchmark configuration; correctness and the same fusion matter.
+struct GnAuxG { float rstd[2]; uint32_t keep; uint32_t pad; };   // GS = 16: rstd of both groups; GS = 64: rstd[0]
+
+template <typename T, bool TRAIN, int GS> struct EpiGNG {
+    static_assert(GS == 16 || GS == 64, "generic GroupNorm epilogue: 16 or 64 channels per group");
+    typedef GNParams Params;                  // (aux points at GnAuxG records)
+    static constexpr int kScratchPerWave = TRAIN ? TileT<T>::SCRATCH_BYTES : 0;
+    static constexpr int kParamArrays = 3;
+    static constexpr int NT = GS == 64 ? 2 : 1;          // tiles per statistics set
+    static constexpr int NG = GS == 16 ? 2 : 1;          // groups per statistics set
+    __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.bias : (a == 1 ? p.gamma : p.beta); }
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
+        static_assert(TC % NT == 0, "a 64-channel group needs both of its tiles in one wave");
+        constexpr bool PRECISE = sizeof(T) == 4;
+        const int j = lane & 31, hi = lane >> 5;
+        T* out = (T*)pp.out;
+        const T* resid = (const T*)pp.resid;
+        T* xhat = (T*)pp.xhat;
+        GnAuxG* aux = reinterpret_cast<GnAuxG*>(pp.aux);
+        const bool drop = TRAIN && pp.drop.p > 0.f;
+#pragma unroll
+        for (int ts = 0; ts < TS; ++ts) {
+            const int64_t s = sbase + ts * 32 + j;
+#pragma unroll
+            for (int t0 = 0; t0 < TC; t0 += NT) {
+                float v[NT][16];
+                float sum[NG] = {};
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(lpar + (t0 + u) * 32 + 8 * q + 4 * hi);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[u][4 * q + r] = acc[t0 + u][ts][4 * q + r] + b4[r];
+                            sum[GS == 16 ? (q >> 1) : 0] += v[u][4 * q + r];
+                        }
+                    }
+                float mean[NG], rstd[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) mean[g] = sum_xor32(sum[g]) * (1.0f / GS);
+                float ss[NG] = {};
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int g = GS == 16 ? (i >> 3) : 0;
+                        v[u][i] -= mean[g];
+                        ss[g] += v[u][i] * v[u][i];
+                    }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float var = sum_xor32(ss[g]) * (1.0f / GS);
+                    rstd[g] = PRECISE ? 1.0f / sqrtf(var + 1e-5f) : rsqrtf(var + 1e-5f);
+                }
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const int c0 = cbase + (t0 + u) * 32;
+                    const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, pp.H);
+                    float keep[16];
+                    uint32_t bits = 0xffffu;
+                    if (drop) bits = dropout_mask16_bits(pp.drop, s, c0 >> 5, hi, keep);
+                    if (TRAIN) {
+                        GnAuxG rec = {{rstd[0], rstd[NG - 1]}, bits, 0u};
+                        aux[gn_aux_index(sbase + ts * 32, c0 >> 5, pp.H, lane)] = rec;
+                    }
+                    float o[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cl = (t0 + u) * 32 + 8 * q + 4 * hi;
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
+                        const f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + 2 * lstride + cl);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 4 * q + r;
+                            v[u][i] *= rstd[GS == 16 ? (i >> 3) : 0];                         // x_hat
+                            float y = silu_f<PRECISE>(g4[r] * v[u][i] + e4[r]);
+                            if (drop) y *= keep[i];
+                            o[i] = y;
+                        }
+                    }
+                    if (TRAIN) TileIO<T>::store(xhat + tb, lane, v[u]);
+                    if (resid) {
+                        float rr[16];
+                        TileIO<T>::load(resid + tb, lane, rr);
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) o[i] += rr[i];
+                    }
+                    TileIO<T>::store(out + tb, lane, o);
+                    if (TRAIN && pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, o);
+                }
+            }
+        }
+    }
+};
+
+template <typename T, int GS> struct EpiGNBwdG {
+    static_assert(GS == 16 || GS == 64, "generic GroupNorm-backward epilogue: 16 or 64 channels per group");
+    typedef GNBwdParams Params;               // (aux points at GnAuxG records)
+    static constexpr int kScratchPerWave = TileT<T>::SCRATCH_BYTES;
+    static constexpr int kParamArrays = 2;
+    static constexpr int NT = GS == 64 ? 2 : 1;
+    static constexpr int NG = GS == 16 ? 2 : 1;
+    __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.gamma : p.beta; }
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int, const float* lpar, int lstride, unsigned char* scr) {
+        static_assert(TC % NT == 0, "a 64-channel group needs both of its tiles in one wave");
+        constexpr bool PRECISE = sizeof(T) == 4;
+        const int j = lane & 31, hi = lane >> 5;
+        const T* carry_in = (const T*)pp.carry_in;
+        T* carry_out = (T*)pp.carry_out;
+        const T* xhat = (const T*)pp.xhat;
+        T* dy = (T*)pp.dy;
+        const GnAuxG* aux = reinterpret_cast<const GnAuxG*>(pp.aux);
+#pragma unroll
+        for (int t0 = 0; t0 < TC; t0 += NT) {
+            float stat[NT][32], dbias[NT][16];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+#pragma unroll
+                for (int r = 0; r < 32; ++r) stat[u][r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dbias[u][r] = 0.f;
+            }
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                const int64_t s = sbase + ts * 32 + j;
+                float xh[NT][16], g[NT][16], rstd[NG];
+                float s1[NG] = {}, s2[NG] = {};
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const int c0 = cbase + (t0 + u) * 32;
+                    const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, pp.H);
+                    const GnAuxG rec = aux[gn_aux_index(sbase + ts * 32, c0 >> 5, pp.H, lane)];
+                    if (u == 0) { rstd[0] = rec.rstd[0]; rstd[NG - 1] = rec.rstd[NG - 1]; }
+                    const uint32_t bits = s < pp.S_valid ? rec.keep : 0u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) g[u][r] = acc[t0 + u][ts][r];
+                    TileIO<T>::load(xhat + tb, lane, xh[u]);
+                    if (carry_in) {
+                        float ci[16];
+                        TileIO<T>::load(carry_in + tb, lane, ci);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) g[u][r] += ci[r];
+                    }
+                    if (carry_out) TileIO<T>::store(carry_out + tb, lane, g[u]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cl = (t0 + u) * 32 + 8 * q + 4 * hi;
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + cl);
+                        const f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 4 * q + r;
+                            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, i, 1);
+                            const float gg = __uint_as_float(__float_as_uint(g[u][i]) & m);
+                            const float da = gg * dsilu_f<PRECISE>(g4[r] * xh[u][i] + e4[r]);
+                            stat[u][i] += da * xh[u][i];
+                            stat[u][16 + i] += da;
+                            g[u][i] = da * (g4[r] * pp.drop_scale);                            // dx
+                            s1[GS == 16 ? (i >> 3) : 0] += g[u][i];
+                            s2[GS == 16 ? (i >> 3) : 0] += g[u][i] * xh[u][i];
+                        }
+                    }
+                }
+                float m1[NG], m2[NG];
+#pragma unroll
+                for (int k = 0; k < NG; ++k) { m1[k] = sum_xor32(s1[k]) * (1.0f / GS); m2[k] = sum_xor32(s2[k]) * (1.0f / GS); }
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const int c0 = cbase + (t0 + u) * 32;
+                    const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, pp.H);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int k = GS == 16 ? (i >> 3) : 0;
+                        g[u][i] = rstd[k] * (g[u][i] - m1[k] - xh[u][i] * m2[k]);              // dy
+                        dbias[u][i] += g[u][i];
+                    }
+                    TileIO<T>::store(dy + tb, lane, g[u]);
+                    if (pp.dyT) TileT<T>::store((T*)pp.dyT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, g[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                butterfly_reduce32(stat[u], lane);
+                const float db = butterfly_reduce16(dbias[u], lane);
+                float* row = pp.part + (int64_t)wrow * 3 * pp.H;
+                const int i = j & 15;
+                const int c = cbase + (t0 + u) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                row[(j >> 4) * pp.H + c] = stat[u][0] * pp.drop_scale;
+                if (j < 16) row[2 * pp.H + c] = db;
+            }
+        }
+    }
+};

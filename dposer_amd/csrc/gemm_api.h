@@ -19,12 +19,13 @@ static inline int shape_ws(int s) { static const int v[] = {4, 2, 1, 4, 1, 2}; r
 
 enum : int { PREC_BF16 = 0, PREC_FP32 = 1 };
 
-hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st);
+// gs = channels per GroupNorm group (hidden_dim / 32): 32 = the shipped tile-per-group epilogues; 16 / 64 = the generic ones (128x128 and 128x32 tilings)
+hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st, int gs = 32);
 hipError_t gemm_bias_silu(int prec, bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st);
 hipError_t gemm_rowmajor(int prec, int shape, const GemmArgs& g, const RowMajorParams& p, hipStream_t st);
 hipError_t gemm_em_step(int prec, int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st);
 hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTParams& p, hipStream_t st);
-hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st);
+hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st, int gs = 32);
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st);
 hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st);
 // bf16, any wgrad tiling (256x256, 128x128, 64x128, 128x64), operands sample-major (gemm_wgrad_tr.h): no transposed activation copies needed

@@ -91,8 +91,30 @@ static hipError_t by_shape_masked(int shape, const GemmArgs& g, const typename E
 
 constexpr unsigned M_MAIN = M_BIG | M_MID | M_SMALL;
 
-hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st) {
+// GroupNorm group sizes 16 / 64 (generic epilogues): 128x128 (wave tile 64 channels: both tiles of a 64-channel group) and 128x32
+// (four waves of one tile for GS = 16, two waves of two tiles for GS = 64)
+template <typename T, typename Epi, bool PAIR>
+static hipError_t by_shape_generic(int shape, const GemmArgs& g, const typename Epi::Params& p, hipStream_t st) {
+    if (shape == SHAPE_MID) return launch_gemm<T, 2, 2, 2, 2, RING_KB, Epi, RING_NB>(g, p, st);
+    if (shape == SHAPE_SMALL) {
+        if constexpr (PAIR) return launch_gemm<T, 2, 1, 2, 1, 4, Epi>(g, p, st);
+        else return launch_gemm<T, 4, 1, 1, 1, 4, Epi>(g, p, st);
+    }
+    return hipErrorInvalidConfiguration;
+}
+#define DISPATCH_GS(EPI, GS)                                                                                       \
+    return prec == PREC_FP32 ? by_shape_generic<float, EPI(float, GS), (GS) == 64>(shape, g, p, st)                \
+                             : by_shape_generic<__bf16, EPI(__bf16, GS), (GS) == 64>(shape, g, p, st)
+
+hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st, int gs) {
     PROF(train ? EPI_GN_TRAIN : EPI_GN);
+    if (gs != 32) {
+#define E_TRAIN(T, GS) EpiGNG<T, true, GS>
+#define E_INFER(T, GS) EpiGNG<T, false, GS>
+        if (gs == 16) { if (train) { DISPATCH_GS(E_TRAIN, 16); } DISPATCH_GS(E_INFER, 16); }
+        if (gs == 64) { if (train) { DISPATCH_GS(E_TRAIN, 64); } DISPATCH_GS(E_INFER, 64); }
+        return hipErrorInvalidConfiguration;
+    }
     if (train) { typedef EpiGN<__bf16, true> A; typedef EpiGN<float, true> B; DISPATCH(A, B, M_MAIN); }
     typedef EpiGN<__bf16, false> A; typedef EpiGN<float, false> B; DISPATCH(A, B, M_MAIN);
 }
@@ -113,8 +135,14 @@ hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTPa
     PROF(EPI_PLAIN_FT);
     typedef EpiPlainFT<__bf16> A; typedef EpiPlainFT<float> B; DISPATCH(A, B, M_MAIN);
 }
-hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st) {
+hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st, int gs) {
     PROF(EPI_GN_BWD);
+    if (gs != 32) {
+#define E_BWD(T, GS) EpiGNBwdG<T, GS>
+        if (gs == 16) { DISPATCH_GS(E_BWD, 16); }
+        if (gs == 64) { DISPATCH_GS(E_BWD, 64); }
+        return hipErrorInvalidConfiguration;
+    }
     typedef EpiGNBwd<__bf16> A; typedef EpiGNBwd<float> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st) {

@@ -46,6 +46,7 @@ struct LayerOff {
 struct dposer_scorefc_s {
     dposer_scorefc_desc d;
     int D, Dpad, H, E, L, Cp;
+    int gs;                    // channels per GroupNorm group = H / 32
     bool f32;
     int esz, KBS;
     std::vector<int64_t> toff, tnum;
@@ -77,9 +78,9 @@ static PackJob mk_job(int64_t dst_off, int64_t src_off, int ktot, int koff, int 
 
 extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_scorefc_t* out) {
     DP_CHECK_ARG(desc && out, "null argument");
-    DP_CHECK_ARG(desc->hidden_dim == 1024,
-                 "hidden_dim must be 1024: nn.GroupNorm(32, H) has H/32 channels per group and the MFMA epilogue fuses exactly one "
-                 "32-channel accumulator tile per group");
+    DP_CHECK_ARG(desc->hidden_dim == 512 || desc->hidden_dim == 1024 || desc->hidden_dim == 2048,
+                 "hidden_dim must be 512, 1024 or 2048: nn.GroupNorm(32, H) has H/32 channels per group and the fused MFMA "
+                 "epilogues cover groups of 16, 32 (one accumulator tile per group, the shipped configuration) and 64 channels");
     DP_CHECK_ARG(desc->embed_dim > 0 && desc->embed_dim % 128 == 0, "embed_dim must be a multiple of 128");
     DP_CHECK_ARG(desc->n_blocks >= 1 && desc->n_blocks <= 3, "n_blocks must be 1..3");
     DP_CHECK_ARG(desc->data_dim > 0 && desc->data_dim <= 512, "data_dim must be in 1..512");
@@ -91,6 +92,7 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
     h->Dpad = (int)round_up(h->D, 64);
     h->Cp = h->Dpad;
     h->H = desc->hidden_dim;
+    h->gs = desc->hidden_dim / 32;
     h->E = desc->embed_dim;
     h->L = 1 + 2 * desc->n_blocks;
     h->f32 = desc->precision == DPOSER_PREC_FP32;
@@ -209,17 +211,17 @@ extern "C" int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat, void* 
 static int64_t pad_batch(int64_t B) { return B <= 512 ? round_up(B, 64) : round_up(B, 256); }
 // `channels` = output channels of the GEMM (H = 1024 for the GroupNorm layers, E for the time branch): the 256x256 tiling
 // needs them to be a multiple of 256 (embed_dim may be any multiple of 128).
-static int main_shape(int64_t Spad, int channels = 1024) {
+static int main_shape(int64_t Spad, int channels = 1024, int gs = 32) {
     static const int64_t big_min = [] { const char* e = getenv("DPOSER_BIG_MIN_BATCH"); return e ? atoll(e) : (int64_t)16384; }();
-    if (Spad % 256 == 0 && Spad >= big_min && channels % 256 == 0) return SHAPE_BIG;
+    if (gs == 32 && Spad % 256 == 0 && Spad >= big_min && channels % 256 == 0) return SHAPE_BIG;   // (generic group sizes: 128-wide tilings)
     if (Spad % 128 == 0) return SHAPE_MID;
     return SHAPE_SMALL;
 }
 // GroupNorm-backward dgrad: the register-lean epilogue fits the 256x256 tile in 248 VGPRs without spilling; it wins from
 // 32768 samples up (227 vs 257 us at 65536, 2.52 vs 2.59 ms per step at 32768, a tie at 16384).  DPOSER_GNBWD_BIG = 0 / 1 forces it.
-static int gnbwd_shape(int64_t Spad) {
+static int gnbwd_shape(int64_t Spad, int gs = 32) {
     static const int forced = [] { const char* e = getenv("DPOSER_GNBWD_BIG"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
-    const bool big = forced >= 0 ? forced == 1 : Spad >= 32768;
+    const bool big = gs == 32 && (forced >= 0 ? forced == 1 : Spad >= 32768);
     if (big && Spad % 256 == 0) return SHAPE_BIG;
     return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL;
 }
@@ -309,7 +311,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
             w.hbuf[l] = take(Bpad * H * esz);
             w.xhat[l] = take(Bpad * H * esz);
             w.dy[l] = take(Bpad * H * esz);
-            w.aux[l] = (GnAux*)take((Bpad / 32) * (H / 32) * 64 * (int64_t)sizeof(GnAux));
+            w.aux[l] = (GnAux*)take((Bpad / 32) * (H / 32) * 64 * (int64_t)(h->gs == 32 ? sizeof(GnAux) : sizeof(GnAuxG)));
             w.gn_part[l] = (float*)take((Bpad / 32) * 3 * (int64_t)H * 4);
         }
         w.carry[0] = take(Bpad * H * esz);
@@ -400,7 +402,7 @@ static DropoutCfg drop_cfg(const dposer_scorefc_s* h, bool train, int site, uint
 static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* packed, int l, const void* in, const void* temb,
                         const float* bias_row, void* out, const void* resid, void* xhat, GnAux* aux, bool train,
                         int64_t Bpad, uint64_t seed, uint32_t step, hipStream_t st) {
-    const int shape = main_shape(Bpad);
+    const int shape = main_shape(Bpad, h->H, h->gs);
     const LayerOff& lo = h->layer[l];
     const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
     g_next_flops = 2.0 * (double)g_alg_batch * h->H * (lo.kin + (temb ? h->E : 0));
@@ -419,7 +421,7 @@ static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* pack
     p.outT = nullptr;
     p.Spad = Bpad;
     p.drop = drop_cfg(h, train, l, seed, step);
-    DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, train, shape, g, p, st));
+    DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, train, shape, g, p, st, h->gs));
     return DPOSER_OK;
 }
 
@@ -827,7 +829,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[l - 2] : nullptr;
         // TRAIN epilogue keeps xhat and the GnAux records (rstd, dropout decisions); dropout only when the module is in train() mode
         const LayerOff& lo = h->layer[l];
-        const int shape = main_shape(w.Bpad);
+        const int shape = main_shape(w.Bpad, h->H, h->gs);
         const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
         g_next_flops = 2.0 * (double)B * h->H * (lo.kin + h->E);
         GemmArgs g = gemm_args(packed + h->pk_wl[l], kx + ke, h->H / (shape_ct(shape) * 32), (int)(w.Bpad / (shape_st(shape) * 32)));
@@ -838,7 +840,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         p.gamma = flat + lo.gamma; p.beta = flat + lo.beta; p.out = w.hbuf[l]; p.resid = resid; p.xhat = w.xhat[l]; p.aux = w.aux[l];
         p.H = h->H; p.drop = drop_cfg(h, dropout_on, l, seed, step);
         p.outT = tr ? nullptr : w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
-        DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, true, shape, g, p, st));
+        DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, true, shape, g, p, st, h->gs));
     }
     return run_post(h, flat, packed, w.hbuf[L - 1], w.res, B, w.Bpad, st);
 }
@@ -957,7 +959,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
             DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.hT[L - 1], H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, sw));
         }
     }
-    const int gshape = gnbwd_shape(Bpad);
+    const int gshape = gnbwd_shape(Bpad, h->gs);
     const int ws_rows = (int)(Bpad / (shape_st(gshape) * 32)) * shape_ws(gshape);   // partial rows written by the dgrad epilogue
     for (int j = L - 1; j >= 0; --j) {
         // gradient w.r.t. the output of GN layer j, through the layer that consumes it
@@ -975,7 +977,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B;
         p.drop_scale = (dropout_on && h->d.dropout_p > 0.f) ? 1.0f / (1.0f - h->d.dropout_p) : 1.0f;   // the decisions themselves come from the forward pass (GnAux)
         p.dyT = (want_w && !tr) ? w.dyT[j] : nullptr; p.Spad = Bpad;
-        DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st));
+        DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st, h->gs));
         if (!want_w) continue;
         if (two) {
             DP_CHECK_HIP(hipEventRecord(h->ev_layer[j], st));

@@ -680,13 +680,18 @@ def test_vp_sde_fused_paths_vs_oracle():
             assert rel_err(t2n(fg[off:off + gr.numel()]), gr.reshape(-1).numpy()) < 3e-4, n
 
 
-@pytest.mark.parametrize("n_blocks,E,n_poses,pose_dim,sbs", [(1, 512, 21, 3, True), (3, 256, 21, 3, True), (1, 128, 21, 3, True),
-                                                            (2, 512, 16, 4, True), (2, 512, 32, 4, False), (2, 384, 40, 5, True),
-                                                            (2, 512, 1, 3, True), (2, 512, 50, 3, True), (2, 512, 55, 6, True)])
-def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sbs):
-    """ScoreModelFC configurations other than the shipped one (2 blocks, embed 512, D = 63, scale_by_sigma): depth (residual-carry
-    logic, bucket layout), embedding width, data dimensions that are / are not multiples of the 64-column padding (64, 128, 150, 200, 330, 3)
-    and scale_by_sigma off.  Forward, sampler step and all gradients vs the oracle (general, pinned at the shipped shape)."""
+@pytest.mark.parametrize("n_blocks,E,n_poses,pose_dim,sbs,H,B", [
+    (1, 512, 21, 3, True, 1024, 200), (3, 256, 21, 3, True, 1024, 200), (1, 128, 21, 3, True, 1024, 200), (2, 512, 16, 4, True, 1024, 200),
+    (2, 512, 32, 4, False, 1024, 200), (2, 384, 40, 5, True, 1024, 200), (2, 512, 1, 3, True, 1024, 200), (2, 512, 50, 3, True, 1024, 200),
+    (2, 512, 55, 6, True, 1024, 200),
+    # hidden_dim 512 / 2048: GroupNorm(32, H) groups of 16 / 64 channels (generic epilogues), on the 128x128 (B = 200 -> 256 rows) and
+    # the 128x32 tiling (B = 150 -> 192 rows)
+    (2, 512, 21, 3, True, 512, 200), (2, 512, 21, 3, True, 512, 150), (2, 256, 21, 6, True, 2048, 200), (1, 512, 21, 3, True, 2048, 150)])
+def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sbs, H, B):
+    """ScoreModelFC configurations other than the shipped one (2 blocks, embed 512, D = 63, hidden 1024, scale_by_sigma): depth
+    (residual-carry logic, bucket layout), embedding width, hidden width (GroupNorm group size), data dimensions that are / are
+    not multiples of the 64-column padding (64, 128, 150, 200, 330, 3) and scale_by_sigma off.  Forward, sampler step and all
+    gradients vs the oracle (general, pinned at the shipped shape)."""
     from dposer_amd.algorithms.advanced import losses, sampling, sde_lib
     from dposer_amd.algorithms.advanced.model import ScoreModelFC
     from dposer_amd.configs import load_config
@@ -695,7 +700,7 @@ def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sb
     cfg.model.scale_by_sigma = sbs
     D = n_poses * pose_dim
     torch.manual_seed(n_blocks + D)
-    m = ScoreModelFC(cfg, n_poses=n_poses, pose_dim=pose_dim, hidden_dim=1024, embed_dim=E, n_blocks=n_blocks)
+    m = ScoreModelFC(cfg, n_poses=n_poses, pose_dim=pose_dim, hidden_dim=H, embed_dim=E, n_blocks=n_blocks)
     with torch.no_grad():
         for q in m.parameters():                     # default init has zero biases / unit gains in places: make every tensor matter
             q.add_(0.05 * torch.randn_like(q))
@@ -705,7 +710,6 @@ def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sb
     p["sigmas"] = R.sigma_table()
     assert len(m._engine().grad_buckets) == 1 + 2 * n_blocks
     rs = np.random.RandomState(n_blocks)
-    B = 200
     x = rs.standard_normal((B, D)).astype(np.float32)
     t = rs.uniform(1e-3, 1.0, B).astype(np.float32)
     z = rs.standard_normal((B, D)).astype(np.float32)
@@ -750,6 +754,43 @@ def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sb
         ref_l, ref_g = R.dposer_prior_loss(p, R.SubVP(), torch.tensor(x), torch.full((B,), tt), torch.tensor(z), weighted=weighted, **fw)
         assert abs(float(lp) - ref_l.item()) / abs(ref_l.item()) < 2e-4
         assert rel_err(t2n(x0.grad), ref_g.numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("H", [512, 2048])
+def test_inkernel_dropout_with_other_group_sizes_vs_oracle(H):
+    """Training step pieces at hidden_dim 512 / 2048 with dropout drawn in-kernel: the forward epilogue hands the decisions to
+    the backward epilogue in the wider aux record; loss and every gradient vs the oracle fed the same Philox masks."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.advanced.model import ScoreModelFC
+    from dposer_amd.configs import load_config
+    cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+    cfg.model.dropout = 0.25
+    torch.manual_seed(H)
+    m = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=H, embed_dim=512, n_blocks=2)
+    with torch.no_grad():
+        for q in m.parameters():
+            q.add_(0.05 * torch.randn_like(q))
+    m.precision = "fp32"
+    m.to(DEV).train()
+    p = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    p["sigmas"] = R.sigma_table()
+    B, seed, step = 320, 5, 11
+    x = np.random.RandomState(1).standard_normal((B, 63)).astype(np.float32)
+    fg = torch.zeros(m._num_flat, device=DEV)
+    l = losses.fused_dsm_grad(m, sde_lib.subVPSDE(0.1, 20.0, 1000), _dev(x), flat_grad=fg, seed=seed, step=step)
+    t = torch.tensor(PH.uniform_t(B, step, seed))
+    z = torch.tensor(PH.normal_matrix(B, 63, PH.STREAM_TRAIN_Z, step, seed))
+    masks = [torch.tensor(PH.dropout_keep_mask(B, H, site, step, seed, 0.25)) for site in range(5)]
+    names = R.param_names()
+    leaves = {n: p[n].clone().requires_grad_(True) for n in names}
+    full = dict(p)
+    full.update(leaves)
+    ref = R.dsm_loss(full, R.SubVP(), torch.tensor(x), t, z, drop_masks=masks, drop_p=0.25)
+    grads = torch.autograd.grad(ref, [leaves[n] for n in names], allow_unused=True)
+    assert abs(float(l) - ref.item()) / ref.item() < 5e-5
+    for n, gr, off in zip(names, grads, m._offsets):
+        if gr is not None:
+            assert rel_err(t2n(fg[off:off + gr.numel()]), gr.reshape(-1).numpy()) < 3e-4, n
 
 
 def test_completion_sampler_inkernel_imputation_noise_matches_oracle():
