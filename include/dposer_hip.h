@@ -50,7 +50,7 @@ enum { DPOSER_SDE_SUBVP = 0, DPOSER_SDE_VP = 1 };
 
 typedef struct {
     int32_t data_dim;        /* n_poses * pose_dim: 63 (axis-angle) or 126 (rot6d), 1..512  model.py:109 */
-    int32_t hidden_dim;      /* must be a multiple of 1024 (GroupNorm(32, H) groups of 32 channels) */
+    int32_t hidden_dim;      /* 512, 1024 (the shipped configuration) or 2048: GroupNorm(32, H) groups of 16 / 32 / 64 channels  model.py:112 */
     int32_t embed_dim;       /* multiple of 128 */
     int32_t n_blocks;        /* 1..3 */
     int32_t embedding;       /* DPOSER_EMB_*      config.model.embedding_type  model.py:116-122 */

@@ -219,8 +219,15 @@ def test_capi_handle_layout_and_error_codes():
     with pytest.raises(_C.DPoserHipError, match="hidden_dim"):
         _C.check(rc, "dposer_scorefc_create")
     assert lib.dposer_scorefc_create(None, C.byref(h)) < 0
-    wide = _C.ScoreFCDesc(63, 2048, 512, 2, _C.EMB_POSITIONAL, 1, 1000, _C.PREC_BF16, 0.1)       # GroupNorm(32, 2048) = 64-channel groups
-    assert lib.dposer_scorefc_create(C.byref(wide), C.byref(h)) < 0 and b"hidden_dim" in lib.dposer_last_error()
+    for width, ok in ((256, False), (512, True), (2048, True), (4096, False)):            # GroupNorm(32, H): groups of 16 / 32 / 64 channels are built
+        d = _C.ScoreFCDesc(63, width, 512, 2, _C.EMB_POSITIONAL, 1, 1000, _C.PREC_BF16, 0.1)
+        hh = C.c_void_p()
+        rc = lib.dposer_scorefc_create(C.byref(d), C.byref(hh))
+        assert (rc == 0) == ok, width
+        if ok:
+            lib.dposer_scorefc_destroy(hh)
+        else:
+            assert b"hidden_dim" in lib.dposer_last_error()
 
     good = _C.ScoreFCDesc(63, 1024, 512, 2, _C.EMB_POSITIONAL, 1, 1000, _C.PREC_BF16, 0.1)
     assert lib.dposer_scorefc_create(C.byref(good), C.byref(h)) == 0

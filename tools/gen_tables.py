@@ -5,7 +5,7 @@ Run in the build container only (imports /root/reference read-only):  python too
 Sources: lib/body_model/constants.py:34-131 (JOINT_NAMES, JOINT_MAP, flip permutations, selectors),
 lib/body_model/utils.py:11-61 (BODY_JOINT_NAMES, BodyPartIndices, BodySegIndices from
 smplx_vert_segmentation.json), :68-177 (smpl_to_openpose), :180-205 (get_smpl_skeleton),
-lib/body_model/smpl.py:55-57 (SMPL-X OpenPose joint list).  tests/test_tables.py pins the result
+lib/body_model/smpl.py:55-57 (SMPL-X OpenPose joint list).  tests/test_host_cpu.py (test_index_tables_bit_exact and neighbours, golden g9) pins the result
 bit-exactly against tests/golden/g9_tables.npz.
 """
 import json
