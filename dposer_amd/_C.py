@@ -86,6 +86,8 @@ SIGNATURES = {
     "dposer_profile_kind_name": (None, [i32, C.c_char_p, i32]),
     "dposer_rot6d_to_rotmat": (C.c_int, [vp, vp, i64, vp]),
     "dposer_rodrigues": (C.c_int, [vp, vp, i64, vp]),
+    "dposer_rot6d_to_axis_angle": (C.c_int, [vp, vp, i64, vp]),
+    "dposer_rotmat_to_axis_angle": (C.c_int, [vp, vp, i64, vp]),
     "dposer_body_create": (C.c_int, [C.POINTER(BodyDesc), C.POINTER(i32), C.POINTER(vp)]),
     "dposer_body_destroy": (None, [vp]),
     "dposer_shape_blend_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, vp]),

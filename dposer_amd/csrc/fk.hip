@@ -144,6 +144,73 @@ __global__ void __launch_bounds__(256) k_rot6d(const float* __restrict__ in, flo
     stream_out<256>(out, lds, item0, n, 9);
 }
 
+// Rotation matrix -> axis-angle through the unit quaternion: the route torchgeometry.rotation_matrix_to_angle_axis takes
+// (rotation_matrix_to_quaternion, quaternion_to_angle_axis), which lib/utils/transforms.py:197-224 calls for rot6d -> axis-angle.
+// Component magnitudes from the diagonal, signs from the antisymmetric part, angle = 2 atan2(|q_xyz|, q_w) in [0, pi];
+// NaNs are zeroed as transforms.py:223 does.  FROM6D: Gram-Schmidt of the 6-D representation first (k_rot6d), one kernel.
+__device__ __forceinline__ void rotmat_to_aa(const float (&m)[9], float (&aa)[3]) {
+    const float t = m[0] + m[4] + m[8];
+    const float qw = sqrtf(fmaxf(1.0f + t, 1e-12f)) * 0.5f;
+    float qx = sqrtf(fmaxf(1.0f + m[0] - m[4] - m[8], 1e-12f)) * 0.5f;
+    float qy = sqrtf(fmaxf(1.0f - m[0] + m[4] - m[8], 1e-12f)) * 0.5f;
+    float qz = sqrtf(fmaxf(1.0f - m[0] - m[4] + m[8], 1e-12f)) * 0.5f;
+    qx = copysignf(qx, m[7] - m[5]);
+    qy = copysignf(qy, m[2] - m[6]);
+    qz = copysignf(qz, m[3] - m[1]);
+    const float sin_half = sqrtf(qx * qx + qy * qy + qz * qz);
+    const float angle = 2.0f * atan2f(sin_half, qw);
+    const float k = sin_half > 1e-8f ? angle / fmaxf(sin_half, 1e-8f) : 2.0f;
+    aa[0] = qx * k; aa[1] = qy * k; aa[2] = qz * k;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (aa[i] != aa[i]) aa[i] = 0.f;
+}
+template <bool FROM6D> __global__ void __launch_bounds__(256) k_to_axis_angle(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+    constexpr int W = FROM6D ? 6 : 9;
+    __shared__ float lds[256 * (W | 1)];
+    const int64_t item0 = (int64_t)blockIdx.x * 256;
+    stream_in<256>(in, lds, item0, n, W);
+    __syncthreads();
+    const float* r = lds + threadIdx.x * (W | 1);
+    float m[9];
+    if constexpr (FROM6D) {
+        const float a1x = r[0], a2x = r[1], a1y = r[2], a2y = r[3], a1z = r[4], a2z = r[5];
+        const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+        const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+        const float d = b1x * a2x + b1y * a2y + b1z * a2z;
+        const float ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
+        const float n2 = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
+        const float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
+        m[0] = b1x; m[1] = b2x; m[2] = b1y * b2z - b1z * b2y;
+        m[3] = b1y; m[4] = b2y; m[5] = b1z * b2x - b1x * b2z;
+        m[6] = b1z; m[7] = b2z; m[8] = b1x * b2y - b1y * b2x;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) m[i] = r[i];
+    }
+    __syncthreads();
+    float aa[3];
+    rotmat_to_aa(m, aa);
+    float* o = lds + threadIdx.x * 3;
+    o[0] = aa[0]; o[1] = aa[1]; o[2] = aa[2];
+    __syncthreads();
+    stream_out<256>(out, lds, item0, n, 3);
+}
+extern "C" int dposer_rotmat_to_axis_angle(const float* rotmat, float* axis_angle, int64_t n, void* stream) {
+    DP_CHECK_ARG(rotmat && axis_angle && n >= 0, "bad argument");
+    if (n == 0) return DPOSER_OK;
+    hipLaunchKernelGGL(k_to_axis_angle<false>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, rotmat, axis_angle, n);
+    FK_HIP_LAUNCH(hipGetLastError());
+    return DPOSER_OK;
+}
+extern "C" int dposer_rot6d_to_axis_angle(const float* rot6d, float* axis_angle, int64_t n, void* stream) {
+    DP_CHECK_ARG(rot6d && axis_angle && n >= 0, "bad argument");
+    if (n == 0) return DPOSER_OK;
+    hipLaunchKernelGGL(k_to_axis_angle<true>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, rot6d, axis_angle, n);
+    FK_HIP_LAUNCH(hipGetLastError());
+    return DPOSER_OK;
+}
+
 extern "C" int dposer_rodrigues(const float* aa, float* rotmat, int64_t n, void* stream) {
     DP_CHECK_ARG(aa && rotmat && n >= 0, "bad argument");
     if (n == 0) return DPOSER_OK;

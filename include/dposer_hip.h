@@ -236,6 +236,11 @@ int dposer_rot6d_to_rotmat(const float* rot6d, float* rotmat, int64_t n, void* s
 /* batch_rodrigues -- smplx/lbs.py: axis-angle [n, 3] -> rotmat [n, 3, 3] */
 int dposer_rodrigues(const float* axis_angle, float* rotmat, int64_t n, void* stream);
 
+/* rot6d_to_axis_angle -- lib/utils/transforms.py:197-224 (Gram-Schmidt, then torchgeometry.rotation_matrix_to_angle_axis:
+ * matrix -> unit quaternion -> angle-axis with the angle in [0, pi]; NaNs zeroed as :223); also from a rotation matrix [n, 3, 3] */
+int dposer_rot6d_to_axis_angle(const float* rot6d, float* axis_angle, int64_t n, void* stream);
+int dposer_rotmat_to_axis_angle(const float* rotmat, float* axis_angle, int64_t n, void* stream);
+
 typedef struct dposer_body_s* dposer_body_t;
 typedef struct {
     int32_t num_joints;      /* 24 SMPL / 52 SMPL-H / 55 SMPL-X */

@@ -497,3 +497,35 @@ def test_fk_large_batch_equals_the_same_poses_in_smaller_calls(bm):
             sub = {k: v[lo:lo + 100_000].contiguous() for k, v in kw.items()}
             parts.append(bm.fk_joints(pose[lo:lo + 100_000].contiguous(), **sub))
         assert torch.equal(big, torch.cat(parts))
+
+
+# ------------------------------------------------------------------------------------------------
+# rotation conversions against scipy.spatial.transform.Rotation (independent implementation; torchgeometry is absent)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 255, 257, 50000])
+def test_rotation_conversions_vs_scipy(n):
+    from scipy.spatial.transform import Rotation
+    from dposer_amd.utils.transforms import (axis_angle_to_mat3x3, axis_angle_to_rot6d, rot6d_to_axis_angle, rot6d_to_mat3x3,
+                                             rotmat_to_axis_angle)
+    rs = np.random.RandomState(n)
+    aa = rs.standard_normal((n, 3)) * 1.2
+    big = np.linalg.norm(aa, axis=1) > 3.0                    # keep the rotation angle below pi: the vector is then unique
+    aa[big] *= 3.0 / np.linalg.norm(aa[big], axis=1, keepdims=True)
+    aa[0] = 0.0                                               # identity
+    aa = aa.astype(np.float32)
+    Rref = Rotation.from_rotvec(aa.astype(np.float64)).as_matrix()
+    R = t2n(axis_angle_to_mat3x3(torch.tensor(aa, device=DEV)))
+    assert np.abs(R - Rref).max() < 2e-6
+    r6 = axis_angle_to_rot6d(torch.tensor(aa, device=DEV))
+    assert np.abs(t2n(r6).reshape(n, 3, 2) - Rref[:, :, :2]).max() < 2e-6          # first two columns, row-major 3x2
+    assert np.abs(t2n(rot6d_to_mat3x3(r6)) - Rref).max() < 5e-6
+    back = t2n(rotmat_to_axis_angle(torch.tensor(Rref.astype(np.float32), device=DEV)))
+    ref_back = Rotation.from_matrix(Rref).as_rotvec()
+    assert np.abs(back - ref_back).max() < 2e-4                                    # fp32 acos-type conditioning near 0 and pi
+    assert np.abs(t2n(rot6d_to_axis_angle(r6)) - aa).max() < 2e-4                  # round trip axis-angle -> 6D -> axis-angle
+    # a scaled / skewed 6-D input is orthonormalised first (Gram-Schmidt), like transforms.py:227-235
+    noisy = t2n(r6) * 1.7 + rs.standard_normal((n, 6)).astype(np.float32) * 0.05
+    M = t2n(rot6d_to_mat3x3(torch.tensor(noisy, device=DEV))).astype(np.float64)
+    assert np.abs(M @ M.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5 and np.abs(np.linalg.det(M) - 1).max() < 1e-5
+    got = t2n(rot6d_to_axis_angle(torch.tensor(noisy, device=DEV)))
+    assert np.abs(got - Rotation.from_matrix(M).as_rotvec()).max() < 2e-4
