@@ -146,20 +146,30 @@ __global__ void __launch_bounds__(256) k_rot6d(const float* __restrict__ in, flo
 
 // Rotation matrix -> axis-angle through the unit quaternion: the route torchgeometry.rotation_matrix_to_angle_axis takes
 // (rotation_matrix_to_quaternion, quaternion_to_angle_axis), which lib/utils/transforms.py:197-224 calls for rot6d -> axis-angle.
-// Component magnitudes from the diagonal, signs from the antisymmetric part, angle = 2 atan2(|q_xyz|, q_w) in [0, pi];
-// NaNs are zeroed as transforms.py:223 does.  FROM6D: Gram-Schmidt of the 6-D representation first (k_rot6d), one kernel.
+// Quaternion by the four-case rule (pivot on the largest of trace, m00, m11, m22: one square root, the other three components
+// from off-diagonal sums / differences, so a near-zero component keeps full relative accuracy); angle-axis with the sign
+// convention of quaternion_to_angle_axis (q and -q give the same vector, angle in [0, pi]); NaNs zeroed as transforms.py:223.
+// FROM6D: Gram-Schmidt of the 6-D representation first (k_rot6d), one kernel.
 __device__ __forceinline__ void rotmat_to_aa(const float (&m)[9], float (&aa)[3]) {
     const float t = m[0] + m[4] + m[8];
-    const float qw = sqrtf(fmaxf(1.0f + t, 1e-12f)) * 0.5f;
-    float qx = sqrtf(fmaxf(1.0f + m[0] - m[4] - m[8], 1e-12f)) * 0.5f;
-    float qy = sqrtf(fmaxf(1.0f - m[0] + m[4] - m[8], 1e-12f)) * 0.5f;
-    float qz = sqrtf(fmaxf(1.0f - m[0] - m[4] + m[8], 1e-12f)) * 0.5f;
-    qx = copysignf(qx, m[7] - m[5]);
-    qy = copysignf(qy, m[2] - m[6]);
-    qz = copysignf(qz, m[3] - m[1]);
-    const float sin_half = sqrtf(qx * qx + qy * qy + qz * qz);
-    const float angle = 2.0f * atan2f(sin_half, qw);
-    const float k = sin_half > 1e-8f ? angle / fmaxf(sin_half, 1e-8f) : 2.0f;
+    float qw, qx, qy, qz;
+    if (t > 0.f) {
+        const float S = sqrtf(t + 1.0f) * 2.0f;
+        qw = 0.25f * S; qx = (m[7] - m[5]) / S; qy = (m[2] - m[6]) / S; qz = (m[3] - m[1]) / S;
+    } else if (m[0] > m[4] && m[0] > m[8]) {
+        const float S = sqrtf(1.0f + m[0] - m[4] - m[8]) * 2.0f;
+        qw = (m[7] - m[5]) / S; qx = 0.25f * S; qy = (m[1] + m[3]) / S; qz = (m[2] + m[6]) / S;
+    } else if (m[4] > m[8]) {
+        const float S = sqrtf(1.0f + m[4] - m[0] - m[8]) * 2.0f;
+        qw = (m[2] - m[6]) / S; qx = (m[1] + m[3]) / S; qy = 0.25f * S; qz = (m[5] + m[7]) / S;
+    } else {
+        const float S = sqrtf(1.0f + m[8] - m[0] - m[4]) * 2.0f;
+        qw = (m[3] - m[1]) / S; qx = (m[2] + m[6]) / S; qy = (m[5] + m[7]) / S; qz = 0.25f * S;
+    }
+    const float sin2 = qx * qx + qy * qy + qz * qz;
+    const float sn = sqrtf(sin2);
+    const float two_theta = 2.0f * (qw < 0.f ? atan2f(-sn, -qw) : atan2f(sn, qw));
+    const float k = sin2 > 0.f ? two_theta / sn : 2.0f;
     aa[0] = qx * k; aa[1] = qy * k; aa[2] = qz * k;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
