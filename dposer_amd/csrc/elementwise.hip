@@ -446,7 +446,7 @@ struct CompletionDev {
     CompletionUpdateArgs a;
     SdeDev sde;
 };
-template <typename T> __global__ void __launch_bounds__(256) k_completion_update(CompletionDev d) {
+__global__ void __launch_bounds__(256) k_completion_update(CompletionDev d) {
     const CompletionUpdateArgs& a = d.a;
     const float lmc = sde_lmc(d.sde, a.t);
     const float alpha = expf(lmc), sigma = sde_std(d.sde, lmc);      // return_alpha_sigma, sde_lib.py:227-231
@@ -454,57 +454,33 @@ template <typename T> __global__ void __launch_bounds__(256) k_completion_update
     const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, 0) : 1.0f;
     const float snr = alpha / sqrtf(sigma2);                          // completion.py:108
     const float w = a.weighted ? 0.5f * sqrtf(1.0f + snr) : 0.5f;     // completion.py:143-146
-    const bool prep = a.t_next >= 0.f;
-    float mcn = 0.f, sdn = 0.f;
-    if (prep) { const float l2 = sde_lmc(d.sde, a.t_next); mcn = expf(l2); sdn = sde_std(d.sde, l2); }
-    const int qx = a.Dpad >> 2;
-    const int QD = (a.D + 3) >> 2;
-    const int64_t total = a.Bpad * qx;
+    const int64_t total = a.B * a.D;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = i / qx;
-        const int q = (int)(i % qx);
-        const int c0 = q * 4;
-        f32x4 xn = {0.f, 0.f, 0.f, 0.f};
-        if (s < a.B && c0 < a.D) {
-            float n4[4];
-            if (prep && !a.z_next) normals4((uint64_t)s * QD + q, STREAM_PRIOR, a.step_next, a.seed, n4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = c0 + r;
-                if (c >= a.D) continue;
-                const int64_t o = s * a.D + c;
-                const float model = a.res[s * a.Cp + c] / usig;
-                const float score = -model / sigma;                           // utils.py:155,162
-                const float x0h = (a.xt[s * a.Dpad + c] + sigma2 * score) / alpha;   // completion.py:107
-                float x = a.x[o];
-                const float mk = a.mask[o];
-                const float g_prior = ((2.0f * w) * (x - x0h) * a.inv_n) * a.w_prior;
-                const float g_data = (((2.0f * (x * mk - a.obs[o] * mk)) * a.inv_n) * a.w_data) * mk;
-                const float g = g_prior + g_data;
-                float m = a.m[o], v = a.v[o];
-                m = m + (g - m) * a.one_minus_beta1;                          // exp_avg.lerp_(grad, 1 - beta1)
-                v = v * a.beta2 + a.one_minus_beta2 * (g * g);                // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-                const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-                x = x - a.step_size * (m / denom);                            // param.addcdiv_(exp_avg, denom, value=-step_size)
-                a.m[o] = m;
-                a.v[o] = v;
-                a.x[o] = x;
-                if (prep) xn[r] = mcn * x + sdn * (a.z_next ? a.z_next[o] : n4[r]);   // completion.py:134-135 of the next step
-            }
-        }
-        if (prep) {
-            store_quad_ft<T>(a.xin, s, c0, a.Dpad, xn);
-            *reinterpret_cast<f32x4*>(a.xt_out + s * a.Dpad + c0) = xn;
-        }
+        const int64_t s = i / a.D;
+        const int c = (int)(i % a.D);
+        const float model = a.res[s * a.Cp + c] / usig;
+        const float score = -model / sigma;                           // utils.py:155,162
+        const float x0h = (a.xt[s * a.Dpad + c] + sigma2 * score) / alpha;   // completion.py:107
+        float x = a.x[i];
+        const float mk = a.mask[i];
+        const float g_prior = ((2.0f * w) * (x - x0h) * a.inv_n) * a.w_prior;
+        const float g_data = (((2.0f * (x * mk - a.obs[i] * mk)) * a.inv_n) * a.w_data) * mk;
+        const float g = g_prior + g_data;
+        float m = a.m[i], v = a.v[i];
+        m = m + (g - m) * a.one_minus_beta1;                          // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * a.beta2 + a.one_minus_beta2 * (g * g);                // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        x = x - a.step_size * (m / denom);                            // param.addcdiv_(exp_avg, denom, value=-step_size)
+        a.m[i] = m;
+        a.v[i] = v;
+        a.x[i] = x;
     }
 }
 hipError_t launch_completion_update(const CompletionUpdateArgs& a, hipStream_t st) {
     CompletionDev d;
     d.a = a;
     d.sde = make_sde_dev(a.sde);
-    const int64_t total = a.Bpad * (a.Dpad >> 2);
-    if (a.f32) hipLaunchKernelGGL(k_completion_update<float>, dim3(grid_for(total, 256, 2048)), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL(k_completion_update<__bf16>, dim3(grid_for(total, 256, 2048)), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(k_completion_update, dim3(grid_for(a.B * a.D, 256, 2048)), dim3(256), 0, st, d);
     return hipGetLastError();
 }
 

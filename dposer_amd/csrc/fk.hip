@@ -800,10 +800,6 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
         std::memset(&g, 0, sizeof(g));
         g.W = pf; g.w_stride_blocks = Ppad / 8; g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(Cpad / 128); g.ksplit = 1;
         g.src[0] = posedirs_packed; g.seg_kblocks[0] = Ppad / 8; g.nseg = 1; g.ktot_blocks = Ppad / 8;
-        // pose-feature tiles in groups of 8 (2 MB of the [Bpad, 486] fp32 matrix): without it every vertex panel pulls the whole
-        // matrix through L2 again (PMC: 2.1 GB read per 4096 poses against 70 MB of operands)
-        static const int cg = [] { const char* e = getenv("DPOSER_LBS_CGROUP"); return e ? atoi(e) : 8; }();
-        if (cg > 0 && g.n_cblk > cg && g.n_cblk % cg == 0) g.cgroup = cg;
         WgradParams wp;
         wp.slab = offsets; wp.slab_stride = 0; wp.ld = (int)Cpad; wp.N_valid = (int)batch; wp.K_valid = V * 3;
         FK_HIP_LAUNCH(gemm_wgrad(PREC_FP32, SHAPE_MID, g, wp, st));

@@ -35,7 +35,6 @@ struct GemmArgs {
     int ksplit;                     // >1: reduction split over blockIdx.y (wgrad); each split gets
                                     //     seg_kblocks[0]/ksplit k-blocks of the (single) segment
     double alg_flops;               // algorithmic FLOPs of this launch (2*M*N*K on the un-padded problem); profiling only
-    int cgroup;                     // > 0: tile order "channel-block groups of cgroup, sample blocks inside" (see the kernel); 0: off
 };
 
 template <typename T> struct Mma;
@@ -144,17 +143,8 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
         L = xcd_remap(blockIdx.x, ntiles);
         split = blockIdx.y;
     }
-    int cblk = L % g.n_cblk;
-    int sblk = L / g.n_cblk;
-    if (g.cgroup > 0) {
-        // Tall "weight" operands (LBS pose blend: W = pose features of ALL poses, 8 MB, far beyond an XCD's 4 MB L2): walk the
-        // sample blocks inside groups of cgroup channel blocks, so that a group's W panel stays L2-resident while the activation
-        // panels stream past it once per group -- instead of re-fetching all of W for every activation panel.
-        const int per = g.cgroup * g.n_sblk;
-        const int grp = L / per, rem = L % per;
-        sblk = rem / g.cgroup;
-        cblk = grp * g.cgroup + rem % g.cgroup;
-    }
+    const int cblk = L % g.n_cblk;
+    const int sblk = L / g.n_cblk;
 
     constexpr int NPAR = EpiParamArrays<Epi>::value;
     float* lds_par = reinterpret_cast<float*>(smem + NB * C::STAGE_BYTES);   // [NPAR][CT*32]

@@ -151,15 +151,6 @@ struct CompletionUpdateArgs {   // one optimisation step of DPoserComp.optimize 
     int64_t B;
     int D, Dpad, Cp, num_scales, scale_by_sigma;
     SdeCfg sde;
-    // perturbation of the NEXT step fused in (completion.py:133-135 of step i+1): t_next < 0 => last step, nothing to prepare
-    float t_next;
-    const float* z_next;   // injected z of the next step [B][D] or null (-> Philox STREAM_PRIOR, step_next)
-    void* xin;             // FT [Bpad][Dpad] next network input
-    float* xt_out;         // [Bpad][Dpad] next perturbed data (may alias xt: every element is read before it is rewritten)
-    int64_t Bpad;
-    int f32;
-    uint64_t seed;
-    uint32_t step_next;
 };
 hipError_t launch_completion_update(const CompletionUpdateArgs& a, hipStream_t st);
 

@@ -758,14 +758,11 @@ extern "C" int dposer_completion_optimize(dposer_scorefc_t h, const float* flat,
     DP_TRY(build_time_table(h, flat, packed, w, w.tt_labels, 0.f, n_steps, freq, st));
     const SdeCfg sc = to_sde(sde);
     const int64_t BD = B * h->D;
-    auto noise_of = [&](int i) { return noise ? noise + (int64_t)i * BD : (const float*)nullptr; };
-    {   // perturbation of step 0; every later one is fused into the update kernel of the step before it
-        PerturbSharedArgs pa;
-        pa.x0 = x; pa.z_in = noise_of(0); pa.xin = w.xin; pa.xt = w.xt; pa.t = t_host[0]; pa.B = B; pa.Bpad = w.Bpad;
-        pa.D = h->D; pa.Dpad = h->Dpad; pa.f32 = h->f32; pa.sde = sc; pa.seed = seed; pa.step = step0;
-        DP_HIP_LAUNCH(launch_perturb_shared(pa, st));
-    }
     for (int i = 0; i < n_steps; ++i) {
+        PerturbSharedArgs pa;
+        pa.x0 = x; pa.z_in = noise ? noise + (int64_t)i * BD : nullptr; pa.xin = w.xin; pa.xt = w.xt; pa.t = t_host[i]; pa.B = B; pa.Bpad = w.Bpad;
+        pa.D = h->D; pa.Dpad = h->Dpad; pa.f32 = h->f32; pa.sde = sc; pa.seed = seed; pa.step = step0 + (uint32_t)i;
+        DP_HIP_LAUNCH(launch_perturb_shared(pa, st));
         DP_TRY(run_shared_t(h, flat, packed, w, i, B, st));
         CompletionUpdateArgs ua;
         ua.res = w.res; ua.xt = w.xt; ua.obs = observation; ua.mask = mask; ua.sigmas = sigmas; ua.x = x; ua.m = adam_m; ua.v = adam_v;
@@ -776,8 +773,6 @@ extern "C" int dposer_completion_optimize(dposer_scorefc_t h, const float* flat,
         ua.one_minus_beta1 = (float)(1.0 - beta1); ua.beta2 = (float)beta2; ua.one_minus_beta2 = (float)(1.0 - beta2);
         ua.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(beta2, k)); ua.eps = (float)eps;
         ua.B = B; ua.D = h->D; ua.Dpad = h->Dpad; ua.Cp = h->Cp; ua.num_scales = h->d.num_scales; ua.scale_by_sigma = h->d.scale_by_sigma; ua.sde = sc;
-        ua.t_next = i + 1 < n_steps ? t_host[i + 1] : -1.0f; ua.z_next = i + 1 < n_steps ? noise_of(i + 1) : nullptr; ua.xin = w.xin;
-        ua.xt_out = w.xt; ua.Bpad = w.Bpad; ua.f32 = h->f32; ua.seed = seed; ua.step_next = step0 + (uint32_t)(i + 1);
         DP_HIP_LAUNCH(launch_completion_update(ua, st));
     }
     return DPOSER_OK;
