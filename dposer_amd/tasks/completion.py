@@ -105,3 +105,34 @@ class DPoserComp:
             tot.backward()
             optimizer.step()
         return observation * mask + x.detach() * (1.0 - mask)
+
+
+def evaluate_completion(model, sde, normalizer, body_model, poses, *, part="legs", hypo=1, batch_size=16384, continuous=True,
+                        num_replicas=None, rank=None, optimize_kwargs=None):
+    """The evaluation loop of run/completion.py:215-323 (``inference``) for the poses of one test set, without its process / CLI
+    shell: this rank's contiguous shard (DistributedEvalSampler arithmetic, EvaSampler.py:78-106) in batches of ``batch_size``
+    with ``drop_last`` like the reference's DataLoader -> create_mask -> ``hypo`` completions -> de-normalise -> Evaler
+    (min over hypotheses) -> mean of every metric over all samples of all ranks.
+
+    Nothing synchronises with the host inside the loop: the per-sample metrics stay device tensors, and the end is ONE all-reduce
+    of (sum, count) pairs (``distributed.reduce_metric_means``) instead of ``gather_object`` of every value (:300-305).
+    ``poses`` [N, D] normalised test poses (the dataset's ``poses`` tensor); returns ``({metric: mean}, samples evaluated here)``."""
+    from .. import distributed as ddp
+    from ..dataset.AMASS import Evaler
+    from ..utils.misc import create_mask
+    world = ddp.world_size() if num_replicas is None else num_replicas
+    rk = ddp.rank() if rank is None else rank
+    lo, hi = ddp.shard_bounds(poses.shape[0], world, rk)
+    dev = next(model.parameters()).device
+    evaler = Evaler(body_model=body_model, part=part)
+    results, done = [], 0
+    for b0 in range(lo, hi - batch_size + 1, batch_size) if hi - lo >= batch_size else []:
+        batch = poses[b0:b0 + batch_size].to(dev, non_blocking=True)
+        mask, observation = create_mask(batch, part=part)
+        comp = DPoserComp(model, sde, continuous, batch_size=batch_size)
+        outs = torch.stack([comp.optimize(observation, mask, **(optimize_kwargs or {})) for _ in range(hypo)], dim=1)
+        preds = normalizer.offline_denormalize(outs, to_axis=True)
+        gts = normalizer.offline_denormalize(batch, to_axis=True)
+        results.append(evaler.multi_eval_bodys(preds, gts, as_tensors=True))
+        done += batch_size
+    return ddp.reduce_metric_means(results, device=dev), done

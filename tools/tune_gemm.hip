@@ -206,6 +206,16 @@ int main(int argc, char** argv) {
         run_all(9, 20);
         return 0;
     }
+    if (getenv("TUNE_4W")) {         // round 2: one wave per SIMD with 128x128 wave tiles (0.5 LDS fragment reads per MFMA instead of 0.75)
+        PL(2, 4, 4, 2, 2, 4);   // shipped: 8 waves, wave tile 128 x 64
+        PL(2, 2, 4, 4, 2, 4);   // 4 waves, wave tile 128 x 128, ring of 4
+        PL(2, 2, 4, 4, 2, 3);
+        PL(2, 2, 4, 4, 4, 2);   // 2-slot loop, 4 k-blocks per stage
+        GN(2, 4, 4, 2, 2, 4);
+        GN(2, 2, 4, 4, 2, 4);
+        run_all(7, 10);
+        return 0;
+    }
     if (getenv("TUNE_GNBWD2")) {     // round 2: where the GroupNorm-backward epilogue spends its time (ablations) and the trimmed version
 #define GBA(WC, WS, TC, TS, ABL, DROP, CI, CO) add_gnbwd<WC, WS, TC, TS, 2, 4, ABL>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, xhat, rstd, gamma, beta, part, nullptr, CI ? cin : nullptr, CO ? cout : nullptr, DROP ? 0.1f : 0.f)
         PL(2, 4, 4, 2, 2, 4);
