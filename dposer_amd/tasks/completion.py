@@ -125,11 +125,11 @@ def evaluate_completion(model, sde, normalizer, body_model, poses, *, part="legs
     lo, hi = ddp.shard_bounds(poses.shape[0], world, rk)
     dev = next(model.parameters()).device
     evaler = Evaler(body_model=body_model, part=part)
+    comp = DPoserComp(model, sde, continuous, batch_size=batch_size)      # one object: its call counter keys the in-kernel noise
     results, done = [], 0
     for b0 in range(lo, hi - batch_size + 1, batch_size) if hi - lo >= batch_size else []:
         batch = poses[b0:b0 + batch_size].to(dev, non_blocking=True)
         mask, observation = create_mask(batch, part=part)
-        comp = DPoserComp(model, sde, continuous, batch_size=batch_size)
         outs = torch.stack([comp.optimize(observation, mask, **(optimize_kwargs or {})) for _ in range(hypo)], dim=1)
         preds = normalizer.offline_denormalize(outs, to_axis=True)
         gts = normalizer.offline_denormalize(batch, to_axis=True)
