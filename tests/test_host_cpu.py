@@ -288,3 +288,22 @@ def test_device_rk45_driver_reproduces_scipy_step_for_step():
     e1 = np.abs(solve_fixed(fun_t, 0.0, 1.0, torch.from_numpy(y0), 40)[0].numpy() - ref).max()
     e2 = np.abs(solve_fixed(fun_t, 0.0, 1.0, torch.from_numpy(y0), 80)[0].numpy() - ref).max()
     assert e2 < e1 / 12 and e2 < 1e-6
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under dposer_amd/ may import it (or read /root/reference), and bench.py /
+    __graft_entry__.py may use it only in cpu_baseline / smoke."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"^\s*(from\s+oracle|import\s+oracle|from\s+\.+oracle)|/root/reference", re.M)
+    for dirpath, _, files in os.walk(os.path.join(root, "dposer_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(src), os.path.join(dirpath, f)
+    bench = open(os.path.join(root, "bench.py")).read()
+    body = bench.split("def cpu_baseline", 1)[1].split("\ndef main", 1)[0]
+    assert "oracle" in body                                              # the CPU leg is the oracle ...
+    assert "oracle" not in bench.replace(body, "").split('"""', 2)[2]    # ... and nothing else in bench.py is (docstring aside)
+    entry = open(os.path.join(root, "__graft_entry__.py")).read()
+    build_body = entry.split("def build", 1)[1].split("def smoke", 1)[0]
+    assert "score_ref." not in build_body and "fk_ref." not in build_body   # build() imports the oracle modules, never calls them
