@@ -331,6 +331,21 @@ def main():
                                            "unit": "GB/s", "frac": fk_gbs / HBM_PEAK_GBS, "traffic": None,
                                            "algorithmic_bytes_per_pose": 516, "avg_launch_us": fk_s * 1e6,
                                            "measured": "HIP events on the launch stream around 20 launches of 2^20 poses"}}
+        # the same kernel on a 4x larger batch (4 GiB of poses + joints in HBM): launch tails and the ragged last wave weigh less
+        nfk4 = 1 << 22
+        pose4 = pose.repeat(4, 1)
+        for _ in range(2):
+            bm.fk_joints(pose4)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            bm.fk_joints(pose4)
+        e1.record()
+        torch.cuda.synchronize()
+        fk4_s = e0.elapsed_time(e1) * 1e-3 / 10
+        extra["fk_joints"]["at_4M_poses"] = {"poses_per_s_per_gpu": nfk4 / fk4_s, "achieved_GBps": 516.0 * nfk4 / fk4_s / 1e9,
+                                            "frac_of_hbm_peak": 516.0 * nfk4 / fk4_s / 1e9 / HBM_PEAK_GBS}
+        del pose4
         # ---- M3b: full linear blend skinning ([B,63] -> 10475 vertices + 127 joints), forward and forward+backward ----
         nl = 4096
         pb = pose[:nl].clone().requires_grad_(True)

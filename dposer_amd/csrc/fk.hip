@@ -568,70 +568,6 @@ template <typename Kin, int NT, int NOUT = 0> __global__ void __launch_bounds__(
     }
 }
 
-// Column-grouped variant of the joints-only body query: the 22 joints are staged, evaluated and written out in two groups of
-// 11 (33 floats per pose), so the per-pose LDS row is 33 floats instead of 67 and a CU holds 16 single-wave blocks (the register
-// limit at 122 VGPRs) instead of 9.  The running transforms G[] stay in registers across the groups; global traffic is unchanged
-// (each 128-byte line is touched once per group, the second touch from L2).
-template <typename Kin, int NOUT, int LO, int... Is>
-__device__ __forceinline__ void fk_chain_range(std::integer_sequence<int, Is...>, Xf (&G)[Kin::J], const float* pose, const float* jr, float* row,
-                                               const float (&tr)[3], const FkArgs& a, int64_t b, int n_out) {
-    (fk_step<Kin, LO + Is, NOUT>(G, pose, jr, row, tr, a, b, n_out), ...);
-}
-template <typename Kin, int NT, int NOUT, int JG> __global__ void __launch_bounds__(NT) k_fk_joints_grouped(FkArgs a) {
-    constexpr int J = Kin::J;
-    constexpr int NGRP = (NOUT + JG - 1) / JG;
-    constexpr int ROW = (JG * 3) | 1;
-    extern __shared__ float lds[];
-    const int64_t item0 = (int64_t)blockIdx.x * NT;
-    const int64_t b = item0 + threadIdx.x;
-    const float* jr = a.j_rest_batched ? a.j_rest + (b < a.B ? b : 0) * (int64_t)J * 3 : a.j_rest;
-    float tr[3] = {0.f, 0.f, 0.f};
-    if (a.transl && b < a.B) { tr[0] = a.transl[b * 3]; tr[1] = a.transl[b * 3 + 1]; tr[2] = a.transl[b * 3 + 2]; }
-    Xf G[J];
-    float* row = lds + threadIdx.x * ROW;
-    auto group = [&](auto gtag) __attribute__((always_inline)) {
-        constexpr int GI = decltype(gtag)::value;
-        constexpr int JLO = GI * JG, JHI = (JLO + JG < NOUT) ? JLO + JG : NOUT;
-        constexpr int W = (JHI - JLO) * 3;                                      // floats per pose in this group
-        // ---- stage the group's pose columns: for every segment, its joints inside [JLO, JHI) ----
-        for (int sg = 0; sg < FK_MAX_SEG; ++sg) {
-            if (sg >= a.nseg) break;
-            const int first = a.seg_first[sg], last = first + a.seg_joints[sg];
-            const int lo = first > JLO ? first : JLO, hi = last < JHI ? last : JHI;
-            if (lo >= hi) continue;
-            const int width = (hi - lo) * 3, col0 = (lo - JLO) * 3, g0 = (lo - first) * 3, gw = a.seg_joints[sg] * 3;
-            const float* g = a.seg[sg];
-            int rw = threadIdx.x / width, col = threadIdx.x % width;
-            const int drow = NT / width, dcol = NT % width;
-            while (rw < NT) {
-                const int64_t bb = item0 + rw;
-                lds[rw * ROW + col0 + col] = (g && bb < a.B) ? g[bb * gw + g0 + col] : 0.f;
-                rw += drow; col += dcol;
-                if (col >= width) { col -= width; ++rw; }
-            }
-        }
-        __syncthreads();
-        fk_chain_range<Kin, NOUT, JLO>(std::make_integer_sequence<int, JHI - JLO>{}, G, row - 3 * JLO, jr, row - 3 * JLO, tr, a, b, NOUT);
-        __syncthreads();
-        // ---- the group's posed joints: LDS rows -> columns [3 JLO, 3 JHI) of the output rows ----
-        {
-            int rw = threadIdx.x / W, col = threadIdx.x % W;
-            constexpr int drow = NT / W, dcol = NT % W;
-            while (rw < NT) {
-                const int64_t bb = item0 + rw;
-                if (bb < a.B) a.joints[bb * a.joints_ld + 3 * JLO + col] = lds[rw * ROW + col];
-                rw += drow; col += dcol;
-                if (col >= W) { col -= W; ++rw; }
-            }
-        }
-        __syncthreads();
-    };
-    group(std::integral_constant<int, 0>{});
-    if constexpr (NGRP > 1) group(std::integral_constant<int, 1>{});
-    if constexpr (NGRP > 2) group(std::integral_constant<int, 2>{});
-    static_assert(NGRP <= 3, "at most three joint groups");
-}
-
 struct dposer_body_s {
     dposer_body_desc d;
     int kind;   // 0 SMPL, 1 SMPL-H, 2 SMPL-X
@@ -673,15 +609,11 @@ template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t
     const int lds_floats = NT * ((a.n_out * 3) | 1);
     // (a persistent variant that prefetches the next pose tile into registers while the chain runs was measured 13-20 % SLOWER --
     //  6.1 vs 7.1 G poses/s at 2^20 poses, 6.6 vs 8.3 at 2^22: 256 VGPRs with spills; tools/experimental/fk_stream.md)
-    if (a.n_out == 22 && Kin::J >= 22 && !a.pf && !a.rel) {     // joints-only body query (the hot case): lean specialisation
-        static const int grouped = [] { const char* e = getenv("DPOSER_FK_GROUPED"); return e ? atoi(e) : 0; }();
-        if (grouped == 11)
-            hipLaunchKernelGGL((k_fk_joints_grouped<Kin, NT, 22, 11>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), NT * 33 * sizeof(float), st, a);
-        else if (grouped == 8)
-            hipLaunchKernelGGL((k_fk_joints_grouped<Kin, NT, 22, 8>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), NT * 25 * sizeof(float), st, a);
-        else
-            hipLaunchKernelGGL((k_fk_joints<Kin, NT, 22>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
-    } else
+    // (also measured and rejected: staging / evaluating / writing the joints in two or three column groups so that the LDS row
+    //  shrinks and 16 instead of 9 waves fit a CU -- bit-identical, but the 132-byte row segments cost 2x: 3.9 vs 7.1 G poses/s)
+    if (a.n_out == 22 && Kin::J >= 22 && !a.pf && !a.rel)       // joints-only body query (the hot case): lean specialisation
+        hipLaunchKernelGGL((k_fk_joints<Kin, NT, 22>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
+    else
         hipLaunchKernelGGL((k_fk_joints<Kin, NT>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
     return hipGetLastError();
 }
