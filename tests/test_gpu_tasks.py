@@ -250,3 +250,39 @@ def test_evaluate_completion_end_to_end():
     out = DPoserComp(m, sde, True, batch_size=16).optimize(obs, mask, **kw)
     ev = Evaler(bm, part="legs").multi_eval_bodys(nz.offline_denormalize(out[:, None], to_axis=True), nz.offline_denormalize(batch, to_axis=True))
     assert abs(float(np.mean(ev["mpjpe_body"])) - m0["mpjpe_body"]) < 1e-3 * m0["mpjpe_body"]
+
+
+def test_completion_loop_vp_sde_and_fixed_time_strategy_vs_oracle():
+    """The fused completion loop under the VP SDE (std = sqrt(1 - e^{2 lmc})) and with time strategy '2' (one fixed time step,
+    completion.py:187): vs the oracle loop / a step-by-step loop through prior_loss + torch.optim.Adam."""
+    from dposer_amd.algorithms.advanced import sde_lib
+    from dposer_amd.tasks.completion import DPoserComp
+    from dposer_amd.utils.misc import create_mask
+    cfg, m, p = make_model(65, precision="fp32")
+    B, iters, spi = 40, 2, 3
+    g = load("g10_normalizer")
+    torch.manual_seed(2)
+    mask, obs = create_mask(torch.tensor(g["norm_minmax0"][:B]), part="arms")
+    noise = np.random.RandomState(3).standard_normal((iters * spi, B, 63)).astype(np.float32)
+    comp = DPoserComp(m, sde_lib.VPSDE(0.1, 20.0, 1000), continuous=True, batch_size=B)
+    out = comp.optimize(obs.to(DEV), mask.to(DEV), iterations=iters, steps_per_iter=spi, noise=torch.tensor(noise, device=DEV))
+    ref = task_loops.completion_optimize(p, R.VP(), obs.numpy(), mask.numpy(), noise, iterations=iters, steps_per_iter=spi)
+    assert rel_err(t2n(out), ref) < 2e-6
+    # time strategy '2' against the un-fused route (prior_loss + torch Adam, one step at a time)
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    comp = DPoserComp(m, sde, continuous=True, batch_size=B)
+    nz = torch.tensor(noise, device=DEV)
+    fused = comp.optimize(obs.to(DEV), mask.to(DEV), time_strategy="2", sample_time=700, iterations=iters, steps_per_iter=spi, noise=nz)
+    x = obs.to(DEV).clone().requires_grad_(True)
+    opt = torch.optim.Adam([x], 0.1, betas=(0.9, 0.999))
+    ts = torch.linspace(1.0, 1e-3, 1000)
+    w = comp.get_loss_weights()
+    for step in range(iters * spi):
+        it = step // spi
+        opt.zero_grad()
+        lp = comp.loss(x, float(ts[700]), weighted=True, z=nz[step])
+        ld = torch.nn.functional.mse_loss(x * mask.to(DEV), obs.to(DEV) * mask.to(DEV))
+        (w["dposer"](lp, it) + w["data"](ld, it)).backward()
+        opt.step()
+    slow = obs.to(DEV) * mask.to(DEV) + x.detach() * (1 - mask.to(DEV))
+    assert rel_err(t2n(fused), t2n(slow)) < 2e-6
