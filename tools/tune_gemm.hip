@@ -206,6 +206,19 @@ int main(int argc, char** argv) {
         run_all(9, 20);
         return 0;
     }
+    if (getenv("TUNE_2WGT")) {       // round 2: training-forward epilogue (three output streams) with two 4-wave workgroups per CU
+        g_drop_p = 0.1f;
+        GNT(2, 4, 4, 2, 2, 4);
+        GNT(2, 2, 4, 2, 2, 3);
+        GNT(1, 4, 4, 2, 2, 3);
+        GNT(4, 1, 2, 4, 2, 3);
+        GNT(2, 2, 2, 4, 2, 3);
+        g_resid = cin;
+        GNT(2, 4, 4, 2, 2, 4); g_cases.back().name += " +resid";
+        GNT(2, 2, 4, 2, 2, 3); g_cases.back().name += " +resid";
+        run_all(7, 10);
+        return 0;
+    }
     if (getenv("TUNE_4W")) {         // round 2: one wave per SIMD with 128x128 wave tiles (0.5 LDS fragment reads per MFMA instead of 0.75)
         PL(2, 4, 4, 2, 2, 4);   // shipped: 8 waves, wave tile 128 x 64
         PL(2, 2, 4, 4, 2, 4);   // 4 waves, wave tile 128 x 128, ring of 4
