@@ -904,3 +904,52 @@ def test_langevin_fused_vp_sde_vs_oracle():
         xo, xm = R.em_step(p, so, xo, t, torch.tensor(noise[k, 1]))
         assert rel_err(t2n(trajs[k]), xo.numpy()) < 1e-4, i
     assert rel_err(t2n(x), xm.numpy()) < 1e-4
+
+
+def test_langevin_fused_completion_imputation_matches_generic_loop():
+    """Predictor-corrector loop with imputation (task = completion, sampling.py:416-420,455-461): per outer step the draws are
+    corrector x n_steps, imputation after the corrector, predictor, imputation after the predictor.  The HIP path
+    (dposer_langevin_step + dposer_em_sampler_steps with observation / mask) against the generic classes run step by step on the
+    HIP score function with the same draws, n_steps = 2."""
+    from unittest import mock
+    from dposer_amd.algorithms.advanced import sampling, sde_lib
+    from dposer_amd.utils.misc import create_mask
+    cfg, m, p = make_model(25, precision="fp32")
+    cfg.sampling.corrector = "langevin"
+    cfg.sampling.n_steps_each = 2
+    N, B, nst = 1000, 32, 2
+    sde = sde_lib.subVPSDE(0.1, 20.0, N)
+    rs = np.random.RandomState(9)
+    poses = torch.tensor((rs.standard_normal((B, 63)) * 0.5).astype(np.float32))
+    torch.manual_seed(3)
+    mask, obs = create_mask(poses, part="legs")
+    mask, obs = mask.to(DEV), obs.to(DEV)
+    z0 = _dev((rs.standard_normal((B, 63)) * 0.3).astype(np.float32))
+    # completion runs all N steps in the reference; compare the first 3 outer steps (the fused loop is driven directly)
+    n_run = 3
+    noise = _dev(rs.standard_normal((n_run, nst + 3, B, 63)).astype(np.float32))
+    ts = torch.linspace(sde.T, 1e-3, N)
+    sde_short = sde_lib.subVPSDE(0.1, 20.0, N)
+    # fused: drive the first n_run steps by treating them as a "range" of the N-step schedule
+    x = z0.clone()
+    from dposer_amd.algorithms.advanced.sampling import fused_pc_langevin_sample
+    # fused_pc_langevin_sample runs [start_step, N): run the LAST n_run steps instead, with the matching timesteps in the oracle loop
+    start = N - n_run
+    trajs, xf, xmf = fused_pc_langevin_sample(m, sde, x, ts, snr=cfg.sampling.snr, n_steps=nst, start_step=start, observation=obs, mask=mask,
+                                              noise=noise, seed=1, traj_stride=1)
+    # generic loop with the same draws
+    flat = [noise[i, k] for i in range(n_run) for k in range(nst + 3)]
+    it = iter(flat)
+    xg = z0.clone()
+    tdev = ts.to(DEV)
+    with torch.no_grad(), mock.patch.object(torch, "randn_like", lambda x_, **k: next(it)):
+        for i in range(start, N):
+            vec_t = torch.ones(B, device=DEV) * tdev[i]
+            xg, _ = sampling.shared_corrector_update_fn(xg, vec_t, obs, mask, sde, m, sampling.LangevinCorrector, True, cfg.sampling.snr, nst)
+            mean, std = sde.marginal_prob(obs, vec_t)
+            xg = xg * (1 - mask) + (mean + torch.randn_like(xg) * std[:, None]) * mask
+            xg, xm = sampling.shared_predictor_update_fn(xg, vec_t, obs, mask, sde, m, sampling.EulerMaruyamaPredictor, False, True)
+            mean, std = sde.marginal_prob(obs, vec_t)
+            xg = xg * (1 - mask) + (mean + torch.randn_like(xg) * std[:, None]) * mask
+            assert rel_err(t2n(trajs[i - start]), t2n(xg)) < 2e-5, i
+    assert rel_err(t2n(xf), t2n(xg)) < 2e-5 and rel_err(t2n(xmf), t2n(xm)) < 2e-5
