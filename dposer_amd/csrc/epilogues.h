@@ -400,98 +400,6 @@ template <typename T> struct EpiEmStep {
     }
 };
 
-// The same step with the NEXT step's first layer (pre_dense + time bias + GroupNorm + SiLU, model.py:177-181) computed from
-// the registers the new state sits in: the 64-channel state of a wave's 32 samples, converted to bf16 and regrouped exactly as
-// TileIO<bf16>::store regroups it for the FT image, IS the MFMA B operand of that layer (4 k-blocks of 16), so layer 0 becomes
-// 32 channel tiles x 4 MFMAs per wave with the weights read straight from L2 (128 KiB, shared by every wave) -- no `xin` round
-// trip, no separate launch whose 128 MiB output store waits behind its own small K loop.  Per-tile arithmetic is the inference
-// EpiGN (same code, same MFMA order: k-blocks 0..3 onto a zero accumulator), so the result equals the two-launch path bit
-// for bit.  bf16, H = 1024 (gs = 32), Cp = Dpad = 64, the 64 x 128 tiling only.
-template <typename T> struct Mma;     // gemm.h
-struct EmStepL0Params {
-    EmStepParams em;
-    const void* w0;          // packed layer-0 weights, FT [H][w0_stride_blocks * 16]
-    int w0_stride_blocks;
-    const float* bias0;      // [H] time-table row of the next step: pre_dense bias + time projection (layer 0)
-    const float* gamma0;
-    const float* beta0;
-    void* h0;                // FT [Spad][H]: output of layer 0 for the next step
-    int H;
-};
-template <typename T> struct EpiEmStepL0 {
-    static_assert(sizeof(T) == 2, "bf16 only (the fp32 parity mode keeps the two-launch path)");
-    typedef EmStepL0Params Params;
-    static constexpr int kH = 1024;
-    static constexpr int kRingPerWave = 3 * kH * 4;      // this wave's copy of bias / gamma / beta in the idle K-loop ring
-    template <int TC, int TS>
-    __device__ static inline void apply_ring(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float*, int, unsigned char*, unsigned char* ring) {
-        static_assert(TC == 2 && TS == 1, "wave tile = the whole 64-channel state of 32 samples");
-        typedef const __attribute__((address_space(1))) void* gptr_t;
-        typedef __attribute__((address_space(3))) void* lptr_t;
-        typedef EpiEmStep<T> Em;
-        typedef typename Mma<T>::Frag Frag;
-        const EmStepParams& p = pp.em;
-        const int j = lane & 31, hi = lane >> 5;
-        // layer-0 parameters -> LDS (DMA, 1 KiB per instruction); they land while the state update runs
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float* src = a == 0 ? pp.bias0 : (a == 1 ? pp.gamma0 : pp.beta0);
-#pragma unroll
-            for (int k = 0; k < kH / 256; ++k)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 256 + lane * 4), (lptr_t)(ring + (a * (kH / 256) + k) * 1024), 16, 0, 0);
-        }
-        const unsigned char* wbase = reinterpret_cast<const unsigned char*>(pp.w0) + lane * 16;
-        Frag fa[2][4];
-        auto load_w = [&](int ct, int set) __attribute__((always_inline)) {
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) fa[set][kb] = *reinterpret_cast<const Frag*>(wbase + (((int64_t)ct * pp.w0_stride_blocks + kb) << 10));
-        };
-        load_w(0, 0);
-        // ---- Euler-Maruyama update of the two 32-channel tiles; the bf16 image of the new state stays in registers ----
-        const typename Em::Scal sc = Em::scalars(p);
-        Frag fb[4];
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc) {
-            const int c0 = cbase + tc * 32;
-            const int64_t s = sbase + j;
-            const int64_t tb = ft_tile_base<float>(sbase, c0, p.Cp);
-            float x[16], xm[16];
-            TileIO<float>::load(p.x_ft + tb, lane, x);
-            Em::tile(p, sc, acc[tc][0], c0, s, hi, x, xm);
-            TileIO<float>::store(p.x_ft + tb, lane, x);
-            if (p.x_mean_ft) TileIO<float>::store(p.x_mean_ft + tb, lane, xm);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {               // = TileIO<bf16>::store's regrouping: lane (j, hi) holds chunk kh = hi of k-block h
-                unsigned a0 = TileIO<T>::pack2(x[8 * h + 0], x[8 * h + 1]), a1 = TileIO<T>::pack2(x[8 * h + 2], x[8 * h + 3]);
-                unsigned b0 = TileIO<T>::pack2(x[8 * h + 4], x[8 * h + 5]), b1 = TileIO<T>::pack2(x[8 * h + 6], x[8 * h + 7]);
-                TileIO<T>::swap_halves(a0, b0);
-                TileIO<T>::swap_halves(a1, b1);
-                u32x4 o = {a0, a1, b0, b1};
-                fb[2 * tc + h] = *reinterpret_cast<Frag*>(&o);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));      // parameter DMA (and the first weight fragments) landed
-        asm volatile("" ::: "memory");
-        // ---- layer 0 of the next step: 32 channel tiles, K = 64 ----
-        GNParams gp = {};                               // (bias / gamma / beta are read from the LDS copy; no dropout at inference)
-        gp.out = pp.h0;
-        gp.H = pp.H;
-        const float* lpar = reinterpret_cast<const float*>(ring);
-        typename EpiGN<T, false, 0>::Carry cy;
-#pragma unroll 2
-        for (int ct = 0; ct < kH / 32; ++ct) {
-            const int set = ct & 1;
-            if (ct + 1 < kH / 32) load_w(ct + 1, set ^ 1);
-            f32x16 a;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) Mma<T>::run(fa[set][kb], fb[kb], a);
-            EpiGN<T, false, 0>::template sub<1, 1, 0, 0, -1>(gp, cy, a, ct * 32, sbase, lane, 0, 0, lpar + ct * 32, kH, nullptr);
-        }
-    }
-};
-
 // out FT = acc  (+ optional FT addend): plain fragment-tiled store (dgrad into the time branch).
 struct PlainFTParams {
     void* out;

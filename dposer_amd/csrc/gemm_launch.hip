@@ -33,7 +33,7 @@ struct ProfScope {
     }
     ~ProfScope() { if (r) hipEventRecord(r->b, st); }
 };
-const char* kEpiNames[EPI_KINDS] = {"gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad", "post_em_step", "post_em_step_l0"};
+const char* kEpiNames[EPI_KINDS] = {"gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad", "post_em_step"};
 const char* kShapeNames[6] = {"256x256", "128x128", "128x32", "64x128", "64x32", "128x64"};
 }   // namespace
 void gemm_prof_enable(int on) {
@@ -130,12 +130,6 @@ hipError_t gemm_rowmajor(int prec, int shape, const GemmArgs& g, const RowMajorP
 hipError_t gemm_em_step(int prec, int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st) {
     PROF(EPI_EM_STEP);
     typedef EpiEmStep<__bf16> A; typedef EpiEmStep<float> B; DISPATCH(A, B, M_FINAL | M_FINAL_S);
-}
-hipError_t gemm_em_step_l0(int shape, const GemmArgs& g, const EmStepL0Params& p, hipStream_t st) {
-    const int prec = PREC_BF16;
-    PROF(EPI_EM_STEP_L0);
-    if (shape != SHAPE_FINAL || p.H != EpiEmStepL0<__bf16>::kH) return hipErrorInvalidConfiguration;
-    return launch_gemm<__bf16, 1, 4, 2, 1, RING_KB, EpiEmStepL0<__bf16>, RING_NB>(g, p, st);
 }
 hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTParams& p, hipStream_t st) {
     PROF(EPI_PLAIN_FT);

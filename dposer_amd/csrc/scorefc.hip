@@ -361,7 +361,6 @@ extern "C" int64_t dposer_scorefc_workspace_bytes(dposer_scorefc_t h, int64_t ba
 // ------------------------------------------------------------------------------------------------
 // GEMM launch helpers
 // ------------------------------------------------------------------------------------------------
-static bool env_flag(const char* name) { const char* v = std::getenv(name); return v && v[0] && v[0] != '0'; }   // A/B switches
 static thread_local double g_next_flops = 0.0;   // algorithmic FLOPs of the next GEMM launch (profiling only)
 static GemmArgs gemm_args(const void* W, int w_stride_blocks, int n_cblk, int n_sblk) {
     GemmArgs g;
@@ -529,11 +528,10 @@ static int build_time_table(dposer_scorefc_s* h, const float* flat, const char* 
 }
 
 // the GroupNorm layers of one shared-t network evaluation (bias rows from table row `row`); returns the last activation
-// l_first = 1: layer 0's output already sits in hbuf[0] (written by the previous step's fused update kernel)
-static int run_shared_t_layers(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t row, hipStream_t st, const void** last, int l_first = 0) {
-    const void* in = l_first ? (const void*)w.hbuf[0] : w.xin;
+static int run_shared_t_layers(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t row, hipStream_t st, const void** last) {
+    const void* in = w.xin;
     const float* trow = w.table + row * (int64_t)h->L * h->H;
-    for (int l = l_first; l < h->L; ++l) {
+    for (int l = 0; l < h->L; ++l) {
         void* o = w.hbuf[l % 3];
         const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[(l - 2) % 3] : nullptr;
         DP_TRY(run_gn_layer(h, flat, packed, l, in, nullptr, trow + (int64_t)l * h->H, o, resid, nullptr, nullptr, false, w.Bpad, 0, 0, st));
@@ -629,12 +627,10 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     DP_HIP_LAUNCH(launch_em_update(ea, st));
     if (fused) {
         const int shape = final_shape(w.Bpad);
-        // bf16, H = 1024, 64 x 128 tiling: the update kernel also computes layer 0 of the NEXT evaluation (EpiEmStepL0)
-        const bool fuse_l0 = !h->f32 && shape == SHAPE_FINAL && h->H == 1024 && h->gs == 32 && h->Dpad == 64 && !env_flag("DPOSER_NO_L0_FUSION");
         for (int i = 0; i < n_run; ++i) {
             const int gi = start_step + i;
             const void* last = nullptr;
-            DP_TRY(run_shared_t_layers(h, flat, packed, w, i, st, &last, (fuse_l0 && i > 0) ? 1 : 0));
+            DP_TRY(run_shared_t_layers(h, flat, packed, w, i, st, &last));
             g_next_flops = 2.0 * (double)B * h->D * h->H;
             GemmArgs g = gemm_args(packed + h->pk_wpost, h->H / h->KBS, h->Cp / (shape_ct(shape) * 32), (int)(w.Bpad / (shape_st(shape) * 32)));
             add_seg(g, last, h->H / h->KBS);
@@ -644,22 +640,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
             p.sigmas = sigmas; p.sde = make_sde_dev(sc); p.t = timesteps_host[gi]; p.num_scales = h->d.num_scales;
             p.scale_by_sigma = h->d.scale_by_sigma; p.D = h->D; p.Cp = h->Cp; p.QD = (h->D + 3) >> 2; p.S_valid = B;
             p.seed = seed; p.step = (uint32_t)gi;
-            if (fuse_l0 && i + 1 < n_run) {
-                const LayerOff& lo = h->layer[0];
-                EmStepL0Params q;
-                std::memset(&q, 0, sizeof(q));
-                q.em = p;
-                q.w0 = packed + h->pk_wl[0];
-                q.w0_stride_blocks = (lo.kin_pad + h->E) / h->KBS;   // rows hold [W | W_time]
-                q.bias0 = w.table + (int64_t)(i + 1) * h->L * h->H;
-                q.gamma0 = flat + lo.gamma; q.beta0 = flat + lo.beta;
-                q.h0 = w.hbuf[0];
-                q.H = h->H;
-                g.alg_flops += 2.0 * (double)B * h->H * lo.kin;
-                DP_HIP_LAUNCH(gemm_em_step_l0(shape, g, q, st));
-            } else {
-                DP_HIP_LAUNCH(gemm_em_step(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
-            }
+            DP_HIP_LAUNCH(gemm_em_step(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
         }
         DP_HIP_LAUNCH(launch_ft_to_rows(w.xft, x, w.xmft, x_mean, B, w.Bpad, h->D, h->Dpad, st));
         return DPOSER_OK;

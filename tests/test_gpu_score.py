@@ -234,28 +234,6 @@ def test_em_sampler_fused_step_path_matches_oracle(B, prec, tol):
     assert rel_err(t2n(trajs_u[-1]), ref_trajs[-1].numpy()) < tol
 
 
-def test_em_sampler_layer0_fused_into_update_is_bit_identical(monkeypatch):
-    """Above 16384 samples (64 x 128 tiling, bf16, H = 1024) the update kernel also computes layer 0 of the NEXT network
-    evaluation from the registers the new state sits in (EpiEmStepL0).  Same per-tile arithmetic and MFMA order as the
-    two-launch path => bit-identical to it (DPOSER_NO_L0_FUSION=1), and within the bf16 tolerance of the oracle fed the same
-    Philox draws.  B is not a multiple of the tile (padding rows) and crosses several workgroups."""
-    cfg, m, p = make_model(23, precision="bf16")
-    N, B, seed = 6, 16500, 99
-    sde, fn = _sampler(m, cfg, N, B)
-    z0 = np.random.RandomState(1).standard_normal((B, 63)).astype(np.float32)
-    _, x_f = fn(m, z=_dev(z0), seed=seed, traj_stride=0)
-    monkeypatch.setenv("DPOSER_NO_L0_FUSION", "1")
-    _, x_u = fn(m, z=_dev(z0), seed=seed, traj_stride=0)
-    monkeypatch.delenv("DPOSER_NO_L0_FUSION")
-    assert torch.isfinite(x_f).all()
-    assert torch.equal(x_f, x_u)
-    _, x_f2 = fn(m, z=_dev(z0), seed=seed, traj_stride=0)
-    assert torch.equal(x_f, x_f2)
-    noises = [torch.tensor(PH.normal_matrix(B, 63, PH.STREAM_EM_NOISE, i, seed)) for i in range(N)]
-    _, ref_x = R.pc_sampler(p, R.SubVP(N=N), torch.tensor(z0), noises)
-    assert rel_err(t2n(x_f), ref_x.numpy()) < 1e-2
-
-
 def test_inkernel_noise_statistics():
     cfg, m, p = make_model(22, precision="bf16")
     sde, fn = _sampler(m, cfg, 2, 8192)
