@@ -33,6 +33,22 @@ class BodyDesc(C.Structure):
                 ("num_extra", C.c_int32), ("num_landmarks", C.c_int32)]
 
 
+class MotionDenoiseArgs(C.Structure):
+    """dposer_motion_denoise_args (include/dposer_hip.h), field for field."""
+    _fields_ = [("net", C.c_void_p), ("flat_params", C.c_void_p), ("packed", C.c_void_p), ("net_ws", C.c_void_p), ("sde", C.POINTER(SdeDesc)),
+                ("freq", C.c_void_p), ("sigmas", C.c_void_p), ("body", C.c_void_p), ("lbs_ws_fwd", C.c_void_p), ("lbs_ws_bwd", C.c_void_p),
+                ("posedirs_packed", C.c_void_p), ("posedirs_bwd_packed", C.c_void_p), ("j_rest", C.c_void_p), ("v_shaped", C.c_void_p),
+                ("rest_batched", C.c_int32), ("skin_idx", C.c_void_p), ("skin_w", C.c_void_p), ("skin_k", C.c_int32), ("joint_ptr", C.c_void_p),
+                ("joint_vidx", C.c_void_p), ("joint_w", C.c_void_p), ("extra_vertex_ids", C.c_void_p), ("lmk_tri", C.c_void_p),
+                ("lmk_bary", C.c_void_p), ("segment_joints_host", C.POINTER(C.c_int32)), ("num_segments", C.c_int32), ("body_segment", C.c_int32),
+                ("num_vertices", C.c_int32), ("num_joints", C.c_int32), ("joint_rows", C.c_int32), ("frames", C.c_int64), ("pose", C.c_void_p),
+                ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("joints_obs", C.c_void_p), ("n_obs_joints", C.c_int32), ("norm_mode", C.c_int32),
+                ("norm_a", C.c_void_p), ("norm_b", C.c_void_p), ("n_steps", C.c_int32), ("weighted", C.c_int32), ("t_host", C.POINTER(C.c_float)),
+                ("w_temp_host", C.POINTER(C.c_float)), ("w_data_host", C.POINTER(C.c_float)), ("w_prior_host", C.POINTER(C.c_float)),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("adam_step0", C.c_int32),
+                ("step0", C.c_uint32), ("seed", C.c_uint64), ("noise", C.c_void_p), ("scratch", C.c_void_p), ("loss_log", C.c_void_p)]
+
+
 class DPoserHipError(RuntimeError):
     pass
 
@@ -67,6 +83,8 @@ SIGNATURES = {
                                     u32, vp, vp, i64, vp]),
     "dposer_completion_optimize": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, vp, vp, C.POINTER(f32), C.POINTER(i32),
                                              C.POINTER(f32), C.POINTER(f32), i32, f64, f64, f64, f64, vp, u64, u32, vp, vp, i64, vp]),
+    "dposer_motion_denoise_scratch_bytes": (i64, [i64, i32, i32, i32]),
+    "dposer_motion_denoise_optimize": (C.c_int, [C.POINTER(MotionDenoiseArgs), vp]),
     "dposer_dsm_loss_fwd_bwd": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, f32, u64, u32, vp, vp,
                                           vp, vp, i64, vp]),
     "dposer_dsm_loss_fwd_bwd_bucketed": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, f32, u64, u32, vp, vp,

@@ -1,0 +1,234 @@
+// Task loops that span both halves of the library (score network + body model) as ONE C call.
+//
+// dposer_motion_denoise_optimize -- MotionDenoise.optimize, reference run/motion_denoising.py:199-300 (loss weights :157-163,
+// DPoser_loss :124-143, temporal / data terms :253-263): per Adam step
+//     x_n   = normalise(pose)                                                     (lib/dataset/AMASS.py offline_normalize, axis-angle)
+//     prior = sum(w (x_n - x0_hat)^2) / T at the step's shared t  -> d prior / d x_n  (dposer_prior_loss; x0_hat is detached)
+//     v, J  = SMPL / SMPL-H / SMPL-X LBS(pose)                                     (dposer_lbs_forward)
+//     temp  = mean_{t,v} || v[t] - v[t+1] ||,   data = mean_{t,j<n_obs} || J[t,j] - obs[t,j] ||   (dropped when not > 0, :261-263)
+//     d pose = LBS^T (w_temp d temp / d v,  w_data d data / d J)  +  w_prior normalise^T (d prior / d x_n)   (dposer_lbs_backward)
+//     torch.optim.Adam update of pose
+// Nothing returns to the host between steps: the launches of all steps are queued from one loop (the Python loop around the
+// same kernels spends ~3/4 of a 60-frame step in interpreter / autograd overhead and ~60 small torch kernels).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "common.h"
+
+#define TK_HIP_LAUNCH(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return dposer_set_error(DPOSER_ERR_HIP, std::string(__func__) + ": " + #expr + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {      // 256 threads, deterministic
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// offline_normalize(from_axis=True) for the axis-angle representation (AMASS.py:126-137): mode 0 identity, 1 z-score (a = mean,
+// b = std), 2 min-max (a = min, b = max)
+__global__ void __launch_bounds__(256) k_md_normalize(const float* pose, const float* a, const float* b, int mode, float* xn, int64_t n, int D) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % D);
+    const float p = pose[i];
+    float x = p;
+    if (mode == 1) x = (p - a[c]) / b[c];
+    else if (mode == 2) x = 2.0f * (p - a[c]) / (b[c] - a[c]) - 1.0f;
+    xn[i] = x;
+}
+
+// temporal term (:253-255): temp = mean over (T-1, V) of ||v[t] - v[t+1]||; d temp / d v[t] = (u_t - u_{t-1}) / ((T-1) V),
+// u_t = (v[t] - v[t+1]) / ||v[t] - v[t+1]||  (0/0 = NaN for two identical vertices, as torch's sqrt backward gives)
+__global__ void __launch_bounds__(256) k_md_vert_grad(const float* verts, float* dverts, float* part, int T, int V, float c) {
+    __shared__ float red[4];
+    const int t = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    float d_sum = 0.f;
+    if (v < V) {
+        const float* p = verts + ((int64_t)t * V + v) * 3;
+        const float px = p[0], py = p[1], pz = p[2];
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (t + 1 < T) {
+            const float* q = p + (int64_t)V * 3;
+            const float ax = px - q[0], ay = py - q[1], az = pz - q[2];
+            const float d = sqrtf(ax * ax + ay * ay + az * az);
+            gx = ax / d; gy = ay / d; gz = az / d;
+            d_sum = d;
+        }
+        if (t > 0) {
+            const float* q = p - (int64_t)V * 3;
+            const float bx = q[0] - px, by = q[1] - py, bz = q[2] - pz;
+            const float d = sqrtf(bx * bx + by * by + bz * bz);
+            gx -= bx / d; gy -= by / d; gz -= bz / d;
+        }
+        float* o = dverts + ((int64_t)t * V + v) * 3;
+        o[0] = c * gx; o[1] = c * gy; o[2] = c * gz;
+    }
+    const float tot = block_sum(d_sum, red);
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+}
+
+// data term (:257-263) and the step's loss log.  One block: pass 1 = mean distance (decides whether the term is kept: finite
+// and > 0, the reference's `if data_term > 0`), pass 2 = gradient rows.  Distances are clamped at 1e-18 before the division: a
+// zero residual contributes the value ~0 and a zero gradient (sqrt'(0) = inf would poison the backward pass).
+__global__ void __launch_bounds__(256) k_md_joint(const float* joints, int64_t ld, const float* obs, float* djoints, int T, int n_obs, float w_data,
+                                                  const float* temp_part, int n_temp_part, float temp_scale, const float* prior_loss, float* log3) {
+    __shared__ float red[4];
+    const int n = T * n_obs;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int t = e / n_obs, j = e % n_obs;
+        const float* a = joints + (int64_t)t * ld + j * 3;
+        const float* o = obs + (int64_t)e * 3;
+        const float dx = a[0] - o[0], dy = a[1] - o[1], dz = a[2] - o[2];
+        acc += sqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-36f));
+    }
+    const float mean = block_sum(acc, red) / (float)n;
+    const bool keep = isfinite(mean) && mean > 0.f;
+    const float g = keep ? w_data / (float)n : 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int t = e / n_obs, j = e % n_obs;
+        const float* a = joints + (int64_t)t * ld + j * 3;
+        const float* o = obs + (int64_t)e * 3;
+        const float dx = a[0] - o[0], dy = a[1] - o[1], dz = a[2] - o[2];
+        const float s = dx * dx + dy * dy + dz * dz;
+        float* dj = djoints + (int64_t)t * ld + j * 3;
+        if (s > 1e-36f) {
+            const float d = sqrtf(s);
+            dj[0] = g * (dx / d); dj[1] = g * (dy / d); dj[2] = g * (dz / d);
+        } else {
+            dj[0] = 0.f; dj[1] = 0.f; dj[2] = 0.f;
+        }
+    }
+    if (log3) {
+        float tp = 0.f;
+        for (int i = threadIdx.x; i < n_temp_part; i += 256) tp += temp_part[i];
+        const float temp = block_sum(tp, red) * temp_scale;
+        if (threadIdx.x == 0) { log3[0] = temp; log3[1] = keep ? mean : 0.f; log3[2] = prior_loss[0]; }
+    }
+}
+
+// d pose = LBS gradient + w_prior * normalise^T(d prior / d x_n); torch.optim.Adam (single-tensor arithmetic, as k_completion_update)
+struct MdUpdateArgs {
+    float* pose; float* m; float* v;
+    const float* dpose; const float* gprior; const float* a; const float* b;
+    int mode, D;
+    int64_t n;
+    float w_prior, step_size, one_minus_beta1, beta2, one_minus_beta2, bc2_sqrt, eps;
+};
+__global__ void __launch_bounds__(256) k_md_update(MdUpdateArgs u) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= u.n) return;
+    const int c = (int)(i % u.D);
+    float gp = u.gprior[i] * u.w_prior;
+    if (u.mode == 1) gp = gp / u.b[c];
+    else if (u.mode == 2) gp = (gp / (u.b[c] - u.a[c])) * 2.0f;
+    const float g = u.dpose[i] + gp;
+    float m = u.m[i], v = u.v[i];
+    m = m + (g - m) * u.one_minus_beta1;
+    v = v * u.beta2 + u.one_minus_beta2 * (g * g);
+    const float denom = sqrtf(v) / u.bc2_sqrt + u.eps;
+    u.pose[i] = u.pose[i] - u.step_size * (m / denom);
+    u.m[i] = m;
+    u.v[i] = v;
+}
+
+struct Scratch {
+    float *xn, *gprior, *loss1, *verts, *joints, *dverts, *djoints, *dpose, *part;
+    int64_t bytes;
+};
+Scratch layout(char* base, int64_t T, int D, int V, int n_joint_rows, int n_part) {
+    Scratch s;
+    char* p = base;
+    auto take = [&](int64_t nfloat) { float* r = (float*)p; p += round_up(nfloat * 4, 256); return r; };
+    s.xn = take(T * D); s.gprior = take(T * D); s.loss1 = take(64);
+    s.verts = take(T * V * 3); s.joints = take(T * n_joint_rows * 3);
+    s.dverts = take(T * V * 3); s.djoints = take(T * n_joint_rows * 3);
+    s.dpose = take(T * D); s.part = take(n_part);
+    s.bytes = p - base;
+    return s;
+}
+
+}   // namespace
+
+extern "C" int64_t dposer_motion_denoise_scratch_bytes(int64_t frames, int32_t pose_dim, int32_t num_vertices, int32_t joint_rows) {
+    if (frames <= 0 || pose_dim <= 0 || num_vertices <= 0 || joint_rows <= 0) return -1;
+    const int n_part = (int)(ceil_div(num_vertices, 256) * frames);
+    return layout(nullptr, frames, pose_dim, num_vertices, joint_rows, n_part).bytes;
+}
+
+extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* a, void* stream) {
+    DP_CHECK_ARG(a, "null argument");
+    DP_CHECK_ARG(a->net && a->flat_params && a->packed && a->net_ws && a->sde && a->freq && a->sigmas, "null score-network argument");
+    DP_CHECK_ARG(a->body && a->lbs_ws_fwd && a->lbs_ws_bwd && a->posedirs_packed && a->posedirs_bwd_packed && a->j_rest && a->v_shaped && a->skin_idx &&
+                     a->skin_w && a->joint_ptr && a->joint_vidx && a->joint_w && a->segment_joints_host, "null body-model argument");
+    DP_CHECK_ARG(a->pose && a->adam_m && a->adam_v && a->joints_obs && a->scratch, "null problem argument");
+    DP_CHECK_ARG(a->t_host && a->w_temp_host && a->w_data_host && a->w_prior_host && a->n_steps >= 0, "null / bad schedule");
+    DP_CHECK_ARG(a->frames >= 2, "the temporal term needs at least two frames");
+    DP_CHECK_ARG(a->num_segments >= 1 && a->num_segments <= 8 && a->body_segment >= 0 && a->body_segment < a->num_segments, "bad pose segments");
+    DP_CHECK_ARG(a->norm_mode == 0 || ((a->norm_mode == 1 || a->norm_mode == 2) && a->norm_a && a->norm_b), "bad normaliser");
+    DP_CHECK_ARG(a->num_vertices > 0 && a->num_joints > 0 && a->joint_rows >= a->num_joints && a->n_obs_joints >= 1 && a->n_obs_joints <= a->num_joints,
+                 "bad body-model sizes");
+    DP_CHECK_ARG(((uintptr_t)a->scratch & 255) == 0, "scratch must be 256-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t T = a->frames;
+    const int D = a->segment_joints_host[a->body_segment] * 3;
+    const int V = a->num_vertices;
+    const int vb = (int)ceil_div(V, 256);
+    const int n_part = vb * (int)T;
+    Scratch s = layout((char*)a->scratch, T, D, V, a->joint_rows, n_part);
+    const int64_t n = T * D;
+
+    const float* segs[8];
+    float* dsegs[8];
+    for (int i = 0; i < 8; ++i) { segs[i] = nullptr; dsegs[i] = nullptr; }
+    segs[a->body_segment] = a->pose;
+    dsegs[a->body_segment] = s.dpose;
+    // d joints: only the observed joints' columns are ever non-zero
+    TK_HIP_LAUNCH(hipMemsetAsync(s.djoints, 0, (size_t)T * a->joint_rows * 3 * 4, st));
+
+    for (int k = 0; k < a->n_steps; ++k) {
+        hipLaunchKernelGGL(k_md_normalize, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n, D);
+        TK_HIP_LAUNCH(hipGetLastError());
+        DP_TRY(dposer_prior_loss(a->net, a->flat_params, a->packed, a->net_ws, a->sde, s.xn, a->noise ? a->noise + (int64_t)k * n : nullptr,
+                                 a->t_host[k], a->weighted, 1.0f / (float)T, nullptr, s.gprior, s.loss1, a->seed, a->step0 + (uint32_t)k, a->freq,
+                                 a->sigmas, T, stream));
+        DP_TRY(dposer_lbs_forward(a->body, a->lbs_ws_fwd, a->posedirs_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest, a->rest_batched,
+                                  a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, nullptr, a->extra_vertex_ids, a->lmk_tri, a->lmk_bary,
+                                  s.verts, s.joints, T, stream));
+        const float c_temp = a->w_temp_host[k] / ((float)(T - 1) * (float)V);
+        hipLaunchKernelGGL(k_md_vert_grad, dim3((unsigned)vb, (unsigned)T), dim3(256), 0, st, (const float*)s.verts, s.dverts, s.part, (int)T, V, c_temp);
+        TK_HIP_LAUNCH(hipGetLastError());
+        hipLaunchKernelGGL(k_md_joint, dim3(1), dim3(256), 0, st, (const float*)s.joints, (int64_t)a->joint_rows * 3, a->joints_obs, s.djoints, (int)T,
+                           a->n_obs_joints, a->w_data_host[k], (const float*)s.part, n_part, 1.0f / ((float)(T - 1) * (float)V), (const float*)s.loss1,
+                           a->loss_log ? a->loss_log + 3 * (int64_t)k : nullptr);
+        TK_HIP_LAUNCH(hipGetLastError());
+        DP_TRY(dposer_lbs_backward(a->body, a->lbs_ws_fwd, a->lbs_ws_bwd, a->posedirs_bwd_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest,
+                                   a->rest_batched, a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, a->joint_ptr, a->joint_vidx, a->joint_w,
+                                   s.dverts, s.djoints, (int64_t)a->joint_rows * 3, dsegs, nullptr, nullptr, T, stream));
+        // torch.optim.Adam scalars of optimiser step adam_step0 + k + 1 (python doubles, rounded once)
+        const double stepno = (double)a->adam_step0 + k + 1;
+        const double bc1 = 1.0 - std::pow(a->beta1, stepno), bc2 = 1.0 - std::pow(a->beta2, stepno);
+        MdUpdateArgs u;
+        u.pose = a->pose; u.m = a->adam_m; u.v = a->adam_v; u.dpose = s.dpose; u.gprior = s.gprior; u.a = a->norm_a; u.b = a->norm_b;
+        u.mode = a->norm_mode; u.D = D; u.n = n; u.w_prior = a->w_prior_host[k];
+        u.step_size = (float)(a->lr / bc1); u.one_minus_beta1 = (float)(1.0 - a->beta1); u.beta2 = (float)a->beta2;
+        u.one_minus_beta2 = (float)(1.0 - a->beta2); u.bc2_sqrt = (float)std::sqrt(bc2); u.eps = (float)a->eps;
+        hipLaunchKernelGGL(k_md_update, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, u);
+        TK_HIP_LAUNCH(hipGetLastError());
+    }
+    return DPOSER_OK;
+}

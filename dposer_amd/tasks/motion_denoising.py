@@ -4,12 +4,18 @@
 Per Adam step: z-score normalise -> ``dposer_prior_loss`` -> ``BodyModel`` forward WITH gradient
 (dposer_lbs_forward / dposer_lbs_backward) -> temporal term on vertices + data term on Jtr[:, :22].
 The frames of one sequence are coupled by the temporal term, so data parallelism is over sequences.
+
+The whole loop is ONE call, ``dposer_motion_denoise_optimize`` (axis-angle representation, sub-VP / VP SDE, positional embedding):
+all steps are queued from C, the loss gradients and torch.optim.Adam's update are kernels, nothing returns to the host in
+between.  Other configurations (and ``fused=False``) run the same step through autograd and torch's Adam.
 """
+import ctypes as C
 import math
 
 import numpy as np
 import torch
 
+from .. import _C
 from ..algorithms.advanced import sde_lib
 from ..prior import prior_loss
 from ..utils.misc import gaussian_smoothing
@@ -54,48 +60,121 @@ class MotionDenoise:
         return {"temp": lambda cst, it: 10.0 ** 1 * cst * (1 + it), "data": lambda cst, it: 10.0 ** 2 * cst / (1 + it * it),
                 "dposer": lambda cst, it: 10.0 ** -1 * cst * (1 + it) * self.dposer_weight}
 
+    def _fused_supported(self):
+        from ..algorithms.advanced.model import ScoreModelFC
+        from ..body_model.body_model import BodyModel
+        nz = self.Normalizer
+        return (sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
+                and self.model.time_embedding_type == "positional" and isinstance(self.body_model, BodyModel)
+                and getattr(nz, "rot_rep", None) == "axis" and self.batch_size >= 2)
+
+    def _optimize_fused(self, pose, init_joints, t_list, its, weights, noise):
+        """All optimisation steps in one C call; ``pose`` [T, 63] is updated in place.  Returns the per-step loss log [steps, 3]
+        (temp, data, prior; device tensor)."""
+        model, core, nz = self.model, self.body_model.bm, self.Normalizer
+        dev = pose.device
+        T, D = pose.shape
+        n_steps = len(t_list)
+        eng = model._engine()
+        flat = model.flat_params()
+        packed = eng.packed(flat, with_backward=False, force=not model.freeze_packed)      # once per loop
+        ws = eng.workspace(T, _C.WS_SHARED_T, 1, dev)
+        lib, h = _C.lib(), core._handle()
+        v_shaped, j_rest, batched = core.rest_shape(self.betas, None)
+        v_shaped, j_rest = v_shaped.contiguous(), j_rest.contiguous()
+        names = [name for name, _ in core.segments]
+        segj = (C.c_int32 * len(names))(*[nj for _, nj in core.segments])
+        jptr, jvidx, jw = core.joint_csr()
+        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+        ws_f, ws_b = u8(lib.dposer_lbs_workspace_bytes(h, T)), u8(lib.dposer_lbs_backward_workspace_bytes(h, T))
+        rows = core.J + core.n_extra + core.n_lmk
+        scratch = u8(lib.dposer_motion_denoise_scratch_bytes(T, D, core.V, rows))
+        m, v = torch.zeros_like(pose), torch.zeros_like(pose)
+        log = torch.zeros(n_steps, 3, dtype=torch.float32, device=dev)
+        obs = init_joints.detach().contiguous().float()
+        if not nz.normalize:
+            mode, na, nb = 0, None, None
+        elif nz.min_max:
+            mode, (na, nb) = 2, nz._stats(nz.min_poses, nz.max_poses, pose)
+        else:
+            mode, (na, nb) = 1, nz._stats(nz.mean_poses, nz.std_poses, pose)
+        if mode:
+            na, nb = na.reshape(-1).contiguous().float(), nb.reshape(-1).contiguous().float()
+        nzs = None if noise is None else noise.detach().contiguous().float()
+        fl = lambda xs: (C.c_float * n_steps)(*[float(x) for x in xs])
+        step0 = self._calls + 1
+        self._calls += n_steps
+        desc = sde_lib.sde_desc(self.sde)
+        a = _C.MotionDenoiseArgs(
+            net=eng.h, flat_params=_C.ptr(flat), packed=_C.ptr(packed), net_ws=_C.ptr(ws), sde=C.pointer(desc), freq=_C.ptr(eng.freq(dev)),
+            sigmas=_C.ptr(model.sigmas), body=h, lbs_ws_fwd=_C.ptr(ws_f), lbs_ws_bwd=_C.ptr(ws_b), posedirs_packed=_C.ptr(core._packed_posedirs()),
+            posedirs_bwd_packed=_C.ptr(core._packed_posedirs_bwd()), j_rest=_C.ptr(j_rest), v_shaped=_C.ptr(v_shaped),
+            rest_batched=1 if batched else 0, skin_idx=_C.ptr(core.skin_idx), skin_w=_C.ptr(core.skin_w), skin_k=int(core.skin_idx.shape[1]),
+            joint_ptr=_C.ptr(jptr), joint_vidx=_C.ptr(jvidx), joint_w=_C.ptr(jw), extra_vertex_ids=_C.ptr(core.extra_vertex_ids),
+            lmk_tri=_C.ptr(core.lmk_tri), lmk_bary=_C.ptr(core.lmk_bary_coords), segment_joints_host=segj, num_segments=len(names),
+            body_segment=names.index("body_pose"), num_vertices=core.V, num_joints=core.J, joint_rows=rows, frames=T, pose=_C.ptr(pose),
+            adam_m=_C.ptr(m), adam_v=_C.ptr(v), joints_obs=_C.ptr(obs), n_obs_joints=int(obs.shape[1]), norm_mode=mode, norm_a=_C.ptr(na),
+            norm_b=_C.ptr(nb), n_steps=n_steps, weighted=0, t_host=fl(t_list), w_temp_host=fl(weights["temp"](1.0, it) for it in its),
+            w_data_host=fl(weights["data"](1.0, it) for it in its), w_prior_host=fl(weights["dposer"](1.0, it) for it in its),
+            lr=0.03, beta1=0.9, beta2=0.999, eps=1e-8, adam_step0=0, step0=int(step0) & 0xFFFFFFFF, seed=int(model._rng_seed + 31),
+            noise=_C.ptr(nzs), scratch=_C.ptr(scratch), loss_log=_C.ptr(log))
+        _C.check(lib.dposer_motion_denoise_optimize(C.byref(a), _C.stream_ptr()), "dposer_motion_denoise_optimize")
+        return log
+
+    def _quan_t(self, time_strategy, step, total_steps, sample_trun, sample_time):
+        if time_strategy == "1":
+            return int(torch.randint(self.sde.N, [1]))
+        if time_strategy == "2":
+            return int(sample_time)
+        if time_strategy == "3":
+            return int(self.sde.N - math.floor(float(np.float32(total_steps - step - 1) * np.float32(self.sde.N / (sample_trun * total_steps)))) - 2)
+        raise NotImplementedError("unsupported time sampling strategy")
+
     def optimize(self, joints3d, gt_poses=None, time_strategy="1", sample_trun=2.0, sample_time=990, iterations=5, steps_per_iter=50,
-                 verbose=False, vis=False, noise=None, init_poses=None):
-        """motion_denoising.py:199-300 (visualisation dropped).  Returns {'init_MPJPE', 'MPJPE', 'MPVPE'} in cm per frame."""
+                 verbose=False, vis=False, noise=None, init_poses=None, fused=None):
+        """motion_denoising.py:199-300 (visualisation dropped).  Returns {'init_MPJPE', 'MPJPE', 'MPVPE'} in cm per frame.
+        ``fused``: None = the one-call loop when the configuration supports it, False = step by step through autograd."""
         bm = self.body_model
         with torch.no_grad():
             gt = bm(betas=self.betas, pose_body=gt_poses)
             joint_error = joints3d - gt.Jtr[:, :22]
             init_mpjpe = torch.mean(torch.sqrt(torch.sum(joint_error * joint_error, dim=2)), dim=1) * 100.0
         init_joints = joints3d.detach()
-        pose = (self.poses if init_poses is None else init_poses).clone().detach().requires_grad_(True)
-        optimizer = torch.optim.Adam([pose], 0.03, betas=(0.9, 0.999))
         weights = self.get_loss_weights()
         timesteps = torch.linspace(self.sde.T, 1e-3, self.sde.N)
         total_steps = iterations * steps_per_iter
-        for it in range(iterations):
-            for i in range(steps_per_iter):
-                step = it * steps_per_iter + i
-                optimizer.zero_grad()
-                poses_n = self.Normalizer.offline_normalize(pose, from_axis=True)
-                if time_strategy == "1":
-                    q = int(torch.randint(self.sde.N, [1]))
-                elif time_strategy == "2":
-                    q = int(sample_time)
-                elif time_strategy == "3":
-                    q = int(self.sde.N - math.floor(float(np.float32(total_steps - step - 1) * np.float32(self.sde.N / (sample_trun * total_steps)))) - 2)
-                else:
-                    raise NotImplementedError("unsupported time sampling strategy")
-                losses = {"dposer": self.DPoser_loss(poses_n, float(timesteps[q]), z=None if noise is None else noise[step])}
-                body = bm(betas=self.betas, pose_body=pose)                          # forward WITH gradient
-                temp = body.v[:-1] - body.v[1:]
-                losses["temp"] = torch.mean(torch.sqrt(torch.sum(temp * temp, dim=2)))
-                data = body.Jtr[:, :22] - init_joints
-                # motion_denoising.py:262 keeps the data term only `if data_term > 0` ("for nans"): a host sync per step whose
-                # real job is the all-zero case (pose still equal to the observation: value 0, but sqrt'(0) = inf poisons the
-                # backward pass).  Same effect without the sync: distances are clamped away from 0 before the sqrt, so a zero
-                # residual contributes the value ~0 and a ZERO gradient, and a non-finite / non-positive term is dropped by value.
-                dist = torch.sqrt(torch.sum(data * data, dim=2).clamp_min(1e-36))
-                data_term = torch.mean(dist)
-                losses["data"] = torch.where(torch.isfinite(data_term) & (data_term > 0), data_term, torch.zeros_like(data_term))
-                tot = torch.stack([weights[k](v, it) for k, v in losses.items()]).sum()
-                tot.backward()
-                optimizer.step()
+        use_fused = self._fused_supported() if fused is None else bool(fused)
+        if use_fused:
+            if not self._fused_supported():
+                raise NotImplementedError("the one-call motion-denoising loop covers axis-angle poses, sub-VP / VP SDEs and the positional embedding")
+            pose = (self.poses if init_poses is None else init_poses).detach().clone().contiguous().float()
+            quan = [self._quan_t(time_strategy, step, total_steps, sample_trun, sample_time) for step in range(total_steps)]
+            self.loss_log = self._optimize_fused(pose, init_joints, [float(timesteps[q]) for q in quan],
+                                                 [s // steps_per_iter for s in range(total_steps)], weights, noise)
+        else:
+            pose = (self.poses if init_poses is None else init_poses).clone().detach().requires_grad_(True)
+            optimizer = torch.optim.Adam([pose], 0.03, betas=(0.9, 0.999))
+            for it in range(iterations):
+                for i in range(steps_per_iter):
+                    step = it * steps_per_iter + i
+                    optimizer.zero_grad()
+                    poses_n = self.Normalizer.offline_normalize(pose, from_axis=True)
+                    q = self._quan_t(time_strategy, step, total_steps, sample_trun, sample_time)
+                    losses = {"dposer": self.DPoser_loss(poses_n, float(timesteps[q]), z=None if noise is None else noise[step])}
+                    body = bm(betas=self.betas, pose_body=pose)                          # forward WITH gradient
+                    temp = body.v[:-1] - body.v[1:]
+                    losses["temp"] = torch.mean(torch.sqrt(torch.sum(temp * temp, dim=2)))
+                    data = body.Jtr[:, :22] - init_joints
+                    # motion_denoising.py:262 keeps the data term only `if data_term > 0` ("for nans"): a host sync per step whose
+                    # real job is the all-zero case (pose still equal to the observation: value 0, but sqrt'(0) = inf poisons the
+                    # backward pass).  Same effect without the sync: distances are clamped away from 0 before the sqrt, so a zero
+                    # residual contributes the value ~0 and a ZERO gradient, and a non-finite / non-positive term is dropped by value.
+                    dist = torch.sqrt(torch.sum(data * data, dim=2).clamp_min(1e-36))
+                    data_term = torch.mean(dist)
+                    losses["data"] = torch.where(torch.isfinite(data_term) & (data_term > 0), data_term, torch.zeros_like(data_term))
+                    tot = torch.stack([weights[k](v, it) for k, v in losses.items()]).sum()
+                    tot.backward()
+                    optimizer.step()
         with torch.no_grad():
             final = pose.detach()
             smooth = gaussian_smoothing(final, window_size=3, sigma=2)

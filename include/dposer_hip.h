@@ -316,6 +316,79 @@ int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const
                         int64_t d_joints_ld, float* const* d_pose_segments_host, float* d_jrest, float* d_vposed,
                         int64_t batch, void* stream);
 
+/* MotionDenoise.optimize -- run/motion_denoising.py:199-300 (DPoser_loss :124-143, weights :157-163, temporal / data terms
+ * :253-263): `n_steps` torch.optim.Adam steps on the axis-angle body pose [frames, body joints * 3] of ONE sequence under
+ *   w_temp[i] * mean ||v[t] - v[t+1]|| + w_data[i] * mean ||Jtr[:, :n_obs_joints] - joints_obs|| + w_prior[i] * DPoser_loss(normalise(pose)),
+ * all steps queued from one call (prior evaluation = dposer_prior_loss, body model = dposer_lbs_forward / _backward, the
+ * loss gradients and the Adam update are kernels of this entry).  The data term is dropped for a step when its value is not
+ * finite and > 0 (:261-263) -- decided on the device.
+ *   score network: handle, parameters, packed weights, a DPOSER_WS_SHARED_T workspace for `frames` samples (1 table row);
+ *   body model: handle + the device tables dposer_lbs_forward / dposer_lbs_backward take, their two workspaces for `frames`
+ *   poses; rest_batched: v_shaped / j_rest are [frames, ...] instead of shared; pose segments other than `body_segment` are
+ *   the zero pose;  joint_rows = J + num_extra + num_landmarks (row count of the LBS joint output);
+ *   norm_mode 0 none / 1 z-score (norm_a = mean, norm_b = std) / 2 min-max (norm_a = min, norm_b = max), arrays [pose dim];
+ *   t_host / w_temp_host / w_data_host / w_prior_host [n_steps]: HOST arrays; weighted: the `weighted` flag of DPoser_loss
+ *   (False in the reference, :124); adam_m / adam_v zero on entry for a fresh optimiser, adam_step0 = steps already taken;
+ *   noise [n_steps, frames, pose dim] injected z of the prior or NULL -> Philox(seed, step0 + i);
+ *   scratch: dposer_motion_denoise_scratch_bytes(frames, pose dim, V, joint_rows) bytes, 256-byte aligned;
+ *   loss_log: DEVICE [n_steps, 3] (temp, data, prior values of every step, unweighted) or NULL. */
+typedef struct dposer_motion_denoise_args {
+    dposer_scorefc_t net;
+    const float* flat_params;
+    const void* packed;
+    void* net_ws;
+    const dposer_sde_desc* sde;
+    const float* freq;
+    const float* sigmas;
+    dposer_body_t body;
+    void* lbs_ws_fwd;
+    void* lbs_ws_bwd;
+    const void* posedirs_packed;
+    const void* posedirs_bwd_packed;
+    const float* j_rest;
+    const float* v_shaped;
+    int32_t rest_batched;
+    const int32_t* skin_idx;
+    const float* skin_w;
+    int32_t skin_k;
+    const int32_t* joint_ptr;
+    const int32_t* joint_vidx;
+    const float* joint_w;
+    const int32_t* extra_vertex_ids;
+    const int32_t* lmk_tri;
+    const float* lmk_bary;
+    const int32_t* segment_joints_host;
+    int32_t num_segments;
+    int32_t body_segment;
+    int32_t num_vertices;
+    int32_t num_joints;
+    int32_t joint_rows;
+    int64_t frames;
+    float* pose;
+    float* adam_m;
+    float* adam_v;
+    const float* joints_obs;
+    int32_t n_obs_joints;
+    int32_t norm_mode;
+    const float* norm_a;
+    const float* norm_b;
+    int32_t n_steps;
+    int32_t weighted;
+    const float* t_host;
+    const float* w_temp_host;
+    const float* w_data_host;
+    const float* w_prior_host;
+    double lr, beta1, beta2, eps;
+    int32_t adam_step0;
+    uint32_t step0;
+    uint64_t seed;
+    const float* noise;
+    void* scratch;
+    float* loss_log;
+} dposer_motion_denoise_args;
+int64_t dposer_motion_denoise_scratch_bytes(int64_t frames, int32_t pose_dim, int32_t num_vertices, int32_t joint_rows);
+int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,6 +150,76 @@ def test_motion_denoise_zero_data_residual_stays_finite():
     assert np.abs(t2n(res["pose_body"]) - g["b_pose_final"]).max() < 0.2          # Adam lr 0.03 x 6 steps bounds the drift
 
 
+def _md_setup(T=12, min_max=False, seed=7):
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    from dposer_amd.dataset.AMASS import Posenormalizer
+    from dposer_amd.tasks.motion_denoising import MotionDenoise
+    cfg, m, p = make_model(63, precision="fp32")
+    asset = make_synthetic_smplx_asset(seed=0)
+    bm = BodyModel(asset).to(DEV)
+    g = load("g10_normalizer")
+    stats = {k.split("/")[-1]: torch.tensor(g[k]) for k in g.files if k.startswith("stats/axis_normalize")}
+    gt = g["raw"][:T].astype(np.float32)
+    rs = np.random.RandomState(seed)
+    init = (gt + rs.standard_normal(gt.shape) * 0.05).astype(np.float32)
+    _, jgt, _, _ = fk_ref.smplx_forward(asset, gt.astype(np.float64), dtype=np.float64)
+    joints3d = (jgt[:, :22] + rs.standard_normal((T, 22, 3)) * 0.04).astype(np.float32)
+
+    class Args:
+        device = DEV
+
+    nz = Posenormalizer(stats, device=DEV, normalize=True, min_max=min_max, rot_rep="axis")
+    md = MotionDenoise(cfg, Args(), m, bm, sde_N=500, batch_size=T, normalizer=nz)
+    dev = lambda a: torch.tensor(a, device=DEV)
+    return md, dev(joints3d), dev(gt), dev(init), rs
+
+
+@pytest.mark.parametrize("min_max", [False, True])
+def test_motion_denoise_one_call_loop_matches_the_autograd_loop(min_max):
+    """dposer_motion_denoise_optimize (all steps queued from C: loss gradients + Adam as kernels) vs the same steps through
+    autograd and torch.optim.Adam around the same HIP kernels, with injected prior noise; z-score and min-max normalisers;
+    two outer iterations so the loss weights change.  The per-step loss log equals the autograd loop's loss values."""
+    T, iters, spi = 12, 2, 4
+    md, joints3d, gt, init, rs = _md_setup(T, min_max)
+    noise = torch.tensor(rs.standard_normal((iters * spi, T, 63)).astype(np.float32), device=DEV)
+    kw = dict(gt_poses=gt, time_strategy="3", iterations=iters, steps_per_iter=spi, noise=noise, init_poses=init)
+    res_f = md.optimize(joints3d, fused=True, **kw)
+    log = t2n(md.loss_log)
+    res_u = md.optimize(joints3d, fused=False, **kw)
+    assert rel_err(t2n(res_f["pose_body"]), t2n(res_u["pose_body"])) < 2e-5
+    assert np.allclose(res_f["MPJPE"], res_u["MPJPE"], rtol=1e-4, atol=1e-4)
+    assert log.shape == (iters * spi, 3) and np.isfinite(log).all() and (log > 0).all()
+    # first step: the loss values at the initial pose, recomputed with the public pieces
+    from dposer_amd.prior import prior_loss
+    with torch.no_grad():
+        body = md.body_model(betas=md.betas, pose_body=init)
+        temp = body.v[:-1] - body.v[1:]
+        l_temp = float(torch.mean(torch.sqrt(torch.sum(temp * temp, dim=2))))
+        d = body.Jtr[:, :22] - joints3d
+        l_data = float(torch.mean(torch.sqrt(torch.sum(d * d, dim=2))))
+    assert abs(log[0, 0] - l_temp) / l_temp < 1e-5 and abs(log[0, 1] - l_data) / l_data < 1e-5
+
+
+def test_motion_denoise_one_call_loop_inkernel_noise():
+    """No injected noise: the prior's z comes from Philox(seed, step0 + i).  Same object state -> same result; the next call
+    (advanced call counter) draws different noise; a zero-residual observation keeps everything finite (data term dropped on
+    the device)."""
+    T = 10
+    md, joints3d, gt, init, rs = _md_setup(T)
+    kw = dict(gt_poses=gt, time_strategy="3", iterations=1, steps_per_iter=5, init_poses=init)
+    c0 = md._calls
+    a = md.optimize(joints3d, **kw)["pose_body"]
+    md._calls = c0
+    b = md.optimize(joints3d, **kw)["pose_body"]
+    c = md.optimize(joints3d, **kw)["pose_body"]
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(c).all()
+    with torch.no_grad():
+        j0 = md.body_model(betas=md.betas, pose_body=init).Jtr[:, :22].contiguous()
+    z = md.optimize(j0, **kw)
+    assert torch.isfinite(z["pose_body"]).all() and np.isfinite(z["MPJPE"]).all()
+
+
 def test_evaler_min_over_hypotheses():
     from dposer_amd.body_model.body_model import BodyModel
     from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset

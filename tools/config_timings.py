@@ -28,6 +28,7 @@ def timed(fn, warm=1, reps=1):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None       # e.g. `cfg5`: that configuration only (for rocprofv3 runs)
     from dposer_amd.algorithms.advanced import losses, sampling, sde_lib
     from dposer_amd.algorithms.advanced.model import ScoreModelFC
     from dposer_amd.algorithms.ema import ExponentialMovingAverage
@@ -49,37 +50,43 @@ def main():
     norm = Posenormalizer(stats, device=dev, normalize=True, min_max=False, rot_rep="axis")
     rows = []
 
-    # cfg2: training step, batch 8192
     sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
-    state = dict(model=model, optimizer=losses.get_optimizer(cfg, model.parameters()),
-                 ema=ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate), step=0)
-    step_fn = losses.get_step_fn(sde, True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
-    batch = norm.offline_normalize(toy[torch.randint(0, 500, (8192,))].to(dev))
-    s = timed(lambda: [step_fn(state, batch) for _ in range(20)], warm=1) / 20
-    rows.append(("cfg2", "train step, batch 8192 (axis-angle)", f"{s * 1e3:.3f} ms / step", f"{8192 / s:,.0f} poses/s"))
+    if only in (None, 'cfg2'):
+        # cfg2: training step, batch 8192
+        state = dict(model=model, optimizer=losses.get_optimizer(cfg, model.parameters()),
+                     ema=ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate), step=0)
+        step_fn = losses.get_step_fn(sde, True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+        batch = norm.offline_normalize(toy[torch.randint(0, 500, (8192,))].to(dev))
+        s = timed(lambda: [step_fn(state, batch) for _ in range(20)], warm=1) / 20
+        rows.append(("cfg2", "train step, batch 8192 (axis-angle)", f"{s * 1e3:.3f} ms / step", f"{8192 / s:,.0f} poses/s"))
 
-    # cfg3: 500 samples, 1000-step EM sampler
     model.eval()
-    fn = sampling.get_sampling_fn(cfg, sde, (500, 63), lambda v: v, 1e-3, device=dev)
-    s = timed(lambda: fn(model, traj_stride=0), warm=1)
-    rows.append(("cfg3", "1000-step EM sampling, 500 poses", f"{s:.3f} s", f"{500 / s:,.0f} samples/s"))
+    if only in (None, 'cfg3'):
+        # cfg3: 500 samples, 1000-step EM sampler
+        fn = sampling.get_sampling_fn(cfg, sde, (500, 63), lambda v: v, 1e-3, device=dev)
+        s = timed(lambda: fn(model, traj_stride=0), warm=1)
+        rows.append(("cfg3", "1000-step EM sampling, 500 poses", f"{s:.3f} s", f"{500 / s:,.0f} samples/s"))
 
-    # cfg4: completion, batch 16384, legs masked, 2 x 100 steps (one hypothesis)
-    poses = norm.offline_normalize(toy[torch.randint(0, 500, (16384,))].to(dev))
-    mask, obs = create_mask(poses, part="legs")
-    comp = DPoserComp(model, sde, continuous=True, batch_size=16384)
-    s = timed(lambda: comp.optimize(obs, mask, iterations=2, steps_per_iter=100), warm=1)
-    rows.append(("cfg4", "completion (legs), batch 16384, 200 optimisation steps", f"{s:.3f} s / hypothesis", f"{16384 / s:,.0f} poses/s/hypothesis"))
+    if only in (None, 'cfg4'):
+        # cfg4: completion, batch 16384, legs masked, 2 x 100 steps (one hypothesis)
+        poses = norm.offline_normalize(toy[torch.randint(0, 500, (16384,))].to(dev))
+        mask, obs = create_mask(poses, part="legs")
+        comp = DPoserComp(model, sde, continuous=True, batch_size=16384)
+        s = timed(lambda: comp.optimize(obs, mask, iterations=2, steps_per_iter=100), warm=1)
+        rows.append(("cfg4", "completion (legs), batch 16384, 200 optimisation steps", f"{s:.3f} s / hypothesis", f"{16384 / s:,.0f} poses/s/hypothesis"))
 
-    # cfg5: motion denoising, one 60-frame sequence, 5 x 50 steps
-    bm = BodyModel(make_synthetic_smplx_asset(seed=0), batch_size=60).to(dev)
-    args = types.SimpleNamespace(device=dev, dataset_folder="", version="", task="denoise")
-    md = MotionDenoise(cfg, args, model, bm, sde_N=1000, batch_size=60, normalizer=norm)
-    gt = toy[:60].to(dev)
-    with torch.no_grad():
-        joints = bm(pose_body=gt, betas=md.betas).Jtr[:, :22] + 0.04 * torch.randn(60, 22, 3, device=dev)
-    s = timed(lambda: md.optimize(joints, gt_poses=gt, iterations=5, steps_per_iter=50), warm=1)
-    rows.append(("cfg5", "motion denoising, 60 frames, 250 optimisation steps (LBS fwd+bwd + prior)", f"{s:.3f} s / sequence", f"{s / 250 * 1e3:.2f} ms / step"))
+    if only in (None, 'cfg5'):
+        # cfg5: motion denoising, one 60-frame sequence, 5 x 50 steps
+        bm = BodyModel(make_synthetic_smplx_asset(seed=0), batch_size=60).to(dev)
+        args = types.SimpleNamespace(device=dev, dataset_folder="", version="", task="denoise")
+        md = MotionDenoise(cfg, args, model, bm, sde_N=1000, batch_size=60, normalizer=norm)
+        gt = toy[:60].to(dev)
+        with torch.no_grad():
+            joints = bm(pose_body=gt, betas=md.betas).Jtr[:, :22] + 0.04 * torch.randn(60, 22, 3, device=dev)
+        s = timed(lambda: md.optimize(joints, gt_poses=gt, iterations=5, steps_per_iter=50), warm=1)
+        rows.append(("cfg5", "motion denoising, 60 frames, 250 optimisation steps (LBS fwd+bwd + prior), one C call", f"{s:.3f} s / sequence", f"{s / 250 * 1e3:.2f} ms / step"))
+        s = timed(lambda: md.optimize(joints, gt_poses=gt, iterations=5, steps_per_iter=50, fused=False), warm=1)
+        rows.append(("cfg5 (autograd loop)", "the same steps through autograd + torch.optim.Adam around the same kernels", f"{s:.3f} s / sequence", f"{s / 250 * 1e3:.2f} ms / step"))
 
     print("| config | workload | time | rate |")
     print("|---|---|---:|---:|")
