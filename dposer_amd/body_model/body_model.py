@@ -110,13 +110,12 @@ class _LBSFunction(torch.autograd.Function):
         J = core.J
         dv = d_verts.contiguous().float().clone()
         dj = d_joints.contiguous().float()
-        # extras / landmarks are gathers of vertices: fold their gradients into d verts
-        if core.n_extra:
-            dv.index_add_(1, core.extra_vertex_ids.long(), dj[:, J:J + core.n_extra])
-        if core.n_lmk:
-            dl = dj[:, J + core.n_extra:]
-            for f in range(3):
-                dv.index_add_(1, core.lmk_tri[:, f].long(), dl * core.lmk_bary_coords[:, f].view(1, -1, 1))
+        # extras / landmarks are gathers of vertices: fold their gradients into d verts.  One small dense product onto the
+        # UNIQUE vertices they touch, then an index_add_ without duplicate indices: deterministic (index_add_ with the raw,
+        # repeating landmark-triangle indices is an atomicAdd race whose order changes the last bit from run to run)
+        if core.n_extra + core.n_lmk:
+            uniq, fold = core.joint_fold()
+            dv.index_add_(1, uniq, torch.matmul(fold, dj[:, J:]))
         # transl shifts every vertex and the J LBS joints (extras / landmarks move with their vertices: already in dv)
         d_transl = (dv.sum(dim=1) + dj[:, :J].sum(dim=1)) if ctx.has_transl else None
         ws_b = torch.empty(lib.dposer_lbs_backward_workspace_bytes(h, B), dtype=torch.uint8, device=dev)
@@ -230,6 +229,25 @@ class _SMPLCore(nn.Module):
             self._jcsr = (torch.tensor(ptr, device=dev), torch.tensor(v[order].astype(np.int32), device=dev),
                           torch.tensor(ww[order].astype(np.float32), device=dev))
         return self._jcsr
+
+    def joint_fold(self):
+        """(unique vertex ids [U], fold [U, n_extra + n_lmk]): d verts[:, ids] += fold @ d joints[:, J:] is the backward of the
+        vertex-selected extra joints and of the barycentric landmarks (smplx VertexJointSelector / vertices2landmarks)."""
+        dev = self.skin_idx.device
+        if getattr(self, "_jfold", None) is None or self._jfold[0].device != dev:
+            ex = self.extra_vertex_ids.cpu().numpy().astype(np.int64)
+            tri = self.lmk_tri.cpu().numpy().astype(np.int64).reshape(-1, 3)
+            bary = self.lmk_bary_coords.cpu().numpy().astype(np.float32).reshape(-1, 3)
+            uniq = np.unique(np.concatenate([ex, tri.reshape(-1)]))
+            pos = {int(v): i for i, v in enumerate(uniq)}
+            fold = np.zeros((len(uniq), len(ex) + len(tri)), dtype=np.float32)
+            for e, v in enumerate(ex):
+                fold[pos[int(v)], e] += 1.0
+            for l in range(len(tri)):
+                for f in range(3):
+                    fold[pos[int(tri[l, f])], len(ex) + l] += bary[l, f]
+            self._jfold = (torch.tensor(uniq, device=dev), torch.tensor(fold, device=dev))
+        return self._jfold
 
     def _packed_posedirs_bwd(self):
         dev = self.posedirs.device

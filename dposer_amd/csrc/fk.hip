@@ -568,6 +568,119 @@ template <typename Kin, int NT, int NOUT = 0> __global__ void __launch_bounds__(
     }
 }
 
+// ---- small batches: one wave per pose, one lane per joint -------------------------------------------------------------------
+// k_fk_joints gives a lane a whole pose: its ~55 Rodrigues + matrix products are a serial chain, 80-100 us however few poses
+// there are (a 60-frame motion-denoising step spent 190 of its 490 us in the forward and backward chains of 60 poses).  Below
+// `fk_small_max()` poses the chain is walked by tree depth instead: lane I owns joint I (J <= 64), every lane evaluates its
+// Rodrigues formula at once, and level d of the tree (<= 10 for SMPL-X) reads its parents' transforms from LDS.  Per-joint
+// arithmetic is the same expressions in the same order as fk_step => bit-identical outputs (tests/test_gpu_fk.py).
+template <typename Kin> constexpr int fk_max_depth() {
+    int m = 0;
+    for (int i = 0; i < Kin::J; ++i) {
+        int d = 0;
+        for (int q = i; q > 0; q = Kin::P[q]) ++d;
+        m = d > m ? d : m;
+    }
+    return m;
+}
+template <typename Kin> struct KinTable {          // the parents table where device code can index it with a lane id
+    int p[Kin::J];
+    constexpr KinTable() : p() {
+        for (int i = 0; i < Kin::J; ++i) p[i] = Kin::P[i] < 0 ? 0 : Kin::P[i];
+    }
+};
+template <typename Kin> __device__ constexpr KinTable<Kin> kKinTable{};
+
+static int64_t fk_small_max() {      // (read at every call: the tests switch between the two kernel families in one process)
+    const char* e = getenv("DPOSER_FK_SMALL_MAX");
+    return e ? atoll(e) : (int64_t)8192;
+}
+
+template <typename Kin> __global__ void __launch_bounds__(64) k_fk_small(FkArgs a) {
+    constexpr int J = Kin::J;
+    constexpr int MAXD = fk_max_depth<Kin>();
+    __shared__ float sG[J][12];
+    const int64_t b = blockIdx.x;
+    const int I = threadIdx.x;
+    const int n_out = a.n_out;
+    const bool on = I < n_out;
+    int P = 0, depth = 0;
+    if (on) {
+        P = kKinTable<Kin>.p[I];
+        for (int q = I; q > 0; q = kKinTable<Kin>.p[q]) ++depth;
+    }
+    // this joint's axis-angle: segment pointers through unrolled selects (a runtime index into the kernel-argument arrays would
+    // spill the argument struct to scratch)
+    int li = I;
+    const float* pose = a.seg[0];
+    int seg_nj = a.seg_joints[0];
+#pragma unroll
+    for (int k = 1; k < FK_MAX_SEG; ++k)
+        if (k < a.nseg && I >= a.seg_first[k]) { li = I - a.seg_first[k]; pose = a.seg[k]; seg_nj = a.seg_joints[k]; }
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (on && pose) { const float* q = pose + (b * seg_nj + li) * 3; rx = q[0]; ry = q[1]; rz = q[2]; }
+    const float* jr = a.j_rest_batched ? a.j_rest + b * (int64_t)J * 3 : a.j_rest;
+    float tr[3] = {0.f, 0.f, 0.f};
+    if (a.transl) { tr[0] = a.transl[b * 3]; tr[1] = a.transl[b * 3 + 1]; tr[2] = a.transl[b * 3 + 2]; }
+    const Mat3 R = rodrigues(rx, ry, rz);
+    float rel[3] = {0.f, 0.f, 0.f};
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rel[k] = jr[3 * I + k] - (I > 0 ? jr[3 * P + k] : 0.f);
+    }
+    Xf G;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) G.r[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) G.t[k] = 0.f;
+    for (int L = 0; L <= MAXD; ++L) {
+        if (on && depth == L) {
+            if (I == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) G.r[k] = R.m[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) G.t[k] = rel[k];
+            } else {
+                Xf Pm;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Pm.r[k] = sG[P][k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) Pm.t[k] = sG[P][9 + k];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        G.r[3 * r + c] = fmaf(Pm.r[3 * r], R.m[c], fmaf(Pm.r[3 * r + 1], R.m[3 + c], Pm.r[3 * r + 2] * R.m[6 + c]));
+                    G.t[r] = fmaf(Pm.r[3 * r], rel[0], fmaf(Pm.r[3 * r + 1], rel[1], fmaf(Pm.r[3 * r + 2], rel[2], Pm.t[r])));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sG[I][k] = G.r[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sG[I][9 + k] = G.t[k];
+        }
+        __syncthreads();
+    }
+    if (!on) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.joints[b * a.joints_ld + 3 * I + k] = G.t[k] + tr[k];
+    if (a.pf && I > 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.pf[FT<float>::index(b, (I - 1) * 9 + k, a.pf_K)] = R.m[k] - ((k % 4 == 0) ? 1.0f : 0.0f);
+    }
+    if (a.rel) {
+        const float jx = jr[3 * I], jy = jr[3 * I + 1], jz = jr[3 * I + 2];
+        f32x4* q = reinterpret_cast<f32x4*>(a.rel + (b * n_out + I) * 12);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            f32x4 v;
+            v[0] = G.r[3 * r]; v[1] = G.r[3 * r + 1]; v[2] = G.r[3 * r + 2];
+            v[3] = G.t[r] - (G.r[3 * r] * jx + G.r[3 * r + 1] * jy + G.r[3 * r + 2] * jz);
+            q[r] = v;
+        }
+    }
+}
+
 struct dposer_body_s {
     dposer_body_desc d;
     int kind;   // 0 SMPL, 1 SMPL-H, 2 SMPL-X
@@ -606,6 +719,10 @@ template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t
 #else
     constexpr int NT = 64;
 #endif
+    if (a.B <= fk_small_max()) {                                    // one wave per pose, one lane per joint
+        hipLaunchKernelGGL(k_fk_small<Kin>, dim3((unsigned)a.B), dim3(64), 0, st, a);
+        return hipGetLastError();
+    }
     const int lds_floats = NT * ((a.n_out * 3) | 1);
     // (a persistent variant that prefetches the next pose tile into registers while the chain runs was measured 13-20 % SLOWER --
     //  6.1 vs 7.1 G poses/s at 2^20 poses, 6.6 vs 8.3 at 2^22: 256 VGPRs with spills; tools/experimental/fk_stream.md)
@@ -969,6 +1086,41 @@ struct FkBwdArgs {
     int J;
     int64_t B;
 };
+// Rodrigues backward: R = I + s K + c1 K^2, K = skew(k), k = r / angle;  o[3] = d loss / d (rx, ry, rz) from dR = d loss / d R
+__device__ __forceinline__ void rodrigues_bwd(float rx, float ry, float rz, const float (&dR)[9], float* o) {
+    const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
+    const float angle = sqrtf(ax * ax + ay * ay + az * az);
+    const float inv = 1.0f / angle;
+    const float kx = rx * inv, ky = ry * inv, kz = rz * inv;
+    float sn, cs;
+    sincos_small(angle, sn, cs);
+    const float c1 = 1.0f - cs;
+    const float K[9] = {0.f, -kz, ky, kz, 0.f, -kx, -ky, kx, 0.f};
+    float KK[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) KK[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+    float ds = 0.f, dc1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { ds += dR[k] * K[k]; dc1 += dR[k] * KK[k]; }
+    float dK[9];                                   // s dR + c1 (dR K^T + K^T dR)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) { t1 += dR[3 * r + m] * K[3 * c + m]; t2 += K[3 * m + r] * dR[3 * m + c]; }
+            dK[3 * r + c] = sn * dR[3 * r + c] + c1 * (t1 + t2);
+        }
+    const float dk[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+    const float dtheta = ds * cs + dc1 * sn;
+    const float kdk = kx * dk[0] + ky * dk[1] + kz * dk[2];
+    const float kv[3] = {kx, ky, kz};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (dk[c] - kdk * kv[c]) * inv + dtheta * kv[c];
+}
 // Reverse walk of the kinematic chain, one lane per pose, joint index (and parent) compile-time constants so that the
 // running gradients acc[joint][12] (d loss / d global transform, accumulated from the children) and the rest-joint
 // gradients stay in REGISTERS: only the few joints between a leaf and its first processed ancestor are live at any time.
@@ -1044,40 +1196,7 @@ __device__ __forceinline__ void fk_bwd_step(const FkBwdArgs& a, int64_t b, const
         for (int c = 0; c < 3; ++c) a.djrest[(b * J + I) * 3 + c] = djr[I][c];        // every child (index > I) has been processed
     }
     if (!dq) return;
-    // Rodrigues backward: R = I + s K + c1 K^2, K = skew(k), k = r / angle
-    const float ax = rx + 1e-8f, ay = ry + 1e-8f, az = rz + 1e-8f;
-    const float angle = sqrtf(ax * ax + ay * ay + az * az);
-    const float inv = 1.0f / angle;
-    const float kx = rx * inv, ky = ry * inv, kz = rz * inv;
-    float sn, cs;
-    sincos_small(angle, sn, cs);
-    const float c1 = 1.0f - cs;
-    const float K[9] = {0.f, -kz, ky, kz, 0.f, -kx, -ky, kx, 0.f};
-    float KK[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) KK[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
-    float ds = 0.f, dc1 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { ds += dR[k] * K[k]; dc1 += dR[k] * KK[k]; }
-    float dK[9];                                   // s dR + c1 (dR K^T + K^T dR)
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) { t1 += dR[3 * r + m] * K[3 * c + m]; t2 += K[3 * m + r] * dR[3 * m + c]; }
-            dK[3 * r + c] = sn * dR[3 * r + c] + c1 * (t1 + t2);
-        }
-    const float dk[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
-    const float dtheta = ds * cs + dc1 * sn;
-    const float kdk = kx * dk[0] + ky * dk[1] + kz * dk[2];
-    const float kv[3] = {kx, ky, kz};
-    float* o = dq + (b * seg_nj + li) * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = (dk[c] - kdk * kv[c]) * inv + dtheta * kv[c];
+    rodrigues_bwd(rx, ry, rz, dR, dq + (b * seg_nj + li) * 3);
 }
 template <typename Kin, int I>
 __device__ __forceinline__ void fk_bwd_chain(const FkBwdArgs& a, int64_t b, const float* jr, const float* A, float (&acc)[Kin::J][12],
@@ -1104,6 +1223,120 @@ template <typename Kin> __global__ void __launch_bounds__(64, 1) k_fk_bwd(FkBwdA
         for (int k = 0; k < 3; ++k) djr[i][k] = 0.f;
     }
     fk_bwd_chain<Kin, J - 1>(a, b, jr, A, acc, djr);
+}
+
+// Small batches: one wave per pose, one lane per joint, the reverse walk by tree depth (deepest level first).  A joint hands
+// its contribution to the parent's global-transform gradient (12 floats) and to the parent's rest-joint gradient (3) through
+// LDS; the parent adds its children's contributions in DESCENDING joint order -- the order the unrolled chain of k_fk_bwd
+// produces -- so both kernels return the same bits.
+template <typename Kin> __global__ void __launch_bounds__(64) k_fk_bwd_small(FkBwdArgs a) {
+    constexpr int J = Kin::J;
+    constexpr int MAXD = fk_max_depth<Kin>();
+    constexpr int MAXC = 6;
+    __shared__ float sC[J][12];
+    __shared__ float sD[J][3];
+    const int64_t b = blockIdx.x;
+    const int I = threadIdx.x;
+    const bool on = I < J;
+    int P = 0, depth = 0, child[MAXC], nchild = 0;
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) child[k] = 0;
+    if (on) {
+        P = kKinTable<Kin>.p[I];
+        for (int q = I; q > 0; q = kKinTable<Kin>.p[q]) ++depth;
+        for (int c = J - 1; c > I; --c)
+            if (kKinTable<Kin>.p[c] == I) {
+#pragma unroll
+                for (int k = 0; k < MAXC; ++k)
+                    if (k == nchild) child[k] = c;
+                ++nchild;
+            }
+    }
+    int li = I;
+    const float* pose = a.seg[0];
+    float* dq = a.dseg[0];
+    int seg_nj = a.seg_joints[0];
+#pragma unroll
+    for (int k = 1; k < FK_MAX_SEG; ++k)
+        if (k < a.nseg && I >= a.seg_first[k]) { li = I - a.seg_first[k]; pose = a.seg[k]; dq = a.dseg[k]; seg_nj = a.seg_joints[k]; }
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (on && pose) { const float* q = pose + (b * seg_nj + li) * 3; rx = q[0]; ry = q[1]; rz = q[2]; }
+    const float* jr = a.j_rest_batched ? a.j_rest + b * J * 3 : a.j_rest;
+    const float* A = a.A + b * J * 12;
+    const int Ic = on ? I : 0;
+    const float* dAi = a.dA + (b * J + Ic) * 12;
+    const float J3[3] = {jr[3 * Ic], jr[3 * Ic + 1], jr[3 * Ic + 2]};
+    const Mat3 R = rodrigues(rx, ry, rz);
+    float RP[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) RP[3 * r + c] = A[P * 12 + 4 * r + c];
+    const float rel[3] = {jr[3 * Ic] - jr[3 * P], jr[3 * Ic + 1] - jr[3 * P + 1], jr[3 * Ic + 2] - jr[3 * P + 2]};
+    float dR[9], djr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dR[k] = 0.f;
+    for (int L = MAXD; L >= 0; --L) {
+        if (on && depth == L) {
+            float acc[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXC; ++k)
+                if (k < nchild) {
+                    const int c = child[k];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) acc[i] += sC[c][i];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) djr[r] -= sD[c][r];
+                }
+            float dRG[9], dt[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float dat = dAi[4 * r + 3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    dRG[3 * r + c] = acc[4 * r + c] + (dAi[4 * r + c] - dat * J3[c]);
+                    djr[c] -= A[I * 12 + 4 * r + c] * dat;
+                }
+                dt[r] = acc[4 * r + 3] + (dat + a.djoints[b * a.ld_dj + 3 * I + r]);
+            }
+            if (I == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dR[k] = dRG[k];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) djr[c] += dt[c];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) dR[3 * r + c] = RP[r] * dRG[c] + RP[3 + r] * dRG[3 + c] + RP[6 + r] * dRG[6 + c];
+                    const float drel = RP[r] * dt[0] + RP[3 + r] * dt[1] + RP[6 + r] * dt[2];
+                    djr[r] += drel;
+                    sD[I][r] = drel;
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        sC[I][4 * r + c] = dRG[3 * r] * R.m[3 * c] + dRG[3 * r + 1] * R.m[3 * c + 1] + dRG[3 * r + 2] * R.m[3 * c + 2] + dt[r] * rel[c];
+                    sC[I][4 * r + 3] = dt[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!on) return;
+    if (I > 0 && a.dpf) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dR[k] += a.dpf[b * a.ldpf + (I - 1) * 9 + k];
+    }
+    if (a.djrest) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.djrest[(b * J + I) * 3 + c] = djr[c];
+    }
+    if (!dq) return;
+    rodrigues_bwd(rx, ry, rz, dR, dq + (b * seg_nj + li) * 3);
 }
 
 // d pose_feature: sum of the split-K slabs of the d_off @ posedirs^T GEMM, [nsplit][Bpad][ld] -> slab 0 (fixed order)
@@ -1232,10 +1465,17 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         }
         a.dpf = dpf; a.dpf_slab = Bpad * prow; a.ldpf = prow; a.nsplit = 1; a.djrest = d_jrest; a.dG = dG; a.parents = parents_dev; a.J = J;
         a.B = batch;
-        const dim3 grid((unsigned)ceil_div(batch, 64));
-        if (h->kind == 0) hipLaunchKernelGGL(k_fk_bwd<KinSMPL>, grid, dim3(64), 0, st, a);
-        else if (h->kind == 1) hipLaunchKernelGGL(k_fk_bwd<KinSMPLH>, grid, dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(k_fk_bwd<KinSMPLX>, grid, dim3(64), 0, st, a);
+        if (batch <= fk_small_max()) {
+            const dim3 grid((unsigned)batch);
+            if (h->kind == 0) hipLaunchKernelGGL(k_fk_bwd_small<KinSMPL>, grid, dim3(64), 0, st, a);
+            else if (h->kind == 1) hipLaunchKernelGGL(k_fk_bwd_small<KinSMPLH>, grid, dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(k_fk_bwd_small<KinSMPLX>, grid, dim3(64), 0, st, a);
+        } else {
+            const dim3 grid((unsigned)ceil_div(batch, 64));
+            if (h->kind == 0) hipLaunchKernelGGL(k_fk_bwd<KinSMPL>, grid, dim3(64), 0, st, a);
+            else if (h->kind == 1) hipLaunchKernelGGL(k_fk_bwd<KinSMPLH>, grid, dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(k_fk_bwd<KinSMPLX>, grid, dim3(64), 0, st, a);
+        }
         FK_HIP_LAUNCH(hipGetLastError());
     }
     return DPOSER_OK;

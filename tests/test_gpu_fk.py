@@ -286,6 +286,58 @@ def test_body_model_backward_all_pose_segments(bm, asset):
         assert err < 2e-4, (name, err)
 
 
+def test_small_batch_fk_kernels_return_the_bits_of_the_large_batch_ones(bm, asset, monkeypatch):
+    """Below DPOSER_FK_SMALL_MAX poses (default 8192) forward kinematics and its backward run one wave per pose / one lane per
+    joint (k_fk_small, k_fk_bwd_small: the chain walked by tree depth through LDS) instead of one lane per pose.  Same
+    per-joint expressions, children summed in the unrolled chain's order => identical bits: joints-only query, full LBS
+    (vertices, 127 joints) and every gradient of the all-segments backward."""
+    B = 37
+    rs = np.random.RandomState(91)
+    mk = lambda n, s=0.3: (rs.standard_normal((B, n)) * s).astype(np.float32)
+    arrs = [mk(63), mk(3), mk(90, 0.2), mk(3, 0.2), mk(6, 0.1), mk(10, 0.5), mk(10, 0.5), mk(3, 1.0)]
+    wv = torch.tensor(rs.standard_normal((B, 10475, 3)).astype(np.float32) / 100.0, device=DEV)
+    wj = torch.tensor(rs.standard_normal((B, 127, 3)).astype(np.float32), device=DEV)
+
+    def run():
+        d = [torch.tensor(a, device=DEV, requires_grad=True) for a in arrs]
+        out = bm(pose_body=d[0], root_orient=d[1], pose_hand=d[2], pose_jaw=d[3], pose_eye=d[4], expression=d[5], betas=d[6], trans=d[7])
+        ((out.v * wv).sum() + (out.Jtr * wj).sum()).backward()
+        with torch.no_grad():
+            jo = bm.fk_joints(d[0].detach(), root_orient=d[1].detach(), trans=d[7].detach())
+        return [out.v.detach(), out.Jtr.detach(), jo] + [t.grad for t in d]
+
+    small = run()
+    monkeypatch.setenv("DPOSER_FK_SMALL_MAX", "0")
+    large = run()
+    monkeypatch.delenv("DPOSER_FK_SMALL_MAX")
+    names = ["v", "Jtr", "fk_joints", "d pose", "d root", "d hand", "d jaw", "d eye", "d expression", "d betas", "d trans"]
+    for n, a, b in zip(names, small, large):
+        assert torch.equal(a, b), n
+
+
+@pytest.mark.parametrize("model_type", ["smpl", "smplh"])
+def test_small_batch_fk_kernels_other_trees(model_type, monkeypatch):
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_asset
+    bm2 = BodyModel(make_synthetic_asset(model_type, seed=3), model_type=model_type).to(DEV)
+    B = 9
+    nb = bm2.bm.NUM_BODY_JOINTS * 3
+    pose = (np.random.RandomState(4).standard_normal((B, nb)) * 0.3).astype(np.float32)
+
+    def run():
+        p = torch.tensor(pose, device=DEV, requires_grad=True)
+        out = bm2(pose_body=p)
+        (out.v.sum() + (out.Jtr ** 2).sum()).backward()
+        return out.v.detach(), out.Jtr.detach(), p.grad
+
+    small = run()
+    monkeypatch.setenv("DPOSER_FK_SMALL_MAX", "0")
+    large = run()
+    monkeypatch.delenv("DPOSER_FK_SMALL_MAX")
+    for a, b in zip(small, large):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------------
 # Pins that need neither smplx nor the restatement in oracle/fk_ref.py: closed-form consequences of the LBS definition
 # (rotations from scipy.spatial.transform, everything else from the asset arrays).
