@@ -81,6 +81,8 @@ SIGNATURES = {
                                        i64, vp]),
     "dposer_prior_loss": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, f32, i32, f32, vp, vp, vp, u64,
                                     u32, vp, vp, i64, vp]),
+    "dposer_prior_table_build": (C.c_int, [vp, vp, vp, vp, C.POINTER(f32), i32, vp, i64, vp]),
+    "dposer_prior_loss_tabled": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, f32, i32, i32, i32, f32, vp, vp, vp, u64, u32, vp, i64, vp]),
     "dposer_completion_optimize": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, vp, vp, C.POINTER(f32), C.POINTER(i32),
                                              C.POINTER(f32), C.POINTER(f32), i32, f64, f64, f64, f64, vp, u64, u32, vp, vp, i64, vp]),
     "dposer_motion_denoise_scratch_bytes": (i64, [i64, i32, i32, i32]),

@@ -701,26 +701,29 @@ extern "C" int dposer_langevin_step(dposer_scorefc_t h, const float* flat, const
     return DPOSER_OK;
 }
 
-extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
-                                 const float* x0, const float* z, float t, int32_t weighted, float inv_n, float* x0_hat, float* grad,
-                                 float* loss, uint64_t seed, uint32_t step, const float* freq, const float* sigmas, int64_t B,
-                                 void* stream) {
+// table_rows <= 0: the time-bias row is built for this call (one row).  table_rows > 0: row `row` of a table that
+// dposer_prior_table_build wrote into the same workspace (laid out for table_rows rows) -- the task loops build it once.
+static int prior_loss_impl(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                           const float* x0, const float* z, float t, int32_t weighted, float inv_n, float* x0_hat, float* grad,
+                           float* loss, uint64_t seed, uint32_t step, const float* freq, const float* sigmas, int64_t B, void* stream,
+                           int32_t row, int32_t table_rows) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
-    DP_CHECK_ARG(sde && x0 && loss && freq && sigmas, "null argument");
+    DP_CHECK_ARG(sde && x0 && loss && sigmas && (freq || table_rows > 0), "null argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "prior loss supports subVP / VP SDEs");
     DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "prior loss supports the positional embedding");
+    DP_CHECK_ARG(table_rows <= 0 || (row >= 0 && row < table_rows), "table row out of range");
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
     Ws w;
-    layout_ws(h, B, DPOSER_WS_SHARED_T, 1, (char*)ws_, w);
-    DP_TRY(build_time_table(h, flat, packed, w, nullptr, t * 999.0f, 1, freq, st));
+    layout_ws(h, B, DPOSER_WS_SHARED_T, table_rows > 0 ? table_rows : 1, (char*)ws_, w);
+    if (table_rows <= 0) DP_TRY(build_time_table(h, flat, packed, w, nullptr, t * 999.0f, 1, freq, st));
     const SdeCfg sc = to_sde(sde);
     PerturbSharedArgs pa;
     pa.x0 = x0; pa.z_in = z; pa.xin = w.xin; pa.xt = w.xt; pa.t = t; pa.B = B; pa.Bpad = w.Bpad; pa.D = h->D; pa.Dpad = h->Dpad;
     pa.f32 = h->f32; pa.sde = sc; pa.seed = seed; pa.step = step;
     DP_HIP_LAUNCH(launch_perturb_shared(pa, st));
-    DP_TRY(run_shared_t(h, flat, packed, w, 0, B, st));
+    DP_TRY(run_shared_t(h, flat, packed, w, table_rows > 0 ? row : 0, B, st));
     DenoiseArgs da;
     da.res = w.res; da.x0 = x0; da.xt = w.xt; da.sigmas = sigmas; da.x0_hat = x0_hat; da.grad = grad; da.loss_part = w.loss_part;
     da.t = t; da.inv_n = inv_n; da.weighted = weighted; da.B = B; da.D = h->D; da.Dpad = h->Dpad; da.Cp = h->Cp;
@@ -729,6 +732,33 @@ extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const vo
     DP_HIP_LAUNCH(launch_denoise(da, &nb, st));
     DP_HIP_LAUNCH(launch_sum_partials(w.loss_part, nb, loss, st));
     return DPOSER_OK;
+}
+extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                 const float* x0, const float* z, float t, int32_t weighted, float inv_n, float* x0_hat, float* grad,
+                                 float* loss, uint64_t seed, uint32_t step, const float* freq, const float* sigmas, int64_t B,
+                                 void* stream) {
+    return prior_loss_impl(h, flat, packed_, ws_, sde, x0, z, t, weighted, inv_n, x0_hat, grad, loss, seed, step, freq, sigmas, B, stream, 0, 0);
+}
+extern "C" int dposer_prior_table_build(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const float* t_host,
+                                        int32_t n_rows, const float* freq, int64_t B, void* stream) {
+    DP_TRY(check_common(h, flat, packed_, ws_, B));
+    DP_CHECK_ARG(t_host && freq && n_rows >= 1, "bad argument");
+    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "the time table covers the positional embedding");
+    hipStream_t st = (hipStream_t)stream;
+    Ws w;
+    layout_ws(h, B, DPOSER_WS_SHARED_T, n_rows, (char*)ws_, w);
+    h->host_stage.resize(n_rows);
+    for (int i = 0; i < n_rows; ++i) h->host_stage[i] = t_host[i] * 999.0f;     // labels = t * 999 (utils.py:152)
+    DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n_rows * sizeof(float), hipMemcpyHostToDevice, st));
+    return build_time_table(h, flat, (const char*)packed_, w, w.tt_labels, 0.f, n_rows, freq, st);
+}
+extern "C" int dposer_prior_loss_tabled(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                        const float* x0, const float* z, float t, int32_t row, int32_t table_rows, int32_t weighted,
+                                        float inv_n, float* x0_hat, float* grad, float* loss, uint64_t seed, uint32_t step,
+                                        const float* sigmas, int64_t B, void* stream) {
+    DP_CHECK_ARG(table_rows >= 1, "table_rows must be >= 1");
+    return prior_loss_impl(h, flat, packed_, ws_, sde, x0, z, t, weighted, inv_n, x0_hat, grad, loss, seed, step, nullptr, sigmas, B, stream, row,
+                           table_rows);
 }
 
 // DPoserComp.optimize (run/completion.py:167-207): the whole optimisation loop in one call.  Per step: perturb x at the step's

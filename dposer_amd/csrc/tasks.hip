@@ -200,12 +200,14 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     // d joints: only the observed joints' columns are ever non-zero
     TK_HIP_LAUNCH(hipMemsetAsync(s.djoints, 0, (size_t)T * a->joint_rows * 3 * 4, st));
 
+    // time-bias rows of all steps: two small GEMMs once instead of per step
+    if (a->n_steps > 0) DP_TRY(dposer_prior_table_build(a->net, a->flat_params, a->packed, a->net_ws, a->t_host, a->n_steps, a->freq, T, stream));
     for (int k = 0; k < a->n_steps; ++k) {
         hipLaunchKernelGGL(k_md_normalize, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n, D);
         TK_HIP_LAUNCH(hipGetLastError());
-        DP_TRY(dposer_prior_loss(a->net, a->flat_params, a->packed, a->net_ws, a->sde, s.xn, a->noise ? a->noise + (int64_t)k * n : nullptr,
-                                 a->t_host[k], a->weighted, 1.0f / (float)T, nullptr, s.gprior, s.loss1, a->seed, a->step0 + (uint32_t)k, a->freq,
-                                 a->sigmas, T, stream));
+        DP_TRY(dposer_prior_loss_tabled(a->net, a->flat_params, a->packed, a->net_ws, a->sde, s.xn, a->noise ? a->noise + (int64_t)k * n : nullptr,
+                                        a->t_host[k], k, a->n_steps, a->weighted, 1.0f / (float)T, nullptr, s.gprior, s.loss1, a->seed,
+                                        a->step0 + (uint32_t)k, a->sigmas, T, stream));
         DP_TRY(dposer_lbs_forward(a->body, a->lbs_ws_fwd, a->posedirs_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest, a->rest_batched,
                                   a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, nullptr, a->extra_vertex_ids, a->lmk_tri, a->lmk_bary,
                                   s.verts, s.joints, T, stream));

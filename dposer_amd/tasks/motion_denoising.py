@@ -78,7 +78,7 @@ class MotionDenoise:
         eng = model._engine()
         flat = model.flat_params()
         packed = eng.packed(flat, with_backward=False, force=not model.freeze_packed)      # once per loop
-        ws = eng.workspace(T, _C.WS_SHARED_T, 1, dev)
+        ws = eng.workspace(T, _C.WS_SHARED_T, n_steps, dev)
         lib, h = _C.lib(), core._handle()
         v_shaped, j_rest, batched = core.rest_shape(self.betas, None)
         v_shaped, j_rest = v_shaped.contiguous(), j_rest.contiguous()

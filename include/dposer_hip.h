@@ -120,6 +120,18 @@ int dposer_prior_loss(dposer_scorefc_t h, const float* flat_params, const void* 
                       float inv_n, float* x0_hat, float* grad, float* loss, uint64_t seed, uint32_t step,
                       const float* freq, const float* sigmas, int64_t batch, void* stream);
 
+/* The same evaluation with the time-bias rows of MANY steps built once: dposer_prior_table_build(t_host [n_rows]) writes the
+ * table into a DPOSER_WS_SHARED_T workspace laid out for n_rows rows; dposer_prior_loss_tabled(row, table_rows = n_rows) then
+ * evaluates the prior at t = t_host[row] (the caller passes the same t for the SDE scalars).  What the task loops use
+ * (run/completion.py:183-201, run/motion_denoising.py:240-252 draw a new t every optimisation step). */
+int dposer_prior_table_build(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws, const float* t_host,
+                             int32_t n_rows, const float* freq, int64_t batch, void* stream);
+int dposer_prior_loss_tabled(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws, const dposer_sde_desc* sde,
+                             const float* x0, const float* z, float t, int32_t row, int32_t table_rows, int32_t weighted, float inv_n,
+                             float* x0_hat, float* grad, float* loss, uint64_t seed, uint32_t step, const float* sigmas,
+                             int64_t batch, void* stream);
+
+
 /* get_sde_loss_fn.loss_fn + loss.backward() -- lib/algorithms/advanced/losses.py:80-137, 260
  * (continuous=True, reduce_mean=True, likelihood_weighting=False, model.train()).
  *   batch [B, D]; t [B] / z [B, D] injected draws or NULL (Philox: t = u*(T-eps)+eps, z ~ N(0,I));
@@ -322,7 +334,7 @@ int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const
  * all steps queued from one call (prior evaluation = dposer_prior_loss, body model = dposer_lbs_forward / _backward, the
  * loss gradients and the Adam update are kernels of this entry).  The data term is dropped for a step when its value is not
  * finite and > 0 (:261-263) -- decided on the device.
- *   score network: handle, parameters, packed weights, a DPOSER_WS_SHARED_T workspace for `frames` samples (1 table row);
+ *   score network: handle, parameters, packed weights, a DPOSER_WS_SHARED_T workspace for `frames` samples and n_steps table rows;
  *   body model: handle + the device tables dposer_lbs_forward / dposer_lbs_backward take, their two workspaces for `frames`
  *   poses; rest_batched: v_shaped / j_rest are [frames, ...] instead of shared; pose segments other than `body_segment` are
  *   the zero pose;  joint_rows = J + num_extra + num_landmarks (row count of the LBS joint output);

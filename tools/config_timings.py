@@ -85,7 +85,11 @@ def main():
             joints = bm(pose_body=gt, betas=md.betas).Jtr[:, :22] + 0.04 * torch.randn(60, 22, 3, device=dev)
         s = timed(lambda: md.optimize(joints, gt_poses=gt, iterations=5, steps_per_iter=50), warm=1)
         rows.append(("cfg5", "motion denoising, 60 frames, 250 optimisation steps (LBS fwd+bwd + prior), one C call", f"{s:.3f} s / sequence", f"{s / 250 * 1e3:.2f} ms / step"))
-        s = timed(lambda: md.optimize(joints, gt_poses=gt, iterations=5, steps_per_iter=50, fused=False), warm=1)
+        if only == "cfg5" and len(sys.argv) > 2 and sys.argv[2] == "fused-only":
+            rows.append(("", "", "", ""))
+            s = 0.0
+        else:
+            s = timed(lambda: md.optimize(joints, gt_poses=gt, iterations=5, steps_per_iter=50, fused=False), warm=1)
         rows.append(("cfg5 (autograd loop)", "the same steps through autograd + torch.optim.Adam around the same kernels", f"{s:.3f} s / sequence", f"{s / 250 * 1e3:.2f} ms / step"))
 
     print("| config | workload | time | rate |")
