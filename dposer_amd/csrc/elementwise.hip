@@ -56,6 +56,7 @@ template <typename T> __device__ __forceinline__ void pack_chunk(const PackJob& 
         const int k = k0 + e;
         float v = 0.f;
         if (r < j.rows_valid && k < j.cols_valid) v = j.trans ? src[(int64_t)k * j.ld + r] : src[(int64_t)r * j.ld + k];
+        if (sizeof(T) == 2 && j.split == 2) v = v - (float)(__bf16)v;          // low part of the two-term bf16 split
         vals[e] = from_f32<T>(v);
     }
     T* dst = reinterpret_cast<T*>(packed + j.dst_off) + FT<T>::index(r, j.koff + k0, j.ktot);

@@ -843,13 +843,49 @@ __global__ void __launch_bounds__(256) k_extra_joints(ExtraArgs a) {
     }
 }
 
+// ---- pose-blend arithmetic -----------------------------------------------------------------------------------------------------
+// offsets = pose_feature @ posedirs is 2 * B * 486 * 3V FLOPs (125 GFLOP at 4096 SMPL-X poses): on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak) it is 2/3 of the LBS forward.  Default: both operands as TWO bf16 terms each
+// (x = hi + lo, hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits) and the three products hi*hi + hi*lo + lo*hi on the bf16 MFMA
+// with fp32 accumulation -- one GEMM with K = 3 * 512 (forward: [pf_hi | pf_hi | pf_lo] x [pd_hi ; pd_lo ; pd_hi] through the
+// kernel's K segments), three split-K launches into one slab set (backward).  The dropped lo*lo term and the split residuals
+// are <= 2^-16 of each product: the offsets (centimetres) move by < 1e-6 m, vertices agree with the fp64 oracle to ~1e-6
+// (tests/test_gpu_fk.py; the bar is 1e-5).  DPOSER_LBS_BLEND=fp32 selects the exact-fp32 chain (both packings are kept).
+static bool lbs_blend_fp32() {
+    const char* e = getenv("DPOSER_LBS_BLEND");
+    return e && e[0] == 'f';
+}
+// FT32 [Bpad][K] -> FT bf16 [Bpad][3K] = [hi | hi | lo]
+__global__ void __launch_bounds__(256) k_split_pf(const float* __restrict__ pf, __bf16* __restrict__ out, int64_t Bpad, int K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 8-element chunk of the bf16 layout
+    const int chunks = K / 8;
+    if (i >= Bpad * chunks) return;
+    const int64_t b = i / chunks;
+    const int k0 = (int)(i % chunks) * 8;
+    __bf16 hi[8], lo[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pf + FT<float>::index(b, k0 + 4 * q, K));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const __bf16 h = (__bf16)v[r];
+            hi[4 * q + r] = h;
+            lo[4 * q + r] = (__bf16)(v[r] - (float)h);
+        }
+    }
+    const u32x4 H = *reinterpret_cast<u32x4*>(hi), L = *reinterpret_cast<u32x4*>(lo);
+    *reinterpret_cast<u32x4*>(out + FT<__bf16>::index(b, k0, 3 * K)) = H;
+    *reinterpret_cast<u32x4*>(out + FT<__bf16>::index(b, K + k0, 3 * K)) = H;
+    *reinterpret_cast<u32x4*>(out + FT<__bf16>::index(b, 2 * K + k0, 3 * K)) = L;
+}
+
 static int64_t lbs_pad_batch(int64_t B) { return round_up(B, 128); }
 static int lbs_ppad(int J) { return (int)round_up((J - 1) * 9, 32); }
 static int64_t lbs_cpad(int V) { return round_up((int64_t)V * 3, 128); }
 
 extern "C" int64_t dposer_lbs_posedirs_packed_bytes(dposer_body_t h) {
     if (!h) return -1;
-    return lbs_cpad(h->d.num_vertices) * lbs_ppad(h->d.num_joints) * 4;
+    return lbs_cpad(h->d.num_vertices) * lbs_ppad(h->d.num_joints) * 8;      // FT32 | bf16 high parts | bf16 low parts
 }
 // posedirs [(J-1)*9][V*3] fp32 row-major (the layout smplx keeps after its reshape/transposition)
 extern "C" int dposer_lbs_pack_posedirs(dposer_body_t h, const float* posedirs, void* packed, void* stream) {
@@ -860,7 +896,11 @@ extern "C" int dposer_lbs_pack_posedirs(dposer_body_t h, const float* posedirs, 
     const int P = (h->d.num_joints - 1) * 9;
     j.dst_off = 0; j.src_off = 0; j.ktot = lbs_ppad(h->d.num_joints); j.koff = 0;
     j.rows_pad = (int)lbs_cpad(h->d.num_vertices); j.kpad = j.ktot; j.rows_valid = h->d.num_vertices * 3; j.cols_valid = P;
-    j.ld = h->d.num_vertices * 3; j.trans = 1; j.f32 = 1;
+    j.ld = h->d.num_vertices * 3; j.trans = 1; j.f32 = 1; j.split = 0;
+    const int64_t n = (int64_t)j.rows_pad * j.ktot;
+    js.n = 3;
+    js.job[1] = j; js.job[1].dst_off = n * 4; js.job[1].f32 = 0; js.job[1].split = 1;
+    js.job[2] = j; js.job[2].dst_off = n * 6; js.job[2].f32 = 0; js.job[2].split = 2;
     FK_HIP_LAUNCH(launch_pack(js, posedirs, packed, (hipStream_t)stream));
     return DPOSER_OK;
 }
@@ -871,6 +911,7 @@ extern "C" int64_t dposer_lbs_workspace_bytes(dposer_body_t h, int64_t batch) {
     p += round_up(Bpad * lbs_ppad(h->d.num_joints) * 4, 256);          // pose feature FT32
     p += round_up(batch * h->d.num_joints * 12 * 4, 256);              // A
     p += round_up(batch * lbs_cpad(h->d.num_vertices) * 4, 256);       // offsets
+    p += round_up(Bpad * 3 * lbs_ppad(h->d.num_joints) * 2, 256);      // pose feature as bf16 [hi | hi | lo]
     return p;
 }
 
@@ -892,7 +933,8 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
     char* p = (char*)ws;
     float* pf = (float*)p; p += round_up(Bpad * Ppad * 4, 256);
     float* A = (float*)p; p += round_up(batch * J * 12 * 4, 256);
-    float* offsets = (float*)p;
+    float* offsets = (float*)p; p += round_up(batch * Cpad * 4, 256);
+    __bf16* pf_split = (__bf16*)p;
     const int n_total = J + h->d.num_extra + h->d.num_landmarks;
 
     // 1. FK: posed joints -> joints[:, :J], skinning transforms A, pose feature (FT32 operand of the blend GEMM)
@@ -917,11 +959,26 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
     {
         GemmArgs g;
         std::memset(&g, 0, sizeof(g));
-        g.W = pf; g.w_stride_blocks = Ppad / 8; g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(Cpad / 128); g.ksplit = 1;
-        g.src[0] = posedirs_packed; g.seg_kblocks[0] = Ppad / 8; g.nseg = 1; g.ktot_blocks = Ppad / 8;
         WgradParams wp;
         wp.slab = offsets; wp.slab_stride = 0; wp.ld = (int)Cpad; wp.N_valid = (int)batch; wp.K_valid = V * 3;
-        FK_HIP_LAUNCH(gemm_wgrad(PREC_FP32, SHAPE_MID, g, wp, st));
+        g.ksplit = 1;
+        if (lbs_blend_fp32()) {
+            g.W = pf; g.w_stride_blocks = Ppad / 8; g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(Cpad / 128);
+            g.src[0] = posedirs_packed; g.seg_kblocks[0] = Ppad / 8; g.nseg = 1; g.ktot_blocks = Ppad / 8;
+            FK_HIP_LAUNCH(gemm_wgrad(PREC_FP32, SHAPE_MID, g, wp, st));
+        } else {
+            hipLaunchKernelGGL(k_split_pf, dim3((unsigned)ceil_div(Bpad * (Ppad / 8), 256)), dim3(256), 0, st, (const float*)pf, pf_split, Bpad, Ppad);
+            FK_HIP_LAUNCH(hipGetLastError());
+            const char* hi = (const char*)posedirs_packed + Cpad * Ppad * 4;
+            const char* lo = hi + Cpad * Ppad * 2;
+            const int kb = Ppad / 16;
+            const int shape = (Bpad % 256 == 0 && Cpad % 256 == 0 && Bpad >= 1024) ? SHAPE_BIG : SHAPE_MID;
+            const int tile = shape == SHAPE_BIG ? 256 : 128;
+            g.W = pf_split; g.w_stride_blocks = 3 * kb; g.n_cblk = (int)(Bpad / tile); g.n_sblk = (int)(Cpad / tile);
+            g.src[0] = hi; g.src[1] = lo; g.src[2] = hi;                        // [pf_hi | pf_hi | pf_lo] x [hi ; lo ; hi]
+            g.seg_kblocks[0] = g.seg_kblocks[1] = g.seg_kblocks[2] = kb; g.nseg = 3; g.ktot_blocks = 3 * kb;
+            FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, shape, g, wp, st));
+        }
     }
     // 3. skinning
     {
@@ -962,7 +1019,9 @@ struct SkinBwdArgs {
     int K, J, V;
     float* vp;                 // [B][V][3] out: posed-blend vertices (v_shaped + offsets)
     float* dvp;                // [B][V][3] out: d loss / d v_posed
-    float* doff_ft;            // FT32 [Bpad][Cpad] out (same values, GEMM operand layout)
+    float* doff_ft;            // FT32 [Bpad][Cpad] out (same values, GEMM operand layout) ...
+    __bf16* doff_hi;           // ... or, for the bf16 x 3 blend GEMMs, the two bf16 terms as FT bf16 [Bpad][Cpad] each (doff_ft null)
+    __bf16* doff_lo;
     int Cpad;
 };
 __global__ void __launch_bounds__(256) k_skin_bwd(SkinBwdArgs a) {
@@ -1010,11 +1069,26 @@ __global__ void __launch_bounds__(256) k_skin_bwd(SkinBwdArgs a) {
             const int k = i * 256 + threadIdx.x;
             if (k < nval) { a.vp[row + k] = stage_vp[k]; a.dvp[row + k] = stage[k]; }
         }
-        if (threadIdx.x < 192) {
-            const int kq = v0 * 3 + threadIdx.x * 4;                                         // first coordinate of this quad
-            if (kq < a.Cpad) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(stage + threadIdx.x * 4);
-                *reinterpret_cast<f32x4*>(a.doff_ft + FT<float>::index(b, kq, a.Cpad)) = q;
+        if (a.doff_ft) {
+            if (threadIdx.x < 192) {
+                const int kq = v0 * 3 + threadIdx.x * 4;                                     // first coordinate of this quad
+                if (kq < a.Cpad) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(stage + threadIdx.x * 4);
+                    *reinterpret_cast<f32x4*>(a.doff_ft + FT<float>::index(b, kq, a.Cpad)) = q;
+                }
+            }
+        } else if (threadIdx.x < 96) {
+            const int k8 = v0 * 3 + threadIdx.x * 8;                                         // first coordinate of this 8-element chunk
+            if (k8 < a.Cpad) {
+                __bf16 hi[8], lo[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = stage[threadIdx.x * 8 + e];
+                    hi[e] = (__bf16)x;
+                    lo[e] = (__bf16)(x - (float)hi[e]);
+                }
+                *reinterpret_cast<u32x4*>(a.doff_hi + FT<__bf16>::index(b, k8, a.Cpad)) = *reinterpret_cast<u32x4*>(hi);
+                *reinterpret_cast<u32x4*>(a.doff_lo + FT<__bf16>::index(b, k8, a.Cpad)) = *reinterpret_cast<u32x4*>(lo);
             }
         }
     }
@@ -1354,7 +1428,7 @@ __global__ void __launch_bounds__(256) k_sum_slabs(float* slabs, int64_t slab_el
 
 extern "C" int64_t dposer_lbs_posedirs_bwd_packed_bytes(dposer_body_t h) {
     if (!h) return -1;
-    return round_up((h->d.num_joints - 1) * 9, 128) * lbs_cpad(h->d.num_vertices) * 4;        // FT32 [rows = pose feature][k = vertex coord]
+    return round_up((h->d.num_joints - 1) * 9, 128) * lbs_cpad(h->d.num_vertices) * 8;        // [rows = pose feature][k = vertex coord]: FT32 | bf16 high | bf16 low
 }
 extern "C" int dposer_lbs_pack_posedirs_bwd(dposer_body_t h, const float* posedirs, void* packed, void* stream) {
     DP_CHECK_ARG(h && posedirs && packed, "null argument");
@@ -1364,7 +1438,11 @@ extern "C" int dposer_lbs_pack_posedirs_bwd(dposer_body_t h, const float* posedi
     const int P = (h->d.num_joints - 1) * 9;
     j.dst_off = 0; j.src_off = 0; j.ktot = (int)lbs_cpad(h->d.num_vertices); j.koff = 0;
     j.rows_pad = (int)round_up(P, 128); j.kpad = j.ktot; j.rows_valid = P; j.cols_valid = h->d.num_vertices * 3;
-    j.ld = h->d.num_vertices * 3; j.trans = 0; j.f32 = 1;
+    j.ld = h->d.num_vertices * 3; j.trans = 0; j.f32 = 1; j.split = 0;
+    const int64_t n = (int64_t)j.rows_pad * j.ktot;
+    js.n = 3;
+    js.job[1] = j; js.job[1].dst_off = n * 4; js.job[1].f32 = 0; js.job[1].split = 1;
+    js.job[2] = j; js.job[2].dst_off = n * 6; js.job[2].f32 = 0; js.job[2].split = 2;
     FK_HIP_LAUNCH(launch_pack(js, posedirs, packed, (hipStream_t)stream));
     return DPOSER_OK;
 }
@@ -1373,6 +1451,21 @@ static int lbs_bwd_ksplit(int64_t stages) {
     for (int c = 2; c <= 24; ++c)
         if (stages % c == 0 && stages / c >= 8) ks = c;
     return ks;
+}
+// bf16 x 3 backward: three launches share the GPU; enough splits that one launch alone covers ~2 workgroups per CU
+static int lbs_bwd_ksplit_bf16(int64_t kblocks, int64_t tiles) {
+    const int64_t want = ceil_div(512, tiles);
+    int best = 1;
+    for (int c = 1; c <= 24; ++c) {
+        if (kblocks % (2 * c) != 0 || kblocks / c < 16) continue;      // whole 2-k-block stages per split
+        best = c;
+        if (c >= want) break;
+    }
+    return best;
+}
+static int64_t lbs_bwd_slabs(int64_t Bpad, int64_t Cpad, int64_t prow) {
+    const int ks = lbs_bwd_ksplit_bf16(Cpad / 16, (Bpad / 128) * (prow / 128));
+    return 3 * ks > 24 ? 3 * ks : 24;
 }
 extern "C" int64_t dposer_lbs_backward_workspace_bytes(dposer_body_t h, int64_t batch) {
     if (!h || batch <= 0) return -1;
@@ -1383,7 +1476,7 @@ extern "C" int64_t dposer_lbs_backward_workspace_bytes(dposer_body_t h, int64_t 
     p += round_up(batch * V * 3 * 4, 256) * 2;         // vp, dvp
     p += round_up(Bpad * Cpad * 4, 256);               // doff FT32
     p += round_up(batch * J * 12 * 4, 256) * 2;        // dA, dG
-    p += round_up(24 * Bpad * prow * 4, 256);          // dpf slabs
+    p += round_up(lbs_bwd_slabs(Bpad, Cpad, prow) * Bpad * prow * 4, 256);          // dpf slabs
     p += 256;                                          // parents
     return p;
 }
@@ -1415,14 +1508,18 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
     float* doff = (float*)p; p += round_up(Bpad * Cpad * 4, 256);
     float* dA = (float*)p; p += round_up(batch * J * 12 * 4, 256);
     float* dG = (float*)p; p += round_up(batch * J * 12 * 4, 256);
-    float* dpf = (float*)p; p += round_up(24 * Bpad * prow * 4, 256);
+    float* dpf = (float*)p; p += round_up(lbs_bwd_slabs(Bpad, Cpad, prow) * Bpad * prow * 4, 256);
     int* parents_dev = (int*)p;
     DP_CHECK_HIP(hipMemcpyAsync(parents_dev, h->parents, J * sizeof(int), hipMemcpyHostToDevice, st));
+    const bool blend32 = lbs_blend_fp32();
+    __bf16* doff_hi = reinterpret_cast<__bf16*>(doff);                  // bf16 x 3: the two terms share the FT32 operand's bytes
+    __bf16* doff_lo = doff_hi + Bpad * Cpad;
     DP_CHECK_HIP(hipMemsetAsync(doff, 0, Bpad * Cpad * 4, st));
     {
         SkinBwdArgs a;
         a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
-        a.skin_idx = skin_idx; a.skin_w = skin_w; a.K = skin_k; a.J = J; a.V = V; a.vp = vp; a.dvp = d_vposed ? d_vposed : dvp; a.doff_ft = doff;
+        a.skin_idx = skin_idx; a.skin_w = skin_w; a.K = skin_k; a.J = J; a.V = V; a.vp = vp; a.dvp = d_vposed ? d_vposed : dvp;
+        a.doff_ft = blend32 ? doff : nullptr; a.doff_hi = doff_hi; a.doff_lo = doff_lo;
         a.Cpad = (int)Cpad;
         hipLaunchKernelGGL(k_skin_bwd, dim3((unsigned)ceil_div(V, 256 * 4), (unsigned)batch), dim3(256), (J * 12 + 1536) * sizeof(float), st, a);
         FK_HIP_LAUNCH(hipGetLastError());
@@ -1435,8 +1532,8 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
     }
     // d pose_feature [B][486] = d_off [B][3V] @ posedirs^T : fp32 MFMA, split over the vertex dimension
     const int64_t stages = Cpad / 32;
-    const int ks = lbs_bwd_ksplit(stages);
-    {
+    int ks = lbs_bwd_ksplit(stages);            // number of slabs k_sum_slabs adds up below
+    if (blend32) {
         GemmArgs g;
         std::memset(&g, 0, sizeof(g));
         g.W = doff; g.w_stride_blocks = (int)(Cpad / 8); g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(prow / 128); g.ksplit = ks;
@@ -1444,6 +1541,24 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         WgradParams wp;
         wp.slab = dpf; wp.slab_stride = Bpad * prow; wp.ld = (int)prow; wp.N_valid = (int)batch; wp.K_valid = (J - 1) * 9;
         FK_HIP_LAUNCH(gemm_wgrad(PREC_FP32, SHAPE_MID, g, wp, st));
+    } else {
+        // d pf = doff_hi pd_hi^T + doff_hi pd_lo^T + doff_lo pd_hi^T: three split-K launches into consecutive slab sets
+        const char* pd_hi = (const char*)posedirs_bwd_packed + prow * Cpad * 4;
+        const char* pd_lo = pd_hi + prow * Cpad * 2;
+        const int kb = (int)(Cpad / 16);
+        const int k1 = lbs_bwd_ksplit_bf16(kb, (Bpad / 128) * (prow / 128));
+        for (int term = 0; term < 3; ++term) {
+            GemmArgs g;
+            std::memset(&g, 0, sizeof(g));
+            g.W = term == 2 ? (const void*)doff_lo : (const void*)doff_hi; g.w_stride_blocks = kb;
+            g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(prow / 128); g.ksplit = k1;
+            g.src[0] = term == 1 ? pd_lo : pd_hi; g.seg_kblocks[0] = kb; g.nseg = 1; g.ktot_blocks = kb;
+            WgradParams wp;
+            wp.slab = dpf + (int64_t)term * k1 * Bpad * prow; wp.slab_stride = Bpad * prow; wp.ld = (int)prow; wp.N_valid = (int)batch;
+            wp.K_valid = (J - 1) * 9;
+            FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, SHAPE_MID, g, wp, st));
+        }
+        ks = 3 * k1;
     }
     {
         FkBwdArgs a;

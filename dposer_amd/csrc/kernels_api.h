@@ -13,6 +13,7 @@ struct PackJob {
     int rows_valid, cols_valid, ld;
     int trans;            // 0: dst[r][koff+k] = src[r*ld + k]     1: dst[r][koff+k] = src[k*ld + r]
     int f32;              // destination element type: 1 fp32, 0 bf16
+    int split;            // bf16 destinations: 0 = bf16(v), 1 = high part bf16(v), 2 = low part bf16(v - float(bf16(v)))
 };
 constexpr int MAX_PACK_JOBS = 40;
 struct PackJobs {

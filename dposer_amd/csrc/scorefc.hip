@@ -72,7 +72,7 @@ static PackJob mk_job(int64_t dst_off, int64_t src_off, int ktot, int koff, int 
                       int ld, int trans, int f32) {
     PackJob j;
     j.dst_off = dst_off; j.src_off = src_off; j.ktot = ktot; j.koff = koff; j.rows_pad = rows_pad; j.kpad = kpad;
-    j.rows_valid = rows_valid; j.cols_valid = cols_valid; j.ld = ld; j.trans = trans; j.f32 = f32;
+    j.rows_valid = rows_valid; j.cols_valid = cols_valid; j.ld = ld; j.trans = trans; j.f32 = f32; j.split = 0;
     return j;
 }
 

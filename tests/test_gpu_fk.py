@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from gpu_common import DEV, t2n
-from helpers import load
+from helpers import _log_measured, load
 from oracle import fk_ref
 
 pytestmark = pytest.mark.gpu
@@ -284,6 +284,40 @@ def test_body_model_backward_all_pose_segments(bm, asset):
     for name, got, want in zip(("pose", "root", "hand", "jaw", "eye", "expression"), d, r):
         err = float(np.linalg.norm(t2n(got.grad) - want.grad.numpy()) / np.linalg.norm(want.grad.numpy()))
         assert err < 2e-4, (name, err)
+
+
+@pytest.mark.parametrize("B", [7, 300])
+def test_pose_blend_bf16x3_against_exact_fp32_and_the_oracle(bm, asset, B, monkeypatch):
+    """The pose-blend GEMMs (offsets = pose_feature @ posedirs and its transpose in the backward pass) run by default as three
+    bf16 products of two-term splits (hi*hi + hi*lo + lo*hi, fp32 accumulation); DPOSER_LBS_BLEND=fp32 selects the exact-fp32 MFMA
+    chain.  Both must sit inside the 1e-5 vertex bar against the fp64 oracle; measured max abs vertex
+    error [m] at 7 / 300 poses of 0.5 rad: bf16x3 6.2e-7 / 1.04e-6, fp32 4.5e-7 / 8.8e-7 (fp32 rounding of the skinning sum dominates both)."""
+    from oracle import fk_torch
+    rs = np.random.RandomState(B)
+    pose = (rs.standard_normal((B, 63)) * 0.5).astype(np.float32)
+    hand = (rs.standard_normal((B, 90)) * 0.3).astype(np.float32)
+    wv = torch.tensor(rs.standard_normal((B, 10475, 3)).astype(np.float32) / 100.0, device=DEV)
+    v_ref, j_ref, _, _ = fk_ref.smplx_forward(asset, pose.astype(np.float64), left_hand_pose=hand[:, :45].astype(np.float64),
+                                              right_hand_pose=hand[:, 45:].astype(np.float64), dtype=np.float64)
+
+    def run():
+        p = torch.tensor(pose, device=DEV, requires_grad=True)
+        hd = torch.tensor(hand, device=DEV, requires_grad=True)
+        out = bm(pose_body=p, pose_hand=hd)
+        (out.v * wv).sum().backward()
+        return t2n(out.v), t2n(p.grad), t2n(hd.grad)
+
+    v3, gp3, gh3 = run()
+    monkeypatch.setenv("DPOSER_LBS_BLEND", "fp32")
+    v1, gp1, gh1 = run()
+    monkeypatch.delenv("DPOSER_LBS_BLEND")
+    e3, e1 = np.abs(v3 - v_ref).max(), np.abs(v1 - v_ref).max()
+    _log_measured("pose blend bf16x3 max abs vertex error", e3)
+    _log_measured("pose blend fp32 max abs vertex error", e1)
+    assert e1 < 1e-6 and e3 < 2e-6, (e1, e3)
+    assert not np.array_equal(v3, v1)                                            # (the two modes really are different arithmetic)
+    for a, b in ((gp3, gp1), (gh3, gh1)):
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-5
 
 
 def test_small_batch_fk_kernels_return_the_bits_of_the_large_batch_ones(bm, asset, monkeypatch):
