@@ -41,7 +41,7 @@ class MotionDenoiseArgs(C.Structure):
                 ("rest_batched", C.c_int32), ("skin_idx", C.c_void_p), ("skin_w", C.c_void_p), ("skin_k", C.c_int32), ("joint_ptr", C.c_void_p),
                 ("joint_vidx", C.c_void_p), ("joint_w", C.c_void_p), ("extra_vertex_ids", C.c_void_p), ("lmk_tri", C.c_void_p),
                 ("lmk_bary", C.c_void_p), ("segment_joints_host", C.POINTER(C.c_int32)), ("num_segments", C.c_int32), ("body_segment", C.c_int32),
-                ("num_vertices", C.c_int32), ("num_joints", C.c_int32), ("joint_rows", C.c_int32), ("frames", C.c_int64), ("pose", C.c_void_p),
+                ("num_vertices", C.c_int32), ("num_joints", C.c_int32), ("joint_rows", C.c_int32), ("frames", C.c_int64), ("frames_per_sequence", C.c_int64), ("pose", C.c_void_p),
                 ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("joints_obs", C.c_void_p), ("n_obs_joints", C.c_int32), ("norm_mode", C.c_int32),
                 ("norm_a", C.c_void_p), ("norm_b", C.c_void_p), ("n_steps", C.c_int32), ("weighted", C.c_int32), ("t_host", C.POINTER(C.c_float)),
                 ("w_temp_host", C.POINTER(C.c_float)), ("w_data_host", C.POINTER(C.c_float)), ("w_prior_host", C.POINTER(C.c_float)),

@@ -52,23 +52,25 @@ __global__ void __launch_bounds__(256) k_md_normalize(const float* pose, const f
 
 // temporal term (:253-255): temp = mean over (T-1, V) of ||v[t] - v[t+1]||; d temp / d v[t] = (u_t - u_{t-1}) / ((T-1) V),
 // u_t = (v[t] - v[t+1]) / ||v[t] - v[t+1]||  (0/0 = NaN for two identical vertices, as torch's sqrt backward gives)
-__global__ void __launch_bounds__(256) k_md_vert_grad(const float* verts, float* dverts, float* part, int T, int V, float c) {
+// (F = frames per sequence: the frames of a batch of sequences are consecutive, neighbours never cross a sequence boundary)
+__global__ void __launch_bounds__(256) k_md_vert_grad(const float* verts, float* dverts, float* part, int F, int V, float c) {
     __shared__ float red[4];
     const int t = blockIdx.y;
+    const int tf = t % F;
     const int v = blockIdx.x * 256 + threadIdx.x;
     float d_sum = 0.f;
     if (v < V) {
         const float* p = verts + ((int64_t)t * V + v) * 3;
         const float px = p[0], py = p[1], pz = p[2];
         float gx = 0.f, gy = 0.f, gz = 0.f;
-        if (t + 1 < T) {
+        if (tf + 1 < F) {
             const float* q = p + (int64_t)V * 3;
             const float ax = px - q[0], ay = py - q[1], az = pz - q[2];
             const float d = sqrtf(ax * ax + ay * ay + az * az);
             gx = ax / d; gy = ay / d; gz = az / d;
             d_sum = d;
         }
-        if (t > 0) {
+        if (tf > 0) {
             const float* q = p - (int64_t)V * 3;
             const float bx = q[0] - px, by = q[1] - py, bz = q[2] - pz;
             const float d = sqrtf(bx * bx + by * by + bz * bz);
@@ -87,6 +89,10 @@ __global__ void __launch_bounds__(256) k_md_vert_grad(const float* verts, float*
 __global__ void __launch_bounds__(256) k_md_joint(const float* joints, int64_t ld, const float* obs, float* djoints, int T, int n_obs, float w_data,
                                                   const float* temp_part, int n_temp_part, float temp_scale, const float* prior_loss, float* log3) {
     __shared__ float red[4];
+    // block = one sequence of T frames
+    joints += (int64_t)blockIdx.x * T * ld; djoints += (int64_t)blockIdx.x * T * ld; obs += (int64_t)blockIdx.x * T * n_obs * 3;
+    temp_part += (int64_t)blockIdx.x * n_temp_part;
+    if (log3) log3 += 3 * (int64_t)blockIdx.x;
     const int n = T * n_obs;
     float acc = 0.f;
     for (int e = threadIdx.x; e < n; e += 256) {
@@ -177,7 +183,9 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
                      a->skin_w && a->joint_ptr && a->joint_vidx && a->joint_w && a->segment_joints_host, "null body-model argument");
     DP_CHECK_ARG(a->pose && a->adam_m && a->adam_v && a->joints_obs && a->scratch, "null problem argument");
     DP_CHECK_ARG(a->t_host && a->w_temp_host && a->w_data_host && a->w_prior_host && a->n_steps >= 0, "null / bad schedule");
-    DP_CHECK_ARG(a->frames >= 2, "the temporal term needs at least two frames");
+    const int64_t F = a->frames_per_sequence > 0 ? a->frames_per_sequence : a->frames;
+    DP_CHECK_ARG(F >= 2 && a->frames >= F && a->frames % F == 0, "frames must be a whole number of sequences of >= 2 frames (the temporal term couples neighbours)");
+    const int64_t n_seq = a->frames / F;
     DP_CHECK_ARG(a->num_segments >= 1 && a->num_segments <= 8 && a->body_segment >= 0 && a->body_segment < a->num_segments, "bad pose segments");
     DP_CHECK_ARG(a->norm_mode == 0 || ((a->norm_mode == 1 || a->norm_mode == 2) && a->norm_a && a->norm_b), "bad normaliser");
     DP_CHECK_ARG(a->num_vertices > 0 && a->num_joints > 0 && a->joint_rows >= a->num_joints && a->n_obs_joints >= 1 && a->n_obs_joints <= a->num_joints,
@@ -206,17 +214,17 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
         hipLaunchKernelGGL(k_md_normalize, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n, D);
         TK_HIP_LAUNCH(hipGetLastError());
         DP_TRY(dposer_prior_loss_tabled(a->net, a->flat_params, a->packed, a->net_ws, a->sde, s.xn, a->noise ? a->noise + (int64_t)k * n : nullptr,
-                                        a->t_host[k], k, a->n_steps, a->weighted, 1.0f / (float)T, nullptr, s.gprior, s.loss1, a->seed,
+                                        a->t_host[k], k, a->n_steps, a->weighted, 1.0f / (float)F, nullptr, s.gprior, s.loss1, a->seed,
                                         a->step0 + (uint32_t)k, a->sigmas, T, stream));
         DP_TRY(dposer_lbs_forward(a->body, a->lbs_ws_fwd, a->posedirs_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest, a->rest_batched,
                                   a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, nullptr, a->extra_vertex_ids, a->lmk_tri, a->lmk_bary,
                                   s.verts, s.joints, T, stream));
-        const float c_temp = a->w_temp_host[k] / ((float)(T - 1) * (float)V);
-        hipLaunchKernelGGL(k_md_vert_grad, dim3((unsigned)vb, (unsigned)T), dim3(256), 0, st, (const float*)s.verts, s.dverts, s.part, (int)T, V, c_temp);
+        const float c_temp = a->w_temp_host[k] / ((float)(F - 1) * (float)V);
+        hipLaunchKernelGGL(k_md_vert_grad, dim3((unsigned)vb, (unsigned)T), dim3(256), 0, st, (const float*)s.verts, s.dverts, s.part, (int)F, V, c_temp);
         TK_HIP_LAUNCH(hipGetLastError());
-        hipLaunchKernelGGL(k_md_joint, dim3(1), dim3(256), 0, st, (const float*)s.joints, (int64_t)a->joint_rows * 3, a->joints_obs, s.djoints, (int)T,
-                           a->n_obs_joints, a->w_data_host[k], (const float*)s.part, n_part, 1.0f / ((float)(T - 1) * (float)V), (const float*)s.loss1,
-                           a->loss_log ? a->loss_log + 3 * (int64_t)k : nullptr);
+        hipLaunchKernelGGL(k_md_joint, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)s.joints, (int64_t)a->joint_rows * 3, a->joints_obs, s.djoints,
+                           (int)F, a->n_obs_joints, a->w_data_host[k], (const float*)s.part, vb * (int)F, 1.0f / ((float)(F - 1) * (float)V),
+                           (const float*)s.loss1, a->loss_log ? a->loss_log + 3 * (int64_t)k * n_seq : nullptr);
         TK_HIP_LAUNCH(hipGetLastError());
         DP_TRY(dposer_lbs_backward(a->body, a->lbs_ws_fwd, a->lbs_ws_bwd, a->posedirs_bwd_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest,
                                    a->rest_batched, a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, a->joint_ptr, a->joint_vidx, a->joint_w,

@@ -68,9 +68,9 @@ class MotionDenoise:
                 and self.model.time_embedding_type == "positional" and isinstance(self.body_model, BodyModel)
                 and getattr(nz, "rot_rep", None) == "axis" and self.batch_size >= 2)
 
-    def _optimize_fused(self, pose, init_joints, t_list, its, weights, noise):
-        """All optimisation steps in one C call; ``pose`` [T, 63] is updated in place.  Returns the per-step loss log [steps, 3]
-        (temp, data, prior; device tensor)."""
+    def _optimize_fused(self, pose, init_joints, t_list, its, weights, noise, frames_per_sequence=0):
+        """All optimisation steps in one C call; ``pose`` [T, 63] is updated in place (T = sequences x frames_per_sequence when a
+        batch of sequences is advanced together).  Returns the per-step loss log [steps, sequences, 3] (temp, data, prior)."""
         model, core, nz = self.model, self.body_model.bm, self.Normalizer
         dev = pose.device
         T, D = pose.shape
@@ -80,7 +80,10 @@ class MotionDenoise:
         packed = eng.packed(flat, with_backward=False, force=not model.freeze_packed)      # once per loop
         ws = eng.workspace(T, _C.WS_SHARED_T, n_steps, dev)
         lib, h = _C.lib(), core._handle()
-        v_shaped, j_rest, batched = core.rest_shape(self.betas, None)
+        F = int(frames_per_sequence) if frames_per_sequence else T
+        n_seq = T // F
+        betas = self.betas if self.betas.shape[0] == T else self.betas[:1].expand(T, -1).contiguous()
+        v_shaped, j_rest, batched = core.rest_shape(betas, None)
         v_shaped, j_rest = v_shaped.contiguous(), j_rest.contiguous()
         names = [name for name, _ in core.segments]
         segj = (C.c_int32 * len(names))(*[nj for _, nj in core.segments])
@@ -90,7 +93,7 @@ class MotionDenoise:
         rows = core.J + core.n_extra + core.n_lmk
         scratch = u8(lib.dposer_motion_denoise_scratch_bytes(T, D, core.V, rows))
         m, v = torch.zeros_like(pose), torch.zeros_like(pose)
-        log = torch.zeros(n_steps, 3, dtype=torch.float32, device=dev)
+        log = torch.zeros(n_steps, n_seq, 3, dtype=torch.float32, device=dev)
         obs = init_joints.detach().contiguous().float()
         if not nz.normalize:
             mode, na, nb = 0, None, None
@@ -112,7 +115,8 @@ class MotionDenoise:
             rest_batched=1 if batched else 0, skin_idx=_C.ptr(core.skin_idx), skin_w=_C.ptr(core.skin_w), skin_k=int(core.skin_idx.shape[1]),
             joint_ptr=_C.ptr(jptr), joint_vidx=_C.ptr(jvidx), joint_w=_C.ptr(jw), extra_vertex_ids=_C.ptr(core.extra_vertex_ids),
             lmk_tri=_C.ptr(core.lmk_tri), lmk_bary=_C.ptr(core.lmk_bary_coords), segment_joints_host=segj, num_segments=len(names),
-            body_segment=names.index("body_pose"), num_vertices=core.V, num_joints=core.J, joint_rows=rows, frames=T, pose=_C.ptr(pose),
+            body_segment=names.index("body_pose"), num_vertices=core.V, num_joints=core.J, joint_rows=rows, frames=T, frames_per_sequence=F,
+            pose=_C.ptr(pose),
             adam_m=_C.ptr(m), adam_v=_C.ptr(v), joints_obs=_C.ptr(obs), n_obs_joints=int(obs.shape[1]), norm_mode=mode, norm_a=_C.ptr(na),
             norm_b=_C.ptr(nb), n_steps=n_steps, weighted=0, t_host=fl(t_list), w_temp_host=fl(weights["temp"](1.0, it) for it in its),
             w_data_host=fl(weights["data"](1.0, it) for it in its), w_prior_host=fl(weights["dposer"](1.0, it) for it in its),
@@ -129,6 +133,43 @@ class MotionDenoise:
         if time_strategy == "3":
             return int(self.sde.N - math.floor(float(np.float32(total_steps - step - 1) * np.float32(self.sde.N / (sample_trun * total_steps)))) - 2)
         raise NotImplementedError("unsupported time sampling strategy")
+
+    def optimize_sequences(self, joints3d, gt_poses, time_strategy="3", sample_trun=2.0, sample_time=990, iterations=5, steps_per_iter=50,
+                           noise=None, init_poses=None):
+        """A BATCH of sequences advanced together by the one-call loop: joints3d [S, F, 22, 3], gt_poses / init_poses [S, F, 63],
+        noise [steps, S * F, 63] or None.  Every sequence is the independent problem ``optimize`` solves (same schedule, same loss
+        weights; temporal neighbours, data-term decision and loss means per sequence), but the S * F frames share every launch --
+        one 60-frame sequence leaves most of an MI355X idle (GPU-bound small kernels), and under data parallelism
+        each rank takes its shard of the sequences.  Returns the ``optimize`` metrics as [S, F] arrays and pose_body [S, F, 63]."""
+        if not self._fused_supported():
+            raise NotImplementedError("optimize_sequences needs the one-call loop (axis-angle poses, sub-VP / VP SDE, positional embedding)")
+        S, F = joints3d.shape[:2]
+        bm = self.body_model
+        flat = lambda x: x.reshape(S * F, *x.shape[2:])
+        betas = self.betas[:1].expand(S * F, -1).contiguous()
+        with torch.no_grad():
+            gt = bm(betas=betas, pose_body=flat(gt_poses))
+            je = flat(joints3d) - gt.Jtr[:, :22]
+            init_mpjpe = torch.mean(torch.sqrt(torch.sum(je * je, dim=2)), dim=1) * 100.0
+        timesteps = torch.linspace(self.sde.T, 1e-3, self.sde.N)
+        total_steps = iterations * steps_per_iter
+        start = self.poses[:1].expand(S * F, -1) if init_poses is None else flat(init_poses)
+        pose = start.detach().clone().contiguous().float()
+        quan = [self._quan_t(time_strategy, step, total_steps, sample_trun, sample_time) for step in range(total_steps)]
+        self.loss_log = self._optimize_fused(pose, flat(joints3d).detach(), [float(timesteps[q]) for q in quan],
+                                             [s // steps_per_iter for s in range(total_steps)], self.get_loss_weights(), noise,
+                                             frames_per_sequence=F)
+        with torch.no_grad():
+            final = pose.reshape(S, F, -1)
+            smooth = torch.stack([gaussian_smoothing(final[i], window_size=3, sigma=2) for i in range(S)])
+            smooth[:, [0, -1]] = final[:, [0, -1]]
+            out = bm(betas=betas, pose_body=flat(smooth))
+            je = out.Jtr[:, :22] - gt.Jtr[:, :22]
+            ve = out.v - gt.v
+            mpjpe = torch.mean(torch.sqrt(torch.sum(je * je, dim=2)), dim=1) * 100.0
+            mpvpe = torch.mean(torch.sqrt(torch.sum(ve * ve, dim=2)), dim=1) * 100.0
+        r = lambda x: x.reshape(S, F).cpu().numpy()
+        return {"init_MPJPE": r(init_mpjpe), "MPJPE": r(mpjpe), "MPVPE": r(mpvpe), "pose_body": final}
 
     def optimize(self, joints3d, gt_poses=None, time_strategy="1", sample_trun=2.0, sample_time=990, iterations=5, steps_per_iter=50,
                  verbose=False, vis=False, noise=None, init_poses=None, fused=None):

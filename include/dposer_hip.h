@@ -343,7 +343,11 @@ int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const
  *   (False in the reference, :124); adam_m / adam_v zero on entry for a fresh optimiser, adam_step0 = steps already taken;
  *   noise [n_steps, frames, pose dim] injected z of the prior or NULL -> Philox(seed, step0 + i);
  *   scratch: dposer_motion_denoise_scratch_bytes(frames, pose dim, V, joint_rows) bytes, 256-byte aligned;
- *   loss_log: DEVICE [n_steps, 3] (temp, data, prior values of every step, unweighted) or NULL. */
+ *   frames_per_sequence: 0 = one sequence of `frames` frames; F = a batch of frames / F sequences of F consecutive frames each
+ *   (independent problems advanced together: temporal neighbours, the data-term decision and the loss means are per sequence; the
+ *   in-kernel prior noise is keyed by the frame index inside the batch);
+ *   loss_log: DEVICE [n_steps, sequences, 3] (temp, data values of each sequence; the prior value is the batch total, i.e. the sum
+ *   over the sequences' prior terms) of every step, unweighted, or NULL. */
 typedef struct dposer_motion_denoise_args {
     dposer_scorefc_t net;
     const float* flat_params;
@@ -376,6 +380,7 @@ typedef struct dposer_motion_denoise_args {
     int32_t num_joints;
     int32_t joint_rows;
     int64_t frames;
+    int64_t frames_per_sequence;
     float* pose;
     float* adam_m;
     float* adam_v;

@@ -189,7 +189,8 @@ def test_motion_denoise_one_call_loop_matches_the_autograd_loop(min_max):
     res_u = md.optimize(joints3d, fused=False, **kw)
     assert rel_err(t2n(res_f["pose_body"]), t2n(res_u["pose_body"])) < 2e-5
     assert np.allclose(res_f["MPJPE"], res_u["MPJPE"], rtol=1e-4, atol=1e-4)
-    assert log.shape == (iters * spi, 3) and np.isfinite(log).all() and (log > 0).all()
+    assert log.shape == (iters * spi, 1, 3) and np.isfinite(log).all() and (log > 0).all()
+    log = log[:, 0]
     # first step: the loss values at the initial pose, recomputed with the public pieces
     from dposer_amd.prior import prior_loss
     with torch.no_grad():
@@ -199,6 +200,27 @@ def test_motion_denoise_one_call_loop_matches_the_autograd_loop(min_max):
         d = body.Jtr[:, :22] - joints3d
         l_data = float(torch.mean(torch.sqrt(torch.sum(d * d, dim=2))))
     assert abs(log[0, 0] - l_temp) / l_temp < 1e-5 and abs(log[0, 1] - l_data) / l_data < 1e-5
+
+
+def test_motion_denoise_batch_of_sequences_equals_one_sequence_at_a_time():
+    """optimize_sequences advances S sequences with the same launches (frames_per_sequence in the C entry: temporal neighbours,
+    data-term decision and loss means per sequence).  With injected prior noise every sequence must come out exactly as
+    ``optimize`` returns it alone -- per-pose kernels do not depend on the batch they run in."""
+    F, S, iters, spi = 8, 3, 2, 3
+    md, joints3d, gt, init, rs = _md_setup(F * S)
+    noise = torch.tensor(rs.standard_normal((iters * spi, F * S, 63)).astype(np.float32), device=DEV)
+    md.batch_size = F
+    md.betas = md.betas[:F]
+    kw = dict(time_strategy="3", iterations=iters, steps_per_iter=spi)
+    res = md.optimize_sequences(joints3d.reshape(S, F, 22, 3), gt.reshape(S, F, 63), noise=noise, init_poses=init.reshape(S, F, 63), **kw)
+    log = t2n(md.loss_log)
+    assert res["pose_body"].shape == (S, F, 63) and res["MPJPE"].shape == (S, F) and log.shape == (iters * spi, S, 3)
+    for i in range(S):
+        sl = slice(i * F, (i + 1) * F)
+        one = md.optimize(joints3d[sl], gt_poses=gt[sl], noise=noise[:, sl].contiguous(), init_poses=init[sl], **kw)
+        assert torch.equal(res["pose_body"][i], one["pose_body"]), i
+        assert np.allclose(res["MPVPE"][i], one["MPVPE"], rtol=1e-6, atol=1e-6)
+        assert np.allclose(log[:, i, :2], t2n(md.loss_log)[:, 0, :2], rtol=1e-6)
 
 
 def test_motion_denoise_one_call_loop_inkernel_noise():

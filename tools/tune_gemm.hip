@@ -195,6 +195,18 @@ int main(int argc, char** argv) {
         run_all(7, 10);
         return 0;
     }
+    if (getenv("TUNE_TINY")) {       // round 2: latency-bound layers (run with S = 128 / 512 / 2048): K pipeline depth and tilings of the small shapes
+        GN(4, 1, 1, 1, 4, 2);        // shipped 128x32: 2 slots x 4 k-blocks
+        GN(4, 1, 1, 1, 4, 4);        // ring of 4 slots x 4 k-blocks
+        GN(2, 1, 1, 1, 4, 4);        // 64x32, 2 waves
+        GN(2, 1, 1, 1, 2, 4);
+        GN(2, 2, 1, 1, 2, 4);        // 64x64, 4 waves
+        GN(1, 2, 1, 1, 2, 4);        // 32x64, 2 waves
+        PL(4, 1, 1, 1, 4, 2);
+        PL(4, 1, 1, 1, 4, 4);
+        run_all(9, 50);
+        return 0;
+    }
     if (getenv("TUNE_SMALLB")) {     // which tiling for one-round problem sizes (run with S = 8192 / 16384)?
         GNT(2, 2, 2, 2, 4, 1);
         GNT(2, 2, 2, 1, 4, 1);
