@@ -132,8 +132,11 @@ class _LBSFunction(torch.autograd.Function):
             else:
                 dsegs.append(None)
                 dsegp[i] = None
-        d_jrest = torch.empty(B, J, 3, dtype=torch.float32, device=dev)
-        d_vposed = torch.empty(B, core.V, 3, dtype=torch.float32, device=dev)
+        # gradients w.r.t. the rest shape only when it is differentiable (betas / expression being optimised): d v_posed alone is a
+        # 515 MB stream at 4096 poses
+        need_vs, need_jr = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        d_jrest = torch.empty(B, J, 3, dtype=torch.float32, device=dev) if need_jr else None
+        d_vposed = torch.empty(B, core.V, 3, dtype=torch.float32, device=dev) if need_vs else None
         jptr, jvidx, jw = core.joint_csr()
         _C.check(lib.dposer_lbs_backward(h, _C.ptr(ctx.ws), _C.ptr(ws_b), _C.ptr(core._packed_posedirs_bwd()), segp, segj, len(core.segments), _C.ptr(ctx.jr),
                                          1 if ctx.batched else 0, _C.ptr(ctx.vs), 1 if ctx.batched else 0, _C.ptr(core.skin_idx),
@@ -143,7 +146,8 @@ class _LBSFunction(torch.autograd.Function):
         if ctx.batched:
             g_vs, g_jr = d_vposed, d_jrest
         else:
-            g_vs, g_jr = d_vposed.sum(dim=0), d_jrest.sum(dim=0)
+            g_vs = None if d_vposed is None else d_vposed.sum(dim=0)
+            g_jr = None if d_jrest is None else d_jrest.sum(dim=0)
         return (None, None, g_vs, g_jr, d_transl, *dsegs)
 
 

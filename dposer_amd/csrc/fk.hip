@@ -1018,7 +1018,7 @@ struct SkinBwdArgs {
     const float* skin_w;
     int K, J, V;
     float* vp;                 // [B][V][3] out: posed-blend vertices (v_shaped + offsets)
-    float* dvp;                // [B][V][3] out: d loss / d v_posed
+    float* dvp;                // [B][V][3] out: d loss / d v_posed, or null
     float* doff_ft;            // FT32 [Bpad][Cpad] out (same values, GEMM operand layout) ...
     __bf16* doff_hi;           // ... or, for the bf16 x 3 blend GEMMs, the two bf16 terms as FT bf16 [Bpad][Cpad] each (doff_ft null)
     __bf16* doff_lo;
@@ -1067,7 +1067,10 @@ __global__ void __launch_bounds__(256) k_skin_bwd(SkinBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int k = i * 256 + threadIdx.x;
-            if (k < nval) { a.vp[row + k] = stage_vp[k]; a.dvp[row + k] = stage[k]; }
+            if (k < nval) {
+                a.vp[row + k] = stage_vp[k];
+                if (a.dvp) a.dvp[row + k] = stage[k];      // gradient w.r.t. v_shaped: only when the caller wants it (515 MB at 4096 poses)
+            }
         }
         if (a.doff_ft) {
             if (threadIdx.x < 192) {
@@ -1504,7 +1507,7 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
     const float* offsets = (const float*)((const char*)A + round_up(batch * J * 12 * 4, 256));
     char* p = (char*)ws_bwd;
     float* vp = (float*)p; p += round_up(batch * V * 3 * 4, 256);
-    float* dvp = (float*)p; p += round_up(batch * V * 3 * 4, 256);
+    p += round_up(batch * V * 3 * 4, 256);                              // (was: scratch for d v_posed; kept so that the layout is unchanged)
     float* doff = (float*)p; p += round_up(Bpad * Cpad * 4, 256);
     float* dA = (float*)p; p += round_up(batch * J * 12 * 4, 256);
     float* dG = (float*)p; p += round_up(batch * J * 12 * 4, 256);
@@ -1518,7 +1521,7 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
     {
         SkinBwdArgs a;
         a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
-        a.skin_idx = skin_idx; a.skin_w = skin_w; a.K = skin_k; a.J = J; a.V = V; a.vp = vp; a.dvp = d_vposed ? d_vposed : dvp;
+        a.skin_idx = skin_idx; a.skin_w = skin_w; a.K = skin_k; a.J = J; a.V = V; a.vp = vp; a.dvp = d_vposed;
         a.doff_ft = blend32 ? doff : nullptr; a.doff_hi = doff_hi; a.doff_lo = doff_lo;
         a.Cpad = (int)Cpad;
         hipLaunchKernelGGL(k_skin_bwd, dim3((unsigned)ceil_div(V, 256 * 4), (unsigned)batch), dim3(256), (J * 12 + 1536) * sizeof(float), st, a);
