@@ -16,6 +16,7 @@
 #include <cstring>
 #include <string>
 #include <utility>
+#include <vector>
 
 #include "../../include/dposer_hip.h"
 #include "common.h"
@@ -685,6 +686,14 @@ struct dposer_body_s {
     dposer_body_desc d;
     int kind;   // 0 SMPL, 1 SMPL-H, 2 SMPL-X
     int parents[64];
+    // k_skin_bwd_joints' table: the caller's CSR-by-joint skinning lists re-cut into vertex chunks (built on first use, rebuilt when
+    // other lists are passed; freed by dposer_body_destroy)
+    const void* jl_key[3] = {nullptr, nullptr, nullptr};
+    int jl_chunks = 0;
+    int32_t* jl_vstart = nullptr;    // device [chunks + 1] first vertex of each chunk
+    int32_t* jl_ptr = nullptr;       // device [chunks][J + 1] entry ranges, relative to the chunk's first entry
+    int32_t* jl_first = nullptr;     // device [chunks + 1] first entry of each chunk
+    float2* jl_entry = nullptr;      // device [nnz] (weight, local vertex index as int bits)
 };
 
 template <typename Kin> static bool same_tree(const int32_t* p, int n) {
@@ -711,7 +720,11 @@ extern "C" int dposer_body_create(const dposer_body_desc* desc, const int32_t* p
     *out = h;
     return DPOSER_OK;
 }
-extern "C" void dposer_body_destroy(dposer_body_t h) { delete h; }
+extern "C" void dposer_body_destroy(dposer_body_t h) {
+    if (!h) return;
+    (void)hipFree(h->jl_vstart); (void)hipFree(h->jl_ptr); (void)hipFree(h->jl_first); (void)hipFree(h->jl_entry);
+    delete h;
+}
 
 template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t st) {
 #ifdef FK_NT
@@ -1097,51 +1110,150 @@ __global__ void __launch_bounds__(256) k_skin_bwd(SkinBwdArgs a) {
     }
 }
 
-// dA[b][j] = sum over the vertices skinned to joint j of w_vj * (dv_v (x) [vp_v ; 1]); one block per (pose, joint),
-// fixed-order tree reduction => deterministic.
+// dA[b][j] = sum over the vertices skinned to joint j of w_vj * (dv_v (x) [vp_v ; 1])
+// One block per pose streams the pose's dverts / vp rows ONCE, a chunk of <= 256 vertices at a time through LDS (coalesced),
+// together with the chunk's slice of the skinning lists (re-cut by chunk on the host, sorted by joint inside a chunk: one
+// contiguous run of (weight, local vertex) pairs).  Joint j is served by 4 lanes (lane q accumulates column q of [vp ; 1] for
+// the three rows); partial sums stay in registers over the whole pose, in a fixed order => deterministic.
+// (Round 1-2 version: one block per (pose, joint) gathering 2 x 12 B per list entry from L2 -- 4.1 GB of gathers per 4096 poses,
+//  1.15 ms even with an XCD-aware block order.  A first streaming version that walked the caller's CSR with a per-lane cursor was
+//  latency-bound on its two dependent global loads per entry: 1.53 ms.)
+constexpr int JL_MAXV = 256, JL_MAXE = 2048;
 struct JointBwdArgs {
     const float* dverts;
     const float* vp;
-    const int32_t* jptr;       // [J+1] CSR by joint
-    const int32_t* jvidx;      // [nnz]
-    const float* jw;           // [nnz]
+    const int32_t* vstart;     // [chunks + 1]
+    const int32_t* cptr;       // [chunks][J + 1]
+    const int32_t* cfirst;     // [chunks + 1]
+    const float2* entry;       // [nnz]
     float* dA;                 // [B][J][12]
-    int J, V;
+    int J, V, chunks;
     int64_t B;
 };
-__global__ void __launch_bounds__(128) k_skin_bwd_joints(JointBwdArgs a) {
-    __shared__ float red[128][13];
-    // XCD-aware order (hardware XCD = linear block id % 8): all J joints of one pose run back to back on ONE XCD, so the
-    // pose's dverts / vp rows (2 x 12 B x V, gathered joint by joint) come from HBM once and from that XCD's L2 afterwards.
-    // With the plain (joint, pose) grid every XCD touched every pose: 14.4 GB of HBM reads per launch at B = 4096.
-    const int64_t q = blockIdx.x >> 3;
-    const int j = (int)(q % a.J);
-    const int64_t b = (q / a.J) * 8 + (blockIdx.x & 7);
-    if (b >= a.B) return;
-    float acc[12];
+__global__ void __launch_bounds__(256) k_skin_bwd_joints(JointBwdArgs a) {
+    __shared__ f32x4 sdv[JL_MAXV];          // (dv.x, dv.y, dv.z, -)
+    __shared__ f32x4 svp[JL_MAXV];          // (vp.x, vp.y, vp.z, 1)
+    __shared__ float2 sent[JL_MAXE];
+    __shared__ int sptr[68];
+    const int64_t b = blockIdx.x;
+    const int j = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const bool on = j < a.J;
+    float acc[3] = {0.f, 0.f, 0.f};
+    const float* dvb = a.dverts + b * a.V * 3;
+    const float* vpb = a.vp + b * a.V * 3;
+    for (int c = 0; c < a.chunks; ++c) {
+        const int v0 = a.vstart[c], nv = a.vstart[c + 1] - v0;
+        const int e0 = a.cfirst[c], ne = a.cfirst[c + 1] - e0;
+        for (int k = threadIdx.x; k < nv * 3; k += 256) {
+            const int l = k / 3, r = k - 3 * l;
+            reinterpret_cast<float*>(&sdv[l])[r] = dvb[(int64_t)v0 * 3 + k];
+            reinterpret_cast<float*>(&svp[l])[r] = vpb[(int64_t)v0 * 3 + k];
+        }
+        if ((int)threadIdx.x < nv) reinterpret_cast<float*>(&svp[threadIdx.x])[3] = 1.0f;
+        for (int k = threadIdx.x; k < ne; k += 256) sent[k] = a.entry[e0 + k];
+        if ((int)threadIdx.x <= a.J) sptr[threadIdx.x] = a.cptr[c * (a.J + 1) + threadIdx.x];
+        __syncthreads();
+        if (on) {
+            const int i1 = sptr[j + 1];
+            int i = sptr[j];
+            // four entries at a time: their three dependent LDS reads each (entry -> dv, vp) overlap; the sums stay in list order
+            for (; i + 4 <= i1; i += 4) {
+                float2 en[4];
+                f32x4 d[4];
+                float h[4];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
-    for (int e = a.jptr[j] + threadIdx.x; e < a.jptr[j + 1]; e += 128) {
-        const int v = a.jvidx[e];
-        const float w = a.jw[e];
-        const float* dv = a.dverts + (b * a.V + v) * 3;
-        const float* p = a.vp + (b * a.V + v) * 3;
-        const float h[4] = {p[0], p[1], p[2], 1.0f};
+                for (int u = 0; u < 4; ++u) en[u] = sent[i + u];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+                for (int u = 0; u < 4; ++u) {
+                    const int l = __float_as_int(en[u].y);
+                    d[u] = sdv[l];
+                    h[u] = reinterpret_cast<const float*>(&svp[l])[q];
+                }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[4 * r + c] += w * dv[r] * h[c];
-    }
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) red[threadIdx.x][i] = acc[i];
-    __syncthreads();
-    for (int s = 64; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s)
+                    for (int r = 0; r < 3; ++r) acc[r] += en[u].x * d[u][r] * h[u];
+            }
+            for (; i < i1; ++i) {
+                const float2 en = sent[i];
+                const int l = __float_as_int(en.y);
+                const f32x4 d = sdv[l];
+                const float h = reinterpret_cast<const float*>(&svp[l])[q];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) red[threadIdx.x][i] += red[threadIdx.x + s][i];
+                for (int r = 0; r < 3; ++r) acc[r] += en.x * d[r] * h;
+            }
+        }
         __syncthreads();
     }
-    if (threadIdx.x < 12) a.dA[(b * a.J + j) * 12 + threadIdx.x] = red[0][threadIdx.x];
+    if (on) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) a.dA[(b * a.J + j) * 12 + 4 * r + q] = acc[r];
+    }
+}
+// (host) cut the CSR-by-joint lists (vertex ids ascending inside a joint) into chunks of <= JL_MAXV vertices and <= JL_MAXE entries
+static int build_joint_chunks(dposer_body_s* h, const int32_t* jptr_dev, const int32_t* jvidx_dev, const float* jw_dev, hipStream_t st) {
+    const int J = h->d.num_joints, V = h->d.num_vertices;
+    if (h->jl_key[0] == jptr_dev && h->jl_key[1] == jvidx_dev && h->jl_key[2] == jw_dev && h->jl_entry) return DPOSER_OK;
+    DP_CHECK_HIP(hipStreamSynchronize(st));
+    std::vector<int32_t> jptr(J + 1);
+    DP_CHECK_HIP(hipMemcpy(jptr.data(), jptr_dev, (J + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int nnz = jptr[J];
+    DP_CHECK_ARG(nnz >= 0 && jptr[0] == 0, "joint_ptr must be a CSR offset array");
+    std::vector<int32_t> jv(nnz);
+    std::vector<float> jw(nnz);
+    if (nnz) {
+        DP_CHECK_HIP(hipMemcpy(jv.data(), jvidx_dev, nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+        DP_CHECK_HIP(hipMemcpy(jw.data(), jw_dev, nnz * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    std::vector<int> per_vertex(V + 1, 0);
+    for (int e = 0; e < nnz; ++e) {
+        DP_CHECK_ARG(jv[e] >= 0 && jv[e] < V, "joint_vidx out of range");
+        per_vertex[jv[e]]++;
+    }
+    std::vector<int32_t> vstart{0};
+    for (int v = 0, nv = 0, ne = 0; v < V; ++v) {
+        DP_CHECK_ARG(per_vertex[v] <= JL_MAXE, "a vertex is skinned to too many joints");
+        if (nv + 1 > JL_MAXV || ne + per_vertex[v] > JL_MAXE) { vstart.push_back(v); nv = 0; ne = 0; }
+        ++nv; ne += per_vertex[v];
+    }
+    vstart.push_back(V);
+    const int chunks = (int)vstart.size() - 1;
+    std::vector<int> chunk_of(V);
+    for (int c = 0; c < chunks; ++c)
+        for (int v = vstart[c]; v < vstart[c + 1]; ++v) chunk_of[v] = c;
+    // count entries per (chunk, joint), then fill in (chunk, joint, ascending vertex) order
+    std::vector<int32_t> cnt((size_t)chunks * (J + 1), 0), cfirst(chunks + 1, 0);
+    for (int j = 0; j < J; ++j)
+        for (int e = jptr[j]; e < jptr[j + 1]; ++e) cnt[(size_t)chunk_of[jv[e]] * (J + 1) + j + 1]++;
+    for (int c = 0; c < chunks; ++c) {
+        int32_t* p = &cnt[(size_t)c * (J + 1)];
+        for (int j = 0; j < J; ++j) p[j + 1] += p[j];
+        cfirst[c + 1] = cfirst[c] + p[J];
+    }
+    std::vector<float2> entry(nnz > 0 ? nnz : 1);
+    std::vector<int32_t> fill(cnt);
+    for (int j = 0; j < J; ++j)
+        for (int e = jptr[j]; e < jptr[j + 1]; ++e) {
+            const int c = chunk_of[jv[e]];
+            const int pos = cfirst[c] + fill[(size_t)c * (J + 1) + j]++;
+            int32_t local = jv[e] - vstart[c];
+            float lf;
+            std::memcpy(&lf, &local, 4);
+            entry[pos] = make_float2(jw[e], lf);
+        }
+    (void)hipFree(h->jl_vstart); (void)hipFree(h->jl_ptr); (void)hipFree(h->jl_first); (void)hipFree(h->jl_entry);
+    h->jl_vstart = nullptr; h->jl_ptr = nullptr; h->jl_first = nullptr; h->jl_entry = nullptr;
+    DP_CHECK_HIP(hipMalloc(&h->jl_vstart, vstart.size() * sizeof(int32_t)));
+    DP_CHECK_HIP(hipMalloc(&h->jl_ptr, cnt.size() * sizeof(int32_t)));
+    DP_CHECK_HIP(hipMalloc(&h->jl_first, cfirst.size() * sizeof(int32_t)));
+    DP_CHECK_HIP(hipMalloc(&h->jl_entry, entry.size() * sizeof(float2)));
+    DP_CHECK_HIP(hipMemcpy(h->jl_vstart, vstart.data(), vstart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    DP_CHECK_HIP(hipMemcpy(h->jl_ptr, cnt.data(), cnt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    DP_CHECK_HIP(hipMemcpy(h->jl_first, cfirst.data(), cfirst.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    DP_CHECK_HIP(hipMemcpy(h->jl_entry, entry.data(), entry.size() * sizeof(float2), hipMemcpyHostToDevice));
+    h->jl_chunks = chunks;
+    h->jl_key[0] = jptr_dev; h->jl_key[1] = jvidx_dev; h->jl_key[2] = jw_dev;
+    return DPOSER_OK;
 }
 
 struct FkBwdArgs {
@@ -1528,9 +1640,11 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         FK_HIP_LAUNCH(hipGetLastError());
     }
     {
+        DP_TRY(build_joint_chunks(h, joint_ptr, joint_vidx, joint_w, st));      // (first call for these lists only)
         JointBwdArgs a;
-        a.dverts = d_verts; a.vp = vp; a.jptr = joint_ptr; a.jvidx = joint_vidx; a.jw = joint_w; a.dA = dA; a.J = J; a.V = V; a.B = batch;
-        hipLaunchKernelGGL(k_skin_bwd_joints, dim3((unsigned)(ceil_div(batch, 8) * 8 * J)), dim3(128), 0, st, a);
+        a.dverts = d_verts; a.vp = vp; a.vstart = h->jl_vstart; a.cptr = h->jl_ptr; a.cfirst = h->jl_first; a.entry = h->jl_entry; a.dA = dA;
+        a.J = J; a.V = V; a.chunks = h->jl_chunks; a.B = batch;
+        hipLaunchKernelGGL(k_skin_bwd_joints, dim3((unsigned)batch), dim3(256), 0, st, a);
         FK_HIP_LAUNCH(hipGetLastError());
     }
     // d pose_feature [B][486] = d_off [B][3V] @ posedirs^T : fp32 MFMA, split over the vertex dimension
