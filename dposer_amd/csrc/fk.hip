@@ -793,6 +793,8 @@ struct SkinArgs {
     const float* transl;       // [B][3] or null
     float* verts;              // [B][V][3]
 };
+// (staging the block's coordinates through LDS so that they enter and leave as consecutive dwords -- what pays in k_skin_bwd -- was
+//  measured SLOWER here: 461 -> 569 us at 4096 poses, four extra barriers per 256 vertices)
 __global__ void __launch_bounds__(256) k_skin(SkinArgs a) {
     extern __shared__ float sA[];   // [J][12]
     const int64_t b = blockIdx.y;
