@@ -153,7 +153,9 @@ class MotionDenoise:
             init_mpjpe = torch.mean(torch.sqrt(torch.sum(je * je, dim=2)), dim=1) * 100.0
         timesteps = torch.linspace(self.sde.T, 1e-3, self.sde.N)
         total_steps = iterations * steps_per_iter
-        start = self.poses[:1].expand(S * F, -1) if init_poses is None else flat(init_poses)
+        # (every sequence starts from the module's random initial poses, as `optimize` does: frames must differ -- two identical
+        #  neighbouring frames give the temporal term's sqrt a zero argument and a NaN gradient, in the reference too)
+        start = self.poses[:F].repeat(S, 1) if init_poses is None else flat(init_poses)
         pose = start.detach().clone().contiguous().float()
         quan = [self._quan_t(time_strategy, step, total_steps, sample_trun, sample_time) for step in range(total_steps)]
         self.loss_log = self._optimize_fused(pose, flat(joints3d).detach(), [float(timesteps[q]) for q in quan],
@@ -226,3 +228,24 @@ class MotionDenoise:
             mpjpe = torch.mean(torch.sqrt(torch.sum(je * je, dim=2)), dim=1) * 100.0
             mpvpe = torch.mean(torch.sqrt(torch.sum(ve * ve, dim=2)), dim=1) * 100.0
         return {"init_MPJPE": init_mpjpe.cpu().numpy(), "MPJPE": mpjpe.cpu().numpy(), "MPVPE": mpvpe.cpu().numpy(), "pose_body": final}
+
+
+def evaluate_motion_denoising(md, joints3d, gt_poses, *, sequences_per_call=32, num_replicas=None, rank=None, **optimize_kwargs):
+    """The dataset loop of run/motion_denoising.py (its ``__main__`` walks the test sequences one at a time, one process) for a set
+    of equal-length sequences, data parallel over SEQUENCES -- the frames of one sequence are coupled by the temporal term, so that
+    is the only axis that shards: this rank's contiguous shard (``distributed.shard_bounds``, the reference's
+    DistributedEvalSampler arithmetic), ``sequences_per_call`` sequences advanced together by ``optimize_sequences``, per-frame
+    metrics kept as device-side sums, ONE all-reduce of (sum, count) pairs at the end (``distributed.reduce_metric_means``).
+    ``joints3d`` [S, F, 22, 3] noisy observations, ``gt_poses`` [S, F, 63].  Returns ({'init_MPJPE', 'MPJPE', 'MPVPE'} means in cm over
+    every frame of every rank, sequences evaluated here)."""
+    from .. import distributed as ddp
+    world = ddp.world_size() if num_replicas is None else num_replicas
+    rk = ddp.rank() if rank is None else rank
+    lo, hi = ddp.shard_bounds(joints3d.shape[0], world, rk)
+    results = []
+    for s0 in range(lo, hi, sequences_per_call):
+        s1 = min(s0 + sequences_per_call, hi)
+        res = md.optimize_sequences(joints3d[s0:s1], gt_poses[s0:s1], **optimize_kwargs)
+        results.append({k: torch.as_tensor(res[k]) for k in ("init_MPJPE", "MPJPE", "MPVPE")})
+    return ddp.reduce_metric_means(results, device=joints3d.device), hi - lo
+

@@ -316,7 +316,10 @@ int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedirs_packed, c
  *   d_verts [B,V,3]; d_joints [B, d_joints_ld] (first J*3 entries of a row = gradient of the posed LBS joints; extras and
  *   landmarks are vertex gathers and must be folded into d_verts by the caller);
  *   d_pose_segments_host[i]: DEVICE pointer [B, seg_joints*3] out or NULL;  d_jrest [B,J,3] out or NULL;
- *   d_vposed [B,V,3] out or NULL (= gradient w.r.t. v_shaped). */
+ *   d_vposed [B,V,3] out or NULL (= gradient w.r.t. v_shaped).
+ *   The handle caches a re-cut copy of the joint lists (by vertex chunk, for the joint-gradient kernel), keyed by the three DEVICE
+ *   ADDRESSES: it is built -- with a stream synchronisation, a device-to-host copy and allocations -- on the first call that sees
+ *   them, and again whenever other addresses are passed; lists whose contents change must therefore live in new buffers. */
 int64_t dposer_lbs_posedirs_bwd_packed_bytes(dposer_body_t h);
 int dposer_lbs_pack_posedirs_bwd(dposer_body_t h, const float* posedirs, void* packed, void* stream);
 int64_t dposer_lbs_backward_workspace_bytes(dposer_body_t h, int64_t batch);

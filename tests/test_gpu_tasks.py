@@ -223,6 +223,30 @@ def test_motion_denoise_batch_of_sequences_equals_one_sequence_at_a_time():
         assert np.allclose(log[:, i, :2], t2n(md.loss_log)[:, 0, :2], rtol=1e-6)
 
 
+def test_evaluate_motion_denoising_shards_sequences_over_ranks():
+    """evaluate_motion_denoising: contiguous shard of the sequences per rank, several sequences per call, metric means from (sum,
+    count) pairs.  Two 'ranks' evaluated one after the other cover all sequences; their frame-weighted means combine to the
+    single-process means (time strategy '2': a fixed t, so the schedule does not depend on how the calls are split; the in-kernel
+    noise is keyed by the frame index inside a call, so the same sequences-per-call split is used on both sides)."""
+    from dposer_amd.tasks.motion_denoising import evaluate_motion_denoising
+    F, S = 6, 5
+    md, joints3d, gt, init, rs = _md_setup(F * S)
+    md.batch_size = F
+    md.betas = md.betas[:F]
+    j, g = joints3d.reshape(S, F, 22, 3), gt.reshape(S, F, 63)
+    kw = dict(time_strategy="2", sample_time=300, iterations=1, steps_per_iter=4, sequences_per_call=1)
+    c0 = md._calls
+    whole, n = evaluate_motion_denoising(md, j, g, num_replicas=1, rank=0, **kw)
+    assert n == S and set(whole) == {"init_MPJPE", "MPJPE", "MPVPE"} and all(np.isfinite(v) for v in whole.values())
+    assert whole["MPJPE"] < whole["init_MPJPE"] * 1.5
+    md._calls = c0
+    m0, n0 = evaluate_motion_denoising(md, j, g, num_replicas=2, rank=0, **kw)
+    m1, n1 = evaluate_motion_denoising(md, j, g, num_replicas=2, rank=1, **kw)
+    assert (n0, n1) == (3, 2)
+    for k in whole:
+        assert abs((m0[k] * n0 + m1[k] * n1) / S - whole[k]) < 1e-4 * abs(whole[k]), k
+
+
 def test_motion_denoise_one_call_loop_inkernel_noise():
     """No injected noise: the prior's z comes from Philox(seed, step0 + i).  Same object state -> same result; the next call
     (advanced call counter) draws different noise; a zero-residual observation keeps everything finite (data term dropped on
