@@ -1192,6 +1192,56 @@ __global__ void __launch_bounds__(256) k_skin_bwd_joints(JointBwdArgs a) {
         for (int r = 0; r < 3; ++r) a.dA[(b * a.J + j) * 12 + 4 * r + q] = acc[r];
     }
 }
+// Small batches: one block per (pose, joint) gathering its list entries -- enough parallelism when there are few poses (the
+// streaming kernel above gives a pose ONE block that walks 41 chunks: ~300 us however few poses there are; this one takes 20 us
+// at 60 poses and loses above ~1500, where its 2 x 12 B gathers per entry from L2 become the bound: 1152 vs 732 us at 4096).
+struct JointGatherArgs {
+    const float* dverts;
+    const float* vp;
+    const int32_t* jptr;       // [J+1] CSR by joint
+    const int32_t* jvidx;      // [nnz]
+    const float* jw;           // [nnz]
+    float* dA;                 // [B][J][12]
+    int J, V;
+    int64_t B;
+};
+__global__ void __launch_bounds__(128) k_skin_bwd_joints_gather(JointGatherArgs a) {
+    __shared__ float red[128][13];
+    // XCD-aware order (hardware XCD = linear block id % 8): all J joints of one pose run back to back on ONE XCD, so the
+    // pose's dverts / vp rows come from HBM once and from that XCD's L2 afterwards
+    const int64_t q = blockIdx.x >> 3;
+    const int j = (int)(q % a.J);
+    const int64_t b = (q / a.J) * 8 + (blockIdx.x & 7);
+    if (b >= a.B) return;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int e = a.jptr[j] + threadIdx.x; e < a.jptr[j + 1]; e += 128) {
+        const int v = a.jvidx[e];
+        const float w = a.jw[e];
+        const float* dv = a.dverts + (b * a.V + v) * 3;
+        const float* p = a.vp + (b * a.V + v) * 3;
+        const float h[4] = {p[0], p[1], p[2], 1.0f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[4 * r + c] += w * dv[r] * h[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) red[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    for (int s = 64; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) red[threadIdx.x][i] += red[threadIdx.x + s][i];
+        __syncthreads();
+    }
+    if (threadIdx.x < 12) a.dA[(b * a.J + j) * 12 + threadIdx.x] = red[0][threadIdx.x];
+}
+static int64_t lbs_joint_stream_min() {      // batch size from which the streaming joint-gradient kernel is used (A/B: env)
+    const char* e = getenv("DPOSER_LBS_JOINT_STREAM_MIN");
+    return e ? atoll(e) : (int64_t)1536;
+}
 // (host) cut the CSR-by-joint lists (vertex ids ascending inside a joint) into chunks of <= JL_MAXV vertices and <= JL_MAXE entries
 static int build_joint_chunks(dposer_body_s* h, const int32_t* jptr_dev, const int32_t* jvidx_dev, const float* jw_dev, hipStream_t st) {
     const int J = h->d.num_joints, V = h->d.num_vertices;
@@ -1642,11 +1692,17 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         FK_HIP_LAUNCH(hipGetLastError());
     }
     {
-        DP_TRY(build_joint_chunks(h, joint_ptr, joint_vidx, joint_w, st));      // (first call for these lists only)
-        JointBwdArgs a;
-        a.dverts = d_verts; a.vp = vp; a.vstart = h->jl_vstart; a.cptr = h->jl_ptr; a.cfirst = h->jl_first; a.entry = h->jl_entry; a.dA = dA;
-        a.J = J; a.V = V; a.chunks = h->jl_chunks; a.B = batch;
-        hipLaunchKernelGGL(k_skin_bwd_joints, dim3((unsigned)batch), dim3(256), 0, st, a);
+        if (batch >= lbs_joint_stream_min()) {
+            DP_TRY(build_joint_chunks(h, joint_ptr, joint_vidx, joint_w, st));      // (first call for these lists only)
+            JointBwdArgs a;
+            a.dverts = d_verts; a.vp = vp; a.vstart = h->jl_vstart; a.cptr = h->jl_ptr; a.cfirst = h->jl_first; a.entry = h->jl_entry; a.dA = dA;
+            a.J = J; a.V = V; a.chunks = h->jl_chunks; a.B = batch;
+            hipLaunchKernelGGL(k_skin_bwd_joints, dim3((unsigned)batch), dim3(256), 0, st, a);
+        } else {
+            JointGatherArgs a;
+            a.dverts = d_verts; a.vp = vp; a.jptr = joint_ptr; a.jvidx = joint_vidx; a.jw = joint_w; a.dA = dA; a.J = J; a.V = V; a.B = batch;
+            hipLaunchKernelGGL(k_skin_bwd_joints_gather, dim3((unsigned)(ceil_div(batch, 8) * 8 * J)), dim3(128), 0, st, a);
+        }
         FK_HIP_LAUNCH(hipGetLastError());
     }
     // d pose_feature [B][486] = d_off [B][3V] @ posedirs^T : fp32 MFMA, split over the vertex dimension

@@ -349,6 +349,27 @@ def test_small_batch_fk_kernels_return_the_bits_of_the_large_batch_ones(bm, asse
         assert torch.equal(a, b), n
 
 
+def test_joint_gradient_kernels_agree(bm, monkeypatch):
+    """d loss / d (skinning transforms): the (pose, joint)-parallel gather kernel (batches below DPOSER_LBS_JOINT_STREAM_MIN = 1536
+    poses) and the streaming per-pose kernel over chunk-major lists (above) sum the same terms in different orders."""
+    B = 9
+    pose = (np.random.RandomState(2).standard_normal((B, 63)) * 0.4).astype(np.float32)
+    wv = torch.tensor(np.random.RandomState(3).standard_normal((B, 10475, 3)).astype(np.float32) / 50.0, device=DEV)
+
+    def run():
+        p = torch.tensor(pose, device=DEV, requires_grad=True)
+        out = bm(pose_body=p)
+        ((out.v * wv).sum() + (out.Jtr ** 2).sum()).backward()
+        return t2n(p.grad)
+
+    g_gather = run()
+    monkeypatch.setenv("DPOSER_LBS_JOINT_STREAM_MIN", "1")
+    g_stream = run()
+    monkeypatch.delenv("DPOSER_LBS_JOINT_STREAM_MIN")
+    assert np.linalg.norm(g_gather - g_stream) / np.linalg.norm(g_gather) < 1e-5
+    assert not np.array_equal(g_gather, g_stream)
+
+
 @pytest.mark.parametrize("model_type", ["smpl", "smplh"])
 def test_small_batch_fk_kernels_other_trees(model_type, monkeypatch):
     from dposer_amd.body_model.body_model import BodyModel
