@@ -1676,8 +1676,8 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
     float* dA = (float*)p; p += round_up(batch * J * 12 * 4, 256);
     float* dG = (float*)p; p += round_up(batch * J * 12 * 4, 256);
     float* dpf = (float*)p; p += round_up(lbs_bwd_slabs(Bpad, Cpad, prow) * Bpad * prow * 4, 256);
-    int* parents_dev = (int*)p;
-    DP_CHECK_HIP(hipMemcpyAsync(parents_dev, h->parents, J * sizeof(int), hipMemcpyHostToDevice, st));
+    // (the kernels walk compile-time parents tables: the per-call host-to-device copy of the parents array that used to sit
+    //  here -- a pageable-memory copy in the middle of every optimisation step -- fed nothing)
     const bool blend32 = lbs_blend_fp32();
     __bf16* doff_hi = reinterpret_cast<__bf16*>(doff);                  // bf16 x 3: the two terms share the FT32 operand's bytes
     __bf16* doff_lo = doff_hi + Bpad * Cpad;
@@ -1753,7 +1753,7 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
             hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)(n4 < 256 * 2048 ? ceil_div(n4, 256) : 2048)), dim3(256), 0, st, dpf, Bpad * prow, ks);
             FK_HIP_LAUNCH(hipGetLastError());
         }
-        a.dpf = dpf; a.dpf_slab = Bpad * prow; a.ldpf = prow; a.nsplit = 1; a.djrest = d_jrest; a.dG = dG; a.parents = parents_dev; a.J = J;
+        a.dpf = dpf; a.dpf_slab = Bpad * prow; a.ldpf = prow; a.nsplit = 1; a.djrest = d_jrest; a.dG = dG; a.parents = nullptr; a.J = J;
         a.B = batch;
         if (batch <= fk_small_max()) {
             const dim3 grid((unsigned)batch);
