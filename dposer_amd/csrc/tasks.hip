@@ -186,6 +186,7 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     const int64_t F = a->frames_per_sequence > 0 ? a->frames_per_sequence : a->frames;
     DP_CHECK_ARG(F >= 2 && a->frames >= F && a->frames % F == 0, "frames must be a whole number of sequences of >= 2 frames (the temporal term couples neighbours)");
     const int64_t n_seq = a->frames / F;
+    DP_CHECK_ARG(a->frames <= 65535, "at most 65535 frames per call (one grid row per frame in the skinning kernels)");
     DP_CHECK_ARG(a->num_segments >= 1 && a->num_segments <= 8 && a->body_segment >= 0 && a->body_segment < a->num_segments, "bad pose segments");
     DP_CHECK_ARG(a->norm_mode == 0 || ((a->norm_mode == 1 || a->norm_mode == 2) && a->norm_a && a->norm_b), "bad normaliser");
     DP_CHECK_ARG(a->num_vertices > 0 && a->num_joints > 0 && a->joint_rows >= a->num_joints && a->n_obs_joints >= 1 && a->n_obs_joints <= a->num_joints,
