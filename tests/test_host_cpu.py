@@ -262,6 +262,37 @@ def test_capi_handle_layout_and_error_codes():
         lib.dposer_scorefc_destroy(h)
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """The structs of include/dposer_hip.h as the C compiler lays them out (gcc, the header is plain C) against their ctypes
+    mirrors in dposer_amd/_C.py: size and the offset of every field."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from dposer_amd import _C
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    pairs = {"dposer_scorefc_desc": _C.ScoreFCDesc, "dposer_sde_desc": _C.SdeDesc, "dposer_body_desc": _C.BodyDesc,
+             "dposer_motion_denoise_args": _C.MotionDenoiseArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dposer_hip.h"', 'int main(void) {']
+    for cname, ct in pairs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "abi_probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi_probe"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        a, b, c = ln.split()
+        got[(a, b)] = int(c)
+    for cname, ct in pairs.items():
+        assert got[(cname, "size")] == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert got[(cname, fname)] == getattr(ct, fname).offset, (cname, fname)
+
+
 def test_device_rk45_driver_reproduces_scipy_step_for_step():
     """ode_device.solve_rk45 is scipy's RK45 controller on torch tensors: on the same right-hand side it must make the same
     accept / reject decisions (identical nfev) and land on the same state, forwards and backwards in time, including a stiff-ish
