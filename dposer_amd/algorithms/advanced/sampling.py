@@ -105,10 +105,15 @@ class EulerMaruyamaPredictor(Predictor):
 
     def update_fn_guide(self, x_t, t, observation, mask, condition=None, grad_step=1.0):
         """MCG / DPS style guided step (sampling.py:191-207); needs d score / d x -> differentiable HIP forward."""
+        import contextlib
         x_t.requires_grad_()
         dt = -1.0 / self.rsde.N
         z = torch.randn_like(x_t)
-        drift, diffusion, alpha, sigma_2, score = self.rsde.sde(x_t, t, condition, mask, guide=True)
+        # only d score / d x is ever asked for here: inside input_grad_only() the backward skips the weight-gradient GEMMs
+        model = getattr(self.score_fn, "model", None)
+        only_x = model.input_grad_only() if hasattr(model, "input_grad_only") else contextlib.nullcontext()
+        with only_x:
+            drift, diffusion, alpha, sigma_2, score = self.rsde.sde(x_t, t, condition, mask, guide=True)
         y_mean = x_t.detach() + drift.detach() * dt
         y_hat = y_mean + diffusion[:, None] * np.sqrt(-dt) * z
         with torch.enable_grad():

@@ -307,6 +307,23 @@ def em_step(p, sde, x, t, z, **fw):
     return x_new, x_mean
 
 
+def em_guided_step(p, sde, x_t, t, z, observation, mask, grad_step=1.0, **fw):
+    """EulerMaruyamaPredictor.update_fn_guide with injected noise -- sampling.py:191-207 around RSDE.sde(guide=True),
+    sde_lib.py:98-109: the Euler-Maruyama step, then minus grad_step times the gradient w.r.t. x_t of
+    || observation * mask - y0_hat * mask ||_F, y0_hat = (x_t + sigma^2 score(x_t, t)) / alpha (the Tweedie estimate,
+    differentiated THROUGH the score network).  Returns (y_hat, y_mean)."""
+    x = x_t.detach().clone().requires_grad_(True)
+    dt = -1.0 / sde.N
+    drift, g, score = rsde_sde(p, sde, x, t, **fw)
+    alpha, sigma = sde.alpha_sigma(t)
+    y_mean = x.detach() + drift.detach() * dt
+    y_hat = y_mean + g[:, None] * np.sqrt(-dt) * z
+    y0_hat = (x + (sigma ** 2)[:, None] * score) / alpha
+    norm = torch.norm(observation * mask - y0_hat * mask)
+    grad = torch.autograd.grad(norm, x)[0]
+    return (y_hat - grad_step * grad).detach(), y_mean
+
+
 def impute(sde, x, t, observation, mask, noise):
     """completion imputation -- sampling.py:416-420."""
     mean, std = sde.marginal_prob(observation, t)

@@ -287,6 +287,35 @@ def g5_sampler():
     save("g5_sampler", **out)
 
 
+def g16_guided_step():
+    """G16: EulerMaruyamaPredictor.update_fn_guide (sampling.py:191-207, MCG / DPS style guidance: the EM step minus
+    grad_step * d||obs * mask - y0_hat * mask|| / d x_t, which differentiates THROUGH the score network w.r.t. its input),
+    sub-VP and VP, injected z; legs masked."""
+    cfg, m = build_model(16, 63)
+    m.eval()
+    out = {"seed": np.int64(16)}
+    B = 12
+    poses, _ = toy_batch(B, seed=46)
+    with Recorder(56):
+        mask, obs = ref_misc.create_mask(poses, part="legs")
+    out["mask"], out["obs"] = mask.numpy(), obs.numpy()
+    rs = np.random.RandomState(160)
+    x_t = torch.tensor((poses.numpy() + 0.3 * rs.standard_normal((B, 63))).astype(np.float32))
+    out["x_t"] = x_t.numpy()
+    for name, sde in (("subvp", ref_sde.subVPSDE(0.1, 20.0, 1000)), ("vp", ref_sde.VPSDE(0.1, 20.0, 1000))):
+        score_fn = ref_mutils.get_score_fn(sde, m, train=False, continuous=True)
+        pred = ref_sampling.EulerMaruyamaPredictor(sde, score_fn, probability_flow=False)
+        for t_val in (0.9, 0.3):
+            t = torch.ones(B) * t_val
+            with Recorder(161) as rec:
+                y_hat, y_mean = pred.update_fn_guide(x_t.clone(), t, obs, mask, grad_step=0.7)
+            tag = f"{name}_t{int(t_val * 10)}"
+            out[f"{tag}_z"] = rec.by_kind("randn")[0]
+            out[f"{tag}_y_hat"] = y_hat.detach().numpy()
+            out[f"{tag}_y_mean"] = y_mean.detach().numpy()
+    save("g16_guided_step", **out)
+
+
 def g7_prior_loss():
     """G7: DPoserComp.loss (run/completion.py:131-149) value + autograd grad wrt x_0 at the
     quan_t schedule of completion.py:189-190 for steps {0,99,100,199}; injected z."""
@@ -598,8 +627,8 @@ def g13_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
-    fns = dict(g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    fns = dict(g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
                g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
     for w in which:
         fns[w]()

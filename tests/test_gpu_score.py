@@ -127,6 +127,31 @@ def test_em_sampler_completion_golden():
     assert np.abs(t2n(trajs)[-1] * mask - g["comp8_trajs"][-1] * mask).max() < 1e-3
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-5), ("bf16", 2e-2)])      # measured: fp32 2.0e-6, bf16 7.6e-3 (a gradient through the network)
+def test_guided_em_step_matches_reference_golden(prec, tol, monkeypatch):
+    """EulerMaruyamaPredictor.update_fn_guide (sampling.py:191-207: the EM step minus grad_step x the gradient of the masked
+    Tweedie residual norm w.r.t. x_t, i.e. a backward pass THROUGH the score network to its input) on the HIP forward /
+    input-gradient path vs the reference's own output (golden g16), sub-VP and VP, the golden's z injected.  The step runs inside
+    ``model.input_grad_only()``: no weight-gradient GEMM is launched for it."""
+    from dposer_amd.algorithms.advanced import sampling, sde_lib
+    from dposer_amd.algorithms.advanced import utils as mutils
+    g = load("g16_guided_step")
+    cfg, m, p = make_model(int(g["seed"]), precision=prec)
+    x_t, obs, mask = _dev(g["x_t"]), _dev(g["obs"]), _dev(g["mask"])
+    for name, sde in (("subvp", sde_lib.subVPSDE(0.1, 20.0, 1000)), ("vp", sde_lib.VPSDE(0.1, 20.0, 1000))):
+        score_fn = mutils.get_score_fn(sde, m, train=False, continuous=True)
+        pred = sampling.EulerMaruyamaPredictor(sde, score_fn, probability_flow=False)
+        for tv in (0.9, 0.3):
+            tag = f"{name}_t{int(tv * 10)}"
+            z = _dev(g[f"{tag}_z"])
+            monkeypatch.setattr(torch, "randn_like", lambda x, **kw: z)
+            y_hat, y_mean = pred.update_fn_guide(x_t.clone(), torch.ones(x_t.shape[0], device=DEV) * tv, obs, mask, grad_step=0.7)
+            monkeypatch.undo()
+            assert rel_err(t2n(y_mean), g[f"{tag}_y_mean"]) < tol, tag
+            assert rel_err(t2n(y_hat), g[f"{tag}_y_hat"]) < tol, tag
+    assert all(q.grad is None for q in m.parameters())
+
+
 def test_langevin_corrector_fused_path_matches_reference_golden():
     """Langevin corrector + EM predictor (sampling.py:282-302, 182-188) on the HIP path -- dposer_langevin_step (two phases around
     the batch-mean norms) + dposer_em_sampler_steps -- fed the golden's recorded draws in the reference's order."""

@@ -221,3 +221,19 @@ def test_motion_denoise_loop_restatement_matches_the_reference_loop(tag):
     assert rel_err(final, g[f"{tag}_pose_final"]) < 1e-5
     for k in ("init_MPJPE", "MPJPE", "MPVPE"):
         assert np.allclose(res[k], g[f"{tag}_{k}"], rtol=1e-4, atol=1e-5), k
+
+
+def test_guided_em_step_restatement_matches_reference_golden():
+    """oracle.score_ref.em_guided_step vs the reference's EulerMaruyamaPredictor.update_fn_guide (golden g16: sub-VP and VP,
+    two times, legs masked, injected z)."""
+    g = load("g16_guided_step")
+    p = make_weights(int(g["seed"]))
+    p["sigmas"] = R.sigma_table()
+    x_t, obs, mask = (torch.tensor(g[k]) for k in ("x_t", "obs", "mask"))
+    for name, sde in (("subvp", R.SubVP(N=1000)), ("vp", R.VP(N=1000))):
+        for tv in (0.9, 0.3):
+            tag = f"{name}_t{int(tv * 10)}"
+            y_hat, y_mean = R.em_guided_step(p, sde, x_t, torch.ones(x_t.shape[0]) * tv, torch.tensor(g[f"{tag}_z"]), obs, mask, grad_step=0.7)
+            assert rel_err(y_mean.numpy(), g[f"{tag}_y_mean"]) < 1e-5, tag
+            assert rel_err(y_hat.numpy(), g[f"{tag}_y_hat"]) < 1e-4, tag
+
