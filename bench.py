@@ -159,6 +159,24 @@ def main():
     ap.add_argument("--precision", default="bf16")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Not under a launcher: start the N ranks ourselves -- as CHILD processes of a parent that has not touched the GPU
+        # (counting devices does not initialise it), like the reference's multi-GPU entry spawns one process per GPU
+        # (run/completion.py:326-338).  Rank 0 of the children prints the JSON line on the inherited stdout.
+        import socket
+        import subprocess
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and os.environ.get("DPOSER_BENCH_ALLOW_SHARED_GPU") != "1":
+            print(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible: refusing to report a {args.gpus}-GPU number from fewer devices "
+                  "(DPOSER_BENCH_ALLOW_SHARED_GPU=1 lets test rigs stack ranks on one device over gloo)", file=sys.stderr)
+            sys.exit(2)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
     from dposer_amd import _C
     from dposer_amd import distributed as ddp
     from dposer_amd.algorithms.advanced import losses, sampling, sde_lib
@@ -167,7 +185,8 @@ def main():
     from dposer_amd.configs import load_config
 
     rank, world, local_rank = ddp.init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)     # (test rigs may run several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -38,6 +38,7 @@ class FusedAdam(optim.Adam):
         self._flat_m = self._flat_v = self._flat_g = self._scratch = None
         self._flat_cache = self._state_views = None
         self._step_count = 0
+        self._sharded = None
         self.world_size = 1
 
     def _params(self):
@@ -132,8 +133,11 @@ class FusedAdam(optim.Adam):
                                                     float(grad_scale), self._step_count, float(omd), _C.ptr(self._scratch),
                                                     _C.stream_ptr()), "dposer_adam_ema_clip_step")
         torch.autograd.graph.increment_version(params)   # the kernel wrote the parameters through raw pointers: tell autograd
-        # torch-compatible per-parameter state: {'step', 'exp_avg', 'exp_avg_sq'} are views of the flat buffers and ONE shared
-        # step tensor, rebuilt only when the set of live parameters (or the buffers) changes -- not 3 tensors per parameter per step
+        self._publish_state(params, offs, live)
+
+    def _publish_state(self, params, offs, live):
+        """torch-compatible per-parameter state: {'step', 'exp_avg', 'exp_avg_sq'} are views of the flat buffers and ONE shared
+        step tensor, rebuilt only when the set of live parameters (or the buffers) changes -- not 3 tensors per parameter per step."""
         live_key = (tuple(bool(ok) for ok in live), self._flat_m.data_ptr())
         if getattr(self, "_state_views", None) != live_key:
             self._step_t = torch.tensor(float(self._step_count))
@@ -147,11 +151,33 @@ class FusedAdam(optim.Adam):
         self._step_t.fill_(float(self._step_count))
 
     @torch.no_grad()
+    def gather_state(self):
+        """After ZeRO-1 steps every rank holds the Adam moments of its OWN range only.  All-gather them (two collectives over the
+        ranges of the last sharded step) and publish the torch-style per-parameter state, so that ``state_dict()`` of a sharded
+        run is the state of the replicated run.  COLLECTIVE: every rank must call it (``state_dict()`` does when needed)."""
+        from ... import distributed as ddp
+        sh = getattr(self, "_sharded", None)
+        if sh is None:
+            return
+        bounds, live = sh
+        flat, offs, params = self._ensure_flat()
+        ddp.all_gather_flat_(self._flat_m, bounds)
+        ddp.all_gather_flat_(self._flat_v, bounds)
+        self._publish_state(params, offs, live)
+        self._sharded = None
+
+    def state_dict(self):
+        """torch's layout.  After sharded (ZeRO-1) steps the moments are gathered first -- a collective, so checkpointing a
+        sharded run means calling ``state_dict()`` on EVERY rank (rank 0 then writes the file)."""
+        self.gather_state()
+        return super().state_dict()
+
+    @torch.no_grad()
     def fused_step_sharded(self, *, live, bounds, rank, grad_clip=-1.0, grad_scale=1.0, ema: ExponentialMovingAverage = None):
         """ZeRO-1 style update (SURVEY 8e): ``self._flat_g`` holds this rank's reduce-scattered gradient range ``bounds[rank]``;
         the global squared norm for the clip is one all-reduced float; Adam / EMA touch only the owned range (1/G of the
-        work and of the moment traffic); the caller all-gathers the parameters afterwards.  Moments outside the owned range stay
-        zero on this rank (a checkpoint of a sharded run must gather them first: ``gather_state``)."""
+        work and of the moment traffic); the caller all-gathers the parameters afterwards.  Moments outside the owned range are
+        stale on this rank until ``gather_state()`` (called by ``state_dict()``) all-gathers them for a checkpoint."""
         from ... import distributed as ddp
         flat, offs, params = self._ensure_flat()
         lo, hi = bounds[rank]
@@ -187,6 +213,7 @@ class FusedAdam(optim.Adam):
                 float(g["betas"][1]), float(g["eps"]), float(grad_clip), float(grad_scale), self._step_count, float(omd),
                 _C.ptr(self._scratch), _C.stream_ptr()), "dposer_adam_ema_clip_step_presummed")
         torch.autograd.graph.increment_version(params)
+        self._sharded = (list(bounds), list(live))      # moments are complete on the owning ranks only: see gather_state()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -372,8 +399,8 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
                 model.train()
             flat_grad = optimizer.flat_grad()
             # Philox key of this rank's shard: sample i of every shard must NOT draw the same t / z / dropout mask
-            seed = (model._rng_seed + 0x9E3779B1 * ddp.rank()) & 0xFFFFFFFFFFFFFFFF if ddp.world_size() > 1 else model._rng_seed
-            zero1 = ddp.world_size() > 1 and (os.environ.get("DPOSER_ZERO1") == "1" or bool(getattr(optimizer, "zero1", False)))
+            seed = (model._rng_seed + 0x9E3779B1 * ddp.rank()) & 0xFFFFFFFFFFFFFFFF if ddp.dp_active() else model._rng_seed
+            zero1 = ddp.dp_active() and (os.environ.get("DPOSER_ZERO1") == "1" or bool(getattr(optimizer, "zero1", False)))
             if zero1:
                 # ZeRO-1 style step: reduce-scatter the gradient, update only the owned 1/G range of parameters,
                 # moments and EMA, all-gather the parameters (and the EMA shadow, which every rank keeps whole for evaluation)
@@ -391,7 +418,7 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
                     ddp.all_gather_flat_(shadow, bounds)
                 state["step"] += 1
                 return {"step_loss": loss, "score_loss": loss}
-            if ddp.world_size() > 1:
+            if ddp.dp_active():
                 # bucketed: each GN layer's gradient is all-reduced (RCCL over xGMI) on a side stream while the layers in
                 # front of it are still being differentiated
                 eng = model._engine()

@@ -318,12 +318,12 @@ def fused_pc_langevin_sample(model, sde, x, timesteps, *, snr, n_steps=1, start_
     msk = None if mask is None else mask.contiguous().float()
     nz = None if noise is None else noise.contiguous().float()
     k_pred = 3 if obs is not None else 1
-    world = ddp.world_size()
+    dp = ddp.dp_active()
     global_batch = B
-    if world > 1:                                  # ragged shards: the global batch is the sum of the local ones (once per call)
-        cnt = torch.tensor([float(B)], dtype=torch.float64)
+    if dp:                                         # ragged shards: the global batch is the sum of the local ones (once per call)
+        cnt = torch.tensor([float(B)], dtype=torch.float64, device=x.device)     # on the device: RCCL cannot reduce a CPU tensor
         ddp.all_reduce_sum_(cnt)
-        global_batch = int(cnt[0])
+        global_batch = int(cnt.item())
     norms = torch.empty(2, dtype=torch.float32, device=x.device)
     alphas = sde.alphas.detach().to("cpu") if hasattr(sde, "alphas") else None
     traj = torch.empty((n_run // traj_stride, B, D), dtype=torch.float32, device=x.device) if (traj_stride and n_run > 0) else None
@@ -338,7 +338,7 @@ def fused_pc_langevin_sample(model, sde, x, timesteps, *, snr, n_steps=1, start_
                     _C.ptr(z), int(seed), (gi * n_steps + k) & 0xFFFFFFFF, _C.ptr(norms))
             _C.check(lib.dposer_langevin_step(*args, 0, 1.0 / global_batch, _C.ptr(freq), _C.ptr(model.sigmas), B, _C.stream_ptr()),
                      "dposer_langevin_step")
-            if world > 1:
+            if dp:
                 ddp.all_reduce_sum_(norms)         # two floats: keeps the reference's global-batch means under DP
             _C.check(lib.dposer_langevin_step(*args, 1, 1.0 / global_batch, _C.ptr(freq), _C.ptr(model.sigmas), B, _C.stream_ptr()),
                      "dposer_langevin_step")

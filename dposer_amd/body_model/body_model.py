@@ -279,7 +279,9 @@ class _SMPLCore(nn.Module):
         * otherwise ``dposer_shape_blend_forward`` (HIP; differentiable w.r.t. betas / expression through
           ``dposer_shape_blend_backward``).  The task loops pass the SAME constant betas tensor every step
           (motion_denoising.py:64,217: ``self.betas``), so the result is cached on (storage, version, shape) of the inputs --
-          an unchanged tensor costs no launch and no host sync; a tensor that requires grad is never cached."""
+          an unchanged tensor costs no launch and no host sync; a tensor that requires grad is never cached.  The cache entry
+          keeps the input tensors alive, so a freed-and-recycled address can never alias an old entry; writes through raw
+          pointers that do not bump ``_version`` are outside the contract (torch ops and ``copy_`` do bump it)."""
         dev = self.v_template.device
         if betas is None and expression is None:
             return self.v_template, self.j_template, False
@@ -289,7 +291,11 @@ class _SMPLCore(nn.Module):
         if not differentiable:
             key = tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) if t is not None else None for t in (betas, expression))
             hit = self._rest_cache.get("shape")
-            if hit is not None and hit[0] == key:
+            # the entry holds the input tensors themselves: while it lives their storage cannot be freed and handed to another
+            # tensor with the same address and version 0 (the caching allocator does exactly that), and a hit requires the SAME
+            # tensor objects' storages, not merely equal addresses
+            if hit is not None and hit[0] == key and all(a is b or (a is not None and b is not None and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr())
+                                                         for a, b in zip(hit[3], (betas, expression))):
                 return hit[1], hit[2], True
         parts = [betas if betas is not None else torch.zeros(B, self.num_betas, device=dev)]
         if self.num_expression_coeffs:
@@ -301,7 +307,7 @@ class _SMPLCore(nn.Module):
             raise ValueError(f"expected {self.shapedirs.shape[2]} shape coefficients, got {shape.shape[1]}")
         v_shaped, j_rest = _ShapeBlendFunction.apply(self, shape)
         if key is not None:
-            self._rest_cache["shape"] = (key, v_shaped, j_rest)
+            self._rest_cache["shape"] = (key, v_shaped, j_rest, (betas, expression))
         return v_shaped, j_rest, True
 
     def forward(self, betas=None, global_orient=None, body_pose=None, left_hand_pose=None, right_hand_pose=None, transl=None,

@@ -194,6 +194,30 @@ template <> struct TileIO<__bf16> {
         }
     }
 };
+// LDS-DMA issued from inline asm (1 KiB / 256 B per wave instruction; LDS destination = wave-uniform base + lane * size).
+// Why asm: beside a global_load_lds it knows of, hipcc drains the whole VMEM queue (s_waitcnt vmcnt(0)) in front of every
+// ordinary load result and every LDS read that may alias the DMA target -- which turns a prefetch into a synchronous load.
+// Issued from asm the DMA is invisible to that pass; the caller then owns the ordering: a counted s_waitcnt vmcnt(N) before
+// the ds_reads of the landed data (VMEM operations of one wave retire in issue order on gfx9-family parts, stores included),
+// and an lgkmcnt(0) between the last ds_read of a buffer and the DMA that refills it.
+__device__ __forceinline__ void glds_asm_b128(const void* src_lane, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds_base) : "memory", "m0");
+}
+__device__ __forceinline__ void glds_asm_b32(const void* src_lane, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src_lane), "s"(lds_base) : "memory", "m0");
+}
+// s_waitcnt vmcnt(n) for an n that folds to a constant after unrolling (the builtin wants a literal)
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+    switch (n) {
+#define DP_WVM(N) case N: __builtin_amdgcn_s_waitcnt(waitcnt_vm(N)); break;
+        DP_WVM(0) DP_WVM(1) DP_WVM(2) DP_WVM(3) DP_WVM(4) DP_WVM(5) DP_WVM(6) DP_WVM(7) DP_WVM(8) DP_WVM(9) DP_WVM(10) DP_WVM(11)
+        DP_WVM(12) DP_WVM(13) DP_WVM(14) DP_WVM(15) DP_WVM(16) DP_WVM(17) DP_WVM(18) DP_WVM(19) DP_WVM(20)
+#undef DP_WVM
+        default: __builtin_amdgcn_s_waitcnt(waitcnt_vm(0)); break;
+    }
+}
+__device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63)); }
+
 // x + (x of lane ^ 32) with one v_permlane32_swap: the two accumulator halves of a GroupNorm group live in lanes l and l ^ 32.
 // (__shfl_xor(x, 32) is a ds_bpermute: an LDS round trip plus an s_waitcnt that stalls the wave -- and its MFMAs -- in an epilogue.)
 __device__ __forceinline__ float sum_xor32(float x) {

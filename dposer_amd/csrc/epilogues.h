@@ -82,6 +82,22 @@ __device__ __forceinline__ uint32_t dropout_mask16_bits(const DropoutCfg& d, int
     return bits;
 }
 
+// the 16 decisions of dropout_mask16 as a bit set only (bit 4q + r); the training epilogue applies them as AND masks
+__device__ __forceinline__ uint32_t dropout_bits16(const DropoutCfg& d, int64_t s, int g, int hi) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        Philox4 r = philox_at((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int i0 = 4 * (2 * m + (w >> 1)) + (w & 1) * 2;
+            bits |= ((r.v[w] & 0xffffu) < d.thr ? 1u : 0u) << i0;
+            bits |= ((r.v[w] >> 16) < d.thr ? 1u : 0u) << (i0 + 1);
+        }
+    }
+    return bits;
+}
+
 // ----------------------------------------------------------------------------------------------
 // forward:  out = [resid +] Drop(SiLU(GroupNorm32(acc + bias)))         model.py:166-187
 // ----------------------------------------------------------------------------------------------
@@ -107,7 +123,17 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
     static constexpr bool FLAT = RESID >= 0;
     static constexpr int kScratchPerWave = TRAIN ? TileT<T>::SCRATCH_BYTES : 0;
     static constexpr int kParamArrays = 3;
+    // TRAIN: the residual input of sub-tile i + 2 is DMA'd (inline asm, common.h) into a per-wave double buffer in the idle
+    // K-loop ring while sub-tile i is processed.  (Round 2 measured a builtin-issued DMA prefetch without gain: hipcc waits
+    // vmcnt(0) for it in front of the LDS read, i.e. at once.  A layer with a residual input cost 34 us more than one without.)
+    static constexpr int kTileBytes = 1024 * (int)sizeof(T);
+    static constexpr int kRingPerWave = TRAIN ? 2 * kTileBytes : 0;
     __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.bias : (a == 1 ? p.gamma : p.beta); }
+    __device__ static inline void resid_dma(const T* resid, int64_t s0, int c0, int H, int it, int lane, unsigned ring_lds) {
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(resid + ft_tile_base<T>(s0, c0, H)) + lane * 16;
+#pragma unroll
+        for (int h = 0; h < kTileBytes / 1024; ++h) glds_asm_b128(src + h * 1024, ring_lds + (it & 1) * kTileBytes + h * 1024);
+    }
     // One 32x32 sub-tile (tc, ts) of the wave tile; `a` = its accumulator.  Sub-tiles are independent of each other, which is
     // what lets the pipelined kernel (gemm_pipe.h) run them inside the k-loop of the NEXT tile.  The work is split in kPhases = 2
     // halves of similar VALU weight (PH = 0: statistics + dropout draw, PH = 1: normalise / SiLU / stores; PH = -1: both), the
@@ -115,8 +141,10 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
     static constexpr int kPhases = 2;
     struct Carry {
         float v[16];       // centred values (phase 0) -> x_hat
-        float keep[16];
+        uint32_t bits;     // dropout keep decisions (bit 4q + r), all ones when dropout is off
         float rstd;
+        const unsigned char* ring = nullptr;   // TRAIN + apply_ring: residual tiles arrive here by DMA (see kRingPerWave)
+        unsigned ring_lds = 0;
         // residual input: the tile of THIS sub-tile (rc) and the one prefetched for the NEXT sub-tile (rn).  Loaded where it
         // is added, each sub-tile paid an exposed HBM round trip (a layer with a residual input took 25-35 us longer than
         // one without); issued one sub-tile ahead the latency hides under ~500 VALU instructions.
@@ -162,15 +190,18 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
             ss = sum_xor32(ss);
             const float var = ss * (1.0f / 32.0f);
             cy.rstd = PRECISE ? 1.0f / sqrtf(var + 1e-5f) : rsqrtf(var + 1e-5f);
-            uint32_t bits = 0xffffu;
-            if (drop) bits = dropout_mask16_bits(p.drop, s, c0 >> 5, hi, cy.keep);
+            cy.bits = 0xffffu;
+            if (drop) cy.bits = dropout_bits16(p.drop, s, c0 >> 5, hi);
             if (TRAIN) {
-                GnAux rec = {cy.rstd, bits};
+                GnAux rec = {cy.rstd, cy.bits};
                 p.aux[gn_aux_index(sbase + ts * 32, c0 >> 5, p.H, lane)] = rec;
             }
         }
         if constexpr (PH != 0) {
             float o[16];
+            // dropout: a decision is an AND mask (v_bfe_i32 + v_and); 1/(1-p) rides inside the sigmoid's reciprocal in bf16 mode:
+            // a * rcp((1 + e)(1 - p)) -- the add becomes an fma, no extra multiply
+            const float dscale = drop ? p.drop.scale : 1.0f, dinv = drop ? 1.0f - p.drop.p : 1.0f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cl = tc * 32 + 8 * q + 4 * hi;
@@ -179,8 +210,12 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     cy.v[4 * q + r] *= cy.rstd;                                   // x_hat
-                    float y = silu_f<PRECISE>(g4[r] * cy.v[4 * q + r] + e4[r]);
-                    if (drop) y *= cy.keep[4 * q + r];
+                    const float a_ = g4[r] * cy.v[4 * q + r] + e4[r];
+                    float y;
+                    if constexpr (!TRAIN) y = silu_f<PRECISE>(a_);
+                    else if constexpr (PRECISE) y = silu_f<true>(a_) * dscale;
+                    else y = a_ * __builtin_amdgcn_rcpf(__builtin_fmaf(__expf(-a_), dinv, dinv));
+                    if constexpr (TRAIN) y = __uint_as_float(__float_as_uint(y) & (uint32_t)__builtin_amdgcn_sbfe((int)cy.bits, 4 * q + r, 1));
                     o[4 * q + r] = y;
                 }
             }
@@ -188,7 +223,20 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
             if (has_res) {
                 float rr[16];
                 if constexpr (PREFETCH) TileIO<T>::unpack(cy.rc, rr);
-                else TileIO<T>::load(p.resid + tb, lane, rr);
+                else if (TRAIN && cy.ring) {
+                    // VMEM operations younger than the DMA of sub-tile I when this point is reached (see apply_ring): the DMA of
+                    // I + 1, and per sub-tile 1 record store + 2 x_hat stores ahead of this point, 2 output stores behind it
+                    constexpr int I = tc * TS + ts, NSUB = TC * TS, ND = kTileBytes / 1024;
+                    constexpr int younger = (I + 1 < NSUB ? ND : 0) + (I == 0 ? 3 : (I == 1 ? 8 : 10));
+                    wait_vmcnt_n(younger);
+                    asm volatile("" ::: "memory");
+                    TileIO<T>::load(reinterpret_cast<const T*>(cy.ring + (I & 1) * kTileBytes), lane, rr);
+                    if constexpr (I + 2 < NSUB) {
+                        wait_lgkmcnt0();
+                        asm volatile("" ::: "memory");
+                        resid_dma(p.resid, sbase + ((I + 2) % TS) * 32, cbase + ((I + 2) / TS) * 32, p.H, I + 2, lane, cy.ring_lds);
+                    }
+                } else TileIO<T>::load(p.resid + tb, lane, rr);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] += rr[r];
             }
@@ -199,6 +247,18 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
     template <int TC, int TS>
     __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int split, const float* lpar, int lstride, unsigned char* scr) {
         Carry c;
+        epi_for_each_sub<EpiGN, TC, TS>(pp, c, acc, cbase, sbase, lane, wrow, split, lpar, lstride, scr);
+    }
+    template <int TC, int TS>
+    __device__ static inline void apply_ring(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int split, const float* lpar, int lstride, unsigned char* scr, unsigned char* ring) {
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        Carry c;
+        if (pp.resid) {
+            c.ring = ring;
+            c.ring_lds = (unsigned)(size_t)(lptr_t)ring;
+            resid_dma((const T*)pp.resid, sbase, cbase, pp.H, 0, lane, c.ring_lds);
+            if constexpr (TC * TS > 1) resid_dma((const T*)pp.resid, sbase + (1 % TS) * 32, cbase + (1 / TS) * 32, pp.H, 1, lane, c.ring_lds);
+        }
         epi_for_each_sub<EpiGN, TC, TS>(pp, c, acc, cbase, sbase, lane, wrow, split, lpar, lstride, scr);
     }
 };
@@ -536,7 +596,9 @@ template <typename T, int ABL = 0> struct EpiGNBwd {
     // into registers, each sub-tile paid a full HBM round trip behind an s_waitcnt (8 per wave tile, and both waves of a
     // SIMD are in the same place at the same time); the register budget leaves no room to prefetch there.
     static constexpr int kTileBytes = 1024 * (int)sizeof(T);
-    static constexpr int kRingPerWave = 2 * 2 * kTileBytes;   // [2 buffers][x_hat, carry]
+    static constexpr bool kDmaAll = sizeof(T) == 2;           // bf16: the GnAux records travel through the ring too (run_dma)
+    static constexpr int kBufBytes = 2 * kTileBytes + (kDmaAll ? 512 : 0);   // x_hat | carry | rstd words, keep words
+    static constexpr int kRingPerWave = 2 * kBufBytes;        // two buffers
     __device__ static inline const float* param_array(const Params& p, int a) { return a == 0 ? p.gamma : p.beta; }
     template <int TC, int TS>
     __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int split, const float* lpar, int lstride, unsigned char* scr) {
@@ -544,7 +606,127 @@ template <typename T, int ABL = 0> struct EpiGNBwd {
     }
     template <int TC, int TS>
     __device__ static inline void apply_ring(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int split, const float* lpar, int lstride, unsigned char* scr, unsigned char* ring) {
-        run<TC, TS, true>(pp, acc, cbase, sbase, lane, wrow, lpar, lstride, scr, ring);
+        if constexpr (kDmaAll && (ABL & 16) == 0) run_dma<TC, TS>(pp, acc, cbase, sbase, lane, wrow, lpar, lstride, scr, ring);
+        else run<TC, TS, true>(pp, acc, cbase, sbase, lane, wrow, lpar, lstride, scr, ring);
+    }
+    // bf16 pipeline, round 3.  What the epilogue was waiting for (round-2 ablation: loads + stores alone cost 31 us per launch,
+    // i.e. ~1 us per 32x32 sub-tile and wave with NO arithmetic): every sub-tile (1) loaded its GnAux record with an ordinary
+    // load right where it is needed, (2) waited with a counted vmcnt that also covers the stores of the sub-tile before, and
+    // (3) hipcc, seeing an ordinary load beside global_load_lds, drained the queue with vmcnt(0) -- the "prefetch" of the next
+    // sub-tile was waited for at once.  Here EVERYTHING the sub-tile reads (x_hat, residual carry, the record as two dword
+    // pieces) arrives by DMA issued from inline asm (common.h), two sub-tiles ahead (the buffer of sub-tile k is refilled
+    // for k + 2 as soon as its LDS reads have returned), and the wait in front of sub-tile k allows every younger operation
+    // to stay in flight: the DMA of k + 1 and the stores of k - 1 and k - 2.
+    template <int TC, int TS>
+    __device__ static inline void run_dma(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, const float* lpar, int lstride, unsigned char* scr, unsigned char* ring) {
+        static_assert(sizeof(T) == 2, "bf16 only");
+        struct { const T* carry_in; T* carry_out; const T* xhat; const GnAux* aux; T* dy; float* part; int H; int64_t S_valid; float scale; } p =
+            {(const T*)pp.carry_in, (T*)pp.carry_out, (const T*)pp.xhat, pp.aux, (T*)pp.dy, pp.part, pp.H, pp.S_valid, pp.drop_scale};
+        constexpr bool PRECISE = false;
+        constexpr int NSUB = TC * TS;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int j = lane & 31, hi = lane >> 5;
+        const bool has_carry = p.carry_in != nullptr;
+        const int nd = has_carry ? 6 : 4;                                 // DMA pieces per sub-tile
+        const unsigned ring_lds = (unsigned)(size_t)(lptr_t)ring;
+        auto dma = [&](int it) __attribute__((always_inline)) {
+            const int tc = it / TS, ts = it % TS;
+            const int64_t tb = ft_tile_base<T>(sbase + ts * 32, cbase + tc * 32, p.H);
+            const unsigned dst = ring_lds + (it & 1) * kBufBytes;
+            const unsigned char* xs = reinterpret_cast<const unsigned char*>(p.xhat + tb) + lane * 16;
+            glds_asm_b128(xs, dst);
+            glds_asm_b128(xs + 1024, dst + 1024);
+            if (has_carry) {
+                const unsigned char* cs = reinterpret_cast<const unsigned char*>(p.carry_in + tb) + lane * 16;
+                glds_asm_b128(cs, dst + 2 * 1024);
+                glds_asm_b128(cs + 1024, dst + 3 * 1024);
+            }
+            const unsigned char* as = reinterpret_cast<const unsigned char*>(p.aux + gn_aux_index(sbase + ts * 32, (cbase + tc * 32) >> 5, p.H, lane));
+            glds_asm_b32(as, dst + 4 * 1024);             // rstd words
+            glds_asm_b32(as + 4, dst + 4 * 1024 + 256);   // keep words
+        };
+        dma(0);
+        if constexpr (NSUB > 1) dma(1);
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) {
+            const int c0 = cbase + tc * 32;
+            float stat[32];   // [0..15] dgamma, [16..31] dbeta (this lane's 16 channels), without the 1/(1-p) factor
+            float dbias[16];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) stat[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dbias[r] = 0.f;
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                const int it = tc * TS + ts;                     // (compile-time after unrolling)
+                const int64_t s = sbase + ts * 32 + j;
+                const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.H);
+                // operations younger than the DMA of sub-tile `it` that may stay in flight (VMEM retires in issue order):
+                //   it = 0: the DMA of 1;   it = 1: the DMA of 2 and the two dy stores of 0;
+                //   it >= 2: the dy stores of it - 2, the DMA of it + 1, the dy stores of it - 1
+                // (carry_out / partial-sum stores are younger operations too: not counting them only waits a little longer)
+                const int younger_dma = (it + 1 < NSUB) ? nd : 0;
+                wait_vmcnt_n(it == 0 ? younger_dma : (it == 1 ? younger_dma + 2 : younger_dma + 4));
+                asm volatile("" ::: "memory");
+                const unsigned char* buf = ring + (it & 1) * kBufBytes;
+                float xh[16], g[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[r] = acc[tc][ts][r];
+                TileIO<T>::load(reinterpret_cast<const T*>(buf), lane, xh);
+                if (has_carry) {
+                    float ci[16];
+                    TileIO<T>::load(reinterpret_cast<const T*>(buf + 2 * 1024), lane, ci);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) g[r] += ci[r];
+                }
+                const float rstd = *reinterpret_cast<const float*>(buf + 4 * 1024 + lane * 4);
+                const uint32_t keep_bits = *reinterpret_cast<const uint32_t*>(buf + 4 * 1024 + 256 + lane * 4);
+                const uint32_t bits = s < p.S_valid ? keep_bits : 0u;
+                if (it + 2 < NSUB) {                             // this buffer is free once its reads have returned
+                    wait_lgkmcnt0();
+                    asm volatile("" ::: "memory");
+                    dma(it + 2);
+                }
+                if (p.carry_out) TileIO<T>::store(p.carry_out + tb, lane, g);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = tc * 32 + 8 * q + 4 * hi;
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + cl);
+                    const f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * q + r;
+                        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, i, 1);
+                        const float gg = __uint_as_float(__float_as_uint(g[i]) & m);
+                        const float ds = dsilu_f<PRECISE>(g4[r] * xh[i] + e4[r]);
+                        const float da = gg * ds;                  // (the 1/(1-p) factor is applied to gamma and to the sums)
+                        stat[i] += da * xh[i];
+                        stat[16 + i] += da;
+                        g[i] = da * (g4[r] * p.scale);             // dx
+                        s1 += g[i];
+                        s2 += g[i] * xh[i];
+                    }
+                }
+                s1 = sum_xor32(s1);
+                s2 = sum_xor32(s2);
+                const float m1 = s1 * (1.0f / 32.0f), m2 = s2 * (1.0f / 32.0f);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    g[i] = rstd * (g[i] - m1 - xh[i] * m2);   // dy
+                    dbias[i] += g[i];
+                }
+                TileIO<T>::store(p.dy + tb, lane, g);
+                if (pp.dyT) TileT<T>::store((T*)pp.dyT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, g);
+            }
+            butterfly_reduce32(stat, lane);
+            const float db = butterfly_reduce16(dbias, lane);
+            float* row = p.part + (int64_t)wrow * 3 * p.H;
+            const int i = j & 15;                              // register index this lane ended up with
+            const int c = c0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+            row[(j >> 4) * p.H + c] = stat[0] * p.scale;       // j<16: dgamma, j>=16: dbeta
+            if (j < 16) row[2 * p.H + c] = db;
+        }
     }
     template <int TC, int TS, bool RING>
     __device__ static inline void run(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, const float* lpar, int lstride, unsigned char* scr, unsigned char* ring) {

@@ -22,6 +22,18 @@ def is_initialized():
     return dist.is_available() and dist.is_initialized()
 
 
+def _forced():
+    """DPOSER_DIST_FORCE_COLLECTIVES=1: run every collective even in a one-rank group.  A single-GPU box can then drive the
+    real RCCL transport (backend "nccl", world size 1) through exactly the code a multi-GPU job runs -- bucket events, the
+    communication stream, reduce-scatter / all-gather -- instead of the world-size-1 shortcuts (tests/test_gpu_distributed.py)."""
+    return os.environ.get("DPOSER_DIST_FORCE_COLLECTIVES") == "1"
+
+
+def dp_active():
+    """True when collectives have to run: a process group with more than one rank (or a forced one-rank group)."""
+    return is_initialized() and (dist.get_world_size() > 1 or _forced())
+
+
 def world_size():
     return dist.get_world_size() if is_initialized() else 1
 
@@ -36,7 +48,7 @@ def init_from_env(backend=None):
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rk = int(os.environ.get("RANK", "0"))
     lr = int(os.environ.get("LOCAL_RANK", "0"))
-    if ws > 1 and not is_initialized():
+    if (ws > 1 or _forced()) and not is_initialized():
         if backend is None:
             backend = os.environ.get("DPOSER_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -70,10 +82,23 @@ def run_fail_fast(fn, *args, **kwargs):
 
 
 def all_reduce_sum_(flat: torch.Tensor) -> int:
-    """In-place SUM all-reduce of the flat gradient; returns the world size (the caller divides)."""
-    if not is_initialized() or dist.get_world_size() == 1:
+    """In-place SUM all-reduce; returns the world size (the caller divides).  The tensor travels on whatever the backend
+    can move: RCCL ("nccl") only reduces device tensors and gloo test rigs reduce on the host, so a tensor on the other side
+    is staged through a copy (a CPU tensor handed to an NCCL collective raises "No backend type associated with device type
+    cpu" -- that was a crash of every data-parallel Langevin run)."""
+    if not dp_active():
         return 1
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    backend = dist.get_backend()
+    if backend == "nccl" and not flat.is_cuda:
+        dev = flat.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(dev, op=dist.ReduceOp.SUM)
+        flat.copy_(dev)
+    elif backend == "gloo" and flat.is_cuda:
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return dist.get_world_size()
 
 
@@ -86,7 +111,7 @@ def all_reduce_buckets_(flat: torch.Tensor, buckets, wait_bucket=None) -> int:
     waits for the producer's per-bucket event (``wait_bucket(i, raw_stream_handle)``), so bucket i is reduced
     while later buckets are still being computed; the caller's stream is made to wait for all of them before
     returning.  Returns the world size (the caller divides)."""
-    if not is_initialized() or dist.get_world_size() == 1:
+    if not dp_active():
         return 1
     works = []
     if flat.is_cuda:
@@ -111,25 +136,38 @@ def all_reduce_buckets_(flat: torch.Tensor, buckets, wait_bucket=None) -> int:
 
 def zero1_bounds(n: int, num_replicas: int):
     """Contiguous ownership ranges of a flat buffer of n elements for the sharded optimiser step: equal sizes rounded up to a
-    multiple of 4 floats (16-byte aligned shard starts), the last rank takes what is left."""
+    multiple of 4 floats (16-byte aligned shard starts), the last rank takes what is left (it may be shorter: the collectives
+    below run on a staging buffer padded to num_replicas equal shards, so the single-collective path is always taken)."""
     per = -(-n // num_replicas)
     per = (per + 3) // 4 * 4
     return [(min(r * per, n), min((r + 1) * per, n)) for r in range(num_replicas)]
 
 
+def _equal_shards(flat, bounds):
+    """(per, padded) when ``bounds`` are the zero1_bounds of ``flat``: shards of ``per`` elements, the last one possibly short."""
+    per = bounds[0][1] - bounds[0][0]
+    ok = per > 0 and all(lo == r * per or lo == flat.numel() for r, (lo, hi) in enumerate(bounds)) and bounds[-1][1] == flat.numel()
+    return per if ok else 0, per * len(bounds)
+
+
 def reduce_scatter_flat_(flat: torch.Tensor, bounds):
     """SUM-reduce ``flat`` so that rank r ends with the reduced values of its range ``bounds[r]`` (other ranges: unspecified).
-    RCCL: one reduce_scatter over equal chunks when the ranges are equal-sized, else one reduce per range (gloo has no
-    reduce-scatter)."""
-    if not is_initialized() or dist.get_world_size() == 1:
+    RCCL: ONE reduce_scatter over equal chunks -- straight from ``flat`` when the ranges tile it exactly, else from a copy
+    padded with zeros to world x per elements (one extra 33 MB device copy instead of `world` reduce calls); gloo has no
+    reduce-scatter: one reduce per range."""
+    if not dp_active():
         return 1
     ws, rk = dist.get_world_size(), dist.get_rank()
-    sizes = {hi - lo for lo, hi in bounds}
-    if dist.get_backend() == "nccl" and len(sizes) == 1 and bounds[-1][1] == flat.numel():
+    per, padded = _equal_shards(flat, bounds)
+    if dist.get_backend() == "nccl" and per:
         lo, hi = bounds[rk]
-        out = torch.empty(hi - lo, dtype=flat.dtype, device=flat.device)
-        dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.SUM)
-        flat[lo:hi].copy_(out)
+        src = flat
+        if padded != flat.numel():
+            src = torch.zeros(padded, dtype=flat.dtype, device=flat.device)
+            src[:flat.numel()].copy_(flat)
+        out = torch.empty(per, dtype=flat.dtype, device=flat.device)
+        dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM)
+        flat[lo:hi].copy_(out[:hi - lo])
     else:
         works = [dist.reduce(flat[lo:hi], dst=r, op=dist.ReduceOp.SUM, async_op=True) for r, (lo, hi) in enumerate(bounds) if hi > lo]
         for w in works:
@@ -139,13 +177,20 @@ def reduce_scatter_flat_(flat: torch.Tensor, bounds):
 
 def all_gather_flat_(flat: torch.Tensor, bounds):
     """Every rank publishes its range ``bounds[rank]`` of ``flat``; afterwards all ranks hold all ranges."""
-    if not is_initialized() or dist.get_world_size() == 1:
+    if not dp_active():
         return
     rk = dist.get_rank()
-    sizes = {hi - lo for lo, hi in bounds}
-    if dist.get_backend() == "nccl" and len(sizes) == 1 and bounds[-1][1] == flat.numel():
+    per, padded = _equal_shards(flat, bounds)
+    if dist.get_backend() == "nccl" and per:
         lo, hi = bounds[rk]
-        dist.all_gather_into_tensor(flat, flat[lo:hi].clone())
+        mine = torch.zeros(per, dtype=flat.dtype, device=flat.device)
+        mine[:hi - lo].copy_(flat[lo:hi])
+        if padded == flat.numel():
+            dist.all_gather_into_tensor(flat, mine)
+        else:
+            full = torch.empty(padded, dtype=flat.dtype, device=flat.device)
+            dist.all_gather_into_tensor(full, mine)
+            flat.copy_(full[:flat.numel()])
     else:
         works = [dist.broadcast(flat[lo:hi], src=r, async_op=True) for r, (lo, hi) in enumerate(bounds) if hi > lo]
         for w in works:
@@ -154,7 +199,7 @@ def all_gather_flat_(flat: torch.Tensor, bounds):
 
 def broadcast_(flat: torch.Tensor, src=0):
     """Make every rank start from rank ``src``'s parameters."""
-    if is_initialized() and dist.get_world_size() > 1:
+    if dp_active():
         dist.broadcast(flat, src=src)
     return flat
 
@@ -188,12 +233,16 @@ def gather_metrics(all_results, dst=0):
     return {k: float(np.mean(np.array(v))) for k, v in merged.items()}, merged
 
 
-def reduce_metric_means(all_results, device=None):
+def reduce_metric_means(all_results, device=None, names=None):
     """The means of run/completion.py:318-321 without shipping per-sample values: every rank folds its batches into one
     [n_metrics, 2] device tensor of (sum, count) in float64, ONE all-reduce (SUM) combines the ranks, and every rank gets
     ``{name: mean over every sample of every rank}``.  ``all_results``: list (one entry per batch) of {name: per-sample tensor}.
-    Metric names must agree across ranks (they come from the same Evaler)."""
-    names = sorted({k for batch in all_results for k in batch})
+    ``names``: the fixed metric-name list of the evaluation.  Pass it whenever ranks can end up with NO batch (``drop_last``
+    per rank on shards that differ by one element, fewer sequences than ranks): the all-reduced tensor must have the same shape
+    on every rank, and a rank without results cannot learn the names from them (mismatched sizes hang or corrupt RCCL)."""
+    if names is None:
+        names = sorted({k for batch in all_results for k in batch})
+    names = list(names)
     if device is None:
         device = next((v.device for batch in all_results for v in batch.values() if torch.is_tensor(v)), torch.device("cpu"))
     acc = torch.zeros(len(names), 2, dtype=torch.float64, device=device)
@@ -203,13 +252,8 @@ def reduce_metric_means(all_results, device=None):
                 v = torch.as_tensor(batch[k], device=device).reshape(-1).double()
                 acc[i, 0] += v.sum()
                 acc[i, 1] += v.numel()
-    if is_initialized() and dist.get_world_size() > 1:
-        if dist.get_backend() == "gloo" and acc.is_cuda:      # (gloo test rigs reduce on the host)
-            host = acc.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            acc = host
-        else:
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    if dp_active():
+        all_reduce_sum_(acc)
     acc = acc.cpu()
     return {k: float(acc[i, 0] / acc[i, 1]) if acc[i, 1] > 0 else float("nan") for i, k in enumerate(names)}
 

@@ -135,4 +135,5 @@ def evaluate_completion(model, sde, normalizer, body_model, poses, *, part="legs
         gts = normalizer.offline_denormalize(batch, to_axis=True)
         results.append(evaler.multi_eval_bodys(preds, gts, as_tensors=True))
         done += batch_size
-    return ddp.reduce_metric_means(results, device=dev), done
+    # fixed name list: a rank whose shard is shorter than one batch (drop_last) has no results to learn the names from
+    return ddp.reduce_metric_means(results, device=dev, names=("mpjpe_body", "mpvpe_all")), done

@@ -247,5 +247,5 @@ def evaluate_motion_denoising(md, joints3d, gt_poses, *, sequences_per_call=32, 
         s1 = min(s0 + sequences_per_call, hi)
         res = md.optimize_sequences(joints3d[s0:s1], gt_poses[s0:s1], **optimize_kwargs)
         results.append({k: torch.as_tensor(res[k]) for k in ("init_MPJPE", "MPJPE", "MPVPE")})
-    return ddp.reduce_metric_means(results, device=joints3d.device), hi - lo
+    return ddp.reduce_metric_means(results, device=joints3d.device, names=("MPJPE", "MPVPE", "init_MPJPE")), hi - lo
 

@@ -282,3 +282,169 @@ def test_zero1_sharded_step_equals_replicated_step():
     assert np.abs(res[0][2][per:]).max() == 0.0 and np.abs(res[1][2][:per]).max() == 0.0
     mean_losses = [(a + b) / 2 for a, b in zip(res[0][3], res[1][3])]
     assert np.allclose(mean_losses, ref_losses, rtol=2e-5)
+
+
+def test_bench_launches_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no torchrun around it (the shape of the driver's single-GPU command with another N):
+    bench.py must start the two ranks itself, as children of a parent that has not touched the GPU, and rank 0's JSON line must
+    say n_gpus = 2.  (One GPU here: DPOSER_BENCH_ALLOW_SHARED_GPU=1 stacks the ranks on cuda:0 over gloo.)  Without that
+    override and with fewer devices than ranks it must refuse with a non-zero exit code instead of reporting one GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--global-batch", "4096",
+           "--no-extra", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=dict(base, DPOSER_DIST_BACKEND="gloo", DPOSER_BENCH_ALLOW_SHARED_GPU="1"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["per_gpu_batch"] == 2048
+    assert np.isfinite(j["extra"]["train_loss_last_step"])
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, cwd=root, env=base, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+_RCCL_SCRIPT = r'''
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.environ["DPOSER_ROOT"], "tests"))
+sys.path.insert(0, os.environ["DPOSER_ROOT"])
+from gpu_common import make_model
+from dposer_amd import distributed as ddp
+from dposer_amd.algorithms.advanced import losses, sde_lib
+from dposer_amd.algorithms.ema import ExponentialMovingAverage
+
+def run(n_steps, zero1):
+    cfg, m, p = make_model(9, precision="fp32", dropout=0.0)
+    cfg.optim.warmup = 0
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    opt = losses.get_optimizer(cfg, m.parameters())
+    opt.zero1 = zero1
+    ema = ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate)
+    step_fn = losses.get_step_fn(sde, True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+    state = dict(model=m, optimizer=opt, ema=ema, step=0)
+    rs = np.random.RandomState(5)
+    for i in range(n_steps):
+        x = torch.tensor(rs.standard_normal((192, 63)).astype(np.float32)).cuda()
+        t = torch.tensor(rs.uniform(1e-3, 1.0, 192).astype(np.float32)).cuda()
+        z = torch.tensor(rs.standard_normal((192, 63)).astype(np.float32)).cuda()
+        step_fn(state, x, t=t, z=z)
+    torch.cuda.synchronize()
+    sd = opt.state_dict()
+    return m.flat_params().detach().cpu().numpy().copy(), opt._flat_m.detach().cpu().numpy().copy(), sd
+
+assert not ddp.dp_active()
+ref, ref_m, _ = run(3, False)                               # no process group: the plain single-process step
+rk, ws, lr = ddp.init_from_env()                            # WORLD_SIZE=1 + DPOSER_DIST_FORCE_COLLECTIVES=1 -> a one-rank RCCL group
+import torch.distributed as dist
+assert dist.is_initialized() and dist.get_backend() == "nccl" and ddp.dp_active()
+a, a_m, _ = run(3, False)                                   # bucket events -> communication stream -> ncclAllReduce per bucket
+b, b_m, sd = run(3, True)                                   # reduce_scatter_tensor / all_gather_into_tensor (padded: 8277567 % 4 != 0 handled for any world)
+cnt = torch.tensor([5.0], dtype=torch.float64)              # a CPU tensor handed to the helper under RCCL (the Langevin global-batch count)
+ddp.all_reduce_sum_(cnt)
+flat = torch.arange(10, dtype=torch.float32, device="cuda")
+bounds = ddp.zero1_bounds(10, 1)
+ddp.reduce_scatter_flat_(flat, bounds); ddp.all_gather_flat_(flat, bounds)
+print(json.dumps({"bucketed_max": float(np.abs(a - ref).max()), "bucketed_m": float(np.abs(a_m - ref_m).max()),
+                  "zero1_max": float(np.abs(b - ref).max()), "zero1_m": float(np.abs(b_m - ref_m).max()), "cnt": float(cnt[0]),
+                  "flat_ok": bool(torch.equal(flat.cpu(), torch.arange(10, dtype=torch.float32))),
+                  "sd_steps": sorted({int(v["step"]) for v in sd["state"].values()})}))
+dist.destroy_process_group()
+'''
+
+
+def test_single_rank_group_drives_the_real_rccl_transport():
+    """Every other distributed test runs over gloo (two ranks cannot share one GPU under RCCL).  This one forms a ONE-rank
+    process group with backend "nccl" (= RCCL) and DPOSER_DIST_FORCE_COLLECTIVES=1, which disables the world-size-1 shortcuts:
+    the training step then runs its bucketed all-reduce (HIP event per bucket -> communication stream -> ncclAllReduce), the
+    ZeRO-1 variant its reduce-scatter / all-gather, and the helper stages a CPU tensor through the device -- all over the real
+    transport.  With one rank every collective is the identity, so the results must equal the plain single-process run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("DPOSER_DIST_BACKEND", "DPOSER_ZERO1")}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               DPOSER_DIST_FORCE_COLLECTIVES="1", DPOSER_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["bucketed_max"] == 0.0 and j["bucketed_m"] == 0.0            # identity collectives: bit-identical
+    assert j["zero1_max"] < 2e-6 and j["zero1_m"] < 1e-6                  # (separate squared-norm launch: same value, other summation order)
+    assert j["cnt"] == 5.0 and j["flat_ok"] and j["sd_steps"] == [3]
+
+
+def _worker_zero1_ckpt(rank, world, port, q, model_seed, batch, t, z):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      DPOSER_DIST_BACKEND="gloo", DPOSER_ZERO1="1")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from gpu_common import make_model
+    from dposer_amd import distributed as ddp
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    import torch.distributed as dist
+    ddp.init_from_env()
+    torch.cuda.set_device(0)
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+
+    def fresh():
+        cfg, m, p = make_model(model_seed, precision="fp32", dropout=0.0)
+        cfg.optim.warmup = 0
+        opt = losses.get_optimizer(cfg, m.parameters())
+        ema = ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate)
+        return cfg, dict(model=m, optimizer=opt, ema=ema, step=0)
+
+    cfg, state = fresh()
+    step_fn = losses.get_step_fn(sde, True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+    lo, hi = ddp.shard_bounds(batch.shape[1], world, rank)
+
+    def go(st, i):
+        step_fn(st, batch[i, lo:hi].cuda(), t=t[i, lo:hi].cuda(), z=z[i, lo:hi].cuda())
+
+    for i in range(2):
+        go(state, i)
+    ck = {"model": {k: v.clone() for k, v in state["model"].state_dict().items()}, "opt": state["optimizer"].state_dict(),
+          "ema": state["ema"].state_dict(), "step": state["step"]}                     # state_dict() gathers the sharded moments (collective)
+    mom_full = state["optimizer"]._flat_m.detach().cpu().numpy().copy()
+    go(state, 2)                                                                       # continue the original run
+    cfg2, st2 = fresh()                                                                # ... and a restored one
+    st2["model"].load_state_dict(ck["model"])
+    st2["optimizer"].load_state_dict(ck["opt"])
+    st2["ema"].load_state_dict(ck["ema"])
+    st2["step"] = ck["step"]
+    go(st2, 2)
+    torch.cuda.synchronize()
+    q.put((rank, state["model"].flat_params().detach().cpu().numpy(), st2["model"].flat_params().detach().cpu().numpy(), mom_full))
+    ddp.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero1_checkpoint_gathers_the_moments_and_resumes():
+    """A ZeRO-1 run keeps each Adam moment on the rank that owns its range.  ``optimizer.state_dict()`` must gather them (it is a
+    collective there), so that a checkpoint taken mid-run restores into a run that continues exactly like the original one."""
+    rs = np.random.RandomState(5)
+    B = 256
+    batch = torch.tensor(rs.standard_normal((3, B, 63)).astype(np.float32))
+    t = torch.tensor(rs.uniform(1e-3, 1.0, (3, B)).astype(np.float32))
+    z = torch.tensor(rs.standard_normal((3, B, 63)).astype(np.float32))
+    ref, ref_mom, _ = _steps(9, batch[:2], t[:2], z[:2], 2, 1, 0, "fp32")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_zero1_ckpt, args=(r, 2, port, q, 9, batch, t, z)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, cont, resumed, mom in res:
+        assert np.array_equal(cont, resumed)                                           # restored run == uninterrupted run, bit for bit
+        assert np.linalg.norm(mom - ref_mom.numpy()) / np.linalg.norm(ref_mom.numpy()) < 1e-4   # gathered moments = replicated moments
+    assert np.array_equal(res[0][1], res[1][1])

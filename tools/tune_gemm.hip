@@ -163,6 +163,19 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&part, (size_t)(S / 32) * 3 * C * 4)); CK(hipMalloc(&cin, (size_t)S * C * 2)); CK(hipMalloc(&cout, (size_t)S * C * 2));
     CK(hipMemset(rstd, 0x3f, (size_t)(S / 32) * (C / 32) * 64 * sizeof(GnAux))); CK(hipMemset(xhat, 0, (size_t)S * C * 2)); CK(hipMemset(cin, 0, (size_t)S * C * 2));
 #define GB(WC, WS, TC, TS, KB, G, DROP, DYT, CI, CO) add_gnbwd<WC, WS, TC, TS, KB, G>(#WC "," #WS "," #TC "," #TS, S, C, K, W, X, o1, xhat, rstd, gamma, beta, part, DYT ? outT : nullptr, CI ? cin : nullptr, CO ? cout : nullptr, DROP ? 0.1f : 0.f)
+    if (getenv("TUNE_R3")) {         // round 3: training epilogues (dropout draw, residual / record prefetch by asm-issued DMA); run old and new builds
+        g_drop_p = 0.1f;
+        PL(2, 4, 4, 2, 2, 4);
+        GNT(2, 4, 4, 2, 2, 4); g_cases.back().name += " +dropout";
+        g_resid = cin;
+        GNT(2, 4, 4, 2, 2, 4); g_cases.back().name += " +dropout +resid";
+        g_resid = nullptr;
+        GB(2, 4, 4, 2, 2, 4, 1, 0, 0, 0);
+        GB(2, 4, 4, 2, 2, 4, 1, 0, 1, 0);
+        GB(2, 4, 4, 2, 2, 4, 1, 0, 1, 1);
+        run_all(7, 10);
+        return 0;
+    }
     if (getenv("TUNE_PIPE")) {
         // correctness: pipelined vs reference kernel, bit for bit
         {
