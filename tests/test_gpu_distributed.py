@@ -312,6 +312,7 @@ def test_bench_launches_its_own_ranks_without_a_launcher():
 _RCCL_SCRIPT = r'''
 import os, sys, json
 import numpy as np, torch
+sys.path.insert(0, os.path.join(os.environ["DPOSER_ROOT"], "tests", "golden"))
 sys.path.insert(0, os.path.join(os.environ["DPOSER_ROOT"], "tests"))
 sys.path.insert(0, os.environ["DPOSER_ROOT"])
 from gpu_common import make_model
@@ -409,8 +410,11 @@ def _worker_zero1_ckpt(rank, world, port, q, model_seed, batch, t, z):
 
     for i in range(2):
         go(state, i)
-    ck = {"model": {k: v.clone() for k, v in state["model"].state_dict().items()}, "opt": state["optimizer"].state_dict(),
-          "ema": state["ema"].state_dict(), "step": state["step"]}                     # state_dict() gathers the sharded moments (collective)
+    import copy
+    # state_dict() gathers the sharded moments (a collective); deepcopy = what torch.save would have written at this point
+    # (state dicts hold references to the live buffers, which the next step overwrites)
+    ck = copy.deepcopy({"model": state["model"].state_dict(), "opt": state["optimizer"].state_dict(), "ema": state["ema"].state_dict(),
+                        "step": state["step"]})
     mom_full = state["optimizer"]._flat_m.detach().cpu().numpy().copy()
     go(state, 2)                                                                       # continue the original run
     cfg2, st2 = fresh()                                                                # ... and a restored one

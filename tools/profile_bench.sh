@@ -12,10 +12,17 @@ grep '^{' $R/gpurun_out/${TAG}_bench_default.log | tail -1 > $R/gpurun_out/${TAG
 SHORT="--steps 3 --warmup 1 --no-cpu-baseline --sampler-steps 20"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${TAG}_rd -o rd -- python3 $R/bench.py $SHORT > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${TAG}_wr -o wr -- python3 $R/bench.py $SHORT > /dev/null 2>&1
+# 4. matrix-pipe evidence: MFMA busy cycles, effective clock (GRBM_GUI_ACTIVE / duration), issue stalls -- two SQ passes + GRBM
+rm -rf $R/gpurun_out/pmc_${TAG}_m1 $R/gpurun_out/pmc_${TAG}_m2
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_${TAG}_m1 -o m1 -- python3 $R/bench.py $SHORT > $R/gpurun_out/${TAG}_pmc_m1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_${TAG}_m2 -o m2 -- python3 $R/bench.py $SHORT > $R/gpurun_out/${TAG}_pmc_m2.log 2>&1
 cd $R
+python3 tools/rocpd_summary.py --mfma $(find gpurun_out/pmc_${TAG}_m1 gpurun_out/pmc_${TAG}_m2 -name "*.db") > gpurun_out/${TAG}_pmc_mfma.md
+python3 tools/rocpd_summary.py --mfma-json $(find gpurun_out/pmc_${TAG}_m1 gpurun_out/pmc_${TAG}_m2 -name "*.db") > gpurun_out/${TAG}_pmc_mfma.json
+rm -rf gpurun_out/pmc_${TAG}_m1 gpurun_out/pmc_${TAG}_m2
 python3 tools/rocpd_summary.py $(find gpurun_out/prof_$TAG -name "*.db" | head -1) > gpurun_out/${TAG}_bench_kernel_stats.md
 python3 tools/rocpd_summary.py --pmc $(find gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr -name "*.db") > gpurun_out/${TAG}_pmc_hbm_traffic.md
 python3 tools/rocpd_summary.py --pmc-json $(find gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr -name "*.db") > gpurun_out/${TAG}_pmc_hbm_traffic.json
 # the raw rocpd databases can exceed what gpurun copies back (64 MiB): keep the summaries only
 rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr
-head -30 gpurun_out/${TAG}_bench_kernel_stats.md; head -24 gpurun_out/${TAG}_pmc_hbm_traffic.md; cat gpurun_out/${TAG}_bench_default.json
+head -30 gpurun_out/${TAG}_bench_kernel_stats.md; head -30 gpurun_out/${TAG}_pmc_mfma.md; head -24 gpurun_out/${TAG}_pmc_hbm_traffic.md; cat gpurun_out/${TAG}_bench_default.json

@@ -150,6 +150,58 @@ def counters(paths):
         print(f"| `{k}` | {n} | " + " | ".join(f"{v[c][1]:.4g}" if c in v else "" for c in names) + " |")
 
 
+def mfma(paths, as_json=False):
+    """Matrix-pipe evidence per kernel from the SQ / GRBM passes of tools/profile_bench.sh (each pass also carries a kernel trace):
+       effective clock  = GRBM_GUI_ACTIVE / 8 / kernel duration      (MI355X_MICROARCH.md, DVFS give-back; the counter is the SUM
+                          over the 8 XCDs' GRBMs: a 2.4 ms fp32-MFMA kernel reads 19.0 "GHz" = 8 x 2.38.  It also counts the
+                          dispatch ramp around a kernel: below ~50 us the quotient overshoots -- read it for the long GEMMs only)
+       MFMA busy        = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)   (the counter adds 32 cycles per
+                          v_mfma_f32_32x32x16_bf16 on the SIMD that issued it; 256 CUs x 4 SIMDs; cross-check: 32 x SQ_INSTS_MFMA)
+       issue stall      = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES,  parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES  (quad-cycles both)."""
+    import json
+    agg, dur = {}, {}
+    for path in paths:
+        cur = sqlite3.connect(path).cursor()
+        for name, counter, n, avg in cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                                 "group by kernel_name, counter_name"):
+            agg.setdefault(short(name), {})[counter] = (n, avg)
+        cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+        for name, n, avg in cur.execute(f"select {name_col}, count(*), avg(end-start) from kernels group by {name_col}"):
+            d = dur.setdefault(short(name), [0, 0.0])
+            d[0] += n
+            d[1] += n * avg
+    rows = []
+    for k, v in agg.items():
+        g = v.get("GRBM_GUI_ACTIVE", (0, 0.0))[1]
+        if g <= 0 or k not in dur:
+            continue
+        us = dur[k][1] / dur[k][0] / 1e3
+        busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0.0))[1]
+        wc = v.get("SQ_WAVE_CYCLES", (0, 0.0))[1]
+        rows.append({"kernel": k, "launches": dur[k][0], "avg_us": us, "grbm_gui_active": g, "clock_ghz": g / 8.0 / us / 1e3,
+                     "mfma_busy_cycles": busy, "mfma_busy_frac": busy / (g / 8.0 * 1024.0), "insts_mfma": v.get("SQ_INSTS_MFMA", (0, 0.0))[1],
+                     "insts_valu": v.get("SQ_INSTS_VALU", (0, 0.0))[1],
+                     "issue_stall_frac": (v.get("SQ_WAIT_INST_ANY", (0, 0.0))[1] / wc) if wc else None,
+                     "parked_frac": (v.get("SQ_WAIT_ANY", (0, 0.0))[1] / wc) if wc else None,
+                     "active_frac": (v.get("SQ_ACTIVE_INST_ANY", (0, 0.0))[1] / wc) if wc else None})
+    rows.sort(key=lambda r: -r["avg_us"] * r["launches"])
+    if as_json:
+        print(json.dumps({r["kernel"]: r for r in rows}, indent=1, sort_keys=True))
+        return
+    print("# Matrix-pipe counters per kernel (rocprofv3 --kernel-trace --pmc, separate SQ / GRBM passes; durations under the profiler)\n")
+    print(mfma.__doc__.strip() + "\n")
+    print("| kernel | launches | avg us | clock GHz | MFMA busy | SQ_INSTS_MFMA | SQ_INSTS_VALU | issue-stall | parked | active |")
+    print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+    f = lambda x: "" if x is None else f"{x:.3f}"
+    for r in rows[:24]:
+        print(f"| `{r['kernel']}` | {r['launches']} | {r['avg_us']:.1f} | {r['clock_ghz']:.2f} | {r['mfma_busy_frac']:.3f} | {r['insts_mfma']:.4g} | "
+              f"{r['insts_valu']:.4g} | {f(r['issue_stall_frac'])} | {f(r['parked_frac'])} | {f(r['active_frac'])} |")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] in ("--mfma", "--mfma-json"):
+    mfma(sys.argv[2:], as_json=sys.argv[1] == "--mfma-json")
+    sys.exit(0)
 if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--sequence":
     if len(sys.argv) > 3:      # --sequence db anchor [which]: e.g. EpiEmStep 500 -> one sampler step
         sequence(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 3, f"from one `{sys.argv[3]}` to the next")
