@@ -122,6 +122,8 @@ SIGNATURES = {
     "dposer_lbs_posedirs_bwd_packed_bytes": (i64, [vp]),
     "dposer_lbs_pack_posedirs_bwd": (C.c_int, [vp, vp, vp, vp]),
     "dposer_lbs_backward_workspace_bytes": (i64, [vp, i64]),
+    "dposer_lbs_prepare_joint_lists": (C.c_int, [vp, vp, vp, vp, vp]),
+    "dposer_body_tuning_reload": (None, []),
     "dposer_lbs_backward": (C.c_int, [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp,
                                       vp, vp, i64, C.POINTER(vp), vp, vp, i64, vp]),
 }

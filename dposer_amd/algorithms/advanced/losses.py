@@ -265,24 +265,52 @@ def optimization_manager(config):
 def get_sde_loss_fn(sde, train, reduce_mean=False, continuous=True, likelihood_weighting=False, eps=1e-5,
                     return_data=False, denoise_steps=5):
     """Denoising score-matching loss for an arbitrary SDE (losses.py:61-137), composed from the
-    differentiable HIP forward and torch elementwise ops (generic path)."""
-    if return_data:
-        raise NotImplementedError("auxiliary_loss / return_data (losses.py:91-119) is off in the shipped config and not built")
+    differentiable HIP forward and torch elementwise ops (generic path).
+
+    ``return_data=True`` (the auxiliary-loss training of losses.py:91-119): the perturbed batch is denoised in ``denoise_steps``
+    deterministic steps from t to t / (2 denoise_steps) -- every step one differentiable network evaluation whose activations
+    stay leased until the backward pass -- and the loss function returns ``(loss, {'clean_sample', 'SNR', 't'})``; the score of
+    the FIRST step carries the DSM term.  Keyword-only ``t=`` / ``z=`` inject the draws of losses.py:110-111 (tests)."""
     reduce_op = torch.mean if reduce_mean else (lambda *a, **k: 0.5 * torch.sum(*a, **k))
 
-    def loss_fn(model, batch, condition, mask):
+    def loss_fn(model, batch, condition, mask, *, t=None, z=None):
         score_fn = mutils.get_score_fn(sde, model, train=train, continuous=continuous)
-        t = torch.rand(batch.shape[0], device=batch.device) * (sde.T - eps) + eps
-        z = torch.randn_like(batch)
+
+        def multi_step_denoise(x_t, t0, t_end, N):                                  # losses.py:91-106
+            from ...utils.misc import linear_interpolation
+            time_traj = linear_interpolation(t0, t_end, N + 1)
+            x_current, score_return = x_t, None
+            for i in range(N):
+                alpha_c, sigma_c = sde.return_alpha_sigma(time_traj[i])
+                alpha_b, sigma_b = sde.return_alpha_sigma(time_traj[i + 1])
+                score = score_fn(x_current, time_traj[i], condition, mask)
+                if i == 0:
+                    score_return = score
+                noise = -score * sigma_c[:, None]                                   # score -> noise prediction
+                x_current = alpha_b / alpha_c * (x_current - sigma_c[:, None] * noise) + sigma_b[:, None] * noise
+            return score_return, x_current
+
+        if t is None:
+            t = torch.rand(batch.shape[0], device=batch.device) * (sde.T - eps) + eps
+        if z is None:
+            z = torch.randn_like(batch)
         mean, std = sde.marginal_prob(batch, t)
         perturbed = mean + std[:, None] * z
-        score = score_fn(perturbed, t, condition, mask)
+        if return_data:
+            alpha, sigma = sde.return_alpha_sigma(t)
+            SNR = alpha / sigma[:, None]
+            score, estimated = multi_step_denoise(perturbed, t, t / (2 * denoise_steps), denoise_steps)
+        else:
+            score = score_fn(perturbed, t, condition, mask)
         if not likelihood_weighting:
             losses = reduce_op(torch.square(score * std[:, None] + z).reshape(batch.shape[0], -1), dim=-1)
         else:
             g2 = sde.sde(torch.zeros_like(batch), t)[1] ** 2
             losses = reduce_op(torch.square(score + z / std[:, None]).reshape(batch.shape[0], -1), dim=-1) * g2
-        return torch.mean(losses)
+        loss = torch.mean(losses)
+        if return_data:
+            return loss, {"clean_sample": estimated, "SNR": SNR, "t": t}
+        return loss
 
     return loss_fn
 
@@ -360,6 +388,23 @@ def _live_params(model):
     return cache[1]
 
 
+def _rot6d_to_axis_angle_autograd(rot6d):
+    """Differentiable 6D -> axis-angle for the auxiliary loss with rot_rep='rot6d' (losses.py:247-249; the reference goes through
+    torchgeometry: matrix -> quaternion -> angle-axis).  Plain torch ops on the device: the HIP conversion kernel
+    (utils.transforms.rot6d_to_axis_angle) has no backward, and this path is neither the shipped configuration nor hot."""
+    a = rot6d.reshape(-1, 3, 2)
+    b1 = torch.nn.functional.normalize(a[:, :, 0], dim=1)
+    b2 = torch.nn.functional.normalize(a[:, :, 1] - (b1 * a[:, :, 1]).sum(dim=1, keepdim=True) * b1, dim=1)
+    b3 = torch.cross(b1, b2, dim=1)
+    R = torch.stack([b1, b2, b3], dim=-1)
+    # log map through the rotation angle and the skew part; the small-angle branch avoids 0/0
+    cos = ((R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]) - 1.0) * 0.5
+    angle = torch.acos(torch.clamp(cos, -1.0 + 1e-7, 1.0 - 1e-7))
+    skew = torch.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], dim=1)
+    scale = torch.where(angle < 1e-4, 0.5 + angle * angle / 12.0, angle / (2.0 * torch.sin(angle).clamp_min(1e-12)))
+    return skew * scale[:, None]
+
+
 def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True, likelihood_weighting=False,
                 auxiliary_loss=False, denormalize=None, body_model=None, rot_rep="rot6d", denoise_steps=5):
     """One-step training / evaluation function (losses.py:187-275).
@@ -367,10 +412,9 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
     ``step_fn(state, batch, condition=None, mask=None)`` with ``state = {model, optimizer, ema, step}``
     returns ``{'step_loss', 'score_loss'}`` exactly like the reference.  Extra keyword-only knobs for
     tests: ``t=``/``z=`` inject the random draws of losses.py:110-111."""
-    if auxiliary_loss:
-        raise NotImplementedError("auxiliary_loss (losses.py:242-258) is off in the shipped config and not built")
     if continuous:
-        loss_fn = get_sde_loss_fn(sde, train, reduce_mean=reduce_mean, continuous=True, likelihood_weighting=likelihood_weighting)
+        loss_fn = get_sde_loss_fn(sde, train, reduce_mean=reduce_mean, continuous=True, likelihood_weighting=likelihood_weighting,
+                                  return_data=auxiliary_loss, denoise_steps=denoise_steps)
     else:
         assert not likelihood_weighting, "Likelihood weighting is not supported for original SMLD/DDPM training."
         if isinstance(sde, VESDE):
@@ -380,14 +424,45 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
         else:
             raise ValueError(f"Discrete training for {sde.__class__.__name__} is not recommended.")
 
+    if auxiliary_loss:
+        assert denormalize is not None and body_model is not None                     # losses.py:213-214
+
+    def aux_step(state, batch, condition, mask, t, z):
+        """losses.py:242-258: DSM term + SNR-weighted vertex / joint errors between the body posed by the multi-step estimate
+        and by the batch.  Score network and body model both run their HIP forward / backward through autograd: this is the one
+        training step where the two meet (the reference calls the body model 'the bottleneck of training', :252)."""
+        model, optimizer = state["model"], state["optimizer"]
+        optimizer.zero_grad()
+        score_loss, data = loss_fn(model, batch, condition, mask, t=t, z=z)
+        weight = torch.log(1.0 + data["SNR"])                                          # [b, 1]
+        estimate, target = denormalize(data["clean_sample"]), denormalize(batch)
+        if rot_rep == "rot6d":
+            n_poses = batch.shape[1] // 6
+            estimate = _rot6d_to_axis_angle_autograd(estimate.reshape(-1, 6)).reshape(-1, n_poses * 3)
+            target = _rot6d_to_axis_angle_autograd(target.reshape(-1, 6)).reshape(-1, n_poses * 3)
+        gt_body = body_model(pose_body=target)
+        pred_body = body_model(pose_body=estimate)
+        loss_v2v = torch.mean(weight * torch.square(gt_body.v - pred_body.v).sum(dim=-1))
+        loss_j2j = torch.mean(weight * torch.square(gt_body.Jtr - pred_body.Jtr).sum(dim=-1))
+        loss = score_loss + loss_v2v + loss_j2j
+        loss.backward()
+        optimize_fn(optimizer, model.parameters(), step=state["step"])
+        state["step"] += 1
+        state["ema"].update(model.parameters())
+        return {"step_loss": loss, "score_loss": score_loss, "v2v_loss": loss_v2v, "j2j_loss": loss_j2j}
+
     def step_fn(state, batch, condition=None, mask=None, *, t=None, z=None):
         model = state["model"]
+        if train and auxiliary_loss:
+            return aux_step(state, batch, condition, mask, t, z)
         if not train:
             with torch.no_grad():                                                  # losses.py:264-271
                 ema = state["ema"]
                 ema.store(model.parameters())
                 ema.copy_to(model.parameters())
                 loss = loss_fn(model, batch, condition, mask)
+                if isinstance(loss, tuple):                                        # (auxiliary-loss loss_fn: the reference's eval step
+                    loss = loss[0]                                                 #  would put the tuple into the dict, :264-271)
                 ema.restore(model.parameters())
             return {"step_loss": loss, "score_loss": loss}
         optimizer = state["optimizer"]

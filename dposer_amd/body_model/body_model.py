@@ -232,6 +232,11 @@ class _SMPLCore(nn.Module):
             dev = self.skin_idx.device
             self._jcsr = (torch.tensor(ptr, device=dev), torch.tensor(v[order].astype(np.int32), device=dev),
                           torch.tensor(ww[order].astype(np.float32), device=dev))
+            if dev.type == "cuda":
+                # setup call (synchronises, allocates): the re-cut table the streaming joint-gradient kernel of dposer_lbs_backward
+                # walks lives in the handle; built here, once per (lists, device), never inside the backward call
+                _C.check(_C.lib().dposer_lbs_prepare_joint_lists(self._handle(), _C.ptr(self._jcsr[0]), _C.ptr(self._jcsr[1]),
+                                                                 _C.ptr(self._jcsr[2]), _C.stream_ptr()), "dposer_lbs_prepare_joint_lists")
         return self._jcsr
 
     def joint_fold(self):

@@ -592,10 +592,27 @@ template <typename Kin> struct KinTable {          // the parents table where de
 };
 template <typename Kin> __device__ constexpr KinTable<Kin> kKinTable{};
 
-static int64_t fk_small_max() {      // (read at every call: the tests switch between the two kernel families in one process)
-    const char* e = getenv("DPOSER_FK_SMALL_MAX");
-    return e ? atoll(e) : (int64_t)8192;
+// A/B switches of the body-model kernels: read from the environment ONCE (first use), not per call; tests and tuners that change
+// them inside one process call dposer_body_tuning_reload() afterwards.
+struct BodyTuning {
+    int64_t fk_small_max = 8192;          // DPOSER_FK_SMALL_MAX: up to this many poses FK runs one wave per pose / one lane per joint
+    int64_t joint_stream_min = 1536;      // DPOSER_LBS_JOINT_STREAM_MIN: from this batch the streaming joint-gradient kernel is used
+    bool blend_fp32 = false;              // DPOSER_LBS_BLEND=fp32: exact-fp32 pose-blend chain
+    void load() {
+        const char* e = getenv("DPOSER_FK_SMALL_MAX");
+        fk_small_max = e ? atoll(e) : (int64_t)8192;
+        e = getenv("DPOSER_LBS_JOINT_STREAM_MIN");
+        joint_stream_min = e ? atoll(e) : (int64_t)1536;
+        e = getenv("DPOSER_LBS_BLEND");
+        blend_fp32 = e && e[0] == 'f';
+    }
+};
+static BodyTuning& body_tuning() {
+    static BodyTuning t = [] { BodyTuning x; x.load(); return x; }();
+    return t;
 }
+extern "C" void dposer_body_tuning_reload(void) { body_tuning().load(); }
+static int64_t fk_small_max() { return body_tuning().fk_small_max; }
 
 template <typename Kin> __global__ void __launch_bounds__(64) k_fk_small(FkArgs a) {
     constexpr int J = Kin::J;
@@ -686,9 +703,10 @@ struct dposer_body_s {
     dposer_body_desc d;
     int kind;   // 0 SMPL, 1 SMPL-H, 2 SMPL-X
     int parents[64];
-    // k_skin_bwd_joints' table: the caller's CSR-by-joint skinning lists re-cut into vertex chunks (built on first use, rebuilt when
-    // other lists are passed; freed by dposer_body_destroy)
-    const void* jl_key[3] = {nullptr, nullptr, nullptr};
+    // k_skin_bwd_joints' table: the caller's CSR-by-joint skinning lists re-cut into vertex chunks by the explicit setup call
+    // dposer_lbs_prepare_joint_lists (freed by dposer_body_destroy).  (Round 2 built it inside dposer_lbs_backward, keyed by the
+    // lists' device ADDRESSES: a caller that re-uploaded other lists to a recycled address got the stale table.)
+    bool jl_ready = false;
     int jl_chunks = 0;
     int32_t* jl_vstart = nullptr;    // device [chunks + 1] first vertex of each chunk
     int32_t* jl_ptr = nullptr;       // device [chunks][J + 1] entry ranges, relative to the chunk's first entry
@@ -866,10 +884,7 @@ __global__ void __launch_bounds__(256) k_extra_joints(ExtraArgs a) {
 // kernel's K segments), three split-K launches into one slab set (backward).  The dropped lo*lo term and the split residuals
 // are <= 2^-16 of each product: the offsets (centimetres) move by < 1e-6 m, vertices agree with the fp64 oracle to ~1e-6
 // (tests/test_gpu_fk.py; the bar is 1e-5).  DPOSER_LBS_BLEND=fp32 selects the exact-fp32 chain (both packings are kept).
-static bool lbs_blend_fp32() {
-    const char* e = getenv("DPOSER_LBS_BLEND");
-    return e && e[0] == 'f';
-}
+static bool lbs_blend_fp32() { return body_tuning().blend_fp32; }
 // FT32 [Bpad][K] -> FT bf16 [Bpad][3K] = [hi | hi | lo]
 __global__ void __launch_bounds__(256) k_split_pf(const float* __restrict__ pf, __bf16* __restrict__ out, int64_t Bpad, int K) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 8-element chunk of the bf16 layout
@@ -1238,14 +1253,16 @@ __global__ void __launch_bounds__(128) k_skin_bwd_joints_gather(JointGatherArgs 
     }
     if (threadIdx.x < 12) a.dA[(b * a.J + j) * 12 + threadIdx.x] = red[0][threadIdx.x];
 }
-static int64_t lbs_joint_stream_min() {      // batch size from which the streaming joint-gradient kernel is used (A/B: env)
-    const char* e = getenv("DPOSER_LBS_JOINT_STREAM_MIN");
-    return e ? atoll(e) : (int64_t)1536;
-}
-// (host) cut the CSR-by-joint lists (vertex ids ascending inside a joint) into chunks of <= JL_MAXV vertices and <= JL_MAXE entries
-static int build_joint_chunks(dposer_body_s* h, const int32_t* jptr_dev, const int32_t* jvidx_dev, const float* jw_dev, hipStream_t st) {
+static int64_t lbs_joint_stream_min() { return body_tuning().joint_stream_min; }
+// dposer_lbs_prepare_joint_lists: (host) cut the CSR-by-joint lists (vertex ids ascending inside a joint) into chunks of
+// <= JL_MAXV vertices and <= JL_MAXE entries, sorted by joint inside a chunk -- the table the streaming joint-gradient kernel
+// walks.  A SETUP call: it synchronises the stream, copies the lists to the host and (re)allocates the handle's tables.
+// dposer_lbs_backward itself never synchronises or allocates: without prepared lists it runs the gather kernel.
+extern "C" int dposer_lbs_prepare_joint_lists(dposer_body_t h, const int32_t* jptr_dev, const int32_t* jvidx_dev, const float* jw_dev, void* stream) {
+    DP_CHECK_ARG(h && jptr_dev && jvidx_dev && jw_dev, "null argument");
+    hipStream_t st = (hipStream_t)stream;
     const int J = h->d.num_joints, V = h->d.num_vertices;
-    if (h->jl_key[0] == jptr_dev && h->jl_key[1] == jvidx_dev && h->jl_key[2] == jw_dev && h->jl_entry) return DPOSER_OK;
+    h->jl_ready = false;
     DP_CHECK_HIP(hipStreamSynchronize(st));
     std::vector<int32_t> jptr(J + 1);
     DP_CHECK_HIP(hipMemcpy(jptr.data(), jptr_dev, (J + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1304,7 +1321,7 @@ static int build_joint_chunks(dposer_body_s* h, const int32_t* jptr_dev, const i
     DP_CHECK_HIP(hipMemcpy(h->jl_first, cfirst.data(), cfirst.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     DP_CHECK_HIP(hipMemcpy(h->jl_entry, entry.data(), entry.size() * sizeof(float2), hipMemcpyHostToDevice));
     h->jl_chunks = chunks;
-    h->jl_key[0] = jptr_dev; h->jl_key[1] = jvidx_dev; h->jl_key[2] = jw_dev;
+    h->jl_ready = true;
     return DPOSER_OK;
 }
 
@@ -1692,8 +1709,7 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         FK_HIP_LAUNCH(hipGetLastError());
     }
     {
-        if (batch >= lbs_joint_stream_min()) {
-            DP_TRY(build_joint_chunks(h, joint_ptr, joint_vidx, joint_w, st));      // (first call for these lists only)
+        if (batch >= lbs_joint_stream_min() && h->jl_ready) {
             JointBwdArgs a;
             a.dverts = d_verts; a.vp = vp; a.vstart = h->jl_vstart; a.cptr = h->jl_ptr; a.cfirst = h->jl_first; a.entry = h->jl_entry; a.dA = dA;
             a.J = J; a.V = V; a.chunks = h->jl_chunks; a.B = batch;

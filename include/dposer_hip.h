@@ -317,9 +317,15 @@ int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedirs_packed, c
  *   landmarks are vertex gathers and must be folded into d_verts by the caller);
  *   d_pose_segments_host[i]: DEVICE pointer [B, seg_joints*3] out or NULL;  d_jrest [B,J,3] out or NULL;
  *   d_vposed [B,V,3] out or NULL (= gradient w.r.t. v_shaped).
- *   The handle caches a re-cut copy of the joint lists (by vertex chunk, for the joint-gradient kernel), keyed by the three DEVICE
- *   ADDRESSES: it is built -- with a stream synchronisation, a device-to-host copy and allocations -- on the first call that sees
- *   them, and again whenever other addresses are passed; lists whose contents change must therefore live in new buffers. */
+ *   dposer_lbs_prepare_joint_lists(h, joint_ptr, joint_vidx, joint_w, stream): SETUP call, once per set of lists (and again
+ *   whenever their contents change): re-cuts the lists by vertex chunk for the streaming joint-gradient kernel and stores the
+ *   table in the handle.  It synchronises the stream, copies the lists to the host and allocates -- dposer_lbs_backward itself
+ *   does none of that (capturable in a hipGraph); without prepared lists it runs the (pose, joint)-parallel gather kernel, which
+ *   is the right kernel below ~1536 poses anyway.
+ *   dposer_body_tuning_reload(): re-reads the A/B environment switches of the body-model kernels (DPOSER_FK_SMALL_MAX,
+ *   DPOSER_LBS_JOINT_STREAM_MIN, DPOSER_LBS_BLEND); they are otherwise read once per process, not per call. */
+int dposer_lbs_prepare_joint_lists(dposer_body_t h, const int32_t* joint_ptr, const int32_t* joint_vidx, const float* joint_w, void* stream);
+void dposer_body_tuning_reload(void);
 int64_t dposer_lbs_posedirs_bwd_packed_bytes(dposer_body_t h);
 int dposer_lbs_pack_posedirs_bwd(dposer_body_t h, const float* posedirs, void* packed, void* stream);
 int64_t dposer_lbs_backward_workspace_bytes(dposer_body_t h, int64_t batch);

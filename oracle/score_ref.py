@@ -207,6 +207,44 @@ def dsm_loss(p: Params, sde, batch, t, z, *, reduce_mean=True, likelihood_weight
     return losses.mean()                                                    # :131
 
 
+def multi_step_denoise(p: Params, sde, x_t, t, t_end, N, **fw):
+    """losses.py:91-106: N deterministic DDIM-style steps from t towards t_end on a linear time grid
+    (lib/utils/misc.py:58-61 linear_interpolation); returns (score at the FIRST step, estimated clean sample)."""
+    alpha_w = torch.linspace(0, 1, N + 1)[:, None]
+    traj = (1 - alpha_w) * t + alpha_w * t_end                               # [N + 1, B]
+    x = x_t
+    score_first = None
+    for i in range(N):
+        a_c, s_c = sde.alpha_sigma(traj[i])                                  # alpha [B, 1], sigma [B]
+        a_b, s_b = sde.alpha_sigma(traj[i + 1])
+        score = score_fn(p, sde, x, traj[i], **fw)
+        if i == 0:
+            score_first = score
+        noise = -score * s_c[:, None]                                        # :102 score -> noise prediction
+        x = a_b / a_c * (x - s_c[:, None] * noise) + s_b[:, None] * noise    # :103
+    return score_first, x
+
+
+def aux_loss(p: Params, sde, batch, t, z, *, denormalize, body_model, denoise_steps=5, reduce_mean=True, **fw):
+    """losses.py:108-119 (return_data=True) + :242-258 (auxiliary_loss=True, rot_rep='axis'): DSM loss on the score of the first
+    denoising step, plus SNR-weighted vertex / joint errors of the body posed by the multi-step estimate against the batch's.
+    ``body_model(pose)`` -> (vertices [B, V, 3], joints [B, J, 3]).  Returns (total, dict of the four terms)."""
+    mean, std = sde.marginal_prob(batch, t)
+    x_t = mean + std[:, None] * z
+    alpha, sigma = sde.alpha_sigma(t)
+    snr = alpha / sigma[:, None]                                             # [B, 1]
+    score, est = multi_step_denoise(p, sde, x_t, t, t / (2 * denoise_steps), denoise_steps, **fw)
+    red = (lambda a: a.mean(dim=-1)) if reduce_mean else (lambda a: 0.5 * a.sum(dim=-1))
+    score_loss = red(torch.square(score * std[:, None] + z)).mean()
+    weight = torch.log(1.0 + snr)                                            # :244
+    v_gt, j_gt = body_model(denormalize(batch))
+    v_pr, j_pr = body_model(denormalize(est))
+    v2v = torch.mean(weight * torch.square(v_gt - v_pr).sum(dim=-1))         # :253
+    j2j = torch.mean(weight * torch.square(j_gt - j_pr).sum(dim=-1))         # :254
+    total = score_loss + v2v + j2j
+    return total, {"step_loss": total, "score_loss": score_loss, "v2v_loss": v2v, "j2j_loss": j2j}
+
+
 PARAM_ORDER_CACHE: Dict[int, List[str]] = {}
 
 
@@ -249,7 +287,7 @@ class TrainState:
 
 
 def train_step(st: TrainState, sde, batch, t, z, *, lr=2e-4, warmup=5000, grad_clip=1.0,
-               beta1=0.9, beta2=0.999, eps=1e-8, reduce_mean=True, **fw):
+               beta1=0.9, beta2=0.999, eps=1e-8, reduce_mean=True, loss_override=None, **fw):
     """One ``step_fn`` (losses.py:220-263) with injected (t, z[, dropout masks]):
     zero_grad -> loss -> backward -> lr warm-up (:51-53) -> clip_grad_norm_ (:54-55) -> Adam
     (:56; torch.optim.Adam semantics, wd=0, amsgrad off) -> step+=1 (:262) -> EMA (:263).
@@ -258,7 +296,8 @@ def train_step(st: TrainState, sde, batch, t, z, *, lr=2e-4, warmup=5000, grad_c
     leaves = {n: st.p[n].detach().clone().requires_grad_(True) for n in st.names}
     full = dict(st.p)
     full.update(leaves)
-    loss = dsm_loss(full, sde, batch, t, z, reduce_mean=reduce_mean, **fw)
+    # loss_override(full_params) -> scalar: another loss on the same step machinery (the auxiliary-loss step, losses.py:242-258)
+    loss = loss_override(full) if loss_override is not None else dsm_loss(full, sde, batch, t, z, reduce_mean=reduce_mean, **fw)
     grads = torch.autograd.grad(loss, [leaves[n] for n in st.names], allow_unused=True)
     grads = dict(zip(st.names, grads))
     cur_lr = lr * min(st.step / warmup, 1.0) if warmup > 0 else lr

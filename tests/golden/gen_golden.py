@@ -450,6 +450,46 @@ def g15_motion_denoise_loop():
 
 
 
+def g17_aux_loss():
+    """G17: the reference's own step_fn with auxiliary_loss=True (losses.py:91-119 multi-step denoise, :242-258 v2v / j2j body
+    terms) driving a torch body model that stands in for smplx (oracle.fk_torch on the synthetic SMPL-X-shaped asset, as in
+    G15) and the z-score de-normaliser of the shipped statistics.  dropout = 0 (a kernel cannot reproduce torch's masks),
+    injected (t, z); full learning rate (step 5000).  Stores the four loss values, probes of every clipped gradient and of every
+    updated parameter."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import fk_torch
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    asset = make_synthetic_smplx_asset(seed=0)
+    cfg, m = build_model(17, 63, dropout=0.0)
+    sde = ref_sde.subVPSDE(0.1, 20.0, 1000)
+    stats = torch.load(os.path.join(REF, "data/AMASS/amass_processed/version1/train/axis_normalize2.pt"))
+    mean, std = stats["mean_poses"].float(), stats["std_poses"].float()
+
+    class TorchBM:
+        def __call__(self, pose_body=None, **kw):
+            v, j = fk_torch.smplx_forward(asset, pose_body.double())
+            return types.SimpleNamespace(v=v.float(), Jtr=j.float())
+
+    B, steps = 8, 3
+    batch, _ = toy_batch(B, seed=49)
+    opt = ref_losses.get_optimizer(cfg, m.parameters())
+    ema = ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate)
+    state = dict(optimizer=opt, model=m, ema=ema, step=5000)
+    step_fn = ref_losses.get_step_fn(sde, train=True, optimize_fn=ref_losses.optimization_manager(cfg), reduce_mean=True, continuous=True,
+                                     likelihood_weighting=False, auxiliary_loss=True, denormalize=lambda x: x * std + mean,
+                                     body_model=TorchBM(), rot_rep="axis", denoise_steps=steps)
+    with Recorder(1700) as rec:
+        ld = step_fn(state, batch)
+    out = {"batch": batch.numpy(), "seed": np.int64(17), "denoise_steps": np.int64(steps), "mean": mean.numpy(), "std": std.numpy(),
+           "u": rec.by_kind("rand")[0], "z": rec.by_kind("randn")[0], "step": np.int64(5000), "lr": np.float64(opt.param_groups[0]["lr"])}
+    for k, v in ld.items():
+        out[k] = np.float64(v.item())
+    for n, p in m.named_parameters():
+        out[f"grad/{n}"] = np.zeros(1) if p.grad is None else sample_tensor(n, p.grad)
+        out[f"param/{n}"] = sample_tensor(n, p)
+    save("g17_aux_loss", **out)
+
+
 def g8_scalars():
     """G8: marginal_prob / sde / return_alpha_sigma / discretize tables on linspace(1,1e-3,1000)."""
     t = torch.linspace(1.0, 1e-3, 1000)
@@ -627,8 +667,8 @@ def g13_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
-    fns = dict(g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    fns = dict(g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
                g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
     for w in which:
         fns[w]()

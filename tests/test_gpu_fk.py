@@ -8,6 +8,12 @@ from gpu_common import DEV, t2n
 from helpers import _log_measured, load
 from oracle import fk_ref
 
+
+def _reload_tuning():
+    """the body-model A/B switches are read from the environment once per process: re-read them after changing one"""
+    from dposer_amd import _C
+    _C.lib().dposer_body_tuning_reload()
+
 pytestmark = pytest.mark.gpu
 
 
@@ -309,8 +315,10 @@ def test_pose_blend_bf16x3_against_exact_fp32_and_the_oracle(bm, asset, B, monke
 
     v3, gp3, gh3 = run()
     monkeypatch.setenv("DPOSER_LBS_BLEND", "fp32")
+    _reload_tuning()
     v1, gp1, gh1 = run()
     monkeypatch.delenv("DPOSER_LBS_BLEND")
+    _reload_tuning()
     e3, e1 = np.abs(v3 - v_ref).max(), np.abs(v1 - v_ref).max()
     _log_measured("pose blend bf16x3 max abs vertex error", e3)
     _log_measured("pose blend fp32 max abs vertex error", e1)
@@ -342,8 +350,10 @@ def test_small_batch_fk_kernels_return_the_bits_of_the_large_batch_ones(bm, asse
 
     small = run()
     monkeypatch.setenv("DPOSER_FK_SMALL_MAX", "0")
+    _reload_tuning()
     large = run()
     monkeypatch.delenv("DPOSER_FK_SMALL_MAX")
+    _reload_tuning()
     names = ["v", "Jtr", "fk_joints", "d pose", "d root", "d hand", "d jaw", "d eye", "d expression", "d betas", "d trans"]
     for n, a, b in zip(names, small, large):
         assert torch.equal(a, b), n
@@ -364,8 +374,10 @@ def test_joint_gradient_kernels_agree(bm, monkeypatch):
 
     g_gather = run()
     monkeypatch.setenv("DPOSER_LBS_JOINT_STREAM_MIN", "1")
+    _reload_tuning()
     g_stream = run()
     monkeypatch.delenv("DPOSER_LBS_JOINT_STREAM_MIN")
+    _reload_tuning()
     assert np.linalg.norm(g_gather - g_stream) / np.linalg.norm(g_gather) < 1e-5
     assert not np.array_equal(g_gather, g_stream)
 
@@ -387,8 +399,10 @@ def test_small_batch_fk_kernels_other_trees(model_type, monkeypatch):
 
     small = run()
     monkeypatch.setenv("DPOSER_FK_SMALL_MAX", "0")
+    _reload_tuning()
     large = run()
     monkeypatch.delenv("DPOSER_FK_SMALL_MAX")
+    _reload_tuning()
     for a, b in zip(small, large):
         assert torch.equal(a, b)
 
@@ -636,3 +650,49 @@ def test_rotation_conversions_vs_scipy(n):
     assert np.abs(M @ M.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5 and np.abs(np.linalg.det(M) - 1).max() < 1e-5
     got = t2n(rot6d_to_axis_angle(torch.tensor(noisy, device=DEV)))
     assert np.abs(got - Rotation.from_matrix(M).as_rotvec()).max() < 2e-5
+
+
+def test_smplx_mean_poses_are_converted_on_the_device(asset, tmp_path, monkeypatch):
+    """lib/body_model/smpl.py:59-62: mean_poses = rot6d_to_axis_angle(smpl_mean_params['pose']).  The conversion is a HIP kernel; a
+    module built from a user-supplied smpl_mean_params.npz must end up with the converted values (round 2 swallowed the
+    device-only error and registered zeros), checked here against scipy."""
+    from scipy.spatial.transform import Rotation
+    from dposer_amd.body_model import constants
+    from dposer_amd.body_model.smpl import SMPLX
+    rs = np.random.RandomState(3)
+    rot = Rotation.from_rotvec(rs.standard_normal((24, 3)) * 0.6)
+    R = rot.as_matrix()
+    rot6d = R[:, :, :2].reshape(24, 6).astype(np.float32)          # 6D = the first two COLUMNS, row-major 3 x 2 (transforms.py:227-235)
+    shape = rs.standard_normal(10).astype(np.float32)
+    path = tmp_path / "smpl_mean_params.npz"
+    np.savez(path, pose=rot6d.reshape(-1), shape=shape, cam=np.zeros(3, np.float32))
+    monkeypatch.setattr(constants, "SMPL_MEAN_PATH", str(path))
+    sm = SMPLX(asset)
+    assert sm.mean_params_loaded and sm.mean_poses.shape == (72,)
+    got = sm.mean_poses.cpu().numpy().reshape(24, 3)
+    assert np.abs(got - rot.as_rotvec()).max() < 1e-5
+    assert np.array_equal(sm.mean_shape.cpu().numpy(), shape)
+    sm = sm.to(DEV)
+    assert sm.mean_poses.device.type == "cuda" and np.abs(sm.mean_poses.cpu().numpy().reshape(24, 3) - rot.as_rotvec()).max() < 1e-5
+    monkeypatch.setattr(constants, "SMPL_MEAN_PATH", str(tmp_path / "missing.npz"))
+    sm0 = SMPLX(asset)
+    assert not sm0.mean_params_loaded and float(sm0.mean_poses.abs().max()) == 0.0
+
+
+def test_smplx_wrapper_accepts_rotation_matrices(asset):
+    """pose2rot=False (smplx): rotation-matrix inputs must give the joints / vertices of the equivalent axis-angle call."""
+    from scipy.spatial.transform import Rotation
+    from dposer_amd.body_model.smpl import SMPLX
+    sm = SMPLX(asset).to(DEV)
+    rs = np.random.RandomState(4)
+    B = 5
+    body = (rs.standard_normal((B, 21, 3)) * 0.4).astype(np.float32)
+    root = (rs.standard_normal((B, 1, 3)) * 0.4).astype(np.float32)
+    Rb = Rotation.from_rotvec(body.reshape(-1, 3)).as_matrix().reshape(B, 21, 3, 3).astype(np.float32)
+    Rr = Rotation.from_rotvec(root.reshape(-1, 3)).as_matrix().reshape(B, 1, 3, 3).astype(np.float32)
+    with torch.no_grad():
+        a = sm(body_pose=torch.tensor(body.reshape(B, 63), device=DEV), global_orient=torch.tensor(root.reshape(B, 3), device=DEV))
+        b = sm(body_pose=torch.tensor(Rb, device=DEV), global_orient=torch.tensor(Rr, device=DEV), pose2rot=False)
+    assert (a.joints - b.joints).abs().max() < 2e-6 and (a.vertices - b.vertices).abs().max() < 2e-6
+    with pytest.raises(ValueError):
+        sm(body_pose=torch.tensor(body.reshape(B, 63), device=DEV), pose2rot=False)

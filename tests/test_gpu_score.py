@@ -978,3 +978,36 @@ def test_langevin_fused_completion_imputation_matches_generic_loop():
             xg = xg * (1 - mask) + (mean + torch.randn_like(xg) * std[:, None]) * mask
             assert rel_err(t2n(trajs[i - start]), t2n(xg)) < 2e-5, i
     assert rel_err(t2n(xf), t2n(xg)) < 2e-5 and rel_err(t2n(xmf), t2n(xm)) < 2e-5
+
+
+def test_auxiliary_loss_step_matches_reference_golden():
+    """g17 = the reference's own get_step_fn(auxiliary_loss=True) (losses.py:91-119 multi-step denoise through the network,
+    :242-258 SNR-weighted v2v / j2j terms of the posed bodies), captured with oracle.fk_torch standing in for smplx.  Here the
+    same step runs on the HIP path end to end: three differentiable network evaluations whose activations stay leased, the LBS
+    forward / backward of BodyModel for both bodies, clip + Adam + EMA.  fp32 mode, dropout off, injected (t, z)."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    g = load("g17_aux_loss")
+    cfg, m, p = make_model(int(g["seed"]), precision="fp32", dropout=0.0)
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    bm = BodyModel(make_synthetic_smplx_asset(seed=0)).to(DEV)
+    mean, std = _dev(g["mean"]), _dev(g["std"])
+    state = dict(model=m, optimizer=losses.get_optimizer(cfg, m.parameters()), ema=ExponentialMovingAverage(m.parameters(), cfg.model.ema_rate),
+                 step=int(g["step"]))
+    step_fn = losses.get_step_fn(sde, True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True,
+                                 auxiliary_loss=True, denormalize=lambda x: x * std + mean, body_model=bm, rot_rep="axis",
+                                 denoise_steps=int(g["denoise_steps"]))
+    t = _dev(g["u"]) * (1.0 - 1e-5) + 1e-5
+    out = step_fn(state, _dev(g["batch"]), t=t, z=_dev(g["z"]))
+    assert set(out) == {"step_loss", "score_loss", "v2v_loss", "j2j_loss"} and state["step"] == int(g["step"]) + 1
+    for k in out:
+        assert abs(float(out[k]) - float(g[k])) / abs(float(g[k])) < 2e-4, (k, float(out[k]), float(g[k]))
+    worst = 0.0
+    for name, prm in m.named_parameters():
+        ref = g[f"grad/{name}"]
+        if ref.shape[0] > 1:                                   # (pre_dense_cond: no gradient)
+            worst = max(worst, rel_err(probe(name, prm.grad), ref))
+        assert rel_err(probe(name, prm), g[f"param/{name}"]) < 2e-5, name
+    assert worst < 2e-3, worst

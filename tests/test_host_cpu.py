@@ -338,3 +338,18 @@ def test_product_never_touches_the_oracle_or_the_reference():
     entry = open(os.path.join(root, "__graft_entry__.py")).read()
     build_body = entry.split("def build", 1)[1].split("def smoke", 1)[0]
     assert "score_ref." not in build_body and "fk_ref." not in build_body   # build() imports the oracle modules, never calls them
+
+
+def test_rot6d_to_axis_angle_autograd_helper_vs_scipy():
+    """The differentiable 6D -> axis-angle map of the auxiliary-loss step (rot_rep = 'rot6d', losses.py:247-249) is plain torch:
+    values against scipy, gradient against finite differences (CPU)."""
+    from scipy.spatial.transform import Rotation
+    from dposer_amd.algorithms.advanced.losses import _rot6d_to_axis_angle_autograd as f
+    rs = np.random.RandomState(2)
+    rv = rs.standard_normal((40, 3)) * 0.8
+    rv[0] = 1e-6                                                # small-angle branch
+    R = Rotation.from_rotvec(rv).as_matrix()
+    x = torch.tensor(R[:, :, :2].reshape(-1, 6) * rs.uniform(0.5, 2.0, (40, 1)), dtype=torch.float64, requires_grad=True)
+    out = f(x)
+    assert np.abs(out.detach().numpy() - Rotation.from_matrix(R).as_rotvec()).max() < 1e-6
+    assert torch.autograd.gradcheck(f, (x[1:9],), eps=1e-6, atol=1e-5)

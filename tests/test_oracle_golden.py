@@ -237,3 +237,42 @@ def test_guided_em_step_restatement_matches_reference_golden():
             assert rel_err(y_mean.numpy(), g[f"{tag}_y_mean"]) < 1e-5, tag
             assert rel_err(y_hat.numpy(), g[f"{tag}_y_hat"]) < 1e-4, tag
 
+
+
+def test_auxiliary_loss_step_restatement_matches_the_reference_step():
+    """g17 = the reference's own get_step_fn(auxiliary_loss=True) (losses.py:91-119, :242-258) with oracle.fk_torch on the
+    synthetic asset as its body model: the restated multi-step denoise, SNR weights, v2v / j2j terms, clipped gradients and the
+    Adam update must reproduce it."""
+    from oracle import fk_torch
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    g = load("g17_aux_loss")
+    asset = make_synthetic_smplx_asset(seed=0)
+    p = make_weights(int(g["seed"]))
+    p["sigmas"] = R.sigma_table()
+    names = R.param_names()
+    st = R.TrainState(p, names)
+    st.step = int(g["step"])
+    batch = torch.tensor(g["batch"])
+    t = torch.tensor(g["u"]) * (1.0 - 1e-5) + 1e-5
+    z = torch.tensor(g["z"])
+    mean, std = torch.tensor(g["mean"]), torch.tensor(g["std"])
+    terms = {}
+
+    def body(pose):
+        v, j = fk_torch.smplx_forward(asset, pose.double())
+        return v.float(), j.float()
+
+    def loss_of(full):
+        total, d = R.aux_loss(full, R.SubVP(), batch, t, z, denormalize=lambda x: x * std + mean, body_model=body,
+                              denoise_steps=int(g["denoise_steps"]))
+        terms.update({k: float(v) for k, v in d.items()})
+        return total
+
+    loss, grads, norm = R.train_step(st, R.SubVP(), batch, t, z, loss_override=loss_of)
+    for k in ("step_loss", "score_loss", "v2v_loss", "j2j_loss"):
+        assert abs(terms[k] - float(g[k])) / abs(float(g[k])) < 2e-5, (k, terms[k], float(g[k]))
+    coef = min(1.0, 1.0 / (norm + 1e-6))                      # the golden holds the gradients AFTER clip_grad_norm_(1.0)
+    for n in names:
+        if grads[n] is not None:
+            assert rel_err(probe(n, grads[n] * coef), g[f"grad/{n}"]) < 2e-4, n
+        assert rel_err(probe(n, st.p[n]), g[f"param/{n}"]) < 1e-5, n

@@ -12,6 +12,8 @@ bm = BodyModel(make_synthetic_smplx_asset(seed=0)).to(DEV)
 pose = torch.randn(B, 63, device=DEV) * 0.3
 for env in ("1000000000", "0"):
     os.environ["DPOSER_FK_SMALL_MAX"] = env
+    from dposer_amd import _C
+    _C.lib().dposer_body_tuning_reload()      # the switch is read once per process otherwise
     p = pose.clone().requires_grad_(True)
     for _ in range(6):
         p.grad = None
