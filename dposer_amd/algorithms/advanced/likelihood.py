@@ -44,16 +44,33 @@ def hutchinson_noise(data, kind):
     raise NotImplementedError(f"Hutchinson type {kind} unknown.")
 
 
-def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e-5, atol=1e-5, method="RK45", eps=1e-5, driver=None):
+FIXED_STEP_METHODS = ("rk4", "euler")
+
+
+def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e-5, atol=1e-5, method="RK45", eps=1e-5, driver=None,
+                      n_steps=None):
     """Returns ``likelihood_fn(model, data) -> (bpd [B], z like data, nfe)`` (likelihood.py:40-113).
 
     ``driver``: 'device' (default for RK45) integrates with ``ode_device.solve_rk45`` -- scipy's RK45 controller with the state and
     all stage arithmetic resident on the GPU in float64, one scalar to the host per attempted step; 'scipy' is the reference's
     own driver (host float64 state, two state copies per right-hand-side evaluation; the only choice for other ``method``s).
-    ``DPOSER_ODE_DRIVER`` overrides the default."""
-    driver = driver or os.environ.get("DPOSER_ODE_DRIVER") or ("device" if method == "RK45" else "scipy")
-    if driver == "device" and method != "RK45":
-        raise NotImplementedError("the device-resident driver implements RK45 (the reference's default); use driver='scipy'")
+    ``DPOSER_ODE_DRIVER`` overrides the default.
+    ``method='rk4' | 'euler'`` with ``n_steps``: fixed-step integration on the device (``ode_device.solve_fixed``) -- no step-size
+    control, hence no host synchronisation at all: the whole likelihood evaluation is queued asynchronously; nfe =
+    4 n_steps / n_steps.  Not a reference mode (its driver is always solve_ivp): for throughput runs such as the validation bpd
+    of run/train.py:279 on large batches.
+
+    One right-hand side is ONE network evaluation: the forward keeps its activations, the drift is its output and the Hutchinson
+    vector-Jacobian product eps^T d drift / d x is the input-gradient (dgrad only, no parameter gradients) of the same evaluation
+    (round 2 ran a second, inference-mode forward for the drift)."""
+    fixed = method in FIXED_STEP_METHODS
+    if fixed and not n_steps:
+        raise ValueError(f"method={method!r} is a fixed-step integrator: pass n_steps")
+    driver = driver or os.environ.get("DPOSER_ODE_DRIVER") or ("device" if (method == "RK45" or fixed) else "scipy")
+    if driver == "device" and not (method == "RK45" or fixed):
+        raise NotImplementedError("the device-resident driver implements RK45 (the reference's default), rk4 and euler; use driver='scipy'")
+    if fixed and driver != "device":
+        raise NotImplementedError("fixed-step methods run on the device-resident driver")
 
     def likelihood_fn(model, data, *, epsilon=None):
         shape, B = tuple(data.shape), data.shape[0]
@@ -61,23 +78,26 @@ def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e
         n_state = int(np.prod(shape))
         with torch.no_grad():
             noise = hutchinson_noise(data, hutchinson_type) if epsilon is None else epsilon
-        div = get_div_fn(lambda xx, tt: probability_flow_drift(sde, model, xx, tt))
         only_x = (lambda: model.input_grad_only()) if hasattr(model, "input_grad_only") else contextlib.nullcontext
 
         def rhs_dev(t, state):
-            """state float64 [n_state + B] on the device -> d state / dt (likelihood.py:86-95)."""
-            x = state[:n_state].reshape(shape).float()
+            """state float64 [n_state + B] on the device -> d state / dt (likelihood.py:86-95): drift and divergence estimate from
+            one differentiable evaluation."""
             vec_t = torch.full((B,), float(t), device=dev, dtype=torch.float32)
-            with torch.no_grad():
-                drift = probability_flow_drift(sde, model, x, vec_t)
-            with only_x():
-                dlogp = div(x, vec_t, noise)
-            return torch.cat([drift.reshape(-1).double(), dlogp.reshape(-1).double()])
+            with torch.enable_grad(), only_x():
+                xg = state[:n_state].reshape(shape).float().requires_grad_(True)
+                drift = probability_flow_drift(sde, model, xg, vec_t)
+                vjp, = torch.autograd.grad((drift * noise).sum(), xg)
+            dlogp = (vjp * noise).flatten(1).sum(dim=1)
+            return torch.cat([drift.detach().reshape(-1).double(), dlogp.reshape(-1).double()])
 
         if driver == "device":
-            from .ode_device import solve_rk45
+            from .ode_device import solve_fixed, solve_rk45
             init = torch.cat([data.detach().reshape(-1).double(), torch.zeros(B, dtype=torch.float64, device=dev)])
-            end, nfev = solve_rk45(rhs_dev, eps, sde.T, init, rtol=rtol, atol=atol)
+            if fixed:
+                end, nfev = solve_fixed(rhs_dev, eps, sde.T, init, int(n_steps), method=method)
+            else:
+                end, nfev = solve_rk45(rhs_dev, eps, sde.T, init, rtol=rtol, atol=atol)
             z = end[:n_state].reshape(shape).float()
             delta_logp = end[n_state:].float()
         else:

@@ -430,7 +430,8 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
     return pc_sampler
 
 
-def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1e-5, method="RK45", eps=1e-3, device="cuda", driver=None):
+def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1e-5, method="RK45", eps=1e-3, device="cuda", driver=None,
+                    n_steps=None):
     """Probability-flow ODE sampler (sampling.py:471-542): ``ode_sampler(model, z=None) -> (nfe, samples)``.
 
     The adaptive RK45 steps follow scipy's controller exactly like the reference (tolerances and ``nfe`` are part of the
@@ -440,9 +441,14 @@ def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1
     import os
     from .likelihood import probability_flow_drift
     from scipy import integrate
-    driver = driver or os.environ.get("DPOSER_ODE_DRIVER") or ("device" if method == "RK45" else "scipy")
-    if driver == "device" and method != "RK45":
-        raise NotImplementedError("the device-resident driver implements RK45 (the reference's default); use driver='scipy'")
+    fixed = method in ("rk4", "euler")      # fixed-step, fully asynchronous device integration (likelihood.get_likelihood_fn has the details)
+    if fixed and not n_steps:
+        raise ValueError(f"method={method!r} is a fixed-step integrator: pass n_steps")
+    driver = driver or os.environ.get("DPOSER_ODE_DRIVER") or ("device" if (method == "RK45" or fixed) else "scipy")
+    if driver == "device" and not (method == "RK45" or fixed):
+        raise NotImplementedError("the device-resident driver implements RK45 (the reference's default), rk4 and euler; use driver='scipy'")
+    if fixed and driver != "device":
+        raise NotImplementedError("fixed-step methods run on the device-resident driver")
 
     def ode_sampler(model, z=None):
         with torch.no_grad():
@@ -454,8 +460,11 @@ def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1
                 return probability_flow_drift(sde, model, xt, vec_t).reshape(-1).double()
 
             if driver == "device":
-                from .ode_device import solve_rk45
-                end, nfev = solve_rk45(rhs_dev, sde.T, eps, x.reshape(-1).double(), rtol=rtol, atol=atol)
+                from .ode_device import solve_fixed, solve_rk45
+                if fixed:
+                    end, nfev = solve_fixed(rhs_dev, sde.T, eps, x.reshape(-1).double(), int(n_steps), method=method)
+                else:
+                    end, nfev = solve_rk45(rhs_dev, sde.T, eps, x.reshape(-1).double(), rtol=rtol, atol=atol)
                 x = end.reshape(shape).float()
             else:
                 sol = integrate.solve_ivp(lambda t, s_: rhs_dev(t, torch.from_numpy(s_).to(device)).cpu().numpy(), (sde.T, eps),

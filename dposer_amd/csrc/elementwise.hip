@@ -896,3 +896,41 @@ hipError_t launch_adam_ema(const AdamArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_adam_ema, dim3(grid_for(a.n, 256, 4096)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Runge-Kutta stage combination on the float64 ODE state (probability-flow ODE / likelihood):
+//     out = [y +] scale * (c_0 K_0 + c_1 K_1 + ... )      left to right, no contraction (this file is built with
+// -ffp-contract=off), i.e. the bits of the torch expression it replaces -- one launch instead of 2 n_terms + 1
+// ------------------------------------------------------------------------------------------------
+struct RkCombineArgs {
+    const double* y;          // or null
+    const double* k[8];
+    double c[8];
+    int n_terms;
+    double scale;
+    double* out;
+    int64_t n;
+};
+__global__ void __launch_bounds__(256) k_rk_combine(RkCombineArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        double acc = a.k[0][i] * a.c[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j)
+            if (j < a.n_terms) acc = acc + a.k[j][i] * a.c[j];
+        acc = acc * a.scale;
+        a.out[i] = a.y ? a.y[i] + acc : acc;
+    }
+}
+extern "C" int dposer_rk_combine_f64(double* out, const double* y, const double* const* k_host, const double* coef_host, int32_t n_terms,
+                                     double scale, int64_t n, void* stream) {
+    DP_CHECK_ARG(out && k_host && coef_host && n_terms >= 1 && n_terms <= 8 && n >= 0, "bad argument");
+    RkCombineArgs a;
+    a.y = y; a.n_terms = n_terms; a.scale = scale; a.out = out; a.n = n;
+    for (int j = 0; j < 8; ++j) { a.k[j] = j < n_terms ? k_host[j] : k_host[0]; a.c[j] = j < n_terms ? coef_host[j] : 0.0; }
+    for (int j = 0; j < n_terms; ++j) DP_CHECK_ARG(k_host[j] != nullptr, "null stage pointer");
+    if (n == 0) return DPOSER_OK;
+    hipLaunchKernelGGL(k_rk_combine, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a);
+    DP_CHECK_LAUNCH();
+    return DPOSER_OK;
+}

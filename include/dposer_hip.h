@@ -190,6 +190,13 @@ int dposer_adam_ema_clip_step(float* flat_params, const float* flat_grad, float*
  *   dposer_adam_ema_clip_step_presummed: dposer_adam_ema_clip_step on the range, taking the squared norm from scratch[0] instead
  *   of recomputing it (pointers and skip ranges are relative to the range). */
 int dposer_grad_sqnorm(const float* grad, int64_t n, float* scratch, void* stream);
+
+/* Runge-Kutta stage combination on the float64 state of the probability-flow ODE (lib/algorithms/advanced/likelihood.py:86-99,
+ * sampling.py:513-530 hand the state to scipy.integrate.solve_ivp, whose RK45 forms these sums on the host):
+ *   out[i] = (y ? y[i] : 0) + scale * (coef[0] k[0][i] + coef[1] k[1][i] + ...), left to right in float64, no fused multiply-add.
+ *   k_host / coef_host: HOST arrays of n_terms (<= 8) DEVICE pointers / coefficients; y may be NULL; out may alias nothing. */
+int dposer_rk_combine_f64(double* out, const double* y, const double* const* k_host, const double* coef_host, int32_t n_terms,
+                          double scale, int64_t n, void* stream);
 int dposer_adam_ema_clip_step_presummed(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* ema,
                                         int64_t n, const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip,
                                         double lr, double beta1, double beta2, double eps, double grad_clip, double grad_scale,

@@ -439,9 +439,12 @@ def test_likelihood_matches_reference_golden(driver):
     for kind in ("Rademacher", "Gaussian"):
         fn = likelihood.get_likelihood_fn(sde, lambda v: v, hutchinson_type=kind, rtol=1e-4, atol=1e-4, eps=1e-4, driver=driver)
         bpd, z, nfe = fn(m, data, epsilon=_dev(g[f"lik_{kind}/eps"]))
-        assert rel_err(t2n(bpd), g[f"lik_{kind}/bpd"]) < 2e-3, kind
-        assert rel_err(t2n(z), g[f"lik_{kind}/z"]) < 2e-3, kind
-        assert abs(int(nfe) - int(g[f"lik_{kind}/nfe"])) <= 60
+        # measured (round 3, one evaluation per right-hand side): Rademacher bpd 1.2e-5 / z 9.3e-6, Gaussian 1.5e-3 / 8.1e-4 (the
+        # Gaussian probe vector weights the random-weight Jacobian's rounding far more); nfe 746 / 734 = the reference's counts
+        tol = 1e-4 if kind == "Rademacher" else 4e-3
+        assert rel_err(t2n(bpd), g[f"lik_{kind}/bpd"]) < tol, kind
+        assert rel_err(t2n(z), g[f"lik_{kind}/z"]) < tol, kind
+        assert abs(int(nfe) - int(g[f"lik_{kind}/nfe"])) <= 6, (kind, nfe)        # at most one RK45 step apart (6 evaluations)
     # the noise draw itself: +-1 entries
     eps = likelihood.hutchinson_noise(data, "Rademacher")
     assert set(np.unique(t2n(eps)).tolist()) <= {-1.0, 1.0}
@@ -475,8 +478,8 @@ def test_ode_sampler_matches_reference_golden(driver):
                                       driver=driver)
         nfe, x = fn(m, z=_dev(g["ode/z"]))
         # random weights are not a trained score: the flow expands |x| by four orders of magnitude, and rounding differences with it
-        assert rel_err(t2n(x), g[f"ode/x_denoise{denoise}"]) < 2e-2
-        assert abs(int(nfe) - int(g[f"ode/nfe_denoise{denoise}"])) <= 60
+        assert rel_err(t2n(x), g[f"ode/x_denoise{denoise}"]) < 2e-3                  # measured 8.9e-5
+        assert abs(int(nfe) - int(g[f"ode/nfe_denoise{denoise}"])) <= 24, nfe          # measured 434 vs 446: two RK45 steps
     cfg.sampling.method = "ode"
     assert callable(sampling.get_sampling_fn(cfg, sde, (6, 63), lambda v: v, 1e-3, device=DEV))
 
@@ -1011,3 +1014,44 @@ def test_auxiliary_loss_step_matches_reference_golden():
             worst = max(worst, rel_err(probe(name, prm.grad), ref))
         assert rel_err(probe(name, prm), g[f"param/{name}"]) < 2e-5, name
     assert worst < 2e-3, worst
+
+
+def test_rk_stage_combination_kernel_returns_the_bits_of_the_torch_expression():
+    """dposer_rk_combine_f64 (one launch per Runge-Kutta stage on the float64 ODE state) against the left-to-right torch
+    expression it replaces, zero coefficients skipped, with and without the base vector."""
+    from dposer_amd.algorithms.advanced import ode_device
+    rs = np.random.RandomState(0)
+    n = 8192 * 64 + 8192 + 3
+    y = torch.tensor(rs.standard_normal(n), device=DEV)
+    ks = [torch.tensor(rs.standard_normal(n), device=DEV) for _ in range(7)]
+    for coefs, base, scale in ((ode_device._A[5], y, 0.0371), (ode_device._B, y, -0.01), (ode_device._E, None, 1.0), ((1.0, 2.0, 2.0, 1.0), y, 0.5 / 6)):
+        k = ks[:len(coefs)]
+        got = ode_device._combine(base, k, coefs, scale)
+        terms = [(kk, c) for kk, c in zip(k, coefs) if c != 0.0]
+        acc = terms[0][0] * terms[0][1]
+        for kk, c in terms[1:]:
+            acc = acc + kk * c
+        acc = acc * scale
+        ref = acc if base is None else base + acc
+        assert torch.equal(got, ref)
+
+
+def test_fixed_step_likelihood_and_ode_sampler():
+    """method='rk4' (no step-size control, no host synchronisation) through get_likelihood_fn / get_ode_sampler: converges to the
+    adaptive RK45 result of the same right-hand side as the step count grows, nfe = 4 n_steps."""
+    from dposer_amd.algorithms.advanced import likelihood, sampling, sde_lib
+    g = load("g12_likelihood_ode")
+    cfg, m, p = make_model(int(g["seed"]), precision="fp32")
+    sde = sde_lib.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000)
+    data, eps = _dev(g["data"]), _dev(g["lik_Rademacher/eps"])
+    ref_bpd, ref_z, _ = likelihood.get_likelihood_fn(sde, lambda v: v, rtol=1e-6, atol=1e-6, eps=1e-4)(m, data, epsilon=eps)
+    errs = []
+    for n in (50, 400):
+        bpd, z, nfe = likelihood.get_likelihood_fn(sde, lambda v: v, method="rk4", n_steps=n, eps=1e-4)(m, data, epsilon=eps)
+        assert nfe == 4 * n
+        errs.append(rel_err(t2n(bpd), t2n(ref_bpd)))
+    assert errs[1] < 1e-3 and errs[1] < errs[0]
+    with pytest.raises(ValueError):
+        likelihood.get_likelihood_fn(sde, lambda v: v, method="rk4")
+    nfe, x = sampling.get_ode_sampler(sde, (6, 63), lambda v: v, method="euler", n_steps=64, eps=1e-3, device=DEV)(m, z=_dev(g["ode/z"]))
+    assert nfe == 64 and torch.isfinite(x).all()

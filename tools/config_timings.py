@@ -3,6 +3,7 @@
   cfg2  train step at batch 8192                      cfg3  1000-step EM sampling of 500 poses
   cfg4  pose completion, one rank's share: batch 16384, `--part legs`, 2 x 100 optimisation steps per hypothesis
   cfg5  motion denoising of one 60-frame sequence: 5 x 50 optimisation steps (SMPL-X LBS forward + backward + prior)
+  bpd   validation likelihood (bits/dim, run/train.py:279) of 8192 poses: adaptive RK45 and fixed-step RK4
 Prints a markdown table (committed as profiles/rNN_configs.md).  Parity of each loop is covered by tests/test_gpu_tasks.py."""
 import os
 import sys
@@ -97,6 +98,29 @@ def main():
         else:
             s = timed(lambda: md.optimize(joints, gt_poses=gt, iterations=5, steps_per_iter=50, fused=False), warm=1)
         rows.append(("cfg5 (autograd loop)", "the same steps through autograd + torch.optim.Adam around the same kernels", f"{s:.3f} s / sequence", f"{s / 250 * 1e3:.2f} ms / step"))
+
+    if only in (None, 'bpd'):
+        # validation bits/dim of run/train.py:279 (likelihood.py:40-113) at batch 8192: adaptive RK45 (the reference's mode; device-
+        # resident controller) and the fixed-step RK4 (no host synchronisation), one network evaluation per right-hand side
+        from dposer_amd.algorithms.advanced import likelihood
+        data = norm.offline_normalize(toy[torch.randint(0, 500, (8192,))].to(dev))
+        eps = likelihood.hutchinson_noise(data, "Rademacher")
+        res = {}
+        for tag, kw in (("RK45 rtol=atol=1e-5 (reference default), device driver", dict(method="RK45")),
+                        ("RK45, scipy driver (host state, as the reference)", dict(method="RK45", driver="scipy")),
+                        ("fixed-step RK4, 100 steps", dict(method="rk4", n_steps=100)),
+                        ("fixed-step RK4, 25 steps", dict(method="rk4", n_steps=25))):
+            fn = likelihood.get_likelihood_fn(sde, lambda v: v, **kw)
+            out = {}
+
+            def run():
+                out["r"] = fn(model, data, epsilon=eps)
+
+            s = timed(run, warm=1)
+            bpd, _, nfe = out["r"]
+            res[tag] = float(bpd.mean())
+            rows.append(("bpd", f"likelihood of 8192 poses, {tag}", f"{s:.3f} s ({nfe} evaluations, {s / nfe * 1e3:.3f} ms each)",
+                         f"{8192 / s:,.0f} poses/s, mean bpd {float(bpd.mean()):.4f}"))
 
     print("| config | workload | time | rate |")
     print("|---|---|---:|---:|")
