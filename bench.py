@@ -49,6 +49,31 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_mfma(kernel):
+    """Matrix-pipe counters of ``kernel`` from the committed SQ / GRBM passes of this same command (profiles/pmc_mfma.json, written by
+    tools/profile_bench.sh): MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) and the effective
+    shader clock GRBM_GUI_ACTIVE / 8 / duration.  A lookup like ``pmc_traffic``; None if absent."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_mfma.json")))
+        head, epi = kernel.rstrip(">").rsplit(",", 1)
+        row = table.get(f"{head},{_EPI_CLASS[epi]}>")
+        return None if row is None else {"mfma_busy_frac": row["mfma_busy_frac"], "clock_ghz": row["clock_ghz"],
+                                         "issue_stall_frac": row.get("issue_stall_frac"), "parked_frac": row.get("parked_frac")}
+    except Exception:
+        return None
+
+
+def pmc_fk_bytes_per_pose():
+    """HBM bytes per pose of the joints-only FK kernel from the committed PMC passes: the bench launches it at 2^20 (23 launches) and
+    2^22 poses (12 launches); the table holds the per-launch average over all of them."""
+    try:
+        row = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))["k_fk_joints<KinSMPLX, 64, 22>"]
+        poses = (23 * (1 << 20) + 12 * (1 << 22)) / 35.0
+        return (row["read_MB"] + row["write_MB"]) * 1e6 / poses if row["launches"] == 35 else None
+    except Exception:
+        return None
+
+
 def synthetic_poses(n, device, seed=42):
     """rows of the reference's examples/toy_data.npz (shipped as a fixture) sampled with replacement,
     z-scored with axis_normalize2."""
@@ -259,6 +284,11 @@ def main():
                     "traffic_source": "lookup: profiles/pmc_hbm_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                       "command, tools/profile_bench.sh); NOT measured in this run", "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3,
                     "flops_per_launch": fl / cnt, "gemm_time_share_of_step": tot_ms / 3 / ms_per_step}
+        mf = pmc_mfma(name)
+        if mf:
+            roofline.update(mf)
+            roofline["mfma_counters_source"] = ("lookup: profiles/pmc_mfma.json (committed rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE "
+                                                "passes of this command); NOT measured in this run")
 
     dropped = state["optimizer"].nonfinite_steps()
     if not np.isfinite(loss) or dropped:
@@ -347,7 +377,9 @@ def main():
         fk_gbs = 516.0 * nfk / fk_s / 1e9
         extra["fk_joints"] = {"poses_per_s_per_gpu": nfk / fk_s, "batch": nfk,
                               "roofline": {"bound": "hbm", "kernel": "k_fk_joints<KinSMPLX, 64, 22>", "achieved": fk_gbs, "peak": HBM_PEAK_GBS,
-                                           "unit": "GB/s", "frac": fk_gbs / HBM_PEAK_GBS, "traffic": None,
+                                           "unit": "GB/s", "frac": fk_gbs / HBM_PEAK_GBS,
+                                           "traffic": None if pmc_fk_bytes_per_pose() is None else pmc_fk_bytes_per_pose() * nfk,
+                                           "traffic_source": "lookup: profiles/pmc_hbm_traffic.json (bytes per pose x 2^20); NOT measured in this run",
                                            "algorithmic_bytes_per_pose": 516, "avg_launch_us": fk_s * 1e6,
                                            "measured": "HIP events on the launch stream around 20 launches of 2^20 poses"}}
         # the same kernel on a 4x larger batch (4 GiB of poses + joints in HBM): launch tails and the ragged last wave weigh less

@@ -108,14 +108,25 @@ class _LBSFunction(torch.autograd.Function):
         dev = d_verts.device
         h, lib = core._handle(), _C.lib()
         J = core.J
-        dv = d_verts.contiguous().float().clone()
+        dv = d_verts.contiguous().float()
         dj = d_joints.contiguous().float()
         # extras / landmarks are gathers of vertices: fold their gradients into d verts.  One small dense product onto the
-        # UNIQUE vertices they touch, then an index_add_ without duplicate indices: deterministic (index_add_ with the raw,
-        # repeating landmark-triangle indices is an atomicAdd race whose order changes the last bit from run to run)
+        # UNIQUE vertices they touch (<= 21 + 3 * 51 of 10475), added without duplicate indices: deterministic (index_add_ with the
+        # raw, repeating landmark-triangle indices is an atomicAdd race whose order changes the last bit from run to run).
+        # Round 2 cloned all of d verts for this (515 MB at 4096 poses, 346 us) and multiplied as a broadcast batch of
+        # [U, 72] x [72, 3] products (a 100 us hipBLASLt launch).  Now: the few touched rows are saved, updated IN the incoming
+        # gradient and restored after the kernels have read it (autograd hands out d verts read-only); the product is ONE
+        # [U, 72] x [72, 3 B] GEMM.
+        saved = uniq = None
         if core.n_extra + core.n_lmk:
             uniq, fold = core.joint_fold()
-            dv.index_add_(1, uniq, torch.matmul(fold, dj[:, J:]))
+            x = dj[:, J:].permute(1, 0, 2).reshape(dj.shape[1] - J, B * 3)                    # [72, 3 B]
+            contrib = torch.matmul(fold, x).reshape(-1, B, 3).permute(1, 0, 2)                  # [B, U, 3]
+            if dv.data_ptr() == d_verts.data_ptr():                                             # still autograd's tensor: restore it later
+                saved = dv[:, uniq]
+                dv[:, uniq] = saved + contrib
+            else:                                                                               # .contiguous() / .float() made a private copy
+                dv[:, uniq] += contrib
         # transl shifts every vertex and the J LBS joints (extras / landmarks move with their vertices: already in dv)
         d_transl = (dv.sum(dim=1) + dj[:, :J].sum(dim=1)) if ctx.has_transl else None
         ws_b = torch.empty(lib.dposer_lbs_backward_workspace_bytes(h, B), dtype=torch.uint8, device=dev)
@@ -143,6 +154,8 @@ class _LBSFunction(torch.autograd.Function):
                                          _C.ptr(core.skin_w), int(core.skin_idx.shape[1]), _C.ptr(jptr), _C.ptr(jvidx), _C.ptr(jw), _C.ptr(dv),
                                          _C.ptr(dj), dj.shape[1] * 3, dsegp, _C.ptr(d_jrest), _C.ptr(d_vposed), B, _C.stream_ptr()),
                  "dposer_lbs_backward")
+        if saved is not None:
+            dv[:, uniq] = saved                        # the incoming gradient is handed back as it came
         if ctx.batched:
             g_vs, g_jr = d_vposed, d_jrest
         else:

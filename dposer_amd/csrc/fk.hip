@@ -598,6 +598,7 @@ struct BodyTuning {
     int64_t fk_small_max = 8192;          // DPOSER_FK_SMALL_MAX: up to this many poses FK runs one wave per pose / one lane per joint
     int64_t joint_stream_min = 1536;      // DPOSER_LBS_JOINT_STREAM_MIN: from this batch the streaming joint-gradient kernel is used
     bool blend_fp32 = false;              // DPOSER_LBS_BLEND=fp32: exact-fp32 pose-blend chain
+    int skin_mode = 2;                    // DPOSER_SKIN_WAVE=0: one vertex per thread and iteration (k_skin) instead of four in flight (A/B)
     void load() {
         const char* e = getenv("DPOSER_FK_SMALL_MAX");
         fk_small_max = e ? atoll(e) : (int64_t)8192;
@@ -605,6 +606,8 @@ struct BodyTuning {
         joint_stream_min = e ? atoll(e) : (int64_t)1536;
         e = getenv("DPOSER_LBS_BLEND");
         blend_fp32 = e && e[0] == 'f';
+        e = getenv("DPOSER_SKIN_WAVE");
+        skin_mode = e ? atoi(e) : 2;
     }
 };
 static BodyTuning& body_tuning() {
@@ -811,6 +814,31 @@ struct SkinArgs {
     const float* transl;       // [B][3] or null
     float* verts;              // [B][V][3]
 };
+// T = sum_k w_k A[idx_k] for one vertex.  K = 4 (every SMPL-family asset: at most four bones per vertex) fetches the ELL row as ONE
+// 16-byte load per table: as four dword loads per table, each wave instruction touched 64 lanes x 16-byte stride = eight 128-B lines at
+// a quarter density, and the eight of them were more than half of the kernel's vector-memory work.
+__device__ __forceinline__ void skin_transform(const SkinArgs& a, const float* sA, int v, float (&T)[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = 0.f;
+    if (a.K == 4) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.skin_w + (int64_t)v * 4);
+        const int4 j4 = *reinterpret_cast<const int4*>(a.skin_idx + (int64_t)v * 4);
+        const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* Aj = sA + jj[k] * 12;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] += w4[k] * Aj[i];
+        }
+    } else {
+        for (int k = 0; k < a.K; ++k) {
+            const float w = a.skin_w[(int64_t)v * a.K + k];
+            const float* Aj = sA + a.skin_idx[(int64_t)v * a.K + k] * 12;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] += w * Aj[i];
+        }
+    }
+}
 // (staging the block's coordinates through LDS so that they enter and leave as consecutive dwords -- what pays in k_skin_bwd -- was
 //  measured SLOWER here: 461 -> 569 us at 4096 poses, four extra barriers per 256 vertices)
 __global__ void __launch_bounds__(256) k_skin(SkinArgs a) {
@@ -825,18 +853,64 @@ __global__ void __launch_bounds__(256) k_skin(SkinArgs a) {
         const float* off = a.offsets + b * a.ld_off + (int64_t)v * 3;
         const float px = vs[0] + off[0], py = vs[1] + off[1], pz = vs[2] + off[2];
         float T[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) T[i] = 0.f;
-        for (int k = 0; k < a.K; ++k) {
-            const float w = a.skin_w[(int64_t)v * a.K + k];
-            const float* Aj = sA + a.skin_idx[(int64_t)v * a.K + k] * 12;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] += w * Aj[i];
-        }
+        skin_transform(a, sA, v, T);
         float* o = a.verts + (b * a.V + v) * 3;
         o[0] = T[0] * px + T[1] * py + T[2] * pz + T[3] + tr[0];
         o[1] = T[4] * px + T[5] * py + T[6] * pz + T[7] + tr[1];
         o[2] = T[8] * px + T[9] * py + T[10] * pz + T[11] + tr[2];
+    }
+}
+
+// k_skin with FOUR vertices per thread in flight (K = 4): every load of the four (rest shape, offsets, ELL row as one 16-byte
+// load per table) is issued before the first use.  Round-3 A/Bs on this kernel (tools/lbs_skin_ab.py, 4096 / 16384 poses, LBS
+// forward 0.885 ms with k_skin): this form 0.874 ms; 16-byte ELL loads alone 0.905; a wave-transposed variant (64 vertices = 192
+// consecutive floats per wave, loaded / stored as fully coalesced dwords and turned into one vertex per lane through a
+// wave-private LDS buffer) 0.964-1.0 ms.  PMC shows the waves parked in s_waitcnt 74 % of their cycles at 2.2 TB/s, and neither more
+// loads in flight nor fewer cache-line touches move it: the kernel's 1.03 GB meet the pose-blend GEMM's freshly written 515 MB of
+// offsets on their way out of L2 / MALL -- keeping the offsets out of HBM (a fused skinning epilogue) is what would help, and the
+// per-(pose, vertex) transform T = sum_k w_k A[pose][j_k] makes that epilogue need 256 poses x 55 x 12 floats (675 KB) per tile.
+__global__ void __launch_bounds__(256) k_skin_x4(SkinArgs a) {
+    extern __shared__ float sA[];   // [J][12]
+    const int64_t b = blockIdx.y;
+    for (int i = threadIdx.x; i < a.J * 12; i += 256) sA[i] = a.A[b * a.J * 12 + i];
+    float tr[3] = {0.f, 0.f, 0.f};
+    if (a.transl) { tr[0] = a.transl[b * 3]; tr[1] = a.transl[b * 3 + 1]; tr[2] = a.transl[b * 3 + 2]; }
+    const float* vs_row = a.v_shaped + (a.v_shaped_batched ? b * a.V * 3 : 0);
+    const float* off_row = a.offsets + b * a.ld_off;
+    float* out_row = a.verts + b * a.V * 3;
+    const int vbase = blockIdx.x * 1024 + threadIdx.x;
+    float p[4][3];
+    f32x4 w4[4];
+    int4 j4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int v = vbase + u * 256;
+        const int vc = v < a.V ? v : a.V - 1;                     // clamp: the tail threads load a valid vertex and do not store
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[u][c] = vs_row[(int64_t)vc * 3 + c] + off_row[(int64_t)vc * 3 + c];
+        w4[u] = *reinterpret_cast<const f32x4*>(a.skin_w + (int64_t)vc * 4);
+        j4[u] = *reinterpret_cast<const int4*>(a.skin_idx + (int64_t)vc * 4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int v = vbase + u * 256;
+        const int jj[4] = {j4[u].x, j4[u].y, j4[u].z, j4[u].w};
+        float T[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* Aj = sA + jj[k] * 12;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] += w4[u][k] * Aj[i];
+        }
+        if (v < a.V) {
+            float* o = out_row + (int64_t)v * 3;
+            o[0] = T[0] * p[u][0] + T[1] * p[u][1] + T[2] * p[u][2] + T[3] + tr[0];
+            o[1] = T[4] * p[u][0] + T[5] * p[u][1] + T[6] * p[u][2] + T[7] + tr[1];
+            o[2] = T[8] * p[u][0] + T[9] * p[u][1] + T[10] * p[u][2] + T[11] + tr[2];
+        }
     }
 }
 
@@ -1016,7 +1090,9 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
         s.offsets = offsets; s.ld_off = Cpad; s.v_shaped = v_shaped; s.v_shaped_batched = v_shaped_batched; s.A = A;
         s.skin_idx = skin_idx; s.skin_w = skin_w; s.K = skin_k; s.J = J; s.V = V; s.transl = transl; s.verts = verts;
         dim3 grid((unsigned)ceil_div(V, 256 * 4), (unsigned)batch);
-        hipLaunchKernelGGL(k_skin, grid, dim3(256), J * 12 * sizeof(float), st, s);
+        const int mode = body_tuning().skin_mode;
+        if (mode != 0 && skin_k == 4) hipLaunchKernelGGL(k_skin_x4, grid, dim3(256), J * 12 * sizeof(float), st, s);
+        else hipLaunchKernelGGL(k_skin, grid, dim3(256), J * 12 * sizeof(float), st, s);
         FK_HIP_LAUNCH(hipGetLastError());
     }
     // 4. extra joints + landmarks

@@ -490,6 +490,35 @@ def g17_aux_loss():
     save("g17_aux_loss", **out)
 
 
+def g18_evaler():
+    """G18: the reference's own completion evaluator (lib/dataset/AMASS.py:263-316: part vertex / joint index sets, MPVPE / MPJPE in
+    mm, minimum over hypotheses) with oracle.fk_torch on the synthetic asset standing in for smplx.  Pins the index arithmetic and
+    the reductions, for every body part and for part=None."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import fk_torch
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    asset = make_synthetic_smplx_asset(seed=0)
+
+    class TorchBM:
+        def __call__(self, pose_body=None, **kw):
+            v, j = fk_torch.smplx_forward(asset, pose_body.double())
+            return types.SimpleNamespace(v=v.float(), Jtr=j.float())
+
+    B, H = 6, 3
+    _, raw = toy_batch(B, seed=50)
+    rs = np.random.RandomState(18)
+    outs = (raw.numpy()[:, None, :] + rs.standard_normal((B, H, 63)) * 0.1).astype(np.float32)
+    out = {"gts": raw.numpy().astype(np.float32), "outs": outs}
+    for part in ("left_leg", "right_leg", "left_arm", "right_arm", "trunk", "hands", "legs", "arms", None):
+        ev = ref_amass.Evaler(TorchBM(), part=part)
+        r = ev.multi_eval_bodys(torch.tensor(outs), torch.tensor(out["gts"]))
+        r1 = ev.eval_bodys(torch.tensor(outs[:, 0]), torch.tensor(out["gts"]))
+        tag = part or "all"
+        out[f"{tag}/mpvpe_all"], out[f"{tag}/mpjpe_body"] = np.asarray(r["mpvpe_all"], np.float64), np.asarray(r["mpjpe_body"], np.float64)
+        out[f"{tag}/h0_mpvpe_all"], out[f"{tag}/h0_mpjpe_body"] = np.asarray(r1["mpvpe_all"], np.float64), np.asarray(r1["mpjpe_body"], np.float64)
+    save("g18_evaler", **out)
+
+
 def g8_scalars():
     """G8: marginal_prob / sde / return_alpha_sigma / discretize tables on linspace(1,1e-3,1000)."""
     t = torch.linspace(1.0, 1e-3, 1000)
@@ -667,8 +696,8 @@ def g13_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
-    fns = dict(g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    fns = dict(g18=g18_evaler, g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
                g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
     for w in which:
         fns[w]()

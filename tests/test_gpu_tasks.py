@@ -402,3 +402,24 @@ def test_completion_loop_vp_sde_and_fixed_time_strategy_vs_oracle():
         opt.step()
     slow = obs.to(DEV) * mask.to(DEV) + x.detach() * (1 - mask.to(DEV))
     assert rel_err(t2n(fused), t2n(slow)) < 2e-6
+
+
+@pytest.mark.parametrize("part", ["left_leg", "right_leg", "left_arm", "right_arm", "trunk", "hands", "legs", "arms", None])
+def test_evaler_matches_the_reference_evaluator(part):
+    """g18 = the reference's own Evaler (lib/dataset/AMASS.py:263-316) on oracle.fk_torch bodies: part vertex / joint index sets
+    (joint index + 1 skips the pelvis), per-sample MPVPE / MPJPE in mm, minimum over hypotheses -- against the device evaluator on
+    the HIP body model (same synthetic asset)."""
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    from dposer_amd.dataset.AMASS import Evaler
+    from helpers import load
+    g = load("g18_evaler")
+    bm = BodyModel(make_synthetic_smplx_asset(seed=0)).to(DEV)
+    ev = Evaler(bm, part=part)
+    outs, gts = torch.tensor(g["outs"], device=DEV), torch.tensor(g["gts"], device=DEV)
+    tag = part or "all"
+    r = ev.multi_eval_bodys(outs, gts)
+    r0 = ev.eval_bodys(outs[:, 0].contiguous(), gts)
+    for k in ("mpvpe_all", "mpjpe_body"):
+        assert np.abs(r[k] - g[f"{tag}/{k}"]).max() / np.abs(g[f"{tag}/{k}"]).max() < 2e-5, (part, k)      # errors of ~100 mm to 1e-3 mm
+        assert np.abs(r0[k].cpu().numpy() - g[f"{tag}/h0_{k}"]).max() / np.abs(g[f"{tag}/h0_{k}"]).max() < 2e-5, (part, k)

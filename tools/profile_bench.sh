@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_${TAG}_m2 -o m2 -- python3 $R/bench.py $SHORT > $R/gpurun_out/${TAG}_pmc_m2.log 2>&1
 cd $R
 python3 tools/rocpd_summary.py --mfma $(find gpurun_out/pmc_${TAG}_m1 gpurun_out/pmc_${TAG}_m2 -name "*.db") > gpurun_out/${TAG}_pmc_mfma.md
-python3 tools/rocpd_summary.py --mfma-json $(find gpurun_out/pmc_${TAG}_m1 gpurun_out/pmc_${TAG}_m2 -name "*.db") > gpurun_out/${TAG}_pmc_mfma.json
+python3 tools/rocpd_summary.py --mfma-json $(find gpurun_out/pmc_${TAG}_m1 gpurun_out/pmc_${TAG}_m2 -name "*.db") > gpurun_out/${TAG}_pmc_mfma.json   # -> profiles/pmc_mfma.json (bench.py looks it up)
 rm -rf gpurun_out/pmc_${TAG}_m1 gpurun_out/pmc_${TAG}_m2
 python3 tools/rocpd_summary.py $(find gpurun_out/prof_$TAG -name "*.db" | head -1) > gpurun_out/${TAG}_bench_kernel_stats.md
 python3 tools/rocpd_summary.py --pmc $(find gpurun_out/pmc_${TAG}_rd gpurun_out/pmc_${TAG}_wr -name "*.db") > gpurun_out/${TAG}_pmc_hbm_traffic.md
