@@ -117,39 +117,26 @@ template <typename Epi> struct EpiRing<Epi, decltype((void)Epi::kRingPerWave)> {
 // Variants that were built and measured without gain (DMA issue interleaved between MFMA GROUPS under s_setprio,
 // delayed DMA issue for the second wave of each SIMD, register staging, persistent workgroups) are in DESIGN.md 4.1.
 // Epi::apply(params, acc, channel_base, sample_base, lane, wave row id, split, staged params, stride, scratch).
-template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int NB = 2>
-__global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_ft_kernel(GemmArgs g, typename Epi::Params ep) {
+// One output tile (cblk, sblk) [x one k-split] by the C::THREADS threads whose workgroup-local id is `tid` (the whole workgroup in
+// gemm_ft_kernel; a persistent kernel -- gemm_sampler.hip -- calls it tile after tile, or with two half-workgroups side by side on
+// disjoint LDS regions: the barriers inside are workgroup-wide, so both halves must run the same number of stages).
+template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int NB>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi::Params& ep, int cblk, int sblk, int split, unsigned char* smem, int tid) {
     static_assert(KB % 2 == 0, "fragment double buffering assumes an even number of k-blocks per stage");
     static_assert(NB >= 2 && NB <= 4, "ring depth");
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
     typedef typename Mma<T>::Frag Frag;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WS, ws = wave % WS;
-
-    const int ntiles = g.n_cblk * g.n_sblk;
-    int L, split;
-    if (g.ksplit >= 8 && (g.ksplit & 7) == 0) {
-        // split-K (wgrad): hardware XCD = linear block id % 8.  Put a k-range on ONE XCD with all output tiles, so each
-        // slice of the two operands is fetched from HBM once and shared through that XCD's L2 by every tile.
-        const int lin = blockIdx.x + blockIdx.y * gridDim.x;
-        split = lin % g.ksplit;
-        L = lin / g.ksplit;
-    } else {
-        L = xcd_remap(blockIdx.x, ntiles);
-        split = blockIdx.y;
-    }
-    const int cblk = L % g.n_cblk;
-    const int sblk = L / g.n_cblk;
 
     constexpr int NPAR = EpiParamArrays<Epi>::value;
     float* lds_par = reinterpret_cast<float*>(smem + NB * C::STAGE_BYTES);   // [NPAR][CT*32]
     if constexpr (NPAR > 0) {
-        for (int i = threadIdx.x; i < NPAR * C::CT * 32; i += C::THREADS) {
+        for (int i = tid; i < NPAR * C::CT * 32; i += C::THREADS) {
             const int a = i / (C::CT * 32), c = i % (C::CT * 32);
             lds_par[i] = Epi::param_array(ep, a)[cblk * C::CT * 32 + c];
         }
@@ -345,6 +332,24 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
         Epi::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
                                     sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32, wave_scratch);
     }
+}
+
+template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int NB = 2>
+__global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_ft_kernel(GemmArgs g, typename Epi::Params ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int ntiles = g.n_cblk * g.n_sblk;
+    int L, split;
+    if (g.ksplit >= 8 && (g.ksplit & 7) == 0) {
+        // split-K (wgrad): hardware XCD = linear block id % 8.  Put a k-range on ONE XCD with all output tiles, so each
+        // slice of the two operands is fetched from HBM once and shared through that XCD's L2 by every tile.
+        const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+        split = lin % g.ksplit;
+        L = lin / g.ksplit;
+    } else {
+        L = xcd_remap(blockIdx.x, ntiles);
+        split = blockIdx.y;
+    }
+    gemm_tile<T, WC, WS, TC, TS, KB, Epi, NB>(g, ep, L % g.n_cblk, L / g.n_cblk, split, smem, (int)threadIdx.x);
 }
 
 template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int NB = 2>

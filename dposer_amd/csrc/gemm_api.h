@@ -31,6 +31,33 @@ hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams&
 // bf16, any wgrad tiling (256x256, 128x128, 64x128, 128x64), operands sample-major (gemm_wgrad_tr.h): no transposed activation copies needed
 hipError_t gemm_wgrad_tr(int shape, const WgradTrArgs& g, const WgradParams& p, hipStream_t st);
 
+// ---- persistent Euler-Maruyama sampler (gemm_sampler.hip): one workgroup per block of 256 samples walks every layer of every step
+struct SamplerLayer {
+    const void* W;            // packed layer weights (x-path prefix of the K-concatenated rows)
+    const void* in;           // FT input of the layer (this step's state for layer 0)
+    const void* resid;        // FT residual input or null
+    void* out;                // FT output
+    const float* gamma;
+    const float* beta;
+    int w_stride_blocks;      // k-blocks per packed weight row-block
+    int kblocks;              // k-blocks of the x-path
+};
+struct SamplerArgs {
+    const SamplerLayer* layers;   // DEVICE table [L]
+    int L, H;
+    int64_t Spad;
+    const float* table;           // [n_steps][L][H] time-bias rows
+    const float* tsteps;          // DEVICE [n_steps] t of every step
+    int n_steps;
+    uint32_t step0;               // global index of the first step (Philox offset)
+    const void* Wpost;
+    int post_kblocks;
+    const void* last;             // FT output of the last GroupNorm layer
+    float* x_mean_ft;             // written on the last step
+    EmStepParams em;              // per-step fields (t, step, x_mean_ft) are filled in by the kernel
+};
+hipError_t launch_sampler_persistent(int prec, const SamplerArgs& a, int64_t n_sample_blocks, hipStream_t st);
+
 // ---- optional per-launch profiling (HIP events on the launch stream; off by default) ------------------
 enum GemmEpiKind : int { EPI_GN = 0, EPI_GN_TRAIN, EPI_BIAS_SILU, EPI_ROWMAJOR, EPI_PLAIN_FT, EPI_GN_BWD, EPI_SILU_BWD, EPI_WGRAD, EPI_EM_STEP, EPI_KINDS };
 constexpr int GEMM_PROF_KINDS = EPI_KINDS * 2 * 6;

@@ -241,6 +241,8 @@ struct Ws {
     // shared-t time table
     int64_t npad;
     float *tt_labels, *tt_emb, *tt_temb, *table;
+    float* tt_t;                   // t of every step (persistent sampler)
+    SamplerLayer* smp_layers;      // device table of the persistent sampler's per-layer operands
     // transposed copies / partials / slabs (training)
     char *dyT[MAX_L], *hT[MAX_L], *tembT, *embT, *xinT, *dresT, *dUT;
     float *gn_part[MAX_L], *cs_part_post, *cs_part_se, *slabs;
@@ -303,6 +305,8 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         w.tt_emb = (float*)take(w.npad * E * 4);
         w.tt_temb = (float*)take(w.npad * E * 4);
         w.table = (float*)take(w.npad * (int64_t)L * H * 4);
+        w.tt_t = (float*)take(w.npad * 4);
+        w.smp_layers = (SamplerLayer*)take(MAX_L * sizeof(SamplerLayer));
     } else {
         w.emb = take(Bpad * E * esz);
         w.temb = take(Bpad * E * esz);
@@ -625,6 +629,49 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     const bool fused = !observation && !noise && !traj && h->Cp == h->Dpad;
     if (fused) ea.x_ft = w.xft;
     DP_HIP_LAUNCH(launch_em_update(ea, st));
+    // Persistent form of the fast path (gemm_sampler.hip): one workgroup per 256 samples walks every layer of every step -- no
+    // grid-wide join per layer, no launch per layer.  Same kernels' code per tile: bit-identical samples (tested).  Needs the
+    // 256 x 256 tiling (hidden_dim 1024 groups, batch padded to 256) and the 64-channel post_dense tile.
+    // OFF by default (DPOSER_SAMPLER_PERSISTENT=1 enables it): measured (tools/sampler_ab.py, profiles/r03_sampler_ab.txt)
+    //   65536 samples: 715 us per step against 680 us for the six launches;  32768 / 16384 samples: 453 us against 341 / 182 us.
+    // A workgroup alone on its CU needs 453 us per step (26 us per 256 x 256 x 1024 tile) however few of them run -- so below 256
+    // blocks the launches win by using every CU -- and at 256 blocks the same work takes 715 us: a workgroup re-reads its 512 KB
+    // input panel for each of the 4 channel tiles (the launches let 4 tiles on one XCD share it through L2), 3.3 GB per step
+    // through MALL / HBM, under the chip's power cap.  Removing the grid-wide joins does not pay for that.
+    static const int persistent_env = [] { const char* e = getenv("DPOSER_SAMPLER_PERSISTENT"); return e ? atoi(e) : 0; }();
+    static const int64_t persistent_min = [] { const char* e = getenv("DPOSER_SAMPLER_PERSISTENT_MIN"); return e ? atoll(e) : (int64_t)256; }();
+    if (fused && persistent_env && h->gs == 32 && h->H % 256 == 0 && h->Cp == 64 && w.Bpad % 256 == 0 && w.Bpad >= persistent_min) {
+        SamplerLayer tab[MAX_L];
+        std::memset(tab, 0, sizeof(tab));
+        for (int l = 0; l < h->L; ++l) {
+            const LayerOff& lo = h->layer[l];
+            tab[l].W = packed + h->pk_wl[l];
+            tab[l].in = l == 0 ? (const void*)w.xin : (const void*)w.hbuf[(l - 1) % 3];
+            tab[l].resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[(l - 2) % 3] : nullptr;
+            tab[l].out = w.hbuf[l % 3];
+            tab[l].gamma = flat + lo.gamma;
+            tab[l].beta = flat + lo.beta;
+            tab[l].w_stride_blocks = (lo.kin_pad + h->E) / h->KBS;
+            tab[l].kblocks = lo.kin_pad / h->KBS;
+        }
+        DP_CHECK_HIP(hipMemcpyAsync(w.smp_layers, tab, sizeof(SamplerLayer) * h->L, hipMemcpyHostToDevice, st));
+        DP_CHECK_HIP(hipMemcpyAsync(w.tt_t, timesteps_host + start_step, n_run * sizeof(float), hipMemcpyHostToDevice, st));
+        // (both copies come from host memory that must stay valid until they have executed: pageable -> the runtime stages them
+        //  before returning; `tab` lives on this stack frame)
+        SamplerArgs sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.layers = w.smp_layers; sa.L = h->L; sa.H = h->H; sa.Spad = w.Bpad; sa.table = w.table; sa.tsteps = w.tt_t; sa.n_steps = n_run;
+        sa.step0 = (uint32_t)start_step; sa.Wpost = packed + h->pk_wpost; sa.post_kblocks = h->H / h->KBS; sa.last = w.hbuf[(h->L - 1) % 3];
+        sa.x_mean_ft = w.xmft;
+        EmStepParams& p = sa.em;
+        p.bias = flat + h->off_post_b; p.x_ft = w.xft; p.x_mean_ft = nullptr; p.xin = w.xin;
+        p.sigmas = sigmas; p.sde = make_sde_dev(sc); p.t = 0.f; p.num_scales = h->d.num_scales;
+        p.scale_by_sigma = h->d.scale_by_sigma; p.D = h->D; p.Cp = h->Cp; p.QD = (h->D + 3) >> 2; p.S_valid = B;
+        p.seed = seed; p.step = 0;
+        DP_HIP_LAUNCH(launch_sampler_persistent(h->f32 ? PREC_FP32 : PREC_BF16, sa, w.Bpad / 256, st));
+        DP_HIP_LAUNCH(launch_ft_to_rows(w.xft, x, w.xmft, x_mean, B, w.Bpad, h->D, h->Dpad, st));
+        return DPOSER_OK;
+    }
     if (fused) {
         const int shape = final_shape(w.Bpad);
         for (int i = 0; i < n_run; ++i) {

@@ -1,5 +1,6 @@
 """GPU parity tests of the score path: HIP kernels (through the C ABI) vs the CPU oracle and vs the
 golden vectors captured from the reference.  Tolerances: gpu_common.TOL_FP32 / TOL_BF16."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -1055,3 +1056,30 @@ def test_fixed_step_likelihood_and_ode_sampler():
         likelihood.get_likelihood_fn(sde, lambda v: v, method="rk4")
     nfe, x = sampling.get_ode_sampler(sde, (6, 63), lambda v: v, method="euler", n_steps=64, eps=1e-3, device=DEV)(m, z=_dev(g["ode/z"]))
     assert nfe == 64 and torch.isfinite(x).all()
+
+
+def test_persistent_sampler_kernel_returns_the_bits_of_the_launch_path():
+    """gemm_sampler.hip: one workgroup per 256 samples walks every layer of every step (opt-in, DPOSER_SAMPLER_PERSISTENT=1) -- the
+    same tile code as the per-layer launches, so the samples must be bit-identical; run in child processes (the switch is read once)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib, torch; sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden'); sys.path.insert(0, '.')\n"
+            "from gpu_common import make_model\n"
+            "from dposer_amd.algorithms.advanced import sampling, sde_lib\n"
+            "for prec in ('bf16', 'fp32'):\n"
+            "    cfg, m, p = make_model(3, precision=prec)\n"
+            "    m.eval()\n"
+            "    sde = sde_lib.subVPSDE(0.1, 20.0, 12)\n"
+            "    fn = sampling.get_sampling_fn(cfg, sde, (700, 63), lambda v: v, 1e-3, device='cuda:0')\n"
+            "    z = torch.randn(700, 63, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(5))\n"
+            "    _, x = fn(m, z=z, seed=11, traj_stride=0)\n"
+            "    print('SHA', prec, hashlib.sha1(x.cpu().numpy().tobytes()).hexdigest(), bool(torch.isfinite(x).all()))\n")
+    outs = {}
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, DPOSER_SAMPLER_PERSISTENT=flag), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[flag] = [l for l in r.stdout.splitlines() if l.startswith("SHA")]
+        assert len(outs[flag]) == 2 and all(l.endswith("True") for l in outs[flag])
+    assert outs["0"] == outs["1"]
