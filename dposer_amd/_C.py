@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdposer_hip.so")
 
 PREC_BF16, PREC_FP32 = 0, 1
 EMB_POSITIONAL, EMB_FOURIER = 0, 1
+ACTIVATIONS = {"swish": 0, "elu": 1, "relu": 2, "lrelu": 3}      # config.model.nonlinearity -> DPOSER_ACT_*
 SDE_SUBVP, SDE_VP = 0, 1
 WS_INFER, WS_SHARED_T, WS_TRAIN = 0, 1, 2
 
@@ -20,7 +21,7 @@ WS_INFER, WS_SHARED_T, WS_TRAIN = 0, 1, 2
 class ScoreFCDesc(C.Structure):
     _fields_ = [("data_dim", C.c_int32), ("hidden_dim", C.c_int32), ("embed_dim", C.c_int32),
                 ("n_blocks", C.c_int32), ("embedding", C.c_int32), ("scale_by_sigma", C.c_int32),
-                ("num_scales", C.c_int32), ("precision", C.c_int32), ("dropout_p", C.c_float)]
+                ("num_scales", C.c_int32), ("precision", C.c_int32), ("dropout_p", C.c_float), ("activation", C.c_int32)]
 
 
 class SdeDesc(C.Structure):
@@ -101,6 +102,8 @@ SIGNATURES = {
     "dposer_rk_combine_f64": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(C.c_double), i32, C.c_double, i64, vp]),
     "dposer_adam_ema_clip_step_presummed": (C.c_int, [vp, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64,
                                                       f64, f64, i64, f64, vp, vp]),
+    "dposer_adam_ema_clip_step_wd": (C.c_int, [vp, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64,
+                                               f64, f64, f64, i64, f64, vp, i32, vp]),
     "dposer_profile_enable": (None, [i32]),
     "dposer_profile_num_kinds": (i32, []),
     "dposer_profile_collect": (C.c_int, [C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),

@@ -28,12 +28,10 @@ class FusedAdam(optim.Adam):
 
     ``state_dict()`` / ``load_state_dict()`` keep torch's per-parameter layout
     ({'step', 'exp_avg', 'exp_avg_sq'}), so reference checkpoints (run/train.py:393-403) round-trip.
-    Semantics follow torch.optim.Adam (amsgrad=False, maximize=False, weight_decay=0): parameters whose
-    ``.grad`` is None are skipped."""
+    Semantics follow torch.optim.Adam (amsgrad=False, maximize=False; weight_decay = the L2 form, grad += wd * param):
+    parameters whose ``.grad`` is None are skipped."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
-        if weight_decay != 0:
-            raise NotImplementedError("FusedAdam: weight_decay != 0 is not built (reference default is 0)")
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._flat_m = self._flat_v = self._flat_g = self._scratch = None
         self._flat_cache = self._state_views = None
@@ -127,11 +125,12 @@ class FusedAdam(optim.Adam):
             if ema_flat is None:
                 raise _C.DPoserHipError("EMA shadow parameters are not flat-backed")
             omd = ema.next_one_minus_decay()
-        _C.check(_C.lib().dposer_adam_ema_clip_step(_C.ptr(flat), _C.ptr(self._flat_g), _C.ptr(self._flat_m), _C.ptr(self._flat_v),
-                                                    _C.ptr(ema_flat), flat.numel(), lo, hi, len(skip), float(g["lr"]),
-                                                    float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(grad_clip),
-                                                    float(grad_scale), self._step_count, float(omd), _C.ptr(self._scratch),
-                                                    _C.stream_ptr()), "dposer_adam_ema_clip_step")
+        _C.check(_C.lib().dposer_adam_ema_clip_step_wd(_C.ptr(flat), _C.ptr(self._flat_g), _C.ptr(self._flat_m), _C.ptr(self._flat_v),
+                                                       _C.ptr(ema_flat), flat.numel(), lo, hi, len(skip), float(g["lr"]),
+                                                       float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                                       float(g.get("weight_decay", 0.0)), float(grad_clip), float(grad_scale),
+                                                       self._step_count, float(omd), _C.ptr(self._scratch), 0, _C.stream_ptr()),
+                 "dposer_adam_ema_clip_step_wd")
         torch.autograd.graph.increment_version(params)   # the kernel wrote the parameters through raw pointers: tell autograd
         self._publish_state(params, offs, live)
 
@@ -207,11 +206,11 @@ class FusedAdam(optim.Adam):
         slo = (C.c_int64 * 2)(*([s_[0] for s_ in skip] + [0, 0])[:2])
         shi = (C.c_int64 * 2)(*([s_[1] for s_ in skip] + [0, 0])[:2])
         if hi > lo:
-            _C.check(lib.dposer_adam_ema_clip_step_presummed(
+            _C.check(lib.dposer_adam_ema_clip_step_wd(
                 _C.ptr(flat[lo:hi]), _C.ptr(self._flat_g[lo:hi]), _C.ptr(self._flat_m[lo:hi]), _C.ptr(self._flat_v[lo:hi]),
                 _C.ptr(None if ema_flat is None else ema_flat[lo:hi]), hi - lo, slo, shi, len(skip), float(g["lr"]), float(g["betas"][0]),
-                float(g["betas"][1]), float(g["eps"]), float(grad_clip), float(grad_scale), self._step_count, float(omd),
-                _C.ptr(self._scratch), _C.stream_ptr()), "dposer_adam_ema_clip_step_presummed")
+                float(g["betas"][1]), float(g["eps"]), float(g.get("weight_decay", 0.0)), float(grad_clip), float(grad_scale),
+                self._step_count, float(omd), _C.ptr(self._scratch), 1, _C.stream_ptr()), "dposer_adam_ema_clip_step_wd")
         torch.autograd.graph.increment_version(params)
         self._sharded = (list(bounds), list(live))      # moments are complete on the owning ranks only: see gather_state()
 

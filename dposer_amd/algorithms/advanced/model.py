@@ -211,9 +211,10 @@ class ScoreModelFC(nn.Module):
     def _engine(self) -> ScoreEngine:
         eng = self._engines.get(self.precision)
         if eng is None:
-            if self.config.model.nonlinearity.lower() != "swish":
-                raise NotImplementedError("the HIP score path fuses SiLU ('swish'); other activations are not built")
-            eng = ScoreEngine(data_dim=self.n_poses * self.joint_dim, hidden_dim=self.hidden_dim, embed_dim=self.embed_dim,
+            act = self.config.model.nonlinearity.lower()          # get_act (model.py:54-66): elu / relu / lrelu / swish
+            if act not in _C.ACTIVATIONS:
+                raise NotImplementedError("activation function does not exist!")
+            eng = ScoreEngine(activation=act, data_dim=self.n_poses * self.joint_dim, hidden_dim=self.hidden_dim, embed_dim=self.embed_dim,
                               n_blocks=self.n_blocks, embedding=self.time_embedding_type,
                               scale_by_sigma=bool(self.config.model.scale_by_sigma), num_scales=int(self.sigmas.numel()),
                               dropout_p=float(self.config.model.dropout), precision=self.precision)

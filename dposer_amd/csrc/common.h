@@ -288,6 +288,11 @@ template <typename T> __device__ __forceinline__ T from_f32(float f);
 template <> __device__ __forceinline__ float from_f32<float>(float f) { return f; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float f) { return (__bf16)f; }
 
+// Activations of lib/algorithms/advanced/model.py:54-66 (get_act): the shipped configuration is 'swish' (= SiLU), which the hot
+// tilings compile in; 'elu' / 'relu' / 'lrelu' (negative slope 0.2) run through the ACTRT epilogue instantiations (128-wide
+// tilings), which pick the function from a wave-uniform runtime code.
+enum : int { DP_ACT_SWISH = 0, DP_ACT_ELU = 1, DP_ACT_RELU = 2, DP_ACT_LRELU = 3 };
+
 // precise / fast scalar math selected by the storage type (fp32 mode = parity mode)
 template <bool PRECISE> __device__ __forceinline__ float silu_f(float a) {
     if (PRECISE) return a / (1.0f + expf(-a));
@@ -297,4 +302,22 @@ template <bool PRECISE> __device__ __forceinline__ float silu_f(float a) {
 template <bool PRECISE> __device__ __forceinline__ float dsilu_f(float a) {
     float s = PRECISE ? 1.0f / (1.0f + expf(-a)) : __builtin_amdgcn_rcpf(1.0f + __expf(-a));
     return s * (1.0f + a * (1.0f - s));
+}
+
+// runtime-selected activation and its derivative (act is wave-uniform)
+template <bool PRECISE> __device__ __forceinline__ float act_rt(float a, int act) {
+    switch (act) {
+        case DP_ACT_ELU: return a > 0.f ? a : (PRECISE ? expm1f(a) : __expf(a) - 1.0f);     // nn.ELU(alpha = 1)
+        case DP_ACT_RELU: return fmaxf(a, 0.f);
+        case DP_ACT_LRELU: return a > 0.f ? a : 0.2f * a;                                   // nn.LeakyReLU(0.2)
+        default: return silu_f<PRECISE>(a);
+    }
+}
+template <bool PRECISE> __device__ __forceinline__ float dact_rt(float a, int act) {
+    switch (act) {
+        case DP_ACT_ELU: return a > 0.f ? 1.0f : (PRECISE ? expf(a) : __expf(a));
+        case DP_ACT_RELU: return a > 0.f ? 1.0f : 0.f;
+        case DP_ACT_LRELU: return a > 0.f ? 1.0f : 0.2f;
+        default: return dsilu_f<PRECISE>(a);
+    }
 }

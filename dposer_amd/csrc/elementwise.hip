@@ -875,7 +875,8 @@ __global__ void __launch_bounds__(256) k_adam_ema(AdamArgs a) {
         float p = a.p[i];
         const bool skip = (i >= a.skip_lo[0] && i < a.skip_hi[0]) || (i >= a.skip_lo[1] && i < a.skip_hi[1]);
         if (!skip) {
-            const float g = a.g[i] * coef;
+            float g = a.g[i] * coef;
+            if (a.weight_decay != 0.f) g = g + a.weight_decay * p;   // torch.optim.Adam: grad = grad.add(param, alpha=weight_decay)
             float m = a.m[i], v = a.v[i];
             m = m + (g - m) * a.one_minus_beta1;                  // exp_avg.lerp_(grad, 1 - beta1)
             v = v * a.beta2 + a.one_minus_beta2 * (g * g);        // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)

@@ -113,12 +113,13 @@ struct GNParams {
     DropoutCfg drop;
     void* outT;            // TRAIN, optional: the output again as FT [H][Spad] (operand of the wgrad GEMMs)
     int64_t Spad;
+    int act;               // DP_ACT_* (read by the ACTRT instantiations only; 0 = swish)
 };
 // RESID: -1 = decide at run time from Params::resid (and null-check the optional outputs); 0 / 1 = residual input absent /
 // present at compile time AND no other branch in the code: dropout is always drawn
 // (DropoutCfg must then be valid: thr = 65536, scale = 1 when disabled), outT must be non-null.  The branch-free form is what
 // the pipelined kernel (gemm_pipe.h) needs: a branch would split the basic block its MFMA / VALU interleave is scheduled in.
-template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
+template <typename T, bool TRAIN, int RESID = -1, bool ACTRT = false> struct EpiGN {
     typedef GNParams Params;
     static constexpr bool FLAT = RESID >= 0;
     static constexpr int kScratchPerWave = TRAIN ? TileT<T>::SCRATCH_BYTES : 0;
@@ -212,7 +213,8 @@ template <typename T, bool TRAIN, int RESID = -1> struct EpiGN {
                     cy.v[4 * q + r] *= cy.rstd;                                   // x_hat
                     const float a_ = g4[r] * cy.v[4 * q + r] + e4[r];
                     float y;
-                    if constexpr (!TRAIN) y = silu_f<PRECISE>(a_);
+                    if constexpr (ACTRT) y = TRAIN ? act_rt<PRECISE>(a_, pp.act) * dscale : act_rt<PRECISE>(a_, pp.act);
+                    else if constexpr (!TRAIN) y = silu_f<PRECISE>(a_);
                     else if constexpr (PRECISE) y = silu_f<true>(a_) * dscale;
                     else y = a_ * __builtin_amdgcn_rcpf(__builtin_fmaf(__expf(-a_), dinv, dinv));
                     if constexpr (TRAIN) y = __uint_as_float(__float_as_uint(y) & (uint32_t)__builtin_amdgcn_sbfe((int)cy.bits, 4 * q + r, 1));
@@ -271,8 +273,9 @@ struct BiasSiLUParams {
     int N;
     void* outT;    // TRAIN, optional: FT [N][Spad]
     int64_t Spad;
+    int act;       // DP_ACT_* (ACTRT instantiations)
 };
-template <typename T, bool TRAIN> struct EpiBiasSiLU {
+template <typename T, bool TRAIN, bool ACTRT = false> struct EpiBiasSiLU {
     typedef BiasSiLUParams Params;
     static constexpr int kScratchPerWave = TRAIN ? TileT<T>::SCRATCH_BYTES : 0;
     static constexpr int kParamArrays = 1;
@@ -297,7 +300,7 @@ template <typename T, bool TRAIN> struct EpiBiasSiLU {
                 const int64_t tb = ft_tile_base<T>(sbase + ts * 32, c0, p.N);
                 float u[16], o[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { u[r] = acc[tc][ts][r] + bia[r]; o[r] = silu_f<PRECISE>(u[r]); }
+                for (int r = 0; r < 16; ++r) { u[r] = acc[tc][ts][r] + bia[r]; o[r] = ACTRT ? act_rt<PRECISE>(u[r], pp.act) : silu_f<PRECISE>(u[r]); }
                 if (TRAIN) TileIO<T>::store(p.pre + tb, lane, u);
                 TileIO<T>::store(p.out + tb, lane, o);
                 if (TRAIN && pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, o);
@@ -584,9 +587,10 @@ struct GNBwdParams {
     float drop_scale;      // 1/(1-p) of the forward pass (1 when dropout was off)
     void* dyT;             // optional: dy again as FT [H][Spad]
     int64_t Spad;
+    int act;               // DP_ACT_* (ACTRT instantiations)
 };
 // ABL (tuner only): 1 = no parameter-gradient sums, 2 = no SiLU', 4 = ds_bpermute butterflies, 8 = loads / stores only
-template <typename T, int ABL = 0> struct EpiGNBwd {
+template <typename T, int ABL = 0, bool ACTRT = false> struct EpiGNBwd {
     typedef GNBwdParams Params;
     static constexpr int kScratchPerWave = TileT<T>::SCRATCH_BYTES;
     static constexpr int kMinWaves = 2;   // keep two 256-thread workgroups per CU (register-heavy epilogue)
@@ -699,7 +703,7 @@ template <typename T, int ABL = 0> struct EpiGNBwd {
                         const int i = 4 * q + r;
                         const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, i, 1);
                         const float gg = __uint_as_float(__float_as_uint(g[i]) & m);
-                        const float ds = dsilu_f<PRECISE>(g4[r] * xh[i] + e4[r]);
+                        const float ds = ACTRT ? dact_rt<PRECISE>(g4[r] * xh[i] + e4[r], pp.act) : dsilu_f<PRECISE>(g4[r] * xh[i] + e4[r]);
                         const float da = gg * ds;                  // (the 1/(1-p) factor is applied to gamma and to the sums)
                         stat[i] += da * xh[i];
                         stat[16 + i] += da;
@@ -816,7 +820,7 @@ template <typename T, int ABL = 0> struct EpiGNBwd {
                             // keep decision as an all-ones / all-zeros word: one v_bfe_i32 + one v_and per element
                             const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, i, 1);
                             const float gg = __uint_as_float(__float_as_uint(g[i]) & m);
-                            const float ds = (ABL & 2) ? 1.0f : dsilu_f<PRECISE>(g4[r] * xh[i] + e4[r]);
+                            const float ds = (ABL & 2) ? 1.0f : (ACTRT ? dact_rt<PRECISE>(g4[r] * xh[i] + e4[r], pp.act) : dsilu_f<PRECISE>(g4[r] * xh[i] + e4[r]));
                             const float da = gg * ds;                  // (the 1/(1-p) factor is applied to gamma and to the sums)
                             if constexpr ((ABL & 1) == 0) {
                                 stat[i] += da * xh[i];
@@ -862,8 +866,9 @@ struct SiLUBwdParams {
     int64_t S_valid;
     void* outT;        // optional: FT [N][Spad]
     int64_t Spad;
+    int act;           // DP_ACT_* (ACTRT instantiations)
 };
-template <typename T> struct EpiSiLUBwd {
+template <typename T, bool ACTRT = false> struct EpiSiLUBwd {
     typedef SiLUBwdParams Params;
     static constexpr int kScratchPerWave = TileT<T>::SCRATCH_BYTES;
     template <int TC, int TS>
@@ -880,7 +885,7 @@ template <typename T> struct EpiSiLUBwd {
                 float u[16], o[16];
                 TileIO<T>::load(p.pre + tb, lane, u);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = (s < p.S_valid) ? acc[tc][ts][r] * dsilu_f<PRECISE>(u[r]) : 0.f;
+                for (int r = 0; r < 16; ++r) o[r] = (s < p.S_valid) ? acc[tc][ts][r] * (ACTRT ? dact_rt<PRECISE>(u[r], pp.act) : dsilu_f<PRECISE>(u[r])) : 0.f;
                 TileIO<T>::store(p.out + tb, lane, o);
                 if (pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, cbase + tc * 32, pp.Spad), scr, lane, o);
             }

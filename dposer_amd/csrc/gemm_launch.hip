@@ -115,11 +115,19 @@ hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNP
         if (gs == 64) { if (train) { DISPATCH_GS(E_TRAIN, 64); } DISPATCH_GS(E_INFER, 64); }
         return hipErrorInvalidConfiguration;
     }
+    if (p.act != DP_ACT_SWISH) {     // elu / relu / lrelu: runtime-selected activation, 128-wide tilings only
+        if (train) { typedef EpiGN<__bf16, true, -1, true> A; typedef EpiGN<float, true, -1, true> B; DISPATCH(A, B, M_MID | M_SMALL); }
+        typedef EpiGN<__bf16, false, -1, true> A; typedef EpiGN<float, false, -1, true> B; DISPATCH(A, B, M_MID | M_SMALL);
+    }
     if (train) { typedef EpiGN<__bf16, true> A; typedef EpiGN<float, true> B; DISPATCH(A, B, M_MAIN); }
     typedef EpiGN<__bf16, false> A; typedef EpiGN<float, false> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_bias_silu(int prec, bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st) {
     PROF(EPI_BIAS_SILU);
+    if (p.act != DP_ACT_SWISH) {
+        if (train) { typedef EpiBiasSiLU<__bf16, true, true> A; typedef EpiBiasSiLU<float, true, true> B; DISPATCH(A, B, M_MID | M_SMALL); }
+        typedef EpiBiasSiLU<__bf16, false, true> A; typedef EpiBiasSiLU<float, false, true> B; DISPATCH(A, B, M_MID | M_SMALL);
+    }
     if (train) { typedef EpiBiasSiLU<__bf16, true> A; typedef EpiBiasSiLU<float, true> B; DISPATCH(A, B, M_MAIN); }
     typedef EpiBiasSiLU<__bf16, false> A; typedef EpiBiasSiLU<float, false> B; DISPATCH(A, B, M_MAIN);
 }
@@ -143,10 +151,12 @@ hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams
         if (gs == 64) { DISPATCH_GS(E_BWD, 64); }
         return hipErrorInvalidConfiguration;
     }
+    if (p.act != DP_ACT_SWISH) { typedef EpiGNBwd<__bf16, 0, true> A; typedef EpiGNBwd<float, 0, true> B; DISPATCH(A, B, M_MID | M_SMALL); }
     typedef EpiGNBwd<__bf16> A; typedef EpiGNBwd<float> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st) {
     PROF(EPI_SILU_BWD);
+    if (p.act != DP_ACT_SWISH) { typedef EpiSiLUBwd<__bf16, true> A; typedef EpiSiLUBwd<float, true> B; DISPATCH(A, B, M_MID | M_SMALL); }
     typedef EpiSiLUBwd<__bf16> A; typedef EpiSiLUBwd<float> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_wgrad_tr(int shape, const WgradTrArgs& g, const WgradParams& p, hipStream_t st) {

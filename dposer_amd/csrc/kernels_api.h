@@ -238,5 +238,6 @@ struct AdamArgs {          // losses.py:44-58 optimize_fn + torch.optim.Adam + e
     float one_minus_beta1, beta2, one_minus_beta2, eps;
     float bc2_sqrt;        // sqrt(1 - beta2^t)
     float ema_one_minus_decay;
+    float weight_decay;    // torch.optim.Adam(weight_decay): grad += weight_decay * param (after the clip, before the moments); 0 = off
 };
 hipError_t launch_adam_ema(const AdamArgs& a, hipStream_t st);

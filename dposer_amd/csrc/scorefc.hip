@@ -86,6 +86,9 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
     DP_CHECK_ARG(desc->data_dim > 0 && desc->data_dim <= 512, "data_dim must be in 1..512");
     DP_CHECK_ARG(desc->precision == DPOSER_PREC_BF16 || desc->precision == DPOSER_PREC_FP32, "bad precision");
     DP_CHECK_ARG(desc->dropout_p >= 0.f && desc->dropout_p < 1.f, "dropout_p must be in [0,1)");
+    DP_CHECK_ARG(desc->activation >= DPOSER_ACT_SWISH && desc->activation <= DPOSER_ACT_LRELU, "bad activation");
+    DP_CHECK_ARG(desc->activation == DPOSER_ACT_SWISH || desc->hidden_dim == 1024,
+                 "elu / relu / lrelu are built for hidden_dim 1024 (the tile-per-group epilogues); other widths are swish only");
     auto* h = new dposer_scorefc_s();
     h->d = *desc;
     h->D = desc->data_dim;
@@ -211,7 +214,9 @@ extern "C" int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat, void* 
 static int64_t pad_batch(int64_t B) { return B <= 512 ? round_up(B, 64) : round_up(B, 256); }
 // `channels` = output channels of the GEMM (H = 1024 for the GroupNorm layers, E for the time branch): the 256x256 tiling
 // needs them to be a multiple of 256 (embed_dim may be any multiple of 128).
+static thread_local int g_act = DPOSER_ACT_SWISH;   // activation of the handle whose call is running (the 256 x 256 tiling compiles swish in)
 static int main_shape(int64_t Spad, int channels = 1024, int gs = 32) {
+    if (g_act != DPOSER_ACT_SWISH) return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL;
     static const int64_t big_min = [] { const char* e = getenv("DPOSER_BIG_MIN_BATCH"); return e ? atoll(e) : (int64_t)16384; }();
     if (gs == 32 && Spad % 256 == 0 && Spad >= big_min && channels % 256 == 0) return SHAPE_BIG;   // (generic group sizes: 128-wide tilings)
     if (Spad % 128 == 0) return SHAPE_MID;
@@ -221,7 +226,7 @@ static int main_shape(int64_t Spad, int channels = 1024, int gs = 32) {
 // 32768 samples up (227 vs 257 us at 65536, 2.52 vs 2.59 ms per step at 32768, a tie at 16384).  DPOSER_GNBWD_BIG = 0 / 1 forces it.
 static int gnbwd_shape(int64_t Spad, int gs = 32) {
     static const int forced = [] { const char* e = getenv("DPOSER_GNBWD_BIG"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
-    const bool big = gs == 32 && (forced >= 0 ? forced == 1 : Spad >= 32768);
+    const bool big = gs == 32 && g_act == DPOSER_ACT_SWISH && (forced >= 0 ? forced == 1 : Spad >= 32768);
     if (big && Spad % 256 == 0) return SHAPE_BIG;
     return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL;
 }
@@ -424,6 +429,7 @@ static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* pack
     p.H = h->H;
     p.outT = nullptr;
     p.Spad = Bpad;
+    p.act = h->d.activation;
     p.drop = drop_cfg(h, train, l, seed, step);
     DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, train, shape, g, p, st, h->gs));
     return DPOSER_OK;
@@ -458,12 +464,14 @@ static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, 
     p.N = h->E;
     p.outT = tembT;
     p.Spad = Bpad;
+    p.act = h->d.activation;
     DP_HIP_LAUNCH(gemm_bias_silu(h->f32 ? PREC_FP32 : PREC_BF16, train, shape, g, p, st));
     return DPOSER_OK;
 }
 
 static int check_common(dposer_scorefc_t h, const float* flat, const void* packed, void* ws, int64_t batch) {
     DP_CHECK_ARG(h && flat && packed && ws, "null argument");
+    g_act = h->d.activation;
     DP_CHECK_ARG(batch > 0, "batch must be positive");
     DP_CHECK_ARG(((uintptr_t)flat & 15) == 0, "flat_params must be 16-byte aligned");
     DP_CHECK_ARG(((uintptr_t)packed & 255) == 0 && ((uintptr_t)ws & 255) == 0, "packed / workspace must be 256-byte aligned");
@@ -517,7 +525,7 @@ static int build_time_table(dposer_scorefc_s* h, const float* flat, const char* 
         GemmArgs g = gemm_args(packed + h->pk_wse32, E / 8, E / (shape_ct(shape) * 32), (int)(npad / (shape_st(shape) * 32)));
         add_seg(g, w.tt_emb, E / 8);
         BiasSiLUParams p;
-        p.bias = flat + h->off_se_b; p.out = w.tt_temb; p.pre = nullptr; p.N = E; p.outT = nullptr; p.Spad = npad;
+        p.bias = flat + h->off_se_b; p.out = w.tt_temb; p.pre = nullptr; p.N = E; p.outT = nullptr; p.Spad = npad; p.act = h->d.activation;
         DP_HIP_LAUNCH(gemm_bias_silu(PREC_FP32, false, shape, g, p, st));
     }
     {
@@ -640,7 +648,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     // through MALL / HBM, under the chip's power cap.  Removing the grid-wide joins does not pay for that.
     static const int persistent_env = [] { const char* e = getenv("DPOSER_SAMPLER_PERSISTENT"); return e ? atoi(e) : 0; }();
     static const int64_t persistent_min = [] { const char* e = getenv("DPOSER_SAMPLER_PERSISTENT_MIN"); return e ? atoll(e) : (int64_t)256; }();
-    if (fused && persistent_env && h->gs == 32 && h->H % 256 == 0 && h->Cp == 64 && w.Bpad % 256 == 0 && w.Bpad >= persistent_min) {
+    if (fused && persistent_env && h->d.activation == DPOSER_ACT_SWISH && h->gs == 32 && h->H % 256 == 0 && h->Cp == 64 && w.Bpad % 256 == 0 && w.Bpad >= persistent_min) {
         SamplerLayer tab[MAX_L];
         std::memset(tab, 0, sizeof(tab));
         for (int l = 0; l < h->L; ++l) {
@@ -915,7 +923,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         GNParams p;
         p.bias = reinterpret_cast<const float*>(packed + h->pk_bias_cat) + (int64_t)l * h->H;
         p.gamma = flat + lo.gamma; p.beta = flat + lo.beta; p.out = w.hbuf[l]; p.resid = resid; p.xhat = w.xhat[l]; p.aux = w.aux[l];
-        p.H = h->H; p.drop = drop_cfg(h, dropout_on, l, seed, step);
+        p.H = h->H; p.drop = drop_cfg(h, dropout_on, l, seed, step); p.act = h->d.activation;
         p.outT = tr ? nullptr : w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
         DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, true, shape, g, p, st, h->gs));
     }
@@ -1053,7 +1061,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         p.xhat = w.xhat[j]; p.aux = w.aux[j]; p.gamma = flat + h->layer[j].gamma; p.beta = flat + h->layer[j].beta;
         p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B;
         p.drop_scale = (dropout_on && h->d.dropout_p > 0.f) ? 1.0f / (1.0f - h->d.dropout_p) : 1.0f;   // the decisions themselves come from the forward pass (GnAux)
-        p.dyT = (want_w && !tr) ? w.dyT[j] : nullptr; p.Spad = Bpad;
+        p.dyT = (want_w && !tr) ? w.dyT[j] : nullptr; p.Spad = Bpad; p.act = h->d.activation;
         DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st, h->gs));
         if (!want_w) continue;
         if (two) {
@@ -1095,7 +1103,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         GemmArgs g = gemm_args(packed + h->pk_wtT_all, L * H / KBS, E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
         for (int l = 0; l < L; ++l) add_seg(g, w.dy[l], H / KBS);
         SiLUBwdParams p;
-        p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B; p.outT = tr ? nullptr : w.dUT; p.Spad = Bpad;
+        p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B; p.outT = tr ? nullptr : w.dUT; p.Spad = Bpad; p.act = h->d.activation;
         DP_HIP_LAUNCH(gemm_silu_bwd(prec, shape, g, p, st));
     }
     if (two) {
@@ -1209,24 +1217,33 @@ extern "C" int dposer_grad_sqnorm(const float* grad, int64_t n, float* scratch, 
 }
 static int adam_step_impl(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n, const int64_t* skip_lo_host,
                           const int64_t* skip_hi_host, int32_t n_skip, double lr, double beta1, double beta2, double eps, double grad_clip,
-                          double grad_scale, int64_t adam_step, double ema_one_minus_decay, float* scratch, bool presummed, void* stream);
+                          double grad_scale, int64_t adam_step, double ema_one_minus_decay, float* scratch, bool presummed, void* stream,
+                          double weight_decay);
 extern "C" int dposer_adam_ema_clip_step(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n,
                                          const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
                                          double beta1, double beta2, double eps, double grad_clip, double grad_scale,
                                          int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream) {
     return adam_step_impl(flat, grad, m, v, ema, n, skip_lo_host, skip_hi_host, n_skip, lr, beta1, beta2, eps, grad_clip, grad_scale, adam_step,
-                          ema_one_minus_decay, scratch, false, stream);
+                          ema_one_minus_decay, scratch, false, stream, 0.0);
+}
+extern "C" int dposer_adam_ema_clip_step_wd(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n,
+                                            const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
+                                            double beta1, double beta2, double eps, double weight_decay, double grad_clip, double grad_scale,
+                                            int64_t adam_step, double ema_one_minus_decay, float* scratch, int32_t presummed, void* stream) {
+    return adam_step_impl(flat, grad, m, v, ema, n, skip_lo_host, skip_hi_host, n_skip, lr, beta1, beta2, eps, grad_clip, grad_scale, adam_step,
+                          ema_one_minus_decay, scratch, presummed != 0, stream, weight_decay);
 }
 extern "C" int dposer_adam_ema_clip_step_presummed(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n,
                                                    const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
                                                    double beta1, double beta2, double eps, double grad_clip, double grad_scale,
                                                    int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream) {
     return adam_step_impl(flat, grad, m, v, ema, n, skip_lo_host, skip_hi_host, n_skip, lr, beta1, beta2, eps, grad_clip, grad_scale, adam_step,
-                          ema_one_minus_decay, scratch, true, stream);
+                          ema_one_minus_decay, scratch, true, stream, 0.0);
 }
 static int adam_step_impl(float* flat, const float* grad, float* m, float* v, float* ema, int64_t n, const int64_t* skip_lo_host,
                           const int64_t* skip_hi_host, int32_t n_skip, double lr, double beta1, double beta2, double eps, double grad_clip,
-                          double grad_scale, int64_t adam_step, double ema_one_minus_decay, float* scratch, bool presummed, void* stream) {
+                          double grad_scale, int64_t adam_step, double ema_one_minus_decay, float* scratch, bool presummed, void* stream,
+                          double weight_decay) {
     DP_CHECK_ARG(flat && grad && m && v && scratch, "null argument");
     DP_CHECK_ARG(adam_step >= 1, "adam_step counts from 1");
     DP_CHECK_ARG(n_skip >= 0 && n_skip <= 2, "at most two no-gradient ranges");
@@ -1245,6 +1262,7 @@ static int adam_step_impl(float* flat, const float* grad, float* m, float* v, fl
     a.one_minus_beta1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.one_minus_beta2 = (float)(1.0 - beta2); a.eps = (float)eps;
     a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(beta2, (double)adam_step));
     a.ema_one_minus_decay = (float)ema_one_minus_decay;
+    a.weight_decay = (float)weight_decay;
     DP_HIP_LAUNCH(launch_adam_ema(a, st));
     return DPOSER_OK;
 }

@@ -27,13 +27,13 @@ class ScoreEngine:
     """One engine = one (module, precision) pair."""
 
     def __init__(self, *, data_dim, hidden_dim, embed_dim, n_blocks, embedding, scale_by_sigma, num_scales,
-                 dropout_p, precision):
+                 dropout_p, precision, activation="swish"):
         self.lib = _C.lib()
         self.precision = precision
         desc = _C.ScoreFCDesc(data_dim, hidden_dim, embed_dim, n_blocks,
                               _C.EMB_FOURIER if embedding == "fourier" else _C.EMB_POSITIONAL,
                               1 if scale_by_sigma else 0, num_scales,
-                              _C.PREC_FP32 if precision == "fp32" else _C.PREC_BF16, float(dropout_p))
+                              _C.PREC_FP32 if precision == "fp32" else _C.PREC_BF16, float(dropout_p), _C.ACTIVATIONS[activation])
         h = C.c_void_p()
         _C.check(self.lib.dposer_scorefc_create(C.byref(desc), C.byref(h)), "dposer_scorefc_create")
         self.h = h

@@ -46,6 +46,9 @@ typedef struct dposer_scorefc_s* dposer_scorefc_t;
 
 enum { DPOSER_PREC_BF16 = 0, DPOSER_PREC_FP32 = 1 };
 enum { DPOSER_EMB_POSITIONAL = 0, DPOSER_EMB_FOURIER = 1 };
+/* config.model.nonlinearity (model.py:54-66): swish = SiLU; lrelu = LeakyReLU(0.2); elu = ELU(alpha = 1).  Swish runs on every
+ * tiling; the other three on the 128-wide tilings (any batch), hidden_dim 1024 only */
+enum { DPOSER_ACT_SWISH = 0, DPOSER_ACT_ELU = 1, DPOSER_ACT_RELU = 2, DPOSER_ACT_LRELU = 3 };
 enum { DPOSER_SDE_SUBVP = 0, DPOSER_SDE_VP = 1 };
 
 typedef struct {
@@ -58,6 +61,7 @@ typedef struct {
     int32_t num_scales;      /* length of the `sigmas` buffer  model.py:128 */
     int32_t precision;       /* DPOSER_PREC_*: bf16 MFMA (throughput) or fp32 MFMA (parity) */
     float dropout_p;         /* config.model.dropout  model.py:113 */
+    int32_t activation;      /* DPOSER_ACT_*: config.model.nonlinearity (model.py:54-66 get_act); swish is the shipped one */
 } dposer_scorefc_desc;
 
 typedef struct {             /* lib/algorithms/advanced/sde_lib.py:122-231 */
@@ -201,6 +205,12 @@ int dposer_adam_ema_clip_step_presummed(float* flat_params, const float* flat_gr
                                         int64_t n, const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip,
                                         double lr, double beta1, double beta2, double eps, double grad_clip, double grad_scale,
                                         int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream);
+/* the same update with torch.optim.Adam's weight_decay (losses.py:35-36 get_optimizer passes config.optim.weight_decay): the
+ * clipped gradient becomes grad + weight_decay * param before the moments; presummed != 0: scratch[0] already holds the squared norm */
+int dposer_adam_ema_clip_step_wd(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* ema_shadow,
+                                 int64_t n, const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
+                                 double beta1, double beta2, double eps, double weight_decay, double grad_clip, double grad_scale,
+                                 int64_t adam_step, double ema_one_minus_decay, float* scratch, int32_t presummed, void* stream);
 
 /* dposer_em_sampler restricted to the steps [start_step, start_step + n_steps) (no look-ahead imputation after the last one):
  * what a predictor-corrector loop with a corrector between the predictor calls drives (sampling.py:455-461). */

@@ -68,13 +68,16 @@ def _lin(p: Params, name: str, x):
 def scorefc_forward(p: Params, batch: torch.Tensor, labels: torch.Tensor, *, n_blocks=2,
                     embed_dim: Optional[int] = None, embedding_type="positional",
                     scale_by_sigma=True, drop_masks: Optional[Sequence[torch.Tensor]] = None,
-                    drop_p: float = 0.0) -> torch.Tensor:
+                    drop_p: float = 0.0, nonlinearity: str = "swish") -> torch.Tensor:
     """ScoreModelFC.forward -- lib/algorithms/advanced/model.py:141-196.
 
     ``labels`` is what the reference calls ``t`` inside the model (= t*999 from get_score_fn).
     ``drop_masks``: optional list of 1+2*n_blocks {0,1} keep-masks [B, H]; when given, dropout is
     applied as ``h * mask / (1 - drop_p)`` exactly where model.py:170,178,185 apply ``self.dropout``.
     """
+    # model.py:54-66 get_act: one activation module used after every GroupNorm and in shared_time_embed
+    silu = {"swish": torch.nn.functional.silu, "elu": torch.nn.functional.elu, "relu": torch.relu,
+            "lrelu": lambda v: torch.nn.functional.leaky_relu(v, negative_slope=0.2)}[nonlinearity]
     if embed_dim is None:
         embed_dim = p["shared_time_embed.0.weight"].shape[0]
     if embedding_type == "fourier":

@@ -519,6 +519,40 @@ def g18_evaler():
     save("g18_evaler", **out)
 
 
+def g19_activations():
+    """G19: ScoreModelFC forward + DSM loss and gradient probes for config.model.nonlinearity in {elu, relu, lrelu} (model.py:54-66),
+    dropout off, injected (t, z)."""
+    out = {"seed": np.int64(19)}
+    batch, _ = toy_batch(24, seed=51)
+    out["batch"] = batch.numpy()
+    sde = ref_sde.subVPSDE(0.1, 20.0, 1000)
+    for act in ("elu", "relu", "lrelu"):
+        cfg = get_config()
+        cfg.model.nonlinearity = act
+        cfg.model.dropout = 0.0
+        m = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=cfg.model.HIDDEN_DIM, embed_dim=cfg.model.EMBED_DIM, n_blocks=cfg.model.N_BLOCKS)
+        sd = m.state_dict()
+        for k, v in make_weights(19, D=63).items():
+            sd[k] = v
+        m.load_state_dict(sd)
+        m.eval()
+        rs = np.random.RandomState(190)
+        t = torch.tensor(rs.uniform(1e-3, 1.0, 24).astype(np.float32))
+        out["t"] = t.numpy()
+        with torch.no_grad():
+            out[f"{act}_model"] = m(batch, t * 999).numpy()
+        m.train()
+        loss_fn = ref_losses.get_sde_loss_fn(sde, train=True, reduce_mean=True, continuous=True)
+        with Recorder(191) as rec:
+            loss = loss_fn(m, batch, None, None)
+        loss.backward()
+        out[f"{act}_loss"] = np.float64(loss.item())
+        out["u"], out["z"] = rec.by_kind("rand")[0], rec.by_kind("randn")[0]
+        for n, p in m.named_parameters():
+            out[f"{act}_grad/{n}"] = np.zeros(1) if p.grad is None else sample_tensor(n, p.grad)
+    save("g19_activations", **out)
+
+
 def g8_scalars():
     """G8: marginal_prob / sde / return_alpha_sigma / discretize tables on linspace(1,1e-3,1000)."""
     t = torch.linspace(1.0, 1e-3, 1000)
@@ -696,8 +730,8 @@ def g13_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
-    fns = dict(g18=g18_evaler, g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    fns = dict(g19=g19_activations, g18=g18_evaler, g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
                g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
     for w in which:
         fns[w]()

@@ -8,12 +8,13 @@ from oracle import score_ref as R
 DEV = "cuda:0"
 
 
-def make_model(seed, D=63, precision="fp32", dropout=0.1, embedding="positional", device=DEV):
+def make_model(seed, D=63, precision="fp32", dropout=0.1, embedding="positional", device=DEV, nonlinearity="swish"):
     from dposer_amd.algorithms.advanced.model import ScoreModelFC
     from dposer_amd.configs import load_config
     cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
     cfg.model.dropout = dropout
     cfg.model.embedding_type = embedding
+    cfg.model.nonlinearity = nonlinearity
     m = ScoreModelFC(cfg, n_poses=21, pose_dim=D // 21, hidden_dim=1024, embed_dim=512, n_blocks=2)
     w = make_weights(seed, D=D, fourier=(embedding == "fourier"))
     sd = m.state_dict()

@@ -1083,3 +1083,49 @@ def test_persistent_sampler_kernel_returns_the_bits_of_the_launch_path():
         outs[flag] = [l for l in r.stdout.splitlines() if l.startswith("SHA")]
         assert len(outs[flag]) == 2 and all(l.endswith("True") for l in outs[flag])
     assert outs["0"] == outs["1"]
+
+
+@pytest.mark.parametrize("act", ["elu", "relu", "lrelu"])
+@pytest.mark.parametrize("prec,tol,tol_g", [("fp32", 2e-5, 2e-4), ("bf16", 1e-2, 1e-2)])
+def test_other_activations_vs_reference_golden(act, prec, tol, tol_g):
+    """config.model.nonlinearity = elu / relu / lrelu (model.py:54-66 get_act): forward, DSM loss and every parameter gradient of
+    the fused training path against g19 (the reference itself), through the runtime-activation epilogues of the 128-wide
+    tilings -- at a ragged batch (128 x 32 tiling) and, replicated 8 x, at a batch the 128 x 128 tiling takes."""
+    g = load("g19_activations")
+    cfg, m, p = make_model(int(g["seed"]), precision=prec, dropout=0.0, nonlinearity=act)
+    batch, t = _dev(g["batch"]), _dev(g["t"])
+    with torch.no_grad():
+        out = m(batch, t * 999)
+        out8 = m(batch.repeat(16, 1), (t * 999).repeat(16))            # 384 samples: 128 x 128 tiles
+    assert rel_err(t2n(out), g[f"{act}_model"]) < tol
+    assert rel_err(t2n(out8[:24]), g[f"{act}_model"]) < tol
+    tt = _dev(g["u"]) * (1.0 - 1e-5) + 1e-5
+    loss, fg = _fused_grad(m, batch, tt, _dev(g["z"]))
+    assert abs(loss - float(g[f"{act}_loss"])) / float(g[f"{act}_loss"]) < (1e-4 if prec == "fp32" else 2e-3)
+    worst = 0.0
+    for (name, prm), off in zip(m.named_parameters(), m._offsets):
+        ref = g[f"{act}_grad/{name}"]
+        if ref.shape[0] > 1:
+            worst = max(worst, rel_err(probe(name, fg[off:off + prm.numel()].reshape(prm.shape)), ref))
+    # (relu / lrelu have a step derivative: a bf16-rounded pre-activation next to zero flips the gate, measured 1.2e-2)
+    assert worst < (3 * tol_g if (prec == "bf16" and act != "elu") else tol_g), worst
+
+
+def test_fused_adam_weight_decay_follows_torch():
+    """config.optim.weight_decay != 0 (losses.py:35-36): torch.optim.Adam's L2 form, grad += weight_decay * param after the clip and
+    before the moments -- the fused kernel against torch.optim.Adam on the same gradients, three steps."""
+    from dposer_amd.algorithms.advanced import losses
+    cfg, m, p = make_model(7, precision="fp32", dropout=0.0)
+    cfg.optim.weight_decay = 0.05
+    opt = losses.get_optimizer(cfg, m.parameters())
+    ref_params = [q.detach().clone().requires_grad_(True) for q in m.parameters()]
+    ref_opt = torch.optim.Adam(ref_params, lr=cfg.optim.lr, betas=(cfg.optim.beta1, 0.999), eps=cfg.optim.eps, weight_decay=0.05)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for step in range(3):
+        for q, r in zip(m.parameters(), ref_params):
+            g = torch.randn(q.shape, device=DEV, generator=gen) * 0.01
+            q.grad, r.grad = g.clone(), g.clone()
+        opt.step()
+        ref_opt.step()
+    for (name, q), r in zip(m.named_parameters(), ref_params):
+        assert (q - r).abs().max() <= 2e-6 * max(1.0, float(r.abs().max())), name

@@ -276,3 +276,24 @@ def test_auxiliary_loss_step_restatement_matches_the_reference_step():
         if grads[n] is not None:
             assert rel_err(probe(n, grads[n] * coef), g[f"grad/{n}"]) < 2e-4, n
         assert rel_err(probe(n, st.p[n]), g[f"param/{n}"]) < 1e-5, n
+
+
+@pytest.mark.parametrize("act", ["elu", "relu", "lrelu"])
+def test_other_activations_forward_and_dsm_gradients(act):
+    """g19: the reference's ScoreModelFC with config.model.nonlinearity = elu / relu / lrelu (model.py:54-66)."""
+    g = load("g19_activations")
+    p = make_weights(int(g["seed"]))
+    p["sigmas"] = R.sigma_table()
+    batch, t = torch.tensor(g["batch"]), torch.tensor(g["t"])
+    assert rel_err(R.scorefc_forward(p, batch, t * 999, nonlinearity=act), g[f"{act}_model"]) < TOL
+    names = R.param_names()
+    leaves = {n: p[n].clone().requires_grad_(True) for n in names}
+    full = dict(p)
+    full.update(leaves)
+    tt = torch.tensor(g["u"]) * (1.0 - 1e-5) + 1e-5
+    loss = R.dsm_loss(full, R.SubVP(), batch, tt, torch.tensor(g["z"]), nonlinearity=act)
+    assert abs(loss.item() - float(g[f"{act}_loss"])) / float(g[f"{act}_loss"]) < 1e-5
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    for n, gr in zip(names, grads):
+        if gr is not None:
+            assert rel_err(probe(n, gr), g[f"{act}_grad/{n}"]) < 1e-4, n
