@@ -218,6 +218,25 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 }
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63)); }
 
+// bit i of `bits` as an all-ones / all-zeros word: ONE v_bfe_i32 (sign-extending 1-bit field extract).  Written with the builtin,
+// hipcc canonicalises "extract and AND" into v_and (bit test) + v_cmp_ne + v_cndmask -- three VALU instructions per element in the
+// dropout epilogues instead of two (v_bfe_i32 + v_and).
+template <int I> __device__ __forceinline__ uint32_t bit_mask(uint32_t bits) {
+    uint32_t m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "n"(I));
+    return m;
+}
+
+// (index that folds to a constant after unrolling)
+__device__ __forceinline__ uint32_t bit_mask_rt(uint32_t bits, int i) {
+    switch (i) {
+#define DP_BM(I) case I: return bit_mask<I>(bits);
+        DP_BM(0) DP_BM(1) DP_BM(2) DP_BM(3) DP_BM(4) DP_BM(5) DP_BM(6) DP_BM(7) DP_BM(8) DP_BM(9) DP_BM(10) DP_BM(11) DP_BM(12) DP_BM(13) DP_BM(14) DP_BM(15)
+#undef DP_BM
+        default: return 0u - ((bits >> i) & 1u);
+    }
+}
+
 // x + (x of lane ^ 32) with one v_permlane32_swap: the two accumulator halves of a GroupNorm group live in lanes l and l ^ 32.
 // (__shfl_xor(x, 32) is a ds_bpermute: an LDS round trip plus an s_waitcnt that stalls the wave -- and its MFMAs -- in an epilogue.)
 __device__ __forceinline__ float sum_xor32(float x) {

@@ -176,21 +176,26 @@ template <typename T, bool TRAIN, int RESID = -1, bool ACTRT = false> struct Epi
             }
         }
         if constexpr (PH != 1) {
-            float sum = 0.f;
+            // two independent partial sums each (even / odd registers): half the dependent-add chain, and the pairs pack
+            float sum0 = 0.f, sum1 = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(lpar + tc * 32 + 8 * q + 4 * hi);   // channel inside the wave's LDS-staged slice
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { cy.v[4 * q + r] = a[4 * q + r] + b4[r]; sum += cy.v[4 * q + r]; }
+                for (int r = 0; r < 4; ++r) cy.v[4 * q + r] = a[4 * q + r] + b4[r];
+                sum0 += cy.v[4 * q] + cy.v[4 * q + 2];
+                sum1 += cy.v[4 * q + 1] + cy.v[4 * q + 3];
             }
-            sum = sum_xor32(sum);
-            const float mean = sum * (1.0f / 32.0f);
-            float ss = 0.f;
+            const float mean = sum_xor32(sum0 + sum1) * (1.0f / 32.0f);
+            float ss0 = 0.f, ss1 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { cy.v[r] -= mean; ss += cy.v[r] * cy.v[r]; }
-            ss = sum_xor32(ss);
-            const float var = ss * (1.0f / 32.0f);
-            cy.rstd = PRECISE ? 1.0f / sqrtf(var + 1e-5f) : rsqrtf(var + 1e-5f);
+            for (int r = 0; r < 16; r += 2) {
+                cy.v[r] -= mean; cy.v[r + 1] -= mean;
+                ss0 += cy.v[r] * cy.v[r]; ss1 += cy.v[r + 1] * cy.v[r + 1];
+            }
+            const float var = sum_xor32(ss0 + ss1) * (1.0f / 32.0f);
+            // (var + eps >= 1e-5: the bare v_rsq_f32 needs none of rsqrtf()'s denormal rescaling)
+            cy.rstd = PRECISE ? 1.0f / sqrtf(var + 1e-5f) : __builtin_amdgcn_rsqf(var + 1e-5f);
             cy.bits = 0xffffu;
             if (drop) cy.bits = dropout_bits16(p.drop, s, c0 >> 5, hi);
             if (TRAIN) {
@@ -217,7 +222,7 @@ template <typename T, bool TRAIN, int RESID = -1, bool ACTRT = false> struct Epi
                     else if constexpr (!TRAIN) y = silu_f<PRECISE>(a_);
                     else if constexpr (PRECISE) y = silu_f<true>(a_) * dscale;
                     else y = a_ * __builtin_amdgcn_rcpf(__builtin_fmaf(__expf(-a_), dinv, dinv));
-                    if constexpr (TRAIN) y = __uint_as_float(__float_as_uint(y) & (uint32_t)__builtin_amdgcn_sbfe((int)cy.bits, 4 * q + r, 1));
+                    if constexpr (TRAIN) y = __uint_as_float(__float_as_uint(y) & bit_mask_rt(cy.bits, 4 * q + r));
                     o[4 * q + r] = y;
                 }
             }
@@ -701,7 +706,7 @@ template <typename T, int ABL = 0, bool ACTRT = false> struct EpiGNBwd {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 4 * q + r;
-                        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, i, 1);
+                        const uint32_t m = bit_mask_rt(bits, i);
                         const float gg = __uint_as_float(__float_as_uint(g[i]) & m);
                         const float ds = ACTRT ? dact_rt<PRECISE>(g4[r] * xh[i] + e4[r], pp.act) : dsilu_f<PRECISE>(g4[r] * xh[i] + e4[r]);
                         const float da = gg * ds;                  // (the 1/(1-p) factor is applied to gamma and to the sums)
@@ -818,7 +823,7 @@ template <typename T, int ABL = 0, bool ACTRT = false> struct EpiGNBwd {
                         for (int r = 0; r < 4; ++r) {
                             const int i = 4 * q + r;
                             // keep decision as an all-ones / all-zeros word: one v_bfe_i32 + one v_and per element
-                            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, i, 1);
+                            const uint32_t m = bit_mask_rt(bits, i);
                             const float gg = __uint_as_float(__float_as_uint(g[i]) & m);
                             const float ds = (ABL & 2) ? 1.0f : (ACTRT ? dact_rt<PRECISE>(g4[r] * xh[i] + e4[r], pp.act) : dsilu_f<PRECISE>(g4[r] * xh[i] + e4[r]));
                             const float da = gg * ds;                  // (the 1/(1-p) factor is applied to gamma and to the sums)
@@ -1085,7 +1090,7 @@ template <typename T, int GS> struct EpiGNBwdG {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int i = 4 * q + r;
-                            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, i, 1);
+                            const uint32_t m = bit_mask_rt(bits, i);
                             const float gg = __uint_as_float(__float_as_uint(g[u][i]) & m);
                             const float da = gg * dsilu_f<PRECISE>(g4[r] * xh[u][i] + e4[r]);
                             stat[u][i] += da * xh[u][i];
