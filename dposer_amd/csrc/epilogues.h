@@ -7,7 +7,7 @@
 #include "sde_dev.h"
 
 // dropout keep decisions for one lane's 16 channels of GroupNorm group g (contract: oracle/philox.py
-// dropout_keep_mask).  Two Philox calls; call m covers quads q = 2m, 2m+1; 16-bit lanes; lane_in_call = (q%2)*4 + r.
+// dropout_keep_mask).  Two Philox4x32-7 calls (rng.h); call m covers quads q = 2m, 2m+1; 16-bit lanes; lane_in_call = (q%2)*4 + r.
 struct DropoutCfg {
     float p;           // drop probability; 0 => disabled
     float scale;       // 1/(1-p)
@@ -24,7 +24,7 @@ struct DropoutCfg {
 __device__ __forceinline__ void dropout_mask16(const DropoutCfg& d, int64_t s, int g, int hi, float keep[16]) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        Philox4 r = philox_at((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
+        Philox4 r = philox_at_dropout((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const int q = 2 * m + (w >> 1), r0 = (w & 1) * 2;
@@ -46,7 +46,7 @@ __device__ __forceinline__ void epi_for_each_sub(const P& pp, C& carry, f32x16 (
 
 // One Philox call = the 8 decisions of quads 2m and 2m+1 (same numbers as dropout_mask16, for register-lean callers).
 __device__ __forceinline__ void dropout_mask8(const DropoutCfg& d, int64_t s, int g, int hi, int m, float keep[8]) {
-    Philox4 r = philox_at((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
+    Philox4 r = philox_at_dropout((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         keep[2 * w] = ((r.v[w] & 0xffffu) < d.thr) ? d.scale : 0.f;
@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t dropout_mask16_bits(const DropoutCfg& d, int
     uint32_t bits = 0;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        Philox4 r = philox_at((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
+        Philox4 r = philox_at_dropout((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const int i0 = 4 * (2 * m + (w >> 1)) + (w & 1) * 2;
@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t dropout_bits16(const DropoutCfg& d, int64_t 
     uint32_t bits = 0;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        Philox4 r = philox_at((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
+        Philox4 r = philox_at_dropout((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const int i0 = 4 * (2 * m + (w >> 1)) + (w & 1) * 2;

@@ -1,4 +1,4 @@
-// Counter-based RNG for the DPoser kernels: Philox4x32-10 (Salmon et al. 2011) + bit->float maps.
+// Counter-based RNG for the DPoser kernels: Philox4x32-10 (Salmon et al. 2011; -7 for the dropout decisions) + bit->float maps.
 // The contract (counter/key layout, stream ids, float maps) is restated on the CPU in
 // oracle/philox.py so tests can inject identical numbers into the oracle.
 #pragma once
@@ -20,10 +20,16 @@ struct Philox4 {
     uint32_t v[4];
 };
 
-__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+// ROUNDS = 10: the standard generator (t, z, sampler / prior noise).  ROUNDS = 7: the dropout decisions -- Salmon et al. (SC'11,
+// "Parallel random numbers: as easy as 1, 2, 3", table 2) find Philox4x32 Crush-resistant from 7 rounds on; 10 is their default with a
+// safety margin.  Two calls per lane and 32 x 32 sub-tile make the draw 35-45 % of the training-forward epilogue's VALU time
+// (tools/valu_bench.hip: 47 ns per wave and call at 10 rounds, 29 ns at 7), and a keep / drop decision at p = 0.1 asks far less of
+// its bits than a Monte-Carlo integrand does.
+template <int ROUNDS = 10>
+__device__ __forceinline__ Philox4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         // one 64-bit product per multiplier: hipcc emits a single v_mad_u64_u32 for it, where __umulhi() + the 32-bit product
         // are a v_mul_hi_u32 and a v_mul_lo_u32 (all three quarter rate): 21 % off a Philox call (tools/valu_bench.hip)
         const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
@@ -39,7 +45,11 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 }
 
 __device__ __forceinline__ Philox4 philox_at(uint64_t index, uint32_t stream, uint32_t offset, uint64_t seed) {
-    return philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), stream, offset, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return philox4x32<10>((uint32_t)index, (uint32_t)(index >> 32), stream, offset, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+// the dropout streams (STREAM_DROPOUT0 + site): 7 rounds, see above
+__device__ __forceinline__ Philox4 philox_at_dropout(uint64_t index, uint32_t stream, uint32_t offset, uint64_t seed) {
+    return philox4x32<7>((uint32_t)index, (uint32_t)(index >> 32), stream, offset, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
 __device__ __forceinline__ float u01_open_low(uint32_t b) { return ((float)(b >> 8) + 1.0f) * 5.9604644775390625e-08f; }  // (0,1]

@@ -26,16 +26,17 @@ STREAM_IMPUTE_A = 4         # imputation noise after the corrector
 STREAM_IMPUTE_B = 5         # imputation noise after the predictor
 STREAM_LANGEVIN = 6         # corrector noise
 STREAM_PRIOR = 7            # x_T ~ N(0, I) prior draw / prior-loss z
-STREAM_DROPOUT0 = 16        # + dropout-site id (0..4): 8 x 16-bit lanes per call
+STREAM_DROPOUT0 = 16        # + dropout-site id (0..4): 8 x 16-bit lanes per call, Philox4x32-7
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Vectorised Philox4x32-10.  All inputs broadcastable uint32 arrays; returns 4 uint32 arrays."""
+def philox4x32_10(c0, c1, c2, c3, k0, k1, rounds=10):
+    """Vectorised Philox4x32-``rounds`` (10 = the standard generator; the dropout streams use 7, see dropout_keep_mask).
+    All inputs broadcastable uint32 arrays; returns 4 uint32 arrays."""
     c0, c1, c2, c3 = (np.asarray(a, dtype=np.uint32) for a in (c0, c1, c2, c3))
     c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
     k0 = np.uint32(k0)
     k1 = np.uint32(k1)
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = M0 * c0.astype(np.uint64)
         p1 = M1 * c2.astype(np.uint64)
         hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
@@ -106,8 +107,10 @@ def dropout_keep_mask(rows, channels, site, offset, seed, p):
     q, hi, r = cl // np.uint64(8), (cl % np.uint64(8)) // np.uint64(4), cl % np.uint64(4)
     idx = s * np.uint64(channels // 8) + g * np.uint64(4) + hi * np.uint64(2) + q // np.uint64(2)
     idx = np.broadcast_to(idx, (rows, channels)).reshape(-1)
+    # 7 rounds for the dropout streams (dposer_amd/csrc/rng.h: philox_at_dropout; Crush-resistant per Salmon et al., and 30 % cheaper
+    # in the training-forward epilogue, whose VALU time the draw dominates)
     w = philox4x32_10((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32),
-                      np.uint32(STREAM_DROPOUT0 + site), np.uint32(offset), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+                      np.uint32(STREAM_DROPOUT0 + site), np.uint32(offset), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, rounds=7)
     w = np.stack(w, axis=-1)                                                  # [n, 4]
     lane = np.broadcast_to((q % np.uint64(2)) * np.uint64(4) + r, (rows, channels)).reshape(-1).astype(np.int64)
     word = np.take_along_axis(w, (lane // 2)[:, None], axis=1)[:, 0]

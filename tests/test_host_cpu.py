@@ -353,3 +353,22 @@ def test_rot6d_to_axis_angle_autograd_helper_vs_scipy():
     out = f(x)
     assert np.abs(out.detach().numpy() - Rotation.from_matrix(R).as_rotvec()).max() < 1e-6
     assert torch.autograd.gradcheck(f, (x[1:9],), eps=1e-6, atol=1e-5)
+
+
+def test_dropout_decisions_philox7_statistics():
+    """The dropout streams run Philox4x32-7 (rng.h, oracle/philox.py): keep rate, independence across channels / samples / sites /
+    steps of the decisions the kernels draw (the 10-round generator is pinned by the Random123 vectors above; 7 rounds are its first 7)."""
+    from oracle.philox import dropout_keep_mask
+    B, H, p = 4096, 1024, 0.1
+    m = dropout_keep_mask(B, H, 0, 5, 42, p)
+    n = m.size
+    sigma = np.sqrt(p * (1 - p) / n)
+    assert abs(m.mean() - (1 - p)) < 5 * sigma + 2e-5                      # thr = floor(0.9 * 65536): keep rate 0.89999
+    assert np.abs(m.mean(axis=0) - 0.9).max() < 6 * np.sqrt(0.09 / B)       # every channel
+    assert np.abs(m.mean(axis=1) - 0.9).max() < 6 * np.sqrt(0.09 / H)       # every sample
+    c = m - m.mean()
+    for a, b in ((c[:, :-1], c[:, 1:]), (c[:-1], c[1:]), (c[:, :-32], c[:, 32:]), (c[:, ::2], c[:, 1::2])):
+        assert abs((a * b).mean() / 0.09) < 5 / np.sqrt(a.size)             # lag correlations: neighbours, next group, lane pairs
+    for other in (dropout_keep_mask(B, H, 1, 5, 42, p), dropout_keep_mask(B, H, 0, 6, 42, p), dropout_keep_mask(B, H, 0, 5, 43, p)):
+        assert abs(((other - other.mean()) * c).mean() / 0.09) < 5 / np.sqrt(n)   # other site / step / seed: uncorrelated
+        assert (other != m).mean() > 0.15
