@@ -231,6 +231,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
             for (int j = 0; j < TS; ++j) Mma<T>::run(fa[set][i], fb[set][j], acc[i][j]);
     };
 
+#ifdef DPOSER_KLOOP_PRIO      // (tuner A/B: static priority for the second-dispatched half of the workgroup, MI355X_MICROARCH.md "two waves per SIMD" item 4)
+    if (DPOSER_KLOOP_PRIO == 1 && wave >= C::NW / 2) __builtin_amdgcn_s_setprio(1);
+    if (DPOSER_KLOOP_PRIO == 2 && wave < C::NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     if constexpr (NB == 2) {
         fetch_glds(0);
         if (nstages > 1) fetch_glds(1);
@@ -323,6 +327,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         stage(N{}, std::integral_constant<int, 0>{}, Y{});
     }
 
+#ifdef DPOSER_KLOOP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     unsigned char* wave_scratch = reinterpret_cast<unsigned char*>(lds_par + NPAR * C::CT * 32) + wave * EpiScratch<Epi>::value;
     if constexpr (EpiRing<Epi>::value > 0 && NB * C::STAGE_BYTES >= C::NW * EpiRing<Epi>::value) {
         __syncthreads_lds_only();      // every wave is done with the ring (no DMA is in flight after the last stage)

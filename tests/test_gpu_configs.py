@@ -118,7 +118,9 @@ def test_cfg3_generation_500_samples_1000_steps_bf16_fused_path():
     assert e32 < 3e-6                                   # measured 6.1e-7 after 1000 reverse steps
     assert e16 < 1.2e-2                                 # measured 5.0e-3: bf16 drift over 1000 reverse steps stays at the per-step level
     assert abs(apd["fp32"] - apd["ref"]) / apd["ref"] < 2e-4      # measured 5e-5  (APD 0.18241 / 0.18242 / 0.18273 m)
-    assert abs(apd["bf16"] - apd["ref"]) / apd["ref"] < 5e-3      # measured 1.7e-3
+    # bf16 APD: the last-bit behaviour of the epilogue re-rolls the 1000-step bf16 trajectories; over three z seeds and three builds of the
+    # library the deviation from the fp32 APD ranged -0.68 % ... +0.61 % (tools/cfg3_apd_spread.py, round 3): a noise floor, not a bias
+    assert abs(apd["bf16"] - apd["ref"]) / apd["ref"] < 1.5e-2
 
 
 # ---- cfg 4 ------------------------------------------------------------------------------------------------------------

@@ -1,9 +1,9 @@
 """Vendor GEMM library (torch.matmul -> hipBLASLt / rocBLAS) on the layer-GEMM problem sizes, for scale (run on the GPU box):
     python tools/vendor_gemm_reference.py
 Compare with `TUNE_RING=1 TUNE_K=<K> tools/bin/tune_gemm` (plain FT store).  Not used by the library."""
-import torch, time
+import os, torch, time
 dev = "cuda:0"
-for K in (1024, 1536, 4096):
+for K in ([int(os.environ["VENDOR_K"])] if os.environ.get("VENDOR_K") else (1024, 1536, 4096)):
     x = (torch.rand(65536, K, device=dev) * 0.2 - 0.1).to(torch.bfloat16)
     w = (torch.rand(1024, K, device=dev) * 0.2 - 0.1).to(torch.bfloat16)
     for _ in range(5): y = x @ w.t()
