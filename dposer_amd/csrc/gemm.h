@@ -37,6 +37,11 @@ struct GemmArgs {
     double alg_flops;               // algorithmic FLOPs of this launch (2*M*N*K on the un-padded problem); profiling only
 };
 
+#include "gemm_kloop_asm.h"
+#ifndef DPOSER_KLOOP_ASM      // (tuner A/B switch: 0 = the hipcc-scheduled steady-state stage)
+#define DPOSER_KLOOP_ASM 1
+#endif
+
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> {
     typedef bf16x8 Frag;
@@ -275,15 +280,68 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
             }
         };
         const int npre = nstages < PRE ? nstages : PRE;
-        for (int s0 = 0; s0 < npre; ++s0) fetch_glds(s0);
+        // Hand-placed steady-state stage (gemm_kloop_asm.h) for the shipped 256x256 bf16 tiling; every DMA of such a kernel is issued
+        // from asm (saddr form: SGPR base per piece + one VGPR offset per operand), the compiler tracks none of them.
+        constexpr bool ASM = DPOSER_KLOOP_ASM && sizeof(T) == 2 && NB == 4 && KB == 2 && TC == 4 && TS == 2 && WC == 2 && WS == 4;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+        const uint32_t s_m0 = __builtin_amdgcn_readfirstlane(lds0 + (wave << 10));
+        uint32_t v_wofs = lane * 16 + (w_kb << 10), v_xofs = lane * 16 + (seg_kb << 10);
+        uint64_t sW[2] = {0, 0}, sX[2] = {0, 0};
+        auto x_bases = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int blk = wave + i * C::NW;
+                sX[i] = sgpr_u64((uint64_t)(uintptr_t)sbase + ((uint64_t)((int64_t)(sblk * C::ST + blk / KB) * seg_total + blk % KB) << 10));
+            }
+        };
+        auto advance_asm = [&]() __attribute__((always_inline)) {       // fetch_advance() for the asm address state (offsets advance in the asm)
+            seg_kb += KB;
+            if (seg_kb >= seg_end && seg + 1 < g.nseg) {
+                ++seg;
+                seg_kb = 0;
+                seg_total = seg_blocks(seg);
+                seg_end = seg_total;
+                sbase = seg_ptr(seg);
+                x_bases();
+                v_xofs = lane * 16;
+            }
+        };
+        if constexpr (ASM) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int blk = wave + i * C::NW;
+                sW[i] = sgpr_u64((uint64_t)(uintptr_t)g.W + ((uint64_t)((int64_t)(cblk * C::CT + blk / KB) * g.w_stride_blocks + blk % KB) << 10));
+            }
+            x_bases();
+        }
+        auto fetch_w_asm = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ring_dma_piece(v_wofs, sW[i], s_m0 + buf * C::STAGE_BYTES + ((i * C::NW) << 10));
+            v_wofs += KB << 10;
+        };
+        auto fetch_x_asm = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ring_dma_piece(v_xofs, sX[i], s_m0 + buf * C::STAGE_BYTES + ((C::CT * KB + i * C::NW) << 10));
+            v_xofs += KB << 10;
+            advance_asm();
+        };
+        // The asm stages take their ring slot as a template parameter and run in groups of four: the ring starts at the slot that
+        // puts the first group on slot 0 (the `rem` stages in front of it run the C++-scheduled stage with asm-issued DMA).
+        const int n_dma = nstages > PRE ? nstages - PRE : 0;          // stages that fetch stage t + PRE
+        const int slot0 = ASM ? ((4 - (n_dma & 3)) & 3) : 0;
+        if constexpr (ASM) {
+            for (int s0 = 0; s0 < npre; ++s0) { fetch_w_asm((slot0 + s0) & 3); fetch_x_asm((slot0 + s0) & 3); }
+        } else {
+            for (int s0 = 0; s0 < npre; ++s0) fetch_glds(s0);
+        }
         // stage 0 landed?  VMEM returns in order: all but the last npre-1 stages
         if (npre >= 3) __builtin_amdgcn_s_waitcnt(waitcnt_vm(2 * C::LPW));
         else if (npre == 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(C::LPW));
         else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
         __syncthreads_lds_only();
-        load_frags(0, 0, 0);
-        int slot = 0;          // slot of the stage being computed
-        int fill = PRE;        // slot the stage fetched now goes to (= the slot of stage t-1)
+        load_frags(slot0, 0, 0);
+        int slot = slot0;                  // slot of the stage being computed
+        int fill = (slot0 + PRE) % NB;     // slot the stage fetched now goes to (= the slot of stage t-1)
         // DMA: fetch stage t+PRE while computing; ALLOW: DMA pieces that may still be in flight at the barrier
         // (everything issued after stage t+1); LAST: no following stage
         auto stage = [&](auto dma, auto allow, auto last) __attribute__((always_inline)) {
@@ -294,7 +352,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
             for (int kb = 0; kb < KB; ++kb) {
                 if (kb + 1 < KB) {
                     load_frags(slot, kb + 1, (kb + 1) & 1);
-                    if (DMA && kb == 0) fetch_w(fill);
+                    if constexpr (DMA && ASM) { if (kb == 0) fetch_w_asm(fill); }
+                    else if (DMA && kb == 0) fetch_w(fill);
                     mma(kb & 1);
                     if (kb == 0) pattern(std::integral_constant<int, DMA ? C::LPW_A : 0>{});
                     else pattern(std::integral_constant<int, 0>{});
@@ -305,7 +364,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                     load_frags(nslot, 0, 0);
-                    if constexpr (DMA) { fetch_x(fill); fetch_advance(); }
+                    if constexpr (DMA && ASM) fetch_x_asm(fill);
+                    else if constexpr (DMA) { fetch_x(fill); fetch_advance(); }
                     mma(kb & 1);
                     pattern(std::integral_constant<int, DMA ? C::LPW_B : 0>{});
                 } else {
@@ -319,7 +379,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         typedef std::true_type Y;
         typedef std::false_type N;
         int t = 0;
-        for (; t + PRE < nstages; ++t) stage(Y{}, std::integral_constant<int, (PRE - 2) * C::LPW + C::LPW_A>{}, N{});
+        if constexpr (ASM) {
+            const uint32_t vA_lo = lds0 + ((wc * TC * KB) << 10) + lane * 16, vB_lo = lds0 + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
+            const uint32_t vA_hi = vA_lo + 65536, vB_hi = vB_lo + 65536;
+#define DP_RING_STAGE(S)                                                                                                             \
+    ring_stage_asm<S>(acc, fa[0], fb[0], fa[1], fb[1], vA_lo, vB_lo, vA_hi, vB_hi, v_wofs, v_xofs, sW[0], sW[1], sX[0], sX[1], s_m0); \
+    advance_asm();                                                                                                                   \
+    ++t
+            for (const int rem = n_dma & 3; t < rem; ++t) stage(Y{}, std::integral_constant<int, (PRE - 2) * C::LPW + C::LPW_A>{}, N{});
+            for (int grp = n_dma >> 2; grp > 0; --grp) {        // slot == 0 here: one loop, one exit (several exits made hipcc spill the accumulators)
+                DP_RING_STAGE(0);
+                DP_RING_STAGE(1);
+                DP_RING_STAGE(2);
+                DP_RING_STAGE(3);
+            }
+#undef DP_RING_STAGE
+        } else {
+            for (; t + PRE < nstages; ++t) stage(Y{}, std::integral_constant<int, (PRE - 2) * C::LPW + C::LPW_A>{}, N{});
+        }
         if constexpr (PRE >= 3) {
             if (nstages - t >= 3) { stage(N{}, std::integral_constant<int, C::LPW>{}, N{}); ++t; }
         }

@@ -1,0 +1,105 @@
+// Hand-placed steady-state stage of the 256x256 / 8-wave bf16 ring K loop (gemm.h: TC = 4, TS = 2, KB = 2, NB = 4).
+//
+// Why: hipcc's schedule of the same stage (tools/tune_gemm, ISA of gemm_ft_kernel<bf16,2,4,4,2,2,EpiPlainFT,4>) re-derives the four
+// DMA addresses of a stage with s_mul / 64-bit add chains (~45 SALU + 8 VALU per 16 MFMAs) and puts ~40 non-MFMA instructions
+// (address arithmetic, s_waitcnt, s_barrier, six ds_reads, two DMAs) between the last MFMA in front of the stage barrier and the
+// first one behind it: both waves of a SIMD reach that stretch together (the barrier keeps them in phase), so the matrix pipe idles
+// there.  rocprofv3 counters on the 65536 x 1024 x 4096 problem: MFMA busy 0.66 at 1.81 GHz for that loop against 0.79 at 1.76 GHz for
+// the vendor library's hand-scheduled kernel (profiles/r03_vendor_pmc_K4096.md) -- the gap is cycles, not clock.
+//
+// This stage: one asm statement, 16 MFMAs with at most three other instructions between two of them;
+//   * DMA addresses = loop-invariant 64-bit SGPR base per piece + one 32-bit VGPR offset per operand that advances 2 KiB per stage
+//     (global_load_lds saddr form): 2 VALU + 4 SALU per stage for all addressing;
+//   * the ring slot is a template parameter, so LDS read offsets and the M0 values are immediates;
+//   * s_waitcnt / s_barrier sit between two MFMAs, the next MFMA follows the barrier at once (its operands were read from LDS
+//     during the first half of the stage).
+// Contract (identical to the C++ `stage(Y, 6, N)` it replaces; same MFMA order per accumulator => bit-identical results):
+//   in : f0a / f0b = fragments of k-block 0 of this stage (slot S), landed;
+//   out: f0a / f0b = fragments of k-block 0 of the next stage (slot S+1), landed (lgkmcnt(0) inside); f1a / f1b scratch;
+//   DMA: the two weight pieces (before the barrier) and the two activation pieces (after it) of stage t+3 into slot S+3;
+//   wait: vmcnt(6) in front of the barrier = everything issued before {stage t+2's four pieces, this stage's two weight pieces}.
+#pragma once
+#include "common.h"
+
+// LDS byte offsets relative to the wave's A / B fragment base of slots {0,1} (lo) or {2,3} (hi): the ds_read offset field is 16 bits
+template <int S> struct RingSlot {
+    static constexpr int kRel = (S & 1) * 32768;       // relative to the lo / hi base
+    static constexpr bool kHi = S >= 2;
+};
+
+template <int S>
+__device__ __forceinline__ void ring_stage_asm(f32x16 (&acc)[4][2], bf16x8 (&f0a)[4], bf16x8 (&f0b)[2], bf16x8 (&f1a)[4], bf16x8 (&f1b)[2],
+                                               uint32_t vA_lo, uint32_t vB_lo, uint32_t vA_hi, uint32_t vB_hi, uint32_t& v_wofs,
+                                               uint32_t& v_xofs, uint64_t sW0, uint64_t sW1, uint64_t sX0, uint64_t sX1, uint32_t s_m0) {
+    constexpr int S1 = (S + 1) & 3, D = (S + 3) & 3;
+    // k-block 1 of slot S (first half), k-block 0 of slot S1 (second half)
+    const uint32_t vA1 = RingSlot<S>::kHi ? vA_hi : vA_lo, vB1 = RingSlot<S>::kHi ? vB_hi : vB_lo;
+    const uint32_t vA0 = RingSlot<S1>::kHi ? vA_hi : vA_lo, vB0 = RingSlot<S1>::kHi ? vB_hi : vB_lo;
+    constexpr int R1 = RingSlot<S>::kRel + 1024, R0 = RingSlot<S1>::kRel;        // fragment i of k-block kb sits at (i * 2 + kb) KiB
+    constexpr int M = D * 32768;                                                  // DMA target slot; pieces: W0, W1 = +0, +8 KiB; X0, X1 = +16, +24 KiB
+    asm volatile(
+        // ---- first half: MFMAs on k-block 0 (f0*), read k-block 1 (f1*), weight DMA of stage t+3
+        "v_mfma_f32_32x32x16_bf16 %[c00], %[a00], %[b00], %[c00]\n"
+        "ds_read_b128 %[a10], %[vA1] offset:%[r1a0]\n"
+        "ds_read_b128 %[b10], %[vB1] offset:%[r1b0]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c01], %[a00], %[b01], %[c01]\n"
+        "ds_read_b128 %[b11], %[vB1] offset:%[r1b1]\n"
+        "s_add_i32 m0, %[sm0], %[mw0]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c10], %[a01], %[b00], %[c10]\n"
+        "ds_read_b128 %[a11], %[vA1] offset:%[r1a1]\n"
+        "global_load_lds_dwordx4 %[vw], %[sW0]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c11], %[a01], %[b01], %[c11]\n"
+        "ds_read_b128 %[a12], %[vA1] offset:%[r1a2]\n"
+        "s_add_i32 m0, %[sm0], %[mw1]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c20], %[a02], %[b00], %[c20]\n"
+        "ds_read_b128 %[a13], %[vA1] offset:%[r1a3]\n"
+        "global_load_lds_dwordx4 %[vw], %[sW1]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c21], %[a02], %[b01], %[c21]\n"
+        "v_add_u32 %[vw], 0x800, %[vw]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c30], %[a03], %[b00], %[c30]\n"
+        "s_waitcnt vmcnt(6) lgkmcnt(0)\n"
+        "v_mfma_f32_32x32x16_bf16 %[c31], %[a03], %[b01], %[c31]\n"
+        "s_barrier\n"
+        // ---- second half: MFMAs on k-block 1, read k-block 0 of the next slot, activation DMA of stage t+3
+        "v_mfma_f32_32x32x16_bf16 %[c00], %[a10], %[b10], %[c00]\n"
+        "ds_read_b128 %[a00], %[vA0] offset:%[r0a0]\n"
+        "ds_read_b128 %[b00], %[vB0] offset:%[r0b0]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c01], %[a10], %[b11], %[c01]\n"
+        "ds_read_b128 %[b01], %[vB0] offset:%[r0b1]\n"
+        "s_add_i32 m0, %[sm0], %[mx0]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c10], %[a11], %[b10], %[c10]\n"
+        "ds_read_b128 %[a01], %[vA0] offset:%[r0a1]\n"
+        "global_load_lds_dwordx4 %[vx], %[sX0]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c11], %[a11], %[b11], %[c11]\n"
+        "ds_read_b128 %[a02], %[vA0] offset:%[r0a2]\n"
+        "s_add_i32 m0, %[sm0], %[mx1]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c20], %[a12], %[b10], %[c20]\n"
+        "ds_read_b128 %[a03], %[vA0] offset:%[r0a3]\n"
+        "global_load_lds_dwordx4 %[vx], %[sX1]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c21], %[a12], %[b11], %[c21]\n"
+        "v_add_u32 %[vx], 0x800, %[vx]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c30], %[a13], %[b10], %[c30]\n"
+        "v_mfma_f32_32x32x16_bf16 %[c31], %[a13], %[b11], %[c31]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]), [c20] "+v"(acc[2][0]),
+          [c21] "+v"(acc[2][1]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]),
+          [a00] "+v"(f0a[0]), [a01] "+v"(f0a[1]), [a02] "+v"(f0a[2]), [a03] "+v"(f0a[3]), [b00] "+v"(f0b[0]), [b01] "+v"(f0b[1]),
+          [a10] "=&v"(f1a[0]), [a11] "=&v"(f1a[1]), [a12] "=&v"(f1a[2]), [a13] "=&v"(f1a[3]), [b10] "=&v"(f1b[0]), [b11] "=&v"(f1b[1]),
+          [vw] "+v"(v_wofs), [vx] "+v"(v_xofs)
+        : [vA1] "v"(vA1), [vB1] "v"(vB1), [vA0] "v"(vA0), [vB0] "v"(vB0), [sW0] "s"(sW0), [sW1] "s"(sW1), [sX0] "s"(sX0), [sX1] "s"(sX1),
+          [sm0] "s"(s_m0),
+          [r1a0] "n"(R1), [r1a1] "n"(R1 + 2048), [r1a2] "n"(R1 + 4096), [r1a3] "n"(R1 + 6144), [r1b0] "n"(R1), [r1b1] "n"(R1 + 2048),
+          [r0a0] "n"(R0), [r0a1] "n"(R0 + 2048), [r0a2] "n"(R0 + 4096), [r0a3] "n"(R0 + 6144), [r0b0] "n"(R0), [r0b1] "n"(R0 + 2048),
+          [mw0] "n"(M), [mw1] "n"(M + 8192), [mx0] "n"(M + 16384), [mx1] "n"(M + 24576)
+        : "memory", "scc");
+}
+
+// One 1-KiB DMA piece (prologue; not hot): M0 = LDS byte address of the piece, source = SGPR base + per-lane VGPR offset.
+__device__ __forceinline__ void ring_dma_piece(uint32_t voff, uint64_t sbase, uint32_t m0val) {
+    asm volatile("s_mov_b32 m0, %2\n s_nop 0\n global_load_lds_dwordx4 %0, %1\n" ::"v"(voff), "s"(sbase), "s"(__builtin_amdgcn_readfirstlane(m0val)) : "memory");
+}
+
+__device__ __forceinline__ uint64_t sgpr_u64(uint64_t x) {       // both halves through v_readfirstlane: an "s" operand must live in SGPRs
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}

@@ -287,7 +287,8 @@ int main(int argc, char** argv) {
     }
     if (getenv("TUNE_TAILS")) {      // ring prologue / tail paths: 1..6 stages, ring (NB 4 and 3) against the 2-slot loop, bit for bit
         size_t total_bad = 0;
-        for (int Kt = 32; Kt <= 192 && Kt <= K; Kt += 32) {
+        const int kt_max = getenv("TUNE_TAILS_MAXK") ? atoi(getenv("TUNE_TAILS_MAXK")) : 192;      // e.g. 1536: covers the hand-placed stage groups (from 7 stages up)
+        for (int Kt = 32; Kt <= kt_max && Kt <= K; Kt += 32) {
             g_cases.clear();
             add_plain<2, 2, 2, 2, 2, 2>("ref", S, C, Kt, W, X, o0);
             add_plain<2, 2, 2, 2, 2, 4>("ring4", S, C, Kt, W, X, o1);
@@ -300,8 +301,17 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(h2.data(), xhat, h2.size() * 2, hipMemcpyDeviceToHost));
             size_t bad1 = 0, bad2 = 0, nz = 0;
             for (size_t i = 0; i < h0.size(); ++i) { bad1 += h0[i] != h1[i]; bad2 += h0[i] != h2[i]; nz += h0[i] != 0; }
-            printf("K = %3d (%d stages): ring NB4 128x128 %zu mismatches, ring NB3 256x256 %zu mismatches of %zu (%zu non-zero)\n", Kt, Kt / 32, bad1, bad2, h0.size(), nz);
-            total_bad += bad1 + bad2;
+            // the shipped 256x256 ring (NB = 4: hand-placed steady-state stages, gemm_kloop_asm.h)
+            g_cases.clear();
+            add_plain<2, 4, 4, 2, 2, 4>("ring4 256", S, C, Kt, W, X, o1);
+            CK(hipMemset(o1, 0xdd, (size_t)S * C * 2));
+            for (auto& c : g_cases) c.launch();
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
+            size_t bad3 = 0;
+            for (size_t i = 0; i < h0.size(); ++i) bad3 += h0[i] != h1[i];
+            printf("K = %4d (%2d stages): ring NB4 128x128 %zu, ring NB3 256x256 %zu, ring NB4 256x256 %zu mismatches of %zu (%zu non-zero)\n", Kt, Kt / 32, bad1, bad2, bad3, h0.size(), nz);
+            total_bad += bad1 + bad2 + bad3;
         }
         printf(total_bad ? "TAILS FAILED\n" : "TAILS OK\n");
         return total_bad != 0;
