@@ -382,26 +382,36 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         if constexpr (ASM) {
             const uint32_t vA_lo = lds0 + ((wc * TC * KB) << 10) + lane * 16, vB_lo = lds0 + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
             const uint32_t vA_hi = vA_lo + 65536, vB_hi = vB_lo + 65536;
-#define DP_RING_STAGE(S)                                                                                                             \
-    ring_stage_asm<S>(acc, fa[0], fb[0], fa[1], fb[1], vA_lo, vB_lo, vA_hi, vB_hi, v_wofs, v_xofs, sW[0], sW[1], sX[0], sX[1], s_m0); \
-    advance_asm();                                                                                                                   \
+#define DP_RING_STAGE(S, MODE)                                                                                                             \
+    ring_stage_asm<S, MODE>(acc, fa[0], fb[0], fa[1], fb[1], vA_lo, vB_lo, vA_hi, vB_hi, v_wofs, v_xofs, sW[0], sW[1], sX[0], sX[1], s_m0); \
     ++t
-            for (const int rem = n_dma & 3; t < rem; ++t) stage(Y{}, std::integral_constant<int, (PRE - 2) * C::LPW + C::LPW_A>{}, N{});
-            for (int grp = n_dma >> 2; grp > 0; --grp) {        // slot == 0 here: one loop, one exit (several exits made hipcc spill the accumulators)
-                DP_RING_STAGE(0);
-                DP_RING_STAGE(1);
-                DP_RING_STAGE(2);
-                DP_RING_STAGE(3);
+            // the ring starts at slot0 = 4 - rem: the `rem` stages in front of the groups of four run on slots 4 - rem ... 3
+            const int rem = n_dma & 3;
+            if (rem >= 3) { DP_RING_STAGE(1, 0); advance_asm(); }
+            if (rem >= 2) { DP_RING_STAGE(2, 0); advance_asm(); }
+            if (rem >= 1) { DP_RING_STAGE(3, 0); advance_asm(); }
+            for (int grp = n_dma >> 2; grp > 0; --grp) {        // one loop, one exit (a loop with several exits made hipcc spill the accumulators)
+                DP_RING_STAGE(0, 0); advance_asm();
+                DP_RING_STAGE(1, 0); advance_asm();
+                DP_RING_STAGE(2, 0); advance_asm();
+                DP_RING_STAGE(3, 0); advance_asm();
+            }
+            if (nstages >= 3) {                                 // the three stages without DMA (slot == 0 here)
+                DP_RING_STAGE(0, 1);
+                DP_RING_STAGE(1, 2);
+                DP_RING_STAGE(2, 3);
             }
 #undef DP_RING_STAGE
         } else {
             for (; t + PRE < nstages; ++t) stage(Y{}, std::integral_constant<int, (PRE - 2) * C::LPW + C::LPW_A>{}, N{});
         }
-        if constexpr (PRE >= 3) {
-            if (nstages - t >= 3) { stage(N{}, std::integral_constant<int, C::LPW>{}, N{}); ++t; }
+        if (!(ASM && nstages >= 3)) {
+            if constexpr (PRE >= 3) {
+                if (nstages - t >= 3) { stage(N{}, std::integral_constant<int, C::LPW>{}, N{}); ++t; }
+            }
+            if (nstages - t >= 2) { stage(N{}, std::integral_constant<int, 0>{}, N{}); ++t; }
+            stage(N{}, std::integral_constant<int, 0>{}, Y{});
         }
-        if (nstages - t >= 2) { stage(N{}, std::integral_constant<int, 0>{}, N{}); ++t; }
-        stage(N{}, std::integral_constant<int, 0>{}, Y{});
     }
 
 #ifdef DPOSER_KLOOP_PRIO

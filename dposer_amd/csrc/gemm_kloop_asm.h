@@ -20,6 +20,9 @@
 //   wait: vmcnt(6) in front of the barrier = everything issued before {stage t+2's four pieces, this stage's two weight pieces}.
 #pragma once
 #include "common.h"
+#ifndef DPOSER_KLOOP_VARIANT
+#define DPOSER_KLOOP_VARIANT 0
+#endif
 
 // LDS byte offsets relative to the wave's A / B fragment base of slots {0,1} (lo) or {2,3} (hi): the ds_read offset field is 16 bits
 template <int S> struct RingSlot {
@@ -27,7 +30,49 @@ template <int S> struct RingSlot {
     static constexpr bool kHi = S >= 2;
 };
 
-template <int S>
+// Stage text.  W0 / W1 / WADD / X0 / X1 / XADD: the DMA lines of a fetching stage ("" in the tail stages); WAIT: the s_waitcnt in front of
+// the barrier; the LAST stage has no barrier and reads no following k-block.
+#define DP_RS_MFMA(c, a, b) "v_mfma_f32_32x32x16_bf16 %[" #c "], %[" #a "], %[" #b "], %[" #c "]\n"
+#define DP_RS_READ(dst, base, off) "ds_read_b128 %[" #dst "], %[" #base "] offset:%[" #off "]\n"
+#define DP_RS_HALF1(W0S, W0L, W1S, W1L, WADD, WAIT, BARRIER)                                                      \
+    DP_RS_MFMA(c00, a00, b00) DP_RS_READ(a10, vA1, r1a0) DP_RS_READ(b10, vB1, r1b0)                                \
+    DP_RS_MFMA(c01, a00, b01) DP_RS_READ(b11, vB1, r1b1) W0S                                                       \
+    DP_RS_MFMA(c10, a01, b00) DP_RS_READ(a11, vA1, r1a1) W0L                                                       \
+    DP_RS_MFMA(c11, a01, b01) DP_RS_READ(a12, vA1, r1a2) W1S                                                       \
+    DP_RS_MFMA(c20, a02, b00) DP_RS_READ(a13, vA1, r1a3) W1L                                                       \
+    DP_RS_MFMA(c21, a02, b01) WADD                                                                                 \
+    DP_RS_MFMA(c30, a03, b00) WAIT                                                                                 \
+    DP_RS_MFMA(c31, a03, b01) BARRIER
+#define DP_RS_HALF2(X0S, X0L, X1S, X1L, XADD)                                                                      \
+    DP_RS_MFMA(c00, a10, b10) DP_RS_READ(a00, vA0, r0a0) DP_RS_READ(b00, vB0, r0b0)                                \
+    DP_RS_MFMA(c01, a10, b11) DP_RS_READ(b01, vB0, r0b1) X0S                                                       \
+    DP_RS_MFMA(c10, a11, b10) DP_RS_READ(a01, vA0, r0a1) X0L                                                       \
+    DP_RS_MFMA(c11, a11, b11) DP_RS_READ(a02, vA0, r0a2) X1S                                                       \
+    DP_RS_MFMA(c20, a12, b10) DP_RS_READ(a03, vA0, r0a3) X1L                                                       \
+    DP_RS_MFMA(c21, a12, b11) XADD                                                                                 \
+    DP_RS_MFMA(c30, a13, b10)                                                                                      \
+    DP_RS_MFMA(c31, a13, b11) "s_waitcnt lgkmcnt(0)\n"
+#define DP_RS_HALF2_LAST                                                                                           \
+    DP_RS_MFMA(c00, a10, b10) DP_RS_MFMA(c01, a10, b11) DP_RS_MFMA(c10, a11, b10) DP_RS_MFMA(c11, a11, b11)        \
+    DP_RS_MFMA(c20, a12, b10) DP_RS_MFMA(c21, a12, b11) DP_RS_MFMA(c30, a13, b10) DP_RS_MFMA(c31, a13, b11)
+#define DP_RS_M0(m) "s_add_i32 m0, %[sm0], %[" #m "]\n"       // (an MFMA and a ds_read sit between the M0 write and the DMA that uses it)
+#define DP_RS_DMA(v, s) "global_load_lds_dwordx4 %[" #v "], %[" #s "]\n"
+#define DP_RS_OPERANDS                                                                                                                 \
+        : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]), [c20] "+v"(acc[2][0]),           \
+          [c21] "+v"(acc[2][1]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]),                                                         \
+          [a00] "+v"(f0a[0]), [a01] "+v"(f0a[1]), [a02] "+v"(f0a[2]), [a03] "+v"(f0a[3]), [b00] "+v"(f0b[0]), [b01] "+v"(f0b[1]),       \
+          [a10] "=&v"(f1a[0]), [a11] "=&v"(f1a[1]), [a12] "=&v"(f1a[2]), [a13] "=&v"(f1a[3]), [b10] "=&v"(f1b[0]), [b11] "=&v"(f1b[1]), \
+          [vw] "+v"(v_wofs), [vx] "+v"(v_xofs)                                                                                         \
+        : [vA1] "v"(vA1), [vB1] "v"(vB1), [vA0] "v"(vA0), [vB0] "v"(vB0), [sW0] "s"(sW0), [sW1] "s"(sW1), [sX0] "s"(sX0), [sX1] "s"(sX1), \
+          [sm0] "s"(s_m0),                                                                                                             \
+          [r1a0] "n"(R1), [r1a1] "n"(R1 + 2048), [r1a2] "n"(R1 + 4096), [r1a3] "n"(R1 + 6144), [r1b0] "n"(R1), [r1b1] "n"(R1 + 2048),  \
+          [r0a0] "n"(R0), [r0a1] "n"(R0 + 2048), [r0a2] "n"(R0 + 4096), [r0a3] "n"(R0 + 6144), [r0b0] "n"(R0), [r0b1] "n"(R0 + 2048),  \
+          [mw0] "n"(M), [mw1] "n"(M + 8192), [mx0] "n"(M + 16384), [mx1] "n"(M + 24576)                                                \
+        : "memory", "scc"
+
+// MODE 0: fetching stage (the DMA lands in slot S+3; vmcnt(6) in front of the barrier); 1 / 2: third-last / second-last stage (no DMA;
+// vmcnt(4) / vmcnt(0): the pieces of the stages behind t+1 may still fly); 3: last stage (no barrier, no following k-block).
+template <int S, int MODE = 0>
 __device__ __forceinline__ void ring_stage_asm(f32x16 (&acc)[4][2], bf16x8 (&f0a)[4], bf16x8 (&f0b)[2], bf16x8 (&f1a)[4], bf16x8 (&f1b)[2],
                                                uint32_t vA_lo, uint32_t vB_lo, uint32_t vA_hi, uint32_t vB_hi, uint32_t& v_wofs,
                                                uint32_t& v_xofs, uint64_t sW0, uint64_t sW1, uint64_t sX0, uint64_t sX1, uint32_t s_m0) {
@@ -37,61 +82,21 @@ __device__ __forceinline__ void ring_stage_asm(f32x16 (&acc)[4][2], bf16x8 (&f0a
     const uint32_t vA0 = RingSlot<S1>::kHi ? vA_hi : vA_lo, vB0 = RingSlot<S1>::kHi ? vB_hi : vB_lo;
     constexpr int R1 = RingSlot<S>::kRel + 1024, R0 = RingSlot<S1>::kRel;        // fragment i of k-block kb sits at (i * 2 + kb) KiB
     constexpr int M = D * 32768;                                                  // DMA target slot; pieces: W0, W1 = +0, +8 KiB; X0, X1 = +16, +24 KiB
-    asm volatile(
-        // ---- first half: MFMAs on k-block 0 (f0*), read k-block 1 (f1*), weight DMA of stage t+3
-        "v_mfma_f32_32x32x16_bf16 %[c00], %[a00], %[b00], %[c00]\n"
-        "ds_read_b128 %[a10], %[vA1] offset:%[r1a0]\n"
-        "ds_read_b128 %[b10], %[vB1] offset:%[r1b0]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c01], %[a00], %[b01], %[c01]\n"
-        "ds_read_b128 %[b11], %[vB1] offset:%[r1b1]\n"
-        "s_add_i32 m0, %[sm0], %[mw0]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c10], %[a01], %[b00], %[c10]\n"
-        "ds_read_b128 %[a11], %[vA1] offset:%[r1a1]\n"
-        "global_load_lds_dwordx4 %[vw], %[sW0]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c11], %[a01], %[b01], %[c11]\n"
-        "ds_read_b128 %[a12], %[vA1] offset:%[r1a2]\n"
-        "s_add_i32 m0, %[sm0], %[mw1]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c20], %[a02], %[b00], %[c20]\n"
-        "ds_read_b128 %[a13], %[vA1] offset:%[r1a3]\n"
-        "global_load_lds_dwordx4 %[vw], %[sW1]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c21], %[a02], %[b01], %[c21]\n"
-        "v_add_u32 %[vw], 0x800, %[vw]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c30], %[a03], %[b00], %[c30]\n"
-        "s_waitcnt vmcnt(6) lgkmcnt(0)\n"
-        "v_mfma_f32_32x32x16_bf16 %[c31], %[a03], %[b01], %[c31]\n"
-        "s_barrier\n"
-        // ---- second half: MFMAs on k-block 1, read k-block 0 of the next slot, activation DMA of stage t+3
-        "v_mfma_f32_32x32x16_bf16 %[c00], %[a10], %[b10], %[c00]\n"
-        "ds_read_b128 %[a00], %[vA0] offset:%[r0a0]\n"
-        "ds_read_b128 %[b00], %[vB0] offset:%[r0b0]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c01], %[a10], %[b11], %[c01]\n"
-        "ds_read_b128 %[b01], %[vB0] offset:%[r0b1]\n"
-        "s_add_i32 m0, %[sm0], %[mx0]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c10], %[a11], %[b10], %[c10]\n"
-        "ds_read_b128 %[a01], %[vA0] offset:%[r0a1]\n"
-        "global_load_lds_dwordx4 %[vx], %[sX0]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c11], %[a11], %[b11], %[c11]\n"
-        "ds_read_b128 %[a02], %[vA0] offset:%[r0a2]\n"
-        "s_add_i32 m0, %[sm0], %[mx1]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c20], %[a12], %[b10], %[c20]\n"
-        "ds_read_b128 %[a03], %[vA0] offset:%[r0a3]\n"
-        "global_load_lds_dwordx4 %[vx], %[sX1]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c21], %[a12], %[b11], %[c21]\n"
-        "v_add_u32 %[vx], 0x800, %[vx]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c30], %[a13], %[b10], %[c30]\n"
-        "v_mfma_f32_32x32x16_bf16 %[c31], %[a13], %[b11], %[c31]\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]), [c20] "+v"(acc[2][0]),
-          [c21] "+v"(acc[2][1]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]),
-          [a00] "+v"(f0a[0]), [a01] "+v"(f0a[1]), [a02] "+v"(f0a[2]), [a03] "+v"(f0a[3]), [b00] "+v"(f0b[0]), [b01] "+v"(f0b[1]),
-          [a10] "=&v"(f1a[0]), [a11] "=&v"(f1a[1]), [a12] "=&v"(f1a[2]), [a13] "=&v"(f1a[3]), [b10] "=&v"(f1b[0]), [b11] "=&v"(f1b[1]),
-          [vw] "+v"(v_wofs), [vx] "+v"(v_xofs)
-        : [vA1] "v"(vA1), [vB1] "v"(vB1), [vA0] "v"(vA0), [vB0] "v"(vB0), [sW0] "s"(sW0), [sW1] "s"(sW1), [sX0] "s"(sX0), [sX1] "s"(sX1),
-          [sm0] "s"(s_m0),
-          [r1a0] "n"(R1), [r1a1] "n"(R1 + 2048), [r1a2] "n"(R1 + 4096), [r1a3] "n"(R1 + 6144), [r1b0] "n"(R1), [r1b1] "n"(R1 + 2048),
-          [r0a0] "n"(R0), [r0a1] "n"(R0 + 2048), [r0a2] "n"(R0 + 4096), [r0a3] "n"(R0 + 6144), [r0b0] "n"(R0), [r0b1] "n"(R0 + 2048),
-          [mw0] "n"(M), [mw1] "n"(M + 8192), [mx0] "n"(M + 16384), [mx1] "n"(M + 24576)
-        : "memory", "scc");
+    if constexpr (MODE == 0) {
+#if DPOSER_KLOOP_VARIANT == 1      // activations (the HBM-sourced operand) first: three full stages of lead instead of two and a half
+        asm volatile(DP_RS_HALF1(DP_RS_M0(mx0), DP_RS_DMA(vx, sX0), DP_RS_M0(mx1), DP_RS_DMA(vx, sX1), "v_add_u32 %[vx], 0x800, %[vx]\n", "s_waitcnt vmcnt(6) lgkmcnt(0)\n", "s_barrier\n")
+                     DP_RS_HALF2(DP_RS_M0(mw0), DP_RS_DMA(vw, sW0), DP_RS_M0(mw1), DP_RS_DMA(vw, sW1), "v_add_u32 %[vw], 0x800, %[vw]\n") DP_RS_OPERANDS);
+#else
+        asm volatile(DP_RS_HALF1(DP_RS_M0(mw0), DP_RS_DMA(vw, sW0), DP_RS_M0(mw1), DP_RS_DMA(vw, sW1), "v_add_u32 %[vw], 0x800, %[vw]\n", "s_waitcnt vmcnt(6) lgkmcnt(0)\n", "s_barrier\n")
+                     DP_RS_HALF2(DP_RS_M0(mx0), DP_RS_DMA(vx, sX0), DP_RS_M0(mx1), DP_RS_DMA(vx, sX1), "v_add_u32 %[vx], 0x800, %[vx]\n") DP_RS_OPERANDS);
+#endif
+    } else if constexpr (MODE == 1) {
+        asm volatile(DP_RS_HALF1("", "", "", "", "", "s_waitcnt vmcnt(4) lgkmcnt(0)\n", "s_barrier\n") DP_RS_HALF2("", "", "", "", "") DP_RS_OPERANDS);
+    } else if constexpr (MODE == 2) {
+        asm volatile(DP_RS_HALF1("", "", "", "", "", "s_waitcnt vmcnt(0) lgkmcnt(0)\n", "s_barrier\n") DP_RS_HALF2("", "", "", "", "") DP_RS_OPERANDS);
+    } else {
+        asm volatile(DP_RS_HALF1("", "", "", "", "", "s_waitcnt lgkmcnt(0)\n", "") DP_RS_HALF2_LAST DP_RS_OPERANDS);
+    }
 }
 
 // One 1-KiB DMA piece (prologue; not hot): M0 = LDS byte address of the piece, source = SGPR base + per-lane VGPR offset.

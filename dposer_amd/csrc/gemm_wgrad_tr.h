@@ -137,6 +137,51 @@ __global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (W
     };
 
     constexpr int PRE = NB - 1;
+    // Hand-placed K loop (gemm_wgrad_tr_asm.inc, generated by tools/gen_wgrad_asm.py) for the shipped 256x256 tiling: one asm statement
+    // (fragments in fixed registers v208 ... v255), DMA addresses = SGPR base per piece + one 32-bit VGPR offset per operand.
+    constexpr bool ASM = DPOSER_KLOOP_ASM && WC == 2 && WS == 4 && TC == 4 && TS == 2 && NB == 4;
+    if constexpr (ASM) {
+        const int64_t span = ((int64_t)g.sblocks * (nA > nB ? nA : nB)) << 10;            // the 32-bit DMA offsets cover the operand
+        if (nstages >= 3 && span < (int64_t)0xfff00000) {
+            const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+            const uint32_t s_m0 = __builtin_amdgcn_readfirstlane(lds0 + (wave << 10));
+            const uint32_t strA = __builtin_amdgcn_readfirstlane(nA << 10), strB = __builtin_amdgcn_readfirstlane(nB << 10);
+            uint32_t v_aofs = ((wave & 1) ? off1 : off0) + (uint32_t)sb * strA, v_bofs = ((wave & 1) ? off1 : off0) + (uint32_t)sb * strB;
+            uint64_t sA[2], sB[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int blk = wave + i * C::NW;
+                sA[i] = sgpr_u64((uint64_t)(uintptr_t)g.dY + ((uint64_t)(cblk * C::CT * 2 + blk) << 10));
+                sB[i] = sgpr_u64((uint64_t)(uintptr_t)g.H + ((uint64_t)(sblk * C::ST * 2 + blk) << 10));
+            }
+            const int n_dma = nstages - PRE;
+            const uint32_t rem = __builtin_amdgcn_readfirstlane(n_dma & 3);
+            uint32_t grp = __builtin_amdgcn_readfirstlane(n_dma >> 2);
+            const int slot0 = (4 - (n_dma & 3)) & 3;                      // the groups of four start on slot 0
+            for (int s0 = 0; s0 < PRE; ++s0) {
+                const uint32_t m = s_m0 + ((slot0 + s0) & 3) * C::STAGE_BYTES;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ring_dma_piece(v_aofs, sA[i], m + ((i * C::NW) << 10));
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ring_dma_piece(v_bofs, sB[i], m + ((C::CT * 2 + i * C::NW) << 10));
+                v_aofs += strA;
+                v_bofs += strB;
+            }
+            __builtin_amdgcn_s_waitcnt(waitcnt_vm(2 * C::LPW));
+            __syncthreads_lds_only();
+            // per-lane addresses of the transposing reads (read_frag below, restated): k-block 0 lo / hi (+128) and k-block 1 lo (+512)
+            // from one base; the hi read of k-block 1 wraps inside its 1-KiB block for the lanes with kh = gq = 1
+            const int gq_ = (lane >> 4) & 1, kh_ = lane >> 5, i16_ = lane & 15;
+            const int base0 = 2 * kh_ * 128 + ((((i16_ & 3) >> 1) * 4 + (i16_ >> 2)) * 16) + (i16_ & 1) * 8 + gq_ * 128;
+            const uint32_t vA0_lo = lds0 + wc * TC * 2048 + gq_ * 1024 + base0, vA1_lo = lds0 + wc * TC * 2048 + gq_ * 1024 + ((base0 + 640) & 1023);
+            const uint32_t vB0_lo = lds0 + ((C::CT * 2) << 10) + ws * TS * 2048 + gq_ * 1024 + base0;
+            const uint32_t vB1_lo = lds0 + ((C::CT * 2) << 10) + ws * TS * 2048 + gq_ * 1024 + ((base0 + 640) & 1023);
+            const uint32_t vA0_hi = vA0_lo + 65536, vA1_hi = vA1_lo + 65536, vB0_hi = vB0_lo + 65536, vB1_hi = vB1_lo + 65536;
+#include "gemm_wgrad_tr_asm.inc"
+            EpiWgrad<T>::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane, 0, split, nullptr, 0, nullptr);
+            return;
+        }
+    }
     const int npre = nstages < PRE ? nstages : PRE;
     for (int s0 = 0; s0 < npre; ++s0) { fetch_a(s0); fetch_b(s0); ++sb; }
     if (npre >= 3) __builtin_amdgcn_s_waitcnt(waitcnt_vm(2 * C::LPW));
