@@ -569,6 +569,50 @@ template <typename Kin, int NT, int NOUT = 0> __global__ void __launch_bounds__(
     }
 }
 
+// Joints-only body query (22 joints, segments = [root | 21 body joints]) on FULL blocks of 64 poses, round 3: the pose rows enter LDS by
+// DMA (global_load_lds: the LDS image IS the global layout -- [64][63] body + [64][3] root, both with an odd row stride, i.e.
+// conflict-free per-lane rows -- 15 x 1 KiB + 6 x 256 B pieces, no index arithmetic, no VGPR round trip), every lane pulls its 66
+// inputs into registers, and the posed joints go back into the SAME 16.9 KB as the [64][66] image of the output, which leaves as 16.5
+// coalesced 16-byte stores per lane.  k_fk_joints spends about a third of its ~3000 instructions per wave on scattering float4 loads
+// into padded rows and gathering them back (integer division by the row width per element); this kernel issues ~1750.
+template <typename Kin> __global__ void __launch_bounds__(64) k_fk_joints_dma(FkArgs a) {
+    constexpr int J = Kin::J, NOUT = 22;
+    extern __shared__ float lds[];                                  // 64 * 66 floats
+    const int lane = threadIdx.x;
+    const int64_t item0 = (int64_t)blockIdx.x * 64;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    const unsigned char* body = reinterpret_cast<const unsigned char*>(a.seg[1] + item0 * 63);
+    const unsigned char* root = reinterpret_cast<const unsigned char*>(a.seg[0] + item0 * 3);
+#pragma unroll
+    for (int i = 0; i < 15; ++i) glds_asm_b128(body + i * 1024 + lane * 16, lds0 + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) glds_asm_b32(body + 15360 + i * 256 + lane * 4, lds0 + 15360 + i * 256);
+    if (a.seg[0]) {                                                 // (absent root segment = identity rotation)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) glds_asm_b32(root + i * 256 + lane * 4, lds0 + 16128 + i * 256);
+    }
+    const int64_t b = item0 + lane;
+    const float* jr = a.j_rest_batched ? a.j_rest + b * (int64_t)J * 3 : a.j_rest;
+    float tr[3] = {0.f, 0.f, 0.f};
+    if (a.transl) { tr[0] = a.transl[b * 3]; tr[1] = a.transl[b * 3 + 1]; tr[2] = a.transl[b * 3 + 2]; }
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    asm volatile("" ::: "memory");
+    float pr[NOUT * 3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pr[k] = a.seg[0] ? lds[4032 + lane * 3 + k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 63; ++k) pr[3 + k] = lds[lane * 63 + k];
+    __syncthreads();                                                // every input is in registers before the first output lands on it
+    Xf G[J];
+    fk_chain<Kin, NOUT>(std::make_integer_sequence<int, J>{}, G, pr, jr, lds + lane * (NOUT * 3), tr, a, b, NOUT);
+    __syncthreads();
+    const f32x4* l4 = reinterpret_cast<const f32x4*>(lds);
+    f32x4* o4 = reinterpret_cast<f32x4*>(a.joints + item0 * (NOUT * 3));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o4[lane + 64 * i] = l4[lane + 64 * i];
+    if (lane < 32) o4[1024 + lane] = l4[1024 + lane];
+}
+
 // ---- small batches: one wave per pose, one lane per joint -------------------------------------------------------------------
 // k_fk_joints gives a lane a whole pose: its ~55 Rodrigues + matrix products are a serial chain, 80-100 us however few poses
 // there are (a 60-frame motion-denoising step spent 190 of its 490 us in the forward and backward chains of 60 poses).  Below
@@ -599,6 +643,7 @@ struct BodyTuning {
     int64_t joint_stream_min = 1536;      // DPOSER_LBS_JOINT_STREAM_MIN: from this batch the streaming joint-gradient kernel is used
     bool blend_fp32 = false;              // DPOSER_LBS_BLEND=fp32: exact-fp32 pose-blend chain
     int skin_mode = 2;                    // DPOSER_SKIN_WAVE=0: one vertex per thread and iteration (k_skin) instead of four in flight (A/B)
+    bool fk_dma = true;                   // DPOSER_FK_DMA=0: joints-only body query through k_fk_joints instead of k_fk_joints_dma (A/B)
     void load() {
         const char* e = getenv("DPOSER_FK_SMALL_MAX");
         fk_small_max = e ? atoll(e) : (int64_t)8192;
@@ -608,6 +653,8 @@ struct BodyTuning {
         blend_fp32 = e && e[0] == 'f';
         e = getenv("DPOSER_SKIN_WAVE");
         skin_mode = e ? atoi(e) : 2;
+        e = getenv("DPOSER_FK_DMA");
+        fk_dma = !(e && e[0] == '0');
     }
 };
 static BodyTuning& body_tuning() {
@@ -762,8 +809,27 @@ template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t
     //  6.1 vs 7.1 G poses/s at 2^20 poses, 6.6 vs 8.3 at 2^22: 256 VGPRs with spills; tools/experimental/fk_stream.md)
     // (also measured and rejected: staging / evaluating / writing the joints in two or three column groups so that the LDS row
     //  shrinks and 16 instead of 9 waves fit a CU -- bit-identical, but the 132-byte row segments cost 2x: 3.9 vs 7.1 G poses/s)
-    if (a.n_out == 22 && Kin::J >= 22 && !a.pf && !a.rel)       // joints-only body query (the hot case): lean specialisation
+    if (a.n_out == 22 && Kin::J >= 22 && !a.pf && !a.rel) {     // joints-only body query (the hot case): lean specialisation
+        const bool dma_ok = NT == 64 && body_tuning().fk_dma && a.nseg >= 2 && a.seg[1] && a.seg_first[0] == 0 && a.seg_joints[0] == 1 &&
+                            a.seg_first[1] == 1 && a.seg_joints[1] == 21 && a.joints_ld == 66 && a.B >= 64 &&
+                            (((uintptr_t)a.seg[0] | (uintptr_t)a.seg[1] | (uintptr_t)a.joints) & 15) == 0;
+        if (dma_ok) {        // full blocks of 64 poses through the DMA kernel, the remaining < 64 poses through the general one
+            const int64_t nfull = a.B / 64, rem = a.B - nfull * 64;
+            hipLaunchKernelGGL(k_fk_joints_dma<Kin>, dim3((unsigned)nfull), dim3(64), 64 * 66 * sizeof(float), st, a);
+            if (rem == 0) return hipGetLastError();
+            FkArgs t = a;
+            const int64_t o = nfull * 64;
+            t.seg[0] = a.seg[0] ? a.seg[0] + o * 3 : nullptr; t.seg[1] = a.seg[1] + o * 63;
+            for (int sg = 2; sg < a.nseg && sg < FK_MAX_SEG; ++sg) t.seg[sg] = a.seg[sg] ? a.seg[sg] + o * a.seg_joints[sg] * 3 : nullptr;
+            if (a.j_rest_batched) t.j_rest = a.j_rest + o * Kin::J * 3;
+            if (a.transl) t.transl = a.transl + o * 3;
+            t.joints = a.joints + o * a.joints_ld;
+            t.B = rem;
+            hipLaunchKernelGGL((k_fk_joints<Kin, NT, 22>), dim3(1), dim3(NT), lds_floats * sizeof(float), st, t);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL((k_fk_joints<Kin, NT, 22>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
+    }
     else
         hipLaunchKernelGGL((k_fk_joints<Kin, NT>), dim3((unsigned)ceil_div(a.B, NT)), dim3(NT), lds_floats * sizeof(float), st, a);
     return hipGetLastError();
