@@ -643,6 +643,7 @@ struct BodyTuning {
     int64_t joint_stream_min = 1536;      // DPOSER_LBS_JOINT_STREAM_MIN: from this batch the streaming joint-gradient kernel is used
     bool blend_fp32 = false;              // DPOSER_LBS_BLEND=fp32: exact-fp32 pose-blend chain
     int skin_mode = 2;                    // DPOSER_SKIN_WAVE=0: one vertex per thread and iteration (k_skin) instead of four in flight (A/B)
+    bool skin_bwd_fused = true;           // DPOSER_SKIN_BWD_FUSED=0: k_skin_bwd + k_skin_bwd_joints instead of the one-pass kernel (A/B)
     bool fk_dma = true;                   // DPOSER_FK_DMA=0: joints-only body query through k_fk_joints instead of k_fk_joints_dma (A/B)
     void load() {
         const char* e = getenv("DPOSER_FK_SMALL_MAX");
@@ -653,6 +654,8 @@ struct BodyTuning {
         blend_fp32 = e && e[0] == 'f';
         e = getenv("DPOSER_SKIN_WAVE");
         skin_mode = e ? atoi(e) : 2;
+        e = getenv("DPOSER_SKIN_BWD_FUSED");
+        skin_bwd_fused = !(e && e[0] == '0');
         e = getenv("DPOSER_FK_DMA");
         fk_dma = !(e && e[0] == '0');
     }
@@ -762,6 +765,11 @@ struct dposer_body_s {
     int32_t* jl_ptr = nullptr;       // device [chunks][J + 1] entry ranges, relative to the chunk's first entry
     int32_t* jl_first = nullptr;     // device [chunks + 1] first entry of each chunk
     float2* jl_entry = nullptr;      // device [nnz] (weight, local vertex index as int bits)
+    // k_skin_bwd_fused's tables (same setup call): every chunk's joint lists cut into segments of <= 32 entries
+    bool jl_fused_ok = false;        // chunks are the regular 256-vertex grid, <= 1024 entries and <= 128 segments per chunk, K = 4
+    int32_t* jl_seg = nullptr;       // device [chunks][128] x int2 (begin, end) relative to the chunk's first entry
+    int32_t* jl_nseg = nullptr;      // device [chunks]
+    int32_t* jl_jseg = nullptr;      // device [chunks][J] (first segment | count << 16) of joint j in chunk c
 };
 
 template <typename Kin> static bool same_tree(const int32_t* p, int n) {
@@ -791,6 +799,7 @@ extern "C" int dposer_body_create(const dposer_body_desc* desc, const int32_t* p
 extern "C" void dposer_body_destroy(dposer_body_t h) {
     if (!h) return;
     (void)hipFree(h->jl_vstart); (void)hipFree(h->jl_ptr); (void)hipFree(h->jl_first); (void)hipFree(h->jl_entry);
+    (void)hipFree(h->jl_seg); (void)hipFree(h->jl_nseg); (void)hipFree(h->jl_jseg);
     delete h;
 }
 
@@ -892,9 +901,13 @@ __device__ __forceinline__ void skin_transform(const SkinArgs& a, const float* s
         const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float* Aj = sA + jj[k] * 12;
+            const f32x4* Aj = reinterpret_cast<const f32x4*>(sA) + jj[k] * 3;        // 16-byte reads: see k_skin_x4
 #pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] += w4[k] * Aj[i];
+            for (int r = 0; r < 3; ++r) {
+                const f32x4 row = Aj[r];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) T[4 * r + i] += w4[k] * row[i];
+            }
         }
     } else {
         for (int k = 0; k < a.K; ++k) {
@@ -908,7 +921,7 @@ __device__ __forceinline__ void skin_transform(const SkinArgs& a, const float* s
 // (staging the block's coordinates through LDS so that they enter and leave as consecutive dwords -- what pays in k_skin_bwd -- was
 //  measured SLOWER here: 461 -> 569 us at 4096 poses, four extra barriers per 256 vertices)
 __global__ void __launch_bounds__(256) k_skin(SkinArgs a) {
-    extern __shared__ float sA[];   // [J][12]
+    extern __shared__ __attribute__((aligned(16))) float sA[];   // [J][12]
     const int64_t b = blockIdx.y;
     for (int i = threadIdx.x; i < a.J * 12; i += 256) sA[i] = a.A[b * a.J * 12 + i];
     __syncthreads();
@@ -936,7 +949,7 @@ __global__ void __launch_bounds__(256) k_skin(SkinArgs a) {
 // offsets on their way out of L2 / MALL -- keeping the offsets out of HBM (a fused skinning epilogue) is what would help, and the
 // per-(pose, vertex) transform T = sum_k w_k A[pose][j_k] makes that epilogue need 256 poses x 55 x 12 floats (675 KB) per tile.
 __global__ void __launch_bounds__(256) k_skin_x4(SkinArgs a) {
-    extern __shared__ float sA[];   // [J][12]
+    extern __shared__ __attribute__((aligned(16))) float sA[];   // [J][12]
     const int64_t b = blockIdx.y;
     for (int i = threadIdx.x; i < a.J * 12; i += 256) sA[i] = a.A[b * a.J * 12 + i];
     float tr[3] = {0.f, 0.f, 0.f};
@@ -967,9 +980,16 @@ __global__ void __launch_bounds__(256) k_skin_x4(SkinArgs a) {
         for (int i = 0; i < 12; ++i) T[i] = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float* Aj = sA + jj[k] * 12;
+            // three 16-byte LDS reads per joint (the 48-byte transform records are 16-byte aligned).  As scalar float reads hipcc emitted
+            // 24 ds_read2_b32 per vertex -- 4 LDS cycles each, banked modulo 32 dwords, so that joints 8 apart collide: the PMC showed the
+            // LDS pipe busy for the whole kernel, 75 % of it bank-conflict cycles (1.9e8 of 2.6e8 at 4096 poses)
+            const f32x4* Aj = reinterpret_cast<const f32x4*>(sA) + jj[k] * 3;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] += w4[u][k] * Aj[i];
+            for (int r = 0; r < 3; ++r) {
+                const f32x4 row = Aj[r];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) T[4 * r + i] += w4[u][k] * row[i];
+            }
         }
         if (v < a.V) {
             float* o = out_row + (int64_t)v * 3;
@@ -1395,6 +1415,196 @@ __global__ void __launch_bounds__(128) k_skin_bwd_joints_gather(JointGatherArgs 
     }
     if (threadIdx.x < 12) a.dA[(b * a.J + j) * 12 + threadIdx.x] = red[0][threadIdx.x];
 }
+// Skinning backward in ONE streaming pass per pose (round 3): k_skin_bwd + k_skin_bwd_joints read d_verts twice and pass v_posed
+// through HBM (516 MB written and read back at 4096 SMPL-X poses; PMC: 2.8 + 1.05 GB for the pair).  One block per pose walks the
+// regular 256-vertex chunks; per chunk
+//   A  thread = vertex: T = sum_k w_k A[j_k], g = T_R^T dv, p = v_shaped + offsets  ->  LDS (dv, p, g) + the chunk's entry / segment tables
+//   B  g leaves as the two bf16 terms of the blend GEMM's operand (FT) [and as d v_posed if asked for]; the 64 lane quads take the
+//      chunk's segments (12 ... 32 list entries each, one per quad: see dposer_lbs_prepare_joint_lists) and leave partial sums in LDS
+//   C  the 4 lanes that own joint j add its segments' partials, in table order, to their running dA[j] (registers, whole pose)
+// Two barriers per chunk; the next chunk's global loads are issued before B.  Summation order: entries inside a segment in list
+// order, segments in order, chunks in order: deterministic (and different from k_skin_bwd_joints' by rounding only).
+constexpr int FUSED_MAXSEG = 128, FUSED_MAXE = 1024;
+struct SkinBwdFusedArgs {
+    const float* dverts;       // [B][V][3]
+    const float* offsets;      // [B][ld_off]
+    int64_t ld_off;
+    const float* v_shaped;
+    int v_shaped_batched;
+    const float* A;            // [B][J][12]
+    const int32_t* skin_idx;   // [V][4]
+    const float* skin_w;       // [V][4]
+    int J, V;
+    float* dvp;                // [B][V][3] or null
+    __bf16* doff_hi;           // FT bf16 [Bpad][Cpad]
+    __bf16* doff_lo;
+    int Cpad;
+    const int32_t* cfirst;     // [chunks + 1]
+    const float2* entry;       // [nnz]
+    const int2* seg;           // [chunks][FUSED_MAXSEG]
+    const int32_t* nseg;       // [chunks]
+    const int32_t* jseg;       // [chunks][J]
+    float* dA;                 // [B][J][12]
+    int chunks;
+    int64_t B;
+};
+__global__ void __launch_bounds__(256) k_skin_bwd_fused(SkinBwdFusedArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[64 * 12];
+    __shared__ f32x4 sP[256 * 4];           // per vertex and q the products dv_r * [p ; 1]_q (r = 0..2, one 16-byte record): formed ONCE per vertex by
+                                            // its own thread (a vertex sits in four joint lists; per list entry a lane does one 16-byte read, 3 FMAs)
+    __shared__ float stage[768];            // g = d loss / d v_posed of the chunk, coordinate-major
+    __shared__ float2 sent[FUSED_MAXE];
+    __shared__ int2 sseg[FUSED_MAXSEG];
+    __shared__ float part[FUSED_MAXSEG][4][3];
+    // block -> pose: the FT operand keeps 4 consecutive poses in one 128-byte line (32 B each), and block i runs on XCD i % 8 with its
+    // own L2 -- blocks 32 g + 8 i + x (i < 4) take the poses 32 g + 4 x + i, so that the four writers of a line share an L2 and are
+    // dispatched back to back (the PMC counted 1043 MB written for 516 MB of operand with the identity map)
+    const int64_t blk = blockIdx.x;
+    const int64_t b = (blk < (a.B & ~(int64_t)31)) ? (blk & ~(int64_t)31) + 4 * (blk & 7) + ((blk >> 3) & 3) : blk;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.J * 12; i += 256) sA[i] = a.A[b * a.J * 12 + i];
+    const float* vs_row = a.v_shaped + (a.v_shaped_batched ? b * a.V * 3 : 0);
+    const float* off_row = a.offsets + b * a.ld_off;
+    const float* dv_row = a.dverts + b * a.V * 3;
+    const int jq = tid >> 2, q = tid & 3;                  // joint owner / segment worker: quad and lane inside it
+    float tot[3] = {0.f, 0.f, 0.f};
+    // the chunk's per-vertex loads (clamped: tail threads load a valid vertex and contribute zeros)
+    float dv[3], pp[3];
+    f32x4 w4;
+    int4 j4;
+    auto load_vertex = [&](int c) __attribute__((always_inline)) {
+        const int v = c * 256 + tid;
+        const int vc = v < a.V ? v : a.V - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dv[k] = dv_row[(int64_t)vc * 3 + k]; pp[k] = vs_row[(int64_t)vc * 3 + k] + off_row[(int64_t)vc * 3 + k]; }
+        w4 = *reinterpret_cast<const f32x4*>(a.skin_w + (int64_t)vc * 4);
+        j4 = *reinterpret_cast<const int4*>(a.skin_idx + (int64_t)vc * 4);
+    };
+    // ... and its tables (entries, segment bounds, this quad's joint): registers, one chunk ahead like the vertex data; the per-chunk
+    // counts sit in LDS (a dependent scalar load -> global load -> LDS chain per chunk was most of the first version's time)
+    __shared__ int scf[64], sns[64];
+    for (int i = tid; i <= a.chunks && i < 64; i += 256) scf[i] = a.cfirst[i];
+    for (int i = tid; i < a.chunks && i < 64; i += 256) sns[i] = a.nseg[i];
+    float2 en_r[4];
+    int2 sg_r;
+    int js_r;
+    auto load_tables = [&](int c) __attribute__((always_inline)) {
+        const int e0 = scf[c], ne = scf[c + 1] - e0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = tid + 256 * i;
+            en_r[i] = a.entry[e0 + (k < ne ? k : 0)];
+        }
+        sg_r = a.seg[(int64_t)c * FUSED_MAXSEG + (tid < FUSED_MAXSEG ? tid : 0)];
+        js_r = a.jseg[(int64_t)c * a.J + (jq < a.J ? jq : 0)];
+    };
+    __syncthreads();
+    load_vertex(0);
+    load_tables(0);
+    for (int c = 0; c < a.chunks; ++c) {
+        const int v0 = c * 256, v = v0 + tid;
+        const int ne = scf[c + 1] - scf[c], ns = sns[c];
+        // ---- A
+        {
+            const bool live = v < a.V;
+            const int jj[4] = {j4.x, j4.y, j4.z, j4.w};
+            float T[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) T[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4* Aj = reinterpret_cast<const f32x4*>(sA) + jj[k] * 3;    // 16-byte reads: see k_skin_x4
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const f32x4 row = Aj[r];
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) T[3 * r + cc] += w4[k] * row[cc];
+                }
+            }
+            const float dx = live ? dv[0] : 0.f, dy = live ? dv[1] : 0.f, dz = live ? dv[2] : 0.f;
+            const float hv[4] = {pp[0], pp[1], pp[2], 1.0f};
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                f32x4 o;
+                o[0] = dx * hv[qq]; o[1] = dy * hv[qq]; o[2] = dz * hv[qq]; o[3] = 0.f;
+                sP[tid * 4 + qq] = o;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) stage[tid * 3 + cc] = T[cc] * dx + T[3 + cc] * dy + T[6 + cc] * dz;      // T_R^T dv
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (tid + 256 * i < ne) sent[tid + 256 * i] = en_r[i];
+        if (tid < ns) sseg[tid] = sg_r;
+        const int js = (jq < a.J) ? js_r : 0;                               // this quad's joint: (first segment | count << 16)
+        if (c + 1 < a.chunks) { load_vertex(c + 1); load_tables(c + 1); }   // in flight across B and C
+        __syncthreads();
+        // ---- B: outputs of the vertex half
+        {
+            const int nval = (a.V - v0 < 256 ? a.V - v0 : 256) * 3;
+            if (a.dvp) {
+                const int64_t row = (b * a.V + v0) * 3;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int k = i * 256 + tid;
+                    if (k < nval) a.dvp[row + k] = stage[k];
+                }
+            }
+            if (tid < 96) {
+                const int k8 = v0 * 3 + tid * 8;                                     // first coordinate of this 8-element chunk
+                if (k8 < a.Cpad) {
+                    __bf16 hi[8], lo[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (tid * 8 + e < nval) ? stage[tid * 8 + e] : 0.f;
+                        hi[e] = (__bf16)x;
+                        lo[e] = (__bf16)(x - (float)hi[e]);
+                    }
+                    *reinterpret_cast<u32x4*>(a.doff_hi + FT<__bf16>::index(b, k8, a.Cpad)) = *reinterpret_cast<u32x4*>(hi);
+                    *reinterpret_cast<u32x4*>(a.doff_lo + FT<__bf16>::index(b, k8, a.Cpad)) = *reinterpret_cast<u32x4*>(lo);
+                }
+            }
+        }
+        // ---- B: segments
+        for (int sgi = jq; sgi < ns; sgi += 64) {
+            const int2 se = sseg[sgi];
+            float acc[3] = {0.f, 0.f, 0.f};
+            int i = se.x;
+            for (; i + 4 <= se.y; i += 4) {        // four entries at a time: their dependent LDS reads (entry -> products) overlap; sums in list order
+                float2 en[4];
+                f32x4 pr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) en[u] = sent[i + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pr[u] = sP[__float_as_int(en[u].y) * 4 + q];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) acc[r] += en[u].x * pr[u][r];
+            }
+            for (; i < se.y; ++i) {
+                const float2 en = sent[i];
+                const f32x4 P = sP[__float_as_int(en.y) * 4 + q];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) acc[r] += en.x * P[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) part[sgi][q][r] = acc[r];
+        }
+        __syncthreads();
+        // ---- C
+        {
+            const int f = js & 0xffff, n = js >> 16;
+            for (int i = 0; i < n; ++i)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) tot[r] += part[f + i][q][r];
+        }
+    }
+    if (jq < a.J) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) a.dA[(b * a.J + jq) * 12 + 4 * r + q] = tot[r];
+    }
+}
 static int64_t lbs_joint_stream_min() { return body_tuning().joint_stream_min; }
 // dposer_lbs_prepare_joint_lists: (host) cut the CSR-by-joint lists (vertex ids ascending inside a joint) into chunks of
 // <= JL_MAXV vertices and <= JL_MAXE entries, sorted by joint inside a chunk -- the table the streaming joint-gradient kernel
@@ -1463,6 +1673,48 @@ extern "C" int dposer_lbs_prepare_joint_lists(dposer_body_t h, const int32_t* jp
     DP_CHECK_HIP(hipMemcpy(h->jl_first, cfirst.data(), cfirst.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     DP_CHECK_HIP(hipMemcpy(h->jl_entry, entry.data(), entry.size() * sizeof(float2), hipMemcpyHostToDevice));
     h->jl_chunks = chunks;
+    // segment tables of the fused backward kernel: joint j's run in chunk c cut into pieces of <= 32 entries, so that the 64 lane
+    // quads of a block share a chunk's ~1024 entries evenly (a chunk's vertices hang on a handful of joints: whole runs per quad,
+    // as k_skin_bwd_joints walks them, leave one quad with hundreds of entries and the rest idle)
+    (void)hipFree(h->jl_seg); (void)hipFree(h->jl_nseg); (void)hipFree(h->jl_jseg);
+    h->jl_seg = nullptr; h->jl_nseg = nullptr; h->jl_jseg = nullptr;
+    h->jl_fused_ok = false;
+    {
+        bool ok = true;
+        std::vector<int32_t> seg((size_t)chunks * FUSED_MAXSEG * 2, 0), nseg(chunks, 0), jseg((size_t)chunks * J, 0);
+        for (int c = 0; c < chunks && ok; ++c) {
+            if (vstart[c] != c * 256 || cfirst[c + 1] - cfirst[c] > FUSED_MAXE) { ok = false; break; }
+            const int32_t* pj = &cnt[(size_t)c * (J + 1)];
+            // shortest segment length that gives every one of the block's 64 quads at most one segment
+            int len = 32;
+            for (int cand : {12, 16, 20, 24, 28, 32}) {
+                int n = 0;
+                for (int j = 0; j < J; ++j) n += (pj[j + 1] - pj[j] + cand - 1) / cand;
+                if (n <= 64) { len = cand; break; }
+            }
+            int ns = 0;
+            for (int j = 0; j < J; ++j) {
+                const int first = ns;
+                for (int b0 = pj[j]; b0 < pj[j + 1]; b0 += len) {
+                    if (ns >= FUSED_MAXSEG) { ok = false; break; }
+                    seg[((size_t)c * FUSED_MAXSEG + ns) * 2] = b0;
+                    seg[((size_t)c * FUSED_MAXSEG + ns) * 2 + 1] = b0 + len < pj[j + 1] ? b0 + len : pj[j + 1];
+                    ++ns;
+                }
+                jseg[(size_t)c * J + j] = first | ((ns - first) << 16);
+            }
+            nseg[c] = ns;
+        }
+        if (ok && J * 4 <= 256 && chunks < 64) {
+            DP_CHECK_HIP(hipMalloc(&h->jl_seg, seg.size() * sizeof(int32_t)));
+            DP_CHECK_HIP(hipMalloc(&h->jl_nseg, nseg.size() * sizeof(int32_t)));
+            DP_CHECK_HIP(hipMalloc(&h->jl_jseg, jseg.size() * sizeof(int32_t)));
+            DP_CHECK_HIP(hipMemcpy(h->jl_seg, seg.data(), seg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            DP_CHECK_HIP(hipMemcpy(h->jl_nseg, nseg.data(), nseg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            DP_CHECK_HIP(hipMemcpy(h->jl_jseg, jseg.data(), jseg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            h->jl_fused_ok = true;
+        }
+    }
     h->jl_ready = true;
     return DPOSER_OK;
 }
@@ -1841,7 +2093,16 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
     __bf16* doff_hi = reinterpret_cast<__bf16*>(doff);                  // bf16 x 3: the two terms share the FT32 operand's bytes
     __bf16* doff_lo = doff_hi + Bpad * Cpad;
     DP_CHECK_HIP(hipMemsetAsync(doff, 0, Bpad * Cpad * 4, st));
-    {
+    const bool fused = !blend32 && skin_k == 4 && h->jl_ready && h->jl_fused_ok && batch >= lbs_joint_stream_min() && body_tuning().skin_bwd_fused;
+    if (fused) {
+        SkinBwdFusedArgs a;
+        a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
+        a.skin_idx = skin_idx; a.skin_w = skin_w; a.J = J; a.V = V; a.dvp = d_vposed; a.doff_hi = doff_hi; a.doff_lo = doff_lo; a.Cpad = (int)Cpad;
+        a.cfirst = h->jl_first; a.entry = h->jl_entry; a.seg = reinterpret_cast<const int2*>(h->jl_seg); a.nseg = h->jl_nseg; a.jseg = h->jl_jseg;
+        a.dA = dA; a.chunks = h->jl_chunks; a.B = batch;
+        hipLaunchKernelGGL(k_skin_bwd_fused, dim3((unsigned)batch), dim3(256), 0, st, a);
+        FK_HIP_LAUNCH(hipGetLastError());
+    } else {
         SkinBwdArgs a;
         a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
         a.skin_idx = skin_idx; a.skin_w = skin_w; a.K = skin_k; a.J = J; a.V = V; a.vp = vp; a.dvp = d_vposed;
@@ -1850,7 +2111,7 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         hipLaunchKernelGGL(k_skin_bwd, dim3((unsigned)ceil_div(V, 256 * 4), (unsigned)batch), dim3(256), (J * 12 + 1536) * sizeof(float), st, a);
         FK_HIP_LAUNCH(hipGetLastError());
     }
-    {
+    if (!fused) {
         if (batch >= lbs_joint_stream_min() && h->jl_ready) {
             JointBwdArgs a;
             a.dverts = d_verts; a.vp = vp; a.vstart = h->jl_vstart; a.cptr = h->jl_ptr; a.cfirst = h->jl_first; a.entry = h->jl_entry; a.dA = dA;
