@@ -1450,7 +1450,7 @@ struct SkinBwdFusedArgs {
 };
 __global__ void __launch_bounds__(256) k_skin_bwd_fused(SkinBwdFusedArgs a) {
     __shared__ __attribute__((aligned(16))) float sA[64 * 12];
-    __shared__ f32x4 sP[256 * 4];           // per vertex and q the products dv_r * [p ; 1]_q (r = 0..2, one 16-byte record): formed ONCE per vertex by
+    __shared__ f32x4 sP[4 * 257];           // [q][vertex] planes of 257 records (conflict-free 16-byte writes; the quad's four reads land 4 banks apart): per vertex and q the products dv_r * [p ; 1]_q (r = 0..2, one 16-byte record): formed ONCE per vertex by
                                             // its own thread (a vertex sits in four joint lists; per list entry a lane does one 16-byte read, 3 FMAs)
     __shared__ float stage[768];            // g = d loss / d v_posed of the chunk, coordinate-major
     __shared__ float2 sent[FUSED_MAXE];
@@ -1527,7 +1527,7 @@ __global__ void __launch_bounds__(256) k_skin_bwd_fused(SkinBwdFusedArgs a) {
             for (int qq = 0; qq < 4; ++qq) {
                 f32x4 o;
                 o[0] = dx * hv[qq]; o[1] = dy * hv[qq]; o[2] = dz * hv[qq]; o[3] = 0.f;
-                sP[tid * 4 + qq] = o;
+                sP[qq * 257 + tid] = o;
             }
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) stage[tid * 3 + cc] = T[cc] * dx + T[3 + cc] * dy + T[6 + cc] * dz;      // T_R^T dv
@@ -1576,7 +1576,7 @@ __global__ void __launch_bounds__(256) k_skin_bwd_fused(SkinBwdFusedArgs a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) en[u] = sent[i + u];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) pr[u] = sP[__float_as_int(en[u].y) * 4 + q];
+                for (int u = 0; u < 4; ++u) pr[u] = sP[q * 257 + __float_as_int(en[u].y)];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -1584,7 +1584,7 @@ __global__ void __launch_bounds__(256) k_skin_bwd_fused(SkinBwdFusedArgs a) {
             }
             for (; i < se.y; ++i) {
                 const float2 en = sent[i];
-                const f32x4 P = sP[__float_as_int(en.y) * 4 + q];
+                const f32x4 P = sP[q * 257 + __float_as_int(en.y)];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) acc[r] += en.x * P[r];
             }
