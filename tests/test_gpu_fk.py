@@ -382,6 +382,66 @@ def test_joint_gradient_kernels_agree(bm, monkeypatch):
     assert not np.array_equal(g_gather, g_stream)
 
 
+def test_fused_skinning_backward_agrees_with_the_two_kernel_path(bm, monkeypatch):
+    """k_skin_bwd_fused (one streaming pass per pose: d_verts read once, v_posed never in HBM, joint lists in balanced segments, poses
+    mapped to blocks in groups of four per XCD) against k_skin_bwd + k_skin_bwd_joints: same terms, another summation order inside a
+    chunk.  B = 70: the first 64 poses go through the permuted block -> pose map, the rest through the identity tail; betas require a
+    gradient, so d v_posed is written too."""
+    B = 70
+    rs = np.random.RandomState(12)
+    pose = (rs.standard_normal((B, 63)) * 0.4).astype(np.float32)
+    betas = (rs.standard_normal((B, 10)) * 0.5).astype(np.float32)
+    wv = torch.tensor(rs.standard_normal((B, 10475, 3)).astype(np.float32) / 50.0, device=DEV)
+    monkeypatch.setenv("DPOSER_LBS_JOINT_STREAM_MIN", "1")
+
+    def run():
+        _reload_tuning()
+        p = torch.tensor(pose, device=DEV, requires_grad=True)
+        b = torch.tensor(betas, device=DEV, requires_grad=True)
+        out = bm(pose_body=p, betas=b)
+        ((out.v * wv).sum() + (out.Jtr ** 2).sum()).backward()
+        return t2n(p.grad), t2n(b.grad)
+
+    fused = run()
+    monkeypatch.setenv("DPOSER_SKIN_BWD_FUSED", "0")
+    two = run()
+    monkeypatch.delenv("DPOSER_SKIN_BWD_FUSED")
+    monkeypatch.delenv("DPOSER_LBS_JOINT_STREAM_MIN")
+    _reload_tuning()
+    for name, a, b in (("d pose", fused[0], two[0]), ("d betas", fused[1], two[1])):
+        err = np.linalg.norm(a - b) / np.linalg.norm(b)
+        _log_measured(f"fused skinning backward vs two kernels, {name}", err)
+        assert err < 1e-5, (name, err)                 # measured 2e-7 / 1e-7
+        assert np.isfinite(a).all()
+    assert not np.array_equal(fused[0], two[0])        # (it really is the other kernel)
+
+
+def test_dma_staged_fk_joints_returns_the_bits_of_the_general_kernel(bm, monkeypatch):
+    """k_fk_joints_dma (full blocks of 64 poses of the 22-joint query: pose rows enter LDS by global_load_lds, joints leave as the
+    [64][66] image) against k_fk_joints, with and without root orientation / translation; 209 poses = 3 full blocks + a tail of 17
+    through the general kernel."""
+    B = 209
+    rs = np.random.RandomState(44)
+    pose = torch.tensor((rs.standard_normal((B, 63)) * 0.5).astype(np.float32), device=DEV)
+    root = torch.tensor((rs.standard_normal((B, 3)) * 0.8).astype(np.float32), device=DEV)
+    tr = torch.tensor(rs.standard_normal((B, 3)).astype(np.float32), device=DEV)
+    monkeypatch.setenv("DPOSER_FK_SMALL_MAX", "0")          # (batches up to 8192 poses would take the one-wave-per-pose kernel)
+
+    def run():
+        _reload_tuning()
+        return [bm.fk_joints(pose), bm.fk_joints(pose, root_orient=root, trans=tr)]
+
+    dma = run()
+    monkeypatch.setenv("DPOSER_FK_DMA", "0")
+    gen = run()
+    monkeypatch.delenv("DPOSER_FK_DMA")
+    monkeypatch.delenv("DPOSER_FK_SMALL_MAX")
+    _reload_tuning()
+    for a, b in zip(dma, gen):
+        assert a.shape == (B, 22, 3) and torch.equal(a, b)
+    assert not torch.equal(dma[0], dma[1])
+
+
 @pytest.mark.parametrize("model_type", ["smpl", "smplh"])
 def test_small_batch_fk_kernels_other_trees(model_type, monkeypatch):
     from dposer_amd.body_model.body_model import BodyModel
