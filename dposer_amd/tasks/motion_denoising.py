@@ -141,9 +141,19 @@ class MotionDenoise:
         weights; temporal neighbours, data-term decision and loss means per sequence), but the S * F frames share every launch --
         one 60-frame sequence leaves most of an MI355X idle (GPU-bound small kernels), and under data parallelism
         each rank takes its shard of the sequences.  Returns the ``optimize`` metrics as [S, F] arrays and pose_body [S, F, 63]."""
-        if not self._fused_supported():
-            raise NotImplementedError("optimize_sequences needs the one-call loop (axis-angle poses, sub-VP / VP SDE, positional embedding)")
         S, F = joints3d.shape[:2]
+        if not self._fused_supported():
+            # configurations outside the one-call loop (6D rotations, the VE SDE, a non-positional embedding): every sequence through
+            # `optimize`'s step-by-step loop, one after the other -- same results layout, none of the batching
+            if F != self.batch_size:
+                raise ValueError(f"optimize_sequences: {F} frames per sequence, the module was built for batch_size = {self.batch_size}")
+            res = [self.optimize(joints3d[i], gt_poses[i], time_strategy=time_strategy, sample_trun=sample_trun, sample_time=sample_time,
+                                 iterations=iterations, steps_per_iter=steps_per_iter,
+                                 noise=None if noise is None else noise[:, i * F:(i + 1) * F],
+                                 init_poses=None if init_poses is None else init_poses[i], fused=False) for i in range(S)]
+            out = {k: np.stack([np.asarray(r[k]) for r in res]) for k in ("init_MPJPE", "MPJPE", "MPVPE")}
+            out["pose_body"] = torch.stack([r["pose_body"] for r in res])
+            return out
         bm = self.body_model
         flat = lambda x: x.reshape(S * F, *x.shape[2:])
         betas = self.betas[:1].expand(S * F, -1).contiguous()

@@ -665,6 +665,28 @@ def test_gradient_is_linear_in_the_batch_across_tiling_thresholds(B):
     assert float((g - gc).norm() / gc.norm()) < 2e-3
 
 
+@pytest.mark.parametrize("reduction", ["mean", "sum_over_batch"])
+def test_prior_loss_under_the_ve_sde_vs_oracle(reduction):
+    """DPoser prior with training.sde = 'vesde' (smplify.py:38-40 builds it; the fused prior kernel covers sub-VP / VP): the unfused path --
+    HIP score function + the reference's elementwise steps -- against the oracle's VE class, loss and gradient w.r.t. the poses."""
+    from dposer_amd.algorithms.advanced import sde_lib
+    from dposer_amd.prior import prior_loss
+    cfg, m, p = make_model(35, precision="fp32", dropout=0.0)
+    rs = np.random.RandomState(13)
+    B = 40
+    sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50.0, N=1000)
+    x0 = rs.standard_normal((B, 63)).astype(np.float32)
+    z = rs.standard_normal((B, 63)).astype(np.float32)
+    for t, weighted in ((0.21, True), (0.6, False)):
+        xg = _dev(x0).requires_grad_(True)
+        loss = prior_loss(m, sde, xg, t, weighted=weighted, reduction=reduction, batch_size=32, z=_dev(z))
+        loss.backward()
+        lref, gref = R.dposer_prior_loss(p, R.VE(), torch.tensor(x0), torch.full((B,), t), torch.tensor(z), weighted=weighted,
+                                         reduction=reduction, batch_size=32)
+        assert abs(float(loss.detach()) - float(lref)) / abs(float(lref)) < 2e-5, (t, weighted)
+        assert rel_err(t2n(xg.grad), gref.numpy()) < 2e-5, (t, weighted)
+
+
 def test_vp_sde_fused_paths_vs_oracle():
     """The fused sampler (both step paths), the prior loss and the DSM gradient under the VP SDE (std = sqrt(1 - e^{2 lmc}),
     g = sqrt(beta): the other branch of the SDE scalars inside the kernels) against the oracle's VP class."""

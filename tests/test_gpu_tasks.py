@@ -223,6 +223,25 @@ def test_motion_denoise_batch_of_sequences_equals_one_sequence_at_a_time():
         assert np.allclose(log[:, i, :2], t2n(md.loss_log)[:, 0, :2], rtol=1e-6)
 
 
+def test_motion_denoise_under_the_ve_sde_runs_the_step_by_step_loop():
+    """training.sde = 'vesde' (motion_denoising.py:60-62 builds it) is outside the one-call loop: `optimize` takes the autograd loop with
+    the unfused VE prior, `optimize_sequences` walks the sequences through it one by one and returns the batched layout."""
+    from dposer_amd.algorithms.advanced import sde_lib
+    F, S, iters, spi = 6, 2, 1, 3
+    md, joints3d, gt, init, rs = _md_setup(F * S)
+    md.sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50.0, N=500)
+    md.batch_size = F
+    md.betas = md.betas[:F]
+    assert not md._fused_supported()
+    noise = torch.tensor(rs.standard_normal((iters * spi, F * S, 63)).astype(np.float32), device=DEV)
+    kw = dict(time_strategy="3", iterations=iters, steps_per_iter=spi)
+    res = md.optimize_sequences(joints3d.reshape(S, F, 22, 3), gt.reshape(S, F, 63), noise=noise, init_poses=init.reshape(S, F, 63), **kw)
+    assert res["pose_body"].shape == (S, F, 63) and res["MPJPE"].shape == (S, F) and np.isfinite(res["MPVPE"]).all()
+    one = md.optimize(joints3d[F:], gt_poses=gt[F:], noise=noise[:, F:].contiguous(), init_poses=init[F:], **kw)
+    assert torch.equal(res["pose_body"][1], one["pose_body"])
+    assert float((res["pose_body"][1] - init[F:]).abs().max()) > 1e-3            # (the poses moved)
+
+
 def test_evaluate_motion_denoising_shards_sequences_over_ranks():
     """evaluate_motion_denoising: contiguous shard of the sequences per rank, several sequences per call, metric means from (sum,
     count) pairs.  Two 'ranks' evaluated one after the other cover all sequences; their frame-weighted means combine to the
