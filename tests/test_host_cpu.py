@@ -372,3 +372,22 @@ def test_dropout_decisions_philox7_statistics():
     for other in (dropout_keep_mask(B, H, 1, 5, 42, p), dropout_keep_mask(B, H, 0, 6, 42, p), dropout_keep_mask(B, H, 0, 5, 43, p)):
         assert abs(((other - other.mean()) * c).mean() / 0.09) < 5 / np.sqrt(n)   # other site / step / seed: uncorrelated
         assert (other != m).mean() > 0.15
+
+
+def test_generated_wgrad_k_loop_is_in_sync_with_its_generator():
+    """dposer_amd/csrc/gemm_wgrad_tr_asm.inc (the hand-placed K loop of the sample-major wgrad kernel, one asm statement) is the committed
+    output of tools/gen_wgrad_asm.py; every ring stage issues its 16 MFMAs, 24 transposing reads and -- when it fetches -- 4 DMA pieces."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_wgrad_asm.py")], capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(root, "dposer_amd", "csrc", "gemm_wgrad_tr_asm.inc")) as f:
+        assert f.read() == out
+    stages = out.split("// ---- stage on slot")[1:]
+    assert len(stages) == 3 + 4 + 3                                        # leading stages 1..3, the group of four, the three tail stages
+    for st in stages:
+        mode = int(st.split("mode")[1].split()[0])
+        assert st.count("v_mfma_f32_32x32x16_bf16") == 16
+        assert st.count("ds_read_b64_tr_b16") == (12 if mode == 3 else 24)
+        assert st.count("global_load_lds_dwordx4") == (4 if mode == 0 else 0)
+        assert st.count("s_barrier") == (0 if mode == 3 else 1)
