@@ -213,17 +213,40 @@ template <typename T, bool TRAIN, int RESID = -1, bool ACTRT = false> struct Epi
                 const int cl = tc * 32 + 8 * q + 4 * hi;
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
                 const f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + 2 * lstride + cl);
+                if constexpr (!ACTRT && !PRECISE) {
+                    // bf16-mode SiLU on register PAIRS: everything around the two transcendentals as packed fp32 math (as scalar code hipcc
+                    // left the -log2(e) multiply and the 1 + e add unpacked: 2 of the ~12 VALU operations per value of the inference epilogue)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    cy.v[4 * q + r] *= cy.rstd;                                   // x_hat
-                    const float a_ = g4[r] * cy.v[4 * q + r] + e4[r];
-                    float y;
-                    if constexpr (ACTRT) y = TRAIN ? act_rt<PRECISE>(a_, pp.act) * dscale : act_rt<PRECISE>(a_, pp.act);
-                    else if constexpr (!TRAIN) y = silu_f<PRECISE>(a_);
-                    else if constexpr (PRECISE) y = silu_f<true>(a_) * dscale;
-                    else y = a_ * __builtin_amdgcn_rcpf(__builtin_fmaf(__expf(-a_), dinv, dinv));
-                    if constexpr (TRAIN) y = __uint_as_float(__float_as_uint(y) & bit_mask_rt(cy.bits, 4 * q + r));
-                    o[4 * q + r] = y;
+                    for (int r = 0; r < 4; r += 2) {
+                        f32x2 v2 = {cy.v[4 * q + r], cy.v[4 * q + r + 1]};
+                        v2 *= cy.rstd;                                            // x_hat
+                        cy.v[4 * q + r] = v2[0]; cy.v[4 * q + r + 1] = v2[1];
+                        const f32x2 g2 = {g4[r], g4[r + 1]}, e2 = {e4[r], e4[r + 1]};
+                        const f32x2 a2 = g2 * v2 + e2;
+                        const f32x2 t2 = a2 * -1.4426950408889634f;
+                        const f32x2 ex = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+                        const f32x2 den = TRAIN ? ex * dinv + dinv : ex + 1.0f;   // training: 1 / (1 - p) rides inside the reciprocal
+                        const f32x2 rc = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                        const f32x2 y2 = a2 * rc;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            float y = y2[u];
+                            if constexpr (TRAIN) y = __uint_as_float(__float_as_uint(y) & bit_mask_rt(cy.bits, 4 * q + r + u));
+                            o[4 * q + r + u] = y;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        cy.v[4 * q + r] *= cy.rstd;                                   // x_hat
+                        const float a_ = g4[r] * cy.v[4 * q + r] + e4[r];
+                        float y;
+                        if constexpr (ACTRT) y = TRAIN ? act_rt<PRECISE>(a_, pp.act) * dscale : act_rt<PRECISE>(a_, pp.act);
+                        else y = TRAIN ? silu_f<true>(a_) * dscale : silu_f<true>(a_);
+                        if constexpr (TRAIN) y = __uint_as_float(__float_as_uint(y) & bit_mask_rt(cy.bits, 4 * q + r));
+                        o[4 * q + r] = y;
+                    }
                 }
             }
             if (TRAIN) TileIO<T>::store(p.xhat + tb, lane, cy.v);
