@@ -41,6 +41,9 @@ struct GemmArgs {
 #ifndef DPOSER_KLOOP_ASM      // (tuner A/B switch: 0 = the hipcc-scheduled steady-state stage)
 #define DPOSER_KLOOP_ASM 1
 #endif
+#ifndef DPOSER_KLOOP_ASM_MID  // (tuner A/B switch for the 128x128 / 4-wave tiling's asm stage)
+#define DPOSER_KLOOP_ASM_MID 1
+#endif
 
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> {
@@ -282,7 +285,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         const int npre = nstages < PRE ? nstages : PRE;
         // Hand-placed steady-state stage (gemm_kloop_asm.h) for the shipped 256x256 bf16 tiling; every DMA of such a kernel is issued
         // from asm (saddr form: SGPR base per piece + one VGPR offset per operand), the compiler tracks none of them.
-        constexpr bool ASM = DPOSER_KLOOP_ASM && sizeof(T) == 2 && NB == 4 && KB == 2 && TC == 4 && TS == 2 && WC == 2 && WS == 4;
+        constexpr bool ASM_BIG = DPOSER_KLOOP_ASM && sizeof(T) == 2 && NB == 4 && KB == 2 && TC == 4 && TS == 2 && WC == 2 && WS == 4;
+        constexpr bool ASM_MID = DPOSER_KLOOP_ASM && DPOSER_KLOOP_ASM_MID && sizeof(T) == 2 && NB == 4 && KB == 2 && TC == 2 && TS == 2 && WC == 2 && WS == 2;
+        constexpr bool ASM = ASM_BIG || ASM_MID;
         const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
         const uint32_t s_m0 = __builtin_amdgcn_readfirstlane(lds0 + (wave << 10));
         uint32_t v_wofs = lane * 16 + (w_kb << 10), v_xofs = lane * 16 + (seg_kb << 10);
@@ -382,8 +387,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         if constexpr (ASM) {
             const uint32_t vA_lo = lds0 + ((wc * TC * KB) << 10) + lane * 16, vB_lo = lds0 + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
             const uint32_t vA_hi = vA_lo + 65536, vB_hi = vB_lo + 65536;
-#define DP_RING_STAGE(S, MODE)                                                                                                             \
-    ring_stage_asm<S, MODE>(acc, fa[0], fb[0], fa[1], fb[1], vA_lo, vB_lo, vA_hi, vB_hi, v_wofs, v_xofs, sW[0], sW[1], sX[0], sX[1], s_m0); \
+#define DP_RING_STAGE(S, MODE)                                                                                                                     \
+    if constexpr (ASM_BIG) ring_stage_asm<S, MODE>(acc, fa[0], fb[0], fa[1], fb[1], vA_lo, vB_lo, vA_hi, vB_hi, v_wofs, v_xofs, sW[0], sW[1], sX[0], sX[1], s_m0); \
+    else ring_stage_asm_mid<S, MODE>(acc, fa[0], fb[0], fa[1], fb[1], vA_lo, vB_lo, v_wofs, v_xofs, sW[0], sW[1], sX[0], sX[1], s_m0);             \
     ++t
             // the ring starts at slot0 = 4 - rem: the `rem` stages in front of the groups of four run on slots 4 - rem ... 3
             const int rem = n_dma & 3;

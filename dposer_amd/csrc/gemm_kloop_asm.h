@@ -52,9 +52,12 @@ template <int S> struct RingSlot {
     DP_RS_MFMA(c21, a12, b11) XADD                                                                                 \
     DP_RS_MFMA(c30, a13, b10)                                                                                      \
     DP_RS_MFMA(c31, a13, b11) "s_waitcnt lgkmcnt(0)\n"
+// The compiler does not know that the statement ends on an MFMA: the wait states between an 8-pass XDL write and a VALU read of its result
+// (11 on gfx940-family parts; the hazard recognizer inserts them for MFMAs it sees) are spent inside the LAST stage's statement.
+#define DP_RS_XDL_DRAIN "s_nop 7\n" "s_nop 7\n"
 #define DP_RS_HALF2_LAST                                                                                           \
     DP_RS_MFMA(c00, a10, b10) DP_RS_MFMA(c01, a10, b11) DP_RS_MFMA(c10, a11, b10) DP_RS_MFMA(c11, a11, b11)        \
-    DP_RS_MFMA(c20, a12, b10) DP_RS_MFMA(c21, a12, b11) DP_RS_MFMA(c30, a13, b10) DP_RS_MFMA(c31, a13, b11)
+    DP_RS_MFMA(c20, a12, b10) DP_RS_MFMA(c21, a12, b11) DP_RS_MFMA(c30, a13, b10) DP_RS_MFMA(c31, a13, b11) DP_RS_XDL_DRAIN
 #define DP_RS_M0(m) "s_add_i32 m0, %[sm0], %[" #m "]\n"       // (an MFMA and a ds_read sit between the M0 write and the DMA that uses it)
 #define DP_RS_DMA(v, s) "global_load_lds_dwordx4 %[" #v "], %[" #s "]\n"
 #define DP_RS_OPERANDS                                                                                                                 \
@@ -96,6 +99,46 @@ __device__ __forceinline__ void ring_stage_asm(f32x16 (&acc)[4][2], bf16x8 (&f0a
         asm volatile(DP_RS_HALF1("", "", "", "", "", "s_waitcnt vmcnt(0) lgkmcnt(0)\n", "s_barrier\n") DP_RS_HALF2("", "", "", "", "") DP_RS_OPERANDS);
     } else {
         asm volatile(DP_RS_HALF1("", "", "", "", "", "s_waitcnt lgkmcnt(0)\n", "") DP_RS_HALF2_LAST DP_RS_OPERANDS);
+    }
+}
+
+// ---- the 128x128 / 4-wave tiling (TC = 2, TS = 2, KB = 2, NB = 4; two workgroups per CU): same stage contract, 8 MFMAs, 8 fragment reads and
+// 4 DMA pieces per stage; slots of 16 KiB, so the whole 64-KiB ring is within the 16-bit ds_read offset of ONE base per operand.
+#define DP_RM_HALF1(W0S, W0L, W1S, W1L, WADD, WAIT, BARRIER)                                                      \
+    DP_RS_MFMA(c00, a00, b00) DP_RS_READ(a10, vA, r1a0) DP_RS_READ(b10, vB, r1b0) W0S                              \
+    DP_RS_MFMA(c01, a00, b01) DP_RS_READ(b11, vB, r1b1) DP_RS_READ(a11, vA, r1a1) W0L W1S                          \
+    DP_RS_MFMA(c10, a01, b00) W1L WADD WAIT                                                                        \
+    DP_RS_MFMA(c11, a01, b01) BARRIER
+#define DP_RM_HALF2(X0S, X0L, X1S, X1L, XADD)                                                                      \
+    DP_RS_MFMA(c00, a10, b10) DP_RS_READ(a00, vA, r0a0) DP_RS_READ(b00, vB, r0b0) X0S                              \
+    DP_RS_MFMA(c01, a10, b11) DP_RS_READ(b01, vB, r0b1) DP_RS_READ(a01, vA, r0a1) X0L X1S                          \
+    DP_RS_MFMA(c10, a11, b10) X1L XADD                                                                             \
+    DP_RS_MFMA(c11, a11, b11) "s_waitcnt lgkmcnt(0)\n"
+#define DP_RM_HALF2_LAST DP_RS_MFMA(c00, a10, b10) DP_RS_MFMA(c01, a10, b11) DP_RS_MFMA(c10, a11, b10) DP_RS_MFMA(c11, a11, b11) DP_RS_XDL_DRAIN
+#define DP_RM_OPERANDS                                                                                                                 \
+        : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),                                  \
+          [a00] "+v"(f0a[0]), [a01] "+v"(f0a[1]), [b00] "+v"(f0b[0]), [b01] "+v"(f0b[1]),                                               \
+          [a10] "=&v"(f1a[0]), [a11] "=&v"(f1a[1]), [b10] "=&v"(f1b[0]), [b11] "=&v"(f1b[1]), [vw] "+v"(v_wofs), [vx] "+v"(v_xofs)     \
+        : [vA] "v"(vA), [vB] "v"(vB), [sW0] "s"(sW0), [sW1] "s"(sW1), [sX0] "s"(sX0), [sX1] "s"(sX1), [sm0] "s"(s_m0),                  \
+          [r1a0] "n"(R1), [r1a1] "n"(R1 + 2048), [r1b0] "n"(R1), [r1b1] "n"(R1 + 2048),                                                \
+          [r0a0] "n"(R0), [r0a1] "n"(R0 + 2048), [r0b0] "n"(R0), [r0b1] "n"(R0 + 2048),                                                \
+          [mw0] "n"(M), [mw1] "n"(M + 4096), [mx0] "n"(M + 8192), [mx1] "n"(M + 12288)                                                 \
+        : "memory", "scc"
+template <int S, int MODE = 0>
+__device__ __forceinline__ void ring_stage_asm_mid(f32x16 (&acc)[2][2], bf16x8 (&f0a)[2], bf16x8 (&f0b)[2], bf16x8 (&f1a)[2], bf16x8 (&f1b)[2],
+                                                   uint32_t vA, uint32_t vB, uint32_t& v_wofs, uint32_t& v_xofs, uint64_t sW0, uint64_t sW1,
+                                                   uint64_t sX0, uint64_t sX1, uint32_t s_m0) {
+    constexpr int S1 = (S + 1) & 3, D = (S + 3) & 3;
+    constexpr int R1 = S * 16384 + 1024, R0 = S1 * 16384, M = D * 16384;
+    if constexpr (MODE == 0) {
+        asm volatile(DP_RM_HALF1(DP_RS_M0(mw0), DP_RS_DMA(vw, sW0), DP_RS_M0(mw1), DP_RS_DMA(vw, sW1), "v_add_u32 %[vw], 0x800, %[vw]\n", "s_waitcnt vmcnt(6) lgkmcnt(0)\n", "s_barrier\n")
+                     DP_RM_HALF2(DP_RS_M0(mx0), DP_RS_DMA(vx, sX0), DP_RS_M0(mx1), DP_RS_DMA(vx, sX1), "v_add_u32 %[vx], 0x800, %[vx]\n") DP_RM_OPERANDS);
+    } else if constexpr (MODE == 1) {
+        asm volatile(DP_RM_HALF1("", "", "", "", "", "s_waitcnt vmcnt(4) lgkmcnt(0)\n", "s_barrier\n") DP_RM_HALF2("", "", "", "", "") DP_RM_OPERANDS);
+    } else if constexpr (MODE == 2) {
+        asm volatile(DP_RM_HALF1("", "", "", "", "", "s_waitcnt vmcnt(0) lgkmcnt(0)\n", "s_barrier\n") DP_RM_HALF2("", "", "", "", "") DP_RM_OPERANDS);
+    } else {
+        asm volatile(DP_RM_HALF1("", "", "", "", "", "s_waitcnt lgkmcnt(0)\n", "") DP_RM_HALF2_LAST DP_RM_OPERANDS);
     }
 }
 

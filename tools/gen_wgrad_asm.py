@@ -113,6 +113,9 @@ def main():
         L += stage(S, 0)
     L += ["s_sub_u32 %[grp], %[grp], 1", "s_cmp_lg_u32 %[grp], 0", "s_cbranch_scc1 Lg_%=", "Lt_%=:"]
     L += stage(0, 1) + stage(1, 2) + stage(2, 3)
+    # the compiler does not know that the statement ends on MFMAs: the wait states between an 8-pass XDL write and a VALU read of its
+    # result (the hazard recognizer inserts them for MFMAs it sees) are spent here
+    L += ["s_nop 7", "s_nop 7"]
     print("// GENERATED by tools/gen_wgrad_asm.py -- do not edit.  The K loop of gemm_wgrad_tr_kernel<2, 4, 4, 2, 4> (see the generator's header).")
     print("asm volatile(")
     for line in L:

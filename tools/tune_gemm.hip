@@ -301,9 +301,19 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(h2.data(), xhat, h2.size() * 2, hipMemcpyDeviceToHost));
             size_t bad1 = 0, bad2 = 0, nz = 0;
             for (size_t i = 0; i < h0.size(); ++i) { bad1 += h0[i] != h1[i]; bad2 += h0[i] != h2[i]; nz += h0[i] != 0; }
+            if (bad1 && getenv("TUNE_TAILS_DEBUG")) {        // where do the mismatches sit inside the 128x128 tile (32x32 sub-tiles: sample block x channel block)?
+                size_t hist[4][4] = {};
+                for (int64_t s_ = 0; s_ < S; ++s_)
+                    for (int c = 0; c < C; ++c) {
+                        const size_t i = (size_t)FT<__bf16>::index(s_, c, C);
+                        if (h0[i] != h1[i]) hist[(s_ % 128) / 32][(c % 128) / 32]++;
+                    }
+                for (int a_ = 0; a_ < 4; ++a_) printf("   sample block %d: %zu %zu %zu %zu (channel blocks 0..3)\n", a_, hist[a_][0], hist[a_][1], hist[a_][2], hist[a_][3]);
+            }
             // the shipped 256x256 ring (NB = 4: hand-placed steady-state stages, gemm_kloop_asm.h)
             g_cases.clear();
             add_plain<2, 4, 4, 2, 2, 4>("ring4 256", S, C, Kt, W, X, o1);
+            add_plain<2, 2, 2, 2, 2, 4>("ring4 128 (again, into xhat)", S, C, Kt, W, X, xhat);
             CK(hipMemset(o1, 0xdd, (size_t)S * C * 2));
             for (auto& c : g_cases) c.launch();
             CK(hipDeviceSynchronize());
