@@ -67,7 +67,7 @@ def pmc_fk_bytes_per_pose():
     """HBM bytes per pose of the joints-only FK kernel from the committed PMC passes: the bench launches it at 2^20 (23 launches) and
     2^22 poses (12 launches); the table holds the per-launch average over all of them."""
     try:
-        row = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))["k_fk_joints<KinSMPLX, 64, 22>"]
+        row = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))["k_fk_joints_dma<KinSMPLX>"]
         poses = (23 * (1 << 20) + 12 * (1 << 22)) / 35.0
         return (row["read_MB"] + row["write_MB"]) * 1e6 / poses if row["launches"] == 35 else None
     except Exception:
@@ -376,7 +376,7 @@ def main():
         fk_s = e0.elapsed_time(e1) * 1e-3 / 20
         fk_gbs = 516.0 * nfk / fk_s / 1e9
         extra["fk_joints"] = {"poses_per_s_per_gpu": nfk / fk_s, "batch": nfk,
-                              "roofline": {"bound": "hbm", "kernel": "k_fk_joints<KinSMPLX, 64, 22>", "achieved": fk_gbs, "peak": HBM_PEAK_GBS,
+                              "roofline": {"bound": "hbm", "kernel": "k_fk_joints_dma<KinSMPLX>", "achieved": fk_gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": fk_gbs / HBM_PEAK_GBS,
                                            "traffic": None if pmc_fk_bytes_per_pose() is None else pmc_fk_bytes_per_pose() * nfk,
                                            "traffic_source": "lookup: profiles/pmc_hbm_traffic.json (bytes per pose x 2^20); NOT measured in this run",
