@@ -721,6 +721,53 @@ template <typename T, int ABL = 0, bool ACTRT = false> struct EpiGNBwd {
                 }
                 if (p.carry_out) TileIO<T>::store(p.carry_out + tb, lane, g);
                 float s1 = 0.f, s2 = 0.f;
+                if constexpr (!ACTRT && (ABL & 32) == 0) {
+                    // register PAIRS (packed fp32 math around the two transcendentals; even / odd partial sums): as scalar code hipcc left ~850
+                    // of this epilogue's ~3500 VALU instructions per wave tile as unpacked v_add_f32 (the running sums are dependent chains)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 s1p = {0.f, 0.f}, s2p = {0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cl = tc * 32 + 8 * q + 4 * hi;
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(lpar + cl);
+                        const f32x4 e4 = *reinterpret_cast<const f32x4*>(lpar + lstride + cl);
+#pragma unroll
+                        for (int r = 0; r < 4; r += 2) {
+                            const int i = 4 * q + r;
+                            const f32x2 xh2 = {xh[i], xh[i + 1]}, gm2 = {g4[r], g4[r + 1]}, be2 = {e4[r], e4[r + 1]};
+                            const f32x2 gg2 = {__uint_as_float(__float_as_uint(g[i]) & bit_mask_rt(bits, i)),
+                                               __uint_as_float(__float_as_uint(g[i + 1]) & bit_mask_rt(bits, i + 1))};
+                            const f32x2 a2 = gm2 * xh2 + be2;
+                            const f32x2 t2 = a2 * -1.4426950408889634f;
+                            const f32x2 ex = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+                            const f32x2 den = ex + 1.0f;
+                            const f32x2 sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                            const f32x2 ds2 = sg * (a2 * (1.0f - sg) + 1.0f);          // silu'(a) = s (1 + a (1 - s))
+                            const f32x2 da2 = gg2 * ds2;                               // (the 1/(1-p) factor is applied to gamma and to the sums)
+                            f32x2 st0 = {stat[i], stat[i + 1]}, st1 = {stat[16 + i], stat[17 + i]};
+                            st0 += da2 * xh2;
+                            st1 += da2;
+                            stat[i] = st0[0]; stat[i + 1] = st0[1]; stat[16 + i] = st1[0]; stat[17 + i] = st1[1];
+                            const f32x2 dx2 = da2 * (gm2 * p.scale);                   // dx
+                            g[i] = dx2[0]; g[i + 1] = dx2[1];
+                            s1p += dx2;
+                            s2p += dx2 * xh2;
+                        }
+                    }
+                    s1 = sum_xor32(s1p[0] + s1p[1]);
+                    s2 = sum_xor32(s2p[0] + s2p[1]);
+                    const float m1 = s1 * (1.0f / 32.0f), m2 = s2 * (1.0f / 32.0f);
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) {
+                        const f32x2 xh2 = {xh[i], xh[i + 1]};
+                        f32x2 g2 = {g[i], g[i + 1]};
+                        g2 = ((g2 - m1) - xh2 * m2) * rstd;                           // dy
+                        g[i] = g2[0]; g[i + 1] = g2[1];
+                        f32x2 db2 = {dbias[i], dbias[i + 1]};
+                        db2 += g2;
+                        dbias[i] = db2[0]; dbias[i + 1] = db2[1];
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int cl = tc * 32 + 8 * q + 4 * hi;
@@ -747,6 +794,7 @@ template <typename T, int ABL = 0, bool ACTRT = false> struct EpiGNBwd {
                 for (int i = 0; i < 16; ++i) {
                     g[i] = rstd * (g[i] - m1 - xh[i] * m2);   // dy
                     dbias[i] += g[i];
+                }
                 }
                 TileIO<T>::store(p.dy + tb, lane, g);
                 if (pp.dyT) TileT<T>::store((T*)pp.dyT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, g);

@@ -173,6 +173,10 @@ int main(int argc, char** argv) {
         GB(2, 4, 4, 2, 2, 4, 1, 0, 0, 0);
         GB(2, 4, 4, 2, 2, 4, 1, 0, 1, 0);
         GB(2, 4, 4, 2, 2, 4, 1, 0, 1, 1);
+        if (getenv("TUNE_GNBWD_PACK")) {       // packed (default) vs scalar inner loop of the GroupNorm-backward epilogue (ABL bit 32), same binary
+            add_gnbwd<2, 4, 4, 2, 2, 4, 32>("2,4,4,2 scalar-loop", S, C, K, W, X, o1, xhat, rstd, gamma, beta, part, nullptr, nullptr, nullptr, 0.1f);
+            add_gnbwd<2, 4, 4, 2, 2, 4, 32>("2,4,4,2 scalar-loop carry11", S, C, K, W, X, o1, xhat, rstd, gamma, beta, part, nullptr, cin, cout, 0.1f);
+        }
         run_all(7, 10);
         return 0;
     }
