@@ -981,6 +981,23 @@ template <typename T> struct EpiWgrad {
     __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int split, const float*, int, unsigned char*) {
         const int j = lane & 31, hi = lane >> 5;
         float* base = p.slab + (int64_t)split * p.slab_stride;
+        // wave tile completely inside the matrix and the slab below 4 GB (every training wgrad): one 32-bit byte offset per lane, row /
+        // tile steps as scalar multiples of ld -- no per-element 64-bit address product, no per-element bounds test (the general loop
+        // below costs ~4 VALU per stored value: 520 of this epilogue's ~1000 instructions per wave)
+        if ((int)sbase + TS * 32 <= p.K_valid && cbase + TC * 32 <= p.N_valid && (uint64_t)p.N_valid * (uint64_t)p.ld < (1ull << 30)) {
+            const uint32_t off0 = ((uint32_t)(cbase + 4 * hi) * (uint32_t)p.ld + (uint32_t)sbase + (uint32_t)j) * 4u;
+            char* b0 = reinterpret_cast<char*>(base);
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                for (int ts = 0; ts < TS; ++ts)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t o = off0 + ((uint32_t)(tc * 32 + (r & 3) + 8 * (r >> 2)) * (uint32_t)p.ld + (uint32_t)(ts * 32)) * 4u;
+                        *reinterpret_cast<float*>(b0 + o) = acc[tc][ts][r];
+                    }
+            return;
+        }
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
