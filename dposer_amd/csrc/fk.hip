@@ -2041,6 +2041,22 @@ static int lbs_bwd_ksplit_bf16(int64_t kblocks, int64_t tiles) {
     }
     return best;
 }
+// 256x256 tiles for the bf16 backward blend GEMMs from 2048 poses up (one 256-CU round of long-K workgroups: 3 x 110 us instead of
+// 3 x 161 us with the 128x128 tiles at 4096 poses): the split count that fills the last round best, at most 8 (24 slabs); 0 = not applicable
+static int lbs_bwd_big_ksplit(int64_t Bpad, int64_t prow, int64_t kblocks) {
+    static const bool off = [] { const char* e = getenv("DPOSER_LBS_BWD_BIG"); return e && e[0] == '0'; }();
+    if (off || Bpad % 256 != 0 || prow % 256 != 0 || Bpad < 2048) return 0;
+    const int64_t tiles = (Bpad / 256) * (prow / 256);
+    int best = 0;
+    double best_u = 0.0;
+    for (int c = 1; c <= 8; ++c) {
+        if (kblocks % (2 * c) != 0 || kblocks / c < 32) continue;
+        const int64_t wg = tiles * c;
+        const double u = (double)wg / (double)(256 * ceil_div(wg, 256));
+        if (u > best_u + 1e-9) { best_u = u; best = c; }
+    }
+    return best_u >= 0.75 ? best : 0;
+}
 static int64_t lbs_bwd_slabs(int64_t Bpad, int64_t Cpad, int64_t prow) {
     const int ks = lbs_bwd_ksplit_bf16(Cpad / 16, (Bpad / 128) * (prow / 128));
     return 3 * ks > 24 ? 3 * ks : 24;
@@ -2150,17 +2166,19 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         const char* pd_hi = (const char*)posedirs_bwd_packed + prow * Cpad * 4;
         const char* pd_lo = pd_hi + prow * Cpad * 2;
         const int kb = (int)(Cpad / 16);
-        const int k1 = lbs_bwd_ksplit_bf16(kb, (Bpad / 128) * (prow / 128));
+        const int kbig = lbs_bwd_big_ksplit(Bpad, prow, kb);
+        const int tile = kbig ? 256 : 128;
+        const int k1 = kbig ? kbig : lbs_bwd_ksplit_bf16(kb, (Bpad / 128) * (prow / 128));
         for (int term = 0; term < 3; ++term) {
             GemmArgs g;
             std::memset(&g, 0, sizeof(g));
             g.W = term == 2 ? (const void*)doff_lo : (const void*)doff_hi; g.w_stride_blocks = kb;
-            g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(prow / 128); g.ksplit = k1;
+            g.n_cblk = (int)(Bpad / tile); g.n_sblk = (int)(prow / tile); g.ksplit = k1;
             g.src[0] = term == 1 ? pd_lo : pd_hi; g.seg_kblocks[0] = kb; g.nseg = 1; g.ktot_blocks = kb;
             WgradParams wp;
             wp.slab = dpf + (int64_t)term * k1 * Bpad * prow; wp.slab_stride = Bpad * prow; wp.ld = (int)prow; wp.N_valid = (int)batch;
             wp.K_valid = (J - 1) * 9;
-            FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, SHAPE_MID, g, wp, st));
+            FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, kbig ? SHAPE_BIG : SHAPE_MID, g, wp, st));
         }
         ks = 3 * k1;
     }
