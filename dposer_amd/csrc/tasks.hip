@@ -67,14 +67,15 @@ __global__ void __launch_bounds__(256) k_md_vert_grad(const float* verts, float*
             const float* q = p + (int64_t)V * 3;
             const float ax = px - q[0], ay = py - q[1], az = pz - q[2];
             const float d = sqrtf(ax * ax + ay * ay + az * az);
-            gx = ax / d; gy = ay / d; gz = az / d;
+            const float inv = __builtin_amdgcn_rcpf(d);          // one v_rcp_f32 (1 ulp) instead of three IEEE divisions (~10 VALU each); 0 * inf = NaN as 0 / 0
+            gx = ax * inv; gy = ay * inv; gz = az * inv;
             d_sum = d;
         }
         if (tf > 0) {
             const float* q = p - (int64_t)V * 3;
             const float bx = q[0] - px, by = q[1] - py, bz = q[2] - pz;
-            const float d = sqrtf(bx * bx + by * by + bz * bz);
-            gx -= bx / d; gy -= by / d; gz -= bz / d;
+            const float inv = __builtin_amdgcn_rsqf(bx * bx + by * by + bz * bz);      // v_rsq_f32: this distance only feeds the gradient (rsq(0) = inf: 0 * inf = NaN)
+            gx -= bx * inv; gy -= by * inv; gz -= bz * inv;
         }
         float* o = dverts + ((int64_t)t * V + v) * 3;
         o[0] = c * gx; o[1] = c * gy; o[2] = c * gz;
