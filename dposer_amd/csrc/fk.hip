@@ -1569,24 +1569,24 @@ __global__ void __launch_bounds__(256) k_skin_bwd_fused(SkinBwdFusedArgs a) {
         for (int sgi = jq; sgi < ns; sgi += 64) {
             const int2 se = sseg[sgi];
             float acc[3] = {0.f, 0.f, 0.f};
-            int i = se.x;
-            for (; i + 4 <= se.y; i += 4) {        // four entries at a time: their dependent LDS reads (entry -> products) overlap; sums in list order
-                float2 en[4];
+            // four entries per iteration, ONE entry read per lane: lane q of the quad fetches entry i + q, DPP quad broadcasts hand every
+            // entry to all four lanes (the LDS pipe is this kernel's bound; a per-lane read of the same entry by all four lanes costs an LDS
+            // instruction each).  Entries past the segment's end carry weight 0 and vertex 0.  Sums in list order.
+            for (int i = se.x; i < se.y; i += 4) {
+                const bool in = i + q < se.y;
+                const float2 mine = sent[in ? i + q : se.x];
+                const int wbits = in ? __float_as_int(mine.x) : 0, lbits = in ? __float_as_int(mine.y) : 0;
                 f32x4 pr[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) en[u] = sent[i + u];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) pr[u] = sP[q * 257 + __float_as_int(en[u].y)];
+                float wu[4];
+#define DP_QUAD_BCAST(U)                                                                              \
+    wu[U] = __int_as_float(__builtin_amdgcn_mov_dpp(wbits, U * 0x55, 0xf, 0xf, false));                 \
+    pr[U] = sP[q * 257 + __builtin_amdgcn_mov_dpp(lbits, U * 0x55, 0xf, 0xf, false)]      /* quad_perm: [U, U, U, U] */
+                DP_QUAD_BCAST(0); DP_QUAD_BCAST(1); DP_QUAD_BCAST(2); DP_QUAD_BCAST(3);
+#undef DP_QUAD_BCAST
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) acc[r] += en[u].x * pr[u][r];
-            }
-            for (; i < se.y; ++i) {
-                const float2 en = sent[i];
-                const f32x4 P = sP[q * 257 + __float_as_int(en.y)];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) acc[r] += en.x * P[r];
+                    for (int r = 0; r < 3; ++r) acc[r] += wu[u] * pr[u][r];
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r) part[sgi][q][r] = acc[r];
