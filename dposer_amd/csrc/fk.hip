@@ -644,6 +644,7 @@ struct BodyTuning {
     bool blend_fp32 = false;              // DPOSER_LBS_BLEND=fp32: exact-fp32 pose-blend chain
     int skin_mode = 2;                    // DPOSER_SKIN_WAVE=0: one vertex per thread and iteration (k_skin) instead of four in flight (A/B)
     bool skin_bwd_fused = true;           // DPOSER_SKIN_BWD_FUSED=0: k_skin_bwd + k_skin_bwd_joints instead of the one-pass kernel (A/B)
+    bool lbs_bwd_big = true;              // DPOSER_LBS_BWD_BIG=0: 128x128 tiles for the blend-gradient GEMMs at every batch size (A/B)
     bool fk_dma = true;                   // DPOSER_FK_DMA=0: joints-only body query through k_fk_joints instead of k_fk_joints_dma (A/B)
     void load() {
         const char* e = getenv("DPOSER_FK_SMALL_MAX");
@@ -656,6 +657,8 @@ struct BodyTuning {
         skin_mode = e ? atoi(e) : 2;
         e = getenv("DPOSER_SKIN_BWD_FUSED");
         skin_bwd_fused = !(e && e[0] == '0');
+        e = getenv("DPOSER_LBS_BWD_BIG");
+        lbs_bwd_big = !(e && e[0] == '0');
         e = getenv("DPOSER_FK_DMA");
         fk_dma = !(e && e[0] == '0');
     }
@@ -2044,8 +2047,7 @@ static int lbs_bwd_ksplit_bf16(int64_t kblocks, int64_t tiles) {
 // 256x256 tiles for the bf16 backward blend GEMMs from 2048 poses up (one 256-CU round of long-K workgroups: 3 x 110 us instead of
 // 3 x 161 us with the 128x128 tiles at 4096 poses): the split count that fills the last round best, at most 8 (24 slabs); 0 = not applicable
 static int lbs_bwd_big_ksplit(int64_t Bpad, int64_t prow, int64_t kblocks) {
-    static const bool off = [] { const char* e = getenv("DPOSER_LBS_BWD_BIG"); return e && e[0] == '0'; }();
-    if (off || Bpad % 256 != 0 || prow % 256 != 0 || Bpad < 2048) return 0;
+    if (!body_tuning().lbs_bwd_big || Bpad % 256 != 0 || prow % 256 != 0 || Bpad < 2048) return 0;
     const int64_t tiles = (Bpad / 256) * (prow / 256);
     int best = 0;
     double best_u = 0.0;

@@ -212,3 +212,60 @@ def test_cfg5_motion_denoising_60_frames_180_steps_vs_oracle_loop():
     assert err < 1e-3                                   # measured 2.3e-4 after 180 Adam steps
     assert abs(res["MPJPE"].mean() - ref["MPJPE"].mean()) < 0.05 * ref["MPJPE"].mean()
     assert res["MPJPE"].mean() < res["init_MPJPE"].mean()                         # denoising reduces the joint error
+
+
+# ---- bench-size checks of the round-3 body-model kernels (size-independent properties) --------------------------------------------
+def test_fk_joints_at_2_pow_20_poses_dma_kernel_equals_general_kernel_and_oracle_on_a_slice(monkeypatch):
+    """bench.py's FK leg (2^20 poses, 22 joints): the DMA-staged kernel returns the general kernel's bits over the whole batch (incl. a tail
+    block: 2^20 + 37 poses), and a 64-pose slice from the far end matches the fp64 oracle."""
+    from dposer_amd import _C
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    from oracle import fk_ref
+    asset = make_synthetic_smplx_asset(seed=0)
+    bm = BodyModel(asset).to(DEV)
+    n = (1 << 20) + 37
+    pose = (torch.randn(n, 63, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)) * 0.4).contiguous()
+    j_dma = bm.fk_joints(pose)
+    monkeypatch.setenv("DPOSER_FK_DMA", "0")
+    _C.lib().dposer_body_tuning_reload()
+    j_gen = bm.fk_joints(pose)
+    monkeypatch.delenv("DPOSER_FK_DMA")
+    _C.lib().dposer_body_tuning_reload()
+    assert torch.equal(j_dma, j_gen)
+    sl = slice(n - 64, n)
+    _, j_ref, _, _ = fk_ref.smplx_forward(asset, t2n(pose[sl]).astype(np.float64), dtype=np.float64)
+    assert np.abs(t2n(j_dma[sl]) - j_ref[:, :22]).max() < 1e-5
+
+
+def test_lbs_backward_at_4096_poses_fused_kernel_vs_two_kernel_path(monkeypatch):
+    """bench.py's LBS leg (4096 poses, 10475 vertices): the one-pass skinning backward (256x256 blend-gradient tiles, padding-row clear)
+    against the two-kernel path with the 128x128 tiles and the full clear; plus linearity in the incoming gradient."""
+    from dposer_amd import _C
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    bm = BodyModel(make_synthetic_smplx_asset(seed=0)).to(DEV)
+    n = 4096
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    pose = (torch.randn(n, 63, device=DEV, generator=gen) * 0.3)
+    gv = torch.randn(n, 10475, 3, device=DEV, generator=gen) / 100.0
+    gj = torch.randn(n, 127, 3, device=DEV, generator=gen)
+
+    def grad(scale=1.0):
+        p = pose.clone().requires_grad_(True)
+        o = bm(pose_body=p)
+        torch.autograd.backward([o.v, o.Jtr], [gv * scale, gj * scale])
+        return p.grad
+
+    g_new = grad()
+    g_twice = grad(2.0)
+    monkeypatch.setenv("DPOSER_SKIN_BWD_FUSED", "0")
+    monkeypatch.setenv("DPOSER_LBS_BWD_BIG", "0")
+    _C.lib().dposer_body_tuning_reload()
+    g_old = grad()
+    monkeypatch.delenv("DPOSER_SKIN_BWD_FUSED")
+    monkeypatch.delenv("DPOSER_LBS_BWD_BIG")
+    _C.lib().dposer_body_tuning_reload()
+    assert torch.isfinite(g_new).all()
+    assert float((g_new - g_old).norm() / g_old.norm()) < 1e-5          # same terms, other summation orders
+    assert float((g_twice - 2.0 * g_new).norm() / g_new.norm()) < 1e-6  # linear in the incoming gradient
