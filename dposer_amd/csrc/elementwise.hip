@@ -857,11 +857,12 @@ hipError_t launch_sqnorm(const float* g, int64_t n, float* part, int* nblocks, h
 // Non-finite gradient guard: a NaN / Inf anywhere in the (all-reduced) gradient makes its squared norm non-finite; such a step
 // is dropped on the device -- parameters, moments and EMA stay as they were -- and counted in sqnorm[1], which the host reads
 // when it wants to (FusedAdam.nonfinite_steps()), not every step.
-__global__ void k_nonfinite_guard(float* sqnorm) {
-    if (!isfinite(sqnorm[0])) sqnorm[1] += 1.0f;
-}
+// (the counter update rides in the first thread of the optimizer kernel: one launch less in a step whose tail is latency-bound)
 __global__ void __launch_bounds__(256) k_adam_ema(AdamArgs a) {
-    if (!isfinite(a.sqnorm[0])) return;
+    if (!isfinite(a.sqnorm[0])) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<float*>(a.sqnorm)[1] += 1.0f;
+        return;
+    }
     // clip_grad_norm_ (losses.py:54-55): coef = max_norm / (total_norm + 1e-6), clamped to 1
     float coef = a.grad_scale;
     if (a.grad_clip >= 0.f) {
@@ -893,7 +894,6 @@ __global__ void __launch_bounds__(256) k_adam_ema(AdamArgs a) {
     }
 }
 hipError_t launch_adam_ema(const AdamArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_nonfinite_guard, dim3(1), dim3(1), 0, st, const_cast<float*>(a.sqnorm));
     hipLaunchKernelGGL(k_adam_ema, dim3(grid_for(a.n, 256, 4096)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
