@@ -391,3 +391,19 @@ def test_generated_wgrad_k_loop_is_in_sync_with_its_generator():
         assert st.count("ds_read_b64_tr_b16") == (12 if mode == 3 else 24)
         assert st.count("global_load_lds_dwordx4") == (4 if mode == 0 else 0)
         assert st.count("s_barrier") == (0 if mode == 3 else 1)
+
+
+def test_asm_k_loops_pass_the_isa_audit():
+    """tools/check_kloop_isa.py on the ISA hipcc emits for the library's GEMM kernels (cross-compiles gemm_launch.hip, ~2 min): the compiler
+    cannot see the MFMAs inside the hand-placed stage statements, so nothing it puts between two neighbouring statements may touch an
+    accumulator register, and the kernels must not spill."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_kloop_isa.py")], capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("ok", "FAIL"))]
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert len(lines) >= 20 and not any(l.startswith("FAIL") for l in lines)
