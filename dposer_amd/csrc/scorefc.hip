@@ -202,6 +202,13 @@ extern "C" int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat, void* 
     DP_CHECK_ARG(h && flat && packed, "null argument");
     DP_CHECK_ARG(((uintptr_t)flat & 15) == 0 && ((uintptr_t)packed & 255) == 0, "flat_params must be 16-B aligned, packed 256-B aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (with_backward && h->fwd_jobs.n + h->bwd_jobs.n <= MAX_PACK_JOBS) {      // one launch for both operand sets (the training step's tail is latency-bound)
+        PackJobs all = h->fwd_jobs;
+        for (int i = 0; i < h->bwd_jobs.n; ++i) all.job[all.n++] = h->bwd_jobs.job[i];
+        DP_HIP_LAUNCH(launch_pack(all, flat, packed, st));
+        DP_HIP_LAUNCH(launch_bias_cat(h->bias_jobs, flat, reinterpret_cast<float*>((char*)packed + h->pk_bias_cat), st));
+        return DPOSER_OK;
+    }
     DP_HIP_LAUNCH(launch_pack(h->fwd_jobs, flat, packed, st));
     DP_HIP_LAUNCH(launch_bias_cat(h->bias_jobs, flat, reinterpret_cast<float*>((char*)packed + h->pk_bias_cat), st));
     if (with_backward) DP_HIP_LAUNCH(launch_pack(h->bwd_jobs, flat, packed, st));
