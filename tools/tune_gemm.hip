@@ -353,13 +353,20 @@ int main(int argc, char** argv) {
         GemmArgs g0;
         memset(&g0, 0, sizeof(g0));
         g0.W = dyT_; g0.w_stride_blocks = (int)(S / 16); g0.src[0] = hbT; g0.seg_kblocks[0] = (int)(S / 16); g0.nseg = 1; g0.ktot_blocks = (int)(S / 16);
-        g0.n_cblk = N / 256; g0.n_sblk = Kc / 256; g0.ksplit = ks;
+        const bool mid = getenv("TUNE_WTR_MID") != nullptr;            // the 128x128 / 4-wave tiling of both kernels
+        const int tile = mid ? 128 : 256;
+        g0.n_cblk = N / tile; g0.n_sblk = Kc / tile; g0.ksplit = ks;
         WgradTrArgs g1;
         memset(&g1, 0, sizeof(g1));
-        g1.dY = dy; g1.H = hb; g1.N = N; g1.Kc = Kc; g1.n_cblk = N / 256; g1.n_sblk = Kc / 256; g1.sblocks = (int)(S / 32); g1.ksplit = ks;
+        g1.dY = dy; g1.H = hb; g1.N = N; g1.Kc = Kc; g1.n_cblk = N / tile; g1.n_sblk = Kc / tile; g1.sblocks = (int)(S / 32); g1.ksplit = ks;
         const double fl = 2.0 * S * N * Kc;
+        if (mid) {
+            g_cases.push_back({"wgrad 128x128, transposed copies (plain kernel)", [=] { CK((launch_gemm<__bf16, 2, 2, 2, 2, 2, EpiWgrad<__bf16>, 4>(g0, wp0, 0))); }, fl, {}});
+            g_cases.push_back({"wgrad 128x128, sample-major operands (tr reads)", [=] { CK((launch_wgrad_tr<2, 2, 2, 2, 4>(g1, wp1, 0))); }, fl, {}});
+        } else {
         g_cases.push_back({"wgrad 256x256, transposed copies (plain kernel)", [=] { CK((launch_gemm<__bf16, 2, 4, 4, 2, 2, EpiWgrad<__bf16>, 4>(g0, wp0, 0))); }, fl, {}});
         g_cases.push_back({"wgrad 256x256, sample-major operands (tr reads)", [=] { CK((launch_wgrad_tr<2, 4, 4, 2, 4>(g1, wp1, 0))); }, fl, {}});
+        }
         for (auto& c : g_cases) c.launch();
         CK(hipDeviceSynchronize());
         {
