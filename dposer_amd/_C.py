@@ -100,6 +100,8 @@ SIGNATURES = {
                                             f64, f64, i64, f64, vp, vp]),
     "dposer_grad_sqnorm": (C.c_int, [vp, i64, vp, vp]),
     "dposer_rk_combine_f64": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(C.c_double), i32, C.c_double, i64, vp]),
+    "dposer_pf_ode_rhs_begin": (C.c_int, [C.POINTER(SdeDesc), f32, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "dposer_pf_ode_rhs_end": (C.c_int, [C.POINTER(SdeDesc), f32, vp, vp, vp, vp, vp, i64, i32, vp]),
     "dposer_adam_ema_clip_step_presummed": (C.c_int, [vp, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64,
                                                       f64, f64, i64, f64, vp, vp]),
     "dposer_adam_ema_clip_step_wd": (C.c_int, [vp, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64,

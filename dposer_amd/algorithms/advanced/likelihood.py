@@ -23,6 +23,77 @@ def probability_flow_drift(sde, model, x, t):
     return sde.reverse(score_fn, probability_flow=True).sde(x, t, condition=None, mask=None)[0]
 
 
+class FusedPfRhs:
+    """One right-hand side of the probability-flow ODE as four library calls (``dposer_pf_ode_rhs_begin`` -> score network forward
+    [-> input-gradient] -> ``dposer_pf_ode_rhs_end``) instead of the ~60 small torch launches of the expression-by-expression path
+    (``probability_flow_drift`` + autograd), which is bound by host enqueue time below ~16k poses.  Same fp32 operation order as that
+    path (the reference's, likelihood.py:60-65 / sde_lib.py:100-104 / utils.py:152-162); only the 63-term Hutchinson sum per sample is
+    formed in a different order.  Covers ScoreModelFC with a VP / sub-VP SDE; ``build`` returns None otherwise (or with
+    ``DPOSER_ODE_FUSED_RHS=0``) and the caller keeps the generic path.
+
+    ``noise`` given: state [B*D + B] -> [d x / dt, d logp / dt] (likelihood.py:86-95); ``noise=None``: state [B*D] -> drift
+    (sampling.py:513-518).  The weights are packed once per solve (they cannot change inside one)."""
+
+    @staticmethod
+    def build(sde, model, shape, device, noise=None):
+        from ... import _C
+        from .model import ScoreModelFC
+        from .sde_lib import sde_desc
+        desc = sde_desc(sde)
+        device = torch.device(device)
+        if (os.environ.get("DPOSER_ODE_FUSED_RHS", "1") == "0" or desc is None or not isinstance(model, ScoreModelFC) or len(shape) != 2
+                or device.type != "cuda" or shape[1] != model._engine().D):
+            return None
+        return FusedPfRhs(_C, desc, model, shape, device, noise)
+
+    def __init__(self, _C, desc, model, shape, device, noise):
+        self._C, self.desc, self.model = _C, desc, model
+        self.B, self.D = int(shape[0]), int(shape[1])
+        model.eval()                                       # get_score_fn(train=False) (utils.py:121-124)
+        if model.sigmas.device != device or model._param_list[0].device != device:
+            raise _C.DPoserHipError("ScoreModelFC parameters and the ODE state are on different devices")
+        eng = self.eng = model._engine()
+        self.flat = model.flat_params()
+        self.with_grad = noise is not None
+        self.packed = eng.packed(self.flat, with_backward=self.with_grad, force=not model.freeze_packed)
+        self.freq = eng.freq(device, model._fourier_W())
+        f32 = dict(dtype=torch.float32, device=device)
+        self.x, self.out = torch.empty(self.B, self.D, **f32), torch.empty(self.B, self.D, **f32)
+        self.labels = torch.empty(self.B, **f32)
+        if self.with_grad:
+            self.noise = noise.detach().reshape(self.B, self.D).contiguous().float()
+            self.dout, self.dx = torch.empty(self.B, self.D, **f32), torch.empty(self.B, self.D, **f32)
+            self.lease = eng.lease_train_workspace(self.B, device)
+            self.ws = self.lease.ws
+        else:
+            self.noise = self.dout = self.dx = self.lease = None
+            self.ws = eng.workspace(self.B, _C.WS_INFER, 0, device)
+        self.n_out = self.B * self.D + (self.B if self.with_grad else 0)
+
+    def __call__(self, t, state):
+        _C, lib, m, B, D = self._C, self.eng.lib, self.model, self.B, self.D
+        ptr, st, h = _C.ptr, _C.stream_ptr(), self.eng.h
+        state = state.to(torch.float64).contiguous()
+        dstate = torch.empty(self.n_out, dtype=torch.float64, device=state.device)
+        t = float(t)
+        _C.check(lib.dposer_pf_ode_rhs_begin(self.desc, t, ptr(state), ptr(self.noise), ptr(self.x), ptr(self.labels), ptr(self.dout), B, D, st),
+                 "dposer_pf_ode_rhs_begin")
+        if self.with_grad:
+            m._rng_step += 1
+            _C.check(lib.dposer_scorefc_forward_train(h, ptr(self.flat), ptr(self.packed), ptr(self.ws), ptr(self.x), ptr(self.labels),
+                                                      ptr(self.freq), ptr(m.sigmas), ptr(self.out), B, 0, m._rng_seed, m._rng_step, st),
+                     "dposer_scorefc_forward_train")
+            _C.check(lib.dposer_scorefc_backward(h, ptr(self.flat), ptr(self.packed), ptr(self.ws), ptr(self.labels), ptr(m.sigmas),
+                                                 ptr(self.dout), None, ptr(self.dx), B, 0, m._rng_seed, m._rng_step, st),
+                     "dposer_scorefc_backward")
+        else:
+            _C.check(lib.dposer_scorefc_forward(h, ptr(self.flat), ptr(self.packed), ptr(self.ws), ptr(self.x), ptr(self.labels),
+                                                ptr(self.freq), ptr(m.sigmas), ptr(self.out), B, st), "dposer_scorefc_forward")
+        _C.check(lib.dposer_pf_ode_rhs_end(self.desc, t, ptr(self.x), ptr(self.out), ptr(self.dx), ptr(self.noise), ptr(dstate), B, D, st),
+                 "dposer_pf_ode_rhs_end")
+        return dstate
+
+
 def get_div_fn(fn):
     """Hutchinson-Skilling estimate of div fn: eps^T (d fn / d x) eps, one value per sample (likelihood.py:25-37)."""
 
@@ -80,7 +151,7 @@ def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e
             noise = hutchinson_noise(data, hutchinson_type) if epsilon is None else epsilon
         only_x = (lambda: model.input_grad_only()) if hasattr(model, "input_grad_only") else contextlib.nullcontext
 
-        def rhs_dev(t, state):
+        def rhs_generic(t, state):
             """state float64 [n_state + B] on the device -> d state / dt (likelihood.py:86-95): drift and divergence estimate from
             one differentiable evaluation."""
             vec_t = torch.full((B,), float(t), device=dev, dtype=torch.float32)
@@ -90,6 +161,8 @@ def get_likelihood_fn(sde, inverse_scaler, hutchinson_type="Rademacher", rtol=1e
                 vjp, = torch.autograd.grad((drift * noise).sum(), xg)
             dlogp = (vjp * noise).flatten(1).sum(dim=1)
             return torch.cat([drift.detach().reshape(-1).double(), dlogp.reshape(-1).double()])
+
+        rhs_dev = FusedPfRhs.build(sde, model, shape, dev, noise) or rhs_generic
 
         if driver == "device":
             from .ode_device import solve_fixed, solve_rk45

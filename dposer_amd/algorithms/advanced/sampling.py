@@ -439,7 +439,7 @@ def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1
     the GPU, with ``driver='scipy'`` ``scipy.integrate.solve_ivp`` drives it from the host.  Each drift evaluation is one HIP
     forward of the score network.  ``denoise`` adds one noise-free reverse-diffusion predictor step at ``eps`` (:492-499)."""
     import os
-    from .likelihood import probability_flow_drift
+    from .likelihood import FusedPfRhs, probability_flow_drift
     from scipy import integrate
     fixed = method in ("rk4", "euler")      # fixed-step, fully asynchronous device integration (likelihood.get_likelihood_fn has the details)
     if fixed and not n_steps:
@@ -454,10 +454,12 @@ def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1
         with torch.no_grad():
             x = sde.prior_sampling(shape).to(device) if z is None else z
 
-            def rhs_dev(t, state):
+            def rhs_generic(t, state):
                 xt = state.reshape(shape).float()
                 vec_t = torch.full((shape[0],), float(t), device=device, dtype=torch.float32)
                 return probability_flow_drift(sde, model, xt, vec_t).reshape(-1).double()
+
+            rhs_dev = FusedPfRhs.build(sde, model, tuple(x.shape), x.device) or rhs_generic      # three launches around the forward
 
             if driver == "device":
                 from .ode_device import solve_fixed, solve_rk45

@@ -935,3 +935,98 @@ extern "C" int dposer_rk_combine_f64(double* out, const double* y, const double*
     DP_CHECK_LAUNCH();
     return DPOSER_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// probability-flow ODE right-hand side around the score network (likelihood.py:60-65, 86-95; sampling.py:513-530):
+//   drift(x, t) = -1/2 beta(t) x - 1/2 g(t)^2 score,  score = -model(x, 999 t) / std(t)          (sde_lib.py:100-104, utils.py:152-162)
+// All samples of one evaluation share t.  `begin` prepares the network input from the float64 solver state and the upstream
+// gradient of sum(drift * noise) w.r.t. the network output; `end` forms the drift and the Hutchinson estimate
+// sum_i noise_i d(sum(drift * noise))/dx_i from the network's input gradient.  fp32 operation order = the torch expressions
+// (and their autograd formulas) they replace; the per-sample sum runs over one wave instead of torch's reduction tree.
+// ------------------------------------------------------------------------------------------------
+struct PfRhsDev {
+    SdeDev sde;
+    float t;
+    const double* state;      // begin: [B * D (+ B)]
+    const float* noise;       // [B, D] or null
+    float* x;                 // begin: out, end: in
+    float* labels;            // begin: out [B]
+    float* dout;              // begin: out [B, D] or null
+    const float* out;         // end: network output [B, D]
+    const float* dx;          // end: network input gradient [B, D] or null
+    double* dstate;           // end: [B * D (+ B)]
+    int64_t B;
+    int D;
+};
+__global__ void __launch_bounds__(256) k_pf_rhs_begin(PfRhsDev d) {
+    const int64_t n = d.B * d.D;
+    const float g = sde_diffusion(d.sde, d.t);
+    const float g2 = g * g;                                                  // diffusion[:, None] ** 2
+    const float sd = sde_std(d.sde, sde_lmc(d.sde, d.t));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        d.x[i] = (float)d.state[i];
+        if (i < d.B) d.labels[i] = d.t * 999.0f;                             // utils.py:152
+        if (d.dout) {
+            // autograd of  drift0 - (g2 * score) * 0.5,  score = (-out) / std  with upstream gradient `noise`
+            const float gscore = ((-d.noise[i]) * 0.5f) * g2;
+            d.dout[i] = -(gscore / sd);
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_pf_rhs_end(PfRhsDev d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= d.B) return;
+    const float g = sde_diffusion(d.sde, d.t);
+    const float g2 = g * g;
+    const float sd = sde_std(d.sde, sde_lmc(d.sde, d.t));
+    const float a = -0.5f * sde_beta(d.sde, d.t);                            // -0.5 * beta_t
+    float acc = 0.f;
+    for (int c = lane; c < d.D; c += 64) {
+        const int64_t i = row * d.D + c;
+        const float score = (-d.out[i]) / sd;
+        const float drift = a * d.x[i] - (g2 * score) * 0.5f;
+        d.dstate[i] = (double)drift;
+        if (d.dx) {
+            const float nz = d.noise[i];
+            const float vjp = d.dx[i] + nz * a;
+            acc += vjp * nz;
+        }
+    }
+    if (d.dx) {
+        for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s);
+        if (lane == 0) d.dstate[d.B * d.D + row] = (double)acc;
+    }
+}
+static SdeDev pf_sde_dev(const dposer_sde_desc* s) {
+    SdeCfg c;
+    c.kind = s->kind == DPOSER_SDE_VP ? SDE_VP : SDE_SUBVP;
+    c.beta_0 = (float)s->beta_min; c.beta_1 = (float)s->beta_max; c.N = s->N; c.T = (float)s->T;
+    return make_sde_dev(c);
+}
+extern "C" int dposer_pf_ode_rhs_begin(const dposer_sde_desc* sde, float t, const double* state, const float* noise, float* x, float* labels,
+                                       float* dout, int64_t batch, int32_t dim, void* stream) {
+    DP_CHECK_ARG(sde && state && x && labels && batch >= 0 && dim >= 1, "bad argument");
+    DP_CHECK_ARG(sde->kind == DPOSER_SDE_VP || sde->kind == DPOSER_SDE_SUBVP, "VP / sub-VP only");
+    DP_CHECK_ARG(!dout || noise, "dout needs noise");
+    if (batch == 0) return DPOSER_OK;
+    PfRhsDev d{};
+    d.sde = pf_sde_dev(sde); d.t = t; d.state = state; d.noise = noise; d.x = x; d.labels = labels; d.dout = dout; d.B = batch; d.D = dim;
+    hipLaunchKernelGGL(k_pf_rhs_begin, dim3(grid_for(batch * dim, 256, 2048)), dim3(256), 0, (hipStream_t)stream, d);
+    DP_CHECK_LAUNCH();
+    return DPOSER_OK;
+}
+extern "C" int dposer_pf_ode_rhs_end(const dposer_sde_desc* sde, float t, const float* x, const float* model_out, const float* dx,
+                                     const float* noise, double* dstate, int64_t batch, int32_t dim, void* stream) {
+    DP_CHECK_ARG(sde && x && model_out && dstate && batch >= 0 && dim >= 1, "bad argument");
+    DP_CHECK_ARG(sde->kind == DPOSER_SDE_VP || sde->kind == DPOSER_SDE_SUBVP, "VP / sub-VP only");
+    DP_CHECK_ARG(!dx || noise, "dx needs noise");
+    DP_CHECK_ARG((batch + 3) / 4 < (int64_t)1 << 31, "batch too large");
+    if (batch == 0) return DPOSER_OK;
+    PfRhsDev d{};
+    d.sde = pf_sde_dev(sde); d.t = t; d.x = const_cast<float*>(x); d.out = model_out; d.dx = dx; d.noise = noise; d.dstate = dstate;
+    d.B = batch; d.D = dim;
+    hipLaunchKernelGGL(k_pf_rhs_end, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d);
+    DP_CHECK_LAUNCH();
+    return DPOSER_OK;
+}

@@ -201,6 +201,17 @@ int dposer_grad_sqnorm(const float* grad, int64_t n, float* scratch, void* strea
  *   k_host / coef_host: HOST arrays of n_terms (<= 8) DEVICE pointers / coefficients; y may be NULL; out may alias nothing. */
 int dposer_rk_combine_f64(double* out, const double* y, const double* const* k_host, const double* coef_host, int32_t n_terms,
                           double scale, int64_t n, void* stream);
+/* Right-hand side of the probability-flow ODE around one evaluation of the score network (lib/algorithms/advanced/likelihood.py:60-65,
+ * 86-95 `ode_func`; sampling.py:513-530 `ode_func`): drift = -1/2 beta(t) x - 1/2 g(t)^2 score, score = -model(x, 999 t) / std(t)
+ * (sde_lib.py:100-104, utils.py:152-162), all samples at the same t, VP / sub-VP.  Two elementwise launches around the network calls:
+ *   begin: x [B, D] = float(state[0 .. B*D)), labels [B] = 999 t, and -- noise != NULL, dout != NULL -- dout [B, D] = the gradient of
+ *          sum(drift * noise) w.r.t. the network output (what torch.autograd hands to the network's backward in likelihood.py:29-35);
+ *   end:   dstate[0 .. B*D) = double(drift(x, model_out)); with dx (the network's input gradient for `dout`) also the Hutchinson
+ *          estimate dstate[B*D + b] = sum_i noise[b,i] * (dx[b,i] - 1/2 beta(t) noise[b,i]);  dx NULL: drift only (dstate [B*D]). */
+int dposer_pf_ode_rhs_begin(const dposer_sde_desc* sde, float t, const double* state, const float* noise, float* x, float* labels,
+                            float* dout, int64_t batch, int32_t dim, void* stream);
+int dposer_pf_ode_rhs_end(const dposer_sde_desc* sde, float t, const float* x, const float* model_out, const float* dx,
+                          const float* noise, double* dstate, int64_t batch, int32_t dim, void* stream);
 int dposer_adam_ema_clip_step_presummed(float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq, float* ema,
                                         int64_t n, const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip,
                                         double lr, double beta1, double beta2, double eps, double grad_clip, double grad_scale,

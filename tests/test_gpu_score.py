@@ -1059,6 +1059,54 @@ def test_rk_stage_combination_kernel_returns_the_bits_of_the_torch_expression():
         assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("kind,precision", [("subvp", "fp32"), ("vp", "fp32"), ("subvp", "bf16")])
+def test_fused_probability_flow_rhs_against_the_expression_path(kind, precision, monkeypatch):
+    """likelihood.FusedPfRhs (dposer_pf_ode_rhs_begin / _end around the network calls) against the expression-by-expression path it
+    replaces (probability_flow_drift + torch.autograd on the same HIP forward / input-gradient): the drift carries the same bits,
+    the Hutchinson sum differs only by summation order; then the whole likelihood and the ODE sampler with and without it."""
+    from dposer_amd.algorithms.advanced import likelihood, sampling, sde_lib
+    g = load("g12_likelihood_ode")
+    cfg, m, p = make_model(int(g["seed"]), precision=precision)
+    sde = (sde_lib.subVPSDE if kind == "subvp" else sde_lib.VPSDE)(beta_min=0.1, beta_max=20.0, N=1000)
+    rs = np.random.RandomState(5)
+    B, D = 1000, 63
+    noise = _dev((rs.randint(0, 2, (B, D)) * 2 - 1).astype(np.float32))
+    fused = likelihood.FusedPfRhs.build(sde, m, (B, D), DEV, noise)
+    drift_only = likelihood.FusedPfRhs.build(sde, m, (B, D), DEV)
+    assert fused is not None and drift_only is not None
+    for t in (1e-4, 0.0371, 0.5, 1.0):
+        state = torch.tensor(np.concatenate([rs.standard_normal(B * D), rs.standard_normal(B)]), device=DEV)
+        got = fused(t, state)
+        vec_t = torch.full((B,), float(t), device=DEV, dtype=torch.float32)
+        with torch.enable_grad(), m.input_grad_only():
+            xg = state[:B * D].reshape(B, D).float().requires_grad_(True)
+            drift = likelihood.probability_flow_drift(sde, m, xg, vec_t)
+            vjp, = torch.autograd.grad((drift * noise).sum(), xg)
+        want_div = (vjp * noise).flatten(1).sum(dim=1).double()
+        assert got.dtype == torch.float64 and got.shape == (B * D + B,)
+        assert torch.equal(got[:B * D], drift.detach().reshape(-1).double()), t
+        assert rel_err(t2n(got[B * D:]), t2n(want_div)) < 2e-6, t
+        with torch.no_grad():
+            want = likelihood.probability_flow_drift(sde, m, state[:B * D].reshape(B, D).float(), vec_t)
+        assert rel_err(t2n(drift_only(t, state[:B * D])), t2n(want.reshape(-1).double())) < (1e-6 if precision == "fp32" else 2e-2), t
+    del fused, drift_only
+    if precision != "fp32":
+        return
+    data, eps = _dev(g["data"]), _dev(g["lik_Rademacher/eps"])
+    z0 = _dev(g["ode/z"]) if "ode/z" in g else torch.randn(16, D, device=DEV)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DPOSER_ODE_FUSED_RHS", flag)
+        res[flag] = [likelihood.get_likelihood_fn(sde, lambda v: v, eps=1e-4, **kw)(m, data, epsilon=eps)
+                     + sampling.get_ode_sampler(sde, tuple(z0.shape), lambda v: v, device=DEV, **kw)(m, z=z0.clone())
+                     for kw in (dict(method="rk4", n_steps=60), dict(rtol=1e-4, atol=1e-4))]
+    # fixed steps: the same step sequence, so only the summation order of the Hutchinson term separates the two;
+    # adaptive steps: the step-size controller amplifies that last-bit difference to a fraction of the solver tolerance
+    for (bpd1, z1, n1, nfe1, x1), (bpd0, zz0, n0, nfe0, x0), tol in zip(res["1"], res["0"], (1e-5, 2e-3)):
+        assert n1 == n0 and nfe1 == nfe0
+        assert rel_err(t2n(bpd1), t2n(bpd0)) < tol and rel_err(t2n(z1), t2n(zz0)) < tol and rel_err(t2n(x1), t2n(x0)) < tol
+
+
 def test_fixed_step_likelihood_and_ode_sampler():
     """method='rk4' (no step-size control, no host synchronisation) through get_likelihood_fn / get_ode_sampler: converges to the
     adaptive RK45 result of the same right-hand side as the step count grows, nfe = 4 n_steps."""
