@@ -646,6 +646,7 @@ struct BodyTuning {
     bool skin_bwd_fused = true;           // DPOSER_SKIN_BWD_FUSED=0: k_skin_bwd + k_skin_bwd_joints instead of the one-pass kernel (A/B)
     bool lbs_bwd_big = true;              // DPOSER_LBS_BWD_BIG=0: 128x128 tiles for the blend-gradient GEMMs at every batch size (A/B)
     bool fk_dma = true;                   // DPOSER_FK_DMA=0: joints-only body query through k_fk_joints instead of k_fk_joints_dma (A/B)
+    int lbs_bwd_panel_order = 1;          // DPOSER_LBS_BWD_PANEL_ORDER=0: generic block -> tile order for the blend-gradient GEMMs (A/B)
     void load() {
         const char* e = getenv("DPOSER_FK_SMALL_MAX");
         fk_small_max = e ? atoll(e) : (int64_t)8192;
@@ -661,6 +662,8 @@ struct BodyTuning {
         lbs_bwd_big = !(e && e[0] == '0');
         e = getenv("DPOSER_FK_DMA");
         fk_dma = !(e && e[0] == '0');
+        e = getenv("DPOSER_LBS_BWD_PANEL_ORDER");
+        lbs_bwd_panel_order = (e && e[0] == '0') ? 0 : 1;
     }
 };
 static BodyTuning& body_tuning() {
@@ -1108,14 +1111,12 @@ extern "C" int64_t dposer_lbs_workspace_bytes(dposer_body_t h, int64_t batch) {
     return p;
 }
 
-extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedirs_packed, const float* const* pose_segments_host,
-                                  const int32_t* segment_joints_host, int32_t num_segments, const float* j_rest, int32_t j_rest_batched,
-                                  const float* v_shaped, int32_t v_shaped_batched, const int32_t* skin_idx, const float* skin_w,
-                                  int32_t skin_k, const float* transl, const int32_t* extra_vertex_ids, const int32_t* lmk_tri,
-                                  const float* lmk_bary, float* verts, float* joints, int64_t batch, void* stream) {
-    DP_CHECK_ARG(h && ws && posedirs_packed && pose_segments_host && segment_joints_host && j_rest && v_shaped && skin_idx && skin_w && verts && joints,
-                 "null argument");
-    DP_CHECK_ARG(batch > 0 && skin_k >= 1, "bad size");
+// FK + pose-blend GEMM of the LBS forward (steps 1 and 2); A / offsets: where the skinning stage finds its inputs in `ws`
+static int lbs_forward_front(dposer_body_t h, void* ws, const void* posedirs_packed, const float* const* pose_segments_host,
+                             const int32_t* segment_joints_host, int32_t num_segments, const float* j_rest, int32_t j_rest_batched,
+                             const float* transl, float* joints, int64_t batch, void* stream, float** A_out, float** offsets_out) {
+    DP_CHECK_ARG(h && ws && posedirs_packed && pose_segments_host && segment_joints_host && j_rest && joints, "null argument");
+    DP_CHECK_ARG(batch > 0, "bad size");
     DP_CHECK_ARG(((uintptr_t)ws & 255) == 0 && ((uintptr_t)posedirs_packed & 255) == 0, "workspace / packed posedirs must be 256-byte aligned");
     DP_CHECK_ARG(num_segments >= 1 && num_segments <= FK_MAX_SEG, "1..8 pose segments");
     hipStream_t st = (hipStream_t)stream;
@@ -1173,6 +1174,25 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
             FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, shape, g, wp, st));
         }
     }
+    *A_out = A;
+    *offsets_out = offsets;
+    return DPOSER_OK;
+}
+
+extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedirs_packed, const float* const* pose_segments_host,
+                                  const int32_t* segment_joints_host, int32_t num_segments, const float* j_rest, int32_t j_rest_batched,
+                                  const float* v_shaped, int32_t v_shaped_batched, const int32_t* skin_idx, const float* skin_w,
+                                  int32_t skin_k, const float* transl, const int32_t* extra_vertex_ids, const int32_t* lmk_tri,
+                                  const float* lmk_bary, float* verts, float* joints, int64_t batch, void* stream) {
+    DP_CHECK_ARG(v_shaped && skin_idx && skin_w && verts, "null argument");
+    DP_CHECK_ARG(skin_k >= 1, "bad size");
+    float *A = nullptr, *offsets = nullptr;
+    DP_TRY(lbs_forward_front(h, ws, posedirs_packed, pose_segments_host, segment_joints_host, num_segments, j_rest, j_rest_batched, transl, joints,
+                             batch, stream, &A, &offsets));
+    hipStream_t st = (hipStream_t)stream;
+    const int J = h->d.num_joints, V = h->d.num_vertices;
+    const int64_t Cpad = lbs_cpad(V);
+    const int n_total = J + h->d.num_extra + h->d.num_landmarks;
     // 3. skinning
     {
         SkinArgs s;
@@ -1194,6 +1214,208 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
         hipLaunchKernelGGL(k_extra_joints, dim3((unsigned)(ceil_div(total, 256) > 4096 ? 4096 : ceil_div(total, 256))), dim3(256), 0, st, e);
         FK_HIP_LAUNCH(hipGetLastError());
     }
+    return DPOSER_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Skinning fused with the temporal term of the motion-denoising loss (run/motion_denoising.py:253-255):
+//   temp = mean over (F-1, V) of ||v[t] - v[t+1]||,  d temp / d v[t] = c (u_t - u_{t-1}),  u_t = (v[t] - v[t+1]) / ||v[t] - v[t+1]||.
+// The fitting loop needs the vertices for nothing else, so they never reach HBM: a block owns NV x 256 vertices of one run of
+// frames of one sequence and walks the frames, the previous frame's vertices in registers -- per frame it reads the pose-blend
+// offsets once and writes d verts once (k_skin_x4 + k_md_vert_grad: offsets in, vertices out, vertices in three times through L2,
+// d verts out).  Vertices = k_skin_x4's expression, gradient and the per-(frame, 256-vertex block) distance sums = k_md_vert_grad's,
+// operation for operation (the file is compiled without FMA contraction): bit-identical to that pair of kernels.
+// A run [f0, f1) recomputes the vertices of frames f0 - 1 and f1 (its halo): `nseg` runs per sequence trade 2 / (F / nseg) extra
+// skinning work for nseg x the workgroups.
+// ------------------------------------------------------------------------------------------------
+struct SkinTemporalArgs {
+    SkinArgs s;                // (verts unused)
+    float* dverts;             // [B][V][3] out
+    float* part;               // [B][ceil(V / 256)] out: sum over the block's vertices of ||v[t] - v[t+1]|| (0 for the last frame of a sequence)
+    int F, nseg;
+    float c;
+};
+template <int NV, bool VSB> __global__ void __launch_bounds__(256, 4) k_skin_temporal(SkinTemporalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const SkinArgs& s = a.s;
+    const int JA = s.J * 12;
+    float* sred = smem + 2 * JA;                                  // [frames of the run][NV][4 waves]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int seq = blockIdx.y / a.nseg, sg = blockIdx.y % a.nseg;
+    const int f0 = (int)((int64_t)sg * a.F / a.nseg), f1 = (int)((int64_t)(sg + 1) * a.F / a.nseg);
+    const int ts = f0 > 0 ? f0 - 1 : 0, te = f1 < a.F ? f1 : a.F - 1;         // frames whose vertices this block forms
+    const int64_t b0 = (int64_t)seq * a.F;
+    const int vb = (s.V + 255) >> 8;
+    const int vbase = blockIdx.x * (NV * 256) + threadIdx.x;
+    int vc[NV];
+    f32x4 w4[NV];
+    int4 j4[NV];
+    float vs[NV][3];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int v = vbase + u * 256;
+        vc[u] = v < s.V ? v : s.V - 1;                              // clamp: the tail threads work on a valid vertex and do not store
+        w4[u] = *reinterpret_cast<const f32x4*>(s.skin_w + (int64_t)vc[u] * 4);
+        j4[u] = *reinterpret_cast<const int4*>(s.skin_idx + (int64_t)vc[u] * 4);
+        if (!VSB) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vs[u][c] = s.v_shaped[(int64_t)vc[u] * 3 + c];
+        }
+    }
+    float an[3];                                                   // the next frame's transforms on their way into LDS
+    auto load_A = [&](int64_t b) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = threadIdx.x + i * 256;
+            an[i] = e < JA ? s.A[b * JA + e] : 0.f;
+        }
+    };
+    auto store_A = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = threadIdx.x + i * 256;
+            if (e < JA) dst[e] = an[i];
+        }
+    };
+    float on[NV][3], vn[NV][3];                                    // the next frame's offsets (and rest shape, if per frame)
+    auto load_p = [&](int64_t b) {
+        const float* off_row = s.offsets + b * s.ld_off;
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                on[u][c] = off_row[(int64_t)vc[u] * 3 + c];
+                if (VSB) vn[u][c] = s.v_shaped[(b * s.V + vc[u]) * 3 + c];
+            }
+    };
+    load_A(b0 + ts);
+    load_p(b0 + ts);
+    store_A(smem);
+    float pv[NV][3], hold[NV][3];
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pv[u][c] = 0.f; hold[u][c] = 0.f; }
+    int cur = 0;
+#pragma unroll 1
+    for (int t = ts; t <= te; ++t) {
+        __syncthreads();                                           // sA[cur] complete; every wave is done with sA[cur ^ 1]
+        const float* sA = smem + cur * JA;
+        float p[NV][3];
+#pragma unroll
+        for (int u = 0; u < NV; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[u][c] = (VSB ? vn[u][c] : vs[u][c]) + on[u][c];
+        float tr[3] = {0.f, 0.f, 0.f};
+        if (s.transl) { tr[0] = s.transl[(b0 + t) * 3]; tr[1] = s.transl[(b0 + t) * 3 + 1]; tr[2] = s.transl[(b0 + t) * 3 + 2]; }
+        if (t < te) { load_A(b0 + t + 1); load_p(b0 + t + 1); }    // in flight behind this frame's arithmetic
+        const bool out_prev = t > ts && t - 1 >= f0;               // frame t - 1 is one of this block's output frames
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v = vbase + u * 256;
+            const int jj[4] = {j4[u].x, j4[u].y, j4[u].z, j4[u].w};
+            float T[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4* Aj = reinterpret_cast<const f32x4*>(sA) + jj[k] * 3;    // 16-byte reads: see k_skin_x4
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const f32x4 row = Aj[r];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) T[4 * r + i] += w4[u][k] * row[i];
+                }
+            }
+            float q[3];
+            q[0] = T[0] * p[u][0] + T[1] * p[u][1] + T[2] * p[u][2] + T[3] + tr[0];
+            q[1] = T[4] * p[u][0] + T[5] * p[u][1] + T[6] * p[u][2] + T[7] + tr[1];
+            q[2] = T[8] * p[u][0] + T[9] * p[u][1] + T[10] * p[u][2] + T[11] + tr[2];
+            if (t > ts) {
+                // the pair (t - 1, t): forward difference of frame t - 1, backward difference of frame t (k_md_vert_grad's two branches)
+                const float ax = pv[u][0] - q[0], ay = pv[u][1] - q[1], az = pv[u][2] - q[2];
+                const float ss = ax * ax + ay * ay + az * az;
+                const float d = sqrtf(ss);
+                const float inv = __builtin_amdgcn_rcpf(d);
+                const float gx = ax * inv - hold[u][0], gy = ay * inv - hold[u][1], gz = az * inv - hold[u][2];
+                const float invb = __builtin_amdgcn_rsqf(ss);
+                hold[u][0] = ax * invb; hold[u][1] = ay * invb; hold[u][2] = az * invb;
+                if (out_prev) {
+                    if (v < s.V) {
+                        float* o = a.dverts + ((b0 + t - 1) * s.V + v) * 3;
+                        o[0] = a.c * gx; o[1] = a.c * gy; o[2] = a.c * gz;
+                    }
+                    float dsum = v < s.V ? d : 0.f;
+#pragma unroll
+                    for (int sh = 32; sh >= 1; sh >>= 1) dsum += __shfl_xor(dsum, sh);
+                    if (lane == 0) sred[((t - 1 - f0) * NV + u) * 4 + wave] = dsum;
+                }
+            }
+            pv[u][0] = q[0]; pv[u][1] = q[1]; pv[u][2] = q[2];
+            __builtin_amdgcn_sched_barrier(0);                     // one vertex at a time: hoisting the 48 LDS reads of all NV vertices spills
+        }
+        if (t < te) store_A(smem + (cur ^ 1) * JA);
+        cur ^= 1;
+    }
+    if (f1 == a.F) {                                               // last frame of the sequence: backward difference only, no distance
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int v = vbase + u * 256;
+            if (v < s.V) {
+                float* o = a.dverts + ((b0 + a.F - 1) * s.V + v) * 3;
+                o[0] = a.c * (0.f - hold[u][0]); o[1] = a.c * (0.f - hold[u][1]); o[2] = a.c * (0.f - hold[u][2]);
+            }
+            if (lane == 0) sred[((a.F - 1 - f0) * NV + u) * 4 + wave] = 0.f;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (f1 - f0) * NV; i += 256) {
+        const int vblk = blockIdx.x * NV + (i % NV);
+        const float* r = sred + i * 4;
+        if (vblk < vb) a.part[(b0 + f0 + i / NV) * vb + vblk] = r[0] + r[1] + r[2] + r[3];
+    }
+}
+
+// runs per sequence: enough workgroups for two rounds of the chip, runs of at least 10 frames (halo <= 20 %)
+static int skin_temporal_nseg(int64_t n_seq, int F, int vchunks) {
+    const char* e = getenv("DPOSER_SKIN_TEMPORAL_NSEG");          // (A/B and tests; read per call)
+    const int forced = e ? atoi(e) : 0;
+    if (forced > 0) return forced < F / 2 ? forced : (F / 2 > 0 ? F / 2 : 1);
+    int nseg = 1;
+    while (n_seq * vchunks * nseg < 2048 && F / (nseg + 1) >= 10) ++nseg;
+    return nseg;
+}
+
+extern "C" int dposer_lbs_forward_temporal_grad(dposer_body_t h, void* ws, const void* posedirs_packed, const float* const* pose_segments_host,
+                                                const int32_t* segment_joints_host, int32_t num_segments, const float* j_rest,
+                                                int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched, const int32_t* skin_idx,
+                                                const float* skin_w, int32_t skin_k, const float* transl, int64_t frames_per_sequence, float scale,
+                                                float* d_verts, float* dist_part, float* joints, int64_t batch, void* stream) {
+    DP_CHECK_ARG(v_shaped && skin_idx && skin_w && d_verts && dist_part, "null argument");
+    DP_CHECK_ARG(skin_k == 4, "four skinning weights per vertex (the ELL width of every SMPL-family asset)");
+    DP_CHECK_ARG(frames_per_sequence >= 2 && batch % frames_per_sequence == 0, "batch must be whole sequences of >= 2 frames");
+    DP_CHECK_ARG(frames_per_sequence <= 4096 && batch / frames_per_sequence <= 16384, "sequence too long / too many sequences");
+    float *A = nullptr, *offsets = nullptr;
+    DP_TRY(lbs_forward_front(h, ws, posedirs_packed, pose_segments_host, segment_joints_host, num_segments, j_rest, j_rest_batched, transl, joints,
+                             batch, stream, &A, &offsets));
+    hipStream_t st = (hipStream_t)stream;
+    const int J = h->d.num_joints, V = h->d.num_vertices, F = (int)frames_per_sequence;
+    const int64_t n_seq = batch / F;
+    SkinTemporalArgs a;
+    a.s.offsets = offsets; a.s.ld_off = lbs_cpad(V); a.s.v_shaped = v_shaped; a.s.v_shaped_batched = v_shaped_batched; a.s.A = A;
+    a.s.skin_idx = skin_idx; a.s.skin_w = skin_w; a.s.K = skin_k; a.s.J = J; a.s.V = V; a.s.transl = transl; a.s.verts = nullptr;
+    a.dverts = d_verts; a.part = dist_part; a.F = F; a.c = scale;
+    constexpr int NV = 2;
+    const int vchunks = (int)ceil_div(V, 256 * NV);
+    a.nseg = skin_temporal_nseg(n_seq, F, vchunks);
+    const int maxrun = (int)ceil_div(F, a.nseg) + 1;
+    const size_t lds = (size_t)(2 * J * 12 + maxrun * NV * 4) * sizeof(float);
+    DP_CHECK_ARG(lds <= 64 * 1024, "sequence too long for one run per workgroup");
+    const dim3 grid((unsigned)vchunks, (unsigned)(n_seq * a.nseg));
+    if (v_shaped_batched) hipLaunchKernelGGL((k_skin_temporal<NV, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_skin_temporal<NV, false>), grid, dim3(256), lds, st, a);
+    FK_HIP_LAUNCH(hipGetLastError());
     return DPOSER_OK;
 }
 
@@ -2177,6 +2399,7 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
             g.W = term == 2 ? (const void*)doff_lo : (const void*)doff_hi; g.w_stride_blocks = kb;
             g.n_cblk = (int)(Bpad / tile); g.n_sblk = (int)(prow / tile); g.ksplit = k1;
             g.src[0] = term == 1 ? pd_lo : pd_hi; g.seg_kblocks[0] = kb; g.nseg = 1; g.ktot_blocks = kb;
+            g.panel_order = body_tuning().lbs_bwd_panel_order;
             WgradParams wp;
             wp.slab = dpf + (int64_t)term * k1 * Bpad * prow; wp.slab_stride = Bpad * prow; wp.ld = (int)prow; wp.N_valid = (int)batch;
             wp.K_valid = (J - 1) * 9;

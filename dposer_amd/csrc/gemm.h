@@ -35,6 +35,8 @@ struct GemmArgs {
     int ksplit;                     // >1: reduction split over blockIdx.y (wgrad); each split gets
                                     //     seg_kblocks[0]/ksplit k-blocks of the (single) segment
     double alg_flops;               // algorithmic FLOPs of this launch (2*M*N*K on the un-padded problem); profiling only
+    int panel_order;                // 1: split-K launches whose W panel is the big stream (LBS blend gradient: W = d_offsets, a few sample
+                                    //    tiles per channel tile) -- the tiles of one (channel tile, split) run side by side on ONE XCD
 };
 
 #include "gemm_kloop_asm.h"
@@ -439,7 +441,17 @@ __global__ void __launch_bounds__(WC* WS * 64, (EpiMinWaves<Epi>::value * 256 + 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int ntiles = g.n_cblk * g.n_sblk;
     int L, split;
-    if (g.ksplit >= 8 && (g.ksplit & 7) == 0) {
+    const int nblocks = ntiles * (g.ksplit > 1 ? g.ksplit : 1);
+    if (g.panel_order == 1 && (nblocks & 7) == 0) {
+        // hardware XCD = linear block id % 8, blocks are placed in id order: XCD x takes the logical ids [x n/8, (x+1) n/8), and the
+        // sample tiles of one (channel tile, split) are consecutive ids -- resident together, they stream the same W panel, so that
+        // panel crosses HBM once and is shared through that XCD's L2 (a pair 30 tiles apart landed on two XCDs: two HBM reads)
+        const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+        const int q = (lin & 7) * (nblocks >> 3) + (lin >> 3);
+        const int r = q / g.n_sblk;
+        split = r / g.n_cblk;
+        L = (r % g.n_cblk) + (q % g.n_sblk) * g.n_cblk;
+    } else if (g.ksplit >= 8 && (g.ksplit & 7) == 0) {
         // split-K (wgrad): hardware XCD = linear block id % 8.  Put a k-range on ONE XCD with all output tiles, so each
         // slice of the two operands is fetched from HBM once and shared through that XCD's L2 by every tile.
         const int lin = blockIdx.x + blockIdx.y * gridDim.x;

@@ -210,6 +210,17 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     // d joints: only the observed joints' columns are ever non-zero
     TK_HIP_LAUNCH(hipMemsetAsync(s.djoints, 0, (size_t)T * a->joint_rows * 3 * 4, st));
 
+    // DPOSER_MD_FUSED_TEMPORAL = 0 / 1 forces the two-kernel / fused form of skinning + temporal gradient (default: fused from
+    // DPOSER_MD_FUSED_TEMPORAL_MIN_SEQ = 4 sequences per call: a workgroup of the fused kernel walks >= 10 frames one after the other;
+    // measured 0.60 vs 0.67 ms per step at 8 sequences of 60 frames, a tie at one)
+    bool fused_temporal = a->skin_k == 4 && F <= 4096 && n_seq <= 16384;
+    {
+        const char* e = getenv("DPOSER_MD_FUSED_TEMPORAL");
+        const char* m = getenv("DPOSER_MD_FUSED_TEMPORAL_MIN_SEQ");
+        if (e && e[0] == '0') fused_temporal = false;
+        else if (!(e && e[0] == '1')) fused_temporal = fused_temporal && n_seq >= (m ? atoll(m) : 4);
+    }
+
     // time-bias rows of all steps: two small GEMMs once instead of per step
     if (a->n_steps > 0) DP_TRY(dposer_prior_table_build(a->net, a->flat_params, a->packed, a->net_ws, a->t_host, a->n_steps, a->freq, T, stream));
     for (int k = 0; k < a->n_steps; ++k) {
@@ -218,12 +229,20 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
         DP_TRY(dposer_prior_loss_tabled(a->net, a->flat_params, a->packed, a->net_ws, a->sde, s.xn, a->noise ? a->noise + (int64_t)k * n : nullptr,
                                         a->t_host[k], k, a->n_steps, a->weighted, 1.0f / (float)F, nullptr, s.gprior, s.loss1, a->seed,
                                         a->step0 + (uint32_t)k, a->sigmas, T, stream));
-        DP_TRY(dposer_lbs_forward(a->body, a->lbs_ws_fwd, a->posedirs_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest, a->rest_batched,
-                                  a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, nullptr, a->extra_vertex_ids, a->lmk_tri, a->lmk_bary,
-                                  s.verts, s.joints, T, stream));
         const float c_temp = a->w_temp_host[k] / ((float)(F - 1) * (float)V);
-        hipLaunchKernelGGL(k_md_vert_grad, dim3((unsigned)vb, (unsigned)T), dim3(256), 0, st, (const float*)s.verts, s.dverts, s.part, (int)F, V, c_temp);
-        TK_HIP_LAUNCH(hipGetLastError());
+        if (fused_temporal) {
+            // the vertices only feed the temporal term: skinning and that term's gradient in one pass, no vertices in HBM (the joints
+            // beyond the kinematic tree -- extra vertices, landmarks -- are not formed: the data term reads observed tree joints only)
+            DP_TRY(dposer_lbs_forward_temporal_grad(a->body, a->lbs_ws_fwd, a->posedirs_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest,
+                                                    a->rest_batched, a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, nullptr, F, c_temp,
+                                                    s.dverts, s.part, s.joints, T, stream));
+        } else {
+            DP_TRY(dposer_lbs_forward(a->body, a->lbs_ws_fwd, a->posedirs_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest, a->rest_batched,
+                                      a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, nullptr, a->extra_vertex_ids, a->lmk_tri, a->lmk_bary,
+                                      s.verts, s.joints, T, stream));
+            hipLaunchKernelGGL(k_md_vert_grad, dim3((unsigned)vb, (unsigned)T), dim3(256), 0, st, (const float*)s.verts, s.dverts, s.part, (int)F, V, c_temp);
+            TK_HIP_LAUNCH(hipGetLastError());
+        }
         hipLaunchKernelGGL(k_md_joint, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)s.joints, (int64_t)a->joint_rows * 3, a->joints_obs, s.djoints,
                            (int)F, a->n_obs_joints, a->w_data_host[k], (const float*)s.part, vb * (int)F, 1.0f / ((float)(F - 1) * (float)V),
                            (const float*)s.loss1, a->loss_log ? a->loss_log + 3 * (int64_t)k * n_seq : nullptr);

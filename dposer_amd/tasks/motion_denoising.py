@@ -82,9 +82,16 @@ class MotionDenoise:
         lib, h = _C.lib(), core._handle()
         F = int(frames_per_sequence) if frames_per_sequence else T
         n_seq = T // F
-        betas = self.betas if self.betas.shape[0] == T else self.betas[:1].expand(T, -1).contiguous()
-        v_shaped, j_rest, batched = core.rest_shape(betas, None)
+        betas = self.betas if self.betas.shape[0] == T else self.betas[:1]
+        if betas.shape[0] > 1 and bool((betas == betas[:1]).all()):
+            # one body shape for every frame (the module's default: motion_denoising.py:64 keeps zeros((batch_size, 10))): the rest
+            # shape is formed once and shared -- the skinning kernels then read 126 KB from L2 instead of a [T, V, 3] copy from HBM
+            # in every step (0.97 GB forward and again backward at 7680 frames); row b of the batched result carries the same bits
+            betas = betas[:1]
+        v_shaped, j_rest, batched = core.rest_shape(betas.contiguous(), None)
         v_shaped, j_rest = v_shaped.contiguous(), j_rest.contiguous()
+        if batched and v_shaped.shape[0] == 1 and T > 1:
+            batched = False                                        # [1, V, 3] / [1, J, 3] read as the shared [V, 3] / [J, 3]
         names = [name for name, _ in core.segments]
         segj = (C.c_int32 * len(names))(*[nj for _, nj in core.segments])
         jptr, jvidx, jw = core.joint_csr()

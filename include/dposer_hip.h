@@ -337,6 +337,19 @@ int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedirs_packed, c
                        int32_t skin_k, const float* transl, const int32_t* extra_vertex_ids, const int32_t* lmk_tri,
                        const float* lmk_bary, float* verts, float* joints, int64_t batch, void* stream);
 
+/* dposer_lbs_forward for callers that need the vertices ONLY for the temporal smoothness term of run/motion_denoising.py:253-255
+ * (`torch.mean(torch.norm(verts[:-1] - verts[1:], dim=-1))` and its autograd): skinning and that term's gradient in one pass, the
+ * vertices never reach HBM.  batch = whole sequences of frames_per_sequence consecutive frames (neighbours never cross a sequence);
+ *   d_verts [B,V,3] out = scale * (u_t - u_{t-1}), u_t = (v[t] - v[t+1]) / ||v[t] - v[t+1]|| (0/0 = NaN like torch's sqrt backward);
+ *   dist_part [B, ceil(V/256)] out: sums of ||v[t] - v[t+1]|| over blocks of 256 vertices (0 for the last frame of a sequence) --
+ *   their sum / ((F-1) V) is the term's value;  joints [B, J+num_extra+num_landmarks, 3]: only [:, :J] is written (the extra
+ *   vertices / landmarks would need the vertices).  skin_k must be 4.  Other arguments as dposer_lbs_forward. */
+int dposer_lbs_forward_temporal_grad(dposer_body_t h, void* ws, const void* posedirs_packed, const float* const* pose_segments_host,
+                                     const int32_t* segment_joints_host, int32_t num_segments, const float* j_rest, int32_t j_rest_batched,
+                                     const float* v_shaped, int32_t v_shaped_batched, const int32_t* skin_idx, const float* skin_w,
+                                     int32_t skin_k, const float* transl, int64_t frames_per_sequence, float scale, float* d_verts,
+                                     float* dist_part, float* joints, int64_t batch, void* stream);
+
 /* Backward of dposer_lbs_forward (autograd of BodyModel.forward w.r.t. pose / rest joints / v_posed; the reference
  * differentiates through smplx in run/motion_denoising.py:217-218,255-267 and run/smplify.py:200-260).
  *   ws_fwd: the workspace of the matching forward call (unmodified since);  posedirs_bwd_packed:

@@ -223,6 +223,30 @@ def test_motion_denoise_batch_of_sequences_equals_one_sequence_at_a_time():
         assert np.allclose(log[:, i, :2], t2n(md.loss_log)[:, 0, :2], rtol=1e-6)
 
 
+@pytest.mark.parametrize("S,F", [(3, 8), (2, 23)])
+def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, monkeypatch):
+    """dposer_lbs_forward_temporal_grad (skinning + the temporal term's gradient in one pass, no vertices in HBM) against k_skin_x4 +
+    k_md_vert_grad inside the same one-call loop: same expressions in the same order, so poses and the loss log must carry the same
+    bits -- one run of frames per sequence and several (halo frames recomputed)."""
+    iters, spi = 2, 3
+    md, joints3d, gt, init, rs = _md_setup(F * S)
+    noise = torch.tensor(rs.standard_normal((iters * spi, F * S, 63)).astype(np.float32), device=DEV)
+    md.batch_size = F
+    md.betas = md.betas[:F]
+    kw = dict(time_strategy="3", iterations=iters, steps_per_iter=spi)
+    out = {}
+    for tag, fused, nseg in (("two-kernel", "0", None), ("fused", "1", None), ("fused-2", "1", "2"), ("fused-3", "1", "3")):
+        monkeypatch.setenv("DPOSER_MD_FUSED_TEMPORAL", fused)
+        if nseg:
+            monkeypatch.setenv("DPOSER_SKIN_TEMPORAL_NSEG", nseg)
+        res = md.optimize_sequences(joints3d.reshape(S, F, 22, 3), gt.reshape(S, F, 63), noise=noise, init_poses=init.reshape(S, F, 63), **kw)
+        out[tag] = (res["pose_body"].clone(), md.loss_log.clone())
+    assert torch.isfinite(out["two-kernel"][0]).all()
+    for tag in ("fused", "fused-2", "fused-3"):
+        assert torch.equal(out[tag][0], out["two-kernel"][0]), tag
+        assert torch.equal(out[tag][1], out["two-kernel"][1]), tag
+
+
 def test_motion_denoise_under_the_ve_sde_runs_the_step_by_step_loop():
     """training.sde = 'vesde' (motion_denoising.py:60-62 builds it) is outside the one-call loop: `optimize` takes the autograd loop with
     the unfused VE prior, `optimize_sequences` walks the sequences through it one by one and returns the batched layout."""
