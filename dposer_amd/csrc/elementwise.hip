@@ -824,6 +824,59 @@ hipError_t launch_reduce_grads(const ReduceJobs& jobs, const float* scratch, flo
     return hipGetLastError();
 }
 
+// Partial tiles of the batched weight-gradient launch (wgrad_batch.h) -> flat gradient.  Block (x, y): rows [16 x, 16 x + 16) of output
+// tile y = (problem, lane slot); the partition is re-derived from the same struct the GEMM kernel used; partials are added in row
+// order of the lane space (for a row-split W_t: first half, then second half) -- a fixed order.
+__global__ void __launch_bounds__(256) k_reduce_wgrad_tiles(WgradBatchArgs a, float* grad) {
+    const int p = blockIdx.y >> 4, slot = blockIdx.y & 15;
+    const WgradLaneProblem& pr = a.prob[p];
+    if (pr.split_k && slot >= 8) return;
+    const int half = slot >> 3, wl = slot & 7;
+    int start = 0;
+    for (int i = 0; i < p; ++i) start += a.prob[i].len;
+    const int end = start + pr.len;
+    const int l0 = start / a.q, l1 = (end - 1) / a.q;
+    const int64_t dst0 = pr.dst_off[half] + (int64_t)((wl & 3) * 256) * pr.ld[half] + (int64_t)(pr.sblk0[half] + (wl >> 2)) * 256;
+    const int ld = pr.ld[half];
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool first = true;
+    for (int rep = 0; rep < (pr.split_k ? 2 : 1); ++rep) {
+        const int sl = slot + 8 * rep;
+        for (int l = l0; l <= l1; ++l) {
+            // ordinal of this problem's segment among the segments of lane l
+            const int lo = l * a.q, hi = lo + a.q;
+            int ord = 0, st2 = 0;
+            for (int i = 0; i < p; ++i) {
+                const int e2 = st2 + a.prob[i].len;
+                if ((lo > st2 ? lo : st2) < (hi < e2 ? hi : e2)) ++ord;
+                st2 = e2;
+            }
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.partials + ((int64_t)(wgb_block(l, sl) * WGB_MAX_SEG + ord) << 16)) + blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = src[i * 256];
+                if (first) acc[i] = v;
+                else { acc[i][0] += v[0]; acc[i][1] += v[1]; acc[i][2] += v[2]; acc[i][3] += v[3]; }
+            }
+            first = false;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx4 = blockIdx.x * 1024 + i * 256 + threadIdx.x;       // float4 index inside the 256 x 256 tile
+        const int row = idx4 >> 6, col = (idx4 & 63) << 2;
+        float* d = grad + dst0 + (int64_t)row * ld + col;
+        if (((dst0 | ld) & 3) == 0) *reinterpret_cast<f32x4*>(d) = acc[i];
+        else { d[0] = acc[i][0]; d[1] = acc[i][1]; d[2] = acc[i][2]; d[3] = acc[i][3]; }
+    }
+}
+hipError_t launch_reduce_wgrad_tiles(const WgradBatchArgs& a, float* flat_grad, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_wgrad_tiles, dim3(16, (unsigned)(a.nprob * 16)), dim3(256), 0, st, a, flat_grad);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) k_sum_partials(const float* part, int n, float* out) {
     float acc = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) acc += part[i];

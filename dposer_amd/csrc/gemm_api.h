@@ -30,6 +30,8 @@ hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdPa
 hipError_t gemm_wgrad(int prec, int shape, const GemmArgs& g, const WgradParams& p, hipStream_t st);
 // bf16, any wgrad tiling (256x256, 128x128, 64x128, 128x64), operands sample-major (gemm_wgrad_tr.h): no transposed activation copies needed
 hipError_t gemm_wgrad_tr(int shape, const WgradTrArgs& g, const WgradParams& p, hipStream_t st);
+// every 256x256 wgrad tile of a training step in one launch (wgrad_batch.h)
+hipError_t gemm_wgrad_tr_batch(const WgradBatchArgs& a, hipStream_t st);
 
 // ---- persistent Euler-Maruyama sampler (gemm_sampler.hip): one workgroup per block of 256 samples walks every layer of every step
 struct SamplerLayer {

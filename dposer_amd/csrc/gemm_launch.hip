@@ -159,6 +159,10 @@ hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdPa
     if (p.act != DP_ACT_SWISH) { typedef EpiSiLUBwd<__bf16, true> A; typedef EpiSiLUBwd<float, true> B; DISPATCH(A, B, M_MID | M_SMALL); }
     typedef EpiSiLUBwd<__bf16> A; typedef EpiSiLUBwd<float> B; DISPATCH(A, B, M_MAIN);
 }
+hipError_t gemm_wgrad_tr_batch(const WgradBatchArgs& a, hipStream_t st) {
+    ProfScope _ps(EPI_WGRAD * 12 + SHAPE_BIG, a.alg_flops, st);
+    return launch_wgrad_tr_batch<2, 4, 4, 2, 4>(a, st);
+}
 hipError_t gemm_wgrad_tr(int shape, const WgradTrArgs& g, const WgradParams& p, hipStream_t st) {
     ProfScope _ps(EPI_WGRAD * 12 + shape, g.alg_flops, st);
     if (shape == SHAPE_BIG) return launch_wgrad_tr<2, 4, 4, 2, 4>(g, p, st);

@@ -19,6 +19,7 @@
 #pragma once
 #include "epilogues.h"
 #include "gemm.h"
+#include "wgrad_batch.h"
 
 struct WgradTrArgs {
     const void* dY;      // FT [Spad][N]   (rows of dW)
@@ -30,30 +31,23 @@ struct WgradTrArgs {
     double alg_flops;
 };
 
+// One output tile over the sample-block rows [sb, sb + nstages): K loop + EpiWgrad store at tile-relative coordinates (en0, ek0) of `ep`.
+// dY_ / H_: operand bases, nA / nB: their 16-channel blocks per sample-block row, span: bytes the 32-bit DMA offsets must cover.
 template <int WC, int WS, int TC, int TS, int NB>
-__global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_wgrad_tr_kernel(WgradTrArgs g, WgradParams ep) {
+__device__ __forceinline__ void wgrad_tr_tile(const void* dY_, const void* H_, const int nA, const int nB, const int cblk, const int sblk, int sb,
+                                              const int nstages, const int64_t span, const WgradParams& ep, const int split, const int en0,
+                                              const int64_t ek0, unsigned char* smem) {
     typedef __bf16 T;
     constexpr int KB = 2;
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     typedef __attribute__((ext_vector_type(4))) short s16x4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(NB >= 3 && NB <= 4, "ring depth");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wc = wave / WS, ws = wave % WS;
-    int L, split;
-    if (g.ksplit >= 8 && (g.ksplit & 7) == 0) {       // one k-range per XCD with all of its tiles (see gemm.h)
-        const int lin = blockIdx.x + blockIdx.y * gridDim.x;
-        split = lin % g.ksplit;
-        L = lin / g.ksplit;
-    } else {
-        L = xcd_remap(blockIdx.x, g.n_cblk * g.n_sblk);
-        split = blockIdx.y;
-    }
-    const int cblk = L % g.n_cblk, sblk = L / g.n_cblk;
 
     f32x16 acc[TC][TS];
 #pragma unroll
@@ -63,8 +57,6 @@ __global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (W
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nstages = g.sblocks / (g.ksplit > 1 ? g.ksplit : 1);
-    int sb = split * nstages;                                   // sample block of the next stage to fetch
     // DMA: LDS position `lane` of a block receives the chunk whose un-rotated position is (lane - rot) & 63
     auto src_off = [&](int rot) __attribute__((always_inline)) {
         const int pn = (lane - rot) & 63;
@@ -79,12 +71,11 @@ __global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (W
         const unsigned lds = (unsigned)(size_t)(lptr_t)dst;
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
     };
-    const int nA = g.N >> 4, nB = g.Kc >> 4;                    // 16-channel blocks per sample-block row
     auto fetch_a = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < C::LPW_A; ++i) {
             const int blk = wave + i * C::NW;                   // 16-channel block inside the tile
-            const unsigned char* p = reinterpret_cast<const unsigned char*>(g.dY) + (((int64_t)sb * nA + cblk * C::CT * 2 + blk) << 10);
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(dY_) + (((int64_t)sb * nA + cblk * C::CT * 2 + blk) << 10);
             dma_1k(p + ((blk & 1) ? off1 : off0), smem + slot * C::STAGE_BYTES + (blk << 10));
         }
     };
@@ -92,7 +83,7 @@ __global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (W
 #pragma unroll
         for (int i = 0; i < C::LPW_B; ++i) {
             const int blk = wave + i * C::NW;
-            const unsigned char* p = reinterpret_cast<const unsigned char*>(g.H) + (((int64_t)sb * nB + sblk * C::ST * 2 + blk) << 10);
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(H_) + (((int64_t)sb * nB + sblk * C::ST * 2 + blk) << 10);
             dma_1k(p + ((blk & 1) ? off1 : off0), smem + slot * C::STAGE_BYTES + ((C::CT * 2 + blk) << 10));
         }
     };
@@ -141,7 +132,6 @@ __global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (W
     // (fragments in fixed registers v208 ... v255), DMA addresses = SGPR base per piece + one 32-bit VGPR offset per operand.
     constexpr bool ASM = DPOSER_KLOOP_ASM && WC == 2 && WS == 4 && TC == 4 && TS == 2 && NB == 4;
     if constexpr (ASM) {
-        const int64_t span = ((int64_t)g.sblocks * (nA > nB ? nA : nB)) << 10;            // the 32-bit DMA offsets cover the operand
         if (nstages >= 3 && span < (int64_t)0xfff00000) {
             const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
             const uint32_t s_m0 = __builtin_amdgcn_readfirstlane(lds0 + (wave << 10));
@@ -151,8 +141,8 @@ __global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (W
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int blk = wave + i * C::NW;
-                sA[i] = sgpr_u64((uint64_t)(uintptr_t)g.dY + ((uint64_t)(cblk * C::CT * 2 + blk) << 10));
-                sB[i] = sgpr_u64((uint64_t)(uintptr_t)g.H + ((uint64_t)(sblk * C::ST * 2 + blk) << 10));
+                sA[i] = sgpr_u64((uint64_t)(uintptr_t)dY_ + ((uint64_t)(cblk * C::CT * 2 + blk) << 10));
+                sB[i] = sgpr_u64((uint64_t)(uintptr_t)H_ + ((uint64_t)(sblk * C::ST * 2 + blk) << 10));
             }
             const int n_dma = nstages - PRE;
             const uint32_t rem = __builtin_amdgcn_readfirstlane(n_dma & 3);
@@ -178,7 +168,7 @@ __global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (W
             const uint32_t vB1_lo = lds0 + ((C::CT * 2) << 10) + ws * TS * 2048 + gq_ * 1024 + ((base0 + 640) & 1023);
             const uint32_t vA0_hi = vA0_lo + 65536, vA1_hi = vA1_lo + 65536, vB0_hi = vB0_lo + 65536, vB1_hi = vB1_lo + 65536;
 #include "gemm_wgrad_tr_asm.inc"
-            EpiWgrad<T>::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane, 0, split, nullptr, 0, nullptr);
+            EpiWgrad<T>::template apply<TC, TS>(ep, acc, en0 + wc * TC * 32, ek0 + ws * TS * 32, lane, 0, split, nullptr, 0, nullptr);
             return;
         }
     }
@@ -225,7 +215,68 @@ __global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (W
     if (nstages - t >= 2) { stage(N_{}, std::integral_constant<int, 0>{}, N_{}); ++t; }
     stage(N_{}, std::integral_constant<int, 0>{}, Y{});
 
-    EpiWgrad<T>::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane, 0, split, nullptr, 0, nullptr);
+    EpiWgrad<T>::template apply<TC, TS>(ep, acc, en0 + wc * TC * 32, ek0 + ws * TS * 32, lane, 0, split, nullptr, 0, nullptr);
+}
+
+template <int WC, int WS, int TC, int TS, int NB>
+__global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_wgrad_tr_kernel(WgradTrArgs g, WgradParams ep) {
+    typedef GemmCfg<__bf16, WC, WS, TC, TS, 2> C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int L, split;
+    if (g.ksplit >= 8 && (g.ksplit & 7) == 0) {       // one k-range per XCD with all of its tiles (see gemm.h)
+        const int lin = blockIdx.x + blockIdx.y * gridDim.x;
+        split = lin % g.ksplit;
+        L = lin / g.ksplit;
+    } else {
+        L = xcd_remap(blockIdx.x, g.n_cblk * g.n_sblk);
+        split = blockIdx.y;
+    }
+    const int cblk = L % g.n_cblk, sblk = L / g.n_cblk;
+    const int nstages = g.sblocks / (g.ksplit > 1 ? g.ksplit : 1);
+    const int nA = g.N >> 4, nB = g.Kc >> 4;                    // 16-channel blocks per sample-block row
+    const int64_t span = ((int64_t)g.sblocks * (nA > nB ? nA : nB)) << 10;                // the 32-bit DMA offsets cover the operand
+    wgrad_tr_tile<WC, WS, TC, TS, NB>(g.dY, g.H, nA, nB, cblk, sblk, split * nstages, nstages, span, ep, split, cblk * C::CT * 32,
+                                      (int64_t)sblk * C::ST * 32, smem);
+}
+
+// ---- all 256 x 256 weight-gradient tiles of a training step as ONE launch (wgrad_batch.h) ---------------------------------------
+template <int WC, int WS, int TC, int TS, int NB>
+__global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_wgrad_tr_batch_kernel(WgradBatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int lane_id = wgb_lane(b), slot = wgb_slot(b), half = slot >> 3, wl = slot & 7;
+    const int lo = lane_id * a.q, hi = lo + a.q;
+    int start = 0, ord = 0;
+    for (int p = 0; p < a.nprob; ++p) {
+        const WgradLaneProblem& pr = a.prob[p];
+        const int end = start + pr.len;
+        const int s0 = lo > start ? lo : start, s1 = hi < end ? hi : end;
+        if (s0 < s1) {
+            WgradParams ep;
+            ep.slab = a.partials + ((int64_t)(b * WGB_MAX_SEG + ord) << 16); ep.slab_stride = 0; ep.ld = 256; ep.N_valid = 256; ep.K_valid = 256;
+            wgrad_tr_tile<WC, WS, TC, TS, NB>(pr.dY[half], pr.H[half], pr.nA[half], pr.nB[half], wl & 3, pr.sblk0[half] + (wl >> 2),
+                                              s0 - start + pr.sb_off[half], s1 - s0, a.span, ep, 0, 0, 0, smem);
+            ++ord;
+            __syncthreads();                                       // the ring is reused by the next segment
+        }
+        start = end;
+    }
+}
+template <int WC, int WS, int TC, int TS, int NB>
+static inline hipError_t launch_wgrad_tr_batch(const WgradBatchArgs& a, hipStream_t stream) {
+    typedef GemmCfg<__bf16, WC, WS, TC, TS, 2> C;
+    auto kern = gemm_wgrad_tr_batch_kernel<WC, WS, TC, TS, NB>;
+    constexpr int lds_bytes = NB * C::STAGE_BYTES;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (lds_bytes > 64 * 1024 && hipGetDevice(&dev) != hipSuccess) return hipErrorInvalidDevice;
+    if (lds_bytes > 64 * 1024 && !attr_set[dev & 63]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set[dev & 63] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(WGB_BLOCKS), dim3(C::THREADS), lds_bytes, stream, a);
+    return hipGetLastError();
 }
 
 template <int WC, int WS, int TC, int TS, int NB>

@@ -1,6 +1,7 @@
 // Elementwise / layout / optimizer kernels of the score path (implemented in elementwise.hip).
 #pragma once
 #include "common.h"
+#include "wgrad_batch.h"
 #include "gemm_api.h"
 
 // ---- weight packing -----------------------------------------------------------------------------
@@ -220,6 +221,7 @@ struct ReduceJobs {
     int n;
 };
 hipError_t launch_reduce_grads(const ReduceJobs& jobs, const float* scratch, float* flat_grad, hipStream_t st);
+hipError_t launch_reduce_wgrad_tiles(const WgradBatchArgs& a, float* flat_grad, hipStream_t st);   // wgrad_batch.h: partial tiles -> flat gradient
 hipError_t launch_sum_partials(const float* part, int n, float* out, hipStream_t st);             // out[0] = sum(part[0..n))
 hipError_t launch_sqnorm(const float* g, int64_t n, float* part, int* nblocks, hipStream_t st);   // partial sums of g^2
 

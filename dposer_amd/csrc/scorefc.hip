@@ -259,6 +259,7 @@ struct Ws {
     char *dyT[MAX_L], *hT[MAX_L], *tembT, *embT, *xinT, *dresT, *dUT;
     float *gn_part[MAX_L], *cs_part_post, *cs_part_se, *slabs;
     int64_t total;
+    int64_t slab_elems;   // capacity of `slabs` in floats
 };
 
 struct WgradPlan {
@@ -362,7 +363,13 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         }
         acc(h->Cp, H, (int64_t)h->D * H);
         acc(E, E, (int64_t)E * E);
+        {   // room for the partial tiles of the one-launch weight gradients (wgrad_batch.h; plan_batched_wgrad has the conditions)
+            const char* e = getenv("DPOSER_WGRAD_BATCHED");
+            const int64_t need = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536 + ((int64_t)14 << 20);
+            if (!(e && e[0] == '0') && !h->f32 && H == 1024 && E == 512 && slab_elems < need) slab_elems = need;
+        }
         w.slabs = (float*)take(slab_elems * 4);
+        w.slab_elems = slab_elems;
     }
     w.total = p;
 }
@@ -1004,6 +1011,72 @@ static int ensure_side_stream(dposer_scorefc_s* h) {
     return DPOSER_OK;
 }
 
+// One launch for every 256 x 256 weight-gradient tile of the step (wgrad_batch.h) instead of two split-K launches per layer: used when
+// no gradient bucket has to be final early (single GPU: bucket events are what the data-parallel all-reduce overlaps with), bf16, the
+// shipped widths (H = 1024: 4 x 4 tiles, E = 512: 4 x 2 tiles).  Measured against the per-layer launches (with their second stream
+// where that was the default), ms per step: 0.489 -> 0.432 at 1280 samples, 0.708 -> 0.561 at 4096, 0.831 -> 0.710 at 8192,
+// 1.195 -> 1.069 at 16384, 1.965 -> 1.755 at 32768, 3.41-3.45 -> 3.23 at 65536.
+// DPOSER_WGRAD_BATCHED = 0 forces it off, 1 also takes it when bucket events were asked for (they are then all recorded at the end).
+// Returns false when not applicable.
+static bool plan_batched_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, bool has_events, WgradBatchArgs& a) {
+    const char* e = getenv("DPOSER_WGRAD_BATCHED");
+    const int forced = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
+    if (forced == 0 || !tr || (has_events && forced != 1) || h->H != 1024 || h->E != 512 || h->L < 2 || h->L > 9) return false;
+    const int64_t need = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536, small = (int64_t)14 << 20;
+    if (w.slab_elems < need + small) return false;
+    const int S = (int)(w.Bpad / 32), L = h->L, nAh = h->H / 16, nE = h->E / 16;
+    if (S % 2 != 0) return false;
+    std::memset(&a, 0, sizeof(a));
+    int n = 0;
+    for (int l = 1; l < L; ++l) {                                   // W_x of layers 1 .. L-1 (layer 0 has 63 input channels: its own small kernel)
+        if (h->layer[l].kin != h->H || h->layer[l].kin_pad != h->H) return false;
+        WgradLaneProblem& p = a.prob[n++];
+        for (int i = 0; i < 2; ++i) {
+            p.dY[i] = w.dy[l]; p.H[i] = w.hbuf[l - 1]; p.nA[i] = nAh; p.nB[i] = nAh; p.sblk0[i] = 2 * i; p.sb_off[i] = 0;
+            p.dst_off[i] = h->layer[l].w; p.ld[i] = h->H;
+        }
+        p.len = S;
+    }
+    for (int l = 0; l + 1 < L; l += 2) {                            // W_t of two layers side by side
+        WgradLaneProblem& p = a.prob[n++];
+        for (int i = 0; i < 2; ++i) {
+            p.dY[i] = w.dy[l + i]; p.H[i] = w.temb; p.nA[i] = nAh; p.nB[i] = nE; p.sblk0[i] = 0; p.sb_off[i] = 0;
+            p.dst_off[i] = h->layer[l + i].wt; p.ld[i] = h->E;
+        }
+        p.len = S;
+    }
+    if (L % 2) {                                                    // the left-over W_t: its rows in two halves
+        WgradLaneProblem& p = a.prob[n++];
+        for (int i = 0; i < 2; ++i) {
+            p.dY[i] = w.dy[L - 1]; p.H[i] = w.temb; p.nA[i] = nAh; p.nB[i] = nE; p.sblk0[i] = 0; p.sb_off[i] = i * (S / 2);
+            p.dst_off[i] = h->layer[L - 1].wt; p.ld[i] = h->E;
+        }
+        p.len = S / 2;
+        p.split_k = 1;
+    }
+    if (n > WGB_MAX_PROB) return false;
+    a.nprob = n;
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) total += a.prob[i].len;
+    a.q = (int)ceil_div(total, WGB_LANES);
+    a.partials = w.slabs + (w.slab_elems - need);
+    a.span = ((int64_t)S * nAh) << 10;
+    if (a.span >= (int64_t)0xfff00000) return false;
+    // every lane: at most WGB_MAX_SEG segments (short ones take the kernel's generic prologue / tail path)
+    for (int lane = 0; lane < WGB_LANES; ++lane) {
+        const int64_t lo = (int64_t)lane * a.q, hi = lo + a.q;
+        int64_t start = 0;
+        int segs = 0;
+        for (int i = 0; i < n; ++i) {
+            const int64_t end = start + a.prob[i].len, s0 = lo > start ? lo : start, s1 = hi < end ? hi : end;
+            if (s0 < s1) ++segs;
+            start = end;
+        }
+        if (segs > WGB_MAX_SEG) return false;
+    }
+    return true;
+}
+
 // backward from dres (FT [Bpad][Cp], zero on padded rows) to the flat parameter gradient and/or dx.
 //   critical path (stream st): dgrad GEMM of layer L-1 ... 0 (each writes dy_j, dy_j^T and the GroupNorm partial sums),
 //                              dx GEMM, dgrad into the time branch;
@@ -1015,8 +1088,10 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     const int H = h->H, E = h->E, L = h->L, KBS = h->KBS;
     const int64_t Bpad = w.Bpad;
     const bool want_w = flat_grad != nullptr;
-    const bool two = want_w && use_side_stream(Bpad);
     const bool tr = wgrad_tr_mode(h, Bpad);
+    WgradBatchArgs wb;
+    const bool batched = want_w && plan_batched_wgrad(h, w, tr, events != nullptr && n_events > 0, wb);
+    const bool two = want_w && !batched && use_side_stream(Bpad);
     if (two) DP_TRY(ensure_side_stream(h));
     hipStream_t sw = two ? h->side : st;
     ReduceJobs rj;
@@ -1078,10 +1153,14 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         // parameter gradients of layer j
         const void* inT = (j == 0) ? (const void*)w.xinT : (const void*)w.hT[j - 1];
         const LayerOff& lo = h->layer[j];
+        if (batched) {       // W_x (j >= 1) and W_t of every layer are tiles of the one launch behind the loop
+            if (j == 0) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], (const void*)w.xin));
+        } else {
         if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], j == 0 ? (const void*)w.xin : (const void*)w.hbuf[j - 1]));
         else DP_TRY(run_wgrad(h, w.dyT[j], H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw));
         if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw, w.dy[j], w.temb));
         else DP_TRY(run_wgrad(h, w.dyT[j], H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw));
+        }
         add_job(lo.gamma, H, w.gn_part[j] + 0 * H, 3 * (int64_t)H, ws_rows);
         add_job(lo.beta, H, w.gn_part[j] + 1 * H, 3 * (int64_t)H, ws_rows);
         add_job(lo.b, H, w.gn_part[j] + 2 * H, 3 * (int64_t)H, ws_rows);
@@ -1089,7 +1168,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         if (from_post) add_job(h->off_post_b, h->D, w.cs_part_post, h->Cp, n_chunks_post);
         // layer j's gradient (and everything behind it in the flat buffer) is final: the data-parallel all-reduce of this
         // bucket can start while the remaining layers are still being differentiated
-        if (j >= 1) DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1 - j, sw));
+        if (j >= 1 && !batched) DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1 - j, sw));
     }
     if (dx) {   // d loss / d x = dy_0 @ W_pre  (the time branch does not depend on x)
         const int shape = final_shape(Bpad);
@@ -1120,8 +1199,16 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     DP_HIP_LAUNCH(launch_colsum(h->f32, w.dU, w.cs_part_se, Bpad, E, &n_chunks_se, sw));
     if (tr) DP_TRY(run_wgrad(h, nullptr, E, E, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw, w.dU, w.emb));
     else DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw));
+    if (batched) {
+        if (slab_cursor > w.slab_elems - (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: slab buffer too small for the batched wgrad launch");
+        wb.alg_flops = 2.0 * (double)B * H * ((double)(L - 1) * H + (double)L * E);
+        DP_HIP_LAUNCH(gemm_wgrad_tr_batch(wb, st));
+        DP_HIP_LAUNCH(launch_reduce_wgrad_tiles(wb, flat_grad, st));
+    }
     // last bucket: layer 0 (jobs queued above), the shared time embedding and the parameters that never get a gradient
     add_job(h->off_se_b, E, w.cs_part_se, E, n_chunks_se);
+    if (batched && events)           // nothing was final before this point: every bucket becomes final with the last reduction
+        for (int b = 0; b + 1 < L; ++b) DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, b, sw));
     DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1, sw));
     if (two) {   // the caller's stream owns the complete gradient (and may reuse the workspace) from here on
         DP_CHECK_HIP(hipEventRecord(h->ev_join, sw));

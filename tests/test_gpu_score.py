@@ -590,10 +590,11 @@ def test_integration_md_ctypes_stub_runs():
 
 
 @pytest.mark.parametrize("env", [
-    {"DPOSER_GNBWD_BIG": "1", "DPOSER_WGRAD_BIG": "1", "DPOSER_BIG_MIN_BATCH": "256"},      # 256x256 tilings from 256 samples up
-    {"DPOSER_GNBWD_BIG": "0", "DPOSER_WGRAD_BIG": "0", "DPOSER_WGRAD_STREAM": "0"},          # 128x128 everywhere, single stream
+    {"DPOSER_GNBWD_BIG": "1", "DPOSER_WGRAD_BIG": "1", "DPOSER_BIG_MIN_BATCH": "256", "DPOSER_WGRAD_BATCHED": "0"},      # 256x256 tilings from 256 samples up
+    {"DPOSER_GNBWD_BIG": "0", "DPOSER_WGRAD_BIG": "0", "DPOSER_WGRAD_STREAM": "0", "DPOSER_WGRAD_BATCHED": "0"},          # 128x128 everywhere, single stream
     {"DPOSER_WGRAD_TR": "0"},                                                                # bf16 wgrads on transposed copies
-    {"DPOSER_WGRAD_STREAM": "1"},                                                            # wgrads on the second stream (default 8192..16384)
+    {"DPOSER_WGRAD_STREAM": "1", "DPOSER_WGRAD_BATCHED": "0"},                                                  # wgrads on the second stream (default 8192..16384)
+    {"DPOSER_WGRAD_BATCHED": "1"},                                                           # all 256x256 wgrad tiles in one launch (the single-GPU default)
 ])
 def test_alternative_tilings_and_streams_keep_parity(env):
     """The tiling / stream policy depends on the batch size (256x256 GroupNorm-backward and wgrad tiles from 32768 samples,
@@ -611,6 +612,35 @@ def test_alternative_tilings_and_streams_keep_parity(env):
                        cwd=root, env=child_env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("B", [8192, 5000, 32768])
+def test_batched_weight_gradient_launch_matches_the_per_layer_launches(B, monkeypatch):
+    """One launch for every 256x256 weight-gradient tile of the step (wgrad_batch.h: 16 lanes x 16 workgroups over a line of lane
+    problems, partial tiles reduced in a fixed order) against two split-K launches per layer: same products, another partition of the
+    sample sum -- the flat gradients agree to fp32 summation error, and the batched form is deterministic."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    cfg, m, p = make_model(5, precision="bf16")
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    rs = np.random.RandomState(11)
+    x = _dev(rs.standard_normal((B, 63)).astype(np.float32))
+    grads = {}
+    for tag, flag in (("per-layer", "0"), ("batched", "1"), ("batched-again", "1")):
+        monkeypatch.setenv("DPOSER_WGRAD_BATCHED", flag)
+        fg = torch.full((m._engine().num_params,), float("nan"), device=DEV)
+        loss = losses.fused_dsm_grad(m, sde, x, flat_grad=fg, seed=3, step=7)
+        grads[tag] = (fg.clone(), float(loss))
+    assert torch.isfinite(grads["batched"][0]).all()
+    assert torch.equal(grads["batched"][0], grads["batched-again"][0])
+    assert not torch.equal(grads["batched"][0], grads["per-layer"][0])          # (another summation order: the batched path did run)
+    assert grads["batched"][1] == grads["per-layer"][1]
+    a, b = grads["batched"][0].double(), grads["per-layer"][0].double()
+    assert float((a - b).norm() / b.norm()) < 2e-6
+    eng = m._engine()
+    for off, prm in zip(eng.offsets, m._param_list):          # every tensor on its own: a misplaced tile cannot hide behind the big ones
+        sl = slice(off, off + prm.numel())
+        if float(b[sl].norm()) > 0:
+            assert float((a[sl] - b[sl]).norm() / b[sl].norm()) < 2e-5, off
 
 
 @pytest.mark.parametrize("B,extra,D", [(640, {}, 63), (1024, {"DPOSER_WGRAD_BIG": "1"}, 63), (96, {}, 63), (1500, {}, 63),
@@ -635,7 +665,8 @@ def test_sample_major_wgrad_is_bit_identical_to_transposed_copy_path(B, extra, D
     outs = []
     for tr in ("1", "0"):
         out = str(tmp_path / f"fg_tr{tr}.npy")
-        env = dict(os.environ, DPOSER_WGRAD_TR=tr, **extra)
+        # (per-layer launches on both sides: the one-launch form of wgrad_batch.h partitions the sample sum differently)
+        env = dict(os.environ, DPOSER_WGRAD_TR=tr, DPOSER_WGRAD_BATCHED="0", **extra)
         r = subprocess.run([sys.executable, "-c", code, out], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(np.load(out))
