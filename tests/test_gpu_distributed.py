@@ -55,7 +55,7 @@ def _steps(model_seed, batch, t, z, n_steps, world, rank, precision):
     return m.flat_params().detach().cpu().clone(), opt._flat_m.detach().cpu().clone(), out
 
 
-def _worker(rank, world, port, q, model_seed, batch, t, z, n_steps):
+def _worker(rank, world, port, q, model_seed, batch, t, z, n_steps, precision="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       DPOSER_DIST_BACKEND="gloo")
     import sys
@@ -64,25 +64,30 @@ def _worker(rank, world, port, q, model_seed, batch, t, z, n_steps):
     import torch.distributed as dist
     ddp.init_from_env()
     torch.cuda.set_device(0)
-    flat, mom, losses_ = _steps(model_seed, batch, t, z, n_steps, world, rank, "fp32")
+    flat, mom, losses_ = _steps(model_seed, batch, t, z, n_steps, world, rank, precision)
     q.put((rank, flat.numpy(), mom.numpy(), losses_))
     ddp.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_bucketed_step_equals_single_process_step():
+@pytest.mark.parametrize("precision,batched", [("fp32", None), ("bf16", "0"), ("bf16", "1")])
+def test_two_rank_bucketed_step_equals_single_process_step(precision, batched, monkeypatch):
     """Mean-reduced DSM loss over equal shards: the averaged shard gradients are the full-batch gradient, so two ranks
-    (bucketed all-reduce overlapped with the backward pass) must track the single-process run on the whole batch."""
+    (bucketed all-reduce overlapped with the backward pass) must track the single-process run on the whole batch.
+    bf16: with the per-layer weight-gradient launches the buckets need (default under data parallelism) and with the one-launch
+    form forced (DPOSER_WGRAD_BATCHED=1: every bucket event is recorded after the last reduction)."""
+    if batched is not None:
+        monkeypatch.setenv("DPOSER_WGRAD_BATCHED", batched)          # (spawned ranks inherit the environment)
     rs = np.random.RandomState(5)
     n_steps, B = 3, 256
     batch = torch.tensor(rs.standard_normal((n_steps, B, 63)).astype(np.float32))
     t = torch.tensor(rs.uniform(1e-3, 1.0, (n_steps, B)).astype(np.float32))
     z = torch.tensor(rs.standard_normal((n_steps, B, 63)).astype(np.float32))
-    ref, ref_mom, ref_losses = _steps(9, batch, t, z, n_steps, 1, 0, "fp32")
+    ref, ref_mom, ref_losses = _steps(9, batch, t, z, n_steps, 1, 0, precision)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 9, batch, t, z, n_steps)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 9, batch, t, z, n_steps, precision)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
@@ -93,11 +98,13 @@ def test_two_rank_bucketed_step_equals_single_process_step():
     assert np.array_equal(f0, f1) and np.array_equal(res[0][2], res[1][2])    # ranks stay bit-identical
     # first moment = running mean of the (clipped, averaged) gradients: the direct check of the all-reduce
     m0, mr = res[0][2], ref_mom.numpy()
-    assert np.linalg.norm(m0 - mr) / np.linalg.norm(mr) < 1e-4
+    # (bf16: the GroupNorm backward sums of a 128-sample shard and of the 256-sample batch round differently -> looser bounds)
+    lo_prec = precision != "fp32"
+    assert np.linalg.norm(m0 - mr) / np.linalg.norm(mr) < (5e-3 if lo_prec else 1e-4)
     # Adam normalises the update (|delta| <= lr per step), so the parameters get an absolute bound well below lr = 2e-4
-    assert np.abs(f0 - ref.numpy()).max() < 2e-5
+    assert np.abs(f0 - ref.numpy()).max() < (1e-4 if lo_prec else 2e-5)
     mean_losses = [(a + b) / 2 for a, b in zip(res[0][3], res[1][3])]
-    assert np.allclose(mean_losses, ref_losses, rtol=2e-5)
+    assert np.allclose(mean_losses, ref_losses, rtol=(2e-3 if lo_prec else 2e-5))
 
 
 def _worker_rng(rank, world, port, q, x):
