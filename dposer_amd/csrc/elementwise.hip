@@ -826,24 +826,26 @@ hipError_t launch_reduce_grads(const ReduceJobs& jobs, const float* scratch, flo
 
 // Partial tiles of the batched weight-gradient launch (wgrad_batch.h) -> flat gradient.  Block (x, y): rows [16 x, 16 x + 16) of output
 // tile y = (problem, lane slot); the partition is re-derived from the same struct the GEMM kernel used; partials are added in row
-// order of the lane space (for a row-split W_t: first half, then second half) -- a fixed order.
+// order of the lane space (row-split tensors: first part, then the next) -- a fixed order.
 __global__ void __launch_bounds__(256) k_reduce_wgrad_tiles(WgradBatchArgs a, float* grad) {
     const int p = blockIdx.y >> 4, slot = blockIdx.y & 15;
     const WgradLaneProblem& pr = a.prob[p];
-    if (pr.split_k && slot >= 8) return;
-    const int half = slot >> 3, wl = slot & 7;
+    if ((pr.split_k && slot >= 8) || (pr.mode == 1 && slot >= 4)) return;
+    const int half = pr.mode == 1 ? 0 : slot >> 3;
+    const int cblk = pr.mode == 1 ? (slot & 1) : (slot & 3), sblk = pr.mode == 1 ? ((slot >> 1) & 1) : pr.sblk0[half] + ((slot & 7) >> 2);
+    const int reps = pr.mode == 1 ? 4 : (pr.split_k ? 2 : 1), rep_stride = pr.mode == 1 ? 4 : 8;
     int start = 0;
     for (int i = 0; i < p; ++i) start += a.prob[i].len;
     const int end = start + pr.len;
     const int l0 = start / a.q, l1 = (end - 1) / a.q;
-    const int64_t dst0 = pr.dst_off[half] + (int64_t)((wl & 3) * 256) * pr.ld[half] + (int64_t)(pr.sblk0[half] + (wl >> 2)) * 256;
+    const int64_t dst0 = pr.dst_off[half] + (int64_t)(cblk * 256) * pr.ld[half] + (int64_t)sblk * 256;
     const int ld = pr.ld[half];
     f32x4 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool first = true;
-    for (int rep = 0; rep < (pr.split_k ? 2 : 1); ++rep) {
-        const int sl = slot + 8 * rep;
+    for (int rep = 0; rep < reps; ++rep) {
+        const int sl = slot + rep_stride * rep;
         for (int l = l0; l <= l1; ++l) {
             // ordinal of this problem's segment among the segments of lane l
             const int lo = l * a.q, hi = lo + a.q;

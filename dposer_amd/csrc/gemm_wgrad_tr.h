@@ -244,7 +244,7 @@ template <int WC, int WS, int TC, int TS, int NB>
 __global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (WC * WS * 64)) gemm_wgrad_tr_batch_kernel(WgradBatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x;
-    const int lane_id = wgb_lane(b), slot = wgb_slot(b), half = slot >> 3, wl = slot & 7;
+    const int lane_id = wgb_lane(b), slot = wgb_slot(b);
     const int lo = lane_id * a.q, hi = lo + a.q;
     int start = 0, ord = 0;
     for (int p = 0; p < a.nprob; ++p) {
@@ -254,8 +254,11 @@ __global__ void __launch_bounds__(WC* WS * 64, (2 * 256 + WC * WS * 64 - 1) / (W
         if (s0 < s1) {
             WgradParams ep;
             ep.slab = a.partials + ((int64_t)(b * WGB_MAX_SEG + ord) << 16); ep.slab_stride = 0; ep.ld = 256; ep.N_valid = 256; ep.K_valid = 256;
-            wgrad_tr_tile<WC, WS, TC, TS, NB>(pr.dY[half], pr.H[half], pr.nA[half], pr.nB[half], wl & 3, pr.sblk0[half] + (wl >> 2),
-                                              s0 - start + pr.sb_off[half], s1 - s0, a.span, ep, 0, 0, 0, smem);
+            int half, cblk, sblk, sboff;
+            if (pr.mode == 1) { half = 0; cblk = slot & 1; sblk = (slot >> 1) & 1; sboff = (slot >> 2) * pr.len; }
+            else { half = slot >> 3; cblk = slot & 3; sblk = pr.sblk0[half] + ((slot & 7) >> 2); sboff = pr.sb_off[half]; }
+            wgrad_tr_tile<WC, WS, TC, TS, NB>(pr.dY[half], pr.H[half], pr.nA[half], pr.nB[half], cblk, sblk, s0 - start + sboff, s1 - s0, a.span, ep,
+                                              0, 0, 0, smem);
             ++ord;
             __syncthreads();                                       // the ring is reused by the next segment
         }

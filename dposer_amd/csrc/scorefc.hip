@@ -1054,27 +1054,41 @@ static bool plan_batched_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, 
         p.len = S / 2;
         p.split_k = 1;
     }
+    if (S % 4 == 0 && n < WGB_MAX_PROB) {                           // shared time embedding [E x E] = 2 x 2 tiles: four row quarters side by side
+        WgradLaneProblem& p = a.prob[n++];
+        p.dY[0] = w.dU; p.H[0] = w.emb; p.nA[0] = nE; p.nB[0] = nE; p.dst_off[0] = h->off_se_w; p.ld[0] = h->E;
+        p.len = S / 4;
+        p.mode = 1;
+    }
     if (n > WGB_MAX_PROB) return false;
-    a.nprob = n;
-    int64_t total = 0;
-    for (int i = 0; i < n; ++i) total += a.prob[i].len;
-    a.q = (int)ceil_div(total, WGB_LANES);
     a.partials = w.slabs + (w.slab_elems - need);
     a.span = ((int64_t)S * nAh) << 10;
     if (a.span >= (int64_t)0xfff00000) return false;
     // every lane: at most WGB_MAX_SEG segments (short ones take the kernel's generic prologue / tail path)
-    for (int lane = 0; lane < WGB_LANES; ++lane) {
-        const int64_t lo = (int64_t)lane * a.q, hi = lo + a.q;
-        int64_t start = 0;
-        int segs = 0;
-        for (int i = 0; i < n; ++i) {
-            const int64_t end = start + a.prob[i].len, s0 = lo > start ? lo : start, s1 = hi < end ? hi : end;
-            if (s0 < s1) ++segs;
-            start = end;
+    auto fits = [&](int np) {
+        int64_t total = 0;
+        for (int i = 0; i < np; ++i) total += a.prob[i].len;
+        a.nprob = np;
+        a.q = (int)ceil_div(total, WGB_LANES);
+        for (int lane = 0; lane < WGB_LANES; ++lane) {
+            const int64_t lo = (int64_t)lane * a.q, hi = lo + a.q;
+            int64_t start = 0;
+            int segs = 0;
+            for (int i = 0; i < np; ++i) {
+                const int64_t end = start + a.prob[i].len, s0 = lo > start ? lo : start, s1 = hi < end ? hi : end;
+                if (s0 < s1) ++segs;
+                start = end;
+            }
+            if (segs > WGB_MAX_SEG) return false;
         }
-        if (segs > WGB_MAX_SEG) return false;
+        return true;
+    };
+    if (fits(n)) return true;
+    if (a.prob[n - 1].mode == 1) {                                  // without the shared embedding (it keeps its own launch)
+        std::memset(&a.prob[n - 1], 0, sizeof(WgradLaneProblem));
+        return fits(n - 1);
     }
-    return true;
+    return false;
 }
 
 // backward from dres (FT [Bpad][Cp], zero on padded rows) to the flat parameter gradient and/or dx.
@@ -1197,11 +1211,13 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         DP_CHECK_HIP(hipStreamWaitEvent(sw, h->ev_time, 0));
     }
     DP_HIP_LAUNCH(launch_colsum(h->f32, w.dU, w.cs_part_se, Bpad, E, &n_chunks_se, sw));
-    if (tr) DP_TRY(run_wgrad(h, nullptr, E, E, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw, w.dU, w.emb));
+    const bool se_in_batch = batched && wb.prob[wb.nprob - 1].mode == 1;
+    if (se_in_batch) {}                                             // a lane problem of the one launch below
+    else if (tr) DP_TRY(run_wgrad(h, nullptr, E, E, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw, w.dU, w.emb));
     else DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw));
     if (batched) {
         if (slab_cursor > w.slab_elems - (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: slab buffer too small for the batched wgrad launch");
-        wb.alg_flops = 2.0 * (double)B * H * ((double)(L - 1) * H + (double)L * E);
+        wb.alg_flops = 2.0 * (double)B * H * ((double)(L - 1) * H + (double)L * E) + (se_in_batch ? 2.0 * (double)B * E * E : 0.0);
         DP_HIP_LAUNCH(gemm_wgrad_tr_batch(wb, st));
         DP_HIP_LAUNCH(launch_reduce_wgrad_tiles(wb, flat_grad, st));
     }

@@ -7,6 +7,7 @@
 //     W_x of a layer           : 4 x 4 tiles of dy_l^T h_{l-1}                                   len = S
 //     W_t of two layers        : 4 x 2 tiles of dy_a^T temb next to 4 x 2 tiles of dy_b^T temb   len = S
 //     W_t of a left-over layer : its 4 x 2 tiles twice, each half taking half of the rows        len = S / 2
+//     shared embedding W_se    : its 2 x 2 tiles four times, each copy a quarter of the rows     len = S / 4   (mode 1)
 // Lane i takes rows [i q, (i + 1) q) of that line (q = total / 16): at most WGB_MAX_SEG problems, one SEGMENT per problem, every
 // workgroup of the lane the same segment of its own tile; a segment's partial sums are one dense 256 x 256 fp32 tile in `partials`.
 // k_reduce_wgrad_tiles adds the partial tiles of each output tile in row order (fixed order: deterministic) into the flat gradient.
@@ -25,6 +26,7 @@ struct WgradLaneProblem {
     int ld[2];
     int len;              // sample-block rows
     int split_k;          // 1: both halves are row ranges of the SAME 8 tiles (dst_off[0], ld[0])
+    int mode;             // 0: two halves of 8 tiles (above);  1: 2 x 2 tiles x 4 row quarters of ONE tensor (index 0 of every field)
 };
 struct WgradBatchArgs {
     WgradLaneProblem prob[WGB_MAX_PROB];
