@@ -503,7 +503,9 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
                                                 lambda i, stream: _C.check(eng.lib.dposer_stream_wait_event(stream, events[i]),
                                                                            "dposer_stream_wait_event"))
             else:
-                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"])
+                # (DPOSER_FORCE_BUCKET_EVENTS=1: single-GPU A/B of the bucketed backward schedule -- the events are recorded, nobody waits)
+                events = model._engine().bucket_events() if os.environ.get("DPOSER_FORCE_BUCKET_EVENTS") == "1" else None
+                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"], bucket_events=events)
                 world = 1
             optimize_fn.warm_lr(optimizer, state["step"])                           # losses.py:51-53
             live = _live_params(model)

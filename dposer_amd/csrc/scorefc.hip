@@ -1018,17 +1018,17 @@ static int ensure_side_stream(dposer_scorefc_s* h) {
 // 1.195 -> 1.069 at 16384, 1.965 -> 1.755 at 32768, 3.41-3.45 -> 3.23 at 65536.
 // DPOSER_WGRAD_BATCHED = 0 forces it off, 1 also takes it when bucket events were asked for (they are then all recorded at the end).
 // Returns false when not applicable.
-static bool plan_batched_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, bool has_events, WgradBatchArgs& a) {
-    const char* e = getenv("DPOSER_WGRAD_BATCHED");
-    const int forced = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
-    if (forced == 0 || !tr || (has_events && forced != 1) || h->H != 1024 || h->E != 512 || h->L < 2 || h->L > 9) return false;
+// the lane problems of layers [l_first, l_last] (+ the shared time embedding): the whole step, or one layer of the bucketed backward
+static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first, int l_last, bool with_se, WgradBatchArgs& a) {
+    if (h->H != 1024 || h->E != 512 || h->L < 2 || h->L > 9) return false;
     const int64_t need = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536, small = (int64_t)14 << 20;
     if (w.slab_elems < need + small) return false;
-    const int S = (int)(w.Bpad / 32), L = h->L, nAh = h->H / 16, nE = h->E / 16;
+    const int S = (int)(w.Bpad / 32), nAh = h->H / 16, nE = h->E / 16;
+    const int L = l_last + 1;
     if (S % 2 != 0) return false;
     std::memset(&a, 0, sizeof(a));
     int n = 0;
-    for (int l = 1; l < L; ++l) {                                   // W_x of layers 1 .. L-1 (layer 0 has 63 input channels: its own small kernel)
+    for (int l = l_first > 1 ? l_first : 1; l < L; ++l) {           // W_x (layer 0 has 63 input channels: its own small kernel)
         if (h->layer[l].kin != h->H || h->layer[l].kin_pad != h->H) return false;
         WgradLaneProblem& p = a.prob[n++];
         for (int i = 0; i < 2; ++i) {
@@ -1037,7 +1037,9 @@ static bool plan_batched_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, 
         }
         p.len = S;
     }
-    for (int l = 0; l + 1 < L; l += 2) {                            // W_t of two layers side by side
+    int lt = l_first;
+    for (; lt + 1 < L; lt += 2) {                                   // W_t of two layers side by side
+        const int l = lt;
         WgradLaneProblem& p = a.prob[n++];
         for (int i = 0; i < 2; ++i) {
             p.dY[i] = w.dy[l + i]; p.H[i] = w.temb; p.nA[i] = nAh; p.nB[i] = nE; p.sblk0[i] = 0; p.sb_off[i] = 0;
@@ -1045,7 +1047,7 @@ static bool plan_batched_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, 
         }
         p.len = S;
     }
-    if (L % 2) {                                                    // the left-over W_t: its rows in two halves
+    if (lt < L) {                                                   // the left-over W_t: its rows in two halves
         WgradLaneProblem& p = a.prob[n++];
         for (int i = 0; i < 2; ++i) {
             p.dY[i] = w.dy[L - 1]; p.H[i] = w.temb; p.nA[i] = nAh; p.nB[i] = nE; p.sblk0[i] = 0; p.sb_off[i] = i * (S / 2);
@@ -1054,7 +1056,7 @@ static bool plan_batched_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, 
         p.len = S / 2;
         p.split_k = 1;
     }
-    if (S % 4 == 0 && n < WGB_MAX_PROB) {                           // shared time embedding [E x E] = 2 x 2 tiles: four row quarters side by side
+    if (with_se && S % 4 == 0 && n < WGB_MAX_PROB) {                           // shared time embedding [E x E] = 2 x 2 tiles: four row quarters side by side
         WgradLaneProblem& p = a.prob[n++];
         p.dY[0] = w.dU; p.H[0] = w.emb; p.nA[0] = nE; p.nB[0] = nE; p.dst_off[0] = h->off_se_w; p.ld[0] = h->E;
         p.len = S / 4;
@@ -1089,6 +1091,25 @@ static bool plan_batched_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, 
         return fits(n - 1);
     }
     return false;
+}
+static bool plan_batched_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, bool has_events, WgradBatchArgs& a) {
+    const char* e = getenv("DPOSER_WGRAD_BATCHED");
+    const int forced = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
+    if (forced == 0 || !tr || (has_events && forced != 1)) return false;
+    return plan_wgrad_lanes(h, w, 0, h->L - 1, true, a);
+}
+// The bucketed backward (data parallel: layer j's gradient must be final before the layers in front of it are differentiated) keeps one
+// weight-gradient launch per LAYER, but as lanes too: W_x of the layer and its W_t in two row halves are one line of 1.5 S rows over the
+// 16 lanes -- 256 workgroups of equal length instead of two split-K launches with 128 / 64-stage workgroups.
+// Measured on one GPU with the bucket events recorded (DPOSER_FORCE_BUCKET_EVENTS=1): 3.41 -> 3.37 ms at 65536 samples, 1.182 -> 1.164 at
+// 16384 -- each output tile now has ~11 partial tiles to add, so most of the one-launch form's gain stays out of reach.  Default from
+// 16384 samples; DPOSER_WGRAD_LAYER_LANES=0 keeps the two split-K launches (as does DPOSER_WGRAD_BATCHED=0), =1 forces the lanes.
+static bool plan_layer_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, int j, WgradBatchArgs& a) {
+    const char* e = getenv("DPOSER_WGRAD_BATCHED");
+    const char* e2 = getenv("DPOSER_WGRAD_LAYER_LANES");
+    if ((e && e[0] == '0') || (e2 && e2[0] == '0') || !tr) return false;
+    if (!(e2 && e2[0] == '1') && w.Bpad < 16384) return false;     // (8192 samples: 0.854 vs 0.841 ms -- the second stream of the split-K form wins)
+    return plan_wgrad_lanes(h, w, j, j, false, a);
 }
 
 // backward from dres (FT [Bpad][Cp], zero on padded rows) to the flat parameter gradient and/or dx.
@@ -1169,6 +1190,12 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         const LayerOff& lo = h->layer[j];
         if (batched) {       // W_x (j >= 1) and W_t of every layer are tiles of the one launch behind the loop
             if (j == 0) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], (const void*)w.xin));
+        } else if (plan_layer_wgrad(h, w, tr, j, wb)) {       // one lane launch for this layer's W_x and W_t, then its partial tiles
+            if (j == 0) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], (const void*)w.xin));
+            if (slab_cursor > w.slab_elems - (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: slab buffer too small for the lane launch");
+            wb.alg_flops = 2.0 * (double)B * H * ((j >= 1 ? (double)H : 0.0) + (double)E);
+            DP_HIP_LAUNCH(gemm_wgrad_tr_batch(wb, sw));
+            DP_HIP_LAUNCH(launch_reduce_wgrad_tiles(wb, flat_grad, sw));
         } else {
         if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], j == 0 ? (const void*)w.xin : (const void*)w.hbuf[j - 1]));
         else DP_TRY(run_wgrad(h, w.dyT[j], H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw));

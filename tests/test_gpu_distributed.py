@@ -70,13 +70,15 @@ def _worker(rank, world, port, q, model_seed, batch, t, z, n_steps, precision="f
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("precision,batched", [("fp32", None), ("bf16", "0"), ("bf16", "1")])
+@pytest.mark.parametrize("precision,batched", [("fp32", None), ("bf16", "0"), ("bf16", "1"), ("bf16", "layer-lanes")])
 def test_two_rank_bucketed_step_equals_single_process_step(precision, batched, monkeypatch):
     """Mean-reduced DSM loss over equal shards: the averaged shard gradients are the full-batch gradient, so two ranks
     (bucketed all-reduce overlapped with the backward pass) must track the single-process run on the whole batch.
-    bf16: with the per-layer weight-gradient launches the buckets need (default under data parallelism) and with the one-launch
-    form forced (DPOSER_WGRAD_BATCHED=1: every bucket event is recorded after the last reduction)."""
-    if batched is not None:
+    bf16: with two split-K weight-gradient launches per layer (DPOSER_WGRAD_BATCHED=0), with the one-launch form forced (=1: every
+    bucket event is recorded after the last reduction) and with one lane launch per layer (the default under data parallelism from 16384 samples per rank)."""
+    if batched == "layer-lanes":
+        monkeypatch.setenv("DPOSER_WGRAD_LAYER_LANES", "1")          # (default from 16384 samples per rank; forced for this small batch)
+    elif batched is not None:
         monkeypatch.setenv("DPOSER_WGRAD_BATCHED", batched)          # (spawned ranks inherit the environment)
     rs = np.random.RandomState(5)
     n_steps, B = 3, 256
