@@ -1239,9 +1239,10 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     }
     DP_HIP_LAUNCH(launch_colsum(h->f32, w.dU, w.cs_part_se, Bpad, E, &n_chunks_se, sw));
     const bool se_in_batch = batched && wb.prob[wb.nprob - 1].mode == 1;
-    if (se_in_batch) {}                                             // a lane problem of the one launch below
-    else if (tr) DP_TRY(run_wgrad(h, nullptr, E, E, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw, w.dU, w.emb));
-    else DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw));
+    if (!se_in_batch) {                                             // (otherwise: a lane problem of the one launch below)
+        if (tr) DP_TRY(run_wgrad(h, nullptr, E, E, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw, w.dU, w.emb));
+        else DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw));
+    }
     if (batched) {
         if (slab_cursor > w.slab_elems - (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: slab buffer too small for the batched wgrad launch");
         wb.alg_flops = 2.0 * (double)B * H * ((double)(L - 1) * H + (double)L * E) + (se_in_batch ? 2.0 * (double)B * E * E : 0.0);
