@@ -182,6 +182,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the sampler / FK measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--no-live-roofline", action="store_true",
+                    help="no HIP events around the dominant GEMM kind inside the timed region (A/B timing of small batches)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -245,7 +247,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         # ... and only in every 4th step: the two event records per launch keep dependent kernels ~10 us apart
-        if i % 4 == 0:
+        if args.no_live_roofline:
+            pass
+        elif i % 4 == 0:
             _C.profile_enable(True, only=DOMINANT_KIND)
         elif i % 4 == 1:
             _C.profile_pause()

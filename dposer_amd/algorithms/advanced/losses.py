@@ -404,6 +404,61 @@ def _rot6d_to_axis_angle_autograd(rot6d):
     return skew * scale[:, None]
 
 
+_RANK_GENERATORS = {}
+
+
+def _dp_draws(sde, batch, eps=1e-5):
+    """Data-parallel runs of the autograd steps (auxiliary loss, generic fallback): t and z of losses.py:110-111 from a generator
+    keyed per RANK -- identically seeded ranks must not perturb sample i of every shard with the same (t, z) (the fused step
+    keys its Philox streams the same way)."""
+    from ... import distributed as ddp
+    key = (batch.device.type, batch.device.index, ddp.rank())
+    gen = _RANK_GENERATORS.get(key)
+    if gen is None:
+        gen = torch.Generator(device=batch.device)
+        gen.manual_seed((torch.initial_seed() + 0x9E3779B1 * (ddp.rank() + 1)) & 0x7FFFFFFFFFFFFFFF)
+        _RANK_GENERATORS[key] = gen
+    t = torch.rand(batch.shape[0], device=batch.device, generator=gen) * (sde.T - eps) + eps
+    z = torch.randn(batch.shape, device=batch.device, dtype=batch.dtype, generator=gen)
+    return t, z
+
+
+@torch.no_grad()
+def _dp_average_grads(params):
+    """All-reduce (mean) of the ``.grad`` tensors of an autograd step under data parallelism: ONE collective over a flat copy
+    (the reference runs these steps under nn.DataParallel, whose gradient covers the global batch).  Every rank must hold a
+    gradient for the same parameters."""
+    from ... import distributed as ddp
+    live = [p for p in params if p.grad is not None]
+    if not live:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in live])
+    world = ddp.all_reduce_sum_(flat)
+    flat.mul_(1.0 / world)
+    o = 0
+    for p in live:
+        n = p.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p.grad))
+        o += n
+
+
+def _dp_model_seed(model):
+    """(context) dropout of the differentiable HIP forward keyed per rank for the duration of an autograd step."""
+    from ... import distributed as ddp
+
+    class _Ctx:
+        def __enter__(self_):
+            self_.keep = getattr(model, "_rng_seed", None)
+            if self_.keep is not None and ddp.dp_active():
+                model._rng_seed = (self_.keep + 0x9E3779B1 * ddp.rank()) & 0xFFFFFFFFFFFFFFFF
+
+        def __exit__(self_, *exc):
+            if self_.keep is not None:
+                model._rng_seed = self_.keep
+            return False
+    return _Ctx()
+
+
 def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True, likelihood_weighting=False,
                 auxiliary_loss=False, denormalize=None, body_model=None, rot_rep="rot6d", denoise_steps=5):
     """One-step training / evaluation function (losses.py:187-275).
@@ -430,9 +485,15 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
         """losses.py:242-258: DSM term + SNR-weighted vertex / joint errors between the body posed by the multi-step estimate
         and by the batch.  Score network and body model both run their HIP forward / backward through autograd: this is the one
         training step where the two meet (the reference calls the body model 'the bottleneck of training', :252)."""
+        from ... import distributed as ddp
         model, optimizer = state["model"], state["optimizer"]
         optimizer.zero_grad()
-        score_loss, data = loss_fn(model, batch, condition, mask, t=t, z=z)
+        dp = ddp.dp_active()
+        if dp and (t is None or z is None):
+            t_r, z_r = _dp_draws(sde, batch)
+            t, z = (t_r if t is None else t), (z_r if z is None else z)
+        with _dp_model_seed(model):
+            score_loss, data = loss_fn(model, batch, condition, mask, t=t, z=z)
         weight = torch.log(1.0 + data["SNR"])                                          # [b, 1]
         estimate, target = denormalize(data["clean_sample"]), denormalize(batch)
         if rot_rep == "rot6d":
@@ -445,6 +506,8 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
         loss_j2j = torch.mean(weight * torch.square(gt_body.Jtr - pred_body.Jtr).sum(dim=-1))
         loss = score_loss + loss_v2v + loss_j2j
         loss.backward()
+        if dp:                                                                     # gradient of the GLOBAL batch, then clip + step
+            _dp_average_grads(list(model.parameters()))
         optimize_fn(optimizer, model.parameters(), step=state["step"])
         state["step"] += 1
         state["ema"].update(model.parameters())
@@ -512,9 +575,24 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
             optimizer.fused_step(live=live, grad_clip=optimize_fn.grad_clip, grad_scale=1.0 / world, ema=state["ema"])
             state["step"] += 1
             return {"step_loss": loss, "score_loss": loss}
+        from ... import distributed as ddp
         optimizer.zero_grad()
-        loss = loss_fn(model, batch, condition, mask)
+        dp = ddp.dp_active()
+        if dp and not continuous:
+            # (SMLD / DDPM draw labels and noise inside their loss functions from the global generator: identically seeded ranks
+            #  would train on perfectly correlated perturbations)
+            raise NotImplementedError("data-parallel training of the legacy SMLD / DDPM losses is not supported: use continuous=True")
+        with _dp_model_seed(model):
+            if dp:
+                t_r, z_r = _dp_draws(sde, batch)
+                loss = loss_fn(model, batch, condition, mask, t=t_r if t is None else t, z=z_r if z is None else z)
+            elif continuous and (t is not None or z is not None):
+                loss = loss_fn(model, batch, condition, mask, t=t, z=z)
+            else:
+                loss = loss_fn(model, batch, condition, mask)
         loss.backward()
+        if dp:
+            _dp_average_grads(list(model.parameters()))
         optimize_fn(optimizer, model.parameters(), step=state["step"])
         state["step"] += 1
         state["ema"].update(model.parameters())

@@ -802,9 +802,20 @@ __global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const flo
         const int64_t n4 = j.count >> 2;
         for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
             const f32x4* p = reinterpret_cast<const f32x4*>(scratch + j.src_off) + e;
+            const int64_t st4 = j.src_stride >> 2;
             f32x4 acc = p[0];
-            for (int k = 1; k < j.nsrc; ++k) {
-                const f32x4 v = p[(int64_t)k * (j.src_stride >> 2)];
+            // eight slab loads in flight, added in slab order (the plain loop was a chain of nsrc dependent L2 / HBM round
+            // trips: 23 us per launch at 1280 samples, where the slabs hold 2 MB)
+            int k = 1;
+            for (; k + 8 <= j.nsrc; k += 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u) * st4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
+            }
+            for (; k < j.nsrc; ++k) {
+                const f32x4 v = p[(int64_t)k * st4];
                 acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
             }
             reinterpret_cast<f32x4*>(grad + j.dst_off)[e] = acc;

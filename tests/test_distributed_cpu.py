@@ -107,3 +107,41 @@ def test_reduce_scatter_and_all_gather_of_flat_ranges():
         assert p.exitcode == 0
     assert all(r[1] and r[2] for r in res)
     assert res[0][3] == [(0, 504), (504, 1003)]                     # 16-byte aligned shard starts, the last rank takes the rest
+
+
+def _worker_autograd_dp(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from dposer_amd import distributed as ddp
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    ddp.init_from_env(backend="gloo")
+    torch.manual_seed(0)                                     # identically seeded ranks
+    w = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4))]
+    w[0].grad = torch.full((5,), float(rank + 1))
+    w[1].grad = torch.arange(6.0).reshape(2, 3) * (rank + 1)
+    losses._dp_average_grads(w)                              # w[2] has no gradient on either rank
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    t, z = losses._dp_draws(sde, torch.zeros(16, 63))
+    out.put((rank, w[0].grad.tolist(), w[1].grad.tolist(), w[2].grad is None, t.tolist(), float(z.abs().sum())))
+    ddp.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_autograd_step_helpers():
+    """The data-parallel pieces of the non-fused training steps (losses.aux_step / generic fallback): mean all-reduce of ``p.grad``
+    and per-rank (t, z) draws although both ranks seeded torch identically."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_autograd_dp, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == [1.5] * 5
+    assert res[0][2] == res[1][2] == (np.arange(6.0).reshape(2, 3) * 1.5).tolist()
+    assert res[0][3] and res[1][3]
+    assert res[0][4] != res[1][4] and all(1e-5 <= v <= 1.0 for v in res[0][4] + res[1][4])
+    assert res[0][5] != res[1][5]

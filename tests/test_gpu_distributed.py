@@ -33,8 +33,9 @@ def test_grad_buckets_partition_the_flat_buffer():
     assert b[3][0] == off["b1_dense1.weight"] == b[4][1]
 
 
-def _steps(model_seed, batch, t, z, n_steps, world, rank, precision):
-    """n_steps optimisation steps on this rank's shard with injected draws; returns the flat parameters."""
+def _steps(model_seed, batch, t, z, n_steps, world, rank, precision, likelihood_weighting=False):
+    """n_steps optimisation steps on this rank's shard with injected draws; returns the flat parameters.
+    ``likelihood_weighting`` takes the step off the fused path: loss.backward() through autograd, gradients in ``p.grad``."""
     from gpu_common import make_model
     from dposer_amd.algorithms.advanced import losses, sde_lib
     from dposer_amd.algorithms.ema import ExponentialMovingAverage
@@ -44,7 +45,8 @@ def _steps(model_seed, batch, t, z, n_steps, world, rank, precision):
     sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
     opt = losses.get_optimizer(cfg, m.parameters())
     ema = ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate)
-    step_fn = losses.get_step_fn(sde, True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+    step_fn = losses.get_step_fn(sde, True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True,
+                                 likelihood_weighting=likelihood_weighting)
     state = dict(model=m, optimizer=opt, ema=ema, step=0)
     lo, hi = ddp.shard_bounds(batch.shape[1], world, rank)
     out = []
@@ -55,7 +57,7 @@ def _steps(model_seed, batch, t, z, n_steps, world, rank, precision):
     return m.flat_params().detach().cpu().clone(), opt._flat_m.detach().cpu().clone(), out
 
 
-def _worker(rank, world, port, q, model_seed, batch, t, z, n_steps, precision="fp32"):
+def _worker(rank, world, port, q, model_seed, batch, t, z, n_steps, precision="fp32", likelihood_weighting=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       DPOSER_DIST_BACKEND="gloo")
     import sys
@@ -64,7 +66,7 @@ def _worker(rank, world, port, q, model_seed, batch, t, z, n_steps, precision="f
     import torch.distributed as dist
     ddp.init_from_env()
     torch.cuda.set_device(0)
-    flat, mom, losses_ = _steps(model_seed, batch, t, z, n_steps, world, rank, precision)
+    flat, mom, losses_ = _steps(model_seed, batch, t, z, n_steps, world, rank, precision, likelihood_weighting)
     q.put((rank, flat.numpy(), mom.numpy(), losses_))
     ddp.barrier()
     dist.destroy_process_group()
@@ -461,3 +463,31 @@ def test_zero1_checkpoint_gathers_the_moments_and_resumes():
         assert np.array_equal(cont, resumed)                                           # restored run == uninterrupted run, bit for bit
         assert np.linalg.norm(mom - ref_mom.numpy()) / np.linalg.norm(ref_mom.numpy()) < 1e-4   # gathered moments = replicated moments
     assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_two_rank_autograd_step_averages_the_gradient():
+    """The steps that are NOT the fused pipeline (likelihood weighting here; the auxiliary-loss step shares the code) run
+    loss.backward() through autograd.  Under data parallelism their ``p.grad`` must be all-reduced (mean) before clip + Adam --
+    the reference runs them under nn.DataParallel, whose gradient covers the global batch -- so two ranks on half batches track the
+    single-process step on the whole batch and stay bit-identical to each other (they used to update unsynchronised replicas)."""
+    rs = np.random.RandomState(6)
+    n_steps, B = 2, 128
+    batch = torch.tensor(rs.standard_normal((n_steps, B, 63)).astype(np.float32))
+    t = torch.tensor(rs.uniform(0.05, 1.0, (n_steps, B)).astype(np.float32))
+    z = torch.tensor(rs.standard_normal((n_steps, B, 63)).astype(np.float32))
+    ref, ref_mom, ref_losses = _steps(9, batch, t, z, n_steps, 1, 0, "fp32", True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 9, batch, t, z, n_steps, "fp32", True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    f0, f1 = res[0][1], res[1][1]
+    assert np.array_equal(f0, f1)                                            # replicas stay in step
+    rel = np.linalg.norm(f0 - ref.numpy()) / np.linalg.norm(ref.numpy())
+    assert rel < 2e-5, rel                                                    # == the whole-batch step (measured 1e-7)
+    assert abs(0.5 * (res[0][3][0] + res[1][3][0]) - ref_losses[0]) < 2e-5 * abs(ref_losses[0])

@@ -199,24 +199,44 @@ def mfma(paths, as_json=False):
               f"{r['insts_valu']:.4g} | {f(r['issue_stall_frac'])} | {f(r['parked_frac'])} | {f(r['active_frac'])} |")
 
 
-if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] in ("--mfma", "--mfma-json"):
-    mfma(sys.argv[2:], as_json=sys.argv[1] == "--mfma-json")
-    sys.exit(0)
-if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--sequence":
-    if len(sys.argv) > 3:      # --sequence db anchor [which]: e.g. EpiEmStep 500 -> one sampler step
-        sequence(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 3, f"from one `{sys.argv[3]}` to the next")
+USAGE = """usage: rocpd_summary.py <kernel-trace.db>                      per-kernel table (calls, total, avg, min, max)
+       rocpd_summary.py --gaps <db>                            idle time in front of each kernel kind
+       rocpd_summary.py --sequence <db> [anchor [which]]       kernels of one step in start order
+       rocpd_summary.py --pmc | --pmc-json <db> ...            FETCH_SIZE / WRITE_SIZE passes -> HBM bytes per launch
+       rocpd_summary.py --counters <db> ...                    per-kernel average of every counter
+       rocpd_summary.py --mfma | --mfma-json <db> ...          matrix-pipe busy fraction, effective clock, stalls"""
+
+
+def cli(argv):
+    if len(argv) < 2 or argv[1] in ("-h", "--help"):
+        print(USAGE)
+        return 0 if len(argv) >= 2 else 2
+    mode, rest = argv[1], argv[2:]
+    if mode.startswith("--") and not rest:
+        print(USAGE, file=sys.stderr)
+        return 2
+    if mode in ("--mfma", "--mfma-json"):
+        mfma(rest, as_json=mode == "--mfma-json")
+    elif mode == "--sequence":
+        if len(rest) > 1:      # --sequence db anchor [which]: e.g. EpiEmStep 500 -> one sampler step
+            sequence(rest[0], rest[1], int(rest[2]) if len(rest) > 2 else 3, f"from one `{rest[1]}` to the next")
+        else:
+            sequence(rest[0])
+    elif mode == "--gaps":
+        gaps(rest[0])
+    elif mode == "--pmc":
+        pmc(rest)
+    elif mode == "--pmc-json":
+        pmc_json(rest)
+    elif mode == "--counters":
+        counters(rest)
+    elif mode.startswith("--"):
+        print(USAGE, file=sys.stderr)
+        return 2
     else:
-        sequence(sys.argv[2])
-    sys.exit(0)
-if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--gaps":
-    gaps(sys.argv[2])
-    sys.exit(0)
+        main(mode)
+    return 0
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "--pmc":
-        pmc(sys.argv[2:])
-    elif sys.argv[1] == "--pmc-json":
-        pmc_json(sys.argv[2:])
-    elif sys.argv[1] == "--counters":
-        counters(sys.argv[2:])
-    else:
-        main(sys.argv[1])
+    sys.exit(cli(sys.argv))
