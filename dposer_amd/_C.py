@@ -56,6 +56,8 @@ class DPoserHipError(RuntimeError):
 
 _lib = None
 vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
+# dposer_ranges_final_fn(user, first_bucket, n_ranges, lo, hi, event): called from inside dposer_dsm_loss_fwd_bwd_notify
+RANGES_FINAL_FN = C.CFUNCTYPE(None, vp, i32, i32, C.POINTER(i64), C.POINTER(i64), vp)
 
 # name -> (restype, argtypes); every symbol include/dposer_hip.h declares
 SIGNATURES = {
@@ -92,6 +94,8 @@ SIGNATURES = {
                                           vp, vp, i64, vp]),
     "dposer_dsm_loss_fwd_bwd_bucketed": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, f32, u64, u32, vp, vp,
                                                    vp, vp, i64, C.POINTER(vp), i32, vp]),
+    "dposer_dsm_loss_fwd_bwd_notify": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, f32, u64, u32, vp, vp,
+                                                 vp, vp, i64, C.POINTER(vp), i32, RANGES_FINAL_FN, vp, vp]),
     "dposer_scorefc_grad_buckets": (i32, [vp, C.POINTER(i64), C.POINTER(i64), i32]),
     "dposer_event_create": (C.c_int, [C.POINTER(vp)]),
     "dposer_event_destroy": (None, [vp]),
@@ -132,6 +136,7 @@ SIGNATURES = {
     "dposer_lbs_backward_workspace_bytes": (i64, [vp, i64]),
     "dposer_lbs_prepare_joint_lists": (C.c_int, [vp, vp, vp, vp, vp]),
     "dposer_body_tuning_reload": (None, []),
+    "dposer_scorefc_tuning_reload": (None, []),
     "dposer_lbs_backward": (C.c_int, [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp,
                                       vp, vp, i64, C.POINTER(vp), vp, vp, i64, vp]),
 }

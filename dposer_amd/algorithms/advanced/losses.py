@@ -357,9 +357,11 @@ def fused_dsm_supported(sde, model, continuous, reduce_mean, likelihood_weightin
             and isinstance(model, ScoreModelFC) and model.time_embedding_type == "positional")
 
 
-def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, seed=0, step=0, bucket_events=None):
-    """dposer_dsm_loss_fwd_bwd[_bucketed]: loss (device scalar) and d loss/d params into ``flat_grad``.
-    ``bucket_events`` (ScoreEngine.bucket_events()) are recorded as each gradient bucket becomes final."""
+def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, seed=0, step=0, bucket_events=None, on_final=None):
+    """dposer_dsm_loss_fwd_bwd[_bucketed | _notify]: loss (device scalar) and d loss/d params into ``flat_grad``.
+    ``bucket_events`` (ScoreEngine.bucket_events()) are recorded as each gradient bucket becomes final; with ``on_final(ranges,
+    event)`` the call itself announces every group of final buckets (one event + merged flat ranges) while it is still queueing
+    the rest of the backward pass (distributed.StreamedAllReduce)."""
     _C.require_gpu(batch, "training batch")
     eng = model._engine()
     flat = model.flat_params()
@@ -369,6 +371,15 @@ def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, se
     loss = torch.empty(1, dtype=torch.float32, device=batch.device)
     desc = sde_desc(sde)
     x = batch.contiguous().float()
+    if on_final is not None:
+        def _cb(user, first_bucket, n_ranges, lo, hi, event):
+            on_final([(lo[i], hi[i]) for i in range(n_ranges)], event)
+        cb = _C.RANGES_FINAL_FN(_cb)                  # (kept alive until the call has returned)
+        _C.check(eng.lib.dposer_dsm_loss_fwd_bwd_notify(
+            eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(t), _C.ptr(z), float(eps), int(seed),
+            int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(batch.device)), _C.ptr(model.sigmas), _C.ptr(flat_grad), _C.ptr(loss), B,
+            bucket_events, len(bucket_events), cb, None, _C.stream_ptr()), "dposer_dsm_loss_fwd_bwd_notify")
+        return loss[0]
     _C.check(eng.lib.dposer_dsm_loss_fwd_bwd_bucketed(
         eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(t), _C.ptr(z), float(eps), int(seed),
         int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(batch.device)), _C.ptr(model.sigmas), _C.ptr(flat_grad), _C.ptr(loss), B,
@@ -560,11 +571,19 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
                 # front of it are still being differentiated
                 eng = model._engine()
                 events = eng.bucket_events()
-                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"],
-                                      bucket_events=events)
-                world = ddp.all_reduce_buckets_(flat_grad, eng.grad_buckets,
-                                                lambda i, stream: _C.check(eng.lib.dposer_stream_wait_event(stream, events[i]),
-                                                                           "dposer_stream_wait_event"))
+                if os.environ.get("DPOSER_DP_NOTIFY", "1") != "0":
+                    # the backward pass announces final bucket groups from inside the call: collectives are issued at once
+                    red = ddp.StreamedAllReduce(flat_grad, lambda stream, ev: _C.check(eng.lib.dposer_stream_wait_event(stream, ev),
+                                                                                       "dposer_stream_wait_event"))
+                    loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"],
+                                          bucket_events=events, on_final=red.on_final)
+                    world = red.finish()
+                else:                                                               # (A/B: all waits + collectives after the call)
+                    loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"],
+                                          bucket_events=events)
+                    world = ddp.all_reduce_buckets_(flat_grad, eng.grad_buckets,
+                                                    lambda i, stream: _C.check(eng.lib.dposer_stream_wait_event(stream, events[i]),
+                                                                               "dposer_stream_wait_event"))
             else:
                 # (DPOSER_FORCE_BUCKET_EVENTS=1: single-GPU A/B of the bucketed backward schedule -- the events are recorded, nobody waits)
                 events = model._engine().bucket_events() if os.environ.get("DPOSER_FORCE_BUCKET_EVENTS") == "1" else None

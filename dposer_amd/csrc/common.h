@@ -200,11 +200,14 @@ template <> struct TileIO<__bf16> {
 // Issued from asm the DMA is invisible to that pass; the caller then owns the ordering: a counted s_waitcnt vmcnt(N) before
 // the ds_reads of the landed data (VMEM operations of one wave retire in issue order on gfx9-family parts, stores included),
 // and an lgkmcnt(0) between the last ds_read of a buffer and the DMA that refills it.
+// M0: the statement writes it and reads it itself.  hipcc reserves M0 and does NOT honour an "m0" clobber (it only warns), so none
+// is listed; what keeps this safe is that every compiler-issued M0 reader re-materialises M0 first -- audited on the emitted ISA of
+// every kernel by tools/check_isa.py (CPU test test_emitted_isa_passes_the_asm_audits).
 __device__ __forceinline__ void glds_asm_b128(const void* src_lane, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds_base) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds_base) : "memory");
 }
 __device__ __forceinline__ void glds_asm_b32(const void* src_lane, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src_lane), "s"(lds_base) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src_lane), "s"(lds_base) : "memory");
 }
 // s_waitcnt vmcnt(n) for an n that folds to a constant after unrolling (the builtin wants a literal)
 __device__ __forceinline__ void wait_vmcnt_n(int n) {

@@ -40,6 +40,20 @@ __device__ __forceinline__ float temb_value(float label, int e, int E, const flo
 // ------------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------------
+// The jobs of a multi-job launch sit at the front of the kernel-argument segment; a wave-uniform index into that segment is a scalar
+// load with a dynamic offset.  (Indexing the by-value argument struct itself makes hipcc copy it to scratch, and the select chain the
+// first version used instead -- `if (i == blockIdx.y) j = jobs.job[i]` over all 40-48 entries -- cost every block ~2 KB of scalar
+// loads: k_reduce_grads took 20 us at ANY batch size for ~13000 mostly idle blocks.)
+template <typename Job> __device__ __forceinline__ Job kernarg_job(int index) {
+    static_assert(sizeof(Job) % 4 == 0, "jobs are copied as dwords");
+    typedef const uint32_t __attribute__((address_space(4))) * ConstWords;                      // constant address space: s_load
+    ConstWords w = (ConstWords)__builtin_amdgcn_kernarg_segment_ptr() + (size_t)index * (sizeof(Job) / 4);   // (argument 0 starts the segment)
+    union { Job j; uint32_t u[sizeof(Job) / 4]; } c;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(Job) / 4; ++i) c.u[i] = w[i];
+    return c.j;
+}
+
 template <typename T> __device__ __forceinline__ void pack_chunk(const PackJob& j, const float* flat, unsigned char* packed, int64_t chunk) {
     constexpr int EPL = FT<T>::EPL, KBS = FT<T>::KBS;
     const int kblocks = j.kpad / KBS;
@@ -63,10 +77,8 @@ template <typename T> __device__ __forceinline__ void pack_chunk(const PackJob& 
     *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<u32x4*>(vals);
 }
 __global__ void __launch_bounds__(256) k_pack(PackJobs jobs, const float* flat, unsigned char* packed) {
-    // select the job without dynamically indexing the kernel-argument array
-    PackJob j = jobs.job[0];
-    for (int i = 1; i < MAX_PACK_JOBS; ++i)
-        if (i == (int)blockIdx.y) j = jobs.job[i];
+    (void)jobs;
+    const PackJob j = kernarg_job<PackJob>((int)blockIdx.y);
     const int epl = j.f32 ? 4 : 8;
     const int64_t nchunks = (int64_t)j.rows_pad * j.kpad / epl;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * blockDim.x) {
@@ -712,7 +724,16 @@ hipError_t launch_ft_transpose(int f32, const void* in, void* out, int64_t Spad,
 }
 
 constexpr int COLSUM_CHUNK = 2048;   // samples per partial row
-template <typename T> __global__ void __launch_bounds__(256) k_colsum(const T* in, float* part, int64_t Spad, int C) {
+template <typename T> __global__ void __launch_bounds__(256) k_colsum(const T* in, float* part, int64_t Spad, int C, SumJob sj) {
+    if (blockIdx.y == gridDim.y - 1 && sj.n > 0) {      // rider: out[0] = sum(part[0..n)) -- k_sum_partials' order, one launch less
+        if (blockIdx.x == 0) {
+            float acc = 0.f;
+            for (int i = threadIdx.x; i < sj.n; i += 256) acc += sj.part[i];
+            const float tot = block_sum_256(acc);
+            if (threadIdx.x == 0) sj.out[0] = tot;
+        }
+        return;
+    }
     // block = (channel quad group of 8 quads, sample chunk): thread (sl = tid&31, cq = tid>>5)
     const int c = (blockIdx.x * 8 + (threadIdx.x >> 5)) * 4;
     const int64_t s_begin = (int64_t)blockIdx.y * COLSUM_CHUNK;
@@ -746,12 +767,14 @@ template <typename T> __global__ void __launch_bounds__(256) k_colsum(const T* i
         for (int r = 0; r < 4; ++r) part[(int64_t)blockIdx.y * C + c + r] = acc[r];
     }
 }
-hipError_t launch_colsum(int f32, const void* in, float* part, int64_t Spad, int C, int* nchunks, hipStream_t st) {
+hipError_t launch_colsum(int f32, const void* in, float* part, int64_t Spad, int C, int* nchunks, hipStream_t st, const SumJob* rider) {
     const int nc = (int)ceil_div(Spad, COLSUM_CHUNK);
     *nchunks = nc;
-    dim3 grid((unsigned)ceil_div(C / 4, 8), (unsigned)nc);
-    if (f32) hipLaunchKernelGGL(k_colsum<float>, grid, dim3(256), 0, st, (const float*)in, part, Spad, C);
-    else hipLaunchKernelGGL(k_colsum<__bf16>, grid, dim3(256), 0, st, (const __bf16*)in, part, Spad, C);
+    SumJob sj{nullptr, 0, nullptr};
+    if (rider && rider->n > 0) sj = *rider;
+    dim3 grid((unsigned)ceil_div(C / 4, 8), (unsigned)(nc + (sj.n > 0 ? 1 : 0)));
+    if (f32) hipLaunchKernelGGL(k_colsum<float>, grid, dim3(256), 0, st, (const float*)in, part, Spad, C, sj);
+    else hipLaunchKernelGGL(k_colsum<__bf16>, grid, dim3(256), 0, st, (const __bf16*)in, part, Spad, C, sj);
     return hipGetLastError();
 }
 
@@ -760,9 +783,17 @@ hipError_t launch_colsum(int f32, const void* in, float* part, int64_t Spad, int
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const float* scratch, float* grad) {
     __shared__ float red[8][32];
-    ReduceJob j = jobs.job[0];
-    for (int i = 1; i < MAX_REDUCE_JOBS; ++i)
-        if (i == (int)blockIdx.y) j = jobs.job[i];
+    (void)jobs;
+    const ReduceJob j = kernarg_job<ReduceJob>((int)blockIdx.y);
+    if (j.nsrc == 0) {      // a range that never gets a gradient (dead parameters): zeros -- was a memset launch of its own
+        const bool al = ((j.dst_off | j.count) & 3) == 0;
+        const int64_t n4 = al ? (j.count >> 2) : 0;
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x)
+            reinterpret_cast<f32x4*>(grad + j.dst_off)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t e = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < j.count; e += (int64_t)gridDim.x * blockDim.x)
+            grad[j.dst_off + e] = 0.f;
+        return;
+    }
     if (j.nsrc > 64) {
         // many partial rows, few elements (GroupNorm / bias partials): 32 elements x 8 source slices per block,
         // fixed summation order => deterministic
@@ -831,7 +862,14 @@ __global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const flo
 }
 hipError_t launch_reduce_grads(const ReduceJobs& jobs, const float* scratch, float* flat_grad, hipStream_t st) {
     if (jobs.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_reduce_grads, dim3(512, jobs.n), dim3(256), 0, st, jobs, scratch, flat_grad);
+    // grid-stride loops inside; the result of every element is formed by one thread / one block in a fixed order whatever the grid.
+    // Blocks per job: enough float4 lanes for the largest slab job, 64 ... 512 (the zero fill and the many-row jobs stride)
+    int64_t big = 0;
+    for (int i = 0; i < jobs.n; ++i)
+        if (jobs.job[i].nsrc > 0 && jobs.job[i].nsrc <= 64 && jobs.job[i].count > big) big = jobs.job[i].count;
+    int gx = (int)((big / 4 + 255) / 256);
+    gx = gx < 64 ? 64 : (gx > 512 ? 512 : gx);
+    hipLaunchKernelGGL(k_reduce_grads, dim3(gx, jobs.n), dim3(256), 0, st, jobs, scratch, flat_grad);
     return hipGetLastError();
 }
 
@@ -925,14 +963,25 @@ hipError_t launch_sqnorm(const float* g, int64_t n, float* part, int* nblocks, h
 // when it wants to (FusedAdam.nonfinite_steps()), not every step.
 // (the counter update rides in the first thread of the optimizer kernel: one launch less in a step whose tail is latency-bound)
 __global__ void __launch_bounds__(256) k_adam_ema(AdamArgs a) {
-    if (!isfinite(a.sqnorm[0])) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<float*>(a.sqnorm)[1] += 1.0f;
+    // squared gradient norm: given (sqnorm[0]: the sharded step all-reduces it), or the per-block partials of k_sqnorm, which every
+    // block adds up itself in k_sum_partials' order (n_part <= 1024 floats from L2: cheaper than the one-block launch it replaces)
+    float sq;
+    if (a.n_part > 0) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < a.n_part; i += 256) acc += a.sq_part[i];
+        sq = block_sum_256(acc);
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.sqnorm[0] = sq;
+    } else {
+        sq = a.sqnorm[0];
+    }
+    if (!isfinite(sq)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.sqnorm[1] += 1.0f;
         return;
     }
     // clip_grad_norm_ (losses.py:54-55): coef = max_norm / (total_norm + 1e-6), clamped to 1
     float coef = a.grad_scale;
     if (a.grad_clip >= 0.f) {
-        const float total_norm = sqrtf(a.sqnorm[0]) * a.grad_scale;
+        const float total_norm = sqrtf(sq) * a.grad_scale;
         float cc = a.grad_clip / (total_norm + 1e-6f);
         cc = cc > 1.0f ? 1.0f : cc;
         coef = a.grad_scale * cc;

@@ -69,7 +69,7 @@ __device__ __forceinline__ void wgrad_tr_tile(const void* dY_, const void* H_, c
     // counted vmcnt waits of the pipeline are explicit anyway.
     auto dma_1k = [&](const unsigned char* src, unsigned char* dst) __attribute__((always_inline)) {
         const unsigned lds = (unsigned)(size_t)(lptr_t)dst;
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");      // (no "m0" clobber: not honoured -- see common.h, tools/check_isa.py)
     };
     auto fetch_a = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll

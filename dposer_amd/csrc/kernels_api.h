@@ -204,8 +204,14 @@ hipError_t launch_dres_from_dout(const DresArgs& a, hipStream_t st);
 // ---- layout helpers ---------------------------------------------------------------------------------
 // out FT [Cpad][Spad] = transpose of in FT [Spad][C]
 hipError_t launch_ft_transpose(int f32, const void* in, void* out, int64_t Spad, int C, hipStream_t st);
-// part[chunk][c] = sum over the chunk's samples of in[s][c];  returns number of chunks
-hipError_t launch_colsum(int f32, const void* in, float* part, int64_t Spad, int C, int* nchunks, hipStream_t st);
+// part[chunk][c] = sum over the chunk's samples of in[s][c];  returns number of chunks.  `rider` (optional): a list of partials summed
+// into out[0] by one extra block of the same launch (the DSM loss of the step: k_sum_partials' summation order, no launch of its own)
+struct SumJob {
+    const float* part;
+    int n;
+    float* out;
+};
+hipError_t launch_colsum(int f32, const void* in, float* part, int64_t Spad, int C, int* nchunks, hipStream_t st, const SumJob* rider = nullptr);
 
 // ---- gradient finalisation and optimizer --------------------------------------------------------------
 struct ReduceJob {
@@ -213,7 +219,7 @@ struct ReduceJob {
     int64_t count;
     int64_t src_off;       // element offset in the scratch buffer
     int64_t src_stride;
-    int nsrc;
+    int nsrc;              // 0: fill [dst_off, dst_off + count) with zeros (parameters that never get a gradient)
 };
 constexpr int MAX_REDUCE_JOBS = 48;
 struct ReduceJobs {
@@ -233,7 +239,9 @@ struct AdamArgs {          // losses.py:44-58 optimize_fn + torch.optim.Adam + e
     float* ema;            // may be null
     int64_t n;
     int64_t skip_lo[2], skip_hi[2];   // parameter ranges without gradient (Adam skipped, EMA still applied)
-    const float* sqnorm;   // device scalar: sum of g^2 over the whole flat gradient (before grad_scale)
+    float* sqnorm;         // device scalars: [0] sum of g^2 over the whole flat gradient (before grad_scale), [1] dropped-step counter
+    const float* sq_part;  // n_part > 0: per-block partials of k_sqnorm, summed by the kernel itself (and published in sqnorm[0])
+    int n_part;
     float grad_scale;      // applied to g before anything else (1/world_size)
     float grad_clip;       // < 0: disabled
     float step_size;       // lr / (1 - beta1^t)

@@ -218,13 +218,53 @@ extern "C" int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat, void* 
 // ------------------------------------------------------------------------------------------------
 // workspace layout
 // ------------------------------------------------------------------------------------------------
+// A/B switches of the score path: read from the environment ONCE (first use), not per call (three to four getenv() per backward
+// pass in round 3); tests and tuners that change them inside one process call dposer_scorefc_tuning_reload() afterwards.
+static int env_tri(const char* name) { const char* e = getenv(name); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }
+struct ScoreTuning {
+    int64_t big_min = 16384;          // DPOSER_BIG_MIN_BATCH: 256x256 tiles from this many padded samples
+    int gnbwd_big = -1;               // DPOSER_GNBWD_BIG = 0 / 1: force the 128x128 / 256x256 GroupNorm-backward dgrad
+    int64_t final_small_max = 16384;  // DPOSER_FINAL_SMALL_MAX: 64x32 tiles for post_dense / dx up to this many samples
+    int wgrad_big = -1;               // DPOSER_WGRAD_BIG = 0 / 1: force the 128x128 / 256x256 split-K wgrads
+    int wgrad_tr = -1;                // DPOSER_WGRAD_TR = 0: bf16 wgrads on transposed operand copies
+    int wgrad_stream = -1;            // DPOSER_WGRAD_STREAM = 0 / 1: parameter-gradient half of the backward on the second stream
+    int wgrad_batched = -1;           // DPOSER_WGRAD_BATCHED = 0 / 1: never / always one lane launch for all 256x256 wgrad tiles
+    int wgrad_layer_lanes = -1;       // DPOSER_WGRAD_LAYER_LANES = 0 / 1: bucketed backward with split-K launches / one lane launch per layer
+    int wgrad_groups = -1;            // DPOSER_WGRAD_GROUPS = n: bucketed backward with the lane launches of n layer groups (0: off)
+    int sampler_persistent = 0;       // DPOSER_SAMPLER_PERSISTENT = 1: one persistent kernel for the plain EM sampler
+    int64_t sampler_persistent_min = 256;
+    void load() {
+        const char* e = getenv("DPOSER_BIG_MIN_BATCH");
+        big_min = e ? atoll(e) : (int64_t)16384;
+        gnbwd_big = env_tri("DPOSER_GNBWD_BIG");
+        e = getenv("DPOSER_FINAL_SMALL_MAX");
+        final_small_max = e ? atoll(e) : (int64_t)16384;
+        wgrad_big = env_tri("DPOSER_WGRAD_BIG");
+        wgrad_tr = env_tri("DPOSER_WGRAD_TR");
+        wgrad_stream = env_tri("DPOSER_WGRAD_STREAM");
+        wgrad_batched = env_tri("DPOSER_WGRAD_BATCHED");
+        wgrad_layer_lanes = env_tri("DPOSER_WGRAD_LAYER_LANES");
+        e = getenv("DPOSER_WGRAD_GROUPS");
+        wgrad_groups = e ? atoi(e) : -1;
+        e = getenv("DPOSER_SAMPLER_PERSISTENT");
+        sampler_persistent = e ? atoi(e) : 0;
+        e = getenv("DPOSER_SAMPLER_PERSISTENT_MIN");
+        sampler_persistent_min = e ? atoll(e) : (int64_t)256;
+    }
+};
+static ScoreTuning& score_tuning() {
+    static ScoreTuning t = [] { ScoreTuning x; x.load(); return x; }();
+    return t;
+}
+extern "C" void dposer_scorefc_tuning_reload(void) { score_tuning().load(); }
+
 static int64_t pad_batch(int64_t B) { return B <= 512 ? round_up(B, 64) : round_up(B, 256); }
 // `channels` = output channels of the GEMM (H = 1024 for the GroupNorm layers, E for the time branch): the 256x256 tiling
 // needs them to be a multiple of 256 (embed_dim may be any multiple of 128).
 static thread_local int g_act = DPOSER_ACT_SWISH;   // activation of the handle whose call is running (the 256 x 256 tiling compiles swish in)
 static int main_shape(int64_t Spad, int channels = 1024, int gs = 32) {
     if (g_act != DPOSER_ACT_SWISH) return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL;
-    static const int64_t big_min = [] { const char* e = getenv("DPOSER_BIG_MIN_BATCH"); return e ? atoll(e) : (int64_t)16384; }();
+    const int64_t big_min = score_tuning().big_min;
     if (gs == 32 && Spad % 256 == 0 && Spad >= big_min && channels % 256 == 0) return SHAPE_BIG;   // (generic group sizes: 128-wide tilings)
     if (Spad % 128 == 0) return SHAPE_MID;
     return SHAPE_SMALL;
@@ -232,7 +272,7 @@ static int main_shape(int64_t Spad, int channels = 1024, int gs = 32) {
 // GroupNorm-backward dgrad: the register-lean epilogue fits the 256x256 tile in 248 VGPRs without spilling; it wins from
 // 32768 samples up (227 vs 257 us at 65536, 2.52 vs 2.59 ms per step at 32768, a tie at 16384).  DPOSER_GNBWD_BIG = 0 / 1 forces it.
 static int gnbwd_shape(int64_t Spad, int gs = 32) {
-    static const int forced = [] { const char* e = getenv("DPOSER_GNBWD_BIG"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
+    const int forced = score_tuning().gnbwd_big;
     const bool big = gs == 32 && g_act == DPOSER_ACT_SWISH && (forced >= 0 ? forced == 1 : Spad >= 32768);
     if (big && Spad % 256 == 0) return SHAPE_BIG;
     return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL;
@@ -240,7 +280,7 @@ static int gnbwd_shape(int64_t Spad, int gs = 32) {
 // post_dense / dx: one 64-channel block tile, so the grid is Spad/128 (or Spad/32) workgroups: below 32768 samples the
 // 64x128 tiling leaves most CUs idle and the 64x32 one is used.
 static int final_shape(int64_t Spad) {
-    static const int64_t small_max = [] { const char* e = getenv("DPOSER_FINAL_SMALL_MAX"); return e ? atoll(e) : (int64_t)16384; }();
+    const int64_t small_max = score_tuning().final_small_max;
     return (Spad % 128 == 0 && Spad > small_max) ? SHAPE_FINAL : SHAPE_FINAL_S;
 }
 
@@ -274,7 +314,7 @@ static int wgrad_shape(int n_rows_pad, int k_rows_pad, int64_t Spad) {
     //  64-column tilings divide that)
     if (n_rows_pad % 128 != 0) return SHAPE_FINAL;
     if (k_rows_pad % 128 != 0) return SHAPE_WIDE64;
-    static const int forced = [] { const char* e = getenv("DPOSER_WGRAD_BIG"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
+    const int forced = score_tuning().wgrad_big;
     const bool big = forced >= 0 ? forced == 1 : Spad >= 32768;
     if (big && n_rows_pad % 256 == 0 && k_rows_pad % 256 == 0) return SHAPE_BIG;
     return SHAPE_MID;
@@ -283,7 +323,7 @@ static int wgrad_shape(int n_rows_pad, int k_rows_pad, int64_t Spad) {
 // copies those GEMMs used to need (fp32 = parity mode keeps them: there is no 32-bit transposing LDS read).
 // DPOSER_WGRAD_TR = 0 forces the transposed-copy path.
 static bool wgrad_tr_mode(const dposer_scorefc_s* h, int64_t Bpad) {
-    static const int forced = [] { const char* e = getenv("DPOSER_WGRAD_TR"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
+    const int forced = score_tuning().wgrad_tr;
     (void)Bpad;
     return forced != 0 && !h->f32;      // every wgrad tiling has a sample-major instantiation
 }
@@ -364,9 +404,8 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         acc(h->Cp, H, (int64_t)h->D * H);
         acc(E, E, (int64_t)E * E);
         {   // room for the partial tiles of the one-launch weight gradients (wgrad_batch.h; plan_batched_wgrad has the conditions)
-            const char* e = getenv("DPOSER_WGRAD_BATCHED");
             const int64_t need = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536 + ((int64_t)14 << 20);
-            if (!(e && e[0] == '0') && !h->f32 && H == 1024 && E == 512 && slab_elems < need) slab_elems = need;
+            if (score_tuning().wgrad_batched != 0 && !h->f32 && H == 1024 && E == 512 && slab_elems < need) slab_elems = need;
         }
         w.slabs = (float*)take(slab_elems * 4);
         w.slab_elems = slab_elems;
@@ -660,8 +699,8 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     // blocks the launches win by using every CU -- and at 256 blocks the same work takes 715 us: a workgroup re-reads its 512 KB
     // input panel for each of the 4 channel tiles (the launches let 4 tiles on one XCD share it through L2), 3.3 GB per step
     // through MALL / HBM, under the chip's power cap.  Removing the grid-wide joins does not pay for that.
-    static const int persistent_env = [] { const char* e = getenv("DPOSER_SAMPLER_PERSISTENT"); return e ? atoi(e) : 0; }();
-    static const int64_t persistent_min = [] { const char* e = getenv("DPOSER_SAMPLER_PERSISTENT_MIN"); return e ? atoll(e) : (int64_t)256; }();
+    const int persistent_env = score_tuning().sampler_persistent;
+    const int64_t persistent_min = score_tuning().sampler_persistent_min;
     if (fused && persistent_env && h->d.activation == DPOSER_ACT_SWISH && h->gs == 32 && h->H % 256 == 0 && h->Cp == 64 && w.Bpad % 256 == 0 && w.Bpad >= persistent_min) {
         SamplerLayer tab[MAX_L];
         std::memset(tab, 0, sizeof(tab));
@@ -944,33 +983,66 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
     return run_post(h, flat, packed, w.hbuf[L - 1], w.res, B, w.Bpad, st);
 }
 
-// backward from dres (FT [Bpad][Cp], zero on padded rows) to the flat parameter gradient and/or dx
-// Launch the pending reduction jobs of one gradient bucket and mark the bucket final on the stream.
-static int flush_bucket(ReduceJobs& rj, const Ws& w, float* flat_grad, void* const* events, int n_events, int bucket, hipStream_t st) {
-    if (rj.n > 0) DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, st));
-    rj.n = 0;
-    if (events && bucket < n_events && events[bucket]) DP_CHECK_HIP(hipEventRecord((hipEvent_t)events[bucket], st));
+// Who learns that gradient buckets are final, and how (data parallel: the all-reduce of a bucket overlaps with the rest of the backward):
+//   events only    : one event per bucket is recorded on the stream (dposer_dsm_loss_fwd_bwd_bucketed); the caller enqueues its waits and
+//                    collectives after the call has returned;
+//   events + notify: ONE event per group of buckets that become final together, then `notify` is called at once, from inside the call,
+//                    with the merged flat ranges -- the host-side cost of issuing the collectives (tens of microseconds each through
+//                    torch.distributed) then overlaps with the GPU work still queued, instead of following the whole backward.
+struct BucketSink {
+    void* const* events = nullptr;
+    int n_events = 0;
+    dposer_ranges_final_fn notify = nullptr;
+    void* user = nullptr;
+};
+static void bucket_range(const dposer_scorefc_s* h, int b, int64_t& lo, int64_t& hi);
+// buckets [first, first + n) of flat_grad are final on `st`
+static int mark_final(const dposer_scorefc_s* h, const BucketSink* sink, int first, int n, hipStream_t st) {
+    if (!sink || !sink->events || n <= 0) return DPOSER_OK;
+    if (!sink->notify) {
+        for (int b = first; b < first + n; ++b)
+            if (b < sink->n_events && sink->events[b]) DP_CHECK_HIP(hipEventRecord((hipEvent_t)sink->events[b], st));
+        return DPOSER_OK;
+    }
+    if (first >= sink->n_events || !sink->events[first]) return dposer_set_error(DPOSER_ERR_BAD_ARG, "notify: missing bucket event");
+    DP_CHECK_HIP(hipEventRecord((hipEvent_t)sink->events[first], st));
+    int64_t lo[MAX_L + 1], hi[MAX_L + 1];
+    int nr = 0;
+    for (int b = first; b < first + n; ++b) {          // buckets come in descending flat order: merge neighbours
+        int64_t l, r;
+        bucket_range(h, b, l, r);
+        if (nr > 0 && lo[nr - 1] == r) lo[nr - 1] = l;
+        else { lo[nr] = l; hi[nr] = r; ++nr; }
+    }
+    sink->notify(sink->user, first, nr, lo, hi, sink->events[first]);
     return DPOSER_OK;
 }
 
-// Gradient buckets in the order the backward pass finishes them (dposer_scorefc_grad_buckets): bucket b < L-1 is GN layer
-// L-1-b (bucket 0 also holds post_dense, which follows the last layer in parameters() order); the last bucket is everything
-// in front of layer 1: layer 0, the dead pre_dense_cond, gauss_proj.W and the shared time embedding.
+// Gradient buckets in the order the backward pass finishes them (dposer_scorefc_grad_buckets), L + 1 of them: bucket b < L-1 is GN
+// layer L-1-b (bucket 0 also holds post_dense, which follows the last layer in parameters() order); bucket L-1 ("front A") is layer
+// 0's weights [pre_dense.w .. dense_t bias], final as soon as layer 0 is differentiated; bucket L ("front B") is the rest in front of
+// layer 1 -- layer 0's GroupNorm affine, gauss_proj.W, the shared time embedding -- final only after the time branch.  The dead
+// pre_dense_cond range between the two (1.05 M floats = 13 % of the flat buffer, always zero) belongs to no bucket: it is not
+// all-reduced.
+static int n_grad_buckets(const dposer_scorefc_s* h) { return h->L + 1; }
 static void bucket_range(const dposer_scorefc_s* h, int b, int64_t& lo, int64_t& hi) {
     const int L = h->L;
     if (b < L - 1) {
         const int j = L - 1 - b;
         lo = h->layer[j].w;
         hi = (b == 0) ? h->nparams : h->layer[j + 1].w;
-    } else {
+    } else if (b == L - 1) {
         lo = 0;
-        hi = L > 1 ? h->layer[1].w : h->nparams;
+        hi = h->off_cond_w;
+    } else {
+        lo = h->layer[0].gamma;
+        hi = h->layer[1].w;
     }
 }
 
 extern "C" int32_t dposer_scorefc_grad_buckets(dposer_scorefc_t h, int64_t* lo, int64_t* hi, int32_t max_buckets) {
     if (!h) return -1;
-    const int n = h->L;
+    const int n = n_grad_buckets(h);
     for (int b = 0; b < n && b < max_buckets; ++b)
         if (lo && hi) bucket_range(h, b, lo[b], hi[b]);
     return n;
@@ -997,8 +1069,8 @@ extern "C" int dposer_stream_wait_event(void* stream, void* event) {
 // and launch gaps show, so the two wgrad GEMMs + bucket reduction of layer j run concurrently with the dgrad GEMM of layer j-1.
 // DPOSER_WGRAD_STREAM = 0 / 1 forces it off / on.
 static bool use_side_stream(int64_t Bpad) {
-    const char* e = getenv("DPOSER_WGRAD_STREAM");
-    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    const int forced = score_tuning().wgrad_stream;
+    if (forced >= 0) return forced == 1;
     return Bpad >= 8192 && Bpad <= 16384;     // (re-measured: 1.28 vs 1.36 ms at 16384, a tie at 8192 and 32768, 0.759 vs 0.747 ms at 4096)
 }
 static int ensure_side_stream(dposer_scorefc_s* h) {
@@ -1093,46 +1165,71 @@ static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first
     return false;
 }
 static bool plan_batched_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, bool has_events, WgradBatchArgs& a) {
-    const char* e = getenv("DPOSER_WGRAD_BATCHED");
-    const int forced = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
+    const int forced = score_tuning().wgrad_batched;
     if (forced == 0 || !tr || (has_events && forced != 1)) return false;
     return plan_wgrad_lanes(h, w, 0, h->L - 1, true, a);
 }
-// The bucketed backward (data parallel: layer j's gradient must be final before the layers in front of it are differentiated) keeps one
-// weight-gradient launch per LAYER, but as lanes too: W_x of the layer and its W_t in two row halves are one line of 1.5 S rows over the
-// 16 lanes -- 256 workgroups of equal length instead of two split-K launches with 128 / 64-stage workgroups.
-// Measured on one GPU with the bucket events recorded (DPOSER_FORCE_BUCKET_EVENTS=1): 3.41 -> 3.37 ms at 65536 samples, 1.182 -> 1.164 at
-// 16384 -- each output tile now has ~11 partial tiles to add, so most of the one-launch form's gain stays out of reach.  Default from
-// 16384 samples; DPOSER_WGRAD_LAYER_LANES=0 keeps the two split-K launches (as does DPOSER_WGRAD_BATCHED=0), =1 forces the lanes.
-static bool plan_layer_wgrad(const dposer_scorefc_s* h, const Ws& w, bool tr, int j, WgradBatchArgs& a) {
-    const char* e = getenv("DPOSER_WGRAD_BATCHED");
-    const char* e2 = getenv("DPOSER_WGRAD_LAYER_LANES");
-    if ((e && e[0] == '0') || (e2 && e2[0] == '0') || !tr) return false;
-    if (!(e2 && e2[0] == '1') && w.Bpad < 16384) return false;     // (8192 samples: 0.854 vs 0.841 ms -- the second stream of the split-K form wins)
-    return plan_wgrad_lanes(h, w, j, j, false, a);
+// The bucketed backward (data parallel: a bucket's gradient must be final while the layers in front of it are still being
+// differentiated, so that its all-reduce overlaps with them) runs the 256 x 256 weight-gradient tiles as lanes too, one launch per
+// GROUP of layers: after the dgrad of the group's lowest layer, W_x and W_t of all its layers are one line of lane problems -- 256
+// workgroups of equal length instead of two split-K launches per layer with 128 / 64-stage workgroups.  Round 3 had one group per
+// layer from 16384 samples per rank (each output tile then has ~11 partial tiles to add: 3.41 -> 3.37 ms at 65536) and split-K launches
+// on a second stream below; round 4 (profiles/r04_dp_rank_step.md): TWO groups by default at every batch size -- layers {L-1, L-2}
+// (+ post_dense) first, everything else after layer 0, and BEFORE the time branch, whose dgrad + shared-embedding wgrad then run under
+// the second group's all-reduce; only "front B" (1 MB) is final at the very end.
+// DPOSER_WGRAD_GROUPS = n picks the number of groups (n = L: one per layer), DPOSER_WGRAD_LAYER_LANES = 1 is n = L, = 0 (or
+// DPOSER_WGRAD_BATCHED = 0) keeps the split-K launches.
+static int plan_wgrad_groups(const dposer_scorefc_s* h, const Ws& w, bool tr, int* lo, int* hi) {
+    const ScoreTuning& tn = score_tuning();
+    if (tn.wgrad_batched == 0 || tn.wgrad_layer_lanes == 0 || tn.wgrad_groups == 0 || !tr) return 0;
+    const int L = h->L;
+    int G = tn.wgrad_groups > 0 ? tn.wgrad_groups : (tn.wgrad_layer_lanes == 1 ? L : 2);
+    if (G > L) G = L;
+    // contiguous groups from the last layer down; the groups at the bottom take the left-over layers ({4,3} {2,1,0} for L = 5, G = 2)
+    const int base = L / G, extra = L % G;
+    int top = L - 1;
+    for (int g = 0; g < G; ++g) {
+        const int size = base + (g >= G - extra ? 1 : 0);
+        hi[g] = top;
+        lo[g] = top - size + 1;
+        top -= size;
+        WgradBatchArgs probe;
+        if (!plan_wgrad_lanes(h, w, lo[g], hi[g], false, probe)) return 0;
+    }
+    return G;
 }
 
 // backward from dres (FT [Bpad][Cp], zero on padded rows) to the flat parameter gradient and/or dx.
-//   critical path (stream st): dgrad GEMM of layer L-1 ... 0 (each writes dy_j, dy_j^T and the GroupNorm partial sums),
-//                              dx GEMM, dgrad into the time branch;
-//   gradient side (stream sw = st, or the handle's second stream): per layer the two split-K wgrad GEMMs and the
-//                              deterministic reduction of that layer's bucket (+ bucket event), in the same layer order.
+//   critical path (stream st): dgrad GEMM of layer L-1 ... 0 (each writes dy_j and the GroupNorm partial sums), dx GEMM, dgrad into the
+//                              time branch;
+//   gradient side, one of:     (batched)  everything at the end: one lane launch for all 256 x 256 tiles (single GPU);
+//                              (grouped)  one lane launch per layer group + that group's reductions and bucket events (data parallel);
+//                              (split-K)  per layer two split-K wgrad GEMMs + the bucket's reduction, optionally on the handle's second
+//                                         stream (fp32 mode, other widths, forced).
 static int backward_core(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
-                         uint32_t step, float* flat_grad, float* dx, void* const* events, int n_events, hipStream_t st) {
+                         uint32_t step, float* flat_grad, float* dx, const BucketSink* sink, hipStream_t st,
+                         const SumJob* loss_sum = nullptr) {
     const int prec = h->f32 ? PREC_FP32 : PREC_BF16;
     const int H = h->H, E = h->E, L = h->L, KBS = h->KBS;
     const int64_t Bpad = w.Bpad;
     const bool want_w = flat_grad != nullptr;
     const bool tr = wgrad_tr_mode(h, Bpad);
+    const bool has_events = sink != nullptr && sink->events != nullptr && sink->n_events > 0;
     WgradBatchArgs wb;
-    const bool batched = want_w && plan_batched_wgrad(h, w, tr, events != nullptr && n_events > 0, wb);
-    const bool two = want_w && !batched && use_side_stream(Bpad);
+    const bool batched = want_w && plan_batched_wgrad(h, w, tr, has_events, wb);
+    int grp_lo[MAX_L], grp_hi[MAX_L];
+    const int n_groups = (want_w && !batched) ? plan_wgrad_groups(h, w, tr, grp_lo, grp_hi) : 0;
+    const bool grouped = n_groups > 0;
+    int cur_group = 0;
+    bool front_a_done = false;
+    const bool two = want_w && !batched && !grouped && use_side_stream(Bpad);
     if (two) DP_TRY(ensure_side_stream(h));
     hipStream_t sw = two ? h->side : st;
     ReduceJobs rj;
     rj.n = 0;
     int64_t slab_cursor = 0;
     int n_chunks_post = 0, n_chunks_se = 0;
+    const int64_t lane_room = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536;
     // Deterministic reduction into the flat gradient: every partial buffer lives in the workspace (offsets relative to
     // w.slabs); the jobs of one bucket are launched together as soon as its last wgrad has been queued.
     auto rel = [&](const float* p) { return (int64_t)(p - w.slabs); };
@@ -1145,24 +1242,37 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
             DP_CHECK_HIP(hipEventRecord(h->ev_start, st));
             DP_CHECK_HIP(hipStreamWaitEvent(sw, h->ev_start, 0));
         }
-        for (int i = 0; i < h->n_nograd; ++i)
-            DP_CHECK_HIP(hipMemsetAsync(flat_grad + h->nograd_lo[i], 0, (h->nograd_hi[i] - h->nograd_lo[i]) * sizeof(float), sw));
         // operands that only depend on the forward pass
         if (!tr) {
             DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.xin, w.xinT, Bpad, h->Dpad, sw));
             DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, sw));
         }
         // post_dense: bias (column sums of dres) and weight
-        DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, sw));
+        DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, sw, loss_sum));    // (+ the loss partials of k_dsm)
         if (tr) {
             DP_TRY(run_wgrad(h, nullptr, h->Cp, h->D, nullptr, H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, sw, w.dres, w.hbuf[L - 1]));
         } else {
             DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, sw));
             DP_TRY(run_wgrad(h, w.dresT, h->Cp, h->D, w.hT[L - 1], H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, sw));
         }
+    } else if (loss_sum && loss_sum->n > 0) {
+        DP_HIP_LAUNCH(launch_sum_partials(loss_sum->part, loss_sum->n, loss_sum->out, st));
     }
     const int gshape = gnbwd_shape(Bpad, h->gs);
     const int ws_rows = (int)(Bpad / (shape_st(gshape) * 32)) * shape_ws(gshape);   // partial rows written by the dgrad epilogue
+    // GroupNorm affine / bias gradients of layer j from the partial sums its dgrad epilogue wrote
+    auto add_layer_jobs = [&](int j) {
+        const LayerOff& lo = h->layer[j];
+        add_job(lo.gamma, H, w.gn_part[j] + 0 * H, 3 * (int64_t)H, ws_rows);
+        add_job(lo.beta, H, w.gn_part[j] + 1 * H, 3 * (int64_t)H, ws_rows);
+        add_job(lo.b, H, w.gn_part[j] + 2 * H, 3 * (int64_t)H, ws_rows);
+        add_job(lo.bt, H, w.gn_part[j] + 2 * H, 3 * (int64_t)H, ws_rows);
+        if (j == L - 1) add_job(h->off_post_b, h->D, w.cs_part_post, h->Cp, n_chunks_post);
+    };
+    auto run_wx0 = [&]() -> int {      // layer 0's W_x has 63 input channels: not a 256-wide lane problem, its own small split-K launch
+        const LayerOff& lo = h->layer[0];
+        return run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[0], (const void*)w.xin);
+    };
     for (int j = L - 1; j >= 0; --j) {
         // gradient w.r.t. the output of GN layer j, through the layer that consumes it
         const bool from_post = (j == L - 1);
@@ -1186,30 +1296,41 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
             DP_CHECK_HIP(hipStreamWaitEvent(sw, h->ev_layer[j], 0));
         }
         // parameter gradients of layer j
-        const void* inT = (j == 0) ? (const void*)w.xinT : (const void*)w.hT[j - 1];
         const LayerOff& lo = h->layer[j];
         if (batched) {       // W_x (j >= 1) and W_t of every layer are tiles of the one launch behind the loop
-            if (j == 0) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], (const void*)w.xin));
-        } else if (plan_layer_wgrad(h, w, tr, j, wb)) {       // one lane launch for this layer's W_x and W_t, then its partial tiles
-            if (j == 0) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], (const void*)w.xin));
-            if (slab_cursor > w.slab_elems - (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: slab buffer too small for the lane launch");
-            wb.alg_flops = 2.0 * (double)B * H * ((j >= 1 ? (double)H : 0.0) + (double)E);
+            if (j == 0) DP_TRY(run_wx0());
+            add_layer_jobs(j);
+        } else if (grouped) {
+            if (j != grp_lo[cur_group]) continue;
+            // the group [grp_lo, grp_hi] is differentiated: its lanes, its partial tiles, its small reductions, its bucket events
+            if (j == 0) DP_TRY(run_wx0());
+            if (slab_cursor > w.slab_elems - lane_room) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: slab buffer too small for the lane launch");
+            if (!plan_wgrad_lanes(h, w, grp_lo[cur_group], grp_hi[cur_group], false, wb)) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: lane plan changed between probe and launch");
+            double fl = 0.0;
+            for (int l = grp_lo[cur_group]; l <= grp_hi[cur_group]; ++l) fl += 2.0 * (double)B * H * ((l >= 1 ? (double)H : 0.0) + (double)E);
+            wb.alg_flops = fl;
             DP_HIP_LAUNCH(gemm_wgrad_tr_batch(wb, sw));
             DP_HIP_LAUNCH(launch_reduce_wgrad_tiles(wb, flat_grad, sw));
+            for (int l = grp_hi[cur_group]; l >= grp_lo[cur_group]; --l) add_layer_jobs(l);
+            if (rj.n > 0) DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, sw));
+            rj.n = 0;
+            DP_TRY(mark_final(h, sink, L - 1 - grp_hi[cur_group], grp_hi[cur_group] - grp_lo[cur_group] + 1, sw));
+            if (j == 0) front_a_done = true;
+            ++cur_group;
         } else {
-        if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], j == 0 ? (const void*)w.xin : (const void*)w.hbuf[j - 1]));
-        else DP_TRY(run_wgrad(h, w.dyT[j], H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw));
-        if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw, w.dy[j], w.temb));
-        else DP_TRY(run_wgrad(h, w.dyT[j], H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw));
+            const void* inT = (j == 0) ? (const void*)w.xinT : (const void*)w.hT[j - 1];
+            if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], j == 0 ? (const void*)w.xin : (const void*)w.hbuf[j - 1]));
+            else DP_TRY(run_wgrad(h, w.dyT[j], H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw));
+            if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw, w.dy[j], w.temb));
+            else DP_TRY(run_wgrad(h, w.dyT[j], H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw));
+            add_layer_jobs(j);
+            // layer j's gradient (and everything behind it in the flat buffer) is final: the data-parallel all-reduce of this
+            // bucket can start while the remaining layers are still being differentiated
+            if (rj.n > 0) DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, sw));
+            rj.n = 0;
+            DP_TRY(mark_final(h, sink, L - 1 - j, 1, sw));
+            if (j == 0) front_a_done = true;
         }
-        add_job(lo.gamma, H, w.gn_part[j] + 0 * H, 3 * (int64_t)H, ws_rows);
-        add_job(lo.beta, H, w.gn_part[j] + 1 * H, 3 * (int64_t)H, ws_rows);
-        add_job(lo.b, H, w.gn_part[j] + 2 * H, 3 * (int64_t)H, ws_rows);
-        add_job(lo.bt, H, w.gn_part[j] + 2 * H, 3 * (int64_t)H, ws_rows);
-        if (from_post) add_job(h->off_post_b, h->D, w.cs_part_post, h->Cp, n_chunks_post);
-        // layer j's gradient (and everything behind it in the flat buffer) is final: the data-parallel all-reduce of this
-        // bucket can start while the remaining layers are still being differentiated
-        if (j >= 1 && !batched) DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1 - j, sw));
     }
     if (dx) {   // d loss / d x = dy_0 @ W_pre  (the time branch does not depend on x)
         const int shape = final_shape(Bpad);
@@ -1244,16 +1365,26 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         else DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw));
     }
     if (batched) {
-        if (slab_cursor > w.slab_elems - (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: slab buffer too small for the batched wgrad launch");
+        if (slab_cursor > w.slab_elems - lane_room) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: slab buffer too small for the batched wgrad launch");
         wb.alg_flops = 2.0 * (double)B * H * ((double)(L - 1) * H + (double)L * E) + (se_in_batch ? 2.0 * (double)B * E * E : 0.0);
         DP_HIP_LAUNCH(gemm_wgrad_tr_batch(wb, st));
         DP_HIP_LAUNCH(launch_reduce_wgrad_tiles(wb, flat_grad, st));
     }
-    // last bucket: layer 0 (jobs queued above), the shared time embedding and the parameters that never get a gradient
+    // what is left: the shared time embedding (front B), layer 0's jobs where they were not flushed with a group, and the parameters
+    // that never get a gradient
     add_job(h->off_se_b, E, w.cs_part_se, E, n_chunks_se);
-    if (batched && events)           // nothing was final before this point: every bucket becomes final with the last reduction
-        for (int b = 0; b + 1 < L; ++b) DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, b, sw));
-    DP_TRY(flush_bucket(rj, w, flat_grad, events, n_events, L - 1, sw));
+    for (int i = 0; i < h->n_nograd; ++i) {                          // dead parameters: zeros (no bucket holds them; the optimiser skips them)
+        ReduceJob& jb = rj.job[rj.n++];
+        jb.dst_off = h->nograd_lo[i]; jb.count = h->nograd_hi[i] - h->nograd_lo[i]; jb.src_off = 0; jb.src_stride = 0; jb.nsrc = 0;
+    }
+    if (rj.n > 0) DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, sw));
+    rj.n = 0;
+    if (batched && has_events) {     // nothing was final before this point: every bucket becomes final with the last reduction
+        DP_TRY(mark_final(h, sink, 0, L + 1, sw));
+    } else {
+        if (!front_a_done) DP_TRY(mark_final(h, sink, L - 1, 2, sw));      // front A + front B
+        else DP_TRY(mark_final(h, sink, L, 1, sw));                         // front B (front A: recorded with layer 0 / its group)
+    }
     if (two) {   // the caller's stream owns the complete gradient (and may reuse the workspace) from here on
         DP_CHECK_HIP(hipEventRecord(h->ev_join, sw));
         DP_CHECK_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -1261,11 +1392,10 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     return DPOSER_OK;
 }
 
-extern "C" int dposer_dsm_loss_fwd_bwd_bucketed(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_,
-                                                const dposer_sde_desc* sde, const float* batch_x, const float* t_in, const float* z_in,
-                                                float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
-                                                float* flat_grad, float* loss, int64_t B, void* const* bucket_events, int32_t n_events,
-                                                void* stream) {
+static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                 const float* batch_x, const float* t_in, const float* z_in, float eps, uint64_t seed, uint32_t step,
+                                 const float* freq, const float* sigmas, float* flat_grad, float* loss, int64_t B, const BucketSink* sink,
+                                 void* stream) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(sde && batch_x && freq && sigmas && flat_grad && loss, "null argument");
@@ -1289,8 +1419,32 @@ extern "C" int dposer_dsm_loss_fwd_bwd_bucketed(dposer_scorefc_t h, const float*
     da.f32 = h->f32; da.fourier = 0; da.grad_scale = (float)(1.0 / ((double)B * (double)h->D)); da.sde = sc;
     int nb = 0;
     DP_HIP_LAUNCH(launch_dsm(da, &nb, st));
-    DP_HIP_LAUNCH(launch_sum_partials(w.loss_part, nb, loss, st));
-    return backward_core(h, flat, packed, w, B, true, seed, step, flat_grad, nullptr, bucket_events, n_events, st);
+    const SumJob loss_sum{w.loss_part, nb, loss};                      // summed by a rider block of the first backward launch
+    return backward_core(h, flat, packed, w, B, true, seed, step, flat_grad, nullptr, sink, st, &loss_sum);
+}
+
+extern "C" int dposer_dsm_loss_fwd_bwd_bucketed(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_,
+                                                const dposer_sde_desc* sde, const float* batch_x, const float* t_in, const float* z_in,
+                                                float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
+                                                float* flat_grad, float* loss, int64_t B, void* const* bucket_events, int32_t n_events,
+                                                void* stream) {
+    BucketSink sink;
+    sink.events = bucket_events; sink.n_events = n_events;
+    return dsm_loss_fwd_bwd_impl(h, flat, packed_, ws_, sde, batch_x, t_in, z_in, eps, seed, step, freq, sigmas, flat_grad, loss, B,
+                                 (bucket_events && n_events > 0) ? &sink : nullptr, stream);
+}
+
+extern "C" int dposer_dsm_loss_fwd_bwd_notify(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_,
+                                              const dposer_sde_desc* sde, const float* batch_x, const float* t_in, const float* z_in,
+                                              float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
+                                              float* flat_grad, float* loss, int64_t B, void* const* bucket_events, int32_t n_events,
+                                              dposer_ranges_final_fn notify, void* user, void* stream) {
+    DP_CHECK_ARG(bucket_events && n_events > 0 && notify, "notify form needs bucket events and a callback");
+    DP_CHECK_ARG(h && n_events >= n_grad_buckets(h), "one event per gradient bucket (dposer_scorefc_grad_buckets)");
+    BucketSink sink;
+    sink.events = bucket_events; sink.n_events = n_events; sink.notify = notify; sink.user = user;
+    return dsm_loss_fwd_bwd_impl(h, flat, packed_, ws_, sde, batch_x, t_in, z_in, eps, seed, step, freq, sigmas, flat_grad, loss, B, &sink,
+                                 stream);
 }
 
 extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, const void* packed, void* ws, const dposer_sde_desc* sde,
@@ -1342,7 +1496,7 @@ extern "C" int dposer_scorefc_backward(dposer_scorefc_t h, const float* flat, co
     da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma; da.fourier = h->d.embedding == DPOSER_EMB_FOURIER;
     da.f32 = h->f32;
     DP_HIP_LAUNCH(launch_dres_from_dout(da, st));
-    return backward_core(h, flat, packed, w, B, train_mode != 0, seed, step, flat_grad, dx, nullptr, 0, st);
+    return backward_core(h, flat, packed, w, B, train_mode != 0, seed, step, flat_grad, dx, nullptr, st);
 }
 
 extern "C" int dposer_grad_sqnorm(const float* grad, int64_t n, float* scratch, void* stream) {
@@ -1386,12 +1540,10 @@ static int adam_step_impl(float* flat, const float* grad, float* m, float* v, fl
     DP_CHECK_ARG(adam_step >= 1, "adam_step counts from 1");
     DP_CHECK_ARG(n_skip >= 0 && n_skip <= 2, "at most two no-gradient ranges");
     hipStream_t st = (hipStream_t)stream;
-    if (!presummed) {
-        int nb = 0;
-        DP_HIP_LAUNCH(launch_sqnorm(grad, n, scratch + 16, &nb, st));
-        DP_HIP_LAUNCH(launch_sum_partials(scratch + 16, nb, scratch, st));
-    }
+    int nb = 0;
+    if (!presummed) DP_HIP_LAUNCH(launch_sqnorm(grad, n, scratch + 16, &nb, st));     // (the partials are added up by k_adam_ema)
     AdamArgs a;
+    a.sq_part = scratch + 16; a.n_part = nb;
     a.p = flat; a.g = grad; a.m = m; a.v = v; a.ema = ema; a.n = n;
     for (int i = 0; i < 2; ++i) { a.skip_lo[i] = i < n_skip ? skip_lo_host[i] : 0; a.skip_hi[i] = i < n_skip ? skip_hi_host[i] : 0; }
     a.sqnorm = scratch; a.grad_scale = (float)grad_scale; a.grad_clip = (float)grad_clip;

@@ -134,6 +134,48 @@ def all_reduce_buckets_(flat: torch.Tensor, buckets, wait_bucket=None) -> int:
     return dist.get_world_size()
 
 
+class StreamedAllReduce:
+    """All-reduce (SUM) of ``flat`` range by range WHILE the producer is still queueing work: the fused backward pass announces
+    every group of final gradient buckets from inside its C call (dposer_dsm_loss_fwd_bwd_notify: one recorded event + the merged
+    flat ranges); ``on_final`` makes the communication stream wait for that event and enqueues the collectives of those ranges at
+    once.  The host-side cost of a torch.distributed call (tens of microseconds) is then paid while the GPU still has the rest of
+    the backward pass queued, not after it -- with one rank per GPU at 8192 poses the step is ~0.6 ms, six collectives issued after
+    the C call returned were ~0.15 ms of exposed host time -- and every collective overlaps with the layers still being
+    differentiated.  ``finish()`` makes the current stream wait for all of them and returns the world size (the caller divides)."""
+
+    def __init__(self, flat: torch.Tensor, wait_event):
+        self.flat, self.wait_event = flat, wait_event
+        self.works, self.error, self.ranges = [], None, []
+        self.comm = None
+        if flat.is_cuda:
+            key = flat.device.index
+            self.comm = _COMM_STREAMS.get(key)
+            if self.comm is None:
+                self.comm = _COMM_STREAMS[key] = torch.cuda.Stream(device=flat.device)
+
+    def on_final(self, ranges, event):
+        """``ranges``: [(lo, hi)] final once ``event`` (raw handle, recorded on the producer's stream) has fired."""
+        try:                                  # (called through ctypes from inside the C call: an exception must not unwind through it)
+            self.ranges.extend(ranges)
+            if self.comm is not None:
+                self.wait_event(self.comm.cuda_stream, event)
+                with torch.cuda.stream(self.comm):
+                    for lo, hi in ranges:
+                        self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                for lo, hi in ranges:
+                    self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        except BaseException as e:            # noqa: BLE001 -- re-raised by finish()
+            self.error = e
+
+    def finish(self) -> int:
+        if self.error is not None:
+            raise self.error
+        for w in self.works:
+            w.wait()                          # NCCL: the current stream waits for the collective; gloo: host wait
+        return dist.get_world_size()
+
+
 def zero1_bounds(n: int, num_replicas: int):
     """Contiguous ownership ranges of a flat buffer of n elements for the sharded optimiser step: equal sizes rounded up to a
     multiple of 4 floats (16-byte aligned shard starts), the last rank takes what is left (it may be shorter: the collectives

@@ -86,6 +86,10 @@ int32_t dposer_scorefc_nograd_ranges(dposer_scorefc_t h, int64_t lo[2], int64_t 
  * GEMMs and, when with_backward != 0, transposed copies for dgrad. */
 int64_t dposer_scorefc_packed_bytes(dposer_scorefc_t h, int32_t with_backward);
 int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat_params, void* packed, int32_t with_backward, void* stream);
+/* Re-reads the A/B environment switches of the score path (DPOSER_BIG_MIN_BATCH, DPOSER_GNBWD_BIG, DPOSER_WGRAD_BIG, DPOSER_WGRAD_TR,
+ * DPOSER_WGRAD_STREAM, DPOSER_WGRAD_BATCHED, DPOSER_WGRAD_LAYER_LANES, DPOSER_WGRAD_GROUPS, DPOSER_FINAL_SMALL_MAX,
+ * DPOSER_SAMPLER_PERSISTENT[_MIN]); they are otherwise read ONCE per process (first use), never per call. */
+void dposer_scorefc_tuning_reload(void);
 
 enum { DPOSER_WS_INFER = 0, DPOSER_WS_SHARED_T = 1, DPOSER_WS_TRAIN = 2 };
 int64_t dposer_scorefc_workspace_bytes(dposer_scorefc_t h, int64_t batch, int32_t mode, int32_t n_steps);
@@ -148,8 +152,10 @@ int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat_params, const 
 /* Same step with the flat gradient delivered in BUCKETS so that the data-parallel all-reduce (RCCL, issued by the host
  * through torch.distributed) overlaps the rest of the backward pass -- the reference trains on one device
  * (run/train.py:150-170); this is the MI355X data-parallel extension BASELINE.json's north star asks for.
- *   dposer_scorefc_grad_buckets: number of buckets; [lo[b], hi[b]) are disjoint ranges of the flat buffer that cover it,
- *     listed in the order the backward pass completes them (last GN layer + post_dense first).
+ *   dposer_scorefc_grad_buckets: number of buckets (n_layers + 1); [lo[b], hi[b]) are disjoint ranges of the flat buffer that
+ *     cover every parameter with a gradient (the dead pre_dense_cond range, always zero in flat_grad, is in no bucket), listed in
+ *     the order the backward pass completes them: last GN layer + post_dense first, ..., layer 0's weights, then layer 0's
+ *     GroupNorm affine + the shared time embedding.
  *   bucket_events[b] (from dposer_event_create) is recorded on `stream` once bucket b of flat_grad is final; a
  *     communication stream waits on it with dposer_stream_wait_event before reducing that range. */
 int32_t dposer_scorefc_grad_buckets(dposer_scorefc_t h, int64_t* lo, int64_t* hi, int32_t max_buckets);
@@ -161,6 +167,19 @@ int dposer_dsm_loss_fwd_bwd_bucketed(dposer_scorefc_t h, const float* flat_param
                                      float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
                                      float* flat_grad, float* loss, int64_t batch_size, void* const* bucket_events,
                                      int32_t n_events, void* stream);
+/* The same step, telling the caller about final buckets WHILE the call is still queueing work: buckets that become final together
+ * (a layer group of the backward pass: see dposer_scorefc_tuning_reload / DPOSER_WGRAD_GROUPS) are announced by ONE event --
+ * bucket_events[first_bucket], recorded on `stream` -- followed at once by a call of `notify` from the calling thread with the
+ * group's flat ranges (neighbouring buckets merged; n_ranges <= n_layers + 1).  The callback typically makes a communication stream
+ * wait for `event` and enqueues the all-reduce of each range there: the host-side cost of issuing the collectives then overlaps
+ * with GPU work that is already queued, and each collective with the rest of the backward pass.  `notify` must not synchronise
+ * `stream`.  n_events >= dposer_scorefc_grad_buckets(). */
+typedef void (*dposer_ranges_final_fn)(void* user, int32_t first_bucket, int32_t n_ranges, const int64_t* lo, const int64_t* hi, void* event);
+int dposer_dsm_loss_fwd_bwd_notify(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws,
+                                   const dposer_sde_desc* sde, const float* batch, const float* t, const float* z,
+                                   float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
+                                   float* flat_grad, float* loss, int64_t batch_size, void* const* bucket_events,
+                                   int32_t n_events, dposer_ranges_final_fn notify, void* user, void* stream);
 
 /* Differentiable ScoreModelFC.forward for torch.autograd (model.py:141-196): forward keeps every layer
  * input / normalised activation in `ws` (DPOSER_WS_TRAIN layout); backward consumes the same `ws`.

@@ -33,3 +33,26 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def tuning_env(monkeypatch):
+    """The library reads its A/B switches once per process.  ``tuning_env(NAME="1", ...)`` sets them for the running test and makes
+    the library re-read them; the switches are restored (and re-read) when the test ends."""
+    from dposer_amd import _C
+
+    def reload():
+        _C.lib().dposer_scorefc_tuning_reload()
+        _C.lib().dposer_body_tuning_reload()
+
+    def set_env(**kv):
+        for k, v in kv.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        reload()
+
+    yield set_env
+    monkeypatch.undo()
+    reload()

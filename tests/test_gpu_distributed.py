@@ -19,18 +19,33 @@ def _free_port():
 
 
 def test_grad_buckets_partition_the_flat_buffer():
+    """L + 1 buckets in backward completion order: layers 4..1 (the first with post_dense), layer 0's weights ("front A"), then layer
+    0's GroupNorm affine + the shared time embedding ("front B").  Together they cover every parameter that gets a gradient, once;
+    the dead pre_dense_cond range lies between front A and front B and belongs to no bucket (it is not all-reduced)."""
     from gpu_common import make_model
     cfg, m, p = make_model(3, precision="fp32", dropout=0.0)
     eng = m._engine()
     b = eng.grad_buckets
-    assert len(b) == 5
-    assert b[0][1] == eng.num_params and b[-1][0] == 0
-    for (lo, hi), (lo2, hi2) in zip(b[:-1], b[1:]):
+    assert len(b) == 6
+    assert b[0][1] == eng.num_params and b[4][0] == 0
+    for (lo, hi), (lo2, hi2) in zip(b[:4], b[1:4]):
         assert lo < hi and hi2 == lo                     # descending, contiguous, disjoint
     names = [n for n, _ in m.named_parameters()]
     off = dict(zip(names, m._offsets))
     assert b[0][0] == off["b2_dense2.weight"] and b[1][0] == off["b2_dense1.weight"]
-    assert b[3][0] == off["b1_dense1.weight"] == b[4][1]
+    assert b[3][0] == off["b1_dense1.weight"] == b[5][1]
+    assert b[4] == (0, off["pre_dense_cond.weight"])
+    assert b[5][0] == off["pre_gnorm.weight"]
+    covered = torch.zeros(eng.num_params, dtype=torch.int32)
+    for lo, hi in b:
+        covered[lo:hi] += 1
+    dead = torch.zeros(eng.num_params, dtype=torch.bool)
+    for lo, hi in eng.nograd:
+        dead[lo:hi] = True
+    assert int(covered.max()) == 1
+    assert bool((covered[~dead] == 1).all())             # every live parameter in exactly one bucket
+    lo_c, hi_c = off["pre_dense_cond.weight"], off["pre_gnorm.weight"]
+    assert int(covered[lo_c:hi_c].sum()) == 0            # the dead range travels nowhere
 
 
 def _steps(model_seed, batch, t, z, n_steps, world, rank, precision, likelihood_weighting=False):
@@ -73,15 +88,15 @@ def _worker(rank, world, port, q, model_seed, batch, t, z, n_steps, precision="f
 
 
 @pytest.mark.parametrize("precision,batched", [("fp32", None), ("bf16", "0"), ("bf16", "1"), ("bf16", "layer-lanes")])
-def test_two_rank_bucketed_step_equals_single_process_step(precision, batched, monkeypatch):
+def test_two_rank_bucketed_step_equals_single_process_step(precision, batched, tuning_env):
     """Mean-reduced DSM loss over equal shards: the averaged shard gradients are the full-batch gradient, so two ranks
     (bucketed all-reduce overlapped with the backward pass) must track the single-process run on the whole batch.
     bf16: with two split-K weight-gradient launches per layer (DPOSER_WGRAD_BATCHED=0), with the one-launch form forced (=1: every
     bucket event is recorded after the last reduction) and with one lane launch per layer (the default under data parallelism from 16384 samples per rank)."""
     if batched == "layer-lanes":
-        monkeypatch.setenv("DPOSER_WGRAD_LAYER_LANES", "1")          # (default from 16384 samples per rank; forced for this small batch)
+        tuning_env(DPOSER_WGRAD_LAYER_LANES="1")          # (default from 16384 samples per rank; forced for this small batch)
     elif batched is not None:
-        monkeypatch.setenv("DPOSER_WGRAD_BATCHED", batched)          # (spawned ranks inherit the environment)
+        tuning_env(DPOSER_WGRAD_BATCHED=batched)          # (spawned ranks inherit the environment)
     rs = np.random.RandomState(5)
     n_steps, B = 3, 256
     batch = torch.tensor(rs.standard_normal((n_steps, B, 63)).astype(np.float32))

@@ -615,7 +615,7 @@ def test_alternative_tilings_and_streams_keep_parity(env):
 
 
 @pytest.mark.parametrize("B", [8192, 5000, 32768])
-def test_batched_weight_gradient_launch_matches_the_per_layer_launches(B, monkeypatch):
+def test_batched_weight_gradient_launch_matches_the_per_layer_launches(B, tuning_env):
     """One launch for every 256x256 weight-gradient tile of the step (wgrad_batch.h: 16 lanes x 16 workgroups over a line of lane
     problems, partial tiles reduced in a fixed order) against two split-K launches per layer: same products, another partition of the
     sample sum -- the flat gradients agree to fp32 summation error, and the batched form is deterministic."""
@@ -626,7 +626,7 @@ def test_batched_weight_gradient_launch_matches_the_per_layer_launches(B, monkey
     x = _dev(rs.standard_normal((B, 63)).astype(np.float32))
     grads = {}
     for tag, flag in (("per-layer", "0"), ("batched", "1"), ("batched-again", "1")):
-        monkeypatch.setenv("DPOSER_WGRAD_BATCHED", flag)
+        tuning_env(DPOSER_WGRAD_BATCHED=flag)
         fg = torch.full((m._engine().num_params,), float("nan"), device=DEV)
         loss = losses.fused_dsm_grad(m, sde, x, flat_grad=fg, seed=3, step=7)
         grads[tag] = (fg.clone(), float(loss))
@@ -790,7 +790,7 @@ def test_other_model_configurations_vs_oracle(n_blocks, E, n_poses, pose_dim, sb
     m.to(DEV).eval()
     p = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     p["sigmas"] = R.sigma_table()
-    assert len(m._engine().grad_buckets) == 1 + 2 * n_blocks
+    assert len(m._engine().grad_buckets) == 2 + 2 * n_blocks          # layers L-1..1, front A, front B
     rs = np.random.RandomState(n_blocks)
     x = rs.standard_normal((B, D)).astype(np.float32)
     t = rs.uniform(1e-3, 1.0, B).astype(np.float32)
