@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 GLOBAL_BATCH = 65536
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
-DOMINANT_KIND = "gn_fwd_train"      # the GEMM kind with the largest share of the training step (profiles/r01_bench_kernel_stats.md)
+FALLBACK_KIND = "gn_fwd_train"      # (only if the untimed all-kinds pass below records nothing)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -70,6 +70,19 @@ def pmc_fk_bytes_per_pose():
         row = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))["k_fk_joints_dma<KinSMPLX>"]
         poses = (23 * (1 << 20) + 12 * (1 << 22)) / 35.0
         return (row["read_MB"] + row["write_MB"]) * 1e6 / poses if row["launches"] == 35 else None
+    except Exception:
+        return None
+
+
+LBS_FWD_KERNELS = ("k_fk", "k_split_pf", "gemm_ft_kernel<bf16,256x256,EpiWgrad>", "k_skin", "k_extra_joints")
+
+
+def pmc_lbs_bytes(with_backward):
+    """HBM bytes of one LBS call from the committed PMC passes (profiles/pmc_lbs_traffic.json, written by tools/lbs_pmc.sh: per-kernel
+    FETCH_SIZE / WRITE_SIZE of a 4096-pose call, summed); None if absent."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_lbs_traffic.json")))
+        return table["fwd_bwd_bytes" if with_backward else "fwd_bytes"]
     except Exception:
         return None
 
@@ -240,6 +253,21 @@ def main():
 
     for _ in range(args.warmup):
         step_fn(state, batch)
+    # which GEMM kind dominates the step?  Decided HERE, by an untimed pass with events around every GEMM launch (two steps), not by a
+    # constant from an old profile: the kind with the largest total time is the one the timed region brackets
+    torch.cuda.synchronize()
+    _C.profile_enable(True)
+    for _ in range(2):
+        step_fn(state, batch)
+    torch.cuda.synchronize()
+    pre = _C.profile_collect()
+    _C.profile_enable(False)
+    dominant_kind = FALLBACK_KIND
+    if pre:
+        dominant_name = max(pre.items(), key=lambda kv: kv[1][0])[0]
+        for kname in _C.PROFILE_EPI_KINDS:
+            if dominant_name.rstrip(">").endswith("," + kname):
+                dominant_kind = kname
     ddp.barrier()
     torch.cuda.synchronize()
     # live roofline: HIP events around the launches of the dominant GEMM kind only (bracketing all ~30 GEMM launches of a
@@ -250,7 +278,7 @@ def main():
         if args.no_live_roofline:
             pass
         elif i % 4 == 0:
-            _C.profile_enable(True, only=DOMINANT_KIND)
+            _C.profile_enable(True, only=dominant_kind)
         elif i % 4 == 1:
             _C.profile_pause()
         out = step_fn(state, batch)
@@ -288,6 +316,17 @@ def main():
                     "traffic_source": "lookup: profiles/pmc_hbm_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                       "command, tools/profile_bench.sh); NOT measured in this run", "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3,
                     "flops_per_launch": fl / cnt, "gemm_time_share_of_step": tot_ms / 3 / ms_per_step}
+        # the big kernel furthest below the roofline (>= 5 % of the GEMM time of the step), from the untimed all-kinds pass
+        big = {k: v for k, v in kernels.items() if v["share_of_gemm_time"] >= 0.05 and v["tflops"]}
+        if big:
+            wname = min(big, key=lambda k: big[k]["tflops"])
+            roofline["worst"] = {"kernel": wname, "achieved": big[wname]["tflops"], "frac": big[wname]["tflops"] / MFMA_BF16_PEAK_TFLOPS,
+                                 "avg_launch_us": big[wname]["avg_us"], "launches": big[wname]["launches"],
+                                 "share_of_gemm_time": big[wname]["share_of_gemm_time"], "measured": "HIP events around every GEMM launch of 3 untimed steps"}
+            wm = pmc_mfma(wname)
+            if wm:
+                roofline["worst"].update(wm)
+        roofline["kernel_chosen_by"] = "largest total GEMM time in an untimed all-kinds pass of this run (2 steps, HIP events around every launch)"
         mf = pmc_mfma(name)
         if mf:
             roofline.update(mf)
@@ -373,22 +412,25 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fk_runs = []
-        for _rep in range(3):                # best of three runs (the first launches after an idle synchronize() see lower clocks)
+        for _rep in range(5):                # (the first launches after an idle synchronize() see lower clocks: every run is reported)
             e0.record()
             for _ in range(20):
                 bm.fk_joints(pose)
             e1.record()
             torch.cuda.synchronize()
             fk_runs.append(e0.elapsed_time(e1) * 1e-3 / 20)
-        fk_s = min(fk_runs)
+        fk_s = sorted(fk_runs)[len(fk_runs) // 2]          # median of the runs is the headline; mean and best are reported beside it
         fk_gbs = 516.0 * nfk / fk_s / 1e9
         extra["fk_joints"] = {"poses_per_s_per_gpu": nfk / fk_s, "batch": nfk,
+                              "poses_per_s_mean_of_runs": nfk / (sum(fk_runs) / len(fk_runs)), "poses_per_s_best_run": nfk / min(fk_runs),
                               "roofline": {"bound": "hbm", "kernel": "k_fk_joints_dma<KinSMPLX>", "achieved": fk_gbs, "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": fk_gbs / HBM_PEAK_GBS,
                                            "traffic": None if pmc_fk_bytes_per_pose() is None else pmc_fk_bytes_per_pose() * nfk,
                                            "traffic_source": "lookup: profiles/pmc_hbm_traffic.json (bytes per pose x 2^20); NOT measured in this run",
                                            "algorithmic_bytes_per_pose": 516, "avg_launch_us": fk_s * 1e6,
-                                           "measured": "HIP events on the launch stream around 20 launches of 2^20 poses, best of three runs",
+                                           "measured": "HIP events on the launch stream around 20 launches of 2^20 poses; median of five runs (all in runs_us)",
+                                           "frac_mean_of_runs": 516.0 * nfk / (sum(fk_runs) / len(fk_runs)) / 1e9 / HBM_PEAK_GBS,
+                                           "frac_best_run": 516.0 * nfk / min(fk_runs) / 1e9 / HBM_PEAK_GBS,
                                            "runs_us": [round(x * 1e6, 2) for x in fk_runs]}}
         # the same kernel on a 4x larger batch (4 GiB of poses + joints in HBM): launch tails and the ragged last wave weigh less
         nfk4 = 1 << 22
@@ -428,7 +470,7 @@ def main():
             for _ in range(3):
                 lbs_fwd_bwd(grad)
             torch.cuda.synchronize()
-            # (best of three runs of ten: the first calls after an idle synchronize() run at a lower clock -- 0.81 against 0.74 ms forward)
+            # (three runs of ten, median reported, every run listed: the first calls after an idle synchronize() run at a lower clock)
             secs = []
             for _rep in range(3):
                 e0.record()
@@ -437,9 +479,38 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 secs.append(e0.elapsed_time(e1) * 1e-3 / 10)
-            sec = min(secs)
-            extra["lbs_full_fwd_bwd" if grad else "lbs_full_fwd"] = {"poses_per_s_per_gpu": nl / sec, "batch": nl, "ms": sec * 1e3,
-                                                                     "runs_ms": [round(x * 1e3, 4) for x in secs]}
+            sec = sorted(secs)[len(secs) // 2]
+            # HBM roofline of the leg: the vertices + joints a pose must produce (10475 x 3 + 127 x 3 floats = 127.2 KB) -- the forward's
+            # algorithmic bytes; forward + backward also reads the incoming vertex / joint gradients of the same size
+            alg = (10475 * 3 + 127 * 3) * 4 * (2 if grad else 1) + 63 * 4 * (2 if grad else 1)
+            gbs = alg * nl / sec / 1e9
+            key = "lbs_full_fwd_bwd" if grad else "lbs_full_fwd"
+            extra[key] = {"poses_per_s_per_gpu": nl / sec, "batch": nl, "ms": sec * 1e3, "ms_mean_of_runs": sum(secs) / len(secs) * 1e3,
+                          "ms_best_run": min(secs) * 1e3, "runs_ms": [round(x * 1e3, 4) for x in secs],
+                          "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                       "algorithmic_bytes_per_pose": alg, "traffic": pmc_lbs_bytes(grad),
+                                       "traffic_source": "lookup: profiles/pmc_hbm_traffic.json (sum over the LBS kernels of one call); NOT measured in this run",
+                                       "note": "the leg is several kernels (FK, pose-blend GEMM on the bf16 matrix pipe, skinning): `achieved` is the "
+                                               "algorithmic output bytes over the whole leg's time, median of the runs"}}
+        # the same forward + backward the way a loss on the outputs reaches it ((v.sum() + Jtr.sum()).backward(): torch's reduction and the
+        # materialisation of its stride-0 gradient are inside the timed region) -- the measurement of rounds 1-2, kept comparable
+        def lbs_loss_backward():
+            out = bm(pose_body=pb)
+            (out.v.sum() + out.Jtr.sum()).backward()
+            pb.grad = None
+        for _ in range(3):
+            lbs_loss_backward()
+        torch.cuda.synchronize()
+        secs = []
+        for _rep in range(3):
+            e0.record()
+            for _ in range(10):
+                lbs_loss_backward()
+            e1.record()
+            torch.cuda.synchronize()
+            secs.append(e0.elapsed_time(e1) * 1e-3 / 10)
+        extra["lbs_full_fwd_bwd_through_loss_backward"] = {"ms_mean_of_runs": sum(secs) / len(secs) * 1e3, "runs_ms": [round(x * 1e3, 4) for x in secs],
+                                                           "poses_per_s_per_gpu": nl / (sum(secs) / len(secs)), "batch": nl}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

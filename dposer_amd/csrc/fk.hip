@@ -647,6 +647,7 @@ struct BodyTuning {
     bool lbs_bwd_big = true;              // DPOSER_LBS_BWD_BIG=0: 128x128 tiles for the blend-gradient GEMMs at every batch size (A/B)
     bool fk_dma = true;                   // DPOSER_FK_DMA=0: joints-only body query through k_fk_joints instead of k_fk_joints_dma (A/B)
     int lbs_bwd_panel_order = 1;          // DPOSER_LBS_BWD_PANEL_ORDER=0: generic block -> tile order for the blend-gradient GEMMs (A/B)
+    bool lbs_k_prefix = true;             // DPOSER_LBS_K_PREFIX=0: blend GEMMs over all padded pose-feature columns, posed or not (A/B)
     void load() {
         const char* e = getenv("DPOSER_FK_SMALL_MAX");
         fk_small_max = e ? atoll(e) : (int64_t)8192;
@@ -662,6 +663,8 @@ struct BodyTuning {
         lbs_bwd_big = !(e && e[0] == '0');
         e = getenv("DPOSER_FK_DMA");
         fk_dma = !(e && e[0] == '0');
+        e = getenv("DPOSER_LBS_K_PREFIX");
+        lbs_k_prefix = !(e && e[0] == '0');
         e = getenv("DPOSER_LBS_BWD_PANEL_ORDER");
         lbs_bwd_panel_order = (e && e[0] == '0') ? 0 : 1;
     }
@@ -1051,8 +1054,8 @@ __global__ void __launch_bounds__(256) k_extra_joints(ExtraArgs a) {
 // are <= 2^-16 of each product: the offsets (centimetres) move by < 1e-6 m, vertices agree with the fp64 oracle to ~1e-6
 // (tests/test_gpu_fk.py; the bar is 1e-5).  DPOSER_LBS_BLEND=fp32 selects the exact-fp32 chain (both packings are kept).
 static bool lbs_blend_fp32() { return body_tuning().blend_fp32; }
-// FT32 [Bpad][K] -> FT bf16 [Bpad][3K] = [hi | hi | lo]
-__global__ void __launch_bounds__(256) k_split_pf(const float* __restrict__ pf, __bf16* __restrict__ out, int64_t Bpad, int K) {
+// FT32 [Bpad][Kin] (its first K columns) -> FT bf16 [Bpad][3K] = [hi | hi | lo]
+__global__ void __launch_bounds__(256) k_split_pf(const float* __restrict__ pf, __bf16* __restrict__ out, int64_t Bpad, int Kin, int K) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 8-element chunk of the bf16 layout
     const int chunks = K / 8;
     if (i >= Bpad * chunks) return;
@@ -1061,7 +1064,7 @@ __global__ void __launch_bounds__(256) k_split_pf(const float* __restrict__ pf, 
     __bf16 hi[8], lo[8];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(pf + FT<float>::index(b, k0 + 4 * q, K));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pf + FT<float>::index(b, k0 + 4 * q, Kin));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const __bf16 h = (__bf16)v[r];
@@ -1075,6 +1078,21 @@ __global__ void __launch_bounds__(256) k_split_pf(const float* __restrict__ pf, 
     *reinterpret_cast<u32x4*>(out + FT<__bf16>::index(b, 2 * K + k0, 3 * K)) = L;
 }
 
+// Pose-feature columns that can be non-zero: joint I >= 1 owns columns [(I-1) 9, I 9) (pose_feature = R_I - 1); a NULL pose segment is
+// the identity rotation (smplx's default zeros), its columns are exactly zero.  The fitting loops and the benchmarks pose the BODY only
+// (joints 1..21 of 55: hands, jaw and eyes stay NULL), so the pose-blend GEMM reduces over 192 of its 512 padded columns and the
+// blend-gradient GEMMs produce 256 of theirs -- adding exact zeros changes no bit of the result, skipping them saves 62 % / 50 % of the
+// two largest GEMMs of the body model.  (`want` = the segment's gradient pointers for the backward; null: the pose pointers.)
+static int lbs_posed_cols(const float* const* segs, const int32_t* seg_joints, int nseg, int J, const float* const* want = nullptr) {
+    int first = 0, last = 0;
+    for (int i = 0; i < nseg; ++i) {
+        const bool on = want ? (want[i] != nullptr && segs[i] != nullptr) : segs[i] != nullptr;
+        if (on && seg_joints[i] > 0) last = first + seg_joints[i] - 1;
+        first += seg_joints[i];
+    }
+    if (last > J - 1) last = J - 1;
+    return last * 9;
+}
 static int64_t lbs_pad_batch(int64_t B) { return round_up(B, 128); }
 static int lbs_ppad(int J) { return (int)round_up((J - 1) * 9, 32); }
 static int64_t lbs_cpad(int V) { return round_up((int64_t)V * 3, 128); }
@@ -1156,21 +1174,25 @@ static int lbs_forward_front(dposer_body_t h, void* ws, const void* posedirs_pac
         WgradParams wp;
         wp.slab = offsets; wp.slab_stride = 0; wp.ld = (int)Cpad; wp.N_valid = (int)batch; wp.K_valid = V * 3;
         g.ksplit = 1;
+        // K prefix: the columns of the joints that are posed (lbs_posed_cols), in whole 32-column stages, at least one
+        int Keff = body_tuning().lbs_k_prefix ? (int)round_up(lbs_posed_cols(pose_segments_host, segment_joints_host, num_segments, J), 32) : Ppad;
+        Keff = Keff < 32 ? 32 : (Keff > Ppad ? Ppad : Keff);
         if (lbs_blend_fp32()) {
             g.W = pf; g.w_stride_blocks = Ppad / 8; g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(Cpad / 128);
-            g.src[0] = posedirs_packed; g.seg_kblocks[0] = Ppad / 8; g.nseg = 1; g.ktot_blocks = Ppad / 8;
+            g.src[0] = posedirs_packed; g.seg_kblocks[0] = Keff / 8; g.seg_stride_blocks[0] = Ppad / 8; g.nseg = 1; g.ktot_blocks = Keff / 8;
             FK_HIP_LAUNCH(gemm_wgrad(PREC_FP32, SHAPE_MID, g, wp, st));
         } else {
-            hipLaunchKernelGGL(k_split_pf, dim3((unsigned)ceil_div(Bpad * (Ppad / 8), 256)), dim3(256), 0, st, (const float*)pf, pf_split, Bpad, Ppad);
+            hipLaunchKernelGGL(k_split_pf, dim3((unsigned)ceil_div(Bpad * (Keff / 8), 256)), dim3(256), 0, st, (const float*)pf, pf_split, Bpad, Ppad, Keff);
             FK_HIP_LAUNCH(hipGetLastError());
             const char* hi = (const char*)posedirs_packed + Cpad * Ppad * 4;
             const char* lo = hi + Cpad * Ppad * 2;
-            const int kb = Ppad / 16;
+            const int kb = Ppad / 16, kbe = Keff / 16;
             const int shape = (Bpad % 256 == 0 && Cpad % 256 == 0 && Bpad >= 1024) ? SHAPE_BIG : SHAPE_MID;
             const int tile = shape == SHAPE_BIG ? 256 : 128;
-            g.W = pf_split; g.w_stride_blocks = 3 * kb; g.n_cblk = (int)(Bpad / tile); g.n_sblk = (int)(Cpad / tile);
+            g.W = pf_split; g.w_stride_blocks = 3 * kbe; g.n_cblk = (int)(Bpad / tile); g.n_sblk = (int)(Cpad / tile);
             g.src[0] = hi; g.src[1] = lo; g.src[2] = hi;                        // [pf_hi | pf_hi | pf_lo] x [hi ; lo ; hi]
-            g.seg_kblocks[0] = g.seg_kblocks[1] = g.seg_kblocks[2] = kb; g.nseg = 3; g.ktot_blocks = 3 * kb;
+            g.seg_kblocks[0] = g.seg_kblocks[1] = g.seg_kblocks[2] = kbe; g.nseg = 3; g.ktot_blocks = 3 * kbe;
+            g.seg_stride_blocks[0] = g.seg_stride_blocks[1] = g.seg_stride_blocks[2] = kb;      // (rows of the packed posedirs keep their full width)
             FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, shape, g, wp, st));
         }
     }
@@ -1956,6 +1978,7 @@ struct FkBwdArgs {
     int64_t ld_dj;
     const float* dpf;              // [nsplit][Bpad_pf][ldpf] slabs of d loss / d pose_feature, or null
     int64_t dpf_slab, ldpf;
+    int pf_cols;                   // columns of dpf that were produced (joints beyond them get no pose gradient: their segment's output is null)
     int nsplit;
     float* djrest;                 // [B][J][3] out or null
     float* dG;                     // scratch [B][J][12]
@@ -2063,7 +2086,7 @@ __device__ __forceinline__ void fk_bwd_step(const FkBwdArgs& a, int64_t b, const
                 acc[P][4 * r + c] += dRG[3 * r] * R.m[3 * c] + dRG[3 * r + 1] * R.m[3 * c + 1] + dRG[3 * r + 2] * R.m[3 * c + 2] + dt[r] * rel[c];
             acc[P][4 * r + 3] += dt[r];
         }
-        if (a.dpf) {                               // pose feature = R_I - I for I >= 1 (slabs already summed: nsplit == 1)
+        if (a.dpf && I * 9 <= a.pf_cols) {         // pose feature = R_I - I for I >= 1 (slabs already summed: nsplit == 1)
 #pragma unroll
             for (int k = 0; k < 9; ++k) dR[k] += a.dpf[b * a.ldpf + (I - 1) * 9 + k];
         }
@@ -2204,7 +2227,7 @@ template <typename Kin> __global__ void __launch_bounds__(64) k_fk_bwd_small(FkB
         __syncthreads();
     }
     if (!on) return;
-    if (I > 0 && a.dpf) {
+    if (I > 0 && a.dpf && I * 9 <= a.pf_cols) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) dR[k] += a.dpf[b * a.ldpf + (I - 1) * 9 + k];
     }
@@ -2268,12 +2291,12 @@ static int lbs_bwd_ksplit_bf16(int64_t kblocks, int64_t tiles) {
 }
 // 256x256 tiles for the bf16 backward blend GEMMs from 2048 poses up (one 256-CU round of long-K workgroups: 3 x 110 us instead of
 // 3 x 161 us with the 128x128 tiles at 4096 poses): the split count that fills the last round best, at most 8 (24 slabs); 0 = not applicable
-static int lbs_bwd_big_ksplit(int64_t Bpad, int64_t prow, int64_t kblocks) {
+static int lbs_bwd_big_ksplit(int64_t Bpad, int64_t prow, int64_t kblocks, int max_split = 8) {
     if (!body_tuning().lbs_bwd_big || Bpad % 256 != 0 || prow % 256 != 0 || Bpad < 2048) return 0;
     const int64_t tiles = (Bpad / 256) * (prow / 256);
     int best = 0;
     double best_u = 0.0;
-    for (int c = 1; c <= 8; ++c) {
+    for (int c = 1; c <= max_split; ++c) {
         if (kblocks % (2 * c) != 0 || kblocks / c < 32) continue;
         const int64_t wg = tiles * c;
         const double u = (double)wg / (double)(256 * ceil_div(wg, 256));
@@ -2374,35 +2397,52 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         }
         FK_HIP_LAUNCH(hipGetLastError());
     }
-    // d pose_feature [B][486] = d_off [B][3V] @ posedirs^T : fp32 MFMA, split over the vertex dimension
+    // d pose_feature [B][486] = d_off [B][3V] @ posedirs^T : split over the vertex dimension.  Only the columns of joints whose pose
+    // gradient is wanted are produced (lbs_posed_cols: 189 -> 256 of 512 for the body): compact slabs [Bpad][pe], fewer column tiles
+    const int64_t slab_budget = lbs_bwd_slabs(Bpad, Cpad, prow) * Bpad * prow;      // floats reserved for the slabs
+    const int want_cols = body_tuning().lbs_k_prefix ? lbs_posed_cols(pose_segments_host, segment_joints_host, num_segments, J, (const float* const*)d_pose_segments_host)
+                                                     : (J - 1) * 9;
     const int64_t stages = Cpad / 32;
     int ks = lbs_bwd_ksplit(stages);            // number of slabs k_sum_slabs adds up below
+    int64_t pe = prow;                          // slab row length = columns produced
     if (blend32) {
+        pe = round_up(want_cols < 1 ? 1 : want_cols, 128);
+        pe = pe > prow ? prow : pe;
         GemmArgs g;
         std::memset(&g, 0, sizeof(g));
-        g.W = doff; g.w_stride_blocks = (int)(Cpad / 8); g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(prow / 128); g.ksplit = ks;
+        g.W = doff; g.w_stride_blocks = (int)(Cpad / 8); g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(pe / 128); g.ksplit = ks;
         g.src[0] = posedirs_bwd_packed; g.seg_kblocks[0] = (int)(Cpad / 8); g.nseg = 1; g.ktot_blocks = (int)(Cpad / 8);
         WgradParams wp;
-        wp.slab = dpf; wp.slab_stride = Bpad * prow; wp.ld = (int)prow; wp.N_valid = (int)batch; wp.K_valid = (J - 1) * 9;
+        wp.slab = dpf; wp.slab_stride = Bpad * pe; wp.ld = (int)pe; wp.N_valid = (int)batch; wp.K_valid = (int)((J - 1) * 9 < pe ? (J - 1) * 9 : pe);
         FK_HIP_LAUNCH(gemm_wgrad(PREC_FP32, SHAPE_MID, g, wp, st));
     } else {
         // d pf = doff_hi pd_hi^T + doff_hi pd_lo^T + doff_lo pd_hi^T: three split-K launches into consecutive slab sets
         const char* pd_hi = (const char*)posedirs_bwd_packed + prow * Cpad * 4;
         const char* pd_lo = pd_hi + prow * Cpad * 2;
         const int kb = (int)(Cpad / 16);
-        const int kbig = lbs_bwd_big_ksplit(Bpad, prow, kb);
+        // 256-wide tiles when the batch allows them: the column count rounds to 256 then (the narrower slabs pay for more splits)
+        int64_t pe_big = round_up(want_cols < 1 ? 1 : want_cols, 256);
+        pe_big = pe_big > prow ? prow : pe_big;
+        const int max_split = (int)(slab_budget / (3 * Bpad * pe_big) < 16 ? slab_budget / (3 * Bpad * pe_big) : 16);
+        const int kbig = lbs_bwd_big_ksplit(Bpad, pe_big, kb, max_split < 1 ? 1 : max_split);
+        if (kbig) pe = pe_big;
+        else {
+            pe = round_up(want_cols < 1 ? 1 : want_cols, 128);
+            pe = pe > prow ? prow : pe;
+        }
         const int tile = kbig ? 256 : 128;
-        const int k1 = kbig ? kbig : lbs_bwd_ksplit_bf16(kb, (Bpad / 128) * (prow / 128));
+        int k1 = kbig ? kbig : lbs_bwd_ksplit_bf16(kb, (Bpad / 128) * (pe / 128));
+        while (!kbig && k1 > 1 && 3 * (int64_t)k1 * Bpad * pe > slab_budget) --k1;
         for (int term = 0; term < 3; ++term) {
             GemmArgs g;
             std::memset(&g, 0, sizeof(g));
             g.W = term == 2 ? (const void*)doff_lo : (const void*)doff_hi; g.w_stride_blocks = kb;
-            g.n_cblk = (int)(Bpad / tile); g.n_sblk = (int)(prow / tile); g.ksplit = k1;
+            g.n_cblk = (int)(Bpad / tile); g.n_sblk = (int)(pe / tile); g.ksplit = k1;
             g.src[0] = term == 1 ? pd_lo : pd_hi; g.seg_kblocks[0] = kb; g.nseg = 1; g.ktot_blocks = kb;
             g.panel_order = body_tuning().lbs_bwd_panel_order;
             WgradParams wp;
-            wp.slab = dpf + (int64_t)term * k1 * Bpad * prow; wp.slab_stride = Bpad * prow; wp.ld = (int)prow; wp.N_valid = (int)batch;
-            wp.K_valid = (J - 1) * 9;
+            wp.slab = dpf + (int64_t)term * k1 * Bpad * pe; wp.slab_stride = Bpad * pe; wp.ld = (int)pe; wp.N_valid = (int)batch;
+            wp.K_valid = (int)((J - 1) * 9 < pe ? (J - 1) * 9 : pe);
             FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, kbig ? SHAPE_BIG : SHAPE_MID, g, wp, st));
         }
         ks = 3 * k1;
@@ -2421,11 +2461,11 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         DP_CHECK_ARG(first == J, "pose segments must cover all joints of the kinematic tree");
         a.nseg = num_segments; a.j_rest = j_rest; a.j_rest_batched = j_rest_batched; a.A = A; a.dA = dA; a.djoints = d_joints; a.ld_dj = d_joints_ld;
         if (ks > 1) {
-            const int64_t n4 = Bpad * prow / 4;
-            hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)(n4 < 256 * 2048 ? ceil_div(n4, 256) : 2048)), dim3(256), 0, st, dpf, Bpad * prow, ks);
+            const int64_t n4 = Bpad * pe / 4;
+            hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)(n4 < 256 * 2048 ? ceil_div(n4, 256) : 2048)), dim3(256), 0, st, dpf, Bpad * pe, ks);
             FK_HIP_LAUNCH(hipGetLastError());
         }
-        a.dpf = dpf; a.dpf_slab = Bpad * prow; a.ldpf = prow; a.nsplit = 1; a.djrest = d_jrest; a.dG = dG; a.parents = nullptr; a.J = J;
+        a.dpf = dpf; a.dpf_slab = Bpad * pe; a.ldpf = pe; a.pf_cols = (int)pe; a.nsplit = 1; a.djrest = d_jrest; a.dG = dG; a.parents = nullptr; a.J = J;
         a.B = batch;
         if (batch <= fk_small_max()) {
             const dim3 grid((unsigned)batch);

@@ -27,6 +27,8 @@ struct GemmArgs {
     const void* W;                  // packed weights, FT [Cpad][Ktot]
     const void* src[GEMM_MAX_SEG];  // activation segments, FT [Spad][Kseg]; concatenated along k
     int seg_kblocks[GEMM_MAX_SEG];  // k-blocks (of FT<T>::KBS) per segment, multiples of KB
+    int seg_stride_blocks[GEMM_MAX_SEG];   // k-blocks per row-block of the segment's ARRAY when only a K-prefix of it is reduced over
+                                    // (0: = seg_kblocks; LBS blend GEMM over the pose-feature columns of the joints that are posed)
     int nseg;
     int ktot_blocks;                // sum of seg_kblocks = k-blocks reduced over
     int w_stride_blocks;            // k-blocks per packed weight row-block (>= ktot_blocks: a K-prefix may be used)
@@ -175,9 +177,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         for (int k = 1; k < GEMM_MAX_SEG; ++k) n = (i == k) ? g.seg_kblocks[k] : n;
         return n;
     };
+    auto seg_stride_of = [&](int i) __attribute__((always_inline)) {
+        int n = g.seg_stride_blocks[0], m = g.seg_kblocks[0];
+#pragma unroll
+        for (int k = 1; k < GEMM_MAX_SEG; ++k) { n = (i == k) ? g.seg_stride_blocks[k] : n; m = (i == k) ? g.seg_kblocks[k] : m; }
+        return n > 0 ? n : m;
+    };
     int seg = 0, seg_kb = 0;   // position of the NEXT stage to fetch
     int w_kb = 0;              // weight k-block of the next stage
-    int seg_total = g.seg_kblocks[0];          // k-blocks per row-block of the current segment
+    int seg_total = g.seg_kblocks[0];          // k-blocks of the current segment
+    int seg_stride = seg_stride_of(0);         // k-blocks per row-block of the current segment's array
     int seg_end = seg_total;                   // first k-block NOT to fetch from this segment
     int nstages = g.ktot_blocks / KB;
     if (g.ksplit > 1) {
@@ -204,7 +213,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         for (int i = 0; i < C::LPW_B; ++i) {
             const int blk = wave + i * C::NW;
             const int rb = blk / KB, kb = blk % KB;
-            const unsigned char* p = sbase + (((int64_t)(sblk * C::ST + rb) * seg_total + seg_kb + kb) << 10);
+            const unsigned char* p = sbase + (((int64_t)(sblk * C::ST + rb) * seg_stride + seg_kb + kb) << 10);
             __builtin_amdgcn_global_load_lds((gptr_t)(p + lane * 16), (lptr_t)(smem + buf * C::STAGE_BYTES + ((C::CT * KB + blk) << 10)), 16, 0, 0);
         }
     };
@@ -215,6 +224,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
             ++seg;
             seg_kb = 0;
             seg_total = seg_blocks(seg);
+            seg_stride = seg_stride_of(seg);
             seg_end = seg_total;
             sbase = seg_ptr(seg);
         }
@@ -298,7 +308,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int blk = wave + i * C::NW;
-                sX[i] = sgpr_u64((uint64_t)(uintptr_t)sbase + ((uint64_t)((int64_t)(sblk * C::ST + blk / KB) * seg_total + blk % KB) << 10));
+                sX[i] = sgpr_u64((uint64_t)(uintptr_t)sbase + ((uint64_t)((int64_t)(sblk * C::ST + blk / KB) * seg_stride + blk % KB) << 10));
             }
         };
         auto advance_asm = [&]() __attribute__((always_inline)) {       // fetch_advance() for the asm address state (offsets advance in the asm)
@@ -307,6 +317,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
                 ++seg;
                 seg_kb = 0;
                 seg_total = seg_blocks(seg);
+                seg_stride = seg_stride_of(seg);
                 seg_end = seg_total;
                 sbase = seg_ptr(seg);
                 x_bases();

@@ -29,9 +29,9 @@ struct ProfScope {
         r = &g_prof.pool[g_prof.used++];
         r->kind = kind;
         r->flops = alg_flops;
-        hipEventRecord(r->a, st);
+        (void)hipEventRecord(r->a, st);
     }
-    ~ProfScope() { if (r) hipEventRecord(r->b, st); }
+    ~ProfScope() { if (r) (void)hipEventRecord(r->b, st); }
 };
 const char* kEpiNames[EPI_KINDS] = {"gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad", "post_em_step"};
 const char* kShapeNames[6] = {"256x256", "128x128", "128x32", "64x128", "64x32", "128x64"};

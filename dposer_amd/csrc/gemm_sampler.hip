@@ -31,6 +31,8 @@ __global__ void __launch_bounds__(512, 1) k_sampler_persistent(SamplerArgs a) {
             g.w_stride_blocks = ly.w_stride_blocks; g.n_cblk = a.H / 256; g.n_sblk = gridDim.x; g.ksplit = 1; g.alg_flops = 0.0;
 #pragma unroll
             for (int k = 1; k < GEMM_MAX_SEG; ++k) { g.src[k] = nullptr; g.seg_kblocks[k] = 0; }
+#pragma unroll
+            for (int k = 0; k < GEMM_MAX_SEG; ++k) g.seg_stride_blocks[k] = 0;
             GNParams p;
             p.bias = trow + l * a.H; p.gamma = ly.gamma; p.beta = ly.beta; p.out = ly.out; p.resid = ly.resid; p.xhat = nullptr; p.aux = nullptr;
             p.H = a.H; p.outT = nullptr; p.Spad = a.Spad; p.act = DP_ACT_SWISH;
@@ -53,6 +55,8 @@ __global__ void __launch_bounds__(512, 1) k_sampler_persistent(SamplerArgs a) {
             g.w_stride_blocks = a.post_kblocks; g.n_cblk = 1; g.n_sblk = 2 * gridDim.x; g.ksplit = 1; g.alg_flops = 0.0;
 #pragma unroll
             for (int k = 1; k < GEMM_MAX_SEG; ++k) { g.src[k] = nullptr; g.seg_kblocks[k] = 0; }
+#pragma unroll
+            for (int k = 0; k < GEMM_MAX_SEG; ++k) g.seg_stride_blocks[k] = 0;
             EmStepParams p = a.em;
             p.t = a.tsteps[i];
             p.step = a.step0 + (uint32_t)i;

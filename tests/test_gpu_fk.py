@@ -756,3 +756,44 @@ def test_smplx_wrapper_accepts_rotation_matrices(asset):
     assert (a.joints - b.joints).abs().max() < 2e-6 and (a.vertices - b.vertices).abs().max() < 2e-6
     with pytest.raises(ValueError):
         sm(body_pose=torch.tensor(body.reshape(B, 63), device=DEV), pose2rot=False)
+
+
+@pytest.mark.parametrize("B,segments", [(300, "body"), (2304, "body"), (300, "body+jaw"), (64, "root only")])
+def test_blend_gemms_over_the_posed_joints_only_keep_every_bit(bm, asset, B, segments, tuning_env):
+    """The pose-blend GEMM reduces over the pose-feature columns of the joints that ARE posed (a NULL segment is the identity rotation:
+    its columns of R - 1 are exact zeros) and the blend-gradient GEMMs produce the columns of the joints whose gradient is wanted --
+    192 of 512 / 256 of 512 columns when only the body is posed, as in the fitting loops.  Adding exact zeros changes no bit:
+    vertices, joints and pose gradients equal those of the full-width GEMMs (DPOSER_LBS_K_PREFIX=0) bit for bit, at the 128-wide
+    (B = 300, 64) and the 256-wide tilings (B = 2304); a posed jaw (joint 22) widens the prefix to 198 -> 224 columns."""
+    rs = np.random.RandomState(B)
+    pose = (rs.standard_normal((B, 63)) * 0.4).astype(np.float32)
+    root = (rs.standard_normal((B, 3)) * 0.4).astype(np.float32)
+    jaw = (rs.standard_normal((B, 3)) * 0.2).astype(np.float32)
+    wv = torch.tensor(rs.standard_normal((B, 10475, 3)).astype(np.float32) / 100.0, device=DEV)
+    wj = torch.tensor(rs.standard_normal((B, 127, 3)).astype(np.float32), device=DEV)
+
+    def run():
+        kw, leaves = {}, []
+        r = torch.tensor(root, device=DEV, requires_grad=True)
+        kw["root_orient"] = r
+        leaves.append(r)
+        if segments != "root only":
+            p = torch.tensor(pose, device=DEV, requires_grad=True)
+            kw["pose_body"] = p
+            leaves.append(p)
+        if segments == "body+jaw":
+            j = torch.tensor(jaw, device=DEV, requires_grad=True)
+            kw["pose_jaw"] = j
+            leaves.append(j)
+        out = bm(**kw)
+        ((out.v * wv).sum() + (out.Jtr * wj).sum()).backward()
+        return [t2n(out.v), t2n(out.Jtr)] + [t2n(x.grad) for x in leaves]
+
+    got = run()
+    tuning_env(DPOSER_LBS_K_PREFIX="0")
+    full = run()
+    for a, b in zip(got, full):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+    if segments == "body":                       # and the result is the oracle's
+        v_ref, j_ref, _, _ = fk_ref.smplx_forward(asset, pose[:16].astype(np.float64), global_orient=root[:16].astype(np.float64), dtype=np.float64)
+        assert np.abs(got[0][:16] - v_ref).max() < 1e-5
