@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdposer_hip.so")
+LIB_PATH = os.environ.get("DPOSER_LIB_PATH") or os.path.join(_HERE, "libdposer_hip.so")      # (override: the host-ASan build of the tests)
 
 PREC_BF16, PREC_FP32 = 0, 1
 EMB_POSITIONAL, EMB_FOURIER = 0, 1
@@ -110,6 +110,8 @@ SIGNATURES = {
                                                       f64, f64, i64, f64, vp, vp]),
     "dposer_adam_ema_clip_step_wd": (C.c_int, [vp, vp, vp, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64,
                                                f64, f64, f64, i64, f64, vp, i32, vp]),
+    "dposer_scorefc_adam_pack_step": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i64), i32, f64, f64, f64, f64, f64, f64, f64,
+                                                i64, f64, vp, i32, vp]),
     "dposer_profile_enable": (None, [i32]),
     "dposer_profile_num_kinds": (i32, []),
     "dposer_profile_collect": (C.c_int, [C.POINTER(f64), C.POINTER(i64), C.POINTER(f64)]),
@@ -188,6 +190,16 @@ def require_gpu(t, name="tensor"):
 
 PROFILE_EPI_KINDS = ("gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad",
                      "post_em_step")
+
+
+# Every library routine that rewrites model parameters through ``.data`` (EMA copy_to / restore, re-flattening) bumps this epoch;
+# together with the parameters' version counters it tells the engine whether the packed weights the fused optimizer step wrote are
+# still those of the parameters (engine.ScoreEngine.packed).  Code that writes ``p.data`` by other means calls ``bump_param_epoch()``.
+PARAM_EPOCH = [0]
+
+
+def bump_param_epoch():
+    PARAM_EPOCH[0] += 1
 
 
 def profile_enable(on: bool, only: str = None):

@@ -103,8 +103,10 @@ class FusedAdam(optim.Adam):
         return self._flat_g
 
     @torch.no_grad()
-    def fused_step(self, *, live, grad_clip=-1.0, grad_scale=1.0, ema: ExponentialMovingAverage = None):
-        """One optimizer update from ``self._flat_g``.  ``live[i]``: parameter i has a gradient."""
+    def fused_step(self, *, live, grad_clip=-1.0, grad_scale=1.0, ema: ExponentialMovingAverage = None, repack=None):
+        """One optimizer update from ``self._flat_g``.  ``live[i]``: parameter i has a gradient.
+        ``repack``: the model's ScoreEngine -- the update then also rewrites the engine's packed weight copies in the same pass
+        (dposer_scorefc_adam_pack_step), and the next training step finds them current instead of re-packing 33 MB."""
         flat, offs, params = self._ensure_flat()
         skip = []
         for p, o, ok in zip(params, offs, live):
@@ -125,13 +127,27 @@ class FusedAdam(optim.Adam):
             if ema_flat is None:
                 raise _C.DPoserHipError("EMA shadow parameters are not flat-backed")
             omd = ema.next_one_minus_decay()
-        _C.check(_C.lib().dposer_adam_ema_clip_step_wd(_C.ptr(flat), _C.ptr(self._flat_g), _C.ptr(self._flat_m), _C.ptr(self._flat_v),
-                                                       _C.ptr(ema_flat), flat.numel(), lo, hi, len(skip), float(g["lr"]),
-                                                       float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                                       float(g.get("weight_decay", 0.0)), float(grad_clip), float(grad_scale),
-                                                       self._step_count, float(omd), _C.ptr(self._scratch), 0, _C.stream_ptr()),
-                 "dposer_adam_ema_clip_step_wd")
+        target = None
+        if repack is not None and os.environ.get("DPOSER_ADAM_REPACK", "1") != "0" and flat.numel() == repack.num_params:
+            target = repack.repack_target(flat)
+        if target is not None:
+            _C.check(_C.lib().dposer_scorefc_adam_pack_step(repack.h, _C.ptr(flat), _C.ptr(self._flat_g), _C.ptr(self._flat_m),
+                                                            _C.ptr(self._flat_v), _C.ptr(ema_flat), _C.ptr(target), lo, hi, len(skip),
+                                                            float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                                            float(g.get("weight_decay", 0.0)), float(grad_clip), float(grad_scale),
+                                                            self._step_count, float(omd), _C.ptr(self._scratch), 0, _C.stream_ptr()),
+                     "dposer_scorefc_adam_pack_step")
+        else:
+            _C.check(_C.lib().dposer_adam_ema_clip_step_wd(_C.ptr(flat), _C.ptr(self._flat_g), _C.ptr(self._flat_m), _C.ptr(self._flat_v),
+                                                           _C.ptr(ema_flat), flat.numel(), lo, hi, len(skip), float(g["lr"]),
+                                                           float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                                           float(g.get("weight_decay", 0.0)), float(grad_clip), float(grad_scale),
+                                                           self._step_count, float(omd), _C.ptr(self._scratch), 0, _C.stream_ptr()),
+                     "dposer_adam_ema_clip_step_wd")
         torch.autograd.graph.increment_version(params)   # the kernel wrote the parameters through raw pointers: tell autograd
+        if target is not None:                           # (after the version bump: the key describes the state the copies were made from)
+            from ...engine import param_state_key
+            repack.mark_packed_by_optimizer(param_state_key(flat, params))
         self._publish_state(params, offs, live)
 
     def _publish_state(self, params, offs, live):
@@ -363,9 +379,11 @@ def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, se
     event)`` the call itself announces every group of final buckets (one event + merged flat ranges) while it is still queueing
     the rest of the backward pass (distributed.StreamedAllReduce)."""
     _C.require_gpu(batch, "training batch")
+    from ...engine import param_state_key
     eng = model._engine()
     flat = model.flat_params()
-    packed = eng.packed(flat, with_backward=True, force=True)
+    # (a key equal to the one the fused optimizer step left behind: it wrote these copies itself, nothing to launch)
+    packed = eng.packed(flat, with_backward=True, force=True, state_key=param_state_key(flat, model._param_list))
     B = batch.shape[0]
     ws = eng.workspace(B, _C.WS_TRAIN, 0, batch.device)
     loss = torch.empty(1, dtype=torch.float32, device=batch.device)
@@ -591,7 +609,7 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
                 world = 1
             optimize_fn.warm_lr(optimizer, state["step"])                           # losses.py:51-53
             live = _live_params(model)
-            optimizer.fused_step(live=live, grad_clip=optimize_fn.grad_clip, grad_scale=1.0 / world, ema=state["ema"])
+            optimizer.fused_step(live=live, grad_clip=optimize_fn.grad_clip, grad_scale=1.0 / world, ema=state["ema"], repack=model._engine())
             state["step"] += 1
             return {"step_loss": loss, "score_loss": loss}
         from ... import distributed as ddp

@@ -9,6 +9,11 @@ shadow parameters are views of one flat shadow buffer too, so the fused Adam/EMA
 import torch
 
 
+def _bump_param_epoch():
+    from .. import _C
+    _C.bump_param_epoch()
+
+
 def flat_base(params):
     """(flat tensor, offsets) if ``params`` are consecutive fp32 views of one storage, else (None, None)."""
     params = list(params)
@@ -71,6 +76,7 @@ class ExponentialMovingAverage:
         params = [p for p in parameters if p.requires_grad]
         for s, p in zip(self.shadow_params, params):
             p.data.copy_(s.data)
+        _bump_param_epoch()                    # (.data writes are invisible to version counters: packed weights are stale now)
 
     def store(self, parameters):
         """Remember the current parameter values (ema.py:66-75)."""
@@ -80,6 +86,7 @@ class ExponentialMovingAverage:
         """Write back what ``store`` remembered (ema.py:77-89)."""
         for c, p in zip(self.collected_params, parameters):
             p.data.copy_(c.data)
+        _bump_param_epoch()
 
     def state_dict(self):
         return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)

@@ -24,17 +24,20 @@ template <typename T> __device__ __forceinline__ void store_quad_ft(void* base, 
 // inside the instruction's +-256 domain; the fp32 product arg * (1/2pi) is off by <= 1e-5 revolutions (6e-5 rad), two orders
 // below the bf16 rounding of the stored embedding.  The fp32 parity mode keeps libm sinf / cosf.
 template <bool FAST = false>
-__device__ __forceinline__ float temb_value(float label, int e, int E, const float* freq, int fourier) {
-    const int half = E >> 1;
-    const int k = e < half ? e : e - half;
+__device__ __forceinline__ float temb_from_freq(float label, bool sin_half, float f, int fourier) {
     float arg;
-    if (fourier) arg = ((logf(label) * freq[k]) * 2.0f) * 3.14159274101257324f;
-    else arg = label * freq[k];
+    if (fourier) arg = ((logf(label) * f) * 2.0f) * 3.14159274101257324f;
+    else arg = label * f;
     if (FAST && !fourier) {
         const float rev = arg * 0.15915494309189535f;
-        return e < half ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
+        return sin_half ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
     }
-    return e < half ? sinf(arg) : cosf(arg);
+    return sin_half ? sinf(arg) : cosf(arg);
+}
+template <bool FAST = false>
+__device__ __forceinline__ float temb_value(float label, int e, int E, const float* freq, int fourier) {
+    const int half = E >> 1;
+    return temb_from_freq<FAST>(label, e < half, freq[e < half ? e : e - half], fourier);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -202,13 +205,23 @@ template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTr
         } else {
             const int g0 = (int)((i - nx) / a.Bpad) * PREP_EQ;
             const float label = t * 999.0f;                 // utils.py:152
+            // all 32 frequencies first: behind a store to `emb` hipcc cannot hoist the next load of `freq` (the two may alias), and the
+            // thread walked 32 dependent load -> sin -> store round trips -- 17 us of the kernel at ANY batch size
+            const int half = a.E >> 1;
+            f32x4 fr[PREP_EQ];
+#pragma unroll
+            for (int k = 0; k < PREP_EQ; ++k) {
+                const int e = (g0 + k) * 4;
+                fr[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (e < a.E) fr[k] = *reinterpret_cast<const f32x4*>(a.freq + (e < half ? e : e - half));      // (E / 2 is a multiple of 4)
+            }
 #pragma unroll
             for (int k = 0; k < PREP_EQ; ++k) {
                 const int e = (g0 + k) * 4;
                 if (e < a.E) {
                     f32x4 v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = temb_value<sizeof(T) == 2>(label, e + r, a.E, a.freq, a.fourier);
+                    for (int r = 0; r < 4; ++r) v[r] = temb_from_freq<sizeof(T) == 2>(label, e < half, fr[k][r], a.fourier);
                     store_quad_ft<T>(a.emb, s, e, a.E, v);
                 }
             }
@@ -962,7 +975,34 @@ hipError_t launch_sqnorm(const float* g, int64_t n, float* part, int* nblocks, h
 // is dropped on the device -- parameters, moments and EMA stay as they were -- and counted in sqnorm[1], which the host reads
 // when it wants to (FusedAdam.nonfinite_steps()), not every step.
 // (the counter update rides in the first thread of the optimizer kernel: one launch less in a step whose tail is latency-bound)
-__global__ void __launch_bounds__(256) k_adam_ema(AdamArgs a) {
+// one element of the update (losses.py:44-58 + torch.optim.Adam + ema.py:51); returns the new parameter value
+__device__ __forceinline__ float adam_math(const AdamArgs& a, float coef, bool skip, float p, float g, float& m, float& v, float& s) {
+    if (!skip) {
+        g = g * coef;
+        if (a.weight_decay != 0.f) g = g + a.weight_decay * p;   // torch.optim.Adam: grad = grad.add(param, alpha=weight_decay)
+        m = m + (g - m) * a.one_minus_beta1;                      // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * a.beta2 + a.one_minus_beta2 * (g * g);            // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        p = p - a.step_size * (m / denom);                        // param.addcdiv_(exp_avg, denom, value=-step_size)
+    }
+    s = s - a.ema_one_minus_decay * (s - p);                      // ema.py:51  s -= (1 - decay) * (s - p)
+    return p;
+}
+__device__ __forceinline__ bool adam_skip(const AdamArgs& a, int64_t i) {
+    return (i >= a.skip_lo[0] && i < a.skip_hi[0]) || (i >= a.skip_lo[1] && i < a.skip_hi[1]);
+}
+__device__ __forceinline__ float adam_elem(const AdamArgs& a, float coef, int64_t i) {
+    const bool skip = adam_skip(a, i);
+    float p = a.p[i], m = 0.f, v = 0.f, g = 0.f, s = 0.f;
+    if (!skip) { g = a.g[i]; m = a.m[i]; v = a.v[i]; }
+    if (a.ema) s = a.ema[i];
+    p = adam_math(a, coef, skip, p, g, m, v, s);
+    if (!skip) { a.m[i] = m; a.v[i] = v; a.p[i] = p; }
+    if (a.ema) a.ema[i] = s;
+    return p;
+}
+// squared gradient norm + clip coefficient shared by the two optimizer kernels; false: non-finite gradient, the step is dropped
+__device__ __forceinline__ bool adam_prologue(const AdamArgs& a, float& coef) {
     // squared gradient norm: given (sqnorm[0]: the sharded step all-reduces it), or the per-block partials of k_sqnorm, which every
     // block adds up itself in k_sum_partials' order (n_part <= 1024 floats from L2: cheaper than the one-block launch it replaces)
     float sq;
@@ -976,40 +1016,136 @@ __global__ void __launch_bounds__(256) k_adam_ema(AdamArgs a) {
     }
     if (!isfinite(sq)) {
         if (blockIdx.x == 0 && threadIdx.x == 0) a.sqnorm[1] += 1.0f;
-        return;
+        return false;
     }
     // clip_grad_norm_ (losses.py:54-55): coef = max_norm / (total_norm + 1e-6), clamped to 1
-    float coef = a.grad_scale;
+    coef = a.grad_scale;
     if (a.grad_clip >= 0.f) {
         const float total_norm = sqrtf(sq) * a.grad_scale;
         float cc = a.grad_clip / (total_norm + 1e-6f);
         cc = cc > 1.0f ? 1.0f : cc;
         coef = a.grad_scale * cc;
     }
-    const float step_size = a.step_size;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
-        float p = a.p[i];
-        const bool skip = (i >= a.skip_lo[0] && i < a.skip_hi[0]) || (i >= a.skip_lo[1] && i < a.skip_hi[1]);
-        if (!skip) {
-            float g = a.g[i] * coef;
-            if (a.weight_decay != 0.f) g = g + a.weight_decay * p;   // torch.optim.Adam: grad = grad.add(param, alpha=weight_decay)
-            float m = a.m[i], v = a.v[i];
-            m = m + (g - m) * a.one_minus_beta1;                  // exp_avg.lerp_(grad, 1 - beta1)
-            v = v * a.beta2 + a.one_minus_beta2 * (g * g);        // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
-            const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-            p = p - step_size * (m / denom);                      // param.addcdiv_(exp_avg, denom, value=-step_size)
-            a.m[i] = m;
-            a.v[i] = v;
-            a.p[i] = p;
-        }
-        if (a.ema) {                                              // ema.py:51  s -= (1 - decay) * (s - p)
-            const float s = a.ema[i];
-            a.ema[i] = s - a.ema_one_minus_decay * (s - p);
-        }
-    }
+    return true;
+}
+__global__ void __launch_bounds__(256) k_adam_ema(AdamArgs a) {
+    float coef;
+    if (!adam_prologue(a, coef)) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) adam_elem(a, coef, i);
 }
 hipError_t launch_adam_ema(const AdamArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_adam_ema, dim3(grid_for(a.n, 256, 4096)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+// ---- Adam + EMA + re-pack of the changed weights (kernels_api.h: AdamPackArgs) -----------------------------------------------------------
+template <typename Job> __device__ __forceinline__ Job kernarg_job_at(size_t byte_off, int index) {
+    static_assert(sizeof(Job) % 4 == 0, "jobs are copied as dwords");
+    typedef const uint32_t __attribute__((address_space(4))) * ConstWords;
+    ConstWords w = (ConstWords)__builtin_amdgcn_kernarg_segment_ptr() + byte_off / 4 + (size_t)index * (sizeof(Job) / 4);
+    union { Job j; uint32_t u[sizeof(Job) / 4]; } c;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(Job) / 4; ++i) c.u[i] = w[i];
+    return c.j;
+}
+// the part of one packed copy that a 64 x 64 tile of the source covers, from the updated values in LDS
+template <typename T>
+__device__ __forceinline__ void adam_pack_dst(const AdamPackDst& d, unsigned char* packed, const float (*tile)[65], int r0, int k0) {
+    constexpr int EPL = FT<T>::EPL, KBS = FT<T>::KBS;
+    constexpr int NKB = 64 / KBS, NCH = 2 * NKB * 64;            // FT blocks along the destination columns; 16-byte chunks of the tile's image
+    T* base = reinterpret_cast<T*>(packed + d.off);
+    const int drow0 = d.trans ? k0 : r0, dcol0 = d.koff + (d.trans ? r0 : k0);
+    for (int c = threadIdx.x; c < NCH; c += 256) {
+        const int lane = c & 63, blk = c >> 6;
+        const int rb = blk / NKB, kb = blk % NKB;
+        const int dr = rb * 32 + (lane & 31), dk = kb * KBS + (lane >> 5) * EPL;        // inside the tile's 64 x 64 image of the destination
+        T vals[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) vals[e] = from_f32<T>(d.trans ? tile[dk + e][dr] : tile[dr][dk + e]);
+        *reinterpret_cast<u32x4*>(base + FT<T>::index(drow0 + dr, dcol0 + dk, d.ktot)) = *reinterpret_cast<u32x4*>(vals);
+    }
+}
+__global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs args) {
+    __shared__ float tile[64][65];
+    const AdamArgs& a = args.a;
+    float coef;
+    if (!adam_prologue(a, coef)) return;          // (dropped step: parameters and their packed copies stay as they are)
+    const int b = blockIdx.x;
+    if (b >= args.n_tiles) {
+        // element ranges: biases (pairs feed the fp32 bias table), GroupNorm affine, dead parameters
+        const int eb = b - args.n_tiles;
+        int e = 0;
+        for (int i = 1; i < args.n_elems; ++i)
+            if (eb >= kernarg_job_at<AdamPackElems>(offsetof(AdamPackArgs, elems), i).block0) e = i;
+        const AdamPackElems r = kernarg_job_at<AdamPackElems>(offsetof(AdamPackArgs, elems), e);
+        const int nblk = (e + 1 < args.n_elems ? kernarg_job_at<AdamPackElems>(offsetof(AdamPackArgs, elems), e + 1).block0 : args.n_elem_blocks) - r.block0;
+        for (int i = (eb - r.block0) * 256 + threadIdx.x; i < r.len; i += nblk * 256) {
+            const float pa = adam_elem(a, coef, r.off_a + i);
+            if (r.off_b >= 0) {
+                const float pb = adam_elem(a, coef, r.off_b + i);
+                reinterpret_cast<float*>(args.packed)[r.cat_off + i] = pa + pb;
+            }
+        }
+        return;
+    }
+    int t = 0;
+    for (int i = 1; i < args.n_tensors; ++i)
+        if (b >= kernarg_job_at<AdamPackTensor>(0, i).tile0) t = i;
+    const AdamPackTensor T = kernarg_job_at<AdamPackTensor>(0, t);
+    const int tiles_k = (T.K + 63) >> 6;
+    const int tb = b - T.tile0;
+    const int r0 = (tb / tiles_k) << 6, k0 = (tb % tiles_k) << 6;
+    // 1. update the tile: thread (tr, tc) owns rows tr + 16 i, columns 4 tc .. 4 tc + 3; elements beyond the matrix are zeros in every copy
+    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+    const bool vec = ((T.src_off | T.ld) & 3) == 0 && k0 + 64 <= T.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + tr + 16 * i;
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < T.R) {
+            const int64_t e0 = T.src_off + (int64_t)r * T.ld + k0 + 4 * tc;
+            if (vec) {
+                f32x4 p = *reinterpret_cast<const f32x4*>(a.p + e0), g = *reinterpret_cast<const f32x4*>(a.g + e0);
+                f32x4 m = *reinterpret_cast<const f32x4*>(a.m + e0), v = *reinterpret_cast<const f32x4*>(a.v + e0);
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                if (a.ema) s = *reinterpret_cast<const f32x4*>(a.ema + e0);
+                bool any_live = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool skip = adam_skip(a, e0 + q);
+                    any_live |= !skip;
+                    float mq = m[q], vq = v[q], sq = s[q];
+                    const float pq = adam_math(a, coef, skip, p[q], g[q], mq, vq, sq);
+                    p[q] = pq; m[q] = mq; v[q] = vq; s[q] = sq;
+                    out[q] = pq;
+                }
+                if (any_live) {
+                    *reinterpret_cast<f32x4*>(a.p + e0) = p;
+                    *reinterpret_cast<f32x4*>(a.m + e0) = m;
+                    *reinterpret_cast<f32x4*>(a.v + e0) = v;
+                }
+                if (a.ema) *reinterpret_cast<f32x4*>(a.ema + e0) = s;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (k0 + 4 * tc + q < T.K) out[q] = adam_elem(a, coef, e0 + q);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tile[tr + 16 * i][4 * tc + q] = out[q];
+    }
+    __syncthreads();
+    // 2. the tile's part of every packed copy
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const AdamPackDst& dd = T.dst[d];
+        if (dd.off < 0) continue;
+        if (dd.f32) adam_pack_dst<float>(dd, args.packed, tile, r0, k0);
+        else adam_pack_dst<__bf16>(dd, args.packed, tile, r0, k0);
+    }
+}
+hipError_t launch_adam_pack(const AdamPackArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_adam_pack, dim3((unsigned)(a.n_tiles + a.n_elem_blocks)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -251,3 +251,36 @@ struct AdamArgs {          // losses.py:44-58 optimize_fn + torch.optim.Adam + e
     float weight_decay;    // torch.optim.Adam(weight_decay): grad += weight_decay * param (after the clip, before the moments); 0 = off
 };
 hipError_t launch_adam_ema(const AdamArgs& a, hipStream_t st);
+
+// ---- the same update fused with the re-packing of the weights it changes (one pass over the optimizer state) --------------------
+// A weight matrix W [R][K] (row-major, leading dimension ld) of the flat buffer and the packed copies the GEMMs read: every 64 x 64
+// tile of W is updated by one block, which then writes the tile's part of each copy from LDS -- instead of k_adam_ema writing the
+// parameters and k_pack / k_bias_cat of the NEXT step reading them back (33 MB read twice or three times, 2 launches).
+struct AdamPackDst {
+    int64_t off;          // byte offset in the packed workspace; < 0: unused
+    int ktot, koff;       // destination FT matrix has ktot columns, this tensor starts at column koff
+    int trans;            // 1: destination rows = columns of W (dgrad copies)
+    int f32;              // destination element type
+};
+struct AdamPackTensor {
+    int64_t src_off;      // element offset of W in the flat buffers
+    int R, K, ld;
+    int tile0;            // index of the tensor's first tile among all tiles of the launch
+    AdamPackDst dst[3];
+};
+struct AdamPackElems {    // a range that is not a packed matrix (biases, GroupNorm affine, dead parameters, ...)
+    int64_t off_a, off_b; // off_b >= 0: a second range of the same length updated by the same thread (dense bias | dense_t bias) ...
+    int64_t cat_off;      // ... whose sums a[i] + b[i] go to the fp32 bias table at this float offset of the packed workspace
+    int len;
+    int block0;           // index of the range's first block among the element blocks
+};
+constexpr int ADAMPACK_MAX_TENSORS = 16, ADAMPACK_MAX_ELEMS = 28;
+struct AdamPackArgs {
+    AdamPackTensor tensor[ADAMPACK_MAX_TENSORS];      // (first member: fetched through the kernel-argument segment)
+    AdamPackElems elems[ADAMPACK_MAX_ELEMS];
+    int n_tensors, n_elems, n_tiles, n_elem_blocks;
+    AdamArgs a;
+    unsigned char* packed;
+    int64_t bias_cat_off; // byte offset of the bias table in `packed`
+};
+hipError_t launch_adam_pack(const AdamPackArgs& a, hipStream_t st);

@@ -13,6 +13,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -60,6 +61,7 @@ struct dposer_scorefc_s {
     int64_t pk_wpostT, pk_wlT[MAX_L], pk_wtT_all, pk_bwd_end;
     PackJobs fwd_jobs, bwd_jobs;
     BiasCatJobs bias_jobs;
+    AdamPackArgs adam_pack;    // tensors / element ranges of the fused optimizer + re-pack step (filled by create(); n_tensors == 0: not available)
     std::vector<float> host_stage;   // staging for small H2D copies (labels)
     // second stream for the parameter-gradient side of the backward pass (small batches), see backward_core
     hipStream_t side = nullptr;
@@ -168,6 +170,66 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
     for (int l = 0; l < L; ++l)
         push(h->bwd_jobs, mk_job(h->pk_wtT_all, h->layer[l].wt, L * H, l * H, E, H, E, H, E, 1, f));
     h->pk_bwd_end = p;
+
+    // ---- fused optimizer + re-pack step: every packed matrix with its copies, everything else as element ranges ------------------
+    {
+        AdamPackArgs& ap = h->adam_pack;
+        std::memset(&ap, 0, sizeof(ap));
+        int nt = 0, tiles = 0;
+        auto none = [] { AdamPackDst d; d.off = -1; d.ktot = d.koff = d.trans = d.f32 = 0; return d; };
+        auto dst = [&](int64_t off, int ktot, int koff, int trans, int f32) { AdamPackDst d; d.off = off; d.ktot = ktot; d.koff = koff; d.trans = trans; d.f32 = f32; return d; };
+        auto add_t = [&](int64_t src, int R, int K, AdamPackDst d0, AdamPackDst d1, AdamPackDst d2) {
+            AdamPackTensor& t = ap.tensor[nt++];
+            t.src_off = src; t.R = R; t.K = K; t.ld = K; t.tile0 = tiles; t.dst[0] = d0; t.dst[1] = d1; t.dst[2] = d2;
+            tiles += (int)(ceil_div(R, 64) * ceil_div(K, 64));
+        };
+        std::vector<std::pair<int64_t, int64_t>> matrices;        // [lo, hi) of the flat buffer covered by tensors
+        auto mat = [&](int64_t off, int64_t n) { matrices.push_back({off, off + n}); };
+        add_t(h->off_se_w, E, E, dst(h->pk_wse, E, 0, 0, f), h->f32 ? none() : dst(h->pk_wse32, E, 0, 0, 1), none());
+        mat(h->off_se_w, (int64_t)E * E);
+        for (int l = 0; l < L; ++l) {
+            const LayerOff& lo = h->layer[l];
+            const int ktot = lo.kin_pad + E;
+            add_t(lo.w, H, lo.kin, dst(h->pk_wl[l], ktot, 0, 0, f), dst(h->pk_wlT[l], H, 0, 1, f), none());
+            add_t(lo.wt, H, E, dst(h->pk_wl[l], ktot, lo.kin_pad, 0, f), dst(h->pk_wt_all32 + (int64_t)l * H * E * 4, E, 0, 0, 1),
+                  dst(h->pk_wtT_all, L * H, l * H, 1, f));
+            mat(lo.w, (int64_t)H * lo.kin);
+            mat(lo.wt, (int64_t)H * E);
+        }
+        add_t(h->off_post_w, D, H, dst(h->pk_wpost, H, 0, 0, f), dst(h->pk_wpostT, h->Cp, 0, 1, f), none());
+        mat(h->off_post_w, (int64_t)D * H);
+        ap.n_tensors = nt;
+        ap.n_tiles = tiles;
+        // element ranges: the dense / dense_t bias pairs (their sums are the fp32 bias table), then every other tensor, neighbours merged
+        int ne = 0, eblocks = 0;
+        auto add_e = [&](int64_t a, int64_t b, int64_t cat, int64_t len) {
+            AdamPackElems& e = ap.elems[ne++];
+            e.off_a = a; e.off_b = b; e.cat_off = cat; e.len = (int)len; e.block0 = eblocks;
+            int nb = (int)ceil_div(len, 1024);
+            eblocks += nb < 1 ? 1 : (nb > 128 ? 128 : nb);
+        };
+        std::vector<std::pair<int64_t, int64_t>> taken = matrices;
+        for (int l = 0; l < L; ++l) {
+            add_e(h->layer[l].b, h->layer[l].bt, h->pk_bias_cat / 4 + (int64_t)l * H, H);
+            taken.push_back({h->layer[l].b, h->layer[l].b + H});
+            taken.push_back({h->layer[l].bt, h->layer[l].bt + H});
+        }
+        std::sort(taken.begin(), taken.end());
+        int64_t cur = 0;
+        bool ok = true;
+        for (size_t i = 0; i <= taken.size(); ++i) {
+            const int64_t lo_ = i < taken.size() ? taken[i].first : h->nparams;
+            if (lo_ > cur) {
+                if (ne >= ADAMPACK_MAX_ELEMS) { ok = false; break; }
+                add_e(cur, -1, 0, lo_ - cur);
+            }
+            if (i < taken.size()) cur = taken[i].second > cur ? taken[i].second : cur;
+        }
+        ap.n_elems = ne;
+        ap.n_elem_blocks = eblocks;
+        ap.bias_cat_off = h->pk_bias_cat;
+        if (!ok || nt > ADAMPACK_MAX_TENSORS) ap.n_tensors = 0;
+    }
     *out = h;
     return DPOSER_OK;
 }
@@ -1554,6 +1616,43 @@ static int adam_step_impl(float* flat, const float* grad, float* m, float* v, fl
     a.ema_one_minus_decay = (float)ema_one_minus_decay;
     a.weight_decay = (float)weight_decay;
     DP_HIP_LAUNCH(launch_adam_ema(a, st));
+    return DPOSER_OK;
+}
+
+// Adam + clip + EMA and the re-packing of the weights in ONE pass over the optimizer state (kernels_api.h: AdamPackArgs): the packed
+// copies the next forward / backward read are written from the updated values while they are in registers / LDS, instead of being
+// re-derived from the flat buffer by dposer_scorefc_pack at the start of the next step (k_pack 31 us + k_bias_cat 5 us per step at
+// every batch size).  `packed` must have been produced by dposer_scorefc_pack(with_backward = 1) before (the zero padding of the copies
+// is written there, never again).  Bitwise the parameters / moments / EMA of dposer_adam_ema_clip_step_wd and the packed bytes of
+// dposer_scorefc_pack.
+extern "C" int dposer_scorefc_adam_pack_step(dposer_scorefc_t h, float* flat, const float* grad, float* m, float* v, float* ema, void* packed,
+                                             const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
+                                             double beta1, double beta2, double eps, double weight_decay, double grad_clip, double grad_scale,
+                                             int64_t adam_step, double ema_one_minus_decay, float* scratch, int32_t presummed, void* stream) {
+    DP_CHECK_ARG(h && flat && grad && m && v && packed && scratch, "null argument");
+    DP_CHECK_ARG(h->adam_pack.n_tensors > 0, "fused optimizer + re-pack step not available for this configuration");
+    DP_CHECK_ARG(adam_step >= 1, "adam_step counts from 1");
+    DP_CHECK_ARG(n_skip >= 0 && n_skip <= 2, "at most two no-gradient ranges");
+    DP_CHECK_ARG(((uintptr_t)flat & 15) == 0 && ((uintptr_t)grad & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)v & 15) == 0 &&
+                     (!ema || ((uintptr_t)ema & 15) == 0) && ((uintptr_t)packed & 255) == 0, "buffers must be 16-byte aligned (packed: 256)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = h->nparams;
+    int nb = 0;
+    if (!presummed) DP_HIP_LAUNCH(launch_sqnorm(grad, n, scratch + 16, &nb, st));
+    AdamPackArgs ap = h->adam_pack;
+    AdamArgs& a = ap.a;
+    a.sq_part = scratch + 16; a.n_part = nb;
+    a.p = flat; a.g = grad; a.m = m; a.v = v; a.ema = ema; a.n = n;
+    for (int i = 0; i < 2; ++i) { a.skip_lo[i] = i < n_skip ? skip_lo_host[i] : 0; a.skip_hi[i] = i < n_skip ? skip_hi_host[i] : 0; }
+    a.sqnorm = scratch; a.grad_scale = (float)grad_scale; a.grad_clip = (float)grad_clip;
+    const double bc1 = 1.0 - std::pow(beta1, (double)adam_step);
+    a.step_size = (float)(lr / bc1);
+    a.one_minus_beta1 = (float)(1.0 - beta1); a.beta2 = (float)beta2; a.one_minus_beta2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(beta2, (double)adam_step));
+    a.ema_one_minus_decay = (float)ema_one_minus_decay;
+    a.weight_decay = (float)weight_decay;
+    ap.packed = (unsigned char*)packed;
+    DP_HIP_LAUNCH(launch_adam_pack(ap, st));
     return DPOSER_OK;
 }
 

@@ -54,6 +54,7 @@ class ScoreEngine:
         self._packed: Optional[torch.Tensor] = None
         self._packed_bwd = False
         self._pack_gen = 0                 # bumped by every (re)pack: lets a backward notice that the packed buffer was rewritten
+        self._fresh_key = None             # state key under which the fused optimizer step last wrote the packed copies itself
         self._ws: Dict[int, torch.Tensor] = {}
         self._train_pool = []              # free WS_TRAIN buffers (see lease_train_workspace)
         self.freq_cpu = positional_freq(embed_dim)
@@ -90,19 +91,36 @@ class ScoreEngine:
             self._freq = self.freq_cpu.to(device)
         return self._freq
 
-    def packed(self, flat: torch.Tensor, with_backward: bool, force: bool = True):
+    def packed(self, flat: torch.Tensor, with_backward: bool, force: bool = True, state_key=None):
         """(Re)pack the fp32 master weights into MFMA fragment order.  ``force=False`` reuses the
-        current packing (caller guarantees the weights did not change)."""
+        current packing (caller guarantees the weights did not change).  ``state_key`` (see ``param_state_key``): when it equals the
+        key under which the fused optimizer step wrote the packed copies itself (dposer_scorefc_adam_pack_step), they ARE the
+        parameters' and nothing is launched."""
         need = self.lib.dposer_scorefc_packed_bytes(self.h, 1)
         if self._packed is None or self._packed.device != flat.device:
             self._packed = torch.empty(need, dtype=torch.uint8, device=flat.device)
             force = True
+            self._fresh_key = None
+        if force and state_key is not None and state_key == self._fresh_key and (self._packed_bwd or not with_backward):
+            return self._packed
         if force or (with_backward and not self._packed_bwd):
             _C.check(self.lib.dposer_scorefc_pack(self.h, _C.ptr(flat), _C.ptr(self._packed), 1 if with_backward else 0,
                                                   _C.stream_ptr()), "dposer_scorefc_pack")
             self._packed_bwd = bool(with_backward)
             self._pack_gen += 1
+            self._fresh_key = None
         return self._packed
+
+    def repack_target(self, flat: torch.Tensor):
+        """The packed buffer the fused optimizer step may write into: it exists, lives on ``flat``'s device and holds the backward
+        copies (so every zero-padded region has been written once); else None."""
+        if self._packed is None or self._packed.device != flat.device or not self._packed_bwd:
+            return None
+        return self._packed
+
+    def mark_packed_by_optimizer(self, state_key):
+        self._fresh_key = state_key
+        self._pack_gen += 1
 
     def workspace(self, batch: int, mode: int, n_steps: int, device):
         need = self.lib.dposer_scorefc_workspace_bytes(self.h, batch, mode, n_steps)
@@ -136,6 +154,15 @@ class ScoreEngine:
             self._train_pool[:] = [w for w in self._train_pool if w.device != device or w.numel() >= need]   # (in place: leases hold this list)
             ws = torch.empty(need, dtype=torch.uint8, device=device)
         return TrainWorkspaceLease(self._train_pool, ws)
+
+
+def param_state_key(flat: torch.Tensor, params):
+    """What the packed weights were derived from: the flat buffer, the library's parameter epoch (bumped by every routine of this
+    package that writes ``.data``) and the version counters of the parameters (bumped by every in-place torch operation on them)."""
+    v = 0
+    for p in params:
+        v += p._version
+    return (flat.data_ptr(), _C.PARAM_EPOCH[0], v)
 
 
 class TrainWorkspaceLease:

@@ -241,6 +241,17 @@ int dposer_adam_ema_clip_step_wd(float* flat_params, const float* flat_grad, flo
                                  int64_t n, const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
                                  double beta1, double beta2, double eps, double weight_decay, double grad_clip, double grad_scale,
                                  int64_t adam_step, double ema_one_minus_decay, float* scratch, int32_t presummed, void* stream);
+/* The same update fused with the re-packing of the weights it changes: ONE pass over the optimizer state writes parameters, moments,
+ * EMA shadow AND the packed copies (MFMA fragment order, transposed dgrad copies, fp32 time-branch copies, the bias table) that the
+ * next forward / backward read -- dposer_scorefc_pack at the start of the next step then has nothing to do.  `packed` must have been
+ * filled by dposer_scorefc_pack(with_backward = 1) before: the zero padding of the copies is written there and never again.  All flat
+ * buffers hold dposer_scorefc_num_params() floats.  Results are bitwise those of dposer_adam_ema_clip_step_wd followed by
+ * dposer_scorefc_pack.  The caller owns staleness: whoever changes the parameters by other means must pack again. */
+int dposer_scorefc_adam_pack_step(dposer_scorefc_t h, float* flat_params, const float* flat_grad, float* exp_avg, float* exp_avg_sq,
+                                  float* ema_shadow, void* packed, const int64_t* skip_lo_host, const int64_t* skip_hi_host,
+                                  int32_t n_skip, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                  double grad_clip, double grad_scale, int64_t adam_step, double ema_one_minus_decay, float* scratch,
+                                  int32_t presummed, void* stream);
 
 /* dposer_em_sampler restricted to the steps [start_step, start_step + n_steps) (no look-ahead imputation after the last one):
  * what a predictor-corrector loop with a corrector between the predictor calls drives (sampling.py:455-461). */

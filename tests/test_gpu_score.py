@@ -1230,3 +1230,62 @@ def test_fused_adam_weight_decay_follows_torch():
         ref_opt.step()
     for (name, q), r in zip(m.named_parameters(), ref_params):
         assert (q - r).abs().max() <= 2e-6 * max(1.0, float(r.abs().max())), name
+
+
+@pytest.mark.parametrize("n_blocks,n_poses,pose_dim,embedding,precision,B", [
+    (2, 21, 3, "positional", "bf16", 320), (2, 21, 3, "positional", "fp32", 96), (1, 49, 3, "positional", "bf16", 200),
+    (3, 21, 6, "positional", "bf16", 128)])
+def test_optimizer_step_that_repacks_the_weights_keeps_every_bit(n_blocks, n_poses, pose_dim, embedding, precision, B, monkeypatch):
+    """dposer_scorefc_adam_pack_step = Adam + clip + EMA and the re-packing of the weights in one pass over the optimizer state: four
+    training steps (warm-up learning rates, dropout on) with an evaluation step in between (EMA copy_to / restore rewrite the
+    parameters through .data: the packed copies must be rebuilt then) end in bitwise the parameters, moments, EMA shadow and packed
+    bytes of the two-kernel path (dposer_adam_ema_clip_step_wd + dposer_scorefc_pack at the start of the next step,
+    DPOSER_ADAM_REPACK=0).  Shapes: the shipped one, fp32 mode, one block with D = 147 (64-column padding of the first / last
+    layer), three blocks with D = 126."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.advanced.model import ScoreModelFC
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    from dposer_amd.configs import load_config
+    D = n_poses * pose_dim
+    rs = np.random.RandomState(D + n_blocks)
+    xs = [_dev(rs.standard_normal((B, D)).astype(np.float32)) for _ in range(5)]
+
+    def run(repack):
+        monkeypatch.setenv("DPOSER_ADAM_REPACK", "1" if repack else "0")
+        cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+        cfg.model.embedding_type = embedding
+        cfg.optim.warmup = 3
+        torch.manual_seed(5)
+        m = ScoreModelFC(cfg, n_poses=n_poses, pose_dim=pose_dim, hidden_dim=1024, embed_dim=512, n_blocks=n_blocks)
+        m.precision = precision
+        m.to(DEV)
+        sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+        opt = losses.get_optimizer(cfg, m.parameters())
+        ema = ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate)
+        state = dict(optimizer=opt, model=m, ema=ema, step=0)
+        train = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+        evalf = losses.get_step_fn(sde, train=False, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+        eng = m._engine()
+        losses_ = []
+        n_packs = []
+        for i in range(4):
+            g0 = eng._pack_gen
+            losses_.append(float(train(state, xs[i])["step_loss"]))
+            n_packs.append(eng._pack_gen - g0)
+            if i == 1:
+                torch.manual_seed(9)
+                evalf(state, xs[4])                      # EMA copy_to / restore in between
+        if not repack:
+            eng.packed(m.flat_params(), with_backward=True, force=True)
+        torch.cuda.synchronize()
+        return (m.flat_params().clone(), opt._flat_m.clone(), opt._flat_v.clone(), ema.flat_shadow_for(m.flat_params()).clone(),
+                eng._packed.clone(), losses_, n_packs)
+
+    a, b = run(True), run(False)
+    assert a[5] == b[5]
+    for name, x, y in zip(("params", "exp_avg", "exp_avg_sq", "ema", "packed"), a[:5], b[:5]):
+        assert torch.equal(x, y), name
+    # step 0 packs once (nothing was packed yet), then the optimizer keeps the copies current: one generation bump per step, by the
+    # optimizer; the step after the evaluation step has to pack again, plus the optimizer's bump
+    assert a[6] == [2, 1, 2, 1], a[6]
+    assert b[6] == [1, 1, 1, 1], b[6]

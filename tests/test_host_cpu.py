@@ -436,3 +436,35 @@ def test_isa_audit_catches_a_stale_m0():
     assert len(ci.audit_m0(loop)[0]) == 1
     bare = ";;#ASMSTART\n\tglobal_load_lds_dwordx4 v1, off\n;;#ASMEND\n"            # asm reader without an M0 write of its own
     assert len(ci.audit_m0(mv + bare)[0]) == 1
+
+
+def test_capi_argument_paths_under_address_sanitizer():
+    """the host side of the C ABI -- argument checks, handle construction (parameter layout, pack-job and optimizer tables,
+    bucket ranges), error strings, struct layouts -- built with -fsanitize=address (device code untouched, `make asan`) and driven by
+    the C-API tests of this file in a child process with the ASan runtime preloaded.  Sanitizers run on the CPU build only."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    if os.environ.get("DPOSER_ASAN_CHILD"):
+        pytest.skip("child process")
+    rt = subprocess.run([hipcc, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(rt) or not os.path.exists(rt):
+        cand = [os.path.join(dp, f) for dp, _, fs in os.walk("/opt/rocm/lib/llvm/lib/clang") for f in fs if f == "libclang_rt.asan-x86_64.so"]
+        if not cand:
+            pytest.skip("no ASan runtime in this toolchain")
+        rt = cand[0]
+    csrc = os.path.join(ROOT, "dposer_amd", "csrc")
+    b = subprocess.run(["make", "-C", csrc, "-j", str(min(8, os.cpu_count() or 1)), "asan"], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, PATH=os.environ.get("PATH", "") + ":/opt/rocm/bin"))
+    assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-2000:]
+    lib = os.path.join(csrc, "build", "asan", "libdposer_hip_asan.so")
+    env = dict(os.environ, DPOSER_LIB_PATH=lib, LD_PRELOAD=rt, DPOSER_ASAN_CHILD="1",
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23:protect_shadow_gap=0:verify_asan_link_order=0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "capi_exports_every_declared_symbol or capi_handle_layout_and_error_codes or ctypes_structs_match"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert "AddressSanitizer" not in r.stdout + r.stderr, (r.stdout + r.stderr)[-4000:]
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout + r.stderr)[-3000:]
