@@ -47,7 +47,8 @@ class MotionDenoiseArgs(C.Structure):
                 ("norm_a", C.c_void_p), ("norm_b", C.c_void_p), ("n_steps", C.c_int32), ("weighted", C.c_int32), ("t_host", C.POINTER(C.c_float)),
                 ("w_temp_host", C.POINTER(C.c_float)), ("w_data_host", C.POINTER(C.c_float)), ("w_prior_host", C.POINTER(C.c_float)),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("adam_step0", C.c_int32),
-                ("step0", C.c_uint32), ("seed", C.c_uint64), ("noise", C.c_void_p), ("scratch", C.c_void_p), ("loss_log", C.c_void_p)]
+                ("step0", C.c_uint32), ("seed", C.c_uint64), ("noise", C.c_void_p), ("scratch", C.c_void_p), ("loss_log", C.c_void_p),
+                ("rot6d", C.c_int32)]
 
 
 class DPoserHipError(RuntimeError):

@@ -169,7 +169,7 @@ class FusedAdam(optim.Adam):
     def gather_state(self):
         """After ZeRO-1 steps every rank holds the Adam moments of its OWN range only.  All-gather them (two collectives over the
         ranges of the last sharded step) and publish the torch-style per-parameter state, so that ``state_dict()`` of a sharded
-        run is the state of the replicated run.  COLLECTIVE: every rank must call it (``state_dict()`` does when needed)."""
+        run is the state of the replicated run.  COLLECTIVE: every rank must call it, explicitly, before ``state_dict()``."""
         from ... import distributed as ddp
         sh = getattr(self, "_sharded", None)
         if sh is None:
@@ -182,9 +182,14 @@ class FusedAdam(optim.Adam):
         self._sharded = None
 
     def state_dict(self):
-        """torch's layout.  After sharded (ZeRO-1) steps the moments are gathered first -- a collective, so checkpointing a
-        sharded run means calling ``state_dict()`` on EVERY rank (rank 0 then writes the file)."""
-        self.gather_state()
+        """torch's layout.  After sharded (ZeRO-1) steps the moments live on their owning ranks: call ``gather_state()`` on EVERY
+        rank first (a collective -- two all-gathers), then ``state_dict()`` wherever the checkpoint is written.  Calling it on
+        ungathered state raises instead of entering a collective that the other ranks may never join (the reference's pattern is
+        'rank 0 saves', run/train.py:393-403: an implicit collective there hangs RCCL / gloo without a diagnostic)."""
+        if getattr(self, "_sharded", None) is not None:
+            raise RuntimeError("FusedAdam.state_dict(): the Adam moments are sharded over the ranks (ZeRO-1 steps since the last gather). "
+                               "Call optimizer.gather_state() on ALL ranks first (it all-gathers them), then state_dict() on the "
+                               "rank that writes the checkpoint.")
         return super().state_dict()
 
     @torch.no_grad()
@@ -419,18 +424,36 @@ def _live_params(model):
 def _rot6d_to_axis_angle_autograd(rot6d):
     """Differentiable 6D -> axis-angle for the auxiliary loss with rot_rep='rot6d' (losses.py:247-249; the reference goes through
     torchgeometry: matrix -> quaternion -> angle-axis).  Plain torch ops on the device: the HIP conversion kernel
-    (utils.transforms.rot6d_to_axis_angle) has no backward, and this path is neither the shipped configuration nor hot."""
+    (utils.transforms.rot6d_to_axis_angle) has no backward, and this path is neither the shipped configuration nor hot.
+    Like the reference's route it is well-conditioned over the whole range: the angle comes from atan2(|skew| / 2, (trace - 1) / 2)
+    (acos loses half its digits near 0 and pi), the axis from the skew part while sin(angle) is not small and, towards pi, from the
+    diagonal of R (R + R^T = 2 cos(a) I + 2 (1 - cos a) n n^T), signed by the skew part; below 1e-4 rad the series of a / (2 sin a)."""
     a = rot6d.reshape(-1, 3, 2)
     b1 = torch.nn.functional.normalize(a[:, :, 0], dim=1)
     b2 = torch.nn.functional.normalize(a[:, :, 1] - (b1 * a[:, :, 1]).sum(dim=1, keepdim=True) * b1, dim=1)
     b3 = torch.cross(b1, b2, dim=1)
     R = torch.stack([b1, b2, b3], dim=-1)
-    # log map through the rotation angle and the skew part; the small-angle branch avoids 0/0
-    cos = ((R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]) - 1.0) * 0.5
-    angle = torch.acos(torch.clamp(cos, -1.0 + 1e-7, 1.0 - 1e-7))
-    skew = torch.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], dim=1)
-    scale = torch.where(angle < 1e-4, 0.5 + angle * angle / 12.0, angle / (2.0 * torch.sin(angle).clamp_min(1e-12)))
-    return skew * scale[:, None]
+    skew = torch.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], dim=1)       # 2 sin(a) n
+    sin_a = 0.5 * torch.sqrt((skew * skew).sum(dim=1) + 1e-30)
+    cos_a = 0.5 * ((R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]) - 1.0)
+    angle = torch.atan2(sin_a, cos_a)
+    # regular branch: angle / (2 sin angle) * skew, with the series for tiny angles
+    small = angle < 1e-4
+    scale = torch.where(small, 0.5 + angle * angle / 12.0, angle / (2.0 * torch.where(small, torch.ones_like(sin_a), sin_a).clamp_min(1e-12)))
+    regular = skew * scale[:, None]
+    # towards pi: |n_i| from the diagonal, signs from the largest component's row of the symmetric part and the skew part
+    one_m_cos = (1.0 - cos_a).clamp_min(1e-12)
+    diag = torch.stack([R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]], dim=1)
+    n_abs = torch.sqrt(((diag - cos_a[:, None]) / one_m_cos[:, None]).clamp_min(0.0) + 1e-30)
+    sym = 0.5 * (R + R.transpose(1, 2))                                                            # cos I + (1 - cos) n n^T
+    k = torch.argmax(n_abs, dim=1)
+    row = sym[torch.arange(R.shape[0], device=R.device), k]                                        # (1 - cos) n_k n  (+ cos e_k)
+    row = row - cos_a[:, None] * torch.nn.functional.one_hot(k, 3).to(R.dtype)
+    n = row / (one_m_cos * n_abs.gather(1, k[:, None]).squeeze(1)).clamp_min(1e-12)[:, None]
+    sgn = torch.sign((n * skew).sum(dim=1))
+    sgn = torch.where(sgn == 0, torch.ones_like(sgn), sgn)                                          # exactly pi: either sign is the same rotation
+    near_pi = n * (sgn * angle)[:, None]
+    return torch.where((cos_a < -0.99)[:, None], near_pi, regular)
 
 
 _RANK_GENERATORS = {}

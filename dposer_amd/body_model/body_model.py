@@ -127,6 +127,14 @@ class _LBSFunction(torch.autograd.Function):
                 dv[:, uniq] = saved + contrib
             else:                                                                               # .contiguous() / .float() made a private copy
                 dv[:, uniq] += contrib
+        try:
+            return _LBSFunction._backward_body(ctx, core, B, dev, h, lib, J, dv, dj)
+        finally:
+            if saved is not None:
+                dv[:, uniq] = saved                    # the incoming gradient is handed back as it came, also when a check raised
+
+    @staticmethod
+    def _backward_body(ctx, core, B, dev, h, lib, J, dv, dj):
         # transl shifts every vertex and the J LBS joints (extras / landmarks move with their vertices: already in dv)
         d_transl = (dv.sum(dim=1) + dj[:, :J].sum(dim=1)) if ctx.has_transl else None
         ws_b = torch.empty(lib.dposer_lbs_backward_workspace_bytes(h, B), dtype=torch.uint8, device=dev)
@@ -154,8 +162,6 @@ class _LBSFunction(torch.autograd.Function):
                                          _C.ptr(core.skin_w), int(core.skin_idx.shape[1]), _C.ptr(jptr), _C.ptr(jvidx), _C.ptr(jw), _C.ptr(dv),
                                          _C.ptr(dj), dj.shape[1] * 3, dsegp, _C.ptr(d_jrest), _C.ptr(d_vposed), B, _C.stream_ptr()),
                  "dposer_lbs_backward")
-        if saved is not None:
-            dv[:, uniq] = saved                        # the incoming gradient is handed back as it came
         if ctx.batched:
             g_vs, g_jr = d_vposed, d_jrest
         else:

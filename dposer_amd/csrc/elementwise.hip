@@ -1095,44 +1095,62 @@ __global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs args) {
     const int tiles_k = (T.K + 63) >> 6;
     const int tb = b - T.tile0;
     const int r0 = (tb / tiles_k) << 6, k0 = (tb % tiles_k) << 6;
-    // 1. update the tile: thread (tr, tc) owns rows tr + 16 i, columns 4 tc .. 4 tc + 3; elements beyond the matrix are zeros in every copy
+    // 1. update the tile: thread (tr, tc) owns rows tr + 16 i, columns 4 tc .. 4 tc + 3; elements beyond the matrix are zeros in every copy.
+    //    All loads of the thread's four rows are issued before the first store: behind a store hipcc cannot hoist the next row's loads
+    //    (the five buffers may alias for all it knows) and the rows would be four dependent HBM round trips.
     const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
     const bool vec = ((T.src_off | T.ld) & 3) == 0 && k0 + 64 <= T.K;
+    if (vec) {
+        f32x4 P[4], G[4], M[4], V[4], S[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + tr + 16 * i;
-        float out[4] = {0.f, 0.f, 0.f, 0.f};
-        if (r < T.R) {
-            const int64_t e0 = T.src_off + (int64_t)r * T.ld + k0 + 4 * tc;
-            if (vec) {
-                f32x4 p = *reinterpret_cast<const f32x4*>(a.p + e0), g = *reinterpret_cast<const f32x4*>(a.g + e0);
-                f32x4 m = *reinterpret_cast<const f32x4*>(a.m + e0), v = *reinterpret_cast<const f32x4*>(a.v + e0);
-                f32x4 s = {0.f, 0.f, 0.f, 0.f};
-                if (a.ema) s = *reinterpret_cast<const f32x4*>(a.ema + e0);
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + tr + 16 * i;
+            const int64_t e0 = T.src_off + (int64_t)(r < T.R ? r : 0) * T.ld + k0 + 4 * tc;      // (rows beyond the matrix: loaded from row 0, never used)
+            P[i] = *reinterpret_cast<const f32x4*>(a.p + e0); G[i] = *reinterpret_cast<const f32x4*>(a.g + e0);
+            M[i] = *reinterpret_cast<const f32x4*>(a.m + e0); V[i] = *reinterpret_cast<const f32x4*>(a.v + e0);
+            S[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.ema) S[i] = *reinterpret_cast<const f32x4*>(a.ema + e0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + tr + 16 * i;
+            float out[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r < T.R) {
+                const int64_t e0 = T.src_off + (int64_t)r * T.ld + k0 + 4 * tc;
                 bool any_live = false;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const bool skip = adam_skip(a, e0 + q);
                     any_live |= !skip;
-                    float mq = m[q], vq = v[q], sq = s[q];
-                    const float pq = adam_math(a, coef, skip, p[q], g[q], mq, vq, sq);
-                    p[q] = pq; m[q] = mq; v[q] = vq; s[q] = sq;
+                    float mq = M[i][q], vq = V[i][q], sq = S[i][q];
+                    const float pq = adam_math(a, coef, skip, P[i][q], G[i][q], mq, vq, sq);
+                    P[i][q] = pq; M[i][q] = mq; V[i][q] = vq; S[i][q] = sq;
                     out[q] = pq;
                 }
                 if (any_live) {
-                    *reinterpret_cast<f32x4*>(a.p + e0) = p;
-                    *reinterpret_cast<f32x4*>(a.m + e0) = m;
-                    *reinterpret_cast<f32x4*>(a.v + e0) = v;
+                    *reinterpret_cast<f32x4*>(a.p + e0) = P[i];
+                    *reinterpret_cast<f32x4*>(a.m + e0) = M[i];
+                    *reinterpret_cast<f32x4*>(a.v + e0) = V[i];
                 }
-                if (a.ema) *reinterpret_cast<f32x4*>(a.ema + e0) = s;
-            } else {
+                if (a.ema) *reinterpret_cast<f32x4*>(a.ema + e0) = S[i];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tile[tr + 16 * i][4 * tc + q] = out[q];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + tr + 16 * i;
+            float out[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r < T.R) {
+                const int64_t e0 = T.src_off + (int64_t)r * T.ld + k0 + 4 * tc;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (k0 + 4 * tc + q < T.K) out[q] = adam_elem(a, coef, e0 + q);
             }
-        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) tile[tr + 16 * i][4 * tc + q] = out[q];
+            for (int q = 0; q < 4; ++q) tile[tr + 16 * i][4 * tc + q] = out[q];
+        }
     }
     __syncthreads();
     // 2. the tile's part of every packed copy

@@ -1164,6 +1164,7 @@ static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first
     int n = 0;
     for (int l = l_first > 1 ? l_first : 1; l < L; ++l) {           // W_x (layer 0 has 63 input channels: its own small kernel)
         if (h->layer[l].kin != h->H || h->layer[l].kin_pad != h->H) return false;
+        if (n >= WGB_MAX_PROB) return false;                        // (three-block models: more lane problems than one launch holds)
         WgradLaneProblem& p = a.prob[n++];
         for (int i = 0; i < 2; ++i) {
             p.dY[i] = w.dy[l]; p.H[i] = w.hbuf[l - 1]; p.nA[i] = nAh; p.nB[i] = nAh; p.sblk0[i] = 2 * i; p.sb_off[i] = 0;
@@ -1174,6 +1175,7 @@ static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first
     int lt = l_first;
     for (; lt + 1 < L; lt += 2) {                                   // W_t of two layers side by side
         const int l = lt;
+        if (n >= WGB_MAX_PROB) return false;                        // (three-block models: more lane problems than one launch holds)
         WgradLaneProblem& p = a.prob[n++];
         for (int i = 0; i < 2; ++i) {
             p.dY[i] = w.dy[l + i]; p.H[i] = w.temb; p.nA[i] = nAh; p.nB[i] = nE; p.sblk0[i] = 0; p.sb_off[i] = 0;
@@ -1182,6 +1184,7 @@ static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first
         p.len = S;
     }
     if (lt < L) {                                                   // the left-over W_t: its rows in two halves
+        if (n >= WGB_MAX_PROB) return false;                        // (three-block models: more lane problems than one launch holds)
         WgradLaneProblem& p = a.prob[n++];
         for (int i = 0; i < 2; ++i) {
             p.dY[i] = w.dy[L - 1]; p.H[i] = w.temb; p.nA[i] = nAh; p.nB[i] = nE; p.sblk0[i] = 0; p.sb_off[i] = i * (S / 2);
@@ -1191,6 +1194,7 @@ static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first
         p.split_k = 1;
     }
     if (with_se && S % 4 == 0 && n < WGB_MAX_PROB) {                           // shared time embedding [E x E] = 2 x 2 tiles: four row quarters side by side
+        if (n >= WGB_MAX_PROB) return false;                        // (three-block models: more lane problems than one launch holds)
         WgradLaneProblem& p = a.prob[n++];
         p.dY[0] = w.dU; p.H[0] = w.emb; p.nA[0] = nE; p.nB[0] = nE; p.dst_off[0] = h->off_se_w; p.ld[0] = h->E;
         p.len = S / 4;

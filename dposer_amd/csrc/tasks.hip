@@ -18,6 +18,7 @@
 #include <string>
 
 #include "common.h"
+#include "rot_dev.h"
 
 #define TK_HIP_LAUNCH(expr)                                                                      \
     do {                                                                                         \
@@ -48,6 +49,26 @@ __global__ void __launch_bounds__(256) k_md_normalize(const float* pose, const f
     if (mode == 1) x = (p - a[c]) / b[c];
     else if (mode == 2) x = 2.0f * (p - a[c]) / (b[c] - a[c]) - 1.0f;
     xn[i] = x;
+}
+
+// offline_normalize(from_axis=True) for rot_rep = 'rot6d' (AMASS.py:126-137 -> lib/utils/transforms.py:238-255): every joint's axis-angle
+// becomes the first two columns of its rotation matrix, row-major (R00 R01 R10 R11 R20 R21), then the 6 J-dimensional statistics apply.
+// One thread per (frame, joint).
+__device__ __forceinline__ float md_norm(float p, int mode, const float* a, const float* b, int c) {
+    if (mode == 1) return (p - a[c]) / b[c];
+    if (mode == 2) return 2.0f * (p - a[c]) / (b[c] - a[c]) - 1.0f;
+    return p;
+}
+__global__ void __launch_bounds__(256) k_md_normalize6d(const float* pose, const float* a, const float* b, int mode, float* xn, int64_t n_joints, int J) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_joints) return;
+    const int j = (int)(i % J);
+    const float* r = pose + i * 3;
+    const Mat3 R = rodrigues(r[0], r[1], r[2]);
+    const float six[6] = {R.m[0], R.m[1], R.m[3], R.m[4], R.m[6], R.m[7]};
+    float* o = xn + i * 6;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) o[e] = md_norm(six[e], mode, a, b, j * 6 + e);
 }
 
 // temporal term (:253-255): temp = mean over (T-1, V) of ||v[t] - v[t+1]||; d temp / d v[t] = (u_t - u_{t-1}) / ((T-1) V),
@@ -153,6 +174,40 @@ __global__ void __launch_bounds__(256) k_md_update(MdUpdateArgs u) {
     u.v[i] = v;
 }
 
+// the same update for rot_rep = 'rot6d': the prior gradient arrives in the 6 J normalised coordinates; normalise^T, then the
+// vector-Jacobian product of axis-angle -> (R00 R01 R10 R11 R20 R21) brings it to the joint's three pose parameters.  One thread per
+// (frame, joint).
+__global__ void __launch_bounds__(256) k_md_update6d(MdUpdateArgs u, int64_t n_joints, int J) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_joints) return;
+    const int j = (int)(i % J);
+    float g6[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const int c = j * 6 + e;
+        float gp = u.gprior[i * 6 + e] * u.w_prior;
+        if (u.mode == 1) gp = gp / u.b[c];
+        else if (u.mode == 2) gp = (gp / (u.b[c] - u.a[c])) * 2.0f;
+        g6[e] = gp;
+    }
+    const float dR[9] = {g6[0], g6[1], 0.f, g6[2], g6[3], 0.f, g6[4], g6[5], 0.f};
+    float* q = u.pose + i * 3;
+    float gq[3];
+    rodrigues_bwd(q[0], q[1], q[2], dR, gq);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int64_t k = i * 3 + c;
+        const float g = u.dpose[k] + gq[c];
+        float m = u.m[k], v = u.v[k];
+        m = m + (g - m) * u.one_minus_beta1;
+        v = v * u.beta2 + u.one_minus_beta2 * (g * g);
+        const float denom = sqrtf(v) / u.bc2_sqrt + u.eps;
+        q[c] = q[c] - u.step_size * (m / denom);
+        u.m[k] = m;
+        u.v[k] = v;
+    }
+}
+
 struct Scratch {
     float *xn, *gprior, *loss1, *verts, *joints, *dverts, *djoints, *dpose, *part;
     int64_t bytes;
@@ -161,7 +216,7 @@ Scratch layout(char* base, int64_t T, int D, int V, int n_joint_rows, int n_part
     Scratch s;
     char* p = base;
     auto take = [&](int64_t nfloat) { float* r = (float*)p; p += round_up(nfloat * 4, 256); return r; };
-    s.xn = take(T * D); s.gprior = take(T * D); s.loss1 = take(64);
+    s.xn = take(T * D * 2); s.gprior = take(T * D * 2); s.loss1 = take(64);      // (2 D: the 6-D representation of rot_rep = 'rot6d')
     s.verts = take(T * V * 3); s.joints = take(T * n_joint_rows * 3);
     s.dverts = take(T * V * 3); s.djoints = take(T * n_joint_rows * 3);
     s.dpose = take(T * D); s.part = take(n_part);
@@ -201,6 +256,8 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     const int n_part = vb * (int)T;
     Scratch s = layout((char*)a->scratch, T, D, V, a->joint_rows, n_part);
     const int64_t n = T * D;
+    const bool rot6d = a->rot6d != 0;                       // the network lives in the 6-D representation: 2 D coordinates per frame
+    const int64_t n_net = rot6d ? 2 * n : n;
 
     const float* segs[8];
     float* dsegs[8];
@@ -224,9 +281,10 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     // time-bias rows of all steps: two small GEMMs once instead of per step
     if (a->n_steps > 0) DP_TRY(dposer_prior_table_build(a->net, a->flat_params, a->packed, a->net_ws, a->t_host, a->n_steps, a->freq, T, stream));
     for (int k = 0; k < a->n_steps; ++k) {
-        hipLaunchKernelGGL(k_md_normalize, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n, D);
+        if (rot6d) hipLaunchKernelGGL(k_md_normalize6d, dim3((unsigned)ceil_div(n / 3, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n / 3, D / 3);
+        else hipLaunchKernelGGL(k_md_normalize, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n, D);
         TK_HIP_LAUNCH(hipGetLastError());
-        DP_TRY(dposer_prior_loss_tabled(a->net, a->flat_params, a->packed, a->net_ws, a->sde, s.xn, a->noise ? a->noise + (int64_t)k * n : nullptr,
+        DP_TRY(dposer_prior_loss_tabled(a->net, a->flat_params, a->packed, a->net_ws, a->sde, s.xn, a->noise ? a->noise + (int64_t)k * n_net : nullptr,
                                         a->t_host[k], k, a->n_steps, a->weighted, 1.0f / (float)F, nullptr, s.gprior, s.loss1, a->seed,
                                         a->step0 + (uint32_t)k, a->sigmas, T, stream));
         const float c_temp = a->w_temp_host[k] / ((float)(F - 1) * (float)V);
@@ -258,7 +316,8 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
         u.mode = a->norm_mode; u.D = D; u.n = n; u.w_prior = a->w_prior_host[k];
         u.step_size = (float)(a->lr / bc1); u.one_minus_beta1 = (float)(1.0 - a->beta1); u.beta2 = (float)a->beta2;
         u.one_minus_beta2 = (float)(1.0 - a->beta2); u.bc2_sqrt = (float)std::sqrt(bc2); u.eps = (float)a->eps;
-        hipLaunchKernelGGL(k_md_update, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, u);
+        if (rot6d) hipLaunchKernelGGL(k_md_update6d, dim3((unsigned)ceil_div(n / 3, 256)), dim3(256), 0, st, u, n / 3, D / 3);
+        else hipLaunchKernelGGL(k_md_update, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, u);
         TK_HIP_LAUNCH(hipGetLastError());
     }
     return DPOSER_OK;

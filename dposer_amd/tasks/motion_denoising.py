@@ -5,7 +5,7 @@ Per Adam step: z-score normalise -> ``dposer_prior_loss`` -> ``BodyModel`` forwa
 (dposer_lbs_forward / dposer_lbs_backward) -> temporal term on vertices + data term on Jtr[:, :22].
 The frames of one sequence are coupled by the temporal term, so data parallelism is over sequences.
 
-The whole loop is ONE call, ``dposer_motion_denoise_optimize`` (axis-angle representation, sub-VP / VP SDE, positional embedding):
+The whole loop is ONE call, ``dposer_motion_denoise_optimize`` (axis-angle or 6-D rotation representation, sub-VP / VP SDE, positional embedding):
 all steps are queued from C, the loss gradients and torch.optim.Adam's update are kernels, nothing returns to the host in
 between.  Other configurations (and ``fused=False``) run the same step through autograd and torch's Adam.
 """
@@ -19,6 +19,32 @@ from .. import _C
 from ..algorithms.advanced import sde_lib
 from ..prior import prior_loss
 from ..utils.misc import gaussian_smoothing
+
+
+def _axis_angle_to_rot6d_autograd(aa):
+    """Differentiable axis-angle -> 6-D (first two columns of the rotation matrix, row-major: lib/utils/transforms.py:238-255) for the
+    step-by-step loop with rot_rep = 'rot6d' -- the HIP conversion kernel has no backward.  Rodrigues as smplx writes it
+    (angle = ||r + 1e-8||), i.e. what the one-call loop's kernels evaluate."""
+    angle = torch.norm(aa + 1e-8, dim=1, keepdim=True)
+    k = aa / angle
+    s, c = torch.sin(angle), torch.cos(angle)
+    kx, ky, kz = k[:, 0:1], k[:, 1:2], k[:, 2:3]
+    c1 = 1.0 - c
+    R00 = 1.0 + c1 * (-(kz * kz) - ky * ky)
+    R01 = s * (-kz) + c1 * (kx * ky)
+    R10 = s * kz + c1 * (kx * ky)
+    R11 = 1.0 + c1 * (-(kz * kz) - kx * kx)
+    R20 = s * (-ky) + c1 * (kx * kz)
+    R21 = s * kx + c1 * (ky * kz)
+    return torch.cat([R00, R01, R10, R11, R20, R21], dim=1)
+
+
+def _normalize_with_grad(nz, pose):
+    """Posenormalizer.offline_normalize(pose, from_axis=True) with a gradient path to the axis-angle pose also for rot_rep = 'rot6d'."""
+    if getattr(nz, "rot_rep", "axis") != "rot6d":
+        return nz.offline_normalize(pose, from_axis=True)
+    six = _axis_angle_to_rot6d_autograd(pose.reshape(-1, 3)).reshape(*pose.shape[:-1], -1)
+    return nz.offline_normalize(six, from_axis=False)
 
 
 class MotionDenoise:
@@ -66,7 +92,7 @@ class MotionDenoise:
         nz = self.Normalizer
         return (sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
                 and self.model.time_embedding_type == "positional" and isinstance(self.body_model, BodyModel)
-                and getattr(nz, "rot_rep", None) == "axis" and self.batch_size >= 2)
+                and getattr(nz, "rot_rep", None) in ("axis", "rot6d") and self.batch_size >= 2)
 
     def _optimize_fused(self, pose, init_joints, t_list, its, weights, noise, frames_per_sequence=0):
         """All optimisation steps in one C call; ``pose`` [T, 63] is updated in place (T = sequences x frames_per_sequence when a
@@ -101,6 +127,9 @@ class MotionDenoise:
         scratch = u8(lib.dposer_motion_denoise_scratch_bytes(T, D, core.V, rows))
         m, v = torch.zeros_like(pose), torch.zeros_like(pose)
         log = torch.zeros(n_steps, n_seq, 3, dtype=torch.float32, device=dev)
+        rot6d = getattr(nz, "rot_rep", "axis") == "rot6d"          # the network sees 6 J coordinates; the optimised pose stays axis-angle
+        if rot6d and eng.D != 2 * D:
+            raise _C.DPoserHipError(f"rot_rep='rot6d': the score network takes {eng.D} inputs, the pose has {D} axis-angle parameters")
         obs = init_joints.detach().contiguous().float()
         if not nz.normalize:
             mode, na, nb = 0, None, None
@@ -128,7 +157,7 @@ class MotionDenoise:
             norm_b=_C.ptr(nb), n_steps=n_steps, weighted=0, t_host=fl(t_list), w_temp_host=fl(weights["temp"](1.0, it) for it in its),
             w_data_host=fl(weights["data"](1.0, it) for it in its), w_prior_host=fl(weights["dposer"](1.0, it) for it in its),
             lr=0.03, beta1=0.9, beta2=0.999, eps=1e-8, adam_step0=0, step0=int(step0) & 0xFFFFFFFF, seed=int(model._rng_seed + 31),
-            noise=_C.ptr(nzs), scratch=_C.ptr(scratch), loss_log=_C.ptr(log))
+            noise=_C.ptr(nzs), scratch=_C.ptr(scratch), loss_log=_C.ptr(log), rot6d=1 if rot6d else 0)
         _C.check(lib.dposer_motion_denoise_optimize(C.byref(a), _C.stream_ptr()), "dposer_motion_denoise_optimize")
         return log
 
@@ -206,7 +235,7 @@ class MotionDenoise:
         use_fused = self._fused_supported() if fused is None else bool(fused)
         if use_fused:
             if not self._fused_supported():
-                raise NotImplementedError("the one-call motion-denoising loop covers axis-angle poses, sub-VP / VP SDEs and the positional embedding")
+                raise NotImplementedError("the one-call motion-denoising loop covers axis-angle / rot6d poses, sub-VP / VP SDEs and the positional embedding")
             pose = (self.poses if init_poses is None else init_poses).detach().clone().contiguous().float()
             quan = [self._quan_t(time_strategy, step, total_steps, sample_trun, sample_time) for step in range(total_steps)]
             self.loss_log = self._optimize_fused(pose, init_joints, [float(timesteps[q]) for q in quan],
@@ -218,7 +247,7 @@ class MotionDenoise:
                 for i in range(steps_per_iter):
                     step = it * steps_per_iter + i
                     optimizer.zero_grad()
-                    poses_n = self.Normalizer.offline_normalize(pose, from_axis=True)
+                    poses_n = _normalize_with_grad(self.Normalizer, pose)
                     q = self._quan_t(time_strategy, step, total_steps, sample_trun, sample_time)
                     losses = {"dposer": self.DPoser_loss(poses_n, float(timesteps[q]), z=None if noise is None else noise[step])}
                     body = bm(betas=self.betas, pose_body=pose)                          # forward WITH gradient

@@ -482,6 +482,8 @@ typedef struct dposer_motion_denoise_args {
     const float* noise;
     void* scratch;
     float* loss_log;
+    int32_t rot6d;        /* != 0: the score network works on the 6-D rotation representation (rot_rep = 'rot6d': 6 J inputs, norm_a / norm_b
+                             hold 6 J statistics, noise is [n_steps, frames, 6 J]); the pose being optimised stays axis-angle */
 } dposer_motion_denoise_args;
 int64_t dposer_motion_denoise_scratch_bytes(int64_t frames, int32_t pose_dim, int32_t num_vertices, int32_t joint_rows);
 int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* args, void* stream);

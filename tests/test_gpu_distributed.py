@@ -362,6 +362,7 @@ def run(n_steps, zero1):
         z = torch.tensor(rs.standard_normal((192, 63)).astype(np.float32)).cuda()
         step_fn(state, x, t=t, z=z)
     torch.cuda.synchronize()
+    opt.gather_state()                                      # (no-op unless the ZeRO-1 step sharded the moments)
     sd = opt.state_dict()
     return m.flat_params().detach().cpu().numpy().copy(), opt._flat_m.detach().cpu().numpy().copy(), sd
 
@@ -437,8 +438,15 @@ def _worker_zero1_ckpt(rank, world, port, q, model_seed, batch, t, z):
     for i in range(2):
         go(state, i)
     import copy
-    # state_dict() gathers the sharded moments (a collective); deepcopy = what torch.save would have written at this point
-    # (state dicts hold references to the live buffers, which the next step overwrites)
+    # the moments are sharded: state_dict() refuses (an implicit collective would hang a 'rank 0 saves' checkpoint) until EVERY rank
+    # has gathered them; deepcopy = what torch.save would have written at this point (state dicts hold references to the live
+    # buffers, which the next step overwrites)
+    try:
+        state["optimizer"].state_dict()
+        raise AssertionError("state_dict() of sharded moments must raise")
+    except RuntimeError as e:
+        assert "gather_state" in str(e)
+    state["optimizer"].gather_state()
     ck = copy.deepcopy({"model": state["model"].state_dict(), "opt": state["optimizer"].state_dict(), "ema": state["ema"].state_dict(),
                         "step": state["step"]})
     mom_full = state["optimizer"]._flat_m.detach().cpu().numpy().copy()
@@ -456,8 +464,10 @@ def _worker_zero1_ckpt(rank, world, port, q, model_seed, batch, t, z):
 
 
 def test_zero1_checkpoint_gathers_the_moments_and_resumes():
-    """A ZeRO-1 run keeps each Adam moment on the rank that owns its range.  ``optimizer.state_dict()`` must gather them (it is a
-    collective there), so that a checkpoint taken mid-run restores into a run that continues exactly like the original one."""
+    """A ZeRO-1 run keeps each Adam moment on the rank that owns its range.  ``optimizer.gather_state()`` (an explicit collective,
+    every rank) makes ``state_dict()`` the state of the replicated run -- ``state_dict()`` on ungathered state raises instead of
+    entering a collective implicitly -- so that a checkpoint taken mid-run restores into a run that continues exactly like the
+    original one."""
     rs = np.random.RandomState(5)
     B = 256
     batch = torch.tensor(rs.standard_normal((3, B, 63)).astype(np.float32))

@@ -466,3 +466,51 @@ def test_evaler_matches_the_reference_evaluator(part):
     for k in ("mpvpe_all", "mpjpe_body"):
         assert np.abs(r[k] - g[f"{tag}/{k}"]).max() / np.abs(g[f"{tag}/{k}"]).max() < 2e-5, (part, k)      # errors of ~100 mm to 1e-3 mm
         assert np.abs(r0[k].cpu().numpy() - g[f"{tag}/h0_{k}"]).max() / np.abs(g[f"{tag}/h0_{k}"]).max() < 2e-5, (part, k)
+
+
+@pytest.mark.parametrize("min_max", [False, True])
+def test_motion_denoise_one_call_loop_with_the_rot6d_representation(min_max):
+    """rot_rep = 'rot6d' (a shipped data option, lib/dataset/AMASS.py:187-259): the network lives in 6 J = 126 coordinates (first
+    two columns of every joint's rotation matrix, normalised with 126 statistics) while the pose being optimised stays axis-angle.
+    The one-call loop converts in its normalise kernel and brings the prior gradient back through the Rodrigues Jacobian in its
+    update kernel; it must track the step-by-step loop, whose conversion is plain differentiable torch (the reference goes through
+    torchgeometry).  Round 3 ran this configuration step by step -- and without a gradient path through the conversion."""
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    from dposer_amd.dataset.AMASS import Posenormalizer
+    from dposer_amd.tasks.motion_denoising import MotionDenoise, _axis_angle_to_rot6d_autograd
+    from dposer_amd.utils.transforms import axis_angle_to_rot6d
+    T, iters, spi = 12, 2, 3
+    cfg, m, p = make_model(64, D=126, precision="fp32")
+    asset = make_synthetic_smplx_asset(seed=0)
+    bm = BodyModel(asset).to(DEV)
+    g = load("g10_normalizer")
+    gt = g["raw"][:T].astype(np.float32)
+    rs = np.random.RandomState(3)
+    # 126-D statistics of the toy poses in the 6-D representation
+    six = t2n(axis_angle_to_rot6d(torch.tensor(g["raw"], device=DEV).reshape(-1, 3))).reshape(g["raw"].shape[0], -1)
+    stats = dict(mean_poses=torch.tensor(six.mean(0)), std_poses=torch.tensor(six.std(0) + 1e-3), min_poses=torch.tensor(six.min(0) - 1e-3),
+                 max_poses=torch.tensor(six.max(0) + 1e-3))
+    init = (gt + rs.standard_normal(gt.shape) * 0.05).astype(np.float32)
+    _, jgt, _, _ = fk_ref.smplx_forward(asset, gt.astype(np.float64), dtype=np.float64)
+    joints3d = torch.tensor((jgt[:, :22] + rs.standard_normal((T, 22, 3)) * 0.04).astype(np.float32), device=DEV)
+
+    class Args:
+        device = DEV
+
+    nz = Posenormalizer(stats, device=DEV, normalize=True, min_max=min_max, rot_rep="rot6d")
+    md = MotionDenoise(cfg, Args(), m, bm, sde_N=500, batch_size=T, normalizer=nz)
+    assert md._fused_supported()
+    # the torch conversion of the step-by-step loop is the kernels' conversion
+    aa = torch.tensor(init, device=DEV).reshape(-1, 3)
+    assert float((_axis_angle_to_rot6d_autograd(aa) - axis_angle_to_rot6d(aa)).abs().max()) < 2e-6
+    noise = torch.tensor(rs.standard_normal((iters * spi, T, 126)).astype(np.float32), device=DEV)
+    kw = dict(gt_poses=torch.tensor(gt, device=DEV), time_strategy="3", iterations=iters, steps_per_iter=spi, noise=noise,
+              init_poses=torch.tensor(init, device=DEV))
+    res_f = md.optimize(joints3d, fused=True, **kw)
+    log = t2n(md.loss_log)
+    res_u = md.optimize(joints3d, fused=False, **kw)
+    assert float((res_f["pose_body"] - kw["init_poses"]).abs().max()) > 1e-2           # the loop moved the pose
+    assert rel_err(t2n(res_f["pose_body"]), t2n(res_u["pose_body"])) < 5e-5
+    assert np.allclose(res_f["MPJPE"], res_u["MPJPE"], rtol=1e-4, atol=1e-4)
+    assert log.shape == (iters * spi, 1, 3) and np.isfinite(log).all() and (log > 0).all()

@@ -354,6 +354,20 @@ def test_rot6d_to_axis_angle_autograd_helper_vs_scipy():
     out = f(x)
     assert np.abs(out.detach().numpy() - Rotation.from_matrix(R).as_rotvec()).max() < 1e-6
     assert torch.autograd.gradcheck(f, (x[1:9],), eps=1e-6, atol=1e-5)
+    # the whole range of angles, in fp32 as the training step runs it: tiny angles, angles up to and AT pi (where a log map through
+    # acos / (2 sin) returns ~0 instead of pi n -- the reference's quaternion route is exact there), every axis octant
+    axes = rs.standard_normal((64, 3))
+    axes /= np.linalg.norm(axes, axis=1, keepdims=True)
+    for ang in (1e-7, 1e-5, 3e-4, 0.1, 1.0, 2.5, 3.0, 3.1, 3.14, np.pi - 1e-4, np.pi - 1e-6, np.pi):
+        rv = axes * ang
+        Rm = Rotation.from_rotvec(rv).as_matrix()
+        got = f(torch.tensor(Rm[:, :, :2].reshape(-1, 6), dtype=torch.float32)).numpy().astype(np.float64)
+        # compare as rotations (at pi the vectors pi n and -pi n are the same rotation)
+        err = np.abs(Rotation.from_rotvec(got).as_matrix() - Rm).max()
+        assert err < 2e-3 if ang > 3.1 else err < 2e-5, (ang, err)
+        assert np.abs(np.linalg.norm(got, axis=1) - ang).max() < (2e-3 if ang > 3.1 else 1e-5), ang
+    x64 = torch.tensor(Rotation.from_rotvec(axes[:6] * 3.05).as_matrix()[:, :, :2].reshape(-1, 6), dtype=torch.float64, requires_grad=True)
+    assert torch.autograd.gradcheck(f, (x64,), eps=1e-6, atol=1e-4)           # the near-pi branch is differentiable too
 
 
 def test_dropout_decisions_philox7_statistics():
