@@ -596,7 +596,7 @@ struct BodyTuning {
     int64_t fk_small_max = 8192;          // DPOSER_FK_SMALL_MAX: up to this many poses FK runs one wave per pose / one lane per joint
     int64_t joint_stream_min = 1536;      // DPOSER_LBS_JOINT_STREAM_MIN: from this batch the streaming joint-gradient kernel is used
     bool blend_fp32 = false;              // DPOSER_LBS_BLEND=fp32: exact-fp32 pose-blend chain
-    int skin_mode = 2;                    // DPOSER_SKIN_WAVE=0: one vertex per thread and iteration (k_skin) instead of four in flight (A/B)
+    int skin_mode = 3;                    // DPOSER_SKIN_WAVE=0: one vertex per thread and iteration (k_skin); 2: four in flight, one pose per block (k_skin_x4); 3: runs of poses (k_skin_run)
     bool skin_bwd_fused = true;           // DPOSER_SKIN_BWD_FUSED=0: k_skin_bwd + k_skin_bwd_joints instead of the one-pass kernel (A/B)
     bool lbs_bwd_big = true;              // DPOSER_LBS_BWD_BIG=0: 128x128 tiles for the blend-gradient GEMMs at every batch size (A/B)
     bool fk_dma = true;                   // DPOSER_FK_DMA=0: joints-only body query through k_fk_joints instead of k_fk_joints_dma (A/B)
@@ -610,7 +610,7 @@ struct BodyTuning {
         e = getenv("DPOSER_LBS_BLEND");
         blend_fp32 = e && e[0] == 'f';
         e = getenv("DPOSER_SKIN_WAVE");
-        skin_mode = e ? atoi(e) : 2;
+        skin_mode = e ? atoi(e) : 3;
         e = getenv("DPOSER_SKIN_BWD_FUSED");
         skin_bwd_fused = !(e && e[0] == '0');
         e = getenv("DPOSER_LBS_BWD_BIG");
@@ -963,6 +963,92 @@ __global__ void __launch_bounds__(256) k_skin_x4(SkinArgs a) {
     }
 }
 
+// k_skin_x4 over a RUN of poses (round 4): a block keeps its 1024 vertices' ELL rows (and the shared rest shape) in registers and walks
+// `run` consecutive poses -- per pose it reads only the 12 bytes of offsets per vertex instead of 56 (offsets + rest shape + two ELL
+// tables: the tables alone were 1.37 GB of L1 / L2 traffic per 4096 poses, more than the 1.03 GB the kernel moves through HBM), the next
+// pose's offsets and transforms are in flight while the current pose is skinned (transforms double-buffered in LDS, one barrier per
+// pose).  Same expressions in the same order per vertex: bit-identical vertices.
+__global__ void __launch_bounds__(256) k_skin_run(SkinArgs a, int run, int64_t B) {
+    extern __shared__ __attribute__((aligned(16))) float sA2[];   // [2][J][12]
+    const int J12 = a.J * 12;
+    const int64_t b0 = (int64_t)blockIdx.y * run;
+    const int64_t b1 = b0 + run < B ? b0 + run : B;
+    const int vbase = blockIdx.x * 1024 + threadIdx.x;
+    f32x4 w4[4];
+    int4 j4[4];
+    int vc[4];
+    float vs[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int v = vbase + u * 256;
+        vc[u] = v < a.V ? v : a.V - 1;                            // clamp: the tail threads load a valid vertex and do not store
+        w4[u] = *reinterpret_cast<const f32x4*>(a.skin_w + (int64_t)vc[u] * 4);
+        j4[u] = *reinterpret_cast<const int4*>(a.skin_idx + (int64_t)vc[u] * 4);
+        if (!a.v_shaped_batched)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vs[u][c] = a.v_shaped[(int64_t)vc[u] * 3 + c];
+    }
+    // pose b0: transforms into buffer 0, offsets (and the batched rest shape) into registers
+    float An[3];                                                   // this thread's <= 3 floats of the NEXT pose's transforms
+    float on[4][3], vn[4][3];
+    auto fetch = [&](int64_t b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int k = threadIdx.x + i * 256; An[i] = k < J12 ? a.A[b * J12 + k] : 0.f; }
+        const float* off_row = a.offsets + b * a.ld_off;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) on[u][c] = off_row[(int64_t)vc[u] * 3 + c];
+        if (a.v_shaped_batched) {
+            const float* vs_row = a.v_shaped + b * a.V * 3;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) vn[u][c] = vs_row[(int64_t)vc[u] * 3 + c];
+        }
+    };
+    fetch(b0);
+    for (int64_t b = b0; b < b1; ++b) {
+        float* sA = sA2 + ((b - b0) & 1) * J12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const int k = threadIdx.x + i * 256; if (k < J12) sA[k] = An[i]; }
+        float p[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p[u][c] = (a.v_shaped_batched ? vn[u][c] : vs[u][c]) + on[u][c];
+        float tr[3] = {0.f, 0.f, 0.f};
+        if (a.transl) { tr[0] = a.transl[b * 3]; tr[1] = a.transl[b * 3 + 1]; tr[2] = a.transl[b * 3 + 2]; }
+        __syncthreads();                                           // buffer (b & 1) is complete; every wave is done reading it two poses ago
+        if (b + 1 < b1) fetch(b + 1);                              // in flight while this pose is skinned
+        float* out_row = a.verts + b * a.V * 3;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = vbase + u * 256;
+            const int jj[4] = {j4[u].x, j4[u].y, j4[u].z, j4[u].w};
+            float T[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4* Aj = reinterpret_cast<const f32x4*>(sA) + jj[k] * 3;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const f32x4 row = Aj[r];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) T[4 * r + i] += w4[u][k] * row[i];
+                }
+            }
+            if (v < a.V) {
+                float* o = out_row + (int64_t)v * 3;
+                o[0] = T[0] * p[u][0] + T[1] * p[u][1] + T[2] * p[u][2] + T[3] + tr[0];
+                o[1] = T[4] * p[u][0] + T[5] * p[u][1] + T[6] * p[u][2] + T[7] + tr[1];
+                o[2] = T[8] * p[u][0] + T[9] * p[u][1] + T[10] * p[u][2] + T[11] + tr[2];
+            }
+        }
+    }
+}
+
 struct ExtraArgs {
     const float* verts;          // [B][V][3] (transl already applied)
     const int32_t* extra_ids;    // [n_extra] vertex ids   (smplx VertexJointSelector)
@@ -1176,7 +1262,12 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
         s.skin_idx = skin_idx; s.skin_w = skin_w; s.K = skin_k; s.J = J; s.V = V; s.transl = transl; s.verts = verts;
         dim3 grid((unsigned)ceil_div(V, 256 * 4), (unsigned)batch);
         const int mode = body_tuning().skin_mode;
-        if (mode != 0 && skin_k == 4) hipLaunchKernelGGL(k_skin_x4, grid, dim3(256), J * 12 * sizeof(float), st, s);
+        if (mode >= 3 && skin_k == 4 && J * 12 <= 768) {
+            // poses per block: enough blocks for ~4 per resident slot (256 CUs x 8), at most 16 poses
+            int run = 1;
+            while (run < 16 && (int64_t)grid.x * ceil_div(batch, run * 2) >= 8192) run *= 2;
+            hipLaunchKernelGGL(k_skin_run, dim3(grid.x, (unsigned)ceil_div(batch, run)), dim3(256), 2 * J * 12 * sizeof(float), st, s, run, (int64_t)batch);
+        } else if (mode != 0 && skin_k == 4) hipLaunchKernelGGL(k_skin_x4, grid, dim3(256), J * 12 * sizeof(float), st, s);
         else hipLaunchKernelGGL(k_skin, grid, dim3(256), J * 12 * sizeof(float), st, s);
         FK_HIP_LAUNCH(hipGetLastError());
     }

@@ -801,3 +801,27 @@ def test_blend_gemms_over_the_posed_joints_only_keep_every_bit(bm, asset, B, seg
     if segments == "body":                       # and the result is the oracle's
         v_ref, j_ref, _, _ = fk_ref.smplx_forward(asset, pose[:16].astype(np.float64), global_orient=root[:16].astype(np.float64), dtype=np.float64)
         assert np.abs(got[0][:16] - v_ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("B,batched_shape", [(7, False), (300, True), (1030, False), (4100, False)])
+def test_skinning_over_runs_of_poses_returns_the_bits_of_the_per_pose_kernel(bm, B, batched_shape, tuning_env):
+    """k_skin_run (a block keeps its vertices' skinning rows in registers and walks a run of poses, next pose's offsets and transforms
+    in flight) against k_skin_x4 (one pose per block, DPOSER_SKIN_WAVE=2): the same per-vertex expressions in the same order, so
+    vertices and joints are bit-identical -- with one shared and with per-pose rest shapes, with a translation, at batch sizes that give
+    runs of 1 (B = 7, 300), 2 (1030) and 4 poses (4100, incl. a ragged last run)."""
+    rs = np.random.RandomState(B)
+    pose = torch.tensor((rs.standard_normal((B, 63)) * 0.4).astype(np.float32), device=DEV)
+    trans = torch.tensor(rs.standard_normal((B, 3)).astype(np.float32), device=DEV)
+    betas = torch.tensor(rs.standard_normal((B if batched_shape else 1, 10)).astype(np.float32), device=DEV)
+    if not batched_shape:
+        betas = betas.expand(B, 10).contiguous()
+
+    def run():
+        with torch.no_grad():
+            out = bm(pose_body=pose, trans=trans, betas=betas)
+        return t2n(out.v), t2n(out.Jtr)
+
+    v3, j3 = run()
+    tuning_env(DPOSER_SKIN_WAVE="2")
+    v2, j2 = run()
+    assert np.isfinite(v3).all() and np.array_equal(v3, v2) and np.array_equal(j3, j2)

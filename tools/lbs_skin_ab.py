@@ -1,5 +1,6 @@
 """A/B of the skinning kernels and the LBS autograd wrapper on one box:  python tools/lbs_skin_ab.py
-DPOSER_SKIN_WAVE = 0 (one vertex per thread and iteration) / 2 (four vertices per thread in flight); forward and forward + backward at 4096
+DPOSER_SKIN_WAVE = 2 (four vertices per thread in flight, one pose per block) / 3 (the same over runs of poses: k_skin_run; round 3
+compared 0 / 2); forward and forward + backward at 4096
 and 16384 poses, interleaved child processes; the first child also checks that both kernels return the same bits."""
 import os
 import subprocess
@@ -17,7 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         pose = (torch.randn(777, 63, device="cuda:0") * 0.3).contiguous()
         tr = torch.randn(777, 3, device="cuda:0")
         outs = []
-        for flag in ("0", "2"):
+        for flag in ("2", "3"):
             os.environ["DPOSER_SKIN_WAVE"] = flag
             _C.lib().dposer_body_tuning_reload()
             with torch.no_grad():
@@ -52,5 +53,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 else:
     subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, CHECK="1"), check=True)
     for rnd in range(2):
-        for flag in ("0", "2"):
+        for flag in ("2", "3"):
             subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, DPOSER_SKIN_WAVE=flag), check=True)
