@@ -975,6 +975,15 @@ hipError_t launch_sqnorm(const float* g, int64_t n, float* part, int* nblocks, h
 // is dropped on the device -- parameters, moments and EMA stay as they were -- and counted in sqnorm[1], which the host reads
 // when it wants to (FusedAdam.nonfinite_steps()), not every step.
 // (the counter update rides in the first thread of the optimizer kernel: one launch less in a step whose tail is latency-bound)
+// 16-byte store of optimizer state.  wt != 0: WRITE-THROUGH (`sc0 sc1`): the line does not stay dirty in the XCD's L2.  Parameters,
+// moments and EMA are not read again before the next step's optimizer launch, and ~130 MB of dirty lines at the end of the kernel are
+// written back at the kernel boundary, in front of the next launch's first loads (the first kernel of the next step measured 17 us at
+// any batch size with its waves parked on memory for 10 of them).  (asm: the string ends with s_nop 1 -- hipcc may reuse the data
+// registers right behind the statement, cdna_hip_programming.md 5.7 item 1.)
+__device__ __forceinline__ void store16(float* p, const f32x4& v, int wt) {
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<f32x4*>(p) = v;
+}
 // one element of the update (losses.py:44-58 + torch.optim.Adam + ema.py:51); returns the new parameter value
 __device__ __forceinline__ float adam_math(const AdamArgs& a, float coef, bool skip, float p, float g, float& m, float& v, float& s) {
     if (!skip) {
@@ -1079,6 +1088,33 @@ __global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs args) {
             if (eb >= kernarg_job_at<AdamPackElems>(offsetof(AdamPackArgs, elems), i).block0) e = i;
         const AdamPackElems r = kernarg_job_at<AdamPackElems>(offsetof(AdamPackArgs, elems), e);
         const int nblk = (e + 1 < args.n_elems ? kernarg_job_at<AdamPackElems>(offsetof(AdamPackArgs, elems), e + 1).block0 : args.n_elem_blocks) - r.block0;
+        if (r.off_b < 0 && ((r.off_a | r.len) & 3) == 0) {
+            // plain range, 16-byte aligned (the dead pre_dense_cond range is 1.05 M floats): one float4 per thread and trip, loads of
+            // the trip before its stores (a scalar loop here was a chain of dependent HBM round trips: 32 trips x ~2 us)
+            const int n4 = r.len >> 2;
+            for (int i = (eb - r.block0) * 256 + threadIdx.x; i < n4; i += nblk * 256) {
+                const int64_t e0 = r.off_a + 4 * (int64_t)i;
+                bool skip[4], any_live = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { skip[q] = adam_skip(a, e0 + q); any_live |= !skip[q]; }
+                f32x4 P = *reinterpret_cast<const f32x4*>(a.p + e0), G = {0.f, 0.f, 0.f, 0.f}, M = G, V = G, S = G;
+                if (any_live) { G = *reinterpret_cast<const f32x4*>(a.g + e0); M = *reinterpret_cast<const f32x4*>(a.m + e0); V = *reinterpret_cast<const f32x4*>(a.v + e0); }
+                if (a.ema) S = *reinterpret_cast<const f32x4*>(a.ema + e0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float mq = M[q], vq = V[q], sq = S[q];
+                    P[q] = adam_math(a, coef, skip[q], P[q], G[q], mq, vq, sq);
+                    M[q] = mq; V[q] = vq; S[q] = sq;
+                }
+                if (any_live) {
+                    store16(a.p + e0, P, args.write_through);
+                    store16(a.m + e0, M, args.write_through);
+                    store16(a.v + e0, V, args.write_through);
+                }
+                if (a.ema) store16(a.ema + e0, S, args.write_through);
+            }
+            return;
+        }
         for (int i = (eb - r.block0) * 256 + threadIdx.x; i < r.len; i += nblk * 256) {
             const float pa = adam_elem(a, coef, r.off_a + i);
             if (r.off_b >= 0) {
@@ -1128,11 +1164,11 @@ __global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs args) {
                     out[q] = pq;
                 }
                 if (any_live) {
-                    *reinterpret_cast<f32x4*>(a.p + e0) = P[i];
-                    *reinterpret_cast<f32x4*>(a.m + e0) = M[i];
-                    *reinterpret_cast<f32x4*>(a.v + e0) = V[i];
+                    store16(a.p + e0, P[i], args.write_through);
+                    store16(a.m + e0, M[i], args.write_through);
+                    store16(a.v + e0, V[i], args.write_through);
                 }
-                if (a.ema) *reinterpret_cast<f32x4*>(a.ema + e0) = S[i];
+                if (a.ema) store16(a.ema + e0, S[i], args.write_through);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) tile[tr + 16 * i][4 * tc + q] = out[q];

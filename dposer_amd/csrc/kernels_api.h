@@ -282,5 +282,6 @@ struct AdamPackArgs {
     AdamArgs a;
     unsigned char* packed;
     int64_t bias_cat_off; // byte offset of the bias table in `packed`
+    int write_through;    // 1: parameters / moments / EMA leave as write-through stores (no dirty L2 lines behind the launch)
 };
 hipError_t launch_adam_pack(const AdamPackArgs& a, hipStream_t st);

@@ -205,8 +205,8 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
         auto add_e = [&](int64_t a, int64_t b, int64_t cat, int64_t len) {
             AdamPackElems& e = ap.elems[ne++];
             e.off_a = a; e.off_b = b; e.cat_off = cat; e.len = (int)len; e.block0 = eblocks;
-            int nb = (int)ceil_div(len, 1024);
-            eblocks += nb < 1 ? 1 : (nb > 128 ? 128 : nb);
+            int nb = (int)ceil_div(len, 1024);                    // one float4 per thread: the big dead range is ~1025 blocks of one trip each
+            eblocks += nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
         };
         std::vector<std::pair<int64_t, int64_t>> taken = matrices;
         for (int l = 0; l < L; ++l) {
@@ -293,6 +293,7 @@ struct ScoreTuning {
     int wgrad_batched = -1;           // DPOSER_WGRAD_BATCHED = 0 / 1: never / always one lane launch for all 256x256 wgrad tiles
     int wgrad_layer_lanes = -1;       // DPOSER_WGRAD_LAYER_LANES = 0 / 1: bucketed backward with split-K launches / one lane launch per layer
     int wgrad_groups = -1;            // DPOSER_WGRAD_GROUPS = n: bucketed backward with the lane launches of n layer groups (0: off)
+    int adam_write_through = 1;       // DPOSER_ADAM_WT = 0: plain stores for the optimizer state in the fused optimizer + re-pack kernel (A/B)
     int sampler_persistent = 0;       // DPOSER_SAMPLER_PERSISTENT = 1: one persistent kernel for the plain EM sampler
     int64_t sampler_persistent_min = 256;
     void load() {
@@ -308,6 +309,7 @@ struct ScoreTuning {
         wgrad_layer_lanes = env_tri("DPOSER_WGRAD_LAYER_LANES");
         e = getenv("DPOSER_WGRAD_GROUPS");
         wgrad_groups = e ? atoi(e) : -1;
+        adam_write_through = env_tri("DPOSER_ADAM_WT") == 0 ? 0 : 1;
         e = getenv("DPOSER_SAMPLER_PERSISTENT");
         sampler_persistent = e ? atoi(e) : 0;
         e = getenv("DPOSER_SAMPLER_PERSISTENT_MIN");
@@ -1656,6 +1658,7 @@ extern "C" int dposer_scorefc_adam_pack_step(dposer_scorefc_t h, float* flat, co
     a.ema_one_minus_decay = (float)ema_one_minus_decay;
     a.weight_decay = (float)weight_decay;
     ap.packed = (unsigned char*)packed;
+    ap.write_through = score_tuning().adam_write_through;
     DP_HIP_LAUNCH(launch_adam_pack(ap, st));
     return DPOSER_OK;
 }

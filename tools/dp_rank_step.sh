@@ -12,14 +12,14 @@ mkdir -p $OUT
 cd $R
 COMMON="--no-extra --no-cpu-baseline --no-live-roofline --steps 200 --warmup 20"
 {
-echo "# per-rank data-parallel step on one MI355X ($TAG, $(git -C $R rev-parse --short HEAD 2>/dev/null || echo snapshot))"
+echo "# per-rank data-parallel step on one MI355X ($TAG, $(git -C $R rev-parse --short HEAD 2>/dev/null || cat $R/.head_rev 2>/dev/null || echo snapshot))"
 echo
 echo "| poses per rank | plain ms | forced one-rank RCCL group ms | extra env |"
 echo "|---:|---:|---:|---|"
 for B in 1280 4096 8192 16384 32768 65536; do
   P=$(python3 bench.py --global-batch $B $COMMON 2>/dev/null | grep '^{' | python3 -c "import sys,json; print('%.4f' % json.loads(sys.stdin.read())['ms_per_step'])")
   F=$(WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 DPOSER_DIST_FORCE_COLLECTIVES=1 python3 bench.py --global-batch $B $COMMON 2>/dev/null | grep '^{' | python3 -c "import sys,json; print('%.4f' % json.loads(sys.stdin.read())['ms_per_step'])")
-  echo "| $B | $P | $F | $DP_EXTRA_ENV |"
+  echo "| $B | $P | $F | ${DP_EXTRA_ENV:-} |"
 done
 } > $OUT/${TAG}_dp_rank_step.md
 cat $OUT/${TAG}_dp_rank_step.md

@@ -199,12 +199,53 @@ def mfma(paths, as_json=False):
               f"{r['insts_valu']:.4g} | {f(r['issue_stall_frac'])} | {f(r['parked_frac'])} | {f(r['active_frac'])} |")
 
 
+def dispatch_table(paths, needle, per_step=0):
+    """Per-DISPATCH counters and durations of the kernels whose short name contains `needle`, in launch order, from PMC-pass databases
+    (each pass also carries a kernel trace).  The n-th dispatch of a kernel name in one database is matched with the n-th in the
+    others.  With `per_step` = launches of that kernel per training step, the table is folded over the steps (mean per position):
+    position 0 of EpiGNBwd is the K = 64 post_dense launch -- a GroupNorm-backward epilogue with (almost) no K loop -- the others K = 1024."""
+    per = {}          # short name -> {"dur": [..], counter: [..]}
+    for path in paths:
+        cur = sqlite3.connect(path).cursor()
+        ccols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+        order = "dispatch_id" if "dispatch_id" in ccols else ("id" if "id" in ccols else "rowid")
+        for name, counter, value in cur.execute(f"select kernel_name, counter_name, value from counters_collection order by {order}"):
+            k = short(name)
+            if needle in k:
+                per.setdefault(k, {}).setdefault(counter, []).append(value)
+        kcols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        name_col = "name" if "name" in kcols else [c for c in kcols if "name" in c][0]
+        durs = {}
+        for name, s0, e0 in cur.execute(f"select {name_col}, start, end from kernels order by start"):
+            k = short(name)
+            if needle in k:
+                durs.setdefault(k, []).append((e0 - s0) / 1e3)
+        for k, v in durs.items():
+            per.setdefault(k, {}).setdefault("duration_us", v)       # (first database wins: durations differ little between passes)
+    for k, cols in per.items():
+        names = sorted(cols)
+        n = min(len(v) for v in cols.values())
+        print(f"\n## `{k}`: {n} dispatches\n")
+        if per_step > 0:
+            print("| position in step | launches | " + " | ".join(names) + " |")
+            print("|---:|---:|" + "---:|" * len(names))
+            for pos in range(per_step):
+                idx = [i for i in range(n) if i % per_step == pos]
+                print(f"| {pos} | {len(idx)} | " + " | ".join(f"{sum(cols[c][i] for i in idx) / max(len(idx), 1):.5g}" for c in names) + " |")
+        else:
+            print("| # | " + " | ".join(names) + " |")
+            print("|---:|" + "---:|" * len(names))
+            for i in range(n):
+                print(f"| {i} | " + " | ".join(f"{cols[c][i]:.5g}" for c in names) + " |")
+
+
 USAGE = """usage: rocpd_summary.py <kernel-trace.db>                      per-kernel table (calls, total, avg, min, max)
        rocpd_summary.py --gaps <db>                            idle time in front of each kernel kind
        rocpd_summary.py --sequence <db> [anchor [which]]       kernels of one step in start order
        rocpd_summary.py --pmc | --pmc-json <db> ...            FETCH_SIZE / WRITE_SIZE passes -> HBM bytes per launch
        rocpd_summary.py --counters <db> ...                    per-kernel average of every counter
-       rocpd_summary.py --mfma | --mfma-json <db> ...          matrix-pipe busy fraction, effective clock, stalls"""
+       rocpd_summary.py --mfma | --mfma-json <db> ...          matrix-pipe busy fraction, effective clock, stalls
+       rocpd_summary.py --dispatches <needle> <per_step> <db> ...   per-dispatch counters of one kernel kind, folded over the steps"""
 
 
 def cli(argv):
@@ -230,6 +271,8 @@ def cli(argv):
         pmc_json(rest)
     elif mode == "--counters":
         counters(rest)
+    elif mode == "--dispatches":
+        dispatch_table(rest[2:], rest[0], int(rest[1]))
     elif mode.startswith("--"):
         print(USAGE, file=sys.stderr)
         return 2
