@@ -221,7 +221,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTr
                 if (e < a.E) {
                     f32x4 v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = temb_from_freq<sizeof(T) == 2>(label, e < half, fr[k][r], a.fourier);
+                    for (int r = 0; r < 4; ++r) v[r] = temb_from_freq<sizeof(T) == 2>(label, e < half, fr[k][r], 0);      // (positional only: see launch_prep_train)
                     store_quad_ft<T>(a.emb, s, e, a.E, v);
                 }
             }
@@ -229,6 +229,11 @@ template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTr
     }
 }
 hipError_t launch_prep_train(const PrepTrainArgs& a, hipStream_t st) {
+    // The fused DSM step is positional-embedding only (its entry point checks).  The kernel compiles the Fourier form OUT: as a runtime
+    // branch it kept 64 inlined libm sinf / cosf (Payne-Hanek slow paths included) between the 32 hardware sin / cos the waves actually
+    // execute -- 10,343 instructions, the executed ones scattered over 70 KB of code, one instruction-cache miss per unrolled element:
+    // the waves sat parked for ~10 of the kernel's 17 us at any batch size (tools/small_step_pmc.sh).
+    if (a.fourier) return hipErrorInvalidValue;
     PrepTrainDev d;
     d.a = a;
     d.sde = make_sde_dev(a.sde);
