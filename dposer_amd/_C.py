@@ -140,6 +140,7 @@ SIGNATURES = {
     "dposer_lbs_prepare_joint_lists": (C.c_int, [vp, vp, vp, vp, vp]),
     "dposer_body_tuning_reload": (None, []),
     "dposer_scorefc_tuning_reload": (None, []),
+    "dposer_scorefc_debug_set_dropout_masks": (C.c_int, [vp, vp, i64]),
     "dposer_lbs_backward": (C.c_int, [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp,
                                       vp, vp, i64, C.POINTER(vp), vp, vp, i64, vp]),
 }

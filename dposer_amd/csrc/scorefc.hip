@@ -61,6 +61,8 @@ struct dposer_scorefc_s {
     int64_t pk_wpostT, pk_wlT[MAX_L], pk_wtT_all, pk_bwd_end;
     PackJobs fwd_jobs, bwd_jobs;
     BiasCatJobs bias_jobs;
+    const unsigned char* dbg_keep = nullptr;   // test hook: injected dropout keep decisions [L][dbg_keep_batch][H] (device), see drop_cfg
+    int64_t dbg_keep_batch = 0;
     AdamPackArgs adam_pack;    // tensors / element ranges of the fused optimizer + re-pack step (filled by create(); n_tensors == 0: not available)
     std::vector<float> host_stage;   // staging for small H2D copies (labels)
     // second stream for the parameter-gradient side of the backward pass (small batches), see backward_core
@@ -519,8 +521,19 @@ static DropoutCfg drop_cfg(const dposer_scorefc_s* h, bool train, int site, uint
         d.offset = step;
         d.seed = seed;
         d.groups_x4 = h->H / 8;
+        if (h->dbg_keep) d.ext_keep = h->dbg_keep + (int64_t)site * h->dbg_keep_batch * h->H;
     }
     return d;
+}
+// TEST HOOK: keep decisions of every dropout site as bytes [n_layers][batch][H] on the device (NULL: back to the Philox streams).  Lets a
+// test feed the masks the REFERENCE drew with torch's generator (golden g4) through the fused training step; honoured by the
+// tile-per-group training epilogue (hidden_dim 1024) for calls with exactly this batch size.
+extern "C" int dposer_scorefc_debug_set_dropout_masks(dposer_scorefc_t h, const unsigned char* keep, int64_t batch) {
+    DP_CHECK_ARG(h, "null handle");
+    DP_CHECK_ARG(!keep || (batch > 0 && h->gs == 32), "injected dropout masks: hidden_dim 1024 only, batch > 0");
+    h->dbg_keep = keep;
+    h->dbg_keep_batch = keep ? batch : 0;
+    return DPOSER_OK;
 }
 
 // One GroupNorm layer.  per_sample_t: K-concat(h, temb) with packed bias_cat; else x-path only with

@@ -90,6 +90,10 @@ int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat_params, void* pack
  * DPOSER_WGRAD_STREAM, DPOSER_WGRAD_BATCHED, DPOSER_WGRAD_LAYER_LANES, DPOSER_WGRAD_GROUPS, DPOSER_FINAL_SMALL_MAX,
  * DPOSER_SAMPLER_PERSISTENT[_MIN]); they are otherwise read ONCE per process (first use), never per call. */
 void dposer_scorefc_tuning_reload(void);
+/* TEST HOOK: dropout keep decisions of every site as bytes [n_layers][batch][hidden_dim] (device memory, NULL = back to the Philox
+ * streams), used by the training epilogues of calls with exactly this batch size (hidden_dim 1024).  It lets a parity test run the
+ * masks the reference drew with torch's generator through the fused training step. */
+int dposer_scorefc_debug_set_dropout_masks(dposer_scorefc_t h, const unsigned char* keep, int64_t batch);
 
 enum { DPOSER_WS_INFER = 0, DPOSER_WS_SHARED_T = 1, DPOSER_WS_TRAIN = 2 };
 int64_t dposer_scorefc_workspace_bytes(dposer_scorefc_t h, int64_t batch, int32_t mode, int32_t n_steps);

@@ -1289,3 +1289,46 @@ def test_optimizer_step_that_repacks_the_weights_keeps_every_bit(n_blocks, n_pos
     # optimizer; the step after the evaluation step has to pack again, plus the optimizer's bump
     assert a[6] == [2, 1, 2, 1], a[6]
     assert b[6] == [1, 1, 1, 1], b[6]
+
+
+def test_train_steps_with_the_reference_dropout_masks_match_the_reference_golden():
+    """Closes the dropout chain directly: golden g4 holds the REFERENCE's own recorded training steps (steps 0, 1, 2, 4999, 5000 of
+    get_step_fn with dropout 0.1) together with the keep masks torch's generator drew.  Those masks are fed through the fused HIP step
+    (test hook dposer_scorefc_debug_set_dropout_masks: the training epilogue takes its keep decisions from them instead of Philox) and
+    loss, learning rate, parameters, Adam moments and EMA shadows are compared with the reference's values themselves -- no oracle in
+    between (round 3 went HIP == oracle without dropout, oracle == g4 with masks)."""
+    from dposer_amd import _C
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    g = load("g4_train_steps")
+    cfg, m, p = make_model(int(g["seed"]), precision="fp32", dropout=0.1)
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    opt = losses.get_optimizer(cfg, m.parameters())
+    ema = ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate)
+    state = dict(optimizer=opt, model=m, ema=ema, step=0)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+    names = R.param_names()
+    batch = g["batch"]
+    B = batch.shape[0]
+    eng = m._engine()
+    try:
+        for i in range(5):
+            s = int(g[f"s{i}_step"])
+            state["step"] = s
+            keep = torch.tensor(np.ascontiguousarray(g[f"s{i}_keep"]), dtype=torch.uint8, device=DEV)          # [5 sites, B, 1024]
+            assert keep.shape == (5, B, 1024) and 0.85 < float(keep.float().mean()) < 0.95
+            _C.check(eng.lib.dposer_scorefc_debug_set_dropout_masks(eng.h, _C.ptr(keep), B), "set_dropout_masks")
+            t = torch.tensor(g[f"s{i}_u"]) * (1.0 - 1e-5) + 1e-5
+            z = torch.tensor(g[f"s{i}_z"])
+            out = step_fn(state, _dev(batch), t=t.to(DEV), z=z.to(DEV))
+            torch.cuda.synchronize()
+            assert abs(float(out["step_loss"]) - float(g[f"s{i}_loss"])) / float(g[f"s{i}_loss"]) < 5e-5, i
+            assert abs(opt.param_groups[0]["lr"] - float(g[f"s{i}_lr"])) < 1e-12
+            for n, prm in m.named_parameters():                # (the golden holds norm + probe entries of every tensor: helpers.probe)
+                assert rel_err(probe(n, prm), g[f"s{i}_param/{n}"]) < 2e-5, (i, n)
+                assert rel_err(probe(n, ema.shadow_params[names.index(n)]), g[f"s{i}_ema/{n}"]) < 2e-5, (i, n)
+                if f"s{i}_m/{n}" in g.files:
+                    assert rel_err(probe(n, opt.state[prm]["exp_avg"]), g[f"s{i}_m/{n}"]) < 5e-3, (i, n)
+                    assert rel_err(probe(n, opt.state[prm]["exp_avg_sq"]), g[f"s{i}_v/{n}"]) < 5e-3, (i, n)
+    finally:
+        eng.lib.dposer_scorefc_debug_set_dropout_masks(eng.h, None, 0)
