@@ -16,6 +16,7 @@ struct DropoutCfg {
     uint32_t offset;   // optimisation step
     uint64_t seed;
     int groups_x4;     // H/8 = number of counters per sample
+    long long ext_rows;              // rows (samples) of ext_keep: padded rows beyond them keep everything
     const unsigned char* ext_keep;   // TEST HOOK (dposer_scorefc_debug_set_dropout_masks): keep decisions [samples][H] of this site, one byte
                                      // each, used instead of the Philox draw -- feeds a recorded torch mask through the fused step
 };
@@ -88,6 +89,7 @@ __device__ __forceinline__ uint32_t dropout_mask16_bits(const DropoutCfg& d, int
 __device__ __forceinline__ uint32_t dropout_bits16(const DropoutCfg& d, int64_t s, int g, int hi) {
     uint32_t bits = 0;
     if (d.ext_keep) {                                  // injected decisions (tests): channel 32 g + 8 q + 4 hi + r -> bit 4 q + r
+        if (s >= d.ext_rows) return 0xffffu;
         const unsigned char* row = d.ext_keep + s * (int64_t)(d.groups_x4 * 8) + 32 * g + 4 * hi;
 #pragma unroll
         for (int q = 0; q < 4; ++q)

@@ -521,7 +521,7 @@ static DropoutCfg drop_cfg(const dposer_scorefc_s* h, bool train, int site, uint
         d.offset = step;
         d.seed = seed;
         d.groups_x4 = h->H / 8;
-        if (h->dbg_keep) d.ext_keep = h->dbg_keep + (int64_t)site * h->dbg_keep_batch * h->H;
+        if (h->dbg_keep) { d.ext_keep = h->dbg_keep + (int64_t)site * h->dbg_keep_batch * h->H; d.ext_rows = h->dbg_keep_batch; }
     }
     return d;
 }
