@@ -375,8 +375,8 @@ def test_train_steps_match_reference_golden():
             assert rel_err(t2n(ema.shadow_params[names.index(n)]), st.ema[n].numpy()) < 2e-5, (i, n)
             if n.startswith("pre_dense_cond"):
                 continue
-            assert rel_err(t2n(opt.state[prm]["exp_avg"]), st.m[n].numpy()) < 5e-3, (i, n)
-            assert rel_err(t2n(opt.state[prm]["exp_avg_sq"]), st.v[n].numpy()) < 5e-3, (i, n)
+            assert rel_err(t2n(opt.state[prm]["exp_avg"]), st.m[n].numpy()) < 2e-4, (i, n)
+            assert rel_err(t2n(opt.state[prm]["exp_avg_sq"]), st.v[n].numpy()) < 2e-4, (i, n)
     assert ema.num_updates == 5
 
 
@@ -1328,7 +1328,7 @@ def test_train_steps_with_the_reference_dropout_masks_match_the_reference_golden
                 assert rel_err(probe(n, prm), g[f"s{i}_param/{n}"]) < 2e-5, (i, n)
                 assert rel_err(probe(n, ema.shadow_params[names.index(n)]), g[f"s{i}_ema/{n}"]) < 2e-5, (i, n)
                 if f"s{i}_m/{n}" in g.files:
-                    assert rel_err(probe(n, opt.state[prm]["exp_avg"]), g[f"s{i}_m/{n}"]) < 5e-3, (i, n)
-                    assert rel_err(probe(n, opt.state[prm]["exp_avg_sq"]), g[f"s{i}_v/{n}"]) < 5e-3, (i, n)
+                    assert rel_err(probe(n, opt.state[prm]["exp_avg"]), g[f"s{i}_m/{n}"]) < 1e-4, (i, n)      # (measured: 4.7e-5 is the
+                    assert rel_err(probe(n, opt.state[prm]["exp_avg_sq"]), g[f"s{i}_v/{n}"]) < 1e-4, (i, n)   #  largest of all 700 comparisons)
     finally:
         eng.lib.dposer_scorefc_debug_set_dropout_masks(eng.h, None, 0)
