@@ -492,6 +492,34 @@ def main():
                                        "traffic_source": "lookup: profiles/pmc_hbm_traffic.json (sum over the LBS kernels of one call); NOT measured in this run",
                                        "note": "the leg is several kernels (FK, pose-blend GEMM on the bf16 matrix pipe, skinning): `achieved` is the "
                                                "algorithmic output bytes over the whole leg's time, median of the runs"}}
+        # the same two legs on an asset whose skinning weights are spatially coherent, as a real SMPL-X template's are (the default
+        # synthetic asset skins every vertex to four RANDOM joints: the worst case for the skinning kernels' per-joint gathers)
+        bm_c = BodyModel(make_synthetic_smplx_asset(seed=0, coherent_skinning=True)).to(dev)
+        for grad in (False, True):
+            def leg():
+                if grad:
+                    out = bm_c(pose_body=pb)
+                    torch.autograd.backward([out.v, out.Jtr], [gv[:, :out.v.shape[1]], gj[:, :out.Jtr.shape[1]]])
+                    pb.grad = None
+                else:
+                    with torch.no_grad():
+                        bm_c(pose_body=pb)
+            for _ in range(3):
+                leg()
+            torch.cuda.synchronize()
+            secs = []
+            for _rep in range(3):
+                e0.record()
+                for _ in range(10):
+                    leg()
+                e1.record()
+                torch.cuda.synchronize()
+                secs.append(e0.elapsed_time(e1) * 1e-3 / 10)
+            sec = sorted(secs)[1]
+            extra[("lbs_full_fwd_bwd" if grad else "lbs_full_fwd") + "_coherent_skinning"] = {
+                "poses_per_s_per_gpu": nl / sec, "batch": nl, "ms": sec * 1e3, "runs_ms": [round(x * 1e3, 4) for x in secs],
+                "note": "synthetic asset with contiguous vertex ranges following one bone and its tree neighbours (make_synthetic_smplx_asset(coherent_skinning=True))"}
+        del bm_c
         # the same forward + backward the way a loss on the outputs reaches it ((v.sum() + Jtr.sum()).backward(): torch's reduction and the
         # materialisation of its stride-0 gradient are inside the timed region) -- the measurement of rounds 1-2, kept comparable
         def lbs_loss_backward():

@@ -38,7 +38,14 @@ def make_synthetic_asset(model_type="smplx", seed=0, num_betas=10, num_expressio
     return a
 
 
-def make_synthetic_smplx_asset(seed=0, num_vertices=10475, num_betas=10, num_expressions=10, nnz_per_vertex=4, parents=None):
+def make_synthetic_smplx_asset(seed=0, num_vertices=10475, num_betas=10, num_expressions=10, nnz_per_vertex=4, parents=None,
+                               coherent_skinning=False):
+    """``coherent_skinning``: the default asset skins every vertex to FOUR RANDOM joints of 55 -- the worst case for any kernel that
+    gathers per-joint transforms (no two neighbouring vertices share a joint; the per-lane LDS reads of the skinning kernels collide in
+    half of their cycles).  A real SMPL-X template is spatially coherent: a vertex follows the bone it sits on and that
+    bone's neighbours in the tree, and consecutive vertex ids mostly lie on the same body part.  With this flag the vertices are cut
+    into J contiguous id ranges, range j follows joint j, its parent and up to two of its tree neighbours (same arithmetic, same
+    sizes -- only the index pattern changes).  Used by the benchmark's ``*_coherent_skinning`` legs; tests keep the default."""
     rs = np.random.RandomState(seed)
     parents = SMPLX_PARENTS if parents is None else parents
     V, J = num_vertices, len(parents)
@@ -53,9 +60,22 @@ def make_synthetic_smplx_asset(seed=0, num_vertices=10475, num_betas=10, num_exp
         J_regressor[j, idx] = (w / w.sum()).astype(np.float32)
     # skinning weights: nnz_per_vertex non-zeros per vertex, rows sum to one (real SMPL-X has <= 4)
     weights = np.zeros((V, J), dtype=np.float32)
+    children = {j: [c for c in range(J) if parents[c] == j] for j in range(J)}
     for v in range(V):
         idx = rs.choice(J, nnz_per_vertex, replace=False)
         w = rs.uniform(0.05, 1.0, nnz_per_vertex)
+        if coherent_skinning:
+            j = min(J - 1, v * J // V)
+            near = [j] + ([int(parents[j])] if parents[j] >= 0 else []) + children[j]
+            if parents[j] >= 0:
+                near += [c for c in children[int(parents[j])] if c != j] + ([int(parents[int(parents[j])])] if parents[int(parents[j])] >= 0 else [])
+            near = list(dict.fromkeys(near))
+            k = 0
+            while len(near) < nnz_per_vertex:                  # (tiny trees: pad with any other joint)
+                if k not in near:
+                    near.append(k)
+                k += 1
+            idx = np.array(near[:nnz_per_vertex])
         weights[v, idx] = (w / w.sum()).astype(np.float32)
     faces = rs.randint(0, V, size=(20908, 3)).astype(np.int32)
     lmk_faces_idx = rs.randint(0, faces.shape[0], size=51).astype(np.int32)
