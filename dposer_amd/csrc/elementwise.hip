@@ -799,16 +799,14 @@ hipError_t launch_colsum(int f32, const void* in, float* part, int64_t Spad, int
 // ------------------------------------------------------------------------------------------------
 // gradient finalisation and optimizer
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const float* scratch, float* grad) {
-    __shared__ float red[8][32];
-    (void)jobs;
-    const ReduceJob j = kernarg_job<ReduceJob>((int)blockIdx.y);
+// one job of the deterministic reductions into the flat gradient; (bx, nbx): this block's index / the number of blocks of the job
+__device__ __forceinline__ void reduce_job_body(const ReduceJob& j, const float* scratch, float* grad, int bx, int nbx, float (*red)[32]) {
     if (j.nsrc == 0) {      // a range that never gets a gradient (dead parameters): zeros -- was a memset launch of its own
         const bool al = ((j.dst_off | j.count) & 3) == 0;
         const int64_t n4 = al ? (j.count >> 2) : 0;
-        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x)
+        for (int64_t e = (int64_t)bx * 256 + threadIdx.x; e < n4; e += (int64_t)nbx * 256)
             reinterpret_cast<f32x4*>(grad + j.dst_off)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int64_t e = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < j.count; e += (int64_t)gridDim.x * blockDim.x)
+        for (int64_t e = (n4 << 2) + (int64_t)bx * 256 + threadIdx.x; e < j.count; e += (int64_t)nbx * 256)
             grad[j.dst_off + e] = 0.f;
         return;
     }
@@ -816,7 +814,7 @@ __global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const flo
         // many partial rows, few elements (GroupNorm / bias partials): 32 elements x 8 source slices per block,
         // fixed summation order => deterministic
         const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
-        for (int64_t e0 = (int64_t)blockIdx.x * 32; e0 < j.count; e0 += (int64_t)gridDim.x * 32) {
+        for (int64_t e0 = (int64_t)bx * 32; e0 < j.count; e0 += (int64_t)nbx * 32) {
             const int64_t e = e0 + el;
             float acc = 0.f;
             if (e < j.count) {
@@ -849,7 +847,7 @@ __global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const flo
     // few partial rows, many elements (split-K weight slabs): 16-byte accesses when every address is 16-byte aligned
     if (((j.src_off | j.src_stride | j.dst_off | j.count) & 3) == 0) {
         const int64_t n4 = j.count >> 2;
-        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t e = (int64_t)bx * 256 + threadIdx.x; e < n4; e += (int64_t)nbx * 256) {
             const f32x4* p = reinterpret_cast<const f32x4*>(scratch + j.src_off) + e;
             const int64_t st4 = j.src_stride >> 2;
             f32x4 acc = p[0];
@@ -871,31 +869,34 @@ __global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const flo
         }
         return;
     }
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < j.count; e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = (int64_t)bx * 256 + threadIdx.x; e < j.count; e += (int64_t)nbx * 256) {
         const float* p = scratch + j.src_off + e;
         float acc = 0.f;
         for (int k = 0; k < j.nsrc; ++k) acc += p[(int64_t)k * j.src_stride];
         grad[j.dst_off + e] = acc;
     }
 }
+__global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const float* scratch, float* grad) {
+    __shared__ float red[8][32];
+    (void)jobs;
+    const ReduceJob j = kernarg_job<ReduceJob>((int)blockIdx.y);
+    reduce_job_body(j, scratch, grad, (int)blockIdx.x, (int)gridDim.x, red);
+}
+static int reduce_job_blocks(const ReduceJobs& jobs);
+static inline int reduce_job_blocks_fwd(const ReduceJobs& jobs) { return reduce_job_blocks(jobs); }
 hipError_t launch_reduce_grads(const ReduceJobs& jobs, const float* scratch, float* flat_grad, hipStream_t st) {
     if (jobs.n <= 0) return hipSuccess;
     // grid-stride loops inside; the result of every element is formed by one thread / one block in a fixed order whatever the grid.
     // Blocks per job: enough float4 lanes for the largest slab job, 64 ... 512 (the zero fill and the many-row jobs stride)
-    int64_t big = 0;
-    for (int i = 0; i < jobs.n; ++i)
-        if (jobs.job[i].nsrc > 0 && jobs.job[i].nsrc <= 64 && jobs.job[i].count > big) big = jobs.job[i].count;
-    int gx = (int)((big / 4 + 255) / 256);
-    gx = gx < 64 ? 64 : (gx > 512 ? 512 : gx);
-    hipLaunchKernelGGL(k_reduce_grads, dim3(gx, jobs.n), dim3(256), 0, st, jobs, scratch, flat_grad);
+    hipLaunchKernelGGL(k_reduce_grads, dim3(reduce_job_blocks_fwd(jobs), jobs.n), dim3(256), 0, st, jobs, scratch, flat_grad);
     return hipGetLastError();
 }
 
 // Partial tiles of the batched weight-gradient launch (wgrad_batch.h) -> flat gradient.  Block (x, y): rows [16 x, 16 x + 16) of output
 // tile y = (problem, lane slot); the partition is re-derived from the same struct the GEMM kernel used; partials are added in row
 // order of the lane space (row-split tensors: first part, then the next) -- a fixed order.
-__global__ void __launch_bounds__(256) k_reduce_wgrad_tiles(WgradBatchArgs a, float* grad) {
-    const int p = blockIdx.y >> 4, slot = blockIdx.y & 15;
+__device__ __forceinline__ void reduce_wgrad_tile_body(const WgradBatchArgs& a, float* grad, int bxi, int byi) {
+    const int p = byi >> 4, slot = byi & 15;
     const WgradLaneProblem& pr = a.prob[p];
     if ((pr.split_k && slot >= 8) || (pr.mode == 1 && slot >= 4)) return;
     const int half = pr.mode == 1 ? 0 : slot >> 3;
@@ -922,7 +923,7 @@ __global__ void __launch_bounds__(256) k_reduce_wgrad_tiles(WgradBatchArgs a, fl
                 if ((lo > st2 ? lo : st2) < (hi < e2 ? hi : e2)) ++ord;
                 st2 = e2;
             }
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.partials + ((int64_t)(wgb_block(l, sl) * WGB_MAX_SEG + ord) << 16)) + blockIdx.x * 1024 + threadIdx.x;
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.partials + ((int64_t)(wgb_block(l, sl) * WGB_MAX_SEG + ord) << 16)) + bxi * 1024 + threadIdx.x;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v = src[i * 256];
@@ -934,12 +935,48 @@ __global__ void __launch_bounds__(256) k_reduce_wgrad_tiles(WgradBatchArgs a, fl
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int idx4 = blockIdx.x * 1024 + i * 256 + threadIdx.x;       // float4 index inside the 256 x 256 tile
+        const int idx4 = bxi * 1024 + i * 256 + threadIdx.x;       // float4 index inside the 256 x 256 tile
         const int row = idx4 >> 6, col = (idx4 & 63) << 2;
         float* d = grad + dst0 + (int64_t)row * ld + col;
         if (((dst0 | ld) & 3) == 0) *reinterpret_cast<f32x4*>(d) = acc[i];
         else { d[0] = acc[i][0]; d[1] = acc[i][1]; d[2] = acc[i][2]; d[3] = acc[i][3]; }
     }
+}
+__global__ void __launch_bounds__(256) k_reduce_wgrad_tiles(WgradBatchArgs a, float* grad) {
+    reduce_wgrad_tile_body(a, grad, (int)blockIdx.x, (int)blockIdx.y);
+}
+// Both reductions behind a lane launch as ONE launch: blocks [0, 16 * 16 nprob) add partial tiles, the rest run the small jobs
+// (GroupNorm / bias partials, split-K slabs of the 63-wide layers, zero fill) -- same bodies, same sums, one kernel boundary less.
+struct ReduceAllArgs {
+    ReduceJobs jobs;          // (first member: jobs are fetched through the kernel-argument segment)
+    WgradBatchArgs wb;
+    int job_blocks;           // blocks per job
+};
+__global__ void __launch_bounds__(256) k_reduce_all(ReduceAllArgs a, const float* scratch, float* grad) {
+    __shared__ float red[8][32];
+    const int n_tile_blocks = 16 * 16 * a.wb.nprob;
+    const int b = blockIdx.x;
+    if (b < n_tile_blocks) {
+        reduce_wgrad_tile_body(a.wb, grad, b & 15, b >> 4);
+        return;
+    }
+    const int jb = b - n_tile_blocks;
+    const ReduceJob j = kernarg_job<ReduceJob>(jb / a.job_blocks);
+    reduce_job_body(j, scratch, grad, jb % a.job_blocks, a.job_blocks, red);
+}
+static int reduce_job_blocks(const ReduceJobs& jobs) {
+    int64_t big = 0;
+    for (int i = 0; i < jobs.n; ++i)
+        if (jobs.job[i].nsrc > 0 && jobs.job[i].nsrc <= 64 && jobs.job[i].count > big) big = jobs.job[i].count;
+    int gx = (int)((big / 4 + 255) / 256);
+    return gx < 64 ? 64 : (gx > 512 ? 512 : gx);
+}
+hipError_t launch_reduce_all(const WgradBatchArgs& wb, const ReduceJobs& jobs, const float* scratch, float* flat_grad, hipStream_t st) {
+    if (jobs.n <= 0) return launch_reduce_wgrad_tiles(wb, flat_grad, st);
+    ReduceAllArgs a;
+    a.jobs = jobs; a.wb = wb; a.job_blocks = reduce_job_blocks(jobs);
+    hipLaunchKernelGGL(k_reduce_all, dim3((unsigned)(16 * 16 * wb.nprob + a.job_blocks * jobs.n)), dim3(256), 0, st, a, scratch, flat_grad);
+    return hipGetLastError();
 }
 hipError_t launch_reduce_wgrad_tiles(const WgradBatchArgs& a, float* flat_grad, hipStream_t st) {
     hipLaunchKernelGGL(k_reduce_wgrad_tiles, dim3(16, (unsigned)(a.nprob * 16)), dim3(256), 0, st, a, flat_grad);

@@ -955,17 +955,22 @@ struct SiLUBwdParams {
     void* outT;        // optional: FT [N][Spad]
     int64_t Spad;
     int act;           // DP_ACT_* (ACTRT instantiations)
+    float* part;       // optional: [wave rows][N] column sums of dU over each wave's samples (the bias gradient's partials: a
+                       // k_colsum launch over dU otherwise), summed like the GroupNorm-backward epilogue sums its bias partials
 };
 template <typename T, bool ACTRT = false> struct EpiSiLUBwd {
     typedef SiLUBwdParams Params;
     static constexpr int kScratchPerWave = TileT<T>::SCRATCH_BYTES;
     template <int TC, int TS>
-    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float* lpar, int lstride, unsigned char* scr) {
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int, const float* lpar, int lstride, unsigned char* scr) {
         struct { const T* pre; T* out; int N; int64_t S_valid; } p = {(const T*)pp.pre, (T*)pp.out, pp.N, pp.S_valid};
         constexpr bool PRECISE = sizeof(T) == 4;
-        const int j = lane & 31;
+        const int j = lane & 31, hi = lane >> 5;
 #pragma unroll
-        for (int tc = 0; tc < TC; ++tc)
+        for (int tc = 0; tc < TC; ++tc) {
+            float dsum[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dsum[r] = 0.f;
 #pragma unroll
             for (int ts = 0; ts < TS; ++ts) {
                 const int64_t s = sbase + ts * 32 + j;
@@ -976,7 +981,16 @@ template <typename T, bool ACTRT = false> struct EpiSiLUBwd {
                 for (int r = 0; r < 16; ++r) o[r] = (s < p.S_valid) ? acc[tc][ts][r] * (ACTRT ? dact_rt<PRECISE>(u[r], pp.act) : dsilu_f<PRECISE>(u[r])) : 0.f;
                 TileIO<T>::store(p.out + tb, lane, o);
                 if (pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, cbase + tc * 32, pp.Spad), scr, lane, o);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dsum[r] += o[r];
             }
+            if (pp.part) {      // column sums over the wave's samples: lane (j & 15) == i ends with the sum of register i (both halves)
+                const float db = butterfly_reduce16(dsum, lane);
+                const int i = j & 15;
+                const int c = cbase + tc * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                if (j < 16) pp.part[(int64_t)wrow * p.N + c] = db;
+            }
+        }
     }
 };
 

@@ -228,6 +228,8 @@ struct ReduceJobs {
 };
 hipError_t launch_reduce_grads(const ReduceJobs& jobs, const float* scratch, float* flat_grad, hipStream_t st);
 hipError_t launch_reduce_wgrad_tiles(const WgradBatchArgs& a, float* flat_grad, hipStream_t st);   // wgrad_batch.h: partial tiles -> flat gradient
+// both of the above in one launch (the partial tiles of a lane launch + the small jobs behind it)
+hipError_t launch_reduce_all(const WgradBatchArgs& a, const ReduceJobs& jobs, const float* scratch, float* flat_grad, hipStream_t st);
 hipError_t launch_sum_partials(const float* part, int n, float* out, hipStream_t st);             // out[0] = sum(part[0..n))
 hipError_t launch_sqnorm(const float* g, int64_t n, float* part, int* nblocks, hipStream_t st);   // partial sums of g^2
 

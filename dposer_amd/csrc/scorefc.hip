@@ -363,7 +363,7 @@ struct Ws {
     SamplerLayer* smp_layers;      // device table of the persistent sampler's per-layer operands
     // transposed copies / partials / slabs (training)
     char *dyT[MAX_L], *hT[MAX_L], *tembT, *embT, *xinT, *dresT, *dUT;
-    float *gn_part[MAX_L], *cs_part_post, *cs_part_se, *slabs;
+    float *gn_part[MAX_L], *cs_part_post, *cs_part_se, *silu_part, *slabs;
     int64_t total;
     int64_t slab_elems;   // capacity of `slabs` in floats
 };
@@ -455,6 +455,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         const int64_t nchunks = ceil_div(Bpad, 2048);
         w.cs_part_post = (float*)take(nchunks * h->Cp * 4);
         w.cs_part_se = (float*)take(nchunks * E * 4);
+        w.silu_part = (float*)take((Bpad / 32) * (int64_t)E * 4);       // per-wave column sums of dU (time-branch dgrad epilogue)
         // slabs: worst case ksplit 32 is never reached for the big tensors; size exactly below
         const int64_t stages = Bpad / (h->KBS * 4);
         int64_t slab_elems = 0;
@@ -1309,7 +1310,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     ReduceJobs rj;
     rj.n = 0;
     int64_t slab_cursor = 0;
-    int n_chunks_post = 0, n_chunks_se = 0;
+    int n_chunks_post = 0, silu_rows = 0;
     const int64_t lane_room = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536;
     // Deterministic reduction into the flat gradient: every partial buffer lives in the workspace (offsets relative to
     // w.slabs); the jobs of one bucket are launched together as soon as its last wgrad has been queued.
@@ -1391,9 +1392,8 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
             for (int l = grp_lo[cur_group]; l <= grp_hi[cur_group]; ++l) fl += 2.0 * (double)B * H * ((l >= 1 ? (double)H : 0.0) + (double)E);
             wb.alg_flops = fl;
             DP_HIP_LAUNCH(gemm_wgrad_tr_batch(wb, sw));
-            DP_HIP_LAUNCH(launch_reduce_wgrad_tiles(wb, flat_grad, sw));
             for (int l = grp_hi[cur_group]; l >= grp_lo[cur_group]; --l) add_layer_jobs(l);
-            if (rj.n > 0) DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, sw));
+            DP_HIP_LAUNCH(launch_reduce_all(wb, rj, w.slabs, flat_grad, sw));          // partial tiles + the group's small reductions: one launch
             rj.n = 0;
             DP_TRY(mark_final(h, sink, L - 1 - grp_hi[cur_group], grp_hi[cur_group] - grp_lo[cur_group] + 1, sw));
             if (j == 0) front_a_done = true;
@@ -1433,13 +1433,14 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         for (int l = 0; l < L; ++l) add_seg(g, w.dy[l], H / KBS);
         SiLUBwdParams p;
         p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B; p.outT = tr ? nullptr : w.dUT; p.Spad = Bpad; p.act = h->d.activation;
+        p.part = w.silu_part;                                            // the shared embedding's bias gradient: no column-sum launch over dU
+        silu_rows = (int)(Bpad / (shape_st(shape) * 32)) * shape_ws(shape);
         DP_HIP_LAUNCH(gemm_silu_bwd(prec, shape, g, p, st));
     }
     if (two) {
         DP_CHECK_HIP(hipEventRecord(h->ev_time, st));
         DP_CHECK_HIP(hipStreamWaitEvent(sw, h->ev_time, 0));
     }
-    DP_HIP_LAUNCH(launch_colsum(h->f32, w.dU, w.cs_part_se, Bpad, E, &n_chunks_se, sw));
     const bool se_in_batch = batched && wb.prob[wb.nprob - 1].mode == 1;
     if (!se_in_batch) {                                             // (otherwise: a lane problem of the one launch below)
         if (tr) DP_TRY(run_wgrad(h, nullptr, E, E, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw, w.dU, w.emb));
@@ -1449,16 +1450,16 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         if (slab_cursor > w.slab_elems - lane_room) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: slab buffer too small for the batched wgrad launch");
         wb.alg_flops = 2.0 * (double)B * H * ((double)(L - 1) * H + (double)L * E) + (se_in_batch ? 2.0 * (double)B * E * E : 0.0);
         DP_HIP_LAUNCH(gemm_wgrad_tr_batch(wb, st));
-        DP_HIP_LAUNCH(launch_reduce_wgrad_tiles(wb, flat_grad, st));
     }
     // what is left: the shared time embedding (front B), layer 0's jobs where they were not flushed with a group, and the parameters
     // that never get a gradient
-    add_job(h->off_se_b, E, w.cs_part_se, E, n_chunks_se);
+    add_job(h->off_se_b, E, w.silu_part, E, silu_rows);
     for (int i = 0; i < h->n_nograd; ++i) {                          // dead parameters: zeros (no bucket holds them; the optimiser skips them)
         ReduceJob& jb = rj.job[rj.n++];
         jb.dst_off = h->nograd_lo[i]; jb.count = h->nograd_hi[i] - h->nograd_lo[i]; jb.src_off = 0; jb.src_stride = 0; jb.nsrc = 0;
     }
-    if (rj.n > 0) DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, sw));
+    if (batched) DP_HIP_LAUNCH(launch_reduce_all(wb, rj, w.slabs, flat_grad, st));      // (batched: sw == st) partial tiles + every small reduction of the step
+    else if (rj.n > 0) DP_HIP_LAUNCH(launch_reduce_grads(rj, w.slabs, flat_grad, sw));
     rj.n = 0;
     if (batched && has_events) {     // nothing was final before this point: every bucket becomes final with the last reduction
         DP_TRY(mark_final(h, sink, 0, L + 1, sw));
