@@ -80,6 +80,7 @@ template <typename T> struct Quad;
 template <> struct Quad<float> {
     __device__ static inline f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
     __device__ static inline void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    __device__ static inline f32x4 round_trip(f32x4 v) { return v; }      // the values as they read back after store()
 };
 template <> struct Quad<__bf16> {
     __device__ static inline f32x4 load(const __bf16* p) {
@@ -95,6 +96,9 @@ template <> struct Quad<__bf16> {
         // native casts lower to v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved): 2 instructions per quad
         bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
         *reinterpret_cast<bf16x4*>(p) = b;
+    }
+    __device__ static inline f32x4 round_trip(f32x4 v) {
+        return f32x4{(float)(__bf16)v[0], (float)(__bf16)v[1], (float)(__bf16)v[2], (float)(__bf16)v[3]};
     }
 };
 

@@ -646,43 +646,65 @@ struct DsmDev {
     DsmArgs a;
     SdeDev sde;
 };
+// One thread keeps ONE channel quad q for all of its samples (thread t: q = t % qc, sample lane t / qc; 256 / qc sample lanes per block),
+// so that the column sums of dres -- the gradient of post_dense's bias, a k_colsum launch of its own before -- are per-thread running sums:
+// each block leaves one partial row [Cp] (fixed order: sample lanes in turn), the last reduction of the step adds the rows.
 template <typename T> __global__ void __launch_bounds__(256) k_dsm(DsmDev d) {
+    __shared__ float cs[256][4];
     const DsmArgs& a = d.a;
     const int qc = a.Cp >> 2;
-    const int64_t total = a.Bpad * qc;
+    const int lanes = 256 / qc;                       // sample lanes of the block (Cp <= 512: >= 2)
+    const int q = threadIdx.x % qc, sl = threadIdx.x / qc;
+    const int c = q * 4;
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = i / qc;
-        const int c = (int)(i % qc) * 4;
-        f32x4 dr = {0.f, 0.f, 0.f, 0.f};
-        if (s < a.B && c < a.D) {
-            const float t = a.t[s];
-            const float lmc = sde_lmc(d.sde, t);
-            const float sd = sde_std(d.sde, lmc);
-            const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, t * 999.0f, a.fourier) : 1.0f;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    if (sl < lanes) {
+        for (int64_t s = (int64_t)blockIdx.x * lanes + sl; s < a.Bpad; s += (int64_t)gridDim.x * lanes) {
+            f32x4 dr = {0.f, 0.f, 0.f, 0.f};
+            if (s < a.B && c < a.D) {
+                const float t = a.t[s];
+                const float lmc = sde_lmc(d.sde, t);
+                const float sd = sde_std(d.sde, lmc);
+                const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, t * 999.0f, a.fourier) : 1.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (c + r < a.D) {
-                    const float model = a.res[s * a.Cp + c + r] / usig;
-                    const float score = -model / sd;                               // utils.py:162
-                    const float e = score * sd + a.z[s * a.Dpad + c + r];          // losses.py:124
-                    acc += e * e;
-                    dr[r] = (-2.0f * e) * a.grad_scale / usig;
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (c + r < a.D) {
+                        const float model = a.res[s * a.Cp + c + r] / usig;
+                        const float score = -model / sd;                               // utils.py:162
+                        const float e = score * sd + a.z[s * a.Dpad + c + r];          // losses.py:124
+                        acc += e * e;
+                        dr[r] = (-2.0f * e) * a.grad_scale / usig;
+                    }
+            }
+            store_quad_ft<T>(a.dres, s, c, a.Cp, dr);
+            // the bias gradient sums what the GEMMs read: the stored (bf16-rounded in bf16 mode) values, like k_colsum did
+            const f32x4 st4 = Quad<T>::round_trip(dr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) csum[r] += st4[r];
         }
-        store_quad_ft<T>(a.dres, s, c, a.Cp, dr);
     }
-    const float tot = block_sum_256(acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[threadIdx.x][r] = csum[r];
+    const float tot = block_sum_256(acc);             // (contains the barrier that publishes cs)
     if (threadIdx.x == 0) a.loss_part[blockIdx.x] = tot * a.grad_scale;
+    if (a.cs_part && threadIdx.x < qc) {
+        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < lanes; ++l)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t4[r] += cs[l * qc + threadIdx.x][r];
+        *reinterpret_cast<f32x4*>(a.cs_part + (int64_t)blockIdx.x * a.Cp + c) = t4;
+    }
 }
 hipError_t launch_dsm(const DsmArgs& a, int* nblocks, hipStream_t st) {
     DsmDev d;
     d.a = a;
     d.sde = make_sde_dev(a.sde);
-    const int g = grid_for(a.Bpad * (a.Cp >> 2), 256, 1024);
-    *nblocks = g;
-    if (a.f32) hipLaunchKernelGGL(k_dsm<float>, dim3(g), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL(k_dsm<__bf16>, dim3(g), dim3(256), 0, st, d);
+    const int lanes = 256 / (a.Cp >> 2);
+    int64_t g = (a.Bpad + lanes - 1) / lanes;
+    g = g < 1 ? 1 : (g > 1024 ? 1024 : g);
+    *nblocks = (int)g;
+    if (a.f32) hipLaunchKernelGGL(k_dsm<float>, dim3((unsigned)g), dim3(256), 0, st, d);
+    else hipLaunchKernelGGL(k_dsm<__bf16>, dim3((unsigned)g), dim3(256), 0, st, d);
     return hipGetLastError();
 }
 
@@ -800,7 +822,16 @@ hipError_t launch_colsum(int f32, const void* in, float* part, int64_t Spad, int
 // gradient finalisation and optimizer
 // ------------------------------------------------------------------------------------------------
 // one job of the deterministic reductions into the flat gradient; (bx, nbx): this block's index / the number of blocks of the job
-__device__ __forceinline__ void reduce_job_body(const ReduceJob& j, const float* scratch, float* grad, int bx, int nbx, float (*red)[32]) {
+__device__ __forceinline__ void reduce_job_body(const ReduceJob& j, const float* scratch, float* grad, int bx, int nbx, float (*red)[32], float* alt) {
+    if (j.nsrc < 0) {       // plain sum of a list of partials to a scalar outside the gradient (k_sum_partials' order; one block)
+        if (bx == 0) {
+            float acc = 0.f;
+            for (int i = threadIdx.x; i < (int)j.count; i += 256) acc += scratch[j.src_off + i];
+            const float tot = block_sum_256(acc);
+            if (threadIdx.x == 0) alt[0] = tot;
+        }
+        return;
+    }
     if (j.nsrc == 0) {      // a range that never gets a gradient (dead parameters): zeros -- was a memset launch of its own
         const bool al = ((j.dst_off | j.count) & 3) == 0;
         const int64_t n4 = al ? (j.count >> 2) : 0;
@@ -880,7 +911,7 @@ __global__ void __launch_bounds__(256) k_reduce_grads(ReduceJobs jobs, const flo
     __shared__ float red[8][32];
     (void)jobs;
     const ReduceJob j = kernarg_job<ReduceJob>((int)blockIdx.y);
-    reduce_job_body(j, scratch, grad, (int)blockIdx.x, (int)gridDim.x, red);
+    reduce_job_body(j, scratch, grad, (int)blockIdx.x, (int)gridDim.x, red, jobs.alt);
 }
 static int reduce_job_blocks(const ReduceJobs& jobs);
 static inline int reduce_job_blocks_fwd(const ReduceJobs& jobs) { return reduce_job_blocks(jobs); }
@@ -962,7 +993,7 @@ __global__ void __launch_bounds__(256) k_reduce_all(ReduceAllArgs a, const float
     }
     const int jb = b - n_tile_blocks;
     const ReduceJob j = kernarg_job<ReduceJob>(jb / a.job_blocks);
-    reduce_job_body(j, scratch, grad, jb % a.job_blocks, a.job_blocks, red);
+    reduce_job_body(j, scratch, grad, jb % a.job_blocks, a.job_blocks, red, a.jobs.alt);
 }
 static int reduce_job_blocks(const ReduceJobs& jobs) {
     int64_t big = 0;

@@ -184,6 +184,7 @@ struct DsmArgs {           // get_sde_loss_fn tail (losses.py:121-131) + d loss 
     const float* sigmas;
     void* dres;            // FT [Bpad][Cp]
     float* loss_part;      // per-block partial sums of the (already normalised) loss
+    float* cs_part;        // optional [blocks][Cp]: per-block column sums of dres (post_dense bias gradient partials)
     int64_t B, Bpad;
     int D, Dpad, Cp, num_scales, scale_by_sigma, f32, fourier;
     float grad_scale;      // 1/(B*D) for reduce_mean
@@ -219,12 +220,14 @@ struct ReduceJob {
     int64_t count;
     int64_t src_off;       // element offset in the scratch buffer
     int64_t src_stride;
-    int nsrc;              // 0: fill [dst_off, dst_off + count) with zeros (parameters that never get a gradient)
+    int nsrc;              // 0: fill [dst_off, dst_off + count) with zeros (parameters that never get a gradient);
+                           // -1: ReduceJobs::alt[0] = sum of scratch[src_off .. src_off + count) in k_sum_partials' order (the step's loss)
 };
 constexpr int MAX_REDUCE_JOBS = 48;
 struct ReduceJobs {
     ReduceJob job[MAX_REDUCE_JOBS];
     int n;
+    float* alt;            // destination of the nsrc = -1 job (outside the flat gradient)
 };
 hipError_t launch_reduce_grads(const ReduceJobs& jobs, const float* scratch, float* flat_grad, hipStream_t st);
 hipError_t launch_reduce_wgrad_tiles(const WgradBatchArgs& a, float* flat_grad, hipStream_t st);   // wgrad_batch.h: partial tiles -> flat gradient

@@ -453,7 +453,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
             w.dUT = take(Bpad * E * esz);
         }
         const int64_t nchunks = ceil_div(Bpad, 2048);
-        w.cs_part_post = (float*)take(nchunks * h->Cp * 4);
+        w.cs_part_post = (float*)take((nchunks > 1024 ? nchunks : 1024) * h->Cp * 4);      // rows: k_colsum chunks, or k_dsm's blocks (<= 1024)
         w.cs_part_se = (float*)take(nchunks * E * 4);
         w.silu_part = (float*)take((Bpad / 32) * (int64_t)E * 4);       // per-wave column sums of dU (time-branch dgrad epilogue)
         // slabs: worst case ksplit 32 is never reached for the big tensors; size exactly below
@@ -1290,7 +1290,7 @@ static int plan_wgrad_groups(const dposer_scorefc_s* h, const Ws& w, bool tr, in
 //                                         stream (fp32 mode, other widths, forced).
 static int backward_core(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
                          uint32_t step, float* flat_grad, float* dx, const BucketSink* sink, hipStream_t st,
-                         const SumJob* loss_sum = nullptr) {
+                         const SumJob* loss_sum = nullptr, int dsm_cs_rows = 0) {
     const int prec = h->f32 ? PREC_FP32 : PREC_BF16;
     const int H = h->H, E = h->E, L = h->L, KBS = h->KBS;
     const int64_t Bpad = w.Bpad;
@@ -1309,6 +1309,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     hipStream_t sw = two ? h->side : st;
     ReduceJobs rj;
     rj.n = 0;
+    rj.alt = nullptr;
     int64_t slab_cursor = 0;
     int n_chunks_post = 0, silu_rows = 0;
     const int64_t lane_room = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536;
@@ -1329,8 +1330,9 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
             DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.xin, w.xinT, Bpad, h->Dpad, sw));
             DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.emb, w.embT, Bpad, E, sw));
         }
-        // post_dense: bias (column sums of dres) and weight
-        DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, sw, loss_sum));    // (+ the loss partials of k_dsm)
+        // post_dense: bias (column sums of dres: left by k_dsm in the fused step, else a k_colsum launch here) and weight
+        if (dsm_cs_rows > 0) n_chunks_post = dsm_cs_rows;
+        else DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, sw, nullptr));
         if (tr) {
             DP_TRY(run_wgrad(h, nullptr, h->Cp, h->D, nullptr, H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, sw, w.dres, w.hbuf[L - 1]));
         } else {
@@ -1454,6 +1456,11 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     // what is left: the shared time embedding (front B), layer 0's jobs where they were not flushed with a group, and the parameters
     // that never get a gradient
     add_job(h->off_se_b, E, w.silu_part, E, silu_rows);
+    if (loss_sum && loss_sum->n > 0) {                              // the step's loss value: summed by one block of the last reduction
+        ReduceJob& jb = rj.job[rj.n++];
+        jb.dst_off = 0; jb.count = loss_sum->n; jb.src_off = rel(loss_sum->part); jb.src_stride = 0; jb.nsrc = -1;
+        rj.alt = loss_sum->out;
+    }
     for (int i = 0; i < h->n_nograd; ++i) {                          // dead parameters: zeros (no bucket holds them; the optimiser skips them)
         ReduceJob& jb = rj.job[rj.n++];
         jb.dst_off = h->nograd_lo[i]; jb.count = h->nograd_hi[i] - h->nograd_lo[i]; jb.src_off = 0; jb.src_stride = 0; jb.nsrc = 0;
@@ -1497,12 +1504,13 @@ static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const vo
     DP_TRY(forward_core_train(h, flat, packed, w, B, true, seed, step, st));
     DsmArgs da;
     da.res = w.res; da.t = w.tbuf; da.z = w.zbuf; da.sigmas = sigmas; da.dres = w.dres; da.loss_part = w.loss_part; da.B = B; da.Bpad = Bpad;
+    da.cs_part = w.cs_part_post;
     da.D = h->D; da.Dpad = h->Dpad; da.Cp = h->Cp; da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma;
     da.f32 = h->f32; da.fourier = 0; da.grad_scale = (float)(1.0 / ((double)B * (double)h->D)); da.sde = sc;
     int nb = 0;
     DP_HIP_LAUNCH(launch_dsm(da, &nb, st));
-    const SumJob loss_sum{w.loss_part, nb, loss};                      // summed by a rider block of the first backward launch
-    return backward_core(h, flat, packed, w, B, true, seed, step, flat_grad, nullptr, sink, st, &loss_sum);
+    const SumJob loss_sum{w.loss_part, nb, loss};                      // summed by one block of the LAST reduction launch of the backward
+    return backward_core(h, flat, packed, w, B, true, seed, step, flat_grad, nullptr, sink, st, &loss_sum, nb);
 }
 
 extern "C" int dposer_dsm_loss_fwd_bwd_bucketed(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_,
