@@ -451,6 +451,7 @@ template <typename T> struct EpiEmStep {
     // per-step scalars (identical for every sample: vec_t = ones(B) * t, sampling.py:458)
     struct Scal { float sd, beta, g, usig; };
     __device__ static inline Scal scalars(const Params& p) {
+#pragma clang fp contract(off)
         Scal sc;
         const float lmc = sde_lmc(p.sde, p.t);
         sc.sd = sde_std(p.sde, lmc);

@@ -57,8 +57,16 @@ struct SamplerArgs {
     const void* last;             // FT output of the last GroupNorm layer
     float* x_mean_ft;             // written on the last step
     EmStepParams em;              // per-step fields (t, step, x_mean_ft) are filled in by the kernel
+    // cluster form only (k_sampler_cluster): all zero before the launch
+    uint32_t* progress;           // DEVICE [n_sblk] tiles finished per sample block (4 per layer / update phase)
+    uint32_t* ctrl;               // DEVICE [SAMPLER_CTRL_WORDS]: [0, 8) workgroups seen per XCD, [8] error flag, [9] longest wait in polls
+    int n_sblk;                   // sample blocks of 256
 };
+constexpr int SAMPLER_CTRL_WORDS = 16;
 hipError_t launch_sampler_persistent(int prec, const SamplerArgs& a, int64_t n_sample_blocks, hipStream_t st);
+// four workgroups of one XCD share a sample block: one channel tile each per layer, joined by a counter per block (sync = 0: no waits --
+// a timing probe whose samples are garbage)
+hipError_t launch_sampler_cluster(int prec, const SamplerArgs& a, int sync, hipStream_t st);
 
 // ---- optional per-launch profiling (HIP events on the launch stream; off by default) ------------------
 enum GemmEpiKind : int { EPI_GN = 0, EPI_GN_TRAIN, EPI_BIAS_SILU, EPI_ROWMAJOR, EPI_PLAIN_FT, EPI_GN_BWD, EPI_SILU_BWD, EPI_WGRAD, EPI_EM_STEP, EPI_KINDS };

@@ -361,6 +361,7 @@ struct Ws {
     float *tt_labels, *tt_emb, *tt_temb, *table;
     float* tt_t;                   // t of every step (persistent sampler)
     SamplerLayer* smp_layers;      // device table of the persistent sampler's per-layer operands
+    uint32_t* smp_sync;            // cluster sampler: control words + one progress counter per block of 256 samples
     // transposed copies / partials / slabs (training)
     char *dyT[MAX_L], *hT[MAX_L], *tembT, *embT, *xinT, *dresT, *dUT;
     float *gn_part[MAX_L], *cs_part_post, *cs_part_se, *silu_part, *slabs;
@@ -426,6 +427,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         w.table = (float*)take(w.npad * (int64_t)L * H * 4);
         w.tt_t = (float*)take(w.npad * 4);
         w.smp_layers = (SamplerLayer*)take(MAX_L * sizeof(SamplerLayer));
+        w.smp_sync = (uint32_t*)take((SAMPLER_CTRL_WORDS + Bpad / 256 + 1) * 4);
     } else {
         w.emb = take(Bpad * E * esz);
         w.temb = take(Bpad * E * esz);
@@ -779,7 +781,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     // through MALL / HBM, under the chip's power cap.  Removing the grid-wide joins does not pay for that.
     const int persistent_env = score_tuning().sampler_persistent;
     const int64_t persistent_min = score_tuning().sampler_persistent_min;
-    if (fused && persistent_env && h->d.activation == DPOSER_ACT_SWISH && h->gs == 32 && h->H % 256 == 0 && h->Cp == 64 && w.Bpad % 256 == 0 && w.Bpad >= persistent_min) {
+    if (fused && persistent_env && h->d.activation == DPOSER_ACT_SWISH && h->gs == 32 && h->H % 256 == 0 && h->Cp == 64 && w.Bpad % 256 == 0 && (persistent_env >= 2 || w.Bpad >= persistent_min)) {
         SamplerLayer tab[MAX_L];
         std::memset(tab, 0, sizeof(tab));
         for (int l = 0; l < h->L; ++l) {
@@ -807,6 +809,22 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
         p.sigmas = sigmas; p.sde = make_sde_dev(sc); p.t = 0.f; p.num_scales = h->d.num_scales;
         p.scale_by_sigma = h->d.scale_by_sigma; p.D = h->D; p.Cp = h->Cp; p.QD = (h->D + 3) >> 2; p.S_valid = B;
         p.seed = seed; p.step = 0;
+        if (persistent_env >= 2) {
+            // cluster form (gemm_sampler.hip): 2 = joined by the per-block counters, 3 = the same walk without waits (timing probe, garbage samples)
+            sa.n_sblk = (int)(w.Bpad / 256);
+            sa.ctrl = w.smp_sync; sa.progress = w.smp_sync + SAMPLER_CTRL_WORDS;
+            DP_CHECK_HIP(hipMemsetAsync(w.smp_sync, 0, (SAMPLER_CTRL_WORDS + sa.n_sblk) * 4, st));
+            DP_HIP_LAUNCH(launch_sampler_cluster(h->f32 ? PREC_FP32 : PREC_BF16, sa, persistent_env == 2, st));
+            DP_HIP_LAUNCH(launch_ft_to_rows(w.xft, x, w.xmft, x_mean, B, w.Bpad, h->D, h->Dpad, st));
+            uint32_t ctrl[SAMPLER_CTRL_WORDS];
+            DP_CHECK_HIP(hipMemcpyAsync(ctrl, w.smp_sync, sizeof(ctrl), hipMemcpyDeviceToHost, st));
+            DP_CHECK_HIP(hipStreamSynchronize(st));
+            if (getenv("DPOSER_SAMPLER_CLUSTER_REPORT"))
+                fprintf(stderr, "[dposer] cluster sampler: workgroups per XCD %u %u %u %u %u %u %u %u, error %u, longest wait %u polls\n",
+                        ctrl[0], ctrl[1], ctrl[2], ctrl[3], ctrl[4], ctrl[5], ctrl[6], ctrl[7], ctrl[8], ctrl[9]);
+            if (ctrl[8]) return dposer_set_error(DPOSER_ERR_HIP, std::string("cluster sampler: ") + (ctrl[8] == 2 ? "workgroups not dealt evenly to the XCDs" : "a workgroup waited past its poll budget (not all resident?)"));
+            return DPOSER_OK;
+        }
         DP_HIP_LAUNCH(launch_sampler_persistent(h->f32 ? PREC_FP32 : PREC_BF16, sa, w.Bpad / 256, st));
         DP_HIP_LAUNCH(launch_ft_to_rows(w.xft, x, w.xmft, x_mean, B, w.Bpad, h->D, h->Dpad, st));
         return DPOSER_OK;

@@ -1159,31 +1159,37 @@ def test_fixed_step_likelihood_and_ode_sampler():
     assert nfe == 64 and torch.isfinite(x).all()
 
 
-def test_persistent_sampler_kernel_returns_the_bits_of_the_launch_path():
-    """gemm_sampler.hip: one workgroup per 256 samples walks every layer of every step (opt-in, DPOSER_SAMPLER_PERSISTENT=1) -- the
-    same tile code as the per-layer launches, so the samples must be bit-identical; run in child processes (the switch is read once)."""
+def test_persistent_sampler_kernels_return_the_bits_of_the_launch_path():
+    """gemm_sampler.hip (opt-in): DPOSER_SAMPLER_PERSISTENT=1 -- one workgroup per 256 samples walks every layer of every step;
+    =2 -- clusters of four workgroups on one XCD take one channel tile each and are joined by a progress counter per sample block.
+    The same tile code as the per-layer launches, so the samples must be bit-identical -- at 3 sample blocks (one per cluster: the
+    counter is a 4-way barrier per layer) and at 129 (two or three per cluster: members run ahead of each other); child processes
+    (the switch is read once).  13 steps: t = 0.334 is among them, where a contracted `m2b0 * t - db * (t * t)` is one ulp off the
+    unfused value -- the three kernels once disagreed there because hipcc fused it in two of them (csrc/sde_dev.h)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import sys, hashlib, torch; sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden'); sys.path.insert(0, '.')\n"
             "from gpu_common import make_model\n"
             "from dposer_amd.algorithms.advanced import sampling, sde_lib\n"
-            "for prec in ('bf16', 'fp32'):\n"
+            "for prec, B in (('bf16', 700), ('fp32', 700), ('bf16', 33000), ('fp32', 16500)):\n"
             "    cfg, m, p = make_model(3, precision=prec)\n"
             "    m.eval()\n"
-            "    sde = sde_lib.subVPSDE(0.1, 20.0, 12)\n"
-            "    fn = sampling.get_sampling_fn(cfg, sde, (700, 63), lambda v: v, 1e-3, device='cuda:0')\n"
-            "    z = torch.randn(700, 63, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(5))\n"
-            "    _, x = fn(m, z=z, seed=11, traj_stride=0)\n"
-            "    print('SHA', prec, hashlib.sha1(x.cpu().numpy().tobytes()).hexdigest(), bool(torch.isfinite(x).all()))\n")
+            "    sde = sde_lib.subVPSDE(0.1, 20.0, 13)\n"
+            "    fn = sampling.get_sampling_fn(cfg, sde, (B, 63), lambda v: v, 1e-3, device='cuda:0')\n"
+            "    z = torch.randn(B, 63, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(5))\n"
+            "    for rep in range(2):\n"
+            "        _, x = fn(m, z=z, seed=11, traj_stride=0)\n"
+            "        print('SHA', prec, B, hashlib.sha1(x.cpu().numpy().tobytes()).hexdigest(), bool(torch.isfinite(x).all()))\n")
     outs = {}
-    for flag in ("0", "1"):
+    for flag in ("0", "1", "2"):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, DPOSER_SAMPLER_PERSISTENT=flag), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[flag] = [l for l in r.stdout.splitlines() if l.startswith("SHA")]
-        assert len(outs[flag]) == 2 and all(l.endswith("True") for l in outs[flag])
+        assert len(outs[flag]) == 8 and all(l.endswith("True") for l in outs[flag])
     assert outs["0"] == outs["1"]
+    assert outs["0"] == outs["2"]
 
 
 @pytest.mark.parametrize("act", ["elu", "relu", "lrelu"])

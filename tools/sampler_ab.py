@@ -1,6 +1,8 @@
-"""A/B of the Euler-Maruyama fast path: per-layer launches vs the persistent kernel (DPOSER_SAMPLER_PERSISTENT = 0 / 1), one box,
-interleaved child processes:  python tools/sampler_ab.py [--batch 65536] [--steps 200]
-Every child also prints a checksum of the samples: the two forms must agree bit for bit."""
+"""A/B of the Euler-Maruyama fast path: per-layer launches vs the persistent kernels (DPOSER_SAMPLER_PERSISTENT = 0: launches,
+1: one workgroup per sample block, 2: clusters of four workgroups per sample block, 3: the cluster walk WITHOUT its waits -- a
+timing bound, garbage samples), one box, interleaved child processes:
+    python tools/sampler_ab.py [--batch 65536] [--steps 200] [--modes 0,2,3]
+Every child also prints a checksum of the samples: modes 0, 1, 2 must agree bit for bit."""
 import hashlib
 import os
 import subprocess
@@ -39,6 +41,7 @@ else:
     B = sys.argv[sys.argv.index("--batch") + 1] if "--batch" in sys.argv else "65536"
     N = sys.argv[sys.argv.index("--steps") + 1] if "--steps" in sys.argv else "200"
     prec = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "bf16"
+    modes = sys.argv[sys.argv.index("--modes") + 1].split(",") if "--modes" in sys.argv else ["0", "1"]
     for rnd in range(2):
-        for flag in ("0", "1"):
+        for flag in modes:
             subprocess.run([sys.executable, __file__, "child", B, N, prec], env=dict(os.environ, DPOSER_SAMPLER_PERSISTENT=flag), check=False)
