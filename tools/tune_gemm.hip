@@ -224,6 +224,24 @@ int main(int argc, char** argv) {
         run_all(9, 50);
         return 0;
     }
+    if (getenv("TUNE_TALL")) {       // round 4: one-round batches (S = 8192 / 16384) are L2-bound on the 128x128 tiling (64 FLOP per byte staged): do 256x128 /
+                                     // 128x256 tiles (85 FLOP per byte; 256 / 512 tiles) on the compiler's ring loop beat the hand-placed 128x128 stage?
+        g_drop_p = 0.1f;
+        GNT(2, 2, 2, 2, 2, 4);   // shipped below 16384 samples: 128 x 128, 4 waves, two workgroups per CU, asm stage
+        GNT(4, 2, 2, 2, 2, 4);   // 256 ch x 128 s, 8 waves, wave tile 64 x 64
+        GNT(2, 4, 2, 2, 2, 4);   // 128 ch x 256 s, 8 waves
+        GNT(2, 4, 4, 1, 2, 4);   // 256 ch x 128 s, 8 waves, wave tile 128 x 32
+        GNT(4, 2, 2, 2, 2, 3);   // three slots: two workgroups per CU
+        GNT(2, 4, 4, 2, 2, 4);   // 256 x 256
+        GB(2, 2, 2, 2, 2, 4, 1, 0, 0, 0);
+        GB(4, 2, 2, 2, 2, 4, 1, 0, 0, 0);
+        GB(2, 4, 2, 2, 2, 4, 1, 0, 0, 0);
+        GB(2, 4, 4, 1, 2, 4, 1, 0, 0, 0);
+        GB(2, 4, 4, 2, 2, 4, 1, 0, 0, 0);
+        PL(2, 2, 2, 2, 2, 4); PL(4, 2, 2, 2, 2, 4); PL(2, 4, 2, 2, 2, 4); PL(2, 4, 4, 1, 2, 4); PL(2, 4, 4, 2, 2, 4);
+        run_all(9, 20);
+        return 0;
+    }
     if (getenv("TUNE_SMALLB")) {     // which tiling for one-round problem sizes (run with S = 8192 / 16384)?
         GNT(2, 2, 2, 2, 4, 1);
         GNT(2, 2, 2, 1, 4, 1);
