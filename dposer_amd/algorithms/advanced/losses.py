@@ -375,7 +375,7 @@ def get_ddpm_loss_fn(vpsde, train, reduce_mean=True):
 def fused_dsm_supported(sde, model, continuous, reduce_mean, likelihood_weighting, auxiliary_loss):
     from .model import ScoreModelFC
     return (continuous and reduce_mean and not likelihood_weighting and not auxiliary_loss and sde_desc(sde) is not None
-            and isinstance(model, ScoreModelFC) and model.time_embedding_type == "positional")
+            and isinstance(model, ScoreModelFC))
 
 
 def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, seed=0, step=0, bucket_events=None, on_final=None):
@@ -400,12 +400,12 @@ def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, se
         cb = _C.RANGES_FINAL_FN(_cb)                  # (kept alive until the call has returned)
         _C.check(eng.lib.dposer_dsm_loss_fwd_bwd_notify(
             eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(t), _C.ptr(z), float(eps), int(seed),
-            int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(batch.device)), _C.ptr(model.sigmas), _C.ptr(flat_grad), _C.ptr(loss), B,
+            int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(batch.device, model._fourier_W())), _C.ptr(model.sigmas), _C.ptr(flat_grad), _C.ptr(loss), B,
             bucket_events, len(bucket_events), cb, None, _C.stream_ptr()), "dposer_dsm_loss_fwd_bwd_notify")
         return loss[0]
     _C.check(eng.lib.dposer_dsm_loss_fwd_bwd_bucketed(
         eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(t), _C.ptr(z), float(eps), int(seed),
-        int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(batch.device)), _C.ptr(model.sigmas), _C.ptr(flat_grad), _C.ptr(loss), B,
+        int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(batch.device, model._fourier_W())), _C.ptr(model.sigmas), _C.ptr(flat_grad), _C.ptr(loss), B,
         bucket_events, 0 if bucket_events is None else len(bucket_events), _C.stream_ptr()), "dposer_dsm_loss_fwd_bwd_bucketed")
     return loss[0]
 

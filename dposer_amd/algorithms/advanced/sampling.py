@@ -256,7 +256,7 @@ def fused_em_supported(sde, model, predictor, corrector, probability_flow, conti
     from .model import ScoreModelFC
     return (predictor is EulerMaruyamaPredictor and corrector in (None, NoneCorrector) and not probability_flow
             and sde_lib.sde_desc(sde) is not None and (continuous or isinstance(sde, sde_lib.subVPSDE))
-            and isinstance(model, ScoreModelFC) and model.time_embedding_type == "positional")
+            and isinstance(model, ScoreModelFC))
 
 
 def fused_em_sample(model, sde, x, timesteps, *, start_step=0, observation=None, mask=None, noise=None, seed=0,
@@ -282,7 +282,7 @@ def fused_em_sample(model, sde, x, timesteps, *, start_step=0, observation=None,
     nz = None if noise is None else noise.contiguous().float()
     _C.check(eng.lib.dposer_em_sampler(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(x_mean),
                                        C.c_void_p(ts_host.data_ptr()), int(start_step), _C.ptr(obs), _C.ptr(msk), _C.ptr(nz),
-                                       int(seed), _C.ptr(traj), int(traj_stride or 1), _C.ptr(eng.freq(x.device)),
+                                       int(seed), _C.ptr(traj), int(traj_stride or 1), _C.ptr(eng.freq(x.device, model._fourier_W())),
                                        _C.ptr(model.sigmas), B, _C.stream_ptr()), "dposer_em_sampler")
     return traj, x, x_mean
 
@@ -291,7 +291,7 @@ def fused_langevin_supported(sde, model, predictor, corrector, probability_flow,
     from .model import ScoreModelFC
     return (predictor is EulerMaruyamaPredictor and corrector is LangevinCorrector and not probability_flow
             and sde_lib.sde_desc(sde) is not None and (continuous or isinstance(sde, sde_lib.subVPSDE))
-            and isinstance(model, ScoreModelFC) and model.time_embedding_type == "positional")
+            and isinstance(model, ScoreModelFC))
 
 
 def fused_pc_langevin_sample(model, sde, x, timesteps, *, snr, n_steps=1, start_step=0, observation=None, mask=None, noise=None,
@@ -327,7 +327,7 @@ def fused_pc_langevin_sample(model, sde, x, timesteps, *, snr, n_steps=1, start_
     norms = torch.empty(2, dtype=torch.float32, device=x.device)
     alphas = sde.alphas.detach().to("cpu") if hasattr(sde, "alphas") else None
     traj = torch.empty((n_run // traj_stride, B, D), dtype=torch.float32, device=x.device) if (traj_stride and n_run > 0) else None
-    freq, lib = eng.freq(x.device), eng.lib
+    freq, lib = eng.freq(x.device, model._fourier_W()), eng.lib
     for i in range(n_run):
         gi = start_step + i
         t = ts_host[gi]

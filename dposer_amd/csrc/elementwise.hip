@@ -157,7 +157,7 @@ struct PrepTrainDev {
     float t_scale;   // (T - eps) as fp32
 };
 constexpr int PREP_EQ = 8;   // embedding quads per thread: the Philox draw of t is shared by 32 embedding values
-template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTrainDev d) {
+template <typename T, bool FOURIER> __global__ void __launch_bounds__(256) k_prep_train(PrepTrainDev d) {
     const PrepTrainArgs& a = d.a;
     const int qx = a.Dpad >> 2, qe = a.E >> 2;
     const int ge = (qe + PREP_EQ - 1) / PREP_EQ;      // embedding work items per sample
@@ -221,7 +221,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTr
                 if (e < a.E) {
                     f32x4 v;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = temb_from_freq<sizeof(T) == 2>(label, e < half, fr[k][r], 0);      // (positional only: see launch_prep_train)
+                    for (int r = 0; r < 4; ++r) v[r] = temb_from_freq<sizeof(T) == 2>(label, e < half, fr[k][r], FOURIER);      // (a template flag: see launch_prep_train)
                     store_quad_ft<T>(a.emb, s, e, a.E, v);
                 }
             }
@@ -229,18 +229,22 @@ template <typename T> __global__ void __launch_bounds__(256) k_prep_train(PrepTr
     }
 }
 hipError_t launch_prep_train(const PrepTrainArgs& a, hipStream_t st) {
-    // The fused DSM step is positional-embedding only (its entry point checks).  The kernel compiles the Fourier form OUT: as a runtime
-    // branch it kept 64 inlined libm sinf / cosf (Payne-Hanek slow paths included) between the 32 hardware sin / cos the waves actually
-    // execute -- 10,343 instructions, the executed ones scattered over 70 KB of code, one instruction-cache miss per unrolled element:
-    // the waves sat parked for ~10 of the kernel's 17 us at any batch size (tools/small_step_pmc.sh).
-    if (a.fourier) return hipErrorInvalidValue;
+    // The embedding kind is a TEMPLATE flag: as a runtime branch the Fourier form kept 64 inlined libm sinf / cosf (Payne-Hanek slow paths
+    // included) between the 32 hardware sin / cos the positional waves actually execute -- 10,343 instructions, the executed ones scattered
+    // over 70 KB of code, one instruction-cache miss per unrolled element: the waves sat parked for ~10 of the kernel's 17 us at any
+    // batch size (tools/small_step_pmc.sh).  The Fourier instantiation (GaussianFourierProjection, model.py:19-21,152-155) pays that.
     PrepTrainDev d;
     d.a = a;
     d.sde = make_sde_dev(a.sde);
     d.t_scale = (float)((double)a.sde.T - (double)a.eps);
     const int64_t total = a.Bpad * ((a.Dpad >> 2) + ((a.E >> 2) + PREP_EQ - 1) / PREP_EQ);
-    if (a.f32) hipLaunchKernelGGL(k_prep_train<float>, dim3(grid_for(total)), dim3(256), 0, st, d);
-    else hipLaunchKernelGGL(k_prep_train<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, d);
+    if (a.fourier) {
+        if (a.f32) hipLaunchKernelGGL((k_prep_train<float, true>), dim3(grid_for(total)), dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((k_prep_train<__bf16, true>), dim3(grid_for(total)), dim3(256), 0, st, d);
+    } else {
+        if (a.f32) hipLaunchKernelGGL((k_prep_train<float, false>), dim3(grid_for(total)), dim3(256), 0, st, d);
+        else hipLaunchKernelGGL((k_prep_train<__bf16, false>), dim3(grid_for(total)), dim3(256), 0, st, d);
+    }
     return hipGetLastError();
 }
 
@@ -294,7 +298,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_em_update(EmDev d
     const float beta = sde_beta(d.sde, t);
     const float g = sde_diffusion(d.sde, t);
     const float label = t * 999.0f;
-    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, label, 0) : 1.0f;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, label, a.scale_by_sigma == 2) : 1.0f;
     float mcn = 0.f, sdn = 0.f;
     if (a.t_next >= 0.f) { const float l2 = sde_lmc(d.sde, a.t_next); mcn = expf(l2); sdn = sde_std(d.sde, l2); }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -440,7 +444,7 @@ __global__ void __launch_bounds__(256) k_denoise(DenoiseDev d) {
     const float alpha = expf(lmc), sigma = sde_std(d.sde, lmc);      // return_alpha_sigma, sde_lib.py:227-231
     const float sigma2 = sigma * sigma;
     const float label = t * 999.0f;
-    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, label, 0) : 1.0f;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, label, a.scale_by_sigma == 2) : 1.0f;
     const float snr = alpha / sqrtf(sigma2);                          // completion.py:108
     const float w = a.weighted ? 0.5f * sqrtf(1.0f + snr) : 0.5f;     // completion.py:143-146
     float acc = 0.f;
@@ -482,7 +486,7 @@ __global__ void __launch_bounds__(256) k_completion_update(CompletionDev d) {
     const float lmc = sde_lmc(d.sde, a.t);
     const float alpha = expf(lmc), sigma = sde_std(d.sde, lmc);      // return_alpha_sigma, sde_lib.py:227-231
     const float sigma2 = sigma * sigma;
-    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, 0) : 1.0f;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, a.scale_by_sigma == 2) : 1.0f;
     const float snr = alpha / sqrtf(sigma2);                          // completion.py:108
     const float w = a.weighted ? 0.5f * sqrtf(1.0f + snr) : 0.5f;     // completion.py:143-146
     const int64_t total = a.B * a.D;
@@ -532,7 +536,7 @@ __global__ void __launch_bounds__(256) k_langevin_norms(LangevinDev d) {
     const LangevinArgs& a = d.a;
     const int QD = (a.D + 3) >> 2;
     const float sd = sde_std(d.sde, sde_lmc(d.sde, a.t));
-    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, 0) : 1.0f;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, a.scale_by_sigma == 2) : 1.0f;
     float gsum = 0.f, nsum = 0.f;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.B; s += (int64_t)gridDim.x * blockDim.x) {
         float g2 = 0.f, n2 = 0.f;
@@ -581,7 +585,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_langevin_update(L
     const int qx = a.Dpad >> 2;
     const int QD = (a.D + 3) >> 2;
     const float sd = sde_std(d.sde, sde_lmc(d.sde, a.t));
-    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, 0) : 1.0f;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, a.scale_by_sigma == 2) : 1.0f;
     const float grad_norm = a.norm_sums[0] * a.inv_global_batch, noise_norm = a.norm_sums[1] * a.inv_global_batch;   // .mean()
     const float r0 = a.snr * noise_norm / grad_norm;
     const float step = ((r0 * r0) * 2.0f) * a.alpha;                  // sampling.py:298

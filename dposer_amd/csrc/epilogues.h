@@ -457,7 +457,7 @@ template <typename T> struct EpiEmStep {
         sc.sd = sde_std(p.sde, lmc);
         sc.beta = sde_beta(p.sde, p.t);
         sc.g = sde_diffusion(p.sde, p.t);
-        sc.usig = p.scale_by_sigma ? used_sigma(p.sigmas, p.num_scales, p.t * 999.0f, 0) : 1.0f;
+        sc.usig = p.scale_by_sigma ? used_sigma(p.sigmas, p.num_scales, p.t * 999.0f, p.scale_by_sigma == 2) : 1.0f;
         return sc;
     }
     // one 32x32 tile: x (in: the state, out: the next state) and x_mean from the post_dense accumulator `a`

@@ -602,6 +602,9 @@ static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, 
     return DPOSER_OK;
 }
 
+// scale_by_sigma as the shared-t kernels take it: 0 off, 1 divide by sigmas[(int)label] (positional embedding, model.py:159), 2 divide by the
+// label itself (Fourier embedding: used_sigmas = t, model.py:152)
+static inline int sbs_mode(const dposer_scorefc_s* h) { return h->d.scale_by_sigma ? (h->d.embedding == DPOSER_EMB_FOURIER ? 2 : 1) : 0; }
 static int check_common(dposer_scorefc_t h, const float* flat, const void* packed, void* ws, int64_t batch) {
     DP_CHECK_ARG(h && flat && packed && ws, "null argument");
     g_act = h->d.activation;
@@ -736,7 +739,6 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x && x_mean && timesteps_host && freq && sigmas, "null argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused sampler supports subVP / VP SDEs");
-    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused sampler supports the positional embedding");
     DP_CHECK_ARG(sde->N >= 1 && start_step >= 0 && start_step <= sde->N, "bad step range");
     DP_CHECK_ARG((observation == nullptr) == (mask == nullptr), "observation and mask go together");
     DP_CHECK_ARG(traj_stride >= 1, "traj_stride must be >= 1");
@@ -760,7 +762,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     std::memset(&ea, 0, sizeof(ea));
     ea.x = x; ea.x_mean = x_mean; ea.xin = w.xin; ea.sigmas = sigmas; ea.obs = observation; ea.mask = mask;
     ea.B = B; ea.Bpad = w.Bpad; ea.D = h->D; ea.Dpad = h->Dpad; ea.Cp = h->Cp; ea.num_scales = h->d.num_scales;
-    ea.f32 = h->f32; ea.scale_by_sigma = h->d.scale_by_sigma; ea.sde = sc; ea.seed = seed;
+    ea.f32 = h->f32; ea.scale_by_sigma = sbs_mode(h); ea.sde = sc; ea.seed = seed;
     // step "-1": imputation ahead of the first predictor call (sampling.py:459) + pack x
     ea.res = nullptr; ea.t = timesteps_host[start_step]; ea.t_next = timesteps_host[start_step];
     ea.step = (uint32_t)(start_step - 1);
@@ -807,7 +809,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
         EmStepParams& p = sa.em;
         p.bias = flat + h->off_post_b; p.x_ft = w.xft; p.x_mean_ft = nullptr; p.xin = w.xin;
         p.sigmas = sigmas; p.sde = make_sde_dev(sc); p.t = 0.f; p.num_scales = h->d.num_scales;
-        p.scale_by_sigma = h->d.scale_by_sigma; p.D = h->D; p.Cp = h->Cp; p.QD = (h->D + 3) >> 2; p.S_valid = B;
+        p.scale_by_sigma = sbs_mode(h); p.D = h->D; p.Cp = h->Cp; p.QD = (h->D + 3) >> 2; p.S_valid = B;
         p.seed = seed; p.step = 0;
         if (persistent_env >= 2) {
             // cluster form (gemm_sampler.hip): 2 = joined by the per-block counters, 3 = the same walk without waits (timing probe, garbage samples)
@@ -842,7 +844,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
             std::memset(&p, 0, sizeof(p));
             p.bias = flat + h->off_post_b; p.x_ft = w.xft; p.x_mean_ft = (i + 1 == n_run) ? w.xmft : nullptr; p.xin = w.xin;
             p.sigmas = sigmas; p.sde = make_sde_dev(sc); p.t = timesteps_host[gi]; p.num_scales = h->d.num_scales;
-            p.scale_by_sigma = h->d.scale_by_sigma; p.D = h->D; p.Cp = h->Cp; p.QD = (h->D + 3) >> 2; p.S_valid = B;
+            p.scale_by_sigma = sbs_mode(h); p.D = h->D; p.Cp = h->Cp; p.QD = (h->D + 3) >> 2; p.S_valid = B;
             p.seed = seed; p.step = (uint32_t)gi;
             DP_HIP_LAUNCH(gemm_em_step(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
         }
@@ -879,7 +881,6 @@ extern "C" int dposer_langevin_step(dposer_scorefc_t h, const float* flat, const
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x && norm_sums && freq && sigmas, "null argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused Langevin step supports subVP / VP SDEs");
-    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused Langevin step supports the positional embedding");
     DP_CHECK_ARG(phase == 0 || phase == 1, "phase must be 0 (norms) or 1 (update)");
     DP_CHECK_ARG(phase == 0 || x_mean, "x_mean is required in the update phase");
     hipStream_t st = (hipStream_t)stream;
@@ -890,7 +891,7 @@ extern "C" int dposer_langevin_step(dposer_scorefc_t h, const float* flat, const
     std::memset(&a, 0, sizeof(a));
     a.res = w.res; a.noise = noise; a.sigmas = sigmas; a.x = x; a.x_mean = x_mean; a.part = w.loss_part; a.norm_sums = norm_sums;
     a.t = t; a.alpha = alpha; a.snr = snr; a.inv_global_batch = (float)inv_global_batch; a.B = B; a.Bpad = w.Bpad; a.D = h->D; a.Dpad = h->Dpad;
-    a.Cp = h->Cp; a.num_scales = h->d.num_scales; a.scale_by_sigma = h->d.scale_by_sigma; a.f32 = h->f32; a.sde = to_sde(sde); a.seed = seed;
+    a.Cp = h->Cp; a.num_scales = h->d.num_scales; a.scale_by_sigma = sbs_mode(h); a.f32 = h->f32; a.sde = to_sde(sde); a.seed = seed;
     a.step = step;
     if (phase == 0) {
         DP_TRY(build_time_table(h, flat, packed, w, nullptr, t * 999.0f, 1, freq, st));
@@ -915,7 +916,6 @@ static int prior_loss_impl(dposer_scorefc_t h, const float* flat, const void* pa
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x0 && loss && sigmas && (freq || table_rows > 0), "null argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "prior loss supports subVP / VP SDEs");
-    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "prior loss supports the positional embedding");
     DP_CHECK_ARG(table_rows <= 0 || (row >= 0 && row < table_rows), "table row out of range");
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
@@ -931,7 +931,7 @@ static int prior_loss_impl(dposer_scorefc_t h, const float* flat, const void* pa
     DenoiseArgs da;
     da.res = w.res; da.x0 = x0; da.xt = w.xt; da.sigmas = sigmas; da.x0_hat = x0_hat; da.grad = grad; da.loss_part = w.loss_part;
     da.t = t; da.inv_n = inv_n; da.weighted = weighted; da.B = B; da.D = h->D; da.Dpad = h->Dpad; da.Cp = h->Cp;
-    da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma; da.sde = sc;
+    da.num_scales = h->d.num_scales; da.scale_by_sigma = sbs_mode(h); da.sde = sc;
     int nb = 0;
     DP_HIP_LAUNCH(launch_denoise(da, &nb, st));
     DP_HIP_LAUNCH(launch_sum_partials(w.loss_part, nb, loss, st));
@@ -947,7 +947,6 @@ extern "C" int dposer_prior_table_build(dposer_scorefc_t h, const float* flat, c
                                         int32_t n_rows, const float* freq, int64_t B, void* stream) {
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     DP_CHECK_ARG(t_host && freq && n_rows >= 1, "bad argument");
-    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "the time table covers the positional embedding");
     hipStream_t st = (hipStream_t)stream;
     Ws w;
     layout_ws(h, B, DPOSER_WS_SHARED_T, n_rows, (char*)ws_, w);
@@ -979,7 +978,6 @@ extern "C" int dposer_completion_optimize(dposer_scorefc_t h, const float* flat,
     DP_CHECK_ARG(sde && x && observation && mask && adam_m && adam_v && t_host && weighted_host && w_prior_host && w_data_host && freq && sigmas,
                  "null argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused completion loop supports subVP / VP SDEs");
-    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused completion loop supports the positional embedding");
     DP_CHECK_ARG(n_steps >= 0, "n_steps must be >= 0");
     if (n_steps == 0) return DPOSER_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -1006,7 +1004,7 @@ extern "C" int dposer_completion_optimize(dposer_scorefc_t h, const float* flat,
         ua.step_size = (float)(lr / (1.0 - std::pow(beta1, k)));                   // torch: step_size = lr / bias_correction1
         ua.one_minus_beta1 = (float)(1.0 - beta1); ua.beta2 = (float)beta2; ua.one_minus_beta2 = (float)(1.0 - beta2);
         ua.bc2_sqrt = (float)std::sqrt(1.0 - std::pow(beta2, k)); ua.eps = (float)eps;
-        ua.B = B; ua.D = h->D; ua.Dpad = h->Dpad; ua.Cp = h->Cp; ua.num_scales = h->d.num_scales; ua.scale_by_sigma = h->d.scale_by_sigma; ua.sde = sc;
+        ua.B = B; ua.D = h->D; ua.Dpad = h->Dpad; ua.Cp = h->Cp; ua.num_scales = h->d.num_scales; ua.scale_by_sigma = sbs_mode(h); ua.sde = sc;
         DP_HIP_LAUNCH(launch_completion_update(ua, st));
     }
     return DPOSER_OK;
@@ -1507,7 +1505,6 @@ static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const vo
     g_alg_batch = B;
     DP_CHECK_ARG(sde && batch_x && freq && sigmas && flat_grad && loss, "null argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused DSM step supports subVP / VP SDEs");
-    DP_CHECK_ARG(h->d.embedding == DPOSER_EMB_POSITIONAL, "fused DSM step supports the positional embedding");
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
     Ws w;
@@ -1516,7 +1513,7 @@ static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const vo
     const SdeCfg sc = to_sde(sde);
     PrepTrainArgs pa;
     pa.x0 = batch_x; pa.t_in = t_in; pa.z_in = z_in; pa.freq = freq; pa.xin = w.xin; pa.emb = w.emb; pa.t_out = w.tbuf; pa.z_out = w.zbuf;
-    pa.B = B; pa.Bpad = Bpad; pa.D = h->D; pa.Dpad = h->Dpad; pa.E = h->E; pa.fourier = 0; pa.f32 = h->f32; pa.sde = sc; pa.eps = eps;
+    pa.B = B; pa.Bpad = Bpad; pa.D = h->D; pa.Dpad = h->Dpad; pa.E = h->E; pa.fourier = h->d.embedding == DPOSER_EMB_FOURIER; pa.f32 = h->f32; pa.sde = sc; pa.eps = eps;
     pa.seed = seed; pa.step = step;
     DP_HIP_LAUNCH(launch_prep_train(pa, st));
     DP_TRY(forward_core_train(h, flat, packed, w, B, true, seed, step, st));
@@ -1524,7 +1521,7 @@ static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const vo
     da.res = w.res; da.t = w.tbuf; da.z = w.zbuf; da.sigmas = sigmas; da.dres = w.dres; da.loss_part = w.loss_part; da.B = B; da.Bpad = Bpad;
     da.cs_part = w.cs_part_post;
     da.D = h->D; da.Dpad = h->Dpad; da.Cp = h->Cp; da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma;
-    da.f32 = h->f32; da.fourier = 0; da.grad_scale = (float)(1.0 / ((double)B * (double)h->D)); da.sde = sc;
+    da.f32 = h->f32; da.fourier = h->d.embedding == DPOSER_EMB_FOURIER; da.grad_scale = (float)(1.0 / ((double)B * (double)h->D)); da.sde = sc;
     int nb = 0;
     DP_HIP_LAUNCH(launch_dsm(da, &nb, st));
     const SumJob loss_sum{w.loss_part, nb, loss};                      // summed by one block of the LAST reduction launch of the backward

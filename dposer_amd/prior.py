@@ -36,7 +36,7 @@ class _PriorLoss(torch.autograd.Function):
         zz = None if z is None else z.contiguous().float()
         _C.check(eng.lib.dposer_prior_loss(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(zz), float(t),
                                            1 if weighted else 0, float(inv_n), _C.ptr(x0_hat), _C.ptr(grad), _C.ptr(loss), int(seed),
-                                           int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(x.device)), _C.ptr(model.sigmas), B,
+                                           int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(x.device, model._fourier_W())), _C.ptr(model.sigmas), B,
                                            _C.stream_ptr()), "dposer_prior_loss")
         ctx.save_for_backward(grad)
         ctx.x0_hat = x0_hat

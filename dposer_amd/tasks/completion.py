@@ -47,8 +47,7 @@ class DPoserComp:
 
     def _fused_supported(self):
         from ..algorithms.advanced.model import ScoreModelFC
-        return (sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
-                and self.model.time_embedding_type == "positional")
+        return sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
 
     def _schedule(self, time_strategy, total_steps, sample_trun, sample_time):
         """quan_t of every step (completion.py:183-192)."""
@@ -91,7 +90,7 @@ class DPoserComp:
             _C.check(eng.lib.dposer_completion_optimize(
                 eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(sde_lib.sde_desc(self.sde)), _C.ptr(x), _C.ptr(obs), _C.ptr(msk),
                 _C.ptr(m), _C.ptr(v), t_host, wflag, w_prior, w_data, total_steps, float(lr), 0.9, 0.999, 1e-8, _C.ptr(nz),
-                int(model._rng_seed + 29), int(step0) & 0xFFFFFFFF, _C.ptr(eng.freq(x.device)), _C.ptr(model.sigmas), B, _C.stream_ptr()),
+                int(model._rng_seed + 29), int(step0) & 0xFFFFFFFF, _C.ptr(eng.freq(x.device, model._fourier_W())), _C.ptr(model.sigmas), B, _C.stream_ptr()),
                 "dposer_completion_optimize")
             return observation * mask + x * (1.0 - mask)
         x = observation.clone().detach().requires_grad_(True)

@@ -5,7 +5,7 @@ Per Adam step: z-score normalise -> ``dposer_prior_loss`` -> ``BodyModel`` forwa
 (dposer_lbs_forward / dposer_lbs_backward) -> temporal term on vertices + data term on Jtr[:, :22].
 The frames of one sequence are coupled by the temporal term, so data parallelism is over sequences.
 
-The whole loop is ONE call, ``dposer_motion_denoise_optimize`` (axis-angle or 6-D rotation representation, sub-VP / VP SDE, positional embedding):
+The whole loop is ONE call, ``dposer_motion_denoise_optimize`` (axis-angle or 6-D rotation representation, sub-VP / VP SDE, positional or Fourier time embedding):
 all steps are queued from C, the loss gradients and torch.optim.Adam's update are kernels, nothing returns to the host in
 between.  Other configurations (and ``fused=False``) run the same step through autograd and torch's Adam.
 """
@@ -91,7 +91,7 @@ class MotionDenoise:
         from ..body_model.body_model import BodyModel
         nz = self.Normalizer
         return (sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
-                and self.model.time_embedding_type == "positional" and isinstance(self.body_model, BodyModel)
+                and isinstance(self.body_model, BodyModel)
                 and getattr(nz, "rot_rep", None) in ("axis", "rot6d") and self.batch_size >= 2)
 
     def _optimize_fused(self, pose, init_joints, t_list, its, weights, noise, frames_per_sequence=0):
@@ -145,7 +145,7 @@ class MotionDenoise:
         self._calls += n_steps
         desc = sde_lib.sde_desc(self.sde)
         a = _C.MotionDenoiseArgs(
-            net=eng.h, flat_params=_C.ptr(flat), packed=_C.ptr(packed), net_ws=_C.ptr(ws), sde=C.pointer(desc), freq=_C.ptr(eng.freq(dev)),
+            net=eng.h, flat_params=_C.ptr(flat), packed=_C.ptr(packed), net_ws=_C.ptr(ws), sde=C.pointer(desc), freq=_C.ptr(eng.freq(dev, self.model._fourier_W())),
             sigmas=_C.ptr(model.sigmas), body=h, lbs_ws_fwd=_C.ptr(ws_f), lbs_ws_bwd=_C.ptr(ws_b), posedirs_packed=_C.ptr(core._packed_posedirs()),
             posedirs_bwd_packed=_C.ptr(core._packed_posedirs_bwd()), j_rest=_C.ptr(j_rest), v_shaped=_C.ptr(v_shaped),
             rest_batched=1 if batched else 0, skin_idx=_C.ptr(core.skin_idx), skin_w=_C.ptr(core.skin_w), skin_k=int(core.skin_idx.shape[1]),
@@ -235,7 +235,7 @@ class MotionDenoise:
         use_fused = self._fused_supported() if fused is None else bool(fused)
         if use_fused:
             if not self._fused_supported():
-                raise NotImplementedError("the one-call motion-denoising loop covers axis-angle / rot6d poses, sub-VP / VP SDEs and the positional embedding")
+                raise NotImplementedError("the one-call motion-denoising loop covers axis-angle / rot6d poses and sub-VP / VP SDEs")
             pose = (self.poses if init_poses is None else init_poses).detach().clone().contiguous().float()
             quan = [self._quan_t(time_strategy, step, total_steps, sample_trun, sample_time) for step in range(total_steps)]
             self.loss_log = self._optimize_fused(pose, init_joints, [float(timesteps[q]) for q in quan],

@@ -115,7 +115,9 @@ int dposer_scorefc_forward(dposer_scorefc_t h, const float* flat_params, const v
  *   noise [n_steps][k][B][D] injected draws in the reference's draw order per step
  *     (k = 1: predictor z;  k = 3 with completion: impute-after-corrector, z, impute-after-predictor)
  *     or NULL -> in-kernel Philox4x32-10 keyed by `seed`;
- *   traj [ceil(n_steps/traj_stride)][B][D] or NULL: state after steps start+traj_stride-1, ... */
+ *   traj [ceil(n_steps/traj_stride)][B][D] or NULL: state after steps start+traj_stride-1, ...
+ * Both time embeddings (here and in every shared-t entry point below): `freq` = the positional frequencies, or gauss_proj.W for
+ * DPOSER_EMB_FOURIER (embedding of log(labels), output divided by the labels: model.py:152-155,192-194). */
 int dposer_em_sampler(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws,
                       const dposer_sde_desc* sde, float* x, float* x_mean, const float* timesteps_host,
                       int32_t start_step, const float* observation, const float* mask, const float* noise,

@@ -290,6 +290,54 @@ def test_prior_loss_matches_reference_golden(prec, tol):
         assert abs(float(lu) - float(g[f"s{step}_loss_unweighted"])) / abs(float(g[f"s{step}_loss_unweighted"])) < tol
 
 
+@pytest.mark.parametrize("prec,tol_loss,tol_grad,tol", [("fp32", 2e-5, 2e-4, 1e-4), ("bf16", 5e-3, 8e-3, 1e-2)])
+def test_fourier_embedding_fused_paths_match_reference_golden(prec, tol_loss, tol_grad, tol, monkeypatch):
+    """`config.model.embedding_type = 'fourier'` (the shipped config's documented alternative: GaussianFourierProjection of
+    log(labels), output divided by the labels -- model.py:117-118,152-155) on the ONE-CALL paths: fused DSM step, fused EM sampler
+    (plain and with completion imputation), prior loss and the completion loop, each against the reference's own output with its
+    recorded draws (golden g20).  The fused entry points must be the ones that run: the step-by-step fallbacks are made to raise."""
+    from dposer_amd.algorithms.advanced import sampling, sde_lib
+    from dposer_amd.prior import prior_loss
+    from dposer_amd.tasks.completion import DPoserComp
+    g = load("g20_fourier_paths")
+    cfg, m, p = make_model(int(g["seed"]), precision=prec, dropout=0.0, embedding="fourier")
+    sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+    assert sampling.fused_em_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, True)
+    # DSM loss + every parameter gradient
+    t = _dev(g["dsm_u"]) * (1.0 - 1e-5) + 1e-5
+    loss, fg = _fused_grad(m, _dev(g["dsm_batch"]), t, _dev(g["dsm_z"]))
+    assert abs(loss - float(g["dsm_loss"])) / float(g["dsm_loss"]) < tol_loss
+    for (name, prm), off in zip(m.named_parameters(), m._offsets):
+        ref = g[f"dsm_grad/{name}"]
+        got = fg[off:off + prm.numel()]
+        if ref.shape == (1,):
+            assert float(got.abs().max()) == 0.0          # pre_dense_cond and the fixed projection W: no gradient
+            continue
+        assert rel_err(probe(name, got), ref) < tol_grad, name
+    # EM sampler, N = 8: plain and with the completion imputation
+    monkeypatch.setattr(sampling, "shared_predictor_update_fn", lambda *a, **k: (_ for _ in ()).throw(AssertionError("step-by-step sampler used")))
+    cfg8, m8, _ = make_model(int(g["seed"]), precision=prec, embedding="fourier")
+    sde8, fn = _sampler(m8, cfg8, 8, 16)
+    trajs, x = fn(m8, z=_dev(g["em8_z0"]), noise=_dev(g["em8_noise"])[:, None])
+    assert rel_err(t2n(trajs), g["em8_trajs"]) < tol and rel_err(t2n(x), g["em8_final"]) < tol
+    trajs, x = fn(m8, observation=_dev(g["comp8_obs"]), mask=_dev(g["comp8_mask"]), z=_dev(g["comp8_z0"]), args=_Args("completion"),
+                  noise=_dev(g["comp8_noise"]).reshape(8, 3, 16, 63))
+    assert rel_err(t2n(trajs), g["comp8_trajs"]) < tol and rel_err(t2n(x), g["comp8_final"]) < tol
+    # prior loss + its gradient
+    for step in (0, 199):
+        x0 = _dev(g["prior_x0"]).requires_grad_(True)
+        lp = prior_loss(m8, sde, x0, float(g[f"prior_s{step}_t"]), weighted=bool(int(g[f"prior_s{step}_quan_t"])), z=_dev(g[f"prior_s{step}_z"]))
+        lp.backward()
+        assert abs(float(lp) - float(g[f"prior_s{step}_loss"])) / abs(float(g[f"prior_s{step}_loss"])) < max(tol, 2e-4)
+        assert rel_err(t2n(x0.grad), g[f"prior_s{step}_grad"]) < max(tol, 2e-4)
+    # the completion loop as one call
+    comp = DPoserComp(m8, sde, continuous=True, batch_size=16)
+    assert comp._fused_supported()
+    out = comp.optimize(_dev(g["loop_observation"]), _dev(g["loop_mask"]), iterations=int(g["loop_iterations"]),
+                        steps_per_iter=int(g["loop_steps_per_iter"]), noise=_dev(g["loop_noise"]))
+    assert rel_err(t2n(out), g["loop_out"]) < max(tol, 2e-4)
+
+
 # ------------------------------------------------------------------------------------------------
 # training: DSM loss, gradients, Adam / EMA
 # ------------------------------------------------------------------------------------------------
@@ -988,7 +1036,8 @@ def test_langevin_fused_vp_sde_vs_oracle():
     assert rel_err(t2n(x), xm.numpy()) < 1e-4
 
 
-def test_langevin_fused_completion_imputation_matches_generic_loop():
+@pytest.mark.parametrize("embedding", ["positional", "fourier"])
+def test_langevin_fused_completion_imputation_matches_generic_loop(embedding):
     """Predictor-corrector loop with imputation (task = completion, sampling.py:416-420,455-461): per outer step the draws are
     corrector x n_steps, imputation after the corrector, predictor, imputation after the predictor.  The HIP path
     (dposer_langevin_step + dposer_em_sampler_steps with observation / mask) against the generic classes run step by step on the
@@ -996,7 +1045,7 @@ def test_langevin_fused_completion_imputation_matches_generic_loop():
     from unittest import mock
     from dposer_amd.algorithms.advanced import sampling, sde_lib
     from dposer_amd.utils.misc import create_mask
-    cfg, m, p = make_model(25, precision="fp32")
+    cfg, m, p = make_model(25, precision="fp32", embedding=embedding)
     cfg.sampling.corrector = "langevin"
     cfg.sampling.n_steps_each = 2
     N, B, nst = 1000, 32, 2

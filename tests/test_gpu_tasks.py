@@ -150,12 +150,12 @@ def test_motion_denoise_zero_data_residual_stays_finite():
     assert np.abs(t2n(res["pose_body"]) - g["b_pose_final"]).max() < 0.2          # Adam lr 0.03 x 6 steps bounds the drift
 
 
-def _md_setup(T=12, min_max=False, seed=7):
+def _md_setup(T=12, min_max=False, seed=7, embedding="positional"):
     from dposer_amd.body_model.body_model import BodyModel
     from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
     from dposer_amd.dataset.AMASS import Posenormalizer
     from dposer_amd.tasks.motion_denoising import MotionDenoise
-    cfg, m, p = make_model(63, precision="fp32")
+    cfg, m, p = make_model(63, precision="fp32", embedding=embedding)
     asset = make_synthetic_smplx_asset(seed=0)
     bm = BodyModel(asset).to(DEV)
     g = load("g10_normalizer")
@@ -175,13 +175,14 @@ def _md_setup(T=12, min_max=False, seed=7):
     return md, dev(joints3d), dev(gt), dev(init), rs
 
 
-@pytest.mark.parametrize("min_max", [False, True])
-def test_motion_denoise_one_call_loop_matches_the_autograd_loop(min_max):
+@pytest.mark.parametrize("min_max,embedding", [(False, "positional"), (True, "positional"), (False, "fourier")])
+def test_motion_denoise_one_call_loop_matches_the_autograd_loop(min_max, embedding):
     """dposer_motion_denoise_optimize (all steps queued from C: loss gradients + Adam as kernels) vs the same steps through
     autograd and torch.optim.Adam around the same HIP kernels, with injected prior noise; z-score and min-max normalisers;
     two outer iterations so the loss weights change.  The per-step loss log equals the autograd loop's loss values."""
     T, iters, spi = 12, 2, 4
-    md, joints3d, gt, init, rs = _md_setup(T, min_max)
+    md, joints3d, gt, init, rs = _md_setup(T, min_max, embedding=embedding)
+    assert md._fused_supported()
     noise = torch.tensor(rs.standard_normal((iters * spi, T, 63)).astype(np.float32), device=DEV)
     kw = dict(gt_poses=gt, time_strategy="3", iterations=iters, steps_per_iter=spi, noise=noise, init_poses=init)
     res_f = md.optimize(joints3d, fused=True, **kw)
