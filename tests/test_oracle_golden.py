@@ -166,6 +166,43 @@ def test_prior_loss():
         assert abs(lu.item() - float(g[f"s{step}_loss_unweighted"])) / abs(float(g[f"s{step}_loss_unweighted"])) < 1e-4
 
 
+def test_fourier_embedding_paths_of_the_restatement_match_the_reference():
+    """Golden g20 (the reference with `embedding_type = 'fourier'`): DSM loss + gradients, EM sampler with and without the
+    completion imputation, prior loss -- the restatement with `embedding_type="fourier"`."""
+    g = load("g20_fourier_paths")
+    fw = dict(embedding_type="fourier")
+    p = make_weights(int(g["seed"]), D=63, fourier=True)
+    p["sigmas"] = R.sigma_table()
+    names = [n for n in R.param_names(fourier=True)]
+    leaves = {n: p[n].clone().requires_grad_(True) for n in names}
+    full = dict(p)
+    full.update(leaves)
+    t = torch.tensor(g["dsm_u"]) * (1.0 - 1e-5) + 1e-5
+    loss = R.dsm_loss(full, R.SubVP(), torch.tensor(g["dsm_batch"]), t, torch.tensor(g["dsm_z"]), **fw)
+    assert abs(loss.item() - float(g["dsm_loss"])) / float(g["dsm_loss"]) < 1e-5
+    grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)
+    for n, gr in zip(names, grads):
+        ref = g[f"dsm_grad/{n}"]
+        if gr is None or ref.shape == (1,):
+            assert ref.shape == (1,), n       # no gradient in the reference: pre_dense_cond (unused), gauss_proj.W (requires_grad = False)
+            continue
+        assert rel_err(probe(n, gr), ref) < 1e-4, n
+    z0, noise = torch.tensor(g["em8_z0"]), torch.tensor(g["em8_noise"])
+    trajs, x = R.pc_sampler(p, R.SubVP(N=8), z0, noise, **fw)
+    assert rel_err(trajs, g["em8_trajs"]) < 1e-4 and rel_err(x, g["em8_final"]) < 1e-4
+    nz = torch.tensor(g["comp8_noise"]).reshape(8, 3, 16, 63)
+    trajs, x = R.pc_sampler(p, R.SubVP(N=8), torch.tensor(g["comp8_z0"]), nz[:, 1], observation=torch.tensor(g["comp8_obs"]),
+                            mask=torch.tensor(g["comp8_mask"]), impute_noises=[(nz[i, 0], nz[i, 2]) for i in range(8)], **fw)
+    assert rel_err(trajs, g["comp8_trajs"]) < 1e-4 and rel_err(x, g["comp8_final"]) < 1e-4
+    x0 = torch.tensor(g["prior_x0"])
+    ts = torch.linspace(1.0, 1e-3, 1000)
+    for step in (0, 199):
+        q = int(g[f"prior_s{step}_quan_t"])
+        lp, grad = R.dposer_prior_loss(p, R.SubVP(), x0, torch.ones(16) * ts[q], torch.tensor(g[f"prior_s{step}_z"]), weighted=bool(q), **fw)
+        assert abs(lp.item() - float(g[f"prior_s{step}_loss"])) / abs(float(g[f"prior_s{step}_loss"])) < 1e-4
+        assert rel_err(grad, g[f"prior_s{step}_grad"]) < 1e-4
+
+
 def test_scalar_tables():
     g = load("g8_scalars")
     t = torch.tensor(g["t"])
