@@ -105,9 +105,9 @@ def test_motion_denoise_steps_match_oracle():
                       steps_per_iter=spi, noise=torch.tensor(noise, device=DEV), init_poses=torch.tensor(init, device=DEV))
     final, ref = task_loops.motion_denoise_optimize(p, R.SubVP(N=500), asset, stats["mean_poses"], stats["std_poses"], joints3d, gt, init, noise,
                                                     iterations=iters, steps_per_iter=spi)
-    # 5e-4: fp32 kernels against the fp64-accumulating restatement over 2 x 4 Adam steps; it also covers the vertex / joint residual
-    # gradients' v_rcp_f32 / v_rsq_f32 (1 ulp each, csrc/tasks.hip: k_md_vert_grad) in place of IEEE divisions -- measured 9e-8 here
-    assert rel_err(t2n(res["pose_body"]), final) < 5e-4
+    # fp32 kernels against the restatement over 2 x 4 Adam steps; the bound also covers the vertex / joint residual gradients'
+    # v_rcp_f32 / v_rsq_f32 (1 ulp each, csrc/tasks.hip: k_md_vert_grad) in place of IEEE divisions -- measured 9e-8
+    assert rel_err(t2n(res["pose_body"]), final) < 1e-5
     assert res["MPJPE"].shape == (T,) and np.isfinite(res["MPVPE"]).all()
 
 
