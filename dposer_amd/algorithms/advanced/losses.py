@@ -384,6 +384,9 @@ def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, se
     event)`` the call itself announces every group of final buckets (one event + merged flat ranges) while it is still queueing
     the rest of the backward pass (distributed.StreamedAllReduce)."""
     _C.require_gpu(batch, "training batch")
+    if batch.shape[0] == 0:
+        # (the reference would take torch.mean of an empty tensor: a NaN loss and NaN gradients into Adam's moments -- refuse instead)
+        raise ValueError("empty training batch")
     from ...engine import param_state_key
     eng = model._engine()
     flat = model.flat_params()

@@ -256,6 +256,9 @@ class ScoreModelFC(nn.Module):
         _C.require_gpu(batch, "ScoreModelFC input")
         if self.sigmas.device != batch.device or self._param_list[0].device != batch.device:
             raise _C.DPoserHipError("ScoreModelFC parameters and input are on different devices")
+        if batch.shape[0] == 0:
+            # torch's layers return an empty [0, D] for an empty batch (model.py:141-196 has no special case); the kernels take B >= 1
+            return batch.float() * 0.0
         flat = self.flat_params()
         eng = self._engine()
         x = batch.contiguous().float()

@@ -269,6 +269,10 @@ def fused_em_sample(model, sde, x, timesteps, *, start_step=0, observation=None,
     B, D = x.shape
     N = int(sde.N)
     n_run = N - start_step
+    if B == 0:                      # nothing to sample: the reference's loop runs on empty tensors and returns them
+        x = x.contiguous().float().clone()
+        traj = torch.empty((max(n_run, 0) // traj_stride, 0, D), dtype=torch.float32, device=x.device) if traj_stride and n_run > 0 else None
+        return traj, x, x.clone()
     ws = eng.workspace(B, _C.WS_SHARED_T, max(n_run, 1), x.device)
     x = x.contiguous().float().clone()
     x_mean = x.clone()

@@ -347,6 +347,13 @@ class _SMPLCore(nn.Module):
         B = given[0].shape[0]
         dev = given[0].device
         _C.require_gpu(given[0], "BodyModel input")
+        if B == 0:                  # smplx returns empty outputs for an empty batch; the kernels take B >= 1
+            n_out = self.J if n_joints is None else int(n_joints)
+            if joints_only:
+                return Struct(vertices=None, joints=torch.zeros(0, n_out, 3, dtype=torch.float32, device=dev))
+            return self._output(torch.zeros(0, self.V, 3, dtype=torch.float32, device=dev),
+                                torch.zeros(0, self.J + self.n_extra + self.n_lmk, 3, dtype=torch.float32, device=dev), segs, betas, expression, B, dev,
+                                return_full_pose)
         needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in given)
         if self.v_template.device != dev:
             raise _C.DPoserHipError("BodyModel buffers and inputs are on different devices; call .to(device)")

@@ -70,6 +70,8 @@ def _prior_loss_unfused(model, sde, x0, t, weighted, inv_n, z):
 def prior_loss(model, sde, x0, t, *, weighted=True, reduction="mean", batch_size=None, z=None, seed=0, step=0):
     """Weighted denoising loss at one shared time ``t`` (python float).
     reduction='mean' -> torch.mean over [B, D] (completion.py:147); 'sum_over_batch' -> sum / batch_size (smplify.py:105)."""
+    if x0.shape[0] == 0:
+        raise ValueError("prior_loss: empty batch (the reference's torch.mean over no elements is NaN)")
     n = x0.numel() if reduction == "mean" else (batch_size if batch_size is not None else x0.shape[0])
     if sde_lib.sde_desc(sde) is None:      # VE: no fused kernel -- the HIP score function + the reference's few elementwise steps
         return _prior_loss_unfused(model, sde, x0, float(t), bool(weighted), 1.0 / float(n), z)

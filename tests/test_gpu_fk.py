@@ -758,6 +758,21 @@ def test_smplx_wrapper_accepts_rotation_matrices(asset):
         sm(body_pose=torch.tensor(body.reshape(B, 63), device=DEV), pose2rot=False)
 
 
+def test_empty_batch_returns_empty_outputs():
+    """B = 0 (smplx returns empty vertices / joints; the kernels take B >= 1): full forward, joints-only forward and the differentiable path."""
+    from dposer_amd.body_model.body_model import BodyModel
+    from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
+    bm = BodyModel(make_synthetic_smplx_asset(seed=0)).to(DEV)
+    pose = torch.zeros(0, 63, device=DEV)
+    out = bm(pose_body=pose)
+    assert out.v.shape == (0, 10475, 3) and out.Jtr.shape[0] == 0 and out.Jtr.shape[2] == 3
+    out = bm(pose_body=pose.clone().requires_grad_(True))
+    assert out.v.shape == (0, 10475, 3)
+    core = bm.bm
+    j = core(body_pose=pose, joints_only=True, n_joints=22)
+    assert j.joints.shape == (0, 22, 3)
+
+
 @pytest.mark.parametrize("B,segments", [(300, "body"), (2304, "body"), (300, "body+jaw"), (64, "root only")])
 def test_blend_gemms_over_the_posed_joints_only_keep_every_bit(bm, asset, B, segments, tuning_env):
     """The pose-blend GEMM reduces over the pose-feature columns of the joints that ARE posed (a NULL segment is the identity rotation:

@@ -50,6 +50,31 @@ def test_forward_fourier_ve_matches_reference_golden():
     assert rel_err(t2n(out), g["axis_fourier_score_ve"]) < 2e-3
 
 
+def test_empty_batches():
+    """B = 0: torch's layers and loops (the reference) return empty tensors; the kernels take B >= 1, so the host mirror answers itself:
+    forward and sampler return empties of the right shape, the training step and the prior loss (NaN in the reference: a mean over
+    nothing) refuse."""
+    from dposer_amd.algorithms.advanced import sde_lib
+    from dposer_amd.prior import prior_loss
+    cfg, m, p = make_model(3, precision="bf16")
+    x0 = torch.zeros(0, 63, device=DEV)
+    assert m(x0, torch.zeros(0, device=DEV)).shape == (0, 63)
+    m.train()
+    xg = x0.clone().requires_grad_(True)
+    out = m(xg, torch.zeros(0, device=DEV))
+    assert out.shape == (0, 63)
+    out.sum().backward()
+    assert xg.grad.shape == (0, 63)
+    m.eval()
+    sde, fn = _sampler(m, cfg, 8, 0)
+    trajs, x = fn(m, z=x0)
+    assert x.shape == (0, 63) and trajs.shape[1:] == (0, 63)
+    with pytest.raises(ValueError):
+        _fused_grad(m, x0, None, None)
+    with pytest.raises(ValueError):
+        prior_loss(m, sde_lib.subVPSDE(0.1, 20.0, 1000), x0, 0.5)
+
+
 @pytest.mark.parametrize("B", [1, 31, 33, 64, 100, 500, 513, 1000, 4096])
 def test_forward_ragged_batches_vs_oracle(B):
     cfg, m, p = make_model(11, precision="fp32")
