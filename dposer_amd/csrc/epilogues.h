@@ -995,6 +995,90 @@ template <typename T, bool ACTRT = false> struct EpiSiLUBwd {
     }
 };
 
+// post_dense + the denoising-score-matching loss + d loss / d res in ONE launch (the fused training step): what EpiRowMajor -> `res`
+// -> k_dsm did in two launches and a round trip of `res`.  Per element, in k_dsm's operation order (losses.py:121-131, utils.py:162,
+// model.py:192-194):
+//   model = (acc + bias) / used_sigma(t);  score = -model / std(t);  e = score * std(t) + z;  loss += e^2;
+//   d res = (-2 e) * grad_scale / used_sigma(t)          (zero on padded samples / channels)
+// t differs per sample (lane = sample): each lane derives std / used_sigma of its own sample once per 32-sample tile.
+// Outputs: dres (FT, the operand of the backward GEMMs), per-wave column sums of the STORED dres (post_dense's bias gradient: summed
+// over the wave rows by the step's reduction launch, like the GroupNorm-backward partials) and one loss partial per wave.
+struct DsmStepParams {
+    const float* bias;     // [D] post_dense bias
+    const float* t;        // [Spad] t of every sample
+    const float* z;        // [Spad][Dpad] fp32 row-major: the noise k_prep_train kept
+    const float* sigmas;
+    void* dres;            // FT [Spad][Cp]
+    float* loss_part;      // [wave rows * waves along the channels]
+    float* cs_part;        // [wave rows][Cp]
+    SdeDev sde;
+    float grad_scale;
+    int num_scales, scale_by_sigma, fourier;
+    int D, Dpad, Cp;
+    int64_t S_valid;
+};
+template <typename T> struct EpiDsm {
+    typedef DsmStepParams Params;
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int wrow, int, const float*, int, unsigned char*) {
+#pragma clang fp contract(off)
+        const int j = lane & 31, hi = lane >> 5;
+        float lsum = 0.f;
+        float csum[TC][16];
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) csum[tc][r] = 0.f;
+#pragma unroll
+        for (int ts = 0; ts < TS; ++ts) {
+            const int64_t s = sbase + ts * 32 + j;
+            const bool live = s < p.S_valid;
+            const float t = live ? p.t[s] : 0.5f;
+            const float lmc = sde_lmc(p.sde, t);
+            const float sd = sde_std(p.sde, lmc);
+            const float usig = p.scale_by_sigma ? used_sigma(p.sigmas, p.num_scales, t * 999.0f, p.fourier) : 1.0f;
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc) {
+                const int c0 = cbase + tc * 32;
+                float o[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + 8 * q + 4 * hi;
+                    f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    if (live && c < p.Dpad) z4 = *reinterpret_cast<const f32x4*>(p.z + s * p.Dpad + c);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 4 * q + r;
+                        const bool ok = live && c + r < p.D;
+                        const float model = (acc[tc][ts][i] + (c + r < p.D ? p.bias[c + r] : 0.f)) / usig;
+                        const float score = -model / sd;                                   // utils.py:162
+                        const float e = score * sd + z4[r];                                // losses.py:124
+                        if (ok) lsum += e * e;
+                        o[i] = ok ? (-2.0f * e) * p.grad_scale / usig : 0.f;
+                    }
+                }
+                TileIO<T>::store((T*)p.dres + ft_tile_base<T>(sbase + ts * 32, c0, p.Cp), lane, o);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) csum[tc][r] += (float)(T)o[r];               // what the backward GEMMs read
+            }
+        }
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) {
+            const float db = butterfly_reduce16(csum[tc], lane);
+            const int i = j & 15;
+            const int c = cbase + tc * 32 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+            if (j < 16) p.cs_part[(int64_t)wrow * p.Cp + c] = db;
+        }
+        // one loss partial per wave: lanes 0..31 / 32..63 by row-shift adds, then the two halves
+        float v = lsum;
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        v = sum_xor32(v);
+        const int chan_waves = p.Cp / (TC * 32);
+        if (lane == 0) p.loss_part[(int64_t)wrow * chan_waves + (cbase / (TC * 32)) % chan_waves] = v * p.grad_scale;
+    }
+};
+
 // wgrad: slab[split][n][k] = acc   (fp32 row-major, lane = k column => 128-B coalesced rows)
 struct WgradParams {
     float* slab;            // base of this parameter inside slab 0

@@ -24,6 +24,7 @@ hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNP
 hipError_t gemm_bias_silu(int prec, bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st);
 hipError_t gemm_rowmajor(int prec, int shape, const GemmArgs& g, const RowMajorParams& p, hipStream_t st);
 hipError_t gemm_em_step(int prec, int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st);
+hipError_t gemm_dsm_step(int prec, int shape, const GemmArgs& g, const DsmStepParams& p, hipStream_t st);   // SHAPE_FINAL / SHAPE_FINAL_S
 hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTParams& p, hipStream_t st);
 hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st, int gs = 32);
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st);
@@ -69,7 +70,7 @@ hipError_t launch_sampler_persistent(int prec, const SamplerArgs& a, int64_t n_s
 hipError_t launch_sampler_cluster(int prec, const SamplerArgs& a, int sync, hipStream_t st);
 
 // ---- optional per-launch profiling (HIP events on the launch stream; off by default) ------------------
-enum GemmEpiKind : int { EPI_GN = 0, EPI_GN_TRAIN, EPI_BIAS_SILU, EPI_ROWMAJOR, EPI_PLAIN_FT, EPI_GN_BWD, EPI_SILU_BWD, EPI_WGRAD, EPI_EM_STEP, EPI_KINDS };
+enum GemmEpiKind : int { EPI_GN = 0, EPI_GN_TRAIN, EPI_BIAS_SILU, EPI_ROWMAJOR, EPI_PLAIN_FT, EPI_GN_BWD, EPI_SILU_BWD, EPI_WGRAD, EPI_EM_STEP, EPI_DSM_STEP, EPI_KINDS };
 constexpr int GEMM_PROF_KINDS = EPI_KINDS * 2 * 6;
 void gemm_prof_enable(int on);
 // synchronises the recorded events, accumulates them per kind and clears the record list

@@ -33,7 +33,7 @@ struct ProfScope {
     }
     ~ProfScope() { if (r) (void)hipEventRecord(r->b, st); }
 };
-const char* kEpiNames[EPI_KINDS] = {"gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad", "post_em_step"};
+const char* kEpiNames[EPI_KINDS] = {"gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad", "post_em_step", "post_dsm_step"};
 const char* kShapeNames[6] = {"256x256", "128x128", "128x32", "64x128", "64x32", "128x64"};
 }   // namespace
 void gemm_prof_enable(int on) {
@@ -138,6 +138,10 @@ hipError_t gemm_rowmajor(int prec, int shape, const GemmArgs& g, const RowMajorP
 hipError_t gemm_em_step(int prec, int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st) {
     PROF(EPI_EM_STEP);
     typedef EpiEmStep<__bf16> A; typedef EpiEmStep<float> B; DISPATCH(A, B, M_FINAL | M_FINAL_S);
+}
+hipError_t gemm_dsm_step(int prec, int shape, const GemmArgs& g, const DsmStepParams& p, hipStream_t st) {
+    PROF(EPI_DSM_STEP);
+    typedef EpiDsm<__bf16> A; typedef EpiDsm<float> B; DISPATCH(A, B, M_FINAL | M_FINAL_S);
 }
 hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTParams& p, hipStream_t st) {
     PROF(EPI_PLAIN_FT);

@@ -296,6 +296,8 @@ struct ScoreTuning {
     int wgrad_layer_lanes = -1;       // DPOSER_WGRAD_LAYER_LANES = 0 / 1: bucketed backward with split-K launches / one lane launch per layer
     int wgrad_groups = -1;            // DPOSER_WGRAD_GROUPS = n: bucketed backward with the lane launches of n layer groups (0: off)
     int adam_write_through = 1;       // DPOSER_ADAM_WT = 0: plain stores for the optimizer state in the fused optimizer + re-pack kernel (A/B)
+    int dsm_fused = 0;                // DPOSER_DSM_FUSED = 1: post_dense with the DSM loss in its epilogue (EpiDsm) instead of GEMM -> res -> k_dsm
+                                      // (opt-in: measured -0.6 % at 8192 poses, -0.2 % at 65536, +0.5 % at 1280 -- profiles/r04_dsm_fused_ab.txt)
     int sampler_persistent = 0;       // DPOSER_SAMPLER_PERSISTENT = 1: one persistent kernel for the plain EM sampler
     int64_t sampler_persistent_min = 256;
     void load() {
@@ -312,6 +314,7 @@ struct ScoreTuning {
         e = getenv("DPOSER_WGRAD_GROUPS");
         wgrad_groups = e ? atoi(e) : -1;
         adam_write_through = env_tri("DPOSER_ADAM_WT") == 0 ? 0 : 1;
+        dsm_fused = env_tri("DPOSER_DSM_FUSED") == 1 ? 1 : 0;
         e = getenv("DPOSER_SAMPLER_PERSISTENT");
         sampler_persistent = e ? atoi(e) : 0;
         e = getenv("DPOSER_SAMPLER_PERSISTENT_MIN");
@@ -400,6 +403,7 @@ static int pick_ksplit(int64_t tiles, int64_t stages, int slots = 512) {
     return ks;
 }
 
+static inline int64_t cs_post_rows(int64_t Bpad) { return Bpad / 32 > 1024 ? Bpad / 32 : 1024; }   // capacity of Ws::cs_part_post in rows
 static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_steps, char* base, Ws& w) {
     std::memset(&w, 0, sizeof(w));
     const int64_t Bpad = pad_batch(B);
@@ -455,7 +459,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
             w.dUT = take(Bpad * E * esz);
         }
         const int64_t nchunks = ceil_div(Bpad, 2048);
-        w.cs_part_post = (float*)take((nchunks > 1024 ? nchunks : 1024) * h->Cp * 4);      // rows: k_colsum chunks, or k_dsm's blocks (<= 1024)
+        w.cs_part_post = (float*)take(cs_post_rows(Bpad) * h->Cp * 4);      // rows: k_colsum chunks, k_dsm's blocks (<= 1024) or EpiDsm's wave rows (Bpad / 32)
         w.cs_part_se = (float*)take(nchunks * E * 4);
         w.silu_part = (float*)take((Bpad / 32) * (int64_t)E * 4);       // per-wave column sums of dU (time-branch dgrad epilogue)
         // slabs: worst case ksplit 32 is never reached for the big tensors; size exactly below
@@ -1052,7 +1056,7 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
 
 // forward in training layout: every layer input / normalised activation is kept for the backward pass
 static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
-                              uint32_t step, hipStream_t st) {
+                              uint32_t step, hipStream_t st, bool with_post = true) {
     const int L = h->L;
     const bool tr = wgrad_tr_mode(h, w.Bpad);   // then no wgrad reads a transposed activation
     DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, w.upre, tr ? nullptr : w.tembT, true, w.Bpad, st));
@@ -1074,6 +1078,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         p.outT = tr ? nullptr : w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
         DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, true, shape, g, p, st, h->gs));
     }
+    if (!with_post) return DPOSER_OK;      // (the fused DSM step runs post_dense itself, with the loss in its epilogue)
     return run_post(h, flat, packed, w.hbuf[L - 1], w.res, B, w.Bpad, st);
 }
 
@@ -1516,13 +1521,33 @@ static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const vo
     pa.B = B; pa.Bpad = Bpad; pa.D = h->D; pa.Dpad = h->Dpad; pa.E = h->E; pa.fourier = h->d.embedding == DPOSER_EMB_FOURIER; pa.f32 = h->f32; pa.sde = sc; pa.eps = eps;
     pa.seed = seed; pa.step = step;
     DP_HIP_LAUNCH(launch_prep_train(pa, st));
-    DP_TRY(forward_core_train(h, flat, packed, w, B, true, seed, step, st));
+    // post_dense + loss + d loss / d res: one launch (EpiDsm) while its partials fit the step's buffers, else GEMM -> res -> k_dsm
+    const int pshape = final_shape(Bpad);
+    const int64_t prow = (Bpad / (shape_st(pshape) * 32)) * shape_ws(pshape);                 // wave rows = column-sum partial rows
+    const int chan_waves = pshape == SHAPE_FINAL ? 1 : 2;                                    // waves side by side over the 64 channels
+    const bool fused_post = score_tuning().dsm_fused && h->Cp == 64 && prow * chan_waves <= 8192 && prow <= cs_post_rows(Bpad);
+    DP_TRY(forward_core_train(h, flat, packed, w, B, true, seed, step, st, !fused_post));
+    int nb = 0;
+    if (fused_post) {
+        g_next_flops = 2.0 * (double)B * h->D * h->H;
+        GemmArgs g = gemm_args(packed + h->pk_wpost, h->H / h->KBS, h->Cp / (shape_ct(pshape) * 32), (int)(Bpad / (shape_st(pshape) * 32)));
+        add_seg(g, w.hbuf[h->L - 1], h->H / h->KBS);
+        DsmStepParams p;
+        std::memset(&p, 0, sizeof(p));
+        p.bias = flat + h->off_post_b; p.t = w.tbuf; p.z = w.zbuf; p.sigmas = sigmas; p.dres = w.dres; p.loss_part = w.loss_part;
+        p.cs_part = w.cs_part_post; p.sde = make_sde_dev(sc); p.grad_scale = (float)(1.0 / ((double)B * (double)h->D));
+        p.num_scales = h->d.num_scales; p.scale_by_sigma = h->d.scale_by_sigma; p.fourier = h->d.embedding == DPOSER_EMB_FOURIER;
+        p.D = h->D; p.Dpad = h->Dpad; p.Cp = h->Cp; p.S_valid = B;
+        DP_HIP_LAUNCH(gemm_dsm_step(h->f32 ? PREC_FP32 : PREC_BF16, pshape, g, p, st));
+        nb = (int)(prow * chan_waves);
+        const SumJob loss_sum{w.loss_part, nb, loss};
+        return backward_core(h, flat, packed, w, B, true, seed, step, flat_grad, nullptr, sink, st, &loss_sum, (int)prow);
+    }
     DsmArgs da;
     da.res = w.res; da.t = w.tbuf; da.z = w.zbuf; da.sigmas = sigmas; da.dres = w.dres; da.loss_part = w.loss_part; da.B = B; da.Bpad = Bpad;
     da.cs_part = w.cs_part_post;
     da.D = h->D; da.Dpad = h->Dpad; da.Cp = h->Cp; da.num_scales = h->d.num_scales; da.scale_by_sigma = h->d.scale_by_sigma;
     da.f32 = h->f32; da.fourier = h->d.embedding == DPOSER_EMB_FOURIER; da.grad_scale = (float)(1.0 / ((double)B * (double)h->D)); da.sde = sc;
-    int nb = 0;
     DP_HIP_LAUNCH(launch_dsm(da, &nb, st));
     const SumJob loss_sum{w.loss_part, nb, loss};                      // summed by one block of the LAST reduction launch of the backward
     return backward_core(h, flat, packed, w, B, true, seed, step, flat_grad, nullptr, sink, st, &loss_sum, nb);

@@ -668,6 +668,8 @@ def test_integration_md_ctypes_stub_runs():
     {"DPOSER_WGRAD_TR": "0"},                                                                # bf16 wgrads on transposed copies
     {"DPOSER_WGRAD_STREAM": "1", "DPOSER_WGRAD_BATCHED": "0"},                                                  # wgrads on the second stream (default 8192..16384)
     {"DPOSER_WGRAD_BATCHED": "1"},                                                           # all 256x256 wgrad tiles in one launch (the single-GPU default)
+    {"DPOSER_DSM_FUSED": "1"},                                                               # post_dense with the loss in its epilogue (opt-in) instead of GEMM -> res -> k_dsm
+    {"DPOSER_DSM_FUSED": "1", "DPOSER_FINAL_SMALL_MAX": "0"},                                # ... and that launch on the 64 x 128 tiling at small batches too
 ])
 def test_alternative_tilings_and_streams_keep_parity(env):
     """The tiling / stream policy depends on the batch size (256x256 GroupNorm-backward and wgrad tiles from 32768 samples,
@@ -685,6 +687,31 @@ def test_alternative_tilings_and_streams_keep_parity(env):
                        cwd=root, env=child_env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("B,prec", [(700, "fp32"), (8192, "bf16"), (20000, "bf16"), (640, "bf16")])
+def test_loss_in_the_post_dense_epilogue_matches_the_two_launch_form(B, prec, tuning_env):
+    """post_dense + DSM loss + d loss / d res as ONE launch (EpiDsm, opt-in: DPOSER_DSM_FUSED=1 -- measured without gain,
+    profiles/r04_dsm_fused_ab.txt) against GEMM -> res -> k_dsm: the same per-element operations, so
+    d res -- and with it every weight gradient -- is bit-identical; the loss and post_dense's bias gradient are the same sums in
+    another order (per wave tile instead of per block)."""
+    cfg, m, p = make_model(12, precision=prec, dropout=0.1)
+    m.train()
+    rs = np.random.RandomState(4)
+    batch = _dev(rs.standard_normal((B, 63)).astype(np.float32))
+    out = {}
+    for flag in ("1", "0"):
+        tuning_env(DPOSER_DSM_FUSED=flag)
+        out[flag] = _fused_grad(m, batch, None, None, step=3)
+    (l1, g1), (l0, g0) = out["1"], out["0"]
+    assert abs(l1 - l0) / abs(l0) < 1e-6
+    names = [n for n, _ in m.named_parameters()]
+    ib = names.index("post_dense.bias")
+    ob, nbias = m._offsets[ib], 63
+    mask = torch.ones_like(g1, dtype=torch.bool)
+    mask[ob:ob + nbias] = False
+    assert torch.equal(g1[mask], g0[mask])
+    assert rel_err(t2n(g1[ob:ob + nbias]), t2n(g0[ob:ob + nbias])) < 1e-5
 
 
 @pytest.mark.parametrize("B", [8192, 5000, 32768])
