@@ -712,6 +712,76 @@ hipError_t launch_dsm(const DsmArgs& a, int* nblocks, hipStream_t st) {
     return hipGetLastError();
 }
 
+// The time-branch dgrad at small batches (a few dozen 128 x 128 tiles with K = L * H): the GEMM runs as one k-split per layer segment
+// (EpiPartialFT), this kernel adds the splits in order, applies act'(u) and keeps the column sums of the stored dU (the shared
+// embedding's bias gradient), like the one-launch epilogue (EpiSiLUBwd) does.  A thread keeps ONE channel quad for all of its samples.
+template <typename T> __global__ void __launch_bounds__(256) k_silu_bwd_reduce(SiLUBwdReduceArgs a) {
+    __shared__ float cs[256][4];
+    constexpr bool PRECISE = sizeof(T) == 4;
+    constexpr int MAXS = 8, SPT = 4;                  // splits held in registers / samples per thread and pass (all loads of a pass in flight)
+    const int qc = a.N >> 2;                          // quads per sample row (N <= 1024: qc <= 256)
+    const int lanes = 256 / qc;
+    const int q = threadIdx.x % qc, sl = threadIdx.x / qc;
+    const int c = q * 4;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    if (sl < lanes) {
+        const int64_t step = (int64_t)gridDim.x * lanes;
+        for (int64_t s0 = (int64_t)blockIdx.x * lanes + sl; s0 < a.Spad; s0 += step * SPT) {
+            f32x4 part[SPT][MAXS], u[SPT];
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) {
+                const int64_t s = s0 + i * step;
+                const bool live = s < a.B;
+                const int64_t idx = live ? FT<float>::index(s, c, a.N) : 0;
+#pragma unroll
+                for (int k = 0; k < MAXS; ++k)
+                    part[i][k] = (live && k < a.nsplit) ? Quad<float>::load(a.part + (int64_t)k * a.split_stride + idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+                u[i] = live ? Quad<T>::load(reinterpret_cast<const T*>(a.pre) + FT<T>::index(s, c, a.N)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < SPT; ++i) {
+                const int64_t s = s0 + i * step;
+                if (s >= a.Spad) break;
+                f32x4 acc = part[i][0];
+#pragma unroll
+                for (int k = 1; k < MAXS; ++k)                // in split (= layer) order; absent splits add +0
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] += part[i][k][r];
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (s < a.B) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = acc[r] * (a.act == DP_ACT_SWISH ? dsilu_f<PRECISE>(u[i][r]) : dact_rt<PRECISE>(u[i][r], a.act));
+                }
+                store_quad_ft<T>(a.out, s, c, a.N, o);
+                const f32x4 st4 = Quad<T>::round_trip(o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) csum[r] += st4[r];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[threadIdx.x][r] = csum[r];
+    __syncthreads();
+    if (threadIdx.x < qc) {
+        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < lanes; ++l)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t4[r] += cs[l * qc + threadIdx.x][r];
+        *reinterpret_cast<f32x4*>(a.cs_part + (int64_t)blockIdx.x * a.N + c) = t4;
+    }
+}
+hipError_t launch_silu_bwd_reduce(const SiLUBwdReduceArgs& a, int max_blocks, int* nblocks, hipStream_t st) {
+    if (a.N % 4 != 0 || a.N > 1024) return hipErrorInvalidValue;
+    if (a.nsplit < 1 || a.nsplit > 8) return hipErrorInvalidValue;
+    const int lanes = 256 / (a.N >> 2);
+    int64_t g = (a.Spad + lanes * 4 - 1) / (lanes * 4);      // four samples per thread: a quarter of the rows for the final reduction
+    g = g < 1 ? 1 : (g > max_blocks ? max_blocks : g);
+    *nblocks = (int)g;
+    if (a.f32) hipLaunchKernelGGL(k_silu_bwd_reduce<float>, dim3((unsigned)g), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_silu_bwd_reduce<__bf16>, dim3((unsigned)g), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 template <typename T> __global__ void __launch_bounds__(256) k_dres_from_dout(DresArgs a) {
     const int qc = a.Cp >> 2;
     const int64_t total = a.Bpad * qc;

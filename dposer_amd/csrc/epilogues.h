@@ -527,6 +527,30 @@ template <typename T> struct EpiPlainFT {
     }
 };
 
+// out[split] FT fp32 = acc: the partial sums of one k-split, whatever the operand type (the time-branch dgrad at small batches: one split
+// per layer segment, summed and finished by k_silu_bwd_reduce).
+struct PartialFTParams {
+    float* out;            // [ksplit][Spad][N] fp32 FT
+    int N;
+    int64_t split_stride;  // elements between the splits' outputs
+};
+template <typename T> struct EpiPartialFT {
+    typedef PartialFTParams Params;
+    template <int TC, int TS>
+    __device__ static inline void apply(const Params& pp, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int split, const float*, int, unsigned char*) {
+        float* base = pp.out + (int64_t)split * pp.split_stride;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                float o[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = acc[tc][ts][r];
+                TileIO<float>::store(base + ft_tile_base<float>(sbase + ts * 32, cbase + tc * 32, pp.N), lane, o);
+            }
+    }
+};
+
 // ----------------------------------------------------------------------------------------------
 // backward helpers
 // ----------------------------------------------------------------------------------------------

@@ -39,6 +39,8 @@ struct GemmArgs {
     double alg_flops;               // algorithmic FLOPs of this launch (2*M*N*K on the un-padded problem); profiling only
     int panel_order;                // 1: split-K launches whose W panel is the big stream (LBS blend gradient: W = d_offsets, a few sample
                                     //    tiles per channel tile) -- the tiles of one (channel tile, split) run side by side on ONE XCD
+    int split_segments;             // 1 (with ksplit == nseg, equal segments): split i reduces over SEGMENT i instead of a slice of segment 0
+                                    //    (the time-branch dgrad at small batches: one split per layer's dy)
 };
 
 #include "gemm_kloop_asm.h"
@@ -189,14 +191,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
     int seg_stride = seg_stride_of(0);         // k-blocks per row-block of the current segment's array
     int seg_end = seg_total;                   // first k-block NOT to fetch from this segment
     int nstages = g.ktot_blocks / KB;
-    if (g.ksplit > 1) {
+    const unsigned char* sbase = seg_ptr(0);
+    if (g.ksplit > 1 && g.split_segments) {
+        seg = split;
+        sbase = seg_ptr(seg);
+        seg_stride = seg_stride_of(seg);
+        nstages = seg_total / KB;               // (equal segments)
+        w_kb = split * seg_total;
+    } else if (g.ksplit > 1) {
         const int per = seg_total / g.ksplit;
         nstages = per / KB;
         seg_kb = split * per;
         w_kb = seg_kb;
         seg_end = seg_kb + per;
     }
-    const unsigned char* sbase = seg_ptr(0);
 
     auto fetch_w = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll

@@ -24,6 +24,7 @@ hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNP
 hipError_t gemm_bias_silu(int prec, bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st);
 hipError_t gemm_rowmajor(int prec, int shape, const GemmArgs& g, const RowMajorParams& p, hipStream_t st);
 hipError_t gemm_em_step(int prec, int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st);
+hipError_t gemm_partial_ft(int prec, int shape, const GemmArgs& g, const PartialFTParams& p, hipStream_t st);   // SHAPE_MID, g.ksplit splits of segment 0
 hipError_t gemm_dsm_step(int prec, int shape, const GemmArgs& g, const DsmStepParams& p, hipStream_t st);   // SHAPE_FINAL / SHAPE_FINAL_S
 hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTParams& p, hipStream_t st);
 hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st, int gs = 32);

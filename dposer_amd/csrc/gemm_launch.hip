@@ -139,6 +139,10 @@ hipError_t gemm_em_step(int prec, int shape, const GemmArgs& g, const EmStepPara
     PROF(EPI_EM_STEP);
     typedef EpiEmStep<__bf16> A; typedef EpiEmStep<float> B; DISPATCH(A, B, M_FINAL | M_FINAL_S);
 }
+hipError_t gemm_partial_ft(int prec, int shape, const GemmArgs& g, const PartialFTParams& p, hipStream_t st) {
+    PROF(EPI_PLAIN_FT);
+    typedef EpiPartialFT<__bf16> A; typedef EpiPartialFT<float> B; DISPATCH(A, B, M_MID);
+}
 hipError_t gemm_dsm_step(int prec, int shape, const GemmArgs& g, const DsmStepParams& p, hipStream_t st) {
     PROF(EPI_DSM_STEP);
     typedef EpiDsm<__bf16> A; typedef EpiDsm<float> B; DISPATCH(A, B, M_FINAL | M_FINAL_S);

@@ -192,6 +192,18 @@ struct DsmArgs {           // get_sde_loss_fn tail (losses.py:121-131) + d loss 
 };
 hipError_t launch_dsm(const DsmArgs& a, int* nblocks, hipStream_t st);
 
+struct SiLUBwdReduceArgs {  // dU = (sum over the k-splits of the time-branch dgrad) * act'(u); column sums of the stored dU per block
+    const float* part;     // [nsplit][Spad][N] fp32 FT (EpiPartialFT)
+    int nsplit;
+    int64_t split_stride;
+    const void* pre;       // u, FT [Spad][N]
+    void* out;             // dU, FT [Spad][N]
+    float* cs_part;        // [blocks][N]
+    int N, act, f32;
+    int64_t B, Spad;
+};
+hipError_t launch_silu_bwd_reduce(const SiLUBwdReduceArgs& a, int max_blocks, int* nblocks, hipStream_t st);
+
 struct DresArgs {          // d res = d out / used_sigmas  (backward of model.py:192-194), FT store
     const float* dout;     // [B][D]
     const float* labels;   // [B]

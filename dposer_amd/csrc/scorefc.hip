@@ -296,6 +296,7 @@ struct ScoreTuning {
     int wgrad_layer_lanes = -1;       // DPOSER_WGRAD_LAYER_LANES = 0 / 1: bucketed backward with split-K launches / one lane launch per layer
     int wgrad_groups = -1;            // DPOSER_WGRAD_GROUPS = n: bucketed backward with the lane launches of n layer groups (0: off)
     int adam_write_through = 1;       // DPOSER_ADAM_WT = 0: plain stores for the optimizer state in the fused optimizer + re-pack kernel (A/B)
+    int64_t silu_split_max = 2048;    // DPOSER_SILU_SPLIT_MAX = <samples>: up to this padded batch the time-branch dgrad runs one k-split per layer + a reduce pass (0: never)
     int dsm_fused = 0;                // DPOSER_DSM_FUSED = 1: post_dense with the DSM loss in its epilogue (EpiDsm) instead of GEMM -> res -> k_dsm
                                       // (opt-in: measured -0.6 % at 8192 poses, -0.2 % at 65536, +0.5 % at 1280 -- profiles/r04_dsm_fused_ab.txt)
     int sampler_persistent = 0;       // DPOSER_SAMPLER_PERSISTENT = 1: one persistent kernel for the plain EM sampler
@@ -315,6 +316,8 @@ struct ScoreTuning {
         wgrad_groups = e ? atoi(e) : -1;
         adam_write_through = env_tri("DPOSER_ADAM_WT") == 0 ? 0 : 1;
         dsm_fused = env_tri("DPOSER_DSM_FUSED") == 1 ? 1 : 0;
+        e = getenv("DPOSER_SILU_SPLIT_MAX");
+        silu_split_max = e ? atoll(e) : (int64_t)2048;
         e = getenv("DPOSER_SAMPLER_PERSISTENT");
         sampler_persistent = e ? atoi(e) : 0;
         e = getenv("DPOSER_SAMPLER_PERSISTENT_MIN");
@@ -367,7 +370,7 @@ struct Ws {
     uint32_t* smp_sync;            // cluster sampler: control words + one progress counter per block of 256 samples
     // transposed copies / partials / slabs (training)
     char *dyT[MAX_L], *hT[MAX_L], *tembT, *embT, *xinT, *dresT, *dUT;
-    float *gn_part[MAX_L], *cs_part_post, *cs_part_se, *silu_part, *slabs;
+    float *gn_part[MAX_L], *cs_part_post, *cs_part_se, *silu_part, *slabs, *dU_part;
     int64_t total;
     int64_t slab_elems;   // capacity of `slabs` in floats
 };
@@ -403,6 +406,8 @@ static int pick_ksplit(int64_t tiles, int64_t stages, int slots = 512) {
     return ks;
 }
 
+constexpr int64_t SILU_SPLIT_CAP = 8192;     // largest padded batch the k-split partial buffer of the time-branch dgrad is laid out for
+static inline int64_t silu_part_rows(int64_t Bpad) { return Bpad <= SILU_SPLIT_CAP ? Bpad / 2 : Bpad / 32; }   // (the reduce pass: one block per two samples)
 static inline int64_t cs_post_rows(int64_t Bpad) { return Bpad / 32 > 1024 ? Bpad / 32 : 1024; }   // capacity of Ws::cs_part_post in rows
 static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_steps, char* base, Ws& w) {
     std::memset(&w, 0, sizeof(w));
@@ -446,6 +451,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         w.carry[0] = take(Bpad * H * esz);
         w.carry[1] = take(Bpad * H * esz);
         w.dU = take(Bpad * E * esz);
+        w.dU_part = Bpad <= SILU_SPLIT_CAP ? (float*)take((int64_t)L * Bpad * E * 4) : nullptr;      // k-split partials of the time-branch dgrad (small batches)
         w.dres = take(Bpad * h->Cp * esz);
         w.tbuf = (float*)take(Bpad * 4);
         w.zbuf = (float*)take(Bpad * h->Dpad * 4);
@@ -461,7 +467,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         const int64_t nchunks = ceil_div(Bpad, 2048);
         w.cs_part_post = (float*)take(cs_post_rows(Bpad) * h->Cp * 4);      // rows: k_colsum chunks, k_dsm's blocks (<= 1024) or EpiDsm's wave rows (Bpad / 32)
         w.cs_part_se = (float*)take(nchunks * E * 4);
-        w.silu_part = (float*)take((Bpad / 32) * (int64_t)E * 4);       // per-wave column sums of dU (time-branch dgrad epilogue)
+        w.silu_part = (float*)take(silu_part_rows(Bpad) * (int64_t)E * 4);       // per-wave column sums of dU (time-branch dgrad epilogue), or k_silu_bwd_reduce's per-block sums
         // slabs: worst case ksplit 32 is never reached for the big tensors; size exactly below
         const int64_t stages = Bpad / (h->KBS * 4);
         int64_t slab_elems = 0;
@@ -1454,11 +1460,28 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         g_next_flops = 2.0 * (double)B * E * L * H;
         GemmArgs g = gemm_args(packed + h->pk_wtT_all, L * H / KBS, E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
         for (int l = 0; l < L; ++l) add_seg(g, w.dy[l], H / KBS);
+        // Small batches: 40 tiles at 1280 samples, each walking K = L * H alone (36 us).  One k-split per layer segment fills the chip
+        // (12 us for the plain GEMM at 1280 samples, tools/tune_gemm.hip TUNE_SPLITK); k_silu_bwd_reduce adds the splits in layer order,
+        // applies act'(u) and keeps the column sums.  From ~4096 samples up the one launch is as fast: DPOSER_SILU_SPLIT_MAX.
+        if (tr && shape == SHAPE_MID && w.dU_part && Bpad <= score_tuning().silu_split_max && Bpad <= SILU_SPLIT_CAP && L <= GEMM_MAX_SEG && L <= 8) {
+            g.ksplit = L;
+            g.split_segments = 1;
+            PartialFTParams pp;
+            pp.out = w.dU_part; pp.N = E; pp.split_stride = Bpad * (int64_t)E;
+            DP_HIP_LAUNCH(gemm_partial_ft(prec, shape, g, pp, st));
+            SiLUBwdReduceArgs ra;
+            ra.part = w.dU_part; ra.nsplit = L; ra.split_stride = Bpad * (int64_t)E; ra.pre = w.upre; ra.out = w.dU; ra.cs_part = w.silu_part;
+            ra.N = E; ra.act = h->d.activation; ra.f32 = h->f32; ra.B = B; ra.Spad = Bpad;
+            int nb = 0;
+            DP_HIP_LAUNCH(launch_silu_bwd_reduce(ra, (int)silu_part_rows(Bpad), &nb, st));
+            silu_rows = nb;
+        } else {
         SiLUBwdParams p;
         p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B; p.outT = tr ? nullptr : w.dUT; p.Spad = Bpad; p.act = h->d.activation;
         p.part = w.silu_part;                                            // the shared embedding's bias gradient: no column-sum launch over dU
         silu_rows = (int)(Bpad / (shape_st(shape) * 32)) * shape_ws(shape);
         DP_HIP_LAUNCH(gemm_silu_bwd(prec, shape, g, p, st));
+        }
     }
     if (two) {
         DP_CHECK_HIP(hipEventRecord(h->ev_time, st));

@@ -689,6 +689,31 @@ def test_alternative_tilings_and_streams_keep_parity(env):
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+@pytest.mark.parametrize("B,prec", [(1280, "bf16"), (300, "bf16"), (2048, "bf16"), (1280, "fp32")])      # (300: the 128 x 32 tiling keeps the one launch)
+def test_layer_split_time_branch_dgrad_matches_the_one_launch_form(B, prec, tuning_env):
+    """Up to 2048 samples the time-branch dgrad (dU = sum_l dy_l Wt_l, times act'(u)) runs one k-split per layer segment plus a
+    reduce pass (k_silu_bwd_reduce) instead of one launch whose few tiles walk K = 5 x 1024 alone: the same products, the five
+    layers' sums added at the end instead of inside one accumulator -- every gradient agrees to fp32 summation error, the ones
+    that do not depend on dU bit for bit."""
+    cfg, m, p = make_model(14, precision=prec, dropout=0.1)
+    m.train()
+    rs = np.random.RandomState(6)
+    batch = _dev(rs.standard_normal((B, 63)).astype(np.float32))
+    out = {}
+    for cap in ("2048", "0"):
+        tuning_env(DPOSER_SILU_SPLIT_MAX=cap)
+        out[cap] = _fused_grad(m, batch, None, None, step=5)
+    (l1, g1), (l0, g0) = out["2048"], out["0"]
+    assert l1 == l0
+    names = [n for n, _ in m.named_parameters()]
+    for name, off, prm in zip(names, m._offsets, m.parameters()):
+        a, b = g1[off:off + prm.numel()], g0[off:off + prm.numel()]
+        if name.startswith("shared_time_embed"):
+            assert rel_err(t2n(a), t2n(b)) < (2e-6 if prec == "fp32" else 2e-3), name     # bf16: dU is rounded to bf16 after the sum
+        else:
+            assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("B,prec", [(700, "fp32"), (8192, "bf16"), (20000, "bf16"), (640, "bf16")])
 def test_loss_in_the_post_dense_epilogue_matches_the_two_launch_form(B, prec, tuning_env):
     """post_dense + DSM loss + d loss / d res as ONE launch (EpiDsm, opt-in: DPOSER_DSM_FUSED=1 -- measured without gain,
@@ -765,8 +790,9 @@ def test_sample_major_wgrad_is_bit_identical_to_transposed_copy_path(B, extra, D
     outs = []
     for tr in ("1", "0"):
         out = str(tmp_path / f"fg_tr{tr}.npy")
-        # (per-layer launches on both sides: the one-launch form of wgrad_batch.h partitions the sample sum differently)
-        env = dict(os.environ, DPOSER_WGRAD_TR=tr, DPOSER_WGRAD_BATCHED="0", **extra)
+        # (per-layer launches on both sides: the one-launch form of wgrad_batch.h partitions the sample sum differently; the one-launch
+        #  time-branch dgrad on both sides: its layer-split form -- sample-major mode only -- adds the layers' sums in another order)
+        env = dict(os.environ, DPOSER_WGRAD_TR=tr, DPOSER_WGRAD_BATCHED="0", DPOSER_SILU_SPLIT_MAX="0", **extra)
         r = subprocess.run([sys.executable, "-c", code, out], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(np.load(out))

@@ -31,6 +31,7 @@ int dposer_set_error(int code, const std::string&) { return code; }
 struct Case { std::string name; std::function<void()> launch; double flops; std::vector<double> us; };
 static std::vector<Case> g_cases;
 static float g_drop_p = 0.f;
+static int g_ksplit = 1;                // TUNE_SPLITK: the plain cases split their reduction over blockIdx.y (every split writes the same tile: timing only)
 static const void* g_resid = nullptr;   // TUNE_RESID cases: residual input of the GroupNorm forward epilogue   // TUNE_DROP=0.1: the gn-train cases draw dropout masks
 
 template <int WC, int WS, int TC, int TS, int KB, int GLDS>
@@ -39,7 +40,7 @@ void add_plain(const char* name, int64_t S, int C, int K, void* W, void* X, void
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.W = W; g.w_stride_blocks = K / 16; g.src[0] = X; g.seg_kblocks[0] = K / 16; g.nseg = 1; g.ktot_blocks = K / 16;
-    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = 1;
+    g.n_cblk = C / (Cfg::CT * 32); g.n_sblk = (int)(S / (Cfg::ST * 32)); g.ksplit = g_ksplit;
    
     PlainFTParams p;
     p.out = out; p.N = C;
@@ -222,6 +223,18 @@ int main(int argc, char** argv) {
         PL(4, 1, 1, 1, 4, 2);
         PL(4, 1, 1, 1, 4, 4);
         run_all(9, 50);
+        return 0;
+    }
+    if (getenv("TUNE_SPLITK")) {     // round 4: the time-branch dgrad at small batches is 40 ... 256 tiles with K = 5120 (run with TUNE_C=512 TUNE_K=5120 and
+                                     // S = 1280 / 4096 / 8192): what would splitting the reduction over the five layers' segments buy?  (timing probe: the
+                                     // splits overwrite one another's tile)
+        for (int ks : {1, 2, 5, 10}) {
+            g_ksplit = ks;
+            PL(2, 2, 2, 2, 2, 4);
+            g_cases.back().name += " ksplit " + std::to_string(ks);
+        }
+        g_ksplit = 1;
+        run_all(9, 20);
         return 0;
     }
     if (getenv("TUNE_TALL")) {       // round 4: one-round batches (S = 8192 / 16384) are L2-bound on the 128x128 tiling (64 FLOP per byte staged): do 256x128 /
