@@ -406,7 +406,7 @@ static int pick_ksplit(int64_t tiles, int64_t stages, int slots = 512) {
     return ks;
 }
 
-constexpr int64_t SILU_SPLIT_CAP = 8192;     // largest padded batch the k-split partial buffer of the time-branch dgrad is laid out for
+constexpr int64_t SILU_SPLIT_CAP = 4096;     // largest padded batch the k-split partial buffer of the time-branch dgrad is laid out for
 static inline int64_t silu_part_rows(int64_t Bpad) { return Bpad <= SILU_SPLIT_CAP ? Bpad / 2 : Bpad / 32; }   // (the reduce pass: one block per two samples)
 static inline int64_t cs_post_rows(int64_t Bpad) { return Bpad / 32 > 1024 ? Bpad / 32 : 1024; }   // capacity of Ws::cs_part_post in rows
 static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_steps, char* base, Ws& w) {
