@@ -197,7 +197,8 @@ class FusedAdam(optim.Adam):
         """ZeRO-1 style update (SURVEY 8e): ``self._flat_g`` holds this rank's reduce-scattered gradient range ``bounds[rank]``;
         the global squared norm for the clip is one all-reduced float; Adam / EMA touch only the owned range (1/G of the
         work and of the moment traffic); the caller all-gathers the parameters afterwards.  Moments outside the owned range are
-        stale on this rank until ``gather_state()`` (called by ``state_dict()``) all-gathers them for a checkpoint."""
+        stale on this rank until ``gather_state()`` all-gathers them (call it on EVERY rank before ``state_dict()``, which refuses
+        sharded moments)."""
         from ... import distributed as ddp
         flat, offs, params = self._ensure_flat()
         lo, hi = bounds[rank]
@@ -398,13 +399,20 @@ def fused_dsm_grad(model, sde, batch, *, flat_grad, t=None, z=None, eps=1e-5, se
     desc = sde_desc(sde)
     x = batch.contiguous().float()
     if on_final is not None:
+        cb_error = []
+
         def _cb(user, first_bucket, n_ranges, lo, hi, event):
-            on_final([(lo[i], hi[i]) for i in range(n_ranges)], event)
+            try:                                      # (an exception must not unwind through the C call: ctypes would swallow it)
+                on_final([(lo[i], hi[i]) for i in range(n_ranges)], event)
+            except BaseException as e:                # noqa: BLE001 -- re-raised below, after the call
+                cb_error.append(e)
         cb = _C.RANGES_FINAL_FN(_cb)                  # (kept alive until the call has returned)
         _C.check(eng.lib.dposer_dsm_loss_fwd_bwd_notify(
             eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(t), _C.ptr(z), float(eps), int(seed),
             int(step) & 0xFFFFFFFF, _C.ptr(eng.freq(batch.device, model._fourier_W())), _C.ptr(model.sigmas), _C.ptr(flat_grad), _C.ptr(loss), B,
             bucket_events, len(bucket_events), cb, None, _C.stream_ptr()), "dposer_dsm_loss_fwd_bwd_notify")
+        if cb_error:
+            raise cb_error[0]
         return loss[0]
     _C.check(eng.lib.dposer_dsm_loss_fwd_bwd_bucketed(
         eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(t), _C.ptr(z), float(eps), int(seed),
@@ -468,11 +476,13 @@ def _dp_draws(sde, batch, eps=1e-5):
     keys its Philox streams the same way)."""
     from ... import distributed as ddp
     key = (batch.device.type, batch.device.index, ddp.rank())
-    gen = _RANK_GENERATORS.get(key)
-    if gen is None:
+    seed0 = torch.initial_seed()
+    ent = _RANK_GENERATORS.get(key)
+    if ent is None or ent[0] != seed0:                # a later torch.manual_seed() (new experiment, resume, tests) re-keys the stream
         gen = torch.Generator(device=batch.device)
-        gen.manual_seed((torch.initial_seed() + 0x9E3779B1 * (ddp.rank() + 1)) & 0x7FFFFFFFFFFFFFFF)
-        _RANK_GENERATORS[key] = gen
+        gen.manual_seed((seed0 + 0x9E3779B1 * (ddp.rank() + 1)) & 0x7FFFFFFFFFFFFFFF)
+        ent = _RANK_GENERATORS[key] = (seed0, gen)
+    gen = ent[1]
     t = torch.rand(batch.shape[0], device=batch.device, generator=gen) * (sde.T - eps) + eps
     z = torch.randn(batch.shape, device=batch.device, dtype=batch.dtype, generator=gen)
     return t, z
@@ -621,7 +631,7 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
                                                                                        "dposer_stream_wait_event"))
                     loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"],
                                           bucket_events=events, on_final=red.on_final)
-                    world = red.finish()
+                    world = red.finish(expect=eng.grad_buckets)
                 else:                                                               # (A/B: all waits + collectives after the call)
                     loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"],
                                           bucket_events=events)

@@ -258,6 +258,11 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     const int64_t n = T * D;
     const bool rot6d = a->rot6d != 0;                       // the network lives in the 6-D representation: 2 D coordinates per frame
     const int64_t n_net = rot6d ? 2 * n : n;
+    {   // the network's input width (pre_dense.weight is [H, D_net], its bias [H]) must be the representation's: the noise and the prior
+        // gradient are indexed with it
+        const int64_t wn = dposer_scorefc_tensor_numel(a->net, 0), bn = dposer_scorefc_tensor_numel(a->net, 1);
+        DP_CHECK_ARG(wn > 0 && bn > 0 && wn / bn == (rot6d ? 2 * D : D), "the score network's input width is not the pose representation's (3 J axis-angle, 6 J with rot6d)");
+    }
 
     const float* segs[8];
     float* dsegs[8];

@@ -168,11 +168,17 @@ class StreamedAllReduce:
         except BaseException as e:            # noqa: BLE001 -- re-raised by finish()
             self.error = e
 
-    def finish(self) -> int:
+    def finish(self, expect=None) -> int:
+        """``expect``: the bucket ranges the producer must have announced (every one covered by an announced range), checked after
+        the wait -- a bucket that was never announced was never reduced."""
+        for w in self.works:                  # first: whatever was enqueued is joined, also on the error path -- the caller must
+            w.wait()                          # not see ``flat`` while a collective still writes it (NCCL: the current stream waits; gloo: host wait)
         if self.error is not None:
             raise self.error
-        for w in self.works:
-            w.wait()                          # NCCL: the current stream waits for the collective; gloo: host wait
+        if expect is not None:
+            for lo, hi in expect:
+                if hi > lo and not any(a <= lo and hi <= b for a, b in self.ranges):
+                    raise RuntimeError(f"gradient bucket [{lo}, {hi}) was never announced as final: not all-reduced")
         return dist.get_world_size()
 
 
@@ -221,6 +227,7 @@ def all_gather_flat_(flat: torch.Tensor, bounds):
     """Every rank publishes its range ``bounds[rank]`` of ``flat``; afterwards all ranks hold all ranges."""
     if not dp_active():
         return
+    _bump_param_epoch()
     rk = dist.get_rank()
     per, padded = _equal_shards(flat, bounds)
     if dist.get_backend() == "nccl" and per:
@@ -243,7 +250,15 @@ def broadcast_(flat: torch.Tensor, src=0):
     """Make every rank start from rank ``src``'s parameters."""
     if dp_active():
         dist.broadcast(flat, src=src)
+        _bump_param_epoch()
     return flat
+
+
+def _bump_param_epoch():
+    """A collective rewrote a flat parameter buffer: c10d bumps no version counter, so the packed-weight freshness key
+    (engine.param_state_key) would not notice -- bump the package's parameter epoch instead."""
+    from . import _C
+    _C.bump_param_epoch()
 
 
 def shard_bounds(total: int, num_replicas: int, rank_: int):

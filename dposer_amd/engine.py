@@ -158,8 +158,10 @@ class ScoreEngine:
 
 def param_state_key(flat: torch.Tensor, params):
     """What the packed weights were derived from: the flat buffer, the library's parameter epoch (bumped by every routine of this
-    package that writes ``.data``) and the version counters of the parameters (bumped by every in-place torch operation on them)."""
-    v = 0
+    package that writes ``.data``) the version counters of the parameters (bumped by every in-place torch operation on them) and the flat buffer's own
+    counter (the parameters are ``.data`` views of it with counters of their own: ``flat.copy_()`` bumps only this one).  Collectives
+    that write the buffer without any counter (RCCL broadcast / all-gather) bump the epoch: distributed.broadcast_ / all_gather_flat_."""
+    v = flat._version          # writes THROUGH the flat buffer (flat.copy_(...), c10d collectives' in-place ops) never reach the views' counters
     for p in params:
         v += p._version
     return (flat.data_ptr(), _C.PARAM_EPOCH[0], v)

@@ -140,6 +140,9 @@ class MotionDenoise:
         if mode:
             na, nb = na.reshape(-1).contiguous().float(), nb.reshape(-1).contiguous().float()
         nzs = None if noise is None else noise.detach().contiguous().float()
+        if nzs is not None and tuple(nzs.shape) != (n_steps, T, eng.D):
+            # the C loop indexes the noise as noise + k * T * D_net: [steps, T, 6 J] with rot_rep = 'rot6d', [steps, T, 3 J] otherwise
+            raise _C.DPoserHipError(f"noise must be [n_steps, frames, network inputs] = {(n_steps, T, eng.D)}, got {tuple(nzs.shape)}")
         fl = lambda xs: (C.c_float * n_steps)(*[float(x) for x in xs])
         step0 = self._calls + 1
         self._calls += n_steps

@@ -1424,6 +1424,46 @@ def test_optimizer_step_that_repacks_the_weights_keeps_every_bit(n_blocks, n_pos
     assert b[6] == [1, 1, 1, 1], b[6]
 
 
+def test_writes_through_the_flat_buffer_invalidate_the_optimizer_packed_weights(monkeypatch):
+    """The parameters are ``.data`` views of ONE flat buffer with version counters of their own: ``flat.copy_(snapshot)`` (and the
+    c10d collectives that rewrite the buffer) bump only the FLAT tensor's counter / nothing at all.  After the optimizer-that-repacks
+    has left its freshness key, such a write must still force a re-pack: fused step, restore a snapshot through the flat buffer, fused
+    step -- bitwise the path that always re-packs (DPOSER_ADAM_REPACK=0)."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.advanced.model import ScoreModelFC
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    from dposer_amd.configs import load_config
+    from dposer_amd import distributed as ddp
+    rs = np.random.RandomState(3)
+    xs = [_dev(rs.standard_normal((192, 63)).astype(np.float32)) for _ in range(3)]
+
+    def run(repack, via):
+        monkeypatch.setenv("DPOSER_ADAM_REPACK", "1" if repack else "0")
+        cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+        cfg.optim.warmup = 2
+        torch.manual_seed(5)
+        m = ScoreModelFC(cfg, n_poses=21, pose_dim=3, hidden_dim=1024, embed_dim=512, n_blocks=2).to(DEV)
+        sde = sde_lib.subVPSDE(0.1, 20.0, 1000)
+        state = dict(optimizer=losses.get_optimizer(cfg, m.parameters()), model=m, ema=ExponentialMovingAverage(m.parameters(), decay=0.999), step=0)
+        train = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+        snap = m.flat_params().clone()
+        out = [float(train(state, xs[0])["step_loss"]), float(train(state, xs[1])["step_loss"])]
+        if via == "copy":
+            m.flat_params().copy_(snap)                       # bumps flat._version only
+        else:
+            m.flat_params().data.copy_(snap)                  # what a collective does: no counter at all ...
+            ddp._bump_param_epoch()                           # ... distributed.broadcast_ / all_gather_flat_ bump the epoch instead
+        out.append(float(train(state, xs[2])["step_loss"]))
+        torch.cuda.synchronize()
+        return out, m.flat_params().clone()
+
+    ref = run(False, "copy")
+    for via in ("copy", "epoch"):
+        got = run(True, via)
+        assert got[0] == ref[0], (via, got[0], ref[0])
+        assert torch.equal(got[1], ref[1]), via
+
+
 def test_train_steps_with_the_reference_dropout_masks_match_the_reference_golden():
     """Closes the dropout chain directly: golden g4 holds the REFERENCE's own recorded training steps (steps 0, 1, 2, 4999, 5000 of
     get_step_fn with dropout 0.1) together with the keep masks torch's generator drew.  Those masks are fed through the fused HIP step
