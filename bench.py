@@ -180,7 +180,10 @@ def cpu_baseline(budget_s=10.0):
     main_leg = train_leg(8192, budget_s)
     return {"value": main_leg["value"], "unit": "poses/s", "cores": cores, "kind": "port",
             "sample": f"{main_leg['sample']} (BASELINE config 2 batch), torch-CPU oracle, {torch.get_num_threads()} threads",
-            "cpu_model": cpu_model, "host_cpus": os.cpu_count(), "legs": legs}
+            "cpu_model": cpu_model, "host_cpus": os.cpu_count(), "legs": legs,
+            "threads_policy": f"min(host threads, 32) = {cores}: BASELINE.md section 4 says os.cpu_count() threads, but on this pool's 256-thread EPYC "
+                              "hosts torch-CPU's GEMMs of these shapes collapse with every thread in use (measured in round 2: 81 s per B = 8192 "
+                              "train step at 256 threads against ~1.9 s at 32) -- the 32-thread figure is the FASTER, i.e. fairer, CPU baseline"}
 
 
 def main():
@@ -272,6 +275,8 @@ def main():
     torch.cuda.synchronize()
     # live roofline: HIP events around the launches of the dominant GEMM kind only (bracketing all ~30 GEMM launches of a
     # step costs ~3 % of it; the full per-kind table comes from three extra, untimed steps below)
+    if ddp.dp_active():
+        ddp.stats_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         # ... and only in every 4th step: the two event records per launch keep dependent kernels ~10 us apart
@@ -285,6 +290,8 @@ def main():
     torch.cuda.synchronize()
     ddp.barrier()
     elapsed = time.perf_counter() - t0
+    dp_stats = ddp.stats_collect() if ddp.dp_active() else None
+    ddp.stats_enable(False)
     prof = _C.profile_collect()
     _C.profile_enable(False)
     _C.profile_enable(True)
@@ -294,6 +301,7 @@ def main():
     prof_all = _C.profile_collect()
     _C.profile_enable(False)
     loss = float(out["step_loss"])
+    own_elapsed = elapsed
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -336,8 +344,21 @@ def main():
     dropped = state["optimizer"].nonfinite_steps()
     if not np.isfinite(loss) or dropped:
         raise RuntimeError(f"training diverged inside the benchmark: last loss {loss}, {dropped} step(s) dropped for a non-finite gradient")
+    dp_extra = None
+    if dp_stats:
+        # attribution of the data-parallel step on THIS rank (rank 0 prints): what the step waited for the collectives vs everything else;
+        # the slowest rank's step time is `ms_per_step` (max over ranks), this rank's own wall time per step is `rank_ms_per_step`
+        own_ms = own_elapsed / args.steps * 1e3
+        eng = model._engine()
+        dp_extra = dict(dp_stats, rank_ms_per_step=own_ms, rank_compute_ms_per_step=own_ms - dp_stats["exposed_allreduce_ms_per_step"],
+                        gradient_buckets=len(eng.grad_buckets), flat_gradient_bytes=int(model.flat_params().numel()) * 4,
+                        backend=torch.distributed.get_backend(), world=world,
+                        note="bucket collectives are enqueued from inside the backward call as their ranges become final "
+                             "(dposer_dsm_loss_fwd_bwd_notify -> StreamedAllReduce); the dead pre_dense_cond range belongs to no bucket")
     extra = {"train_loss_last_step": loss, "nonfinite_gradient_steps_dropped": dropped, "train_tflops_algorithmic": 42.59e6 * value / 1e12,
              "gemm_kernels": kernels}
+    if dp_extra:
+        extra["dp"] = dp_extra
     if not args.no_extra and args.precision != "fp32":
         # the same step in fp32 parity mode (exact-fp32 MFMA, 1/16 of the bf16 matrix rate): the mode the tight parity numbers
         # of the test suite come from, next to the bf16 headline
@@ -358,7 +379,11 @@ def main():
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             e32 = float(tt[0])
         extra["train_step_fp32_mode"] = {"poses_per_s": args.global_batch * n32 / e32, "ms_per_step": e32 / n32 * 1e3, "steps": n32,
-                                         "tflops_algorithmic": 42.59e6 * args.global_batch * n32 / e32 / 1e12, "fp32_mfma_peak_tflops": 157.3}
+                                         "tflops_algorithmic": 42.59e6 * args.global_batch * n32 / e32 / 1e12, "fp32_mfma_peak_tflops": 157.3,
+                                         "roofline": {"bound": "mfma", "achieved": 42.59e6 * args.global_batch * n32 / e32 / 1e12, "peak": 157.3,
+                                                      "unit": "TFLOP/s", "frac": 42.59e6 * args.global_batch * n32 / e32 / 1e12 / 157.3, "traffic": None,
+                                                      "scope": "whole step (42.59 MFLOP per pose over the step's wall time), exact-fp32 MFMA "
+                                                               "(v_mfma_f32_32x32x2_f32) peak"}}
         model.precision = args.precision
         model._engines.pop("fp32", None)                    # release the fp32 engine's packed weights / workspaces
         torch.cuda.empty_cache()

@@ -146,8 +146,7 @@ class FusedAdam(optim.Adam):
                      "dposer_adam_ema_clip_step_wd")
         torch.autograd.graph.increment_version(params)   # the kernel wrote the parameters through raw pointers: tell autograd
         if target is not None:                           # (after the version bump: the key describes the state the copies were made from)
-            from ...engine import param_state_key
-            repack.mark_packed_by_optimizer(param_state_key(flat, params))
+            repack.mark_packed_by_optimizer(flat, params)
         self._publish_state(params, offs, live)
 
     def _publish_state(self, params, offs, live):

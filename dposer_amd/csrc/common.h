@@ -38,6 +38,19 @@ int dposer_set_error(int code, const std::string& msg);
         if (_rc != DPOSER_OK) return _rc; \
     } while (0)
 
+// roctx range around a library call (SURVEY 5 tracing row): with DPOSER_ROCTX=1 in the environment every compute entry point of the C ABI
+// pushes / pops a range named after itself, so a rocprofv3 --marker-trace --kernel-trace run folds the kernel trace by CALL instead of "by
+// position in the step".  libroctx64.so is dlopen'ed at the first use (no link-time dependency); off (one predictable branch) otherwise.
+void dposer_range_push(const char* name);
+void dposer_range_pop();
+struct DpRange {
+    explicit DpRange(const char* name) { dposer_range_push(name); }
+    ~DpRange() { dposer_range_pop(); }
+    DpRange(const DpRange&) = delete;
+    DpRange& operator=(const DpRange&) = delete;
+};
+#define DP_RANGE() DpRange _dp_range(__func__)
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
 

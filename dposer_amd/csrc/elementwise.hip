@@ -1377,6 +1377,7 @@ __global__ void __launch_bounds__(256) k_rk_combine(RkCombineArgs a) {
 }
 extern "C" int dposer_rk_combine_f64(double* out, const double* y, const double* const* k_host, const double* coef_host, int32_t n_terms,
                                      double scale, int64_t n, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(out && k_host && coef_host && n_terms >= 1 && n_terms <= 8 && n >= 0, "bad argument");
     RkCombineArgs a;
     a.y = y; a.n_terms = n_terms; a.scale = scale; a.out = out; a.n = n;
@@ -1458,6 +1459,7 @@ static SdeDev pf_sde_dev(const dposer_sde_desc* s) {
 }
 extern "C" int dposer_pf_ode_rhs_begin(const dposer_sde_desc* sde, float t, const double* state, const float* noise, float* x, float* labels,
                                        float* dout, int64_t batch, int32_t dim, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(sde && state && x && labels && batch >= 0 && dim >= 1, "bad argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_VP || sde->kind == DPOSER_SDE_SUBVP, "VP / sub-VP only");
     DP_CHECK_ARG(!dout || noise, "dout needs noise");
@@ -1470,6 +1472,7 @@ extern "C" int dposer_pf_ode_rhs_begin(const dposer_sde_desc* sde, float t, cons
 }
 extern "C" int dposer_pf_ode_rhs_end(const dposer_sde_desc* sde, float t, const float* x, const float* model_out, const float* dx,
                                      const float* noise, double* dstate, int64_t batch, int32_t dim, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(sde && x && model_out && dstate && batch >= 0 && dim >= 1, "bad argument");
     DP_CHECK_ARG(sde->kind == DPOSER_SDE_VP || sde->kind == DPOSER_SDE_SUBVP, "VP / sub-VP only");
     DP_CHECK_ARG(!dx || noise, "dx needs noise");

@@ -18,7 +18,9 @@ struct DropoutCfg {
     int groups_x4;     // H/8 = number of counters per sample
     long long ext_rows;              // rows (samples) of ext_keep: padded rows beyond them keep everything
     const unsigned char* ext_keep;   // TEST HOOK (dposer_scorefc_debug_set_dropout_masks): keep decisions [samples][H] of this site, one byte
-                                     // each, used instead of the Philox draw -- feeds a recorded torch mask through the fused step
+                                     // each, used instead of the Philox draw -- feeds a recorded torch mask through the fused step.  Read
+                                     // only by the test-hook build (-DDPOSER_TEST_HOOKS, libdposer_hip_testhooks.so); the fields stay in
+                                     // the struct so every object file agrees on its layout
 };
 
 // keep[4q + r] = 1/(1-p) or 0 for channel 8q + 4hi + r.  Storing the decisions (one bit each) in the forward pass for the
@@ -88,6 +90,7 @@ __device__ __forceinline__ uint32_t dropout_mask16_bits(const DropoutCfg& d, int
 // the 16 decisions of dropout_mask16 as a bit set only (bit 4q + r); the training epilogue applies them as AND masks
 __device__ __forceinline__ uint32_t dropout_bits16(const DropoutCfg& d, int64_t s, int g, int hi) {
     uint32_t bits = 0;
+#ifdef DPOSER_TEST_HOOKS                               // libdposer_hip_testhooks.so only: the shipped epilogue has no such branch
     if (d.ext_keep) {                                  // injected decisions (tests): channel 32 g + 8 q + 4 hi + r -> bit 4 q + r
         if (s >= d.ext_rows) return 0xffffu;
         const unsigned char* row = d.ext_keep + s * (int64_t)(d.groups_x4 * 8) + 32 * g + 4 * hi;
@@ -97,6 +100,7 @@ __device__ __forceinline__ uint32_t dropout_bits16(const DropoutCfg& d, int64_t 
             for (int r = 0; r < 4; ++r) bits |= (row[8 * q + r] ? 1u : 0u) << (4 * q + r);
         return bits;
     }
+#endif
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         Philox4 r = philox_at_dropout((uint64_t)s * d.groups_x4 + g * 4 + hi * 2 + m, STREAM_DROPOUT0 + d.site, d.offset, d.seed);

@@ -162,6 +162,7 @@ template <bool FROM6D> __global__ void __launch_bounds__(256) k_to_axis_angle(co
     stream_out<256>(out, lds, item0, n, 3);
 }
 extern "C" int dposer_rotmat_to_axis_angle(const float* rotmat, float* axis_angle, int64_t n, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(rotmat && axis_angle && n >= 0, "bad argument");
     if (n == 0) return DPOSER_OK;
     hipLaunchKernelGGL(k_to_axis_angle<false>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, rotmat, axis_angle, n);
@@ -169,6 +170,7 @@ extern "C" int dposer_rotmat_to_axis_angle(const float* rotmat, float* axis_angl
     return DPOSER_OK;
 }
 extern "C" int dposer_rot6d_to_axis_angle(const float* rot6d, float* axis_angle, int64_t n, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(rot6d && axis_angle && n >= 0, "bad argument");
     if (n == 0) return DPOSER_OK;
     hipLaunchKernelGGL(k_to_axis_angle<true>, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, rot6d, axis_angle, n);
@@ -177,6 +179,7 @@ extern "C" int dposer_rot6d_to_axis_angle(const float* rot6d, float* axis_angle,
 }
 
 extern "C" int dposer_rodrigues(const float* aa, float* rotmat, int64_t n, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(aa && rotmat && n >= 0, "bad argument");
     if (n == 0) return DPOSER_OK;
     hipLaunchKernelGGL(k_rodrigues, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, aa, rotmat, n);
@@ -184,6 +187,7 @@ extern "C" int dposer_rodrigues(const float* aa, float* rotmat, int64_t n, void*
     return DPOSER_OK;
 }
 extern "C" int dposer_rot6d_to_rotmat(const float* rot6d, float* rotmat, int64_t n, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(rot6d && rotmat && n >= 0, "bad argument");
     if (n == 0) return DPOSER_OK;
     hipLaunchKernelGGL(k_rot6d, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, rot6d, rotmat, n);
@@ -277,6 +281,7 @@ __global__ void k_shape_blend_bwd_final(const float* __restrict__ part, const fl
 extern "C" int dposer_shape_blend_forward(const float* v_template, const float* shapedirs, const float* j_template, const float* jdirs,
                                           const float* shape, float* v_shaped, float* j_rest, int32_t num_vertices, int32_t num_joints,
                                           int32_t num_shape, int64_t batch, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(v_template && shapedirs && j_template && jdirs && shape && v_shaped && j_rest, "null argument");
     DP_CHECK_ARG(num_shape >= 1 && num_shape <= 1024, "num_shape must be in 1..1024");
     DP_CHECK_ARG(num_vertices > 0 && num_joints > 0 && batch >= 0, "bad size");
@@ -295,6 +300,7 @@ extern "C" int64_t dposer_shape_blend_scratch_floats(int32_t num_vertices, int32
 extern "C" int dposer_shape_blend_backward(const float* shapedirs, const float* jdirs, const float* d_v_shaped, const float* d_j_rest,
                                            float* d_shape, float* scratch, int32_t num_vertices, int32_t num_joints, int32_t num_shape,
                                            int64_t batch, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(shapedirs && jdirs && d_v_shaped && d_shape && scratch, "null argument");
     DP_CHECK_ARG(num_shape >= 1 && num_shape <= 1024, "num_shape must be in 1..1024");
     if (batch == 0) return DPOSER_OK;
@@ -810,6 +816,7 @@ template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t
 extern "C" int dposer_fk_joints(dposer_body_t h, const float* const* pose_segments_host, const int32_t* segment_joints_host,
                                 int32_t num_segments, const float* j_rest, int32_t j_rest_batched, const float* transl, float* joints,
                                 float* rel_transforms, int32_t n_out, int64_t batch, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(h && pose_segments_host && segment_joints_host && j_rest && joints, "null argument");
     DP_CHECK_ARG(num_segments >= 1 && num_segments <= FK_MAX_SEG, "1..8 pose segments");
     DP_CHECK_ARG(batch > 0, "batch must be positive");
@@ -1246,6 +1253,7 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
                                   const float* v_shaped, int32_t v_shaped_batched, const int32_t* skin_idx, const float* skin_w,
                                   int32_t skin_k, const float* transl, const int32_t* extra_vertex_ids, const int32_t* lmk_tri,
                                   const float* lmk_bary, float* verts, float* joints, int64_t batch, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(v_shaped && skin_idx && skin_w && verts, "null argument");
     DP_CHECK_ARG(skin_k >= 1, "bad size");
     float *A = nullptr, *offsets = nullptr;
@@ -1459,6 +1467,7 @@ extern "C" int dposer_lbs_forward_temporal_grad(dposer_body_t h, void* ws, const
                                                 int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched, const int32_t* skin_idx,
                                                 const float* skin_w, int32_t skin_k, const float* transl, int64_t frames_per_sequence, float scale,
                                                 float* d_verts, float* dist_part, float* joints, int64_t batch, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(v_shaped && skin_idx && skin_w && d_verts && dist_part, "null argument");
     DP_CHECK_ARG(skin_k == 4, "four skinning weights per vertex (the ELL width of every SMPL-family asset)");
     DP_CHECK_ARG(frames_per_sequence >= 2 && batch % frames_per_sequence == 0, "batch must be whole sequences of >= 2 frames");
@@ -2340,6 +2349,7 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
                                    const int32_t* joint_vidx, const float* joint_w, const float* d_verts, const float* d_joints,
                                    int64_t d_joints_ld, float* const* d_pose_segments_host, float* d_jrest, float* d_vposed,
                                    int64_t batch, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(h && ws_fwd && ws_bwd && posedirs_bwd_packed && pose_segments_host && segment_joints_host && j_rest && v_shaped && skin_idx &&
                      skin_w && joint_ptr && joint_vidx && joint_w && d_verts && d_joints && d_pose_segments_host,
                  "null argument");

@@ -408,8 +408,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         if constexpr (ASM) {
             const uint32_t vA_lo = lds0 + ((wc * TC * KB) << 10) + lane * 16, vB_lo = lds0 + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
             const uint32_t vA_hi = vA_lo + 65536, vB_hi = vB_lo + 65536;
+#ifdef DPOSER_KLOOP_FILL_INC
+            // issue-slot probe (tools/kloop_fill_probe.hip): filler stores go to the scratch g.src[7] -- 4 KiB per wave and stage, a fresh
+            // range every stage (HBM traffic like an epilogue's, no line written twice); g.src[6] receives this wave's K-loop cycles
+#define DP_RS_FILL_ARGS , fill_off, fill_base, fill_stride
+            uint32_t fill_off = (uint32_t)((blockIdx.x * C::NW + wave) * 4096 + lane * 16);
+            const uint64_t fill_base = sgpr_u64((uint64_t)(uintptr_t)g.src[7]);
+            const uint32_t fill_stride = __builtin_amdgcn_readfirstlane((uint32_t)(gridDim.x * C::NW * 4096));
+            const uint64_t stamp0 = __builtin_amdgcn_s_memtime();
+#else
+#define DP_RS_FILL_ARGS
+#endif
 #define DP_RING_STAGE(S, MODE)                                                                                                                     \
-    if constexpr (ASM_BIG) ring_stage_asm<S, MODE>(acc, fa[0], fb[0], fa[1], fb[1], vA_lo, vB_lo, vA_hi, vB_hi, v_wofs, v_xofs, sW[0], sW[1], sX[0], sX[1], s_m0); \
+    if constexpr (ASM_BIG) ring_stage_asm<S, MODE>(acc, fa[0], fb[0], fa[1], fb[1], vA_lo, vB_lo, vA_hi, vB_hi, v_wofs, v_xofs, sW[0], sW[1], sX[0], sX[1], s_m0 DP_RS_FILL_ARGS); \
     else ring_stage_asm_mid<S, MODE>(acc, fa[0], fb[0], fa[1], fb[1], vA_lo, vB_lo, v_wofs, v_xofs, sW[0], sW[1], sX[0], sX[1], s_m0);             \
     ++t
             // the ring starts at slot0 = 4 - rem: the `rem` stages in front of the groups of four run on slots 4 - rem ... 3
@@ -429,6 +440,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
                 DP_RING_STAGE(2, 3);
             }
 #undef DP_RING_STAGE
+#ifdef DPOSER_KLOOP_FILL_INC
+            if (lane == 0) reinterpret_cast<uint64_t*>(const_cast<void*>(g.src[6]))[blockIdx.x * C::NW + wave] = __builtin_amdgcn_s_memtime() - stamp0;
+#endif
+#undef DP_RS_FILL_ARGS
         } else {
             for (; t + PRE < nstages; ++t) stage(Y{}, std::integral_constant<int, (PRE - 2) * C::LPW + C::LPW_A>{}, N{});
         }

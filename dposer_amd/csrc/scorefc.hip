@@ -23,6 +23,30 @@
 #include "kernels_api.h"
 
 static thread_local std::string g_last_error;
+// ---- roctx ranges (common.h: DP_RANGE) -------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("DPOSER_ROCTX");
+        if (!e || e[0] != '1') return;
+        for (const char* name : {"libroctx64.so", "libroctx64.so.4", "librocprofiler-sdk-roctx.so"}) {
+            void* so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!so) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(so, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(so, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void dposer_range_push(const char* name) { Roctx& r = roctx(); if (r.push) r.push(name); }
+void dposer_range_pop() { Roctx& r = roctx(); if (r.pop) r.pop(); }
+
 int dposer_set_error(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
@@ -263,6 +287,7 @@ extern "C" int64_t dposer_scorefc_packed_bytes(dposer_scorefc_t h, int32_t with_
 }
 
 extern "C" int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat, void* packed, int32_t with_backward, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(h && flat && packed, "null argument");
     DP_CHECK_ARG(((uintptr_t)flat & 15) == 0 && ((uintptr_t)packed & 255) == 0, "flat_params must be 16-B aligned, packed 256-B aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -542,6 +567,12 @@ static DropoutCfg drop_cfg(const dposer_scorefc_s* h, bool train, int site, uint
 // test feed the masks the REFERENCE drew with torch's generator (golden g4) through the fused training step; honoured by the
 // tile-per-group training epilogue (hidden_dim 1024) for calls with exactly this batch size.
 extern "C" int dposer_scorefc_debug_set_dropout_masks(dposer_scorefc_t h, const unsigned char* keep, int64_t batch) {
+#ifndef DPOSER_TEST_HOOKS
+    (void)h; (void)batch;
+    DP_CHECK_ARG(!keep, "this library was built without DPOSER_TEST_HOOKS: the training epilogues have no injected-mask branch "
+                        "(load libdposer_hip_testhooks.so, DPOSER_LIB_PATH, for tests that need it)");
+    return DPOSER_OK;
+#endif
     DP_CHECK_ARG(h, "null handle");
     DP_CHECK_ARG(!keep || (batch > 0 && h->gs == 32), "injected dropout masks: hidden_dim 1024 only, batch > 0");
     h->dbg_keep = keep;
@@ -630,6 +661,7 @@ static int check_common(dposer_scorefc_t h, const float* flat, const void* packe
 extern "C" int dposer_scorefc_forward(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const float* x,
                                       const float* labels, const float* freq, const float* sigmas, float* out, int64_t B,
                                       void* stream) {
+    DP_RANGE();
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(x && labels && freq && sigmas && out, "null tensor argument");
@@ -745,6 +777,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
                            float* x_mean, const float* timesteps_host, int32_t start_step, int32_t n_steps, const float* observation,
                            const float* mask, const float* noise, uint64_t seed, float* traj, int32_t traj_stride, const float* freq,
                            const float* sigmas, int64_t B, void* stream) {
+    DpRange _dp_range("dposer_em_sampler");
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x && x_mean && timesteps_host && freq && sigmas, "null argument");
@@ -887,6 +920,7 @@ extern "C" int dposer_langevin_step(dposer_scorefc_t h, const float* flat, const
                                     float* x, float* x_mean, float t, float alpha, float snr, const float* noise, uint64_t seed,
                                     uint32_t step, float* norm_sums, int32_t phase, double inv_global_batch, const float* freq,
                                     const float* sigmas, int64_t B, void* stream) {
+    DP_RANGE();
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x && norm_sums && freq && sigmas, "null argument");
@@ -951,10 +985,12 @@ extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const vo
                                  const float* x0, const float* z, float t, int32_t weighted, float inv_n, float* x0_hat, float* grad,
                                  float* loss, uint64_t seed, uint32_t step, const float* freq, const float* sigmas, int64_t B,
                                  void* stream) {
+    DP_RANGE();
     return prior_loss_impl(h, flat, packed_, ws_, sde, x0, z, t, weighted, inv_n, x0_hat, grad, loss, seed, step, freq, sigmas, B, stream, 0, 0);
 }
 extern "C" int dposer_prior_table_build(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const float* t_host,
                                         int32_t n_rows, const float* freq, int64_t B, void* stream) {
+    DP_RANGE();
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     DP_CHECK_ARG(t_host && freq && n_rows >= 1, "bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -969,6 +1005,7 @@ extern "C" int dposer_prior_loss_tabled(dposer_scorefc_t h, const float* flat, c
                                         const float* x0, const float* z, float t, int32_t row, int32_t table_rows, int32_t weighted,
                                         float inv_n, float* x0_hat, float* grad, float* loss, uint64_t seed, uint32_t step,
                                         const float* sigmas, int64_t B, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(table_rows >= 1, "table_rows must be >= 1");
     return prior_loss_impl(h, flat, packed_, ws_, sde, x0, z, t, weighted, inv_n, x0_hat, grad, loss, seed, step, nullptr, sigmas, B, stream, row,
                            table_rows);
@@ -983,6 +1020,7 @@ extern "C" int dposer_completion_optimize(dposer_scorefc_t h, const float* flat,
                                           const float* w_data_host, int32_t n_steps, double lr, double beta1, double beta2, double eps,
                                           const float* noise, uint64_t seed, uint32_t step0, const float* freq, const float* sigmas,
                                           int64_t B, void* stream) {
+    DP_RANGE();
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x && observation && mask && adam_m && adam_v && t_host && weighted_host && w_prior_host && w_data_host && freq && sigmas,
@@ -1581,6 +1619,7 @@ extern "C" int dposer_dsm_loss_fwd_bwd_bucketed(dposer_scorefc_t h, const float*
                                                 float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
                                                 float* flat_grad, float* loss, int64_t B, void* const* bucket_events, int32_t n_events,
                                                 void* stream) {
+    DP_RANGE();
     BucketSink sink;
     sink.events = bucket_events; sink.n_events = n_events;
     return dsm_loss_fwd_bwd_impl(h, flat, packed_, ws_, sde, batch_x, t_in, z_in, eps, seed, step, freq, sigmas, flat_grad, loss, B,
@@ -1592,6 +1631,7 @@ extern "C" int dposer_dsm_loss_fwd_bwd_notify(dposer_scorefc_t h, const float* f
                                               float eps, uint64_t seed, uint32_t step, const float* freq, const float* sigmas,
                                               float* flat_grad, float* loss, int64_t B, void* const* bucket_events, int32_t n_events,
                                               dposer_ranges_final_fn notify, void* user, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(bucket_events && n_events > 0 && notify, "notify form needs bucket events and a callback");
     DP_CHECK_ARG(h && n_events >= n_grad_buckets(h), "one event per gradient bucket (dposer_scorefc_grad_buckets)");
     BucketSink sink;
@@ -1604,6 +1644,7 @@ extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, co
                                        const float* batch_x, const float* t_in, const float* z_in, float eps, uint64_t seed,
                                        uint32_t step, const float* freq, const float* sigmas, float* flat_grad, float* loss, int64_t B,
                                        void* stream) {
+    DP_RANGE();
     return dposer_dsm_loss_fwd_bwd_bucketed(h, flat, packed, ws, sde, batch_x, t_in, z_in, eps, seed, step, freq, sigmas, flat_grad, loss, B,
                                             nullptr, 0, stream);
 }
@@ -1612,6 +1653,7 @@ extern "C" int dposer_dsm_loss_fwd_bwd(dposer_scorefc_t h, const float* flat, co
 extern "C" int dposer_scorefc_forward_train(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const float* x,
                                             const float* labels, const float* freq, const float* sigmas, float* out, int64_t B,
                                             int32_t train_mode, uint64_t seed, uint32_t step, void* stream) {
+    DP_RANGE();
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(x && labels && freq && sigmas && out, "null tensor argument");
@@ -1637,6 +1679,7 @@ extern "C" int dposer_scorefc_forward_train(dposer_scorefc_t h, const float* fla
 extern "C" int dposer_scorefc_backward(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const float* labels,
                                        const float* sigmas, const float* dout, float* flat_grad, float* dx, int64_t B,
                                        int32_t train_mode, uint64_t seed, uint32_t step, void* stream) {
+    DP_RANGE();
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(labels && sigmas && dout, "null tensor argument");
@@ -1653,6 +1696,7 @@ extern "C" int dposer_scorefc_backward(dposer_scorefc_t h, const float* flat, co
 }
 
 extern "C" int dposer_grad_sqnorm(const float* grad, int64_t n, float* scratch, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(grad && scratch && n >= 0, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     int nb = 0;
@@ -1668,6 +1712,7 @@ extern "C" int dposer_adam_ema_clip_step(float* flat, const float* grad, float* 
                                          const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
                                          double beta1, double beta2, double eps, double grad_clip, double grad_scale,
                                          int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream) {
+    DP_RANGE();
     return adam_step_impl(flat, grad, m, v, ema, n, skip_lo_host, skip_hi_host, n_skip, lr, beta1, beta2, eps, grad_clip, grad_scale, adam_step,
                           ema_one_minus_decay, scratch, false, stream, 0.0);
 }
@@ -1675,6 +1720,7 @@ extern "C" int dposer_adam_ema_clip_step_wd(float* flat, const float* grad, floa
                                             const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
                                             double beta1, double beta2, double eps, double weight_decay, double grad_clip, double grad_scale,
                                             int64_t adam_step, double ema_one_minus_decay, float* scratch, int32_t presummed, void* stream) {
+    DP_RANGE();
     return adam_step_impl(flat, grad, m, v, ema, n, skip_lo_host, skip_hi_host, n_skip, lr, beta1, beta2, eps, grad_clip, grad_scale, adam_step,
                           ema_one_minus_decay, scratch, presummed != 0, stream, weight_decay);
 }
@@ -1682,6 +1728,7 @@ extern "C" int dposer_adam_ema_clip_step_presummed(float* flat, const float* gra
                                                    const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
                                                    double beta1, double beta2, double eps, double grad_clip, double grad_scale,
                                                    int64_t adam_step, double ema_one_minus_decay, float* scratch, void* stream) {
+    DP_RANGE();
     return adam_step_impl(flat, grad, m, v, ema, n, skip_lo_host, skip_hi_host, n_skip, lr, beta1, beta2, eps, grad_clip, grad_scale, adam_step,
                           ema_one_minus_decay, scratch, true, stream, 0.0);
 }
@@ -1720,6 +1767,7 @@ extern "C" int dposer_scorefc_adam_pack_step(dposer_scorefc_t h, float* flat, co
                                              const int64_t* skip_lo_host, const int64_t* skip_hi_host, int32_t n_skip, double lr,
                                              double beta1, double beta2, double eps, double weight_decay, double grad_clip, double grad_scale,
                                              int64_t adam_step, double ema_one_minus_decay, float* scratch, int32_t presummed, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(h && flat && grad && m && v && packed && scratch, "null argument");
     DP_CHECK_ARG(h->adam_pack.n_tensors > 0, "fused optimizer + re-pack step not available for this configuration");
     DP_CHECK_ARG(adam_step >= 1, "adam_step counts from 1");

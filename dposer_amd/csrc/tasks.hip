@@ -233,6 +233,7 @@ extern "C" int64_t dposer_motion_denoise_scratch_bytes(int64_t frames, int32_t p
 }
 
 extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* a, void* stream) {
+    DP_RANGE();
     DP_CHECK_ARG(a, "null argument");
     DP_CHECK_ARG(a->net && a->flat_params && a->packed && a->net_ws && a->sde && a->freq && a->sigmas, "null score-network argument");
     DP_CHECK_ARG(a->body && a->lbs_ws_fwd && a->lbs_ws_bwd && a->posedirs_packed && a->posedirs_bwd_packed && a->j_rest && a->v_shaped && a->skin_idx &&

@@ -134,6 +134,34 @@ def all_reduce_buckets_(flat: torch.Tensor, buckets, wait_bucket=None) -> int:
     return dist.get_world_size()
 
 
+# ---- attribution of a data-parallel step (bench.py `extra.dp`): what the collectives moved and what of them the step had to wait for ----
+_STATS = None
+
+
+def stats_enable(on=True):
+    """Start (or stop) recording, per data-parallel step: bytes handed to the all-reduce, number of collectives and the time the
+    compute stream stalled in ``StreamedAllReduce.finish()`` (an event pair around the waits: the EXPOSED part of the communication --
+    everything else ran under the backward pass)."""
+    global _STATS
+    _STATS = {"steps": 0, "bytes": 0, "collectives": 0, "events": [], "host_wait_s": 0.0} if on else None
+
+
+def stats_collect():
+    """{steps, allreduce_bytes_per_step, collectives_per_step, exposed_allreduce_ms_per_step} of the steps since stats_enable(); None
+    when nothing was recorded.  Synchronises the device (reads the event pairs)."""
+    st = _STATS
+    if not st or st["steps"] == 0:
+        return None
+    exposed = st["host_wait_s"] * 1e3
+    if st["events"]:
+        torch.cuda.synchronize()
+        exposed += sum(a.elapsed_time(b) for a, b in st["events"])
+    n = st["steps"]
+    return {"steps": n, "allreduce_bytes_per_step": st["bytes"] / n, "collectives_per_step": st["collectives"] / n,
+            "exposed_allreduce_ms_per_step": exposed / n,
+            "how": "event pair on the compute stream around the waits for the bucket collectives (gloo: host wall time of the waits)"}
+
+
 class StreamedAllReduce:
     """All-reduce (SUM) of ``flat`` range by range WHILE the producer is still queueing work: the fused backward pass announces
     every group of final gradient buckets from inside its C call (dposer_dsm_loss_fwd_bwd_notify: one recorded event + the merged
@@ -171,8 +199,26 @@ class StreamedAllReduce:
     def finish(self, expect=None) -> int:
         """``expect``: the bucket ranges the producer must have announced (every one covered by an announced range), checked after
         the wait -- a bucket that was never announced was never reduced."""
+        st = _STATS
+        ev = None
+        if st is not None:
+            if self.comm is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            else:
+                import time
+                t0 = time.perf_counter()
         for w in self.works:                  # first: whatever was enqueued is joined, also on the error path -- the caller must
             w.wait()                          # not see ``flat`` while a collective still writes it (NCCL: the current stream waits; gloo: host wait)
+        if st is not None:
+            if ev is not None:
+                ev[1].record()
+                st["events"].append(ev)
+            else:
+                st["host_wait_s"] += time.perf_counter() - t0
+            st["steps"] += 1
+            st["collectives"] += len(self.works)
+            st["bytes"] += sum(hi - lo for lo, hi in self.ranges) * self.flat.element_size()
         if self.error is not None:
             raise self.error
         if expect is not None:

@@ -55,6 +55,7 @@ class ScoreEngine:
         self._packed_bwd = False
         self._pack_gen = 0                 # bumped by every (re)pack: lets a backward notice that the packed buffer was rewritten
         self._fresh_key = None             # state key under which the fused optimizer step last wrote the packed copies itself
+        self._key_flat = None
         self._ws: Dict[int, torch.Tensor] = {}
         self._train_pool = []              # free WS_TRAIN buffers (see lease_train_workspace)
         self.freq_cpu = positional_freq(embed_dim)
@@ -97,6 +98,7 @@ class ScoreEngine:
         key under which the fused optimizer step wrote the packed copies itself (dposer_scorefc_adam_pack_step), they ARE the
         parameters' and nothing is launched."""
         need = self.lib.dposer_scorefc_packed_bytes(self.h, 1)
+        self._key_flat = flat              # the tensor OBJECT whose version counter the freshness key reads (see mark_packed_by_optimizer)
         if self._packed is None or self._packed.device != flat.device:
             self._packed = torch.empty(need, dtype=torch.uint8, device=flat.device)
             force = True
@@ -118,8 +120,15 @@ class ScoreEngine:
             return None
         return self._packed
 
-    def mark_packed_by_optimizer(self, state_key):
-        self._fresh_key = state_key
+    def mark_packed_by_optimizer(self, flat, params):
+        """The fused optimizer step has just rewritten the packed copies from the parameters it updated.  The freshness key must be
+        built from the SAME tensor object the next ``packed()`` call will present (the model's flat buffer): the optimizer reaches the
+        storage through an alias of its own (losses.flat_base), whose version counter is a different one."""
+        key_flat = getattr(self, "_key_flat", None)
+        if key_flat is None or key_flat.data_ptr() != flat.data_ptr() or key_flat.numel() != flat.numel():
+            self._fresh_key = None         # never packed from this buffer: the next step packs
+        else:
+            self._fresh_key = param_state_key(key_flat, params)
         self._pack_gen += 1
 
     def workspace(self, batch: int, mode: int, n_steps: int, device):

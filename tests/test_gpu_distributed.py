@@ -243,6 +243,35 @@ def test_bench_runs_as_two_ranks_launched_by_torchrun():
     assert j["value"] > 0 and abs(j["value"] - 8192 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-6
     assert np.isfinite(j["extra"]["train_loss_last_step"]) and j["extra"]["nonfinite_gradient_steps_dropped"] == 0
     assert j["roofline"]["bound"] == "mfma" and "traffic_source" in j["roofline"]
+    # the data-parallel step is attributable: what the collectives moved and what of them the step waited for
+    dp = j["extra"]["dp"]
+    assert dp["world"] == 2 and dp["backend"] == "gloo" and dp["steps"] == 3
+    assert dp["collectives_per_step"] >= 2 and dp["gradient_buckets"] >= dp["collectives_per_step"]
+    live = dp["flat_gradient_bytes"] - 4 * (1024 * 1024 + 1024)         # every gradient byte but the dead pre_dense_cond range travels
+    assert dp["allreduce_bytes_per_step"] == live, (dp["allreduce_bytes_per_step"], live)
+    assert 0.0 <= dp["exposed_allreduce_ms_per_step"] <= dp["rank_ms_per_step"]
+    assert abs(dp["rank_compute_ms_per_step"] + dp["exposed_allreduce_ms_per_step"] - dp["rank_ms_per_step"]) < 1e-6
+
+
+def test_bench_attributes_the_step_of_a_forced_one_rank_rccl_group():
+    """bench.py through a ONE-rank process group over the real RCCL transport (DPOSER_DIST_FORCE_COLLECTIVES=1): `extra.dp` reports the
+    bytes handed to ncclAllReduce, the number of collectives and the exposed wait (an event pair on the compute stream) -- what makes
+    the first 8-GPU run attributable."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("DPOSER_DIST_BACKEND", "DPOSER_ZERO1")}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               DPOSER_DIST_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--global-batch", "8192",
+                        "--no-extra", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    dp = j["extra"]["dp"]
+    assert dp["backend"] == "nccl" and dp["world"] == 1 and dp["steps"] == 4
+    assert dp["allreduce_bytes_per_step"] == dp["flat_gradient_bytes"] - 4 * (1024 * 1024 + 1024)
+    assert 0.0 <= dp["exposed_allreduce_ms_per_step"] < dp["rank_ms_per_step"]
 
 
 def test_nonfinite_gradient_step_is_dropped_on_the_device():

@@ -1469,10 +1469,25 @@ def test_train_steps_with_the_reference_dropout_masks_match_the_reference_golden
     get_step_fn with dropout 0.1) together with the keep masks torch's generator drew.  Those masks are fed through the fused HIP step
     (test hook dposer_scorefc_debug_set_dropout_masks: the training epilogue takes its keep decisions from them instead of Philox) and
     loss, learning rate, parameters, Adam moments and EMA shadows are compared with the reference's values themselves -- no oracle in
-    between (round 3 went HIP == oracle without dropout, oracle == g4 with masks)."""
+    between (round 3 went HIP == oracle without dropout, oracle == g4 with masks).  The injected-mask branch exists only in the
+    test-hook build of the library (libdposer_hip_testhooks.so, -DDPOSER_TEST_HOOKS: the shipped training epilogue carries no such
+    branch), which a process must load from the start: the body runs in a child process with DPOSER_LIB_PATH pointing at it."""
+    import os
+    if not os.environ.get("DPOSER_HOOKS_CHILD"):
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        lib = os.path.join(root, "dposer_amd", "libdposer_hip_testhooks.so")
+        assert os.path.exists(lib), "build the test-hook library: make -C dposer_amd/csrc (target ../libdposer_hip_testhooks.so)"
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_score.py"), "-m", "gpu", "-q", "-x", "-k",
+                            "test_train_steps_with_the_reference_dropout_masks_match_the_reference_golden"],
+                           cwd=root, env=dict(os.environ, DPOSER_HOOKS_CHILD="1", DPOSER_LIB_PATH=lib), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        return
     from dposer_amd import _C
     from dposer_amd.algorithms.advanced import losses, sde_lib
     from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    assert _C.LIB_PATH.endswith("libdposer_hip_testhooks.so")
     g = load("g4_train_steps")
     cfg, m, p = make_model(int(g["seed"]), precision="fp32", dropout=0.1)
     sde = sde_lib.subVPSDE(0.1, 20.0, 1000)

@@ -114,6 +114,27 @@ def test_capi_exports_every_declared_symbol():
     assert _C.lib().dposer_abi_version() == 1
 
 
+def test_shipped_library_has_no_dropout_mask_hook():
+    """The injected-dropout-mask test hook lives in the test-hook build only (libdposer_hip_testhooks.so, -DDPOSER_TEST_HOOKS): the
+    shipped library keeps the symbol (one ABI) but refuses masks, and its training epilogues reference no `ext_keep` load -- both
+    libraries export the same symbols."""
+    import ctypes as C
+    from dposer_amd import _C
+    lib = _C.lib()
+    h = C.c_void_p()
+    d = _C.ScoreFCDesc(63, 1024, 512, 2, _C.EMB_POSITIONAL, 1, 1000, _C.PREC_BF16, 0.1)
+    assert lib.dposer_scorefc_create(C.byref(d), C.byref(h)) == 0
+    fake = C.c_void_p(0x1000)
+    assert lib.dposer_scorefc_debug_set_dropout_masks(h, fake, 32) < 0 and b"DPOSER_TEST_HOOKS" in lib.dposer_last_error()
+    assert lib.dposer_scorefc_debug_set_dropout_masks(h, None, 0) == 0           # clearing is always fine
+    lib.dposer_scorefc_destroy(h)
+    th = os.path.join(os.path.dirname(_C.LIB_PATH), "libdposer_hip_testhooks.so")
+    assert os.path.exists(th), "make -C dposer_amd/csrc builds it beside libdposer_hip.so"
+    hooks = ctypes.CDLL(th)
+    for name in _C.SIGNATURES:
+        assert hasattr(hooks, name), name
+
+
 def test_model_surface_and_flat_params():
     from dposer_amd import _C
     from dposer_amd.algorithms.advanced.model import ScoreModelFC

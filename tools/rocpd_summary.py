@@ -147,7 +147,7 @@ def counters(paths):
     print("|---|---:|" + "---:|" * len(names))
     for k, v in agg.items():
         n = max(x[0] for x in v.values())
-        print(f"| `{k}` | {n} | " + " | ".join(f"{v[c][1]:.4g}" if c in v else "" for c in names) + " |")
+        print(f"| `{k}` | {n} | " + " | ".join(f"{v[c][1]:.4g}" if c in v else "n/a" for c in names) + " |")
 
 
 def mfma(paths, as_json=False):
@@ -177,14 +177,15 @@ def mfma(paths, as_json=False):
         if g <= 0 or k not in dur:
             continue
         us = dur[k][1] / dur[k][0] / 1e3
-        busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0.0))[1]
-        wc = v.get("SQ_WAVE_CYCLES", (0, 0.0))[1]
+        # a counter NO pass collected for this kernel is None ("n/a" in the table / null in the JSON), never a zero: a pass that only
+        # asked for GRBM_GUI_ACTIVE used to print a GEMM with SQ_INSTS_MFMA 0 and MFMA busy 0.000
+        get = lambda name: v[name][1] if name in v else None
+        busy, wc = get("SQ_VALU_MFMA_BUSY_CYCLES"), get("SQ_WAVE_CYCLES")
+        frac = lambda name: (get(name) / wc) if (wc and get(name) is not None) else None
         rows.append({"kernel": k, "launches": dur[k][0], "avg_us": us, "grbm_gui_active": g, "clock_ghz": g / 8.0 / us / 1e3,
-                     "mfma_busy_cycles": busy, "mfma_busy_frac": busy / (g / 8.0 * 1024.0), "insts_mfma": v.get("SQ_INSTS_MFMA", (0, 0.0))[1],
-                     "insts_valu": v.get("SQ_INSTS_VALU", (0, 0.0))[1],
-                     "issue_stall_frac": (v.get("SQ_WAIT_INST_ANY", (0, 0.0))[1] / wc) if wc else None,
-                     "parked_frac": (v.get("SQ_WAIT_ANY", (0, 0.0))[1] / wc) if wc else None,
-                     "active_frac": (v.get("SQ_ACTIVE_INST_ANY", (0, 0.0))[1] / wc) if wc else None})
+                     "mfma_busy_cycles": busy, "mfma_busy_frac": None if busy is None else busy / (g / 8.0 * 1024.0),
+                     "insts_mfma": get("SQ_INSTS_MFMA"), "insts_valu": get("SQ_INSTS_VALU"),
+                     "issue_stall_frac": frac("SQ_WAIT_INST_ANY"), "parked_frac": frac("SQ_WAIT_ANY"), "active_frac": frac("SQ_ACTIVE_INST_ANY")})
     rows.sort(key=lambda r: -r["avg_us"] * r["launches"])
     if as_json:
         print(json.dumps({r["kernel"]: r for r in rows}, indent=1, sort_keys=True))
@@ -193,10 +194,11 @@ def mfma(paths, as_json=False):
     print(mfma.__doc__.strip() + "\n")
     print("| kernel | launches | avg us | clock GHz | MFMA busy | SQ_INSTS_MFMA | SQ_INSTS_VALU | issue-stall | parked | active |")
     print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
-    f = lambda x: "" if x is None else f"{x:.3f}"
+    f = lambda x: "n/a" if x is None else f"{x:.3f}"
+    g4 = lambda x: "n/a" if x is None else f"{x:.4g}"
     for r in rows[:24]:
-        print(f"| `{r['kernel']}` | {r['launches']} | {r['avg_us']:.1f} | {r['clock_ghz']:.2f} | {r['mfma_busy_frac']:.3f} | {r['insts_mfma']:.4g} | "
-              f"{r['insts_valu']:.4g} | {f(r['issue_stall_frac'])} | {f(r['parked_frac'])} | {f(r['active_frac'])} |")
+        print(f"| `{r['kernel']}` | {r['launches']} | {r['avg_us']:.1f} | {r['clock_ghz']:.2f} | {f(r['mfma_busy_frac'])} | {g4(r['insts_mfma'])} | "
+              f"{g4(r['insts_valu'])} | {f(r['issue_stall_frac'])} | {f(r['parked_frac'])} | {f(r['active_frac'])} |")
 
 
 def dispatch_table(paths, needle, per_step=0):
