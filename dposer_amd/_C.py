@@ -51,6 +51,12 @@ class MotionDenoiseArgs(C.Structure):
                 ("rot6d", C.c_int32)]
 
 
+class LbsJointFold(C.Structure):
+    """dposer_lbs_joint_fold (include/dposer_hip.h): which vertices the extra joints / landmarks read, as device tables."""
+    _fields_ = [("vertex_slot", C.c_void_p), ("slot_vertex", C.c_void_p), ("slot_ptr", C.c_void_p), ("entry_row", C.c_void_p),
+                ("entry_weight", C.c_void_p), ("n_slots", C.c_int32)]
+
+
 class DPoserHipError(RuntimeError):
     pass
 
@@ -143,6 +149,8 @@ SIGNATURES = {
     "dposer_scorefc_debug_set_dropout_masks": (C.c_int, [vp, vp, i64]),
     "dposer_lbs_backward": (C.c_int, [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp,
                                       vp, vp, i64, C.POINTER(vp), vp, vp, i64, vp]),
+    "dposer_lbs_backward_fold": (C.c_int, [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp,
+                                           vp, vp, i64, C.POINTER(LbsJointFold), C.POINTER(vp), vp, vp, i64, vp]),
 }
 
 

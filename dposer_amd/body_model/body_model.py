@@ -110,33 +110,17 @@ class _LBSFunction(torch.autograd.Function):
         J = core.J
         dv = d_verts.contiguous().float()
         dj = d_joints.contiguous().float()
-        # extras / landmarks are gathers of vertices: fold their gradients into d verts.  One small dense product onto the
-        # UNIQUE vertices they touch (<= 21 + 3 * 51 of 10475), added without duplicate indices: deterministic (index_add_ with the
-        # raw, repeating landmark-triangle indices is an atomicAdd race whose order changes the last bit from run to run).
-        # Round 2 cloned all of d verts for this (515 MB at 4096 poses, 346 us) and multiplied as a broadcast batch of
-        # [U, 72] x [72, 3] products (a 100 us hipBLASLt launch).  Now: the few touched rows are saved, updated IN the incoming
-        # gradient and restored after the kernels have read it (autograd hands out d verts read-only); the product is ONE
-        # [U, 72] x [72, 3 B] GEMM.
-        saved = uniq = None
-        if core.n_extra + core.n_lmk:
-            uniq, fold = core.joint_fold()
-            x = dj[:, J:].permute(1, 0, 2).reshape(dj.shape[1] - J, B * 3)                    # [72, 3 B]
-            contrib = torch.matmul(fold, x).reshape(-1, B, 3).permute(1, 0, 2)                  # [B, U, 3]
-            if dv.data_ptr() == d_verts.data_ptr():                                             # still autograd's tensor: restore it later
-                saved = dv[:, uniq]
-                dv[:, uniq] = saved + contrib
-            else:                                                                               # .contiguous() / .float() made a private copy
-                dv[:, uniq] += contrib
-        try:
-            return _LBSFunction._backward_body(ctx, core, B, dev, h, lib, J, dv, dj)
-        finally:
-            if saved is not None:
-                dv[:, uniq] = saved                    # the incoming gradient is handed back as it came, also when a check raised
+        # extras / landmarks are gathers of vertices (smplx VertexJointSelector / vertices2landmarks): their gradients d_joints[:, J:] belong to
+        # the <= 21 + 3 * 51 vertices they read.  dposer_lbs_backward_fold adds them INSIDE the library (k_fold_rows writes the corrected
+        # rows into its workspace, the skinning kernels read those instead of the caller's rows; fixed summation order): the incoming
+        # gradient is only read -- rounds 2-4 did this here with torch.matmul (hipBLASLt) + index / index_put launches and wrote into
+        # autograd's tensor in place, restoring it afterwards.
+        return _LBSFunction._backward_body(ctx, core, B, dev, h, lib, J, dv, dj)
 
     @staticmethod
     def _backward_body(ctx, core, B, dev, h, lib, J, dv, dj):
-        # transl shifts every vertex and the J LBS joints (extras / landmarks move with their vertices: already in dv)
-        d_transl = (dv.sum(dim=1) + dj[:, :J].sum(dim=1)) if ctx.has_transl else None
+        # transl shifts every vertex and every joint row (the weights of an extra joint / landmark over its vertices sum to 1)
+        d_transl = (dv.sum(dim=1) + dj.sum(dim=1)) if ctx.has_transl else None
         ws_b = torch.empty(lib.dposer_lbs_backward_workspace_bytes(h, B), dtype=torch.uint8, device=dev)
         segp, dsegp = (C.c_void_p * _MAX_SEG)(), (C.c_void_p * _MAX_SEG)()
         segj = (C.c_int32 * _MAX_SEG)()
@@ -157,11 +141,13 @@ class _LBSFunction(torch.autograd.Function):
         d_jrest = torch.empty(B, J, 3, dtype=torch.float32, device=dev) if need_jr else None
         d_vposed = torch.empty(B, core.V, 3, dtype=torch.float32, device=dev) if need_vs else None
         jptr, jvidx, jw = core.joint_csr()
-        _C.check(lib.dposer_lbs_backward(h, _C.ptr(ctx.ws), _C.ptr(ws_b), _C.ptr(core._packed_posedirs_bwd()), segp, segj, len(core.segments), _C.ptr(ctx.jr),
-                                         1 if ctx.batched else 0, _C.ptr(ctx.vs), 1 if ctx.batched else 0, _C.ptr(core.skin_idx),
-                                         _C.ptr(core.skin_w), int(core.skin_idx.shape[1]), _C.ptr(jptr), _C.ptr(jvidx), _C.ptr(jw), _C.ptr(dv),
-                                         _C.ptr(dj), dj.shape[1] * 3, dsegp, _C.ptr(d_jrest), _C.ptr(d_vposed), B, _C.stream_ptr()),
-                 "dposer_lbs_backward")
+        fold = core.joint_fold_tables() if (core.n_extra + core.n_lmk) and dj.shape[1] > J else None
+        _C.check(lib.dposer_lbs_backward_fold(h, _C.ptr(ctx.ws), _C.ptr(ws_b), _C.ptr(core._packed_posedirs_bwd()), segp, segj, len(core.segments), _C.ptr(ctx.jr),
+                                              1 if ctx.batched else 0, _C.ptr(ctx.vs), 1 if ctx.batched else 0, _C.ptr(core.skin_idx),
+                                              _C.ptr(core.skin_w), int(core.skin_idx.shape[1]), _C.ptr(jptr), _C.ptr(jvidx), _C.ptr(jw), _C.ptr(dv),
+                                              _C.ptr(dj), dj.shape[1] * 3, None if fold is None else C.byref(fold[0]), dsegp, _C.ptr(d_jrest),
+                                              _C.ptr(d_vposed), B, _C.stream_ptr()),
+                 "dposer_lbs_backward_fold")
         if ctx.batched:
             g_vs, g_jr = d_vposed, d_jrest
         else:
@@ -259,24 +245,36 @@ class _SMPLCore(nn.Module):
                                                                  _C.ptr(self._jcsr[2]), _C.stream_ptr()), "dposer_lbs_prepare_joint_lists")
         return self._jcsr
 
-    def joint_fold(self):
-        """(unique vertex ids [U], fold [U, n_extra + n_lmk]): d verts[:, ids] += fold @ d joints[:, J:] is the backward of the
-        vertex-selected extra joints and of the barycentric landmarks (smplx VertexJointSelector / vertices2landmarks)."""
+    def joint_fold_tables(self):
+        """(dposer_lbs_joint_fold struct, tensors it points at) for dposer_lbs_backward_fold, built once per (asset, device): the vertices
+        the vertex-selected extra joints and the barycentric landmarks read, each with its (d_joints row, weight) entries -- extras
+        first, then landmarks in landmark order: the order the library adds them in."""
         dev = self.skin_idx.device
-        if getattr(self, "_jfold", None) is None or self._jfold[0].device != dev:
+        if getattr(self, "_jfold_tab", None) is None or self._jfold_tab[1][0].device != dev:
             ex = self.extra_vertex_ids.cpu().numpy().astype(np.int64)
             tri = self.lmk_tri.cpu().numpy().astype(np.int64).reshape(-1, 3)
             bary = self.lmk_bary_coords.cpu().numpy().astype(np.float32).reshape(-1, 3)
-            uniq = np.unique(np.concatenate([ex, tri.reshape(-1)]))
-            pos = {int(v): i for i, v in enumerate(uniq)}
-            fold = np.zeros((len(uniq), len(ex) + len(tri)), dtype=np.float32)
+            per = {}
             for e, v in enumerate(ex):
-                fold[pos[int(v)], e] += 1.0
+                per.setdefault(int(v), []).append((self.J + e, 1.0))
             for l in range(len(tri)):
                 for f in range(3):
-                    fold[pos[int(tri[l, f])], len(ex) + l] += bary[l, f]
-            self._jfold = (torch.tensor(uniq, device=dev), torch.tensor(fold, device=dev))
-        return self._jfold
+                    per.setdefault(int(tri[l, f]), []).append((self.J + len(ex) + l, float(bary[l, f])))
+            uniq = sorted(per)
+            vslot = np.full(self.V, -1, dtype=np.int32)
+            ptr, rows, ws = [0], [], []
+            for u, v in enumerate(uniq):
+                vslot[v] = u
+                for r, w in per[v]:
+                    rows.append(r)
+                    ws.append(w)
+                ptr.append(len(rows))
+            t = (torch.tensor(vslot, device=dev), torch.tensor(np.asarray(uniq, dtype=np.int32), device=dev),
+                 torch.tensor(np.asarray(ptr, dtype=np.int32), device=dev), torch.tensor(np.asarray(rows, dtype=np.int32), device=dev),
+                 torch.tensor(np.asarray(ws, dtype=np.float32), device=dev))
+            st = _C.LbsJointFold(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), len(uniq))
+            self._jfold_tab = (st, t)
+        return self._jfold_tab
 
     def _packed_posedirs_bwd(self):
         dev = self.posedirs.device

@@ -1500,7 +1500,53 @@ extern "C" int dposer_lbs_forward_temporal_grad(dposer_body_t h, void* ws, const
 // Backward of linear blend skinning + forward kinematics (d verts, d joints -> d pose, d rest joints, d v_shaped)
 // needed by the fitting loops that differentiate through the body model (run/motion_denoising.py:217-218,255-267).
 // ------------------------------------------------------------------------------------------------
+// Gradients of the vertex-selected extra joints and of the barycentric landmarks (smplx VertexJointSelector / vertices2landmarks:
+// rows J ... of the joint output are gathers / 3-term combinations of vertices) folded into the vertex gradient WITHOUT touching the
+// caller's d_verts: k_fold_rows writes the corrected rows of the <= n_extra + 3 n_landmarks vertices they touch into a compact
+// [B][U][3] array (d_verts row + sum over the vertex's entries, in table order: deterministic), and every kernel below that reads a
+// vertex gradient goes through VertGrad::row(), which picks the corrected row where the vertex has a slot.  (Round 3-4: the Python
+// wrapper did this with torch.matmul -- a hipBLASLt launch -- plus index / index_put kernels, and wrote into autograd's incoming
+// gradient in place.)
+struct FoldArgs {
+    const int32_t* vslot;      // [V]: slot u of vertex v in the compact array, or -1; null: no fold
+    const int32_t* uniq;       // [U] vertex of slot u
+    const int32_t* ptr;        // [U + 1] entries of slot u
+    const int32_t* row;        // [n] row of d_joints the entry gathers from (absolute: >= J)
+    const float* w;            // [n] its weight (1 for an extra joint, a barycentric coordinate for a landmark)
+    int U;
+};
+struct VertGrad {
+    const float* dverts;       // [B][V][3] (the caller's, read-only)
+    const int32_t* vslot;      // or null
+    const float* fixed;        // [B][U][3] corrected rows
+    int U;
+    __device__ __forceinline__ const float* row(int64_t b, int v, int V) const {
+        if (vslot) {
+            const int u = vslot[v];
+            if (u >= 0) return fixed + (b * U + u) * 3;
+        }
+        return dverts + (b * V + v) * 3;
+    }
+};
+__global__ void __launch_bounds__(64) k_fold_rows(FoldArgs f, const float* __restrict__ dverts, const float* __restrict__ djoints, int64_t ld_j,
+                                                  float* __restrict__ fixed, int V, int64_t B) {
+    const int u = blockIdx.x * 64 + threadIdx.x;
+    const int64_t b = blockIdx.y;
+    if (u >= f.U || b >= B) return;
+    const float* dv = dverts + (b * V + f.uniq[u]) * 3;
+    float acc[3] = {dv[0], dv[1], dv[2]};
+    for (int e = f.ptr[u]; e < f.ptr[u + 1]; ++e) {
+        const float* dj = djoints + b * ld_j + (int64_t)f.row[e] * 3;
+        const float w = f.w[e];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] += w * dj[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fixed[(b * f.U + u) * 3 + k] = acc[k];
+}
+
 struct SkinBwdArgs {
+    VertGrad vg;
     const float* dverts;       // [B][V][3]
     const float* offsets;      // [B][ld_off] (forward workspace)
     int64_t ld_off;
@@ -1530,7 +1576,7 @@ __global__ void __launch_bounds__(256) k_skin_bwd(SkinBwdArgs a) {
         if (v < a.V) {
             const float* vs = a.v_shaped + (a.v_shaped_batched ? b * a.V * 3 : 0) + (int64_t)v * 3;
             const float* off = a.offsets + b * a.ld_off + (int64_t)v * 3;
-            const float* dv = a.dverts + (b * a.V + v) * 3;
+            const float* dv = a.vg.row(b, v, a.V);
             float T[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) T[i] = 0.f;
@@ -1600,6 +1646,7 @@ __global__ void __launch_bounds__(256) k_skin_bwd(SkinBwdArgs a) {
 //  latency-bound on its two dependent global loads per entry: 1.53 ms.)
 constexpr int JL_MAXV = 256, JL_MAXE = 2048;
 struct JointBwdArgs {
+    VertGrad vg;
     const float* dverts;
     const float* vp;
     const int32_t* vstart;     // [chunks + 1]
@@ -1626,7 +1673,7 @@ __global__ void __launch_bounds__(256) k_skin_bwd_joints(JointBwdArgs a) {
         const int e0 = a.cfirst[c], ne = a.cfirst[c + 1] - e0;
         for (int k = threadIdx.x; k < nv * 3; k += 256) {
             const int l = k / 3, r = k - 3 * l;
-            reinterpret_cast<float*>(&sdv[l])[r] = dvb[(int64_t)v0 * 3 + k];
+            reinterpret_cast<float*>(&sdv[l])[r] = a.vg.vslot ? a.vg.row(b, v0 + l, a.V)[r] : dvb[(int64_t)v0 * 3 + k];
             reinterpret_cast<float*>(&svp[l])[r] = vpb[(int64_t)v0 * 3 + k];
         }
         if ((int)threadIdx.x < nv) reinterpret_cast<float*>(&svp[threadIdx.x])[3] = 1.0f;
@@ -1674,6 +1721,7 @@ __global__ void __launch_bounds__(256) k_skin_bwd_joints(JointBwdArgs a) {
 // streaming kernel above gives a pose ONE block that walks 41 chunks: ~300 us however few poses there are; this one takes 20 us
 // at 60 poses and loses above ~1500, where its 2 x 12 B gathers per entry from L2 become the bound: 1152 vs 732 us at 4096).
 struct JointGatherArgs {
+    VertGrad vg;
     const float* dverts;
     const float* vp;
     const int32_t* jptr;       // [J+1] CSR by joint
@@ -1697,7 +1745,7 @@ __global__ void __launch_bounds__(128) k_skin_bwd_joints_gather(JointGatherArgs 
     for (int e = a.jptr[j] + threadIdx.x; e < a.jptr[j + 1]; e += 128) {
         const int v = a.jvidx[e];
         const float w = a.jw[e];
-        const float* dv = a.dverts + (b * a.V + v) * 3;
+        const float* dv = a.vg.row(b, v, a.V);
         const float* p = a.vp + (b * a.V + v) * 3;
         const float h[4] = {p[0], p[1], p[2], 1.0f};
 #pragma unroll
@@ -1727,6 +1775,7 @@ __global__ void __launch_bounds__(128) k_skin_bwd_joints_gather(JointGatherArgs 
 // order, segments in order, chunks in order: deterministic (and different from k_skin_bwd_joints' by rounding only).
 constexpr int FUSED_MAXSEG = 128, FUSED_MAXE = 1024;
 struct SkinBwdFusedArgs {
+    VertGrad vg;
     const float* dverts;       // [B][V][3]
     const float* offsets;      // [B][ld_off]
     int64_t ld_off;
@@ -1776,8 +1825,9 @@ __global__ void __launch_bounds__(256) k_skin_bwd_fused(SkinBwdFusedArgs a) {
     auto load_vertex = [&](int c) __attribute__((always_inline)) {
         const int v = c * 256 + tid;
         const int vc = v < a.V ? v : a.V - 1;
+        const float* dvr = a.vg.vslot ? a.vg.row(b, vc, a.V) : dv_row + (int64_t)vc * 3;     // (corrected row where a landmark / extra joint touches the vertex)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { dv[k] = dv_row[(int64_t)vc * 3 + k]; pp[k] = vs_row[(int64_t)vc * 3 + k] + off_row[(int64_t)vc * 3 + k]; }
+        for (int k = 0; k < 3; ++k) { dv[k] = dvr[k]; pp[k] = vs_row[(int64_t)vc * 3 + k] + off_row[(int64_t)vc * 3 + k]; }
         w4 = *reinterpret_cast<const f32x4*>(a.skin_w + (int64_t)vc * 4);
         j4 = *reinterpret_cast<const int4*>(a.skin_idx + (int64_t)vc * 4);
     };
@@ -2349,7 +2399,21 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
                                    const int32_t* joint_vidx, const float* joint_w, const float* d_verts, const float* d_joints,
                                    int64_t d_joints_ld, float* const* d_pose_segments_host, float* d_jrest, float* d_vposed,
                                    int64_t batch, void* stream) {
+    return dposer_lbs_backward_fold(h, ws_fwd, ws_bwd, posedirs_bwd_packed, pose_segments_host, segment_joints_host, num_segments, j_rest, j_rest_batched,
+                                    v_shaped, v_shaped_batched, skin_idx, skin_w, skin_k, joint_ptr, joint_vidx, joint_w, d_verts, d_joints, d_joints_ld,
+                                    nullptr, d_pose_segments_host, d_jrest, d_vposed, batch, stream);
+}
+extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
+                                        const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,
+                                        const float* j_rest, int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched,
+                                        const int32_t* skin_idx, const float* skin_w, int32_t skin_k, const int32_t* joint_ptr,
+                                        const int32_t* joint_vidx, const float* joint_w, const float* d_verts, const float* d_joints,
+                                        int64_t d_joints_ld, const dposer_lbs_joint_fold* fold, float* const* d_pose_segments_host, float* d_jrest,
+                                        float* d_vposed, int64_t batch, void* stream) {
     DP_RANGE();
+    DP_CHECK_ARG(!fold || (fold->n_slots >= 0 && fold->n_slots <= h->d.num_vertices && (fold->n_slots == 0 || (fold->vertex_slot && fold->slot_vertex &&
+                                                                                     fold->slot_ptr && fold->entry_row && fold->entry_weight))),
+                 "bad joint fold tables");
     DP_CHECK_ARG(h && ws_fwd && ws_bwd && posedirs_bwd_packed && pose_segments_host && segment_joints_host && j_rest && v_shaped && skin_idx &&
                      skin_w && joint_ptr && joint_vidx && joint_w && d_verts && d_joints && d_pose_segments_host,
                  "null argument");
@@ -2365,7 +2429,8 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
     const float* offsets = (const float*)((const char*)A + round_up(batch * J * 12 * 4, 256));
     char* p = (char*)ws_bwd;
     float* vp = (float*)p; p += round_up(batch * V * 3 * 4, 256);
-    p += round_up(batch * V * 3 * 4, 256);                              // (was: scratch for d v_posed; kept so that the layout is unchanged)
+    float* dv_fixed = (float*)p;                                        // [B][U][3] corrected vertex-gradient rows of the joint fold (U <= V)
+    p += round_up(batch * V * 3 * 4, 256);
     float* doff = (float*)p; p += round_up(Bpad * Cpad * 4, 256);
     float* dA = (float*)p; p += round_up(batch * J * 12 * 4, 256);
     float* dG = (float*)p; p += round_up(batch * J * 12 * 4, 256);
@@ -2375,6 +2440,15 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
     const bool blend32 = lbs_blend_fp32();
     __bf16* doff_hi = reinterpret_cast<__bf16*>(doff);                  // bf16 x 3: the two terms share the FT32 operand's bytes
     __bf16* doff_lo = doff_hi + Bpad * Cpad;
+    VertGrad vg;
+    vg.dverts = d_verts; vg.vslot = nullptr; vg.fixed = dv_fixed; vg.U = 0;
+    if (fold && fold->n_slots > 0) {
+        FoldArgs f;
+        f.vslot = fold->vertex_slot; f.uniq = fold->slot_vertex; f.ptr = fold->slot_ptr; f.row = fold->entry_row; f.w = fold->entry_weight; f.U = fold->n_slots;
+        hipLaunchKernelGGL(k_fold_rows, dim3((unsigned)ceil_div(f.U, 64), (unsigned)batch), dim3(64), 0, st, f, d_verts, d_joints, d_joints_ld, dv_fixed, V, batch);
+        FK_HIP_LAUNCH(hipGetLastError());
+        vg.vslot = fold->vertex_slot; vg.U = fold->n_slots;
+    }
     const bool fused = !blend32 && skin_k == 4 && h->jl_ready && h->jl_fused_ok && batch >= lbs_joint_stream_min() && body_tuning().skin_bwd_fused;
     if (fused && (int64_t)h->jl_chunks * 768 >= Cpad) {
         // the fused kernel writes every coordinate column of every pose: only the 32-row groups that hold padding rows need zeros (a
@@ -2389,6 +2463,7 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
     }
     if (fused) {
         SkinBwdFusedArgs a;
+        a.vg = vg;
         a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
         a.skin_idx = skin_idx; a.skin_w = skin_w; a.J = J; a.V = V; a.dvp = d_vposed; a.doff_hi = doff_hi; a.doff_lo = doff_lo; a.Cpad = (int)Cpad;
         a.cfirst = h->jl_first; a.entry = h->jl_entry; a.seg = reinterpret_cast<const int2*>(h->jl_seg); a.nseg = h->jl_nseg; a.jseg = h->jl_jseg;
@@ -2397,6 +2472,7 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
         FK_HIP_LAUNCH(hipGetLastError());
     } else {
         SkinBwdArgs a;
+        a.vg = vg;
         a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
         a.skin_idx = skin_idx; a.skin_w = skin_w; a.K = skin_k; a.J = J; a.V = V; a.vp = vp; a.dvp = d_vposed;
         a.doff_ft = blend32 ? doff : nullptr; a.doff_hi = doff_hi; a.doff_lo = doff_lo;
@@ -2407,11 +2483,13 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
     if (!fused) {
         if (batch >= lbs_joint_stream_min() && h->jl_ready) {
             JointBwdArgs a;
+            a.vg = vg;
             a.dverts = d_verts; a.vp = vp; a.vstart = h->jl_vstart; a.cptr = h->jl_ptr; a.cfirst = h->jl_first; a.entry = h->jl_entry; a.dA = dA;
             a.J = J; a.V = V; a.chunks = h->jl_chunks; a.B = batch;
             hipLaunchKernelGGL(k_skin_bwd_joints, dim3((unsigned)batch), dim3(256), 0, st, a);
         } else {
             JointGatherArgs a;
+            a.vg = vg;
             a.dverts = d_verts; a.vp = vp; a.jptr = joint_ptr; a.jvidx = joint_vidx; a.jw = joint_w; a.dA = dA; a.J = J; a.V = V; a.B = batch;
             hipLaunchKernelGGL(k_skin_bwd_joints_gather, dim3((unsigned)(ceil_div(batch, 8) * 8 * J)), dim3(128), 0, st, a);
         }

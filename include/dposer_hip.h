@@ -406,6 +406,29 @@ int dposer_lbs_prepare_joint_lists(dposer_body_t h, const int32_t* joint_ptr, co
 void dposer_body_tuning_reload(void);
 int64_t dposer_lbs_posedirs_bwd_packed_bytes(dposer_body_t h);
 int dposer_lbs_pack_posedirs_bwd(dposer_body_t h, const float* posedirs, void* packed, void* stream);
+/* dposer_lbs_backward_fold: dposer_lbs_backward + the backward of the joint rows that are functions of VERTICES -- smplx
+ *   VertexJointSelector (row J + e = vertex extra_vertex_ids[e]) and vertices2landmarks (row J + n_extra + l = barycentric combination of
+ *   the three vertices of landmark l; called from lib/body_model/body_model.py:75-88 through smplx.SMPLX.forward): their gradients
+ *   d_joints[:, J:] are added to the gradient of the vertices they read.  `fold` (device tables, built once per asset by the caller):
+ *     vertex_slot [V]   slot u of the vertex, or -1;      slot_vertex [n_slots]   the vertex of slot u;
+ *     slot_ptr [n_slots + 1], entry_row [n], entry_weight [n]: slot u receives sum_e entry_weight[e] * d_joints[:, entry_row[e]] over
+ *     e in [slot_ptr[u], slot_ptr[u + 1]), added in that order (deterministic).
+ *   d_verts is only READ (the corrected rows live in ws_bwd); fold == NULL is dposer_lbs_backward. */
+typedef struct dposer_lbs_joint_fold {
+    const int32_t* vertex_slot;
+    const int32_t* slot_vertex;
+    const int32_t* slot_ptr;
+    const int32_t* entry_row;
+    const float* entry_weight;
+    int32_t n_slots;
+} dposer_lbs_joint_fold;
+int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
+                             const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,
+                             const float* j_rest, int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched,
+                             const int32_t* skin_idx, const float* skin_w, int32_t skin_k, const int32_t* joint_ptr,
+                             const int32_t* joint_vidx, const float* joint_w, const float* d_verts, const float* d_joints,
+                             int64_t d_joints_ld, const dposer_lbs_joint_fold* fold, float* const* d_pose_segments_host, float* d_jrest,
+                             float* d_vposed, int64_t batch, void* stream);
 int64_t dposer_lbs_backward_workspace_bytes(dposer_body_t h, int64_t batch);
 int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
                         const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,

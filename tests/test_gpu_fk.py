@@ -416,6 +416,54 @@ def test_fused_skinning_backward_agrees_with_the_two_kernel_path(bm, monkeypatch
     assert not np.array_equal(fused[0], two[0])        # (it really is the other kernel)
 
 
+@pytest.mark.parametrize("stream_min", ["1", None])       # the fused streaming kernel forced onto the small batch / the small-batch kernels
+def test_landmark_and_extra_joint_gradients_are_folded_inside_the_library(bm, asset, monkeypatch, stream_min):
+    """d_joints[:, J:] (vertex-selected extra joints, barycentric landmarks) reaches the pose through dposer_lbs_backward_fold: a loss on
+    those rows ONLY against the fp64 oracle, and the incoming vertex gradient -- autograd's tensor -- is bit-unchanged while the call
+    runs (copied out on a second stream, unsynchronised with the first) and after it.  (Rounds 3-4 added the fold to that tensor in
+    place with torch ops and restored it afterwards.)"""
+    from oracle import fk_torch
+    if stream_min:
+        monkeypatch.setenv("DPOSER_LBS_JOINT_STREAM_MIN", stream_min)
+    _reload_tuning()
+    try:
+        B, J = 12, 55
+        rs = np.random.RandomState(31)
+        pose = (rs.standard_normal((B, 63)) * 0.4).astype(np.float32)
+        wj = rs.standard_normal((B, 127, 3)).astype(np.float32)
+        wj[:, :J] = 0.0
+        p = torch.tensor(pose, device=DEV, requires_grad=True)
+        out = bm(pose_body=p)
+        gv = torch.tensor(rs.standard_normal((B, 10475, 3)).astype(np.float32) / 50.0, device=DEV)
+        gj = torch.tensor(wj, device=DEV)
+        gv0 = gv.clone()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        torch.autograd.backward([out.v, out.Jtr], [gv, gj])          # enqueues the backward kernels on the current stream ...
+        with torch.cuda.stream(side):
+            during = gv.clone()                                      # ... while this copy races them on another one
+        torch.cuda.synchronize()
+        assert torch.equal(during, gv0) and torch.equal(gv, gv0)
+        p_r = torch.tensor(pose, dtype=torch.float64, requires_grad=True)
+        v, j = fk_torch.smplx_forward(asset, p_r)
+        ((v * gv0.cpu().double()).sum() + (j * torch.tensor(wj, dtype=torch.float64)).sum()).backward()
+        err = float(np.linalg.norm(t2n(p.grad) - p_r.grad.numpy()) / np.linalg.norm(p_r.grad.numpy()))
+        assert err < 1e-5, err
+        # and the landmark rows alone (no vertex gradient at all): everything the pose receives came through the fold
+        p2 = torch.tensor(pose, device=DEV, requires_grad=True)
+        out2 = bm(pose_body=p2)
+        torch.autograd.backward([out2.v, out2.Jtr], [torch.zeros_like(gv), gj])
+        p_r2 = torch.tensor(pose, dtype=torch.float64, requires_grad=True)
+        _, j2 = fk_torch.smplx_forward(asset, p_r2)
+        (j2 * torch.tensor(wj, dtype=torch.float64)).sum().backward()
+        err2 = float(np.linalg.norm(t2n(p2.grad) - p_r2.grad.numpy()) / np.linalg.norm(p_r2.grad.numpy()))
+        assert err2 < 1e-5 and float(np.linalg.norm(p_r2.grad.numpy())) > 0, err2
+    finally:
+        if stream_min:
+            monkeypatch.delenv("DPOSER_LBS_JOINT_STREAM_MIN")
+        _reload_tuning()
+
+
 def test_dma_staged_fk_joints_returns_the_bits_of_the_general_kernel(bm, monkeypatch):
     """k_fk_joints_dma (full blocks of 64 poses of the 22-joint query: pose rows enter LDS by global_load_lds, joints leave as the
     [64][66] image) against k_fk_joints, with and without root orientation / translation; 209 poses = 3 full blocks + a tail of 17
