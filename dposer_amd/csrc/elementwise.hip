@@ -837,6 +837,35 @@ hipError_t launch_ft_transpose(int f32, const void* in, void* out, int64_t Spad,
     return hipGetLastError();
 }
 
+// ---- bf16 x 3 precision mode: an fp32 fragment-tiled matrix as two bf16 fragment-tiled planes ------------------------------------------
+// x = hi + lo + O(2^-17 |x|), hi = bf16(x), lo = bf16(x - hi): the operands of the three-term products hi*hi + lo*hi + hi*lo that the
+// bf16 matrix pipe accumulates in fp32 (scorefc.hip, precision DPOSER_PREC_BF16X3; the LBS blend GEMMs use the same split, fk.hip).
+// FT32 block (rb, kb): lane (kh, r) holds T[32 rb + r][8 kb + 4 kh + 0..3]; FT16 block (rb, kb'): lane (kh, r) holds
+// T[32 rb + r][16 kb' + 8 kh + 0..7] = the two lane halves' chunks of FT32 block (rb, 2 kb' + kh).  One thread = one 16-byte output chunk
+// per plane: two 16-byte reads (512 B apart, each a coalesced 512-B run per half-wave), two 16-byte writes (1 KiB runs).
+__global__ void __launch_bounds__(256) k_split_ft32(const float* __restrict__ src, __bf16* __restrict__ hi, __bf16* __restrict__ lo, int64_t n_chunks) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;           // output chunk: block (i >> 6), lane (i & 63)
+    if (i >= n_chunks) return;
+    const int64_t blk = i >> 6;
+    const int lane = (int)(i & 63), kh = lane >> 5, r = lane & 31;
+    const float* s = src + ((2 * blk + kh) << 8);                         // FT32 block (rb, 2 kb' + kh): 256 floats; (rb * K/16 + kb') * 2 + kh
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s + r * 4), b = *reinterpret_cast<const f32x4*>(s + (32 + r) * 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    __bf16 h8[8], l8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h8[e] = (__bf16)v[e];
+        l8[e] = (__bf16)(v[e] - (float)h8[e]);
+    }
+    *reinterpret_cast<u32x4*>(hi + i * 8) = *reinterpret_cast<const u32x4*>(h8);
+    *reinterpret_cast<u32x4*>(lo + i * 8) = *reinterpret_cast<const u32x4*>(l8);
+}
+hipError_t launch_split_ft32(const void* src, void* hi, void* lo, int64_t rows_pad, int K, hipStream_t st) {
+    const int64_t n_chunks = rows_pad * (int64_t)K / 8;                  // (rows_pad % 32 == 0, K % 16 == 0: whole FT16 blocks)
+    hipLaunchKernelGGL(k_split_ft32, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st, (const float*)src, (__bf16*)hi, (__bf16*)lo, n_chunks);
+    return hipGetLastError();
+}
+
 constexpr int COLSUM_CHUNK = 2048;   // samples per partial row
 template <typename T> __global__ void __launch_bounds__(256) k_colsum(const T* in, float* part, int64_t Spad, int C, SumJob sj) {
     if (blockIdx.y == gridDim.y - 1 && sj.n > 0) {      // rider: out[0] = sum(part[0..n)) -- k_sum_partials' order, one launch less

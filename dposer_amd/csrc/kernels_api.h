@@ -217,6 +217,8 @@ hipError_t launch_dres_from_dout(const DresArgs& a, hipStream_t st);
 // ---- layout helpers ---------------------------------------------------------------------------------
 // out FT [Cpad][Spad] = transpose of in FT [Spad][C]
 hipError_t launch_ft_transpose(int f32, const void* in, void* out, int64_t Spad, int C, hipStream_t st);
+// fp32 FT [rows_pad][K] -> bf16 FT planes hi = bf16(x), lo = bf16(x - hi) of the same shape (bf16 x 3 precision mode)
+hipError_t launch_split_ft32(const void* src, void* hi, void* lo, int64_t rows_pad, int K, hipStream_t st);
 // part[chunk][c] = sum over the chunk's samples of in[s][c];  returns number of chunks.  `rider` (optional): a list of partials summed
 // into out[0] by one extra block of the same launch (the DSM loss of the step: k_sum_partials' summation order, no launch of its own)
 struct SumJob {
