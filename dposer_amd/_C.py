@@ -11,7 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DPOSER_LIB_PATH") or os.path.join(_HERE, "libdposer_hip.so")      # (override: the host-ASan build of the tests)
 
-PREC_BF16, PREC_FP32 = 0, 1
+PREC_BF16, PREC_FP32, PREC_BF16X3 = 0, 1, 2
+PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
 EMB_POSITIONAL, EMB_FOURIER = 0, 1
 ACTIVATIONS = {"swish": 0, "elu": 1, "relu": 2, "lrelu": 3}      # config.model.nonlinearity -> DPOSER_ACT_*
 SDE_SUBVP, SDE_VP = 0, 1

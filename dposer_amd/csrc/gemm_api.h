@@ -17,7 +17,9 @@ static inline int shape_ct(int s) { static const int v[] = {8, 4, 4, 2, 2, 4}; r
 static inline int shape_st(int s) { static const int v[] = {8, 4, 1, 4, 1, 2}; return v[s]; }   // 32-sample tiles / block
 static inline int shape_ws(int s) { static const int v[] = {4, 2, 1, 4, 1, 2}; return v[s]; }   // waves along samples
 
-enum : int { PREC_BF16 = 0, PREC_FP32 = 1 };
+// PREC_BF16X3: the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) under the fp32-storage epilogues -- the caller hands the operands as bf16
+// hi / lo planes (three K segments per term against weights packed [hi | lo | hi]); instantiated in gemm_launch_x3.hip
+enum : int { PREC_BF16 = 0, PREC_FP32 = 1, PREC_BF16X3 = 2 };
 
 // gs = channels per GroupNorm group (hidden_dim / 32): 32 = the shipped tile-per-group epilogues; 16 / 64 = the generic ones (128x128 and 128x32 tilings)
 hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st, int gs = 32);
@@ -72,7 +74,13 @@ hipError_t launch_sampler_cluster(int prec, const SamplerArgs& a, int sync, hipS
 
 // ---- optional per-launch profiling (HIP events on the launch stream; off by default) ------------------
 enum GemmEpiKind : int { EPI_GN = 0, EPI_GN_TRAIN, EPI_BIAS_SILU, EPI_ROWMAJOR, EPI_PLAIN_FT, EPI_GN_BWD, EPI_SILU_BWD, EPI_WGRAD, EPI_EM_STEP, EPI_DSM_STEP, EPI_KINDS };
-constexpr int GEMM_PROF_KINDS = EPI_KINDS * 2 * 6;
+constexpr int GEMM_PROF_KINDS = EPI_KINDS * 3 * 6;      // (epilogue kind, precision, tiling)
+// bf16x3 entry points (gemm_launch_x3.hip): the dispatchers of gemm_launch.hip forward prec == PREC_BF16X3 here
+hipError_t gemm_gn_x3(bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st);
+hipError_t gemm_bias_silu_x3(bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st);
+hipError_t gemm_em_step_x3(int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st);
+hipError_t gemm_partial_ft_x3(int shape, const GemmArgs& g, const PartialFTParams& p, hipStream_t st);
+hipError_t gemm_gn_bwd_x3(int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st);
 void gemm_prof_enable(int on);
 // synchronises the recorded events, accumulates them per kind and clears the record list
 int gemm_prof_collect(double* ms, long long* launches, double* flops);   // arrays of GEMM_PROF_KINDS

@@ -20,7 +20,7 @@ struct ProfScope {
     ProfRec* r = nullptr;
     hipStream_t st;
     ProfScope(int kind, double alg_flops, hipStream_t s) : st(s) {
-        if (!g_prof.enabled || (g_prof.only >= 0 && kind / 12 != g_prof.only)) return;
+        if (!g_prof.enabled || (g_prof.only >= 0 && kind / 18 != g_prof.only)) return;
         if (g_prof.used == g_prof.pool.size()) {
             ProfRec n;
             if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
@@ -55,10 +55,10 @@ int gemm_prof_collect(double* ms, long long* launches, double* flops) {
     return 0;
 }
 void gemm_prof_kind_name(int kind, char* out, int n) {
-    const int epi = kind / 12, prec = (kind / 6) % 2, shape = kind % 6;
-    snprintf(out, n, "gemm_ft_kernel<%s,%s,%s>", prec ? "fp32" : "bf16", kShapeNames[shape], kEpiNames[epi]);
+    const int epi = kind / 18, prec = (kind / 6) % 3, shape = kind % 6;
+    snprintf(out, n, "gemm_ft_kernel<%s,%s,%s>", prec == PREC_FP32 ? "fp32" : (prec == PREC_BF16X3 ? "bf16x3" : "bf16"), kShapeNames[shape], kEpiNames[epi]);
 }
-#define PROF(EPI) ProfScope _ps((EPI) * 12 + (prec == PREC_FP32 ? 6 : 0) + shape, g.alg_flops, st)
+#define PROF(EPI) ProfScope _ps((EPI) * 18 + prec * 6 + shape, g.alg_flops, st)
 
 
 // Each epilogue only instantiates the tilings it is used with (bit i = GemmShape i).
@@ -108,6 +108,7 @@ static hipError_t by_shape_generic(int shape, const GemmArgs& g, const typename 
 
 hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st, int gs) {
     PROF(train ? EPI_GN_TRAIN : EPI_GN);
+    if (prec == PREC_BF16X3) return (gs == 32 && p.act == DP_ACT_SWISH) ? gemm_gn_x3(train, shape, g, p, st) : hipErrorInvalidConfiguration;
     if (gs != 32) {
 #define E_TRAIN(T, GS) EpiGNG<T, true, GS>
 #define E_INFER(T, GS) EpiGNG<T, false, GS>
@@ -124,6 +125,7 @@ hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNP
 }
 hipError_t gemm_bias_silu(int prec, bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st) {
     PROF(EPI_BIAS_SILU);
+    if (prec == PREC_BF16X3) return p.act == DP_ACT_SWISH ? gemm_bias_silu_x3(train, shape, g, p, st) : hipErrorInvalidConfiguration;
     if (p.act != DP_ACT_SWISH) {
         if (train) { typedef EpiBiasSiLU<__bf16, true, true> A; typedef EpiBiasSiLU<float, true, true> B; DISPATCH(A, B, M_MID | M_SMALL); }
         typedef EpiBiasSiLU<__bf16, false, true> A; typedef EpiBiasSiLU<float, false, true> B; DISPATCH(A, B, M_MID | M_SMALL);
@@ -133,14 +135,17 @@ hipError_t gemm_bias_silu(int prec, bool train, int shape, const GemmArgs& g, co
 }
 hipError_t gemm_rowmajor(int prec, int shape, const GemmArgs& g, const RowMajorParams& p, hipStream_t st) {
     PROF(EPI_ROWMAJOR);
+    if (prec == PREC_BF16X3) return by_shape_masked<__bf16, EpiRowMajor<__bf16>, M_MID | M_SMALL | M_FINAL | M_FINAL_S>(shape, g, p, st);   // (fp32 row-major output whatever the operands: the bf16 instantiation)
     typedef EpiRowMajor<__bf16> A; typedef EpiRowMajor<float> B; DISPATCH(A, B, M_MID | M_SMALL | M_FINAL | M_FINAL_S);
 }
 hipError_t gemm_em_step(int prec, int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st) {
     PROF(EPI_EM_STEP);
+    if (prec == PREC_BF16X3) return gemm_em_step_x3(shape, g, p, st);
     typedef EpiEmStep<__bf16> A; typedef EpiEmStep<float> B; DISPATCH(A, B, M_FINAL | M_FINAL_S);
 }
 hipError_t gemm_partial_ft(int prec, int shape, const GemmArgs& g, const PartialFTParams& p, hipStream_t st) {
     PROF(EPI_PLAIN_FT);
+    if (prec == PREC_BF16X3) return gemm_partial_ft_x3(shape, g, p, st);
     typedef EpiPartialFT<__bf16> A; typedef EpiPartialFT<float> B; DISPATCH(A, B, M_MID);
 }
 hipError_t gemm_dsm_step(int prec, int shape, const GemmArgs& g, const DsmStepParams& p, hipStream_t st) {
@@ -153,6 +158,7 @@ hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTPa
 }
 hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st, int gs) {
     PROF(EPI_GN_BWD);
+    if (prec == PREC_BF16X3) return (gs == 32 && p.act == DP_ACT_SWISH) ? gemm_gn_bwd_x3(shape, g, p, st) : hipErrorInvalidConfiguration;
     if (gs != 32) {
 #define E_BWD(T, GS) EpiGNBwdG<T, GS>
         if (gs == 16) { DISPATCH_GS(E_BWD, 16); }
@@ -168,11 +174,11 @@ hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdPa
     typedef EpiSiLUBwd<__bf16> A; typedef EpiSiLUBwd<float> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_wgrad_tr_batch(const WgradBatchArgs& a, hipStream_t st) {
-    ProfScope _ps(EPI_WGRAD * 12 + SHAPE_BIG, a.alg_flops, st);
+    ProfScope _ps(EPI_WGRAD * 18 + SHAPE_BIG, a.alg_flops, st);
     return launch_wgrad_tr_batch<2, 4, 4, 2, 4>(a, st);
 }
 hipError_t gemm_wgrad_tr(int shape, const WgradTrArgs& g, const WgradParams& p, hipStream_t st) {
-    ProfScope _ps(EPI_WGRAD * 12 + shape, g.alg_flops, st);
+    ProfScope _ps(EPI_WGRAD * 18 + shape, g.alg_flops, st);
     if (shape == SHAPE_BIG) return launch_wgrad_tr<2, 4, 4, 2, 4>(g, p, st);
     if (shape == SHAPE_MID) return launch_wgrad_tr<2, 2, 2, 2, 4>(g, p, st);
     if (shape == SHAPE_FINAL) return launch_wgrad_tr<1, 4, 2, 1, 4>(g, p, st);

@@ -1,0 +1,44 @@
+// bf16 x 3 precision mode (DPOSER_PREC_BF16X3): instantiations of gemm_ft_kernel whose K loop runs on the bf16 matrix pipe
+// (v_mfma_f32_32x32x16_bf16, the hand-placed ring stages of gemm_kloop_asm.h) while the epilogue is the fp32 mode's -- precise
+// GroupNorm / SiLU arithmetic, activations stored as fp32 fragment tiles.  The caller (scorefc.hip) hands every operand as its two bf16
+// planes (hi = bf16(x), lo = bf16(x - hi), k_split_ft32) in three K segments against weights packed [hi | lo | hi]: three matrix-pipe
+// products per term, fp32 accumulation -- reference-precision results at a third of the bf16 rate instead of a sixteenth.
+// Own translation unit: the instantiations compile next to gemm_launch.hip's, not behind them.
+#include "gemm_api.h"
+
+#ifndef DPOSER_RING_KB
+#define DPOSER_RING_KB 2
+#define DPOSER_RING_NB 4
+#endif
+namespace {
+constexpr int RING_KB = DPOSER_RING_KB, RING_NB = DPOSER_RING_NB;
+template <typename Epi>
+hipError_t main_shapes(int shape, const GemmArgs& g, const typename Epi::Params& p, hipStream_t st) {
+    switch (shape) {
+        case SHAPE_BIG: return launch_gemm<__bf16, 2, 4, 4, 2, RING_KB, Epi, RING_NB>(g, p, st);
+        case SHAPE_MID: return launch_gemm<__bf16, 2, 2, 2, 2, RING_KB, Epi, RING_NB>(g, p, st);
+        case SHAPE_SMALL: return launch_gemm<__bf16, 4, 1, 1, 1, 4, Epi>(g, p, st);
+    }
+    return hipErrorInvalidConfiguration;
+}
+}   // namespace
+
+hipError_t gemm_gn_x3(bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st) {
+    if (train) return main_shapes<EpiGN<float, true>>(shape, g, p, st);
+    return main_shapes<EpiGN<float, false>>(shape, g, p, st);
+}
+hipError_t gemm_bias_silu_x3(bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st) {
+    if (train) return main_shapes<EpiBiasSiLU<float, true>>(shape, g, p, st);
+    return main_shapes<EpiBiasSiLU<float, false>>(shape, g, p, st);
+}
+hipError_t gemm_em_step_x3(int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st) {
+    if (shape == SHAPE_FINAL) return launch_gemm<__bf16, 1, 4, 2, 1, RING_KB, EpiEmStep<float>, RING_NB>(g, p, st);
+    if (shape == SHAPE_FINAL_S) return launch_gemm<__bf16, 2, 1, 1, 1, RING_KB, EpiEmStep<float>, RING_NB>(g, p, st);
+    return hipErrorInvalidConfiguration;
+}
+hipError_t gemm_partial_ft_x3(int shape, const GemmArgs& g, const PartialFTParams& p, hipStream_t st) {
+    return main_shapes<EpiPartialFT<__bf16>>(shape, g, p, st);     // (fp32 partial tiles whatever the operand type)
+}
+hipError_t gemm_gn_bwd_x3(int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st) {
+    return main_shapes<EpiGNBwd<float>>(shape, g, p, st);
+}

@@ -72,8 +72,11 @@ struct dposer_scorefc_s {
     dposer_scorefc_desc d;
     int D, Dpad, H, E, L, Cp;
     int gs;                    // channels per GroupNorm group = H / 32
-    bool f32;
-    int esz, KBS;
+    bool f32;                  // activations live in HBM as fp32 fragment tiles (precision fp32 AND bf16x3)
+    bool x3;                   // DPOSER_PREC_BF16X3: GEMMs on the bf16 matrix pipe over hi / lo operand planes (three products per term), fp32 everywhere else
+    bool w32;                  // packed weights are fp32 and the GEMMs run the exact-fp32 MFMA (precision fp32 only)
+    int esz, KBS;              // bytes per stored activation element; k-block of the GEMM operands (8 fp32 / 16 bf16)
+    int wk;                    // K multiplier of the packed weights: 3 in bf16x3 mode ([hi | lo | hi] per K segment), else 1
     std::vector<int64_t> toff, tnum;
     LayerOff layer[MAX_L];
     int64_t off_cond_w, off_cond_b, off_gauss, off_se_w, off_se_b, off_post_w, off_post_b;
@@ -83,7 +86,7 @@ struct dposer_scorefc_s {
     // packed workspace (byte offsets)
     int64_t pk_wse, pk_wl[MAX_L], pk_wpost, pk_bias_cat, pk_wt_all32, pk_wse32, pk_fwd_end;
     int64_t pk_wpostT, pk_wlT[MAX_L], pk_wtT_all, pk_bwd_end;
-    PackJobs fwd_jobs, bwd_jobs;
+    std::vector<PackJob> fwd_jobs, bwd_jobs;
     BiasCatJobs bias_jobs;
     const unsigned char* dbg_keep = nullptr;   // test hook: injected dropout keep decisions [L][dbg_keep_batch][H] (device), see drop_cfg
     int64_t dbg_keep_batch = 0;
@@ -112,7 +115,9 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
     DP_CHECK_ARG(desc->embed_dim > 0 && desc->embed_dim % 128 == 0, "embed_dim must be a multiple of 128");
     DP_CHECK_ARG(desc->n_blocks >= 1 && desc->n_blocks <= 3, "n_blocks must be 1..3");
     DP_CHECK_ARG(desc->data_dim > 0 && desc->data_dim <= 512, "data_dim must be in 1..512");
-    DP_CHECK_ARG(desc->precision == DPOSER_PREC_BF16 || desc->precision == DPOSER_PREC_FP32, "bad precision");
+    DP_CHECK_ARG(desc->precision == DPOSER_PREC_BF16 || desc->precision == DPOSER_PREC_FP32 || desc->precision == DPOSER_PREC_BF16X3, "bad precision");
+    DP_CHECK_ARG(desc->precision != DPOSER_PREC_BF16X3 || (desc->hidden_dim == 1024 && desc->activation == DPOSER_ACT_SWISH),
+                 "precision bf16x3 is built for hidden_dim 1024 / swish (the tile-per-group epilogues)");
     DP_CHECK_ARG(desc->dropout_p >= 0.f && desc->dropout_p < 1.f, "dropout_p must be in [0,1)");
     DP_CHECK_ARG(desc->activation >= DPOSER_ACT_SWISH && desc->activation <= DPOSER_ACT_LRELU, "bad activation");
     DP_CHECK_ARG(desc->activation == DPOSER_ACT_SWISH || desc->hidden_dim == 1024,
@@ -126,9 +131,12 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
     h->gs = desc->hidden_dim / 32;
     h->E = desc->embed_dim;
     h->L = 1 + 2 * desc->n_blocks;
-    h->f32 = desc->precision == DPOSER_PREC_FP32;
+    h->x3 = desc->precision == DPOSER_PREC_BF16X3;
+    h->w32 = desc->precision == DPOSER_PREC_FP32;
+    h->f32 = h->w32 || h->x3;
     h->esz = h->f32 ? 4 : 2;
-    h->KBS = h->f32 ? 8 : 16;
+    h->KBS = h->w32 ? 8 : 16;
+    h->wk = h->x3 ? 3 : 1;
     const int D = h->D, H = h->H, E = h->E, L = h->L;
 
     // ---- flat parameter layout = ScoreModelFC.parameters() order (model.py:98-139) ----------------
@@ -156,45 +164,64 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
     if (h->off_gauss >= 0) { h->nograd_lo[1] = h->off_gauss; h->nograd_hi[1] = h->off_gauss + E / 2; h->n_nograd = 2; }
 
     // ---- packed workspace ----------------------------------------------------------------------------
-    const int esz = h->esz, f = h->f32 ? 1 : 0;
+    // bf16x3: every GEMM weight matrix is packed as THREE bf16 column groups per K segment, [hi | lo | hi] (hi = bf16(w), lo =
+    // bf16(w - hi)), against activation segments (x_hi, x_hi, x_lo): w x ~ hi hi + lo hi + hi lo, fp32 accumulation (lo lo and the split
+    // residuals are <= 2^-16 of a product).  The fp32 copies of the time branch (time-bias table GEMMs) exist in every mode.
+    const int esz = h->w32 ? 4 : 2, f = h->w32 ? 1 : 0, wk = h->wk;
     int64_t p = 0;
-    h->fwd_jobs.n = 0;
-    auto push = [&](PackJobs& js, const PackJob& j) { js.job[js.n++] = j; };
-    h->pk_wse = p; p = align256(p + (int64_t)E * E * esz);
-    push(h->fwd_jobs, mk_job(h->pk_wse, h->off_se_w, E, 0, E, E, E, E, E, 0, f));
+    h->fwd_jobs.clear();
+    h->bwd_jobs.clear();
+    // one logical job = wk jobs in bf16x3 mode: column group g of segment [koff, koff + kpad) lands at wk * koff + g * kpad
+    auto push = [&](std::vector<PackJob>& js, int64_t dst, int64_t src, int ktot, int koff, int rows_pad, int kpad, int rows_valid, int cols_valid,
+                    int ld, int trans, int f32) {
+        if (!h->x3 || f32) { js.push_back(mk_job(dst, src, ktot, koff, rows_pad, kpad, rows_valid, cols_valid, ld, trans, f32)); return; }
+        for (int g = 0; g < 3; ++g) {
+            PackJob j = mk_job(dst, src, 3 * ktot, 3 * koff + g * kpad, rows_pad, kpad, rows_valid, cols_valid, ld, trans, 0);
+            j.split = g == 1 ? 2 : 1;
+            js.push_back(j);
+        }
+    };
+    h->pk_wse = p; p = align256(p + (int64_t)E * E * esz * wk);
+    push(h->fwd_jobs, h->pk_wse, h->off_se_w, E, 0, E, E, E, E, E, 0, f);
     for (int l = 0; l < L; ++l) {
         const LayerOff& lo = h->layer[l];
         const int ktot = lo.kin_pad + E;
-        h->pk_wl[l] = p; p = align256(p + (int64_t)H * ktot * esz);
-        push(h->fwd_jobs, mk_job(h->pk_wl[l], lo.w, ktot, 0, H, lo.kin_pad, H, lo.kin, lo.kin, 0, f));
-        push(h->fwd_jobs, mk_job(h->pk_wl[l], lo.wt, ktot, lo.kin_pad, H, E, H, E, E, 0, f));
+        h->pk_wl[l] = p; p = align256(p + (int64_t)H * ktot * esz * wk);
+        push(h->fwd_jobs, h->pk_wl[l], lo.w, ktot, 0, H, lo.kin_pad, H, lo.kin, lo.kin, 0, f);
+        push(h->fwd_jobs, h->pk_wl[l], lo.wt, ktot, lo.kin_pad, H, E, H, E, E, 0, f);
     }
-    h->pk_wpost = p; p = align256(p + (int64_t)h->Cp * H * esz);
-    push(h->fwd_jobs, mk_job(h->pk_wpost, h->off_post_w, H, 0, h->Cp, H, D, H, H, 0, f));
+    h->pk_wpost = p; p = align256(p + (int64_t)h->Cp * H * esz * wk);
+    push(h->fwd_jobs, h->pk_wpost, h->off_post_w, H, 0, h->Cp, H, D, H, H, 0, f);
     h->pk_bias_cat = p; p = align256(p + (int64_t)L * H * 4);
     h->bias_jobs.n = L; h->bias_jobs.H = H;
     for (int l = 0; l < L; ++l) { h->bias_jobs.a_off[l] = h->layer[l].b; h->bias_jobs.b_off[l] = h->layer[l].bt; }
     h->pk_wt_all32 = p; p = align256(p + (int64_t)L * H * E * 4);
     for (int l = 0; l < L; ++l)
-        push(h->fwd_jobs, mk_job(h->pk_wt_all32 + (int64_t)l * H * E * 4, h->layer[l].wt, E, 0, H, E, H, E, E, 0, 1));
-    if (h->f32) h->pk_wse32 = h->pk_wse;
+        push(h->fwd_jobs, h->pk_wt_all32 + (int64_t)l * H * E * 4, h->layer[l].wt, E, 0, H, E, H, E, E, 0, 1);
+    if (h->w32) h->pk_wse32 = h->pk_wse;
     else {
         h->pk_wse32 = p; p = align256(p + (int64_t)E * E * 4);
-        push(h->fwd_jobs, mk_job(h->pk_wse32, h->off_se_w, E, 0, E, E, E, E, E, 0, 1));
+        push(h->fwd_jobs, h->pk_wse32, h->off_se_w, E, 0, E, E, E, E, E, 0, 1);
     }
     h->pk_fwd_end = p;
     // backward: transposed copies (dgrad computes dX = dY @ W, i.e. "weights" = W^T)
-    h->bwd_jobs.n = 0;
-    h->pk_wpostT = p; p = align256(p + (int64_t)H * h->Cp * esz);
-    push(h->bwd_jobs, mk_job(h->pk_wpostT, h->off_post_w, h->Cp, 0, H, h->Cp, H, D, H, 1, f));
+    h->pk_wpostT = p; p = align256(p + (int64_t)H * h->Cp * esz * wk);
+    push(h->bwd_jobs, h->pk_wpostT, h->off_post_w, h->Cp, 0, H, h->Cp, H, D, H, 1, f);
     for (int l = 0; l < L; ++l) {
         const LayerOff& lo = h->layer[l];
-        h->pk_wlT[l] = p; p = align256(p + (int64_t)lo.kin_pad * H * esz);
-        push(h->bwd_jobs, mk_job(h->pk_wlT[l], lo.w, H, 0, lo.kin_pad, H, lo.kin, H, lo.kin, 1, f));
+        h->pk_wlT[l] = p; p = align256(p + (int64_t)lo.kin_pad * H * esz * wk);
+        push(h->bwd_jobs, h->pk_wlT[l], lo.w, H, 0, lo.kin_pad, H, lo.kin, H, lo.kin, 1, f);
     }
-    h->pk_wtT_all = p; p = align256(p + (int64_t)E * L * H * esz);
-    for (int l = 0; l < L; ++l)
-        push(h->bwd_jobs, mk_job(h->pk_wtT_all, h->layer[l].wt, L * H, l * H, E, H, E, H, E, 1, f));
+    if (h->x3) {
+        // the time-branch dgrad runs one GEMM per layer in this mode (three activation segments each): one [E][3 H] matrix per layer
+        h->pk_wtT_all = p; p = align256(p + (int64_t)E * L * H * esz * wk);
+        for (int l = 0; l < L; ++l)
+            push(h->bwd_jobs, h->pk_wtT_all + (int64_t)l * E * H * esz * wk, h->layer[l].wt, H, 0, E, H, E, H, E, 1, f);
+    } else {
+        h->pk_wtT_all = p; p = align256(p + (int64_t)E * L * H * esz);
+        for (int l = 0; l < L; ++l)
+            push(h->bwd_jobs, h->pk_wtT_all, h->layer[l].wt, L * H, l * H, E, H, E, H, E, 1, f);
+    }
     h->pk_bwd_end = p;
 
     // ---- fused optimizer + re-pack step: every packed matrix with its copies, everything else as element ranges ------------------
@@ -211,7 +238,7 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
         };
         std::vector<std::pair<int64_t, int64_t>> matrices;        // [lo, hi) of the flat buffer covered by tensors
         auto mat = [&](int64_t off, int64_t n) { matrices.push_back({off, off + n}); };
-        add_t(h->off_se_w, E, E, dst(h->pk_wse, E, 0, 0, f), h->f32 ? none() : dst(h->pk_wse32, E, 0, 0, 1), none());
+        add_t(h->off_se_w, E, E, dst(h->pk_wse, E, 0, 0, f), h->w32 ? none() : dst(h->pk_wse32, E, 0, 0, 1), none());
         mat(h->off_se_w, (int64_t)E * E);
         for (int l = 0; l < L; ++l) {
             const LayerOff& lo = h->layer[l];
@@ -254,7 +281,7 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
         ap.n_elems = ne;
         ap.n_elem_blocks = eblocks;
         ap.bias_cat_off = h->pk_bias_cat;
-        if (!ok || nt > ADAMPACK_MAX_TENSORS) ap.n_tensors = 0;
+        if (!ok || nt > ADAMPACK_MAX_TENSORS || h->x3) ap.n_tensors = 0;      // (bf16x3: three column groups per segment -- the plain pack launch)
     }
     *out = h;
     return DPOSER_OK;
@@ -291,16 +318,17 @@ extern "C" int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat, void* 
     DP_CHECK_ARG(h && flat && packed, "null argument");
     DP_CHECK_ARG(((uintptr_t)flat & 15) == 0 && ((uintptr_t)packed & 255) == 0, "flat_params must be 16-B aligned, packed 256-B aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (with_backward && h->fwd_jobs.n + h->bwd_jobs.n <= MAX_PACK_JOBS) {      // one launch for both operand sets (the training step's tail is latency-bound)
-        PackJobs all = h->fwd_jobs;
-        for (int i = 0; i < h->bwd_jobs.n; ++i) all.job[all.n++] = h->bwd_jobs.job[i];
-        DP_HIP_LAUNCH(launch_pack(all, flat, packed, st));
-        DP_HIP_LAUNCH(launch_bias_cat(h->bias_jobs, flat, reinterpret_cast<float*>((char*)packed + h->pk_bias_cat), st));
-        return DPOSER_OK;
+    // as few launches as the job table of one launch allows (the training step's tail is latency-bound): forward and backward operand
+    // sets together where they fit (40 jobs; bf16 / fp32: 14 + 7 of them), in chunks otherwise (bf16x3: three jobs per matrix segment)
+    std::vector<PackJob> all = h->fwd_jobs;
+    if (with_backward) all.insert(all.end(), h->bwd_jobs.begin(), h->bwd_jobs.end());
+    for (size_t i0 = 0; i0 < all.size(); i0 += MAX_PACK_JOBS) {
+        PackJobs js;
+        js.n = (int)(all.size() - i0 < (size_t)MAX_PACK_JOBS ? all.size() - i0 : (size_t)MAX_PACK_JOBS);
+        for (int i = 0; i < js.n; ++i) js.job[i] = all[i0 + i];
+        DP_HIP_LAUNCH(launch_pack(js, flat, packed, st));
     }
-    DP_HIP_LAUNCH(launch_pack(h->fwd_jobs, flat, packed, st));
     DP_HIP_LAUNCH(launch_bias_cat(h->bias_jobs, flat, reinterpret_cast<float*>((char*)packed + h->pk_bias_cat), st));
-    if (with_backward) DP_HIP_LAUNCH(launch_pack(h->bwd_jobs, flat, packed, st));
     return DPOSER_OK;
 }
 
@@ -381,8 +409,10 @@ static int final_shape(int64_t Spad) {
     return (Spad % 128 == 0 && Spad > small_max) ? SHAPE_FINAL : SHAPE_FINAL_S;
 }
 
+struct Planes { char *hi, *lo; };    // bf16x3 mode: the two bf16 FT planes of an fp32 FT activation (k_split_ft32), operands of the GEMMs
 struct Ws {
     int64_t Bpad;
+    Planes p_xin, p_emb, p_temb, p_h[MAX_L], p_dres, p_dy[MAX_L], p_dU;
     char *xin, *emb, *temb, *upre, *hbuf[MAX_L], *xhat[MAX_L], *dy[MAX_L], *carry[2], *dU, *dres;
     GnAux* aux[MAX_L];        // per GroupNorm layer: rstd + dropout decisions for the backward epilogue (epilogues.h)
     float *res, *xt, *tbuf, *zbuf, *loss_part, *scalar;
@@ -423,7 +453,7 @@ static int wgrad_shape(int n_rows_pad, int k_rows_pad, int64_t Spad) {
 static bool wgrad_tr_mode(const dposer_scorefc_s* h, int64_t Bpad) {
     const int forced = score_tuning().wgrad_tr;
     (void)Bpad;
-    return forced != 0 && !h->f32;      // every wgrad tiling has a sample-major instantiation
+    return h->x3 || (forced != 0 && !h->f32);      // every wgrad tiling has a sample-major instantiation (bf16x3: on the bf16 planes, always)
 }
 static int pick_ksplit(int64_t tiles, int64_t stages, int slots = 512) {
     int ks = 1;
@@ -432,7 +462,7 @@ static int pick_ksplit(int64_t tiles, int64_t stages, int slots = 512) {
 }
 
 constexpr int64_t SILU_SPLIT_CAP = 4096;     // largest padded batch the k-split partial buffer of the time-branch dgrad is laid out for
-static inline int64_t silu_part_rows(int64_t Bpad) { return Bpad <= SILU_SPLIT_CAP ? Bpad / 2 : Bpad / 32; }   // (the reduce pass: one block per two samples)
+static inline int64_t silu_part_rows(int64_t Bpad, bool always_reduce = false) { return (Bpad <= SILU_SPLIT_CAP || always_reduce) ? Bpad / 2 : Bpad / 32; }   // (the reduce pass: one block per two samples)
 static inline int64_t cs_post_rows(int64_t Bpad) { return Bpad / 32 > 1024 ? Bpad / 32 : 1024; }   // capacity of Ws::cs_part_post in rows
 static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_steps, char* base, Ws& w) {
     std::memset(&w, 0, sizeof(w));
@@ -441,16 +471,20 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
     const int esz = h->esz, H = h->H, E = h->E, L = h->L;
     int64_t p = 0;
     auto take = [&](int64_t bytes) { char* r = base + p; p = align256(p + bytes); return r; };
+    auto planes = [&](int64_t elems) { Planes q; q.hi = q.lo = nullptr; if (h->x3) { q.hi = take(elems * 2); q.lo = take(elems * 2); } return q; };
     w.xin = take(Bpad * h->Dpad * esz);
+    w.p_xin = planes(Bpad * h->Dpad);
     w.res = (float*)take(Bpad * h->Cp * 4);
     w.loss_part = (float*)take(8192 * 4);
     w.scalar = (float*)take(256);
     if (mode == DPOSER_WS_INFER) {
         w.emb = take(Bpad * E * esz);
         w.temb = take(Bpad * E * esz);
-        for (int i = 0; i < 3; ++i) w.hbuf[i] = take(Bpad * H * esz);
+        w.p_emb = planes(Bpad * E);
+        w.p_temb = planes(Bpad * E);
+        for (int i = 0; i < 3; ++i) { w.hbuf[i] = take(Bpad * H * esz); w.p_h[i] = planes(Bpad * H); }
     } else if (mode == DPOSER_WS_SHARED_T) {
-        for (int i = 0; i < 3; ++i) w.hbuf[i] = take(Bpad * H * esz);
+        for (int i = 0; i < 3; ++i) { w.hbuf[i] = take(Bpad * H * esz); w.p_h[i] = planes(Bpad * H); }
         w.xt = (float*)take(Bpad * h->Dpad * 4);
         w.xft = (float*)take(Bpad * h->Dpad * 4);
         w.xmft = (float*)take(Bpad * h->Dpad * 4);
@@ -466,6 +500,11 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         w.emb = take(Bpad * E * esz);
         w.temb = take(Bpad * E * esz);
         w.upre = take(Bpad * E * esz);
+        w.p_emb = planes(Bpad * E);
+        w.p_temb = planes(Bpad * E);
+        w.p_dU = planes(Bpad * E);
+        w.p_dres = planes(Bpad * h->Cp);
+        for (int l = 0; l < L; ++l) { w.p_h[l] = planes(Bpad * H); w.p_dy[l] = planes(Bpad * H); }
         for (int l = 0; l < L; ++l) {
             w.hbuf[l] = take(Bpad * H * esz);
             w.xhat[l] = take(Bpad * H * esz);
@@ -476,7 +515,7 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         w.carry[0] = take(Bpad * H * esz);
         w.carry[1] = take(Bpad * H * esz);
         w.dU = take(Bpad * E * esz);
-        w.dU_part = Bpad <= SILU_SPLIT_CAP ? (float*)take((int64_t)L * Bpad * E * 4) : nullptr;      // k-split partials of the time-branch dgrad (small batches)
+        w.dU_part = (Bpad <= SILU_SPLIT_CAP || h->x3) ? (float*)take((int64_t)L * Bpad * E * 4) : nullptr;      // k-split partials of the time-branch dgrad (small batches; bf16x3: one GEMM per layer)
         w.dres = take(Bpad * h->Cp * esz);
         w.tbuf = (float*)take(Bpad * 4);
         w.zbuf = (float*)take(Bpad * h->Dpad * 4);
@@ -492,14 +531,14 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         const int64_t nchunks = ceil_div(Bpad, 2048);
         w.cs_part_post = (float*)take(cs_post_rows(Bpad) * h->Cp * 4);      // rows: k_colsum chunks, k_dsm's blocks (<= 1024) or EpiDsm's wave rows (Bpad / 32)
         w.cs_part_se = (float*)take(nchunks * E * 4);
-        w.silu_part = (float*)take(silu_part_rows(Bpad) * (int64_t)E * 4);       // per-wave column sums of dU (time-branch dgrad epilogue), or k_silu_bwd_reduce's per-block sums
+        w.silu_part = (float*)take(silu_part_rows(Bpad, h->x3) * (int64_t)E * 4);       // per-wave column sums of dU (time-branch dgrad epilogue), or k_silu_bwd_reduce's per-block sums
         // slabs: worst case ksplit 32 is never reached for the big tensors; size exactly below
         const int64_t stages = Bpad / (h->KBS * 4);
         int64_t slab_elems = 0;
         auto acc = [&](int n_rows_pad, int k_rows_pad, int64_t numel) {
             const int shape = wgrad_shape(n_rows_pad, k_rows_pad, Bpad);
             const int64_t tiles = (int64_t)(n_rows_pad / (shape_ct(shape) * 32)) * (k_rows_pad / (shape_st(shape) * 32));
-            slab_elems += (int64_t)pick_ksplit(tiles, stages, shape == SHAPE_BIG ? 256 : 512) * numel;
+            slab_elems += (int64_t)pick_ksplit(tiles, stages, shape == SHAPE_BIG ? 256 : 512) * numel * h->wk;      // (bf16x3: one slab set per product term)
         };
         for (int l = 0; l < L; ++l) {
             acc(H, h->layer[l].kin_pad, (int64_t)H * h->layer[l].kin);
@@ -547,6 +586,23 @@ static void add_seg(GemmArgs& g, const void* src, int kblocks) {
     g.ktot_blocks += kblocks;
 }
 
+// ---- bf16x3 mode: GEMM operands are the bf16 planes of the stored fp32 activations --------------------------------------------------
+static inline int gemm_prec(const dposer_scorefc_s* h) { return h->x3 ? PREC_BF16X3 : (h->w32 ? PREC_FP32 : PREC_BF16); }
+// the activation operand `stored` ([Bpad][kblocks * KBS]) of a GEMM: one segment, or its planes as the three segments (hi, hi, lo) that
+// meet the packed weight columns [hi | lo | hi]
+static void add_act(const dposer_scorefc_s* h, GemmArgs& g, const void* stored, const Planes& pl, int kblocks) {
+    if (!h->x3) { add_seg(g, stored, kblocks); return; }
+    add_seg(g, pl.hi, kblocks);
+    add_seg(g, pl.hi, kblocks);
+    add_seg(g, pl.lo, kblocks);
+}
+// (re)build the planes of a stored activation [Bpad][K] (no-op outside bf16x3 mode)
+static int split_act(const dposer_scorefc_s* h, const void* stored, const Planes& pl, int64_t Bpad, int K, hipStream_t st) {
+    if (!h->x3) return DPOSER_OK;
+    DP_HIP_LAUNCH(launch_split_ft32(stored, pl.hi, pl.lo, Bpad, K, st));
+    return DPOSER_OK;
+}
+
 static thread_local int64_t g_alg_batch = 0;   // un-padded batch of the running call (profiling only)
 static DropoutCfg drop_cfg(const dposer_scorefc_s* h, bool train, int site, uint64_t seed, uint32_t step) {
     DropoutCfg d;
@@ -582,16 +638,16 @@ extern "C" int dposer_scorefc_debug_set_dropout_masks(dposer_scorefc_t h, const 
 
 // One GroupNorm layer.  per_sample_t: K-concat(h, temb) with packed bias_cat; else x-path only with
 // `bias_row` (time-table row of this step and layer).
-static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* packed, int l, const void* in, const void* temb,
-                        const float* bias_row, void* out, const void* resid, void* xhat, GnAux* aux, bool train,
-                        int64_t Bpad, uint64_t seed, uint32_t step, hipStream_t st) {
+static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* packed, int l, const void* in, const Planes& in_pl, const void* temb,
+                        const Planes& temb_pl, const float* bias_row, void* out, const Planes& out_pl, const void* resid, void* xhat, GnAux* aux,
+                        bool train, int64_t Bpad, uint64_t seed, uint32_t step, hipStream_t st) {
     const int shape = main_shape(Bpad, h->H, h->gs);
     const LayerOff& lo = h->layer[l];
     const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
     g_next_flops = 2.0 * (double)g_alg_batch * h->H * (lo.kin + (temb ? h->E : 0));
-    GemmArgs g = gemm_args(packed + h->pk_wl[l], kx + ke, h->H / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
-    add_seg(g, in, kx);
-    if (temb) add_seg(g, temb, ke);
+    GemmArgs g = gemm_args(packed + h->pk_wl[l], (kx + ke) * h->wk, h->H / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
+    add_act(h, g, in, in_pl, kx);
+    if (temb) add_act(h, g, temb, temb_pl, ke);
     GNParams p;
     p.bias = temb ? reinterpret_cast<const float*>(packed + h->pk_bias_cat) + (int64_t)l * h->H : bias_row;
     p.gamma = flat + lo.gamma;
@@ -605,15 +661,15 @@ static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* pack
     p.Spad = Bpad;
     p.act = h->d.activation;
     p.drop = drop_cfg(h, train, l, seed, step);
-    DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, train, shape, g, p, st, h->gs));
-    return DPOSER_OK;
+    DP_HIP_LAUNCH(gemm_gn(gemm_prec(h), train, shape, g, p, st, h->gs));
+    return split_act(h, out, out_pl, Bpad, h->H, st);
 }
 
-static int run_post(dposer_scorefc_s* h, const float* flat, const char* packed, const void* in, float* res, int64_t B, int64_t Bpad, hipStream_t st) {
+static int run_post(dposer_scorefc_s* h, const float* flat, const char* packed, const void* in, const Planes& in_pl, float* res, int64_t B, int64_t Bpad, hipStream_t st) {
     const int shape = final_shape(Bpad);
     g_next_flops = 2.0 * (double)B * h->D * h->H;
-    GemmArgs g = gemm_args(packed + h->pk_wpost, h->H / h->KBS, h->Cp / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
-    add_seg(g, in, h->H / h->KBS);
+    GemmArgs g = gemm_args(packed + h->pk_wpost, h->H / h->KBS * h->wk, h->Cp / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
+    add_act(h, g, in, in_pl, h->H / h->KBS);
     RowMajorParams p;
     p.bias = flat + h->off_post_b;
     p.out = res;
@@ -621,26 +677,29 @@ static int run_post(dposer_scorefc_s* h, const float* flat, const char* packed, 
     p.C_valid = h->D;
     p.S_valid = Bpad;     // padded rows are written too (finite, never read back as samples)
     (void)B;
-    DP_HIP_LAUNCH(gemm_rowmajor(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
+    DP_HIP_LAUNCH(gemm_rowmajor(gemm_prec(h), shape, g, p, st));
     return DPOSER_OK;
 }
 
-static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, const void* emb, void* temb, void* upre, void* tembT,
-                    bool train, int64_t Bpad, hipStream_t st) {
+// shared_time_embed: temb = SiLU(emb W^T + b); in bf16x3 mode the planes of `emb` are built here (emb comes from an elementwise kernel) and
+// those of temb behind the GEMM
+static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, void* upre, void* tembT, bool train, hipStream_t st) {
+    const int64_t Bpad = w.Bpad;
     const int shape = main_shape(Bpad, h->E);
     g_next_flops = 2.0 * (double)g_alg_batch * h->E * h->E;
-    GemmArgs g = gemm_args(packed + h->pk_wse, h->E / h->KBS, h->E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
-    add_seg(g, emb, h->E / h->KBS);
+    DP_TRY(split_act(h, w.emb, w.p_emb, Bpad, h->E, st));
+    GemmArgs g = gemm_args(packed + h->pk_wse, h->E / h->KBS * h->wk, h->E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
+    add_act(h, g, w.emb, w.p_emb, h->E / h->KBS);
     BiasSiLUParams p;
     p.bias = flat + h->off_se_b;
-    p.out = temb;
+    p.out = w.temb;
     p.pre = upre;
     p.N = h->E;
     p.outT = tembT;
     p.Spad = Bpad;
     p.act = h->d.activation;
-    DP_HIP_LAUNCH(gemm_bias_silu(h->f32 ? PREC_FP32 : PREC_BF16, train, shape, g, p, st));
-    return DPOSER_OK;
+    DP_HIP_LAUNCH(gemm_bias_silu(gemm_prec(h), train, shape, g, p, st));
+    return split_act(h, w.temb, w.p_temb, Bpad, h->E, st);
 }
 
 // scale_by_sigma as the shared-t kernels take it: 0 off, 1 divide by sigmas[(int)label] (positional embedding, model.py:159), 2 divide by the
@@ -674,15 +733,18 @@ extern "C" int dposer_scorefc_forward(dposer_scorefc_t h, const float* flat, con
     pa.B = B; pa.Bpad = w.Bpad; pa.D = h->D; pa.Dpad = h->Dpad; pa.E = h->E;
     pa.fourier = h->d.embedding == DPOSER_EMB_FOURIER; pa.f32 = h->f32;
     DP_HIP_LAUNCH(launch_prep_infer(pa, st));
-    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, nullptr, nullptr, false, w.Bpad, st));
+    DP_TRY(run_temb(h, flat, packed, w, nullptr, nullptr, false, st));
+    DP_TRY(split_act(h, w.xin, w.p_xin, w.Bpad, h->Dpad, st));
     const void* in = w.xin;
+    const Planes* in_pl = &w.p_xin;
     for (int l = 0; l < h->L; ++l) {
         void* o = w.hbuf[l % 3];
         const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[(l - 2) % 3] : nullptr;
-        DP_TRY(run_gn_layer(h, flat, packed, l, in, w.temb, nullptr, o, resid, nullptr, nullptr, false, w.Bpad, 0, 0, st));
+        DP_TRY(run_gn_layer(h, flat, packed, l, in, *in_pl, w.temb, w.p_temb, nullptr, o, w.p_h[l % 3], resid, nullptr, nullptr, false, w.Bpad, 0, 0, st));
         in = o;
+        in_pl = &w.p_h[l % 3];
     }
-    DP_TRY(run_post(h, flat, packed, in, w.res, B, w.Bpad, st));
+    DP_TRY(run_post(h, flat, packed, in, *in_pl, w.res, B, w.Bpad, st));
     OutModelArgs oa;
     oa.res = w.res; oa.labels = labels; oa.sigmas = sigmas; oa.out = out; oa.B = B; oa.D = h->D; oa.Cp = h->Cp;
     oa.num_scales = h->d.num_scales; oa.scale_by_sigma = h->d.scale_by_sigma; oa.fourier = pa.fourier;
@@ -717,31 +779,33 @@ static int build_time_table(dposer_scorefc_s* h, const float* flat, const char* 
     return DPOSER_OK;
 }
 
-// the GroupNorm layers of one shared-t network evaluation (bias rows from table row `row`); returns the last activation
-static int run_shared_t_layers(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t row, hipStream_t st, const void** last) {
+// the GroupNorm layers of one shared-t network evaluation (bias rows from table row `row`); returns the last activation (and its planes).
+// bf16x3: the planes of the input `xin` are built here (every producer of xin is an elementwise kernel or an fp32-storing epilogue).
+static int run_shared_t_layers(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t row, hipStream_t st, const void** last,
+                               const Planes** last_pl) {
+    DP_TRY(split_act(h, w.xin, w.p_xin, w.Bpad, h->Dpad, st));
     const void* in = w.xin;
+    const Planes* in_pl = &w.p_xin;
     const float* trow = w.table + row * (int64_t)h->L * h->H;
+    const Planes none = {nullptr, nullptr};
     for (int l = 0; l < h->L; ++l) {
         void* o = w.hbuf[l % 3];
         const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[(l - 2) % 3] : nullptr;
-        DP_TRY(run_gn_layer(h, flat, packed, l, in, nullptr, trow + (int64_t)l * h->H, o, resid, nullptr, nullptr, false, w.Bpad, 0, 0, st));
+        DP_TRY(run_gn_layer(h, flat, packed, l, in, *in_pl, nullptr, none, trow + (int64_t)l * h->H, o, w.p_h[l % 3], resid, nullptr, nullptr, false, w.Bpad, 0, 0, st));
         in = o;
+        in_pl = &w.p_h[l % 3];
     }
     *last = in;
+    *last_pl = in_pl;
     return DPOSER_OK;
 }
 
 // one shared-t network evaluation: xin -> res, bias rows from table row `row`
 static int run_shared_t(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t row, int64_t B, hipStream_t st) {
-    const void* in = w.xin;
-    const float* trow = w.table + row * (int64_t)h->L * h->H;
-    for (int l = 0; l < h->L; ++l) {
-        void* o = w.hbuf[l % 3];
-        const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[(l - 2) % 3] : nullptr;
-        DP_TRY(run_gn_layer(h, flat, packed, l, in, nullptr, trow + (int64_t)l * h->H, o, resid, nullptr, nullptr, false, w.Bpad, 0, 0, st));
-        in = o;
-    }
-    return run_post(h, flat, packed, in, w.res, B, w.Bpad, st);
+    const void* last = nullptr;
+    const Planes* last_pl = nullptr;
+    DP_TRY(run_shared_t_layers(h, flat, packed, w, row, st, &last, &last_pl));
+    return run_post(h, flat, packed, last, *last_pl, w.res, B, w.Bpad, st);
 }
 
 static SdeCfg to_sde(const dposer_sde_desc* s) {
@@ -826,7 +890,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     // through MALL / HBM, under the chip's power cap.  Removing the grid-wide joins does not pay for that.
     const int persistent_env = score_tuning().sampler_persistent;
     const int64_t persistent_min = score_tuning().sampler_persistent_min;
-    if (fused && persistent_env && h->d.activation == DPOSER_ACT_SWISH && h->gs == 32 && h->H % 256 == 0 && h->Cp == 64 && w.Bpad % 256 == 0 && (persistent_env >= 2 || w.Bpad >= persistent_min)) {
+    if (fused && persistent_env && !h->x3 && h->d.activation == DPOSER_ACT_SWISH && h->gs == 32 && h->H % 256 == 0 && h->Cp == 64 && w.Bpad % 256 == 0 && (persistent_env >= 2 || w.Bpad >= persistent_min)) {
         SamplerLayer tab[MAX_L];
         std::memset(tab, 0, sizeof(tab));
         for (int l = 0; l < h->L; ++l) {
@@ -879,17 +943,18 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
         for (int i = 0; i < n_run; ++i) {
             const int gi = start_step + i;
             const void* last = nullptr;
-            DP_TRY(run_shared_t_layers(h, flat, packed, w, i, st, &last));
+            const Planes* last_pl = nullptr;
+            DP_TRY(run_shared_t_layers(h, flat, packed, w, i, st, &last, &last_pl));
             g_next_flops = 2.0 * (double)B * h->D * h->H;
-            GemmArgs g = gemm_args(packed + h->pk_wpost, h->H / h->KBS, h->Cp / (shape_ct(shape) * 32), (int)(w.Bpad / (shape_st(shape) * 32)));
-            add_seg(g, last, h->H / h->KBS);
+            GemmArgs g = gemm_args(packed + h->pk_wpost, h->H / h->KBS * h->wk, h->Cp / (shape_ct(shape) * 32), (int)(w.Bpad / (shape_st(shape) * 32)));
+            add_act(h, g, last, *last_pl, h->H / h->KBS);
             EmStepParams p;
             std::memset(&p, 0, sizeof(p));
             p.bias = flat + h->off_post_b; p.x_ft = w.xft; p.x_mean_ft = (i + 1 == n_run) ? w.xmft : nullptr; p.xin = w.xin;
             p.sigmas = sigmas; p.sde = make_sde_dev(sc); p.t = timesteps_host[gi]; p.num_scales = h->d.num_scales;
             p.scale_by_sigma = sbs_mode(h); p.D = h->D; p.Cp = h->Cp; p.QD = (h->D + 3) >> 2; p.S_valid = B;
             p.seed = seed; p.step = (uint32_t)gi;
-            DP_HIP_LAUNCH(gemm_em_step(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
+            DP_HIP_LAUNCH(gemm_em_step(gemm_prec(h), shape, g, p, st));
         }
         DP_HIP_LAUNCH(launch_ft_to_rows(w.xft, x, w.xmft, x_mean, B, w.Bpad, h->D, h->Dpad, st));
         return DPOSER_OK;
@@ -1065,7 +1130,7 @@ extern "C" int dposer_completion_optimize(dposer_scorefc_t h, const float* flat,
 // (FT [Bpad][rows]) -- given (non-null) when the sample-major kernel is to be used, in which case dyT / inT may be null.
 static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n_valid, const void* inT, int k_rows_pad, int k_valid,
                      int64_t Bpad, float* slabs, int64_t& slab_cursor, int64_t numel, int64_t flat_off, ReduceJobs& rj, hipStream_t st,
-                     const void* dy = nullptr, const void* in = nullptr) {
+                     const void* dy = nullptr, const void* in = nullptr, const Planes* dy_pl = nullptr, const Planes* in_pl = nullptr) {
     const int shape = wgrad_shape(n_rows_pad, k_rows_pad, Bpad);
     const int ct = shape_ct(shape), stt = shape_st(shape);
     const int kb_total = (int)(Bpad / h->KBS);
@@ -1082,7 +1147,24 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
     p.ld = k_valid;
     p.N_valid = n_valid;
     p.K_valid = k_valid;
-    if (dy && in) {
+    if (dy_pl && in_pl) {
+        // bf16x3: dW = dy_hi^T in_hi + dy_lo^T in_hi + dy_hi^T in_lo -- three sample-major launches on the bf16 planes into consecutive slab
+        // sets, summed by the bucket's reduction like the k-splits of one launch
+        for (int term = 0; term < 3; ++term) {
+            WgradTrArgs t;
+            std::memset(&t, 0, sizeof(t));
+            t.dY = term == 1 ? dy_pl->lo : dy_pl->hi; t.H = term == 2 ? in_pl->lo : in_pl->hi;
+            t.N = n_rows_pad; t.Kc = k_rows_pad; t.n_cblk = n_cblk; t.n_sblk = n_sblk; t.sblocks = (int)(Bpad / 32); t.ksplit = ks;
+            t.alg_flops = term == 0 ? g.alg_flops : 0.0;
+            WgradParams pt = p;
+            pt.slab = p.slab + (int64_t)term * ks * numel;
+            DP_HIP_LAUNCH(gemm_wgrad_tr(shape, t, pt, st));
+        }
+        ReduceJob& j = rj.job[rj.n++];
+        j.dst_off = flat_off; j.count = numel; j.src_off = slab_cursor; j.src_stride = numel; j.nsrc = 3 * ks;
+        slab_cursor += (int64_t)3 * ks * numel;
+        return DPOSER_OK;
+    } else if (dy && in) {
         if (h->f32) return dposer_set_error(DPOSER_ERR_BAD_ARG, "run_wgrad: sample-major operands are bf16 only");
         WgradTrArgs t;
         std::memset(&t, 0, sizeof(t));
@@ -1090,7 +1172,7 @@ static int run_wgrad(dposer_scorefc_s* h, const void* dyT, int n_rows_pad, int n
         t.alg_flops = g.alg_flops;
         DP_HIP_LAUNCH(gemm_wgrad_tr(shape, t, p, st));
     } else {
-        DP_HIP_LAUNCH(gemm_wgrad(h->f32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
+        DP_HIP_LAUNCH(gemm_wgrad(h->w32 ? PREC_FP32 : PREC_BF16, shape, g, p, st));
     }
     ReduceJob& j = rj.job[rj.n++];
     j.dst_off = flat_off; j.count = numel; j.src_off = slab_cursor; j.src_stride = numel; j.nsrc = ks;
@@ -1103,27 +1185,30 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
                               uint32_t step, hipStream_t st, bool with_post = true) {
     const int L = h->L;
     const bool tr = wgrad_tr_mode(h, w.Bpad);   // then no wgrad reads a transposed activation
-    DP_TRY(run_temb(h, flat, packed, w.emb, w.temb, w.upre, tr ? nullptr : w.tembT, true, w.Bpad, st));
+    DP_TRY(run_temb(h, flat, packed, w, w.upre, tr ? nullptr : w.tembT, true, st));
+    DP_TRY(split_act(h, w.xin, w.p_xin, w.Bpad, h->Dpad, st));
     for (int l = 0; l < L; ++l) {
         const void* in = l == 0 ? (const void*)w.xin : (const void*)w.hbuf[l - 1];
+        const Planes& in_pl = l == 0 ? w.p_xin : w.p_h[l - 1];
         const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[l - 2] : nullptr;
         // TRAIN epilogue keeps xhat and the GnAux records (rstd, dropout decisions); dropout only when the module is in train() mode
         const LayerOff& lo = h->layer[l];
         const int shape = main_shape(w.Bpad, h->H, h->gs);
         const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
         g_next_flops = 2.0 * (double)B * h->H * (lo.kin + h->E);
-        GemmArgs g = gemm_args(packed + h->pk_wl[l], kx + ke, h->H / (shape_ct(shape) * 32), (int)(w.Bpad / (shape_st(shape) * 32)));
-        add_seg(g, in, kx);
-        add_seg(g, w.temb, ke);
+        GemmArgs g = gemm_args(packed + h->pk_wl[l], (kx + ke) * h->wk, h->H / (shape_ct(shape) * 32), (int)(w.Bpad / (shape_st(shape) * 32)));
+        add_act(h, g, in, in_pl, kx);
+        add_act(h, g, w.temb, w.p_temb, ke);
         GNParams p;
         p.bias = reinterpret_cast<const float*>(packed + h->pk_bias_cat) + (int64_t)l * h->H;
         p.gamma = flat + lo.gamma; p.beta = flat + lo.beta; p.out = w.hbuf[l]; p.resid = resid; p.xhat = w.xhat[l]; p.aux = w.aux[l];
         p.H = h->H; p.drop = drop_cfg(h, dropout_on, l, seed, step); p.act = h->d.activation;
         p.outT = tr ? nullptr : w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
-        DP_HIP_LAUNCH(gemm_gn(h->f32 ? PREC_FP32 : PREC_BF16, true, shape, g, p, st, h->gs));
+        DP_HIP_LAUNCH(gemm_gn(gemm_prec(h), true, shape, g, p, st, h->gs));
+        DP_TRY(split_act(h, w.hbuf[l], w.p_h[l], w.Bpad, h->H, st));
     }
     if (!with_post) return DPOSER_OK;      // (the fused DSM step runs post_dense itself, with the loss in its epilogue)
-    return run_post(h, flat, packed, w.hbuf[L - 1], w.res, B, w.Bpad, st);
+    return run_post(h, flat, packed, w.hbuf[L - 1], w.p_h[L - 1], w.res, B, w.Bpad, st);
 }
 
 // Who learns that gradient buckets are final, and how (data parallel: the all-reduce of a bucket overlaps with the rest of the backward):
@@ -1356,16 +1441,18 @@ static int plan_wgrad_groups(const dposer_scorefc_s* h, const Ws& w, bool tr, in
 static int backward_core(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, int64_t B, bool dropout_on, uint64_t seed,
                          uint32_t step, float* flat_grad, float* dx, const BucketSink* sink, hipStream_t st,
                          const SumJob* loss_sum = nullptr, int dsm_cs_rows = 0) {
-    const int prec = h->f32 ? PREC_FP32 : PREC_BF16;
-    const int H = h->H, E = h->E, L = h->L, KBS = h->KBS;
+    const int prec = gemm_prec(h);
+    const int H = h->H, E = h->E, L = h->L, KBS = h->KBS, wk = h->wk;
     const int64_t Bpad = w.Bpad;
     const bool want_w = flat_grad != nullptr;
     const bool tr = wgrad_tr_mode(h, Bpad);
     const bool has_events = sink != nullptr && sink->events != nullptr && sink->n_events > 0;
     WgradBatchArgs wb;
-    const bool batched = want_w && plan_batched_wgrad(h, w, tr, has_events, wb);
+    const bool batched = want_w && !h->x3 && plan_batched_wgrad(h, w, tr, has_events, wb);      // (bf16x3: three product terms per gradient -- the split-K launches)
     int grp_lo[MAX_L], grp_hi[MAX_L];
-    const int n_groups = (want_w && !batched) ? plan_wgrad_groups(h, w, tr, grp_lo, grp_hi) : 0;
+    const int n_groups = (want_w && !batched && !h->x3) ? plan_wgrad_groups(h, w, tr, grp_lo, grp_hi) : 0;
+    // bf16x3: dres arrives from an elementwise kernel as fp32 fragment tiles
+    DP_TRY(split_act(h, w.dres, w.p_dres, Bpad, h->Cp, st));
     const bool grouped = n_groups > 0;
     int cur_group = 0;
     bool front_a_done = false;
@@ -1398,7 +1485,9 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         // post_dense: bias (column sums of dres: left by k_dsm in the fused step, else a k_colsum launch here) and weight
         if (dsm_cs_rows > 0) n_chunks_post = dsm_cs_rows;
         else DP_HIP_LAUNCH(launch_colsum(h->f32, w.dres, w.cs_part_post, Bpad, h->Cp, &n_chunks_post, sw, nullptr));
-        if (tr) {
+        if (h->x3) {
+            DP_TRY(run_wgrad(h, nullptr, h->Cp, h->D, nullptr, H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, sw, nullptr, nullptr, &w.p_dres, &w.p_h[L - 1]));
+        } else if (tr) {
             DP_TRY(run_wgrad(h, nullptr, h->Cp, h->D, nullptr, H, H, Bpad, w.slabs, slab_cursor, (int64_t)h->D * H, h->off_post_w, rj, sw, w.dres, w.hbuf[L - 1]));
         } else {
             DP_HIP_LAUNCH(launch_ft_transpose(h->f32, w.dres, w.dresT, Bpad, h->Cp, sw));
@@ -1420,6 +1509,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     };
     auto run_wx0 = [&]() -> int {      // layer 0's W_x has 63 input channels: not a 256-wide lane problem, its own small split-K launch
         const LayerOff& lo = h->layer[0];
+        if (h->x3) return run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, nullptr, nullptr, &w.p_dy[0], &w.p_xin);
         return run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[0], (const void*)w.xin);
     };
     for (int j = L - 1; j >= 0; --j) {
@@ -1428,8 +1518,8 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         const void* Wt = packed + (from_post ? h->pk_wpostT : h->pk_wlT[j + 1]);
         const int kblocks = (from_post ? h->Cp : H) / KBS;
         g_next_flops = 2.0 * (double)B * H * (from_post ? h->D : H);
-        GemmArgs g = gemm_args(Wt, kblocks, H / (shape_ct(gshape) * 32), (int)(Bpad / (shape_st(gshape) * 32)));
-        add_seg(g, from_post ? (const void*)w.dres : (const void*)w.dy[j + 1], kblocks);
+        GemmArgs g = gemm_args(Wt, kblocks * wk, H / (shape_ct(gshape) * 32), (int)(Bpad / (shape_st(gshape) * 32)));
+        add_act(h, g, from_post ? (const void*)w.dres : (const void*)w.dy[j + 1], from_post ? w.p_dres : w.p_dy[j + 1], kblocks);
         GNBwdParams p;
         const bool even = (j % 2) == 0;
         p.carry_in = (even && j < L - 1) ? w.carry[(j / 2 + 1) & 1] : nullptr;
@@ -1439,6 +1529,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         p.drop_scale = (dropout_on && h->d.dropout_p > 0.f) ? 1.0f / (1.0f - h->d.dropout_p) : 1.0f;   // the decisions themselves come from the forward pass (GnAux)
         p.dyT = (want_w && !tr) ? w.dyT[j] : nullptr; p.Spad = Bpad; p.act = h->d.activation;
         DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st, h->gs));
+        DP_TRY(split_act(h, w.dy[j], w.p_dy[j], Bpad, H, st));
         if (!want_w) continue;
         if (two) {
             DP_CHECK_HIP(hipEventRecord(h->ev_layer[j], st));
@@ -1467,10 +1558,15 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
             ++cur_group;
         } else {
             const void* inT = (j == 0) ? (const void*)w.xinT : (const void*)w.hT[j - 1];
+            if (h->x3) {
+                DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, nullptr, nullptr, &w.p_dy[j], j == 0 ? &w.p_xin : &w.p_h[j - 1]));
+                DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw, nullptr, nullptr, &w.p_dy[j], &w.p_temb));
+            } else {
             if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw, w.dy[j], j == 0 ? (const void*)w.xin : (const void*)w.hbuf[j - 1]));
             else DP_TRY(run_wgrad(h, w.dyT[j], H, H, inT, lo.kin_pad, lo.kin, Bpad, w.slabs, slab_cursor, (int64_t)H * lo.kin, lo.w, rj, sw));
             if (tr) DP_TRY(run_wgrad(h, nullptr, H, H, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw, w.dy[j], w.temb));
             else DP_TRY(run_wgrad(h, w.dyT[j], H, H, w.tembT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)H * E, lo.wt, rj, sw));
+            }
             add_layer_jobs(j);
             // layer j's gradient (and everything behind it in the flat buffer) is final: the data-parallel all-reduce of this
             // bucket can start while the remaining layers are still being differentiated
@@ -1483,8 +1579,8 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     if (dx) {   // d loss / d x = dy_0 @ W_pre  (the time branch does not depend on x)
         const int shape = final_shape(Bpad);
         g_next_flops = 2.0 * (double)B * H * h->D;
-        GemmArgs g = gemm_args(packed + h->pk_wlT[0], H / KBS, h->Dpad / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
-        add_seg(g, w.dy[0], H / KBS);
+        GemmArgs g = gemm_args(packed + h->pk_wlT[0], H / KBS * wk, h->Dpad / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
+        add_act(h, g, w.dy[0], w.p_dy[0], H / KBS);
         RowMajorParams p;
         p.bias = nullptr; p.out = dx; p.ldc = h->D; p.C_valid = h->D; p.S_valid = B;
         DP_HIP_LAUNCH(gemm_rowmajor(prec, shape, g, p, st));
@@ -1495,6 +1591,25 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         // (at 8192 samples this is 256 workgroups of 128x128 with K = L*H = 5120 -- one per CU, latency-bound, 121 us; the
         //  128x32 tiling with 4x the workgroups was measured slower, 144 us)
         const int shape = main_shape(Bpad, E);
+        if (h->x3) {
+            // bf16x3: one GEMM per layer (three plane segments against that layer's [E][3 H] matrix) into fp32 partials; k_silu_bwd_reduce adds
+            // them in layer order, applies act'(u) and keeps the column sums -- the small-batch form of the bf16 mode, at every batch size
+            for (int l = 0; l < L; ++l) {
+                g_next_flops = 2.0 * (double)B * E * H;
+                GemmArgs gl = gemm_args(packed + h->pk_wtT_all + (int64_t)l * E * H * 2 * wk, H / KBS * wk, E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
+                add_act(h, gl, w.dy[l], w.p_dy[l], H / KBS);
+                PartialFTParams pp;
+                pp.out = w.dU_part + (int64_t)l * Bpad * E; pp.N = E; pp.split_stride = 0;
+                DP_HIP_LAUNCH(gemm_partial_ft(prec, shape, gl, pp, st));
+            }
+            SiLUBwdReduceArgs ra;
+            ra.part = w.dU_part; ra.nsplit = L; ra.split_stride = Bpad * (int64_t)E; ra.pre = w.upre; ra.out = w.dU; ra.cs_part = w.silu_part;
+            ra.N = E; ra.act = h->d.activation; ra.f32 = h->f32; ra.B = B; ra.Spad = Bpad;
+            int nb = 0;
+            DP_HIP_LAUNCH(launch_silu_bwd_reduce(ra, (int)silu_part_rows(Bpad, true), &nb, st));
+            silu_rows = nb;
+            DP_TRY(split_act(h, w.dU, w.p_dU, Bpad, E, st));
+        } else {
         g_next_flops = 2.0 * (double)B * E * L * H;
         GemmArgs g = gemm_args(packed + h->pk_wtT_all, L * H / KBS, E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
         for (int l = 0; l < L; ++l) add_seg(g, w.dy[l], H / KBS);
@@ -1520,6 +1635,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         silu_rows = (int)(Bpad / (shape_st(shape) * 32)) * shape_ws(shape);
         DP_HIP_LAUNCH(gemm_silu_bwd(prec, shape, g, p, st));
         }
+        }
     }
     if (two) {
         DP_CHECK_HIP(hipEventRecord(h->ev_time, st));
@@ -1527,7 +1643,8 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     }
     const bool se_in_batch = batched && wb.prob[wb.nprob - 1].mode == 1;
     if (!se_in_batch) {                                             // (otherwise: a lane problem of the one launch below)
-        if (tr) DP_TRY(run_wgrad(h, nullptr, E, E, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw, w.dU, w.emb));
+        if (h->x3) DP_TRY(run_wgrad(h, nullptr, E, E, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw, nullptr, nullptr, &w.p_dU, &w.p_emb));
+        else if (tr) DP_TRY(run_wgrad(h, nullptr, E, E, nullptr, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw, w.dU, w.emb));
         else DP_TRY(run_wgrad(h, w.dUT, E, E, w.embT, E, E, Bpad, w.slabs, slab_cursor, (int64_t)E * E, h->off_se_w, rj, sw));
     }
     if (batched) {
@@ -1586,7 +1703,7 @@ static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const vo
     const int pshape = final_shape(Bpad);
     const int64_t prow = (Bpad / (shape_st(pshape) * 32)) * shape_ws(pshape);                 // wave rows = column-sum partial rows
     const int chan_waves = pshape == SHAPE_FINAL ? 1 : 2;                                    // waves side by side over the 64 channels
-    const bool fused_post = score_tuning().dsm_fused && h->Cp == 64 && prow * chan_waves <= 8192 && prow <= cs_post_rows(Bpad);
+    const bool fused_post = score_tuning().dsm_fused && !h->x3 && h->Cp == 64 && prow * chan_waves <= 8192 && prow <= cs_post_rows(Bpad);
     DP_TRY(forward_core_train(h, flat, packed, w, B, true, seed, step, st, !fused_post));
     int nb = 0;
     if (fused_post) {

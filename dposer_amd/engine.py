@@ -33,7 +33,7 @@ class ScoreEngine:
         desc = _C.ScoreFCDesc(data_dim, hidden_dim, embed_dim, n_blocks,
                               _C.EMB_FOURIER if embedding == "fourier" else _C.EMB_POSITIONAL,
                               1 if scale_by_sigma else 0, num_scales,
-                              _C.PREC_FP32 if precision == "fp32" else _C.PREC_BF16, float(dropout_p), _C.ACTIVATIONS[activation])
+                              _C.PRECISIONS[precision], float(dropout_p), _C.ACTIVATIONS[activation])
         h = C.c_void_p()
         _C.check(self.lib.dposer_scorefc_create(C.byref(desc), C.byref(h)), "dposer_scorefc_create")
         self.h = h
@@ -116,8 +116,8 @@ class ScoreEngine:
     def repack_target(self, flat: torch.Tensor):
         """The packed buffer the fused optimizer step may write into: it exists, lives on ``flat``'s device and holds the backward
         copies (so every zero-padded region has been written once); else None."""
-        if self._packed is None or self._packed.device != flat.device or not self._packed_bwd:
-            return None
+        if self._packed is None or self._packed.device != flat.device or not self._packed_bwd or self.precision == "bf16x3":
+            return None                    # (bf16x3: three column groups per weight segment -- packed by dposer_scorefc_pack only)
         return self._packed
 
     def mark_packed_by_optimizer(self, flat, params):
@@ -205,6 +205,6 @@ def default_precision(config=None) -> str:
         except Exception:
             p = None
     p = (p or "bf16").lower()
-    if p not in ("bf16", "fp32"):
-        raise ValueError(f"unknown precision {p!r} (bf16 | fp32)")
+    if p not in _C.PRECISIONS:
+        raise ValueError(f"unknown precision {p!r} (bf16 | fp32 | bf16x3)")
     return p

@@ -44,7 +44,11 @@ const char* dposer_last_error(void);
  * ---------------------------------------------------------------------------------------- */
 typedef struct dposer_scorefc_s* dposer_scorefc_t;
 
-enum { DPOSER_PREC_BF16 = 0, DPOSER_PREC_FP32 = 1 };
+/* DPOSER_PREC_BF16X3: reference-precision results ON the bf16 matrix pipe -- activations and weights are split into two bf16 terms
+ * (x = hi + lo, 16 mantissa bits), every GEMM accumulates hi*hi + lo*hi + hi*lo in fp32 (three v_mfma_f32_32x32x16_bf16 per product
+ * instead of sixteen-times-slower exact-fp32 MFMAs), everything outside the GEMMs (GroupNorm, SiLU, loss, optimizer, stored
+ * activations) is the fp32 mode's.  hidden_dim 1024 / swish. */
+enum { DPOSER_PREC_BF16 = 0, DPOSER_PREC_FP32 = 1, DPOSER_PREC_BF16X3 = 2 };
 enum { DPOSER_EMB_POSITIONAL = 0, DPOSER_EMB_FOURIER = 1 };
 /* config.model.nonlinearity (model.py:54-66): swish = SiLU; lrelu = LeakyReLU(0.2); elu = ELU(alpha = 1).  Swish runs on every
  * tiling; the other three on the 128-wide tilings (any batch), hidden_dim 1024 only */
@@ -59,7 +63,7 @@ typedef struct {
     int32_t embedding;       /* DPOSER_EMB_*      config.model.embedding_type  model.py:116-122 */
     int32_t scale_by_sigma;  /* config.model.scale_by_sigma  model.py:192 */
     int32_t num_scales;      /* length of the `sigmas` buffer  model.py:128 */
-    int32_t precision;       /* DPOSER_PREC_*: bf16 MFMA (throughput) or fp32 MFMA (parity) */
+    int32_t precision;       /* DPOSER_PREC_*: bf16 MFMA (throughput), fp32 MFMA (parity) or bf16 x 3 (parity on the bf16 pipe) */
     float dropout_p;         /* config.model.dropout  model.py:113 */
     int32_t activation;      /* DPOSER_ACT_*: config.model.nonlinearity (model.py:54-66 get_act); swish is the shipped one */
 } dposer_scorefc_desc;

@@ -25,7 +25,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "dposer_amd", "csrc")
-CONTRACT_OK = {"gemm_launch.hip", "gemm_sampler.hip"}          # (Makefile: everything else is built with -ffp-contract=off)
+CONTRACT_OK = {"gemm_launch.hip", "gemm_launch_x3.hip", "gemm_sampler.hip"}          # (Makefile: everything else is built with -ffp-contract=off)
 
 # the opt-in persistent sampler (DPOSER_SAMPLER_PERSISTENT=1, off by default: measured slower) keeps 8 pointer registers of its prologue in
 # scratch; nothing between its stage statements touches scratch (that check still applies to it)
