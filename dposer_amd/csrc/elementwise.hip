@@ -782,6 +782,65 @@ hipError_t launch_silu_bwd_reduce(const SiLUBwdReduceArgs& a, int max_blocks, in
     return hipGetLastError();
 }
 
+// FT-order form (fp32 storage): block (x, y) owns the four k-blocks [4 x, 4 x + 4) -- 32 columns -- of the row blocks y, y + gridDim.y, ...;
+// thread = (k-block, lane) keeps ONE column quad for all of its rows, so its column sums stay in registers; the 32 lanes (rows) of a
+// (k-block, half) are added through LDS at the end, in lane order.  Same per-element arithmetic and split order as k_silu_bwd_reduce.
+__global__ void __launch_bounds__(256) k_silu_bwd_reduce_ft(SiLUBwdReduceArgs a, __bf16* __restrict__ out_hi, __bf16* __restrict__ out_lo) {
+    __shared__ float cs[256][4];
+    const int kbs = a.N >> 3;                                       // FT32 k-blocks per row block
+    const int kb = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, kh = lane >> 5, r = lane & 31;
+    const int c = 8 * kb + 4 * kh;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    const float* pre = reinterpret_cast<const float*>(a.pre);
+    float* out = reinterpret_cast<float*>(a.out);
+    for (int64_t rb = blockIdx.y; rb < (a.Spad >> 5); rb += gridDim.y) {
+        const int64_t idx = ((rb * kbs + kb) << 8) + lane * 4;      // this thread's chunk of FT32 block (rb, kb)
+        const bool live = rb * 32 + r < a.B;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(a.part + idx);
+        for (int k = 1; k < a.nsplit; ++k) {                        // in split (= layer) order
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.part + (int64_t)k * a.split_stride + idx);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += v[q];
+        }
+        const f32x4 u = *reinterpret_cast<const f32x4*>(pre + idx);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = acc[q] * (a.act == DP_ACT_SWISH ? dsilu_f<true>(u[q]) : dact_rt<true>(u[q], a.act));
+        }
+        *reinterpret_cast<f32x4*>(out + idx) = o;
+        if (out_hi) {      // this thread's half (kh) of the 16-byte chunk of FT16 block (rb, kb >> 1), lane ((kb & 1), r)
+            __bf16 h4[4], l4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { h4[q] = (__bf16)o[q]; l4[q] = (__bf16)(o[q] - (float)h4[q]); }
+            const int64_t pidx = (((rb * (a.N >> 4) + (kb >> 1)) << 6) + ((kb & 1) << 5) + r) * 8 + kh * 4;
+            *reinterpret_cast<uint2*>(out_hi + pidx) = *reinterpret_cast<const uint2*>(h4);
+            *reinterpret_cast<uint2*>(out_lo + pidx) = *reinterpret_cast<const uint2*>(l4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) csum[q] += o[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cs[threadIdx.x][q] = csum[q];
+    __syncthreads();
+    if (r == 0) {                                                   // 8 threads: one per (k-block, half)
+        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < 32; ++l)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t4[q] += cs[threadIdx.x + l][q];
+        *reinterpret_cast<f32x4*>(a.cs_part + (int64_t)blockIdx.y * a.N + c) = t4;
+    }
+}
+hipError_t launch_silu_bwd_reduce_ft(const SiLUBwdReduceArgs& a, void* out_hi, void* out_lo, int max_blocks, int* nblocks, hipStream_t st) {
+    if (a.N % 32 != 0 || !a.f32 || a.nsplit < 1) return hipErrorInvalidValue;
+    int64_t gy = a.Spad >> 5;
+    gy = gy > 256 ? 256 : gy;                                        // partial rows of column sums (each block walks Spad / 32 / gy row blocks)
+    gy = gy > max_blocks ? max_blocks : gy;
+    *nblocks = (int)gy;
+    hipLaunchKernelGGL(k_silu_bwd_reduce_ft, dim3((unsigned)(a.N / 32), (unsigned)gy), dim3(256), 0, st, a, (__bf16*)out_hi, (__bf16*)out_lo);
+    return hipGetLastError();
+}
+
 template <typename T> __global__ void __launch_bounds__(256) k_dres_from_dout(DresArgs a) {
     const int qc = a.Cp >> 2;
     const int64_t total = a.Bpad * qc;
@@ -1046,6 +1105,8 @@ __device__ __forceinline__ void reduce_wgrad_tile_body(const WgradBatchArgs& a, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool first = true;
+    const int nterm = a.nterm > 1 ? a.nterm : 1;
+    for (int tm = 0; tm < nterm; ++tm)
     for (int rep = 0; rep < reps; ++rep) {
         const int sl = slot + rep_stride * rep;
         for (int l = l0; l <= l1; ++l) {
@@ -1057,7 +1118,7 @@ __device__ __forceinline__ void reduce_wgrad_tile_body(const WgradBatchArgs& a, 
                 if ((lo > st2 ? lo : st2) < (hi < e2 ? hi : e2)) ++ord;
                 st2 = e2;
             }
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.partials + ((int64_t)(wgb_block(l, sl) * WGB_MAX_SEG + ord) << 16)) + bxi * 1024 + threadIdx.x;
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.partials + (int64_t)tm * a.term_stride + ((int64_t)(wgb_block(l, sl) * WGB_MAX_SEG + ord) << 16)) + bxi * 1024 + threadIdx.x;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v = src[i * 256];

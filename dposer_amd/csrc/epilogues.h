@@ -130,7 +130,18 @@ struct GNParams {
     void* outT;            // TRAIN, optional: the output again as FT [H][Spad] (operand of the wgrad GEMMs)
     int64_t Spad;
     int act;               // DP_ACT_* (read by the ACTRT instantiations only; 0 = swish)
+    void* out_hi;          // fp32-storage instantiations only (bf16x3 mode), optional: the output again as two bf16 FT planes [Spad][H],
+    void* out_lo;          //   hi = bf16(out), lo = bf16(out - hi) -- the operand form of the consuming GEMMs; `out` itself may then be null
 };
+// bf16 planes of a 32 x 32 fp32 tile (bf16x3 mode: common.h TileIO<__bf16> converts with round-to-nearest-even, as k_split_ft32 does)
+__device__ __forceinline__ void store_tile_planes(void* hi_plane, void* lo_plane, int64_t s0, int c0, int K, int lane, const float (&v)[16]) {
+    float lo[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lo[r] = v[r] - (float)(__bf16)v[r];
+    const int64_t tb = ft_tile_base<__bf16>(s0, c0, K);
+    TileIO<__bf16>::store(reinterpret_cast<__bf16*>(hi_plane) + tb, lane, v);
+    TileIO<__bf16>::store(reinterpret_cast<__bf16*>(lo_plane) + tb, lane, lo);
+}
 // RESID: -1 = decide at run time from Params::resid (and null-check the optional outputs); 0 / 1 = residual input absent /
 // present at compile time AND no other branch in the code: dropout is always drawn
 // (DropoutCfg must then be valid: thr = 65536, scale = 1 when disabled), outT must be non-null.  The branch-free form is what
@@ -286,7 +297,12 @@ template <typename T, bool TRAIN, int RESID = -1, bool ACTRT = false> struct Epi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] += rr[r];
             }
-            TileIO<T>::store(p.out + tb, lane, o);
+            if constexpr (sizeof(T) == 4 && !FLAT) {
+                if (p.out) TileIO<T>::store(p.out + tb, lane, o);
+                if (pp.out_hi) store_tile_planes(pp.out_hi, pp.out_lo, sbase + ts * 32, c0, p.H, lane, o);
+            } else {
+                TileIO<T>::store(p.out + tb, lane, o);
+            }
             if (TRAIN && (FLAT || pp.outT)) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, o);
         }
     }
@@ -318,6 +334,8 @@ struct BiasSiLUParams {
     void* outT;    // TRAIN, optional: FT [N][Spad]
     int64_t Spad;
     int act;       // DP_ACT_* (ACTRT instantiations)
+    void* out_hi;  // fp32-storage instantiations only (bf16x3 mode), optional: `out` again as two bf16 FT planes
+    void* out_lo;
 };
 template <typename T, bool TRAIN, bool ACTRT = false> struct EpiBiasSiLU {
     typedef BiasSiLUParams Params;
@@ -347,6 +365,9 @@ template <typename T, bool TRAIN, bool ACTRT = false> struct EpiBiasSiLU {
                 for (int r = 0; r < 16; ++r) { u[r] = acc[tc][ts][r] + bia[r]; o[r] = ACTRT ? act_rt<PRECISE>(u[r], pp.act) : silu_f<PRECISE>(u[r]); }
                 if (TRAIN) TileIO<T>::store(p.pre + tb, lane, u);
                 TileIO<T>::store(p.out + tb, lane, o);
+                if constexpr (sizeof(T) == 4) {
+                    if (pp.out_hi) store_tile_planes(pp.out_hi, pp.out_lo, sbase + ts * 32, c0, p.N, lane, o);
+                }
                 if (TRAIN && pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, o);
             }
         }
@@ -657,6 +678,8 @@ struct GNBwdParams {
     void* dyT;             // optional: dy again as FT [H][Spad]
     int64_t Spad;
     int act;               // DP_ACT_* (ACTRT instantiations)
+    void* dy_hi;           // fp32-storage instantiations only (bf16x3 mode), optional: dy as two bf16 FT planes [Spad][H]; `dy` may then be null
+    void* dy_lo;
 };
 // ABL (tuner only): 1 = no parameter-gradient sums, 2 = no SiLU', 4 = ds_bpermute butterflies, 8 = loads / stores only
 template <typename T, int ABL = 0, bool ACTRT = false> struct EpiGNBwd {
@@ -957,7 +980,12 @@ template <typename T, int ABL = 0, bool ACTRT = false> struct EpiGNBwd {
                         if constexpr ((ABL & 1) == 0) dbias[i] += g[i];
                     }
                 }
-                TileIO<T>::store(p.dy + tb, lane, g);
+                if constexpr (sizeof(T) == 4) {
+                    if (p.dy) TileIO<T>::store(p.dy + tb, lane, g);
+                    if (pp.dy_hi) store_tile_planes(pp.dy_hi, pp.dy_lo, sbase + ts * 32, c0, p.H, lane, g);
+                } else {
+                    TileIO<T>::store(p.dy + tb, lane, g);
+                }
                 if (pp.dyT) TileT<T>::store((T*)pp.dyT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, g);
             }
             if constexpr ((ABL & 9) == 0) {

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(512, 1) k_sampler_persistent(SamplerArgs a) {
             for (int k = 0; k < GEMM_MAX_SEG; ++k) g.seg_stride_blocks[k] = 0;
             GNParams p;
             p.bias = trow + l * a.H; p.gamma = ly.gamma; p.beta = ly.beta; p.out = ly.out; p.resid = ly.resid; p.xhat = nullptr; p.aux = nullptr;
-            p.H = a.H; p.outT = nullptr; p.Spad = a.Spad; p.act = DP_ACT_SWISH;
+            p.H = a.H; p.outT = nullptr; p.Spad = a.Spad; p.act = DP_ACT_SWISH; p.out_hi = nullptr; p.out_lo = nullptr;
             p.drop.p = 0.f; p.drop.scale = 1.f; p.drop.thr = 65536; p.drop.site = 0; p.drop.offset = 0; p.drop.seed = 0; p.drop.groups_x4 = a.H / 8; p.drop.ext_keep = nullptr; p.drop.ext_rows = 0;
             // layer boundary: this workgroup's stores of the previous layer (or of the state update) have reached L2 before any of
             // its waves fetches them as the next operand
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(512, 1) k_sampler_cluster(SamplerArgs a) {
             for (int k = 0; k < GEMM_MAX_SEG; ++k) g.seg_stride_blocks[k] = 0;
             GNParams p;
             p.bias = trow + l * a.H; p.gamma = ly.gamma; p.beta = ly.beta; p.out = ly.out; p.resid = ly.resid; p.xhat = nullptr; p.aux = nullptr;
-            p.H = a.H; p.outT = nullptr; p.Spad = a.Spad; p.act = DP_ACT_SWISH;
+            p.H = a.H; p.outT = nullptr; p.Spad = a.Spad; p.act = DP_ACT_SWISH; p.out_hi = nullptr; p.out_lo = nullptr;
             p.drop.p = 0.f; p.drop.scale = 1.f; p.drop.thr = 65536; p.drop.site = 0; p.drop.offset = 0; p.drop.seed = 0; p.drop.groups_x4 = a.H / 8; p.drop.ext_keep = nullptr; p.drop.ext_rows = 0;
             for (int b = cluster; b < a.n_sblk; b += n_clusters) {
                 if (!cluster_wait<SYNC>(a, b, 4u * phase, tid, &s_word[1])) return;

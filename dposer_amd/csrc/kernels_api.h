@@ -203,6 +203,10 @@ struct SiLUBwdReduceArgs {  // dU = (sum over the k-splits of the time-branch dg
     int64_t B, Spad;
 };
 hipError_t launch_silu_bwd_reduce(const SiLUBwdReduceArgs& a, int max_blocks, int* nblocks, hipStream_t st);
+// the same reduction walked in FRAGMENT-TILE order (fp32 storage; bf16x3 mode at every batch size): every access is a coalesced 1-KiB run
+// (the row-major walk above touches one 16-byte chunk per 1-KiB block); optionally writes dU's bf16 operand planes too.  Column sums:
+// one partial row per row-block group (`*nblocks` rows of N floats in cs_part).
+hipError_t launch_silu_bwd_reduce_ft(const SiLUBwdReduceArgs& a, void* out_hi, void* out_lo, int max_blocks, int* nblocks, hipStream_t st);
 
 struct DresArgs {          // d res = d out / used_sigmas  (backward of model.py:192-194), FT store
     const float* dout;     // [B][D]

@@ -547,8 +547,8 @@ static void layout_ws(const dposer_scorefc_s* h, int64_t B, int mode, int n_step
         acc(h->Cp, H, (int64_t)h->D * H);
         acc(E, E, (int64_t)E * E);
         {   // room for the partial tiles of the one-launch weight gradients (wgrad_batch.h; plan_batched_wgrad has the conditions)
-            const int64_t need = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536 + ((int64_t)14 << 20);
-            if (score_tuning().wgrad_batched != 0 && !h->f32 && H == 1024 && E == 512 && slab_elems < need) slab_elems = need;
+            const int64_t need = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536 * h->wk + ((int64_t)14 << 20) * h->wk;      // (bf16x3: one partial set per product term)
+            if (score_tuning().wgrad_batched != 0 && (!h->f32 || h->x3) && H == 1024 && E == 512 && slab_elems < need) slab_elems = need;
         }
         w.slabs = (float*)take(slab_elems * 4);
         w.slab_elems = slab_elems;
@@ -661,8 +661,13 @@ static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* pack
     p.Spad = Bpad;
     p.act = h->d.activation;
     p.drop = drop_cfg(h, train, l, seed, step);
+    // bf16x3: the epilogue writes the operand planes of the consuming GEMMs itself; the fp32 tiles are kept only where a later layer adds
+    // them as its residual input (the outputs of layers 0, 2, ... below the last block)
+    p.out_hi = h->x3 ? out_pl.hi : nullptr;
+    p.out_lo = h->x3 ? out_pl.lo : nullptr;
+    if (h->x3 && !((l % 2) == 0 && l + 2 < h->L)) p.out = nullptr;
     DP_HIP_LAUNCH(gemm_gn(gemm_prec(h), train, shape, g, p, st, h->gs));
-    return split_act(h, out, out_pl, Bpad, h->H, st);
+    return DPOSER_OK;
 }
 
 static int run_post(dposer_scorefc_s* h, const float* flat, const char* packed, const void* in, const Planes& in_pl, float* res, int64_t B, int64_t Bpad, hipStream_t st) {
@@ -698,8 +703,10 @@ static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, 
     p.outT = tembT;
     p.Spad = Bpad;
     p.act = h->d.activation;
+    p.out_hi = h->x3 ? w.p_temb.hi : nullptr;      // (bf16x3: temb's operand planes straight from the epilogue)
+    p.out_lo = h->x3 ? w.p_temb.lo : nullptr;
     DP_HIP_LAUNCH(gemm_bias_silu(gemm_prec(h), train, shape, g, p, st));
-    return split_act(h, w.temb, w.p_temb, Bpad, h->E, st);
+    return DPOSER_OK;
 }
 
 // scale_by_sigma as the shared-t kernels take it: 0 off, 1 divide by sigmas[(int)label] (positional embedding, model.py:159), 2 divide by the
@@ -766,6 +773,7 @@ static int build_time_table(dposer_scorefc_s* h, const float* flat, const char* 
         add_seg(g, w.tt_emb, E / 8);
         BiasSiLUParams p;
         p.bias = flat + h->off_se_b; p.out = w.tt_temb; p.pre = nullptr; p.N = E; p.outT = nullptr; p.Spad = npad; p.act = h->d.activation;
+        p.out_hi = nullptr; p.out_lo = nullptr;
         DP_HIP_LAUNCH(gemm_bias_silu(PREC_FP32, false, shape, g, p, st));
     }
     {
@@ -1204,8 +1212,10 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         p.gamma = flat + lo.gamma; p.beta = flat + lo.beta; p.out = w.hbuf[l]; p.resid = resid; p.xhat = w.xhat[l]; p.aux = w.aux[l];
         p.H = h->H; p.drop = drop_cfg(h, dropout_on, l, seed, step); p.act = h->d.activation;
         p.outT = tr ? nullptr : w.hT[l]; p.Spad = w.Bpad;     // transposed copy for the wgrad GEMMs of the consuming layer
+        p.out_hi = h->x3 ? w.p_h[l].hi : nullptr;             // bf16x3: operand planes from the epilogue; fp32 tiles only where they are a residual input
+        p.out_lo = h->x3 ? w.p_h[l].lo : nullptr;
+        if (h->x3 && !((l % 2) == 0 && l + 2 < L)) p.out = nullptr;
         DP_HIP_LAUNCH(gemm_gn(gemm_prec(h), true, shape, g, p, st, h->gs));
-        DP_TRY(split_act(h, w.hbuf[l], w.p_h[l], w.Bpad, h->H, st));
     }
     if (!with_post) return DPOSER_OK;      // (the fused DSM step runs post_dense itself, with the loss in its epilogue)
     return run_post(h, flat, packed, w.hbuf[L - 1], w.p_h[L - 1], w.res, B, w.Bpad, st);
@@ -1319,10 +1329,14 @@ static int ensure_side_stream(dposer_scorefc_s* h) {
 // DPOSER_WGRAD_BATCHED = 0 forces it off, 1 also takes it when bucket events were asked for (they are then all recorded at the end).
 // Returns false when not applicable.
 // the lane problems of layers [l_first, l_last] (+ the shared time embedding): the whole step, or one layer of the bucketed backward
-static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first, int l_last, bool with_se, WgradBatchArgs& a) {
+// term (bf16x3 only): 0 = dy_hi^T in_hi, 1 = dy_lo^T in_hi, 2 = dy_hi^T in_lo on the bf16 planes; -1 = the stored (bf16) arrays
+static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first, int l_last, bool with_se, WgradBatchArgs& a, int term = -1) {
     if (h->H != 1024 || h->E != 512 || h->L < 2 || h->L > 9) return false;
-    const int64_t need = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536, small = (int64_t)14 << 20;
+    const int64_t set = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536, need = set * h->wk, small = ((int64_t)14 << 20) * h->wk;
     if (w.slab_elems < need + small) return false;
+    if (h->x3 && term < 0) term = 0;
+    auto A = [&](const void* stored, const Planes& pl) -> const void* { return term < 0 ? stored : (term == 1 ? pl.lo : pl.hi); };      // dY side
+    auto Bs = [&](const void* stored, const Planes& pl) -> const void* { return term < 0 ? stored : (term == 2 ? pl.lo : pl.hi); };     // input side
     const int S = (int)(w.Bpad / 32), nAh = h->H / 16, nE = h->E / 16;
     const int L = l_last + 1;
     if (S % 2 != 0) return false;
@@ -1333,7 +1347,7 @@ static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first
         if (n >= WGB_MAX_PROB) return false;                        // (three-block models: more lane problems than one launch holds)
         WgradLaneProblem& p = a.prob[n++];
         for (int i = 0; i < 2; ++i) {
-            p.dY[i] = w.dy[l]; p.H[i] = w.hbuf[l - 1]; p.nA[i] = nAh; p.nB[i] = nAh; p.sblk0[i] = 2 * i; p.sb_off[i] = 0;
+            p.dY[i] = A(w.dy[l], w.p_dy[l]); p.H[i] = Bs(w.hbuf[l - 1], w.p_h[l - 1]); p.nA[i] = nAh; p.nB[i] = nAh; p.sblk0[i] = 2 * i; p.sb_off[i] = 0;
             p.dst_off[i] = h->layer[l].w; p.ld[i] = h->H;
         }
         p.len = S;
@@ -1344,7 +1358,7 @@ static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first
         if (n >= WGB_MAX_PROB) return false;                        // (three-block models: more lane problems than one launch holds)
         WgradLaneProblem& p = a.prob[n++];
         for (int i = 0; i < 2; ++i) {
-            p.dY[i] = w.dy[l + i]; p.H[i] = w.temb; p.nA[i] = nAh; p.nB[i] = nE; p.sblk0[i] = 0; p.sb_off[i] = 0;
+            p.dY[i] = A(w.dy[l + i], w.p_dy[l + i]); p.H[i] = Bs(w.temb, w.p_temb); p.nA[i] = nAh; p.nB[i] = nE; p.sblk0[i] = 0; p.sb_off[i] = 0;
             p.dst_off[i] = h->layer[l + i].wt; p.ld[i] = h->E;
         }
         p.len = S;
@@ -1353,7 +1367,7 @@ static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first
         if (n >= WGB_MAX_PROB) return false;                        // (three-block models: more lane problems than one launch holds)
         WgradLaneProblem& p = a.prob[n++];
         for (int i = 0; i < 2; ++i) {
-            p.dY[i] = w.dy[L - 1]; p.H[i] = w.temb; p.nA[i] = nAh; p.nB[i] = nE; p.sblk0[i] = 0; p.sb_off[i] = i * (S / 2);
+            p.dY[i] = A(w.dy[L - 1], w.p_dy[L - 1]); p.H[i] = Bs(w.temb, w.p_temb); p.nA[i] = nAh; p.nB[i] = nE; p.sblk0[i] = 0; p.sb_off[i] = i * (S / 2);
             p.dst_off[i] = h->layer[L - 1].wt; p.ld[i] = h->E;
         }
         p.len = S / 2;
@@ -1362,12 +1376,13 @@ static bool plan_wgrad_lanes(const dposer_scorefc_s* h, const Ws& w, int l_first
     if (with_se && S % 4 == 0 && n < WGB_MAX_PROB) {                           // shared time embedding [E x E] = 2 x 2 tiles: four row quarters side by side
         if (n >= WGB_MAX_PROB) return false;                        // (three-block models: more lane problems than one launch holds)
         WgradLaneProblem& p = a.prob[n++];
-        p.dY[0] = w.dU; p.H[0] = w.emb; p.nA[0] = nE; p.nB[0] = nE; p.dst_off[0] = h->off_se_w; p.ld[0] = h->E;
+        p.dY[0] = A(w.dU, w.p_dU); p.H[0] = Bs(w.emb, w.p_emb); p.nA[0] = nE; p.nB[0] = nE; p.dst_off[0] = h->off_se_w; p.ld[0] = h->E;
         p.len = S / 4;
         p.mode = 1;
     }
     if (n > WGB_MAX_PROB) return false;
-    a.partials = w.slabs + (w.slab_elems - need);
+    a.partials = w.slabs + (w.slab_elems - need) + (term > 0 ? term * set : 0);
+    a.nterm = h->wk; a.term_stride = set;
     a.span = ((int64_t)S * nAh) << 10;
     if (a.span >= (int64_t)0xfff00000) return false;
     // every lane: at most WGB_MAX_SEG segments (short ones take the kernel's generic prologue / tail path)
@@ -1448,7 +1463,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     const bool tr = wgrad_tr_mode(h, Bpad);
     const bool has_events = sink != nullptr && sink->events != nullptr && sink->n_events > 0;
     WgradBatchArgs wb;
-    const bool batched = want_w && !h->x3 && plan_batched_wgrad(h, w, tr, has_events, wb);      // (bf16x3: three product terms per gradient -- the split-K launches)
+    const bool batched = want_w && plan_batched_wgrad(h, w, tr, has_events, wb);      // (bf16x3: one lane launch per product term, the partial sets added by one reduction)
     int grp_lo[MAX_L], grp_hi[MAX_L];
     const int n_groups = (want_w && !batched && !h->x3) ? plan_wgrad_groups(h, w, tr, grp_lo, grp_hi) : 0;
     // bf16x3: dres arrives from an elementwise kernel as fp32 fragment tiles
@@ -1464,7 +1479,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     rj.alt = nullptr;
     int64_t slab_cursor = 0;
     int n_chunks_post = 0, silu_rows = 0;
-    const int64_t lane_room = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536;
+    const int64_t lane_room = (int64_t)WGB_BLOCKS * WGB_MAX_SEG * 65536 * h->wk;
     // Deterministic reduction into the flat gradient: every partial buffer lives in the workspace (offsets relative to
     // w.slabs); the jobs of one bucket are launched together as soon as its last wgrad has been queued.
     auto rel = [&](const float* p) { return (int64_t)(p - w.slabs); };
@@ -1528,8 +1543,10 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         p.dy = w.dy[j]; p.part = w.gn_part[j]; p.H = H; p.S_valid = B;
         p.drop_scale = (dropout_on && h->d.dropout_p > 0.f) ? 1.0f / (1.0f - h->d.dropout_p) : 1.0f;   // the decisions themselves come from the forward pass (GnAux)
         p.dyT = (want_w && !tr) ? w.dyT[j] : nullptr; p.Spad = Bpad; p.act = h->d.activation;
+        p.dy_hi = h->x3 ? w.p_dy[j].hi : nullptr;            // bf16x3: dy is only ever a GEMM operand -- its planes, no fp32 tiles
+        p.dy_lo = h->x3 ? w.p_dy[j].lo : nullptr;
+        if (h->x3) p.dy = nullptr;
         DP_HIP_LAUNCH(gemm_gn_bwd(prec, gshape, g, p, st, h->gs));
-        DP_TRY(split_act(h, w.dy[j], w.p_dy[j], Bpad, H, st));
         if (!want_w) continue;
         if (two) {
             DP_CHECK_HIP(hipEventRecord(h->ev_layer[j], st));
@@ -1606,9 +1623,8 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
             ra.part = w.dU_part; ra.nsplit = L; ra.split_stride = Bpad * (int64_t)E; ra.pre = w.upre; ra.out = w.dU; ra.cs_part = w.silu_part;
             ra.N = E; ra.act = h->d.activation; ra.f32 = h->f32; ra.B = B; ra.Spad = Bpad;
             int nb = 0;
-            DP_HIP_LAUNCH(launch_silu_bwd_reduce(ra, (int)silu_part_rows(Bpad, true), &nb, st));
+            DP_HIP_LAUNCH(launch_silu_bwd_reduce_ft(ra, w.p_dU.hi, w.p_dU.lo, (int)silu_part_rows(Bpad, true), &nb, st));      // (writes dU's operand planes too)
             silu_rows = nb;
-            DP_TRY(split_act(h, w.dU, w.p_dU, Bpad, E, st));
         } else {
         g_next_flops = 2.0 * (double)B * E * L * H;
         GemmArgs g = gemm_args(packed + h->pk_wtT_all, L * H / KBS, E / (shape_ct(shape) * 32), (int)(Bpad / (shape_st(shape) * 32)));
@@ -1651,6 +1667,14 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         if (slab_cursor > w.slab_elems - lane_room) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: slab buffer too small for the batched wgrad launch");
         wb.alg_flops = 2.0 * (double)B * H * ((double)(L - 1) * H + (double)L * E) + (se_in_batch ? 2.0 * (double)B * E * E : 0.0);
         DP_HIP_LAUNCH(gemm_wgrad_tr_batch(wb, st));
+        if (h->x3) {     // the other two product terms: the same plan on the other planes, each into its own partial set
+            for (int term = 1; term < 3; ++term) {
+                WgradBatchArgs wt;
+                if (!plan_wgrad_lanes(h, w, 0, L - 1, se_in_batch, wt, term) || wt.nprob != wb.nprob) return dposer_set_error(DPOSER_ERR_BAD_ARG, "backward: lane plan changed between the product terms");
+                wt.alg_flops = 0.0;
+                DP_HIP_LAUNCH(gemm_wgrad_tr_batch(wt, st));
+            }
+        }
     }
     // what is left: the shared time embedding (front B), layer 0's jobs where they were not flushed with a group, and the parameters
     // that never get a gradient

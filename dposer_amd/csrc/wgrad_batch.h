@@ -32,6 +32,8 @@ struct WgradBatchArgs {
     WgradLaneProblem prob[WGB_MAX_PROB];
     int nprob, q;
     float* partials;      // [WGB_BLOCKS][WGB_MAX_SEG][256 * 256]
+    int nterm;            // reduction only: partial sets to add per output tile (0 / 1: one; bf16x3: the three product terms, one lane launch each)
+    int64_t term_stride;  // floats between the partial sets
     int64_t span;         // bytes the 32-bit DMA offsets must cover
     double alg_flops;     // algorithmic FLOPs of the launch (profiling only)
 };
