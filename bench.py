@@ -387,6 +387,35 @@ def main():
         model.precision = args.precision
         model._engines.pop("fp32", None)                    # release the fp32 engine's packed weights / workspaces
         torch.cuda.empty_cache()
+        # ... and in bf16x3 mode: reference-precision results ON the bf16 matrix pipe (operands split into two bf16 terms, three products per
+        # term, fp32 accumulation; fp32 epilogues) -- the same goldens at the same tolerances as the fp32 mode (tests/test_gpu_score.py)
+        model.precision = "bf16x3"
+        for _ in range(2):
+            step_fn(state, batch)
+        ddp.barrier()
+        torch.cuda.synchronize()
+        tx3 = time.perf_counter()
+        nx3 = 10
+        for _ in range(nx3):
+            step_fn(state, batch)
+        torch.cuda.synchronize()
+        ddp.barrier()
+        ex3 = time.perf_counter() - tx3
+        if world > 1:
+            tt = torch.tensor([ex3], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            ex3 = float(tt[0])
+        alg = 42.59e6 * args.global_batch * nx3 / ex3 / 1e12
+        extra["train_step_bf16x3_mode"] = {"poses_per_s": args.global_batch * nx3 / ex3, "ms_per_step": ex3 / nx3 * 1e3, "steps": nx3, "tflops_algorithmic": alg,
+                                           "roofline": {"bound": "mfma", "achieved": alg, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                        "frac": alg / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                                                        "matrix_pipe_tflops": 3 * alg, "matrix_pipe_frac": 3 * alg / MFMA_BF16_PEAK_TFLOPS,
+                                                        "scope": "whole step; `achieved` counts the ALGORITHMIC 42.59 MFLOP per pose -- the matrix pipe executes three "
+                                                                 "bf16 products per term (hi*hi + lo*hi + hi*lo), `matrix_pipe_*` is that machine work"},
+                                           "parity": "fp32-mode tolerances against the reference goldens (forward 2e-5, gradients 2e-4, sampler 1e-4)"}
+        model.precision = args.precision
+        model._engines.pop("bf16x3", None)
+        torch.cuda.empty_cache()
     if not args.no_extra:
         # ---- M2: 1000-step Euler-Maruyama sampling of the local shard, no trajectory kept ----
         model.eval()
@@ -417,6 +446,26 @@ def main():
         sps = args.global_batch / t_s
         extra["sampler"] = {"samples_per_s": sps, "seconds": t_s, "steps": args.sampler_steps, "finite": bool(torch.isfinite(xs).all()),
                             "tflops_algorithmic": 8.647e6 * args.sampler_steps * sps / 1e12}
+        if args.precision == "bf16" and world == 1:
+            # the same sampler in bf16x3 mode (reference-precision samples on the bf16 pipe), a bounded run of consecutive steps scaled to N
+            model.precision = "bf16x3"
+            n_x3 = min(100, args.sampler_steps)
+            sde_x = sde_lib.subVPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=n_x3)
+            fn_x = sampling.get_sampling_fn(cfg, sde_x, (B_local, 63), lambda v: v, 1e-3, device=dev)
+            fn_x(model, z=z_T, traj_stride=0)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            _, xs3 = fn_x(model, z=z_T, traj_stride=0)
+            torch.cuda.synchronize()
+            t_x = (time.perf_counter() - t2) / n_x3 * args.sampler_steps
+            alg_s = 8.647e6 * args.sampler_steps * (args.global_batch / t_x) / 1e12
+            extra["sampler_bf16x3_mode"] = {"samples_per_s": args.global_batch / t_x, "seconds_scaled_to_n_steps": t_x, "steps_timed": n_x3, "steps": args.sampler_steps,
+                                            "finite": bool(torch.isfinite(xs3).all()), "tflops_algorithmic": alg_s,
+                                            "roofline": {"bound": "mfma", "achieved": alg_s, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                         "frac": alg_s / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "matrix_pipe_frac": 3 * alg_s / MFMA_BF16_PEAK_TFLOPS}}
+            model.precision = args.precision
+            model._engines.pop("bf16x3", None)
+            torch.cuda.empty_cache()
         if sprof:
             name, (ms, cnt, fl) = max(sprof.items(), key=lambda kv: kv[1][0])
             ach_s = (fl / (ms * 1e-3)) / 1e12

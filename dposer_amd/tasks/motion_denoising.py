@@ -178,7 +178,7 @@ class MotionDenoise:
         """A BATCH of sequences advanced together by the one-call loop: joints3d [S, F, 22, 3], gt_poses / init_poses [S, F, 63],
         noise [steps, S * F, 63] or None.  Every sequence is the independent problem ``optimize`` solves (same schedule, same loss
         weights; temporal neighbours, data-term decision and loss means per sequence), but the S * F frames share every launch --
-        one 60-frame sequence leaves most of an MI355X idle (GPU-bound small kernels, DESIGN.md 4.5), and under data parallelism
+        one 60-frame sequence leaves most of an MI355X idle (GPU-bound small kernels, DESIGN.md 4.8), and under data parallelism
         each rank takes its shard of the sequences.  Returns the ``optimize`` metrics as [S, F] arrays and pose_body [S, F, 63]."""
         S, F = joints3d.shape[:2]
         if not self._fused_supported():

@@ -16,7 +16,7 @@
 // phases on paper, 89 measured).  A deeper pipeline (64-sample chunks, update overlapped with layer 0) could approach
 // ~60-65 us = 3 % of the sampler; not pursued.
 // The useful by-product is in the library: the bf16 image of a 32 x 32 accumulator tile, regrouped as TileIO<bf16>::store
-// regroups it, IS the MFMA B operand of the next layer (no LDS round trip) -- noted in DESIGN.md 4.2.
+// regroups it, IS the MFMA B operand of the next layer (no LDS round trip) -- noted in EXPERIMENTS.md (old 4.2).
 #pragma once
 #include "../../dposer_amd/csrc/gemm_api.h"
 
