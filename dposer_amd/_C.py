@@ -15,7 +15,7 @@ PREC_BF16, PREC_FP32, PREC_BF16X3 = 0, 1, 2
 PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
 EMB_POSITIONAL, EMB_FOURIER = 0, 1
 ACTIVATIONS = {"swish": 0, "elu": 1, "relu": 2, "lrelu": 3}      # config.model.nonlinearity -> DPOSER_ACT_*
-SDE_SUBVP, SDE_VP = 0, 1
+SDE_SUBVP, SDE_VP, SDE_VE = 0, 1, 2
 WS_INFER, WS_SHARED_T, WS_TRAIN = 0, 1, 2
 
 
@@ -93,6 +93,7 @@ SIGNATURES = {
     "dposer_prior_loss": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, f32, i32, f32, vp, vp, vp, u64,
                                     u32, vp, vp, i64, vp]),
     "dposer_prior_table_build": (C.c_int, [vp, vp, vp, vp, C.POINTER(f32), i32, vp, i64, vp]),
+    "dposer_prior_table_build_sde": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), C.POINTER(f32), i32, vp, i64, vp]),
     "dposer_prior_loss_tabled": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, f32, i32, i32, i32, f32, vp, vp, vp, u64, u32, vp, i64, vp]),
     "dposer_completion_optimize": (C.c_int, [vp, vp, vp, vp, C.POINTER(SdeDesc), vp, vp, vp, vp, vp, C.POINTER(f32), C.POINTER(i32),
                                              C.POINTER(f32), C.POINTER(f32), i32, f64, f64, f64, f64, vp, u64, u32, vp, vp, i64, vp]),

@@ -41,7 +41,7 @@ class FusedPfRhs:
         from .sde_lib import sde_desc
         desc = sde_desc(sde)
         device = torch.device(device)
-        if (os.environ.get("DPOSER_ODE_FUSED_RHS", "1") == "0" or desc is None or not isinstance(model, ScoreModelFC) or len(shape) != 2
+        if (os.environ.get("DPOSER_ODE_FUSED_RHS", "1") == "0" or desc is None or desc.kind == _C.SDE_VE or not isinstance(model, ScoreModelFC) or len(shape) != 2
                 or device.type != "cuda" or shape[1] != model._engine().D):
             return None
         return FusedPfRhs(_C, desc, model, shape, device, noise)

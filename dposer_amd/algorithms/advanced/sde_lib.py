@@ -211,6 +211,10 @@ def sde_desc(sde):
         kind = _C.SDE_SUBVP
     elif isinstance(sde, VPSDE):
         kind = _C.SDE_VP
+    elif isinstance(sde, VESDE):
+        # the beta fields carry sigma_min / sigma_max (include/dposer_hip.h: DPOSER_SDE_VE); the fused paths evaluate the CONTINUOUS
+        # VE score function (the network conditioned on sigma(t), utils.py:173) -- callers check `continuous` themselves
+        return _C.SdeDesc(_C.SDE_VE, int(sde.N), float(sde.sigma_min), float(sde.sigma_max), float(sde.T))
     else:
         return None
     return _C.SdeDesc(kind, int(sde.N), float(sde.beta_0), float(sde.beta_1), float(sde.T))

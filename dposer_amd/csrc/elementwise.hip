@@ -193,8 +193,8 @@ template <typename T, bool FOURIER> __global__ void __launch_bounds__(256) k_pre
                     for (int r = 0; r < 4; ++r)
                         if (c + r < a.D) z[r] = n4[r];
                 }
-                const float lmc = sde_lmc(d.sde, t);
-                const float mc = expf(lmc), sd = sde_std(d.sde, lmc);
+                const SdeAt at = sde_at(d.sde, t);
+                const float mc = at.mc, sd = at.sd;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)                 // losses.py:112-113  x_t = mean + std*z
                     if (c + r < a.D) v[r] = mc * a.x0[s * a.D + c + r] + sd * z[r];
@@ -204,7 +204,7 @@ template <typename T, bool FOURIER> __global__ void __launch_bounds__(256) k_pre
             if (q == 0) a.t_out[s] = t;
         } else {
             const int g0 = (int)((i - nx) / a.Bpad) * PREP_EQ;
-            const float label = t * 999.0f;                 // utils.py:152
+            const float label = d.sde.kind == SDE_VE ? sde_ve_sigma(d.sde.smin, d.sde.ratio, t) : t * 999.0f;     // utils.py:152 / :173
             // all 32 frequencies first: behind a store to `emb` hipcc cannot hoist the next load of `freq` (the two may alias), and the
             // thread walked 32 dependent load -> sin -> store round trips -- 17 us of the kernel at ANY batch size
             const int half = a.E >> 1;
@@ -293,14 +293,11 @@ template <typename T> __global__ void __launch_bounds__(256) k_em_update(EmDev d
     const int64_t total = a.Bpad * qx;
     // per-step scalars (identical for every sample: vec_t = ones(B)*t, sampling.py:458)
     const float t = a.t;
-    const float lmc = sde_lmc(d.sde, t);
-    const float mc = expf(lmc), sd = sde_std(d.sde, lmc);
-    const float beta = sde_beta(d.sde, t);
-    const float g = sde_diffusion(d.sde, t);
-    const float label = t * 999.0f;
+    const SdeAt at = sde_at(d.sde, t);
+    const float mc = at.mc, sd = at.sd, beta = at.beta, g = at.g, label = at.label;
     const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, label, a.scale_by_sigma == 2) : 1.0f;
     float mcn = 0.f, sdn = 0.f;
-    if (a.t_next >= 0.f) { const float l2 = sde_lmc(d.sde, a.t_next); mcn = expf(l2); sdn = sde_std(d.sde, l2); }
+    if (a.t_next >= 0.f) { const SdeAt an = sde_at(d.sde, a.t_next); mcn = an.mc; sdn = an.sd; }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = i / qx;              // quad index fastest: row-major [B][D] streams are read/written contiguously
         const int q = (int)(i % qx);
@@ -319,7 +316,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_em_update(EmDev d
                 if (a.res) {
                     // score = -(res / used_sigmas) / std                         model.py:194, utils.py:162
                     const float model = a.res[s * a.Cp + c + r] / usig;
-                    const float score = -model / sd;
+                    const float score = sde_score(d.sde, model, sd);
                     // rsde.sde: drift = -0.5 beta x - g^2 score                  sde_lib.py:98-104
                     float drift = (-0.5f * beta) * x;
                     drift = drift - ((g * g) * score) * 1.0f;
@@ -401,8 +398,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_perturb_shared(Pe
     const PerturbSharedArgs& a = d.a;
     const int qx = a.Dpad >> 2;
     const int QD = (a.D + 3) >> 2;
-    const float lmc = sde_lmc(d.sde, a.t);
-    const float mc = expf(lmc), sd = sde_std(d.sde, lmc);
+    const SdeAt at = sde_at(d.sde, a.t);
+    const float mc = at.mc, sd = at.sd;
     const int64_t total = a.Bpad * qx;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = i / qx;
@@ -440,10 +437,10 @@ struct DenoiseDev {
 __global__ void __launch_bounds__(256) k_denoise(DenoiseDev d) {
     const DenoiseArgs& a = d.a;
     const float t = a.t;
-    const float lmc = sde_lmc(d.sde, t);
-    const float alpha = expf(lmc), sigma = sde_std(d.sde, lmc);      // return_alpha_sigma, sde_lib.py:227-231
+    const SdeAt at = sde_at(d.sde, t);
+    const float alpha = at.mc, sigma = at.sd;                         // return_alpha_sigma, sde_lib.py:227-231 (VE: 1, sigma(t), :289-292)
     const float sigma2 = sigma * sigma;
-    const float label = t * 999.0f;
+    const float label = at.label;
     const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, label, a.scale_by_sigma == 2) : 1.0f;
     const float snr = alpha / sqrtf(sigma2);                          // completion.py:108
     const float w = a.weighted ? 0.5f * sqrtf(1.0f + snr) : 0.5f;     // completion.py:143-146
@@ -453,7 +450,7 @@ __global__ void __launch_bounds__(256) k_denoise(DenoiseDev d) {
         const int64_t s = i / a.D;
         const int c = (int)(i % a.D);
         const float model = a.res[s * a.Cp + c] / usig;
-        const float score = -model / sigma;                           // utils.py:155,162 (std == sigma)
+        const float score = sde_score(d.sde, model, sigma);           // utils.py:155,162 (std == sigma)
         const float x0h = (a.xt[s * a.Dpad + c] + sigma2 * score) / alpha;   // completion.py:107
         const float diff = a.x0[i] - x0h;
         acc += w * (diff * diff);
@@ -483,10 +480,10 @@ struct CompletionDev {
 };
 __global__ void __launch_bounds__(256) k_completion_update(CompletionDev d) {
     const CompletionUpdateArgs& a = d.a;
-    const float lmc = sde_lmc(d.sde, a.t);
-    const float alpha = expf(lmc), sigma = sde_std(d.sde, lmc);      // return_alpha_sigma, sde_lib.py:227-231
+    const SdeAt at = sde_at(d.sde, a.t);
+    const float alpha = at.mc, sigma = at.sd;                         // return_alpha_sigma, sde_lib.py:227-231
     const float sigma2 = sigma * sigma;
-    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, a.scale_by_sigma == 2) : 1.0f;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, at.label, a.scale_by_sigma == 2) : 1.0f;
     const float snr = alpha / sqrtf(sigma2);                          // completion.py:108
     const float w = a.weighted ? 0.5f * sqrtf(1.0f + snr) : 0.5f;     // completion.py:143-146
     const int64_t total = a.B * a.D;
@@ -494,7 +491,7 @@ __global__ void __launch_bounds__(256) k_completion_update(CompletionDev d) {
         const int64_t s = i / a.D;
         const int c = (int)(i % a.D);
         const float model = a.res[s * a.Cp + c] / usig;
-        const float score = -model / sigma;                           // utils.py:155,162
+        const float score = sde_score(d.sde, model, sigma);           // utils.py:155,162
         const float x0h = (a.xt[s * a.Dpad + c] + sigma2 * score) / alpha;   // completion.py:107
         float x = a.x[i];
         const float mk = a.mask[i];
@@ -530,13 +527,14 @@ struct LangevinDev {
     SdeDev sde;
 };
 __device__ __forceinline__ float langevin_score(const LangevinDev& d, float res, float usig, float sd) {
-    return -(res / usig) / sd;                                        // model.py:194, utils.py:155,162
+    return sde_score(d.sde, res / usig, sd);                          // model.py:194, utils.py:155,162
 }
 __global__ void __launch_bounds__(256) k_langevin_norms(LangevinDev d) {
     const LangevinArgs& a = d.a;
     const int QD = (a.D + 3) >> 2;
-    const float sd = sde_std(d.sde, sde_lmc(d.sde, a.t));
-    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, a.scale_by_sigma == 2) : 1.0f;
+    const SdeAt at = sde_at(d.sde, a.t);
+    const float sd = at.sd;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, at.label, a.scale_by_sigma == 2) : 1.0f;
     float gsum = 0.f, nsum = 0.f;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.B; s += (int64_t)gridDim.x * blockDim.x) {
         float g2 = 0.f, n2 = 0.f;
@@ -584,8 +582,9 @@ template <typename T> __global__ void __launch_bounds__(256) k_langevin_update(L
     const LangevinArgs& a = d.a;
     const int qx = a.Dpad >> 2;
     const int QD = (a.D + 3) >> 2;
-    const float sd = sde_std(d.sde, sde_lmc(d.sde, a.t));
-    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, a.t * 999.0f, a.scale_by_sigma == 2) : 1.0f;
+    const SdeAt at = sde_at(d.sde, a.t);
+    const float sd = at.sd;
+    const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, at.label, a.scale_by_sigma == 2) : 1.0f;
     const float grad_norm = a.norm_sums[0] * a.inv_global_batch, noise_norm = a.norm_sums[1] * a.inv_global_batch;   // .mean()
     const float r0 = a.snr * noise_norm / grad_norm;
     const float step = ((r0 * r0) * 2.0f) * a.alpha;                  // sampling.py:298
@@ -667,17 +666,19 @@ template <typename T> __global__ void __launch_bounds__(256) k_dsm(DsmDev d) {
             f32x4 dr = {0.f, 0.f, 0.f, 0.f};
             if (s < a.B && c < a.D) {
                 const float t = a.t[s];
-                const float lmc = sde_lmc(d.sde, t);
-                const float sd = sde_std(d.sde, lmc);
-                const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, t * 999.0f, a.fourier) : 1.0f;
+                const SdeAt at = sde_at(d.sde, t);
+                const float sd = at.sd;
+                const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, at.label, a.fourier) : 1.0f;
+                const bool ve = d.sde.kind == SDE_VE;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (c + r < a.D) {
                         const float model = a.res[s * a.Cp + c + r] / usig;
-                        const float score = -model / sd;                               // utils.py:162
+                        const float score = sde_score(d.sde, model, sd);               // utils.py:162 / :180
                         const float e = score * sd + a.z[s * a.Dpad + c + r];          // losses.py:124
                         acc += e * e;
-                        dr[r] = (-2.0f * e) * a.grad_scale / usig;
+                        // d e / d res = -1 / used_sigma (sub-VP / VP: std cancels) or std / used_sigma (VE)
+                        dr[r] = ve ? ((2.0f * e) * sd) * a.grad_scale / usig : (-2.0f * e) * a.grad_scale / usig;
                     }
             }
             store_quad_ft<T>(a.dres, s, c, a.Cp, dr);
@@ -1544,7 +1545,7 @@ __global__ void __launch_bounds__(256) k_pf_rhs_end(PfRhsDev d) {
 static SdeDev pf_sde_dev(const dposer_sde_desc* s) {
     SdeCfg c;
     c.kind = s->kind == DPOSER_SDE_VP ? SDE_VP : SDE_SUBVP;
-    c.beta_0 = (float)s->beta_min; c.beta_1 = (float)s->beta_max; c.N = s->N; c.T = (float)s->T;
+    c.beta_0 = s->beta_min; c.beta_1 = s->beta_max; c.N = s->N; c.T = (float)s->T;
     return make_sde_dev(c);
 }
 extern "C" int dposer_pf_ode_rhs_begin(const dposer_sde_desc* sde, float t, const double* state, const float* noise, float* x, float* labels,

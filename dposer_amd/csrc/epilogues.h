@@ -478,11 +478,11 @@ template <typename T> struct EpiEmStep {
     __device__ static inline Scal scalars(const Params& p) {
 #pragma clang fp contract(off)
         Scal sc;
-        const float lmc = sde_lmc(p.sde, p.t);
-        sc.sd = sde_std(p.sde, lmc);
-        sc.beta = sde_beta(p.sde, p.t);
-        sc.g = sde_diffusion(p.sde, p.t);
-        sc.usig = p.scale_by_sigma ? used_sigma(p.sigmas, p.num_scales, p.t * 999.0f, p.scale_by_sigma == 2) : 1.0f;
+        const SdeAt at = sde_at(p.sde, p.t);
+        sc.sd = at.sd;
+        sc.beta = at.beta;
+        sc.g = at.g;
+        sc.usig = p.scale_by_sigma ? used_sigma(p.sigmas, p.num_scales, at.label, p.scale_by_sigma == 2) : 1.0f;
         return sc;
     }
     // one 32x32 tile: x (in: the state, out: the next state) and x_mean from the post_dense accumulator `a`
@@ -499,7 +499,7 @@ template <typename T> struct EpiEmStep {
                 const int i = 4 * q + r;
                 const bool valid = s < p.S_valid && c + r < p.D;
                 const float model = (a[i] + (c + r < p.D ? p.bias[c + r] : 0.f)) / usig;
-                const float score = -model / sd;
+                const float score = sde_score(p.sde, model, sd);
                 float drift = (-0.5f * beta) * x[i];
                 drift = drift - ((g * g) * score) * 1.0f;
                 const float mean = x[i] + drift * p.sde.dt;

@@ -818,14 +818,21 @@ static int run_shared_t(dposer_scorefc_s* h, const float* flat, const char* pack
 
 static SdeCfg to_sde(const dposer_sde_desc* s) {
     SdeCfg c;
-    c.kind = s->kind == DPOSER_SDE_VP ? SDE_VP : SDE_SUBVP;
-    c.beta_0 = (float)s->beta_min;
-    c.beta_1 = (float)s->beta_max;
+    c.kind = s->kind == DPOSER_SDE_VP ? SDE_VP : (s->kind == DPOSER_SDE_VE ? SDE_VE : SDE_SUBVP);
+    c.beta_0 = s->beta_min;
+    c.beta_1 = s->beta_max;
     c.N = s->N;
     c.T = (float)s->T;
     return c;
 }
 
+static bool sde_kind_ok(const dposer_sde_desc* s) { return s->kind == DPOSER_SDE_SUBVP || s->kind == DPOSER_SDE_VP || s->kind == DPOSER_SDE_VE; }
+// what the network is conditioned on at time t: t * 999 (utils.py:152) or, for VE, sigma(t) (utils.py:173) -- fp32, as the kernels form it
+static float sde_label_host(const dposer_sde_desc* s, float t) {
+    if (s->kind != DPOSER_SDE_VE) return t * 999.0f;
+    const SdeDev d = make_sde_dev(to_sde(s));
+    return sde_ve_sigma(d.smin, d.ratio, t);
+}
 static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde, float* x,
                            float* x_mean, const float* timesteps_host, int32_t start_step, int32_t n_steps, const float* observation,
                            const float* mask, const float* noise, uint64_t seed, float* traj, int32_t traj_stride, const float* freq,
@@ -853,7 +860,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x && x_mean && timesteps_host && freq && sigmas, "null argument");
-    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused sampler supports subVP / VP SDEs");
+    DP_CHECK_ARG(sde_kind_ok(sde), "unknown SDE kind");
     DP_CHECK_ARG(sde->N >= 1 && start_step >= 0 && start_step <= sde->N, "bad step range");
     DP_CHECK_ARG((observation == nullptr) == (mask == nullptr), "observation and mask go together");
     DP_CHECK_ARG(traj_stride >= 1, "traj_stride must be >= 1");
@@ -866,7 +873,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     layout_ws(h, B, DPOSER_WS_SHARED_T, n_run, (char*)ws_, w);
     // labels = t * 999 (utils.py:152), fp32 product on the host, one H2D copy
     h->host_stage.resize(n_run);
-    for (int i = 0; i < n_run; ++i) h->host_stage[i] = timesteps_host[start_step + i] * 999.0f;
+    for (int i = 0; i < n_run; ++i) h->host_stage[i] = sde_label_host(sde, timesteps_host[start_step + i]);
     DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n_run * sizeof(float), hipMemcpyHostToDevice, st));
     DP_TRY(build_time_table(h, flat, packed, w, w.tt_labels, 0.f, n_run, freq, st));
 
@@ -997,7 +1004,7 @@ extern "C" int dposer_langevin_step(dposer_scorefc_t h, const float* flat, const
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x && norm_sums && freq && sigmas, "null argument");
-    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused Langevin step supports subVP / VP SDEs");
+    DP_CHECK_ARG(sde_kind_ok(sde), "unknown SDE kind");
     DP_CHECK_ARG(phase == 0 || phase == 1, "phase must be 0 (norms) or 1 (update)");
     DP_CHECK_ARG(phase == 0 || x_mean, "x_mean is required in the update phase");
     hipStream_t st = (hipStream_t)stream;
@@ -1011,7 +1018,7 @@ extern "C" int dposer_langevin_step(dposer_scorefc_t h, const float* flat, const
     a.Cp = h->Cp; a.num_scales = h->d.num_scales; a.scale_by_sigma = sbs_mode(h); a.f32 = h->f32; a.sde = to_sde(sde); a.seed = seed;
     a.step = step;
     if (phase == 0) {
-        DP_TRY(build_time_table(h, flat, packed, w, nullptr, t * 999.0f, 1, freq, st));
+        DP_TRY(build_time_table(h, flat, packed, w, nullptr, sde_label_host(sde, t), 1, freq, st));
         DP_HIP_LAUNCH(launch_pack_rows(x, w.xin, B, w.Bpad, h->D, h->Dpad, h->f32, st));
         DP_TRY(run_shared_t(h, flat, packed, w, 0, B, st));
         int nb = 0;
@@ -1032,13 +1039,13 @@ static int prior_loss_impl(dposer_scorefc_t h, const float* flat, const void* pa
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x0 && loss && sigmas && (freq || table_rows > 0), "null argument");
-    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "prior loss supports subVP / VP SDEs");
+    DP_CHECK_ARG(sde_kind_ok(sde), "unknown SDE kind");
     DP_CHECK_ARG(table_rows <= 0 || (row >= 0 && row < table_rows), "table row out of range");
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
     Ws w;
     layout_ws(h, B, DPOSER_WS_SHARED_T, table_rows > 0 ? table_rows : 1, (char*)ws_, w);
-    if (table_rows <= 0) DP_TRY(build_time_table(h, flat, packed, w, nullptr, t * 999.0f, 1, freq, st));
+    if (table_rows <= 0) DP_TRY(build_time_table(h, flat, packed, w, nullptr, sde_label_host(sde, t), 1, freq, st));
     const SdeCfg sc = to_sde(sde);
     PerturbSharedArgs pa;
     pa.x0 = x0; pa.z_in = z; pa.xin = w.xin; pa.xt = w.xt; pa.t = t; pa.B = B; pa.Bpad = w.Bpad; pa.D = h->D; pa.Dpad = h->Dpad;
@@ -1063,14 +1070,19 @@ extern "C" int dposer_prior_loss(dposer_scorefc_t h, const float* flat, const vo
 }
 extern "C" int dposer_prior_table_build(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const float* t_host,
                                         int32_t n_rows, const float* freq, int64_t B, void* stream) {
+    return dposer_prior_table_build_sde(h, flat, packed_, ws_, nullptr, t_host, n_rows, freq, B, stream);
+}
+extern "C" int dposer_prior_table_build_sde(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
+                                            const float* t_host, int32_t n_rows, const float* freq, int64_t B, void* stream) {
     DP_RANGE();
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     DP_CHECK_ARG(t_host && freq && n_rows >= 1, "bad argument");
+    DP_CHECK_ARG(!sde || sde_kind_ok(sde), "unknown SDE kind");
     hipStream_t st = (hipStream_t)stream;
     Ws w;
     layout_ws(h, B, DPOSER_WS_SHARED_T, n_rows, (char*)ws_, w);
     h->host_stage.resize(n_rows);
-    for (int i = 0; i < n_rows; ++i) h->host_stage[i] = t_host[i] * 999.0f;     // labels = t * 999 (utils.py:152)
+    for (int i = 0; i < n_rows; ++i) h->host_stage[i] = sde ? sde_label_host(sde, t_host[i]) : t_host[i] * 999.0f;     // labels = t * 999 (utils.py:152); VE: sigma(t)
     DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n_rows * sizeof(float), hipMemcpyHostToDevice, st));
     return build_time_table(h, flat, (const char*)packed_, w, w.tt_labels, 0.f, n_rows, freq, st);
 }
@@ -1098,7 +1110,7 @@ extern "C" int dposer_completion_optimize(dposer_scorefc_t h, const float* flat,
     g_alg_batch = B;
     DP_CHECK_ARG(sde && x && observation && mask && adam_m && adam_v && t_host && weighted_host && w_prior_host && w_data_host && freq && sigmas,
                  "null argument");
-    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused completion loop supports subVP / VP SDEs");
+    DP_CHECK_ARG(sde_kind_ok(sde), "unknown SDE kind");
     DP_CHECK_ARG(n_steps >= 0, "n_steps must be >= 0");
     if (n_steps == 0) return DPOSER_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -1106,7 +1118,7 @@ extern "C" int dposer_completion_optimize(dposer_scorefc_t h, const float* flat,
     Ws w;
     layout_ws(h, B, DPOSER_WS_SHARED_T, n_steps, (char*)ws_, w);
     h->host_stage.resize(n_steps);
-    for (int i = 0; i < n_steps; ++i) h->host_stage[i] = t_host[i] * 999.0f;      // labels = t * 999 (utils.py:152)
+    for (int i = 0; i < n_steps; ++i) h->host_stage[i] = sde_label_host(sde, t_host[i]);      // labels = t * 999 (utils.py:152) / sigma(t) (VE, :173)
     DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n_steps * sizeof(float), hipMemcpyHostToDevice, st));
     DP_TRY(build_time_table(h, flat, packed, w, w.tt_labels, 0.f, n_steps, freq, st));
     const SdeCfg sc = to_sde(sde);
@@ -1711,7 +1723,7 @@ static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const vo
     DP_TRY(check_common(h, flat, packed_, ws_, B));
     g_alg_batch = B;
     DP_CHECK_ARG(sde && batch_x && freq && sigmas && flat_grad && loss, "null argument");
-    DP_CHECK_ARG(sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VP, "fused DSM step supports subVP / VP SDEs");
+    DP_CHECK_ARG(sde_kind_ok(sde), "unknown SDE kind");
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
     Ws w;
@@ -1727,7 +1739,7 @@ static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const vo
     const int pshape = final_shape(Bpad);
     const int64_t prow = (Bpad / (shape_st(pshape) * 32)) * shape_ws(pshape);                 // wave rows = column-sum partial rows
     const int chan_waves = pshape == SHAPE_FINAL ? 1 : 2;                                    // waves side by side over the 64 channels
-    const bool fused_post = score_tuning().dsm_fused && !h->x3 && h->Cp == 64 && prow * chan_waves <= 8192 && prow <= cs_post_rows(Bpad);
+    const bool fused_post = score_tuning().dsm_fused && !h->x3 && sde->kind != DPOSER_SDE_VE && h->Cp == 64 && prow * chan_waves <= 8192 && prow <= cs_post_rows(Bpad);
     DP_TRY(forward_core_train(h, flat, packed, w, B, true, seed, step, st, !fused_post));
     int nb = 0;
     if (fused_post) {

@@ -8,10 +8,10 @@
 #include "common.h"
 
 // ---- SDE description (reference lib/algorithms/advanced/sde_lib.py) --------------------------------
-enum : int { SDE_SUBVP = 0, SDE_VP = 1 };
+enum : int { SDE_SUBVP = 0, SDE_VP = 1, SDE_VE = 2 };
 struct SdeCfg {
     int kind;
-    float beta_0, beta_1;
+    double beta_0, beta_1;   // python floats of the reference's constructor; VE: sigma_min, sigma_max (sde_lib.py:235-247)
     int N;
     float T;
 };
@@ -20,16 +20,29 @@ struct SdeDev {
     int kind;
     float b0, db, m2b0;   // beta_0, (beta_1 - beta_0), -2*beta_0  (python doubles rounded to fp32)
     float dt, sqrt_mdt;   // -1/N, sqrt(1/N)
+    float smin, ratio, gk;   // VE: sigma_min, sigma_max / sigma_min, sqrt(fp32(2 (ln sigma_max - ln sigma_min)))   sde_lib.py:260-264
 };
 static inline SdeDev make_sde_dev(const SdeCfg& s) {
     SdeDev d;
     d.kind = s.kind;
-    d.b0 = (float)(double)s.beta_0;
-    d.db = (float)((double)s.beta_1 - (double)s.beta_0);
-    d.m2b0 = (float)(-2.0 * (double)s.beta_0);
+    const double b0 = (double)(float)s.beta_0, b1 = (double)(float)s.beta_1;      // (sub-VP / VP: the fp32-rounded constructor arguments, as rounds 1-4 formed them)
+    d.b0 = (float)b0;
+    d.db = (float)(b1 - b0);
+    d.m2b0 = (float)(-2.0 * b0);
     d.dt = (float)(-1.0 / (double)s.N);
     d.sqrt_mdt = (float)sqrt(1.0 / (double)s.N);
+    d.smin = d.ratio = d.gk = 0.f;
+    if (s.kind == SDE_VE) {
+        d.smin = (float)s.beta_0;                                           // `self.sigma_min * tensor`: the python float enters as an fp32 scalar
+        d.ratio = (float)(s.beta_1 / s.beta_0);                             // `(self.sigma_max / self.sigma_min) ** t`: python-float quotient, fp32 pow
+        d.gk = sqrtf((float)(2.0 * (log(s.beta_1) - log(s.beta_0))));       // torch.sqrt(torch.tensor(2 * (np.log(smax) - np.log(smin)))): fp32 tensor, fp32 sqrt
+    }
     return d;
+}
+// sigma(t) of the VE SDE (sde_lib.py:260,267): the same expression on host (time-table labels) and device
+__host__ __device__ __forceinline__ float sde_ve_sigma(float smin, float ratio, float t) {
+#pragma clang fp contract(off)
+    return smin * powf(ratio, t);
 }
 __device__ __forceinline__ float sde_lmc(const SdeDev& s, float t) {          // sde_lib.py:214
 #pragma clang fp contract(off)
@@ -50,6 +63,30 @@ __device__ __forceinline__ float sde_diffusion(const SdeDev& s, float t) {     /
     if (s.kind == SDE_VP) return sqrtf(beta);
     const float discount = 1.0f - expf(s.m2b0 * t - s.db * (t * t));
     return sqrtf(beta * discount);
+}
+
+// Everything the kernels need of the forward SDE at one t, for all three kinds (the sub-VP / VP members are the functions above, evaluated
+// in the order the call sites always used):
+//   mc, sd  marginal_prob: mean = mc * x, std = sd        (VE: 1, sigma(t))
+//   beta, g sde: drift = -1/2 beta x, diffusion g         (VE: 0, sigma(t) * sqrt(2 ln(sigma_max / sigma_min)))
+//   label   what the network is conditioned on            (t * 999, utils.py:152; VE: sigma(t), utils.py:173)
+struct SdeAt { float mc, sd, beta, g, label; };
+__device__ __forceinline__ SdeAt sde_at(const SdeDev& s, float t) {
+#pragma clang fp contract(off)
+    SdeAt r;
+    if (s.kind == SDE_VE) {
+        const float sig = sde_ve_sigma(s.smin, s.ratio, t);
+        r.mc = 1.0f; r.sd = sig; r.beta = 0.0f; r.g = sig * s.gk; r.label = sig;
+    } else {
+        const float lmc = sde_lmc(s, t);
+        r.mc = expf(lmc); r.sd = sde_std(s, lmc); r.beta = sde_beta(s, t); r.g = sde_diffusion(s, t); r.label = t * 999.0f;
+    }
+    return r;
+}
+// score from the network output `model` (already divided by used_sigmas): -model / std for sub-VP / VP (utils.py:162), the output itself for VE (:180)
+__device__ __forceinline__ float sde_score(const SdeDev& s, float model, float sd) {
+#pragma clang fp contract(off)
+    return s.kind == SDE_VE ? model : -model / sd;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -285,7 +285,7 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     }
 
     // time-bias rows of all steps: two small GEMMs once instead of per step
-    if (a->n_steps > 0) DP_TRY(dposer_prior_table_build(a->net, a->flat_params, a->packed, a->net_ws, a->t_host, a->n_steps, a->freq, T, stream));
+    if (a->n_steps > 0) DP_TRY(dposer_prior_table_build_sde(a->net, a->flat_params, a->packed, a->net_ws, a->sde, a->t_host, a->n_steps, a->freq, T, stream));
     for (int k = 0; k < a->n_steps; ++k) {
         if (rot6d) hipLaunchKernelGGL(k_md_normalize6d, dim3((unsigned)ceil_div(n / 3, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n / 3, D / 3);
         else hipLaunchKernelGGL(k_md_normalize, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n, D);

@@ -73,7 +73,7 @@ def prior_loss(model, sde, x0, t, *, weighted=True, reduction="mean", batch_size
     if x0.shape[0] == 0:
         raise ValueError("prior_loss: empty batch (the reference's torch.mean over no elements is NaN)")
     n = x0.numel() if reduction == "mean" else (batch_size if batch_size is not None else x0.shape[0])
-    if sde_lib.sde_desc(sde) is None:      # VE: no fused kernel -- the HIP score function + the reference's few elementwise steps
+    if sde_lib.sde_desc(sde) is None:      # an SDE the fused kernel does not cover: the HIP score function + the reference's few elementwise steps (VE is fused since round 5)
         return _prior_loss_unfused(model, sde, x0, float(t), bool(weighted), 1.0 / float(n), z)
     return _PriorLoss.apply(x0, model, sde, float(t), bool(weighted), 1.0 / float(n), z, seed, step)
 

@@ -47,7 +47,9 @@ class DPoserComp:
 
     def _fused_supported(self):
         from ..algorithms.advanced.model import ScoreModelFC
-        return sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
+        # (the fused kernels evaluate the CONTINUOUS score function; a discrete VE model conditions on other labels, utils.py:175-178)
+        return (sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
+                and (getattr(self, "continuous", True) or not isinstance(self.sde, sde_lib.VESDE)))
 
     def _schedule(self, time_strategy, total_steps, sample_trun, sample_time):
         """quan_t of every step (completion.py:183-192)."""

@@ -53,7 +53,9 @@ enum { DPOSER_EMB_POSITIONAL = 0, DPOSER_EMB_FOURIER = 1 };
 /* config.model.nonlinearity (model.py:54-66): swish = SiLU; lrelu = LeakyReLU(0.2); elu = ELU(alpha = 1).  Swish runs on every
  * tiling; the other three on the 128-wide tilings (any batch), hidden_dim 1024 only */
 enum { DPOSER_ACT_SWISH = 0, DPOSER_ACT_ELU = 1, DPOSER_ACT_RELU = 2, DPOSER_ACT_LRELU = 3 };
-enum { DPOSER_SDE_SUBVP = 0, DPOSER_SDE_VP = 1 };
+/* DPOSER_SDE_VE (sde_lib.py:234-292): beta_min / beta_max of dposer_sde_desc carry sigma_min / sigma_max; the network is conditioned on
+ * sigma(t) (continuous VE score function, utils.py:164-181) and its output is the score itself. */
+enum { DPOSER_SDE_SUBVP = 0, DPOSER_SDE_VP = 1, DPOSER_SDE_VE = 2 };
 
 typedef struct {
     int32_t data_dim;        /* n_poses * pose_dim: 63 (axis-angle) or 126 (rot6d), 1..512  model.py:109 */
@@ -145,6 +147,10 @@ int dposer_prior_loss(dposer_scorefc_t h, const float* flat_params, const void* 
  * (run/completion.py:183-201, run/motion_denoising.py:240-252 draw a new t every optimisation step). */
 int dposer_prior_table_build(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws, const float* t_host,
                              int32_t n_rows, const float* freq, int64_t batch, void* stream);
+/* ... with the SDE given: the rows are built for the labels the SDE's score function conditions the network on (t * 999; VE: sigma(t)).
+ * sde == NULL is dposer_prior_table_build. */
+int dposer_prior_table_build_sde(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws, const dposer_sde_desc* sde,
+                                 const float* t_host, int32_t n_rows, const float* freq, int64_t batch, void* stream);
 int dposer_prior_loss_tabled(dposer_scorefc_t h, const float* flat_params, const void* packed, void* ws, const dposer_sde_desc* sde,
                              const float* x0, const float* z, float t, int32_t row, int32_t table_rows, int32_t weighted, float inv_n,
                              float* x0_hat, float* grad, float* loss, uint64_t seed, uint32_t step, const float* sigmas,

@@ -643,6 +643,92 @@ def g20_fourier_paths():
     save("g20_fourier_paths", **out)
 
 
+def g21_ve_paths():
+    """G21: the reference's own outputs under the VARIANCE-EXPLODING SDE (sde_lib.py:234-292; continuous score function utils.py:164-181:
+    the network is conditioned on sigma(t) and its output IS the score) on the paths this repository fuses: DSM loss + gradients, EM
+    sampler (plain and with completion imputation), prior loss and the completion loop.  Recording scheme of g20 (positional embedding)."""
+    out = {"seed": np.int64(29), "sigma_min": np.float64(0.01), "sigma_max": np.float64(50.0)}
+    mk = lambda N: ref_sde.VESDE(sigma_min=0.01, sigma_max=50.0, N=N)
+    cfg, m = build_model(29, 63, dropout=0.0)
+    sde = mk(1000)
+    batch, _ = toy_batch(32)
+    loss_fn = ref_losses.get_sde_loss_fn(sde, train=True, reduce_mean=True, continuous=True)
+    with Recorder(7) as rec:
+        loss = loss_fn(m, batch, None, None)
+    loss.backward()
+    out["dsm_loss"] = np.float64(loss.item())
+    out["dsm_u"] = rec.by_kind("rand")[0]
+    out["dsm_z"] = rec.by_kind("randn")[0]
+    out["dsm_batch"] = batch.numpy()
+    for n, p in m.named_parameters():
+        out[f"dsm_grad/{n}"] = (np.zeros(1) if p.grad is None else sample_tensor(n, p.grad))
+    cfg, m = build_model(29, 63)
+    m.eval()
+
+    class Args:
+        task = None
+
+    for tag, task in (("em8", None), ("comp8", "completion")):
+        N, B = 8, 16
+        sde = mk(N)
+        cfg.sampling.corrector = "none"
+        fn = ref_sampling.get_sampling_fn(cfg, sde, (B, 63), lambda x: x, 1e-3, device="cpu")
+        z0 = torch.tensor((np.random.RandomState(960 + len(tag)).standard_normal((B, 63)) * 50.0).astype(np.float32))      # prior_sampling: N(0, sigma_max^2)
+        obs = mask = args = None
+        if task is not None:
+            args = Args()
+            args.task = task
+            poses, _ = toy_batch(B, seed=44)
+            with Recorder(55):
+                mask, obs = ref_misc.create_mask(poses, part="legs")
+            out[f"{tag}_mask"] = mask.numpy()
+            out[f"{tag}_obs"] = obs.numpy()
+        with Recorder(77) as rec:
+            trajs, x = fn(m, observation=obs, mask=mask, z=z0, start_step=0, args=args)
+        out[f"{tag}_z0"] = z0.numpy()
+        out[f"{tag}_noise"] = np.stack(rec.by_kind("randn"))
+        out[f"{tag}_final"] = x.numpy()
+        out[f"{tag}_trajs"] = trajs.numpy()
+    sde = mk(1000)
+    B = 16
+    comp = ref_completion.DPoserComp(m, sde, continuous=True, batch_size=B)
+    x0, _ = toy_batch(B, seed=45)
+    timesteps = torch.linspace(sde.T, 1e-3, sde.N)
+    out["prior_x0"] = x0.numpy()
+    import math
+    total = 200
+    for step in (0, 199):
+        quan_t = sde.N - math.floor(torch.tensor(total - step - 1) * (sde.N / (5.0 * total))) - 2
+        t = timesteps[quan_t]
+        vec_t = torch.ones(B) * t
+        xv = x0.clone().requires_grad_(True)
+        with Recorder(300 + step) as rec:
+            loss = comp.loss(xv, vec_t, quan_t)
+        loss.backward()
+        out[f"prior_s{step}_quan_t"] = np.int64(quan_t)
+        out[f"prior_s{step}_t"] = np.float32(t.item())
+        out[f"prior_s{step}_z"] = rec.by_kind("randn")[0]
+        out[f"prior_s{step}_loss"] = np.float64(loss.item())
+        out[f"prior_s{step}_grad"] = xv.grad.numpy()
+    iters, spi = 2, 4
+    _, raw = toy_batch(B, seed=47)
+    nz = ref_amass.Posenormalizer(os.path.join(REF, "data/AMASS/amass_processed/version1/train"), device="cpu", normalize=True,
+                                  min_max=False, rot_rep="axis")
+    poses = nz.offline_normalize(raw)
+    torch.manual_seed(0)
+    mask, obs = ref_misc.create_mask(poses, part="legs")
+    comp = ref_completion.DPoserComp(m, sde, continuous=True, batch_size=B)
+    with Recorder(1400) as rec:
+        res = comp.optimize(obs, mask, iterations=iters, steps_per_iter=spi)
+    out["loop_observation"] = obs.numpy()
+    out["loop_mask"] = mask.numpy()
+    out["loop_noise"] = np.stack(rec.by_kind("randn"))
+    out["loop_out"] = res.detach().numpy()
+    out["loop_iterations"] = np.int64(iters)
+    out["loop_steps_per_iter"] = np.int64(spi)
+    save("g21_ve_paths", **out)
+
+
 def g8_scalars():
     """G8: marginal_prob / sde / return_alpha_sigma / discretize tables on linspace(1,1e-3,1000)."""
     t = torch.linspace(1.0, 1e-3, 1000)
@@ -820,8 +906,8 @@ def g13_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
-    fns = dict(g20=g20_fourier_paths, g19=g19_activations, g18=g18_evaler, g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
+    fns = dict(g21=g21_ve_paths, g20=g20_fourier_paths, g19=g19_activations, g18=g18_evaler, g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
                g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
     for w in which:
         fns[w]()

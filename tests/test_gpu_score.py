@@ -363,6 +363,62 @@ def test_fourier_embedding_fused_paths_match_reference_golden(prec, tol_loss, to
     assert rel_err(t2n(out), g["loop_out"]) < max(tol, 2e-4)
 
 
+@pytest.mark.parametrize("prec,tol_loss,tol_grad,tol", [("fp32", 2e-5, 2e-4, 1e-4), ("bf16", 1e-2, 2e-2, 2e-2), ("bf16x3", 2e-5, 2e-4, 1e-4)])
+def test_ve_sde_fused_paths_match_reference_golden(prec, tol_loss, tol_grad, tol, monkeypatch):
+    """The variance-exploding SDE (sde_lib.py:234-292; continuous score function utils.py:164-181: the network is conditioned on
+    sigma(t) = sigma_min (sigma_max / sigma_min)^t and its output is the score) on the ONE-CALL paths -- fused DSM step, fused EM sampler
+    (plain and with completion imputation), prior loss, completion loop -- against the reference's own outputs with its recorded draws
+    (golden g21).  Rounds 1-4 ran VE step by step on the HIP score function; the fallbacks are made to raise here."""
+    from dposer_amd.algorithms.advanced import sampling, sde_lib
+    from dposer_amd.algorithms.advanced.losses import fused_dsm_grad, fused_dsm_supported
+    from dposer_amd.prior import prior_loss
+    from dposer_amd import prior as prior_mod
+    from dposer_amd.tasks.completion import DPoserComp
+    g = load("g21_ve_paths")
+    mk = lambda N: sde_lib.VESDE(sigma_min=float(g["sigma_min"]), sigma_max=float(g["sigma_max"]), N=N)
+    cfg, m, p = make_model(int(g["seed"]), precision=prec, dropout=0.0)
+    sde = mk(1000)
+    assert sampling.fused_em_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, True)
+    assert not sampling.fused_em_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, False)     # discrete VE: other labels
+    assert fused_dsm_supported(sde, m, True, True, False, False)
+    # DSM loss + every parameter gradient
+    t = _dev(g["dsm_u"]) * (1.0 - 1e-5) + 1e-5
+    fg = torch.zeros(m._num_flat, device=DEV)
+    loss = float(fused_dsm_grad(m, sde, _dev(g["dsm_batch"]), flat_grad=fg, t=t, z=_dev(g["dsm_z"]), seed=m._rng_seed, step=0))
+    assert abs(loss - float(g["dsm_loss"])) / float(g["dsm_loss"]) < tol_loss
+    for (name, prm), off in zip(m.named_parameters(), m._offsets):
+        ref = g[f"dsm_grad/{name}"]
+        got = fg[off:off + prm.numel()]
+        if ref.shape == (1,):
+            assert float(got.abs().max()) == 0.0
+            continue
+        assert rel_err(probe(name, got), ref) < tol_grad, name
+    # EM sampler, N = 8: plain and with the completion imputation
+    monkeypatch.setattr(sampling, "shared_predictor_update_fn", lambda *a, **k: (_ for _ in ()).throw(AssertionError("step-by-step sampler used")))
+    monkeypatch.setattr(prior_mod, "_prior_loss_unfused", lambda *a, **k: (_ for _ in ()).throw(AssertionError("step-by-step prior loss used")))
+    cfg8, m8, _ = make_model(int(g["seed"]), precision=prec)
+    cfg8.sampling.corrector = "none"
+    fn = sampling.get_sampling_fn(cfg8, mk(8), (16, 63), lambda x: x, 1e-3, device=DEV)
+    trajs, x = fn(m8, z=_dev(g["em8_z0"]), noise=_dev(g["em8_noise"])[:, None])
+    assert rel_err(t2n(trajs), g["em8_trajs"]) < tol and rel_err(t2n(x), g["em8_final"]) < tol
+    trajs, x = fn(m8, observation=_dev(g["comp8_obs"]), mask=_dev(g["comp8_mask"]), z=_dev(g["comp8_z0"]), args=_Args("completion"),
+                  noise=_dev(g["comp8_noise"]).reshape(8, 3, 16, 63))
+    assert rel_err(t2n(trajs), g["comp8_trajs"]) < tol and rel_err(t2n(x), g["comp8_final"]) < tol
+    # prior loss + its gradient
+    for step in (0, 199):
+        x0 = _dev(g["prior_x0"]).requires_grad_(True)
+        lp = prior_loss(m8, sde, x0, float(g[f"prior_s{step}_t"]), weighted=bool(int(g[f"prior_s{step}_quan_t"])), z=_dev(g[f"prior_s{step}_z"]))
+        lp.backward()
+        assert abs(float(lp) - float(g[f"prior_s{step}_loss"])) / abs(float(g[f"prior_s{step}_loss"])) < max(tol, 2e-4)
+        assert rel_err(t2n(x0.grad), g[f"prior_s{step}_grad"]) < max(tol, 2e-4)
+    # the completion loop as one call
+    comp = DPoserComp(m8, sde, continuous=True, batch_size=16)
+    assert comp._fused_supported()
+    out = comp.optimize(_dev(g["loop_observation"]), _dev(g["loop_mask"]), iterations=int(g["loop_iterations"]),
+                        steps_per_iter=int(g["loop_steps_per_iter"]), noise=_dev(g["loop_noise"]))
+    assert rel_err(t2n(out), g["loop_out"]) < max(tol, 2e-4)
+
+
 # ------------------------------------------------------------------------------------------------
 # training: DSM loss, gradients, Adam / EMA
 # ------------------------------------------------------------------------------------------------
