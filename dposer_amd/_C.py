@@ -25,6 +25,12 @@ class ScoreFCDesc(C.Structure):
                 ("num_scales", C.c_int32), ("precision", C.c_int32), ("dropout_p", C.c_float), ("activation", C.c_int32)]
 
 
+class MlpDesc(C.Structure):
+    """dposer_mlp_desc (include/dposer_hip.h)."""
+    _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32), ("hidden_dim", C.c_int32), ("n_blocks", C.c_int32),
+                ("precision", C.c_int32), ("activation", C.c_int32), ("dropout_p", C.c_float)]
+
+
 class SdeDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("N", C.c_int32), ("beta_min", C.c_double),
                 ("beta_max", C.c_double), ("T", C.c_double)]
@@ -149,6 +155,14 @@ SIGNATURES = {
     "dposer_body_tuning_reload": (None, []),
     "dposer_scorefc_tuning_reload": (None, []),
     "dposer_scorefc_debug_set_dropout_masks": (C.c_int, [vp, vp, i64]),
+    "dposer_mlp_create": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(vp)]),
+    "dposer_mlp_destroy": (None, [vp]),
+    "dposer_mlp_num_params": (i64, [vp]),
+    "dposer_mlp_packed_bytes": (i64, [vp]),
+    "dposer_mlp_workspace_bytes": (i64, [vp, i64]),
+    "dposer_mlp_pack": (C.c_int, [vp, vp, vp, vp]),
+    "dposer_mlp_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, i32, u64, u32, vp]),
+    "dposer_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i64, i32, u64, u32, vp]),
     "dposer_lbs_backward": (C.c_int, [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp,
                                       vp, vp, i64, C.POINTER(vp), vp, vp, i64, vp]),
     "dposer_lbs_backward_fold": (C.c_int, [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp,

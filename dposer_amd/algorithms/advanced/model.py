@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import _C
-from ...engine import ScoreEngine, default_precision
+from ...engine import ScoreEngine, default_precision, param_state_key
 
 
 class GaussianFourierProjection(nn.Module):
@@ -63,13 +63,125 @@ def get_act(config):
     return _ACTIVATIONS[name]()
 
 
-class TimeMLPs(nn.Module):
-    """Plain MLP on [x, t] (model.py:69-90).  Secondary model of the reference, kept for surface
-    completeness as ordinary torch modules (not on the accelerated path; unused by the shipped config)."""
+class _FlatParams(nn.Module):
+    """Parameters as views into ONE flat fp32 buffer (what the weight packer and the fused optimizer consume).  Sub-classes set
+    ``_param_list`` / ``_offsets`` / ``_num_flat`` / ``_flat`` at the end of ``__init__``."""
+
+    def flat_params(self) -> torch.Tensor:
+        """The flat fp32 buffer all parameters are views of (re-built if someone replaced ``.data``)."""
+        dev = self._param_list[0].device
+        ok = self._flat is not None and self._flat.device == dev
+        if ok:
+            base = self._flat.data_ptr()
+            ok = all(p.data_ptr() == base + 4 * off for p, off in zip(self._param_list, self._offsets))
+        if not ok:
+            flat = torch.empty(self._num_flat, dtype=torch.float32, device=dev)
+            for p, off in zip(self._param_list, self._offsets):
+                flat[off:off + p.numel()].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + p.numel()].view(p.shape)
+            self._flat = flat
+        return self._flat
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flat = None          # .to()/.cuda()/.float() replace parameter storage: re-flatten
+        self.flat_params()
+        return out
+
+
+class _MlpEngine:
+    """Handle, packed weights and workspaces of one TimeMLPs instance on one device (dposer_mlp_* of include/dposer_hip.h)."""
+
+    def __init__(self, in_dim, out_dim, hidden_dim, n_blocks, precision, activation, dropout_p):
+        import ctypes as C
+        self.lib = _C.lib()
+        self.h = C.c_void_p()
+        d = _C.MlpDesc(in_dim, out_dim, hidden_dim, n_blocks, _C.PRECISIONS[precision], _C.ACTIVATIONS[activation], dropout_p)
+        _C.check(self.lib.dposer_mlp_create(C.byref(d), C.byref(self.h)), "dposer_mlp_create")
+        self.num_params = self.lib.dposer_mlp_num_params(self.h)
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self._packed = None
+        self._pack_key = None
+        self._ws = {}
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.dposer_mlp_destroy(self.h)
+            self.h = None
+
+    def packed(self, flat, params):
+        key = param_state_key(flat, params)
+        if self._packed is None or self._packed.device != flat.device:
+            self._packed = torch.empty(self.lib.dposer_mlp_packed_bytes(self.h), dtype=torch.uint8, device=flat.device)
+            self._pack_key = None
+        if key != self._pack_key:
+            _C.check(self.lib.dposer_mlp_pack(self.h, _C.ptr(flat), _C.ptr(self._packed), _C.stream_ptr()), "dposer_mlp_pack")
+            self._pack_key = key
+        return self._packed
+
+    def workspace(self, batch, device, fresh=False):
+        """Inference calls share one buffer per batch size; a differentiable forward takes a buffer of its own (``fresh``), which its
+        autograd node keeps until the node is freed."""
+        n = self.lib.dposer_mlp_workspace_bytes(self.h, batch)
+        if fresh:
+            return torch.empty(n, dtype=torch.uint8, device=device)
+        ws = self._ws.get((batch, device))
+        if ws is None:
+            ws = self._ws[(batch, device)] = torch.empty(n, dtype=torch.uint8, device=device)
+        return ws
+
+
+class _MlpFunction(torch.autograd.Function):
+    N_FIXED = 5     # (module, xin, train_mode, seed, step) in front of the parameters
+
+    @staticmethod
+    def forward(ctx, module, xin, train_mode, seed, step, *params):
+        eng = module._engine()
+        flat = module._flat
+        packed = eng.packed(flat, module._param_list)
+        B = xin.shape[0]
+        ws = eng.workspace(B, xin.device, fresh=True)
+        out = torch.empty(B, eng.out_dim, dtype=torch.float32, device=xin.device)
+        _C.check(eng.lib.dposer_mlp_forward(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), _C.ptr(xin), _C.ptr(out), B,
+                                            1 if train_mode else 0, 1, seed, step, _C.stream_ptr()), "dposer_mlp_forward")
+        ctx.module, ctx.ws, ctx.flat = module, ws, flat
+        ctx.train_mode, ctx.seed, ctx.step = train_mode, seed, step
+        ctx.versions = tuple(p._version for p in module._param_list)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.module
+        eng = m._engine()
+        if m._flat is not ctx.flat or tuple(p._version for p in m._param_list) != ctx.versions:
+            raise RuntimeError("TimeMLPs: parameters were modified in place between forward and backward")
+        B = dout.shape[0]
+        dout = dout.contiguous().float()
+        want = ctx.needs_input_grad[_MlpFunction.N_FIXED:]
+        need_dw, need_dx = any(want), ctx.needs_input_grad[1]
+        flat_grad = torch.empty(eng.num_params, dtype=torch.float32, device=dout.device) if need_dw else None
+        dx = torch.empty(B, eng.in_dim, dtype=torch.float32, device=dout.device) if need_dx else None
+        packed = eng.packed(ctx.flat, m._param_list)       # (same parameter versions: a no-op unless another device's call re-packed)
+        _C.check(eng.lib.dposer_mlp_backward(eng.h, _C.ptr(ctx.flat), _C.ptr(packed), _C.ptr(ctx.ws), _C.ptr(dout), _C.ptr(flat_grad),
+                                             _C.ptr(dx), B, 1 if ctx.train_mode else 0, ctx.seed, ctx.step, _C.stream_ptr()),
+                 "dposer_mlp_backward")
+        ctx.ws = None
+        grads = [flat_grad[off:off + p.numel()].view_as(p) if w else None for p, off, w in zip(m._param_list, m._offsets, want)]
+        return (None, dx, None, None, None, *grads)
+
+
+class TimeMLPs(_FlatParams):
+    """Plain MLP on [x, t] (model.py:69-90), the reference's secondary score model (run/train.py:163-170).
+
+    Same constructor, sub-module names and ``state_dict`` keys as the reference; the parameters are views into one flat fp32 buffer
+    and ``forward`` runs on the GEMM kernels of ``libdposer_hip.so`` (one launch per Linear + activation, dropout drawn in the
+    epilogue; dposer_amd/csrc/mlp.hip).  Like ScoreModelFC there is no torch/CPU fallback: a forward on CPU tensors raises."""
 
     def __init__(self, config, n_poses=21, pose_dim=6, hidden_dim=64, n_blocks=2):
         super().__init__()
         dim = n_poses * pose_dim
+        self.config = config
+        self.data_dim, self.hidden_dim, self.n_blocks = dim, hidden_dim, n_blocks
         self.act = get_act(config)
         layers = [nn.Linear(dim + 1, hidden_dim), self.act]
         for _ in range(n_blocks):
@@ -77,8 +189,48 @@ class TimeMLPs(nn.Module):
         layers.append(nn.Linear(hidden_dim, dim))
         self.net = nn.Sequential(*layers)
 
+        prec = default_precision(config)
+        self.precision = "fp32" if prec == "bf16x3" else prec      # (no split-operand instantiation of this model: fp32 is the exact mode)
+        self._engines = {}
+        self._flat = None
+        self._param_list = list(self.parameters())
+        self._offsets = [0]
+        for p in self._param_list:
+            self._offsets.append(self._offsets[-1] + p.numel())
+        self._num_flat = self._offsets.pop()
+        self.flat_params()
+        self._rng_seed = int(getattr(config, "seed", 0) or 0) * 1000003 + 54321
+        self._rng_step = 0
+
+    def _engine(self) -> _MlpEngine:
+        eng = self._engines.get(self.precision)
+        if eng is None:
+            eng = _MlpEngine(self.data_dim + 1, self.data_dim, self.hidden_dim, self.n_blocks, self.precision,
+                             self.config.model.nonlinearity.lower(), float(self.config.model.dropout))
+            assert eng.num_params == self._num_flat, "flat layout disagrees with parameters()"
+            self._engines[self.precision] = eng
+        return eng
+
     def forward(self, x, t, condition=None, mask=None):
-        return self.net(torch.cat([x, t[:, None]], dim=1))
+        """x [B, dim], t [B] -> [B, dim]: net(cat[x, t[:, None]]) (model.py:89-90)."""
+        _C.require_gpu(x, "TimeMLPs input")
+        if self._param_list[0].device != x.device:
+            raise _C.DPoserHipError("TimeMLPs parameters and input are on different devices")
+        xin = torch.cat([x.float(), t.float()[:, None]], dim=1).contiguous()
+        if xin.shape[0] == 0:
+            return xin[:, :self.data_dim] * 0.0
+        flat = self.flat_params()
+        eng = self._engine()
+        needs_grad = torch.is_grad_enabled() and (xin.requires_grad or any(p.requires_grad for p in self._param_list))
+        if needs_grad or self.training:
+            self._rng_step += 1
+            return _MlpFunction.apply(self, xin, bool(self.training), self._rng_seed, self._rng_step, *self._param_list)
+        B = xin.shape[0]
+        out = torch.empty(B, self.data_dim, dtype=torch.float32, device=xin.device)
+        _C.check(eng.lib.dposer_mlp_forward(eng.h, _C.ptr(flat), _C.ptr(eng.packed(flat, self._param_list)),
+                                            _C.ptr(eng.workspace(B, xin.device)), _C.ptr(xin), _C.ptr(out), B, 0, 0, 0, 0, _C.stream_ptr()),
+                 "dposer_mlp_forward")
+        return out
 
 
 class _ScoreFCFunction(torch.autograd.Function):
@@ -145,7 +297,7 @@ class _ScoreFCFunction(torch.autograd.Function):
         return (None, dx, None, None, None, None, *grads)
 
 
-class ScoreModelFC(nn.Module):
+class ScoreModelFC(_FlatParams):
     """Time-embedded residual MLP with independent time projections per layer (model.py:93-196)."""
 
     def __init__(self, config, n_poses=21, pose_dim=6, hidden_dim=64, embed_dim=32, n_blocks=2):
@@ -228,27 +380,6 @@ class ScoreModelFC(nn.Module):
     def _fourier_W(self):
         return self.gauss_proj.W if self.time_embedding_type == "fourier" else None
 
-    def flat_params(self) -> torch.Tensor:
-        """The flat fp32 buffer all parameters are views of (re-built if someone replaced ``.data``)."""
-        dev = self._param_list[0].device
-        ok = self._flat is not None and self._flat.device == dev
-        if ok:
-            base = self._flat.data_ptr()
-            ok = all(p.data_ptr() == base + 4 * off for p, off in zip(self._param_list, self._offsets))
-        if not ok:
-            flat = torch.empty(self._num_flat, dtype=torch.float32, device=dev)
-            for p, off in zip(self._param_list, self._offsets):
-                flat[off:off + p.numel()].copy_(p.data.reshape(-1))
-                p.data = flat[off:off + p.numel()].view(p.shape)
-            self._flat = flat
-        return self._flat
-
-    def _apply(self, fn, *a, **k):
-        out = super()._apply(fn, *a, **k)
-        self._flat = None          # .to()/.cuda()/.float() replace parameter storage: re-flatten
-        self.flat_params()
-        return out
-
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, batch, t, condition=None, mask=None):
         """batch [B, j*3|j*6], t [B] (the *labels*, i.e. t*999 for the continuous sub-VP model) -> [B, same].
@@ -278,3 +409,4 @@ class ScoreModelFC(nn.Module):
                                                 _C.ptr(freq), _C.ptr(self.sigmas), _C.ptr(out), x.shape[0], _C.stream_ptr()),
                  "dposer_scorefc_forward")
         return out
+

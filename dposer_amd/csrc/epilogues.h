@@ -336,6 +336,7 @@ struct BiasSiLUParams {
     int act;       // DP_ACT_* (ACTRT instantiations)
     void* out_hi;  // fp32-storage instantiations only (bf16x3 mode), optional: `out` again as two bf16 FT planes
     void* out_lo;
+    DropoutCfg drop;   // TRAIN only: nn.Dropout BEHIND the activation (TimeMLPs blocks, model.py:78-82); p = 0: none (shared_time_embed has none)
 };
 template <typename T, bool TRAIN, bool ACTRT = false> struct EpiBiasSiLU {
     typedef BiasSiLUParams Params;
@@ -363,6 +364,11 @@ template <typename T, bool TRAIN, bool ACTRT = false> struct EpiBiasSiLU {
                 float u[16], o[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { u[r] = acc[tc][ts][r] + bia[r]; o[r] = ACTRT ? act_rt<PRECISE>(u[r], pp.act) : silu_f<PRECISE>(u[r]); }
+                if (TRAIN && pp.drop.p > 0.f) {      // the decisions are re-drawn from the same counters by the backward epilogue (EpiSiLUBwd)
+                    const uint32_t bits = dropout_bits16(pp.drop, sbase + ts * 32 + (lane & 31), c0 >> 5, hi);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = ((bits >> r) & 1u) ? o[r] * pp.drop.scale : 0.f;
+                }
                 if (TRAIN) TileIO<T>::store(p.pre + tb, lane, u);
                 TileIO<T>::store(p.out + tb, lane, o);
                 if constexpr (sizeof(T) == 4) {
@@ -1014,6 +1020,7 @@ struct SiLUBwdParams {
     int act;           // DP_ACT_* (ACTRT instantiations)
     float* part;       // optional: [wave rows][N] column sums of dU over each wave's samples (the bias gradient's partials: a
                        // k_colsum launch over dU otherwise), summed like the GroupNorm-backward epilogue sums its bias partials
+    DropoutCfg drop;   // the forward epilogue's dropout behind the activation (TimeMLPs): same counters, same decisions; p = 0: none
 };
 template <typename T, bool ACTRT = false> struct EpiSiLUBwd {
     typedef SiLUBwdParams Params;
@@ -1036,6 +1043,11 @@ template <typename T, bool ACTRT = false> struct EpiSiLUBwd {
                 TileIO<T>::load(p.pre + tb, lane, u);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] = (s < p.S_valid) ? acc[tc][ts][r] * (ACTRT ? dact_rt<PRECISE>(u[r], pp.act) : dsilu_f<PRECISE>(u[r])) : 0.f;
+                if (pp.drop.p > 0.f) {
+                    const uint32_t bits = dropout_bits16(pp.drop, s, (cbase + tc * 32) >> 5, hi);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = ((bits >> r) & 1u) ? o[r] * pp.drop.scale : 0.f;
+                }
                 TileIO<T>::store(p.out + tb, lane, o);
                 if (pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, cbase + tc * 32, pp.Spad), scr, lane, o);
 #pragma unroll

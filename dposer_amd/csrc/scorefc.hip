@@ -703,6 +703,7 @@ static int run_temb(dposer_scorefc_s* h, const float* flat, const char* packed, 
     p.outT = tembT;
     p.Spad = Bpad;
     p.act = h->d.activation;
+    std::memset(&p.drop, 0, sizeof(p.drop));
     p.out_hi = h->x3 ? w.p_temb.hi : nullptr;      // (bf16x3: temb's operand planes straight from the epilogue)
     p.out_lo = h->x3 ? w.p_temb.lo : nullptr;
     DP_HIP_LAUNCH(gemm_bias_silu(gemm_prec(h), train, shape, g, p, st));
@@ -774,6 +775,7 @@ static int build_time_table(dposer_scorefc_s* h, const float* flat, const char* 
         BiasSiLUParams p;
         p.bias = flat + h->off_se_b; p.out = w.tt_temb; p.pre = nullptr; p.N = E; p.outT = nullptr; p.Spad = npad; p.act = h->d.activation;
         p.out_hi = nullptr; p.out_lo = nullptr;
+        std::memset(&p.drop, 0, sizeof(p.drop));
         DP_HIP_LAUNCH(gemm_bias_silu(PREC_FP32, false, shape, g, p, st));
     }
     {
@@ -1660,6 +1662,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         SiLUBwdParams p;
         p.pre = w.upre; p.out = w.dU; p.N = E; p.S_valid = B; p.outT = tr ? nullptr : w.dUT; p.Spad = Bpad; p.act = h->d.activation;
         p.part = w.silu_part;                                            // the shared embedding's bias gradient: no column-sum launch over dU
+        std::memset(&p.drop, 0, sizeof(p.drop));
         silu_rows = (int)(Bpad / (shape_st(shape) * 32)) * shape_ws(shape);
         DP_HIP_LAUNCH(gemm_silu_bwd(prec, shape, g, p, st));
         }

@@ -156,6 +156,35 @@ int dposer_prior_loss_tabled(dposer_scorefc_t h, const float* flat_params, const
                              float* x0_hat, float* grad, float* loss, uint64_t seed, uint32_t step, const float* sigmas,
                              int64_t batch, void* stream);
 
+/* ---- TimeMLPs (lib/algorithms/advanced/model.py:69-90): the reference's secondary score model -------------------------------------
+ *   net = Linear(in_dim, H), act, [Linear(H, H), act, Dropout(p)] x n_blocks, Linear(H, out_dim)      (in_dim = data_dim + 1: [x, t])
+ * Flat parameter buffer: net.parameters() in order (weight [out][in] row-major, bias) per Linear, contiguous fp32.  Every Linear + act
+ * is one MFMA GEMM launch of the score network's kernel family; the hidden width is padded to 128 channels inside the library. */
+typedef struct dposer_mlp_s* dposer_mlp_t;
+typedef struct {
+    int32_t in_dim;          /* n_poses * pose_dim + 1 */
+    int32_t out_dim;         /* n_poses * pose_dim */
+    int32_t hidden_dim;      /* config.model.HIDDEN_DIM */
+    int32_t n_blocks;        /* config.model.N_BLOCKS (0..8) */
+    int32_t precision;       /* DPOSER_PREC_BF16 | DPOSER_PREC_FP32 */
+    int32_t activation;      /* DPOSER_ACT_* (get_act, model.py:54-66) */
+    float dropout_p;         /* config.model.dropout */
+} dposer_mlp_desc;
+int dposer_mlp_create(const dposer_mlp_desc* desc, dposer_mlp_t* out);
+void dposer_mlp_destroy(dposer_mlp_t h);
+int64_t dposer_mlp_num_params(dposer_mlp_t h);
+int64_t dposer_mlp_packed_bytes(dposer_mlp_t h);
+int64_t dposer_mlp_workspace_bytes(dposer_mlp_t h, int64_t batch);
+int dposer_mlp_pack(dposer_mlp_t h, const float* flat_params, void* packed, void* stream);
+/* out [B, out_dim] = net(x [B, in_dim]).  train_mode != 0: the Dropout modules draw from Philox(seed, step) (site = block index, same
+ * counter layout as the score network's dropout); keep_for_backward != 0 keeps the pre-activations in `ws` for dposer_mlp_backward. */
+int dposer_mlp_forward(dposer_mlp_t h, const float* flat_params, const void* packed, void* ws, const float* x, float* out, int64_t batch,
+                       int32_t train_mode, int32_t keep_for_backward, uint64_t seed, uint32_t step, void* stream);
+/* Backward of the forward that last ran on `ws` with keep_for_backward != 0 (same train_mode / seed / step): flat_grad [num_params]
+ * (every element written; NULL: input gradient only) and dx [B, in_dim] (NULL: none). */
+int dposer_mlp_backward(dposer_mlp_t h, const float* flat_params, const void* packed, void* ws, const float* dout, float* flat_grad,
+                        float* dx, int64_t batch, int32_t train_mode, uint64_t seed, uint32_t step, void* stream);
+
 
 /* get_sde_loss_fn.loss_fn + loss.backward() -- lib/algorithms/advanced/losses.py:80-137, 260
  * (continuous=True, reduce_mean=True, likelihood_weighting=False, model.train()).

@@ -43,13 +43,13 @@ _mlc = types.ModuleType("ml_collections")
 _mlc.ConfigDict = _ConfigDict
 sys.modules["ml_collections"] = _mlc
 
-from weights import make_weights, probe_indices  # noqa: E402
+from weights import make_weights, make_mlp_weights, probe_indices  # noqa: E402
 
 import lib.algorithms.advanced.losses as ref_losses  # noqa: E402
 import lib.algorithms.advanced.sampling as ref_sampling  # noqa: E402
 import lib.algorithms.advanced.sde_lib as ref_sde  # noqa: E402
 import lib.algorithms.advanced.utils as ref_mutils  # noqa: E402
-from lib.algorithms.advanced.model import ScoreModelFC  # noqa: E402
+from lib.algorithms.advanced.model import ScoreModelFC, TimeMLPs  # noqa: E402
 from lib.algorithms.ema import ExponentialMovingAverage  # noqa: E402
 import lib.utils.misc as ref_misc  # noqa: E402
 import lib.utils.transforms as ref_tf  # noqa: E402
@@ -876,6 +876,48 @@ def g12_likelihood_ode():
     save("g12_likelihood_ode", **out)
 
 
+def g22_timemlps():
+    """G22: the reference's secondary score model TimeMLPs (model.py:69-90; run/train.py:163-170): eval forward, gradients of a fixed
+    linear functional w.r.t. every parameter and the input, and the sub-VP DSM loss + gradients with the model in train mode
+    (dropout 0: the Dropout modules draw nothing), for three shapes -- the shipped widths (swish, H = 1024, 2 blocks), the constructor's
+    default width (H = 64: padded inside the library) on the 6-D representation with leaky ReLU, and one block of ELU at H = 256."""
+    out = {}
+    for tag, D, H, nb, act, seed in (("swish1024", 63, 1024, 2, "swish", 31), ("lrelu64", 126, 64, 2, "lrelu", 32), ("elu256", 63, 256, 1, "elu", 33)):
+        cfg = get_config()
+        cfg.model.nonlinearity = act
+        cfg.model.dropout = 0.0
+        m = TimeMLPs(cfg, n_poses=21, pose_dim=D // 21, hidden_dim=H, n_blocks=nb)
+        m.load_state_dict(make_mlp_weights(seed, D, H, nb))
+        m.eval()
+        rs = np.random.RandomState(seed + 100)
+        B = 48
+        x = torch.tensor(rs.standard_normal((B, D)).astype(np.float32), requires_grad=True)
+        t = torch.tensor((rs.random_sample(B) * 999.0).astype(np.float32))
+        c = torch.tensor(rs.standard_normal((B, D)).astype(np.float32))
+        y = m(x, t)
+        (y * c).sum().backward()
+        out[f"{tag}/x"], out[f"{tag}/t"], out[f"{tag}/c"] = x.detach().numpy(), t.numpy(), c.numpy()
+        out[f"{tag}/y"] = y.detach().numpy()
+        out[f"{tag}/dx"] = x.grad.numpy()
+        for n, p in m.named_parameters():
+            out[f"{tag}/grad/{n}"] = sample_tensor(n, p.grad)
+            p.grad = None
+        # DSM training loss through the reference's loss function (losses.py:93-133), model.train() with p = 0
+        sde = ref_sde.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000)
+        loss_fn = ref_losses.get_sde_loss_fn(sde, train=True, reduce_mean=True, continuous=True)
+        batch = torch.tensor(rs.standard_normal((B, D)).astype(np.float32))
+        with Recorder(seed + 200) as rec:
+            loss = loss_fn(m, batch, None, None)
+        loss.backward()
+        out[f"{tag}/dsm_batch"] = batch.numpy()
+        out[f"{tag}/dsm_u"] = rec.by_kind("rand")[0]
+        out[f"{tag}/dsm_z"] = rec.by_kind("randn")[0]
+        out[f"{tag}/dsm_loss"] = np.float64(loss.item())
+        for n, p in m.named_parameters():
+            out[f"{tag}/dsm_grad/{n}"] = sample_tensor(n, p.grad)
+    save("g22_timemlps", **out)
+
+
 def g13_dataset():
     """AMASSDataset (lib/dataset/AMASS.py:12-182) on a temporary root holding the toy poses: sampling, both normalisations
     (statistics computed and written, then re-read), Denormalize."""
@@ -906,8 +948,8 @@ def g13_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
-    fns = dict(g21=g21_ve_paths, g20=g20_fourier_paths, g19=g19_activations, g18=g18_evaler, g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
+    fns = dict(g22=g22_timemlps, g21=g21_ve_paths, g20=g20_fourier_paths, g19=g19_activations, g18=g18_evaler, g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
                g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
     for w in which:
         fns[w]()

@@ -49,6 +49,28 @@ def make_weights(seed, D=63, H=1024, E=512, n_blocks=2, fourier=False, fourier_s
     return out
 
 
+def timemlps_shapes(D=63, H=1024, n_blocks=2):
+    """state_dict order and shapes of TimeMLPs (reference model.py:69-88): net.<index of the Linear inside the Sequential>."""
+    idx = [0] + [2 + 3 * k for k in range(n_blocks)] + [2 + 3 * n_blocks]
+    dims = [(H, D + 1)] + [(H, H)] * n_blocks + [(D, H)]
+    shp = []
+    for i, (o, k) in zip(idx, dims):
+        shp += [(f"net.{i}.weight", (o, k)), (f"net.{i}.bias", (o,))]
+    return shp
+
+
+def make_mlp_weights(seed, D=63, H=1024, n_blocks=2):
+    """nn.Linear's default scale U(-1/sqrt(fan_in), 1/sqrt(fan_in)) from a frozen numpy stream."""
+    rs = np.random.RandomState(seed)
+    out, fan_in = {}, None
+    for name, shape in timemlps_shapes(D, H, n_blocks):
+        if len(shape) == 2:
+            fan_in = shape[1]
+        b = 1.0 / np.sqrt(fan_in)
+        out[name] = torch.tensor(rs.uniform(-b, b, size=shape).astype(np.float32))
+    return out
+
+
 def probe_indices(name, numel, n=48):
     """Indices at which per-tensor goldens (grads, updated params ...) are sampled."""
     rs = np.random.RandomState(abs(hash_name(name)) % (2 ** 31))

@@ -1578,3 +1578,116 @@ def test_train_steps_with_the_reference_dropout_masks_match_the_reference_golden
                     assert rel_err(probe(n, opt.state[prm]["exp_avg_sq"]), g[f"s{i}_v/{n}"]) < 1e-4, (i, n)   #  largest of all 700 comparisons)
     finally:
         eng.lib.dposer_scorefc_debug_set_dropout_masks(eng.h, None, 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# TimeMLPs (reference model.py:69-90): the secondary score model on the same GEMM family
+# ------------------------------------------------------------------------------------------------
+_MLP_CASES = [("swish1024", 63, 1024, 2, "swish", 31), ("lrelu64", 126, 64, 2, "lrelu", 32), ("elu256", 63, 256, 1, "elu", 33)]
+
+
+def _make_mlp(D, H, nb, act, seed, prec, dropout=0.0):
+    from weights import make_mlp_weights
+    from dposer_amd.algorithms.advanced.model import TimeMLPs
+    from dposer_amd.configs import load_config
+    cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+    cfg.model.nonlinearity = act
+    cfg.model.dropout = dropout
+    m = TimeMLPs(cfg, n_poses=21, pose_dim=D // 21, hidden_dim=H, n_blocks=nb)
+    m.load_state_dict(make_mlp_weights(seed, D, H, nb))
+    m.precision = prec
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("tag,D,H,nb,act,seed", _MLP_CASES)
+def test_timemlps_forward_and_gradients_match_reference_golden(tag, D, H, nb, act, seed, prec, tol):
+    """Eval forward, gradients of a linear functional w.r.t. every parameter and the input, and the sub-VP DSM loss + gradients through
+    the library's loss function (train mode, dropout 0), against what the reference's TimeMLPs produced (g22, gen_golden.py)."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    g = load("g22_timemlps")
+    m = _make_mlp(D, H, nb, act, seed, prec)
+    m.eval()
+    x = _dev(g[f"{tag}/x"]).requires_grad_(True)
+    t, c = _dev(g[f"{tag}/t"]), _dev(g[f"{tag}/c"])
+    with torch.no_grad():
+        assert rel_err(t2n(m(x.detach(), t)), g[f"{tag}/y"]) < tol           # inference instantiation (nothing kept)
+    y = m(x, t)
+    assert rel_err(t2n(y), g[f"{tag}/y"]) < tol
+    (y * c).sum().backward()
+    assert rel_err(t2n(x.grad), g[f"{tag}/dx"]) < 2 * tol
+    for n, p in m.named_parameters():
+        assert rel_err(probe(n, p.grad), g[f"{tag}/grad/{n}"]) < 3 * tol, n
+        p.grad = None
+    sde = sde_lib.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000)
+    loss_fn = losses.get_sde_loss_fn(sde, train=True, reduce_mean=True, continuous=True)
+    u = _dev(g[f"{tag}/dsm_u"])
+    loss = loss_fn(m, _dev(g[f"{tag}/dsm_batch"]), None, None, t=u * (sde.T - 1e-5) + 1e-5, z=_dev(g[f"{tag}/dsm_z"]))
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{tag}/dsm_loss"])) < (5 * tol) * abs(float(g[f"{tag}/dsm_loss"]))
+    for n, p in m.named_parameters():
+        assert rel_err(probe(n, p.grad), g[f"{tag}/dsm_grad/{n}"]) < 5 * tol, n
+
+
+@pytest.mark.parametrize("B", [1, 100, 640, 1280])
+def test_timemlps_train_mode_dropout_matches_philox_restatement(B):
+    """Train mode with p = 0.1: the keep decisions of every Dropout module come from the oracle's restatement of the epilogue's Philox
+    draw (site = block index); a torch fp32 restatement of model.py:74-88 with those masks gives the output, the input gradient and
+    every parameter gradient.  Ragged batch sizes exercise every tiling (64-, 128- and 256-sample padding)."""
+    D, H, nb = 63, 1024, 2
+    m = _make_mlp(D, H, nb, "swish", 41, "fp32", dropout=0.1)
+    m.train()
+    rs = np.random.RandomState(B)
+    x = _dev(rs.standard_normal((B, D))).requires_grad_(True)
+    t, c = _dev(rs.random_sample(B) * 999.0), _dev(rs.standard_normal((B, D)))
+    y = m(x, t)
+    (y * c).sum().backward()
+    seed, step = m._rng_seed, m._rng_step
+    ws = [p.detach().double() for p in m.parameters()]
+    xr = x.detach().double().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    h = torch.nn.functional.silu(torch.cat([xr, t.double()[:, None]], 1) @ wr[0].T + wr[1])
+    kept = []
+    for k in range(nb):
+        keep = torch.tensor(PH.dropout_keep_mask(B, H, k, step, seed, 0.1), dtype=torch.float64, device=DEV)
+        kept.append(float(keep.mean()))
+        h = torch.nn.functional.silu(h @ wr[2 + 2 * k].T + wr[3 + 2 * k]) * keep / 0.9
+    yr = h @ wr[-2].T + wr[-1]
+    (yr * c.double()).sum().backward()
+    assert all(0.85 < k < 0.95 for k in kept) or B < 16
+    assert rel_err(t2n(y), t2n(yr)) < TOL_FP32
+    assert rel_err(t2n(x.grad), t2n(xr.grad)) < 2 * TOL_FP32
+    for p, r in zip(m.parameters(), wr):
+        assert rel_err(t2n(p.grad), t2n(r.grad)) < 3 * TOL_FP32
+    # a second forward draws from the next step's counters; eval mode draws nothing
+    y2 = m(x.detach(), t)
+    assert not torch.equal(y2, y.detach())
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x.detach(), t), m(x.detach(), t))
+
+
+def test_timemlps_trains_with_the_fused_optimizer_and_refuses_cpu():
+    """run/train.py:163-176 with config.model.type = 'TimeMLPs': the model trains through get_step_fn (optimizer + EMA on the flat
+    buffer) and its loss falls; a CPU input raises (no torch fallback)."""
+    from dposer_amd.algorithms.advanced import losses, sde_lib
+    from dposer_amd.algorithms.ema import ExponentialMovingAverage
+    from dposer_amd.configs import load_config
+    cfg = load_config("configs.subvp.amass_scorefc_continuous.get_config")
+    m = _make_mlp(63, 1024, 2, "swish", 43, "bf16", dropout=0.1)
+    with pytest.raises(Exception, match="no CPU fallback"):
+        m(torch.zeros(4, 63), torch.zeros(4))
+    sde = sde_lib.subVPSDE(beta_min=0.1, beta_max=20.0, N=1000)
+    opt = losses.get_optimizer(cfg, m.parameters())
+    ema = ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate)
+    state = dict(optimizer=opt, model=m, ema=ema, step=0)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True, continuous=True)
+    torch.manual_seed(0)
+    batch = torch.randn(1280, 63, device=DEV) * 0.3
+    first = last = None
+    for i in range(60):
+        loss = step_fn(state, batch, None, None)["step_loss"]
+        if i == 0:
+            first = float(loss)
+        last = float(loss)
+    assert np.isfinite(last) and last < first

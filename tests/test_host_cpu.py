@@ -294,7 +294,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     pairs = {"dposer_scorefc_desc": _C.ScoreFCDesc, "dposer_sde_desc": _C.SdeDesc, "dposer_body_desc": _C.BodyDesc,
-             "dposer_motion_denoise_args": _C.MotionDenoiseArgs, "dposer_lbs_joint_fold": _C.LbsJointFold}
+             "dposer_motion_denoise_args": _C.MotionDenoiseArgs, "dposer_lbs_joint_fold": _C.LbsJointFold, "dposer_mlp_desc": _C.MlpDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dposer_hip.h"', 'int main(void) {']
     for cname, ct in pairs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')

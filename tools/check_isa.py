@@ -27,9 +27,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "dposer_amd", "csrc")
 CONTRACT_OK = {"gemm_launch.hip", "gemm_launch_x3.hip", "gemm_sampler.hip"}          # (Makefile: everything else is built with -ffp-contract=off)
 
-# the opt-in persistent sampler (DPOSER_SAMPLER_PERSISTENT=1, off by default: measured slower) keeps 8 pointer registers of its prologue in
-# scratch; nothing between its stage statements touches scratch (that check still applies to it)
-SPILL_NOTED = re.compile(r"k_sampler_persistent")
+# the opt-in persistent / cluster samplers (DPOSER_SAMPLER_PERSISTENT=1 / =2, off by default: measured slower, profiles/r05_sampler_small_ab.txt)
+# keep 3..8 registers of their prologue in scratch (12..28 bytes per lane); nothing between their stage statements touches scratch (that
+# check still applies to them)
+SPILL_NOTED = re.compile(r"k_sampler_(persistent|cluster)")
 M0_READER = re.compile(r"^(global_load_lds|s_movrel|v_movrel|ds_gws|s_sendmsg)")
 
 
