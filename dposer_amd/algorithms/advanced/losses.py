@@ -607,8 +607,18 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
                 # moments and EMA, all-gather the parameters (and the EMA shadow, which every rank keeps whole for evaluation)
                 world, rk = ddp.world_size(), ddp.rank()
                 bounds = ddp.zero1_bounds(flat_grad.numel(), world)
-                loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"])
-                ddp.reduce_scatter_flat_(flat_grad, bounds)
+                if os.environ.get("DPOSER_DP_NOTIFY", "1") != "0":
+                    # the reduce-scatter bucket by bucket UNDER the backward pass: every announced group of final ranges is cut at the
+                    # ownership boundaries and each piece reduced to its owner from the communication stream
+                    eng = model._engine()
+                    red = ddp.StreamedReduceToOwners(flat_grad, lambda stream, ev: _C.check(eng.lib.dposer_stream_wait_event(stream, ev),
+                                                                                            "dposer_stream_wait_event"), bounds)
+                    loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"],
+                                          bucket_events=eng.bucket_events(), on_final=red.on_final)
+                    red.finish(expect=eng.grad_buckets)
+                else:                                                               # (A/B: one collective after the call)
+                    loss = fused_dsm_grad(model, sde, batch, flat_grad=flat_grad, t=t, z=z, seed=seed, step=state["step"])
+                    ddp.reduce_scatter_flat_(flat_grad, bounds)
                 optimize_fn.warm_lr(optimizer, state["step"])
                 live = _live_params(model)
                 optimizer.fused_step_sharded(live=live, bounds=bounds, rank=rk, grad_clip=optimize_fn.grad_clip, grad_scale=1.0 / world,

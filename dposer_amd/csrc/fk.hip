@@ -608,6 +608,8 @@ struct BodyTuning {
     bool fk_dma = true;                   // DPOSER_FK_DMA=0: joints-only body query through k_fk_joints instead of k_fk_joints_dma (A/B)
     int lbs_bwd_panel_order = 1;          // DPOSER_LBS_BWD_PANEL_ORDER=0: generic block -> tile order for the blend-gradient GEMMs (A/B)
     bool lbs_k_prefix = true;             // DPOSER_LBS_K_PREFIX=0: blend GEMMs over all padded pose-feature columns, posed or not (A/B)
+    int64_t lbs_fwd_chunk = 0;            // DPOSER_LBS_FWD_CHUNK=n (multiple of 256): the full forward runs blend GEMM and skinning in chunks of n poses, the
+                                          // skinning of chunk i on a side stream beside the GEMM of chunk i + 1 (0: one launch each over the whole batch)
     void load() {
         const char* e = getenv("DPOSER_FK_SMALL_MAX");
         fk_small_max = e ? atoll(e) : (int64_t)8192;
@@ -627,6 +629,8 @@ struct BodyTuning {
         lbs_k_prefix = !(e && e[0] == '0');
         e = getenv("DPOSER_LBS_BWD_PANEL_ORDER");
         lbs_bwd_panel_order = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("DPOSER_LBS_FWD_CHUNK");
+        lbs_fwd_chunk = e ? atoll(e) / 256 * 256 : (int64_t)0;
     }
 };
 static BodyTuning& body_tuning() {
@@ -739,6 +743,9 @@ struct dposer_body_s {
     int32_t* jl_seg = nullptr;       // device [chunks][128] x int2 (begin, end) relative to the chunk's first entry
     int32_t* jl_nseg = nullptr;      // device [chunks]
     int32_t* jl_jseg = nullptr;      // device [chunks][J] (first segment | count << 16) of joint j in chunk c
+    // chunked forward: the skinning of chunk i runs on this stream beside the blend GEMM of chunk i + 1 (created on first use)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_chunk[2] = {nullptr, nullptr}, ev_join = nullptr;
 };
 
 template <typename Kin> static bool same_tree(const int32_t* p, int n) {
@@ -769,6 +776,9 @@ extern "C" void dposer_body_destroy(dposer_body_t h) {
     if (!h) return;
     (void)hipFree(h->jl_vstart); (void)hipFree(h->jl_ptr); (void)hipFree(h->jl_first); (void)hipFree(h->jl_entry);
     (void)hipFree(h->jl_seg); (void)hipFree(h->jl_nseg); (void)hipFree(h->jl_jseg);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    for (hipEvent_t e : {h->ev_chunk[0], h->ev_chunk[1], h->ev_join})
+        if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -1177,9 +1187,48 @@ extern "C" int64_t dposer_lbs_workspace_bytes(dposer_body_t h, int64_t batch) {
 }
 
 // FK + pose-blend GEMM of the LBS forward (steps 1 and 2); A / offsets: where the skinning stage finds its inputs in `ws`
+// The pose-blend GEMM of the padded pose rows [r0, r1) (multiples of the 256 / 128-row tile): lbs_forward_front runs it over the whole batch,
+// the chunked forward (dposer_lbs_forward) chunk by chunk with the skinning of the previous chunk running beside it.
+struct LbsBlend {
+    float* pf;
+    __bf16* pf_split;
+    float* offsets;
+    const void* posedirs_packed;
+    int Keff, Ppad, V;
+    int64_t Cpad, Bpad, batch;
+};
+static int lbs_blend_rows(const LbsBlend& b, int64_t r0, int64_t r1, hipStream_t st) {
+    GemmArgs g;
+    std::memset(&g, 0, sizeof(g));
+    WgradParams wp;
+    const int64_t valid = (b.batch < r1 ? b.batch : r1) - r0;
+    if (valid <= 0) return DPOSER_OK;
+    wp.slab = b.offsets + r0 * b.Cpad; wp.slab_stride = 0; wp.ld = (int)b.Cpad; wp.N_valid = (int)valid; wp.K_valid = b.V * 3;
+    g.ksplit = 1;
+    const int64_t rows = r1 - r0;
+    if (lbs_blend_fp32()) {
+        g.W = (const char*)b.pf + (r0 / 32) * (int64_t)(b.Ppad / 8) * 1024; g.w_stride_blocks = b.Ppad / 8; g.n_cblk = (int)(rows / 128); g.n_sblk = (int)(b.Cpad / 128);
+        g.src[0] = b.posedirs_packed; g.seg_kblocks[0] = b.Keff / 8; g.seg_stride_blocks[0] = b.Ppad / 8; g.nseg = 1; g.ktot_blocks = b.Keff / 8;
+        FK_HIP_LAUNCH(gemm_wgrad(PREC_FP32, SHAPE_MID, g, wp, st));
+    } else {
+        const char* hi = (const char*)b.posedirs_packed + b.Cpad * b.Ppad * 4;
+        const char* lo = hi + b.Cpad * b.Ppad * 2;
+        const int kb = b.Ppad / 16, kbe = b.Keff / 16;
+        const int shape = (rows % 256 == 0 && b.Cpad % 256 == 0 && b.Bpad >= 1024) ? SHAPE_BIG : SHAPE_MID;
+        const int tile = shape == SHAPE_BIG ? 256 : 128;
+        g.W = (const char*)b.pf_split + (r0 / 32) * (int64_t)(3 * kbe) * 1024; g.w_stride_blocks = 3 * kbe; g.n_cblk = (int)(rows / tile); g.n_sblk = (int)(b.Cpad / tile);
+        g.src[0] = hi; g.src[1] = lo; g.src[2] = hi;                        // [pf_hi | pf_hi | pf_lo] x [hi ; lo ; hi]
+        g.seg_kblocks[0] = g.seg_kblocks[1] = g.seg_kblocks[2] = kbe; g.nseg = 3; g.ktot_blocks = 3 * kbe;
+        g.seg_stride_blocks[0] = g.seg_stride_blocks[1] = g.seg_stride_blocks[2] = kb;      // (rows of the packed posedirs keep their full width)
+        FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, shape, g, wp, st));
+    }
+    return DPOSER_OK;
+}
+
 static int lbs_forward_front(dposer_body_t h, void* ws, const void* posedirs_packed, const float* const* pose_segments_host,
                              const int32_t* segment_joints_host, int32_t num_segments, const float* j_rest, int32_t j_rest_batched,
-                             const float* transl, float* joints, int64_t batch, void* stream, float** A_out, float** offsets_out) {
+                             const float* transl, float* joints, int64_t batch, void* stream, float** A_out, float** offsets_out,
+                             LbsBlend* blend = nullptr) {
     DP_CHECK_ARG(h && ws && posedirs_packed && pose_segments_host && segment_joints_host && j_rest && joints, "null argument");
     DP_CHECK_ARG(batch > 0, "bad size");
     DP_CHECK_ARG(((uintptr_t)ws & 255) == 0 && ((uintptr_t)posedirs_packed & 255) == 0, "workspace / packed posedirs must be 256-byte aligned");
@@ -1214,34 +1263,21 @@ static int lbs_forward_front(dposer_body_t h, void* ws, const void* posedirs_pac
     else if (h->kind == 1) FK_HIP_LAUNCH(launch_fk<KinSMPLH>(a, st));
     else FK_HIP_LAUNCH(launch_fk<KinSMPLX>(a, st));
 
-    // 2. pose-blend offsets[b][3V] = pose_feature @ posedirs: fp32 MFMA, rows = poses, lanes = vertex coords
-    {
-        GemmArgs g;
-        std::memset(&g, 0, sizeof(g));
-        WgradParams wp;
-        wp.slab = offsets; wp.slab_stride = 0; wp.ld = (int)Cpad; wp.N_valid = (int)batch; wp.K_valid = V * 3;
-        g.ksplit = 1;
-        // K prefix: the columns of the joints that are posed (lbs_posed_cols), in whole 32-column stages, at least one
-        int Keff = body_tuning().lbs_k_prefix ? (int)round_up(lbs_posed_cols(pose_segments_host, segment_joints_host, num_segments, J), 32) : Ppad;
-        Keff = Keff < 32 ? 32 : (Keff > Ppad ? Ppad : Keff);
-        if (lbs_blend_fp32()) {
-            g.W = pf; g.w_stride_blocks = Ppad / 8; g.n_cblk = (int)(Bpad / 128); g.n_sblk = (int)(Cpad / 128);
-            g.src[0] = posedirs_packed; g.seg_kblocks[0] = Keff / 8; g.seg_stride_blocks[0] = Ppad / 8; g.nseg = 1; g.ktot_blocks = Keff / 8;
-            FK_HIP_LAUNCH(gemm_wgrad(PREC_FP32, SHAPE_MID, g, wp, st));
-        } else {
-            hipLaunchKernelGGL(k_split_pf, dim3((unsigned)ceil_div(Bpad * (Keff / 8), 256)), dim3(256), 0, st, (const float*)pf, pf_split, Bpad, Ppad, Keff);
-            FK_HIP_LAUNCH(hipGetLastError());
-            const char* hi = (const char*)posedirs_packed + Cpad * Ppad * 4;
-            const char* lo = hi + Cpad * Ppad * 2;
-            const int kb = Ppad / 16, kbe = Keff / 16;
-            const int shape = (Bpad % 256 == 0 && Cpad % 256 == 0 && Bpad >= 1024) ? SHAPE_BIG : SHAPE_MID;
-            const int tile = shape == SHAPE_BIG ? 256 : 128;
-            g.W = pf_split; g.w_stride_blocks = 3 * kbe; g.n_cblk = (int)(Bpad / tile); g.n_sblk = (int)(Cpad / tile);
-            g.src[0] = hi; g.src[1] = lo; g.src[2] = hi;                        // [pf_hi | pf_hi | pf_lo] x [hi ; lo ; hi]
-            g.seg_kblocks[0] = g.seg_kblocks[1] = g.seg_kblocks[2] = kbe; g.nseg = 3; g.ktot_blocks = 3 * kbe;
-            g.seg_stride_blocks[0] = g.seg_stride_blocks[1] = g.seg_stride_blocks[2] = kb;      // (rows of the packed posedirs keep their full width)
-            FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, shape, g, wp, st));
-        }
+    // 2. pose-blend offsets[b][3V] = pose_feature @ posedirs: rows = poses, lanes = vertex coords
+    int Keff = body_tuning().lbs_k_prefix ? (int)round_up(lbs_posed_cols(pose_segments_host, segment_joints_host, num_segments, J), 32) : Ppad;
+    Keff = Keff < 32 ? 32 : (Keff > Ppad ? Ppad : Keff);       // K prefix: the columns of the joints that are posed, in whole 32-column stages, at least one
+    if (!lbs_blend_fp32()) {
+        hipLaunchKernelGGL(k_split_pf, dim3((unsigned)ceil_div(Bpad * (Keff / 8), 256)), dim3(256), 0, st, (const float*)pf, pf_split, Bpad, Ppad, Keff);
+        FK_HIP_LAUNCH(hipGetLastError());
+    }
+    if (blend) {
+        blend->pf = pf; blend->pf_split = pf_split; blend->offsets = offsets; blend->posedirs_packed = posedirs_packed;
+        blend->Keff = Keff; blend->Ppad = Ppad; blend->Cpad = Cpad; blend->Bpad = Bpad; blend->batch = batch; blend->V = V;
+    } else {
+        LbsBlend b;
+        b.pf = pf; b.pf_split = pf_split; b.offsets = offsets; b.posedirs_packed = posedirs_packed;
+        b.Keff = Keff; b.Ppad = Ppad; b.Cpad = Cpad; b.Bpad = Bpad; b.batch = batch; b.V = V;
+        DP_TRY(lbs_blend_rows(b, 0, Bpad, st));
     }
     *A_out = A;
     *offsets_out = offsets;
@@ -1257,27 +1293,52 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
     DP_CHECK_ARG(v_shaped && skin_idx && skin_w && verts, "null argument");
     DP_CHECK_ARG(skin_k >= 1, "bad size");
     float *A = nullptr, *offsets = nullptr;
-    DP_TRY(lbs_forward_front(h, ws, posedirs_packed, pose_segments_host, segment_joints_host, num_segments, j_rest, j_rest_batched, transl, joints,
-                             batch, stream, &A, &offsets));
     hipStream_t st = (hipStream_t)stream;
     const int J = h->d.num_joints, V = h->d.num_vertices;
     const int64_t Cpad = lbs_cpad(V);
     const int n_total = J + h->d.num_extra + h->d.num_landmarks;
-    // 3. skinning
-    {
+    const int64_t chunk = body_tuning().lbs_fwd_chunk;
+    const bool chunked = chunk >= 256 && batch > chunk;
+    LbsBlend blend;
+    DP_TRY(lbs_forward_front(h, ws, posedirs_packed, pose_segments_host, segment_joints_host, num_segments, j_rest, j_rest_batched, transl, joints,
+                             batch, stream, &A, &offsets, chunked ? &blend : nullptr));
+    // 3. skinning of the poses [b0, b0 + nb)
+    auto skin = [&](int64_t b0, int64_t nb, hipStream_t ss) -> int {
         SkinArgs s;
-        s.offsets = offsets; s.ld_off = Cpad; s.v_shaped = v_shaped; s.v_shaped_batched = v_shaped_batched; s.A = A;
-        s.skin_idx = skin_idx; s.skin_w = skin_w; s.K = skin_k; s.J = J; s.V = V; s.transl = transl; s.verts = verts;
-        dim3 grid((unsigned)ceil_div(V, 256 * 4), (unsigned)batch);
+        s.offsets = offsets + b0 * Cpad; s.ld_off = Cpad; s.v_shaped = v_shaped_batched ? v_shaped + b0 * V * 3 : v_shaped; s.v_shaped_batched = v_shaped_batched;
+        s.A = A + b0 * J * 12; s.skin_idx = skin_idx; s.skin_w = skin_w; s.K = skin_k; s.J = J; s.V = V; s.transl = transl ? transl + b0 * 3 : nullptr;
+        s.verts = verts + b0 * V * 3;
+        dim3 grid((unsigned)ceil_div(V, 256 * 4), (unsigned)nb);
         const int mode = body_tuning().skin_mode;
         if (mode >= 3 && skin_k == 4 && J * 12 <= 768) {
             // poses per block: enough blocks for ~4 per resident slot (256 CUs x 8), at most 16 poses
             int run = 1;
-            while (run < 16 && (int64_t)grid.x * ceil_div(batch, run * 2) >= 8192) run *= 2;
-            hipLaunchKernelGGL(k_skin_run, dim3(grid.x, (unsigned)ceil_div(batch, run)), dim3(256), 2 * J * 12 * sizeof(float), st, s, run, (int64_t)batch);
-        } else if (mode != 0 && skin_k == 4) hipLaunchKernelGGL(k_skin_x4, grid, dim3(256), J * 12 * sizeof(float), st, s);
-        else hipLaunchKernelGGL(k_skin, grid, dim3(256), J * 12 * sizeof(float), st, s);
+            while (run < 16 && (int64_t)grid.x * ceil_div(nb, run * 2) >= 8192) run *= 2;
+            hipLaunchKernelGGL(k_skin_run, dim3(grid.x, (unsigned)ceil_div(nb, run)), dim3(256), 2 * J * 12 * sizeof(float), ss, s, run, (int64_t)nb);
+        } else if (mode != 0 && skin_k == 4) hipLaunchKernelGGL(k_skin_x4, grid, dim3(256), J * 12 * sizeof(float), ss, s);
+        else hipLaunchKernelGGL(k_skin, grid, dim3(256), J * 12 * sizeof(float), ss, s);
         FK_HIP_LAUNCH(hipGetLastError());
+        return DPOSER_OK;
+    };
+    if (!chunked) {
+        DP_TRY(skin(0, batch, st));
+    } else {
+        // blend GEMM chunk by chunk on the caller's stream; the skinning of a finished chunk runs on the side stream beside the next
+        // chunk's GEMM (matrix pipe beside a streaming kernel), and reads its pose-blend offsets while they are still cache-resident
+        if (!h->side) {
+            DP_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            for (hipEvent_t* e : {&h->ev_chunk[0], &h->ev_chunk[1], &h->ev_join}) DP_CHECK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+        int k = 0;
+        for (int64_t b0 = 0; b0 < batch; b0 += chunk, ++k) {
+            const int64_t r1 = b0 + chunk < blend.Bpad ? b0 + chunk : blend.Bpad;
+            DP_TRY(lbs_blend_rows(blend, b0, b0 + chunk >= batch ? blend.Bpad : r1, st));
+            DP_CHECK_HIP(hipEventRecord(h->ev_chunk[k & 1], st));
+            DP_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_chunk[k & 1], 0));
+            DP_TRY(skin(b0, (b0 + chunk < batch ? b0 + chunk : batch) - b0, h->side));
+        }
+        DP_CHECK_HIP(hipEventRecord(h->ev_join, h->side));
+        DP_CHECK_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     }
     // 4. extra joints + landmarks
     if (h->d.num_extra + h->d.num_landmarks > 0) {

@@ -228,6 +228,39 @@ class StreamedAllReduce:
         return dist.get_world_size()
 
 
+class StreamedReduceToOwners(StreamedAllReduce):
+    """The ZeRO-1 form of StreamedAllReduce: ``bounds[r]`` = the contiguous range of ``flat`` whose optimizer state rank r owns.  Every
+    announced range is cut at the ownership boundaries and each piece is SUM-reduced to its owner (``dist.reduce``) from the
+    communication stream, while the backward pass is still running -- the reduce-scatter of the sharded step, issued bucket by bucket
+    under the backward instead of as one collective after it (half the wire bytes of the all-reduce the replicated step issues).
+    After ``finish()`` rank r holds the reduced gradient of ``bounds[r]``; other ranges are unspecified."""
+
+    def __init__(self, flat, wait_event, bounds):
+        super().__init__(flat, wait_event)
+        self.bounds = list(bounds)
+
+    def _pieces(self, ranges):
+        for lo, hi in ranges:
+            for r, (a, b) in enumerate(self.bounds):
+                p, q = max(lo, a), min(hi, b)
+                if q > p:
+                    yield r, p, q
+
+    def on_final(self, ranges, event):
+        try:
+            self.ranges.extend(ranges)
+            if self.comm is not None:
+                self.wait_event(self.comm.cuda_stream, event)
+                with torch.cuda.stream(self.comm):
+                    for r, p, q in self._pieces(ranges):
+                        self.works.append(dist.reduce(self.flat[p:q], dst=r, op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                for r, p, q in self._pieces(ranges):
+                    self.works.append(dist.reduce(self.flat[p:q], dst=r, op=dist.ReduceOp.SUM, async_op=True))
+        except BaseException as e:            # noqa: BLE001 -- re-raised by finish()
+            self.error = e
+
+
 def zero1_bounds(n: int, num_replicas: int):
     """Contiguous ownership ranges of a flat buffer of n elements for the sharded optimiser step: equal sizes rounded up to a
     multiple of 4 floats (16-byte aligned shard starts), the last rank takes what is left (it may be shorter: the collectives

@@ -88,6 +88,20 @@ def _worker_shards(rank, world, port, out):
     p[lo:hi] = float(rank + 1)
     ddp.all_gather_flat_(p, bounds)
     want = torch.cat([torch.full((b - a,), float(r + 1)) for r, (a, b) in enumerate(bounds)])
+    # the same reduce-scatter range by range as the backward pass announces them (ZeRO-1 under the backward): ranges that straddle the
+    # ownership boundary are cut there, an un-announced range is caught by finish(expect=...)
+    g2 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red = ddp.StreamedReduceToOwners(g2, None, bounds)
+    red.on_final([(700, 1003)], None)
+    red.on_final([(400, 700), (100, 400)], None)
+    caught = False
+    try:
+        red.finish(expect=[(0, 100)])
+    except RuntimeError:
+        caught = True
+    red.on_final([(0, 100)], None)
+    red.finish(expect=[(0, 100), (100, 400), (400, 700), (700, 1003)])
+    ok = ok and caught and torch.equal(g2[lo:hi], torch.arange(n, dtype=torch.float32)[lo:hi] * 3) and len(red.works) == 5
     out.put((rank, bool(ok), bool(torch.equal(p, want)), bounds))
     ddp.barrier()
     dist.destroy_process_group()

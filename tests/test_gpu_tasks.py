@@ -250,23 +250,30 @@ def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, 
         assert torch.equal(out[tag][1], out["two-kernel"][1]), tag
 
 
-def test_motion_denoise_under_the_ve_sde_runs_the_step_by_step_loop():
-    """training.sde = 'vesde' (motion_denoising.py:60-62 builds it) is outside the one-call loop: `optimize` takes the autograd loop with
-    the unfused VE prior, `optimize_sequences` walks the sequences through it one by one and returns the batched layout."""
+def test_motion_denoise_under_the_ve_sde():
+    """training.sde = 'vesde' (motion_denoising.py:60-62 builds it).  Continuous score function: the one-call loop takes it (the prior's
+    label is sigma(t), its output the score) and lands where the step-by-step autograd loop lands.  The discrete VE score function
+    (continuous = False) stays outside the one-call loop: `optimize_sequences` walks the sequences through `optimize` one by one and
+    returns the batched layout."""
     from dposer_amd.algorithms.advanced import sde_lib
     F, S, iters, spi = 6, 2, 1, 3
     md, joints3d, gt, init, rs = _md_setup(F * S)
     md.sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50.0, N=500)
     md.batch_size = F
     md.betas = md.betas[:F]
-    assert not md._fused_supported()
+    assert md._fused_supported()
     noise = torch.tensor(rs.standard_normal((iters * spi, F * S, 63)).astype(np.float32), device=DEV)
     kw = dict(time_strategy="3", iterations=iters, steps_per_iter=spi)
+    one_f = md.optimize(joints3d[F:], gt_poses=gt[F:], noise=noise[:, F:].contiguous(), init_poses=init[F:], fused=True, **kw)
+    one_u = md.optimize(joints3d[F:], gt_poses=gt[F:], noise=noise[:, F:].contiguous(), init_poses=init[F:], fused=False, **kw)
+    assert rel_err(t2n(one_f["pose_body"]), t2n(one_u["pose_body"])) < 2e-5
+    assert float((one_f["pose_body"] - init[F:]).abs().max()) > 1e-3            # (the poses moved)
+    md.continuous = False
+    assert not md._fused_supported()
     res = md.optimize_sequences(joints3d.reshape(S, F, 22, 3), gt.reshape(S, F, 63), noise=noise, init_poses=init.reshape(S, F, 63), **kw)
     assert res["pose_body"].shape == (S, F, 63) and res["MPJPE"].shape == (S, F) and np.isfinite(res["MPVPE"]).all()
     one = md.optimize(joints3d[F:], gt_poses=gt[F:], noise=noise[:, F:].contiguous(), init_poses=init[F:], **kw)
     assert torch.equal(res["pose_body"][1], one["pose_body"])
-    assert float((res["pose_body"][1] - init[F:]).abs().max()) > 1e-3            # (the poses moved)
 
 
 def test_evaluate_motion_denoising_shards_sequences_over_ranks():
