@@ -136,6 +136,10 @@ template <typename Epi> struct EpiRing<Epi, decltype((void)Epi::kRingPerWave)> {
 // disjoint LDS regions: the barriers inside are workgroup-wide, so both halves must run the same number of stages).
 template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int NB>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi::Params& ep, int cblk, int sblk, int split, unsigned char* smem, int tid) {
+#ifdef DPOSER_PHASE_STAMPS     // tools/tile_phase_probe.hip: where a tile's time goes (prologue / K loop / epilogue) and when it ran
+    const uint64_t ps_rt0 = __builtin_amdgcn_s_memrealtime(), ps_t0 = __builtin_amdgcn_s_memtime();
+    uint64_t ps_t1 = 0, ps_t2 = 0;
+#endif
     static_assert(KB % 2 == 0, "fragment double buffering assumes an even number of k-blocks per stage");
     static_assert(NB >= 2 && NB <= 4, "ring depth");
     typedef GemmCfg<T, WC, WS, TC, TS, KB> C;
@@ -405,6 +409,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         typedef std::true_type Y;
         typedef std::false_type N;
         int t = 0;
+#ifdef DPOSER_PHASE_STAMPS
+        ps_t1 = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (ASM) {
             const uint32_t vA_lo = lds0 + ((wc * TC * KB) << 10) + lane * 16, vB_lo = lds0 + ((C::CT * KB + ws * TS * KB) << 10) + lane * 16;
             const uint32_t vA_hi = vA_lo + 65536, vB_hi = vB_lo + 65536;
@@ -456,6 +463,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         }
     }
 
+#ifdef DPOSER_PHASE_STAMPS
+    ps_t2 = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef DPOSER_KLOOP_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -468,6 +478,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         Epi::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
                                     sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32, wave_scratch);
     }
+#ifdef DPOSER_PHASE_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);      // (the epilogue's stores have left the wave)
+    if ((tid & 63) == 0) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<void*>(g.src[6])) + ((size_t)(blockIdx.x + blockIdx.y * gridDim.x) * (WC * WS) + (tid >> 6)) * 6;
+        const uint64_t t3 = __builtin_amdgcn_s_memtime();
+        o[0] = ps_rt0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = ps_t1 - ps_t0; o[3] = ps_t2 - ps_t1; o[4] = t3 - ps_t2;
+        o[5] = ((uint64_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));      // XCC_ID, HW_ID
+    }
+#endif
 }
 
 template <typename T, int WC, int WS, int TC, int TS, int KB, typename Epi, int NB = 2>
