@@ -111,6 +111,21 @@ def scorefc_forward(p: Params, batch: torch.Tensor, labels: torch.Tensor, *, n_b
     return res
 
 
+def timemlps_forward(p: Params, x: torch.Tensor, t: torch.Tensor, *, n_blocks=2, nonlinearity: str = "swish",
+                     drop_masks: Optional[Sequence[torch.Tensor]] = None, drop_p: float = 0.0) -> torch.Tensor:
+    """TimeMLPs.forward -- lib/algorithms/advanced/model.py:69-90: net(cat[x, t[:, None]]), net = Linear(D + 1, H), act,
+    [Linear(H, H), act, Dropout] x n_blocks, Linear(H, D); parameters keyed ``net.<index in the Sequential>``.
+    ``drop_masks``: optional n_blocks {0,1} keep masks [B, H] applied where model.py:82 has the Dropout modules."""
+    act = {"swish": torch.nn.functional.silu, "elu": torch.nn.functional.elu, "relu": torch.relu,
+           "lrelu": lambda v: torch.nn.functional.leaky_relu(v, negative_slope=0.2)}[nonlinearity]
+    h = act(_lin(p, "net.0", torch.cat([x, t[:, None].to(x.dtype)], dim=1)))          # model.py:75-76, :90
+    for k in range(n_blocks):
+        h = act(_lin(p, f"net.{2 + 3 * k}", h))                                        # model.py:79-81
+        if drop_masks is not None:
+            h = h * drop_masks[k].to(h.dtype) / (1.0 - drop_p)                         # model.py:82
+    return _lin(p, f"net.{2 + 3 * n_blocks}", h)                                       # model.py:85
+
+
 # --------------------------------------------------------------------------------------------
 # sde_lib.py
 # --------------------------------------------------------------------------------------------

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from helpers import load, rel_err, probe, masks_from_keep
-from weights import make_weights
+from weights import make_mlp_weights, make_weights
 from oracle import score_ref as R
 from oracle import fk_ref
 
@@ -334,3 +334,71 @@ def test_other_activations_forward_and_dsm_gradients(act):
     for n, gr in zip(names, grads):
         if gr is not None:
             assert rel_err(probe(n, gr), g[f"{act}_grad/{n}"]) < 1e-4, n
+
+
+@pytest.mark.parametrize("tag,D,H,nb,act,seed", [("swish1024", 63, 1024, 2, "swish", 31), ("lrelu64", 126, 64, 2, "lrelu", 32), ("elu256", 63, 256, 1, "elu", 33)])
+def test_timemlps_forward_gradients_and_dsm_loss(tag, D, H, nb, act, seed):
+    """oracle.score_ref.timemlps_forward against the reference's TimeMLPs (golden g22): output, gradients of the recorded linear
+    functional w.r.t. the input and every parameter, and the sub-VP DSM loss with the recorded draws."""
+    g = load("g22_timemlps")
+    p = {k: v.clone().requires_grad_(True) for k, v in make_mlp_weights(seed, D, H, nb).items()}
+    x = torch.tensor(g[f"{tag}/x"]).requires_grad_(True)
+    t, c = torch.tensor(g[f"{tag}/t"]), torch.tensor(g[f"{tag}/c"])
+    y = R.timemlps_forward(p, x, t, n_blocks=nb, nonlinearity=act)
+    assert rel_err(y.detach(), g[f"{tag}/y"]) < TOL
+    (y * c).sum().backward()
+    assert rel_err(x.grad, g[f"{tag}/dx"]) < TOL
+    for n, w in p.items():
+        assert rel_err(probe(n, w.grad), g[f"{tag}/grad/{n}"]) < 5 * TOL, n
+        w.grad = None
+    sde = R.SubVP()
+    tt = torch.tensor(g[f"{tag}/dsm_u"]) * (1.0 - 1e-5) + 1e-5                  # losses.py:110
+    z, batch = torch.tensor(g[f"{tag}/dsm_z"]), torch.tensor(g[f"{tag}/dsm_batch"])
+    mean, std = sde.marginal_prob(batch, tt)
+    score = -R.timemlps_forward(p, mean + std[:, None] * z, tt * 999, n_blocks=nb, nonlinearity=act) / std[:, None]      # utils.py:152-160
+    loss = torch.mean(torch.mean(torch.square(score * std[:, None] + z), dim=-1))                                        # losses.py:121-131
+    assert abs(loss.item() - float(g[f"{tag}/dsm_loss"])) < 5 * TOL * abs(float(g[f"{tag}/dsm_loss"]))
+    loss.backward()
+    for n, w in p.items():
+        assert rel_err(probe(n, w.grad), g[f"{tag}/dsm_grad/{n}"]) < 10 * TOL, n
+
+
+def test_ve_sde_paths():
+    """The oracle under the variance-exploding SDE (sde_lib.py:234-292) against the reference's own outputs (golden g21): DSM loss +
+    gradients, the EM sampler (plain and with completion imputation), the prior loss + its gradient, the completion loop."""
+    from oracle import task_loops
+    g = load("g21_ve_paths")
+    mk = lambda N: R.VE(float(g["sigma_min"]), float(g["sigma_max"]), N)
+    w = make_weights(int(g["seed"]), D=63)
+    p = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    p["sigmas"] = R.sigma_table()
+    t = torch.tensor(g["dsm_u"]) * (1.0 - 1e-5) + 1e-5
+    loss = R.dsm_loss(p, mk(1000), torch.tensor(g["dsm_batch"]), t, torch.tensor(g["dsm_z"]))
+    assert abs(loss.item() - float(g["dsm_loss"])) < TOL * abs(float(g["dsm_loss"]))
+    loss.backward()
+    for n in w:
+        ref = g[f"dsm_grad/{n}"]
+        if ref.shape == (1,):
+            assert p[n].grad is None or float(p[n].grad.abs().max()) == 0.0
+        else:
+            assert rel_err(probe(n, p[n].grad), ref) < 2e-4, n
+    p = dict(w)
+    p["sigmas"] = R.sigma_table()
+    with torch.no_grad():
+        trajs, x = R.pc_sampler(p, mk(8), torch.tensor(g["em8_z0"]), list(torch.tensor(g["em8_noise"])))
+        assert rel_err(trajs, g["em8_trajs"]) < 1e-4 and rel_err(x, g["em8_final"]) < 1e-4
+        noise = torch.tensor(g["comp8_noise"])
+        imp = [(noise[3 * i], noise[3 * i + 2]) for i in range(8)]
+        em = [noise[3 * i + 1] for i in range(8)]
+        trajs, x = R.pc_sampler(p, mk(8), torch.tensor(g["comp8_z0"]), em, observation=torch.tensor(g["comp8_obs"]),
+                                mask=torch.tensor(g["comp8_mask"]), impute_noises=imp)
+        assert rel_err(trajs, g["comp8_trajs"]) < 1e-4 and rel_err(x, g["comp8_final"]) < 1e-4
+        x0 = torch.tensor(g["prior_x0"])
+        for step in (0, 199):
+            tt = torch.ones(x0.shape[0]) * float(g[f"prior_s{step}_t"])
+            lp, gp = R.dposer_prior_loss(p, mk(1000), x0, tt, torch.tensor(g[f"prior_s{step}_z"]), weighted=bool(int(g[f"prior_s{step}_quan_t"])))
+            assert abs(lp.item() - float(g[f"prior_s{step}_loss"])) < 2e-4 * abs(float(g[f"prior_s{step}_loss"]))
+            assert rel_err(gp, g[f"prior_s{step}_grad"]) < 2e-4
+    out = task_loops.completion_optimize(p, mk(1000), g["loop_observation"], g["loop_mask"], g["loop_noise"],
+                                         iterations=int(g["loop_iterations"]), steps_per_iter=int(g["loop_steps_per_iter"]))
+    assert rel_err(out, g["loop_out"]) < 2e-4
