@@ -31,9 +31,15 @@ def short(name):
     name = demangle(name)
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "")
-    name = re.sub(r"gemm_ft_kernel<(__bf16|float), (\d+), (\d+), (\d+), (\d+), (\d+), (Epi\w+)<([^>]*)>(, \d+)?\s*>",
-                  lambda m: f"gemm_ft_kernel<{'bf16' if m.group(1) == '__bf16' else 'fp32'},{int(m.group(2)) * int(m.group(4)) * 32}x"
-                            f"{int(m.group(3)) * int(m.group(5)) * 32},{m.group(7)}{'<train>' if 'true' in m.group(8) else ''}>", name)
+    name = name.replace("gemm_ft_kernel<bool _Accum, int, E,", "gemm_ft_kernel<__bf16, 1,")      # (a demangler that does not know DF16b)
+
+    def gemm(m):
+        t = "bf16" if m.group(1) == "__bf16" else "fp32"
+        if t == "bf16" and m.group(8).split(",")[0].strip() == "float":
+            t = "bf16x3"                           # bf16 operand planes under a fp32-storage epilogue (gemm_launch_x3.hip)
+        return (f"gemm_ft_kernel<{t},{int(m.group(2)) * int(m.group(4)) * 32}x{int(m.group(3)) * int(m.group(5)) * 32},"
+                f"{m.group(7)}{'<train>' if 'true' in m.group(8) else ''}>")
+    name = re.sub(r"gemm_ft_kernel<(__bf16|float), (\d+), (\d+), (\d+), (\d+), (\d+), (Epi\w+)<([^>]*)>(, \d+)?\s*>", gemm, name)
     return name[:110]
 
 
