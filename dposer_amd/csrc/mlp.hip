@@ -212,7 +212,8 @@ extern "C" int dposer_mlp_forward(dposer_mlp_t h, const float* flat, const void*
                              h->kin_pad[i] / KBS, 2.0 * (double)B * h->H * h->kin[i]);
         BiasSiLUParams p;
         std::memset(&p, 0, sizeof(p));
-        p.bias = h->Hp != h->H ? (const float*)(packed + h->pk_b[i]) : flat + h->b_off[i]; p.out = w.hb[i]; p.pre = keep ? w.pre[i] : nullptr; p.N = h->Hp; p.Spad = w.Bpad; p.act = h->d.activation;
+        p.bias = h->Hp != h->H ? (const float*)(packed + h->pk_b[i]) : flat + h->b_off[i]; p.out = w.hb[i]; p.pre = w.pre[i]; p.N = h->Hp;      // (the training instantiation always stores u)
+         p.Spad = w.Bpad; p.act = h->d.activation;
         p.outT = (keep && h->f32) ? w.hT[i] : nullptr;
         p.drop = ml_drop(h, train_mode != 0, i, seed, step);
         // (the inference instantiation has no dropout and keeps nothing; train mode or a kept graph take the training one)

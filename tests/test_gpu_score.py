@@ -1629,13 +1629,14 @@ def test_timemlps_forward_and_gradients_match_reference_golden(tag, D, H, nb, ac
         assert rel_err(probe(n, p.grad), g[f"{tag}/dsm_grad/{n}"]) < 5 * tol, n
 
 
-@pytest.mark.parametrize("B", [1, 100, 640, 1280])
-def test_timemlps_train_mode_dropout_matches_philox_restatement(B):
+@pytest.mark.parametrize("B,prec,tol", [(1, "fp32", TOL_FP32), (100, "fp32", TOL_FP32), (640, "fp32", TOL_FP32), (1280, "fp32", TOL_FP32),
+                                        (100, "bf16", TOL_BF16), (1280, "bf16", TOL_BF16), (20000, "bf16", TOL_BF16)])
+def test_timemlps_train_mode_dropout_matches_philox_restatement(B, prec, tol):
     """Train mode with p = 0.1: the keep decisions of every Dropout module come from the oracle's restatement of the epilogue's Philox
     draw (site = block index); a torch fp32 restatement of model.py:74-88 with those masks gives the output, the input gradient and
     every parameter gradient.  Ragged batch sizes exercise every tiling (64-, 128- and 256-sample padding)."""
     D, H, nb = 63, 1024, 2
-    m = _make_mlp(D, H, nb, "swish", 41, "fp32", dropout=0.1)
+    m = _make_mlp(D, H, nb, "swish", 41, prec, dropout=0.1)
     m.train()
     rs = np.random.RandomState(B)
     x = _dev(rs.standard_normal((B, D))).requires_grad_(True)
@@ -1655,10 +1656,10 @@ def test_timemlps_train_mode_dropout_matches_philox_restatement(B):
     yr = h @ wr[-2].T + wr[-1]
     (yr * c.double()).sum().backward()
     assert all(0.85 < k < 0.95 for k in kept) or B < 16
-    assert rel_err(t2n(y), t2n(yr)) < TOL_FP32
-    assert rel_err(t2n(x.grad), t2n(xr.grad)) < 2 * TOL_FP32
+    assert rel_err(t2n(y), t2n(yr)) < tol
+    assert rel_err(t2n(x.grad), t2n(xr.grad)) < 2 * tol
     for p, r in zip(m.parameters(), wr):
-        assert rel_err(t2n(p.grad), t2n(r.grad)) < 3 * TOL_FP32
+        assert rel_err(t2n(p.grad), t2n(r.grad)) < 3 * tol
     # a second forward draws from the next step's counters; eval mode draws nothing
     y2 = m(x.detach(), t)
     assert not torch.equal(y2, y.detach())
