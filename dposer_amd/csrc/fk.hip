@@ -608,6 +608,8 @@ struct BodyTuning {
     bool fk_dma = true;                   // DPOSER_FK_DMA=0: joints-only body query through k_fk_joints instead of k_fk_joints_dma (A/B)
     int lbs_bwd_panel_order = 1;          // DPOSER_LBS_BWD_PANEL_ORDER=0: generic block -> tile order for the blend-gradient GEMMs (A/B)
     bool lbs_k_prefix = true;             // DPOSER_LBS_K_PREFIX=0: blend GEMMs over all padded pose-feature columns, posed or not (A/B)
+    int skin_bwd_mfma = 1;                // DPOSER_SKIN_BWD_MFMA=0: the LDS-walking one-pass kernel (k_skin_bwd_fused) instead of the one whose joint reduction runs
+                                          // on the matrix pipe (k_skin_bwd_mfma); 4 / 8: poses per workgroup of the latter (default 4)
     int64_t lbs_fwd_chunk = 0;            // DPOSER_LBS_FWD_CHUNK=n (multiple of 256): the full forward runs blend GEMM and skinning in chunks of n poses, the
                                           // skinning of chunk i on a side stream beside the GEMM of chunk i + 1 (0: one launch each over the whole batch)
     void load() {
@@ -629,6 +631,8 @@ struct BodyTuning {
         lbs_k_prefix = !(e && e[0] == '0');
         e = getenv("DPOSER_LBS_BWD_PANEL_ORDER");
         lbs_bwd_panel_order = (e && e[0] == '0') ? 0 : 1;
+        e = getenv("DPOSER_SKIN_BWD_MFMA");
+        skin_bwd_mfma = e ? atoi(e) : 1;
         e = getenv("DPOSER_LBS_FWD_CHUNK");
         lbs_fwd_chunk = e ? atoll(e) / 256 * 256 : (int64_t)0;
     }
@@ -743,6 +747,10 @@ struct dposer_body_s {
     int32_t* jl_seg = nullptr;       // device [chunks][128] x int2 (begin, end) relative to the chunk's first entry
     int32_t* jl_nseg = nullptr;      // device [chunks]
     int32_t* jl_jseg = nullptr;      // device [chunks][J] (first segment | count << 16) of joint j in chunk c
+    // k_skin_bwd_mfma's table (same setup call): the skinning weights of every 256-vertex chunk as a dense [64 joints][256 vertices] matrix,
+    // bf16 hi / lo planes, in the lane order of the MFMA A operand (64 KB per chunk; J <= 64, regular chunks)
+    bool jl_mfma_ok = false;
+    void* jl_wfrag = nullptr;
     // chunked forward: the skinning of chunk i runs on this stream beside the blend GEMM of chunk i + 1 (created on first use)
     hipStream_t side = nullptr;
     hipEvent_t ev_chunk[2] = {nullptr, nullptr}, ev_join = nullptr;
@@ -775,7 +783,7 @@ extern "C" int dposer_body_create(const dposer_body_desc* desc, const int32_t* p
 extern "C" void dposer_body_destroy(dposer_body_t h) {
     if (!h) return;
     (void)hipFree(h->jl_vstart); (void)hipFree(h->jl_ptr); (void)hipFree(h->jl_first); (void)hipFree(h->jl_entry);
-    (void)hipFree(h->jl_seg); (void)hipFree(h->jl_nseg); (void)hipFree(h->jl_jseg);
+    (void)hipFree(h->jl_seg); (void)hipFree(h->jl_nseg); (void)hipFree(h->jl_jseg); (void)hipFree(h->jl_wfrag);
     if (h->side) (void)hipStreamDestroy(h->side);
     for (hipEvent_t e : {h->ev_chunk[0], h->ev_chunk[1], h->ev_join})
         if (e) (void)hipEventDestroy(e);
@@ -2017,6 +2025,257 @@ __global__ void __launch_bounds__(256) k_skin_bwd_fused(SkinBwdFusedArgs a) {
         for (int r = 0; r < 3; ++r) a.dA[(b * a.J + jq) * 12 + 4 * r + q] = tot[r];
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Skinning backward with the joint reduction on the MATRIX PIPE (round 5).  k_skin_bwd_fused is LDS-bound: every one of a chunk's
+// ~1024 (vertex, joint) list entries costs four 16-byte LDS reads (65 KB per pose and chunk, a third of them bank conflicts).  The
+// reduction  dA[j][4 r + q] = sum_v W[v][j] * (dv_r [p ; 1]_q)  is a GEMM with a sparse factor -- D [64 joints][12] = W^T [64][256] P [256][12] per
+// pose and chunk -- and small enough for the dense form: 8 k-steps x 4 joint tiles of v_mfma_f32_16x16x32_bf16, three products per term
+// (bf16 hi / lo planes of both factors, fp32 accumulate: the arithmetic of the blend GEMMs).  A workgroup owns G consecutive poses and
+// walks the chunks; wave w reduces the chunk's vertices [64 w, 64 w + 64) for all 64 joints: its slice of W^T -- 16 fragments, prepared in
+// lane order by dposer_lbs_prepare_joint_lists -- is loaded from L2 once per chunk and serves the G poses from registers; P is formed
+// once per vertex by the vertex's thread (as before), leaves as 24 two-byte LDS writes and is read back ONCE (four 16-byte reads per
+// lane).  The running dA of every pose stays in accumulator registers over the whole walk; the four waves' partial sums meet in LDS at
+// the end.  One barrier per pose and chunk (P and the d v_posed stage are double-buffered).  Deterministic; differs from
+// k_skin_bwd_fused by the rounding of the split products (~1e-6 relative).
+// ------------------------------------------------------------------------------------------------
+constexpr int SBM_PSTRIDE = 72;                  // bf16 per row of a wave's P plane: 64 vertices + 8 (144 B: the 16 rows of a fragment read land 4 banks apart)
+constexpr int SBM_PLANE = 16 * SBM_PSTRIDE;      // 12 product rows + 4 zero rows
+struct SkinBwdMfmaArgs {
+    VertGrad vg;
+    const float* dverts;       // [B][V][3]
+    const float* offsets;      // [B][ld_off]
+    int64_t ld_off;
+    const float* v_shaped;
+    int v_shaped_batched;
+    const float* A;            // [B][J][12]
+    const int32_t* skin_idx;   // [V][4]
+    const float* skin_w;       // [V][4]
+    int J, V;
+    float* dvp;                // [B][V][3] or null
+    __bf16* doff_hi;           // FT bf16 [Bpad][Cpad]
+    __bf16* doff_lo;
+    int Cpad;
+    const bf16x8* wfrag;       // [chunks][4 waves][4 joint tiles][2 k-steps][hi | lo][64 lanes]
+    float* dA;                 // [B][J][12]
+    int chunks;
+    int64_t B;
+};
+template <int G, bool VSB> __global__ void __launch_bounds__(256, 2) k_skin_bwd_mfma(SkinBwdMfmaArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[G][64 * 12];
+    __shared__ __attribute__((aligned(16))) __bf16 sP[4][2][SBM_PLANE];     // [wave][hi | lo][product row][the wave's 64 vertices]
+    __shared__ __attribute__((aligned(16))) float stage[4][G][192];         // [wave][pose]: g = d loss / d v_posed of the wave's vertices, coordinate-major
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * G;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int64_t b = b0 + g < a.B ? b0 + g : b0;
+        for (int i = tid; i < a.J * 12; i += 256) sA[g][i] = a.A[b * a.J * 12 + i];
+    }
+    for (int i = tid; i < 4 * 2 * SBM_PLANE / 8; i += 256) reinterpret_cast<u32x4*>(&sP[0][0][0])[i] = u32x4{0u, 0u, 0u, 0u};      // (rows 12 ... 15 stay zero)
+    f32x4 acc[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[g][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // per-vertex data of (pose, chunk): dv and the rest + pose-blend position of this thread's vertex, loaded a whole chunk ahead (the
+    // set of pose g is refilled for chunk c + 1 as soon as (g, c) has consumed it: G iterations of lead -- with one iteration of lead
+    // every pose and chunk waited for a full HBM round trip, 70 % of the wave cycles)
+    float dvn[G][3], ofn[G][3], vsn[VSB ? G : 1][3];
+    // slot of this thread's vertex in the corrected-row array (extra joints / landmarks folded in: VertGrad), for the chunk whose pose data
+    // is being prefetched: the lookup is pose-independent and runs TWO chunks ahead -- as part of every pose's load (vg.row) it put a
+    // dependent load in front of every dv load and a full vmcnt(0) drain into every iteration
+    int slot_pf = -1, slot_nn = -1;              // of chunk c + 1 (used by the prefetches issued during chunk c) / of chunk c + 2
+    float vs_pf[3] = {0.f, 0.f, 0.f}, vs_nn[3] = {0.f, 0.f, 0.f};      // rest-shape position of the vertex, same schedule (unless it is per pose)
+    // (every load below is unconditional and its address a select: a branch around a load makes hipcc wait for it at the join -- the
+    //  first version's `vslot ? row() : ...` and `v_shaped_batched ? ... : ...` drained the whole prefetch queue in every iteration)
+    const int32_t* vslot = a.vg.vslot ? a.vg.vslot : a.skin_idx;          // (no fold: any readable table, the value is ignored)
+    const bool has_fold = a.vg.vslot != nullptr;
+    const float* fixed = has_fold ? a.vg.fixed : a.dverts;
+    auto load_slot = [&](int c) __attribute__((always_inline)) {
+        const int v = c * 256 + tid;
+        const int vc = v < a.V ? v : a.V - 1;
+        const int sl = vslot[vc];
+        slot_nn = has_fold ? sl : -1;
+        if constexpr (!VSB) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vs_nn[k] = a.v_shaped[(int64_t)vc * 3 + k];
+        }
+    };
+    auto load_pose = [&](int c, int g) __attribute__((always_inline)) {
+        const int v = c * 256 + tid;
+        const int vc = v < a.V ? v : a.V - 1;
+        const int64_t b = b0 + g < a.B ? b0 + g : b0;
+        const float* plain = a.dverts + (b * a.V + vc) * 3;
+        const float* corr = fixed + (b * a.vg.U + (slot_pf >= 0 ? slot_pf : 0)) * 3;
+        const float* dvr = slot_pf >= 0 ? corr : plain;
+        const float* off = a.offsets + b * a.ld_off + (int64_t)vc * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dvn[g][k] = dvr[k]; ofn[g][k] = off[k]; }
+        if constexpr (VSB) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vsn[g][k] = a.v_shaped[(b * a.V + vc) * 3 + k];
+        }
+    };
+    f32x4 w4n;
+    int4 j4n;
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
+        const int v = c * 256 + tid;
+        const int vc = v < a.V ? v : a.V - 1;
+        w4n = *reinterpret_cast<const f32x4*>(a.skin_w + (int64_t)vc * 4);
+        j4n = *reinterpret_cast<const int4*>(a.skin_idx + (int64_t)vc * 4);
+    };
+    load_chunk(0);
+    load_slot(0);
+    slot_pf = slot_nn;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vs_pf[k] = vs_nn[k];
+#pragma unroll
+    for (int g = 0; g < G; ++g) load_pose(0, g);
+    load_slot(a.chunks > 1 ? 1 : 0);
+    __syncthreads();
+    __bf16* myP = &sP[wave][0][0];
+    // A wave reduces the vertices its OWN threads own (64 wave ... 64 wave + 63 of the chunk): P goes through the wave's private LDS
+    // rows only to be transposed (thread = vertex -> lane = 8 consecutive vertices of one product row), LDS operations of one wave
+    // execute in order, and so the walk over poses and chunks needs NO barrier (the first version's barrier per pose and chunk left
+    // the eight resident waves of a CU parked 58 % of their cycles).
+    for (int c = 0; c < a.chunks; ++c) {
+        const int v0 = c * 256, v = v0 + tid;
+        const bool live = v < a.V;
+        const f32x4 w4 = w4n;
+        const int jj[4] = {j4n.x, j4n.y, j4n.z, j4n.w};
+        // this wave's slice of the chunk's dense skinning weights: joints x its 64 vertices, hi and lo planes
+        bf16x8 wf[4][2][2];
+        {
+            const bf16x8* wp = a.wfrag + ((int64_t)(c * 4 + wave) * 16) * 64 + lane;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) wf[mt][kk][p] = wp[((mt * 2 + kk) * 2 + p) * 64];
+        }
+        const int cn = c + 1 < a.chunks ? c + 1 : c;                         // (the last chunk prefetches itself again: no branch around a load)
+        load_chunk(cn);
+        const float vs_cur[3] = {vs_pf[0], vs_pf[1], vs_pf[2]};              // the current chunk's rest positions
+        slot_pf = slot_nn;                                                   // chunk c + 1's (loaded during chunk c - 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vs_pf[k] = vs_nn[k];
+        load_slot(c + 2 < a.chunks ? c + 2 : a.chunks - 1);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const bool bv = b0 + g < a.B;
+            const float dx = (live && bv) ? dvn[g][0] : 0.f, dy = (live && bv) ? dvn[g][1] : 0.f, dz = (live && bv) ? dvn[g][2] : 0.f;
+            const float hv[4] = {ofn[g][0] + (VSB ? vsn[VSB ? g : 0][0] : vs_cur[0]), ofn[g][1] + (VSB ? vsn[VSB ? g : 0][1] : vs_cur[1]),
+                                 ofn[g][2] + (VSB ? vsn[VSB ? g : 0][2] : vs_cur[2]), 1.0f};
+            load_pose(cn, g);
+            // ---- A: thread = vertex
+            {
+                float T[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) T[i] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4* Aj = reinterpret_cast<const f32x4*>(&sA[g][0]) + jj[k] * 3;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const f32x4 row = Aj[r];
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) T[3 * r + cc] += w4[k] * row[cc];
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) stage[wave][g][lane * 3 + cc] = T[cc] * dx + T[3 + cc] * dy + T[6 + cc] * dz;      // T_R^T dv
+                const float d3[3] = {dx, dy, dz};
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const float pv = d3[r] * hv[qq];
+                        const __bf16 ph = (__bf16)pv;
+                        myP[(4 * r + qq) * SBM_PSTRIDE + lane] = ph;
+                        myP[SBM_PLANE + (4 * r + qq) * SBM_PSTRIDE + lane] = (__bf16)(pv - (float)ph);
+                    }
+            }
+            // ---- B: joint reduction of the wave's 64 vertices on the matrix pipe
+            {
+                bf16x8 pf[2][2];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        pf[kk][p] = *reinterpret_cast<const bf16x8*>(myP + p * SBM_PLANE + (lane & 15) * SBM_PSTRIDE + 32 * kk + 8 * (lane >> 4));
+                // (the four joint tiles are independent accumulators: innermost, so that no MFMA waits for its predecessor)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[g][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mt][kk][0], pf[kk][0], acc[g][mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[g][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mt][kk][1], pf[kk][0], acc[g][mt], 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[g][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mt][kk][0], pf[kk][1], acc[g][mt], 0, 0, 0);
+                }
+            }
+        }
+        // ---- outputs of the wave's vertices, all G poses at once: the G poses of a workgroup are consecutive rows of the FT operand,
+        // i.e. 16 G contiguous bytes per group of 8 coordinates (pose by pose the same bytes left as G separate 16-byte stores: the
+        // counters read 1037 MB written for 516 MB of operand)
+        {
+            const int vw = v0 + 64 * wave;                                  // first vertex of the wave
+            const int nval = (a.V - vw < 64 ? (a.V - vw < 0 ? 0 : a.V - vw) : 64) * 3;
+            for (int i = lane; i < 24 * G; i += 64) {
+                const int g = i % G, grp = i / G;
+                const int64_t b = b0 + g;
+                const int k8 = vw * 3 + grp * 8;
+                if (b < a.B && k8 < a.Cpad) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(&stage[wave][g][grp * 8]), x1 = *reinterpret_cast<const f32x4*>(&stage[wave][g][grp * 8 + 4]);
+                    __bf16 hi[8], lo[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (grp * 8 + e < nval) ? (e < 4 ? x0[e] : x1[e - 4]) : 0.f;
+                        hi[e] = (__bf16)x;
+                        lo[e] = (__bf16)(x - (float)hi[e]);
+                    }
+                    *reinterpret_cast<u32x4*>(a.doff_hi + FT<__bf16>::index(b, k8, a.Cpad)) = *reinterpret_cast<u32x4*>(hi);
+                    *reinterpret_cast<u32x4*>(a.doff_lo + FT<__bf16>::index(b, k8, a.Cpad)) = *reinterpret_cast<u32x4*>(lo);
+                }
+            }
+            if (a.dvp) {
+                for (int i = lane; i < nval * G; i += 64) {
+                    const int g = i / nval, k = i % nval;
+                    if (b0 + g < a.B) a.dvp[((b0 + g) * a.V + vw) * 3 + k] = stage[wave][g][k];
+                }
+            }
+        }
+    }
+    // the four waves' partial sums (vertex quarters of every chunk), added in wave order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&sP[0][0][0]);                   // 16 KB of the planes' 33 KB
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *reinterpret_cast<f32x4*>(red + ((wave * 4 + mt) * 64 + lane) * 4) = acc[g][mt];
+        __syncthreads();
+        {
+            const int mt = tid >> 6;
+            f32x4 s = *reinterpret_cast<const f32x4*>(red + ((0 * 4 + mt) * 64 + lane) * 4);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(red + ((w * 4 + mt) * 64 + lane) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += t[i];
+            }
+            const int64_t b = b0 + g;
+            const int n = lane & 15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = 16 * mt + (lane >> 4) * 4 + i;                // C / D layout of the 16x16 MFMAs: column = lane & 15, row = 4 (lane >> 4) + register
+                if (b < a.B && j < a.J && n < 12) a.dA[(b * a.J + j) * 12 + n] = s[i];
+            }
+        }
+        __syncthreads();
+    }
+}
 static int64_t lbs_joint_stream_min() { return body_tuning().joint_stream_min; }
 // dposer_lbs_prepare_joint_lists: (host) cut the CSR-by-joint lists (vertex ids ascending inside a joint) into chunks of
 // <= JL_MAXV vertices and <= JL_MAXE entries, sorted by joint inside a chunk -- the table the streaming joint-gradient kernel
@@ -2125,6 +2384,43 @@ extern "C" int dposer_lbs_prepare_joint_lists(dposer_body_t h, const int32_t* jp
             DP_CHECK_HIP(hipMemcpy(h->jl_nseg, nseg.data(), nseg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             DP_CHECK_HIP(hipMemcpy(h->jl_jseg, jseg.data(), jseg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             h->jl_fused_ok = true;
+        }
+    }
+    // dense weight chunks of k_skin_bwd_mfma: W^T[c][joint][local vertex] (entries of one (vertex, joint) pair summed), split hi / lo,
+    // stored in the lane order of the MFMA A operand: [chunk][wave = vertex quarter][joint tile][k-step][plane][lane][8 vertices]
+    (void)hipFree(h->jl_wfrag);
+    h->jl_wfrag = nullptr;
+    h->jl_mfma_ok = false;
+    {
+        bool regular = J <= 64 && chunks >= 1;
+        for (int c = 0; c < chunks && regular; ++c) regular = vstart[c] == c * 256;
+        if (regular) {
+            std::vector<float> dense((size_t)chunks * 64 * 256, 0.f);
+            for (int j = 0; j < J; ++j)
+                for (int e = jptr[j]; e < jptr[j + 1]; ++e) dense[((size_t)(jv[e] >> 8) * 64 + j) * 256 + (jv[e] & 255)] += jw[e];
+            std::vector<uint16_t> frag((size_t)chunks * 4 * 16 * 64 * 8);
+            auto bf16_bits = [](float x) {                       // round to nearest even, as the device's float -> __bf16 conversion
+                uint32_t u;
+                std::memcpy(&u, &x, 4);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                return (uint16_t)(u >> 16);
+            };
+            auto bf16_val = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
+            for (int c = 0; c < chunks; ++c)
+                for (int w = 0; w < 4; ++w)
+                    for (int mt = 0; mt < 4; ++mt)
+                        for (int kk = 0; kk < 2; ++kk)
+                            for (int l = 0; l < 64; ++l)
+                                for (int e = 0; e < 8; ++e) {
+                                    const float x = dense[((size_t)c * 64 + 16 * mt + (l & 15)) * 256 + 64 * w + 32 * kk + 8 * (l >> 4) + e];
+                                    const uint16_t hi = bf16_bits(x), lo = bf16_bits(x - bf16_val(hi));
+                                    const size_t base = ((((size_t)(c * 4 + w) * 4 + mt) * 2 + kk) * 2) * 64;
+                                    frag[((base + l) * 8) + e] = hi;
+                                    frag[((base + 64 + l) * 8) + e] = lo;
+                                }
+            DP_CHECK_HIP(hipMalloc(&h->jl_wfrag, frag.size() * sizeof(uint16_t)));
+            DP_CHECK_HIP(hipMemcpy(h->jl_wfrag, frag.data(), frag.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            h->jl_mfma_ok = true;
         }
     }
     h->jl_ready = true;
@@ -2522,7 +2818,22 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
     } else {
         DP_CHECK_HIP(hipMemsetAsync(doff, 0, Bpad * Cpad * 4, st));
     }
-    if (fused) {
+    const int mfma_g = body_tuning().skin_bwd_mfma;
+    if (fused && mfma_g != 0 && h->jl_mfma_ok) {
+        SkinBwdMfmaArgs a;
+        a.vg = vg;
+        a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
+        a.skin_idx = skin_idx; a.skin_w = skin_w; a.J = J; a.V = V; a.dvp = d_vposed; a.doff_hi = doff_hi; a.doff_lo = doff_lo; a.Cpad = (int)Cpad;
+        a.wfrag = reinterpret_cast<const bf16x8*>(h->jl_wfrag); a.dA = dA; a.chunks = h->jl_chunks; a.B = batch;
+        if (mfma_g == 2) {
+            if (v_shaped_batched) hipLaunchKernelGGL((k_skin_bwd_mfma<2, true>), dim3((unsigned)ceil_div(batch, 2)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_skin_bwd_mfma<2, false>), dim3((unsigned)ceil_div(batch, 2)), dim3(256), 0, st, a);
+        } else {
+            if (v_shaped_batched) hipLaunchKernelGGL((k_skin_bwd_mfma<4, true>), dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_skin_bwd_mfma<4, false>), dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, st, a);
+        }
+        FK_HIP_LAUNCH(hipGetLastError());
+    } else if (fused) {
         SkinBwdFusedArgs a;
         a.vg = vg;
         a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
