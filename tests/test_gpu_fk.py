@@ -383,9 +383,9 @@ def test_joint_gradient_kernels_agree(bm, monkeypatch):
 
 
 def test_fused_skinning_backward_agrees_with_the_two_kernel_path(bm, monkeypatch):
-    """k_skin_bwd_fused (one streaming pass per pose: d_verts read once, v_posed never in HBM, joint lists in balanced segments, poses
-    mapped to blocks in groups of four per XCD) against k_skin_bwd + k_skin_bwd_joints: same terms, another summation order inside a
-    chunk.  B = 70: the first 64 poses go through the permuted block -> pose map, the rest through the identity tail; betas require a
+    """The one-pass skinning-backward kernels -- k_skin_bwd_mfma (default: the joint reduction as dense 16x16x32 MFMAs on bf16 hi / lo
+    planes, a workgroup per four poses) and k_skin_bwd_fused (one streaming pass per pose: d_verts read once, v_posed never in HBM, joint
+    lists in balanced segments) -- against k_skin_bwd + k_skin_bwd_joints: same terms, other summation orders.  B = 70: the first 64 poses go through the permuted block -> pose map, the rest through the identity tail; betas require a
     gradient, so d v_posed is written too."""
     B = 70
     rs = np.random.RandomState(12)
@@ -402,18 +402,25 @@ def test_fused_skinning_backward_agrees_with_the_two_kernel_path(bm, monkeypatch
         ((out.v * wv).sum() + (out.Jtr ** 2).sum()).backward()
         return t2n(p.grad), t2n(b.grad)
 
-    fused = run()
+    mfma = run()                                       # default: k_skin_bwd_mfma (joint reduction on the matrix pipe, four poses per workgroup)
+    monkeypatch.setenv("DPOSER_SKIN_BWD_MFMA", "2")
+    mfma2 = run()                                      # ... two poses per workgroup
+    monkeypatch.setenv("DPOSER_SKIN_BWD_MFMA", "0")
+    fused = run()                                      # k_skin_bwd_fused (joint lists walked through LDS)
     monkeypatch.setenv("DPOSER_SKIN_BWD_FUSED", "0")
     two = run()
     monkeypatch.delenv("DPOSER_SKIN_BWD_FUSED")
+    monkeypatch.delenv("DPOSER_SKIN_BWD_MFMA")
     monkeypatch.delenv("DPOSER_LBS_JOINT_STREAM_MIN")
     _reload_tuning()
-    for name, a, b in (("d pose", fused[0], two[0]), ("d betas", fused[1], two[1])):
-        err = np.linalg.norm(a - b) / np.linalg.norm(b)
-        _log_measured(f"fused skinning backward vs two kernels, {name}", err)
-        assert err < 1e-5, (name, err)                 # measured 2e-7 / 1e-7
-        assert np.isfinite(a).all()
-    assert not np.array_equal(fused[0], two[0])        # (it really is the other kernel)
+    for tag, got in (("mfma", mfma), ("mfma, 2 poses", mfma2), ("fused", fused)):
+        for name, a, b in (("d pose", got[0], two[0]), ("d betas", got[1], two[1])):
+            err = np.linalg.norm(a - b) / np.linalg.norm(b)
+            _log_measured(f"{tag} skinning backward vs two kernels, {name}", err)
+            assert err < 1e-5, (tag, name, err)        # measured: fused 2e-7 / 1e-7, mfma 3e-6 (bf16 hi / lo split products)
+            assert np.isfinite(a).all()
+    assert not np.array_equal(fused[0], two[0]) and not np.array_equal(mfma[0], fused[0])        # (they really are other kernels)
+    assert np.array_equal(mfma[0], mfma2[0]) and np.array_equal(mfma[1], mfma2[1])               # the workgroup's pose count changes no sum
 
 
 @pytest.mark.parametrize("stream_min", ["1", None])       # the fused streaming kernel forced onto the small batch / the small-batch kernels
