@@ -610,6 +610,8 @@ struct BodyTuning {
     bool lbs_k_prefix = true;             // DPOSER_LBS_K_PREFIX=0: blend GEMMs over all padded pose-feature columns, posed or not (A/B)
     int skin_bwd_mfma = 1;                // DPOSER_SKIN_BWD_MFMA=0: the LDS-walking one-pass kernel (k_skin_bwd_fused) instead of the one whose joint reduction runs
                                           // on the matrix pipe (k_skin_bwd_mfma); 4 / 8: poses per workgroup of the latter (default 4)
+    bool lbs_bwd_terms_parallel = true;   // DPOSER_LBS_BWD_TERMS_PARALLEL=0: the three product terms of the bf16 x 3 blend-gradient GEMM one after the other on the
+                                          // caller's stream (A/B) instead of side by side on three streams
     int64_t lbs_fwd_chunk = 0;            // DPOSER_LBS_FWD_CHUNK=n (multiple of 256): the full forward runs blend GEMM and skinning in chunks of n poses, the
                                           // skinning of chunk i on a side stream beside the GEMM of chunk i + 1 (0: one launch each over the whole batch)
     void load() {
@@ -633,6 +635,8 @@ struct BodyTuning {
         lbs_bwd_panel_order = (e && e[0] == '0') ? 0 : 1;
         e = getenv("DPOSER_SKIN_BWD_MFMA");
         skin_bwd_mfma = e ? atoi(e) : 1;
+        e = getenv("DPOSER_LBS_BWD_TERMS_PARALLEL");
+        lbs_bwd_terms_parallel = !(e && e[0] == '0');
         e = getenv("DPOSER_LBS_FWD_CHUNK");
         lbs_fwd_chunk = e ? atoll(e) / 256 * 256 : (int64_t)0;
     }
@@ -754,6 +758,9 @@ struct dposer_body_s {
     // chunked forward: the skinning of chunk i runs on this stream beside the blend GEMM of chunk i + 1 (created on first use)
     hipStream_t side = nullptr;
     hipEvent_t ev_chunk[2] = {nullptr, nullptr}, ev_join = nullptr;
+    // backward: the three product terms of the bf16 x 3 blend-gradient GEMM run side by side on the caller's stream and these two
+    hipStream_t bwd_side[2] = {nullptr, nullptr};
+    hipEvent_t ev_bwd_fork = nullptr, ev_bwd_join[2] = {nullptr, nullptr};
 };
 
 template <typename Kin> static bool same_tree(const int32_t* p, int n) {
@@ -785,7 +792,9 @@ extern "C" void dposer_body_destroy(dposer_body_t h) {
     (void)hipFree(h->jl_vstart); (void)hipFree(h->jl_ptr); (void)hipFree(h->jl_first); (void)hipFree(h->jl_entry);
     (void)hipFree(h->jl_seg); (void)hipFree(h->jl_nseg); (void)hipFree(h->jl_jseg); (void)hipFree(h->jl_wfrag);
     if (h->side) (void)hipStreamDestroy(h->side);
-    for (hipEvent_t e : {h->ev_chunk[0], h->ev_chunk[1], h->ev_join})
+    for (hipStream_t q : {h->bwd_side[0], h->bwd_side[1]})
+        if (q) (void)hipStreamDestroy(q);
+    for (hipEvent_t e : {h->ev_chunk[0], h->ev_chunk[1], h->ev_join, h->ev_bwd_fork, h->ev_bwd_join[0], h->ev_bwd_join[1]})
         if (e) (void)hipEventDestroy(e);
     delete h;
 }
@@ -2717,9 +2726,9 @@ static int lbs_bwd_ksplit_bf16(int64_t kblocks, int64_t tiles, int max_split = 2
 }
 // 256x256 tiles for the bf16 backward blend GEMMs from 2048 poses up (one 256-CU round of long-K workgroups: 3 x 110 us instead of
 // 3 x 161 us with the 128x128 tiles at 4096 poses): the split count that fills the last round best, at most 8 (24 slabs); 0 = not applicable
-static int lbs_bwd_big_ksplit(int64_t Bpad, int64_t prow, int64_t kblocks, int max_split = 8) {
+static int lbs_bwd_big_ksplit(int64_t Bpad, int64_t prow, int64_t kblocks, int max_split = 8, int concurrent = 1) {
     if (!body_tuning().lbs_bwd_big || Bpad % 256 != 0 || prow % 256 != 0 || Bpad < 2048) return 0;
-    const int64_t tiles = (Bpad / 256) * (prow / 256);
+    const int64_t tiles = (Bpad / 256) * (prow / 256) * concurrent;      // (launches that share the chip count as one grid)
     int best = 0;
     double best_u = 0.0;
     for (int c = 1; c <= max_split; ++c) {
@@ -2894,7 +2903,11 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
         int64_t pe_big = round_up(want_cols < 1 ? 1 : want_cols, 256);
         pe_big = pe_big > prow ? prow : pe_big;
         const int max_split = (int)(slab_budget / (3 * Bpad * pe_big) < 16 ? slab_budget / (3 * Bpad * pe_big) : 16);
-        const int kbig = lbs_bwd_big_ksplit(Bpad, pe_big, kb, max_split < 1 ? 1 : max_split);
+        // The three terms are independent launches of (tiles x splits) workgroups each.  One after the other they left half the chip idle
+        // at 4096 poses (16 tiles x 8 splits = 128 workgroups per launch, 3 x 109 us); side by side on three streams they share it:
+        // the split count is then chosen for the three launches TOGETHER (3 x 16 x 4 = 192 workgroups of twice the K range).
+        const bool par = body_tuning().lbs_bwd_terms_parallel;
+        const int kbig = lbs_bwd_big_ksplit(Bpad, pe_big, kb, max_split < 1 ? 1 : max_split, par ? 3 : 1);
         if (kbig) pe = pe_big;
         else {
             pe = round_up(want_cols < 1 ? 1 : want_cols, 128);
@@ -2905,7 +2918,17 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
         //  only whole-stage splits are valid, so the bound goes INTO the search)
         const int64_t fit = slab_budget / (3 * Bpad * pe);
         const int k1 = kbig ? kbig : lbs_bwd_ksplit_bf16(kb, (Bpad / 128) * (pe / 128), (int)(fit < 1 ? 1 : (fit > 24 ? 24 : fit)));
+        const bool fork = par && kbig;
+        if (fork) {
+            if (!h->bwd_side[0]) {
+                for (hipStream_t* q : {&h->bwd_side[0], &h->bwd_side[1]}) DP_CHECK_HIP(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
+                for (hipEvent_t* e : {&h->ev_bwd_fork, &h->ev_bwd_join[0], &h->ev_bwd_join[1]}) DP_CHECK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            }
+            DP_CHECK_HIP(hipEventRecord(h->ev_bwd_fork, st));
+            for (int i = 0; i < 2; ++i) DP_CHECK_HIP(hipStreamWaitEvent(h->bwd_side[i], h->ev_bwd_fork, 0));
+        }
         for (int term = 0; term < 3; ++term) {
+            hipStream_t ts = (fork && term > 0) ? h->bwd_side[term - 1] : st;
             GemmArgs g;
             std::memset(&g, 0, sizeof(g));
             g.W = term == 2 ? (const void*)doff_lo : (const void*)doff_hi; g.w_stride_blocks = kb;
@@ -2915,7 +2938,13 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
             WgradParams wp;
             wp.slab = dpf + (int64_t)term * k1 * Bpad * pe; wp.slab_stride = Bpad * pe; wp.ld = (int)pe; wp.N_valid = (int)batch;
             wp.K_valid = (int)((J - 1) * 9 < pe ? (J - 1) * 9 : pe);
-            FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, kbig ? SHAPE_BIG : SHAPE_MID, g, wp, st));
+            FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, kbig ? SHAPE_BIG : SHAPE_MID, g, wp, ts));
+        }
+        if (fork) {
+            for (int i = 0; i < 2; ++i) {
+                DP_CHECK_HIP(hipEventRecord(h->ev_bwd_join[i], h->bwd_side[i]));
+                DP_CHECK_HIP(hipStreamWaitEvent(st, h->ev_bwd_join[i], 0));
+            }
         }
         ks = 3 * k1;
     }
