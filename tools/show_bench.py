@@ -9,9 +9,15 @@ for f in sys.argv[1:]:
         print("   %-52s n=%4d %8.1f us %6.0f TF" % (k, v["launches"], v["avg_us"], v["tflops"]))
     ex = d.get("extra", {})
     if "sampler" in ex:
-        print("   sampler", ex["sampler"]["seconds"], "s", ex["sampler"]["dominant_kernel"])
+        r = ex["sampler"].get("roofline", {})
+        print("   sampler %.4f s  %s %.1f us  frac %.3f" % (ex["sampler"]["seconds"], r.get("kernel", "?"), r.get("avg_launch_us", 0.0), r.get("frac", 0.0)))
+    for k in ("train_step_bf16x3_mode", "train_step_fp32_mode"):
+        if k in ex:
+            print("   %-28s %.3f ms / step" % (k, ex[k]["ms_per_step"]))
+    if "sampler_bf16x3_mode" in ex:
+        print("   sampler_bf16x3_mode          %.3f s" % ex["sampler_bf16x3_mode"]["seconds_scaled_to_n_steps"])
     if "fk_joints" in ex:
-        print("   fk", ex["fk_joints"])
+        print("   fk_joints %.3f G poses/s  frac %.3f" % (ex["fk_joints"]["poses_per_s_per_gpu"] / 1e9, ex["fk_joints"]["roofline"]["frac"]))
     for k in ("lbs_full_fwd", "lbs_full_fwd_bwd"):
         if k in ex:
-            print("   " + k, ex[k])
+            print("   %-18s %.3f ms  runs %s" % (k, ex[k]["ms"], ex[k].get("runs_ms")))
