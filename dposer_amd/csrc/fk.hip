@@ -600,7 +600,7 @@ template <typename Kin> __device__ constexpr KinTable<Kin> kKinTable{};
 // them inside one process call dposer_body_tuning_reload() afterwards.
 struct BodyTuning {
     int64_t fk_small_max = 8192;          // DPOSER_FK_SMALL_MAX: up to this many poses FK runs one wave per pose / one lane per joint
-    int64_t joint_stream_min = 1536;      // DPOSER_LBS_JOINT_STREAM_MIN: from this batch the streaming joint-gradient kernel is used
+    int64_t joint_stream_min = 320;       // DPOSER_LBS_JOINT_STREAM_MIN: from this batch the one-pass streaming skinning backward is used (round 5: with k_skin_bwd_mfma it wins from 512 poses, ties at 256)
     bool blend_fp32 = false;              // DPOSER_LBS_BLEND=fp32: exact-fp32 pose-blend chain
     int skin_mode = 3;                    // DPOSER_SKIN_WAVE=0: one vertex per thread and iteration (k_skin); 2: four in flight, one pose per block (k_skin_x4); 3: runs of poses (k_skin_run)
     bool skin_bwd_fused = true;           // DPOSER_SKIN_BWD_FUSED=0: k_skin_bwd + k_skin_bwd_joints instead of the one-pass kernel (A/B)
@@ -618,7 +618,7 @@ struct BodyTuning {
         const char* e = getenv("DPOSER_FK_SMALL_MAX");
         fk_small_max = e ? atoll(e) : (int64_t)8192;
         e = getenv("DPOSER_LBS_JOINT_STREAM_MIN");
-        joint_stream_min = e ? atoll(e) : (int64_t)1536;
+        joint_stream_min = e ? atoll(e) : (int64_t)320;
         e = getenv("DPOSER_LBS_BLEND");
         blend_fp32 = e && e[0] == 'f';
         e = getenv("DPOSER_SKIN_WAVE");

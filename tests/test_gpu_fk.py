@@ -360,7 +360,7 @@ def test_small_batch_fk_kernels_return_the_bits_of_the_large_batch_ones(bm, asse
 
 
 def test_joint_gradient_kernels_agree(bm, monkeypatch):
-    """d loss / d (skinning transforms): the (pose, joint)-parallel gather kernel (batches below DPOSER_LBS_JOINT_STREAM_MIN = 1536
+    """d loss / d (skinning transforms): the (pose, joint)-parallel gather kernel (batches below DPOSER_LBS_JOINT_STREAM_MIN = 320
     poses) and the streaming per-pose kernel over chunk-major lists (above) sum the same terms in different orders."""
     B = 9
     pose = (np.random.RandomState(2).standard_normal((B, 63)) * 0.4).astype(np.float32)
