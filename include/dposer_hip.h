@@ -435,10 +435,13 @@ int dposer_lbs_forward_temporal_grad(dposer_body_t h, void* ws, const void* pose
  *   d_pose_segments_host[i]: DEVICE pointer [B, seg_joints*3] out or NULL;  d_jrest [B,J,3] out or NULL;
  *   d_vposed [B,V,3] out or NULL (= gradient w.r.t. v_shaped).
  *   dposer_lbs_prepare_joint_lists(h, joint_ptr, joint_vidx, joint_w, stream): SETUP call, once per set of lists (and again
- *   whenever their contents change): re-cuts the lists by vertex chunk for the streaming joint-gradient kernel and stores the
- *   table in the handle.  It synchronises the stream, copies the lists to the host and allocates -- dposer_lbs_backward itself
- *   does none of that (capturable in a hipGraph); without prepared lists it runs the (pose, joint)-parallel gather kernel, which
- *   is the right kernel below ~1536 poses anyway.
+ *   whenever their contents change): re-cuts the lists by vertex chunk for the one-pass skinning-backward kernels and stores the
+ *   tables in the handle -- among them the skinning weights of every 256-vertex chunk as a dense 64 x 256 matrix in bf16 hi / lo planes,
+ *   laid out as MFMA operand fragments (64 KB per chunk: the joint-transform reduction runs on the matrix pipe).  It synchronises the
+ *   stream, copies the lists to the host and allocates -- dposer_lbs_backward itself does none of that; without prepared lists it runs
+ *   the (pose, joint)-parallel gather kernel, which is the right kernel below ~320 poses anyway.  dposer_lbs_backward forks onto two
+ *   internal streams of the handle for the three product terms of its blend-gradient GEMM and joins them before it returns control
+ *   of `stream` (events only, no host synchronisation): one call at a time per handle.
  *   dposer_body_tuning_reload(): re-reads the A/B environment switches of the body-model kernels (DPOSER_FK_SMALL_MAX,
  *   DPOSER_LBS_JOINT_STREAM_MIN, DPOSER_LBS_BLEND); they are otherwise read once per process, not per call. */
 int dposer_lbs_prepare_joint_lists(dposer_body_t h, const int32_t* joint_ptr, const int32_t* joint_vidx, const float* joint_w, void* stream);
