@@ -382,6 +382,36 @@ def test_joint_gradient_kernels_agree(bm, monkeypatch):
     assert not np.array_equal(g_gather, g_stream)
 
 
+def test_blend_gradient_terms_side_by_side_equal_one_after_the_other(bm, monkeypatch):
+    """From 2048 poses the three product terms of the bf16 x 3 blend-gradient GEMM run side by side on three streams of the body handle,
+    with a split count chosen for the three launches together; DPOSER_LBS_BWD_TERMS_PARALLEL=0 runs them one after the other on the
+    caller's stream.  Same products, another number of split-K slabs: the pose gradient agrees to fp32 summation noise, the call leaves
+    the caller's stream joined (a second backward right behind the first reads finished buffers), and repeated calls are bit-identical."""
+    B = 2048
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    pose = (torch.randn(B, 63, device=DEV, generator=gen) * 0.3)
+    gv = torch.randn(B, 10475, 3, device=DEV, generator=gen) * 0.01
+    gj = torch.randn(B, 127, 3, device=DEV, generator=gen)
+
+    def run():
+        _reload_tuning()
+        p = pose.clone().requires_grad_(True)
+        out = bm(pose_body=p)
+        torch.autograd.backward([out.v, out.Jtr], [gv, gj])
+        return p.grad.clone()
+
+    par = run()
+    par2 = run()
+    monkeypatch.setenv("DPOSER_LBS_BWD_TERMS_PARALLEL", "0")
+    ser = run()
+    monkeypatch.delenv("DPOSER_LBS_BWD_TERMS_PARALLEL")
+    _reload_tuning()
+    assert torch.equal(par, par2)
+    err = float((par - ser).norm() / ser.norm())
+    _log_measured("blend-gradient terms on three streams vs one", err)
+    assert err < 1e-6 and bool(torch.isfinite(par).all())
+
+
 def test_fused_skinning_backward_agrees_with_the_two_kernel_path(bm, monkeypatch):
     """The one-pass skinning-backward kernels -- k_skin_bwd_mfma (default: the joint reduction as dense 16x16x32 MFMAs on bf16 hi / lo
     planes, a workgroup per four poses) and k_skin_bwd_fused (one streaming pass per pose: d_verts read once, v_posed never in HBM, joint
