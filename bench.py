@@ -335,6 +335,8 @@ def main():
             if wm:
                 roofline["worst"].update(wm)
         roofline["kernel_chosen_by"] = "largest total GEMM time in an untimed all-kinds pass of this run (2 steps, HIP events around every launch)"
+        roofline["peak_note"] = ("peak = the guide's dense bf16 figure at 2.4 GHz; under MFMA load this chip clocks 1.3-2.1 GHz (`clock_ghz`), and the K loop "
+                                 "of this kernel issues an MFMA every 33 cycles of a SIMD (the pipe's floor): profiles/r05_tile_phase_probe.txt")
         mf = pmc_mfma(name)
         if mf:
             roofline.update(mf)
