@@ -4,6 +4,7 @@ import ctypes
 import math
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -503,3 +504,18 @@ def test_capi_argument_paths_under_address_sanitizer():
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert "AddressSanitizer" not in r.stdout + r.stderr, (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_profile_summariser_names_the_precision_modes_apart():
+    """tools/rocpd_summary.py folds kernel names into `gemm_ft_kernel<precision,tile,epilogue>`: the bf16x3 instantiations (bf16 operand
+    planes under a fp32-storage epilogue) must not share a name with the bf16 ones -- the bench looks its `traffic` / MFMA counters up by
+    these names (a first round-5 pass averaged the two modes' launches together) -- and absent counters print as n/a, not as zero."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import rocpd_summary as rs
+    finally:
+        sys.path.pop(0)
+    assert rs.short("void gemm_ft_kernel<__bf16, 2, 4, 4, 2, 2, EpiGN<__bf16, true, -1, false>, 4>(GemmArgs, GNParams)") == "gemm_ft_kernel<bf16,256x256,EpiGN<train>>"
+    assert rs.short("void gemm_ft_kernel<__bf16, 2, 4, 4, 2, 2, EpiGN<float, true, -1, false>, 4>(GemmArgs, GNParams)") == "gemm_ft_kernel<bf16x3,256x256,EpiGN<train>>"
+    assert rs.short("void gemm_ft_kernel<float, 2, 4, 4, 2, 2, EpiGNBwd<float, 0, false>, 4>(GemmArgs, GNBwdParams)") == "gemm_ft_kernel<fp32,256x256,EpiGNBwd>"
+    assert rs.short("void gemm_ft_kernel<bool _Accum, int, E, 4, 2, 1, 2, EpiEmStep<float>, 4>(GemmArgs)") == "gemm_ft_kernel<bf16x3,64x128,EpiEmStep>"
