@@ -352,6 +352,9 @@ struct ScoreTuning {
     int64_t silu_split_max = 2048;    // DPOSER_SILU_SPLIT_MAX = <samples>: up to this padded batch the time-branch dgrad runs one k-split per layer + a reduce pass (0: never)
     int dsm_fused = 0;                // DPOSER_DSM_FUSED = 1: post_dense with the DSM loss in its epilogue (EpiDsm) instead of GEMM -> res -> k_dsm
                                       // (opt-in: measured -0.6 % at 8192 poses, -0.2 % at 65536, +0.5 % at 1280 -- profiles/r04_dsm_fused_ab.txt)
+    int64_t small_tile_max = 1280;    // DPOSER_SMALL_TILE_MAX = <samples>: up to this padded batch the GroupNorm layers take the 128x32 tiling also where 128x128
+                                      // divides the batch (1280 samples are 80 workgroups of 128x128 on 256 CUs).  Bit-identical; sampler step 61.3 -> 58.7 us at
+                                      // 500 samples, 63.3 -> 61.6 at 1280, training step -2 % at 512, unchanged at 1280, slower from 2048 (profiles/r05_small_tile_ab.txt)
     int sampler_persistent = 0;       // DPOSER_SAMPLER_PERSISTENT = 1: one persistent kernel for the plain EM sampler
     int64_t sampler_persistent_min = 256;
     void load() {
@@ -371,6 +374,8 @@ struct ScoreTuning {
         dsm_fused = env_tri("DPOSER_DSM_FUSED") == 1 ? 1 : 0;
         e = getenv("DPOSER_SILU_SPLIT_MAX");
         silu_split_max = e ? atoll(e) : (int64_t)2048;
+        e = getenv("DPOSER_SMALL_TILE_MAX");
+        small_tile_max = e ? atoll(e) : (int64_t)1280;
         e = getenv("DPOSER_SAMPLER_PERSISTENT");
         sampler_persistent = e ? atoi(e) : 0;
         e = getenv("DPOSER_SAMPLER_PERSISTENT_MIN");
@@ -388,6 +393,7 @@ static int64_t pad_batch(int64_t B) { return B <= 512 ? round_up(B, 64) : round_
 // needs them to be a multiple of 256 (embed_dim may be any multiple of 128).
 static thread_local int g_act = DPOSER_ACT_SWISH;   // activation of the handle whose call is running (the 256 x 256 tiling compiles swish in)
 static int main_shape(int64_t Spad, int channels = 1024, int gs = 32) {
+    if (Spad <= score_tuning().small_tile_max) return SHAPE_SMALL;
     if (g_act != DPOSER_ACT_SWISH) return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL;
     const int64_t big_min = score_tuning().big_min;
     if (gs == 32 && Spad % 256 == 0 && Spad >= big_min && channels % 256 == 0) return SHAPE_BIG;   // (generic group sizes: 128-wide tilings)
@@ -397,6 +403,7 @@ static int main_shape(int64_t Spad, int channels = 1024, int gs = 32) {
 // GroupNorm-backward dgrad: the register-lean epilogue fits the 256x256 tile in 248 VGPRs without spilling; it wins from
 // 32768 samples up (227 vs 257 us at 65536, 2.52 vs 2.59 ms per step at 32768, a tie at 16384).  DPOSER_GNBWD_BIG = 0 / 1 forces it.
 static int gnbwd_shape(int64_t Spad, int gs = 32) {
+    if (Spad <= score_tuning().small_tile_max) return SHAPE_SMALL;
     const int forced = score_tuning().gnbwd_big;
     const bool big = gs == 32 && g_act == DPOSER_ACT_SWISH && (forced >= 0 ? forced == 1 : Spad >= 32768);
     if (big && Spad % 256 == 0) return SHAPE_BIG;

@@ -93,7 +93,7 @@ int32_t dposer_scorefc_nograd_ranges(dposer_scorefc_t h, int64_t lo[2], int64_t 
 int64_t dposer_scorefc_packed_bytes(dposer_scorefc_t h, int32_t with_backward);
 int dposer_scorefc_pack(dposer_scorefc_t h, const float* flat_params, void* packed, int32_t with_backward, void* stream);
 /* Re-reads the A/B environment switches of the score path (DPOSER_BIG_MIN_BATCH, DPOSER_GNBWD_BIG, DPOSER_WGRAD_BIG, DPOSER_WGRAD_TR,
- * DPOSER_WGRAD_STREAM, DPOSER_WGRAD_BATCHED, DPOSER_WGRAD_LAYER_LANES, DPOSER_WGRAD_GROUPS, DPOSER_FINAL_SMALL_MAX,
+ * DPOSER_WGRAD_STREAM, DPOSER_WGRAD_BATCHED, DPOSER_SMALL_TILE_MAX, DPOSER_WGRAD_LAYER_LANES, DPOSER_WGRAD_GROUPS, DPOSER_FINAL_SMALL_MAX,
  * DPOSER_SAMPLER_PERSISTENT[_MIN], DPOSER_ADAM_WT, DPOSER_DSM_FUSED, DPOSER_SILU_SPLIT_MAX); they are otherwise read ONCE per
  * process (first use), never per call. */
 void dposer_scorefc_tuning_reload(void);
