@@ -401,11 +401,12 @@ static int main_shape(int64_t Spad, int channels = 1024, int gs = 32) {
     return SHAPE_SMALL;
 }
 // GroupNorm-backward dgrad: the register-lean epilogue fits the 256x256 tile in 248 VGPRs without spilling; it wins from
-// 32768 samples up (227 vs 257 us at 65536, 2.52 vs 2.59 ms per step at 32768, a tie at 16384).  DPOSER_GNBWD_BIG = 0 / 1 forces it.
+// 16384 samples up (227 vs 257 us at 65536, 2.52 vs 2.59 ms per step at 32768; round 5, re-measured: 0.960 vs 0.976 ms per step at 16384,
+// 0.665 vs 0.621 at 8192 -- profiles/r05_small_tile_ab.txt).  DPOSER_GNBWD_BIG = 0 / 1 forces it.
 static int gnbwd_shape(int64_t Spad, int gs = 32) {
     if (Spad <= score_tuning().small_tile_max) return SHAPE_SMALL;
     const int forced = score_tuning().gnbwd_big;
-    const bool big = gs == 32 && g_act == DPOSER_ACT_SWISH && (forced >= 0 ? forced == 1 : Spad >= 32768);
+    const bool big = gs == 32 && g_act == DPOSER_ACT_SWISH && (forced >= 0 ? forced == 1 : Spad >= 16384);
     if (big && Spad % 256 == 0) return SHAPE_BIG;
     return Spad % 128 == 0 ? SHAPE_MID : SHAPE_SMALL;
 }
