@@ -1692,3 +1692,40 @@ def test_timemlps_trains_with_the_fused_optimizer_and_refuses_cpu():
             first = float(loss)
         last = float(loss)
     assert np.isfinite(last) and last < first
+
+
+def test_roctx_ranges_are_balanced_and_change_nothing(tmp_path):
+    """DPOSER_ROCTX=1: every compute entry point pushes a roctx range named after itself (libroctx64 dlopen'ed on first use) and pops it on
+    every return path.  A child process with the switch on runs a forward, then pushes a range of its own: libroctx reports nesting
+    level 0 for it (the library left no range open), and the results are the bits of a child without the switch.  (That the ranges
+    carry the entry points' names is what `rocprofv3 --marker-trace` shows; no test reads a trace.)"""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, os, sys, hashlib
+sys.path.insert(0, os.getcwd())
+import torch
+from gpu_common import make_model
+cfg, m, p = make_model(5, precision='bf16')
+x = torch.randn(64, 63, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(1))
+t = torch.rand(64, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(2)) * 999
+with torch.no_grad():
+    y = m(x, t)
+depth = -2
+if os.environ.get('DPOSER_ROCTX') == '1':
+    r = ctypes.CDLL('libroctx64.so')
+    r.roctxRangePushA.argtypes = [ctypes.c_char_p]
+    a = r.roctxRangePushA(b'probe')            # nesting level of the new range: 0 when the library left none open
+    r.roctxRangePop()
+    depth = a
+print('RESULT', hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest(), depth)
+"""
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, DPOSER_ROCTX=flag, PYTHONPATH=os.pathsep.join([here, os.path.join(here, "golden"), os.path.dirname(here)]))
+        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split())
+    assert outs[0][1] == outs[1][1]                      # same bits with and without ranges
+    assert outs[1][2] == "0"                             # every pushed range was popped again
