@@ -32,7 +32,8 @@ struct Roctx {
     Roctx() {
         const char* e = getenv("DPOSER_ROCTX");
         if (!e || e[0] != '1') return;
-        for (const char* name : {"libroctx64.so", "libroctx64.so.4", "librocprofiler-sdk-roctx.so"}) {
+        // (rocprofv3 --marker-trace records the ranges of rocprofiler-sdk's roctx library; roctracer's legacy libroctx64 is the fallback)
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
             void* so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (!so) continue;
             push = reinterpret_cast<int (*)(const char*)>(dlsym(so, "roctxRangePushA"));

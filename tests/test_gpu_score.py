@@ -1713,7 +1713,7 @@ with torch.no_grad():
     y = m(x, t)
 depth = -2
 if os.environ.get('DPOSER_ROCTX') == '1':
-    r = ctypes.CDLL('libroctx64.so')
+    r = ctypes.CDLL('librocprofiler-sdk-roctx.so')
     r.roctxRangePushA.argtypes = [ctypes.c_char_p]
     a = r.roctxRangePushA(b'probe')            # nesting level of the new range: 0 when the library left none open
     r.roctxRangePop()
