@@ -1172,6 +1172,30 @@ def test_langevin_fused_vp_sde_vs_oracle():
     assert rel_err(t2n(x), xm.numpy()) < 1e-4
 
 
+def test_langevin_fused_ve_sde_vs_oracle():
+    """Langevin + EM under the VE SDE (sde_lib.py:234-292): alpha = 1 in the step size (sampling.py:293-294), the network is conditioned on
+    sigma(t) and its output is the score; the fused two-phase corrector + the fused predictor against the oracle step by step (the oracle
+    itself is pinned to the reference's VE outputs: golden g21)."""
+    from dposer_amd.algorithms.advanced import sampling, sde_lib
+    cfg, m, p = make_model(26, precision="fp32")
+    cfg.sampling.corrector = "langevin"
+    N, B, start = 1000, 40, 995
+    sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50.0, N=N)
+    assert sampling.fused_langevin_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.LangevinCorrector, False, True)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 63), lambda v: v, 1e-3, device=DEV)
+    rs = np.random.RandomState(10)
+    z0 = (rs.standard_normal((B, 63)) * 0.5).astype(np.float32)
+    noise = rs.standard_normal((N - start, 2, B, 63)).astype(np.float32)
+    trajs, x = fn(m, z=_dev(z0), noise=_dev(noise), start_step=start, args=_Args("denoise"))
+    xo, so, ts = torch.tensor(z0), R.VE(0.01, 50.0, N), torch.linspace(1.0, 1e-3, N)
+    for k, i in enumerate(range(start, N)):
+        t = torch.ones(B) * ts[i]
+        xo, _ = R.langevin_step(p, so, xo, t, torch.tensor(noise[k, 0]), snr=cfg.sampling.snr)
+        xo, xm = R.em_step(p, so, xo, t, torch.tensor(noise[k, 1]))
+        assert rel_err(t2n(trajs[k]), xo.numpy()) < 1e-4, i
+    assert rel_err(t2n(x), xm.numpy()) < 1e-4
+
+
 @pytest.mark.parametrize("embedding", ["positional", "fourier"])
 def test_langevin_fused_completion_imputation_matches_generic_loop(embedding):
     """Predictor-corrector loop with imputation (task = completion, sampling.py:416-420,455-461): per outer step the draws are
