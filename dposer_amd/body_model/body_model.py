@@ -3,7 +3,8 @@
 arithmetic (Rodrigues, kinematic chain, pose-blend GEMM, skinning, landmark joints -- smplx/lbs.py)
 runs in the HIP kernels of dposer_amd/csrc/fk.hip behind ``dposer_fk_joints`` / ``dposer_lbs_forward``.
 
-``bm_path`` may be an official model ``.npz`` or an asset dictionary (``body_model.synthetic.make_synthetic_asset``).
+``bm_path`` may be an official model file (``.npz`` / ``.pkl``) or directory (``body_model/assets.py``), or an asset dictionary
+(``body_model.synthetic.make_synthetic_asset``).
 ``model_type`` 'smpl' (24 joints), 'smplh' (52) and 'smplx' (55) share the kernels: the C library unrolls the kinematic chain
 over the matching compile-time parents table.
 """
@@ -426,7 +427,13 @@ class BodyModel(nn.Module):
     def __init__(self, bm_path, num_betas=10, batch_size=1, num_expressions=10, model_type="smplx"):
         super().__init__()
         assert model_type in ["smpl", "smplh", "smplx"]                    # body_model.py:39
-        asset = bm_path if isinstance(bm_path, dict) else load_model_npz(bm_path, model_type, num_betas, num_expressions)
+        if not isinstance(bm_path, dict):
+            # a model file or directory (.npz / .pkl; body_model/assets.py restates smplx's loader): the shape / expression spaces
+            # are clamped to what the file holds, as smplx does (it prints a warning), and the module is built with the clamped sizes
+            asset = load_model_npz(bm_path, model_type, num_betas, num_expressions)
+            num_betas, num_expressions = asset["num_betas"], asset["num_expressions"]
+        else:
+            asset = bm_path
         self.bm = _SMPLCore(asset, num_betas=num_betas, num_expression_coeffs=num_expressions, batch_size=batch_size, model_type=model_type)
         self.num_joints = self.bm.NUM_JOINTS                                # SMPL 23 / SMPL-H 51 / SMPL-X 54 (body_model.py:42,58,62)
         self.model_type = model_type

@@ -14,8 +14,13 @@ JOINT_IDS = {constants.JOINT_NAMES[i]: i for i in range(len(constants.JOINT_NAME
 class SMPLX(torch.nn.Module):
     def __init__(self, model_path, **kwargs):
         super().__init__()
-        asset = model_path if isinstance(model_path, dict) else load_smplx_npz(model_path)
-        self.bm = _SMPLCore(asset, num_betas=kwargs.get("num_betas", 10), num_expression_coeffs=kwargs.get("num_expression_coeffs", 10),
+        nb, ne = kwargs.get("num_betas", 10), kwargs.get("num_expression_coeffs", 10)
+        if isinstance(model_path, dict):
+            asset = model_path
+        else:                                                           # (file or directory: sizes clamped to the file's, as smplx does)
+            asset = load_smplx_npz(model_path, nb, ne)
+            nb, ne = asset["num_betas"], asset["num_expressions"]
+        self.bm = _SMPLCore(asset, num_betas=nb, num_expression_coeffs=ne,
                             batch_size=kwargs.get("batch_size", 1), model_type="smplx")
         joints = [constants.JOINT_MAP[i] for i in constants.JOINT_NAMES]
         joints[:25] = constants.SMPLX_OPENPOSE_25                      # smpl.py:55-57

@@ -88,38 +88,13 @@ def make_synthetic_smplx_asset(seed=0, num_vertices=10475, num_betas=10, num_exp
 
 
 def load_smplx_npz(path, num_betas=10, num_expressions=10):
-    """Build the asset dictionary from an official SMPLX_{NEUTRAL,MALE,FEMALE}.npz (smplx body_models.py
-    conventions: shapedirs[:, :, :num_betas] | [:, :, 300:300+num_expressions], posedirs reshaped to [486, V*3])."""
-    d = np.load(path, allow_pickle=True, encoding="latin1")
-    V = d["v_template"].shape[0]
-    sd = d["shapedirs"]
-    shapedirs = np.concatenate([sd[:, :, :num_betas], sd[:, :, 300:300 + num_expressions]], axis=2).astype(np.float32)
-    posedirs = np.reshape(d["posedirs"], [V * 3, -1]).T.astype(np.float32)
-    parents = d["kintree_table"][0].astype(np.int64)
-    parents[0] = -1
-    return dict(v_template=d["v_template"].astype(np.float32), shapedirs=shapedirs, posedirs=posedirs,
-                J_regressor=np.asarray(d["J_regressor"], dtype=np.float32), parents=parents,
-                weights=d["weights"].astype(np.float32), faces=d["f"].astype(np.int32),
-                lmk_faces_idx=d["lmk_faces_idx"].astype(np.int32), lmk_bary_coords=d["lmk_bary_coords"].astype(np.float32),
-                extra_joint_vertex_ids=SMPLX_EXTRA_VERTEX_IDS.copy(), num_betas=num_betas, num_expressions=num_expressions,
-                model_type="smplx")
+    """Asset dictionary from an official SMPL-X model file (``.npz`` / ``.pkl``, v1.0 or v1.1): see ``assets.load_model_file``."""
+    from .assets import load_model_file
+    return load_model_file(path, "smplx", num_betas, num_expressions)
 
 
 def load_model_npz(path, model_type="smplx", num_betas=10, num_expressions=10):
-    """Asset dictionary from an official model ``.npz``: SMPL-X via ``load_smplx_npz``; SMPL / SMPL-H the way the reference
-    loads them (lib/body_model/body_model.py:44-57: raw arrays, shape space truncated to ``num_betas``, flat hand mean)."""
-    if model_type == "smplx":
-        return load_smplx_npz(path, num_betas, num_expressions)
-    d = np.load(path, allow_pickle=True, encoding="latin1")
-    V = d["v_template"].shape[0]
-    posedirs = np.reshape(d["posedirs"], [V * 3, -1]).T.astype(np.float32)
-    parents = d["kintree_table"][0].astype(np.int64)
-    parents[0] = -1
-    sd = np.asarray(d["shapedirs"], dtype=np.float32)[:, :, :num_betas]
-    if sd.shape[2] < num_betas:                                     # body_model.py:53-56 pads the shape space with zeros
-        sd = np.concatenate([sd, np.zeros((V, 3, num_betas - sd.shape[2]), np.float32)], axis=2)
-    return dict(v_template=d["v_template"].astype(np.float32), shapedirs=sd, posedirs=posedirs,
-                J_regressor=np.asarray(d["J_regressor"].todense() if hasattr(d["J_regressor"], "todense") else d["J_regressor"], dtype=np.float32),
-                parents=parents, weights=d["weights"].astype(np.float32), faces=d["f"].astype(np.int32),
-                lmk_faces_idx=np.zeros((0,), np.int32), lmk_bary_coords=np.zeros((0, 3), np.float32),
-                extra_joint_vertex_ids=SMPLH_EXTRA_VERTEX_IDS.copy(), num_betas=num_betas, num_expressions=0, model_type=model_type)
+    """Asset dictionary from an official SMPL / SMPL-H / SMPL-X model file or directory (name kept from round 2; ``.pkl`` is read
+    too): ``assets.load_model_file`` restates what smplx 0.1.28 does with the file (lib/body_model/body_model.py:39-62)."""
+    from .assets import load_model_file
+    return load_model_file(path, model_type, num_betas, num_expressions)

@@ -48,7 +48,7 @@ class _PriorLoss(torch.autograd.Function):
         return (grad * g, None, None, None, None, None, None, None, None)
 
 
-def _prior_loss_unfused(model, sde, x0, t, weighted, inv_n, z):
+def _prior_loss_unfused(model, sde, x0, t, weighted, inv_n, z, continuous=True):
     """smplify.py:93-107 / completion.py:131-149 step by step for an SDE the fused kernel does not cover (VE).  The one-step estimate is
     detached in the reference (smplify.py:73), so the gradient reaches x0 through the explicit (x0 - x0_hat) only."""
     from .algorithms.advanced import utils as mutils
@@ -58,7 +58,7 @@ def _prior_loss_unfused(model, sde, x0, t, weighted, inv_n, z):
         zz = torch.randn_like(x0) if z is None else z.to(x0.device, torch.float32)
         mean, std = sde.marginal_prob(x0.detach().float(), vec_t)
         x_t = mean + std[:, None] * zz
-        score = mutils.get_score_fn(sde, model, train=False, continuous=True)(x_t, vec_t, condition=None, mask=None)
+        score = mutils.get_score_fn(sde, model, train=False, continuous=continuous)(x_t, vec_t, condition=None, mask=None)
         alpha, sigma = sde.return_alpha_sigma(vec_t)
         alpha, sigma = alpha.to(x0.device), sigma.to(x0.device)
         x0_hat = (x_t + (sigma ** 2)[:, None] * score) / alpha              # alpha: [1, 1] (VE) or [B, 1]
@@ -67,14 +67,18 @@ def _prior_loss_unfused(model, sde, x0, t, weighted, inv_n, z):
     return (w * (x0.float() - x0_hat) ** 2).sum() * inv_n
 
 
-def prior_loss(model, sde, x0, t, *, weighted=True, reduction="mean", batch_size=None, z=None, seed=0, step=0):
+def prior_loss(model, sde, x0, t, *, weighted=True, reduction="mean", batch_size=None, z=None, seed=0, step=0, continuous=True):
     """Weighted denoising loss at one shared time ``t`` (python float).
-    reduction='mean' -> torch.mean over [B, D] (completion.py:147); 'sum_over_batch' -> sum / batch_size (smplify.py:105)."""
+    reduction='mean' -> torch.mean over [B, D] (completion.py:147); 'sum_over_batch' -> sum / batch_size (smplify.py:105).
+    ``continuous``: ``config.training.continuous`` as the reference hands it to ``get_score_fn`` (motion_denoising.py:94,
+    completion.py:103).  It only changes the VE score function (utils.py:164-181: a discrete VE model is conditioned on the label
+    round((T - t)(N - 1)), not on sigma(t)); the fused kernel evaluates the continuous form, so a discrete VE prior runs step by step."""
     if x0.shape[0] == 0:
         raise ValueError("prior_loss: empty batch (the reference's torch.mean over no elements is NaN)")
     n = x0.numel() if reduction == "mean" else (batch_size if batch_size is not None else x0.shape[0])
-    if sde_lib.sde_desc(sde) is None:      # an SDE the fused kernel does not cover: the HIP score function + the reference's few elementwise steps (VE is fused since round 5)
-        return _prior_loss_unfused(model, sde, x0, float(t), bool(weighted), 1.0 / float(n), z)
+    discrete_ve = (not continuous) and isinstance(sde, sde_lib.VESDE)
+    if sde_lib.sde_desc(sde) is None or discrete_ve:      # not covered by the fused kernel: the HIP score function + the reference's few elementwise steps
+        return _prior_loss_unfused(model, sde, x0, float(t), bool(weighted), 1.0 / float(n), z, continuous=not discrete_ve)
     return _PriorLoss.apply(x0, model, sde, float(t), bool(weighted), 1.0 / float(n), z, seed, step)
 
 

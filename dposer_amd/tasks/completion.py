@@ -33,7 +33,7 @@ class DPoserComp:
         """completion.py:131-149 at one shared time ``t`` (python float): mean(weight * (x_0 - x0_hat)^2)."""
         self._calls += 1
         return prior_loss(self.model, self.sde, x_0, t, weighted=bool(weighted), reduction="mean", z=z,
-                          seed=self.model._rng_seed + 29, step=self._calls)
+                          seed=self.model._rng_seed + 29, step=self._calls, continuous=bool(getattr(self, "continuous", True)))
 
     def get_loss_weights(self):
         """completion.py:151-155."""

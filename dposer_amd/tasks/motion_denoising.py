@@ -72,6 +72,7 @@ class MotionDenoise:
             raise NotImplementedError(f"SDE {config.training.sde} unknown.")
         sde.N = sde_N
         self.sde = sde
+        self.continuous = bool(getattr(config.training, "continuous", True))      # motion_denoising.py:94: the score function's flavour
         self.model = diffusion_model
         self._calls = 0
 
@@ -79,7 +80,7 @@ class MotionDenoise:
         """motion_denoising.py:124-143: sum(weight * (x_0 - x0_hat)^2) / batch_size."""
         self._calls += 1
         return prior_loss(self.model, self.sde, x_0, t, weighted=weighted, reduction="sum_over_batch", batch_size=self.batch_size, z=z,
-                          seed=self.model._rng_seed + 31, step=self._calls)
+                          seed=self.model._rng_seed + 31, step=self._calls, continuous=getattr(self, "continuous", True))
 
     def get_loss_weights(self):
         """motion_denoising.py:157-163."""

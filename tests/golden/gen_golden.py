@@ -757,6 +757,20 @@ def g8_scalars():
     save("g8_scalars", **out)
 
 
+def g24_openpose_maps():
+    """G24: smpl_to_openpose (lib/body_model/utils.py:68-177) for EVERY argument combination it accepts:
+    model_type x use_hands x use_face x use_face_contour x {coco25, coco19} (bit-exact index tables)."""
+    out = {}
+    for fmt in ("coco25", "coco19"):
+        for mt in ("smpl", "smplh", "smplx"):
+            for hands in (False, True):
+                for face in (False, True):
+                    for contour in (False, True):
+                        m = ref_bmu.smpl_to_openpose(mt, use_hands=hands, use_face=face, use_face_contour=contour, openpose_format=fmt)
+                        out[f"{fmt}/{mt}/{int(hands)}{int(face)}{int(contour)}"] = np.asarray(m).astype(np.int64)
+    save("g24_openpose_maps", **out)
+
+
 def g9_tables():
     """G9: integer index tables (bit-exact): create_mask, BodyPartIndices, BodySegIndices lengths
     + checksums, JOINT_NAMES/JOINT_MAP, smpl.py joint_map, smpl_to_openpose, 22-joint parents,
@@ -948,8 +962,8 @@ def g13_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g24"]
     fns = dict(g22=g22_timemlps, g21=g21_ve_paths, g20=g20_fourier_paths, g19=g19_activations, g18=g18_evaler, g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
-               g8=g8_scalars, g9=g9_tables, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
+               g8=g8_scalars, g9=g9_tables, g24=g24_openpose_maps, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
     for w in which:
         fns[w]()

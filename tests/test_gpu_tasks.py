@@ -261,6 +261,7 @@ def test_motion_denoise_under_the_ve_sde():
     md.sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50.0, N=500)
     md.batch_size = F
     md.betas = md.betas[:F]
+    assert md.continuous is True                                                # read from config.training.continuous by __init__ (motion_denoising.py:94)
     assert md._fused_supported()
     noise = torch.tensor(rs.standard_normal((iters * spi, F * S, 63)).astype(np.float32), device=DEV)
     kw = dict(time_strategy="3", iterations=iters, steps_per_iter=spi)
@@ -274,6 +275,8 @@ def test_motion_denoise_under_the_ve_sde():
     assert res["pose_body"].shape == (S, F, 63) and res["MPJPE"].shape == (S, F) and np.isfinite(res["MPVPE"]).all()
     one = md.optimize(joints3d[F:], gt_poses=gt[F:], noise=noise[:, F:].contiguous(), init_poses=init[F:], **kw)
     assert torch.equal(res["pose_body"][1], one["pose_body"])
+    # the discrete score function conditions the network on round((T - t)(N - 1)) instead of sigma(t): it must really have been used
+    assert not torch.equal(one["pose_body"], one_u["pose_body"])
 
 
 def test_evaluate_motion_denoising_shards_sequences_over_ranks():

@@ -35,6 +35,25 @@ def test_index_tables_bit_exact():
     assert np.array_equal(SMPLX_PARENTS[:22], g["parents22"])
 
 
+def test_smpl_to_openpose_every_argument_combination_bit_exact():
+    """lib/body_model/utils.py:68-177 over model_type x use_hands x use_face x use_face_contour x format (golden g24 = the
+    reference's own outputs), plus its error behaviour."""
+    from dposer_amd.body_model import utils
+    g = load("g24_openpose_maps")
+    assert len(g.files) == 48
+    for key in g.files:
+        fmt, mt, flags = key.split("/")
+        got = utils.smpl_to_openpose(mt, use_hands=flags[0] == "1", use_face=flags[1] == "1", use_face_contour=flags[2] == "1", openpose_format=fmt)
+        assert got.dtype == np.int32 and np.array_equal(got, g[key]), key
+    assert np.array_equal(utils.smpl_to_openpose("smplx", openpose_format="COCO25"), g["coco25/smplx/110"])
+    with pytest.raises(ValueError, match="Unknown model type"):
+        utils.smpl_to_openpose("mano")
+    with pytest.raises(ValueError, match="Unknown joint format"):
+        utils.smpl_to_openpose("smplx", openpose_format="COCO19")
+    with pytest.raises(ValueError, match="Unknown joint format"):
+        utils.smpl_to_openpose("smplx", openpose_format="coco17")
+
+
 def test_smplx_joint_map_bit_exact():
     from dposer_amd.body_model import constants
     g = load("g9_tables")

@@ -35,6 +35,22 @@ out = {
     "smpl_to_openpose": {mt: [int(i) for i in U.smpl_to_openpose(mt)] for mt in ("smpl", "smplh", "smplx")},
     "smpl_skeleton": [[int(a), int(b)] for a, b in U.get_smpl_skeleton()],
 }
+# smpl_to_openpose for every argument combination (utils.py:68-177), as the blocks the function concatenates: per (format, model
+# type) the body map, the two hand maps and the first face index -- read off the function's own outputs (body = no hands / no face;
+# hands = what use_hands appends; face = an arange from the first appended index, 51 + 17 * use_face_contour long).
+blocks = {}
+for fmt in ("coco25", "coco19"):
+    for mt in ("smpl", "smplh", "smplx"):
+        body = U.smpl_to_openpose(mt, use_hands=False, use_face=False, openpose_format=fmt)
+        hands = U.smpl_to_openpose(mt, use_hands=True, use_face=False, openpose_format=fmt)[len(body):]
+        face = U.smpl_to_openpose(mt, use_hands=False, use_face=True, openpose_format=fmt)[len(body):]
+        face_c = U.smpl_to_openpose(mt, use_hands=False, use_face=True, use_face_contour=True, openpose_format=fmt)[len(body):]
+        assert len(hands) in (0, 42) and len(face) in (0, 51) and len(face_c) in (0, 68)
+        if len(face):
+            assert list(face) == list(range(int(face[0]), int(face[0]) + 51)) and list(face_c) == list(range(int(face[0]), int(face[0]) + 68))
+        blocks[f"{fmt}/{mt}"] = {"body": [int(i) for i in body], "lhand": [int(i) for i in hands[:21]], "rhand": [int(i) for i in hands[21:]],
+                                 "face_start": int(face[0]) if len(face) else -1}
+out["smpl_to_openpose_blocks"] = blocks
 for perm in ("H36M_TO_J17", "H36M_TO_J14", "J24_TO_J17", "J24_TO_J14", "SMPL_JOINTS_FLIP_PERM", "SMPL_POSE_FLIP_PERM",
              "J24_FLIP_PERM", "J49_FLIP_PERM"):
     out[perm] = [int(i) for i in getattr(C, perm)]
