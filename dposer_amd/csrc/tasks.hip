@@ -74,7 +74,10 @@ __global__ void __launch_bounds__(256) k_md_normalize6d(const float* pose, const
 // temporal term (:253-255): temp = mean over (T-1, V) of ||v[t] - v[t+1]||; d temp / d v[t] = (u_t - u_{t-1}) / ((T-1) V),
 // u_t = (v[t] - v[t+1]) / ||v[t] - v[t+1]||  (0/0 = NaN for two identical vertices, as torch's sqrt backward gives)
 // (F = frames per sequence: the frames of a batch of sequences are consecutive, neighbours never cross a sequence boundary)
-__global__ void __launch_bounds__(256) k_md_vert_grad(const float* verts, float* dverts, float* part, int F, int V, float c) {
+// IEEE: the three quotients as IEEE divisions by the distance (what torch computes: x / sqrt(s)) instead of one v_rcp_f32 / v_rsq_f32 (1 ulp)
+// and three products -- DPOSER_MD_IEEE_DIV=1 (A/B for config 5's tolerance: profiles/r06_cfg5_ieee_ab.md; the loop's own sensitivity
+// to one ulp, profiles/r06_cfg5_sensitivity.md, is what bounds the agreement, not this)
+template <bool IEEE> __global__ void __launch_bounds__(256) k_md_vert_grad(const float* verts, float* dverts, float* part, int F, int V, float c) {
     __shared__ float red[4];
     const int t = blockIdx.y;
     const int tf = t % F;
@@ -88,15 +91,21 @@ __global__ void __launch_bounds__(256) k_md_vert_grad(const float* verts, float*
             const float* q = p + (int64_t)V * 3;
             const float ax = px - q[0], ay = py - q[1], az = pz - q[2];
             const float d = sqrtf(ax * ax + ay * ay + az * az);
-            const float inv = __builtin_amdgcn_rcpf(d);          // one v_rcp_f32 (1 ulp) instead of three IEEE divisions (~10 VALU each); 0 * inf = NaN as 0 / 0
-            gx = ax * inv; gy = ay * inv; gz = az * inv;
+            if (IEEE) { gx = ax / d; gy = ay / d; gz = az / d; }
+            else {
+                const float inv = __builtin_amdgcn_rcpf(d);      // one v_rcp_f32 (1 ulp) instead of three IEEE divisions (~10 VALU each); 0 * inf = NaN as 0 / 0
+                gx = ax * inv; gy = ay * inv; gz = az * inv;
+            }
             d_sum = d;
         }
         if (tf > 0) {
             const float* q = p - (int64_t)V * 3;
             const float bx = q[0] - px, by = q[1] - py, bz = q[2] - pz;
-            const float inv = __builtin_amdgcn_rsqf(bx * bx + by * by + bz * bz);      // v_rsq_f32: this distance only feeds the gradient (rsq(0) = inf: 0 * inf = NaN)
-            gx -= bx * inv; gy -= by * inv; gz -= bz * inv;
+            if (IEEE) { const float db = sqrtf(bx * bx + by * by + bz * bz); gx -= bx / db; gy -= by / db; gz -= bz / db; }
+            else {
+                const float inv = __builtin_amdgcn_rsqf(bx * bx + by * by + bz * bz);      // v_rsq_f32: this distance only feeds the gradient (rsq(0) = inf: 0 * inf = NaN)
+                gx -= bx * inv; gy -= by * inv; gz -= bz * inv;
+            }
         }
         float* o = dverts + ((int64_t)t * V + v) * 3;
         o[0] = c * gx; o[1] = c * gy; o[2] = c * gz;
@@ -277,6 +286,9 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     // DPOSER_MD_FUSED_TEMPORAL_MIN_SEQ = 4 sequences per call: a workgroup of the fused kernel walks >= 10 frames one after the other;
     // measured 0.60 vs 0.67 ms per step at 8 sequences of 60 frames, a tie at one)
     bool fused_temporal = a->skin_k == 4 && F <= 4096 && n_seq <= 16384;
+    bool ieee_div = false;
+    { const char* e = getenv("DPOSER_MD_IEEE_DIV"); ieee_div = e && e[0] == '1'; }
+    if (ieee_div) fused_temporal = false;                    // (the A/B switch exists in the two-kernel form only)
     {
         const char* e = getenv("DPOSER_MD_FUSED_TEMPORAL");
         const char* m = getenv("DPOSER_MD_FUSED_TEMPORAL_MIN_SEQ");
@@ -304,7 +316,8 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
             DP_TRY(dposer_lbs_forward(a->body, a->lbs_ws_fwd, a->posedirs_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest, a->rest_batched,
                                       a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, nullptr, a->extra_vertex_ids, a->lmk_tri, a->lmk_bary,
                                       s.verts, s.joints, T, stream));
-            hipLaunchKernelGGL(k_md_vert_grad, dim3((unsigned)vb, (unsigned)T), dim3(256), 0, st, (const float*)s.verts, s.dverts, s.part, (int)F, V, c_temp);
+            if (ieee_div) hipLaunchKernelGGL(k_md_vert_grad<true>, dim3((unsigned)vb, (unsigned)T), dim3(256), 0, st, (const float*)s.verts, s.dverts, s.part, (int)F, V, c_temp);
+            else hipLaunchKernelGGL(k_md_vert_grad<false>, dim3((unsigned)vb, (unsigned)T), dim3(256), 0, st, (const float*)s.verts, s.dverts, s.part, (int)F, V, c_temp);
             TK_HIP_LAUNCH(hipGetLastError());
         }
         hipLaunchKernelGGL(k_md_joint, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)s.joints, (int64_t)a->joint_rows * 3, a->joints_obs, s.djoints,

@@ -16,8 +16,10 @@ def batch_rodrigues(rv):
 
 
 def smplx_forward(asset, body_pose, betas=None, global_orient=None, transl=None, expression=None, jaw_pose=None, leye_pose=None,
-                  reye_pose=None, left_hand_pose=None, right_hand_pose=None):
-    dt = torch.float64
+                  reye_pose=None, left_hand_pose=None, right_hand_pose=None, dtype=torch.float64):
+    """``dtype``: float64 (the arbiter) or float32 -- the precision smplx itself runs in inside the reference's loops (used by
+    tests/sensitivity/cfg5_sensitivity.py to size the reference's own rounding noise); inputs must already be of that dtype."""
+    dt = dtype
     t = lambda a: torch.as_tensor(a, dtype=dt)
     B = body_pose.shape[0]
     z = lambda n: torch.zeros(B, n, dtype=dt)

@@ -62,14 +62,14 @@ def gaussian_smoothing(x, window_size=3, sigma=2.0):
 
 
 def motion_denoise_optimize(p, sde, asset, mean, std, joints3d, gt_poses, init_poses, noise, *, iterations=5, steps_per_iter=50,
-                            sample_trun=2.0, dposer_weight=1.0):
+                            sample_trun=2.0, dposer_weight=1.0, body_dtype=torch.float64):
     """run/motion_denoising.py:199-300, time strategy '3', z-score normaliser.  Returns (final pose_body before smoothing,
-    {'init_MPJPE', 'MPJPE', 'MPVPE'}).  The body model is fk_torch (float64); poses are an fp32 leaf like in the reference."""
+    {'init_MPJPE', 'MPJPE', 'MPVPE'}).  The body model is fk_torch (float64; ``body_dtype=torch.float32`` = the precision smplx runs in inside the reference); poses are an fp32 leaf like in the reference."""
     T = init_poses.shape[0]
     mean = torch.as_tensor(mean, dtype=torch.float32)
     std = torch.as_tensor(std, dtype=torch.float32)
-    joints = torch.as_tensor(joints3d, dtype=torch.float64)
-    bm = lambda pose: fk_torch.smplx_forward(asset, pose.double())
+    joints = torch.as_tensor(joints3d, dtype=body_dtype)
+    bm = lambda pose: fk_torch.smplx_forward(asset, pose.to(body_dtype), dtype=body_dtype)
     with torch.no_grad():
         v_gt, j_gt = bm(torch.as_tensor(gt_poses, dtype=torch.float32))
     je = joints - j_gt[:, :22]

@@ -110,3 +110,33 @@ def test_wrong_files_are_refused_with_a_reason(tmp_path, smplx_asset):
 def test_influence_count_reported(smplx_asset):
     assert assets.max_skinning_influences(smplx_asset) == 4
     assert assets.max_skinning_influences(make_synthetic_asset("smpl", seed=1, nnz_per_vertex=7)) == 7
+
+
+def test_pin_script_plumbing_with_a_stand_in_for_smplx(tmp_path, monkeypatch):
+    """tests/golden/pin_fk_parity.py end to end with ``run_smplx`` replaced by the oracle on the loaded file (smplx itself cannot be
+    imported here): files are written, keyword sets map onto the full pose in smplx's order, the golden has the keys its consumers
+    read.  What this cannot show -- that smplx agrees -- is exactly what the script is for."""
+    import pin_fk_parity as P
+    from oracle import fk_ref
+    from pin_cases import build_case, case_inputs
+
+    def fake_run_smplx(path, model_type, nb, ne, d):
+        loaded = assets.load_model_file(path, model_type, nb, ne)
+        full, shape = P.full_pose_and_shape(model_type, d)
+        v, j, _ = fk_ref.model_forward(loaded, full.astype(np.float64), shape=shape.astype(np.float64), transl=d["transl"].astype(np.float64))
+        return v, j, full
+    monkeypatch.setattr(P, "run_smplx", fake_run_smplx)
+    monkeypatch.setitem(sys.modules, "smplx", types.SimpleNamespace(__version__="stand-in"))
+    monkeypatch.setattr(P, "CASES", P.CASES[1:2] + P.CASES[3:4])          # (the 10 + 10 SMPL-X file and the SMPL .pkl: the small ones)
+    out = str(tmp_path / "g23.npz")
+    monkeypatch.setattr(sys, "argv", ["pin_fk_parity.py", "--out", out])
+    with pytest.raises(SystemExit) as e:
+        P.main()
+    assert e.value.code == 0
+    g = np.load(out, allow_pickle=False)
+    assert [str(c) for c in g["cases"]] == ["smplx_v1.0", "smpl"]
+    for i, layout in enumerate([str(c) for c in g["cases"]]):
+        bm_kwargs = build_case(g, i, layout, tmp_path)[1]
+        d = case_inputs(g, layout)
+        assert set(bm_kwargs) >= {"root_orient", "pose_body", "betas", "trans"} and g[f"{layout}/vertices"].shape[0] == P.B
+        assert ("pose_hand" in bm_kwargs) == ("left_hand_pose" in d)

@@ -173,16 +173,24 @@ def test_cfg4_full_completion_loop_at_batch_16384():
 
 
 # ---- cfg 5 ------------------------------------------------------------------------------------------------------------
-def test_cfg5_motion_denoising_60_frames_180_steps_vs_oracle_loop():
+@pytest.mark.parametrize("iters,tol", [(2, 1e-5), (5, 1e-3)])
+def test_cfg5_motion_denoising_60_frames_180_steps_vs_oracle_loop(iters, tol):
     """motion_denoising.py:199-300 at the size of config 5: one 60-frame sequence, 180 optimisation steps (5 x 36), noise std
     0.04 on the observed joints, SMPL-X-shaped FK + LBS forward/backward + prior loss per step, vs the oracle loop (pinned to
-    the reference's own loop by g15) fed the same z."""
+    the reference's own loop by g15) fed the same z.
+
+    Tolerances (profiles/r06_cfg5_sensitivity.md, r06_cfg5_ieee_ab.md): the loop is well conditioned for its first ~72 steps (a one-ulp
+    change of the initial pose moves the ORACLE's result by 1e-7 .. 4e-7) and the HIP loop is held to `north_star`'s 1e-5 there
+    (2 x 36 steps).  From ~100 steps on the loop itself amplifies rounding: after 180 steps ONE ulp in ONE coordinate of the initial pose
+    moves the oracle's own result by 1.1e-4, and the reference's own arithmetic (smplx in float32 instead of the oracle's float64) by
+    1.9e-4 -- the HIP loop's 2.0e-4 is that noise, not kernel error (IEEE divisions in place of v_rcp / v_rsq in the temporal-term
+    gradient: 4.6e-4, i.e. another draw of the same noise).  1e-3 = 5 x that floor."""
     from dposer_amd.body_model.body_model import BodyModel
     from dposer_amd.body_model.synthetic import make_synthetic_smplx_asset
     from dposer_amd.dataset.AMASS import Posenormalizer
     from dposer_amd.tasks.motion_denoising import MotionDenoise
     from oracle import fk_torch
-    T, iters, spi, N = 60, 5, 36, 1000
+    T, spi, N = 60, 36, 1000
     cfg, m, p = make_model(63, precision="fp32")
     asset = make_synthetic_smplx_asset(seed=0)
     bm = BodyModel(asset).to(DEV)
@@ -209,8 +217,8 @@ def test_cfg5_motion_denoising_60_frames_180_steps_vs_oracle_loop():
     final, ref = task_loops.motion_denoise_optimize(p, R.SubVP(N=N), asset, stats["mean_poses"], stats["std_poses"], joints3d, gt, init,
                                                     noise, iterations=iters, steps_per_iter=spi)
     err = rel_err(t2n(res["pose_body"]), final)
-    print(f"cfg5: pose rel err {err:.2e}; MPJPE {res['MPJPE'].mean():.3f} vs {ref['MPJPE'].mean():.3f} cm (init {ref['init_MPJPE'].mean():.3f})")
-    assert err < 1e-3                                   # measured 2.3e-4 after 180 Adam steps
+    print(f"cfg5 ({iters * spi} steps): pose rel err {err:.2e}; MPJPE {res['MPJPE'].mean():.3f} vs {ref['MPJPE'].mean():.3f} cm (init {ref['init_MPJPE'].mean():.3f})")
+    assert err < tol                                    # measured 2.0e-4 after 180 Adam steps (the loop's own rounding floor, see the docstring)
     assert abs(res["MPJPE"].mean() - ref["MPJPE"].mean()) < 0.05 * ref["MPJPE"].mean()
     assert res["MPJPE"].mean() < res["init_MPJPE"].mean()                         # denoising reduces the joint error
 
