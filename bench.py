@@ -361,6 +361,49 @@ def main():
              "gemm_kernels": kernels}
     if dp_extra:
         extra["dp"] = dp_extra
+    per_rank = None
+    if ddp.is_initialized():
+        # ---- self-validation of a multi-rank run (the first 8-GPU run has nobody to debug it): what the communicator says about itself,
+        # which device every rank really ran on, every rank's own step time, and the N = 1 step of THIS build on every rank's GPU (global
+        # batch, no collective: comparable with the single-GPU BENCH line; a slow GPU or a rank that shares a device shows up here)
+        backend = torch.distributed.get_backend()
+        comm = {"backend": backend, "world_size_reported_by_the_process_group": torch.distributed.get_world_size(), "launcher_world_size": world,
+                "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                "forced_one_rank_collectives": os.environ.get("DPOSER_DIST_FORCE_COLLECTIVES") == "1"}
+        n1 = None
+        if not args.no_extra or os.environ.get("DPOSER_BENCH_N1_LEG") == "1":
+            opt = state["optimizer"]
+            opt._ensure_flat()
+            keep = [t.clone() for t in (model.flat_params(), opt._flat_m, opt._flat_v, state["ema"].flat_shadow_for(model.flat_params()))]
+            keep_step, keep_count = state["step"], opt._step_count
+            full = batch_all.to(dev).contiguous()
+            with ddp.local_only():
+                for _ in range(2):
+                    step_fn(state, full)
+                torch.cuda.synchronize()
+                tn = time.perf_counter()
+                n_n1 = max(3, min(args.steps, 10))
+                for _ in range(n_n1):
+                    step_fn(state, full)
+                torch.cuda.synchronize()
+                n1_ms = (time.perf_counter() - tn) / n_n1 * 1e3
+            for dst, src in zip((model.flat_params(), opt._flat_m, opt._flat_v, state["ema"].flat_shadow_for(model.flat_params())), keep):
+                dst.copy_(src)                                     # the replicas stepped on their own inside the block: back to the common state
+            _C.bump_param_epoch()
+            state["step"], opt._step_count = keep_step, keep_count
+            del full, keep
+            n1 = {"ms_per_step": n1_ms, "poses_per_s": args.global_batch / (n1_ms * 1e-3), "steps": n_n1, "global_batch": args.global_batch}
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "device_name": torch.cuda.get_device_name(dev),
+                "device_uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")), "host": __import__("socket").gethostname(),
+                "per_gpu_batch": hi - lo, "own_ms_per_step": own_elapsed / args.steps * 1e3, "n1_same_build": n1}
+        per_rank = [None] * torch.distributed.get_world_size()
+        torch.distributed.all_gather_object(per_rank, mine)
+        devices = [(r["host"], r["device_uuid"] or r["device_index"]) for r in per_rank]
+        extra["ranks"] = {"communicator": comm, "per_rank": per_rank, "distinct_devices": len(set(devices)),
+                          "all_ranks_on_distinct_devices": len(set(devices)) == len(devices),
+                          "n1_same_build": {"what": "the single-process step (no collective) of this build at the GLOBAL batch, timed on every rank's own GPU",
+                                            "ms_per_step_per_rank": [r["n1_same_build"]["ms_per_step"] if r["n1_same_build"] else None for r in per_rank],
+                                            "poses_per_s_rank0": per_rank[0]["n1_same_build"]["poses_per_s"] if per_rank[0]["n1_same_build"] else None}}
     if not args.no_extra and args.precision != "fp32":
         # the same step in fp32 parity mode (exact-fp32 MFMA, 1/16 of the bf16 matrix rate): the mode the tight parity numbers
         # of the test suite come from, next to the bf16 headline
@@ -444,6 +487,7 @@ def main():
         torch.cuda.synchronize()
         sprof = _C.profile_collect()
         _C.profile_enable(False)
+        t_s_own = t_s
         if world > 1:
             tt = torch.tensor([t_s], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -619,6 +663,13 @@ def main():
         extra["lbs_full_fwd_bwd_through_loss_backward"] = {"ms_mean_of_runs": sum(secs) / len(secs) * 1e3, "runs_ms": [round(x * 1e3, 4) for x in secs],
                                                            "poses_per_s_per_gpu": nl / (sum(secs) / len(secs)), "batch": nl}
 
+    if ddp.is_initialized() and not args.no_extra:
+        # the legs that shard with no collective, as every rank measured them on its own shard / GPU
+        legs = [None] * torch.distributed.get_world_size()
+        torch.distributed.all_gather_object(legs, {"rank": rank, "sampler_seconds": t_s_own, "sampler_samples": B_local,
+                                                   "fk_poses_per_s": extra["fk_joints"]["poses_per_s_per_gpu"], "lbs_fwd_ms": extra["lbs_full_fwd"]["ms"],
+                                                   "lbs_fwd_bwd_ms": extra["lbs_full_fwd_bwd"]["ms"]})
+        extra["ranks"]["unsharded_legs_per_rank"] = legs
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()

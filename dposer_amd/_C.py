@@ -148,6 +148,10 @@ SIGNATURES = {
                                      vp, vp, vp, vp, vp, vp, i64, vp]),
     "dposer_lbs_forward_temporal_grad": (C.c_int, [vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, i32, vp, vp, i32,
                                                    vp, i64, f32, vp, vp, vp, i64, vp]),
+    "dposer_lbs_temporal_in_backward_ok": (i32, [vp, i32, i64]),
+    "dposer_lbs_forward_front": (C.c_int, [vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, vp, i64, vp]),
+    "dposer_lbs_backward_temporal": (C.c_int, [vp, vp, vp, vp, C.POINTER(vp), C.POINTER(i32), i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp,
+                                               i64, f32, vp, vp, i64, C.POINTER(vp), i64, vp]),
     "dposer_lbs_posedirs_bwd_packed_bytes": (i64, [vp]),
     "dposer_lbs_pack_posedirs_bwd": (C.c_int, [vp, vp, vp, vp]),
     "dposer_lbs_backward_workspace_bytes": (i64, [vp, i64]),

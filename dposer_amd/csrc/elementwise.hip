@@ -261,6 +261,15 @@ __global__ void __launch_bounds__(256) k_time_embed(const float* labels, float l
         store_quad_ft<float>(emb, s, e, E, v);
     }
 }
+__global__ void __launch_bounds__(256) k_ve_labels(float* t_inout, int n, float smin, float ratio) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) t_inout[i] = sde_ve_sigma(smin, ratio, t_inout[i]);
+}
+hipError_t launch_ve_labels(float* t_inout, int n, float smin, float ratio, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ve_labels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t_inout, n, smin, ratio);
+    return hipGetLastError();
+}
 hipError_t launch_time_embed(const float* labels, float label0, int64_t n, int64_t npad, const float* freq, int E, int fourier, float* emb, hipStream_t st) {
     hipLaunchKernelGGL(k_time_embed, dim3(grid_for(npad * (E >> 2))), dim3(256), 0, st, labels, label0, n, npad, freq, E, fourier, emb);
     return hipGetLastError();

@@ -761,7 +761,22 @@ struct dposer_body_s {
     // backward: the three product terms of the bf16 x 3 blend-gradient GEMM run side by side on the caller's stream and these two
     hipStream_t bwd_side[2] = {nullptr, nullptr};
     hipEvent_t ev_bwd_fork = nullptr, ev_bwd_join[2] = {nullptr, nullptr};
+    // the side streams and events above belong to ONE device: the one that was current when they were created.  A handle that moves
+    // with its module (.to(other_device)) gets them re-created there (side_streams_for_current_device)
+    int side_dev = -1;
 };
+// (re)create nothing, but drop the handle's side streams / events when they belong to another device than the current one
+static int side_streams_for_current_device(dposer_body_t h) {
+    int dev = -1;
+    DP_CHECK_HIP(hipGetDevice(&dev));
+    if (h->side_dev == dev) return DPOSER_OK;
+    if (h->side) (void)hipStreamDestroy(h->side);
+    for (hipStream_t* q : {&h->bwd_side[0], &h->bwd_side[1]}) { if (*q) (void)hipStreamDestroy(*q); *q = nullptr; }
+    for (hipEvent_t* e : {&h->ev_chunk[0], &h->ev_chunk[1], &h->ev_join, &h->ev_bwd_fork, &h->ev_bwd_join[0], &h->ev_bwd_join[1]}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+    h->side = nullptr;
+    h->side_dev = dev;
+    return DPOSER_OK;
+}
 
 template <typename Kin> static bool same_tree(const int32_t* p, int n) {
     if (n != Kin::J) return false;
@@ -1342,20 +1357,28 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
     } else {
         // blend GEMM chunk by chunk on the caller's stream; the skinning of a finished chunk runs on the side stream beside the next
         // chunk's GEMM (matrix pipe beside a streaming kernel), and reads its pose-blend offsets while they are still cache-resident
+        DP_TRY(side_streams_for_current_device(h));
         if (!h->side) {
             DP_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
             for (hipEvent_t* e : {&h->ev_chunk[0], &h->ev_chunk[1], &h->ev_join}) DP_CHECK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
-        int k = 0;
-        for (int64_t b0 = 0; b0 < batch; b0 += chunk, ++k) {
-            const int64_t r1 = b0 + chunk < blend.Bpad ? b0 + chunk : blend.Bpad;
-            DP_TRY(lbs_blend_rows(blend, b0, b0 + chunk >= batch ? blend.Bpad : r1, st));
-            DP_CHECK_HIP(hipEventRecord(h->ev_chunk[k & 1], st));
-            DP_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_chunk[k & 1], 0));
-            DP_TRY(skin(b0, (b0 + chunk < batch ? b0 + chunk : batch) - b0, h->side));
-        }
+        // (a failing launch must not leave the side stream's kernels unjoined: the caller may free or reuse the workspace as soon as
+        //  this call has returned -- the join below runs on the error path too)
+        auto chunks = [&]() -> int {
+            int k = 0;
+            for (int64_t b0 = 0; b0 < batch; b0 += chunk, ++k) {
+                const int64_t r1 = b0 + chunk < blend.Bpad ? b0 + chunk : blend.Bpad;
+                DP_TRY(lbs_blend_rows(blend, b0, b0 + chunk >= batch ? blend.Bpad : r1, st));
+                DP_CHECK_HIP(hipEventRecord(h->ev_chunk[k & 1], st));
+                DP_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_chunk[k & 1], 0));
+                DP_TRY(skin(b0, (b0 + chunk < batch ? b0 + chunk : batch) - b0, h->side));
+            }
+            return DPOSER_OK;
+        };
+        const int rc_chunks = chunks();
         DP_CHECK_HIP(hipEventRecord(h->ev_join, h->side));
         DP_CHECK_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
+        if (rc_chunks != DPOSER_OK) return rc_chunks;
     }
     // 4. extra joints + landmarks
     if (h->d.num_extra + h->d.num_landmarks > 0) {
@@ -2069,17 +2092,33 @@ struct SkinBwdMfmaArgs {
     float* dA;                 // [B][J][12]
     int chunks;
     int64_t B;
+    // TMP (motion-denoising loop, run/motion_denoising.py:253-255): the vertex gradient is NOT read -- it is the temporal term's,
+    //   d/dv[t] of w/((F-1)V) sum_{t,v} ||v[t] - v[t+1]|| = c (u_t - u_{t-1}),  u_t = (v[t] - v[t+1]) / ||v[t] - v[t+1]||,
+    // formed here from the skinned vertices of the pose itself and of its two neighbouring frames (k_skin_x4's expression for the
+    // vertices, k_md_vert_grad's for the gradient and the distance sums, operation for operation: the bits of that pair of kernels).
+    int F;                     // frames per sequence (the poses of a batch of sequences are consecutive)
+    float c;                   // weight / ((F - 1) V)
+    float* part4;              // [B][chunks][4]: per wave, the sum over its 64 vertices of ||v[t] - v[t+1]|| (0 for a sequence's last frame)
 };
-template <int G, bool VSB> __global__ void __launch_bounds__(256, 2) k_skin_bwd_mfma(SkinBwdMfmaArgs a) {
-    __shared__ __attribute__((aligned(16))) float sA[G][64 * 12];
+template <int G, bool VSB, bool TMP = false> __global__ void __launch_bounds__(256, 2) k_skin_bwd_mfma(SkinBwdMfmaArgs a) {
+    constexpr int NQ = TMP ? G + 2 : G;             // pose slots: TMP adds the frame in front of the workgroup's poses (slot 0) and the one behind (slot G + 1)
+    constexpr int Q0 = TMP ? 1 : 0;                 // slot of the workgroup's first own pose
+    __shared__ __attribute__((aligned(16))) float sA[NQ][64 * 12];
     __shared__ __attribute__((aligned(16))) __bf16 sP[4][2][SBM_PLANE];     // [wave][hi | lo][product row][the wave's 64 vertices]
     __shared__ __attribute__((aligned(16))) float stage[4][G][192];         // [wave][pose]: g = d loss / d v_posed of the wave's vertices, coordinate-major
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t b0 = (int64_t)blockIdx.x * G;
+    // pose of slot q (clamped to the batch: a clamped slot is never used -- own poses beyond the batch are masked, the neighbour
+    // slots of a sequence's first / last frame too)
+    auto slot_pose = [&](int q) __attribute__((always_inline)) -> int64_t {
+        int64_t b = b0 + q - Q0;
+        b = b < 0 ? 0 : b;
+        return b < a.B ? b : (TMP ? a.B - 1 : b0);
+    };
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int64_t b = b0 + g < a.B ? b0 + g : b0;
-        for (int i = tid; i < a.J * 12; i += 256) sA[g][i] = a.A[b * a.J * 12 + i];
+    for (int q = 0; q < NQ; ++q) {
+        const int64_t b = slot_pose(q);
+        for (int i = tid; i < a.J * 12; i += 256) sA[q][i] = a.A[b * a.J * 12 + i];
     }
     for (int i = tid; i < 4 * 2 * SBM_PLANE / 8; i += 256) reinterpret_cast<u32x4*>(&sP[0][0][0])[i] = u32x4{0u, 0u, 0u, 0u};      // (rows 12 ... 15 stay zero)
     f32x4 acc[G][4];
@@ -2090,7 +2129,7 @@ template <int G, bool VSB> __global__ void __launch_bounds__(256, 2) k_skin_bwd_
     // per-vertex data of (pose, chunk): dv and the rest + pose-blend position of this thread's vertex, loaded a whole chunk ahead (the
     // set of pose g is refilled for chunk c + 1 as soon as (g, c) has consumed it: G iterations of lead -- with one iteration of lead
     // every pose and chunk waited for a full HBM round trip, 70 % of the wave cycles)
-    float dvn[G][3], ofn[G][3], vsn[VSB ? G : 1][3];
+    float dvn[TMP ? 1 : G][3], ofn[NQ][3], vsn[VSB ? NQ : 1][3];
     // slot of this thread's vertex in the corrected-row array (extra joints / landmarks folded in: VertGrad), for the chunk whose pose data
     // is being prefetched: the lookup is pose-independent and runs TWO chunks ahead -- as part of every pose's load (vg.row) it put a
     // dependent load in front of every dv load and a full vmcnt(0) drain into every iteration
@@ -2111,16 +2150,20 @@ template <int G, bool VSB> __global__ void __launch_bounds__(256, 2) k_skin_bwd_
             for (int k = 0; k < 3; ++k) vs_nn[k] = a.v_shaped[(int64_t)vc * 3 + k];
         }
     };
-    auto load_pose = [&](int c, int g) __attribute__((always_inline)) {
+    auto load_pose = [&](int c, int g) __attribute__((always_inline)) {       // g: pose slot
         const int v = c * 256 + tid;
         const int vc = v < a.V ? v : a.V - 1;
-        const int64_t b = b0 + g < a.B ? b0 + g : b0;
-        const float* plain = a.dverts + (b * a.V + vc) * 3;
-        const float* corr = fixed + (b * a.vg.U + (slot_pf >= 0 ? slot_pf : 0)) * 3;
-        const float* dvr = slot_pf >= 0 ? corr : plain;
+        const int64_t b = slot_pose(g);
         const float* off = a.offsets + b * a.ld_off + (int64_t)vc * 3;
+        if constexpr (!TMP) {
+            const float* plain = a.dverts + (b * a.V + vc) * 3;
+            const float* corr = fixed + (b * a.vg.U + (slot_pf >= 0 ? slot_pf : 0)) * 3;
+            const float* dvr = slot_pf >= 0 ? corr : plain;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { dvn[g][k] = dvr[k]; ofn[g][k] = off[k]; }
+            for (int k = 0; k < 3; ++k) dvn[g][k] = dvr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ofn[g][k] = off[k];
         if constexpr (VSB) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) vsn[g][k] = a.v_shaped[(b * a.V + vc) * 3 + k];
@@ -2140,7 +2183,7 @@ template <int G, bool VSB> __global__ void __launch_bounds__(256, 2) k_skin_bwd_
 #pragma unroll
     for (int k = 0; k < 3; ++k) vs_pf[k] = vs_nn[k];
 #pragma unroll
-    for (int g = 0; g < G; ++g) load_pose(0, g);
+    for (int q = 0; q < NQ; ++q) load_pose(0, q);
     load_slot(a.chunks > 1 ? 1 : 0);
     __syncthreads();
     __bf16* myP = &sP[wave][0][0];
@@ -2155,7 +2198,7 @@ template <int G, bool VSB> __global__ void __launch_bounds__(256, 2) k_skin_bwd_
         const int jj[4] = {j4n.x, j4n.y, j4n.z, j4n.w};
         // this wave's slice of the chunk's dense skinning weights: joints x its 64 vertices, hi and lo planes
         bf16x8 wf[4][2][2];
-        {
+        auto load_wf = [&]() __attribute__((always_inline)) {
             const bf16x8* wp = a.wfrag + ((int64_t)(c * 4 + wave) * 16) * 64 + lane;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -2163,7 +2206,8 @@ template <int G, bool VSB> __global__ void __launch_bounds__(256, 2) k_skin_bwd_
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int p = 0; p < 2; ++p) wf[mt][kk][p] = wp[((mt * 2 + kk) * 2 + p) * 64];
-        }
+        };
+        if constexpr (!TMP) load_wf();      // (TMP: behind the pre-pass below -- 64 registers that its window of transforms needs)
         const int cn = c + 1 < a.chunks ? c + 1 : c;                         // (the last chunk prefetches itself again: no branch around a load)
         load_chunk(cn);
         const float vs_cur[3] = {vs_pf[0], vs_pf[1], vs_pf[2]};              // the current chunk's rest positions
@@ -2171,15 +2215,97 @@ template <int G, bool VSB> __global__ void __launch_bounds__(256, 2) k_skin_bwd_
 #pragma unroll
         for (int k = 0; k < 3; ++k) vs_pf[k] = vs_nn[k];
         load_slot(c + 2 < a.chunks ? c + 2 : a.chunks - 1);
+        // TMP pre-pass: the temporal term's gradient of the thread's vertex for the G own poses.  The frames are skinned one after the
+        // other as k_skin_x4 skins them (slot 0 = the frame in front of the workgroup's poses, G + 1 = the one behind) with a window of
+        // three vertices and two transforms; per own pose the gradient (k_md_vert_grad's expression), its distance sum and T_R^T dv leave
+        // the window.  The weight fragments of the joint reduction are loaded BEHIND it (with them the window spilled 49 registers).
+        float dvk[TMP ? G : 1][3];
+        if constexpr (TMP) {
+            float Tq[9], vprev[3], vcur[3], hold[3];
+            auto skin_slot = [&](int q, float* T9, float* vout) __attribute__((always_inline)) {
+                float T[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T[i] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4* Aj = reinterpret_cast<const f32x4*>(&sA[q][0]) + jj[k] * 3;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const f32x4 row = Aj[r];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) T[4 * r + i] += w4[k] * row[i];
+                    }
+                }
+                float pq[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) pq[k] = (VSB ? vsn[VSB ? q : 0][k] : vs_cur[k]) + ofn[q][k];      // rest + pose-blend offset, k_skin_x4's operand order
+                const float tr0 = 0.f;         // (k_skin_x4 adds the translation -- none in this loop -- behind the transform: the add is kept, -0 + 0 = +0)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    vout[r] = T[4 * r] * pq[0] + T[4 * r + 1] * pq[1] + T[4 * r + 2] * pq[2] + T[4 * r + 3] + tr0;
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) T9[3 * r + cc] = T[4 * r + cc];
+                }
+            };
+            {
+                float T0[9];
+                skin_slot(0, T0, vprev);
+                load_pose(cn, 0);
+                skin_slot(1, Tq, vcur);
+                // pair (frame in front, first own frame): its backward-difference role only (k_md_vert_grad: v_rsq_f32 of the squared distance)
+                const float ax = vprev[0] - vcur[0], ay = vprev[1] - vcur[1], az = vprev[2] - vcur[2];
+                const float invb = __builtin_amdgcn_rsqf(ax * ax + ay * ay + az * az);
+                hold[0] = ax * invb; hold[1] = ay * invb; hold[2] = az * invb;
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const bool bv = b0 + g < a.B;
+                const int tf = (int)((b0 + g) % a.F);
+                const bool has_prev = tf > 0, has_next = tf + 1 < a.F;
+                float Tn[9], vnext[3];
+                skin_slot(g + 2, Tn, vnext);
+                if (g + 1 == G) load_pose(cn, g + 2);
+                const float ax = vcur[0] - vnext[0], ay = vcur[1] - vnext[1], az = vcur[2] - vnext[2];
+                const float ss = ax * ax + ay * ay + az * az;
+                const float d = sqrtf(ss);
+                const float inv = __builtin_amdgcn_rcpf(d);
+                float gx = 0.f, gy = 0.f, gz = 0.f;
+                if (has_next) { gx = ax * inv; gy = ay * inv; gz = az * inv; }
+                if (has_prev) { gx -= hold[0]; gy -= hold[1]; gz -= hold[2]; }
+                const float invb = __builtin_amdgcn_rsqf(ss);
+                hold[0] = ax * invb; hold[1] = ay * invb; hold[2] = az * invb;
+                const float dx = (live && bv) ? a.c * gx : 0.f, dy = (live && bv) ? a.c * gy : 0.f, dz = (live && bv) ? a.c * gz : 0.f;
+                dvk[g][0] = dx; dvk[g][1] = dy; dvk[g][2] = dz;
+                float dsum = (live && bv && has_next) ? d : 0.f;
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) dsum += __shfl_xor(dsum, sh);
+                if (lane == 0 && bv) a.part4[((b0 + g) * a.chunks + c) * 4 + wave] = dsum;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) stage[wave][g][lane * 3 + cc] = Tq[cc] * dx + Tq[3 + cc] * dy + Tq[6 + cc] * dz;      // T_R^T dv
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Tq[i] = Tn[i];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vcur[k] = vnext[k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_wf();
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const bool bv = b0 + g < a.B;
-            const float dx = (live && bv) ? dvn[g][0] : 0.f, dy = (live && bv) ? dvn[g][1] : 0.f, dz = (live && bv) ? dvn[g][2] : 0.f;
-            const float hv[4] = {ofn[g][0] + (VSB ? vsn[VSB ? g : 0][0] : vs_cur[0]), ofn[g][1] + (VSB ? vsn[VSB ? g : 0][1] : vs_cur[1]),
-                                 ofn[g][2] + (VSB ? vsn[VSB ? g : 0][2] : vs_cur[2]), 1.0f};
-            load_pose(cn, g);
-            // ---- A: thread = vertex
-            {
+            float dx, dy, dz;
+            float hv[4];
+            if constexpr (TMP) {
+                dx = dvk[g][0]; dy = dvk[g][1]; dz = dvk[g][2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) hv[k] = ofn[g + 1][k] + (VSB ? vsn[VSB ? g + 1 : 0][k] : vs_cur[k]);
+                hv[3] = 1.0f;
+                load_pose(cn, g + 1);
+            } else {
+                dx = (live && bv) ? dvn[g][0] : 0.f; dy = (live && bv) ? dvn[g][1] : 0.f; dz = (live && bv) ? dvn[g][2] : 0.f;
+                hv[0] = ofn[g][0] + (VSB ? vsn[VSB ? g : 0][0] : vs_cur[0]); hv[1] = ofn[g][1] + (VSB ? vsn[VSB ? g : 0][1] : vs_cur[1]);
+                hv[2] = ofn[g][2] + (VSB ? vsn[VSB ? g : 0][2] : vs_cur[2]); hv[3] = 1.0f;
+                load_pose(cn, g);
                 float T[9];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) T[i] = 0.f;
@@ -2195,6 +2321,9 @@ template <int G, bool VSB> __global__ void __launch_bounds__(256, 2) k_skin_bwd_
                 }
 #pragma unroll
                 for (int cc = 0; cc < 3; ++cc) stage[wave][g][lane * 3 + cc] = T[cc] * dx + T[3 + cc] * dy + T[6 + cc] * dz;      // T_R^T dv
+            }
+            // ---- A: thread = vertex
+            {
                 const float d3[3] = {dx, dy, dz};
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
@@ -2769,6 +2898,22 @@ extern "C" int dposer_lbs_backward(dposer_body_t h, const void* ws_fwd, void* ws
                                     v_shaped, v_shaped_batched, skin_idx, skin_w, skin_k, joint_ptr, joint_vidx, joint_w, d_verts, d_joints, d_joints_ld,
                                     nullptr, d_pose_segments_host, d_jrest, d_vposed, batch, stream);
 }
+// the temporal term of the motion-denoising loss as the vertex gradient (k_skin_bwd_mfma<TMP>): frames per sequence, weight / ((F - 1) V),
+// per-wave distance sums [batch][ceil(V / 256)][4]
+struct LbsTemporal { int64_t F; float scale; float* part4; };
+static bool lbs_temporal_in_backward_ok(dposer_body_t h, int32_t skin_k, int64_t batch) {
+    return h && !lbs_blend_fp32() && skin_k == 4 && h->jl_ready && h->jl_fused_ok && h->jl_mfma_ok && batch >= lbs_joint_stream_min() &&
+           body_tuning().skin_bwd_fused && body_tuning().skin_bwd_mfma != 0 && (int64_t)h->jl_chunks * 768 >= lbs_cpad(h->d.num_vertices) &&
+           h->jl_chunks == (int)ceil_div(h->d.num_vertices, 256);
+}
+extern "C" int32_t dposer_lbs_temporal_in_backward_ok(dposer_body_t h, int32_t skin_k, int64_t batch) { return lbs_temporal_in_backward_ok(h, skin_k, batch) ? 1 : 0; }
+static int lbs_backward_impl(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
+                             const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,
+                             const float* j_rest, int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched,
+                             const int32_t* skin_idx, const float* skin_w, int32_t skin_k, const int32_t* joint_ptr,
+                             const int32_t* joint_vidx, const float* joint_w, const float* d_verts, const float* d_joints,
+                             int64_t d_joints_ld, const dposer_lbs_joint_fold* fold, float* const* d_pose_segments_host, float* d_jrest,
+                             float* d_vposed, int64_t batch, void* stream, const LbsTemporal* tmp);
 extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
                                         const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,
                                         const float* j_rest, int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched,
@@ -2777,11 +2922,55 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
                                         int64_t d_joints_ld, const dposer_lbs_joint_fold* fold, float* const* d_pose_segments_host, float* d_jrest,
                                         float* d_vposed, int64_t batch, void* stream) {
     DP_RANGE();
+    DP_CHECK_ARG(d_verts, "null argument");
+    return lbs_backward_impl(h, ws_fwd, ws_bwd, posedirs_bwd_packed, pose_segments_host, segment_joints_host, num_segments, j_rest, j_rest_batched, v_shaped,
+                             v_shaped_batched, skin_idx, skin_w, skin_k, joint_ptr, joint_vidx, joint_w, d_verts, d_joints, d_joints_ld, fold,
+                             d_pose_segments_host, d_jrest, d_vposed, batch, stream, nullptr);
+}
+// LBS backward of the motion-denoising step (run/motion_denoising.py:253-267) WITHOUT a vertex gradient in HBM: d loss / d vertices is the
+// temporal term's, formed inside the skinning-backward kernel from the forward workspace (skinning transforms + pose-blend offsets of the
+// pose and of its two neighbouring frames); d_joints carries the data term.  dist_part4 [batch][ceil(V / 256)][4] receives the per-wave sums
+// of ||v[t] - v[t+1]|| (0 behind a sequence's last frame): ((p0 + p1) + p2) + p3 of an entry is k_md_vert_grad's block sum.  Needs
+// dposer_lbs_temporal_in_backward_ok(); bit-identical to dposer_lbs_forward + k_md_vert_grad + dposer_lbs_backward.
+extern "C" int dposer_lbs_backward_temporal(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
+                                            const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,
+                                            const float* j_rest, int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched,
+                                            const int32_t* skin_idx, const float* skin_w, int32_t skin_k, const int32_t* joint_ptr,
+                                            const int32_t* joint_vidx, const float* joint_w, int64_t frames_per_sequence, float scale,
+                                            float* dist_part4, const float* d_joints, int64_t d_joints_ld, float* const* d_pose_segments_host,
+                                            int64_t batch, void* stream) {
+    DP_RANGE();
+    DP_CHECK_ARG(dist_part4 && frames_per_sequence >= 2 && batch > 0 && batch % frames_per_sequence == 0, "batch must be whole sequences of >= 2 frames");
+    if (!lbs_temporal_in_backward_ok(h, skin_k, batch))
+        return dposer_set_error(DPOSER_ERR_UNSUPPORTED, "dposer_lbs_backward_temporal: needs the matrix-pipe skinning backward (4 influences per vertex, prepared joint lists, batch >= DPOSER_LBS_JOINT_STREAM_MIN)");
+    LbsTemporal t;
+    t.F = frames_per_sequence; t.scale = scale; t.part4 = dist_part4;
+    return lbs_backward_impl(h, ws_fwd, ws_bwd, posedirs_bwd_packed, pose_segments_host, segment_joints_host, num_segments, j_rest, j_rest_batched, v_shaped,
+                             v_shaped_batched, skin_idx, skin_w, skin_k, joint_ptr, joint_vidx, joint_w, nullptr, d_joints, d_joints_ld, nullptr,
+                             d_pose_segments_host, nullptr, nullptr, batch, stream, &t);
+}
+// FK + pose-blend offsets of dposer_lbs_forward WITHOUT the skinning kernel: joints[:, :J] and the workspace (pose feature, skinning transforms,
+// offsets) that dposer_lbs_backward_temporal reads.  The rows of `joints` behind the kinematic tree (extra vertices, landmarks) are not written.
+extern "C" int dposer_lbs_forward_front(dposer_body_t h, void* ws, const void* posedirs_packed, const float* const* pose_segments_host,
+                                        const int32_t* segment_joints_host, int32_t num_segments, const float* j_rest, int32_t j_rest_batched,
+                                        const float* transl, float* joints, int64_t batch, void* stream) {
+    DP_RANGE();
+    float *A = nullptr, *offsets = nullptr;
+    return lbs_forward_front(h, ws, posedirs_packed, pose_segments_host, segment_joints_host, num_segments, j_rest, j_rest_batched, transl, joints, batch,
+                             stream, &A, &offsets);
+}
+static int lbs_backward_impl(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
+                             const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,
+                             const float* j_rest, int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched,
+                             const int32_t* skin_idx, const float* skin_w, int32_t skin_k, const int32_t* joint_ptr,
+                             const int32_t* joint_vidx, const float* joint_w, const float* d_verts, const float* d_joints,
+                             int64_t d_joints_ld, const dposer_lbs_joint_fold* fold, float* const* d_pose_segments_host, float* d_jrest,
+                             float* d_vposed, int64_t batch, void* stream, const LbsTemporal* tmp) {
     DP_CHECK_ARG(!fold || (fold->n_slots >= 0 && fold->n_slots <= h->d.num_vertices && (fold->n_slots == 0 || (fold->vertex_slot && fold->slot_vertex &&
                                                                                      fold->slot_ptr && fold->entry_row && fold->entry_weight))),
                  "bad joint fold tables");
     DP_CHECK_ARG(h && ws_fwd && ws_bwd && posedirs_bwd_packed && pose_segments_host && segment_joints_host && j_rest && v_shaped && skin_idx &&
-                     skin_w && joint_ptr && joint_vidx && joint_w && d_verts && d_joints && d_pose_segments_host,
+                     skin_w && joint_ptr && joint_vidx && joint_w && (d_verts || tmp) && d_joints && d_pose_segments_host,
                  "null argument");
     DP_CHECK_ARG(batch > 0 && num_segments >= 1 && num_segments <= FK_MAX_SEG, "bad size");
     hipStream_t st = (hipStream_t)stream;
@@ -2834,7 +3023,11 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
         a.dverts = d_verts; a.offsets = offsets; a.ld_off = Cpad; a.v_shaped = v_shaped; a.v_shaped_batched = v_shaped_batched; a.A = A;
         a.skin_idx = skin_idx; a.skin_w = skin_w; a.J = J; a.V = V; a.dvp = d_vposed; a.doff_hi = doff_hi; a.doff_lo = doff_lo; a.Cpad = (int)Cpad;
         a.wfrag = reinterpret_cast<const bf16x8*>(h->jl_wfrag); a.dA = dA; a.chunks = h->jl_chunks; a.B = batch;
-        if (mfma_g == 2) {
+        a.F = tmp ? (int)tmp->F : 1; a.c = tmp ? tmp->scale : 0.f; a.part4 = tmp ? tmp->part4 : nullptr;
+        if (tmp) {
+            if (v_shaped_batched) hipLaunchKernelGGL((k_skin_bwd_mfma<4, true, true>), dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_skin_bwd_mfma<4, false, true>), dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, st, a);
+        } else if (mfma_g == 2) {
             if (v_shaped_batched) hipLaunchKernelGGL((k_skin_bwd_mfma<2, true>), dim3((unsigned)ceil_div(batch, 2)), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_skin_bwd_mfma<2, false>), dim3((unsigned)ceil_div(batch, 2)), dim3(256), 0, st, a);
         } else {
@@ -2920,6 +3113,7 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
         const int k1 = kbig ? kbig : lbs_bwd_ksplit_bf16(kb, (Bpad / 128) * (pe / 128), (int)(fit < 1 ? 1 : (fit > 24 ? 24 : fit)));
         const bool fork = par && kbig;
         if (fork) {
+            DP_TRY(side_streams_for_current_device(h));
             if (!h->bwd_side[0]) {
                 for (hipStream_t* q : {&h->bwd_side[0], &h->bwd_side[1]}) DP_CHECK_HIP(hipStreamCreateWithFlags(q, hipStreamNonBlocking));
                 for (hipEvent_t* e : {&h->ev_bwd_fork, &h->ev_bwd_join[0], &h->ev_bwd_join[1]}) DP_CHECK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -2927,7 +3121,10 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
             DP_CHECK_HIP(hipEventRecord(h->ev_bwd_fork, st));
             for (int i = 0; i < 2; ++i) DP_CHECK_HIP(hipStreamWaitEvent(h->bwd_side[i], h->ev_bwd_fork, 0));
         }
-        for (int term = 0; term < 3; ++term) {
+        // (between fork and join nothing returns: a failed launch of one term still joins the side streams back into `st` -- the caller
+        //  may free or reuse ws_bwd as soon as this call has returned -- and is reported afterwards)
+        hipError_t term_err = hipSuccess;
+        for (int term = 0; term < 3 && term_err == hipSuccess; ++term) {
             hipStream_t ts = (fork && term > 0) ? h->bwd_side[term - 1] : st;
             GemmArgs g;
             std::memset(&g, 0, sizeof(g));
@@ -2938,7 +3135,7 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
             WgradParams wp;
             wp.slab = dpf + (int64_t)term * k1 * Bpad * pe; wp.slab_stride = Bpad * pe; wp.ld = (int)pe; wp.N_valid = (int)batch;
             wp.K_valid = (int)((J - 1) * 9 < pe ? (J - 1) * 9 : pe);
-            FK_HIP_LAUNCH(gemm_wgrad(PREC_BF16, kbig ? SHAPE_BIG : SHAPE_MID, g, wp, ts));
+            term_err = gemm_wgrad(PREC_BF16, kbig ? SHAPE_BIG : SHAPE_MID, g, wp, ts);
         }
         if (fork) {
             for (int i = 0; i < 2; ++i) {
@@ -2946,6 +3143,7 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
                 DP_CHECK_HIP(hipStreamWaitEvent(st, h->ev_bwd_join[i], 0));
             }
         }
+        FK_HIP_LAUNCH(term_err);
         ks = 3 * k1;
     }
     {

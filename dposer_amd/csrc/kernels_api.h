@@ -66,6 +66,9 @@ hipError_t launch_prep_train(const PrepTrainArgs& a, hipStream_t st);
 
 // time embedding rows for a list of labels (labels == null: every row uses label0): emb FT32 [Npad][E]
 hipError_t launch_time_embed(const float* labels, float label0, int64_t n, int64_t npad, const float* freq, int E, int fourier, float* emb_ft32, hipStream_t st);
+// VE labels in place: t[i] -> sigma(t[i]) = sigma_min * (sigma_max / sigma_min)^t with the DEVICE's powf -- the value every kernel that perturbs with /
+// divides by sigma(t) forms for itself (host libm's powf may differ by an ulp)
+hipError_t launch_ve_labels(float* t_inout, int n, float smin, float ratio, hipStream_t st);
 
 // ---- output stages ---------------------------------------------------------------------------------
 struct OutModelArgs {      // ScoreModelFC.forward tail: res / used_sigmas   (model.py:189-196)

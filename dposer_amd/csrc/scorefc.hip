@@ -838,11 +838,26 @@ static SdeCfg to_sde(const dposer_sde_desc* s) {
 }
 
 static bool sde_kind_ok(const dposer_sde_desc* s) { return s->kind == DPOSER_SDE_SUBVP || s->kind == DPOSER_SDE_VP || s->kind == DPOSER_SDE_VE; }
-// what the network is conditioned on at time t: t * 999 (utils.py:152) or, for VE, sigma(t) (utils.py:173) -- fp32, as the kernels form it
-static float sde_label_host(const dposer_sde_desc* s, float t) {
-    if (s->kind != DPOSER_SDE_VE) return t * 999.0f;
-    const SdeDev d = make_sde_dev(to_sde(s));
-    return sde_ve_sigma(d.smin, d.ratio, t);
+// What the network is conditioned on at the n step times `t_host`, into w.tt_labels: t * 999 (utils.py:152: one IEEE fp32 product, the same
+// bits on host and device) or, for VE, sigma(t) (utils.py:173) -- formed ON THE DEVICE from the staged times (k_ve_labels), because every
+// kernel that perturbs with sigma(t) / divides the output by it calls the device's powf, and the host's libm may round the last bit the other way.
+static int stage_step_labels(dposer_scorefc_s* h, Ws& w, const dposer_sde_desc* s, const float* t_host, int n, hipStream_t st) {
+    const bool ve = s && s->kind == DPOSER_SDE_VE;
+    h->host_stage.resize(n);
+    for (int i = 0; i < n; ++i) h->host_stage[i] = ve ? t_host[i] : t_host[i] * 999.0f;
+    DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
+    if (ve) {
+        const SdeDev d = make_sde_dev(to_sde(s));
+        DP_HIP_LAUNCH(launch_ve_labels(w.tt_labels, n, d.smin, d.ratio, st));
+    }
+    return DPOSER_OK;
+}
+// the one-row time table of a call at a single time t
+static int build_time_table_at(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, const dposer_sde_desc* s, float t, const float* freq,
+                               hipStream_t st) {
+    if (!s || s->kind != DPOSER_SDE_VE) return build_time_table(h, flat, packed, w, nullptr, t * 999.0f, 1, freq, st);      // the label travels by value
+    DP_TRY(stage_step_labels(h, w, s, &t, 1, st));
+    return build_time_table(h, flat, packed, w, w.tt_labels, 0.f, 1, freq, st);
 }
 static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde, float* x,
                            float* x_mean, const float* timesteps_host, int32_t start_step, int32_t n_steps, const float* observation,
@@ -882,10 +897,8 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     if (n_run == 0) return DPOSER_OK;
     Ws w;
     layout_ws(h, B, DPOSER_WS_SHARED_T, n_run, (char*)ws_, w);
-    // labels = t * 999 (utils.py:152), fp32 product on the host, one H2D copy
-    h->host_stage.resize(n_run);
-    for (int i = 0; i < n_run; ++i) h->host_stage[i] = sde_label_host(sde, timesteps_host[start_step + i]);
-    DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n_run * sizeof(float), hipMemcpyHostToDevice, st));
+    // labels = t * 999 (utils.py:152; VE: sigma(t), on the device), one H2D copy
+    DP_TRY(stage_step_labels(h, w, sde, timesteps_host + start_step, n_run, st));
     DP_TRY(build_time_table(h, flat, packed, w, w.tt_labels, 0.f, n_run, freq, st));
 
     const SdeCfg sc = to_sde(sde);
@@ -1029,7 +1042,7 @@ extern "C" int dposer_langevin_step(dposer_scorefc_t h, const float* flat, const
     a.Cp = h->Cp; a.num_scales = h->d.num_scales; a.scale_by_sigma = sbs_mode(h); a.f32 = h->f32; a.sde = to_sde(sde); a.seed = seed;
     a.step = step;
     if (phase == 0) {
-        DP_TRY(build_time_table(h, flat, packed, w, nullptr, sde_label_host(sde, t), 1, freq, st));
+        DP_TRY(build_time_table_at(h, flat, packed, w, sde, t, freq, st));
         DP_HIP_LAUNCH(launch_pack_rows(x, w.xin, B, w.Bpad, h->D, h->Dpad, h->f32, st));
         DP_TRY(run_shared_t(h, flat, packed, w, 0, B, st));
         int nb = 0;
@@ -1056,7 +1069,7 @@ static int prior_loss_impl(dposer_scorefc_t h, const float* flat, const void* pa
     const char* packed = (const char*)packed_;
     Ws w;
     layout_ws(h, B, DPOSER_WS_SHARED_T, table_rows > 0 ? table_rows : 1, (char*)ws_, w);
-    if (table_rows <= 0) DP_TRY(build_time_table(h, flat, packed, w, nullptr, sde_label_host(sde, t), 1, freq, st));
+    if (table_rows <= 0) DP_TRY(build_time_table_at(h, flat, packed, w, sde, t, freq, st));
     const SdeCfg sc = to_sde(sde);
     PerturbSharedArgs pa;
     pa.x0 = x0; pa.z_in = z; pa.xin = w.xin; pa.xt = w.xt; pa.t = t; pa.B = B; pa.Bpad = w.Bpad; pa.D = h->D; pa.Dpad = h->Dpad;
@@ -1092,9 +1105,7 @@ extern "C" int dposer_prior_table_build_sde(dposer_scorefc_t h, const float* fla
     hipStream_t st = (hipStream_t)stream;
     Ws w;
     layout_ws(h, B, DPOSER_WS_SHARED_T, n_rows, (char*)ws_, w);
-    h->host_stage.resize(n_rows);
-    for (int i = 0; i < n_rows; ++i) h->host_stage[i] = sde ? sde_label_host(sde, t_host[i]) : t_host[i] * 999.0f;     // labels = t * 999 (utils.py:152); VE: sigma(t)
-    DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n_rows * sizeof(float), hipMemcpyHostToDevice, st));
+    DP_TRY(stage_step_labels(h, w, sde, t_host, n_rows, st));      // labels = t * 999 (utils.py:152); VE: sigma(t)
     return build_time_table(h, flat, (const char*)packed_, w, w.tt_labels, 0.f, n_rows, freq, st);
 }
 extern "C" int dposer_prior_loss_tabled(dposer_scorefc_t h, const float* flat, const void* packed_, void* ws_, const dposer_sde_desc* sde,
@@ -1128,9 +1139,7 @@ extern "C" int dposer_completion_optimize(dposer_scorefc_t h, const float* flat,
     const char* packed = (const char*)packed_;
     Ws w;
     layout_ws(h, B, DPOSER_WS_SHARED_T, n_steps, (char*)ws_, w);
-    h->host_stage.resize(n_steps);
-    for (int i = 0; i < n_steps; ++i) h->host_stage[i] = sde_label_host(sde, t_host[i]);      // labels = t * 999 (utils.py:152) / sigma(t) (VE, :173)
-    DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n_steps * sizeof(float), hipMemcpyHostToDevice, st));
+    DP_TRY(stage_step_labels(h, w, sde, t_host, n_steps, st));      // labels = t * 999 (utils.py:152) / sigma(t) (VE, :173)
     DP_TRY(build_time_table(h, flat, packed, w, w.tt_labels, 0.f, n_steps, freq, st));
     const SdeCfg sc = to_sde(sde);
     const int64_t BD = B * h->D;

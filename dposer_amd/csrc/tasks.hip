@@ -119,6 +119,7 @@ template <bool IEEE> __global__ void __launch_bounds__(256) k_md_vert_grad(const
 // zero residual contributes the value ~0 and a zero gradient (sqrt'(0) = inf would poison the backward pass).
 __global__ void __launch_bounds__(256) k_md_joint(const float* joints, int64_t ld, const float* obs, float* djoints, int T, int n_obs, float w_data,
                                                   const float* temp_part, int n_temp_part, float temp_scale, const float* prior_loss, float* log3) {
+    // (n_temp_part = 0: the temporal term's distance sums do not exist yet -- k_md_temp_log writes log3[0] behind the LBS backward)
     __shared__ float red[4];
     // block = one sequence of T frames
     joints += (int64_t)blockIdx.x * T * ld; djoints += (int64_t)blockIdx.x * T * ld; obs += (int64_t)blockIdx.x * T * n_obs * 3;
@@ -156,6 +157,20 @@ __global__ void __launch_bounds__(256) k_md_joint(const float* joints, int64_t l
         const float temp = block_sum(tp, red) * temp_scale;
         if (threadIdx.x == 0) { log3[0] = temp; log3[1] = keep ? mean : 0.f; log3[2] = prior_loss[0]; }
     }
+}
+
+// log3[0] of a step whose temporal term is formed inside the skinning backward (dposer_lbs_backward_temporal): the per-wave distance sums
+// [frames][vb][4] arrive behind that kernel; ((p0 + p1) + p2) + p3 of an entry is k_md_vert_grad's block sum, the rest is k_md_joint's sum
+__global__ void __launch_bounds__(256) k_md_temp_log(const float* part4, int n_temp_part, float temp_scale, float* log3) {
+    __shared__ float red[4];
+    part4 += (int64_t)blockIdx.x * n_temp_part * 4;
+    float tp = 0.f;
+    for (int i = threadIdx.x; i < n_temp_part; i += 256) {
+        const float* p = part4 + (int64_t)i * 4;
+        tp += p[0] + p[1] + p[2] + p[3];
+    }
+    const float temp = block_sum(tp, red) * temp_scale;
+    if (threadIdx.x == 0) log3[3 * (int64_t)blockIdx.x] = temp;
 }
 
 // d pose = LBS gradient + w_prior * normalise^T(d prior / d x_n); torch.optim.Adam (single-tensor arithmetic, as k_completion_update)
@@ -228,7 +243,7 @@ Scratch layout(char* base, int64_t T, int D, int V, int n_joint_rows, int n_part
     s.xn = take(T * D * 2); s.gprior = take(T * D * 2); s.loss1 = take(64);      // (2 D: the 6-D representation of rot_rep = 'rot6d')
     s.verts = take(T * V * 3); s.joints = take(T * n_joint_rows * 3);
     s.dverts = take(T * V * 3); s.djoints = take(T * n_joint_rows * 3);
-    s.dpose = take(T * D); s.part = take(n_part);
+    s.dpose = take(T * D); s.part = take((int64_t)n_part * 4);      // (x 4: per-wave sums when the temporal term is formed inside the skinning backward)
     s.bytes = p - base;
     return s;
 }
@@ -286,14 +301,19 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     // DPOSER_MD_FUSED_TEMPORAL_MIN_SEQ = 4 sequences per call: a workgroup of the fused kernel walks >= 10 frames one after the other;
     // measured 0.60 vs 0.67 ms per step at 8 sequences of 60 frames, a tie at one)
     bool fused_temporal = a->skin_k == 4 && F <= 4096 && n_seq <= 16384;
+    // DPOSER_MD_FUSED_TEMPORAL = 2 (default wherever dposer_lbs_temporal_in_backward_ok: from 320 frames per call): the temporal term's
+    // gradient is formed INSIDE the skinning backward from the forward's transforms and offsets -- no skinning kernel, no vertices and no
+    // vertex gradient in HBM (k_skin_temporal wrote 967 MB at 7680 frames that k_skin_bwd_mfma read back; 2.71 -> see profiles/r06_md_*.md)
+    bool temporal_in_backward = dposer_lbs_temporal_in_backward_ok(a->body, a->skin_k, T) != 0;
     bool ieee_div = false;
     { const char* e = getenv("DPOSER_MD_IEEE_DIV"); ieee_div = e && e[0] == '1'; }
-    if (ieee_div) fused_temporal = false;                    // (the A/B switch exists in the two-kernel form only)
+    if (ieee_div) { fused_temporal = false; temporal_in_backward = false; }      // (the A/B switch exists in the two-kernel form only)
     {
         const char* e = getenv("DPOSER_MD_FUSED_TEMPORAL");
         const char* m = getenv("DPOSER_MD_FUSED_TEMPORAL_MIN_SEQ");
-        if (e && e[0] == '0') fused_temporal = false;
-        else if (!(e && e[0] == '1')) fused_temporal = fused_temporal && n_seq >= (m ? atoll(m) : 4);
+        if (e && e[0] == '0') { fused_temporal = false; temporal_in_backward = false; }
+        else if (e && e[0] == '1') temporal_in_backward = false;
+        else if (!(e && e[0] == '2')) fused_temporal = fused_temporal && n_seq >= (m ? atoll(m) : 4);
     }
 
     // time-bias rows of all steps: two small GEMMs once instead of per step
@@ -306,7 +326,11 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
                                         a->t_host[k], k, a->n_steps, a->weighted, 1.0f / (float)F, nullptr, s.gprior, s.loss1, a->seed,
                                         a->step0 + (uint32_t)k, a->sigmas, T, stream));
         const float c_temp = a->w_temp_host[k] / ((float)(F - 1) * (float)V);
-        if (fused_temporal) {
+        if (temporal_in_backward) {
+            // FK + pose-blend offsets only: the skinned vertices exist in registers of the backward kernel, nowhere else
+            DP_TRY(dposer_lbs_forward_front(a->body, a->lbs_ws_fwd, a->posedirs_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest,
+                                            a->rest_batched, nullptr, s.joints, T, stream));
+        } else if (fused_temporal) {
             // the vertices only feed the temporal term: skinning and that term's gradient in one pass, no vertices in HBM (the joints
             // beyond the kinematic tree -- extra vertices, landmarks -- are not formed: the data term reads observed tree joints only)
             DP_TRY(dposer_lbs_forward_temporal_grad(a->body, a->lbs_ws_fwd, a->posedirs_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest,
@@ -321,9 +345,19 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
             TK_HIP_LAUNCH(hipGetLastError());
         }
         hipLaunchKernelGGL(k_md_joint, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)s.joints, (int64_t)a->joint_rows * 3, a->joints_obs, s.djoints,
-                           (int)F, a->n_obs_joints, a->w_data_host[k], (const float*)s.part, vb * (int)F, 1.0f / ((float)(F - 1) * (float)V),
-                           (const float*)s.loss1, a->loss_log ? a->loss_log + 3 * (int64_t)k * n_seq : nullptr);
+                           (int)F, a->n_obs_joints, a->w_data_host[k], (const float*)s.part, temporal_in_backward ? 0 : vb * (int)F,
+                           1.0f / ((float)(F - 1) * (float)V), (const float*)s.loss1, a->loss_log ? a->loss_log + 3 * (int64_t)k * n_seq : nullptr);
         TK_HIP_LAUNCH(hipGetLastError());
+        if (temporal_in_backward) {
+            DP_TRY(dposer_lbs_backward_temporal(a->body, a->lbs_ws_fwd, a->lbs_ws_bwd, a->posedirs_bwd_packed, segs, a->segment_joints_host, a->num_segments,
+                                                a->j_rest, a->rest_batched, a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, a->joint_ptr,
+                                                a->joint_vidx, a->joint_w, F, c_temp, s.part, s.djoints, (int64_t)a->joint_rows * 3, dsegs, T, stream));
+            if (a->loss_log) {
+                hipLaunchKernelGGL(k_md_temp_log, dim3((unsigned)n_seq), dim3(256), 0, st, (const float*)s.part, vb * (int)F, 1.0f / ((float)(F - 1) * (float)V),
+                                   a->loss_log + 3 * (int64_t)k * n_seq);
+                TK_HIP_LAUNCH(hipGetLastError());
+            }
+        } else
         DP_TRY(dposer_lbs_backward(a->body, a->lbs_ws_fwd, a->lbs_ws_bwd, a->posedirs_bwd_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest,
                                    a->rest_batched, a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, a->joint_ptr, a->joint_vidx, a->joint_w,
                                    s.dverts, s.djoints, (int64_t)a->joint_rows * 3, dsegs, nullptr, nullptr, T, stream));

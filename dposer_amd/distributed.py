@@ -29,9 +29,30 @@ def _forced():
     return os.environ.get("DPOSER_DIST_FORCE_COLLECTIVES") == "1"
 
 
+_LOCAL_ONLY = 0
+
+
 def dp_active():
-    """True when collectives have to run: a process group with more than one rank (or a forced one-rank group)."""
-    return is_initialized() and (dist.get_world_size() > 1 or _forced())
+    """True when collectives have to run: a process group with more than one rank (or a forced one-rank group) -- and no
+    ``local_only()`` block is open."""
+    return _LOCAL_ONLY == 0 and is_initialized() and (dist.get_world_size() > 1 or _forced())
+
+
+class local_only:
+    """``with local_only():`` -- inside a data-parallel job, run the enclosed steps as a single-process job would (no collective, no
+    per-rank Philox offset): bench.py times the N = 1 step of the SAME build on every rank's GPU this way, next to the N-rank number.
+    Every rank must leave the block before the next collective; parameters that were stepped inside it have diverged between the ranks
+    (the caller restores or re-broadcasts them)."""
+
+    def __enter__(self):
+        global _LOCAL_ONLY
+        _LOCAL_ONLY += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _LOCAL_ONLY
+        _LOCAL_ONLY -= 1
+        return False
 
 
 def world_size():

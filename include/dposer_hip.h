@@ -426,6 +426,29 @@ int dposer_lbs_forward_temporal_grad(dposer_body_t h, void* ws, const void* pose
                                      int32_t skin_k, const float* transl, int64_t frames_per_sequence, float scale, float* d_verts,
                                      float* dist_part, float* joints, int64_t batch, void* stream);
 
+/* The same step with NO vertex-sized array in HBM at all (round 6; run/motion_denoising.py:217-218,253-267):
+ *   dposer_lbs_forward_front          FK + pose-blend offsets of dposer_lbs_forward without its skinning kernel: joints[:, :J] and the
+ *                                     workspace `ws` (pose feature, skinning transforms, offsets);
+ *   dposer_lbs_backward_temporal      dposer_lbs_backward whose vertex gradient is the temporal term's -- scale * (u_t - u_{t-1}) -- formed
+ *                                     inside the skinning-backward kernel from `ws_fwd` (the vertices of a frame and of its two neighbours
+ *                                     are skinned in registers); d_joints carries the data term.  dist_part4 [B, ceil(V/256), 4] out: per-wave
+ *                                     sums of ||v[t] - v[t+1]||, ((p0 + p1) + p2) + p3 of an entry = dist_part of dposer_lbs_forward_temporal_grad.
+ *                                     Bit-identical to dposer_lbs_forward + the two-kernel gradient + dposer_lbs_backward.
+ *   dposer_lbs_temporal_in_backward_ok(h, skin_k, batch): 1 when dposer_lbs_backward_temporal can run (prepared joint lists with the
+ *                                     matrix-pipe tables, four influences per vertex, batch >= DPOSER_LBS_JOINT_STREAM_MIN, bf16 x 3 blend);
+ *                                     dposer_motion_denoise_optimize asks it and falls back to the forms above. */
+int32_t dposer_lbs_temporal_in_backward_ok(dposer_body_t h, int32_t skin_k, int64_t batch);
+int dposer_lbs_forward_front(dposer_body_t h, void* ws, const void* posedirs_packed, const float* const* pose_segments_host,
+                             const int32_t* segment_joints_host, int32_t num_segments, const float* j_rest, int32_t j_rest_batched,
+                             const float* transl, float* joints, int64_t batch, void* stream);
+int dposer_lbs_backward_temporal(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
+                                 const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,
+                                 const float* j_rest, int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched,
+                                 const int32_t* skin_idx, const float* skin_w, int32_t skin_k, const int32_t* joint_ptr,
+                                 const int32_t* joint_vidx, const float* joint_w, int64_t frames_per_sequence, float scale,
+                                 float* dist_part4, const float* d_joints, int64_t d_joints_ld, float* const* d_pose_segments_host,
+                                 int64_t batch, void* stream);
+
 /* Backward of dposer_lbs_forward (autograd of BodyModel.forward w.r.t. pose / rest joints / v_posed; the reference
  * differentiates through smplx in run/motion_denoising.py:217-218,255-267 and run/smplify.py:200-260).
  *   ws_fwd: the workspace of the matching forward call (unmodified since);  posedirs_bwd_packed:

@@ -229,7 +229,7 @@ def test_bench_runs_as_two_ranks_launched_by_torchrun():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DPOSER_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, DPOSER_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", DPOSER_BENCH_N1_LEG="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--global-batch", "8192", "--no-extra", "--no-cpu-baseline"]
@@ -251,6 +251,18 @@ def test_bench_runs_as_two_ranks_launched_by_torchrun():
     assert dp["allreduce_bytes_per_step"] == live, (dp["allreduce_bytes_per_step"], live)
     assert 0.0 <= dp["exposed_allreduce_ms_per_step"] <= dp["rank_ms_per_step"]
     assert abs(dp["rank_compute_ms_per_step"] + dp["exposed_allreduce_ms_per_step"] - dp["rank_ms_per_step"]) < 1e-6
+    # ... and self-validating: the communicator's own size, which device every rank ran on, every rank's step time, and the N = 1 step
+    # of the same build on every rank's GPU (here both ranks share cuda:0 -- which the line must SAY)
+    rk = j["extra"]["ranks"]
+    assert rk["communicator"]["world_size_reported_by_the_process_group"] == 2 and rk["communicator"]["launcher_world_size"] == 2
+    assert rk["communicator"]["backend"] == "gloo" and rk["communicator"]["rccl_version"] is None
+    assert [r["rank"] for r in rk["per_rank"]] == [0, 1] and all(r["per_gpu_batch"] == 4096 for r in rk["per_rank"])
+    assert all("MI3" in r["device_name"] or "Instinct" in r["device_name"] or r["device_name"] for r in rk["per_rank"])
+    assert rk["distinct_devices"] == 1 and rk["all_ranks_on_distinct_devices"] is False
+    assert all(r["own_ms_per_step"] > 0 and r["own_ms_per_step"] <= j["ms_per_step"] * 1.0001 for r in rk["per_rank"])
+    n1 = rk["n1_same_build"]
+    assert len(n1["ms_per_step_per_rank"]) == 2 and all(x > 0 for x in n1["ms_per_step_per_rank"])
+    assert abs(n1["poses_per_s_rank0"] - 8192 / (n1["ms_per_step_per_rank"][0] * 1e-3)) / n1["poses_per_s_rank0"] < 1e-6
 
 
 def test_bench_attributes_the_step_of_a_forced_one_rank_rccl_group():
@@ -272,6 +284,9 @@ def test_bench_attributes_the_step_of_a_forced_one_rank_rccl_group():
     assert dp["backend"] == "nccl" and dp["world"] == 1 and dp["steps"] == 4
     assert dp["allreduce_bytes_per_step"] == dp["flat_gradient_bytes"] - 4 * (1024 * 1024 + 1024)
     assert 0.0 <= dp["exposed_allreduce_ms_per_step"] < dp["rank_ms_per_step"]
+    rk = j["extra"]["ranks"]
+    assert rk["communicator"]["backend"] == "nccl" and rk["communicator"]["rccl_version"] and rk["communicator"]["forced_one_rank_collectives"] is True
+    assert rk["communicator"]["world_size_reported_by_the_process_group"] == 1 and rk["all_ranks_on_distinct_devices"] is True
 
 
 def test_nonfinite_gradient_step_is_dropped_on_the_device():

@@ -162,7 +162,7 @@ def _md_setup(T=12, min_max=False, seed=7, embedding="positional"):
     bm = BodyModel(asset).to(DEV)
     g = load("g10_normalizer")
     stats = {k.split("/")[-1]: torch.tensor(g[k]) for k in g.files if k.startswith("stats/axis_normalize")}
-    gt = g["raw"][:T].astype(np.float32)
+    gt = (g["raw"][:T] if T <= g["raw"].shape[0] else g["toy_pose_samples"][np.arange(T) % g["toy_pose_samples"].shape[0]]).astype(np.float32)
     rs = np.random.RandomState(seed)
     init = (gt + rs.standard_normal(gt.shape) * 0.05).astype(np.float32)
     _, jgt, _, _ = fk_ref.smplx_forward(asset, gt.astype(np.float64), dtype=np.float64)
@@ -226,11 +226,14 @@ def test_motion_denoise_batch_of_sequences_equals_one_sequence_at_a_time():
         assert np.allclose(log[:, i, :2], t2n(md.loss_log)[:, 0, :2], rtol=1e-6)
 
 
-@pytest.mark.parametrize("S,F", [(3, 8), (2, 23)])
-def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, monkeypatch):
-    """dposer_lbs_forward_temporal_grad (skinning + the temporal term's gradient in one pass, no vertices in HBM) against k_skin_x4 +
-    k_md_vert_grad inside the same one-call loop: same expressions in the same order, so poses and the loss log must carry the same
-    bits -- one run of frames per sequence and several (halo frames recomputed)."""
+@pytest.mark.parametrize("S,F", [(3, 8), (2, 23), (7, 60)])
+def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, monkeypatch, tuning_env):
+    """The three homes of the temporal term's gradient inside the one-call loop must carry the same bits -- poses and loss log:
+    k_skin_x4 + k_md_vert_grad (vertices and their gradient through HBM); dposer_lbs_forward_temporal_grad (skinning + gradient in one
+    pass, one run of frames per sequence and several: halo frames recomputed); and, round 6, dposer_lbs_backward_temporal (no skinning
+    kernel at all: the skinning BACKWARD skins the frame and its two neighbours in registers and forms the gradient itself; workgroups of
+    four poses that straddle sequence boundaries at F = 23, a partly filled last workgroup at 46 frames; 420 frames = the size where it is
+    the default)."""
     iters, spi = 2, 3
     md, joints3d, gt, init, rs = _md_setup(F * S)
     noise = torch.tensor(rs.standard_normal((iters * spi, F * S, 63)).astype(np.float32), device=DEV)
@@ -238,16 +241,22 @@ def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, 
     md.betas = md.betas[:F]
     kw = dict(time_strategy="3", iterations=iters, steps_per_iter=spi)
     out = {}
-    for tag, fused, nseg in (("two-kernel", "0", None), ("fused", "1", None), ("fused-2", "1", "2"), ("fused-3", "1", "3")):
-        monkeypatch.setenv("DPOSER_MD_FUSED_TEMPORAL", fused)
-        if nseg:
-            monkeypatch.setenv("DPOSER_SKIN_TEMPORAL_NSEG", nseg)
+    from dposer_amd import _C
+    for tag, fused, nseg in (("two-kernel", "0", None), ("fused", "1", None), ("fused-2", "1", "2"), ("fused-3", "1", "3"), ("in-backward", "2", None),
+                             ("default", None, None)):
+        # (the same skinning-backward kernel under every variant -- the matrix-pipe one, forced onto the small batches: the small-batch
+        #  kernels sum in another order, which is not what this test is about)
+        tuning_env(DPOSER_MD_FUSED_TEMPORAL=fused, DPOSER_SKIN_TEMPORAL_NSEG=nseg, DPOSER_LBS_JOINT_STREAM_MIN="1")
+        if tag == "in-backward":
+            assert _C.lib().dposer_lbs_temporal_in_backward_ok(md.body_model.bm._handle(), 4, F * S) == 1
         res = md.optimize_sequences(joints3d.reshape(S, F, 22, 3), gt.reshape(S, F, 63), noise=noise, init_poses=init.reshape(S, F, 63), **kw)
         out[tag] = (res["pose_body"].clone(), md.loss_log.clone())
     assert torch.isfinite(out["two-kernel"][0]).all()
-    for tag in ("fused", "fused-2", "fused-3"):
-        assert torch.equal(out[tag][0], out["two-kernel"][0]), tag
-        assert torch.equal(out[tag][1], out["two-kernel"][1]), tag
+    for tag in ("fused", "fused-2", "fused-3", "in-backward", "default"):
+        assert torch.equal(out[tag][0], out["two-kernel"][0]), (tag, float((out[tag][0] - out["two-kernel"][0]).abs().max()))
+        assert torch.equal(out[tag][1], out["two-kernel"][1]), (tag, float((out[tag][1] - out["two-kernel"][1]).abs().max()))
+    tuning_env(DPOSER_LBS_JOINT_STREAM_MIN=None)
+    assert _C.lib().dposer_lbs_temporal_in_backward_ok(md.body_model.bm._handle(), 4, F * S) == (1 if F * S >= 320 else 0)      # the shipped rule: from 320 frames per call
 
 
 def test_motion_denoise_under_the_ve_sde():
