@@ -451,12 +451,33 @@ def main():
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             ex3 = float(tt[0])
         alg = 42.59e6 * args.global_batch * nx3 / ex3 / 1e12
+        # per-kernel rates of this mode from live HIP events (three more, untimed steps): the dominant GEMM kind's roofline.  A launch's FLOPs
+        # are the ALGORITHMIC ones (2 M N K of the layer); the matrix pipe executes three bf16 products per term, `matrix_pipe_frac` says so
+        _C.profile_enable(True)
+        for _ in range(3):
+            step_fn(state, batch)
+        torch.cuda.synchronize()
+        prof_x3 = _C.profile_collect()
+        _C.profile_enable(False)
+        kernels_x3, dom_x3 = {}, None
+        if prof_x3:
+            tot_x3 = sum(v[0] for v in prof_x3.values())
+            for kname, (ms, cnt, fl) in sorted(prof_x3.items(), key=lambda kv: -kv[1][0]):
+                kernels_x3[kname] = {"launches": int(cnt), "avg_us": ms / cnt * 1e3, "share_of_gemm_time": ms / tot_x3,
+                                     "tflops": (fl / (ms * 1e-3)) / 1e12 if ms > 0 else None}
+            kname, (ms, cnt, fl) = max(prof_x3.items(), key=lambda kv: kv[1][0])
+            ach3 = (fl / (ms * 1e-3)) / 1e12
+            dom_x3 = {"bound": "mfma", "kernel": kname, "achieved": ach3, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach3 / MFMA_BF16_PEAK_TFLOPS,
+                      "traffic": None, "launches": int(cnt), "avg_launch_us": ms / cnt * 1e3, "flops_per_launch": fl / cnt,
+                      "matrix_pipe_frac": 3 * ach3 / MFMA_BF16_PEAK_TFLOPS, "gemm_time_share_of_step": tot_x3 / 3 / (ex3 / nx3 * 1e3),
+                      "measured": "HIP events around every GEMM launch of 3 untimed steps in this mode; algorithmic FLOPs per launch (one product per term)"}
         extra["train_step_bf16x3_mode"] = {"poses_per_s": args.global_batch * nx3 / ex3, "ms_per_step": ex3 / nx3 * 1e3, "steps": nx3, "tflops_algorithmic": alg,
                                            "roofline": {"bound": "mfma", "achieved": alg, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                         "frac": alg / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                                                         "matrix_pipe_tflops": 3 * alg, "matrix_pipe_frac": 3 * alg / MFMA_BF16_PEAK_TFLOPS,
                                                         "scope": "whole step; `achieved` counts the ALGORITHMIC 42.59 MFLOP per pose -- the matrix pipe executes three "
                                                                  "bf16 products per term (hi*hi + lo*hi + hi*lo), `matrix_pipe_*` is that machine work"},
+                                           "dominant_kernel_roofline": dom_x3, "gemm_kernels": kernels_x3,
                                            "parity": "fp32-mode tolerances against the reference goldens (forward 2e-5, gradients 2e-4, sampler 1e-4)"}
         model.precision = args.precision
         model._engines.pop("bf16x3", None)

@@ -10,6 +10,7 @@ Adam/EMA kernel and the weight packer consume) and evaluates ``forward`` with th
 """
 import contextlib
 import functools
+import os
 import math
 
 import numpy as np
@@ -189,8 +190,11 @@ class TimeMLPs(_FlatParams):
         layers.append(nn.Linear(hidden_dim, dim))
         self.net = nn.Sequential(*layers)
 
-        prec = default_precision(config)
-        self.precision = "fp32" if prec == "bf16x3" else prec      # (no split-operand instantiation of this model: fp32 is the exact mode)
+        # Precision: what the configuration / DPOSER_PRECISION asks for; with neither, "bf16x3" -- the raw time label t * 999 is an INPUT
+        # COLUMN of this model (model.py:89-90), and one bf16 operand keeps 8 bits of it (above 512 neighbouring labels collapse: 0.4 %);
+        # the split operand keeps 16 (7.6e-6), on the bf16 matrix pipe (ScoreModelFC embeds t in fp32 before any GEMM and defaults to bf16).
+        explicit = os.environ.get("DPOSER_PRECISION") is not None or (hasattr(config.model, "get") and config.model.get("precision", None) is not None)
+        self.precision = default_precision(config) if explicit else "bf16x3"
         self._engines = {}
         self._flat = None
         self._param_list = list(self.parameters())

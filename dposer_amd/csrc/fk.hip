@@ -612,6 +612,8 @@ struct BodyTuning {
                                           // on the matrix pipe (k_skin_bwd_mfma); 4 / 8: poses per workgroup of the latter (default 4)
     bool lbs_bwd_terms_parallel = true;   // DPOSER_LBS_BWD_TERMS_PARALLEL=0: the three product terms of the bf16 x 3 blend-gradient GEMM one after the other on the
                                           // caller's stream (A/B) instead of side by side on three streams
+    bool lbs_bwd_rowcat = true;           // DPOSER_LBS_BWD_ROWCAT=0: the two blend-gradient product terms that read the high plane of d_offsets as two launches
+                                          // (A/B) instead of ONE launch against the row-concatenated [posedirs high ; posedirs low] (round 6: the 258 MB plane is read once)
     int64_t lbs_fwd_chunk = 0;            // DPOSER_LBS_FWD_CHUNK=n (multiple of 256): the full forward runs blend GEMM and skinning in chunks of n poses, the
                                           // skinning of chunk i on a side stream beside the GEMM of chunk i + 1 (0: one launch each over the whole batch)
     void load() {
@@ -637,6 +639,8 @@ struct BodyTuning {
         skin_bwd_mfma = e ? atoi(e) : 1;
         e = getenv("DPOSER_LBS_BWD_TERMS_PARALLEL");
         lbs_bwd_terms_parallel = !(e && e[0] == '0');
+        e = getenv("DPOSER_LBS_BWD_ROWCAT");
+        lbs_bwd_rowcat = !(e && e[0] == '0');
         e = getenv("DPOSER_LBS_FWD_CHUNK");
         lbs_fwd_chunk = e ? atoll(e) / 256 * 256 : (int64_t)0;
     }
@@ -1204,6 +1208,12 @@ extern "C" int dposer_lbs_pack_posedirs(dposer_body_t h, const float* posedirs, 
     js.n = 3;
     js.job[1] = j; js.job[1].dst_off = n * 4; js.job[1].f32 = 0; js.job[1].split = 1;
     js.job[2] = j; js.job[2].dst_off = n * 6; js.job[2].f32 = 0; js.job[2].split = 2;
+    if (j.rows_pad > 256) {
+        const int64_t n256 = (int64_t)256 * j.ktot;
+        js.n = 5;
+        js.job[3] = j; js.job[3].dst_off = n * 8; js.job[3].f32 = 0; js.job[3].split = 1; js.job[3].rows_pad = 256; js.job[3].rows_valid = P < 256 ? P : 256;
+        js.job[4] = js.job[3]; js.job[4].dst_off = n * 8 + n256 * 2; js.job[4].split = 2;
+    }
     FK_HIP_LAUNCH(launch_pack(js, posedirs, packed, (hipStream_t)stream));
     return DPOSER_OK;
 }
@@ -2816,9 +2826,38 @@ __global__ void __launch_bounds__(256) k_sum_slabs(float* slabs, int64_t slab_el
     }
 }
 
+// The slabs of the row-concatenated blend gradient: A [ka][rows][2 pe] (columns [0, pe) = d_off_hi pd_hi^T, [pe, 2 pe) = d_off_hi pd_lo^T) and
+// B [kb][rows][pe] (d_off_lo pd_hi^T) -> out [rows][pe], added in k_sum_slabs' order of the three-launch form (term by term, split by split):
+// the same bits.  `out` may be B's first slab (every thread reads its own elements before it writes them).
+__global__ void __launch_bounds__(256) k_sum_slabs_rowcat(const float* A, int ka, const float* B, int kb, float* out, int64_t rows, int pe) {
+    const int64_t n4 = rows * pe / 4;
+    const int pe4 = pe / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / pe4;
+        const int c4 = (int)(i % pe4);
+        const f32x4* a0 = reinterpret_cast<const f32x4*>(A + r * 2 * pe) + c4;
+        f32x4 v = a0[0];
+        for (int k = 1; k < ka; ++k) {
+            const f32x4 w = a0[k * (rows * 2 * pe / 4)];
+            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+        }
+        for (int k = 0; k < ka; ++k) {
+            const f32x4 w = a0[k * (rows * 2 * pe / 4) + pe4];
+            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+        }
+        for (int k = 0; k < kb; ++k) {
+            const f32x4 w = reinterpret_cast<const f32x4*>(B + k * rows * pe)[i];
+            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+        }
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
 extern "C" int64_t dposer_lbs_posedirs_bwd_packed_bytes(dposer_body_t h) {
     if (!h) return -1;
-    return round_up((h->d.num_joints - 1) * 9, 128) * lbs_cpad(h->d.num_vertices) * 8;        // [rows = pose feature][k = vertex coord]: FT32 | bf16 high | bf16 low
+    const int64_t prow = round_up((h->d.num_joints - 1) * 9, 128), Cpad = lbs_cpad(h->d.num_vertices);
+    // [rows = pose feature][k = vertex coord]: FT32 | bf16 high | bf16 low | (prow > 256) the first 256 rows once more as ONE matrix
+    // [high 0..255 ; low 0..255]: the row-concatenated operand of the combined blend-gradient launch when only the body is posed
+    return prow * Cpad * 8 + (prow > 256 ? 2 * 256 * Cpad * 2 : 0);
 }
 extern "C" int dposer_lbs_pack_posedirs_bwd(dposer_body_t h, const float* posedirs, void* packed, void* stream) {
     DP_CHECK_ARG(h && posedirs && packed, "null argument");
@@ -2833,6 +2872,12 @@ extern "C" int dposer_lbs_pack_posedirs_bwd(dposer_body_t h, const float* posedi
     js.n = 3;
     js.job[1] = j; js.job[1].dst_off = n * 4; js.job[1].f32 = 0; js.job[1].split = 1;
     js.job[2] = j; js.job[2].dst_off = n * 6; js.job[2].f32 = 0; js.job[2].split = 2;
+    if (j.rows_pad > 256) {
+        const int64_t n256 = (int64_t)256 * j.ktot;
+        js.n = 5;
+        js.job[3] = j; js.job[3].dst_off = n * 8; js.job[3].f32 = 0; js.job[3].split = 1; js.job[3].rows_pad = 256; js.job[3].rows_valid = P < 256 ? P : 256;
+        js.job[4] = js.job[3]; js.job[4].dst_off = n * 8 + n256 * 2; js.job[4].split = 2;
+    }
     FK_HIP_LAUNCH(launch_pack(js, posedirs, packed, (hipStream_t)stream));
     return DPOSER_OK;
 }
@@ -3112,6 +3157,11 @@ static int lbs_backward_impl(dposer_body_t h, const void* ws_fwd, void* ws_bwd, 
         const int64_t fit = slab_budget / (3 * Bpad * pe);
         const int k1 = kbig ? kbig : lbs_bwd_ksplit_bf16(kb, (Bpad / 128) * (pe / 128), (int)(fit < 1 ? 1 : (fit > 24 ? 24 : fit)));
         const bool fork = par && kbig;
+        // round 6: the terms d_off_hi pd_hi^T and d_off_hi pd_lo^T as ONE launch against the row-concatenated [pd_hi ; pd_lo] (2 pe rows: the
+        // natural layout when every pose-feature row is wanted, the packed 256-row prefix panel when only the body is posed) -- the two
+        // column tiles of a row panel run side by side on one XCD (panel_order) and d_off_hi leaves HBM once instead of twice
+        const bool rowcat = kbig && body_tuning().lbs_bwd_rowcat && (pe == prow || (pe == 256 && prow > 256));
+        const int nlaunch = rowcat ? 2 : 3;
         if (fork) {
             DP_TRY(side_streams_for_current_device(h));
             if (!h->bwd_side[0]) {
@@ -3119,32 +3169,53 @@ static int lbs_backward_impl(dposer_body_t h, const void* ws_fwd, void* ws_bwd, 
                 for (hipEvent_t* e : {&h->ev_bwd_fork, &h->ev_bwd_join[0], &h->ev_bwd_join[1]}) DP_CHECK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
             }
             DP_CHECK_HIP(hipEventRecord(h->ev_bwd_fork, st));
-            for (int i = 0; i < 2; ++i) DP_CHECK_HIP(hipStreamWaitEvent(h->bwd_side[i], h->ev_bwd_fork, 0));
+            for (int i = 0; i < nlaunch - 1; ++i) DP_CHECK_HIP(hipStreamWaitEvent(h->bwd_side[i], h->ev_bwd_fork, 0));
         }
         // (between fork and join nothing returns: a failed launch of one term still joins the side streams back into `st` -- the caller
         //  may free or reuse ws_bwd as soon as this call has returned -- and is reported afterwards)
         hipError_t term_err = hipSuccess;
-        for (int term = 0; term < 3 && term_err == hipSuccess; ++term) {
+        float* slabB = dpf + (int64_t)2 * k1 * Bpad * pe;               // (rowcat) the d_off_lo term's slabs behind the combined launch's
+        for (int term = 0; term < nlaunch && term_err == hipSuccess; ++term) {
             hipStream_t ts = (fork && term > 0) ? h->bwd_side[term - 1] : st;
             GemmArgs g;
             std::memset(&g, 0, sizeof(g));
-            g.W = term == 2 ? (const void*)doff_lo : (const void*)doff_hi; g.w_stride_blocks = kb;
-            g.n_cblk = (int)(Bpad / tile); g.n_sblk = (int)(pe / tile); g.ksplit = k1;
-            g.src[0] = term == 1 ? pd_lo : pd_hi; g.seg_kblocks[0] = kb; g.nseg = 1; g.ktot_blocks = kb;
+            g.w_stride_blocks = kb; g.n_cblk = (int)(Bpad / tile); g.ksplit = k1; g.seg_kblocks[0] = kb; g.nseg = 1; g.ktot_blocks = kb;
             g.panel_order = body_tuning().lbs_bwd_panel_order;
             WgradParams wp;
-            wp.slab = dpf + (int64_t)term * k1 * Bpad * pe; wp.slab_stride = Bpad * pe; wp.ld = (int)pe; wp.N_valid = (int)batch;
-            wp.K_valid = (int)((J - 1) * 9 < pe ? (J - 1) * 9 : pe);
+            wp.N_valid = (int)batch;
+            if (rowcat) {
+                const bool both = term == 0;
+                g.W = both ? (const void*)doff_hi : (const void*)doff_lo;
+                g.src[0] = both ? (pe == prow ? pd_hi : pd_lo + prow * Cpad * 2) : pd_hi;
+                g.n_sblk = (int)((both ? 2 * pe : pe) / tile);
+                wp.slab = both ? dpf : slabB;
+                wp.ld = (int)(both ? 2 * pe : pe); wp.slab_stride = Bpad * (int64_t)wp.ld;
+                wp.K_valid = both ? (int)(2 * pe) : (int)((J - 1) * 9 < pe ? (J - 1) * 9 : pe);      // (padded posedirs rows are zeros: their columns are written as such)
+            } else {
+                g.W = term == 2 ? (const void*)doff_lo : (const void*)doff_hi;
+                g.src[0] = term == 1 ? pd_lo : pd_hi;
+                g.n_sblk = (int)(pe / tile);
+                wp.slab = dpf + (int64_t)term * k1 * Bpad * pe; wp.slab_stride = Bpad * pe; wp.ld = (int)pe;
+                wp.K_valid = (int)((J - 1) * 9 < pe ? (J - 1) * 9 : pe);
+            }
             term_err = gemm_wgrad(PREC_BF16, kbig ? SHAPE_BIG : SHAPE_MID, g, wp, ts);
         }
         if (fork) {
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < nlaunch - 1; ++i) {
                 DP_CHECK_HIP(hipEventRecord(h->ev_bwd_join[i], h->bwd_side[i]));
                 DP_CHECK_HIP(hipStreamWaitEvent(st, h->ev_bwd_join[i], 0));
             }
         }
         FK_HIP_LAUNCH(term_err);
         ks = 3 * k1;
+        if (rowcat) {
+            const int64_t n4 = Bpad * pe / 4;
+            hipLaunchKernelGGL(k_sum_slabs_rowcat, dim3((unsigned)(n4 < 256 * 2048 ? ceil_div(n4, 256) : 2048)), dim3(256), 0, st, (const float*)dpf, k1, (const float*)slabB, k1,
+                               slabB, Bpad, (int)pe);
+            FK_HIP_LAUNCH(hipGetLastError());
+            dpf = slabB;
+            ks = 1;                                                      // (already summed)
+        }
     }
     {
         FkBwdArgs a;

@@ -125,7 +125,7 @@ hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNP
 }
 hipError_t gemm_bias_silu(int prec, bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st) {
     PROF(EPI_BIAS_SILU);
-    if (prec == PREC_BF16X3) return p.act == DP_ACT_SWISH ? gemm_bias_silu_x3(train, shape, g, p, st) : hipErrorInvalidConfiguration;
+    if (prec == PREC_BF16X3) return gemm_bias_silu_x3(train, shape, g, p, st);
     if (p.act != DP_ACT_SWISH) {
         if (train) { typedef EpiBiasSiLU<__bf16, true, true> A; typedef EpiBiasSiLU<float, true, true> B; DISPATCH(A, B, M_MID | M_SMALL); }
         typedef EpiBiasSiLU<__bf16, false, true> A; typedef EpiBiasSiLU<float, false, true> B; DISPATCH(A, B, M_MID | M_SMALL);
@@ -170,6 +170,7 @@ hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams
 }
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st) {
     PROF(EPI_SILU_BWD);
+    if (prec == PREC_BF16X3) return gemm_silu_bwd_x3(shape, g, p, st);
     if (p.act != DP_ACT_SWISH) { typedef EpiSiLUBwd<__bf16, true> A; typedef EpiSiLUBwd<float, true> B; DISPATCH(A, B, M_MID | M_SMALL); }
     typedef EpiSiLUBwd<__bf16> A; typedef EpiSiLUBwd<float> B; DISPATCH(A, B, M_MAIN);
 }

@@ -27,9 +27,26 @@ hipError_t gemm_gn_x3(bool train, int shape, const GemmArgs& g, const GNParams& 
     if (train) return main_shapes<EpiGN<float, true>>(shape, g, p, st);
     return main_shapes<EpiGN<float, false>>(shape, g, p, st);
 }
+template <typename Epi>
+hipError_t narrow_shapes(int shape, const GemmArgs& g, const typename Epi::Params& p, hipStream_t st) {      // (runtime-selected activations: the 128-wide tilings only, as in gemm_launch.hip)
+    switch (shape) {
+        case SHAPE_MID: return launch_gemm<__bf16, 2, 2, 2, 2, RING_KB, Epi, RING_NB>(g, p, st);
+        case SHAPE_SMALL: return launch_gemm<__bf16, 4, 1, 1, 1, 4, Epi>(g, p, st);
+    }
+    return hipErrorInvalidConfiguration;
+}
 hipError_t gemm_bias_silu_x3(bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st) {
+    if (p.act != DP_ACT_SWISH) {       // elu / relu / lrelu (TimeMLPs, model.py:54-66)
+        if (train) return narrow_shapes<EpiBiasSiLU<float, true, true>>(shape, g, p, st);
+        return narrow_shapes<EpiBiasSiLU<float, false, true>>(shape, g, p, st);
+    }
     if (train) return main_shapes<EpiBiasSiLU<float, true>>(shape, g, p, st);
     return main_shapes<EpiBiasSiLU<float, false>>(shape, g, p, st);
+}
+// dgrad of a Linear + activation layer on the bf16 planes, fp32-storage epilogue (TimeMLPs in bf16x3 mode)
+hipError_t gemm_silu_bwd_x3(int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st) {
+    if (p.act != DP_ACT_SWISH) return narrow_shapes<EpiSiLUBwd<float, true>>(shape, g, p, st);
+    return main_shapes<EpiSiLUBwd<float>>(shape, g, p, st);
 }
 hipError_t gemm_em_step_x3(int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st) {
     if (shape == SHAPE_FINAL) return launch_gemm<__bf16, 1, 4, 2, 1, RING_KB, EpiEmStep<float>, RING_NB>(g, p, st);

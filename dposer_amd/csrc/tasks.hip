@@ -301,10 +301,17 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     // DPOSER_MD_FUSED_TEMPORAL_MIN_SEQ = 4 sequences per call: a workgroup of the fused kernel walks >= 10 frames one after the other;
     // measured 0.60 vs 0.67 ms per step at 8 sequences of 60 frames, a tie at one)
     bool fused_temporal = a->skin_k == 4 && F <= 4096 && n_seq <= 16384;
-    // DPOSER_MD_FUSED_TEMPORAL = 2 (default wherever dposer_lbs_temporal_in_backward_ok: from 320 frames per call): the temporal term's
+    // DPOSER_MD_FUSED_TEMPORAL = 2 (default from 960 frames per call, where dposer_lbs_temporal_in_backward_ok): the temporal term's
     // gradient is formed INSIDE the skinning backward from the forward's transforms and offsets -- no skinning kernel, no vertices and no
-    // vertex gradient in HBM (k_skin_temporal wrote 967 MB at 7680 frames that k_skin_bwd_mfma read back; 2.71 -> see profiles/r06_md_*.md)
+    // vertex gradient in HBM (k_skin_temporal wrote 967 MB at 7680 frames that k_skin_bwd_mfma read back)
+    // (measured, profiles/r06_md_ab.md: 2.63 -> 2.51 ms per step at 7680 frames, 0.83 -> 0.79 at 1920, a loss at 480 -- the backward kernel is
+    //  VALU-bound once it skins three frames per pose -- hence DPOSER_MD_TEMPORAL_IN_BWD_MIN_FRAMES = 960)
     bool temporal_in_backward = dposer_lbs_temporal_in_backward_ok(a->body, a->skin_k, T) != 0;
+    {
+        const char* m = getenv("DPOSER_MD_TEMPORAL_IN_BWD_MIN_FRAMES");
+        const char* e = getenv("DPOSER_MD_FUSED_TEMPORAL");
+        if (!(e && e[0] == '2') && T < (m ? atoll(m) : 960)) temporal_in_backward = false;
+    }
     bool ieee_div = false;
     { const char* e = getenv("DPOSER_MD_IEEE_DIV"); ieee_div = e && e[0] == '1'; }
     if (ieee_div) { fused_temporal = false; temporal_in_backward = false; }      // (the A/B switch exists in the two-kernel form only)

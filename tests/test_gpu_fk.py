@@ -412,6 +412,43 @@ def test_blend_gradient_terms_side_by_side_equal_one_after_the_other(bm, monkeyp
     assert err < 1e-6 and bool(torch.isfinite(par).all())
 
 
+@pytest.mark.parametrize("segments", ["body", "all"])
+def test_row_concatenated_blend_gradient_launch_keeps_every_bit(bm, tuning_env, segments):
+    """Round 6: the two blend-gradient product terms that read the high plane of d_offsets are ONE launch against the row-concatenated
+    [posedirs high ; posedirs low] -- the packed 256-row prefix panel when only the body is posed (pe = 256 of 512 rows), the natural
+    layout when every pose segment wants a gradient -- and the slabs are added in the three-launch form's order: the pose gradients must
+    carry the bits of DPOSER_LBS_BWD_ROWCAT=0, with the terms side by side and one after the other."""
+    B = 2304
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    pose = (torch.randn(B, 63, device=DEV, generator=gen) * 0.3)
+    hand = (torch.randn(B, 90, device=DEV, generator=gen) * 0.2)
+    jaw = (torch.randn(B, 3, device=DEV, generator=gen) * 0.2)
+    gv = torch.randn(B, 10475, 3, device=DEV, generator=gen) * 0.01
+    gj = torch.randn(B, 127, 3, device=DEV, generator=gen)
+
+    def run():
+        p = pose.clone().requires_grad_(True)
+        kw = dict(pose_body=p)
+        leaves = [p]
+        if segments == "all":
+            h, jw = hand.clone().requires_grad_(True), jaw.clone().requires_grad_(True)
+            kw.update(pose_hand=h, pose_jaw=jw)
+            leaves += [h, jw]
+        out = bm(**kw)
+        torch.autograd.backward([out.v, out.Jtr], [gv, gj])
+        return [t.grad.clone() for t in leaves]
+
+    got = {}
+    for par in ("1", "0"):
+        for rowcat in ("1", "0"):
+            tuning_env(DPOSER_LBS_BWD_TERMS_PARALLEL=par, DPOSER_LBS_BWD_ROWCAT=rowcat)
+            got[(par, rowcat)] = run()
+    for par in ("1", "0"):
+        for a, b in zip(got[(par, "1")], got[(par, "0")]):
+            assert torch.equal(a, b), (segments, par, float((a - b).abs().max()))
+            assert bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0
+
+
 def test_fused_skinning_backward_agrees_with_the_two_kernel_path(bm, monkeypatch):
     """The one-pass skinning-backward kernels -- k_skin_bwd_mfma (default: the joint reduction as dense 16x16x32 MFMAs on bf16 hi / lo
     planes, a workgroup per four poses) and k_skin_bwd_fused (one streaming pass per pose: d_verts read once, v_posed never in HBM, joint

@@ -226,14 +226,14 @@ def test_motion_denoise_batch_of_sequences_equals_one_sequence_at_a_time():
         assert np.allclose(log[:, i, :2], t2n(md.loss_log)[:, 0, :2], rtol=1e-6)
 
 
-@pytest.mark.parametrize("S,F", [(3, 8), (2, 23), (7, 60)])
+@pytest.mark.parametrize("S,F", [(3, 8), (2, 23), (17, 60)])
 def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, monkeypatch, tuning_env):
     """The three homes of the temporal term's gradient inside the one-call loop must carry the same bits -- poses and loss log:
     k_skin_x4 + k_md_vert_grad (vertices and their gradient through HBM); dposer_lbs_forward_temporal_grad (skinning + gradient in one
     pass, one run of frames per sequence and several: halo frames recomputed); and, round 6, dposer_lbs_backward_temporal (no skinning
     kernel at all: the skinning BACKWARD skins the frame and its two neighbours in registers and forms the gradient itself; workgroups of
-    four poses that straddle sequence boundaries at F = 23, a partly filled last workgroup at 46 frames; 420 frames = the size where it is
-    the default)."""
+    four poses that straddle sequence boundaries at F = 23, a partly filled last workgroup at 46 frames; 1020 frames = a size where it is
+    the default: from 960)."""
     iters, spi = 2, 3
     md, joints3d, gt, init, rs = _md_setup(F * S)
     noise = torch.tensor(rs.standard_normal((iters * spi, F * S, 63)).astype(np.float32), device=DEV)
@@ -256,7 +256,7 @@ def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, 
         assert torch.equal(out[tag][0], out["two-kernel"][0]), (tag, float((out[tag][0] - out["two-kernel"][0]).abs().max()))
         assert torch.equal(out[tag][1], out["two-kernel"][1]), (tag, float((out[tag][1] - out["two-kernel"][1]).abs().max()))
     tuning_env(DPOSER_LBS_JOINT_STREAM_MIN=None)
-    assert _C.lib().dposer_lbs_temporal_in_backward_ok(md.body_model.bm._handle(), 4, F * S) == (1 if F * S >= 320 else 0)      # the shipped rule: from 320 frames per call
+    assert _C.lib().dposer_lbs_temporal_in_backward_ok(md.body_model.bm._handle(), 4, F * S) == (1 if F * S >= 320 else 0)      # (possible from 320 frames per call, the default from 960)
 
 
 def test_motion_denoise_under_the_ve_sde():
