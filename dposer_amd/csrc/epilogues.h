@@ -1291,7 +1291,12 @@ template <typename T, bool TRAIN, int GS> struct EpiGNG {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) o[i] += rr[i];
                     }
-                    TileIO<T>::store(out + tb, lane, o);
+                    if constexpr (sizeof(T) == 4) {       // (bf16x3 mode: `out` is optional, the operand planes beside or instead of it)
+                        if (out) TileIO<T>::store(out + tb, lane, o);
+                        if (pp.out_hi) store_tile_planes(pp.out_hi, pp.out_lo, sbase + ts * 32, c0, pp.H, lane, o);
+                    } else {
+                        TileIO<T>::store(out + tb, lane, o);
+                    }
                     if (TRAIN && pp.outT) TileT<T>::store((T*)pp.outT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, o);
                 }
             }
@@ -1381,7 +1386,12 @@ template <typename T, int GS> struct EpiGNBwdG {
                         g[u][i] = rstd[k] * (g[u][i] - m1[k] - xh[u][i] * m2[k]);              // dy
                         dbias[u][i] += g[u][i];
                     }
-                    TileIO<T>::store(dy + tb, lane, g[u]);
+                    if constexpr (sizeof(T) == 4) {
+                        if (dy) TileIO<T>::store(dy + tb, lane, g[u]);
+                        if (pp.dy_hi) store_tile_planes(pp.dy_hi, pp.dy_lo, sbase + ts * 32, c0, pp.H, lane, g[u]);
+                    } else {
+                        TileIO<T>::store(dy + tb, lane, g[u]);
+                    }
                     if (pp.dyT) TileT<T>::store((T*)pp.dyT + ft_tileT_base<T>(sbase + ts * 32, c0, pp.Spad), scr, lane, g[u]);
                 }
             }

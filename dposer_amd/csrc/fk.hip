@@ -614,6 +614,8 @@ struct BodyTuning {
                                           // caller's stream (A/B) instead of side by side on three streams
     bool lbs_bwd_rowcat = true;           // DPOSER_LBS_BWD_ROWCAT=0: the two blend-gradient product terms that read the high plane of d_offsets as two launches
                                           // (A/B) instead of ONE launch against the row-concatenated [posedirs high ; posedirs low] (round 6: the 258 MB plane is read once)
+    int64_t fk_lds_pad = 0;               // DPOSER_FK_LDS_PAD=bytes: extra (unused) dynamic LDS per workgroup of k_fk_joints_dma -- an occupancy probe (fewer resident
+                                          // waves per CU, same kernel): tools/fk_occupancy_sweep.sh, profiles/r06_fk_occupancy.md
     int64_t lbs_fwd_chunk = 0;            // DPOSER_LBS_FWD_CHUNK=n (multiple of 256): the full forward runs blend GEMM and skinning in chunks of n poses, the
                                           // skinning of chunk i on a side stream beside the GEMM of chunk i + 1 (0: one launch each over the whole batch)
     void load() {
@@ -641,6 +643,8 @@ struct BodyTuning {
         lbs_bwd_terms_parallel = !(e && e[0] == '0');
         e = getenv("DPOSER_LBS_BWD_ROWCAT");
         lbs_bwd_rowcat = !(e && e[0] == '0');
+        e = getenv("DPOSER_FK_LDS_PAD");
+        fk_lds_pad = e ? atoll(e) : (int64_t)0;
         e = getenv("DPOSER_LBS_FWD_CHUNK");
         lbs_fwd_chunk = e ? atoll(e) / 256 * 256 : (int64_t)0;
     }
@@ -839,7 +843,7 @@ template <typename Kin> static hipError_t launch_fk(const FkArgs& a, hipStream_t
                             (((uintptr_t)a.seg[0] | (uintptr_t)a.seg[1] | (uintptr_t)a.joints) & 15) == 0;
         if (dma_ok) {        // full blocks of 64 poses through the DMA kernel, the remaining < 64 poses through the general one
             const int64_t nfull = a.B / 64, rem = a.B - nfull * 64;
-            hipLaunchKernelGGL(k_fk_joints_dma<Kin>, dim3((unsigned)nfull), dim3(64), 64 * 66 * sizeof(float), st, a);
+            hipLaunchKernelGGL(k_fk_joints_dma<Kin>, dim3((unsigned)nfull), dim3(64), 64 * 66 * sizeof(float) + (size_t)body_tuning().fk_lds_pad, st, a);
             if (rem == 0) return hipGetLastError();
             FkArgs t = a;
             const int64_t o = nfull * 64;

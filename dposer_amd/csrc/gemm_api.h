@@ -76,12 +76,12 @@ hipError_t launch_sampler_cluster(int prec, const SamplerArgs& a, int sync, hipS
 enum GemmEpiKind : int { EPI_GN = 0, EPI_GN_TRAIN, EPI_BIAS_SILU, EPI_ROWMAJOR, EPI_PLAIN_FT, EPI_GN_BWD, EPI_SILU_BWD, EPI_WGRAD, EPI_EM_STEP, EPI_DSM_STEP, EPI_KINDS };
 constexpr int GEMM_PROF_KINDS = EPI_KINDS * 3 * 6;      // (epilogue kind, precision, tiling)
 // bf16x3 entry points (gemm_launch_x3.hip): the dispatchers of gemm_launch.hip forward prec == PREC_BF16X3 here
-hipError_t gemm_gn_x3(bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st);
+hipError_t gemm_gn_x3(bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st, int gs = 32);      // every activation, group sizes 16 / 32 / 64
 hipError_t gemm_bias_silu_x3(bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st);      // every activation
 hipError_t gemm_silu_bwd_x3(int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st);
 hipError_t gemm_em_step_x3(int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st);
 hipError_t gemm_partial_ft_x3(int shape, const GemmArgs& g, const PartialFTParams& p, hipStream_t st);
-hipError_t gemm_gn_bwd_x3(int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st);
+hipError_t gemm_gn_bwd_x3(int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st, int gs = 32);
 void gemm_prof_enable(int on);
 // synchronises the recorded events, accumulates them per kind and clears the record list
 int gemm_prof_collect(double* ms, long long* launches, double* flops);   // arrays of GEMM_PROF_KINDS

@@ -108,7 +108,7 @@ static hipError_t by_shape_generic(int shape, const GemmArgs& g, const typename 
 
 hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st, int gs) {
     PROF(train ? EPI_GN_TRAIN : EPI_GN);
-    if (prec == PREC_BF16X3) return (gs == 32 && p.act == DP_ACT_SWISH) ? gemm_gn_x3(train, shape, g, p, st) : hipErrorInvalidConfiguration;
+    if (prec == PREC_BF16X3) return gemm_gn_x3(train, shape, g, p, st, gs);
     if (gs != 32) {
 #define E_TRAIN(T, GS) EpiGNG<T, true, GS>
 #define E_INFER(T, GS) EpiGNG<T, false, GS>
@@ -158,7 +158,7 @@ hipError_t gemm_plain_ft(int prec, int shape, const GemmArgs& g, const PlainFTPa
 }
 hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st, int gs) {
     PROF(EPI_GN_BWD);
-    if (prec == PREC_BF16X3) return (gs == 32 && p.act == DP_ACT_SWISH) ? gemm_gn_bwd_x3(shape, g, p, st) : hipErrorInvalidConfiguration;
+    if (prec == PREC_BF16X3) return gemm_gn_bwd_x3(shape, g, p, st, gs);
     if (gs != 32) {
 #define E_BWD(T, GS) EpiGNBwdG<T, GS>
         if (gs == 16) { DISPATCH_GS(E_BWD, 16); }

@@ -23,10 +23,6 @@ hipError_t main_shapes(int shape, const GemmArgs& g, const typename Epi::Params&
 }
 }   // namespace
 
-hipError_t gemm_gn_x3(bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st) {
-    if (train) return main_shapes<EpiGN<float, true>>(shape, g, p, st);
-    return main_shapes<EpiGN<float, false>>(shape, g, p, st);
-}
 template <typename Epi>
 hipError_t narrow_shapes(int shape, const GemmArgs& g, const typename Epi::Params& p, hipStream_t st) {      // (runtime-selected activations: the 128-wide tilings only, as in gemm_launch.hip)
     switch (shape) {
@@ -34,6 +30,28 @@ hipError_t narrow_shapes(int shape, const GemmArgs& g, const typename Epi::Param
         case SHAPE_SMALL: return launch_gemm<__bf16, 4, 1, 1, 1, 4, Epi>(g, p, st);
     }
     return hipErrorInvalidConfiguration;
+}
+// generic GroupNorm group sizes (hidden 512 / 2048): the tilings of gemm_launch.hip's by_shape_generic (a 64-channel group needs both of its
+// tiles in one wave: the paired 128x32 form)
+template <typename Epi, bool PAIR>
+hipError_t generic_shapes(int shape, const GemmArgs& g, const typename Epi::Params& p, hipStream_t st) {
+    if (shape == SHAPE_MID) return launch_gemm<__bf16, 2, 2, 2, 2, RING_KB, Epi, RING_NB>(g, p, st);
+    if (shape == SHAPE_SMALL) {
+        if constexpr (PAIR) return launch_gemm<__bf16, 2, 1, 2, 1, 4, Epi>(g, p, st);
+        else return launch_gemm<__bf16, 4, 1, 1, 1, 4, Epi>(g, p, st);
+    }
+    return hipErrorInvalidConfiguration;
+}
+hipError_t gemm_gn_x3(bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st, int gs) {
+    if (gs == 16) return train ? generic_shapes<EpiGNG<float, true, 16>, false>(shape, g, p, st) : generic_shapes<EpiGNG<float, false, 16>, false>(shape, g, p, st);
+    if (gs == 64) return train ? generic_shapes<EpiGNG<float, true, 64>, true>(shape, g, p, st) : generic_shapes<EpiGNG<float, false, 64>, true>(shape, g, p, st);
+    if (gs != 32) return hipErrorInvalidConfiguration;
+    if (p.act != DP_ACT_SWISH) {       // elu / relu / lrelu (model.py:54-66)
+        if (train) return narrow_shapes<EpiGN<float, true, -1, true>>(shape, g, p, st);
+        return narrow_shapes<EpiGN<float, false, -1, true>>(shape, g, p, st);
+    }
+    if (train) return main_shapes<EpiGN<float, true>>(shape, g, p, st);
+    return main_shapes<EpiGN<float, false>>(shape, g, p, st);
 }
 hipError_t gemm_bias_silu_x3(bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st) {
     if (p.act != DP_ACT_SWISH) {       // elu / relu / lrelu (TimeMLPs, model.py:54-66)
@@ -56,6 +74,10 @@ hipError_t gemm_em_step_x3(int shape, const GemmArgs& g, const EmStepParams& p, 
 hipError_t gemm_partial_ft_x3(int shape, const GemmArgs& g, const PartialFTParams& p, hipStream_t st) {
     return main_shapes<EpiPartialFT<__bf16>>(shape, g, p, st);     // (fp32 partial tiles whatever the operand type)
 }
-hipError_t gemm_gn_bwd_x3(int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st) {
+hipError_t gemm_gn_bwd_x3(int shape, const GemmArgs& g, const GNBwdParams& p, hipStream_t st, int gs) {
+    if (gs == 16) return generic_shapes<EpiGNBwdG<float, 16>, false>(shape, g, p, st);
+    if (gs == 64) return generic_shapes<EpiGNBwdG<float, 64>, true>(shape, g, p, st);
+    if (gs != 32) return hipErrorInvalidConfiguration;
+    if (p.act != DP_ACT_SWISH) return narrow_shapes<EpiGNBwd<float, 0, true>>(shape, g, p, st);
     return main_shapes<EpiGNBwd<float>>(shape, g, p, st);
 }

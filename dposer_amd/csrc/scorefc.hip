@@ -117,8 +117,6 @@ extern "C" int dposer_scorefc_create(const dposer_scorefc_desc* desc, dposer_sco
     DP_CHECK_ARG(desc->n_blocks >= 1 && desc->n_blocks <= 3, "n_blocks must be 1..3");
     DP_CHECK_ARG(desc->data_dim > 0 && desc->data_dim <= 512, "data_dim must be in 1..512");
     DP_CHECK_ARG(desc->precision == DPOSER_PREC_BF16 || desc->precision == DPOSER_PREC_FP32 || desc->precision == DPOSER_PREC_BF16X3, "bad precision");
-    DP_CHECK_ARG(desc->precision != DPOSER_PREC_BF16X3 || (desc->hidden_dim == 1024 && desc->activation == DPOSER_ACT_SWISH),
-                 "precision bf16x3 is built for hidden_dim 1024 / swish (the tile-per-group epilogues)");
     DP_CHECK_ARG(desc->dropout_p >= 0.f && desc->dropout_p < 1.f, "dropout_p must be in [0,1)");
     DP_CHECK_ARG(desc->activation >= DPOSER_ACT_SWISH && desc->activation <= DPOSER_ACT_LRELU, "bad activation");
     DP_CHECK_ARG(desc->activation == DPOSER_ACT_SWISH || desc->hidden_dim == 1024,

@@ -61,11 +61,11 @@ m.train()
 ref.train()
 y_ref = run(ref_fn, list(ref.parameters()))
 g_ref = ref[2].weight.grad.clone()
-for prec in ("bf16", "fp32"):
+for prec in ("bf16", "bf16x3", "fp32"):
     m.precision = prec
     y = run(lambda: m(x, t), list(m.parameters()))
     g = list(m.parameters())[2].grad
     ms = timed(lambda: m(x, t), list(m.parameters()))
-    print(f"dposer_mlp {prec:5s} B={B}: {ms:7.3f} ms fwd+bwd   out rel {float((y - y_ref).norm() / y_ref.norm()):.2e}  dW rel {float((g - g_ref).norm() / g_ref.norm()):.2e}", flush=True)
+    print(f"dposer_mlp {prec:6s} B={B}: {ms:7.3f} ms fwd+bwd   out rel {float((y - y_ref).norm() / y_ref.norm()):.2e}  dW rel {float((g - g_ref).norm() / g_ref.norm()):.2e}", flush=True)
 print(f"torch modules fp32 B={B}: {timed(ref_fn, list(ref.parameters())):7.3f} ms fwd+bwd", flush=True)
 print(f"torch modules bf16 autocast B={B}: {timed(ref_bf16, list(ref.parameters())):7.3f} ms fwd+bwd", flush=True)
