@@ -129,7 +129,7 @@ template <typename Epi> struct EpiRing<Epi, decltype((void)Epi::kRingPerWave)> {
 // (64 KiB per CU through the 64 B/clk vector-memory path) with no MFMA behind it, while DMA latency itself costs
 // ~50 cycles per stage; spreading the pieces removes the burst (+9-11 % on the 256x256 loop, bit-identical results).
 // Variants that were built and measured without gain (DMA issue interleaved between MFMA GROUPS under s_setprio,
-// delayed DMA issue for the second wave of each SIMD, register staging, persistent workgroups) are in EXPERIMENTS.md (old 4.1).
+// delayed DMA issue for the second wave of each SIMD, register staging, persistent workgroups) are in docs/experiments_rounds_1-4.md (4.1).
 // Epi::apply(params, acc, channel_base, sample_base, lane, wave row id, split, staged params, stride, scratch).
 // One output tile (cblk, sblk) [x one k-split] by the C::THREADS threads whose workgroup-local id is `tid` (the whole workgroup in
 // gemm_ft_kernel; a persistent kernel -- gemm_sampler.hip -- calls it tile after tile, or with two half-workgroups side by side on

@@ -1,6 +1,6 @@
 """Host enqueue time vs wall time of the fused training step at several batch sizes (run on the GPU box from the repo root):
     python tools/host_enqueue_time.py
-enqueue ~= wall  =>  the loop is bound by the host launching kernels, not by the GPU (EXPERIMENTS.md, old section 8 item 2)."""
+enqueue ~= wall  =>  the loop is bound by the host launching kernels, not by the GPU (docs/experiments_rounds_1-4.md, section 8 item 2)."""
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import torch
