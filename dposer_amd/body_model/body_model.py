@@ -187,6 +187,12 @@ class _SMPLCore(nn.Module):
         w = np.asarray(a["weights"], dtype=np.float32)
         k = int((w != 0).sum(axis=1).max())
         order = np.argsort(-(w != 0).astype(np.int8), axis=1, kind="stable")[:, :k]
+        if k != 4:
+            # every fast skinning path (runs of poses, the matrix-pipe backward, the fused temporal gradient) is built for the ELL width 4 of
+            # the SMPL-family templates; other widths run the general kernels -- correct (tests/test_gpu_assets.py: 5 and 8), slower
+            import warnings
+            warnings.warn(f"body model asset has up to {k} skinning influences per vertex (SMPL-family templates have 4): the general LBS kernels "
+                          "are used -- same results, several times slower forward and backward", RuntimeWarning, stacklevel=3)
         self.register_buffer("skin_idx", torch.tensor(order.astype(np.int32)))
         self.register_buffer("skin_w", torch.tensor(np.take_along_axis(w, order, axis=1)))
         tri = np.asarray(a["faces"])[np.asarray(a["lmk_faces_idx"]).astype(np.int64)].reshape(-1, 3)
