@@ -614,6 +614,7 @@ struct BodyTuning {
                                           // caller's stream (A/B) instead of side by side on three streams
     bool lbs_bwd_rowcat = true;           // DPOSER_LBS_BWD_ROWCAT=0: the two blend-gradient product terms that read the high plane of d_offsets as two launches
                                           // (A/B) instead of ONE launch against the row-concatenated [posedirs high ; posedirs low] (round 6: the 258 MB plane is read once)
+    int lbs_bwd_ksplit = 0;               // DPOSER_LBS_BWD_KSPLIT=n: force the split count of the 256x256 blend-gradient GEMMs (A/B; 0 = chosen by lbs_bwd_big_ksplit)
     int64_t fk_lds_pad = 0;               // DPOSER_FK_LDS_PAD=bytes: extra (unused) dynamic LDS per workgroup of k_fk_joints_dma -- an occupancy probe (fewer resident
                                           // waves per CU, same kernel): tools/fk_occupancy_sweep.sh, profiles/r06_fk_occupancy.md
     int64_t lbs_fwd_chunk = 0;            // DPOSER_LBS_FWD_CHUNK=n (multiple of 256): the full forward runs blend GEMM and skinning in chunks of n poses, the
@@ -643,6 +644,8 @@ struct BodyTuning {
         lbs_bwd_terms_parallel = !(e && e[0] == '0');
         e = getenv("DPOSER_LBS_BWD_ROWCAT");
         lbs_bwd_rowcat = !(e && e[0] == '0');
+        e = getenv("DPOSER_LBS_BWD_KSPLIT");
+        lbs_bwd_ksplit = e ? atoi(e) : 0;
         e = getenv("DPOSER_FK_LDS_PAD");
         fk_lds_pad = e ? atoll(e) : (int64_t)0;
         e = getenv("DPOSER_LBS_FWD_CHUNK");
@@ -897,6 +900,14 @@ extern "C" int dposer_fk_joints(dposer_body_t h, const float* const* pose_segmen
 //   T_v     = sum_j W[v][j] A_j ;  v = T_v [v_posed ; 1]     -> ELL-sparse skinning, A staged in LDS
 //   joints  = [J posed joints | vertex-selected extras | barycentric landmarks] (+ transl)
 // ------------------------------------------------------------------------------------------------
+// A/B (round 6): -DDPOSER_SKIN_CONTRACT builds the skinning kernels with FMA contraction (this file is compiled with -ffp-contract=off so that the
+// body-model arithmetic mirrors torch's unfused ops): the transform blend is 48 multiply-add pairs per (pose, vertex) and the one-pass backward
+// kernels are VALU-issue-bound.  Every kernel that forms vertices carries the pragma, so the bit-identity relations between them survive.
+#ifdef DPOSER_SKIN_CONTRACT
+#define DP_SKIN_FP _Pragma("clang fp contract(fast)")
+#else
+#define DP_SKIN_FP
+#endif
 struct SkinArgs {
     const float* offsets;      // [B][ld_off] pose-blend offsets (3V valid)
     int64_t ld_off;
@@ -941,6 +952,7 @@ __device__ __forceinline__ void skin_transform(const SkinArgs& a, const float* s
 // (staging the block's coordinates through LDS so that they enter and leave as consecutive dwords -- what pays in k_skin_bwd -- was
 //  measured SLOWER here: 461 -> 569 us at 4096 poses, four extra barriers per 256 vertices)
 __global__ void __launch_bounds__(256) k_skin(SkinArgs a) {
+    DP_SKIN_FP
     extern __shared__ __attribute__((aligned(16))) float sA[];   // [J][12]
     const int64_t b = blockIdx.y;
     for (int i = threadIdx.x; i < a.J * 12; i += 256) sA[i] = a.A[b * a.J * 12 + i];
@@ -969,6 +981,7 @@ __global__ void __launch_bounds__(256) k_skin(SkinArgs a) {
 // offsets on their way out of L2 / MALL -- keeping the offsets out of HBM (a fused skinning epilogue) is what would help, and the
 // per-(pose, vertex) transform T = sum_k w_k A[pose][j_k] makes that epilogue need 256 poses x 55 x 12 floats (675 KB) per tile.
 __global__ void __launch_bounds__(256) k_skin_x4(SkinArgs a) {
+    DP_SKIN_FP
     extern __shared__ __attribute__((aligned(16))) float sA[];   // [J][12]
     const int64_t b = blockIdx.y;
     for (int i = threadIdx.x; i < a.J * 12; i += 256) sA[i] = a.A[b * a.J * 12 + i];
@@ -1026,6 +1039,7 @@ __global__ void __launch_bounds__(256) k_skin_x4(SkinArgs a) {
 // pose's offsets and transforms are in flight while the current pose is skinned (transforms double-buffered in LDS, one barrier per
 // pose).  Same expressions in the same order per vertex: bit-identical vertices.
 __global__ void __launch_bounds__(256) k_skin_run(SkinArgs a, int run, int64_t B) {
+    DP_SKIN_FP
     extern __shared__ __attribute__((aligned(16))) float sA2[];   // [2][J][12]
     const int J12 = a.J * 12;
     const int64_t b0 = (int64_t)blockIdx.y * run;
@@ -1427,6 +1441,7 @@ struct SkinTemporalArgs {
     float c;
 };
 template <int NV, bool VSB> __global__ void __launch_bounds__(256, 4) k_skin_temporal(SkinTemporalArgs a) {
+    DP_SKIN_FP
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const SkinArgs& s = a.s;
     const int JA = s.J * 12;
@@ -2115,6 +2130,7 @@ struct SkinBwdMfmaArgs {
     float* part4;              // [B][chunks][4]: per wave, the sum over its 64 vertices of ||v[t] - v[t+1]|| (0 for a sequence's last frame)
 };
 template <int G, bool VSB, bool TMP = false> __global__ void __launch_bounds__(256, 2) k_skin_bwd_mfma(SkinBwdMfmaArgs a) {
+    DP_SKIN_FP
     constexpr int NQ = TMP ? G + 2 : G;             // pose slots: TMP adds the frame in front of the workgroup's poses (slot 0) and the one behind (slot G + 1)
     constexpr int Q0 = TMP ? 1 : 0;                 // slot of the workgroup's first own pose
     __shared__ __attribute__((aligned(16))) float sA[NQ][64 * 12];
@@ -3149,7 +3165,11 @@ static int lbs_backward_impl(dposer_body_t h, const void* ws_fwd, void* ws_bwd, 
         // at 4096 poses (16 tiles x 8 splits = 128 workgroups per launch, 3 x 109 us); side by side on three streams they share it:
         // the split count is then chosen for the three launches TOGETHER (3 x 16 x 4 = 192 workgroups of twice the K range).
         const bool par = body_tuning().lbs_bwd_terms_parallel;
-        const int kbig = lbs_bwd_big_ksplit(Bpad, pe_big, kb, max_split < 1 ? 1 : max_split, par ? 3 : 1);
+        int kbig = lbs_bwd_big_ksplit(Bpad, pe_big, kb, max_split < 1 ? 1 : max_split, par ? 3 : 1);
+        {   // (A/B: a forced split count, if it is a valid one -- whole two-k-block stages per split, inside the slab space)
+            const int f = body_tuning().lbs_bwd_ksplit;
+            if (kbig && f >= 1 && f <= max_split && kb % (2 * f) == 0 && kb / f >= 32) kbig = f;
+        }
         if (kbig) pe = pe_big;
         else {
             pe = round_up(want_cols < 1 ? 1 : want_cols, 128);

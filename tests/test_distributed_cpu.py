@@ -37,6 +37,16 @@ def _worker(rank, world, port, out):
     # the same means from (sum, count) pairs with ONE all-reduce: every rank gets them, no per-sample values travel
     red = ddp.reduce_metric_means(mine)
     assert abs(red["mpjpe"] - 8 / 12) < 1e-12 and abs(red["mpvpe"] - 80 / 12) < 1e-12
+    # local_only(): inside a data-parallel job the enclosed work runs as a single-process job would (bench.py's N = 1 leg of the same build)
+    assert ddp.dp_active()
+    with ddp.local_only():
+        assert not ddp.dp_active()
+        with ddp.local_only():
+            assert not ddp.dp_active()
+        assert not ddp.dp_active()
+        h = torch.full((8,), float(rank + 1))
+        assert ddp.all_reduce_sum_(h) == 1 and float(h[0]) == rank + 1            # no collective: untouched, "world" of one
+    assert ddp.dp_active()
     flat = torch.arange(10.0) * (rank + 1)
     ddp.broadcast_(flat, src=0)
     lo, hi = ddp.shard_bounds(65536 + 3, world, rank)

@@ -226,8 +226,8 @@ def test_motion_denoise_batch_of_sequences_equals_one_sequence_at_a_time():
         assert np.allclose(log[:, i, :2], t2n(md.loss_log)[:, 0, :2], rtol=1e-6)
 
 
-@pytest.mark.parametrize("S,F", [(3, 8), (2, 23), (17, 60)])
-def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, monkeypatch, tuning_env):
+@pytest.mark.parametrize("S,F,per_frame_betas", [(3, 8, False), (2, 23, False), (17, 60, False), (3, 12, True)])
+def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, per_frame_betas, monkeypatch, tuning_env):
     """The three homes of the temporal term's gradient inside the one-call loop must carry the same bits -- poses and loss log:
     k_skin_x4 + k_md_vert_grad (vertices and their gradient through HBM); dposer_lbs_forward_temporal_grad (skinning + gradient in one
     pass, one run of frames per sequence and several: halo frames recomputed); and, round 6, dposer_lbs_backward_temporal (no skinning
@@ -239,6 +239,8 @@ def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, 
     noise = torch.tensor(rs.standard_normal((iters * spi, F * S, 63)).astype(np.float32), device=DEV)
     md.batch_size = F
     md.betas = md.betas[:F]
+    if per_frame_betas:                                  # a rest shape per frame ([T, V, 3] operands: the VSB instantiations of every kernel)
+        md.betas = torch.tensor(rs.standard_normal((F * S, 10)).astype(np.float32) * 0.5, device=DEV)
     kw = dict(time_strategy="3", iterations=iters, steps_per_iter=spi)
     out = {}
     from dposer_amd import _C
