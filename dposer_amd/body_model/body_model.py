@@ -230,6 +230,17 @@ class _SMPLCore(nn.Module):
             self._h = h
         return self._h
 
+    def __del__(self):
+        # the C handle owns device tables (joint lists, weight fragments) and the side streams / events of the backward: release them with
+        # the module (round 6: they used to live until the process ended -- a test session built ~100 body models)
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                _C.lib().dposer_body_destroy(h)
+            except Exception:      # (interpreter shutdown: the library may already be gone)
+                pass
+            self._h = None
+
     def joint_csr(self):
         """CSR-by-joint form of the skinning weights (which vertices does joint j move) for the backward kernel."""
         if getattr(self, "_jcsr", None) is None or self._jcsr[0].device != self.skin_idx.device:

@@ -609,7 +609,7 @@ struct BodyTuning {
     int lbs_bwd_panel_order = 1;          // DPOSER_LBS_BWD_PANEL_ORDER=0: generic block -> tile order for the blend-gradient GEMMs (A/B)
     bool lbs_k_prefix = true;             // DPOSER_LBS_K_PREFIX=0: blend GEMMs over all padded pose-feature columns, posed or not (A/B)
     int skin_bwd_mfma = 1;                // DPOSER_SKIN_BWD_MFMA=0: the LDS-walking one-pass kernel (k_skin_bwd_fused) instead of the one whose joint reduction runs
-                                          // on the matrix pipe (k_skin_bwd_mfma); 4 / 8: poses per workgroup of the latter (default 4)
+                                          // on the matrix pipe (k_skin_bwd_mfma); 2 / 4 / 5: poses per workgroup of the latter (default 4; the temporal form 5 from 5120 frames)
     bool lbs_bwd_terms_parallel = true;   // DPOSER_LBS_BWD_TERMS_PARALLEL=0: the three product terms of the bf16 x 3 blend-gradient GEMM one after the other on the
                                           // caller's stream (A/B) instead of side by side on three streams
     bool lbs_bwd_rowcat = true;           // DPOSER_LBS_BWD_ROWCAT=0: the two blend-gradient product terms that read the high plane of d_offsets as two launches
@@ -900,14 +900,16 @@ extern "C" int dposer_fk_joints(dposer_body_t h, const float* const* pose_segmen
 //   T_v     = sum_j W[v][j] A_j ;  v = T_v [v_posed ; 1]     -> ELL-sparse skinning, A staged in LDS
 //   joints  = [J posed joints | vertex-selected extras | barycentric landmarks] (+ transl)
 // ------------------------------------------------------------------------------------------------
-// A/B (round 6): -DDPOSER_SKIN_CONTRACT builds the skinning kernels with FMA contraction (this file is compiled with -ffp-contract=off so that the
-// body-model arithmetic mirrors torch's unfused ops): the transform blend is 48 multiply-add pairs per (pose, vertex) and the one-pass backward
-// kernels are VALU-issue-bound.  Every kernel that forms vertices carries the pragma, so the bit-identity relations between them survive.
-#ifdef DPOSER_SKIN_CONTRACT
+// FMA contraction for the code that FORMS SKINNED VERTICES (round 6).  This file is compiled with -ffp-contract=off; the transform blend is 48
+// multiply-add pairs per (pose, vertex), and the motion-denoising backward that skins three frames per pose (k_skin_bwd_mfma<TMP>) is
+// VALU-issue-bound: contracted it is 15 % fewer VALU instructions and the batched loop 5 % faster (profiles/r06_skin_contract_ab.md).  Every kernel
+// that forms vertices (k_skin, k_skin_x4, k_skin_run, k_skin_temporal, the TMP pre-pass) carries the pragma over the SAME two expressions (transform
+// blend, transform x position), so the bit-identity relations between them hold (tests); the temporal term's gradient is formed from those vertices
+// with contraction OFF again (DP_SKIN_FP_OFF: k_md_vert_grad in tasks.hip writes `gx -= bx * inv` where the fused forms write `ax * inv - hold` --
+// contracted, the two would round differently).  The plain backward k_skin_bwd_mfma<TMP = false> does NOT: contracted it is 7 % slower (same file, A/B'd
+// in rounds 5 and 6) and its transform blend is bound to no other kernel's bits.
 #define DP_SKIN_FP _Pragma("clang fp contract(fast)")
-#else
-#define DP_SKIN_FP
-#endif
+#define DP_SKIN_FP_OFF _Pragma("clang fp contract(off)")
 struct SkinArgs {
     const float* offsets;      // [B][ld_off] pose-blend offsets (3V valid)
     int64_t ld_off;
@@ -1226,12 +1228,6 @@ extern "C" int dposer_lbs_pack_posedirs(dposer_body_t h, const float* posedirs, 
     js.n = 3;
     js.job[1] = j; js.job[1].dst_off = n * 4; js.job[1].f32 = 0; js.job[1].split = 1;
     js.job[2] = j; js.job[2].dst_off = n * 6; js.job[2].f32 = 0; js.job[2].split = 2;
-    if (j.rows_pad > 256) {
-        const int64_t n256 = (int64_t)256 * j.ktot;
-        js.n = 5;
-        js.job[3] = j; js.job[3].dst_off = n * 8; js.job[3].f32 = 0; js.job[3].split = 1; js.job[3].rows_pad = 256; js.job[3].rows_valid = P < 256 ? P : 256;
-        js.job[4] = js.job[3]; js.job[4].dst_off = n * 8 + n256 * 2; js.job[4].split = 2;
-    }
     FK_HIP_LAUNCH(launch_pack(js, posedirs, packed, (hipStream_t)stream));
     return DPOSER_OK;
 }
@@ -1538,6 +1534,7 @@ template <int NV, bool VSB> __global__ void __launch_bounds__(256, 4) k_skin_tem
             q[1] = T[4] * p[u][0] + T[5] * p[u][1] + T[6] * p[u][2] + T[7] + tr[1];
             q[2] = T[8] * p[u][0] + T[9] * p[u][1] + T[10] * p[u][2] + T[11] + tr[2];
             if (t > ts) {
+                DP_SKIN_FP_OFF
                 // the pair (t - 1, t): forward difference of frame t - 1, backward difference of frame t (k_md_vert_grad's two branches)
                 const float ax = pv[u][0] - q[0], ay = pv[u][1] - q[1], az = pv[u][2] - q[2];
                 const float ss = ax * ax + ay * ay + az * az;
@@ -2130,7 +2127,6 @@ struct SkinBwdMfmaArgs {
     float* part4;              // [B][chunks][4]: per wave, the sum over its 64 vertices of ||v[t] - v[t+1]|| (0 for a sequence's last frame)
 };
 template <int G, bool VSB, bool TMP = false> __global__ void __launch_bounds__(256, 2) k_skin_bwd_mfma(SkinBwdMfmaArgs a) {
-    DP_SKIN_FP
     constexpr int NQ = TMP ? G + 2 : G;             // pose slots: TMP adds the frame in front of the workgroup's poses (slot 0) and the one behind (slot G + 1)
     constexpr int Q0 = TMP ? 1 : 0;                 // slot of the workgroup's first own pose
     __shared__ __attribute__((aligned(16))) float sA[NQ][64 * 12];
@@ -2251,8 +2247,10 @@ template <int G, bool VSB, bool TMP = false> __global__ void __launch_bounds__(2
         // the window.  The weight fragments of the joint reduction are loaded BEHIND it (with them the window spilled 49 registers).
         float dvk[TMP ? G : 1][3];
         if constexpr (TMP) {
+            DP_SKIN_FP
             float Tq[9], vprev[3], vcur[3], hold[3];
             auto skin_slot = [&](int q, float* T9, float* vout) __attribute__((always_inline)) {
+                DP_SKIN_FP
                 float T[12];
 #pragma unroll
                 for (int i = 0; i < 12; ++i) T[i] = 0.f;
@@ -2282,10 +2280,13 @@ template <int G, bool VSB, bool TMP = false> __global__ void __launch_bounds__(2
                 skin_slot(0, T0, vprev);
                 load_pose(cn, 0);
                 skin_slot(1, Tq, vcur);
-                // pair (frame in front, first own frame): its backward-difference role only (k_md_vert_grad: v_rsq_f32 of the squared distance)
-                const float ax = vprev[0] - vcur[0], ay = vprev[1] - vcur[1], az = vprev[2] - vcur[2];
-                const float invb = __builtin_amdgcn_rsqf(ax * ax + ay * ay + az * az);
-                hold[0] = ax * invb; hold[1] = ay * invb; hold[2] = az * invb;
+                {
+                    DP_SKIN_FP_OFF
+                    // pair (frame in front, first own frame): its backward-difference role only (k_md_vert_grad: v_rsq_f32 of the squared distance)
+                    const float ax = vprev[0] - vcur[0], ay = vprev[1] - vcur[1], az = vprev[2] - vcur[2];
+                    const float invb = __builtin_amdgcn_rsqf(ax * ax + ay * ay + az * az);
+                    hold[0] = ax * invb; hold[1] = ay * invb; hold[2] = az * invb;
+                }
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -2295,16 +2296,20 @@ template <int G, bool VSB, bool TMP = false> __global__ void __launch_bounds__(2
                 float Tn[9], vnext[3];
                 skin_slot(g + 2, Tn, vnext);
                 if (g + 1 == G) load_pose(cn, g + 2);
-                const float ax = vcur[0] - vnext[0], ay = vcur[1] - vnext[1], az = vcur[2] - vnext[2];
-                const float ss = ax * ax + ay * ay + az * az;
-                const float d = sqrtf(ss);
-                const float inv = __builtin_amdgcn_rcpf(d);
-                float gx = 0.f, gy = 0.f, gz = 0.f;
-                if (has_next) { gx = ax * inv; gy = ay * inv; gz = az * inv; }
-                if (has_prev) { gx -= hold[0]; gy -= hold[1]; gz -= hold[2]; }
-                const float invb = __builtin_amdgcn_rsqf(ss);
-                hold[0] = ax * invb; hold[1] = ay * invb; hold[2] = az * invb;
-                const float dx = (live && bv) ? a.c * gx : 0.f, dy = (live && bv) ? a.c * gy : 0.f, dz = (live && bv) ? a.c * gz : 0.f;
+                float dx, dy, dz, d;
+                {
+                    DP_SKIN_FP_OFF
+                    const float ax = vcur[0] - vnext[0], ay = vcur[1] - vnext[1], az = vcur[2] - vnext[2];
+                    const float ss = ax * ax + ay * ay + az * az;
+                    d = sqrtf(ss);
+                    const float inv = __builtin_amdgcn_rcpf(d);
+                    float gx = 0.f, gy = 0.f, gz = 0.f;
+                    if (has_next) { gx = ax * inv; gy = ay * inv; gz = az * inv; }
+                    if (has_prev) { gx -= hold[0]; gy -= hold[1]; gz -= hold[2]; }
+                    const float invb = __builtin_amdgcn_rsqf(ss);
+                    hold[0] = ax * invb; hold[1] = ay * invb; hold[2] = az * invb;
+                    dx = (live && bv) ? a.c * gx : 0.f; dy = (live && bv) ? a.c * gy : 0.f; dz = (live && bv) ? a.c * gz : 0.f;
+                }
                 dvk[g][0] = dx; dvk[g][1] = dy; dvk[g][2] = dz;
                 float dsum = (live && bv && has_next) ? d : 0.f;
 #pragma unroll
@@ -2337,16 +2342,21 @@ template <int G, bool VSB, bool TMP = false> __global__ void __launch_bounds__(2
                 hv[2] = ofn[g][2] + (VSB ? vsn[VSB ? g : 0][2] : vs_cur[2]); hv[3] = 1.0f;
                 load_pose(cn, g);
                 float T[9];
+                {
+#ifdef DPOSER_CT2      // (A/B: contraction in the plain backward's transform blend only)
+                    DP_SKIN_FP
+#endif
 #pragma unroll
-                for (int i = 0; i < 9; ++i) T[i] = 0.f;
+                    for (int i = 0; i < 9; ++i) T[i] = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x4* Aj = reinterpret_cast<const f32x4*>(&sA[g][0]) + jj[k] * 3;
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4* Aj = reinterpret_cast<const f32x4*>(&sA[g][0]) + jj[k] * 3;
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const f32x4 row = Aj[r];
+                        for (int r = 0; r < 3; ++r) {
+                            const f32x4 row = Aj[r];
 #pragma unroll
-                        for (int cc = 0; cc < 3; ++cc) T[3 * r + cc] += w4[k] * row[cc];
+                            for (int cc = 0; cc < 3; ++cc) T[3 * r + cc] += w4[k] * row[cc];
+                        }
                     }
                 }
 #pragma unroll
@@ -2996,7 +3006,8 @@ extern "C" int dposer_lbs_backward_fold(dposer_body_t h, const void* ws_fwd, voi
 // temporal term's, formed inside the skinning-backward kernel from the forward workspace (skinning transforms + pose-blend offsets of the
 // pose and of its two neighbouring frames); d_joints carries the data term.  dist_part4 [batch][ceil(V / 256)][4] receives the per-wave sums
 // of ||v[t] - v[t+1]|| (0 behind a sequence's last frame): ((p0 + p1) + p2) + p3 of an entry is k_md_vert_grad's block sum.  Needs
-// dposer_lbs_temporal_in_backward_ok(); bit-identical to dposer_lbs_forward + k_md_vert_grad + dposer_lbs_backward.
+// dposer_lbs_temporal_in_backward_ok().  Same vertices and vertex gradient as dposer_lbs_forward + k_md_vert_grad, bit for bit; the backward half (own pose's
+// 3 x 3 transform, T^T dv) is FMA-contracted here and agrees with dposer_lbs_backward to fp32 rounding.
 extern "C" int dposer_lbs_backward_temporal(dposer_body_t h, const void* ws_fwd, void* ws_bwd, const void* posedirs_bwd_packed,
                                             const float* const* pose_segments_host, const int32_t* segment_joints_host, int32_t num_segments,
                                             const float* j_rest, int32_t j_rest_batched, const float* v_shaped, int32_t v_shaped_batched,
@@ -3090,8 +3101,14 @@ static int lbs_backward_impl(dposer_body_t h, const void* ws_fwd, void* ws_bwd, 
         a.wfrag = reinterpret_cast<const bf16x8*>(h->jl_wfrag); a.dA = dA; a.chunks = h->jl_chunks; a.B = batch;
         a.F = tmp ? (int)tmp->F : 1; a.c = tmp ? tmp->scale : 0.f; a.part4 = tmp ? tmp->part4 : nullptr;
         if (tmp) {
+            // five poses per workgroup from 5120 frames: 7 skinnings per 5 poses instead of 6 per 4, the chunk's weight fragments serve one pose
+            // more (243 VGPRs, no spills; six spill) -- cfg 5 x 128 (7680 frames): 2.37 -> 2.28 ms per step; below, the smaller grid's last round
+            // costs more than that (1920 frames: 0.78 -> 0.85 ms).  DPOSER_SKIN_BWD_MFMA=4 / 5 forces four / five (A/B; profiles/r06_skin_contract_ab3.md).
+            // (a rest shape per frame keeps four: with five its instantiation spills 4 VGPRs)
+            const bool five = !v_shaped_batched && (mfma_g == 5 || (mfma_g != 4 && batch >= 5120));
             if (v_shaped_batched) hipLaunchKernelGGL((k_skin_bwd_mfma<4, true, true>), dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_skin_bwd_mfma<4, false, true>), dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, st, a);
+            else if (!five) hipLaunchKernelGGL((k_skin_bwd_mfma<4, false, true>), dim3((unsigned)ceil_div(batch, 4)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_skin_bwd_mfma<5, false, true>), dim3((unsigned)ceil_div(batch, 5)), dim3(256), 0, st, a);
         } else if (mfma_g == 2) {
             if (v_shaped_batched) hipLaunchKernelGGL((k_skin_bwd_mfma<2, true>), dim3((unsigned)ceil_div(batch, 2)), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((k_skin_bwd_mfma<2, false>), dim3((unsigned)ceil_div(batch, 2)), dim3(256), 0, st, a);

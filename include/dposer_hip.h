@@ -433,7 +433,8 @@ int dposer_lbs_forward_temporal_grad(dposer_body_t h, void* ws, const void* pose
  *                                     inside the skinning-backward kernel from `ws_fwd` (the vertices of a frame and of its two neighbours
  *                                     are skinned in registers); d_joints carries the data term.  dist_part4 [B, ceil(V/256), 4] out: per-wave
  *                                     sums of ||v[t] - v[t+1]||, ((p0 + p1) + p2) + p3 of an entry = dist_part of dposer_lbs_forward_temporal_grad.
- *                                     Bit-identical to dposer_lbs_forward + the two-kernel gradient + dposer_lbs_backward.
+ *                                     The vertices and the vertex gradient carry the bits of dposer_lbs_forward + the two-kernel gradient; the backward half agrees with
+ *                                     dposer_lbs_backward to fp32 rounding (FMA-contracted transform blend: 2e-6 on the optimised poses).
  *   dposer_lbs_temporal_in_backward_ok(h, skin_k, batch): 1 when dposer_lbs_backward_temporal can run (prepared joint lists with the
  *                                     matrix-pipe tables, four influences per vertex, batch >= DPOSER_LBS_JOINT_STREAM_MIN, bf16 x 3 blend);
  *                                     dposer_motion_denoise_optimize asks it and falls back to the forms above. */

@@ -962,3 +962,30 @@ def test_skinning_over_runs_of_poses_returns_the_bits_of_the_per_pose_kernel(bm,
     tuning_env(DPOSER_SKIN_WAVE="2")
     v2, j2 = run()
     assert np.isfinite(v3).all() and np.array_equal(v3, v2) and np.array_equal(j3, j2)
+
+
+def test_pack_calls_stay_inside_the_buffers_they_are_given(bm):
+    """Every packing entry point writes a caller-owned buffer whose size the library itself reports.  Guard words behind that size must
+    survive the call (round 6: a pack-job list that had grown by two jobs in the WRONG function wrote 32 MB behind the forward posedirs
+    buffer -- the allocator's neighbours absorbed it until an unrelated test aborted)."""
+    from dposer_amd import _C
+    lib, core = _C.lib(), bm.bm
+    h = core._handle()
+    guard = 1 << 16
+    for nbytes, call in ((lib.dposer_lbs_posedirs_packed_bytes(h), lib.dposer_lbs_pack_posedirs),
+                         (lib.dposer_lbs_posedirs_bwd_packed_bytes(h), lib.dposer_lbs_pack_posedirs_bwd)):
+        buf = torch.full((nbytes + guard,), 0xAB, dtype=torch.uint8, device=DEV)
+        _C.check(call(h, _C.ptr(core.posedirs), _C.ptr(buf), _C.stream_ptr()), "pack")
+        torch.cuda.synchronize()
+        assert bool((buf[nbytes:] == 0xAB).all()), call
+        assert bool((buf[:nbytes] != 0xAB).any())
+    # the score network's and the TimeMLPs' packed weights
+    from gpu_common import make_model
+    for prec in ("bf16", "bf16x3", "fp32"):
+        cfg, m, _ = make_model(3, precision=prec)
+        eng = m._engine()
+        nbytes = eng.lib.dposer_scorefc_packed_bytes(eng.h, 1)
+        buf = torch.full((nbytes + guard,), 0xAB, dtype=torch.uint8, device=DEV)
+        _C.check(eng.lib.dposer_scorefc_pack(eng.h, _C.ptr(m.flat_params()), _C.ptr(buf), 1, _C.stream_ptr()), "dposer_scorefc_pack")
+        torch.cuda.synchronize()
+        assert bool((buf[nbytes:] == 0xAB).all()), prec
