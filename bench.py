@@ -614,9 +614,10 @@ def main():
             for _ in range(3):
                 lbs_fwd_bwd(grad)
             torch.cuda.synchronize()
-            # (three runs of ten, median reported, every run listed: the first calls after an idle synchronize() run at a lower clock)
+            # (five runs of ten, median reported, every run listed: the first calls after an idle synchronize() run at a lower clock -- with three
+            #  runs the median itself was such a run every other time: 1.39 / 1.41 / 1.29 ms in one bench, 1.31 in a dedicated A/B on the same box)
             secs = []
-            for _rep in range(3):
+            for _rep in range(5):
                 e0.record()
                 for _ in range(10):
                     lbs_fwd_bwd(grad)
@@ -652,14 +653,14 @@ def main():
                 leg()
             torch.cuda.synchronize()
             secs = []
-            for _rep in range(3):
+            for _rep in range(5):
                 e0.record()
                 for _ in range(10):
                     leg()
                 e1.record()
                 torch.cuda.synchronize()
                 secs.append(e0.elapsed_time(e1) * 1e-3 / 10)
-            sec = sorted(secs)[1]
+            sec = sorted(secs)[len(secs) // 2]
             extra[("lbs_full_fwd_bwd" if grad else "lbs_full_fwd") + "_coherent_skinning"] = {
                 "poses_per_s_per_gpu": nl / sec, "batch": nl, "ms": sec * 1e3, "runs_ms": [round(x * 1e3, 4) for x in secs],
                 "note": "synthetic asset with contiguous vertex ranges following one bone and its tree neighbours (make_synthetic_smplx_asset(coherent_skinning=True))"}
