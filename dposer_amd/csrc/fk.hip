@@ -617,6 +617,8 @@ struct BodyTuning {
     int lbs_bwd_ksplit = 0;               // DPOSER_LBS_BWD_KSPLIT=n: force the split count of the 256x256 blend-gradient GEMMs (A/B; 0 = chosen by lbs_bwd_big_ksplit)
     int64_t fk_lds_pad = 0;               // DPOSER_FK_LDS_PAD=bytes: extra (unused) dynamic LDS per workgroup of k_fk_joints_dma -- an occupancy probe (fewer resident
                                           // waves per CU, same kernel): tools/fk_occupancy_sweep.sh, profiles/r06_fk_occupancy.md
+    bool lbs_fwd_chunk_serial = false;    // DPOSER_LBS_FWD_CHUNK_SERIAL=1: the chunks of DPOSER_LBS_FWD_CHUNK one after the other on the caller's stream (blend GEMM of chunk i,
+                                          // its skinning, chunk i + 1 ...): no overlap, but a chunk's offsets may still sit in the memory-side cache when they are read
     int64_t lbs_fwd_chunk = 0;            // DPOSER_LBS_FWD_CHUNK=n (multiple of 256): the full forward runs blend GEMM and skinning in chunks of n poses, the
                                           // skinning of chunk i on a side stream beside the GEMM of chunk i + 1 (0: one launch each over the whole batch)
     void load() {
@@ -648,6 +650,8 @@ struct BodyTuning {
         lbs_bwd_ksplit = e ? atoi(e) : 0;
         e = getenv("DPOSER_FK_LDS_PAD");
         fk_lds_pad = e ? atoll(e) : (int64_t)0;
+        e = getenv("DPOSER_LBS_FWD_CHUNK_SERIAL");
+        lbs_fwd_chunk_serial = e && e[0] == '1';
         e = getenv("DPOSER_LBS_FWD_CHUNK");
         lbs_fwd_chunk = e ? atoll(e) / 256 * 256 : (int64_t)0;
     }
@@ -1388,11 +1392,13 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
         }
         // (a failing launch must not leave the side stream's kernels unjoined: the caller may free or reuse the workspace as soon as
         //  this call has returned -- the join below runs on the error path too)
+        const bool serial = body_tuning().lbs_fwd_chunk_serial;
         auto chunks = [&]() -> int {
             int k = 0;
             for (int64_t b0 = 0; b0 < batch; b0 += chunk, ++k) {
                 const int64_t r1 = b0 + chunk < blend.Bpad ? b0 + chunk : blend.Bpad;
                 DP_TRY(lbs_blend_rows(blend, b0, b0 + chunk >= batch ? blend.Bpad : r1, st));
+                if (serial) { DP_TRY(skin(b0, (b0 + chunk < batch ? b0 + chunk : batch) - b0, st)); continue; }
                 DP_CHECK_HIP(hipEventRecord(h->ev_chunk[k & 1], st));
                 DP_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_chunk[k & 1], 0));
                 DP_TRY(skin(b0, (b0 + chunk < batch ? b0 + chunk : batch) - b0, h->side));
