@@ -28,7 +28,7 @@ class FusedPfRhs:
     [-> input-gradient] -> ``dposer_pf_ode_rhs_end``) instead of the ~60 small torch launches of the expression-by-expression path
     (``probability_flow_drift`` + autograd), which is bound by host enqueue time below ~16k poses.  Same fp32 operation order as that
     path (the reference's, likelihood.py:60-65 / sde_lib.py:100-104 / utils.py:152-162); only the 63-term Hutchinson sum per sample is
-    formed in a different order.  Covers ScoreModelFC with a VP / sub-VP SDE; ``build`` returns None otherwise (or with
+    formed in a different order.  Covers ScoreModelFC with a VP / sub-VP / (continuous) VE SDE; ``build`` returns None otherwise (or with
     ``DPOSER_ODE_FUSED_RHS=0``) and the caller keeps the generic path.
 
     ``noise`` given: state [B*D + B] -> [d x / dt, d logp / dt] (likelihood.py:86-95); ``noise=None``: state [B*D] -> drift
@@ -41,7 +41,7 @@ class FusedPfRhs:
         from .sde_lib import sde_desc
         desc = sde_desc(sde)
         device = torch.device(device)
-        if (os.environ.get("DPOSER_ODE_FUSED_RHS", "1") == "0" or desc is None or desc.kind == _C.SDE_VE or not isinstance(model, ScoreModelFC) or len(shape) != 2
+        if (os.environ.get("DPOSER_ODE_FUSED_RHS", "1") == "0" or desc is None or not isinstance(model, ScoreModelFC) or len(shape) != 2
                 or device.type != "cuda" or shape[1] != model._engine().D):
             return None
         return FusedPfRhs(_C, desc, model, shape, device, noise)

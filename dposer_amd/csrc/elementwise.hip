@@ -1511,18 +1511,23 @@ struct PfRhsDev {
     int64_t B;
     int D;
 };
+// VE SDE (round 6; sde_lib.py:258-268, utils.py:164-181, continuous): drift0 = 0, g = sigma(t) sqrt(2 ln(sigma_max / sigma_min)), the network is
+// conditioned on sigma(t) and its output IS the score -- the same two kernels with the std division and the -1/2 beta x term gone.
 __global__ void __launch_bounds__(256) k_pf_rhs_begin(PfRhsDev d) {
     const int64_t n = d.B * d.D;
-    const float g = sde_diffusion(d.sde, d.t);
+    const bool ve = d.sde.kind == SDE_VE;
+    const SdeAt at = sde_at(d.sde, d.t);                                      // (sub-VP / VP: the functions the call sites always used, in their order)
+    const float g = ve ? at.g : sde_diffusion(d.sde, d.t);
     const float g2 = g * g;                                                  // diffusion[:, None] ** 2
-    const float sd = sde_std(d.sde, sde_lmc(d.sde, d.t));
+    const float sd = ve ? 1.0f : sde_std(d.sde, sde_lmc(d.sde, d.t));
+    const float label = ve ? at.label : d.t * 999.0f;                        // utils.py:152 / :173
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         d.x[i] = (float)d.state[i];
-        if (i < d.B) d.labels[i] = d.t * 999.0f;                             // utils.py:152
+        if (i < d.B) d.labels[i] = label;
         if (d.dout) {
-            // autograd of  drift0 - (g2 * score) * 0.5,  score = (-out) / std  with upstream gradient `noise`
+            // autograd of  drift0 - (g2 * score) * 0.5,  score = (-out) / std  (VE: score = out)  with upstream gradient `noise`
             const float gscore = ((-d.noise[i]) * 0.5f) * g2;
-            d.dout[i] = -(gscore / sd);
+            d.dout[i] = ve ? gscore : -(gscore / sd);
         }
     }
 }
@@ -1530,14 +1535,15 @@ __global__ void __launch_bounds__(256) k_pf_rhs_end(PfRhsDev d) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= d.B) return;
-    const float g = sde_diffusion(d.sde, d.t);
+    const bool ve = d.sde.kind == SDE_VE;
+    const float g = ve ? sde_at(d.sde, d.t).g : sde_diffusion(d.sde, d.t);
     const float g2 = g * g;
-    const float sd = sde_std(d.sde, sde_lmc(d.sde, d.t));
-    const float a = -0.5f * sde_beta(d.sde, d.t);                            // -0.5 * beta_t
+    const float sd = ve ? 1.0f : sde_std(d.sde, sde_lmc(d.sde, d.t));
+    const float a = ve ? 0.0f : -0.5f * sde_beta(d.sde, d.t);                // -0.5 * beta_t (VE: drift0 = zeros_like(x), sde_lib.py:261)
     float acc = 0.f;
     for (int c = lane; c < d.D; c += 64) {
         const int64_t i = row * d.D + c;
-        const float score = (-d.out[i]) / sd;
+        const float score = ve ? d.out[i] : (-d.out[i]) / sd;
         const float drift = a * d.x[i] - (g2 * score) * 0.5f;
         d.dstate[i] = (double)drift;
         if (d.dx) {
@@ -1553,15 +1559,15 @@ __global__ void __launch_bounds__(256) k_pf_rhs_end(PfRhsDev d) {
 }
 static SdeDev pf_sde_dev(const dposer_sde_desc* s) {
     SdeCfg c;
-    c.kind = s->kind == DPOSER_SDE_VP ? SDE_VP : SDE_SUBVP;
-    c.beta_0 = s->beta_min; c.beta_1 = s->beta_max; c.N = s->N; c.T = (float)s->T;
+    c.kind = s->kind == DPOSER_SDE_VP ? SDE_VP : (s->kind == DPOSER_SDE_VE ? SDE_VE : SDE_SUBVP);
+    c.beta_0 = s->beta_min; c.beta_1 = s->beta_max; c.N = s->N; c.T = (float)s->T;      // (VE: the beta fields carry sigma_min / sigma_max)
     return make_sde_dev(c);
 }
 extern "C" int dposer_pf_ode_rhs_begin(const dposer_sde_desc* sde, float t, const double* state, const float* noise, float* x, float* labels,
                                        float* dout, int64_t batch, int32_t dim, void* stream) {
     DP_RANGE();
     DP_CHECK_ARG(sde && state && x && labels && batch >= 0 && dim >= 1, "bad argument");
-    DP_CHECK_ARG(sde->kind == DPOSER_SDE_VP || sde->kind == DPOSER_SDE_SUBVP, "VP / sub-VP only");
+    DP_CHECK_ARG(sde->kind == DPOSER_SDE_VP || sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VE, "unknown SDE kind");
     DP_CHECK_ARG(!dout || noise, "dout needs noise");
     if (batch == 0) return DPOSER_OK;
     PfRhsDev d{};
@@ -1574,7 +1580,7 @@ extern "C" int dposer_pf_ode_rhs_end(const dposer_sde_desc* sde, float t, const 
                                      const float* noise, double* dstate, int64_t batch, int32_t dim, void* stream) {
     DP_RANGE();
     DP_CHECK_ARG(sde && x && model_out && dstate && batch >= 0 && dim >= 1, "bad argument");
-    DP_CHECK_ARG(sde->kind == DPOSER_SDE_VP || sde->kind == DPOSER_SDE_SUBVP, "VP / sub-VP only");
+    DP_CHECK_ARG(sde->kind == DPOSER_SDE_VP || sde->kind == DPOSER_SDE_SUBVP || sde->kind == DPOSER_SDE_VE, "unknown SDE kind");
     DP_CHECK_ARG(!dx || noise, "dx needs noise");
     DP_CHECK_ARG((batch + 3) / 4 < (int64_t)1 << 31, "batch too large");
     if (batch == 0) return DPOSER_OK;

@@ -268,7 +268,9 @@ int dposer_rk_combine_f64(double* out, const double* y, const double* const* k_h
                           double scale, int64_t n, void* stream);
 /* Right-hand side of the probability-flow ODE around one evaluation of the score network (lib/algorithms/advanced/likelihood.py:60-65,
  * 86-95 `ode_func`; sampling.py:513-530 `ode_func`): drift = -1/2 beta(t) x - 1/2 g(t)^2 score, score = -model(x, 999 t) / std(t)
- * (sde_lib.py:100-104, utils.py:152-162), all samples at the same t, VP / sub-VP.  Two elementwise launches around the network calls:
+ * (sde_lib.py:100-104, utils.py:152-162), all samples at the same t, VP / sub-VP; under the VE SDE (sde_lib.py:208-253) drift =
+ * -1/2 g(t)^2 score with g = sigma(t) sqrt(2 ln(sigma_max / sigma_min)), labels = sigma(t) and score = model(x, sigma(t)) (utils.py:164-175),
+ * the beta terms below zero.  Two elementwise launches around the network calls:
  *   begin: x [B, D] = float(state[0 .. B*D)), labels [B] = 999 t, and -- noise != NULL, dout != NULL -- dout [B, D] = the gradient of
  *          sum(drift * noise) w.r.t. the network output (what torch.autograd hands to the network's backward in likelihood.py:29-35);
  *   end:   dstate[0 .. B*D) = double(drift(x, model_out)); with dx (the network's input gradient for `dout`) also the Hutchinson

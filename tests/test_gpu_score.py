@@ -1369,6 +1369,45 @@ def test_fixed_step_likelihood_and_ode_sampler():
     assert nfe == 64 and torch.isfinite(x).all()
 
 
+def test_ve_probability_flow_ode_on_the_fused_right_hand_side(monkeypatch):
+    """training.sde = 'vesde' through get_likelihood_fn / get_ode_sampler (likelihood.py:40-113, sampling.py:471-542; both build the CONTINUOUS
+    score function): round 6 the VE drift -- drift0 = 0, g = sigma(t) sqrt(2 ln(sigma_max / sigma_min)), the network conditioned on sigma(t),
+    its output the score -- runs on dposer_pf_ode_rhs_begin / _end like VP / sub-VP.  Against the step-by-step form
+    (DPOSER_ODE_FUSED_RHS=0: the reference's torch expressions + autograd around the HIP score function): one right-hand side has the drift
+    bit for bit and the Hutchinson term to its 63-term summation order; the sampler (drift only) therefore takes identical adaptive steps,
+    the likelihood solve (1e-7 differences in d logp / dt under an untrained, stiff VE field) may place a few steps differently and lands on
+    the same bpd / latents to the solver tolerance."""
+    from dposer_amd.algorithms.advanced import likelihood, sampling, sde_lib
+    g = load("g12_likelihood_ode")
+    cfg, m, p = make_model(int(g["seed"]), precision="fp32")
+    sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50.0, N=1000)
+    data, eps = _dev(g["data"]), _dev(g["lik_Rademacher/eps"])
+    B, D = data.shape
+    rhs = likelihood.FusedPfRhs.build(sde, m, (B, D), DEV, eps)
+    assert rhs is not None
+    state = torch.cat([data.reshape(-1).double(), torch.zeros(B, dtype=torch.float64, device=DEV)])
+    drift_fn = lambda xx, tt: likelihood.probability_flow_drift(sde, m, xx, tt)
+    for t in (0.9, 0.5, 0.1, 1e-3):
+        got = rhs(t, state)
+        vt = torch.full((B,), t, device=DEV)
+        want_drift = drift_fn(data, vt).detach().reshape(-1).double()
+        want_div = likelihood.get_div_fn(drift_fn)(data, vt, eps).double()
+        assert torch.equal(got[:B * D], want_drift), t
+        assert rel_err(t2n(got[B * D:]), t2n(want_div)) < 1e-6, t
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DPOSER_ODE_FUSED_RHS", flag)
+        bpd, z, nfe = likelihood.get_likelihood_fn(sde, lambda v: v, rtol=1e-5, atol=1e-5, eps=1e-5)(m, data, epsilon=eps)
+        nfe_s, x = sampling.get_ode_sampler(sde, (6, 63), lambda v: v, rtol=1e-5, atol=1e-5, eps=1e-3, device=DEV)(m, z=_dev(g["ode/z"]) * 50.0)
+        out[flag] = (t2n(bpd), t2n(z), nfe, nfe_s, t2n(x))
+    monkeypatch.delenv("DPOSER_ODE_FUSED_RHS")
+    f, u = out["1"], out["0"]
+    assert f[3] == u[3] and f[3] > 0 and np.array_equal(f[4], u[4])         # drift-only solve: identical step decisions, identical samples
+    assert 0 < f[2] and abs(f[2] - u[2]) <= 0.1 * u[2]
+    assert np.isfinite(f[0]).all() and np.isfinite(f[4]).all()
+    assert rel_err(f[0], u[0]) < 1e-4 and rel_err(f[1], u[1]) < 1e-3
+
+
 def test_persistent_sampler_kernels_return_the_bits_of_the_launch_path():
     """gemm_sampler.hip (opt-in): DPOSER_SAMPLER_PERSISTENT=1 -- one workgroup per 256 samples walks every layer of every step;
     =2 -- clusters of four workgroups on one XCD take one channel tile each and are joined by a progress counter per sample block.
