@@ -604,6 +604,7 @@ struct BodyTuning {
     bool blend_fp32 = false;              // DPOSER_LBS_BLEND=fp32: exact-fp32 pose-blend chain
     int skin_mode = 3;                    // DPOSER_SKIN_WAVE=0: one vertex per thread and iteration (k_skin); 2: four in flight, one pose per block (k_skin_x4); 3: runs of poses (k_skin_run)
     bool skin_bwd_fused = true;           // DPOSER_SKIN_BWD_FUSED=0: k_skin_bwd + k_skin_bwd_joints instead of the one-pass kernel (A/B)
+    bool lbs_fwd_big = true;              // DPOSER_LBS_FWD_BIG=0: 128x128 tiles for the pose-blend GEMM of the forward at every batch size (A/B)
     bool lbs_bwd_big = true;              // DPOSER_LBS_BWD_BIG=0: 128x128 tiles for the blend-gradient GEMMs at every batch size (A/B)
     bool fk_dma = true;                   // DPOSER_FK_DMA=0: joints-only body query through k_fk_joints instead of k_fk_joints_dma (A/B)
     int lbs_bwd_panel_order = 1;          // DPOSER_LBS_BWD_PANEL_ORDER=0: generic block -> tile order for the blend-gradient GEMMs (A/B)
@@ -634,6 +635,8 @@ struct BodyTuning {
         skin_bwd_fused = !(e && e[0] == '0');
         e = getenv("DPOSER_LBS_BWD_BIG");
         lbs_bwd_big = !(e && e[0] == '0');
+        e = getenv("DPOSER_LBS_FWD_BIG");
+        lbs_fwd_big = !(e && e[0] == '0');
         e = getenv("DPOSER_FK_DMA");
         fk_dma = !(e && e[0] == '0');
         e = getenv("DPOSER_LBS_K_PREFIX");
@@ -1274,7 +1277,7 @@ static int lbs_blend_rows(const LbsBlend& b, int64_t r0, int64_t r1, hipStream_t
         const char* hi = (const char*)b.posedirs_packed + b.Cpad * b.Ppad * 4;
         const char* lo = hi + b.Cpad * b.Ppad * 2;
         const int kb = b.Ppad / 16, kbe = b.Keff / 16;
-        const int shape = (rows % 256 == 0 && b.Cpad % 256 == 0 && b.Bpad >= 1024) ? SHAPE_BIG : SHAPE_MID;
+        const int shape = (rows % 256 == 0 && b.Cpad % 256 == 0 && b.Bpad >= 1024 && body_tuning().lbs_fwd_big) ? SHAPE_BIG : SHAPE_MID;
         const int tile = shape == SHAPE_BIG ? 256 : 128;
         g.W = (const char*)b.pf_split + (r0 / 32) * (int64_t)(3 * kbe) * 1024; g.w_stride_blocks = 3 * kbe; g.n_cblk = (int)(rows / tile); g.n_sblk = (int)(b.Cpad / tile);
         g.src[0] = hi; g.src[1] = lo; g.src[2] = hi;                        // [pf_hi | pf_hi | pf_lo] x [hi ; lo ; hi]
