@@ -96,7 +96,7 @@ class MotionDenoise:
                 and isinstance(self.body_model, BodyModel)
                 and getattr(nz, "rot_rep", None) in ("axis", "rot6d") and self.batch_size >= 2)
 
-    def _optimize_fused(self, pose, init_joints, t_list, its, weights, noise, frames_per_sequence=0):
+    def _optimize_fused(self, pose, init_joints, t_list, its, weights, noise, frames_per_sequence=0, betas=None):
         """All optimisation steps in one C call; ``pose`` [T, 63] is updated in place (T = sequences x frames_per_sequence when a
         batch of sequences is advanced together).  Returns the per-step loss log [steps, sequences, 3] (temp, data, prior)."""
         model, core, nz = self.model, self.body_model.bm, self.Normalizer
@@ -110,7 +110,8 @@ class MotionDenoise:
         lib, h = _C.lib(), core._handle()
         F = int(frames_per_sequence) if frames_per_sequence else T
         n_seq = T // F
-        betas = self.betas if self.betas.shape[0] == T else self.betas[:1]
+        if betas is None:
+            betas = self.betas if self.betas.shape[0] == T else self.betas[:1]
         if betas.shape[0] > 1 and bool((betas == betas[:1]).all()):
             # one body shape for every frame (the module's default: motion_denoising.py:64 keeps zeros((batch_size, 10))): the rest
             # shape is formed once and shared -- the skinning kernels then read 126 KB from L2 instead of a [T, V, 3] copy from HBM
@@ -209,9 +210,18 @@ class MotionDenoise:
         start = self.poses[:F].repeat(S, 1) if init_poses is None else flat(init_poses)
         pose = start.detach().clone().contiguous().float()
         quan = [self._quan_t(time_strategy, step, total_steps, sample_trun, sample_time) for step in range(total_steps)]
-        self.loss_log = self._optimize_fused(pose, flat(joints3d).detach(), [float(timesteps[q]) for q in quan],
-                                             [s // steps_per_iter for s in range(total_steps)], self.get_loss_weights(), noise,
-                                             frames_per_sequence=F)
+        # (the C entry takes at most 65535 frames per call -- one grid row per frame in its skinning kernels; sequences are independent
+        #  problems, so a larger batch goes through in groups of whole sequences, each group with its rows of the injected noise)
+        per_call = max(1, 65535 // F)
+        joints_flat, t_steps = flat(joints3d).detach(), [float(timesteps[q]) for q in quan]
+        iters_of_step, weights, logs = [s // steps_per_iter for s in range(total_steps)], self.get_loss_weights(), []
+        for s0 in range(0, S, per_call):
+            fr = slice(s0 * F, min(S, s0 + per_call) * F)
+            logs.append(self._optimize_fused(pose[fr], joints_flat[fr], t_steps, iters_of_step, weights,
+                                             None if noise is None else (noise if per_call >= S else noise[:, fr].contiguous()),
+                                             frames_per_sequence=F,
+                                             betas=self.betas[fr] if (per_call < S and self.betas.shape[0] == S * F) else None))
+        self.loss_log = logs[0] if len(logs) == 1 else torch.cat(logs, dim=1)
         with torch.no_grad():
             final = pose.reshape(S, F, -1)
             smooth = torch.stack([gaussian_smoothing(final[i], window_size=3, sigma=2) for i in range(S)])
