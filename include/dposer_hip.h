@@ -557,7 +557,8 @@ typedef struct dposer_motion_denoise_args {
     int32_t num_vertices;
     int32_t num_joints;
     int32_t joint_rows;
-    int64_t frames;
+    int64_t frames;       /* sequences x frames_per_sequence, at most 65535 per call (sequences are independent: a larger batch goes through in groups
+                             of whole sequences, as MotionDenoise.optimize_sequences does) */
     int64_t frames_per_sequence;
     float* pose;
     float* adam_m;
