@@ -146,7 +146,7 @@ hipError_t gemm_em_step(int prec, int shape, const GemmArgs& g, const EmStepPara
 hipError_t gemm_partial_ft(int prec, int shape, const GemmArgs& g, const PartialFTParams& p, hipStream_t st) {
     PROF(EPI_PLAIN_FT);
     if (prec == PREC_BF16X3) return gemm_partial_ft_x3(shape, g, p, st);
-    typedef EpiPartialFT<__bf16> A; typedef EpiPartialFT<float> B; DISPATCH(A, B, M_MID);
+    typedef EpiPartialFT<__bf16> A; typedef EpiPartialFT<float> B; DISPATCH(A, B, M_MID | M_SMALL);
 }
 hipError_t gemm_dsm_step(int prec, int shape, const GemmArgs& g, const DsmStepParams& p, hipStream_t st) {
     PROF(EPI_DSM_STEP);

@@ -1662,7 +1662,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
         // Small batches: 40 tiles at 1280 samples, each walking K = L * H alone (36 us).  One k-split per layer segment fills the chip
         // (12 us for the plain GEMM at 1280 samples, tools/tune_gemm.hip TUNE_SPLITK); k_silu_bwd_reduce adds the splits in layer order,
         // applies act'(u) and keeps the column sums.  From ~4096 samples up the one launch is as fast: DPOSER_SILU_SPLIT_MAX.
-        if (tr && shape == SHAPE_MID && w.dU_part && Bpad <= score_tuning().silu_split_max && Bpad <= SILU_SPLIT_CAP && L <= GEMM_MAX_SEG && L <= 8) {
+        if (tr && (shape == SHAPE_MID || shape == SHAPE_SMALL) && w.dU_part && Bpad <= score_tuning().silu_split_max && Bpad <= SILU_SPLIT_CAP && L <= GEMM_MAX_SEG && L <= 8) {
             g.ksplit = L;
             g.split_segments = 1;
             PartialFTParams pp;
