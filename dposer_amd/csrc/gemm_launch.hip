@@ -63,12 +63,18 @@ void gemm_prof_kind_name(int kind, char* out, int n) {
 
 // Each epilogue only instantiates the tilings it is used with (bit i = GemmShape i).
 // K pipeline of every tiling but 128x32: ring of 4 slots x 2 k-blocks with the DMA spread between the MFMAs (gemm.h);
-// 128x32 (one sample tile: its two activation blocks per stage do not split over four waves) keeps the 2 x 4 k-block loop.
+// 128x32 (one sample tile: its two activation blocks per stage do not split over four waves) keeps stages of 4 k-blocks.
 #ifndef DPOSER_RING_KB
 #define DPOSER_RING_KB 2
 #define DPOSER_RING_NB 4
 #endif
 constexpr int RING_KB = DPOSER_RING_KB, RING_NB = DPOSER_RING_NB;
+// 128x32, bf16: THREE slots of 4 k-blocks (round 6, tools/tune_gemm.hip TUNE_TINY2, profiles/r06_small_tile_pipeline.txt: -8 ... -16 % per launch from 128 to 3968
+// samples against two slots; four slots = 80 KB leave one workgroup per CU and lose from 1280 samples up).  Same K order: bit-identical.
+#ifndef DPOSER_SMALL_NB
+#define DPOSER_SMALL_NB 3
+#endif
+template <typename T> constexpr int small_nb() { return sizeof(T) == 2 ? DPOSER_SMALL_NB : 2; }
 constexpr unsigned M_BIG = 1u << SHAPE_BIG, M_MID = 1u << SHAPE_MID, M_SMALL = 1u << SHAPE_SMALL, M_FINAL = 1u << SHAPE_FINAL,
                    M_FINAL_S = 1u << SHAPE_FINAL_S, M_WIDE = 1u << SHAPE_WIDE64;
 
@@ -77,7 +83,7 @@ static hipError_t by_shape_masked(int shape, const GemmArgs& g, const typename E
     switch (shape) {
         case SHAPE_BIG: if constexpr (ALLOWED & M_BIG) return launch_gemm<T, 2, 4, 4, 2, RING_KB, Epi, RING_NB>(g, p, st); break;
         case SHAPE_MID: if constexpr (ALLOWED & M_MID) return launch_gemm<T, 2, 2, 2, 2, RING_KB, Epi, RING_NB>(g, p, st); break;
-        case SHAPE_SMALL: if constexpr (ALLOWED & M_SMALL) return launch_gemm<T, 4, 1, 1, 1, 4, Epi>(g, p, st); break;
+        case SHAPE_SMALL: if constexpr (ALLOWED & M_SMALL) return launch_gemm<T, 4, 1, 1, 1, 4, Epi, small_nb<T>()>(g, p, st); break;
         case SHAPE_FINAL: if constexpr (ALLOWED & M_FINAL) return launch_gemm<T, 1, 4, 2, 1, RING_KB, Epi, RING_NB>(g, p, st); break;
         case SHAPE_FINAL_S: if constexpr (ALLOWED & M_FINAL_S) return launch_gemm<T, 2, 1, 1, 1, RING_KB, Epi, RING_NB>(g, p, st); break;
         case SHAPE_WIDE64: if constexpr (ALLOWED & M_WIDE) return launch_gemm<T, 2, 2, 2, 1, RING_KB, Epi, RING_NB>(g, p, st); break;
@@ -98,7 +104,7 @@ static hipError_t by_shape_generic(int shape, const GemmArgs& g, const typename 
     if (shape == SHAPE_MID) return launch_gemm<T, 2, 2, 2, 2, RING_KB, Epi, RING_NB>(g, p, st);
     if (shape == SHAPE_SMALL) {
         if constexpr (PAIR) return launch_gemm<T, 2, 1, 2, 1, 4, Epi>(g, p, st);
-        else return launch_gemm<T, 4, 1, 1, 1, 4, Epi>(g, p, st);
+        else return launch_gemm<T, 4, 1, 1, 1, 4, Epi, small_nb<T>()>(g, p, st);
     }
     return hipErrorInvalidConfiguration;
 }

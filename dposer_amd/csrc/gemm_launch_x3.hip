@@ -12,12 +12,16 @@
 #endif
 namespace {
 constexpr int RING_KB = DPOSER_RING_KB, RING_NB = DPOSER_RING_NB;
+#ifndef DPOSER_SMALL_NB
+#define DPOSER_SMALL_NB 3
+#endif
+constexpr int SMALL_NB = DPOSER_SMALL_NB;       // (gemm_launch.hip: three slots for the 128x32 tiling)
 template <typename Epi>
 hipError_t main_shapes(int shape, const GemmArgs& g, const typename Epi::Params& p, hipStream_t st) {
     switch (shape) {
         case SHAPE_BIG: return launch_gemm<__bf16, 2, 4, 4, 2, RING_KB, Epi, RING_NB>(g, p, st);
         case SHAPE_MID: return launch_gemm<__bf16, 2, 2, 2, 2, RING_KB, Epi, RING_NB>(g, p, st);
-        case SHAPE_SMALL: return launch_gemm<__bf16, 4, 1, 1, 1, 4, Epi>(g, p, st);
+        case SHAPE_SMALL: return launch_gemm<__bf16, 4, 1, 1, 1, 4, Epi, SMALL_NB>(g, p, st);
     }
     return hipErrorInvalidConfiguration;
 }
@@ -27,7 +31,7 @@ template <typename Epi>
 hipError_t narrow_shapes(int shape, const GemmArgs& g, const typename Epi::Params& p, hipStream_t st) {      // (runtime-selected activations: the 128-wide tilings only, as in gemm_launch.hip)
     switch (shape) {
         case SHAPE_MID: return launch_gemm<__bf16, 2, 2, 2, 2, RING_KB, Epi, RING_NB>(g, p, st);
-        case SHAPE_SMALL: return launch_gemm<__bf16, 4, 1, 1, 1, 4, Epi>(g, p, st);
+        case SHAPE_SMALL: return launch_gemm<__bf16, 4, 1, 1, 1, 4, Epi, SMALL_NB>(g, p, st);
     }
     return hipErrorInvalidConfiguration;
 }
@@ -38,7 +42,7 @@ hipError_t generic_shapes(int shape, const GemmArgs& g, const typename Epi::Para
     if (shape == SHAPE_MID) return launch_gemm<__bf16, 2, 2, 2, 2, RING_KB, Epi, RING_NB>(g, p, st);
     if (shape == SHAPE_SMALL) {
         if constexpr (PAIR) return launch_gemm<__bf16, 2, 1, 2, 1, 4, Epi>(g, p, st);
-        else return launch_gemm<__bf16, 4, 1, 1, 1, 4, Epi>(g, p, st);
+        else return launch_gemm<__bf16, 4, 1, 1, 1, 4, Epi, SMALL_NB>(g, p, st);
     }
     return hipErrorInvalidConfiguration;
 }

@@ -351,9 +351,10 @@ struct ScoreTuning {
     int64_t silu_split_max = 2048;    // DPOSER_SILU_SPLIT_MAX = <samples>: up to this padded batch the time-branch dgrad runs one k-split per layer + a reduce pass (0: never)
     int dsm_fused = 0;                // DPOSER_DSM_FUSED = 1: post_dense with the DSM loss in its epilogue (EpiDsm) instead of GEMM -> res -> k_dsm
                                       // (opt-in: measured -0.6 % at 8192 poses, -0.2 % at 65536, +0.5 % at 1280 -- profiles/r04_dsm_fused_ab.txt)
-    int64_t small_tile_max = 1280;    // DPOSER_SMALL_TILE_MAX = <samples>: up to this padded batch the GroupNorm layers take the 128x32 tiling also where 128x128
-                                      // divides the batch (1280 samples are 80 workgroups of 128x128 on 256 CUs).  Bit-identical; sampler step 61.3 -> 58.7 us at
-                                      // 500 samples, 63.3 -> 61.6 at 1280, training step -2 % at 512, unchanged at 1280, slower from 2048 (profiles/r05_small_tile_ab.txt)
+    int64_t small_tile_max = 2048;    // DPOSER_SMALL_TILE_MAX = <samples>: up to this padded batch the GroupNorm layers take the 128x32 tiling also where 128x128
+                                      // divides the batch (1280 samples are 80 workgroups of 128x128 on 256 CUs).  Bit-identical.  Round 6, with three K-loop slots on
+                                      // that tiling (gemm_launch.hip): training step 0.370 -> 0.339 ms at 1536 poses, 0.389 -> 0.383 at 2048, slower from 2560
+                                      // (profiles/r06_small_tile_max_sweep.md; round 5, two slots: the crossover was 1280, profiles/r05_small_tile_ab.txt)
     int sampler_persistent = 0;       // DPOSER_SAMPLER_PERSISTENT = 1: one persistent kernel for the plain EM sampler
     int64_t sampler_persistent_min = 256;
     void load() {
@@ -374,7 +375,7 @@ struct ScoreTuning {
         e = getenv("DPOSER_SILU_SPLIT_MAX");
         silu_split_max = e ? atoll(e) : (int64_t)2048;
         e = getenv("DPOSER_SMALL_TILE_MAX");
-        small_tile_max = e ? atoll(e) : (int64_t)1280;
+        small_tile_max = e ? atoll(e) : (int64_t)2048;
         e = getenv("DPOSER_SAMPLER_PERSISTENT");
         sampler_persistent = e ? atoi(e) : 0;
         e = getenv("DPOSER_SAMPLER_PERSISTENT_MIN");

@@ -225,6 +225,28 @@ int main(int argc, char** argv) {
         run_all(9, 50);
         return 0;
     }
+    if (getenv("TUNE_TINY2")) {      // round 6: the 128x32 tiling of the small batches (sampler at 500 samples, training at <= 1280): deeper K pipelines, wider tiles
+        GN(4, 1, 1, 1, 4, 2);        // shipped until round 6: 2 slots x 4 k-blocks
+        GN(4, 1, 1, 1, 4, 3);
+        GN(4, 2, 1, 1, 4, 3);        // 128 x 64, 8 waves
+        GN(4, 2, 1, 1, 4, 4);
+        GN(2, 2, 1, 1, 4, 3);        // 64 x 64, 4 waves
+        GN(2, 2, 2, 2, 2, 4);        // 128 x 128 (asm stage)
+        GNT(4, 1, 1, 1, 4, 2);
+        GNT(4, 1, 1, 1, 4, 3);
+        GNT(4, 2, 1, 1, 4, 3);
+        GNT(4, 2, 1, 1, 4, 4);
+        GNT(2, 2, 1, 1, 4, 3);
+        GNT(2, 2, 2, 2, 2, 4);
+        GB(4, 1, 1, 1, 4, 2, 1, 0, 0, 0);
+        GB(4, 1, 1, 1, 4, 3, 1, 0, 0, 0);
+        GB(4, 2, 1, 1, 4, 3, 1, 0, 0, 0);
+        GB(4, 2, 1, 1, 4, 4, 1, 0, 0, 0);
+        GB(2, 2, 1, 1, 4, 3, 1, 0, 0, 0);
+        GB(2, 2, 2, 2, 2, 4, 1, 0, 0, 0);
+        run_all(9, 50);
+        return 0;
+    }
     if (getenv("TUNE_SPLITK")) {     // round 4: the time-branch dgrad at small batches is 40 ... 256 tiles with K = 5120 (run with TUNE_C=512 TUNE_K=5120 and
                                      // S = 1280 / 4096 / 8192): what would splitting the reduction over the five layers' segments buy?  (timing probe: the
                                      // splits overwrite one another's tile)
