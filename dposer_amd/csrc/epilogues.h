@@ -492,14 +492,22 @@ template <typename T> struct EpiEmStep {
         return sc;
     }
     // one 32x32 tile: x (in: the state, out: the next state) and x_mean from the post_dense accumulator `a`
-    __device__ static inline void tile(const Params& p, const Scal& sc, const f32x16& a, int c0, int64_t s, int hi, float (&x)[16], float (&xm)[16]) {
+    // the tile's 16 standard normals per lane (they do not depend on the accumulator: drawn in front of the K loop, see Pre)
+    __device__ static inline void draw(const Params& p, int c0, int64_t s, int hi, float (&z)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float z4[4];
+            normals4((uint64_t)s * p.QD + ((c0 + 8 * q + 4 * hi) >> 2), STREAM_EM_NOISE, p.step, p.seed, z4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[4 * q + r] = z4[r];
+        }
+    }
+    __device__ static inline void tile(const Params& p, const Scal& sc, const f32x16& a, int c0, int64_t s, int hi, float (&x)[16], float (&xm)[16], const float (&z)[16]) {
 #pragma clang fp contract(off)
         const float sd = sc.sd, beta = sc.beta, g = sc.g, usig = sc.usig;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = c0 + 8 * q + 4 * hi;
-            float z[4];
-            normals4((uint64_t)s * p.QD + (c >> 2), STREAM_EM_NOISE, p.step, p.seed, z);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 4 * q + r;
@@ -510,9 +518,49 @@ template <typename T> struct EpiEmStep {
                 drift = drift - ((g * g) * score) * 1.0f;
                 const float mean = x[i] + drift * p.sde.dt;
                 xm[i] = valid ? mean : 0.f;
-                x[i] = valid ? mean + (g * p.sde.sqrt_mdt) * z[r] : 0.f;
+                x[i] = valid ? mean + (g * p.sde.sqrt_mdt) * z[i] : 0.f;
             }
         }
+    }
+    // In front of the K loop (gemm.h EpiPre): the state tiles are requested before the first DMA and the normals are drawn behind the prologue's
+    // DMA issue -- at 500 samples (16 workgroups, a latency-bound launch) both used to sit behind the last MFMA: 11.9 us per step, 6.3 of them K loop.
+    template <int TC, int TS> struct Pre { float x[TC * TS][16]; float z[TC * TS][16]; };
+    template <int TC, int TS>
+    __device__ static inline void pre_issue(const Params& p, Pre<TC, TS>& pre, int cbase, int64_t sbase, int lane) {
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) TileIO<float>::load(p.x_ft + ft_tile_base<float>(sbase + ts * 32, cbase + tc * 32, p.Cp), lane, pre.x[tc * TS + ts]);
+    }
+    template <int TC, int TS>
+    __device__ static inline void pre_compute(const Params& p, Pre<TC, TS>& pre, int cbase, int64_t sbase, int lane) {
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                draw(p, cbase + tc * 32, sbase + ts * 32 + (lane & 31), lane >> 5, pre.z[tc * TS + ts]);
+                // (pin: without it hipcc sinks the whole draw to its first use, behind the K loop)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(pre.z[tc * TS + ts][i]));
+            }
+    }
+    template <int TC, int TS>
+    __device__ static inline void apply_pre(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, Pre<TC, TS>& pre) {
+        const int j = lane & 31, hi = lane >> 5;
+        const Scal sc = scalars(p);
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int ts = 0; ts < TS; ++ts) {
+                const int c0 = cbase + tc * 32;
+                const int64_t s = sbase + ts * 32 + j;
+                const int64_t tb = ft_tile_base<float>(sbase + ts * 32, c0, p.Cp);
+                float xm[16];
+                tile(p, sc, acc[tc][ts], c0, s, hi, pre.x[tc * TS + ts], xm, pre.z[tc * TS + ts]);
+                TileIO<float>::store(p.x_ft + tb, lane, pre.x[tc * TS + ts]);
+                if (p.x_mean_ft) TileIO<float>::store(p.x_mean_ft + tb, lane, xm);
+                TileIO<T>::store((T*)p.xin + ft_tile_base<T>(sbase + ts * 32, c0, p.Cp), lane, pre.x[tc * TS + ts]);
+            }
     }
     template <int TC, int TS>
     __device__ static inline void apply(const Params& p, f32x16 (&acc)[TC][TS], int cbase, int64_t sbase, int lane, int, int, const float*, int, unsigned char*) {
@@ -525,9 +573,10 @@ template <typename T> struct EpiEmStep {
                 const int c0 = cbase + tc * 32;
                 const int64_t s = sbase + ts * 32 + j;
                 const int64_t tb = ft_tile_base<float>(sbase + ts * 32, c0, p.Cp);
-                float x[16], xm[16];
+                float x[16], xm[16], z[16];
                 TileIO<float>::load(p.x_ft + tb, lane, x);
-                tile(p, sc, acc[tc][ts], c0, s, hi, x, xm);
+                draw(p, c0, s, hi, z);
+                tile(p, sc, acc[tc][ts], c0, s, hi, x, xm, z);
                 TileIO<float>::store(p.x_ft + tb, lane, x);
                 if (p.x_mean_ft) TileIO<float>::store(p.x_mean_ft + tb, lane, xm);
                 TileIO<T>::store((T*)p.xin + ft_tile_base<T>(sbase + ts * 32, c0, p.Cp), lane, x);

@@ -109,6 +109,15 @@ template <typename Epi, typename = void> struct EpiScratch { static constexpr in
 template <typename Epi> struct EpiScratch<Epi, decltype((void)Epi::kScratchPerWave)> { static constexpr int value = Epi::kScratchPerWave; };
 
 // Epilogues that prefetch their own operands through the (idle) K-loop ring declare kRingPerWave bytes and apply_ring(...).
+// Optional epilogue work IN FRONT of the K loop (round 6: latency-bound small launches, e.g. the sampler's fused post_dense + Euler-Maruyama step, whose
+// epilogue -- state tile loads, Philox normals -- was as long as its K loop).  `Epi::Pre<TC, TS>` = register state; `Epi::pre_issue` issues global loads
+// into it BEFORE the first DMA (VMEM returns in order and the loop's vmcnt waits count the YOUNGEST operations: older loads do not disturb them);
+// `Epi::pre_compute` = arithmetic that needs no accumulator, run behind the prologue's DMA issue, under its latency; the epilogue is then `apply_pre`.
+template <typename Epi, int TC, int TS, typename = void> struct EpiPre { struct type {}; static constexpr bool value = false; };
+template <typename Epi, int TC, int TS> struct EpiPre<Epi, TC, TS, decltype((void)sizeof(typename Epi::template Pre<TC, TS>))> {
+    typedef typename Epi::template Pre<TC, TS> type;
+    static constexpr bool value = true;
+};
 template <typename Epi, typename = void> struct EpiRing { static constexpr int value = 0; };
 #ifndef DPOSER_NO_EPI_RING   // (A/B switch for the tuner)
 template <typename Epi> struct EpiRing<Epi, decltype((void)Epi::kRingPerWave)> { static constexpr int value = Epi::kRingPerWave; };
@@ -267,9 +276,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
     if (DPOSER_KLOOP_PRIO == 1 && wave >= C::NW / 2) __builtin_amdgcn_s_setprio(1);
     if (DPOSER_KLOOP_PRIO == 2 && wave < C::NW / 2) __builtin_amdgcn_s_setprio(1);
 #endif
+    typedef EpiPre<Epi, TC, TS> PreT;
+    typename PreT::type pre_state;
+    const int e_cbase = (cblk * C::CT + wc * TC) * 32;
+    const int64_t e_sbase = ((int64_t)sblk * C::ST + ws * TS) * 32;
+    if constexpr (PreT::value) Epi::template pre_issue<TC, TS>(ep, pre_state, e_cbase, e_sbase, lane);
     if constexpr (NB == 2) {
         fetch_glds(0);
         if (nstages > 1) fetch_glds(1);
+        if constexpr (PreT::value) Epi::template pre_compute<TC, TS>(ep, pre_state, e_cbase, e_sbase, lane);
         if (nstages > 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(C::LPW)); else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
         __syncthreads_lds_only();
         load_frags(0, 0, 0);
@@ -364,6 +379,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         } else {
             for (int s0 = 0; s0 < npre; ++s0) fetch_glds(s0);
         }
+        if constexpr (PreT::value) Epi::template pre_compute<TC, TS>(ep, pre_state, e_cbase, e_sbase, lane);
         // stage 0 landed?  VMEM returns in order: all but the last npre-1 stages
         if (npre >= 3) __builtin_amdgcn_s_waitcnt(waitcnt_vm(2 * C::LPW));
         else if (npre == 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(C::LPW));
@@ -474,6 +490,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const typename Epi:
         __syncthreads_lds_only();      // every wave is done with the ring (no DMA is in flight after the last stage)
         Epi::template apply_ring<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
                                          sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32, wave_scratch, smem + wave * EpiRing<Epi>::value);
+    } else if constexpr (PreT::value) {
+        Epi::template apply_pre<TC, TS>(ep, acc, e_cbase, e_sbase, lane, pre_state);
     } else {
         Epi::template apply<TC, TS>(ep, acc, (cblk * C::CT + wc * TC) * 32, ((int64_t)sblk * C::ST + ws * TS) * 32, lane,
                                     sblk * WS + ws, split, lds_par + wc * TC * 32, C::CT * 32, wave_scratch);

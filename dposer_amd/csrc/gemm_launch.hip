@@ -74,6 +74,12 @@ constexpr int RING_KB = DPOSER_RING_KB, RING_NB = DPOSER_RING_NB;
 #ifndef DPOSER_SMALL_NB
 #define DPOSER_SMALL_NB 3
 #endif
+// 64x32 (post_dense / dx / the fused Euler-Maruyama step at small batches), bf16: three slots of 4 k-blocks instead of four of 2 (16 stages for K = 1024
+// instead of 32: 6.3 -> 5.7 us, profiles/r06_final_tile.txt).  Same K order.
+#ifndef DPOSER_FINAL_S_KB
+#define DPOSER_FINAL_S_KB 4
+#define DPOSER_FINAL_S_NB 3
+#endif
 template <typename T> constexpr int small_nb() { return sizeof(T) == 2 ? DPOSER_SMALL_NB : 2; }
 constexpr unsigned M_BIG = 1u << SHAPE_BIG, M_MID = 1u << SHAPE_MID, M_SMALL = 1u << SHAPE_SMALL, M_FINAL = 1u << SHAPE_FINAL,
                    M_FINAL_S = 1u << SHAPE_FINAL_S, M_WIDE = 1u << SHAPE_WIDE64;
@@ -85,7 +91,7 @@ static hipError_t by_shape_masked(int shape, const GemmArgs& g, const typename E
         case SHAPE_MID: if constexpr (ALLOWED & M_MID) return launch_gemm<T, 2, 2, 2, 2, RING_KB, Epi, RING_NB>(g, p, st); break;
         case SHAPE_SMALL: if constexpr (ALLOWED & M_SMALL) return launch_gemm<T, 4, 1, 1, 1, 4, Epi, small_nb<T>()>(g, p, st); break;
         case SHAPE_FINAL: if constexpr (ALLOWED & M_FINAL) return launch_gemm<T, 1, 4, 2, 1, RING_KB, Epi, RING_NB>(g, p, st); break;
-        case SHAPE_FINAL_S: if constexpr (ALLOWED & M_FINAL_S) return launch_gemm<T, 2, 1, 1, 1, RING_KB, Epi, RING_NB>(g, p, st); break;
+        case SHAPE_FINAL_S: if constexpr (ALLOWED & M_FINAL_S) return launch_gemm<T, 2, 1, 1, 1, (sizeof(T) == 2 ? DPOSER_FINAL_S_KB : RING_KB), Epi, (sizeof(T) == 2 ? DPOSER_FINAL_S_NB : RING_NB)>(g, p, st); break;
         case SHAPE_WIDE64: if constexpr (ALLOWED & M_WIDE) return launch_gemm<T, 2, 2, 2, 1, RING_KB, Epi, RING_NB>(g, p, st); break;
     }
     return hipErrorInvalidConfiguration;

@@ -72,7 +72,7 @@ hipError_t gemm_silu_bwd_x3(int shape, const GemmArgs& g, const SiLUBwdParams& p
 }
 hipError_t gemm_em_step_x3(int shape, const GemmArgs& g, const EmStepParams& p, hipStream_t st) {
     if (shape == SHAPE_FINAL) return launch_gemm<__bf16, 1, 4, 2, 1, RING_KB, EpiEmStep<float>, RING_NB>(g, p, st);
-    if (shape == SHAPE_FINAL_S) return launch_gemm<__bf16, 2, 1, 1, 1, RING_KB, EpiEmStep<float>, RING_NB>(g, p, st);
+    if (shape == SHAPE_FINAL_S) return launch_gemm<__bf16, 2, 1, 1, 1, 4, EpiEmStep<float>, 3>(g, p, st);
     return hipErrorInvalidConfiguration;
 }
 hipError_t gemm_partial_ft_x3(int shape, const GemmArgs& g, const PartialFTParams& p, hipStream_t st) {

@@ -441,6 +441,10 @@ int main(int argc, char** argv) {
         PL(1, 4, 2, 1, 8, 3);
         PL(2, 1, 1, 1, 2, 4);
         PL(2, 1, 1, 1, 4, 4);
+        PL(2, 1, 1, 1, 4, 3);
+        PL(2, 1, 1, 1, 8, 3);
+        PL(2, 1, 1, 1, 8, 4);
+        PL(2, 1, 1, 1, 16, 2);
         PL(2, 2, 1, 1, 2, 4);
         PL(2, 2, 1, 1, 4, 4);
         PL(2, 2, 1, 2, 2, 4);
