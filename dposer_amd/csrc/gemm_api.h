@@ -12,10 +12,12 @@ enum GemmShape : int {
     SHAPE_FINAL = 3,    //  64 x 128, 4 waves (1x4), wave tile  64 x 32    -- post_dense (N = 63 -> 64)
     SHAPE_FINAL_S = 4,  //  64 x  32, 2 waves (2x1), wave tile  32 x 32
     SHAPE_WIDE64 = 5,   // 128 x  64, 4 waves (2x2), wave tile  64 x 32    -- wgrad of pre_dense (K = 63 -> 64)
+    SHAPE_SMALL64 = 6,  // 128 x  64, 8 waves (4x2), wave tile  32 x 32    -- GroupNorm layers at 1024 < samples <= 2048 (bf16; round 6)
+    GEMM_NSHAPES = 7
 };
-static inline int shape_ct(int s) { static const int v[] = {8, 4, 4, 2, 2, 4}; return v[s]; }   // 32-channel tiles / block
-static inline int shape_st(int s) { static const int v[] = {8, 4, 1, 4, 1, 2}; return v[s]; }   // 32-sample tiles / block
-static inline int shape_ws(int s) { static const int v[] = {4, 2, 1, 4, 1, 2}; return v[s]; }   // waves along samples
+static inline int shape_ct(int s) { static const int v[] = {8, 4, 4, 2, 2, 4, 4}; return v[s]; }   // 32-channel tiles / block
+static inline int shape_st(int s) { static const int v[] = {8, 4, 1, 4, 1, 2, 2}; return v[s]; }   // 32-sample tiles / block
+static inline int shape_ws(int s) { static const int v[] = {4, 2, 1, 4, 1, 2, 2}; return v[s]; }   // waves along samples
 
 // PREC_BF16X3: the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16) under the fp32-storage epilogues -- the caller hands the operands as bf16
 // hi / lo planes (three K segments per term against weights packed [hi | lo | hi]); instantiated in gemm_launch_x3.hip
@@ -74,7 +76,7 @@ hipError_t launch_sampler_cluster(int prec, const SamplerArgs& a, int sync, hipS
 
 // ---- optional per-launch profiling (HIP events on the launch stream; off by default) ------------------
 enum GemmEpiKind : int { EPI_GN = 0, EPI_GN_TRAIN, EPI_BIAS_SILU, EPI_ROWMAJOR, EPI_PLAIN_FT, EPI_GN_BWD, EPI_SILU_BWD, EPI_WGRAD, EPI_EM_STEP, EPI_DSM_STEP, EPI_KINDS };
-constexpr int GEMM_PROF_KINDS = EPI_KINDS * 3 * 6;      // (epilogue kind, precision, tiling)
+constexpr int GEMM_PROF_KINDS = EPI_KINDS * 3 * GEMM_NSHAPES;      // (epilogue kind, precision, tiling)
 // bf16x3 entry points (gemm_launch_x3.hip): the dispatchers of gemm_launch.hip forward prec == PREC_BF16X3 here
 hipError_t gemm_gn_x3(bool train, int shape, const GemmArgs& g, const GNParams& p, hipStream_t st, int gs = 32);      // every activation, group sizes 16 / 32 / 64
 hipError_t gemm_bias_silu_x3(bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st);      // every activation

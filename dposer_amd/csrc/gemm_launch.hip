@@ -20,7 +20,7 @@ struct ProfScope {
     ProfRec* r = nullptr;
     hipStream_t st;
     ProfScope(int kind, double alg_flops, hipStream_t s) : st(s) {
-        if (!g_prof.enabled || (g_prof.only >= 0 && kind / 18 != g_prof.only)) return;
+        if (!g_prof.enabled || (g_prof.only >= 0 && kind / (3 * GEMM_NSHAPES) != g_prof.only)) return;
         if (g_prof.used == g_prof.pool.size()) {
             ProfRec n;
             if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
@@ -34,7 +34,7 @@ struct ProfScope {
     ~ProfScope() { if (r) (void)hipEventRecord(r->b, st); }
 };
 const char* kEpiNames[EPI_KINDS] = {"gn_fwd", "gn_fwd_train", "bias_silu", "rowmajor", "plain_ft", "gn_bwd_dgrad", "silu_bwd_dgrad", "wgrad", "post_em_step", "post_dsm_step"};
-const char* kShapeNames[6] = {"256x256", "128x128", "128x32", "64x128", "64x32", "128x64"};
+const char* kShapeNames[GEMM_NSHAPES] = {"256x256", "128x128", "128x32", "64x128", "64x32", "128x64", "128x64w8"};
 }   // namespace
 void gemm_prof_enable(int on) {
     if (on < 0) { g_prof.enabled = 0; return; }      // pause: keep what was recorded so far
@@ -55,10 +55,10 @@ int gemm_prof_collect(double* ms, long long* launches, double* flops) {
     return 0;
 }
 void gemm_prof_kind_name(int kind, char* out, int n) {
-    const int epi = kind / 18, prec = (kind / 6) % 3, shape = kind % 6;
+    const int epi = kind / (3 * GEMM_NSHAPES), prec = (kind / GEMM_NSHAPES) % 3, shape = kind % GEMM_NSHAPES;
     snprintf(out, n, "gemm_ft_kernel<%s,%s,%s>", prec == PREC_FP32 ? "fp32" : (prec == PREC_BF16X3 ? "bf16x3" : "bf16"), kShapeNames[shape], kEpiNames[epi]);
 }
-#define PROF(EPI) ProfScope _ps((EPI) * 18 + prec * 6 + shape, g.alg_flops, st)
+#define PROF(EPI) ProfScope _ps((EPI) * 3 * GEMM_NSHAPES + prec * GEMM_NSHAPES + shape, g.alg_flops, st)
 
 
 // Each epilogue only instantiates the tilings it is used with (bit i = GemmShape i).
@@ -82,7 +82,7 @@ constexpr int RING_KB = DPOSER_RING_KB, RING_NB = DPOSER_RING_NB;
 #endif
 template <typename T> constexpr int small_nb() { return sizeof(T) == 2 ? DPOSER_SMALL_NB : 2; }
 constexpr unsigned M_BIG = 1u << SHAPE_BIG, M_MID = 1u << SHAPE_MID, M_SMALL = 1u << SHAPE_SMALL, M_FINAL = 1u << SHAPE_FINAL,
-                   M_FINAL_S = 1u << SHAPE_FINAL_S, M_WIDE = 1u << SHAPE_WIDE64;
+                   M_FINAL_S = 1u << SHAPE_FINAL_S, M_WIDE = 1u << SHAPE_WIDE64, M_SMALL64 = 1u << SHAPE_SMALL64;
 
 template <typename T, typename Epi, unsigned ALLOWED>
 static hipError_t by_shape_masked(int shape, const GemmArgs& g, const typename Epi::Params& p, hipStream_t st) {
@@ -93,6 +93,9 @@ static hipError_t by_shape_masked(int shape, const GemmArgs& g, const typename E
         case SHAPE_FINAL: if constexpr (ALLOWED & M_FINAL) return launch_gemm<T, 1, 4, 2, 1, RING_KB, Epi, RING_NB>(g, p, st); break;
         case SHAPE_FINAL_S: if constexpr (ALLOWED & M_FINAL_S) return launch_gemm<T, 2, 1, 1, 1, (sizeof(T) == 2 ? DPOSER_FINAL_S_KB : RING_KB), Epi, (sizeof(T) == 2 ? DPOSER_FINAL_S_NB : RING_NB)>(g, p, st); break;
         case SHAPE_WIDE64: if constexpr (ALLOWED & M_WIDE) return launch_gemm<T, 2, 2, 2, 1, RING_KB, Epi, RING_NB>(g, p, st); break;
+        // 128 x 64 on eight waves, 4 slots x 4 k-blocks (bf16 only): between 1024 and 2048 samples the GroupNorm layers' launches take 7-11 % less than on
+        // 128x32 and 128x128 (tools/tune_gemm.hip TUNE_WIDE, profiles/r06_wide_tile.txt); same K order: bit-identical
+        case SHAPE_SMALL64: if constexpr ((ALLOWED & M_SMALL64) != 0 && sizeof(T) == 2) return launch_gemm<T, 4, 2, 1, 1, 4, Epi, 4>(g, p, st); break;
     }
     return hipErrorInvalidConfiguration;
 }
@@ -132,8 +135,8 @@ hipError_t gemm_gn(int prec, bool train, int shape, const GemmArgs& g, const GNP
         if (train) { typedef EpiGN<__bf16, true, -1, true> A; typedef EpiGN<float, true, -1, true> B; DISPATCH(A, B, M_MID | M_SMALL); }
         typedef EpiGN<__bf16, false, -1, true> A; typedef EpiGN<float, false, -1, true> B; DISPATCH(A, B, M_MID | M_SMALL);
     }
-    if (train) { typedef EpiGN<__bf16, true> A; typedef EpiGN<float, true> B; DISPATCH(A, B, M_MAIN); }
-    typedef EpiGN<__bf16, false> A; typedef EpiGN<float, false> B; DISPATCH(A, B, M_MAIN);
+    if (train) { typedef EpiGN<__bf16, true> A; typedef EpiGN<float, true> B; DISPATCH(A, B, M_MAIN | M_SMALL64); }
+    typedef EpiGN<__bf16, false> A; typedef EpiGN<float, false> B; DISPATCH(A, B, M_MAIN | M_SMALL64);
 }
 hipError_t gemm_bias_silu(int prec, bool train, int shape, const GemmArgs& g, const BiasSiLUParams& p, hipStream_t st) {
     PROF(EPI_BIAS_SILU);
@@ -178,7 +181,7 @@ hipError_t gemm_gn_bwd(int prec, int shape, const GemmArgs& g, const GNBwdParams
         return hipErrorInvalidConfiguration;
     }
     if (p.act != DP_ACT_SWISH) { typedef EpiGNBwd<__bf16, 0, true> A; typedef EpiGNBwd<float, 0, true> B; DISPATCH(A, B, M_MID | M_SMALL); }
-    typedef EpiGNBwd<__bf16> A; typedef EpiGNBwd<float> B; DISPATCH(A, B, M_MAIN);
+    typedef EpiGNBwd<__bf16> A; typedef EpiGNBwd<float> B; DISPATCH(A, B, M_MAIN | M_SMALL64);
 }
 hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdParams& p, hipStream_t st) {
     PROF(EPI_SILU_BWD);
@@ -187,11 +190,11 @@ hipError_t gemm_silu_bwd(int prec, int shape, const GemmArgs& g, const SiLUBwdPa
     typedef EpiSiLUBwd<__bf16> A; typedef EpiSiLUBwd<float> B; DISPATCH(A, B, M_MAIN);
 }
 hipError_t gemm_wgrad_tr_batch(const WgradBatchArgs& a, hipStream_t st) {
-    ProfScope _ps(EPI_WGRAD * 18 + SHAPE_BIG, a.alg_flops, st);
+    ProfScope _ps(EPI_WGRAD * 3 * GEMM_NSHAPES + SHAPE_BIG, a.alg_flops, st);
     return launch_wgrad_tr_batch<2, 4, 4, 2, 4>(a, st);
 }
 hipError_t gemm_wgrad_tr(int shape, const WgradTrArgs& g, const WgradParams& p, hipStream_t st) {
-    ProfScope _ps(EPI_WGRAD * 18 + shape, g.alg_flops, st);
+    ProfScope _ps(EPI_WGRAD * 3 * GEMM_NSHAPES + shape, g.alg_flops, st);
     if (shape == SHAPE_BIG) return launch_wgrad_tr<2, 4, 4, 2, 4>(g, p, st);
     if (shape == SHAPE_MID) return launch_wgrad_tr<2, 2, 2, 2, 4>(g, p, st);
     if (shape == SHAPE_FINAL) return launch_wgrad_tr<1, 4, 2, 1, 4>(g, p, st);

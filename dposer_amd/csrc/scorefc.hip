@@ -351,6 +351,8 @@ struct ScoreTuning {
     int64_t silu_split_max = 2048;    // DPOSER_SILU_SPLIT_MAX = <samples>: up to this padded batch the time-branch dgrad runs one k-split per layer + a reduce pass (0: never)
     int dsm_fused = 0;                // DPOSER_DSM_FUSED = 1: post_dense with the DSM loss in its epilogue (EpiDsm) instead of GEMM -> res -> k_dsm
                                       // (opt-in: measured -0.6 % at 8192 poses, -0.2 % at 65536, +0.5 % at 1280 -- profiles/r04_dsm_fused_ab.txt)
+    bool small64 = true;              // DPOSER_SMALL64=0: never the 128x64 / 8-wave tiling (A/B; bit-identical)
+    int64_t small64_min = 1024, small64_max = 2048;      // DPOSER_SMALL64_MIN / _MAX: its window, min < padded samples <= max
     int64_t small_tile_max = 2048;    // DPOSER_SMALL_TILE_MAX = <samples>: up to this padded batch the GroupNorm layers take the 128x32 tiling also where 128x128
                                       // divides the batch (1280 samples are 80 workgroups of 128x128 on 256 CUs).  Bit-identical.  Round 6, with three K-loop slots on
                                       // that tiling (gemm_launch.hip): training step 0.370 -> 0.339 ms at 1536 poses, 0.389 -> 0.383 at 2048, slower from 2560
@@ -374,6 +376,12 @@ struct ScoreTuning {
         dsm_fused = env_tri("DPOSER_DSM_FUSED") == 1 ? 1 : 0;
         e = getenv("DPOSER_SILU_SPLIT_MAX");
         silu_split_max = e ? atoll(e) : (int64_t)2048;
+        e = getenv("DPOSER_SMALL64");
+        small64 = !(e && e[0] == '0');
+        e = getenv("DPOSER_SMALL64_MIN");
+        small64_min = e ? atoll(e) : (int64_t)1024;
+        e = getenv("DPOSER_SMALL64_MAX");
+        small64_max = e ? atoll(e) : (int64_t)2048;
         e = getenv("DPOSER_SMALL_TILE_MAX");
         small_tile_max = e ? atoll(e) : (int64_t)2048;
         e = getenv("DPOSER_SAMPLER_PERSISTENT");
@@ -403,7 +411,14 @@ static int main_shape(int64_t Spad, int channels = 1024, int gs = 32) {
 // GroupNorm-backward dgrad: the register-lean epilogue fits the 256x256 tile in 248 VGPRs without spilling; it wins from
 // 16384 samples up (227 vs 257 us at 65536, 2.52 vs 2.59 ms per step at 32768; round 5, re-measured: 0.960 vs 0.976 ms per step at 16384,
 // 0.665 vs 0.621 at 8192 -- profiles/r05_small_tile_ab.txt).  DPOSER_GNBWD_BIG = 0 / 1 forces it.
-static int gnbwd_shape(int64_t Spad, int gs = 32) {
+// GroupNorm layers (forward and dgrad), bf16 storage, SiLU, 32-channel groups: 128 x 64 on eight waves between 1024 and 2048 samples (SHAPE_SMALL64)
+static bool small64_window(int64_t Spad, int gs, bool bf16) {
+    const ScoreTuning& tn = score_tuning();
+    return bf16 && tn.small64 && gs == 32 && g_act == DPOSER_ACT_SWISH && Spad % 64 == 0 && Spad > tn.small64_min && Spad <= tn.small64_max;
+}
+static int gn_shape(int64_t Spad, int channels, int gs, bool bf16) { return small64_window(Spad, gs, bf16) ? SHAPE_SMALL64 : main_shape(Spad, channels, gs); }
+static int gnbwd_shape(int64_t Spad, int gs = 32, bool bf16 = false) {
+    if (small64_window(Spad, gs, bf16)) return SHAPE_SMALL64;
     if (Spad <= score_tuning().small_tile_max) return SHAPE_SMALL;
     const int forced = score_tuning().gnbwd_big;
     const bool big = gs == 32 && g_act == DPOSER_ACT_SWISH && (forced >= 0 ? forced == 1 : Spad >= 16384);
@@ -649,7 +664,7 @@ extern "C" int dposer_scorefc_debug_set_dropout_masks(dposer_scorefc_t h, const 
 static int run_gn_layer(dposer_scorefc_s* h, const float* flat, const char* packed, int l, const void* in, const Planes& in_pl, const void* temb,
                         const Planes& temb_pl, const float* bias_row, void* out, const Planes& out_pl, const void* resid, void* xhat, GnAux* aux,
                         bool train, int64_t Bpad, uint64_t seed, uint32_t step, hipStream_t st) {
-    const int shape = main_shape(Bpad, h->H, h->gs);
+    const int shape = gn_shape(Bpad, h->H, h->gs, !h->f32);
     const LayerOff& lo = h->layer[l];
     const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
     g_next_flops = 2.0 * (double)g_alg_batch * h->H * (lo.kin + (temb ? h->E : 0));
@@ -1232,7 +1247,7 @@ static int forward_core_train(dposer_scorefc_s* h, const float* flat, const char
         const void* resid = (l >= 2 && (l % 2) == 0) ? w.hbuf[l - 2] : nullptr;
         // TRAIN epilogue keeps xhat and the GnAux records (rstd, dropout decisions); dropout only when the module is in train() mode
         const LayerOff& lo = h->layer[l];
-        const int shape = main_shape(w.Bpad, h->H, h->gs);
+        const int shape = gn_shape(w.Bpad, h->H, h->gs, !h->f32);
         const int kx = lo.kin_pad / h->KBS, ke = h->E / h->KBS;
         g_next_flops = 2.0 * (double)B * h->H * (lo.kin + h->E);
         GemmArgs g = gemm_args(packed + h->pk_wl[l], (kx + ke) * h->wk, h->H / (shape_ct(shape) * 32), (int)(w.Bpad / (shape_st(shape) * 32)));
@@ -1542,7 +1557,7 @@ static int backward_core(dposer_scorefc_s* h, const float* flat, const char* pac
     } else if (loss_sum && loss_sum->n > 0) {
         DP_HIP_LAUNCH(launch_sum_partials(loss_sum->part, loss_sum->n, loss_sum->out, st));
     }
-    const int gshape = gnbwd_shape(Bpad, h->gs);
+    const int gshape = gnbwd_shape(Bpad, h->gs, !h->f32);
     const int ws_rows = (int)(Bpad / (shape_st(gshape) * 32)) * shape_ws(gshape);   // partial rows written by the dgrad epilogue
     // GroupNorm affine / bias gradients of layer j from the partial sums its dgrad epilogue wrote
     auto add_layer_jobs = [&](int j) {

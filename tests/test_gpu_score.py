@@ -1812,3 +1812,34 @@ print('RESULT', hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest(), depth)
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split())
     assert outs[0][1] == outs[1][1]                      # same bits with and without ranges
     assert outs[1][2] == "0"                             # every pushed range was popped again
+
+
+@pytest.mark.parametrize("B", [1100, 1536, 2048])
+def test_the_eight_wave_128x64_tiling_carries_the_bits_of_the_128x32_tiling(B, tuning_env):
+    """Round 6: between 1024 and 2048 padded samples the GroupNorm layers (forward, training forward, dgrad) of the bf16 mode run on 128 x 64
+    tiles of eight waves (SHAPE_SMALL64) instead of 128 x 32 tiles of four.  Every wave still owns one 32 x 32 sub-tile and walks K in the
+    same order, and the dgrad's partial sums keep one row per 32 samples: forward output, DSM loss, every parameter gradient (dropout on)
+    and four sampler steps must be bit-identical with DPOSER_SMALL64=0."""
+    from dposer_amd.algorithms.advanced import sampling, sde_lib
+    cfg, m, p = make_model(23, precision="bf16", dropout=0.1)
+    gen = torch.Generator(device=DEV).manual_seed(B)
+    x = torch.randn(B, 63, device=DEV, generator=gen) * 0.5
+    t = torch.rand(B, device=DEV, generator=gen) * (1 - 1e-5) + 1e-5
+    z = torch.randn(B, 63, device=DEV, generator=gen)
+    noise = torch.randn(4, 1, B, 63, device=DEV, generator=gen)
+    sde = sde_lib.subVPSDE(0.1, 20.0, 4)
+    cfg.sampling.corrector = "none"
+    out = {}
+    for tag, env in (("128x64", None), ("128x32", "0")):
+        tuning_env(DPOSER_SMALL64=env)
+        m.eval()
+        with torch.no_grad():
+            fwd = m(x, t * 999)
+            _, xs = sampling.get_sampling_fn(cfg, sde, (B, 63), lambda v: v, 1e-3, device=DEV)(m, z=z, noise=noise)
+        m.train()
+        loss, fg = _fused_grad(m, x, t, z, step=3)
+        out[tag] = (fwd.clone(), xs.clone(), loss, fg.clone())
+    a, b = out["128x64"], out["128x32"]
+    assert torch.isfinite(a[0]).all() and torch.isfinite(a[3]).all() and float(a[3].abs().max()) > 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[2] == b[2] and torch.equal(a[3], b[3])

@@ -225,6 +225,31 @@ int main(int argc, char** argv) {
         run_all(9, 50);
         return 0;
     }
+    if (getenv("TUNE_WIDE")) {       // round 6: 128 x 64 tilings for 1024 ... 4096 samples against the shipped 128x32 (3 slots) and 128x128 (asm)
+        GNT(4, 1, 1, 1, 4, 3);       // shipped <= 2048
+        GNT(2, 2, 2, 2, 2, 4);       // shipped above
+        GNT(4, 2, 1, 1, 4, 3);       // 128 x 64, 8 waves, wave tile 32 x 32
+        GNT(4, 2, 1, 1, 4, 4);
+        GNT(2, 2, 2, 1, 2, 4);       // 128 x 64, 4 waves, wave tile 64 x 32 (SHAPE_WIDE64's pipeline)
+        GNT(2, 2, 2, 1, 4, 3);
+        GNT(2, 2, 2, 1, 4, 4);
+        GNT(2, 1, 2, 2, 4, 3);       // 128 x 64, 2 waves, wave tile 64 x 64
+        GB(4, 1, 1, 1, 4, 3, 1, 0, 0, 0);
+        GB(2, 2, 2, 2, 2, 4, 1, 0, 0, 0);
+        GB(4, 2, 1, 1, 4, 3, 1, 0, 0, 0);
+        GB(4, 2, 1, 1, 4, 4, 1, 0, 0, 0);
+        GB(2, 2, 2, 1, 2, 4, 1, 0, 0, 0);
+        GB(2, 2, 2, 1, 4, 3, 1, 0, 0, 0);
+        GB(2, 2, 2, 1, 4, 4, 1, 0, 0, 0);
+        GB(2, 1, 2, 2, 4, 3, 1, 0, 0, 0);
+        GN(4, 1, 1, 1, 4, 3);
+        GN(2, 2, 2, 2, 2, 4);
+        GN(4, 2, 1, 1, 4, 3);
+        GN(2, 2, 2, 1, 4, 3);
+        GN(2, 2, 2, 1, 2, 4);
+        run_all(9, 50);
+        return 0;
+    }
     if (getenv("TUNE_TINY2")) {      // round 6: the 128x32 tiling of the small batches (sampler at 500 samples, training at <= 1280): deeper K pipelines, wider tiles
         GN(4, 1, 1, 1, 4, 2);        // shipped until round 6: 2 slots x 4 k-blocks
         GN(4, 1, 1, 1, 4, 3);
