@@ -225,6 +225,25 @@ int main(int argc, char** argv) {
         run_all(9, 50);
         return 0;
     }
+    if (getenv("TUNE_LDS")) {        // round 6: the 128x128 tiling moves 1.5 KB through LDS per MFMA (1.0 fragment reads + 0.5 DMA), the CU's LDS delivers 1 KB per
+                                     // MFMA slot -- four-wave tiles with 128x64 / 64x128 wave tiles (0.75 + 0.375) for the one-round batches (8192 / 16384)?
+        g_drop_p = 0.1f;
+        GNT(2, 2, 2, 2, 2, 4);       // shipped: 128 x 128 (asm stage)
+        GNT(2, 2, 4, 2, 2, 4);       // 256 ch x 128 s, 4 waves, wave tile 128 x 64
+        GNT(2, 2, 4, 2, 2, 3);
+        GNT(2, 2, 2, 4, 2, 4);       // 128 ch x 256 s, 4 waves, wave tile 64 x 128
+        GNT(2, 2, 2, 4, 2, 3);
+        GNT(2, 4, 4, 2, 2, 4);       // 256 x 256 (asm stage)
+        GB(2, 2, 2, 2, 2, 4, 1, 0, 0, 0);
+        GB(2, 2, 4, 2, 2, 4, 1, 0, 0, 0);
+        GB(2, 2, 4, 2, 2, 3, 1, 0, 0, 0);
+        GB(2, 2, 2, 4, 2, 4, 1, 0, 0, 0);
+        GB(2, 2, 2, 4, 2, 3, 1, 0, 0, 0);
+        GB(2, 4, 4, 2, 2, 4, 1, 0, 0, 0);
+        PL(2, 2, 2, 2, 2, 4); PL(2, 2, 4, 2, 2, 4); PL(2, 2, 4, 2, 2, 3); PL(2, 2, 2, 4, 2, 4); PL(2, 2, 2, 4, 2, 3); PL(2, 4, 4, 2, 2, 4);
+        run_all(9, 20);
+        return 0;
+    }
     if (getenv("TUNE_WIDE")) {       // round 6: 128 x 64 tilings for 1024 ... 4096 samples against the shipped 128x32 (3 slots) and 128x128 (asm)
         GNT(4, 1, 1, 1, 4, 3);       // shipped <= 2048
         GNT(2, 2, 2, 2, 2, 4);       // shipped above
