@@ -588,10 +588,33 @@ template <typename Kin> constexpr int fk_max_depth() {
     }
     return m;
 }
+template <typename Kin> constexpr int fk_max_children() {
+    int m = 0;
+    for (int i = 0; i < Kin::J; ++i) {
+        int n = 0;
+        for (int c = 0; c < Kin::J; ++c)
+            if (Kin::P[c] == i) ++n;
+        m = n > m ? n : m;
+    }
+    return m;
+}
 template <typename Kin> struct KinTable {          // the parents table where device code can index it with a lane id
+    static constexpr int MAXC = 6;
     int p[Kin::J];
-    constexpr KinTable() : p() {
+    // per joint: depth in the tree, number of children, the children in DESCENDING index order (the one-lane-per-joint kernels used to find
+    // these by walking the parents table per lane: a chain of dependent loads up to the tree's depth + a 54-iteration search at every launch)
+    int depth[Kin::J], nchild[Kin::J], child[Kin::J][MAXC];
+    constexpr KinTable() : p(), depth(), nchild(), child() {
         for (int i = 0; i < Kin::J; ++i) p[i] = Kin::P[i] < 0 ? 0 : Kin::P[i];
+        for (int i = 0; i < Kin::J; ++i) {
+            int d = 0;
+            for (int q = i; q > 0; q = p[q]) ++d;
+            depth[i] = d;
+            int n = 0;
+            for (int c = Kin::J - 1; c > i; --c)
+                if (p[c] == i) { if (n < MAXC) child[i][n] = c; ++n; }
+            nchild[i] = n;
+        }
     }
 };
 template <typename Kin> __device__ constexpr KinTable<Kin> kKinTable{};
@@ -677,7 +700,7 @@ template <typename Kin> __global__ void __launch_bounds__(64) k_fk_small(FkArgs 
     int P = 0, depth = 0;
     if (on) {
         P = kKinTable<Kin>.p[I];
-        for (int q = I; q > 0; q = kKinTable<Kin>.p[q]) ++depth;
+        depth = kKinTable<Kin>.depth[I];
     }
     // this joint's axis-angle: segment pointers through unrolled selects (a runtime index into the kernel-argument arrays would
     // spill the argument struct to scratch)
@@ -2745,7 +2768,8 @@ template <typename Kin> __global__ void __launch_bounds__(64, 1) k_fk_bwd(FkBwdA
 template <typename Kin> __global__ void __launch_bounds__(64) k_fk_bwd_small(FkBwdArgs a) {
     constexpr int J = Kin::J;
     constexpr int MAXD = fk_max_depth<Kin>();
-    constexpr int MAXC = 6;
+    constexpr int MAXC = KinTable<Kin>::MAXC;
+    static_assert(fk_max_children<Kin>() <= MAXC, "children per joint");
     __shared__ float sC[J][12];
     __shared__ float sD[J][3];
     const int64_t b = blockIdx.x;
@@ -2756,14 +2780,10 @@ template <typename Kin> __global__ void __launch_bounds__(64) k_fk_bwd_small(FkB
     for (int k = 0; k < MAXC; ++k) child[k] = 0;
     if (on) {
         P = kKinTable<Kin>.p[I];
-        for (int q = I; q > 0; q = kKinTable<Kin>.p[q]) ++depth;
-        for (int c = J - 1; c > I; --c)
-            if (kKinTable<Kin>.p[c] == I) {
+        depth = kKinTable<Kin>.depth[I];
+        nchild = kKinTable<Kin>.nchild[I];
 #pragma unroll
-                for (int k = 0; k < MAXC; ++k)
-                    if (k == nchild) child[k] = c;
-                ++nchild;
-            }
+        for (int k = 0; k < MAXC; ++k) child[k] = kKinTable<Kin>.child[I][k];
     }
     int li = I;
     const float* pose = a.seg[0];
@@ -2857,8 +2877,17 @@ __global__ void __launch_bounds__(256) k_sum_slabs(float* slabs, int64_t slab_el
     const int64_t n4 = slab_elems >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 v = reinterpret_cast<const f32x4*>(slabs)[i];
-        for (int k = 1; k < nsplit; ++k) {
-            const f32x4 w = reinterpret_cast<const f32x4*>(slabs + k * slab_elems)[i];
+        // (eight slabs' loads in flight, added in slab order: at 60 poses this is 32 blocks walking 72 slabs -- one load per round trip took 19 us)
+        int k = 1;
+        for (; k + 8 <= nsplit; k += 8) {
+            f32x4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = reinterpret_cast<const f32x4*>(slabs + (int64_t)(k + u) * slab_elems)[i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[0] += w[u][0]; v[1] += w[u][1]; v[2] += w[u][2]; v[3] += w[u][3]; }
+        }
+        for (; k < nsplit; ++k) {
+            const f32x4 w = reinterpret_cast<const f32x4*>(slabs + (int64_t)k * slab_elems)[i];
             v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
         }
         reinterpret_cast<f32x4*>(slabs)[i] = v;
@@ -3206,10 +3235,14 @@ static int lbs_backward_impl(dposer_body_t h, const void* ws_fwd, void* ws_bwd, 
         //  only whole-stage splits are valid, so the bound goes INTO the search)
         const int64_t fit = slab_budget / (3 * Bpad * pe);
         const int k1 = kbig ? kbig : lbs_bwd_ksplit_bf16(kb, (Bpad / 128) * (pe / 128), (int)(fit < 1 ? 1 : (fit > 24 ? 24 : fit)));
+        // (small batches, 128x128 tiles, 3 x 48 workgroups at 60 poses: side by side on three streams measured SLOWER -- 0.33 vs 0.22 ms per step of a
+        //  60-frame motion-denoising loop, profiles/r06_md_small_ab.md: the event hand-overs cost more than the launches; they stay on one stream)
         const bool fork = par && kbig;
         // round 6: the terms d_off_hi pd_hi^T and d_off_hi pd_lo^T as ONE launch against the row-concatenated [pd_hi ; pd_lo] (2 pe rows: the
         // natural layout when every pose-feature row is wanted, the packed 256-row prefix panel when only the body is posed) -- the two
         // column tiles of a row panel run side by side on one XCD (panel_order) and d_off_hi leaves HBM once instead of twice
+        // (256x256 tiles only: on the 128x128 tiles of the small batches two launches instead of three measured no gain at 60 frames and a loss at 480,
+        //  profiles/r06_md_small_ab.md)
         const bool rowcat = kbig && body_tuning().lbs_bwd_rowcat && (pe == prow || (pe == 256 && prow > 256));
         const int nlaunch = rowcat ? 2 : 3;
         if (fork) {

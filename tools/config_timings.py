@@ -86,13 +86,13 @@ def main():
             joints = bm(pose_body=gt, betas=md.betas).Jtr[:, :22] + 0.04 * torch.randn(60, 22, 3, device=dev)
         s = timed(lambda: md.optimize(joints, gt_poses=gt, iterations=5, steps_per_iter=50), warm=1)
         rows.append(("cfg5", "motion denoising, 60 frames, 250 optimisation steps (LBS fwd+bwd + prior), one C call", f"{s:.3f} s / sequence", f"{s / 250 * 1e3:.2f} ms / step"))
-        for S in (8, 32, 128):
+        for S in (() if (len(sys.argv) > 2 and sys.argv[2] == "one") else (8, 32, 128)):      # (`cfg5 one`: the single sequence only -- for kernel traces)
             jb = joints[None].expand(S, -1, -1, -1).contiguous() + 0.01 * torch.randn(S, 60, 22, 3, device=dev)
             gb = gt[None].expand(S, -1, -1).contiguous()
             s = timed(lambda: md.optimize_sequences(jb, gb, time_strategy="1", iterations=5, steps_per_iter=50), warm=1)
             rows.append((f"cfg5 x {S}", f"{S} sequences of 60 frames advanced together (optimize_sequences), 250 steps", f"{s / S:.4f} s / sequence",
                          f"{s / 250 * 1e3:.2f} ms / step, {S / s:,.0f} sequences/s"))
-        if only == "cfg5" and len(sys.argv) > 2 and sys.argv[2] == "fused-only":
+        if only == "cfg5" and len(sys.argv) > 2 and sys.argv[2] in ("fused-only", "one"):
             rows.append(("", "", "", ""))
             s = 0.0
         else:

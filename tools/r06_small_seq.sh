@@ -4,10 +4,9 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/small_seq; rm -rf $O
 rocprofv3 --kernel-trace --stats -d $O/c3 -o c3 -- python3 $R/tools/config_timings.py cfg3 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d $O/c5 -o c5 -- python3 $R/tools/config_timings.py cfg5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $O/c5 -o c5 -- python3 $R/tools/config_timings.py cfg5 one > /dev/null 2>&1
 cd $R
 python3 tools/rocpd_summary.py --sequence $(find $O/c3 -name "*.db") EpiEmStep 700 > gpurun_out/r06_seq_cfg3.md
-python3 tools/rocpd_summary.py --sequence $(find $O/c5 -name "*.db") k_md_normalize 300 > gpurun_out/r06_seq_cfg5.md
-python3 tools/rocpd_summary.py $(find $O/c5 -name "*.db") | head -50 > gpurun_out/r06_stats_cfg5.md
-cat gpurun_out/r06_seq_cfg3.md gpurun_out/r06_seq_cfg5.md
+python3 tools/rocpd_summary.py --sequence $(find $O/c5 -name "*.db") k_md_update 300 > gpurun_out/r06_seq_cfg5.md
+cat gpurun_out/r06_seq_cfg5.md
 rm -rf $O

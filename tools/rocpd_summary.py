@@ -28,7 +28,7 @@ def demangle(name):
 
 
 def short(name):
-    name = demangle(name)
+    name = demangle(name).replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)
     name = name.replace("void ", "")
     name = name.replace("gemm_ft_kernel<bool _Accum, int, E,", "gemm_ft_kernel<__bf16, 1,")      # (a demangler that does not know DF16b)
