@@ -1819,7 +1819,7 @@ def test_the_eight_wave_128x64_tiling_carries_the_bits_of_the_128x32_tiling(B, t
     """Round 6: between 1024 and 2048 padded samples the GroupNorm layers (forward, training forward, dgrad) of the bf16 mode run on 128 x 64
     tiles of eight waves (SHAPE_SMALL64) instead of 128 x 32 tiles of four.  Every wave still owns one 32 x 32 sub-tile and walks K in the
     same order, and the dgrad's partial sums keep one row per 32 samples: forward output, DSM loss, every parameter gradient (dropout on)
-    and four sampler steps must be bit-identical with DPOSER_SMALL64=0."""
+    and four sampler steps must be bit-identical with DPOSER_SMALL64=0 -- in the single-GPU form of the backward and in the bucketed one."""
     from dposer_amd.algorithms.advanced import sampling, sde_lib
     cfg, m, p = make_model(23, precision="bf16", dropout=0.1)
     gen = torch.Generator(device=DEV).manual_seed(B)
@@ -1838,8 +1838,15 @@ def test_the_eight_wave_128x64_tiling_carries_the_bits_of_the_128x32_tiling(B, t
             _, xs = sampling.get_sampling_fn(cfg, sde, (B, 63), lambda v: v, 1e-3, device=DEV)(m, z=z, noise=noise)
         m.train()
         loss, fg = _fused_grad(m, x, t, z, step=3)
-        out[tag] = (fwd.clone(), xs.clone(), loss, fg.clone())
+        # the data-parallel form of the backward (weight gradients as lane launches per layer group, a HIP event per gradient bucket)
+        from dposer_amd.algorithms.advanced.losses import fused_dsm_grad
+        fg_b = torch.zeros(m._num_flat, device=DEV)
+        loss_b = fused_dsm_grad(m, sde_lib.subVPSDE(0.1, 20.0, 1000), x, flat_grad=fg_b, t=t, z=z, seed=m._rng_seed, step=3,
+                                bucket_events=m._engine().bucket_events())
+        out[tag] = (fwd.clone(), xs.clone(), loss, fg.clone(), float(loss_b), fg_b.clone())
     a, b = out["128x64"], out["128x32"]
     assert torch.isfinite(a[0]).all() and torch.isfinite(a[3]).all() and float(a[3].abs().max()) > 0
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert a[2] == b[2] and torch.equal(a[3], b[3])
+    assert a[4] == b[4] and torch.equal(a[5], b[5])
+    assert rel_err(t2n(a[5]), t2n(a[3])) < 1e-5            # (the bucketed form adds the weight-gradient partials in another order)
