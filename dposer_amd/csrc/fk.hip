@@ -1437,7 +1437,8 @@ extern "C" int dposer_lbs_forward(dposer_body_t h, void* ws, const void* posedir
         if (rc_chunks != DPOSER_OK) return rc_chunks;
     }
     // 4. extra joints + landmarks
-    if (h->d.num_extra + h->d.num_landmarks > 0) {
+    // (all three tables NULL: the caller reads tree joints only -- rows [J, J + num_extra + num_landmarks) of `joints` are left unwritten)
+    if (h->d.num_extra + h->d.num_landmarks > 0 && (extra_vertex_ids || lmk_tri || lmk_bary)) {
         DP_CHECK_ARG((h->d.num_extra == 0 || extra_vertex_ids) && (h->d.num_landmarks == 0 || (lmk_tri && lmk_bary)), "missing landmark tables");
         ExtraArgs e;
         e.verts = verts; e.extra_ids = extra_vertex_ids; e.lmk_tri = lmk_tri; e.lmk_bary = lmk_bary; e.joints = joints;

@@ -40,25 +40,20 @@ __device__ __forceinline__ float block_sum(float v, float* red) {      // 256 th
 
 // offline_normalize(from_axis=True) for the axis-angle representation (AMASS.py:126-137): mode 0 identity, 1 z-score (a = mean,
 // b = std), 2 min-max (a = min, b = max)
-__global__ void __launch_bounds__(256) k_md_normalize(const float* pose, const float* a, const float* b, int mode, float* xn, int64_t n, int D) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % D);
-    const float p = pose[i];
-    float x = p;
-    if (mode == 1) x = (p - a[c]) / b[c];
-    else if (mode == 2) x = 2.0f * (p - a[c]) / (b[c] - a[c]) - 1.0f;
-    xn[i] = x;
-}
-
-// offline_normalize(from_axis=True) for rot_rep = 'rot6d' (AMASS.py:126-137 -> lib/utils/transforms.py:238-255): every joint's axis-angle
-// becomes the first two columns of its rotation matrix, row-major (R00 R01 R10 R11 R20 R21), then the 6 J-dimensional statistics apply.
-// One thread per (frame, joint).
 __device__ __forceinline__ float md_norm(float p, int mode, const float* a, const float* b, int c) {
     if (mode == 1) return (p - a[c]) / b[c];
     if (mode == 2) return 2.0f * (p - a[c]) / (b[c] - a[c]) - 1.0f;
     return p;
 }
+__global__ void __launch_bounds__(256) k_md_normalize(const float* pose, const float* a, const float* b, int mode, float* xn, int64_t n, int D) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    xn[i] = md_norm(pose[i], mode, a, b, (int)(i % D));
+}
+
+// offline_normalize(from_axis=True) for rot_rep = 'rot6d' (AMASS.py:126-137 -> lib/utils/transforms.py:238-255): every joint's axis-angle
+// becomes the first two columns of its rotation matrix, row-major (R00 R01 R10 R11 R20 R21), then the 6 J-dimensional statistics apply.
+// One thread per (frame, joint).
 __global__ void __launch_bounds__(256) k_md_normalize6d(const float* pose, const float* a, const float* b, int mode, float* xn, int64_t n_joints, int J) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_joints) return;
@@ -176,6 +171,7 @@ __global__ void __launch_bounds__(256) k_md_temp_log(const float* part4, int n_t
 // d pose = LBS gradient + w_prior * normalise^T(d prior / d x_n); torch.optim.Adam (single-tensor arithmetic, as k_completion_update)
 struct MdUpdateArgs {
     float* pose; float* m; float* v;
+    float* xn_next;      // axis-angle form, optional: the NEXT step's normalised pose (k_md_normalize's expression on the value just written: one launch less per step)
     const float* dpose; const float* gprior; const float* a; const float* b;
     int mode, D;
     int64_t n;
@@ -193,9 +189,11 @@ __global__ void __launch_bounds__(256) k_md_update(MdUpdateArgs u) {
     m = m + (g - m) * u.one_minus_beta1;
     v = v * u.beta2 + u.one_minus_beta2 * (g * g);
     const float denom = sqrtf(v) / u.bc2_sqrt + u.eps;
-    u.pose[i] = u.pose[i] - u.step_size * (m / denom);
+    const float p = u.pose[i] - u.step_size * (m / denom);
+    u.pose[i] = p;
     u.m[i] = m;
     u.v[i] = v;
+    if (u.xn_next) u.xn_next[i] = md_norm(p, u.mode, u.a, u.b, c);
 }
 
 // the same update for rot_rep = 'rot6d': the prior gradient arrives in the 6 J normalised coordinates; normalise^T, then the
@@ -327,7 +325,8 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
     if (a->n_steps > 0) DP_TRY(dposer_prior_table_build_sde(a->net, a->flat_params, a->packed, a->net_ws, a->sde, a->t_host, a->n_steps, a->freq, T, stream));
     for (int k = 0; k < a->n_steps; ++k) {
         if (rot6d) hipLaunchKernelGGL(k_md_normalize6d, dim3((unsigned)ceil_div(n / 3, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n / 3, D / 3);
-        else hipLaunchKernelGGL(k_md_normalize, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n, D);
+        else if (k == 0) hipLaunchKernelGGL(k_md_normalize, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, (const float*)a->pose, a->norm_a, a->norm_b, a->norm_mode, s.xn, n, D);
+        // (axis-angle, k > 0: the previous step's update kernel has written s.xn already)
         TK_HIP_LAUNCH(hipGetLastError());
         DP_TRY(dposer_prior_loss_tabled(a->net, a->flat_params, a->packed, a->net_ws, a->sde, s.xn, a->noise ? a->noise + (int64_t)k * n_net : nullptr,
                                         a->t_host[k], k, a->n_steps, a->weighted, 1.0f / (float)F, nullptr, s.gprior, s.loss1, a->seed,
@@ -345,7 +344,7 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
                                                     s.dverts, s.part, s.joints, T, stream));
         } else {
             DP_TRY(dposer_lbs_forward(a->body, a->lbs_ws_fwd, a->posedirs_packed, segs, a->segment_joints_host, a->num_segments, a->j_rest, a->rest_batched,
-                                      a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, nullptr, a->extra_vertex_ids, a->lmk_tri, a->lmk_bary,
+                                      a->v_shaped, a->rest_batched, a->skin_idx, a->skin_w, a->skin_k, nullptr, nullptr, nullptr, nullptr,      // (the data term reads tree joints only)
                                       s.verts, s.joints, T, stream));
             if (ieee_div) hipLaunchKernelGGL(k_md_vert_grad<true>, dim3((unsigned)vb, (unsigned)T), dim3(256), 0, st, (const float*)s.verts, s.dverts, s.part, (int)F, V, c_temp);
             else hipLaunchKernelGGL(k_md_vert_grad<false>, dim3((unsigned)vb, (unsigned)T), dim3(256), 0, st, (const float*)s.verts, s.dverts, s.part, (int)F, V, c_temp);
@@ -372,6 +371,7 @@ extern "C" int dposer_motion_denoise_optimize(const dposer_motion_denoise_args* 
         const double stepno = (double)a->adam_step0 + k + 1;
         const double bc1 = 1.0 - std::pow(a->beta1, stepno), bc2 = 1.0 - std::pow(a->beta2, stepno);
         MdUpdateArgs u;
+        u.xn_next = (!rot6d && k + 1 < a->n_steps) ? s.xn : nullptr;
         u.pose = a->pose; u.m = a->adam_m; u.v = a->adam_v; u.dpose = s.dpose; u.gprior = s.gprior; u.a = a->norm_a; u.b = a->norm_b;
         u.mode = a->norm_mode; u.D = D; u.n = n; u.w_prior = a->w_prior_host[k];
         u.step_size = (float)(a->lr / bc1); u.one_minus_beta1 = (float)(1.0 - a->beta1); u.beta2 = (float)a->beta2;

@@ -404,7 +404,8 @@ int dposer_fk_joints(dposer_body_t h, const float* const* pose_segments_host, co
  *   posedirs_packed: dposer_lbs_pack_posedirs(posedirs [(J-1)*9, V*3]) (MFMA fragment order, fp32);
  *   v_shaped [V,3] (betas folded in, shared) or [B,V,3]; j_rest as in dposer_fk_joints;
  *   skin_idx / skin_w [V, skin_k]: ELL form of lbs_weights [V,J] (zero weights dropped or padded);
- *   extra_vertex_ids [num_extra], lmk_tri [num_landmarks,3] (= faces[lmk_faces_idx]), lmk_bary [num_landmarks,3];
+ *   extra_vertex_ids [num_extra], lmk_tri [num_landmarks,3] (= faces[lmk_faces_idx]), lmk_bary [num_landmarks,3] -- or all three NULL: the rows behind
+ *   the kinematic tree's J joints are then left unwritten (callers that read tree joints only: the motion-denoising loop);
  *   verts [B,V,3] out; joints [B, J+num_extra+num_landmarks, 3] out (SMPL-X: 55+21+51 = 127). */
 int64_t dposer_lbs_posedirs_packed_bytes(dposer_body_t h);
 int dposer_lbs_pack_posedirs(dposer_body_t h, const float* posedirs, void* packed, void* stream);
