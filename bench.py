@@ -685,6 +685,37 @@ def main():
         extra["lbs_full_fwd_bwd_through_loss_backward"] = {"ms_mean_of_runs": sum(secs) / len(secs) * 1e3, "runs_ms": [round(x * 1e3, 4) for x in secs],
                                                            "poses_per_s_per_gpu": nl / (sum(secs) / len(secs)), "batch": nl}
 
+    if not args.no_extra and world == 1 and args.precision == "bf16":
+        # ---- the latency-bound end of the same path (not the headline): the training step at the reference's own batch (1280 poses,
+        # configs/default_amass_configs.py:22) and at the per-rank batch of the headline's 8-GPU leg (8192), BASELINE config 3 (1000-step sampler,
+        # 500 poses).  Same model / optimizer state / kernels, other tilings (128x32 / 128x64 / 128x128); HBM-resident inputs, whole-call wall time.
+        small = {}
+        model.train()
+        for nb, nsteps in ((1280, 200), (8192, 100)):
+            xb = synthetic_poses(nb, dev, seed=7)[0]
+            for _ in range(10):
+                step_fn(state, xb)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nsteps):
+                step_fn(state, xb)
+            torch.cuda.synchronize()
+            e = time.perf_counter() - t1
+            small[f"train_step_{nb}"] = {"ms_per_step": e / nsteps * 1e3, "poses_per_s": nb * nsteps / e, "steps": nsteps,
+                                         "tflops_algorithmic": 42.59e6 * nb * nsteps / e / 1e12,
+                                         "frac_of_mfma_peak": 42.59e6 * nb * nsteps / e / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+        model.eval()
+        sde_c3 = sde_lib.subVPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=1000)
+        fn_c3 = sampling.get_sampling_fn(cfg, sde_c3, (500, 63), lambda v: v, 1e-3, device=dev)
+        z3 = torch.randn(500, 63, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+        fn_c3(model, z=z3, traj_stride=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, x3 = fn_c3(model, z=z3, traj_stride=0)
+        torch.cuda.synchronize()
+        e = time.perf_counter() - t1
+        small["sampler_500x1000"] = {"seconds": e, "samples_per_s": 500 / e, "us_per_step": e / 1000 * 1e6, "finite": bool(torch.isfinite(x3).all())}
+        extra["small_batches"] = small
     if ddp.is_initialized() and not args.no_extra:
         # the legs that shard with no collective, as every rank measured them on its own shard / GPU
         legs = [None] * torch.distributed.get_world_size()

@@ -21,3 +21,9 @@ for f in sys.argv[1:]:
     for k in ("lbs_full_fwd", "lbs_full_fwd_bwd"):
         if k in ex:
             print("   %-18s %.3f ms  runs %s" % (k, ex[k]["ms"], ex[k].get("runs_ms")))
+    sb = ex.get("small_batches", {})
+    for k, v in sb.items():
+        if "ms_per_step" in v:
+            print("   %-18s %.4f ms / step (%.3f of the bf16 peak)" % (k, v["ms_per_step"], v["frac_of_mfma_peak"]))
+        else:
+            print("   %-18s %.4f s = %.0f samples/s" % (k, v["seconds"], v["samples_per_s"]))
