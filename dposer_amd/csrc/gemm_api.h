@@ -4,7 +4,8 @@
 #include "gemm.h"
 #include "gemm_wgrad_tr.h"
 
-// Workgroup tilings (channels x samples); K pipeline = ring of 4 slots x 2 FT k-blocks (128 x 32: 2 slots x 4):
+// Workgroup tilings (channels x samples); K pipeline = ring of 4 slots x 2 FT k-blocks (bf16: 128 x 32 and 64 x 32 three slots x 4, 128 x 64 / 8 waves four x 4;
+// fp32 128 x 32: 2 slots x 4):
 enum GemmShape : int {
     SHAPE_BIG = 0,      // 256 x 256, 8 waves (2x4), wave tile 128 x 64    -- large batches
     SHAPE_MID = 1,      // 128 x 128, 4 waves (2x2), wave tile  64 x 64
