@@ -255,12 +255,12 @@ def shared_corrector_update_fn(x, t, observation, mask, sde, model, corrector, c
 def fused_em_supported(sde, model, predictor, corrector, probability_flow, continuous):
     from .model import ScoreModelFC
     return (predictor is EulerMaruyamaPredictor and corrector in (None, NoneCorrector) and not probability_flow
-            and sde_lib.sde_desc(sde) is not None and (continuous or isinstance(sde, sde_lib.subVPSDE))
+            and sde_lib.sde_desc(sde) is not None and (continuous or isinstance(sde, (sde_lib.subVPSDE, sde_lib.VESDE)))
             and isinstance(model, ScoreModelFC))
 
 
 def fused_em_sample(model, sde, x, timesteps, *, start_step=0, observation=None, mask=None, noise=None, seed=0,
-                    traj_stride=0):
+                    traj_stride=0, continuous=True):
     """dposer_em_sampler.  x [B, D] initial state (consumed); returns (trajs or None, x, x_mean)."""
     _C.require_gpu(x, "sampler state")
     eng = model._engine()
@@ -280,7 +280,7 @@ def fused_em_sample(model, sde, x, timesteps, *, start_step=0, observation=None,
     traj = None
     if traj_stride and n_run > 0:
         traj = torch.empty((n_run // traj_stride, B, D), dtype=torch.float32, device=x.device)
-    desc = sde_lib.sde_desc(sde)
+    desc = sde_lib.sde_desc(sde, continuous)
     obs = None if observation is None else observation.contiguous().float()
     msk = None if mask is None else mask.contiguous().float()
     nz = None if noise is None else noise.contiguous().float()
@@ -294,12 +294,12 @@ def fused_em_sample(model, sde, x, timesteps, *, start_step=0, observation=None,
 def fused_langevin_supported(sde, model, predictor, corrector, probability_flow, continuous):
     from .model import ScoreModelFC
     return (predictor is EulerMaruyamaPredictor and corrector is LangevinCorrector and not probability_flow
-            and sde_lib.sde_desc(sde) is not None and (continuous or isinstance(sde, sde_lib.subVPSDE))
+            and sde_lib.sde_desc(sde) is not None and (continuous or isinstance(sde, (sde_lib.subVPSDE, sde_lib.VESDE)))
             and isinstance(model, ScoreModelFC))
 
 
 def fused_pc_langevin_sample(model, sde, x, timesteps, *, snr, n_steps=1, start_step=0, observation=None, mask=None, noise=None,
-                             seed=0, traj_stride=0):
+                             seed=0, traj_stride=0, continuous=True):
     """Predictor-corrector loop of sampling.py:455-461 with the Langevin corrector (:282-302) and the Euler-Maruyama predictor
     on the HIP path.  Per outer step: ``n_steps`` x [``dposer_langevin_step`` phase 0 -> all-reduce of the two norm sums over
     the data-parallel ranks -> phase 1], then ``dposer_em_sampler_steps`` for the (imputation,) predictor (, imputation) of that
@@ -317,7 +317,7 @@ def fused_pc_langevin_sample(model, sde, x, timesteps, *, snr, n_steps=1, start_
     x = x.contiguous().float().clone()
     x_mean = x.clone()
     ts_host = timesteps.detach().to("cpu", torch.float32).contiguous()
-    desc = sde_lib.sde_desc(sde)
+    desc = sde_lib.sde_desc(sde, continuous)
     obs = None if observation is None else observation.contiguous().float()
     msk = None if mask is None else mask.contiguous().float()
     nz = None if noise is None else noise.contiguous().float()
@@ -401,7 +401,7 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
                 trajs, x, x_mean = fused_em_sample(model, sde, x, torch.linspace(sde.T, eps, sde.N), start_step=start_t,
                                                    observation=observation if completion else None,
                                                    mask=mask if completion else None, noise=noise, seed=seed,
-                                                   traj_stride=traj_stride)
+                                                   traj_stride=traj_stride, continuous=continuous)
                 model.train(was_training)
                 if trajs is None:
                     trajs = x.new_empty((0,) + tuple(x.shape))
@@ -415,7 +415,7 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
                 trajs, x, x_mean = fused_pc_langevin_sample(model, sde, x, torch.linspace(sde.T, eps, sde.N), snr=snr, n_steps=n_steps,
                                                             start_step=start_t, observation=observation if completion else None,
                                                             mask=mask if completion else None, noise=noise, seed=seed,
-                                                            traj_stride=traj_stride)
+                                                            traj_stride=traj_stride, continuous=continuous)
                 model.train(was_training)
                 if trajs is None:
                     trajs = x.new_empty((0,) + tuple(x.shape))

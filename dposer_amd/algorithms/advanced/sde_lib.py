@@ -202,8 +202,10 @@ class VESDE(SDE):
         return torch.tensor([[1.0]]), self._sigma(t)
 
 
-def sde_desc(sde):
-    """(kind, N, beta_min, beta_max, T) for the C ABI; None when the fused kernels do not cover the SDE."""
+def sde_desc(sde, continuous=True):
+    """(kind, N, beta_min, beta_max, T) for the C ABI; None when the fused kernels do not cover the SDE.  ``continuous=False`` selects the
+    discrete VE score function (utils.py:175-178: the network conditioned on round((T - t)(N - 1))); it changes nothing for sub-VP, and the
+    callers keep a discrete VP score function off the fused paths themselves."""
     from ... import _C
     if isinstance(sde, _ReverseSDE):
         sde = sde._fwd
@@ -212,9 +214,8 @@ def sde_desc(sde):
     elif isinstance(sde, VPSDE):
         kind = _C.SDE_VP
     elif isinstance(sde, VESDE):
-        # the beta fields carry sigma_min / sigma_max (include/dposer_hip.h: DPOSER_SDE_VE); the fused paths evaluate the CONTINUOUS
-        # VE score function (the network conditioned on sigma(t), utils.py:173) -- callers check `continuous` themselves
-        return _C.SdeDesc(_C.SDE_VE, int(sde.N), float(sde.sigma_min), float(sde.sigma_max), float(sde.T))
+        # the beta fields carry sigma_min / sigma_max (include/dposer_hip.h: DPOSER_SDE_VE / DPOSER_SDE_VE_DISCRETE)
+        return _C.SdeDesc(_C.SDE_VE if continuous else _C.SDE_VE_DISCRETE, int(sde.N), float(sde.sigma_min), float(sde.sigma_max), float(sde.T))
     else:
         return None
     return _C.SdeDesc(kind, int(sde.N), float(sde.beta_0), float(sde.beta_1), float(sde.T))

@@ -204,7 +204,7 @@ template <typename T, bool FOURIER> __global__ void __launch_bounds__(256) k_pre
             if (q == 0) a.t_out[s] = t;
         } else {
             const int g0 = (int)((i - nx) / a.Bpad) * PREP_EQ;
-            const float label = d.sde.kind == SDE_VE ? sde_ve_sigma(d.sde.smin, d.sde.ratio, t) : t * 999.0f;     // utils.py:152 / :173
+            const float label = d.sde.kind == SDE_VE ? sde_ve_sigma(d.sde.smin, d.sde.ratio, t) : t * 999.0f;     // utils.py:152 / :173 (training: continuous only)
             // all 32 frequencies first: behind a store to `emb` hipcc cannot hoist the next load of `freq` (the two may alias), and the
             // thread walked 32 dependent load -> sin -> store round trips -- 17 us of the kernel at ANY batch size
             const int half = a.E >> 1;

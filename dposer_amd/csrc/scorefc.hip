@@ -843,7 +843,8 @@ static int run_shared_t(dposer_scorefc_s* h, const float* flat, const char* pack
 
 static SdeCfg to_sde(const dposer_sde_desc* s) {
     SdeCfg c;
-    c.kind = s->kind == DPOSER_SDE_VP ? SDE_VP : (s->kind == DPOSER_SDE_VE ? SDE_VE : SDE_SUBVP);
+    c.kind = s->kind == DPOSER_SDE_VP ? SDE_VP : ((s->kind == DPOSER_SDE_VE || s->kind == DPOSER_SDE_VE_DISCRETE) ? SDE_VE : SDE_SUBVP);
+    c.discrete = s->kind == DPOSER_SDE_VE_DISCRETE;
     c.beta_0 = s->beta_min;
     c.beta_1 = s->beta_max;
     c.N = s->N;
@@ -851,14 +852,19 @@ static SdeCfg to_sde(const dposer_sde_desc* s) {
     return c;
 }
 
-static bool sde_kind_ok(const dposer_sde_desc* s) { return s->kind == DPOSER_SDE_SUBVP || s->kind == DPOSER_SDE_VP || s->kind == DPOSER_SDE_VE; }
+// (shared-t entry points; the training step takes the continuous kinds only: dsm_loss_fwd_bwd_impl)
+static bool sde_kind_ok(const dposer_sde_desc* s) {
+    return s->kind == DPOSER_SDE_SUBVP || s->kind == DPOSER_SDE_VP || s->kind == DPOSER_SDE_VE || s->kind == DPOSER_SDE_VE_DISCRETE;
+}
 // What the network is conditioned on at the n step times `t_host`, into w.tt_labels: t * 999 (utils.py:152: one IEEE fp32 product, the same
 // bits on host and device) or, for VE, sigma(t) (utils.py:173) -- formed ON THE DEVICE from the staged times (k_ve_labels), because every
 // kernel that perturbs with sigma(t) / divides the output by it calls the device's powf, and the host's libm may round the last bit the other way.
 static int stage_step_labels(dposer_scorefc_s* h, Ws& w, const dposer_sde_desc* s, const float* t_host, int n, hipStream_t st) {
     const bool ve = s && s->kind == DPOSER_SDE_VE;
+    const bool ve_disc = s && s->kind == DPOSER_SDE_VE_DISCRETE;      // round((T - t)(N - 1)): exact fp32 operations, formed here
     h->host_stage.resize(n);
-    for (int i = 0; i < n; ++i) h->host_stage[i] = ve ? t_host[i] : t_host[i] * 999.0f;
+    for (int i = 0; i < n; ++i)
+        h->host_stage[i] = ve ? t_host[i] : (ve_disc ? sde_ve_discrete_label((float)s->T, (float)(s->N - 1), t_host[i]) : t_host[i] * 999.0f);
     DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
     if (ve) {
         const SdeDev d = make_sde_dev(to_sde(s));
@@ -869,6 +875,7 @@ static int stage_step_labels(dposer_scorefc_s* h, Ws& w, const dposer_sde_desc* 
 // the one-row time table of a call at a single time t
 static int build_time_table_at(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, const dposer_sde_desc* s, float t, const float* freq,
                                hipStream_t st) {
+    if (s && s->kind == DPOSER_SDE_VE_DISCRETE) return build_time_table(h, flat, packed, w, nullptr, sde_ve_discrete_label((float)s->T, (float)(s->N - 1), t), 1, freq, st);
     if (!s || s->kind != DPOSER_SDE_VE) return build_time_table(h, flat, packed, w, nullptr, t * 999.0f, 1, freq, st);      // the label travels by value
     DP_TRY(stage_step_labels(h, w, s, &t, 1, st));
     return build_time_table(h, flat, packed, w, w.tt_labels, 0.f, 1, freq, st);
@@ -1759,6 +1766,7 @@ static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const vo
     g_alg_batch = B;
     DP_CHECK_ARG(sde && batch_x && freq && sigmas && flat_grad && loss, "null argument");
     DP_CHECK_ARG(sde_kind_ok(sde), "unknown SDE kind");
+    DP_CHECK_ARG(sde->kind != DPOSER_SDE_VE_DISCRETE, "the denoising-score-matching step takes the continuous score function (a discrete VE model trains on the SMLD loss)");
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
     Ws w;

@@ -11,6 +11,7 @@
 enum : int { SDE_SUBVP = 0, SDE_VP = 1, SDE_VE = 2 };
 struct SdeCfg {
     int kind;
+    int discrete = 0;        // SDE_VE only: the discrete score function's label round((T - t)(N - 1)) instead of sigma(t) (utils.py:175-178)
     double beta_0, beta_1;   // python floats of the reference's constructor; VE: sigma_min, sigma_max (sde_lib.py:235-247)
     int N;
     float T;
@@ -21,6 +22,8 @@ struct SdeDev {
     float b0, db, m2b0;   // beta_0, (beta_1 - beta_0), -2*beta_0  (python doubles rounded to fp32)
     float dt, sqrt_mdt;   // -1/N, sqrt(1/N)
     float smin, ratio, gk;   // VE: sigma_min, sigma_max / sigma_min, sqrt(fp32(2 (ln sigma_max - ln sigma_min)))   sde_lib.py:260-264
+    int disc;                // VE: discrete score function
+    float Tf, nm1;           // VE, discrete: T and N - 1 as the fp32 scalars torch multiplies with
 };
 static inline SdeDev make_sde_dev(const SdeCfg& s) {
     SdeDev d;
@@ -32,6 +35,9 @@ static inline SdeDev make_sde_dev(const SdeCfg& s) {
     d.dt = (float)(-1.0 / (double)s.N);
     d.sqrt_mdt = (float)sqrt(1.0 / (double)s.N);
     d.smin = d.ratio = d.gk = 0.f;
+    d.disc = s.kind == SDE_VE ? s.discrete : 0;
+    d.Tf = s.T;
+    d.nm1 = (float)(s.N - 1);
     if (s.kind == SDE_VE) {
         d.smin = (float)s.beta_0;                                           // `self.sigma_min * tensor`: the python float enters as an fp32 scalar
         d.ratio = (float)(s.beta_1 / s.beta_0);                             // `(self.sigma_max / self.sigma_min) ** t`: python-float quotient, fp32 pow
@@ -43,6 +49,12 @@ static inline SdeDev make_sde_dev(const SdeCfg& s) {
 __host__ __device__ __forceinline__ float sde_ve_sigma(float smin, float ratio, float t) {
 #pragma clang fp contract(off)
     return smin * powf(ratio, t);
+}
+// label of the discrete VE score function (utils.py:176-178): `labels = sde.T - t; labels *= sde.N - 1; labels = torch.round(labels)` -- two fp32
+// operations and a round-half-to-even, the same bits on host and device
+__host__ __device__ __forceinline__ float sde_ve_discrete_label(float Tf, float nm1, float t) {
+#pragma clang fp contract(off)
+    return rintf((Tf - t) * nm1);
 }
 __device__ __forceinline__ float sde_lmc(const SdeDev& s, float t) {          // sde_lib.py:214
 #pragma clang fp contract(off)
@@ -69,14 +81,14 @@ __device__ __forceinline__ float sde_diffusion(const SdeDev& s, float t) {     /
 // in the order the call sites always used):
 //   mc, sd  marginal_prob: mean = mc * x, std = sd        (VE: 1, sigma(t))
 //   beta, g sde: drift = -1/2 beta x, diffusion g         (VE: 0, sigma(t) * sqrt(2 ln(sigma_max / sigma_min)))
-//   label   what the network is conditioned on            (t * 999, utils.py:152; VE: sigma(t), utils.py:173)
+//   label   what the network is conditioned on            (t * 999, utils.py:152; VE: sigma(t), utils.py:173, or round((T - t)(N - 1)), :176-178)
 struct SdeAt { float mc, sd, beta, g, label; };
 __device__ __forceinline__ SdeAt sde_at(const SdeDev& s, float t) {
 #pragma clang fp contract(off)
     SdeAt r;
     if (s.kind == SDE_VE) {
         const float sig = sde_ve_sigma(s.smin, s.ratio, t);
-        r.mc = 1.0f; r.sd = sig; r.beta = 0.0f; r.g = sig * s.gk; r.label = sig;
+        r.mc = 1.0f; r.sd = sig; r.beta = 0.0f; r.g = sig * s.gk; r.label = s.disc ? sde_ve_discrete_label(s.Tf, s.nm1, t) : sig;
     } else {
         const float lmc = sde_lmc(s, t);
         r.mc = expf(lmc); r.sd = sde_std(s, lmc); r.beta = sde_beta(s, t); r.g = sde_diffusion(s, t); r.label = t * 999.0f;

@@ -21,7 +21,7 @@ from .dataset.AMASS import N_POSES, Posenormalizer
 
 class _PriorLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, model, sde, t, weighted, inv_n, z, seed, step):
+    def forward(ctx, x0, model, sde, t, weighted, inv_n, z, seed, step, continuous=True):
         _C.require_gpu(x0, "prior-loss input")
         eng = model._engine()
         flat = model.flat_params()
@@ -32,7 +32,7 @@ class _PriorLoss(torch.autograd.Function):
         grad = torch.empty_like(x)
         x0_hat = torch.empty_like(x)
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
-        desc = sde_lib.sde_desc(sde)
+        desc = sde_lib.sde_desc(sde, continuous)
         zz = None if z is None else z.contiguous().float()
         _C.check(eng.lib.dposer_prior_loss(eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(desc), _C.ptr(x), _C.ptr(zz), float(t),
                                            1 if weighted else 0, float(inv_n), _C.ptr(x0_hat), _C.ptr(grad), _C.ptr(loss), int(seed),
@@ -45,7 +45,7 @@ class _PriorLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return (grad * g, None, None, None, None, None, None, None, None)
+        return (grad * g, None, None, None, None, None, None, None, None, None)
 
 
 def _prior_loss_unfused(model, sde, x0, t, weighted, inv_n, z, continuous=True):
@@ -71,15 +71,16 @@ def prior_loss(model, sde, x0, t, *, weighted=True, reduction="mean", batch_size
     """Weighted denoising loss at one shared time ``t`` (python float).
     reduction='mean' -> torch.mean over [B, D] (completion.py:147); 'sum_over_batch' -> sum / batch_size (smplify.py:105).
     ``continuous``: ``config.training.continuous`` as the reference hands it to ``get_score_fn`` (motion_denoising.py:94,
-    completion.py:103).  It only changes the VE score function (utils.py:164-181: a discrete VE model is conditioned on the label
-    round((T - t)(N - 1)), not on sigma(t)); the fused kernel evaluates the continuous form, so a discrete VE prior runs step by step."""
+    completion.py:103).  Under the VE SDE it selects the label the network is conditioned on (utils.py:164-181: sigma(t), or
+    round((T - t)(N - 1)) for a discrete model) -- both on the fused kernel since round 6 (DPOSER_SDE_VE / DPOSER_SDE_VE_DISCRETE); a discrete
+    VP score function (utils.py:152-160) runs step by step."""
     if x0.shape[0] == 0:
         raise ValueError("prior_loss: empty batch (the reference's torch.mean over no elements is NaN)")
     n = x0.numel() if reduction == "mean" else (batch_size if batch_size is not None else x0.shape[0])
-    discrete_ve = (not continuous) and isinstance(sde, sde_lib.VESDE)
-    if sde_lib.sde_desc(sde) is None or discrete_ve:      # not covered by the fused kernel: the HIP score function + the reference's few elementwise steps
-        return _prior_loss_unfused(model, sde, x0, float(t), bool(weighted), 1.0 / float(n), z, continuous=not discrete_ve)
-    return _PriorLoss.apply(x0, model, sde, float(t), bool(weighted), 1.0 / float(n), z, seed, step)
+    discrete_vp = (not continuous) and isinstance(sde, sde_lib.VPSDE)
+    if sde_lib.sde_desc(sde) is None or discrete_vp:      # not covered by the fused kernel: the HIP score function + the reference's few elementwise steps
+        return _prior_loss_unfused(model, sde, x0, float(t), bool(weighted), 1.0 / float(n), z, continuous=bool(continuous))
+    return _PriorLoss.apply(x0, model, sde, float(t), bool(weighted), 1.0 / float(n), z, seed, step, bool(continuous))
 
 
 class DPoser(nn.Module):
@@ -106,6 +107,7 @@ class DPoser(nn.Module):
             raise NotImplementedError(f"SDE {config.training.sde} unknown.")
         sde.N = args.sde_N
         self.sde = sde
+        self.continuous = bool(getattr(config.training, "continuous", True))      # smplify.py:44: the score function's flavour
         self.model = diffusion_model
         self.model.eval()
         self.model.freeze_packed = False
@@ -127,7 +129,7 @@ class DPoser(nn.Module):
     def DPoser_loss(self, x_0, t, z=None):
         self._calls += 1
         return prior_loss(self.model, self.sde, x_0, t, weighted=True, reduction="sum_over_batch", batch_size=self.batch_size,
-                          z=z, seed=self.model._rng_seed + 17, step=self._calls)
+                          z=z, seed=self.model._rng_seed + 17, step=self._calls, continuous=getattr(self, "continuous", True))
 
     def forward(self, poses, betas, quan_t, z=None):
         poses = self.Normalizer.offline_normalize(poses[:, :N_POSES * 3], from_axis=True)

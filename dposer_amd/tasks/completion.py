@@ -47,9 +47,10 @@ class DPoserComp:
 
     def _fused_supported(self):
         from ..algorithms.advanced.model import ScoreModelFC
-        # (the fused kernels evaluate the CONTINUOUS score function; a discrete VE model conditions on other labels, utils.py:175-178)
+        # (sub-VP: one score function; VE: continuous or discrete labels, both on the fused kernels; a discrete VP score function,
+        #  utils.py:152-160, runs step by step)
         return (sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
-                and (getattr(self, "continuous", True) or not isinstance(self.sde, sde_lib.VESDE)))
+                and (getattr(self, "continuous", True) or not isinstance(self.sde, sde_lib.VPSDE)))
 
     def _schedule(self, time_strategy, total_steps, sample_trun, sample_time):
         """quan_t of every step (completion.py:183-192)."""
@@ -90,7 +91,7 @@ class DPoserComp:
             step0 = self._calls + 1
             self._calls += total_steps
             _C.check(eng.lib.dposer_completion_optimize(
-                eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(sde_lib.sde_desc(self.sde)), _C.ptr(x), _C.ptr(obs), _C.ptr(msk),
+                eng.h, _C.ptr(flat), _C.ptr(packed), _C.ptr(ws), C.byref(sde_lib.sde_desc(self.sde, bool(getattr(self, "continuous", True)))), _C.ptr(x), _C.ptr(obs), _C.ptr(msk),
                 _C.ptr(m), _C.ptr(v), t_host, wflag, w_prior, w_data, total_steps, float(lr), 0.9, 0.999, 1e-8, _C.ptr(nz),
                 int(model._rng_seed + 29), int(step0) & 0xFFFFFFFF, _C.ptr(eng.freq(x.device, model._fourier_W())), _C.ptr(model.sigmas), B, _C.stream_ptr()),
                 "dposer_completion_optimize")

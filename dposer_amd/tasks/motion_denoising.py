@@ -92,7 +92,7 @@ class MotionDenoise:
         from ..body_model.body_model import BodyModel
         nz = self.Normalizer
         return (sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
-                and (getattr(self, "continuous", True) or not isinstance(self.sde, sde_lib.VESDE))
+                and (getattr(self, "continuous", True) or not isinstance(self.sde, sde_lib.VPSDE))
                 and isinstance(self.body_model, BodyModel)
                 and getattr(nz, "rot_rep", None) in ("axis", "rot6d") and self.batch_size >= 2)
 
@@ -149,7 +149,7 @@ class MotionDenoise:
         fl = lambda xs: (C.c_float * n_steps)(*[float(x) for x in xs])
         step0 = self._calls + 1
         self._calls += n_steps
-        desc = sde_lib.sde_desc(self.sde)
+        desc = sde_lib.sde_desc(self.sde, bool(getattr(self, "continuous", True)))
         a = _C.MotionDenoiseArgs(
             net=eng.h, flat_params=_C.ptr(flat), packed=_C.ptr(packed), net_ws=_C.ptr(ws), sde=C.pointer(desc), freq=_C.ptr(eng.freq(dev, self.model._fourier_W())),
             sigmas=_C.ptr(model.sigmas), body=h, lbs_ws_fwd=_C.ptr(ws_f), lbs_ws_bwd=_C.ptr(ws_b), posedirs_packed=_C.ptr(core._packed_posedirs()),

@@ -54,8 +54,12 @@ enum { DPOSER_EMB_POSITIONAL = 0, DPOSER_EMB_FOURIER = 1 };
  * tiling; the other three on the 128-wide tilings (any batch), hidden_dim 1024 only */
 enum { DPOSER_ACT_SWISH = 0, DPOSER_ACT_ELU = 1, DPOSER_ACT_RELU = 2, DPOSER_ACT_LRELU = 3 };
 /* DPOSER_SDE_VE (sde_lib.py:234-292): beta_min / beta_max of dposer_sde_desc carry sigma_min / sigma_max; the network is conditioned on
- * sigma(t) (continuous VE score function, utils.py:164-181) and its output is the score itself. */
-enum { DPOSER_SDE_SUBVP = 0, DPOSER_SDE_VP = 1, DPOSER_SDE_VE = 2 };
+ * sigma(t) (continuous VE score function, utils.py:164-181) and its output is the score itself.
+ * DPOSER_SDE_VE_DISCRETE: the same SDE with the DISCRETE score function (get_score_fn(..., continuous=False), utils.py:175-181): the network is
+ * conditioned on the label round((T - t) (N - 1)) -- an index into `sigmas` for scale_by_sigma and the argument of the positional embedding --
+ * everything else as DPOSER_SDE_VE.  Shared-t evaluation only (sampler, Langevin step, prior loss and the two fitting loops): the training
+ * loss of a discrete model is the legacy SMLD loss, the probability-flow ODE is always continuous; those entry points refuse this kind. */
+enum { DPOSER_SDE_SUBVP = 0, DPOSER_SDE_VP = 1, DPOSER_SDE_VE = 2, DPOSER_SDE_VE_DISCRETE = 3 };
 
 typedef struct {
     int32_t data_dim;        /* n_poses * pose_dim: 63 (axis-angle) or 126 (rot6d), 1..512  model.py:109 */

@@ -32,6 +32,8 @@ def timestep_embedding(labels: torch.Tensor, dim: int, max_positions=10000) -> t
     """lib/algorithms/advanced/model.py:37-51 (sinusoidal embedding of the labels t*999)."""
     half = dim // 2
     scale = math.log(max_positions) / (half - 1)
+    if not labels.is_floating_point():
+        labels = labels.float()                                                # model.py:46 `timesteps.float()` (integer labels: the discrete score functions)
     freq = torch.exp(torch.arange(half, dtype=torch.float32) * -scale).to(labels.dtype)
     arg = labels[:, None] * freq[None, :]
     emb = torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
@@ -178,8 +180,9 @@ class VE:
     """lib/algorithms/advanced/sde_lib.py:234-292."""
     name = "VESDE"
 
-    def __init__(self, sigma_min=0.01, sigma_max=50.0, N=1000):
+    def __init__(self, sigma_min=0.01, sigma_max=50.0, N=1000, discrete=False):
         self.smin, self.smax, self.N, self.T = sigma_min, sigma_max, N, 1.0
+        self.discrete = discrete          # get_score_fn(..., continuous=False): the network's label is round((T - t)(N - 1)), utils.py:175-178
 
     def sde(self, x, t):                                                     # :253-262
         sigma = self.smin * (self.smax / self.smin) ** t
@@ -197,13 +200,18 @@ class VE:
 # utils.py : get_score_fn
 # --------------------------------------------------------------------------------------------
 def score_fn(p: Params, sde, x, t, **fw):
-    """lib/algorithms/advanced/utils.py:127-186, continuous=True branch for VP/subVP, and VE."""
+    """lib/algorithms/advanced/utils.py:127-186, continuous=True branch for VP/subVP, and VE (continuous :173, discrete :175-178)."""
     if sde.name in ("VPSDE", "subVPSDE"):
         labels = t * 999                                                     # utils.py:152
         out = scorefc_forward(p, x, labels, **fw)
         std = sde.marginal_prob(torch.zeros_like(x), t)[1]                   # utils.py:155
         return -out / std[:, None]                                           # utils.py:162
-    labels = sde.marginal_prob(torch.zeros_like(x), t)[1]                    # utils.py:173
+    if getattr(sde, "discrete", False):
+        labels = sde.T - t                                                   # utils.py:176
+        labels = labels * (sde.N - 1)                                        # :177
+        labels = torch.round(labels).long()                                  # :178
+    else:
+        labels = sde.marginal_prob(torch.zeros_like(x), t)[1]                # utils.py:173
     return scorefc_forward(p, x, labels, **fw)
 
 

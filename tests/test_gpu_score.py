@@ -379,7 +379,8 @@ def test_ve_sde_fused_paths_match_reference_golden(prec, tol_loss, tol_grad, tol
     cfg, m, p = make_model(int(g["seed"]), precision=prec, dropout=0.0)
     sde = mk(1000)
     assert sampling.fused_em_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, True)
-    assert not sampling.fused_em_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, False)     # discrete VE: other labels
+    assert sampling.fused_em_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, False)         # discrete VE: other labels, same kernels (g25)
+    assert not sampling.fused_em_supported(sde_lib.VPSDE(0.1, 20.0, 1000), m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, False)     # discrete VP: step by step
     assert fused_dsm_supported(sde, m, True, True, False, False)
     # DSM loss + every parameter gradient
     t = _dev(g["dsm_u"]) * (1.0 - 1e-5) + 1e-5
@@ -417,6 +418,52 @@ def test_ve_sde_fused_paths_match_reference_golden(prec, tol_loss, tol_grad, tol
     out = comp.optimize(_dev(g["loop_observation"]), _dev(g["loop_mask"]), iterations=int(g["loop_iterations"]),
                         steps_per_iter=int(g["loop_steps_per_iter"]), noise=_dev(g["loop_noise"]))
     assert rel_err(t2n(out), g["loop_out"]) < max(tol, 2e-4)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("bf16", 2e-2), ("bf16x3", 1e-4)])
+def test_discrete_ve_score_function_on_the_fused_paths_matches_reference_golden(prec, tol, monkeypatch):
+    """training.continuous = False under the VE SDE (get_score_fn(..., continuous=False), utils.py:175-181: the network is conditioned on the label
+    round((T - t)(N - 1)) -- an index into `sigmas`, the argument of the positional embedding) on the one-call paths (DPOSER_SDE_VE_DISCRETE, round 6):
+    EM sampler (plain and with completion imputation), prior loss + gradient, completion loop, against the reference's own outputs with its recorded
+    draws (golden g25).  The step-by-step fallbacks are made to raise; the training step refuses the kind (a discrete model trains on the SMLD loss)."""
+    from dposer_amd.algorithms.advanced import sampling, sde_lib
+    from dposer_amd.algorithms.advanced.losses import fused_dsm_supported
+    from dposer_amd.prior import prior_loss
+    from dposer_amd import prior as prior_mod, _C
+    from dposer_amd.tasks.completion import DPoserComp
+    g = load("g25_ve_discrete_paths")
+    mk = lambda N: sde_lib.VESDE(sigma_min=float(g["sigma_min"]), sigma_max=float(g["sigma_max"]), N=N)
+    cfg8, m8, _ = make_model(int(g["seed"]), precision=prec)
+    cfg8.training.continuous = False
+    cfg8.sampling.corrector = "none"
+    assert sde_lib.sde_desc(mk(8), False).kind == _C.SDE_VE_DISCRETE and sde_lib.sde_desc(mk(8)).kind == _C.SDE_VE
+    assert not fused_dsm_supported(mk(1000), m8, False, True, False, False)
+    monkeypatch.setattr(sampling, "shared_predictor_update_fn", lambda *a, **k: (_ for _ in ()).throw(AssertionError("step-by-step sampler used")))
+    monkeypatch.setattr(prior_mod, "_prior_loss_unfused", lambda *a, **k: (_ for _ in ()).throw(AssertionError("step-by-step prior loss used")))
+    fn = sampling.get_sampling_fn(cfg8, mk(8), (16, 63), lambda x: x, 1e-3, device=DEV)
+    trajs, x = fn(m8, z=_dev(g["em8_z0"]), noise=_dev(g["em8_noise"])[:, None])
+    assert rel_err(t2n(trajs), g["em8_trajs"]) < tol and rel_err(t2n(x), g["em8_final"]) < tol
+    trajs, x = fn(m8, observation=_dev(g["comp8_obs"]), mask=_dev(g["comp8_mask"]), z=_dev(g["comp8_z0"]), args=_Args("completion"),
+                  noise=_dev(g["comp8_noise"]).reshape(8, 3, 16, 63))
+    assert rel_err(t2n(trajs), g["comp8_trajs"]) < tol and rel_err(t2n(x), g["comp8_final"]) < tol
+    sde = mk(1000)
+    for step in (0, 100, 199):
+        x0 = _dev(g["prior_x0"]).requires_grad_(True)
+        lp = prior_loss(m8, sde, x0, float(g[f"prior_s{step}_t"]), weighted=bool(int(g[f"prior_s{step}_quan_t"])), z=_dev(g[f"prior_s{step}_z"]),
+                        continuous=False)
+        lp.backward()
+        assert abs(float(lp) - float(g[f"prior_s{step}_loss"])) / abs(float(g[f"prior_s{step}_loss"])) < max(tol, 2e-4)
+        assert rel_err(t2n(x0.grad), g[f"prior_s{step}_grad"]) < max(tol, 2e-4)
+    comp = DPoserComp(m8, sde, continuous=False, batch_size=16)
+    assert comp._fused_supported()
+    out = comp.optimize(_dev(g["loop_observation"]), _dev(g["loop_mask"]), iterations=int(g["loop_iterations"]),
+                        steps_per_iter=int(g["loop_steps_per_iter"]), noise=_dev(g["loop_noise"]))
+    assert rel_err(t2n(out), g["loop_out"]) < max(tol, 2e-4)
+    # the continuous score function on the same inputs must NOT land on the discrete golden (the label really is another one)
+    cfg8.training.continuous = True
+    fn_c = sampling.get_sampling_fn(cfg8, mk(8), (16, 63), lambda x: x, 1e-3, device=DEV)
+    _, xc = fn_c(m8, z=_dev(g["em8_z0"]), noise=_dev(g["em8_noise"])[:, None])
+    assert rel_err(t2n(xc), g["em8_final"]) > 10 * tol
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1173,22 +1220,25 @@ def test_langevin_fused_vp_sde_vs_oracle():
     assert rel_err(t2n(x), xm.numpy()) < 1e-4
 
 
-def test_langevin_fused_ve_sde_vs_oracle():
+@pytest.mark.parametrize("continuous", [True, False])
+def test_langevin_fused_ve_sde_vs_oracle(continuous):
     """Langevin + EM under the VE SDE (sde_lib.py:234-292): alpha = 1 in the step size (sampling.py:293-294), the network is conditioned on
-    sigma(t) and its output is the score; the fused two-phase corrector + the fused predictor against the oracle step by step (the oracle
-    itself is pinned to the reference's VE outputs: golden g21)."""
+    sigma(t) -- or, with the discrete score function (training.continuous = False), on round((T - t)(N - 1)) -- and its output is the score;
+    the fused two-phase corrector + the fused predictor against the oracle step by step (the oracle itself is pinned to the reference's VE
+    outputs: goldens g21 / g25)."""
     from dposer_amd.algorithms.advanced import sampling, sde_lib
     cfg, m, p = make_model(26, precision="fp32")
     cfg.sampling.corrector = "langevin"
+    cfg.training.continuous = continuous
     N, B, start = 1000, 40, 995
     sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50.0, N=N)
-    assert sampling.fused_langevin_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.LangevinCorrector, False, True)
+    assert sampling.fused_langevin_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.LangevinCorrector, False, continuous)
     fn = sampling.get_sampling_fn(cfg, sde, (B, 63), lambda v: v, 1e-3, device=DEV)
     rs = np.random.RandomState(10)
     z0 = (rs.standard_normal((B, 63)) * 0.5).astype(np.float32)
     noise = rs.standard_normal((N - start, 2, B, 63)).astype(np.float32)
     trajs, x = fn(m, z=_dev(z0), noise=_dev(noise), start_step=start, args=_Args("denoise"))
-    xo, so, ts = torch.tensor(z0), R.VE(0.01, 50.0, N), torch.linspace(1.0, 1e-3, N)
+    xo, so, ts = torch.tensor(z0), R.VE(0.01, 50.0, N, discrete=not continuous), torch.linspace(1.0, 1e-3, N)
     for k, i in enumerate(range(start, N)):
         t = torch.ones(B) * ts[i]
         xo, _ = R.langevin_step(p, so, xo, t, torch.tensor(noise[k, 0]), snr=cfg.sampling.snr)

@@ -280,8 +280,8 @@ def test_motion_denoise_fused_skinning_temporal_gradient_is_bit_identical(S, F, 
 def test_motion_denoise_under_the_ve_sde():
     """training.sde = 'vesde' (motion_denoising.py:60-62 builds it).  Continuous score function: the one-call loop takes it (the prior's
     label is sigma(t), its output the score) and lands where the step-by-step autograd loop lands.  The discrete VE score function
-    (continuous = False) stays outside the one-call loop: `optimize_sequences` walks the sequences through `optimize` one by one and
-    returns the batched layout."""
+    (continuous = False: the prior's label is round((T - t)(N - 1))) is on the one-call loop too since round 6 (DPOSER_SDE_VE_DISCRETE); its
+    reference here is the autograd loop with the prior forced onto the step-by-step form (the reference's own discrete outputs: golden g25)."""
     from dposer_amd.algorithms.advanced import sde_lib
     F, S, iters, spi = 6, 2, 1, 3
     md, joints3d, gt, init, rs = _md_setup(F * S)
@@ -297,11 +297,27 @@ def test_motion_denoise_under_the_ve_sde():
     assert rel_err(t2n(one_f["pose_body"]), t2n(one_u["pose_body"])) < 2e-5
     assert float((one_f["pose_body"] - init[F:]).abs().max()) > 1e-3            # (the poses moved)
     md.continuous = False
-    assert not md._fused_supported()
+    assert md._fused_supported()
     res = md.optimize_sequences(joints3d.reshape(S, F, 22, 3), gt.reshape(S, F, 63), noise=noise, init_poses=init.reshape(S, F, 63), **kw)
     assert res["pose_body"].shape == (S, F, 63) and res["MPJPE"].shape == (S, F) and np.isfinite(res["MPVPE"]).all()
-    one = md.optimize(joints3d[F:], gt_poses=gt[F:], noise=noise[:, F:].contiguous(), init_poses=init[F:], **kw)
+    one = md.optimize(joints3d[F:], gt_poses=gt[F:], noise=noise[:, F:].contiguous(), init_poses=init[F:], fused=True, **kw)
     assert torch.equal(res["pose_body"][1], one["pose_body"])
+    # ... against the autograd loop whose prior runs step by step on the host mirror of the reference's discrete score function
+    from dposer_amd import prior as prior_mod
+    from dposer_amd.algorithms.advanced import sde_lib as sl
+    real = prior_mod.prior_loss
+
+    def stepwise(model, sde, x0, t, *, weighted=True, reduction="mean", batch_size=None, z=None, seed=0, step=0, continuous=True):
+        n = x0.numel() if reduction == "mean" else (batch_size if batch_size is not None else x0.shape[0])
+        return prior_mod._prior_loss_unfused(model, sde, x0, float(t), bool(weighted), 1.0 / float(n), z, continuous=False)
+    import dposer_amd.tasks.motion_denoising as mdmod
+    monkey = mdmod.prior_loss
+    mdmod.prior_loss = stepwise
+    try:
+        one_s = md.optimize(joints3d[F:], gt_poses=gt[F:], noise=noise[:, F:].contiguous(), init_poses=init[F:], fused=False, **kw)
+    finally:
+        mdmod.prior_loss = monkey
+    assert rel_err(t2n(one["pose_body"]), t2n(one_s["pose_body"])) < 2e-5
     # the discrete score function conditions the network on round((T - t)(N - 1)) instead of sigma(t): it must really have been used
     assert not torch.equal(one["pose_body"], one_u["pose_body"])
 
