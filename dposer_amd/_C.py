@@ -15,7 +15,7 @@ PREC_BF16, PREC_FP32, PREC_BF16X3 = 0, 1, 2
 PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_FP32, "bf16x3": PREC_BF16X3}
 EMB_POSITIONAL, EMB_FOURIER = 0, 1
 ACTIVATIONS = {"swish": 0, "elu": 1, "relu": 2, "lrelu": 3}      # config.model.nonlinearity -> DPOSER_ACT_*
-SDE_SUBVP, SDE_VP, SDE_VE, SDE_VE_DISCRETE = 0, 1, 2, 3
+SDE_SUBVP, SDE_VP, SDE_VE, SDE_VE_DISCRETE, SDE_VP_DISCRETE = 0, 1, 2, 3, 4
 WS_INFER, WS_SHARED_T, WS_TRAIN = 0, 1, 2
 
 

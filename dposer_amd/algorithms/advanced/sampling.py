@@ -255,7 +255,7 @@ def shared_corrector_update_fn(x, t, observation, mask, sde, model, corrector, c
 def fused_em_supported(sde, model, predictor, corrector, probability_flow, continuous):
     from .model import ScoreModelFC
     return (predictor is EulerMaruyamaPredictor and corrector in (None, NoneCorrector) and not probability_flow
-            and sde_lib.sde_desc(sde) is not None and (continuous or isinstance(sde, (sde_lib.subVPSDE, sde_lib.VESDE)))
+            and sde_lib.sde_desc(sde, continuous) is not None
             and isinstance(model, ScoreModelFC))
 
 
@@ -294,7 +294,7 @@ def fused_em_sample(model, sde, x, timesteps, *, start_step=0, observation=None,
 def fused_langevin_supported(sde, model, predictor, corrector, probability_flow, continuous):
     from .model import ScoreModelFC
     return (predictor is EulerMaruyamaPredictor and corrector is LangevinCorrector and not probability_flow
-            and sde_lib.sde_desc(sde) is not None and (continuous or isinstance(sde, (sde_lib.subVPSDE, sde_lib.VESDE)))
+            and sde_lib.sde_desc(sde, continuous) is not None
             and isinstance(model, ScoreModelFC))
 
 

@@ -204,8 +204,9 @@ class VESDE(SDE):
 
 def sde_desc(sde, continuous=True):
     """(kind, N, beta_min, beta_max, T) for the C ABI; None when the fused kernels do not cover the SDE.  ``continuous=False`` selects the
-    discrete VE score function (utils.py:175-178: the network conditioned on round((T - t)(N - 1))); it changes nothing for sub-VP, and the
-    callers keep a discrete VP score function off the fused paths themselves."""
+    discrete score functions: VE (utils.py:175-178: the network conditioned on round((T - t)(N - 1))) and VP (utils.py:157-160: label
+    t (N - 1), std from the DDPM table -- which the kernels rebuild for sde.N, so a VPSDE whose N was changed after construction, its table
+    still the constructor's, returns None: step by step); it changes nothing for sub-VP."""
     from ... import _C
     if isinstance(sde, _ReverseSDE):
         sde = sde._fwd
@@ -213,6 +214,10 @@ def sde_desc(sde, continuous=True):
         kind = _C.SDE_SUBVP
     elif isinstance(sde, VPSDE):
         kind = _C.SDE_VP
+        if not continuous:
+            if int(sde.sqrt_1m_alphas_cumprod.shape[0]) != int(sde.N):
+                return None
+            kind = _C.SDE_VP_DISCRETE
     elif isinstance(sde, VESDE):
         # the beta fields carry sigma_min / sigma_max (include/dposer_hip.h: DPOSER_SDE_VE / DPOSER_SDE_VE_DISCRETE)
         return _C.SdeDesc(_C.SDE_VE if continuous else _C.SDE_VE_DISCRETE, int(sde.N), float(sde.sigma_min), float(sde.sigma_max), float(sde.T))

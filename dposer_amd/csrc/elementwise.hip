@@ -325,7 +325,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_em_update(EmDev d
                 if (a.res) {
                     // score = -(res / used_sigmas) / std                         model.py:194, utils.py:162
                     const float model = a.res[s * a.Cp + c + r] / usig;
-                    const float score = sde_score(d.sde, model, sd);
+                    const float score = sde_score(d.sde, model, at.sd_score);
                     // rsde.sde: drift = -0.5 beta x - g^2 score                  sde_lib.py:98-104
                     float drift = (-0.5f * beta) * x;
                     drift = drift - ((g * g) * score) * 1.0f;
@@ -380,7 +380,7 @@ hipError_t launch_ft_to_rows(const float* a_ft, float* a, const float* b_ft, flo
 hipError_t launch_em_update(const EmUpdateArgs& a, hipStream_t st) {
     EmDev d;
     d.a = a;
-    d.sde = make_sde_dev(a.sde);
+    d.sde = make_sde_dev_at(a.sde, a.t);
     const int64_t total = a.Bpad * (a.Dpad >> 2);
     if (a.f32) hipLaunchKernelGGL(k_em_update<float>, dim3(grid_for(total)), dim3(256), 0, st, d);
     else hipLaunchKernelGGL(k_em_update<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, d);
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(256) k_denoise(DenoiseDev d) {
         const int64_t s = i / a.D;
         const int c = (int)(i % a.D);
         const float model = a.res[s * a.Cp + c] / usig;
-        const float score = sde_score(d.sde, model, sigma);           // utils.py:155,162 (std == sigma)
+        const float score = sde_score(d.sde, model, at.sd_score);     // utils.py:155,162 (std == sigma; the DDPM table's entry for a discrete VP score function, :160)
         const float x0h = (a.xt[s * a.Dpad + c] + sigma2 * score) / alpha;   // completion.py:107
         const float diff = a.x0[i] - x0h;
         acc += w * (diff * diff);
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(256) k_denoise(DenoiseDev d) {
 hipError_t launch_denoise(const DenoiseArgs& a, int* nblocks, hipStream_t st) {
     DenoiseDev d;
     d.a = a;
-    d.sde = make_sde_dev(a.sde);
+    d.sde = make_sde_dev_at(a.sde, a.t);
     const int g = grid_for(a.B * a.D, 256, 1024);
     *nblocks = g;
     hipLaunchKernelGGL(k_denoise, dim3(g), dim3(256), 0, st, d);
@@ -500,7 +500,7 @@ __global__ void __launch_bounds__(256) k_completion_update(CompletionDev d) {
         const int64_t s = i / a.D;
         const int c = (int)(i % a.D);
         const float model = a.res[s * a.Cp + c] / usig;
-        const float score = sde_score(d.sde, model, sigma);           // utils.py:155,162
+        const float score = sde_score(d.sde, model, at.sd_score);     // utils.py:155,162 / :160
         const float x0h = (a.xt[s * a.Dpad + c] + sigma2 * score) / alpha;   // completion.py:107
         float x = a.x[i];
         const float mk = a.mask[i];
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(256) k_completion_update(CompletionDev d) {
 hipError_t launch_completion_update(const CompletionUpdateArgs& a, hipStream_t st) {
     CompletionDev d;
     d.a = a;
-    d.sde = make_sde_dev(a.sde);
+    d.sde = make_sde_dev_at(a.sde, a.t);
     hipLaunchKernelGGL(k_completion_update, dim3(grid_for(a.B * a.D, 256, 2048)), dim3(256), 0, st, d);
     return hipGetLastError();
 }
@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(256) k_langevin_norms(LangevinDev d) {
     const LangevinArgs& a = d.a;
     const int QD = (a.D + 3) >> 2;
     const SdeAt at = sde_at(d.sde, a.t);
-    const float sd = at.sd;
+    const float sd = at.sd_score;      // (the score's std: utils.py:155 / :160)
     const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, at.label, a.scale_by_sigma == 2) : 1.0f;
     float gsum = 0.f, nsum = 0.f;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.B; s += (int64_t)gridDim.x * blockDim.x) {
@@ -571,7 +571,7 @@ __global__ void __launch_bounds__(256) k_langevin_norms(LangevinDev d) {
 hipError_t launch_langevin_norms(const LangevinArgs& a, int* nblocks, hipStream_t st) {
     LangevinDev d;
     d.a = a;
-    d.sde = make_sde_dev(a.sde);
+    d.sde = make_sde_dev_at(a.sde, a.t);
     const int g = grid_for(a.B, 256, 1024);
     *nblocks = g;
     hipLaunchKernelGGL(k_langevin_norms, dim3(g), dim3(256), 0, st, d);
@@ -592,7 +592,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_langevin_update(L
     const int qx = a.Dpad >> 2;
     const int QD = (a.D + 3) >> 2;
     const SdeAt at = sde_at(d.sde, a.t);
-    const float sd = at.sd;
+    const float sd = at.sd_score;      // (the score's std: utils.py:155 / :160)
     const float usig = a.scale_by_sigma ? used_sigma(a.sigmas, a.num_scales, at.label, a.scale_by_sigma == 2) : 1.0f;
     const float grad_norm = a.norm_sums[0] * a.inv_global_batch, noise_norm = a.norm_sums[1] * a.inv_global_batch;   // .mean()
     const float r0 = a.snr * noise_norm / grad_norm;
@@ -626,7 +626,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_langevin_update(L
 hipError_t launch_langevin_update(const LangevinArgs& a, hipStream_t st) {
     LangevinDev d;
     d.a = a;
-    d.sde = make_sde_dev(a.sde);
+    d.sde = make_sde_dev_at(a.sde, a.t);
     const int64_t total = a.Bpad * (a.Dpad >> 2);
     if (a.f32) hipLaunchKernelGGL(k_langevin_update<float>, dim3(grid_for(total)), dim3(256), 0, st, d);
     else hipLaunchKernelGGL(k_langevin_update<__bf16>, dim3(grid_for(total)), dim3(256), 0, st, d);

@@ -485,7 +485,7 @@ template <typename T> struct EpiEmStep {
 #pragma clang fp contract(off)
         Scal sc;
         const SdeAt at = sde_at(p.sde, p.t);
-        sc.sd = at.sd;
+        sc.sd = at.sd_score;      // (only the score is formed with it: utils.py:155 / :160)
         sc.beta = at.beta;
         sc.g = at.g;
         sc.usig = p.scale_by_sigma ? used_sigma(p.sigmas, p.num_scales, at.label, p.scale_by_sigma == 2) : 1.0f;

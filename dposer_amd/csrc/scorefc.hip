@@ -843,8 +843,8 @@ static int run_shared_t(dposer_scorefc_s* h, const float* flat, const char* pack
 
 static SdeCfg to_sde(const dposer_sde_desc* s) {
     SdeCfg c;
-    c.kind = s->kind == DPOSER_SDE_VP ? SDE_VP : ((s->kind == DPOSER_SDE_VE || s->kind == DPOSER_SDE_VE_DISCRETE) ? SDE_VE : SDE_SUBVP);
-    c.discrete = s->kind == DPOSER_SDE_VE_DISCRETE;
+    c.kind = (s->kind == DPOSER_SDE_VP || s->kind == DPOSER_SDE_VP_DISCRETE) ? SDE_VP : ((s->kind == DPOSER_SDE_VE || s->kind == DPOSER_SDE_VE_DISCRETE) ? SDE_VE : SDE_SUBVP);
+    c.discrete = s->kind == DPOSER_SDE_VE_DISCRETE || s->kind == DPOSER_SDE_VP_DISCRETE;
     c.beta_0 = s->beta_min;
     c.beta_1 = s->beta_max;
     c.N = s->N;
@@ -854,7 +854,7 @@ static SdeCfg to_sde(const dposer_sde_desc* s) {
 
 // (shared-t entry points; the training step takes the continuous kinds only: dsm_loss_fwd_bwd_impl)
 static bool sde_kind_ok(const dposer_sde_desc* s) {
-    return s->kind == DPOSER_SDE_SUBVP || s->kind == DPOSER_SDE_VP || s->kind == DPOSER_SDE_VE || s->kind == DPOSER_SDE_VE_DISCRETE;
+    return s->kind == DPOSER_SDE_SUBVP || s->kind == DPOSER_SDE_VP || s->kind == DPOSER_SDE_VE || s->kind == DPOSER_SDE_VE_DISCRETE || s->kind == DPOSER_SDE_VP_DISCRETE;
 }
 // What the network is conditioned on at the n step times `t_host`, into w.tt_labels: t * 999 (utils.py:152: one IEEE fp32 product, the same
 // bits on host and device) or, for VE, sigma(t) (utils.py:173) -- formed ON THE DEVICE from the staged times (k_ve_labels), because every
@@ -862,9 +862,11 @@ static bool sde_kind_ok(const dposer_sde_desc* s) {
 static int stage_step_labels(dposer_scorefc_s* h, Ws& w, const dposer_sde_desc* s, const float* t_host, int n, hipStream_t st) {
     const bool ve = s && s->kind == DPOSER_SDE_VE;
     const bool ve_disc = s && s->kind == DPOSER_SDE_VE_DISCRETE;      // round((T - t)(N - 1)): exact fp32 operations, formed here
+    const bool vp_disc = s && s->kind == DPOSER_SDE_VP_DISCRETE;      // t (N - 1), utils.py:158
     h->host_stage.resize(n);
     for (int i = 0; i < n; ++i)
-        h->host_stage[i] = ve ? t_host[i] : (ve_disc ? sde_ve_discrete_label((float)s->T, (float)(s->N - 1), t_host[i]) : t_host[i] * 999.0f);
+        h->host_stage[i] = ve ? t_host[i] : (ve_disc ? sde_ve_discrete_label((float)s->T, (float)(s->N - 1), t_host[i])
+                                                     : (vp_disc ? t_host[i] * (float)(s->N - 1) : t_host[i] * 999.0f));
     DP_CHECK_HIP(hipMemcpyAsync(w.tt_labels, h->host_stage.data(), n * sizeof(float), hipMemcpyHostToDevice, st));
     if (ve) {
         const SdeDev d = make_sde_dev(to_sde(s));
@@ -876,6 +878,7 @@ static int stage_step_labels(dposer_scorefc_s* h, Ws& w, const dposer_sde_desc* 
 static int build_time_table_at(dposer_scorefc_s* h, const float* flat, const char* packed, Ws& w, const dposer_sde_desc* s, float t, const float* freq,
                                hipStream_t st) {
     if (s && s->kind == DPOSER_SDE_VE_DISCRETE) return build_time_table(h, flat, packed, w, nullptr, sde_ve_discrete_label((float)s->T, (float)(s->N - 1), t), 1, freq, st);
+    if (s && s->kind == DPOSER_SDE_VP_DISCRETE) return build_time_table(h, flat, packed, w, nullptr, t * (float)(s->N - 1), 1, freq, st);
     if (!s || s->kind != DPOSER_SDE_VE) return build_time_table(h, flat, packed, w, nullptr, t * 999.0f, 1, freq, st);      // the label travels by value
     DP_TRY(stage_step_labels(h, w, s, &t, 1, st));
     return build_time_table(h, flat, packed, w, w.tt_labels, 0.f, 1, freq, st);
@@ -950,7 +953,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
     // through MALL / HBM, under the chip's power cap.  Removing the grid-wide joins does not pay for that.
     const int persistent_env = score_tuning().sampler_persistent;
     const int64_t persistent_min = score_tuning().sampler_persistent_min;
-    if (fused && persistent_env && !h->x3 && h->d.activation == DPOSER_ACT_SWISH && h->gs == 32 && h->H % 256 == 0 && h->Cp == 64 && w.Bpad % 256 == 0 && (persistent_env >= 2 || w.Bpad >= persistent_min)) {
+    if (fused && persistent_env && !(sc.kind == SDE_VP && sc.discrete) && !h->x3 && h->d.activation == DPOSER_ACT_SWISH && h->gs == 32 && h->H % 256 == 0 && h->Cp == 64 && w.Bpad % 256 == 0 && (persistent_env >= 2 || w.Bpad >= persistent_min)) {
         SamplerLayer tab[MAX_L];
         std::memset(tab, 0, sizeof(tab));
         for (int l = 0; l < h->L; ++l) {
@@ -1011,7 +1014,7 @@ static int em_sampler_impl(dposer_scorefc_t h, const float* flat, const void* pa
             EmStepParams p;
             std::memset(&p, 0, sizeof(p));
             p.bias = flat + h->off_post_b; p.x_ft = w.xft; p.x_mean_ft = (i + 1 == n_run) ? w.xmft : nullptr; p.xin = w.xin;
-            p.sigmas = sigmas; p.sde = make_sde_dev(sc); p.t = timesteps_host[gi]; p.num_scales = h->d.num_scales;
+            p.sigmas = sigmas; p.sde = make_sde_dev_at(sc, timesteps_host[gi]); p.t = timesteps_host[gi]; p.num_scales = h->d.num_scales;
             p.scale_by_sigma = sbs_mode(h); p.D = h->D; p.Cp = h->Cp; p.QD = (h->D + 3) >> 2; p.S_valid = B;
             p.seed = seed; p.step = (uint32_t)gi;
             DP_HIP_LAUNCH(gemm_em_step(gemm_prec(h), shape, g, p, st));
@@ -1766,7 +1769,8 @@ static int dsm_loss_fwd_bwd_impl(dposer_scorefc_t h, const float* flat, const vo
     g_alg_batch = B;
     DP_CHECK_ARG(sde && batch_x && freq && sigmas && flat_grad && loss, "null argument");
     DP_CHECK_ARG(sde_kind_ok(sde), "unknown SDE kind");
-    DP_CHECK_ARG(sde->kind != DPOSER_SDE_VE_DISCRETE, "the denoising-score-matching step takes the continuous score function (a discrete VE model trains on the SMLD loss)");
+    DP_CHECK_ARG(sde->kind != DPOSER_SDE_VE_DISCRETE && sde->kind != DPOSER_SDE_VP_DISCRETE,
+                 "the denoising-score-matching step takes the continuous score function (discrete models train on the SMLD / DDPM losses)");
     hipStream_t st = (hipStream_t)stream;
     const char* packed = (const char*)packed_;
     Ws w;

@@ -11,7 +11,8 @@
 enum : int { SDE_SUBVP = 0, SDE_VP = 1, SDE_VE = 2 };
 struct SdeCfg {
     int kind;
-    int discrete = 0;        // SDE_VE only: the discrete score function's label round((T - t)(N - 1)) instead of sigma(t) (utils.py:175-178)
+    int discrete = 0;        // the discrete score function: SDE_VE label round((T - t)(N - 1)) instead of sigma(t) (utils.py:175-178); SDE_VP label t (N - 1) and
+                             // the DDPM table's std (utils.py:157-160)
     double beta_0, beta_1;   // python floats of the reference's constructor; VE: sigma_min, sigma_max (sde_lib.py:235-247)
     int N;
     float T;
@@ -22,8 +23,9 @@ struct SdeDev {
     float b0, db, m2b0;   // beta_0, (beta_1 - beta_0), -2*beta_0  (python doubles rounded to fp32)
     float dt, sqrt_mdt;   // -1/N, sqrt(1/N)
     float smin, ratio, gk;   // VE: sigma_min, sigma_max / sigma_min, sqrt(fp32(2 (ln sigma_max - ln sigma_min)))   sde_lib.py:260-264
-    int disc;                // VE: discrete score function
-    float Tf, nm1;           // VE, discrete: T and N - 1 as the fp32 scalars torch multiplies with
+    int disc;                // VE / VP: discrete score function
+    float Tf, nm1;           // discrete: T and N - 1 as the fp32 scalars torch multiplies with
+    float sd_disc;           // VP, discrete: sqrt_1m_alphas_cumprod[(t (N - 1)).long()] at the launch's shared t (make_sde_dev_at)
 };
 static inline SdeDev make_sde_dev(const SdeCfg& s) {
     SdeDev d;
@@ -35,14 +37,36 @@ static inline SdeDev make_sde_dev(const SdeCfg& s) {
     d.dt = (float)(-1.0 / (double)s.N);
     d.sqrt_mdt = (float)sqrt(1.0 / (double)s.N);
     d.smin = d.ratio = d.gk = 0.f;
-    d.disc = s.kind == SDE_VE ? s.discrete : 0;
+    d.disc = (s.kind == SDE_VE || s.kind == SDE_VP) ? s.discrete : 0;
     d.Tf = s.T;
     d.nm1 = (float)(s.N - 1);
+    d.sd_disc = 0.f;
     if (s.kind == SDE_VE) {
         d.smin = (float)s.beta_0;                                           // `self.sigma_min * tensor`: the python float enters as an fp32 scalar
         d.ratio = (float)(s.beta_1 / s.beta_0);                             // `(self.sigma_max / self.sigma_min) ** t`: python-float quotient, fp32 pow
         d.gk = sqrtf((float)(2.0 * (log(s.beta_1) - log(s.beta_0))));       // torch.sqrt(torch.tensor(2 * (np.log(smax) - np.log(smin)))): fp32 tensor, fp32 sqrt
     }
+    return d;
+}
+// VPSDE.sqrt_1m_alphas_cumprod[k] (sde_lib.py:134-139): discrete_betas = linspace(beta_min / N, beta_max / N, N) as torch forms it in fp32 (from both
+// ends: start + step i below the middle, end - step (N - 1 - i) above), alphas = 1 - betas, a running fp32 product, sqrt(1 - product)
+static inline float sde_vp_sqrt_1m_alphas_cumprod(const SdeCfg& s, int k) {
+    const int N = s.N;
+    if (N < 1) return 0.f;
+    k = k < 0 ? 0 : (k >= N ? N - 1 : k);
+    const float start = (float)(s.beta_0 / (double)N), end = (float)(s.beta_1 / (double)N);
+    const float step = N > 1 ? (end - start) / (float)(N - 1) : 0.f;
+    float prod = 1.0f;
+    for (int i = 0; i <= k; ++i) {
+        const float beta = i < N / 2 ? start + step * (float)i : end - step * (float)(N - 1 - i);
+        prod = prod * (1.0f - beta);
+    }
+    return sqrtf(1.0f - prod);
+}
+// the descriptor of a launch at ONE shared time t: for the discrete VP score function the table entry travels by value
+static inline SdeDev make_sde_dev_at(const SdeCfg& s, float t) {
+    SdeDev d = make_sde_dev(s);
+    if (d.kind == SDE_VP && d.disc) d.sd_disc = sde_vp_sqrt_1m_alphas_cumprod(s, (int)(t * d.nm1));
     return d;
 }
 // sigma(t) of the VE SDE (sde_lib.py:260,267): the same expression on host (time-table labels) and device
@@ -82,16 +106,19 @@ __device__ __forceinline__ float sde_diffusion(const SdeDev& s, float t) {     /
 //   mc, sd  marginal_prob: mean = mc * x, std = sd        (VE: 1, sigma(t))
 //   beta, g sde: drift = -1/2 beta x, diffusion g         (VE: 0, sigma(t) * sqrt(2 ln(sigma_max / sigma_min)))
 //   label   what the network is conditioned on            (t * 999, utils.py:152; VE: sigma(t), utils.py:173, or round((T - t)(N - 1)), :176-178)
-struct SdeAt { float mc, sd, beta, g, label; };
+struct SdeAt { float mc, sd, beta, g, label, sd_score; };      // sd_score: the std the score is formed with (utils.py:155 / :160); sd: marginal_prob's
 __device__ __forceinline__ SdeAt sde_at(const SdeDev& s, float t) {
 #pragma clang fp contract(off)
     SdeAt r;
     if (s.kind == SDE_VE) {
         const float sig = sde_ve_sigma(s.smin, s.ratio, t);
         r.mc = 1.0f; r.sd = sig; r.beta = 0.0f; r.g = sig * s.gk; r.label = s.disc ? sde_ve_discrete_label(s.Tf, s.nm1, t) : sig;
+        r.sd_score = sig;
     } else {
         const float lmc = sde_lmc(s, t);
         r.mc = expf(lmc); r.sd = sde_std(s, lmc); r.beta = sde_beta(s, t); r.g = sde_diffusion(s, t); r.label = t * 999.0f;
+        r.sd_score = r.sd;
+        if (s.kind == SDE_VP && s.disc) { r.label = t * s.nm1; r.sd_score = s.sd_disc; }      // utils.py:158-160
     }
     return r;
 }

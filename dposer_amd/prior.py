@@ -72,13 +72,12 @@ def prior_loss(model, sde, x0, t, *, weighted=True, reduction="mean", batch_size
     reduction='mean' -> torch.mean over [B, D] (completion.py:147); 'sum_over_batch' -> sum / batch_size (smplify.py:105).
     ``continuous``: ``config.training.continuous`` as the reference hands it to ``get_score_fn`` (motion_denoising.py:94,
     completion.py:103).  Under the VE SDE it selects the label the network is conditioned on (utils.py:164-181: sigma(t), or
-    round((T - t)(N - 1)) for a discrete model) -- both on the fused kernel since round 6 (DPOSER_SDE_VE / DPOSER_SDE_VE_DISCRETE); a discrete
-    VP score function (utils.py:152-160) runs step by step."""
+    round((T - t)(N - 1)) for a discrete model), under the VP SDE label and std of the score (utils.py:152-160) -- all on the fused kernel
+    since round 6 (DPOSER_SDE_VE_DISCRETE / DPOSER_SDE_VP_DISCRETE)."""
     if x0.shape[0] == 0:
         raise ValueError("prior_loss: empty batch (the reference's torch.mean over no elements is NaN)")
     n = x0.numel() if reduction == "mean" else (batch_size if batch_size is not None else x0.shape[0])
-    discrete_vp = (not continuous) and isinstance(sde, sde_lib.VPSDE)
-    if sde_lib.sde_desc(sde) is None or discrete_vp:      # not covered by the fused kernel: the HIP score function + the reference's few elementwise steps
+    if sde_lib.sde_desc(sde, bool(continuous)) is None:   # not covered by the fused kernel: the HIP score function + the reference's few elementwise steps
         return _prior_loss_unfused(model, sde, x0, float(t), bool(weighted), 1.0 / float(n), z, continuous=bool(continuous))
     return _PriorLoss.apply(x0, model, sde, float(t), bool(weighted), 1.0 / float(n), z, seed, step, bool(continuous))
 

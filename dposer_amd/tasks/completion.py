@@ -47,10 +47,8 @@ class DPoserComp:
 
     def _fused_supported(self):
         from ..algorithms.advanced.model import ScoreModelFC
-        # (sub-VP: one score function; VE: continuous or discrete labels, both on the fused kernels; a discrete VP score function,
-        #  utils.py:152-160, runs step by step)
-        return (sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
-                and (getattr(self, "continuous", True) or not isinstance(self.sde, sde_lib.VPSDE)))
+        # (sub-VP: one score function; VE / VP: continuous or discrete, all on the fused kernels)
+        return sde_lib.sde_desc(self.sde, bool(getattr(self, "continuous", True))) is not None and isinstance(self.model, ScoreModelFC)
 
     def _schedule(self, time_strategy, total_steps, sample_trun, sample_time):
         """quan_t of every step (completion.py:183-192)."""

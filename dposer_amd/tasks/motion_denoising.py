@@ -91,8 +91,7 @@ class MotionDenoise:
         from ..algorithms.advanced.model import ScoreModelFC
         from ..body_model.body_model import BodyModel
         nz = self.Normalizer
-        return (sde_lib.sde_desc(self.sde) is not None and isinstance(self.model, ScoreModelFC)
-                and (getattr(self, "continuous", True) or not isinstance(self.sde, sde_lib.VPSDE))
+        return (sde_lib.sde_desc(self.sde, bool(getattr(self, "continuous", True))) is not None and isinstance(self.model, ScoreModelFC)
                 and isinstance(self.body_model, BodyModel)
                 and getattr(nz, "rot_rep", None) in ("axis", "rot6d") and self.batch_size >= 2)
 

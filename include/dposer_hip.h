@@ -58,8 +58,11 @@ enum { DPOSER_ACT_SWISH = 0, DPOSER_ACT_ELU = 1, DPOSER_ACT_RELU = 2, DPOSER_ACT
  * DPOSER_SDE_VE_DISCRETE: the same SDE with the DISCRETE score function (get_score_fn(..., continuous=False), utils.py:175-181): the network is
  * conditioned on the label round((T - t) (N - 1)) -- an index into `sigmas` for scale_by_sigma and the argument of the positional embedding --
  * everything else as DPOSER_SDE_VE.  Shared-t evaluation only (sampler, Langevin step, prior loss and the two fitting loops): the training
- * loss of a discrete model is the legacy SMLD loss, the probability-flow ODE is always continuous; those entry points refuse this kind. */
-enum { DPOSER_SDE_SUBVP = 0, DPOSER_SDE_VP = 1, DPOSER_SDE_VE = 2, DPOSER_SDE_VE_DISCRETE = 3 };
+ * loss of a discrete model is the legacy SMLD loss, the probability-flow ODE is always continuous; those entry points refuse this kind.
+ * DPOSER_SDE_VP_DISCRETE: the VP SDE with its discrete score function (utils.py:157-162): label t (N - 1) and
+ * score = -model / sqrt_1m_alphas_cumprod[label.long()] with the DDPM table of sde_lib.py:134-139 for THIS N (linspace(beta_min / N, beta_max / N, N),
+ * cumulative product, in fp32); perturbation and reverse SDE stay the continuous ones.  Shared-t evaluation only, like the VE one. */
+enum { DPOSER_SDE_SUBVP = 0, DPOSER_SDE_VP = 1, DPOSER_SDE_VE = 2, DPOSER_SDE_VE_DISCRETE = 3, DPOSER_SDE_VP_DISCRETE = 4 };
 
 typedef struct {
     int32_t data_dim;        /* n_poses * pose_dim: 63 (axis-angle) or 126 (rot6d), 1..512  model.py:109 */

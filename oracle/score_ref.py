@@ -135,10 +135,12 @@ class SubVP:
     """lib/algorithms/advanced/sde_lib.py:184-231 (scalars only; T = 1)."""
     name = "subVPSDE"
 
-    def __init__(self, beta_min=0.1, beta_max=20.0, N=1000):
+    def __init__(self, beta_min=0.1, beta_max=20.0, N=1000, discrete=False):
         self.b0, self.b1, self.N, self.T = beta_min, beta_max, N, 1.0
         self.discrete_betas = torch.linspace(beta_min / N, beta_max / N, N)   # :197
         self.alphas = 1.0 - self.discrete_betas                              # :198
+        self.sqrt_1m_alphas_cumprod = torch.sqrt(1.0 - torch.cumprod(self.alphas, dim=0))      # VPSDE :137-139
+        self.discrete = discrete          # VP only: get_score_fn(..., continuous=False), utils.py:157-160
 
     def lmc(self, t):
         return -0.25 * t ** 2 * (self.b1 - self.b0) - 0.5 * t * self.b0     # :214
@@ -200,8 +202,13 @@ class VE:
 # utils.py : get_score_fn
 # --------------------------------------------------------------------------------------------
 def score_fn(p: Params, sde, x, t, **fw):
-    """lib/algorithms/advanced/utils.py:127-186, continuous=True branch for VP/subVP, and VE (continuous :173, discrete :175-178)."""
+    """lib/algorithms/advanced/utils.py:127-186: VP / sub-VP (continuous :152-155, discrete VP :157-160) and VE (continuous :173, discrete :175-178)."""
     if sde.name in ("VPSDE", "subVPSDE"):
+        if sde.name == "VPSDE" and getattr(sde, "discrete", False):
+            labels = t * (sde.N - 1)                                         # utils.py:158
+            out = scorefc_forward(p, x, labels, **fw)
+            std = sde.sqrt_1m_alphas_cumprod[labels.long()]                  # :160
+            return -out / std[:, None]
         labels = t * 999                                                     # utils.py:152
         out = scorefc_forward(p, x, labels, **fw)
         std = sde.marginal_prob(torch.zeros_like(x), t)[1]                   # utils.py:155

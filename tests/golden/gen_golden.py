@@ -803,6 +803,80 @@ def g25_ve_discrete_paths():
     save("g25_ve_discrete_paths", **out)
 
 
+def g26_vp_discrete_paths():
+    """G26: the reference's own outputs under the VP SDE with the DISCRETE score function (get_score_fn(..., continuous=False), utils.py:157-162:
+    label t (N - 1), score = -model / sqrt_1m_alphas_cumprod[label.long()]; config.training.continuous = False) on the shared-t paths this
+    repository fuses: EM sampler (plain and with completion imputation), prior loss and the completion loop.  Recording scheme of G21 / G25."""
+    out = {"seed": np.int64(33), "beta_min": np.float64(0.1), "beta_max": np.float64(20.0)}
+    mk = lambda N: ref_sde.VPSDE(beta_min=0.1, beta_max=20.0, N=N)
+    cfg, m = build_model(33, 63)
+    cfg.training.continuous = False
+    m.eval()
+
+    class Args:
+        task = None
+
+    for tag, task in (("em8", None), ("comp8", "completion")):
+        N, B = 8, 16
+        sde = mk(N)
+        cfg.sampling.corrector = "none"
+        fn = ref_sampling.get_sampling_fn(cfg, sde, (B, 63), lambda x: x, 1e-3, device="cpu")
+        z0 = torch.tensor((np.random.RandomState(980 + len(tag)).standard_normal((B, 63))).astype(np.float32))
+        obs = mask = args = None
+        if task is not None:
+            args = Args()
+            args.task = task
+            poses, _ = toy_batch(B, seed=48)
+            with Recorder(56):
+                mask, obs = ref_misc.create_mask(poses, part="legs")
+            out[f"{tag}_mask"] = mask.numpy()
+            out[f"{tag}_obs"] = obs.numpy()
+        with Recorder(78) as rec:
+            trajs, x = fn(m, observation=obs, mask=mask, z=z0, start_step=0, args=args)
+        out[f"{tag}_z0"] = z0.numpy()
+        out[f"{tag}_noise"] = np.stack(rec.by_kind("randn"))
+        out[f"{tag}_final"] = x.numpy()
+        out[f"{tag}_trajs"] = trajs.numpy()
+    sde = mk(1000)
+    B = 16
+    comp = ref_completion.DPoserComp(m, sde, continuous=False, batch_size=B)
+    x0, _ = toy_batch(B, seed=49)
+    timesteps = torch.linspace(sde.T, 1e-3, sde.N)
+    out["prior_x0"] = x0.numpy()
+    import math
+    total = 200
+    for step in (0, 100, 199):
+        quan_t = sde.N - math.floor(torch.tensor(total - step - 1) * (sde.N / (5.0 * total))) - 2
+        t = timesteps[quan_t]
+        vec_t = torch.ones(B) * t
+        xv = x0.clone().requires_grad_(True)
+        with Recorder(400 + step) as rec:
+            loss = comp.loss(xv, vec_t, quan_t)
+        loss.backward()
+        out[f"prior_s{step}_quan_t"] = np.int64(quan_t)
+        out[f"prior_s{step}_t"] = np.float32(t.item())
+        out[f"prior_s{step}_z"] = rec.by_kind("randn")[0]
+        out[f"prior_s{step}_loss"] = np.float64(loss.item())
+        out[f"prior_s{step}_grad"] = xv.grad.numpy()
+    iters, spi = 2, 4
+    _, raw = toy_batch(B, seed=50)
+    nz = ref_amass.Posenormalizer(os.path.join(REF, "data/AMASS/amass_processed/version1/train"), device="cpu", normalize=True,
+                                  min_max=False, rot_rep="axis")
+    poses = nz.offline_normalize(raw)
+    torch.manual_seed(0)
+    mask, obs = ref_misc.create_mask(poses, part="legs")
+    comp = ref_completion.DPoserComp(m, sde, continuous=False, batch_size=B)
+    with Recorder(1500) as rec:
+        res = comp.optimize(obs, mask, iterations=iters, steps_per_iter=spi)
+    out["loop_observation"] = obs.numpy()
+    out["loop_mask"] = mask.numpy()
+    out["loop_noise"] = np.stack(rec.by_kind("randn"))
+    out["loop_out"] = res.detach().numpy()
+    out["loop_iterations"] = np.int64(iters)
+    out["loop_steps_per_iter"] = np.int64(spi)
+    save("g26_vp_discrete_paths", **out)
+
+
 def g8_scalars():
     """G8: marginal_prob / sde / return_alpha_sigma / discretize tables on linspace(1,1e-3,1000)."""
     t = torch.linspace(1.0, 1e-3, 1000)
@@ -1036,8 +1110,8 @@ def g13_dataset():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g24", "g25"]
-    fns = dict(g25=g25_ve_discrete_paths, g22=g22_timemlps, g21=g21_ve_paths, g20=g20_fourier_paths, g19=g19_activations, g18=g18_evaler, g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22", "g24", "g25", "g26"]
+    fns = dict(g26=g26_vp_discrete_paths, g25=g25_ve_discrete_paths, g22=g22_timemlps, g21=g21_ve_paths, g20=g20_fourier_paths, g19=g19_activations, g18=g18_evaler, g17=g17_aux_loss, g16=g16_guided_step, g14=g14_completion_loop, g15=g15_motion_denoise_loop, g1=g1_forward, g3=g3_loss_grads, g4=g4_train_steps, g5=g5_sampler, g7=g7_prior_loss,
                g8=g8_scalars, g9=g9_tables, g24=g24_openpose_maps, g10=g10_normalizer, g11=g11_rot6d, g12=g12_likelihood_ode, g13=g13_dataset)
     for w in which:
         fns[w]()

@@ -380,7 +380,7 @@ def test_ve_sde_fused_paths_match_reference_golden(prec, tol_loss, tol_grad, tol
     sde = mk(1000)
     assert sampling.fused_em_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, True)
     assert sampling.fused_em_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, False)         # discrete VE: other labels, same kernels (g25)
-    assert not sampling.fused_em_supported(sde_lib.VPSDE(0.1, 20.0, 1000), m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, False)     # discrete VP: step by step
+    assert sampling.fused_em_supported(sde_lib.VPSDE(0.1, 20.0, 1000), m, sampling.EulerMaruyamaPredictor, sampling.NoneCorrector, False, False)         # discrete VP too (g26)
     assert fused_dsm_supported(sde, m, True, True, False, False)
     # DSM loss + every parameter gradient
     t = _dev(g["dsm_u"]) * (1.0 - 1e-5) + 1e-5
@@ -437,6 +437,56 @@ def test_discrete_ve_score_function_on_the_fused_paths_matches_reference_golden(
     cfg8.training.continuous = False
     cfg8.sampling.corrector = "none"
     assert sde_lib.sde_desc(mk(8), False).kind == _C.SDE_VE_DISCRETE and sde_lib.sde_desc(mk(8)).kind == _C.SDE_VE
+    assert not fused_dsm_supported(mk(1000), m8, False, True, False, False)
+    monkeypatch.setattr(sampling, "shared_predictor_update_fn", lambda *a, **k: (_ for _ in ()).throw(AssertionError("step-by-step sampler used")))
+    monkeypatch.setattr(prior_mod, "_prior_loss_unfused", lambda *a, **k: (_ for _ in ()).throw(AssertionError("step-by-step prior loss used")))
+    fn = sampling.get_sampling_fn(cfg8, mk(8), (16, 63), lambda x: x, 1e-3, device=DEV)
+    trajs, x = fn(m8, z=_dev(g["em8_z0"]), noise=_dev(g["em8_noise"])[:, None])
+    assert rel_err(t2n(trajs), g["em8_trajs"]) < tol and rel_err(t2n(x), g["em8_final"]) < tol
+    trajs, x = fn(m8, observation=_dev(g["comp8_obs"]), mask=_dev(g["comp8_mask"]), z=_dev(g["comp8_z0"]), args=_Args("completion"),
+                  noise=_dev(g["comp8_noise"]).reshape(8, 3, 16, 63))
+    assert rel_err(t2n(trajs), g["comp8_trajs"]) < tol and rel_err(t2n(x), g["comp8_final"]) < tol
+    sde = mk(1000)
+    for step in (0, 100, 199):
+        x0 = _dev(g["prior_x0"]).requires_grad_(True)
+        lp = prior_loss(m8, sde, x0, float(g[f"prior_s{step}_t"]), weighted=bool(int(g[f"prior_s{step}_quan_t"])), z=_dev(g[f"prior_s{step}_z"]),
+                        continuous=False)
+        lp.backward()
+        assert abs(float(lp) - float(g[f"prior_s{step}_loss"])) / abs(float(g[f"prior_s{step}_loss"])) < max(tol, 2e-4)
+        assert rel_err(t2n(x0.grad), g[f"prior_s{step}_grad"]) < max(tol, 2e-4)
+    comp = DPoserComp(m8, sde, continuous=False, batch_size=16)
+    assert comp._fused_supported()
+    out = comp.optimize(_dev(g["loop_observation"]), _dev(g["loop_mask"]), iterations=int(g["loop_iterations"]),
+                        steps_per_iter=int(g["loop_steps_per_iter"]), noise=_dev(g["loop_noise"]))
+    assert rel_err(t2n(out), g["loop_out"]) < max(tol, 2e-4)
+    # the continuous score function on the same inputs must NOT land on the discrete golden (the label really is another one)
+    cfg8.training.continuous = True
+    fn_c = sampling.get_sampling_fn(cfg8, mk(8), (16, 63), lambda x: x, 1e-3, device=DEV)
+    _, xc = fn_c(m8, z=_dev(g["em8_z0"]), noise=_dev(g["em8_noise"])[:, None])
+    assert rel_err(t2n(xc), g["em8_final"]) > 10 * tol
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("bf16", 2e-2), ("bf16x3", 1e-4)])
+def test_discrete_vp_score_function_on_the_fused_paths_matches_reference_golden(prec, tol, monkeypatch):
+    """training.continuous = False under the VP SDE (get_score_fn(..., continuous=False), utils.py:157-162: label t (N - 1), score =
+    -model / sqrt_1m_alphas_cumprod[label.long()], the DDPM table of sde_lib.py:134-139) on the one-call paths (DPOSER_SDE_VP_DISCRETE, round 6): EM
+    sampler (plain and with completion imputation), prior loss + gradient, completion loop, against the reference's own outputs with its recorded
+    draws (golden g26).  The step-by-step fallbacks are made to raise.  A VPSDE whose N was changed after construction keeps the constructor's
+    table in the reference: such an object stays off the fused paths."""
+    from dposer_amd.algorithms.advanced import sampling, sde_lib
+    from dposer_amd.algorithms.advanced.losses import fused_dsm_supported
+    from dposer_amd.prior import prior_loss
+    from dposer_amd import prior as prior_mod, _C
+    from dposer_amd.tasks.completion import DPoserComp
+    g = load("g26_vp_discrete_paths")
+    mk = lambda N: sde_lib.VPSDE(beta_min=float(g["beta_min"]), beta_max=float(g["beta_max"]), N=N)
+    cfg8, m8, _ = make_model(int(g["seed"]), precision=prec)
+    cfg8.training.continuous = False
+    cfg8.sampling.corrector = "none"
+    assert sde_lib.sde_desc(mk(8), False).kind == _C.SDE_VP_DISCRETE and sde_lib.sde_desc(mk(8)).kind == _C.SDE_VP
+    stale = mk(1000)
+    stale.N = 500
+    assert sde_lib.sde_desc(stale, False) is None and sde_lib.sde_desc(stale) is not None
     assert not fused_dsm_supported(mk(1000), m8, False, True, False, False)
     monkeypatch.setattr(sampling, "shared_predictor_update_fn", lambda *a, **k: (_ for _ in ()).throw(AssertionError("step-by-step sampler used")))
     monkeypatch.setattr(prior_mod, "_prior_loss_unfused", lambda *a, **k: (_ for _ in ()).throw(AssertionError("step-by-step prior loss used")))

@@ -436,6 +436,38 @@ def test_discrete_ve_score_function_paths():
     assert rel_err(xc, g["em8_final"]) > 1e-3
 
 
+def test_discrete_vp_score_function_paths():
+    """The oracle under the VP SDE with the DISCRETE score function (utils.py:157-162: label t (N - 1), std from the DDPM table) against the
+    reference's own outputs (golden g26): EM sampler (plain and with completion imputation), prior loss + gradient, completion loop."""
+    from oracle import task_loops
+    g = load("g26_vp_discrete_paths")
+    mk = lambda N: R.VP(float(g["beta_min"]), float(g["beta_max"]), N, discrete=True)
+    p = dict(make_weights(int(g["seed"]), D=63))
+    p["sigmas"] = R.sigma_table()
+    with torch.no_grad():
+        trajs, x = R.pc_sampler(p, mk(8), torch.tensor(g["em8_z0"]), list(torch.tensor(g["em8_noise"])))
+        assert rel_err(trajs, g["em8_trajs"]) < 1e-4 and rel_err(x, g["em8_final"]) < 1e-4
+        noise = torch.tensor(g["comp8_noise"])
+        imp = [(noise[3 * i], noise[3 * i + 2]) for i in range(8)]
+        em = [noise[3 * i + 1] for i in range(8)]
+        trajs, x = R.pc_sampler(p, mk(8), torch.tensor(g["comp8_z0"]), em, observation=torch.tensor(g["comp8_obs"]),
+                                mask=torch.tensor(g["comp8_mask"]), impute_noises=imp)
+        assert rel_err(trajs, g["comp8_trajs"]) < 1e-4 and rel_err(x, g["comp8_final"]) < 1e-4
+        x0 = torch.tensor(g["prior_x0"])
+        for step in (0, 100, 199):
+            tt = torch.ones(x0.shape[0]) * float(g[f"prior_s{step}_t"])
+            lp, gp = R.dposer_prior_loss(p, mk(1000), x0, tt, torch.tensor(g[f"prior_s{step}_z"]), weighted=bool(int(g[f"prior_s{step}_quan_t"])))
+            assert abs(lp.item() - float(g[f"prior_s{step}_loss"])) < 2e-4 * abs(float(g[f"prior_s{step}_loss"]))
+            assert rel_err(gp, g[f"prior_s{step}_grad"]) < 2e-4
+    out = task_loops.completion_optimize(p, mk(1000), g["loop_observation"], g["loop_mask"], g["loop_noise"],
+                                         iterations=int(g["loop_iterations"]), steps_per_iter=int(g["loop_steps_per_iter"]))
+    assert rel_err(out, g["loop_out"]) < 2e-4
+    # ... and the labels really differ from the continuous ones: the continuous oracle must NOT reproduce the golden
+    with torch.no_grad():
+        _, xc = R.pc_sampler(p, R.VP(float(g["beta_min"]), float(g["beta_max"]), 8), torch.tensor(g["em8_z0"]), list(torch.tensor(g["em8_noise"])))
+    assert rel_err(xc, g["em8_final"]) > 1e-3
+
+
 def test_fk_oracle_against_smplx_golden(tmp_path):
     """oracle/fk_ref.py against outputs of the reference's own dependency smplx==0.1.28 (golden g23, written by tests/golden/pin_fk_parity.py
     wherever smplx can be installed -- it cannot here).  Until that file exists the FK / LBS half of the oracle stays "parity unpinned"
