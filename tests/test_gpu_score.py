@@ -1248,20 +1248,24 @@ def test_embed_dim_not_multiple_of_256_at_large_batch():
     assert rel_err(t2n(g_full), t2n(g_sum / n_chunk)) < 1e-4
 
 
-def test_langevin_fused_vp_sde_vs_oracle():
+@pytest.mark.parametrize("continuous", [True, False])
+def test_langevin_fused_vp_sde_vs_oracle(continuous):
     """Langevin + EM under the VP SDE: alpha = sde.alphas[timestep] (sampling.py:290-292) enters the step size, the score uses
-    std = sqrt(1 - e^{2 lmc}); injected draws, oracle step by step."""
+    std = sqrt(1 - e^{2 lmc}) -- or, with the discrete score function (training.continuous = False, utils.py:157-160), the DDPM table's entry
+    and the label t (N - 1); injected draws, oracle step by step (pinned to the reference's own outputs: goldens g5 / g26)."""
     from dposer_amd.algorithms.advanced import sampling, sde_lib
     cfg, m, p = make_model(24, precision="fp32")
     cfg.sampling.corrector = "langevin"
+    cfg.training.continuous = continuous
     N, B, start = 1000, 40, 995
     sde = sde_lib.VPSDE(0.1, 20.0, N)
+    assert sampling.fused_langevin_supported(sde, m, sampling.EulerMaruyamaPredictor, sampling.LangevinCorrector, False, continuous)
     fn = sampling.get_sampling_fn(cfg, sde, (B, 63), lambda v: v, 1e-3, device=DEV)
     rs = np.random.RandomState(8)
     z0 = (rs.standard_normal((B, 63)) * 0.3).astype(np.float32)
     noise = rs.standard_normal((N - start, 2, B, 63)).astype(np.float32)
     trajs, x = fn(m, z=_dev(z0), noise=_dev(noise), start_step=start, args=_Args("denoise"))
-    xo, so, ts = torch.tensor(z0), R.VP(N=N), torch.linspace(1.0, 1e-3, N)
+    xo, so, ts = torch.tensor(z0), R.VP(N=N, discrete=not continuous), torch.linspace(1.0, 1e-3, N)
     for k, i in enumerate(range(start, N)):
         t = torch.ones(B) * ts[i]
         xo, _ = R.langevin_step(p, so, xo, t, torch.tensor(noise[k, 0]), snr=cfg.sampling.snr)
